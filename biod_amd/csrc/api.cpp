@@ -1,0 +1,352 @@
+// api.cpp -- the extern "C" surface of libbiodgpu.so (include/biodgpu.h): context, staging,
+// result hand-out, column iteration, timing.  All compute is in the .hip units; there is no CPU
+// implementation of any kernel in this library.
+#include "common.h"
+
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <cstdio>
+
+static thread_local std::string g_last_hip_error;
+
+void bgp_note_hip_error(hipError_t e, const char* what, const char* file, int line) {
+    char buf[512];
+    snprintf(buf, sizeof buf, "%s failed: %s (%s:%d)", what, hipGetErrorString(e), file, line);
+    g_last_hip_error = buf;
+    if (getenv("BGP_VERBOSE")) fprintf(stderr, "[biodgpu] %s\n", buf);
+}
+
+int bgp_status_from_bits(uint32_t bits) {
+    if (bits & ST_ETRUNC) return BGP_ETRUNC;
+    if (bits & ST_EINVAL) return BGP_EINVAL;
+    if (bits & ST_EUNSORTED) return BGP_EUNSORTED;
+    if (bits & ST_ECIGAR) return BGP_ECIGAR;
+    if (bits & ST_EMD) return BGP_EMD;
+    if (bits & ST_ESEQ) return BGP_ESEQ;
+    return BGP_OK;
+}
+
+TimedRegion::TimedRegion(bgp_ctx* ctx, const char* name, uint64_t alg_bytes) : c(ctx) {
+    if (!c->timing) return;
+    for (size_t i = 0; i < c->timers.size(); ++i) if (c->timers[i].name == name) idx = (int)i;
+    if (idx < 0) { c->timers.emplace_back(); c->timers.back().name = name; idx = (int)c->timers.size() - 1; }
+    c->timers[idx].algorithmic_bytes += alg_bytes;
+    c->timers[idx].launches += 1;
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { idx = -1; return; }
+    (void)hipEventRecord(a, c->stream);
+}
+TimedRegion::~TimedRegion() {
+    if (!c->timing || idx < 0) return;
+    (void)hipEventRecord(b, c->stream);
+    c->timers[idx].pending.emplace_back(a, b);
+}
+void bgp_timing_collect(bgp_ctx* c) {
+    for (auto& t : c->timers) {
+        for (auto& ev : t.pending) {
+            float ms = 0;
+            (void)hipEventSynchronize(ev.second);
+            if (hipEventElapsedTime(&ms, ev.first, ev.second) == hipSuccess) t.total_ms += ms;
+            (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second);
+        }
+        t.pending.clear();
+    }
+}
+
+extern "C" {
+
+const char* bgp_strerror(int s) {
+    switch (s) {
+        case BGP_OK: return "ok";
+        case BGP_EOF: return "end of iteration";
+        case BGP_EINVAL: return "invalid argument or malformed BAM record";
+        case BGP_ETRUNC: return "record runs past the end of the data";
+        case BGP_ECIGAR: return "pileup cursor ran off the CIGAR (invalid read)";
+        case BGP_EDEVICE: return "HIP device error (no usable gfx950 device?)";
+        case BGP_ENOMEM: return "out of memory";
+        case BGP_ESTATE: return "call out of order";
+        case BGP_EMD: return "MD tag missing or inconsistent / reference_base not available";
+        case BGP_EUNSORTED: return "reads are not coordinate sorted";
+        case BGP_ESEQ: return "query offset past the end of a read sequence";
+        default: return "unknown status";
+    }
+}
+
+int bgp_abi_version(void) { return BGP_ABI_VERSION; }
+
+int bgp_init(int device, bgp_ctx** out) {
+    if (!out) return BGP_EINVAL;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return BGP_EDEVICE;
+    BGP_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    BGP_HIP(hipGetDeviceProperties(&prop, device));
+    if (!strstr(prop.gcnArchName, "gfx950") && !getenv("BGP_ALLOW_ANY_ARCH")) {
+        g_last_hip_error = std::string("device is ") + prop.gcnArchName + ", libbiodgpu is built for gfx950 only";
+        return BGP_EDEVICE;
+    }
+    bgp_ctx* c = new (std::nothrow) bgp_ctx();
+    if (!c) return BGP_ENOMEM;
+    c->device = device;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return BGP_EDEVICE; }
+    c->own_stream = true;
+    if (c->d_status.reserve(64) < 0) { (void)hipStreamDestroy(c->stream); delete c; return BGP_ENOMEM; }
+    *out = c;
+    return BGP_OK;
+}
+
+static void release_all(bgp_ctx* c) {
+    DevBuf* d[] = {&c->d_stream_own, &c->d_synth, &c->d_seg_entry, &c->d_seg_end, &c->d_seg_cnt, &c->d_seg_lseq, &c->d_seg_ncig, &c->d_seg_dirty,
+                   &c->d_seg_rec_base, &c->d_seg_seq_base, &c->d_seg_cig_base, &c->d_scan_tmp, &c->d_status, &c->d_rec, &c->d_seq_off, &c->d_cigar_off,
+                   &c->d_seq, &c->d_qual, &c->d_cigar, &c->d_pmax_end, &c->d_pmax_pos, &c->d_runs, &c->d_columns, &c->d_depth_hist, &c->d_pstats,
+                   &c->d_tiles, &c->d_entry_off, &c->d_entries, &c->d_col_lo};
+    for (auto* b : d) b->release();
+    HostBuf* h[] = {&c->h_stage, &c->h_rec, &c->h_seq_off, &c->h_cigar_off, &c->h_seq, &c->h_qual, &c->h_cigar, &c->h_cols, &c->h_entry_off, &c->h_entries, &c->h_refbase};
+    for (auto* b : h) b->release();
+}
+
+void bgp_destroy(bgp_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    bgp_timing_collect(c);
+    release_all(c);
+    if (c->own_stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int bgp_set_stream(bgp_ctx* c, void* s) {
+    if (!c) return BGP_EINVAL;
+    BGP_HIP(hipStreamSynchronize(c->stream));
+    if (s) { if (c->own_stream) { (void)hipStreamDestroy(c->stream); c->own_stream = false; } c->stream = (hipStream_t)s; }
+    else if (!c->own_stream) { BGP_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
+    return BGP_OK;
+}
+
+int bgp_set_n_ref(bgp_ctx* c, int32_t n_ref) { if (!c || n_ref < 0) return BGP_EINVAL; c->n_ref_hint = n_ref; return BGP_OK; }
+
+int bgp_reset(bgp_ctx* c) {
+    if (!c) return BGP_EINVAL;
+    BGP_HIP(hipStreamSynchronize(c->stream));
+    c->h_stage_len = 0; c->d_stream = nullptr; c->stream_len = 0; c->stream_on_device = false;
+    c->flushed = false; c->piled = false; c->n_records = 0; c->decoded_what = 0; c->it = bgp_ctx::Iter();
+    c->runs.clear();
+    return BGP_OK;
+}
+
+int bgp_push_inflated(bgp_ctx* c, const uint8_t* data, size_t len, uint64_t coffset, uint32_t first_record_uoffset) {
+    (void)coffset; (void)first_record_uoffset;   // boundaries are found and verified on the device (frame.hip)
+    if (!c || (!data && len)) return BGP_EINVAL;
+    if (c->flushed || c->stream_on_device) return BGP_ESTATE;
+    BGP_TRY(c->h_stage.reserve_keep(c->h_stage_len + len, c->h_stage_len));
+    memcpy(c->h_stage.as<uint8_t>() + c->h_stage_len, data, len);
+    c->h_stage_len += len;
+    return BGP_OK;
+}
+
+int bgp_attach_device_stream(bgp_ctx* c, const void* dptr, uint64_t len) {
+    if (!c || (!dptr && len)) return BGP_EINVAL;
+    if (c->flushed || c->h_stage_len) return BGP_ESTATE;
+    c->d_stream = (const uint8_t*)dptr; c->stream_len = len; c->stream_on_device = true;
+    return BGP_OK;
+}
+
+int bgp_flush(bgp_ctx* c) {
+    if (!c) return BGP_EINVAL;
+    BGP_HIP(hipSetDevice(c->device));
+    if (!c->stream_on_device) {
+        BGP_TRY(c->d_stream_own.reserve(c->h_stage_len + 64));
+        if (c->h_stage_len) BGP_HIP(hipMemcpyAsync(c->d_stream_own.p, c->h_stage.p, c->h_stage_len, hipMemcpyHostToDevice, c->stream));
+        c->d_stream = c->d_stream_own.as<uint8_t>(); c->stream_len = c->h_stage_len; c->stream_on_device = true;
+    }
+    c->piled = false; c->decoded_what = 0;
+    int rc = k0_frame(c);
+    if (rc < 0) return rc;
+    c->flushed = true;
+    return BGP_OK;
+}
+
+int bgp_num_records(bgp_ctx* c, uint64_t* n) { if (!c || !n) return BGP_EINVAL; if (!c->flushed) return BGP_ESTATE; *n = c->n_records; return BGP_OK; }
+
+int bgp_decode_device(bgp_ctx* c, uint32_t what, bgp_records* o) {
+    if (!c || !o) return BGP_EINVAL;
+    if (!c->flushed) return BGP_ESTATE;
+    BGP_HIP(hipSetDevice(c->device));
+    const uint32_t todo = what & ~c->decoded_what & BGP_FETCH_ALL;
+    if (todo) BGP_TRY(k2_decode(c, todo));
+    memset(o, 0, sizeof *o);
+    o->n = c->n_records; o->rec = c->d_rec.as<bgp_record>(); o->seq_off = c->d_seq_off.as<uint64_t>(); o->cigar_off = c->d_cigar_off.as<uint64_t>();
+    o->seq = (what & BGP_FETCH_SEQ) ? c->d_seq.as<uint8_t>() : nullptr;
+    o->qual = (what & BGP_FETCH_QUAL) ? c->d_qual.as<uint8_t>() : nullptr;
+    o->cigar = (what & BGP_FETCH_CIGAR) ? c->d_cigar.as<uint32_t>() : nullptr;
+    o->stream = c->d_stream; o->stream_len = c->stream_len;
+    return BGP_OK;
+}
+
+int bgp_decode_fetch(bgp_ctx* c, uint32_t what, bgp_records* o) {
+    bgp_records d;
+    BGP_TRY(bgp_decode_device(c, what, &d));
+    const uint64_t n = c->n_records;
+    BGP_TRY(c->h_rec.reserve((n + 1) * sizeof(bgp_record))); BGP_TRY(c->h_seq_off.reserve((n + 1) * 8)); BGP_TRY(c->h_cigar_off.reserve((n + 1) * 8));
+    if (n) BGP_HIP(hipMemcpyAsync(c->h_rec.p, d.rec, n * sizeof(bgp_record), hipMemcpyDeviceToHost, c->stream));
+    BGP_HIP(hipMemcpyAsync(c->h_seq_off.p, d.seq_off, (n + 1) * 8, hipMemcpyDeviceToHost, c->stream));
+    BGP_HIP(hipMemcpyAsync(c->h_cigar_off.p, d.cigar_off, (n + 1) * 8, hipMemcpyDeviceToHost, c->stream));
+    if ((what & BGP_FETCH_SEQ) && c->sum_lseq) { BGP_TRY(c->h_seq.reserve(c->sum_lseq)); BGP_HIP(hipMemcpyAsync(c->h_seq.p, d.seq, c->sum_lseq, hipMemcpyDeviceToHost, c->stream)); }
+    if ((what & BGP_FETCH_QUAL) && c->sum_lseq) { BGP_TRY(c->h_qual.reserve(c->sum_lseq)); BGP_HIP(hipMemcpyAsync(c->h_qual.p, d.qual, c->sum_lseq, hipMemcpyDeviceToHost, c->stream)); }
+    if ((what & BGP_FETCH_CIGAR) && c->sum_ncig) { BGP_TRY(c->h_cigar.reserve(c->sum_ncig * 4)); BGP_HIP(hipMemcpyAsync(c->h_cigar.p, d.cigar, c->sum_ncig * 4, hipMemcpyDeviceToHost, c->stream)); }
+    BGP_HIP(hipStreamSynchronize(c->stream));
+    memset(o, 0, sizeof *o);
+    o->n = n; o->rec = c->h_rec.as<bgp_record>(); o->seq_off = c->h_seq_off.as<uint64_t>(); o->cigar_off = c->h_cigar_off.as<uint64_t>();
+    o->seq = (what & BGP_FETCH_SEQ) ? c->h_seq.as<uint8_t>() : nullptr;
+    o->qual = (what & BGP_FETCH_QUAL) ? c->h_qual.as<uint8_t>() : nullptr;
+    o->cigar = (what & BGP_FETCH_CIGAR) ? c->h_cigar.as<uint32_t>() : nullptr;
+    o->stream = c->h_stage_len ? c->h_stage.as<uint8_t>() : nullptr; o->stream_len = c->h_stage_len;
+    return BGP_OK;
+}
+
+int bgp_pileup_run(bgp_ctx* c, bgp_pileup_info* info) {
+    if (!c) return BGP_EINVAL;
+    if (!c->flushed) return BGP_ESTATE;
+    BGP_HIP(hipSetDevice(c->device));
+    BGP_TRY(k34_pileup(c));
+    c->piled = true;
+    if (info) *info = c->pinfo;
+    return BGP_OK;
+}
+
+int bgp_pileup_begin(bgp_ctx* c, int mode, int use_md_tag, uint64_t start_from, uint64_t end_at, int skip_zero, int want_entries, uint32_t window) {
+    if (!c || (mode != BGP_PILEUP_COLUMNS && mode != BGP_MAKE_PILEUP)) return BGP_EINVAL;
+    if (!c->flushed) return BGP_ESTATE;
+    if (use_md_tag) { c->last_error = "reference_base from MD tags is not on the device path yet"; return BGP_EMD; }
+    if (!c->piled) BGP_TRY(bgp_pileup_run(c, nullptr));
+    auto& it = c->it;
+    it = bgp_ctx::Iter();
+    it.active = true; it.mode = mode; it.use_md = use_md_tag; it.skip_zero = skip_zero; it.want_entries = want_entries;
+    it.window = window ? window : 65536u;
+    it.run = 0; it.run_end = (uint32_t)c->runs.size(); it.ref_id = -1;
+    if (mode == BGP_PILEUP_COLUMNS) { it.start_from = 0; it.end_at = ~0ull; }     // pileupColumns has no clipping (pileup.d:509)
+    else {
+        it.start_from = start_from; it.end_at = end_at;
+        // pileupInstance (pileup.d:482-494): drop leading reads with position + basesCovered < start_from
+        // (any reference), then keep only the reference of the first survivor.  Reads are sorted, so the
+        // first survivor lives in the first run whose max end_position reaches start_from... unless an
+        // earlier read of that run already qualifies, which is the same run.
+        uint32_t j = 0;
+        while (j < it.run_end && c->runs[j].end_pos < start_from) ++j;
+        if (j < it.run_end) { it.run = j; it.run_end = j + 1; it.ref_id = c->runs[j].ref_id; }
+        else { it.run = it.run_end; }
+    }
+    if (it.run < it.run_end) {
+        uint64_t first = c->runs[it.run].start_pos;
+        if (mode == BGP_MAKE_PILEUP && it.start_from > first) {
+            // the sweep starts at the first surviving read, not at the run's first read (matters for
+            // zero-coverage columns when skip_zero_coverage is false)
+            BGP_TRY(k34_first_survivor(c, it.run, it.start_from, &first));
+            if (first == ~0ull) { it.run = it.run_end; return BGP_OK; }
+        }
+        it.next_pos = std::max<uint64_t>(first, it.start_from);
+    }
+    return BGP_OK;
+}
+
+int bgp_pileup_ref_id(bgp_ctx* c, int32_t* ref_id) { if (!c || !ref_id) return BGP_EINVAL; if (!c->it.active) return BGP_ESTATE; *ref_id = c->it.ref_id; return BGP_OK; }
+
+int bgp_pileup_next_window(bgp_ctx* c, bgp_columns* o) {
+    if (!c || !o) return BGP_EINVAL;
+    auto& it = c->it;
+    if (!it.active) return BGP_ESTATE;
+    BGP_HIP(hipSetDevice(c->device));
+    for (;;) {
+        if (it.run >= it.run_end) return BGP_EOF;
+        const bgp_run& r = c->runs[it.run];
+        const uint64_t hi = std::min<uint64_t>(r.end_pos, it.end_at);
+        if (it.next_pos >= hi) {
+            ++it.run;
+            if (it.run < it.run_end) it.next_pos = std::max<uint64_t>(c->runs[it.run].start_pos, it.start_from);
+            continue;
+        }
+        const uint64_t a = it.next_pos, b = std::min<uint64_t>(hi, a + it.window);
+        const uint64_t np = b - a;
+        BGP_TRY(c->h_cols.reserve(np * sizeof(bgp_column)));
+        BGP_HIP(hipMemcpyAsync(c->h_cols.p, c->d_columns.as<bgp_column>() + r.column_base + (a - r.start_pos), np * sizeof(bgp_column), hipMemcpyDeviceToHost, c->stream));
+        memset(o, 0, sizeof *o);
+        if (it.want_entries) {
+            uint64_t ne = 0;
+            BGP_TRY(k5_entries(c, it.run, a, b, &ne));
+            BGP_TRY(c->h_entry_off.reserve((np + 1) * 8)); BGP_TRY(c->h_entries.reserve((ne + 1) * sizeof(bgp_entry)));
+            BGP_HIP(hipMemcpyAsync(c->h_entry_off.p, c->d_entry_off.p, (np + 1) * 8, hipMemcpyDeviceToHost, c->stream));
+            if (ne) BGP_HIP(hipMemcpyAsync(c->h_entries.p, c->d_entries.p, ne * sizeof(bgp_entry), hipMemcpyDeviceToHost, c->stream));
+            o->entry_off = c->h_entry_off.as<uint64_t>(); o->entries = c->h_entries.as<bgp_entry>();
+        }
+        BGP_HIP(hipStreamSynchronize(c->stream));
+        o->ref_id = r.ref_id; o->n_positions = (uint32_t)np; o->first_position = a; o->columns = c->h_cols.as<bgp_column>();
+        it.next_pos = b;
+        return BGP_OK;
+    }
+}
+
+int bgp_hist_reduce(bgp_ctx* c, void* comm, uint64_t* device_hist, size_t n) {
+    if (!c || !comm || !device_hist) return BGP_EINVAL;
+    // RCCL is resolved at run time so that single-GPU users need no librccl.
+    typedef int (*allreduce_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
+    static allreduce_fn fn = nullptr;
+    if (!fn) {
+        void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) { c->last_error = "librccl not found"; return BGP_EDEVICE; }
+        fn = (allreduce_fn)dlsym(h, "ncclAllReduce");
+        if (!fn) return BGP_EDEVICE;
+    }
+    const int ncclUint64 = 5, ncclSum = 0;
+    int rc = fn(device_hist, device_hist, n, ncclUint64, ncclSum, comm, c->stream);
+    if (rc != 0) { c->last_error = "ncclAllReduce failed"; return BGP_EDEVICE; }
+    BGP_HIP(hipStreamSynchronize(c->stream));
+    return BGP_OK;
+}
+
+int bgp_timing_enable(bgp_ctx* c, int on) { if (!c) return BGP_EINVAL; c->timing = on != 0; return BGP_OK; }
+int bgp_timing_reset(bgp_ctx* c) {
+    if (!c) return BGP_EINVAL;
+    BGP_HIP(hipStreamSynchronize(c->stream));
+    bgp_timing_collect(c);
+    c->timers.clear();
+    return BGP_OK;
+}
+int bgp_timing_get(bgp_ctx* c, const bgp_kernel_time** out, uint32_t* n) {
+    if (!c || !out || !n) return BGP_EINVAL;
+    BGP_HIP(hipStreamSynchronize(c->stream));
+    bgp_timing_collect(c);
+    c->timing_out.clear();
+    for (auto& t : c->timers) c->timing_out.push_back(bgp_kernel_time{t.name.c_str(), t.total_ms, t.launches, t.algorithmic_bytes});
+    *out = c->timing_out.data(); *n = (uint32_t)c->timing_out.size();
+    return BGP_OK;
+}
+
+int bgp_synth_host(const bgp_synth_cfg_c* cfg, uint64_t first, uint64_t count, uint8_t* out, uint64_t cap, uint64_t* bytes) {
+    if (!cfg || !bytes) return BGP_EINVAL;
+    return synth_host(cfg, first, count, out, cap, bytes);
+}
+int bgp_synth_device(bgp_ctx* c, const bgp_synth_cfg_c* cfg, uint64_t* bytes) {
+    if (!c || !cfg) return BGP_EINVAL;
+    if (c->flushed || c->h_stage_len) return BGP_ESTATE;
+    BGP_HIP(hipSetDevice(c->device));
+    return synth_device(c, cfg, bytes);
+}
+
+int bgp_load_bam(bgp_ctx* c, const char* path, int n_threads) {
+    if (!c || !path) return BGP_EINVAL;
+    if (c->flushed || c->stream_on_device) return BGP_ESTATE;
+    return bgzf_load_bam(c, path, n_threads);
+}
+int bgp_n_ref(bgp_ctx* c, int32_t* n) { if (!c || !n) return BGP_EINVAL; *n = (int32_t)c->refs.size(); return BGP_OK; }
+int bgp_ref_info(bgp_ctx* c, int32_t id, const char** name, int32_t* length) {
+    if (!c || id < 0 || (size_t)id >= c->refs.size()) return BGP_EINVAL;
+    if (name) *name = c->refs[id].name.c_str();
+    if (length) *length = c->refs[id].length;
+    return BGP_OK;
+}
+
+const char* bgp_last_error(bgp_ctx* c) { return c && !c->last_error.empty() ? c->last_error.c_str() : g_last_hip_error.c_str(); }
+
+}  // extern "C"

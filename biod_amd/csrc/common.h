@@ -1,0 +1,171 @@
+// common.h -- internals shared by the translation units of libbiodgpu.so (not part of the ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/biodgpu.h"
+
+#define BGP_HIP(expr)                                                         \
+    do {                                                                      \
+        hipError_t e_ = (expr);                                               \
+        if (e_ != hipSuccess) { bgp_note_hip_error(e_, #expr, __FILE__, __LINE__); return BGP_EDEVICE; } \
+    } while (0)
+#define BGP_TRY(expr)              \
+    do {                           \
+        int rc_ = (expr);          \
+        if (rc_ < 0) return rc_;   \
+    } while (0)
+
+void bgp_note_hip_error(hipError_t e, const char* what, const char* file, int line);
+
+// A growable device allocation (never shrinks; reused across bgp_reset).
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes) {
+        if (bytes <= cap) return BGP_OK;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        size_t want = bytes + (bytes >> 4) + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) { p = nullptr; bgp_note_hip_error(e, "hipMalloc", __FILE__, __LINE__); return e == hipErrorOutOfMemory ? BGP_ENOMEM : BGP_EDEVICE; }
+        cap = want;
+        return BGP_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <class T> T* as() const { return (T*)p; }
+};
+
+struct HostBuf {                      // pinned host memory
+    void* p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes) {
+        if (bytes <= cap) return BGP_OK;
+        void* np = nullptr;
+        size_t want = bytes + (bytes >> 3) + 4096;
+        hipError_t e = hipHostMalloc(&np, want, hipHostMallocDefault);
+        if (e != hipSuccess) { bgp_note_hip_error(e, "hipHostMalloc", __FILE__, __LINE__); return BGP_ENOMEM; }
+        if (p) { (void)hipHostFree(p); }
+        p = np; cap = want;
+        return BGP_OK;
+    }
+    int reserve_keep(size_t bytes, size_t used) {   // grow, preserving the first `used` bytes
+        if (bytes <= cap) return BGP_OK;
+        void* np = nullptr;
+        size_t want = bytes + (bytes >> 1) + 4096;
+        hipError_t e = hipHostMalloc(&np, want, hipHostMallocDefault);
+        if (e != hipSuccess) { bgp_note_hip_error(e, "hipHostMalloc", __FILE__, __LINE__); return BGP_ENOMEM; }
+        if (p) { memcpy(np, p, used); (void)hipHostFree(p); }
+        p = np; cap = want;
+        return BGP_OK;
+    }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+    template <class T> T* as() const { return (T*)p; }
+};
+
+// Device status word layout (one uint32 of sticky bits set by kernels).
+enum : uint32_t {
+    ST_EINVAL = 1u << 0, ST_ETRUNC = 1u << 1, ST_ECIGAR = 1u << 2, ST_EUNSORTED = 1u << 3, ST_ESEQ = 1u << 4, ST_EMD = 1u << 5,
+};
+int bgp_status_from_bits(uint32_t bits);      // hard errors first; ESEQ is soft
+
+struct KernelTimer {
+    std::string name;
+    double total_ms = 0;
+    uint64_t launches = 0;
+    uint64_t algorithmic_bytes = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+};
+
+struct RefInfo { std::string name; int32_t length; };
+
+struct bgp_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int32_t n_ref_hint = 0;
+
+    // staged stream
+    HostBuf h_stage; uint64_t h_stage_len = 0;        // pushed host bytes
+    DevBuf d_stream_own;                              // device copy of pushed bytes
+    const uint8_t* d_stream = nullptr; uint64_t stream_len = 0;
+    bool stream_on_device = false;                    // d_stream valid
+    std::vector<RefInfo> refs;
+    DevBuf d_synth;                                   // synthetic stream storage
+
+    // framing (K0)
+    uint32_t seg_bytes = 0; uint64_t n_seg = 0;
+    DevBuf d_seg_entry, d_seg_end, d_seg_cnt, d_seg_lseq, d_seg_ncig, d_seg_dirty;   // per segment
+    DevBuf d_seg_rec_base, d_seg_seq_base, d_seg_cig_base;
+    DevBuf d_scan_tmp;
+    DevBuf d_status;                                  // uint32 status bits + counters
+    bool flushed = false;
+    uint64_t n_records = 0, sum_lseq = 0, sum_ncig = 0;
+
+    // record table (K1)
+    DevBuf d_rec, d_seq_off, d_cigar_off;
+    // decode arenas (K2)
+    DevBuf d_seq, d_qual, d_cigar;
+    uint32_t decoded_what = 0;
+    HostBuf h_rec, h_seq_off, h_cigar_off, h_seq, h_qual, h_cigar;
+
+    // pileup (K3/K4)
+    DevBuf d_pmax_end, d_pmax_pos;                    // prefix maxima (u64 keys)
+    DevBuf d_runs, d_columns, d_depth_hist, d_pstats, d_tiles;
+    std::vector<bgp_run> runs;
+    bgp_pileup_info pinfo{};
+    bool piled = false;
+
+    // column iteration
+    struct Iter {
+        bool active = false; int mode = 0, use_md = 0, skip_zero = 1, want_entries = 0;
+        uint64_t start_from = 0, end_at = ~0ull; uint32_t window = 0;
+        uint32_t run = 0, run_end = 0; uint64_t next_pos = 0; int32_t ref_id = -1;
+    } it;
+    HostBuf h_cols, h_entry_off, h_entries, h_refbase;
+    DevBuf d_entry_off, d_entries, d_col_lo;
+
+    // timing
+    bool timing = false;
+    std::vector<KernelTimer> timers;
+    std::vector<bgp_kernel_time> timing_out;
+
+    std::string last_error;
+};
+
+// timing helpers: wrap a launch region with HIP events on the ctx stream
+struct TimedRegion {
+    bgp_ctx* c; int idx = -1; hipEvent_t a = nullptr, b = nullptr;
+    TimedRegion(bgp_ctx* ctx, const char* name, uint64_t alg_bytes);
+    ~TimedRegion();
+};
+void bgp_timing_collect(bgp_ctx* c);
+
+// ---- per-file entry points (implemented in the .hip units) ----
+int k0_frame(bgp_ctx* c);                                   // frame.hip : segments, guess/chase/verify, scans, record table
+int k2_decode(bgp_ctx* c, uint32_t what);                   // decode.hip
+int k34_pileup(bgp_ctx* c);                                 // pileup.hip : runs + dense columns
+int k34_first_survivor(bgp_ctx* c, uint32_t run, uint64_t start_from, uint64_t* pos);
+int k5_entries(bgp_ctx* c, uint32_t run, uint64_t pos_begin, uint64_t pos_end, uint64_t* n_entries);  // pileup.hip : CSR for a window
+int scan_exclusive_u64(bgp_ctx* c, const uint64_t* in, uint64_t* out, uint64_t n, uint64_t* total_host);   // scan.hip (out has n+1 entries)
+int scan_inclusive_max_u64(bgp_ctx* c, const uint64_t* in, uint64_t* out, uint64_t n);
+int synth_device(bgp_ctx* c, const bgp_synth_cfg_c* cfg, uint64_t* bytes);   // synth.hip
+int synth_host(const bgp_synth_cfg_c* cfg, uint64_t first, uint64_t count, uint8_t* out, uint64_t cap, uint64_t* bytes);
+int bgzf_load_bam(bgp_ctx* c, const char* path, int n_threads);               // bgzf_host.cpp
+
+// device helpers shared by kernels
+#if defined(__HIPCC__)
+__device__ __forceinline__ uint32_t ld_u32(const uint8_t* p) {   // unaligned little-endian load
+    uint32_t v;
+    __builtin_memcpy(&v, p, 4);
+    return v;
+}
+// CIGAR_TYPE bit pairs (cigar.d:113-116): bit0 query consuming, bit1 reference consuming
+__device__ __forceinline__ uint32_t cig_qc(uint32_t raw) { return (0x3C1A7u >> ((raw & 15u) * 2)) & 1u; }
+__device__ __forceinline__ uint32_t cig_rc(uint32_t raw) { return (0x3C1A7u >> ((raw & 15u) * 2 + 1)) & 1u; }
+#endif

@@ -1,0 +1,250 @@
+// frame.hip -- kernels K0 (record framing) and K1 (fixed fields, offsets, end_position).
+//
+// Reference semantics: BamReadRange.readNext (bio/std/hts/bam/readrange.d:118-173) -- a serial
+// pointer chase `next = off + 4 + block_size` -- and the BamRead field accessors
+// (bio/std/hts/bam/read.d:907-1003), basesCovered (read.d:255-262), EagerBamRead (read.d:1380-1383).
+//
+// MI355X design.  The chase is the only serial dependency of the whole path, so it is cut into
+// fixed-size byte segments and run speculatively:
+//   k0_guess   one wave per segment scans for the first *plausible* record header (64 candidate
+//              offsets per step, ballot picks the first whose successor header is plausible too).
+//   k0_chase   one lane per segment chases length prefixes from the segment's entry until it
+//              leaves the segment; emits (chain end, #records, sum l_seq, sum n_cigar).
+//   k0_verify  entry[k] must equal chain_end[k-1]; mismatches are corrected and re-chased until
+//              no segment is dirty.  At the fixpoint every entry is, by induction from entry[0] = 0,
+//              the true record boundary -- the guess only ever costs time, never correctness.
+// Exclusive scans of the per-segment counts give every segment its base record index and arena
+// offsets; k1_emit re-chases (L2-warm) and writes the 32-byte record table.
+#include "common.h"
+
+namespace {
+
+constexpr uint64_t NONE = ~0ull;        // entry/end not known (speculation found nothing)
+constexpr uint64_t STOP = ~0ull - 1;    // chain is over (error upstream); segment holds no records
+
+struct FrameArgs {
+    const uint8_t* s; uint64_t len; uint32_t seg_bytes; uint64_t n_seg; int32_t ref_bound;
+    uint64_t* entry; uint64_t* end; uint64_t* cnt; uint64_t* lseq; uint64_t* ncig; uint32_t* dirty; uint32_t* seg_err;
+    uint32_t* status; /* [0] status bits, [1] dirty counter */
+};
+
+__device__ __forceinline__ bool plausible(const uint8_t* s, uint64_t len, uint64_t o, int32_t ref_bound, uint32_t* bs_out) {
+    if (o + 36 > len) return false;
+    const uint32_t bs = ld_u32(s + o);
+    *bs_out = bs;
+    if (bs < 33u || bs > (1u << 30) || (uint64_t)bs > len - o - 4) return false;
+    const int32_t ref = (int32_t)ld_u32(s + o + 4), pos = (int32_t)ld_u32(s + o + 8);
+    const uint32_t bmn = ld_u32(s + o + 12), fnc = ld_u32(s + o + 16);
+    const int32_t lseq = (int32_t)ld_u32(s + o + 20), nref = (int32_t)ld_u32(s + o + 24), npos = (int32_t)ld_u32(s + o + 28);
+    if (ref < -1 || ref >= ref_bound || nref < -1 || nref >= ref_bound || pos < -1 || npos < -1 || lseq < 0) return false;
+    const uint32_t l_name = bmn & 0xFFu, n_cig = fnc & 0xFFFFu;
+    if (l_name == 0) return false;
+    const uint64_t need = 32ull + l_name + 4ull * n_cig + (uint64_t)((lseq + 1) / 2) + (uint64_t)lseq;
+    if (need > bs) return false;
+    return s[o + 36 + l_name - 1] == 0;                       // read name is NUL terminated
+}
+
+// one wave per segment
+__global__ __launch_bounds__(256) void k0_guess(FrameArgs a) {
+    const uint64_t k = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (k >= a.n_seg) return;
+    if (k == 0) { if (lane == 0) a.entry[0] = 0; return; }
+    const uint64_t beg = k * a.seg_bytes;
+    const uint64_t lim = min(beg + a.seg_bytes, a.len);
+    uint64_t found = NONE;
+    for (uint64_t base = beg; base < lim && found == NONE; base += 64) {
+        const uint64_t o = base + lane;
+        uint32_t bs = 0;
+        const bool ok = o < lim && plausible(a.s, a.len, o, a.ref_bound, &bs);
+        unsigned long long m = __ballot(ok);
+        while (m) {
+            const int l = __ffsll((long long)m) - 1;
+            const uint32_t bsl = __shfl(bs, l, 64);
+            const uint64_t nxt = base + l + 4 + bsl;
+            uint32_t dummy;
+            if (a.len - nxt < 4 || plausible(a.s, a.len, nxt, a.ref_bound, &dummy)) { found = base + l; break; }
+            m &= m - 1;
+        }
+    }
+    if (lane == 0) a.entry[k] = found;
+}
+
+// one lane per segment
+__global__ __launch_bounds__(256) void k0_chase(FrameArgs a) {
+    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= a.n_seg || !a.dirty[k]) return;
+    a.dirty[k] = 0;
+    const uint64_t seg_end = min((k + 1) * (uint64_t)a.seg_bytes, a.len);
+    uint64_t off = a.entry[k], cnt = 0, ls = 0, nc = 0;
+    uint32_t err = 0;
+    if (off == NONE || off == STOP) { a.end[k] = off; a.cnt[k] = 0; a.lseq[k] = 0; a.ncig[k] = 0; a.seg_err[k] = 0; return; }
+    while (off < seg_end) {
+        if (a.len - off < 4) { off = a.len; break; }                       // readrange.d:139-149: short prefix ends the range
+        const int32_t bs = (int32_t)ld_u32(a.s + off);
+        if (bs < 0) { err = ST_EINVAL; break; }
+        if ((uint64_t)bs > a.len - off - 4) { err = ST_ETRUNC; break; }    // readrange.d:169
+        if (bs < 32) { err = ST_EINVAL; break; }
+        const uint32_t bmn = ld_u32(a.s + off + 12), fnc = ld_u32(a.s + off + 16);
+        const int32_t lseq = (int32_t)ld_u32(a.s + off + 20);
+        const uint32_t l_name = bmn & 0xFFu, n_cig = fnc & 0xFFFFu;
+        if (lseq < 0 || l_name == 0 || 32ull + l_name + 4ull * n_cig + (uint64_t)((lseq + 1) / 2) + (uint64_t)lseq > (uint64_t)bs) { err = ST_EINVAL; break; }
+        ++cnt; ls += (uint64_t)lseq; nc += n_cig;
+        off += 4 + (uint64_t)bs;
+    }
+    a.end[k] = err ? STOP : off;
+    a.cnt[k] = cnt; a.lseq[k] = ls; a.ncig[k] = nc; a.seg_err[k] = err;
+}
+
+__global__ __launch_bounds__(256) void k0_verify(FrameArgs a) {
+    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x + 1;
+    if (k >= a.n_seg) return;
+    const uint64_t prev_end = a.end[k - 1];
+    if (prev_end == NONE) return;                 // predecessor not resolved yet: keep the speculation
+    if (a.entry[k] != prev_end) {
+        a.entry[k] = prev_end;
+        a.dirty[k] = 1;
+        atomicAdd(&a.status[1], 1u);
+    }
+}
+
+__global__ __launch_bounds__(256) void k0_collect_errors(FrameArgs a) {
+    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= a.n_seg) return;
+    const uint32_t e = a.seg_err[k];
+    if (e) atomicOr(&a.status[0], e);
+}
+
+struct EmitArgs {
+    const uint8_t* s; uint64_t len; uint32_t seg_bytes; uint64_t n_seg;
+    const uint64_t* entry; const uint64_t* rec_base; const uint64_t* seq_base; const uint64_t* cig_base;
+    bgp_record* rec; uint64_t* seq_off; uint64_t* cigar_off; uint64_t n_records, sum_lseq, sum_ncig;
+};
+
+// one lane per segment: second (L2-warm) chase that writes the record table
+__global__ __launch_bounds__(256) void k1_emit(EmitArgs a) {
+    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k == 0) { a.seq_off[a.n_records] = a.sum_lseq; a.cigar_off[a.n_records] = a.sum_ncig; }
+    if (k >= a.n_seg) return;
+    uint64_t off = a.entry[k];
+    if (off == NONE || off == STOP) return;
+    const uint64_t seg_end = min((k + 1) * (uint64_t)a.seg_bytes, a.len);
+    uint64_t r = a.rec_base[k], so = a.seq_base[k], co = a.cig_base[k];
+    const uint64_t r_end = a.rec_base[k + 1];
+    while (off < seg_end && r < r_end) {
+        const uint8_t* p = a.s + off;
+        const uint32_t bs = ld_u32(p);
+        bgp_record rec;
+        rec.ref_id = (int32_t)ld_u32(p + 4);                     // read.d:907
+        rec.pos = (int32_t)ld_u32(p + 8);                        // read.d:911
+        rec.bin_mq_nl = ld_u32(p + 12);                          // read.d:915
+        rec.flag_nc = ld_u32(p + 16);                            // read.d:919
+        rec.l_seq = (int32_t)ld_u32(p + 20);                     // read.d:923
+        rec.rec_off = off;
+        const uint32_t l_name = rec.bin_mq_nl & 0xFFu, n_cig = rec.flag_nc & 0xFFFFu;
+        uint32_t covered = 0;
+        if (!((rec.flag_nc >> 16) & 0x4u)) {                      // read.d:257-259 is_unmapped -> 0
+            const uint8_t* cg = p + 36 + l_name;                  // read.d:988-990 _cigar_offset
+            for (uint32_t j = 0; j < n_cig; ++j) {
+                const uint32_t op = ld_u32(cg + 4 * j);
+                covered += cig_rc(op) ? (op >> 4) : 0u;           // read.d:261
+            }
+        }
+        rec.end_pos = (int32_t)((uint32_t)rec.pos + covered);     // read.d:1382
+        a.rec[r] = rec;
+        a.seq_off[r] = so;
+        a.cigar_off[r] = co;
+        so += (uint64_t)rec.l_seq; co += n_cig; ++r;
+        off += 4 + (uint64_t)bs;
+    }
+}
+
+uint32_t pow2_ceil(uint64_t v) { uint32_t p = 1; while (p < v && p < (1u << 30)) p <<= 1; return p; }
+
+}  // namespace
+
+int k0_frame(bgp_ctx* c) {
+    const uint64_t len = c->stream_len;
+    c->n_records = 0; c->sum_lseq = 0; c->sum_ncig = 0;
+    BGP_TRY(c->d_status.reserve(64));
+    BGP_HIP(hipMemsetAsync(c->d_status.p, 0, 64, c->stream));
+    if (len < 4) {                       // empty range (readrange.d:123-149)
+        BGP_TRY(c->d_rec.reserve(sizeof(bgp_record)));
+        BGP_TRY(c->d_seq_off.reserve(8)); BGP_TRY(c->d_cigar_off.reserve(8));
+        BGP_HIP(hipMemsetAsync(c->d_seq_off.p, 0, 8, c->stream));
+        BGP_HIP(hipMemsetAsync(c->d_cigar_off.p, 0, 8, c->stream));
+        BGP_HIP(hipStreamSynchronize(c->stream));
+        return BGP_OK;
+    }
+    // segment size: ~8 average records, from the first record's size (any value is correct)
+    uint32_t bs0 = 0;
+    BGP_HIP(hipMemcpyAsync(&bs0, c->d_stream, 4, hipMemcpyDeviceToHost, c->stream));
+    BGP_HIP(hipStreamSynchronize(c->stream));
+    uint64_t want = 8ull * (4ull + (bs0 & 0x3FFFFFFFu));
+    uint32_t seg = pow2_ceil(want);
+    if (seg < 4096u) seg = 4096u;
+    if (seg > (1u << 20)) seg = 1u << 20;
+    c->seg_bytes = seg;
+    const uint64_t n_seg = (len + seg - 1) / seg;
+    c->n_seg = n_seg;
+
+    BGP_TRY(c->d_seg_entry.reserve((n_seg + 1) * 8)); BGP_TRY(c->d_seg_end.reserve((n_seg + 1) * 8));
+    BGP_TRY(c->d_seg_cnt.reserve((n_seg + 1) * 8)); BGP_TRY(c->d_seg_lseq.reserve((n_seg + 1) * 8)); BGP_TRY(c->d_seg_ncig.reserve((n_seg + 1) * 8));
+    BGP_TRY(c->d_seg_dirty.reserve((n_seg + 1) * 8));          // dirty[n_seg] u32 followed by seg_err[n_seg] u32
+    BGP_TRY(c->d_seg_rec_base.reserve((n_seg + 2) * 8)); BGP_TRY(c->d_seg_seq_base.reserve((n_seg + 2) * 8)); BGP_TRY(c->d_seg_cig_base.reserve((n_seg + 2) * 8));
+
+    FrameArgs a;
+    a.s = c->d_stream; a.len = len; a.seg_bytes = seg; a.n_seg = n_seg;
+    a.ref_bound = c->n_ref_hint > 0 ? c->n_ref_hint : (1 << 24);
+    a.entry = c->d_seg_entry.as<uint64_t>(); a.end = c->d_seg_end.as<uint64_t>();
+    a.cnt = c->d_seg_cnt.as<uint64_t>(); a.lseq = c->d_seg_lseq.as<uint64_t>(); a.ncig = c->d_seg_ncig.as<uint64_t>();
+    a.dirty = c->d_seg_dirty.as<uint32_t>(); a.seg_err = a.dirty + n_seg;
+    a.status = c->d_status.as<uint32_t>();
+
+    const unsigned lane_blocks = (unsigned)((n_seg + 255) / 256);
+    {
+        TimedRegion t(c, "k0_guess", n_seg * 64);
+        BGP_HIP(hipMemsetAsync(a.dirty, 0x01, n_seg * 4, c->stream));        // every segment dirty (any non-zero)
+        hipLaunchKernelGGL(k0_guess, dim3((unsigned)((n_seg + 3) / 4)), dim3(256), 0, c->stream, a);
+    }
+    uint64_t rounds = 0;
+    for (;;) {
+        {
+            TimedRegion t(c, "k0_chase", 0);
+            hipLaunchKernelGGL(k0_chase, dim3(lane_blocks), dim3(256), 0, c->stream, a);
+        }
+        BGP_HIP(hipMemsetAsync(a.status + 1, 0, 4, c->stream));
+        hipLaunchKernelGGL(k0_verify, dim3(lane_blocks), dim3(256), 0, c->stream, a);
+        uint32_t ndirty = 0;
+        BGP_HIP(hipMemcpyAsync(&ndirty, a.status + 1, 4, hipMemcpyDeviceToHost, c->stream));
+        BGP_HIP(hipStreamSynchronize(c->stream));
+        if (ndirty == 0) break;
+        if (++rounds > n_seg + 2) { c->last_error = "record framing did not converge"; return BGP_EDEVICE; }
+    }
+    hipLaunchKernelGGL(k0_collect_errors, dim3(lane_blocks), dim3(256), 0, c->stream, a);
+    uint32_t bits = 0;
+    BGP_HIP(hipMemcpyAsync(&bits, a.status, 4, hipMemcpyDeviceToHost, c->stream));
+    BGP_HIP(hipStreamSynchronize(c->stream));
+    const int st = bgp_status_from_bits(bits);
+    if (st < 0 && st != BGP_ESEQ) return st;
+
+    uint64_t n = 0, sl = 0, sc = 0;
+    BGP_TRY(scan_exclusive_u64(c, a.cnt, c->d_seg_rec_base.as<uint64_t>(), n_seg, &n));
+    BGP_TRY(scan_exclusive_u64(c, a.lseq, c->d_seg_seq_base.as<uint64_t>(), n_seg, &sl));
+    BGP_TRY(scan_exclusive_u64(c, a.ncig, c->d_seg_cig_base.as<uint64_t>(), n_seg, &sc));
+    c->n_records = n; c->sum_lseq = sl; c->sum_ncig = sc;
+
+    BGP_TRY(c->d_rec.reserve((n + 1) * sizeof(bgp_record)));
+    BGP_TRY(c->d_seq_off.reserve((n + 1) * 8)); BGP_TRY(c->d_cigar_off.reserve((n + 1) * 8));
+    EmitArgs e;
+    e.s = c->d_stream; e.len = len; e.seg_bytes = seg; e.n_seg = n_seg; e.entry = a.entry;
+    e.rec_base = c->d_seg_rec_base.as<uint64_t>(); e.seq_base = c->d_seg_seq_base.as<uint64_t>(); e.cig_base = c->d_seg_cig_base.as<uint64_t>();
+    e.rec = c->d_rec.as<bgp_record>(); e.seq_off = c->d_seq_off.as<uint64_t>(); e.cigar_off = c->d_cigar_off.as<uint64_t>();
+    e.n_records = n; e.sum_lseq = sl; e.sum_ncig = sc;
+    {
+        TimedRegion t(c, "k1_emit", n * (36 + 32 + 16) + sc * 4);
+        hipLaunchKernelGGL(k1_emit, dim3(lane_blocks), dim3(256), 0, c->stream, e);
+    }
+    BGP_HIP(hipGetLastError());
+    return BGP_OK;
+}

@@ -1,0 +1,399 @@
+// pileup.hip -- kernels K3 (reference runs, halo search keys), K4 (per-position column summary)
+// and K5 (per-column read entries for a window).
+//
+// Reference semantics (bio/std/hts/bam/pileup.d).  PileupRange.popFront (:345-397) sweeps one
+// reference position at a time keeping the reads with position <= pos < end_position in file order;
+// PileupRead (:175-222) steps a per-read cursor (cigar op index, offset in op, query offset).  Both
+// are serial only in form: the state of read R at column p is a closed function of (R, p - R.position):
+//   * ops before the first reference-consuming non-N op only add their query length (S, I) (:180-189);
+//   * from there every reference-consuming op k owns max(len_k, 1) consecutive columns (a zero-length
+//     op still holds the cursor for one column, :196-203); cstart[k] = exclusive sum of those;
+//   * column offset r lies in op k with cstart[k] <= r < cstart[k+1]; cigar_operation_offset =
+//     r - cstart[k]; query_offset = qstart[k] + (op k consumes query ? r - cstart[k] : 0) (:199-201,
+//     :215-217), qstart[k] = query bases consumed by all earlier ops;
+//   * the read is in the column while r < basesCovered (end_position > pos, :352);
+//   * current_base = sequence[query_offset] for M/=/X, '-' otherwise (:115-122).
+// A column is the set of such reads, in file order (:351-359 stable compaction, :377-386 appends).
+//
+// MI355X design.  K4 is a histogram-shaped scatter (integer, HBM/LDS-bound, no MFMA): one workgroup
+// owns a window of W reference positions with seven u32 counters per position in LDS
+// (A,C,G,T,other,'-',n_starting_here; coverage is their sum), finds the contiguous record range that
+// can touch the window by binary search over two prefix-maximum arrays (exact halo: first record
+// whose running max end_position exceeds the window start -- SURVEY.md 3.3), and lets each wave
+// walk one read at a time with LANES ALONG THE READ: consecutive lanes hit consecutive positions =
+// consecutive LDS banks, so the ds_add_u32 traffic is conflict-free regardless of base class.
+// The window is flushed once, 32 contiguous bytes per position, fully coalesced.
+#include "common.h"
+
+#include <algorithm>
+
+namespace {
+
+constexpr int W = 2048;                // reference positions per workgroup
+constexpr int HB = 1024;               // depth-histogram bins kept in LDS
+constexpr int K4_T = 256;
+constexpr uint32_t MAX_RUNS = 1u << 16;
+
+__device__ __forceinline__ uint64_t ref_key(int32_t ref_id) { return ref_id < 0 ? 0x7FFFFFFFull : (uint64_t)(uint32_t)(ref_id + 1); }
+
+struct RunDev { int32_t ref_id; uint32_t pad; uint64_t first_record, end_record, start_pos, end_pos, column_base, tile_base; };
+
+struct K3Args { const bgp_record* rec; uint64_t n; uint64_t* key_end; uint64_t* key_pos; };
+
+__global__ __launch_bounds__(256) void k3_keys(K3Args a) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n) return;
+    const bgp_record r = a.rec[i];
+    const bool cov = r.end_pos != r.pos;                         // basesCovered() > 0, pileup.d:481,510
+    const uint64_t rk = ref_key(r.ref_id) << 32;
+    a.key_end[i] = cov ? (rk | (uint32_t)r.end_pos) : 0;
+    a.key_pos[i] = cov ? (rk | (uint32_t)r.pos) : 0;
+}
+
+struct K3bArgs { const bgp_record* rec; uint64_t n; const uint64_t* pmax_pos; RunDev* runs; uint32_t* status; /* [0] bits [2] n_runs */ unsigned long long* n_used; };
+
+__global__ __launch_bounds__(256) void k3_bounds(K3bArgs a) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool cov = false;
+    if (i < a.n) {
+        const bgp_record r = a.rec[i];
+        cov = r.end_pos != r.pos;
+        if (cov) {
+            if (r.pos < 0 || r.end_pos < r.pos) atomicOr(&a.status[0], ST_EINVAL);
+            const uint64_t key = (ref_key(r.ref_id) << 32) | (uint32_t)r.pos;
+            const uint64_t prev = i ? a.pmax_pos[i - 1] : 0;
+            if (key < prev) atomicOr(&a.status[0], ST_EUNSORTED);      // makePileup precondition, pileup.d:25-27
+            if ((prev >> 32) != (key >> 32)) {                          // first read of a reference run, pileup.d:399-424
+                const uint32_t slot = atomicAdd(&a.status[2], 1u);
+                if (slot < MAX_RUNS) { RunDev rd{}; rd.ref_id = r.ref_id; rd.first_record = i; rd.start_pos = (uint64_t)r.pos; a.runs[slot] = rd; }
+            }
+        }
+    }
+    const unsigned long long m = __ballot(cov);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(a.n_used, (unsigned long long)__popcll(m));
+}
+
+__global__ void k3_run_ends(RunDev* runs, uint32_t n_runs, const uint64_t* pmax_end, uint64_t n) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_runs) return;
+    const uint64_t last = runs[j].end_record - 1;
+    runs[j].end_pos = (uint64_t)(uint32_t)pmax_end[last];
+}
+
+struct K4Args {
+    const uint8_t* s; const bgp_record* rec; const uint64_t* pmax_end; const uint64_t* pmax_pos;
+    const RunDev* runs; uint32_t n_runs; uint64_t n_tiles;
+    bgp_column* cols; unsigned long long* hist; unsigned long long* pstats; /* [0] n_columns [1] sum_cov [2] max_cov */
+    uint32_t* status;
+};
+
+__device__ __forceinline__ uint64_t lower_bound_gt(const uint64_t* a, uint64_t lo, uint64_t hi, uint64_t key) {   // first i in [lo,hi) with a[i] > key
+    while (lo < hi) { const uint64_t m = (lo + hi) >> 1; if (a[m] > key) hi = m; else lo = m + 1; }
+    return lo;
+}
+
+__device__ __forceinline__ uint32_t base_class(uint32_t code) {   // nt16 code -> A,C,G,T,other
+    return (uint32_t)(0x4444444344424104ull >> (code * 4)) & 0xFu;  // 1->0 2->1 4->2 8->3 else 4
+}
+
+// One read against one window, executed by a whole wave (all arguments wave-uniform).
+__device__ __forceinline__ void pile_read(const uint8_t* s, const bgp_record& r, uint32_t T0, uint32_t Tend, uint32_t* cnt /*LDS [7][W]*/, int lane, uint32_t* status) {
+    const uint32_t pos = (uint32_t)r.pos, covered = (uint32_t)r.end_pos - pos;
+    const uint32_t l_name = r.bin_mq_nl & 0xFFu, n_cig = r.flag_nc & 0xFFFFu;
+    const uint8_t* cg = s + r.rec_off + 36 + l_name;
+    const uint8_t* sq = cg + 4ull * n_cig;
+    if (pos >= T0 && lane == 0) atomicAdd(&cnt[6 * W + (pos - T0)], 1u);       // n_starting_here, pileup.d:386,422
+    // column offsets of this read that fall into the window
+    const uint32_t need_hi = min(covered, Tend - pos);                          // exclusive
+    const uint32_t need_lo = T0 > pos ? T0 - pos : 0;
+    uint32_t cs = 0, qs = 0;
+    bool started = false;
+    uint32_t k = 0;
+    for (; k < n_cig && cs < need_hi; ++k) {
+        const uint32_t op = ld_u32(cg + 4 * k);
+        const uint32_t len = op >> 4, qc = cig_qc(op), rc = cig_rc(op);
+        if (!started) {                                                        // PileupRead ctor, pileup.d:180-189
+            if (rc) { if ((op & 15u) != 3u) started = true; else continue; }
+            else { if (qc) qs += len; continue; }
+        }
+        if (!rc) { if (qc) qs += len; continue; }                              // pileup.d:215-217
+        const uint32_t elen = len ? len : 1u;                                  // pileup.d:196-203
+        const uint32_t lo = max(cs, need_lo), hi = min(cs + elen, need_hi);
+        if (qc) {                                                              // M, =, X : sequence[query_offset]
+            for (uint32_t rr = lo + lane; rr < hi; rr += 64) {
+                const uint32_t q = qs + (rr - cs);
+                uint32_t cls = 4;
+                if (q < (uint32_t)r.l_seq) {
+                    const uint32_t byte = sq[q >> 1];
+                    cls = base_class((q & 1u) ? (byte & 0xFu) : (byte >> 4));
+                } else atomicOr(status, ST_ESEQ);
+                atomicAdd(&cnt[cls * W + (pos + rr - T0)], 1u);
+            }
+            qs += elen;
+        } else {                                                               // D, N : '-'
+            for (uint32_t rr = lo + lane; rr < hi; rr += 64) atomicAdd(&cnt[5 * W + (pos + rr - T0)], 1u);
+        }
+        cs += elen;
+    }
+    if (k == n_cig && cs < need_hi && lane == 0) atomicOr(status, ST_ECIGAR);   // assertCigarIndexIsValid, pileup.d:224-228
+}
+
+__global__ __launch_bounds__(K4_T) void k4_tile(K4Args a) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];             // cnt[7][W] then hist[HB]
+    uint32_t* cnt = lds;
+    uint32_t* hist = lds + 7 * W;
+    // XCD-aware order: consecutive tiles of a reference go to the same XCD (block b runs on XCD b % 8)
+    const uint64_t nb = a.n_tiles;
+    const uint64_t per = (nb + 7) / 8;
+    uint64_t tile = (blockIdx.x % 8) * per + blockIdx.x / 8;
+    if (nb < 64) tile = blockIdx.x;
+    if (tile >= nb) return;
+    // run of this tile
+    uint32_t lo_r = 0, hi_r = a.n_runs;
+    while (hi_r - lo_r > 1) { const uint32_t m = (lo_r + hi_r) >> 1; if (a.runs[m].tile_base <= tile) lo_r = m; else hi_r = m; }
+    const RunDev run = a.runs[lo_r];
+    const uint64_t T0 = run.start_pos + (tile - run.tile_base) * (uint64_t)W;
+    const uint64_t Tend = min(T0 + W, run.end_pos);
+    for (int i = threadIdx.x; i < 7 * W + HB; i += K4_T) lds[i] = 0;
+    const uint64_t rk = ref_key(run.ref_id) << 32;
+    // exact halo: first record whose running max end_position exceeds T0; last: first record starting at/after Tend
+    const uint64_t i_lo = lower_bound_gt(a.pmax_end, run.first_record, run.end_record, rk | (uint32_t)T0);
+    const uint64_t i_hi = lower_bound_gt(a.pmax_pos, run.first_record, run.end_record, rk | (uint32_t)(Tend - 1));
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    for (uint64_t i = i_lo + wave; i < i_hi; i += K4_T / 64) {
+        const bgp_record r = a.rec[i];
+        if (r.end_pos == r.pos) continue;                                       // filter basesCovered() > 0
+        if ((uint64_t)(uint32_t)r.end_pos <= T0 || (uint64_t)(uint32_t)r.pos >= Tend) continue;
+        pile_read(a.s, r, (uint32_t)T0, (uint32_t)Tend, cnt, lane, a.status);
+    }
+    __syncthreads();
+    // flush: 32 contiguous bytes per position
+    bgp_column* out = a.cols + run.column_base + (T0 - run.start_pos);
+    const uint32_t np = (uint32_t)(Tend - T0);
+    uint64_t ncol = 0, scov = 0; uint32_t mx = 0;
+    for (uint32_t p = threadIdx.x; p < np; p += K4_T) {
+        const uint32_t A = cnt[p], C = cnt[W + p], G = cnt[2 * W + p], Tt = cnt[3 * W + p], O = cnt[4 * W + p], D = cnt[5 * W + p], S = cnt[6 * W + p];
+        const uint32_t cov = A + C + G + Tt + O + D;
+        uint4* o4 = reinterpret_cast<uint4*>(out + p);
+        o4[0] = make_uint4(cov, S, A, C);
+        o4[1] = make_uint4(G, Tt, O, D);
+        ncol += cov > 0; scov += cov; mx = max(mx, cov);
+        if (cov < HB) atomicAdd(&hist[cov], 1u);
+        else atomicAdd(&a.hist[min(cov, (uint32_t)BGP_DEPTH_BINS - 1)], 1ull);
+    }
+    for (int d = 32; d >= 1; d >>= 1) { ncol += __shfl_down(ncol, d, 64); scov += __shfl_down(scov, d, 64); mx = max(mx, (uint32_t)__shfl_down(mx, d, 64)); }
+    if (lane == 0) {
+        if (ncol) atomicAdd(&a.pstats[0], (unsigned long long)ncol);
+        if (scov) atomicAdd(&a.pstats[1], (unsigned long long)scov);
+        if (mx) atomicMax(&a.pstats[2], (unsigned long long)mx);
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < HB; b += K4_T) { const uint32_t h = hist[b]; if (h) atomicAdd(&a.hist[b], (unsigned long long)h); }
+}
+
+// ---------------------------------------------------------------------------------------------- K5
+
+struct K5Args {
+    const uint8_t* s; const bgp_record* rec; const uint64_t* pmax_end; const uint64_t* pmax_pos;
+    RunDev run; uint64_t pos_begin, pos_end; const bgp_column* cols; uint64_t* cov64; const uint64_t* col_off; bgp_entry* entries;
+};
+
+__global__ __launch_bounds__(256) void k5_cov(K5Args a) {
+    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= a.pos_end - a.pos_begin) return;
+    a.cov64[k] = a.cols[a.run.column_base + (a.pos_begin - a.run.start_pos) + k].coverage;
+}
+
+// closed-form cursor of read r at column offset rr (see file header)
+__device__ __forceinline__ bgp_entry entry_of(const uint8_t* s, const bgp_record& r, uint32_t rr, uint32_t ordinal) {
+    const uint32_t l_name = r.bin_mq_nl & 0xFFu, n_cig = r.flag_nc & 0xFFFFu;
+    const uint8_t* cg = s + r.rec_off + 36 + l_name;
+    const uint8_t* sq = cg + 4ull * n_cig;
+    const uint8_t* ql = sq + (uint32_t)((r.l_seq + 1) / 2);
+    bgp_entry e; e.read_ordinal = ordinal; e.cigar_op_offset = 0; e.query_offset = 0; e.cigar_op_index = 0xFFFF; e.base = 0xFF; e.qual = 0xFF;
+    uint32_t cs = 0, qs = 0; bool started = false;
+    for (uint32_t k = 0; k < n_cig; ++k) {
+        const uint32_t op = ld_u32(cg + 4 * k);
+        const uint32_t len = op >> 4, qc = cig_qc(op), rc = cig_rc(op);
+        if (!started) {
+            if (rc) { if ((op & 15u) != 3u) started = true; else continue; }
+            else { if (qc) qs += len; continue; }
+        }
+        if (!rc) { if (qc) qs += len; continue; }
+        const uint32_t elen = len ? len : 1u;
+        if (rr < cs + elen) {
+            e.cigar_op_index = (uint16_t)k; e.cigar_op_offset = rr - cs;
+            e.query_offset = qs + (qc ? rr - cs : 0u);
+            if (qc) {
+                if (e.query_offset < (uint32_t)r.l_seq) {
+                    const uint32_t byte = sq[e.query_offset >> 1];
+                    const uint32_t code = (e.query_offset & 1u) ? (byte & 0xFu) : (byte >> 4);
+                    const uint64_t lo = 0x565352474D43413Dull, hi = 0x4E42444B48595754ull;   // "=ACMGRSVTWYHKDBN", base.d:85
+                    e.base = (uint8_t)(((code & 8u) ? hi : lo) >> ((code & 7u) * 8));
+                    e.qual = ql[e.query_offset];
+                }
+            } else { e.base = '-'; e.qual = 255; }                                         // pileup.d:119-121,131-133
+            return e;
+        }
+        cs += elen; if (qc) qs += elen;
+    }
+    return e;
+}
+
+// one wave per column: stream-compact the overlapping reads in file order
+__global__ __launch_bounds__(256) void k5_fill(K5Args a) {
+    const uint64_t col = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (col >= a.pos_end - a.pos_begin) return;
+    const uint64_t p = a.pos_begin + col;
+    const uint64_t rk = ref_key(a.run.ref_id) << 32;
+    const uint64_t i_lo = lower_bound_gt(a.pmax_end, a.run.first_record, a.run.end_record, rk | (uint32_t)p);
+    const uint64_t i_hi = lower_bound_gt(a.pmax_pos, a.run.first_record, a.run.end_record, rk | (uint32_t)p);
+    uint64_t w = a.col_off[col];
+    for (uint64_t base = i_lo; base < i_hi; base += 64) {
+        const uint64_t i = base + lane;
+        bool alive = false; bgp_record r{};
+        if (i < i_hi) { r = a.rec[i]; alive = r.end_pos != r.pos && (uint64_t)(uint32_t)r.pos <= p && (uint64_t)(uint32_t)r.end_pos > p; }
+        const unsigned long long m = __ballot(alive);
+        if (alive) {
+            const uint32_t rank = __popcll(m & ((1ull << lane) - 1));
+            a.entries[w + rank] = entry_of(a.s, r, (uint32_t)(p - (uint32_t)r.pos), (uint32_t)i);
+        }
+        w += __popcll(m);
+    }
+}
+
+}  // namespace
+
+int k34_pileup(bgp_ctx* c) {
+    const uint64_t n = c->n_records;
+    c->runs.clear();
+    memset(&c->pinfo, 0, sizeof c->pinfo);
+    BGP_TRY(c->d_pstats.reserve(64));
+    BGP_TRY(c->d_depth_hist.reserve((size_t)BGP_DEPTH_BINS * 8));
+    BGP_HIP(hipMemsetAsync(c->d_pstats.p, 0, 64, c->stream));
+    BGP_HIP(hipMemsetAsync(c->d_depth_hist.p, 0, (size_t)BGP_DEPTH_BINS * 8, c->stream));
+    BGP_HIP(hipMemsetAsync(c->d_status.p, 0, 64, c->stream));
+    if (n == 0) { BGP_HIP(hipStreamSynchronize(c->stream)); c->pinfo.device_depth_hist = c->d_depth_hist.as<uint64_t>(); return BGP_OK; }
+    if (n >= (1ull << 32)) return BGP_EINVAL;                  // read_ordinal is 32 bit
+    BGP_TRY(c->d_pmax_end.reserve(n * 8)); BGP_TRY(c->d_pmax_pos.reserve(n * 8));
+    BGP_TRY(c->d_runs.reserve(sizeof(RunDev) * MAX_RUNS));
+    const unsigned nb = (unsigned)((n + 255) / 256);
+    uint32_t* status = c->d_status.as<uint32_t>();
+    unsigned long long* n_used = (unsigned long long*)(c->d_pstats.as<uint64_t>() + 4);
+    {
+        TimedRegion t(c, "k3_keys_scan", n * (32 + 16 + 32));
+        K3Args a{c->d_rec.as<bgp_record>(), n, c->d_pmax_end.as<uint64_t>(), c->d_pmax_pos.as<uint64_t>()};
+        hipLaunchKernelGGL(k3_keys, dim3(nb), dim3(256), 0, c->stream, a);
+        BGP_TRY(scan_inclusive_max_u64(c, a.key_end, a.key_end, n));
+        BGP_TRY(scan_inclusive_max_u64(c, a.key_pos, a.key_pos, n));
+        K3bArgs b{c->d_rec.as<bgp_record>(), n, c->d_pmax_pos.as<uint64_t>(), c->d_runs.as<RunDev>(), status, n_used};
+        hipLaunchKernelGGL(k3_bounds, dim3(nb), dim3(256), 0, c->stream, b);
+    }
+    uint32_t st[4] = {0, 0, 0, 0};
+    BGP_HIP(hipMemcpyAsync(st, status, 16, hipMemcpyDeviceToHost, c->stream));
+    BGP_HIP(hipStreamSynchronize(c->stream));
+    int rc = bgp_status_from_bits(st[0]);
+    if (rc < 0 && rc != BGP_ESEQ) return rc;
+    const uint32_t n_runs = st[2];
+    if (n_runs > MAX_RUNS) { c->last_error = "too many reference runs"; return BGP_EINVAL; }
+    std::vector<RunDev> runs(n_runs);
+    if (n_runs) BGP_HIP(hipMemcpy(runs.data(), c->d_runs.p, sizeof(RunDev) * n_runs, hipMemcpyDeviceToHost));
+    std::sort(runs.begin(), runs.end(), [](const RunDev& x, const RunDev& y) { return x.first_record < y.first_record; });
+    for (uint32_t j = 0; j < n_runs; ++j) runs[j].end_record = j + 1 < n_runs ? runs[j + 1].first_record : n;
+    if (n_runs) {
+        BGP_HIP(hipMemcpyAsync(c->d_runs.p, runs.data(), sizeof(RunDev) * n_runs, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(k3_run_ends, dim3((n_runs + 63) / 64), dim3(64), 0, c->stream, c->d_runs.as<RunDev>(), n_runs, c->d_pmax_end.as<uint64_t>(), n);
+        BGP_HIP(hipMemcpyAsync(runs.data(), c->d_runs.p, sizeof(RunDev) * n_runs, hipMemcpyDeviceToHost, c->stream));
+        BGP_HIP(hipStreamSynchronize(c->stream));
+    }
+    uint64_t col_base = 0, tile_base = 0;
+    for (auto& r : runs) {
+        r.column_base = col_base; r.tile_base = tile_base;
+        const uint64_t span = r.end_pos - r.start_pos;
+        col_base += span; tile_base += (span + W - 1) / W;
+    }
+    if (tile_base >= (1ull << 31)) return BGP_EINVAL;
+    c->runs.resize(n_runs);
+    for (uint32_t j = 0; j < n_runs; ++j) {
+        bgp_run& o = c->runs[j]; const RunDev& r = runs[j];
+        o.ref_id = r.ref_id; o._pad = 0; o.first_record = r.first_record; o.end_record = r.end_record;
+        o.start_pos = r.start_pos; o.end_pos = r.end_pos; o.column_base = r.column_base;
+    }
+    BGP_TRY(c->d_columns.reserve((col_base + 1) * sizeof(bgp_column)));
+    if (n_runs) {
+        BGP_HIP(hipMemcpyAsync(c->d_runs.p, runs.data(), sizeof(RunDev) * n_runs, hipMemcpyHostToDevice, c->stream));
+        K4Args a;
+        a.s = c->d_stream; a.rec = c->d_rec.as<bgp_record>(); a.pmax_end = c->d_pmax_end.as<uint64_t>(); a.pmax_pos = c->d_pmax_pos.as<uint64_t>();
+        a.runs = c->d_runs.as<RunDev>(); a.n_runs = n_runs; a.n_tiles = tile_base;
+        a.cols = c->d_columns.as<bgp_column>(); a.hist = (unsigned long long*)c->d_depth_hist.p; a.pstats = (unsigned long long*)c->d_pstats.p; a.status = status;
+        const size_t lds_bytes = (7 * W + HB) * 4;
+        const uint64_t grid = tile_base < 64 ? tile_base : ((tile_base + 7) / 8) * 8;
+        uint64_t used = 0;   // algorithmic bytes: record table + CIGAR + packed SEQ per read, 32 B per position
+        used = c->n_records * 32 + c->sum_ncig * 4 + (c->sum_lseq + 1) / 2 + col_base * 32;
+        TimedRegion t(c, "k4_tile", used);
+        hipLaunchKernelGGL(k4_tile, dim3((unsigned)grid), dim3(K4_T), lds_bytes, c->stream, a);
+        BGP_HIP(hipGetLastError());
+    }
+    uint64_t ps[8];
+    BGP_HIP(hipMemcpyAsync(ps, c->d_pstats.p, 64, hipMemcpyDeviceToHost, c->stream));
+    BGP_HIP(hipMemcpyAsync(st, status, 16, hipMemcpyDeviceToHost, c->stream));
+    BGP_HIP(hipStreamSynchronize(c->stream));
+    rc = bgp_status_from_bits(st[0]);
+    if (rc < 0 && rc != BGP_ESEQ) return rc;
+    bgp_pileup_info& pi = c->pinfo;
+    pi.n_runs = n_runs; pi.runs = c->runs.data(); pi.n_positions = col_base;
+    pi.n_columns = ps[0]; pi.sum_coverage = ps[1]; pi.max_coverage = (uint32_t)ps[2]; pi.n_reads_used = ps[4];
+    pi.soft_status = rc == BGP_ESEQ ? BGP_ESEQ : BGP_OK;
+    pi.device_columns = c->d_columns.as<bgp_column>(); pi.device_depth_hist = c->d_depth_hist.as<uint64_t>();
+    return BGP_OK;
+}
+
+namespace {
+__global__ void k_first_survivor(const uint64_t* pmax_end, const bgp_record* rec, uint64_t first, uint64_t end, uint64_t key, uint64_t* out) {
+    // first record of the run whose running max end_position reaches `key`: it is the read that raised the max
+    uint64_t lo = first, hi = end;
+    while (lo < hi) { const uint64_t m = (lo + hi) >> 1; if (pmax_end[m] >= key) hi = m; else lo = m + 1; }
+    out[0] = lo < end ? (uint64_t)(uint32_t)rec[lo].pos : ~0ull;
+}
+}  // namespace
+
+// position of the first read of run `run_idx` with position + basesCovered >= start_from (pileup.d:482-489)
+int k34_first_survivor(bgp_ctx* c, uint32_t run_idx, uint64_t start_from, uint64_t* pos) {
+    const bgp_run& r = c->runs[run_idx];
+    if (start_from > 0x7FFFFFFFull) { *pos = ~0ull; return BGP_OK; }
+    const uint64_t key = (((uint64_t)(r.ref_id < 0 ? 0x7FFFFFFFu : (uint32_t)(r.ref_id + 1))) << 32) | (uint32_t)start_from;
+    uint64_t* out = c->d_pstats.as<uint64_t>() + 6;
+    hipLaunchKernelGGL(k_first_survivor, dim3(1), dim3(1), 0, c->stream, c->d_pmax_end.as<uint64_t>(), c->d_rec.as<bgp_record>(), r.first_record, r.end_record, key, out);
+    BGP_HIP(hipMemcpyAsync(pos, out, 8, hipMemcpyDeviceToHost, c->stream));
+    BGP_HIP(hipStreamSynchronize(c->stream));
+    return BGP_OK;
+}
+
+int k5_entries(bgp_ctx* c, uint32_t run_idx, uint64_t pos_begin, uint64_t pos_end, uint64_t* n_entries) {
+    const bgp_run& r = c->runs[run_idx];
+    const uint64_t np = pos_end - pos_begin;
+    *n_entries = 0;
+    if (np == 0) return BGP_OK;
+    BGP_TRY(c->d_entry_off.reserve((np + 1) * 8)); BGP_TRY(c->d_col_lo.reserve((np + 1) * 8));
+    K5Args a;
+    a.s = c->d_stream; a.rec = c->d_rec.as<bgp_record>(); a.pmax_end = c->d_pmax_end.as<uint64_t>(); a.pmax_pos = c->d_pmax_pos.as<uint64_t>();
+    a.run.ref_id = r.ref_id; a.run.first_record = r.first_record; a.run.end_record = r.end_record; a.run.start_pos = r.start_pos; a.run.end_pos = r.end_pos;
+    a.run.column_base = r.column_base; a.run.tile_base = 0; a.run.pad = 0;
+    a.pos_begin = pos_begin; a.pos_end = pos_end; a.cols = c->d_columns.as<bgp_column>(); a.cov64 = c->d_col_lo.as<uint64_t>();
+    a.col_off = c->d_entry_off.as<uint64_t>(); a.entries = nullptr;
+    hipLaunchKernelGGL(k5_cov, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, c->stream, a);
+    uint64_t total = 0;
+    BGP_TRY(scan_exclusive_u64(c, a.cov64, c->d_entry_off.as<uint64_t>(), np, &total));
+    BGP_TRY(c->d_entries.reserve((total + 1) * sizeof(bgp_entry)));
+    a.entries = c->d_entries.as<bgp_entry>();
+    {
+        TimedRegion t(c, "k5_fill", total * 16);
+        hipLaunchKernelGGL(k5_fill, dim3((unsigned)((np + 3) / 4)), dim3(256), 0, c->stream, a);
+    }
+    BGP_HIP(hipGetLastError());
+    *n_entries = total;
+    return BGP_OK;
+}

@@ -1,0 +1,116 @@
+// scan.hip -- device-wide prefix scans over uint64 (sum, max) used by framing, decode and pileup.
+// Three passes (block reduce -> scan of block totals -> block scan with carry-in); wave64 shuffles
+// inside a wave, LDS only for the 4 wave totals of a 256-thread block.
+#include "common.h"
+
+namespace {
+
+constexpr int T = 256;
+constexpr int ITEMS = 8;
+constexpr int TILE = T * ITEMS;
+
+struct OpSum { __device__ static uint64_t id() { return 0; } __device__ static uint64_t f(uint64_t a, uint64_t b) { return a + b; } };
+struct OpMax { __device__ static uint64_t id() { return 0; } __device__ static uint64_t f(uint64_t a, uint64_t b) { return a > b ? a : b; } };
+
+template <class Op> __device__ __forceinline__ uint64_t wave_incl(uint64_t v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint64_t o = __shfl_up(v, d, 64);
+        if (lane >= d) v = Op::f(o, v);
+    }
+    return v;
+}
+
+// exclusive prefix of per-thread totals across the block; also returns the block total
+template <class Op> __device__ __forceinline__ uint64_t block_excl(uint64_t mine, uint64_t* total, uint64_t* lds /*4*/) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint64_t inc = wave_incl<Op>(mine, lane);
+    if (lane == 63) lds[w] = inc;
+    __syncthreads();
+    uint64_t carry = Op::id();
+#pragma unroll
+    for (int k = 0; k < T / 64; ++k) if (k < w) carry = Op::f(carry, lds[k]);
+    uint64_t tot = Op::id();
+#pragma unroll
+    for (int k = 0; k < T / 64; ++k) tot = Op::f(tot, lds[k]);
+    *total = tot;
+    uint64_t prev = __shfl_up(inc, 1, 64);
+    uint64_t ex = lane == 0 ? Op::id() : prev;
+    __syncthreads();
+    return Op::f(carry, ex);
+}
+
+template <class Op> __global__ __launch_bounds__(T) void k_reduce(const uint64_t* __restrict__ in, uint64_t* __restrict__ bsum, uint64_t n) {
+    __shared__ uint64_t lds[T / 64];
+    const uint64_t base = (uint64_t)blockIdx.x * TILE + (uint64_t)threadIdx.x * ITEMS;
+    uint64_t acc = Op::id();
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) if (base + k < n) acc = Op::f(acc, in[base + k]);
+    uint64_t tot;
+    (void)block_excl<Op>(acc, &tot, lds);
+    if (threadIdx.x == 0) bsum[blockIdx.x] = tot;
+}
+
+// single block: bsum[i] <- exclusive prefix; bsum[nb] <- grand total
+template <class Op> __global__ __launch_bounds__(T) void k_scan_bsum(uint64_t* bsum, uint64_t nb) {
+    __shared__ uint64_t lds[T / 64];
+    uint64_t carry = Op::id();
+    for (uint64_t base = 0; base < nb; base += T) {
+        const uint64_t i = base + threadIdx.x;
+        const uint64_t v = i < nb ? bsum[i] : Op::id();
+        uint64_t tot;
+        const uint64_t ex = block_excl<Op>(v, &tot, lds);
+        if (i < nb) bsum[i] = Op::f(carry, ex);
+        carry = Op::f(carry, tot);
+    }
+    if (threadIdx.x == 0) bsum[nb] = carry;
+}
+
+template <class Op, bool EXCL> __global__ __launch_bounds__(T) void k_down(const uint64_t* __restrict__ in, uint64_t* __restrict__ out,
+                                                                           const uint64_t* __restrict__ bsum, uint64_t n, uint64_t nb) {
+    __shared__ uint64_t lds[T / 64];
+    const uint64_t base = (uint64_t)blockIdx.x * TILE + (uint64_t)threadIdx.x * ITEMS;
+    uint64_t v[ITEMS];
+    uint64_t acc = Op::id();
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) { v[k] = base + k < n ? in[base + k] : Op::id(); acc = Op::f(acc, v[k]); }
+    uint64_t tot;
+    uint64_t run = Op::f(bsum[blockIdx.x], block_excl<Op>(acc, &tot, lds));
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) {
+        if (base + k < n) {
+            if (EXCL) { out[base + k] = run; run = Op::f(run, v[k]); }
+            else { run = Op::f(run, v[k]); out[base + k] = run; }
+        }
+    }
+    if (EXCL && blockIdx.x == 0 && threadIdx.x == 0) out[n] = bsum[nb];
+}
+
+template <class Op, bool EXCL> int run_scan(bgp_ctx* c, const uint64_t* in, uint64_t* out, uint64_t n, uint64_t* total_host) {
+    const uint64_t nb = (n + TILE - 1) / TILE;
+    BGP_TRY(c->d_scan_tmp.reserve((nb + 2) * sizeof(uint64_t)));
+    uint64_t* bsum = c->d_scan_tmp.as<uint64_t>();
+    if (n == 0) {
+        if (EXCL) BGP_HIP(hipMemsetAsync(out, 0, sizeof(uint64_t), c->stream));
+        if (total_host) *total_host = 0;
+        return BGP_OK;
+    }
+    hipLaunchKernelGGL((k_reduce<Op>), dim3((unsigned)nb), dim3(T), 0, c->stream, in, bsum, n);
+    hipLaunchKernelGGL((k_scan_bsum<Op>), dim3(1), dim3(T), 0, c->stream, bsum, nb);
+    hipLaunchKernelGGL((k_down<Op, EXCL>), dim3((unsigned)nb), dim3(T), 0, c->stream, in, out, bsum, n, nb);
+    BGP_HIP(hipGetLastError());
+    if (total_host) {
+        BGP_HIP(hipMemcpyAsync(total_host, bsum + nb, sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+        BGP_HIP(hipStreamSynchronize(c->stream));
+    }
+    return BGP_OK;
+}
+
+}  // namespace
+
+int scan_exclusive_u64(bgp_ctx* c, const uint64_t* in, uint64_t* out, uint64_t n, uint64_t* total_host) {
+    return run_scan<OpSum, true>(c, in, out, n, total_host);
+}
+int scan_inclusive_max_u64(bgp_ctx* c, const uint64_t* in, uint64_t* out, uint64_t n) {
+    return run_scan<OpMax, false>(c, in, out, n, nullptr);
+}

@@ -1,0 +1,394 @@
+"""Host-side mirror of BioD's pileup interface over the libbiodgpu C ABI.
+
+Names, argument order, defaults and error behaviour follow ``bio/std/hts/bam/pileup.d``:
+``makePileup(reads, use_md_tag=false, start_from=0, end_at=ulong.max, skip_zero_coverage=true)``
+(pileup.d:683-687) and ``pileupColumns(reads, use_md_tag=false, skip_zero_coverage=true)``
+(pileup.d:509); columns expose ``coverage / ref_id / position / reads / reads_starting_here / bases /
+base_qualities / read_qualities`` (pileup.d:236-290) and every read of a column exposes
+``cigar_operation / cigar_operation_offset / cigar_before / cigar_after / current_base /
+current_base_quality / query_offset`` (pileup.d:86-230) plus the ``BamRead`` accessors used by BioD's
+consumers (name, position, mapping_quality, is_reverse_strand, sequence, base_qualities, cigar).
+
+``reads`` is a :class:`RecordStream` (inflated record bytes, host or device resident) or a
+:class:`BamReader` (file), the analogue of ``BamReader.reads`` (reader.d:228-231).  All computation
+happens in the HIP kernels behind the ABI; this module only moves pointers and wraps results.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Iterator, List, Optional
+
+import numpy as np
+
+from . import _lib as L
+
+ULONG_MAX = (1 << 64) - 1
+_CIGAR_CHARS = "MIDNSHP=X???????"
+
+
+class Context:
+    """One bgp_ctx: a (host thread, GPU) pair."""
+
+    def __init__(self, device: int = 0):
+        self._h = C.c_void_p()
+        L.check(L.lib().bgp_init(device, C.byref(self._h)))
+        self._keep = None
+
+    def close(self):
+        if self._h:
+            L.lib().bgp_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- staging
+    def reset(self):
+        L.check(L.lib().bgp_reset(self._h), self._h)
+        self._keep = None
+
+    def set_stream(self, hip_stream: int):
+        L.check(L.lib().bgp_set_stream(self._h, C.c_void_p(hip_stream)), self._h)
+
+    def set_n_ref(self, n_ref: int):
+        L.check(L.lib().bgp_set_n_ref(self._h, n_ref), self._h)
+
+    def push_inflated(self, data: bytes, coffset: int = 0, first_record_uoffset: int = L.BGP_UOFFSET_UNKNOWN):
+        buf = (C.c_char * len(data)).from_buffer_copy(data) if data else None
+        L.check(L.lib().bgp_push_inflated(self._h, C.cast(buf, C.c_void_p) if buf else None, len(data), coffset, first_record_uoffset), self._h)
+
+    def attach_device_stream(self, device_ptr: int, length: int, keepalive=None):
+        self._keep = keepalive
+        L.check(L.lib().bgp_attach_device_stream(self._h, C.c_void_p(device_ptr), length), self._h)
+
+    def load_bam(self, path: str, n_threads: int = 0):
+        L.check(L.lib().bgp_load_bam(self._h, path.encode(), n_threads), self._h)
+
+    def references(self):
+        n = C.c_int32()
+        L.check(L.lib().bgp_n_ref(self._h, C.byref(n)), self._h)
+        out = []
+        for i in range(n.value):
+            nm, ln = C.c_char_p(), C.c_int32()
+            L.check(L.lib().bgp_ref_info(self._h, i, C.byref(nm), C.byref(ln)), self._h)
+            out.append((nm.value.decode("latin-1"), ln.value))
+        return out
+
+    def synth_device(self, cfg: "L.SynthCfg") -> int:
+        n = C.c_uint64()
+        L.check(L.lib().bgp_synth_device(self._h, C.byref(cfg), C.byref(n)), self._h)
+        return n.value
+
+    # -- decode
+    def flush(self):
+        L.check(L.lib().bgp_flush(self._h), self._h)
+
+    def num_records(self) -> int:
+        n = C.c_uint64()
+        L.check(L.lib().bgp_num_records(self._h, C.byref(n)), self._h)
+        return n.value
+
+    def decode_fetch(self, what: int = L.BGP_FETCH_ALL) -> "DecodedRecords":
+        r = L.Records()
+        L.check(L.lib().bgp_decode_fetch(self._h, what, C.byref(r)), self._h)
+        n = r.n
+        seq_off = L.as_array(r.seq_off, n + 1, "<u8")
+        cigar_off = L.as_array(r.cigar_off, n + 1, "<u8")
+        return DecodedRecords(rec=L.as_array(r.rec, n, L.RECORD_DTYPE), seq_off=seq_off, cigar_off=cigar_off,
+                              seq=L.as_array(r.seq, int(seq_off[n]), "u1") if r.seq else None,
+                              qual=L.as_array(r.qual, int(seq_off[n]), "u1") if r.qual else None,
+                              cigar=L.as_array(r.cigar, int(cigar_off[n]), "<u4") if r.cigar else None)
+
+    def decode_device(self, what: int = L.BGP_FETCH_ALL) -> "L.Records":
+        r = L.Records()
+        L.check(L.lib().bgp_decode_device(self._h, what, C.byref(r)), self._h)
+        return r
+
+    # -- pileup
+    def pileup_run(self) -> "PileupInfo":
+        info = L.PileupInfo()
+        L.check(L.lib().bgp_pileup_run(self._h, C.byref(info)), self._h)
+        return PileupInfo(runs=L.as_array(info.runs, info.n_runs, L.RUN_DTYPE), n_positions=info.n_positions, n_columns=info.n_columns,
+                          sum_coverage=info.sum_coverage, max_coverage=info.max_coverage, soft_status=info.soft_status,
+                          n_reads_used=info.n_reads_used, device_columns=info.device_columns or 0, device_depth_hist=info.device_depth_hist or 0)
+
+    def pileup_windows(self, mode: int, use_md_tag=False, start_from=0, end_at=ULONG_MAX, skip_zero_coverage=True,
+                       want_entries=False, window_positions=0):
+        L.check(L.lib().bgp_pileup_begin(self._h, mode, int(use_md_tag), start_from, end_at, int(skip_zero_coverage), int(want_entries), window_positions), self._h)
+        while True:
+            cw = L.Columns()
+            rc = L.check(L.lib().bgp_pileup_next_window(self._h, C.byref(cw)), self._h)
+            if rc == L.BGP_EOF:
+                return
+            cols = L.as_array(cw.columns, cw.n_positions, L.COLUMN_DTYPE)
+            eoff = L.as_array(cw.entry_off, cw.n_positions + 1, "<u8") if cw.entry_off else None
+            ents = L.as_array(cw.entries, int(eoff[-1]), L.ENTRY_DTYPE) if eoff is not None else None
+            yield Window(cw.ref_id, cw.first_position, cols, eoff, ents)
+
+    def pileup_ref_id(self) -> int:
+        r = C.c_int32()
+        L.check(L.lib().bgp_pileup_ref_id(self._h, C.byref(r)), self._h)
+        return r.value
+
+    # -- timing
+    def timing_enable(self, on=True):
+        L.check(L.lib().bgp_timing_enable(self._h, int(on)), self._h)
+
+    def timing_reset(self):
+        L.check(L.lib().bgp_timing_reset(self._h), self._h)
+
+    def timing_get(self):
+        p = C.POINTER(L.KernelTime)()
+        n = C.c_uint32()
+        L.check(L.lib().bgp_timing_get(self._h, C.byref(p), C.byref(n)), self._h)
+        return {p[i].name.decode(): dict(total_ms=p[i].total_ms, launches=p[i].launches, algorithmic_bytes=p[i].algorithmic_bytes) for i in range(n.value)}
+
+    @property
+    def handle(self):
+        return self._h
+
+
+class DecodedRecords:
+    def __init__(self, rec, seq_off, cigar_off, seq, qual, cigar):
+        self.rec, self.seq_off, self.cigar_off, self.seq, self.qual, self.cigar = rec, seq_off, cigar_off, seq, qual, cigar
+
+    def __len__(self):
+        return len(self.rec)
+
+
+class PileupInfo:
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+class Window:
+    def __init__(self, ref_id, first_position, columns, entry_off, entries):
+        self.ref_id, self.first_position, self.columns, self.entry_off, self.entries = ref_id, first_position, columns, entry_off, entries
+
+
+# ------------------------------------------------------------------------------------------ reads
+
+class RecordStream:
+    """An input range of BAM reads given as inflated record bytes (what ``BamReadRange`` consumes,
+    readrange.d:118-173).  Holds the host copy so per-read accessors can view names and tags."""
+
+    def __init__(self, data: bytes, ctx: Optional[Context] = None, n_ref: int = 0):
+        self.data = data
+        self.ctx = ctx or Context()
+        self.n_ref = n_ref
+        self._staged = False
+        self.records = None
+
+    def _stage(self):
+        if not self._staged:
+            self.ctx.reset()
+            if self.n_ref:
+                self.ctx.set_n_ref(self.n_ref)
+            self.ctx.push_inflated(self.data)
+            self.ctx.flush()
+            self._staged = True
+        return self.ctx
+
+    def decode(self, what=L.BGP_FETCH_ALL) -> DecodedRecords:
+        self.records = self._stage().decode_fetch(what)
+        return self.records
+
+
+class BamReader:
+    """``new BamReader(filename)`` (reader.d:127-138): ``.reads`` is the range handed to makePileup."""
+
+    def __init__(self, filename: str, n_threads: int = 0, ctx: Optional[Context] = None):
+        self.filename = filename
+        self.ctx = ctx or Context()
+        self.ctx.reset()
+        self.ctx.load_bam(filename, n_threads)
+        self.reference_sequences = self.ctx.references()
+        self.ctx.flush()
+        self.reads = _LoadedReads(self.ctx)
+
+
+class _LoadedReads:
+    def __init__(self, ctx):
+        self.ctx = ctx
+        self.data = None
+        self.records = None
+
+    def _stage(self):
+        return self.ctx
+
+    def decode(self, what=L.BGP_FETCH_ALL):
+        self.records = self.ctx.decode_fetch(what)
+        return self.records
+
+
+# ------------------------------------------------------------------------------------------ columns
+
+class CigarOperation:
+    """cigar.d:58-136"""
+    __slots__ = ("raw",)
+
+    def __init__(self, raw: int):
+        self.raw = int(raw)
+
+    @property
+    def length(self):
+        return self.raw >> 4
+
+    @property
+    def type(self):
+        return _CIGAR_CHARS[self.raw & 0xF]
+
+    @property
+    def is_query_consuming(self):
+        return bool((0x3C1A7 >> ((self.raw & 0xF) * 2)) & 1)
+
+    @property
+    def is_reference_consuming(self):
+        return bool((0x3C1A7 >> ((self.raw & 0xF) * 2)) & 2)
+
+    def __repr__(self):
+        return f"{self.length}{self.type}"
+
+
+class PileupRead:
+    """pileup.d:86-230 over one bgp_entry + the decoded record."""
+    __slots__ = ("_col", "_e")
+
+    def __init__(self, col, e):
+        self._col, self._e = col, e
+
+    @property
+    def _rec(self):
+        return self._col._records.rec[int(self._e["read_ordinal"])]
+
+    def _cig(self):
+        r = self._col._records
+        i = int(self._e["read_ordinal"])
+        return r.cigar[int(r.cigar_off[i]):int(r.cigar_off[i + 1])]
+
+    read_ordinal = property(lambda s: int(s._e["read_ordinal"]))
+    cigar_operation_offset = property(lambda s: int(s._e["cigar_op_offset"]))
+    query_offset = property(lambda s: int(s._e["query_offset"]))
+    current_base = property(lambda s: chr(int(s._e["base"])))
+    current_base_quality = property(lambda s: int(s._e["qual"]))
+    cigar_operation = property(lambda s: CigarOperation(s._cig()[int(s._e["cigar_op_index"])]))
+    cigar_before = property(lambda s: [CigarOperation(x) for x in s._cig()[:int(s._e["cigar_op_index"])]])
+    cigar_after = property(lambda s: [CigarOperation(x) for x in s._cig()[int(s._e["cigar_op_index"]) + 1:]])
+    cigar = property(lambda s: [CigarOperation(x) for x in s._cig()])
+    ref_id = property(lambda s: int(s._rec["ref_id"]))
+    position = property(lambda s: int(s._rec["pos"]))
+    end_position = property(lambda s: int(s._rec["end_pos"]))
+    mapping_quality = property(lambda s: (int(s._rec["bin_mq_nl"]) >> 8) & 0xFF)
+    flag = property(lambda s: int(s._rec["flag_nc"]) >> 16)
+    is_reverse_strand = property(lambda s: bool(s.flag & 0x10))
+    is_unmapped = property(lambda s: bool(s.flag & 0x4))
+    sequence_length = property(lambda s: int(s._rec["l_seq"]))
+
+    @property
+    def sequence(self):
+        r = self._col._records
+        i = self.read_ordinal
+        return bytes(r.seq[int(r.seq_off[i]):int(r.seq_off[i + 1])]).decode("latin-1")
+
+    @property
+    def base_qualities(self):
+        r = self._col._records
+        i = self.read_ordinal
+        return r.qual[int(r.seq_off[i]):int(r.seq_off[i + 1])]
+
+    @property
+    def name(self):
+        data = self._col._data
+        if data is None:
+            raise AttributeError("read names need the host copy of the record stream")
+        off = int(self._rec["rec_off"]) + 36
+        ln = int(self._rec["bin_mq_nl"]) & 0xFF
+        return data[off:off + ln - 1].decode("latin-1")
+
+
+class PileupColumn:
+    """pileup.d:236-290"""
+    __slots__ = ("ref_id", "position", "_c", "_entries", "_records", "_data", "reference_base")
+
+    def __init__(self, ref_id, position, c, entries, records, data):
+        self.ref_id, self.position, self._c, self._entries, self._records, self._data = ref_id, position, c, entries, records, data
+        self.reference_base = "N"            # pileup.d:245-249 default
+
+    coverage = property(lambda s: int(s._c["coverage"]))
+    n_starting_here = property(lambda s: int(s._c["n_starting_here"]))
+
+    @property
+    def reads(self) -> List[PileupRead]:
+        if self._entries is None:
+            raise AttributeError("column was produced without per-read entries (want_entries=False)")
+        return [PileupRead(self, e) for e in self._entries]
+
+    @property
+    def reads_starting_here(self):
+        r = self.reads
+        return r[len(r) - self.n_starting_here:]                # pileup.d:272-274
+
+    @property
+    def bases(self):
+        return bytes(self._entries["base"]).decode("latin-1")   # pileup.d:277-279
+
+    @property
+    def base_qualities(self):
+        return self._entries["qual"]                             # pileup.d:282-284
+
+    @property
+    def read_qualities(self):
+        return [r.mapping_quality for r in self.reads]           # pileup.d:287-289
+
+    @property
+    def counts(self):
+        c = self._c
+        return dict(A=int(c["a"]), C=int(c["c"]), G=int(c["g"]), T=int(c["t"]), other=int(c["other"]), deletion=int(c["del"]))
+
+
+class _Pileup:
+    """AbstractPileup (pileup.d:428-458): iterable of columns + start_position/end_position/ref_id."""
+
+    def __init__(self, reads, mode, use_md_tag, start_from, end_at, skip_zero_coverage, want_entries, window_positions):
+        self.reads = reads
+        self.start_position, self.end_position = start_from, end_at
+        self._args = (mode, use_md_tag, start_from, end_at, skip_zero_coverage, want_entries, window_positions)
+        self._ctx = reads._stage()
+        self.ref_id = -1
+
+    def windows(self) -> Iterator[Window]:
+        mode, use_md, s, e, skip, want, win = self._args
+        gen = self._ctx.pileup_windows(mode, use_md, s, e, skip, want, win)
+        first = True
+        for w in gen:
+            if first and mode == L.BGP_MAKE_PILEUP:
+                self.ref_id = self._ctx.pileup_ref_id()
+                first = False
+            yield w
+
+    def __iter__(self) -> Iterator[PileupColumn]:
+        mode, use_md, s, e, skip, want, win = self._args
+        records = None
+        if want:
+            records = self.reads.records or self.reads.decode()
+        for w in self.windows():
+            cols = w.columns
+            for k in range(len(cols)):
+                c = cols[k]
+                if skip and c["coverage"] == 0:          # PileupRange.popFront jumps over these, pileup.d:388-392
+                    continue
+                ents = w.entries[int(w.entry_off[k]):int(w.entry_off[k + 1])] if w.entries is not None else None
+                yield PileupColumn(w.ref_id, int(w.first_position) + k, c, ents, records, getattr(self.reads, "data", None))
+
+
+def makePileup(reads, use_md_tag=False, start_from=0, end_at=ULONG_MAX, skip_zero_coverage=True, *, want_entries=True, window_positions=0):
+    """pileup.d:683-694.  Only the first reference of `reads` is processed (pileup.d:490-494)."""
+    return _Pileup(reads, L.BGP_MAKE_PILEUP, use_md_tag, start_from, end_at, skip_zero_coverage, want_entries, window_positions)
+
+
+def pileupColumns(reads, use_md_tag=False, skip_zero_coverage=True, *, want_entries=True, window_positions=0):
+    """pileup.d:509-519."""
+    return _Pileup(reads, L.BGP_PILEUP_COLUMNS, use_md_tag, 0, ULONG_MAX, skip_zero_coverage, want_entries, window_positions)

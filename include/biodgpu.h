@@ -1,0 +1,213 @@
+/*
+ * biodgpu.h -- C ABI of libbiodgpu.so: BioD's BAM-record decode -> CIGAR walk -> pileup hot path on
+ * MI355X (gfx950).  This is the drop-in boundary a BioD maintainer binds with `extern (C)`, exactly
+ * the way BioD already binds zlib (bio/core/utils/zlib.d:6-245, linked with -L-lz, Makefile:10):
+ * plain pointers and sizes, int status codes turned into exceptions by the D caller
+ * (cf. bio/core/bgzf/block.d:162-185).  No C++/torch types cross this boundary.
+ *
+ * Every entry point names the reference interface (file:line in biod/BioD v0.2.4) it replaces.
+ * The D-side binding is shown in INTEGRATION.md; a C++ mirror of BioD's range API over this ABI is
+ * include/biodgpu_pileup.hpp.
+ *
+ * Threading (mirrors BioD: the consumer side of the path is single threaded, inflate runs on
+ * TaskPool workers -- bio/core/bgzf/inputstream.d:414-428): one bgp_ctx per (host thread, GPU);
+ * functions taking a ctx are not re-entrant.  Ownership (mirrors bio/std/hts/bam/pileup.d:396,
+ * 660-661 "storage is reused"): every pointer returned through an out-struct is owned by the ctx and
+ * stays valid until the next call that produces the same kind of result, or bgp_destroy.
+ *
+ * There is NO CPU fallback: without a usable gfx950 device bgp_init fails with BGP_EDEVICE.
+ */
+#ifndef BIODGPU_H
+#define BIODGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BGP_ABI_VERSION 1
+
+/* ---- status codes -------------------------------------------------------------------------- */
+enum {
+    BGP_OK = 0,
+    BGP_EINVAL = -1,    /* bad argument; malformed record (sections exceed block_size)              */
+    BGP_ETRUNC = -2,    /* record body runs past the data -- readExact, readrange.d:169              */
+    BGP_ECIGAR = -3,    /* cursor ran off the CIGAR -- assertCigarIndexIsValid, pileup.d:224-228     */
+    BGP_EDEVICE = -4,   /* HIP error / no gfx950 device                                              */
+    BGP_ENOMEM = -5,
+    BGP_ESTATE = -6,    /* call out of order (e.g. pileup before flush)                              */
+    BGP_EMD = -7,       /* MD tag missing/short (use_md_tag)                                         */
+    BGP_EUNSORTED = -8, /* reads not coordinate sorted -- precondition of makePileup, pileup.d:25-27 */
+    BGP_ESEQ = -9,      /* soft: a query offset ran past l_seq (RangeError in read.d:364-383);
+                           results are still produced, such bases counted as "other"                 */
+    BGP_EOF = 1         /* iteration finished                                                        */
+};
+
+typedef struct bgp_ctx bgp_ctx;
+
+const char* bgp_strerror(int status);
+int bgp_abi_version(void);
+/* Human-readable detail of the last failure on this ctx (or of the last HIP failure when ctx is NULL). */
+const char* bgp_last_error(bgp_ctx* ctx);
+
+/* Creates a context on HIP device `device`.  Replaces nothing in BioD (BioD has no device); plays
+ * the role of `new BamReader(fn, taskPool)` resource setup, bio/std/hts/bam/reader.d:127-138. */
+int bgp_init(int device, bgp_ctx** out);
+void bgp_destroy(bgp_ctx* ctx);
+/* Use a caller-owned hipStream_t for every launch (NULL = the ctx's own stream). */
+int bgp_set_stream(bgp_ctx* ctx, void* hip_stream);
+/* Number of reference sequences from the BAM header (tightens the record-boundary guesser; 0 = unknown). */
+int bgp_set_n_ref(bgp_ctx* ctx, int32_t n_ref);
+/* Drops all staged data and results; keeps allocations for reuse. */
+int bgp_reset(bgp_ctx* ctx);
+
+/* ---- staging: inflated record bytes ---------------------------------------------------------
+ * Replaces BgzfInputStream.readBlock feeding BamReadRange (inputstream.d:497-530, readrange.d:137-169):
+ * the caller hands over already-inflated BGZF payloads in file order, starting at the first record
+ * (after the BAM header, reader.d:121-123).  `coffset` is the block's compressed file offset (kept
+ * for virtual offsets, virtualoffset.d:29-59).  `first_record_uoffset` is a hint: offset inside this
+ * block of the first record that STARTS in it, or BGP_UOFFSET_UNKNOWN.  The hint is never trusted --
+ * record boundaries are verified on the device -- it only saves guessing work. */
+#define BGP_UOFFSET_UNKNOWN 0xFFFFFFFFu
+int bgp_push_inflated(bgp_ctx* ctx, const uint8_t* data, size_t len, uint64_t coffset, uint32_t first_record_uoffset);
+/* Zero-copy variant: the record stream is already resident in HBM (device pointer, caller keeps it
+ * alive until bgp_reset/bgp_destroy). */
+int bgp_attach_device_stream(bgp_ctx* ctx, const void* device_ptr, uint64_t len);
+
+/* Convenience file path: BGZF inflate on host worker threads (the TaskPool analogue,
+ * inputstream.d:386-483, block.d:127-216), BAM magic + header + reference table
+ * (reader.d:111-116,579-597), then pushes every record block.  n_threads <= 0: all cores. */
+int bgp_load_bam(bgp_ctx* ctx, const char* path, int n_threads);
+int bgp_n_ref(bgp_ctx* ctx, int32_t* n_ref);
+int bgp_ref_info(bgp_ctx* ctx, int32_t ref_id, const char** name, int32_t* length);   /* referenceinfo.d */
+
+/* ---- decode -----------------------------------------------------------------------------------
+ * bgp_flush = kernels K0+K1: record framing (readrange.d:118-173) and the fixed fields / offsets /
+ * end_position of every record (read.d:907-1003, 255-262, 1380-1383). */
+typedef struct bgp_record {      /* 32 bytes per record, SURVEY.md 8(a2) */
+    int32_t ref_id;              /* read.d:907  _refID                              */
+    int32_t pos;                 /* read.d:911  _pos                                */
+    int32_t end_pos;             /* read.d:1382 position + basesCovered()           */
+    uint32_t bin_mq_nl;          /* read.d:915  bin<<16 | mapq<<8 | l_read_name     */
+    uint32_t flag_nc;            /* read.d:919  flag<<16 | n_cigar_op               */
+    int32_t l_seq;               /* read.d:923                                      */
+    uint64_t rec_off;            /* offset of the record's block_size prefix in the stream */
+} bgp_record;
+
+int bgp_flush(bgp_ctx* ctx);
+int bgp_num_records(bgp_ctx* ctx, uint64_t* n);
+
+typedef struct bgp_records {
+    uint64_t n;
+    const bgp_record* rec;       /* n                                                            */
+    const uint64_t* seq_off;     /* n+1: exclusive prefix sum of l_seq      (seq and qual arenas) */
+    const uint64_t* cigar_off;   /* n+1: exclusive prefix sum of n_cigar_op                      */
+    const uint8_t* seq;          /* BamRead.sequence as chars, read.d:364-383,438-440, base.d:85 */
+    const uint8_t* qual;         /* BamRead.base_qualities, read.d:468-470                       */
+    const uint32_t* cigar;       /* BamRead.cigar raw ops, read.d:225-228                        */
+    const uint8_t* stream;       /* host copy of the raw record stream (names, tags), or NULL    */
+    uint64_t stream_len;
+} bgp_records;
+
+#define BGP_FETCH_SEQ 1u
+#define BGP_FETCH_QUAL 2u
+#define BGP_FETCH_CIGAR 4u
+#define BGP_FETCH_ALL 7u
+/* Kernel K2 (4-bit seq -> chars, qual copy, CIGAR copy) + copy to host memory owned by the ctx. */
+int bgp_decode_fetch(bgp_ctx* ctx, uint32_t what, bgp_records* out);
+/* Same products left in HBM (device pointers); nothing is copied to the host. */
+int bgp_decode_device(bgp_ctx* ctx, uint32_t what, bgp_records* out_device);
+
+/* ---- pileup -------------------------------------------------------------------------------- */
+typedef struct bgp_column {      /* per reference position, 32 bytes (SURVEY.md 8 a-out summary) */
+    uint32_t coverage;           /* PileupColumn.coverage, pileup.d:252                          */
+    uint32_t n_starting_here;    /* _n_starting_here, pileup.d:241,272-274                       */
+    uint32_t a, c, g, t;         /* counts of current_base (pileup.d:115-122) over the column     */
+    uint32_t other;              /* any other M/=/X base (N, IUPAC, '=')                          */
+    uint32_t del;                /* '-' : current op is D or N                                    */
+} bgp_column;
+
+typedef struct bgp_entry {       /* one (read, column) pair, 16 bytes (SURVEY.md 8 a-out entries) */
+    uint32_t read_ordinal;       /* index of the record in the stream                             */
+    uint32_t cigar_op_offset;    /* PileupRead.cigar_operation_offset, pileup.d:99                */
+    uint32_t query_offset;       /* PileupRead.query_offset, pileup.d:146                         */
+    uint16_t cigar_op_index;     /* index of cigar_operation; cigar_before/after split, pileup.d:104-111 */
+    uint8_t base;                /* current_base, pileup.d:115-122                                */
+    uint8_t qual;                /* current_base_quality, pileup.d:127-134                        */
+} bgp_entry;
+
+typedef struct bgp_run {         /* one reference's worth of columns (a "run" of the sweep)       */
+    int32_t ref_id;
+    uint32_t _pad;
+    uint64_t first_record, end_record;  /* record index range holding the run's reads            */
+    uint64_t start_pos, end_pos;        /* columns exist for start_pos <= position < end_pos      */
+    uint64_t column_base;               /* index of start_pos in the dense column array           */
+} bgp_run;
+
+typedef struct bgp_pileup_info {
+    uint32_t n_runs;
+    const bgp_run* runs;         /* host, ctx owned                                              */
+    uint64_t n_positions;        /* dense positions over all runs                                */
+    uint64_t n_columns;          /* positions with coverage > 0 (= columns BioD yields with skip_zero_coverage) */
+    uint64_t sum_coverage;
+    uint32_t max_coverage;
+    int32_t soft_status;         /* BGP_OK or BGP_ESEQ                                           */
+    uint64_t n_reads_used;       /* reads with basesCovered() > 0, pileup.d:481,510              */
+    const bgp_column* device_columns; /* dense array in HBM, n_positions entries                 */
+    const uint64_t* device_depth_hist; /* HBM, BGP_DEPTH_BINS bins: #positions with coverage d (clipped) */
+} bgp_pileup_info;
+#define BGP_DEPTH_BINS 65536
+
+/* Kernels K3+K4 over every staged read: the whole-stream equivalent of
+ * pileupColumns(reads, false, skip_zero_coverage) (pileup.d:509-519).  Requires bgp_flush. */
+int bgp_pileup_run(bgp_ctx* ctx, bgp_pileup_info* info);
+
+/* Column iteration with BioD's argument lists.
+ *   mode BGP_MAKE_PILEUP    = makePileup(reads, use_md_tag, start_from, end_at, skip_zero_coverage), pileup.d:683-694
+ *   mode BGP_PILEUP_COLUMNS = pileupColumns(reads, use_md_tag, skip_zero_coverage),                   pileup.d:509-519
+ * next_window hands out consecutive dense windows (zero-coverage positions included -- the D/C++
+ * facade skips them when skip_zero_coverage is set, exactly the columns PileupRange.popFront
+ * pileup.d:345-397 would have yielded). */
+#define BGP_PILEUP_COLUMNS 0
+#define BGP_MAKE_PILEUP 1
+typedef struct bgp_columns {
+    int32_t ref_id;
+    uint32_t n_positions;
+    uint64_t first_position;
+    const bgp_column* columns;   /* host, n_positions                                             */
+    const uint64_t* entry_off;   /* host, n_positions+1, or NULL when entries were not requested  */
+    const bgp_entry* entries;    /* host, reads of column k: entries[entry_off[k] .. entry_off[k+1]) in file order */
+    const uint8_t* reference_base; /* host, n_positions (use_md_tag) or NULL                      */
+} bgp_columns;
+int bgp_pileup_begin(bgp_ctx* ctx, int mode, int use_md_tag, uint64_t start_from, uint64_t end_at,
+                     int skip_zero_coverage, int want_entries, uint32_t window_positions);
+int bgp_pileup_next_window(bgp_ctx* ctx, bgp_columns* out);   /* BGP_OK, BGP_EOF, or error */
+int bgp_pileup_ref_id(bgp_ctx* ctx, int32_t* ref_id);          /* AbstractPileup.ref_id, pileup.d:455 */
+
+/* Whole-BAM histogram reduce across ranks (the only collective of the path): sums `n` uint64
+ * values in HBM over all ranks of an RCCL communicator (ncclComm_t passed as void*).
+ * CPU equivalent: a fold over column.coverage (pileup.d:252). */
+int bgp_hist_reduce(bgp_ctx* ctx, void* rccl_comm, uint64_t* device_hist, size_t n);
+
+/* ---- timing hooks for bench.py (HIP events on the ctx's stream) ---------------------------- */
+typedef struct bgp_kernel_time { const char* name; double total_ms; uint64_t launches; uint64_t algorithmic_bytes; } bgp_kernel_time;
+int bgp_timing_enable(bgp_ctx* ctx, int on);
+int bgp_timing_reset(bgp_ctx* ctx);
+int bgp_timing_get(bgp_ctx* ctx, const bgp_kernel_time** out, uint32_t* n);
+
+/* ---- synthetic input generator (bench/test support) ------------------------- */
+typedef struct bgp_synth_cfg_c {
+    uint64_t seed, n_reads;
+    uint32_t n_ref, ref_len, len_min, len_max, profile, first_ref;
+} bgp_synth_cfg_c;
+/* Host generation of records [first, first+count) of a configuration.  out == NULL: size query. */
+int bgp_synth_host(const bgp_synth_cfg_c* cfg, uint64_t first, uint64_t count, uint8_t* out, uint64_t cap, uint64_t* bytes);
+/* Device generation of the whole configuration straight into HBM; the stream is attached to ctx. */
+int bgp_synth_device(bgp_ctx* ctx, const bgp_synth_cfg_c* cfg, uint64_t* bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,339 @@
+"""Parity tests proper: the HIP path (through the C ABI) against the CPU oracle, bit for bit.
+Run on the GPU box with `pytest -m gpu`."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from biod_amd import _lib as L
+from biod_amd import bamio
+from biod_amd.pileup import BamReader, Context, RecordStream, makePileup, pileupColumns
+from biod_amd.synth import host_stream, host_stream_np, make_cfg, scaled
+
+pytestmark = pytest.mark.gpu
+
+FIXTURES = ["ex1_header.bam", "illu_20_chunk.bam", "ion_20_chunk.bam", "b7_295_chunk.bam", "mg1655_chunk.bam", "tags.bam", "bins.bam"]
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = Context(0)
+    yield c
+    c.close()
+
+
+def stage(ctx, st, n_ref=0):
+    ctx.reset()
+    if n_ref:
+        ctx.set_n_ref(n_ref)
+    ctx.push_inflated(st)
+    ctx.flush()
+    return ctx
+
+
+def dense_from_oracle(ora, runs, skip_zero=True):
+    """Oracle columns scattered into the dense per-run layout the device produces."""
+    n_pos = int(sum(int(r["end_pos"]) - int(r["start_pos"]) for r in runs))
+    dense = np.zeros(n_pos, L.COLUMN_DTYPE)
+    base = {int(r["ref_id"]): (int(r["column_base"]), int(r["start_pos"])) for r in runs}
+    idx = np.array([base[int(r)][0] - base[int(r)][1] for r in ora.ref], dtype=np.int64) + ora.pos.astype(np.int64)
+    dense["coverage"][idx] = ora.cov
+    dense["n_starting_here"][idx] = ora.nstart
+    for j, f in enumerate(("a", "c", "g", "t", "other", "del")):
+        dense[f][idx] = ora.counts[:, j]
+    return dense
+
+
+def device_columns(ctx, info):
+    """Copy the dense column array out of HBM through the window iterator."""
+    out = []
+    for w in ctx.pileup_windows(L.BGP_PILEUP_COLUMNS, skip_zero_coverage=False, window_positions=1 << 20):
+        out.append(w.columns)
+    return np.concatenate(out) if out else np.zeros(0, L.COLUMN_DTYPE)
+
+
+def check_decode(ctx, st):
+    dec = ctx.decode_fetch()
+    soa = O.decode_soa(st)
+    assert len(dec) == len(soa.rec_off)
+    assert np.array_equal(dec.rec["rec_off"], soa.rec_off)
+    for f in ("ref_id", "pos", "end_pos", "bin_mq_nl", "flag_nc", "l_seq"):
+        assert np.array_equal(dec.rec[f], getattr(soa, f)), f
+    assert np.array_equal(dec.seq_off, soa.seq_off) and np.array_equal(dec.cigar_off, soa.cigar_off)
+    assert np.array_equal(dec.seq, soa.seq), "seq"
+    assert np.array_equal(dec.qual, soa.qual), "qual"
+    assert np.array_equal(dec.cigar, soa.cigar), "cigar"
+    return dec, soa
+
+
+def check_pileup(ctx, st, entries=True, window=4096):
+    info = ctx.pileup_run()
+    ora = O.pileup(st, want_entries=entries)
+    assert info.soft_status == (L.BGP_ESEQ if ora.status == O.ORC_ESEQ else 0)
+    assert (info.n_columns, info.sum_coverage, info.max_coverage) == (ora.n_columns, ora.sum_coverage, ora.max_coverage)
+    dense = device_columns(ctx, info)
+    exp = dense_from_oracle(ora, info.runs)
+    assert len(dense) == len(exp) == info.n_positions
+    for f in L.COLUMN_DTYPE.names:
+        assert np.array_equal(dense[f], exp[f]), f
+    assert (dense["coverage"] == dense["a"] + dense["c"] + dense["g"] + dense["t"] + dense["other"] + dense["del"]).all()
+    assert int(dense["n_starting_here"].sum()) == info.n_reads_used
+    if entries:
+        k = 0
+        for w in ctx.pileup_windows(L.BGP_PILEUP_COLUMNS, want_entries=True, window_positions=window):
+            nz = np.nonzero(w.columns["coverage"])[0]
+            for j in nz:
+                e = w.entries[int(w.entry_off[j]):int(w.entry_off[j + 1])]
+                oe = ora.entries[int(ora.entry_off[k]):int(ora.entry_off[k + 1])]
+                assert int(ora.pos[k]) == w.first_position + j and int(ora.ref[k]) == w.ref_id
+                assert np.array_equal(e["read_ordinal"], oe["read_ordinal"].astype(np.uint32)), (k, "ordinal")
+                assert np.array_equal(e["cigar_op_index"], oe["cigar_op_index"].astype(np.uint16)), (k, "op index")
+                assert np.array_equal(e["cigar_op_offset"], oe["cigar_op_offset"]), (k, "op offset")
+                assert np.array_equal(e["query_offset"], oe["query_offset"]), (k, "query offset")
+                assert np.array_equal(e["base"], oe["base"]) and np.array_equal(e["qual"], oe["qual"]), (k, "base/qual")
+                k += 1
+        assert k == ora.n_columns
+    return info, ora
+
+
+# ------------------------------------------------------------------------------------------ fixtures of the reference
+
+@pytest.mark.parametrize("name", FIXTURES)
+def test_fixture_decode_parity(ctx, data_dir, name):
+    hdr, st = bamio.read_bam(os.path.join(data_dir, name))
+    stage(ctx, st, len(hdr.refs))
+    check_decode(ctx, st)
+
+
+@pytest.mark.parametrize("name", [f for f in FIXTURES if f != "bins.bam"])
+def test_fixture_pileup_parity(ctx, data_dir, name):
+    hdr, st = bamio.read_bam(os.path.join(data_dir, name))
+    stage(ctx, st, len(hdr.refs))
+    check_pileup(ctx, st, entries=True)
+
+
+def test_bins_bam_coverage_parity(ctx, data_dir):
+    """Reads with CIGARs but empty SEQ: BioD would throw on current_base; coverage is still defined."""
+    hdr, st = bamio.read_bam(os.path.join(data_dir, "bins.bam"))
+    stage(ctx, st, len(hdr.refs))
+    info, ora = check_pileup(ctx, st, entries=False)
+    assert info.soft_status == L.BGP_ESEQ and info.n_columns == 1114626
+
+
+def test_load_bam_matches_python_inflate(ctx, data_dir):
+    path = os.path.join(data_dir, "mg1655_chunk.bam")       # has records spanning BGZF blocks
+    hdr, st = bamio.read_bam(path)
+    ctx.reset()
+    ctx.load_bam(path, 3)
+    assert ctx.references() == hdr.refs
+    ctx.flush()
+    check_decode(ctx, st)
+
+
+@pytest.mark.parametrize("name", ["corrupted_zlib_archive.bam", "duplicated_block_size.bam", "no_block_size.bam",
+                                  "wrong_bc_subfield_length.bam", "wrong_extra_gzip_length.bam"])
+def test_Z1_negative_bgzf_through_abi(ctx, data_dir, name):
+    ctx.reset()
+    with pytest.raises(L.BiodGpuError):
+        ctx.load_bam(os.path.join(data_dir, name), 2)
+
+
+# ------------------------------------------------------------------------------------------ KATs through the reference-shaped API
+
+def test_P1_through_api(ctx):
+    from test_oracle_kats import P1_CIGARS, p1_stream
+    st = p1_stream()
+    reads = RecordStream(st, ctx)
+    pile = makePileup(reads, False, 796, 849, False)
+    cols = list(pile)
+    assert cols[0].position == 796 and cols[-1].position == 848 and pile.ref_id == 0
+    by_pos = {c.position: c for c in cols}
+    assert by_pos[796].bases == "CCCCCCAC" and by_pos[805].bases == "TCCCCCCCC" and by_pos[806].bases == "AAAAAAAGA"
+    assert by_pos[821].bases == "AAGG-AA" and by_pos[826].bases == "CCCCCC"
+    c = by_pos[810]; assert c.reads[c.coverage - 2].cigar_after[0].type == "D"
+    c = by_pos[817]; assert c.reads[c.coverage - 2].cigar_before[-1].type == "I"
+    c = by_pos[821]; assert c.reads[c.coverage - 3].cigar_operation.type == "D" and c.reads[c.coverage - 3].current_base_quality == 255
+    full = {c.position: c for c in makePileup(RecordStream(st, ctx), False, 0, (1 << 64) - 1, False)}
+    assert len(full) == 113 and full[849].bases == "TAT"
+    assert all(by_pos[p].coverage == full[p].coverage for p in by_pos)
+    assert [r.name for r in full[758].reads] == ["r0"]
+
+
+def test_P3_P4_through_api(ctx, data_dir):
+    bam = BamReader(os.path.join(data_dir, "ex1_header.bam"), ctx=ctx)
+    assert [n for n, _ in bam.reference_sequences] == ["chr1", "chr2"]
+    cols = list(pileupColumns(bam.reads, want_entries=False))
+    refs = np.array([c.ref_id for c in cols])
+    assert int((refs == 0).sum()) == 1470 and int((refs == 1).sum()) == 1567 and (np.diff(refs) >= 0).all()
+    assert cols[0].position == 99 and cols[1470].position == 0
+    only = list(makePileup(bam.reads, want_entries=False))
+    assert len(only) == 1470 and all(c.ref_id == 0 for c in only)
+
+
+def test_P5_reads_starting_here(ctx, data_dir):
+    _, st = bamio.read_bam(os.path.join(data_dir, "illu_20_chunk.bam"))
+    starting = []
+    for col in makePileup(RecordStream(st, ctx)):
+        starting += [r.read_ordinal for r in col.reads_starting_here]
+    assert starting == list(range(29))
+
+
+def test_make_pileup_clipping_matches_oracle(ctx, data_dir):
+    _, st = bamio.read_bam(os.path.join(data_dir, "ex1_header.bam"))
+    for (a, b, skip) in [(0, (1 << 64) - 1, True), (500, 700, True), (500, 700, False), (1569, 5000, True), (1600, 1700, False), (3000, 4000, True)]:
+        ora = O.pileup(st, O.MODE_MAKE_PILEUP, start_from=a, end_at=b, skip_zero=skip)
+        pile = makePileup(RecordStream(st, ctx), False, a, b, skip, want_entries=False)
+        cols = list(pile)
+        assert [c.position for c in cols] == [int(p) for p in ora.pos], (a, b, skip)
+        assert [c.coverage for c in cols] == [int(c) for c in ora.cov]
+        assert [c.ref_id for c in cols] == [int(r) for r in ora.ref]
+
+
+def test_zero_coverage_gaps(ctx):
+    recs = [bamio.pack_record("a", "ACGTACGTAC", [(10, "M")], ref_id=0, pos=10), bamio.pack_record("b", "ACGTACGTAC", [(10, "M")], ref_id=0, pos=100),
+            bamio.pack_record("c", "ACGTA", [(5, "M")], ref_id=2, pos=7)]
+    st = b"".join(recs)
+    for skip in (True, False):
+        ora = O.pileup(st, O.MODE_PILEUP_COLUMNS, skip_zero=skip)
+        cols = list(pileupColumns(RecordStream(st, ctx), False, skip, want_entries=False))
+        assert [(c.ref_id, c.position, c.coverage) for c in cols] == [(int(r), int(p), int(c)) for r, p, c in zip(ora.ref, ora.pos, ora.cov)]
+    ora = O.pileup(st, O.MODE_MAKE_PILEUP, start_from=50, skip_zero=False)      # sweep starts at the first surviving read
+    cols = list(makePileup(RecordStream(st, ctx), False, 50, (1 << 64) - 1, False, want_entries=False))
+    assert [c.position for c in cols] == [int(p) for p in ora.pos] == list(range(100, 110))
+
+
+# ------------------------------------------------------------------------------------------ edge cases of the record format
+
+def test_empty_and_ragged_streams(ctx):
+    rec = bamio.pack_record("r", "ACGT", [(4, "M")], ref_id=0, pos=5)
+    for st, n in [(b"", 0), (b"\x01\x02", 0), (rec, 1), (rec + b"\x07", 1), (rec + rec + b"\x00\x00\x00", 2)]:
+        stage(ctx, st)
+        assert ctx.num_records() == n
+        info = ctx.pileup_run()
+        assert info.n_columns == 4 * (n > 0)
+    with pytest.raises(L.BiodGpuError) as e:
+        stage(ctx, rec + rec[:-1])
+    assert e.value.code == L.BGP_ETRUNC
+    bad = bytearray(rec); bad[0:4] = (0xFFFFFFF0).to_bytes(4, "little")
+    with pytest.raises(L.BiodGpuError) as e:
+        stage(ctx, bytes(bad))
+    assert e.value.code == L.BGP_EINVAL
+    bad = bytearray(rec); bad[20:24] = (5000).to_bytes(4, "little")       # l_seq larger than the record
+    with pytest.raises(L.BiodGpuError) as e:
+        stage(ctx, bytes(bad) + rec)
+    assert e.value.code == L.BGP_EINVAL
+
+
+def test_error_statuses_match_oracle(ctx):
+    lead_n = bamio.pack_record("r", "ACGTACGTAC", [(5, "N"), (10, "M")], ref_id=0, pos=10)
+    stage(ctx, lead_n)
+    with pytest.raises(L.BiodGpuError) as e:
+        ctx.pileup_run()
+    assert e.value.code == L.BGP_ECIGAR
+    a = bamio.pack_record("a", "ACGT", [(4, "M")], ref_id=0, pos=50)
+    b = bamio.pack_record("b", "ACGT", [(4, "M")], ref_id=0, pos=10)
+    stage(ctx, a + b)
+    with pytest.raises(L.BiodGpuError) as e:
+        ctx.pileup_run()
+    assert e.value.code == L.BGP_EUNSORTED
+
+
+def test_odd_cigars(ctx):
+    """Zero-length ops, P/H, =/X, trailing soft clips, unmapped reads in the middle, reads that are all clip."""
+    recs = [
+        bamio.pack_record("z0", "ACGTACGT", [(2, "S"), (0, "M"), (3, "M"), (0, "D"), (2, "I"), (1, "M")], ref_id=0, pos=3),
+        bamio.pack_record("z1", "ACGTAC", [(1, "H"), (2, "="), (1, "P"), (2, "X"), (3, "D"), (2, "M"), (4, "H")], ref_id=0, pos=3),
+        bamio.pack_record("un", "ACGT", [(4, "M")], ref_id=0, pos=4, flag=4),
+        bamio.pack_record("cl", "ACGT", [(4, "S")], ref_id=0, pos=5),
+        bamio.pack_record("z2", "NNRYACGT", [(8, "M")], ref_id=0, pos=6),
+        bamio.pack_record("z3", "ACG", [(1, "M"), (7, "N"), (2, "M")], ref_id=1, pos=0),
+    ]
+    st = b"".join(recs)
+    stage(ctx, st)
+    check_decode(ctx, st)
+    check_pileup(ctx, st, entries=True, window=3)
+
+
+# ------------------------------------------------------------------------------------------ synthetic configurations
+
+@pytest.mark.parametrize("profile,read_len,n_reads,ref_len", [(0, 150, 20000, 120_000), (1, 150, 20000, 150_000), (1, 100, 10000, 50_000),
+                                                              (2, (2000, 9000), 600, 400_000)])
+def test_synthetic_parity(ctx, profile, read_len, n_reads, ref_len):
+    cfg = make_cfg(n_reads=n_reads, n_ref=2, ref_len=ref_len, read_len=read_len, profile=profile, seed=100 + profile)
+    st = host_stream(cfg)
+    ctx.reset()
+    nbytes = ctx.synth_device(cfg)                      # generated by the gfx950 kernel straight into HBM
+    assert nbytes == len(st)
+    ctx.flush()
+    dec, soa = check_decode(ctx, st)                    # also proves device bytes == host bytes for every decoded field
+    check_pileup(ctx, st, entries=(profile != 2), window=8192)
+    if profile == 2:                                    # long reads: entries on a few windows only
+        ora = O.pileup(st, want_entries=True)
+        it = ctx.pileup_windows(L.BGP_PILEUP_COLUMNS, want_entries=True, window_positions=2000)
+        k = 0
+        for wi, w in enumerate(it):
+            nz = np.nonzero(w.columns["coverage"])[0]
+            if wi % 37 == 0:
+                for jj, j in enumerate(nz):
+                    e = w.entries[int(w.entry_off[j]):int(w.entry_off[j + 1])]
+                    oe = ora.entries[int(ora.entry_off[k + jj]):int(ora.entry_off[k + jj + 1])]
+                    assert np.array_equal(e["read_ordinal"], oe["read_ordinal"].astype(np.uint32))
+                    assert np.array_equal(e["query_offset"], oe["query_offset"]) and np.array_equal(e["base"], oe["base"])
+                    assert np.array_equal(e["cigar_op_index"], oe["cigar_op_index"].astype(np.uint16)) and np.array_equal(e["qual"], oe["qual"])
+            k += len(nz)
+
+
+def test_device_stream_bytes_equal_host(ctx):
+    import torch
+    cfg = make_cfg(n_reads=5000, n_ref=2, ref_len=60_000, read_len=150, profile=1, seed=5)
+    host = host_stream_np(cfg)
+    ctx.reset()
+    n = ctx.synth_device(cfg)
+    ctx.flush()
+    r = ctx.decode_device(0)
+    dev = torch.empty(n, dtype=torch.uint8, device="cuda:0")
+    hip = C.CDLL("libamdhip64.so")
+    assert hip.hipMemcpy(C.c_void_p(dev.data_ptr()), C.c_void_p(r.stream), C.c_size_t(n), 3) == 0
+    assert np.array_equal(dev.cpu().numpy(), host)
+
+
+def test_attach_torch_tensor(ctx):
+    """Caller-owned HBM: a torch uint8 tensor handed over by pointer (zero copy)."""
+    import torch
+    cfg = make_cfg(n_reads=3000, n_ref=1, ref_len=40_000, read_len=150, profile=1, seed=9)
+    host = host_stream_np(cfg)
+    t = torch.from_numpy(host).to("cuda:0")
+    torch.cuda.synchronize()
+    ctx.reset()
+    ctx.attach_device_stream(t.data_ptr(), t.numel(), keepalive=t)
+    ctx.flush()
+    check_decode(ctx, host.tobytes())
+    check_pileup(ctx, host.tobytes(), entries=False)
+
+
+def test_scale_properties(ctx):
+    """Size-independent properties at a size the oracle would take minutes for: 2 M reads of cfg3's model."""
+    cfg = scaled("cfg3", 2_000_000)
+    ctx.reset()
+    ctx.synth_device(cfg)
+    ctx.flush()
+    assert ctx.num_records() == 2_000_000
+    info = ctx.pileup_run()
+    dec = ctx.decode_fetch(0)
+    covered = (dec.rec["end_pos"] - dec.rec["pos"]).astype(np.int64)
+    assert info.n_reads_used == int((covered > 0).sum()) == 2_000_000
+    assert info.sum_coverage == int(covered.sum())                       # every read contributes basesCovered entries
+    assert (np.diff(dec.rec["ref_id"].astype(np.int64) << 32 | dec.rec["pos"]) >= 0).all()
+    n_start, cov_sum, classes = 0, 0, 0
+    for w in ctx.pileup_windows(L.BGP_PILEUP_COLUMNS, skip_zero_coverage=False, window_positions=1 << 22):
+        c = w.columns
+        n_start += int(c["n_starting_here"].sum()); cov_sum += int(c["coverage"].sum())
+        classes += int((c["a"].astype(np.int64) + c["c"] + c["g"] + c["t"] + c["other"] + c["del"]).sum())
+    assert n_start == 2_000_000 and cov_sum == classes == info.sum_coverage
+    # the oracle on a prefix shard (records are independent, so a prefix of the stream is a valid stream)
+    k = 20_000
+    st = host_stream(cfg, 0, k)
+    stage(ctx, st)
+    check_pileup(ctx, st, entries=False)
