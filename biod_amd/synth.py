@@ -33,13 +33,28 @@ def scaled(name: str, n_reads: int, first_ref: int = 0) -> L.SynthCfg:
     return make_cfg(first_ref=first_ref, **c)
 
 
-def host_stream_np(cfg: L.SynthCfg, first: int = 0, count: int | None = None) -> np.ndarray:
-    count = cfg.n_reads - first if count is None else count
+def _host_chunk(cfg: L.SynthCfg, first: int, count: int) -> np.ndarray:
     n = C.c_uint64()
     L.check(L.lib().bgp_synth_host(C.byref(cfg), first, count, None, 0, C.byref(n)))
     buf = np.zeros(n.value, np.uint8)
     L.check(L.lib().bgp_synth_host(C.byref(cfg), first, count, buf.ctypes.data, n.value, C.byref(n)))
     return buf
+
+
+def host_stream_np(cfg: L.SynthCfg, first: int = 0, count: int | None = None) -> np.ndarray:
+    """Records [first, first+count) generated on the host (threads over index ranges: records are
+    pure functions of their index, and ctypes releases the GIL)."""
+    count = cfg.n_reads - first if count is None else count
+    if count < 50_000:
+        return _host_chunk(cfg, first, count)
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    nt = min(os.cpu_count() or 1, 32)
+    step = (count + nt * 4 - 1) // (nt * 4)
+    parts = [(first + o, min(step, count - o)) for o in range(0, count, step)]
+    with ThreadPoolExecutor(nt) as ex:
+        bufs = list(ex.map(lambda p: _host_chunk(cfg, p[0], p[1]), parts))
+    return np.concatenate(bufs)
 
 
 def host_stream(cfg: L.SynthCfg, first: int = 0, count: int | None = None) -> bytes:
