@@ -49,6 +49,9 @@ def cpu_baseline(cfg_name, n_sample):
         n_probe = 20_000 if cfg_name != "cfg5" else 60
         t0 = time.perf_counter(); O.pileup_bench(probe, 1); dt = max(time.perf_counter() - t0, 1e-4)
         n_sample = int(min(max(20.0 / (dt / n_probe), n_probe), 3_000_000))      # ~20 CPU-seconds of pileup work
+        if cfg_name != "cfg5":
+            # every thread needs work: pileupChunks cuts 16 384 000-byte chunks (~56k reads); give each core two
+            n_sample = int(min(max(n_sample, cores * 2 * 56_000), 32_000_000))
     stream = host_stream_np(scaled(cfg_name, n_sample))
     t0 = time.perf_counter(); rs = O.pileup_bench(stream[: len(stream)], 1) if n_sample <= 400_000 else None; ts = time.perf_counter() - t0
     t0 = time.perf_counter(); rp = O.pileup_bench(stream, cores); tp = time.perf_counter() - t0

@@ -16,6 +16,7 @@
 // Exclusive scans of the per-segment counts give every segment its base record index and arena
 // offsets; k1_emit re-chases (L2-warm) and writes the 32-byte record table.
 #include "common.h"
+#include <cstdio>
 
 namespace {
 
@@ -24,7 +25,7 @@ constexpr uint64_t STOP = ~0ull - 1;    // chain is over (error upstream); segme
 
 struct FrameArgs {
     const uint8_t* s; uint64_t len; uint32_t seg_bytes; uint64_t n_seg; int32_t ref_bound;
-    uint64_t* entry; uint64_t* end; uint64_t* cnt; uint64_t* lseq; uint64_t* ncig; uint32_t* dirty; uint32_t* seg_err;
+    uint64_t* entry; uint64_t* fix; uint64_t* end; uint64_t* cnt; uint64_t* lseq; uint64_t* ncig; uint32_t* dirty; uint32_t* seg_err;
     uint32_t* status; /* [0] status bits, [1] dirty counter */
 };
 
@@ -73,7 +74,10 @@ __global__ __launch_bounds__(256) void k0_guess(FrameArgs a) {
 // one lane per segment
 __global__ __launch_bounds__(256) void k0_chase(FrameArgs a) {
     const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= a.n_seg || !a.dirty[k]) return;
+    if (k >= a.n_seg) return;
+    const uint32_t d = a.dirty[k];
+    if (!d) return;
+    if (d == 2) a.entry[k] = a.fix[k];                                     // repaired by k0_verify
     a.dirty[k] = 0;
     const uint64_t seg_end = min((k + 1) * (uint64_t)a.seg_bytes, a.len);
     uint64_t off = a.entry[k], cnt = 0, ls = 0, nc = 0;
@@ -96,16 +100,20 @@ __global__ __launch_bounds__(256) void k0_chase(FrameArgs a) {
     a.cnt[k] = cnt; a.lseq[k] = ls; a.ncig[k] = nc; a.seg_err[k] = err;
 }
 
+// A link k is consistent when entry[k] == end[k-1].  A broken link is repaired only when the
+// predecessor's own link is consistent: otherwise end[k-1] was chased from a wrong entry and would
+// overwrite a (probably correct) guess with garbage, which then ripples forward one segment per
+// round forever.  entry[] is never written here (fix[] is applied by the next k0_chase), so every
+// thread judges its neighbours from the same snapshot.
 __global__ __launch_bounds__(256) void k0_verify(FrameArgs a) {
     const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x + 1;
     if (k >= a.n_seg) return;
     const uint64_t prev_end = a.end[k - 1];
-    if (prev_end == NONE) return;                 // predecessor not resolved yet: keep the speculation
-    if (a.entry[k] != prev_end) {
-        a.entry[k] = prev_end;
-        a.dirty[k] = 1;
-        atomicAdd(&a.status[1], 1u);
-    }
+    if (a.entry[k] == prev_end) return;
+    if (k >= 2 && a.entry[k - 1] != a.end[k - 2]) return;
+    a.fix[k] = prev_end;
+    a.dirty[k] = 2;
+    atomicAdd(&a.status[1], 1u);
 }
 
 __global__ __launch_bounds__(256) void k0_collect_errors(FrameArgs a) {
@@ -188,7 +196,7 @@ int k0_frame(bgp_ctx* c) {
     const uint64_t n_seg = (len + seg - 1) / seg;
     c->n_seg = n_seg;
 
-    BGP_TRY(c->d_seg_entry.reserve((n_seg + 1) * 8)); BGP_TRY(c->d_seg_end.reserve((n_seg + 1) * 8));
+    BGP_TRY(c->d_seg_entry.reserve((n_seg + 1) * 16)); BGP_TRY(c->d_seg_end.reserve((n_seg + 1) * 8));
     BGP_TRY(c->d_seg_cnt.reserve((n_seg + 1) * 8)); BGP_TRY(c->d_seg_lseq.reserve((n_seg + 1) * 8)); BGP_TRY(c->d_seg_ncig.reserve((n_seg + 1) * 8));
     BGP_TRY(c->d_seg_dirty.reserve((n_seg + 1) * 8));          // dirty[n_seg] u32 followed by seg_err[n_seg] u32
     BGP_TRY(c->d_seg_rec_base.reserve((n_seg + 2) * 8)); BGP_TRY(c->d_seg_seq_base.reserve((n_seg + 2) * 8)); BGP_TRY(c->d_seg_cig_base.reserve((n_seg + 2) * 8));
@@ -196,7 +204,7 @@ int k0_frame(bgp_ctx* c) {
     FrameArgs a;
     a.s = c->d_stream; a.len = len; a.seg_bytes = seg; a.n_seg = n_seg;
     a.ref_bound = c->n_ref_hint > 0 ? c->n_ref_hint : (1 << 24);
-    a.entry = c->d_seg_entry.as<uint64_t>(); a.end = c->d_seg_end.as<uint64_t>();
+    a.entry = c->d_seg_entry.as<uint64_t>(); a.fix = a.entry + n_seg + 1; a.end = c->d_seg_end.as<uint64_t>();
     a.cnt = c->d_seg_cnt.as<uint64_t>(); a.lseq = c->d_seg_lseq.as<uint64_t>(); a.ncig = c->d_seg_ncig.as<uint64_t>();
     a.dirty = c->d_seg_dirty.as<uint32_t>(); a.seg_err = a.dirty + n_seg;
     a.status = c->d_status.as<uint32_t>();
@@ -218,6 +226,7 @@ int k0_frame(bgp_ctx* c) {
         uint32_t ndirty = 0;
         BGP_HIP(hipMemcpyAsync(&ndirty, a.status + 1, 4, hipMemcpyDeviceToHost, c->stream));
         BGP_HIP(hipStreamSynchronize(c->stream));
+        if (getenv("BGP_VERBOSE") && rounds < 8) fprintf(stderr, "[biodgpu] framing round %llu: %u of %llu segments re-entered (seg %u B)\n", (unsigned long long)rounds, ndirty, (unsigned long long)n_seg, seg);
         if (ndirty == 0) break;
         if (++rounds > n_seg + 2) { c->last_error = "record framing did not converge"; return BGP_EDEVICE; }
     }
