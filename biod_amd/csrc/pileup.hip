@@ -31,7 +31,7 @@ namespace {
 
 constexpr int W = 2048;                // reference positions per workgroup
 constexpr int HB = 1024;               // depth-histogram bins kept in LDS
-constexpr int K4_T = 256;
+constexpr int K4_T = 512;
 constexpr uint32_t MAX_RUNS = 1u << 16;
 
 __device__ __forceinline__ uint64_t ref_key(int32_t ref_id) { return ref_id < 0 ? 0x7FFFFFFFull : (uint64_t)(uint32_t)(ref_id + 1); }
@@ -82,7 +82,7 @@ __global__ void k3_run_ends(RunDev* runs, uint32_t n_runs, const uint64_t* pmax_
 
 struct K4Args {
     const uint8_t* s; const bgp_record* rec; const uint64_t* pmax_end; const uint64_t* pmax_pos;
-    const RunDev* runs; uint32_t n_runs; uint64_t n_tiles;
+    const RunDev* runs; uint32_t n_runs; uint64_t n_tiles; uint64_t stream_len;
     bgp_column* cols; unsigned long long* hist; unsigned long long* pstats; /* [0] n_columns [1] sum_cov [2] max_cov */
     uint32_t* status;
 };
@@ -96,91 +96,272 @@ __device__ __forceinline__ uint32_t base_class(uint32_t code) {   // nt16 code -
     return (uint32_t)(0x4444444344424104ull >> (code * 4)) & 0xFu;  // 1->0 2->1 4->2 8->3 else 4
 }
 
-// One read against one window, executed by a whole wave (all arguments wave-uniform).
-__device__ __forceinline__ void pile_read(const uint8_t* s, const bgp_record& r, uint32_t T0, uint32_t Tend, uint32_t* cnt /*LDS [7][W]*/, int lane, uint32_t* status) {
-    const uint32_t pos = (uint32_t)r.pos, covered = (uint32_t)r.end_pos - pos;
-    const uint32_t l_name = r.bin_mq_nl & 0xFFu, n_cig = r.flag_nc & 0xFFFFu;
-    const uint8_t* cg = s + r.rec_off + 36 + l_name;
-    const uint8_t* sq = cg + 4ull * n_cig;
-    if (pos >= T0 && lane == 0) atomicAdd(&cnt[6 * W + (pos - T0)], 1u);       // n_starting_here, pileup.d:386,422
-    // column offsets of this read that fall into the window
-    const uint32_t need_hi = min(covered, Tend - pos);                          // exclusive
+// ---- K4: per-position column summary ----------------------------------------------------------
+// LDS tile (u32 words): cnt[5][W] (A,C,G,T,other) | deld[W+4] ('-' as a difference array: +1 where a
+// D/N op starts, -1 where it ends, summed at flush) | nst[W] (n_starting_here) | hist[HB] | list[LCAP].
+//
+// Per window: (1) SCAN the candidate record range 512 at a time (one coalesced 16-byte read per lane),
+// count n_starting_here and compact the indices of the reads that really overlap the window into an
+// LDS list; (2) PROCESS the list 64 reads per wave with LANE = READ: a lane loads its read's whole
+// packed SEQ up front (five unaligned 16-byte loads, all in flight together -- this is what hides HBM
+// latency) and then every lane of the wave steps the same query index q, walking its own CIGAR with a
+// tiny state machine: an M/=/X base becomes one ds_add_u32 on cnt[class][position], an I/S base is
+// skipped, a D/N op is two adds on the difference array.  Reads that do not fit that mould (longer than
+// 160 bases, more than 4 CIGAR ops, zero-length or leading-N ops, CIGAR longer than SEQ) take the
+// wave-cooperative path below, which implements the closed form of pileup.d:175-222 in full generality
+// with lanes along the read.
+
+constexpr int DELD = 5 * W;            // word offsets inside the tile
+constexpr int NST = 6 * W + 4;
+constexpr int HIST = 7 * W + 4;
+constexpr int LIST = HIST + HB;
+constexpr int LCAP = 2048;
+constexpr int LDS_WORDS = LIST + LCAP;
+constexpr int FAST_LSEQ = 160;         // 20 dwords of packed SEQ per lane
+
+__device__ __forceinline__ uint32_t rl(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
+
+// packed SEQ dwords [w0, w0+64) of a read; lane i holds dword w0+i (bytes past the stream end read as 0)
+__device__ __forceinline__ uint32_t load_seq_words(const uint8_t* s, uint64_t stream_len, uint64_t seq_off, uint32_t n_bytes, uint32_t w0, int lane) {
+    const uint32_t b = (w0 + lane) * 4;
+    if (b >= n_bytes) return 0;
+    const uint64_t o = seq_off + b;
+    if (o + 4 <= stream_len) return ld_u32(s + o);
+    uint32_t v = 0;
+    for (uint32_t k = 0; k < 4 && o + k < stream_len; ++k) v |= (uint32_t)s[o + k] << (8 * k);
+    return v;
+}
+
+// General path: one read against the window, executed by a whole wave with lanes along the read.
+// All arguments are wave-uniform.
+__device__ __forceinline__ void pile_read_coop(const K4Args& a, uint32_t* lds, uint32_t T0, uint32_t Tend, int lane,
+                                               uint32_t pos, uint32_t covered, uint32_t n_cig, uint32_t l_seq, uint64_t cig_off) {
+    const uint64_t seq_off = cig_off + 4ull * n_cig;
+    const uint32_t seq_bytes = (l_seq + 1) / 2;
+    uint32_t win0 = 0;
+    uint32_t words = load_seq_words(a.s, a.stream_len, seq_off, seq_bytes, 0, lane);
+    const uint32_t need_hi = min(covered, Tend - pos);                    // column offsets [need_lo, need_hi) fall into the window
     const uint32_t need_lo = T0 > pos ? T0 - pos : 0;
-    uint32_t cs = 0, qs = 0;
+    uint32_t cs = 0, qs = 0, k = 0;
     bool started = false;
-    uint32_t k = 0;
     for (; k < n_cig && cs < need_hi; ++k) {
-        const uint32_t op = ld_u32(cg + 4 * k);
+        const uint32_t op = ld_u32(a.s + cig_off + 4ull * k);
         const uint32_t len = op >> 4, qc = cig_qc(op), rc = cig_rc(op);
-        if (!started) {                                                        // PileupRead ctor, pileup.d:180-189
+        if (!started) {                                                   // PileupRead ctor, pileup.d:180-189
             if (rc) { if ((op & 15u) != 3u) started = true; else continue; }
             else { if (qc) qs += len; continue; }
         }
-        if (!rc) { if (qc) qs += len; continue; }                              // pileup.d:215-217
-        const uint32_t elen = len ? len : 1u;                                  // pileup.d:196-203
+        if (!rc) { if (qc) qs += len; continue; }                         // pileup.d:215-217
+        const uint32_t elen = len ? len : 1u;                             // pileup.d:196-203
         const uint32_t lo = max(cs, need_lo), hi = min(cs + elen, need_hi);
-        if (qc) {                                                              // M, =, X : sequence[query_offset]
-            for (uint32_t rr = lo + lane; rr < hi; rr += 64) {
-                const uint32_t q = qs + (rr - cs);
-                uint32_t cls = 4;
-                if (q < (uint32_t)r.l_seq) {
-                    const uint32_t byte = sq[q >> 1];
-                    cls = base_class((q & 1u) ? (byte & 0xFu) : (byte >> 4));
-                } else atomicOr(status, ST_ESEQ);
-                atomicAdd(&cnt[cls * W + (pos + rr - T0)], 1u);
+        if (lo < hi) {
+            if (qc) {                                                     // M, =, X : sequence[query_offset], pileup.d:117-118
+                for (uint32_t r0 = lo; r0 < hi; r0 += 64) {
+                    const uint32_t qa = qs + (r0 - cs);                   // query offset of lane 0 in this step
+                    const uint32_t qb = qa + min(hi - r0, 64u) - 1;
+                    if ((qa >> 3) < win0 || (qb >> 3) >= win0 + 64) {     // slide the 512-base window
+                        win0 = qa >> 3;
+                        words = load_seq_words(a.s, a.stream_len, seq_off, seq_bytes, win0, lane);
+                    }
+                    const uint32_t q = qa + lane;
+                    const uint32_t wv = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((q >> 3) - win0) << 2), (int)words);
+                    if (r0 + lane < hi) {
+                        uint32_t cls = 4;
+                        if (q < l_seq) {
+                            const uint32_t byte = (wv >> (((q >> 1) & 3u) * 8)) & 0xFFu;
+                            cls = base_class((q & 1u) ? (byte & 0xFu) : (byte >> 4));   // read.d:368-373
+                        } else atomicOr(a.status, ST_ESEQ);
+                        atomicAdd(&lds[cls * W + (pos + r0 + lane - T0)], 1u);
+                    }
+                }
+            } else if (lane == 0) {                                       // D, N : '-' over [lo, hi), pileup.d:119-121
+                atomicAdd(&lds[DELD + (pos + lo - T0)], 1u);
+                atomicAdd(&lds[DELD + (pos + hi - T0)], 0xFFFFFFFFu);
             }
-            qs += elen;
-        } else {                                                               // D, N : '-'
-            for (uint32_t rr = lo + lane; rr < hi; rr += 64) atomicAdd(&cnt[5 * W + (pos + rr - T0)], 1u);
         }
+        if (qc) qs += elen;
         cs += elen;
     }
-    if (k == n_cig && cs < need_hi && lane == 0) atomicOr(status, ST_ECIGAR);   // assertCigarIndexIsValid, pileup.d:224-228
+    if (k == n_cig && cs < need_hi && lane == 0) atomicOr(a.status, ST_ECIGAR);   // assertCigarIndexIsValid, pileup.d:224-228
 }
 
 __global__ __launch_bounds__(K4_T) void k4_tile(K4Args a) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];             // cnt[7][W] then hist[HB]
-    uint32_t* cnt = lds;
-    uint32_t* hist = lds + 7 * W;
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    __shared__ uint32_t s_n;           // entries in the LDS list
+    __shared__ uint32_t wsum[K4_T / 64];
     // XCD-aware order: consecutive tiles of a reference go to the same XCD (block b runs on XCD b % 8)
     const uint64_t nb = a.n_tiles;
     const uint64_t per = (nb + 7) / 8;
     uint64_t tile = (blockIdx.x % 8) * per + blockIdx.x / 8;
     if (nb < 64) tile = blockIdx.x;
     if (tile >= nb) return;
-    // run of this tile
     uint32_t lo_r = 0, hi_r = a.n_runs;
     while (hi_r - lo_r > 1) { const uint32_t m = (lo_r + hi_r) >> 1; if (a.runs[m].tile_base <= tile) lo_r = m; else hi_r = m; }
     const RunDev run = a.runs[lo_r];
-    const uint64_t T0 = run.start_pos + (tile - run.tile_base) * (uint64_t)W;
-    const uint64_t Tend = min(T0 + W, run.end_pos);
-    for (int i = threadIdx.x; i < 7 * W + HB; i += K4_T) lds[i] = 0;
+    const uint32_t T0 = (uint32_t)(run.start_pos + (tile - run.tile_base) * (uint64_t)W);
+    const uint32_t Tend = (uint32_t)min((uint64_t)T0 + W, run.end_pos);
+    for (int i = threadIdx.x; i < LIST; i += K4_T) lds[i] = 0;
     const uint64_t rk = ref_key(run.ref_id) << 32;
     // exact halo: first record whose running max end_position exceeds T0; last: first record starting at/after Tend
-    const uint64_t i_lo = lower_bound_gt(a.pmax_end, run.first_record, run.end_record, rk | (uint32_t)T0);
-    const uint64_t i_hi = lower_bound_gt(a.pmax_pos, run.first_record, run.end_record, rk | (uint32_t)(Tend - 1));
-    __syncthreads();
+    const uint64_t i_lo = lower_bound_gt(a.pmax_end, run.first_record, run.end_record, rk | T0);
+    const uint64_t i_hi = lower_bound_gt(a.pmax_pos, run.first_record, run.end_record, rk | (Tend - 1));
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    for (uint64_t i = i_lo + wave; i < i_hi; i += K4_T / 64) {
-        const bgp_record r = a.rec[i];
-        if (r.end_pos == r.pos) continue;                                       // filter basesCovered() > 0
-        if ((uint64_t)(uint32_t)r.end_pos <= T0 || (uint64_t)(uint32_t)r.pos >= Tend) continue;
-        pile_read(a.s, r, (uint32_t)T0, (uint32_t)Tend, cnt, lane, a.status);
+    uint32_t* list = lds + LIST;
+
+    for (uint64_t scan = i_lo; scan < i_hi;) {
+        if (threadIdx.x == 0) s_n = 0;
+        __syncthreads();
+        // ---- scan: compact the reads that overlap the window
+        for (;;) {
+            const uint64_t i = scan + threadIdx.x;
+            bool valid = false;
+            if (i < i_hi) {
+                const uint4 x = *reinterpret_cast<const uint4*>(a.rec + i);     // ref_id, pos, end_pos, bin_mq_nl
+                valid = x.z != x.y && x.z > T0 && x.y < Tend;                   // basesCovered() > 0 and overlaps the window
+                if (valid && x.y >= T0) atomicAdd(&lds[NST + (x.y - T0)], 1u);  // n_starting_here, pileup.d:386,422
+            }
+            const unsigned long long m = __ballot(valid);
+            uint32_t slot = 0;
+            if (lane == 0 && m) slot = atomicAdd(&s_n, (uint32_t)__popcll(m));
+            slot = rl(slot, 0);
+            if (valid) list[slot + __popcll(m & ((1ull << lane) - 1))] = (uint32_t)(i - i_lo);
+            scan += K4_T;
+            __syncthreads();
+            if (scan >= i_hi || s_n > LCAP - K4_T) break;
+        }
+        const uint32_t n_list = s_n;
+        // ---- process: 64 listed reads per wave, lane = read
+        for (uint32_t b0 = (uint32_t)wave * 64; b0 < n_list; b0 += (K4_T / 64) * 64) {
+            const bool have = b0 + lane < n_list;
+            uint32_t pos = 0, covered = 0, n_cig = 0, l_seq = 0, o0 = 0, o1 = 0, o2 = 0, o3 = 0;
+            uint64_t cig_off = 0;
+            uint4 w0 = {}, w1 = {}, w2 = {}, w3 = {}, w4 = {};
+            bool fast = false;
+            uint32_t qsum = 0;
+            if (have) {
+                const uint4* rp = reinterpret_cast<const uint4*>(a.rec + i_lo + list[b0 + lane]);
+                const uint4 x = rp[0], y = rp[1];             // ref_id,pos,end_pos,bin_mq_nl | flag_nc,l_seq,rec_off
+                pos = x.y; covered = x.z - x.y; n_cig = y.x & 0xFFFFu; l_seq = y.y;
+                cig_off = (((uint64_t)y.w << 32) | y.z) + 36 + (x.w & 0xFFu);
+                const uint64_t seq_off = cig_off + 4ull * n_cig;
+                fast = n_cig >= 1 && n_cig <= 4 && l_seq <= FAST_LSEQ && seq_off + 80 <= a.stream_len;
+                if (fast) {
+                    const uint8_t* c = a.s + cig_off;
+                    o0 = ld_u32(c);
+                    if (n_cig > 1) o1 = ld_u32(c + 4);
+                    if (n_cig > 2) o2 = ld_u32(c + 8);
+                    if (n_cig > 3) o3 = ld_u32(c + 12);
+                    const uint8_t* sp = a.s + seq_off;
+                    __builtin_memcpy(&w0, sp, 16); __builtin_memcpy(&w1, sp + 16, 16); __builtin_memcpy(&w2, sp + 32, 16);
+                    __builtin_memcpy(&w3, sp + 48, 16); __builtin_memcpy(&w4, sp + 64, 16);
+                    // the mould: no zero-length reference-consuming op, first reference-consuming op is not N,
+                    // the CIGAR does not consume more query than SEQ holds
+                    bool seen_ref = false, ok = true;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const uint32_t op = k == 0 ? o0 : k == 1 ? o1 : k == 2 ? o2 : o3;
+                        if ((uint32_t)k < n_cig) {
+                            const uint32_t len = op >> 4;
+                            if (cig_rc(op)) { if (len == 0 || (!seen_ref && (op & 15u) == 3u)) ok = false; seen_ref = true; }
+                            if (cig_qc(op)) qsum += len;
+                        }
+                    }
+                    fast = ok && qsum <= l_seq;
+                }
+            }
+            // lane-parallel walk: all lanes step the same query index q
+            uint32_t maxq = fast ? qsum : 0;
+            for (int d = 32; d >= 1; d >>= 1) maxq = max(maxq, (uint32_t)__shfl_xor((int)maxq, d, 64));
+            if (maxq || __ballot(fast)) {
+                const uint32_t need_hi = min(covered, Tend - pos), need_lo = T0 > pos ? T0 - pos : 0;
+                const uint32_t colbase = pos - T0;                         // (wraps; only used when p >= need_lo)
+                uint32_t opk = 0, rem = 0, p = 0; bool is_m = false, act = fast;
+                auto advance = [&]() {                                      // enter the next op that consumes query bases
+                    while (rem == 0 && opk < n_cig) {
+                        const uint32_t op = opk == 0 ? o0 : opk == 1 ? o1 : opk == 2 ? o2 : o3;
+                        ++opk;
+                        const uint32_t len = op >> 4;
+                        if (cig_qc(op)) { rem = len; is_m = cig_rc(op) != 0; }
+                        else if (cig_rc(op)) {                              // D, N: '-' over [p, p+len), pileup.d:119-121
+                            const uint32_t lo = max(p, need_lo), hi = min(p + len, need_hi);
+                            if (lo < hi) { atomicAdd(&lds[DELD + colbase + lo], 1u); atomicAdd(&lds[DELD + colbase + hi], 0xFFFFFFFFu); }
+                            p += len;
+                        }
+                    }
+                    if (rem == 0) act = false;
+                };
+                const uint32_t nwords = (maxq + 7) >> 3;
+                for (uint32_t wi = 0; wi < nwords; ++wi) {
+                    uint32_t cur;                                           // dword wi of this lane's packed SEQ (wi is wave-uniform)
+                    switch (wi) {
+                        case 0: cur = w0.x; break; case 1: cur = w0.y; break; case 2: cur = w0.z; break; case 3: cur = w0.w; break;
+                        case 4: cur = w1.x; break; case 5: cur = w1.y; break; case 6: cur = w1.z; break; case 7: cur = w1.w; break;
+                        case 8: cur = w2.x; break; case 9: cur = w2.y; break; case 10: cur = w2.z; break; case 11: cur = w2.w; break;
+                        case 12: cur = w3.x; break; case 13: cur = w3.y; break; case 14: cur = w3.z; break; case 15: cur = w3.w; break;
+                        case 16: cur = w4.x; break; case 17: cur = w4.y; break; case 18: cur = w4.z; break; default: cur = w4.w; break;
+                    }
+#pragma unroll
+                    for (int b = 0; b < 8; ++b) {
+                        if (act) {
+                            if (rem == 0) advance();
+                            if (act) {
+                                if (is_m) {
+                                    if (p >= need_lo && p < need_hi) {
+                                        const uint32_t byte = (cur >> ((b >> 1) * 8)) & 0xFFu;
+                                        const uint32_t cls = base_class((b & 1) ? (byte & 0xFu) : (byte >> 4));   // read.d:368-373
+                                        atomicAdd(&lds[cls * W + colbase + p], 1u);
+                                    }
+                                    ++p;
+                                }
+                                --rem;
+                            }
+                        }
+                    }
+                }
+                if (fast) { rem = 0; act = true; advance(); }               // trailing D/N after the last query base
+            }
+            // everything else, one read at a time with lanes along the read
+            unsigned long long slow = __ballot(have && !fast);
+            while (slow) {
+                const int r = __ffsll((long long)slow) - 1;
+                slow &= slow - 1;
+                const uint64_t co = ((uint64_t)rl((uint32_t)(cig_off >> 32), r) << 32) | rl((uint32_t)cig_off, r);
+                pile_read_coop(a, lds, T0, Tend, lane, rl(pos, r), rl(covered, r), rl(n_cig, r), rl(l_seq, r), co);
+            }
+        }
+        __syncthreads();
     }
-    __syncthreads();
-    // flush: 32 contiguous bytes per position
+    // ---- flush: prefix-sum the '-' difference array, then 32 contiguous bytes per position
+    const uint32_t np = Tend - T0;
+    {
+        constexpr int PER = W / K4_T;
+        const uint32_t p0 = threadIdx.x * PER;
+        uint32_t loc[PER]; uint32_t run_sum = 0;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) { run_sum += lds[DELD + p0 + j]; loc[j] = run_sum; }
+        uint32_t inc = run_sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(inc, d, 64); if (lane >= d) inc += o; }
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        uint32_t carry = 0;
+        for (int w = 0; w < wave; ++w) carry += wsum[w];
+        const uint32_t ex = carry + inc - run_sum;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) lds[DELD + p0 + j] = ex + loc[j];
+        __syncthreads();
+    }
     bgp_column* out = a.cols + run.column_base + (T0 - run.start_pos);
-    const uint32_t np = (uint32_t)(Tend - T0);
     uint64_t ncol = 0, scov = 0; uint32_t mx = 0;
     for (uint32_t p = threadIdx.x; p < np; p += K4_T) {
-        const uint32_t A = cnt[p], C = cnt[W + p], G = cnt[2 * W + p], Tt = cnt[3 * W + p], O = cnt[4 * W + p], D = cnt[5 * W + p], S = cnt[6 * W + p];
+        const uint32_t A = lds[p], C = lds[W + p], G = lds[2 * W + p], Tt = lds[3 * W + p], O = lds[4 * W + p], D = lds[DELD + p], S = lds[NST + p];
         const uint32_t cov = A + C + G + Tt + O + D;
         uint4* o4 = reinterpret_cast<uint4*>(out + p);
         o4[0] = make_uint4(cov, S, A, C);
         o4[1] = make_uint4(G, Tt, O, D);
         ncol += cov > 0; scov += cov; mx = max(mx, cov);
-        if (cov < HB) atomicAdd(&hist[cov], 1u);
+        if (cov < HB) atomicAdd(&lds[HIST + cov], 1u);
         else atomicAdd(&a.hist[min(cov, (uint32_t)BGP_DEPTH_BINS - 1)], 1ull);
     }
     for (int d = 32; d >= 1; d >>= 1) { ncol += __shfl_down(ncol, d, 64); scov += __shfl_down(scov, d, 64); mx = max(mx, (uint32_t)__shfl_down(mx, d, 64)); }
@@ -190,7 +371,7 @@ __global__ __launch_bounds__(K4_T) void k4_tile(K4Args a) {
         if (mx) atomicMax(&a.pstats[2], (unsigned long long)mx);
     }
     __syncthreads();
-    for (int b = threadIdx.x; b < HB; b += K4_T) { const uint32_t h = hist[b]; if (h) atomicAdd(&a.hist[b], (unsigned long long)h); }
+    for (int b = threadIdx.x; b < HB; b += K4_T) { const uint32_t h = lds[HIST + b]; if (h) atomicAdd(&a.hist[b], (unsigned long long)h); }
 }
 
 // ---------------------------------------------------------------------------------------------- K5
@@ -327,9 +508,9 @@ int k34_pileup(bgp_ctx* c) {
         BGP_HIP(hipMemcpyAsync(c->d_runs.p, runs.data(), sizeof(RunDev) * n_runs, hipMemcpyHostToDevice, c->stream));
         K4Args a;
         a.s = c->d_stream; a.rec = c->d_rec.as<bgp_record>(); a.pmax_end = c->d_pmax_end.as<uint64_t>(); a.pmax_pos = c->d_pmax_pos.as<uint64_t>();
-        a.runs = c->d_runs.as<RunDev>(); a.n_runs = n_runs; a.n_tiles = tile_base;
+        a.runs = c->d_runs.as<RunDev>(); a.n_runs = n_runs; a.n_tiles = tile_base; a.stream_len = c->stream_len;
         a.cols = c->d_columns.as<bgp_column>(); a.hist = (unsigned long long*)c->d_depth_hist.p; a.pstats = (unsigned long long*)c->d_pstats.p; a.status = status;
-        const size_t lds_bytes = (7 * W + HB) * 4;
+        const size_t lds_bytes = (size_t)LDS_WORDS * 4;
         const uint64_t grid = tile_base < 64 ? tile_base : ((tile_base + 7) / 8) * 8;
         uint64_t used = 0;   // algorithmic bytes: record table + CIGAR + packed SEQ per read, 32 B per position
         used = c->n_records * 32 + c->sum_ncig * 4 + (c->sum_lseq + 1) / 2 + col_base * 32;
