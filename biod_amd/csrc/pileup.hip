@@ -26,6 +26,7 @@
 #include "common.h"
 
 #include <algorithm>
+#include <cstdio>
 
 namespace {
 
@@ -54,10 +55,9 @@ struct K3bArgs { const bgp_record* rec; uint64_t n; const uint64_t* pmax_pos; Ru
 
 __global__ __launch_bounds__(256) void k3_bounds(K3bArgs a) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    bool cov = false;
     if (i < a.n) {
         const bgp_record r = a.rec[i];
-        cov = r.end_pos != r.pos;
+        const bool cov = r.end_pos != r.pos;
         if (cov) {
             if (r.pos < 0 || r.end_pos < r.pos) atomicOr(&a.status[0], ST_EINVAL);
             const uint64_t key = (ref_key(r.ref_id) << 32) | (uint32_t)r.pos;
@@ -69,8 +69,6 @@ __global__ __launch_bounds__(256) void k3_bounds(K3bArgs a) {
             }
         }
     }
-    const unsigned long long m = __ballot(cov);
-    if ((threadIdx.x & 63) == 0 && m) atomicAdd(a.n_used, (unsigned long long)__popcll(m));
 }
 
 __global__ void k3_run_ends(RunDev* runs, uint32_t n_runs, const uint64_t* pmax_end, uint64_t n) {
@@ -84,7 +82,7 @@ struct K4Args {
     const uint8_t* s; const bgp_record* rec; const uint64_t* pmax_end; const uint64_t* pmax_pos;
     const RunDev* runs; uint32_t n_runs; uint64_t n_tiles; uint64_t stream_len;
     bgp_column* cols; unsigned long long* hist; unsigned long long* pstats; /* [0] n_columns [1] sum_cov [2] max_cov */
-    uint32_t* status;
+    uint32_t* status; const struct TileB* tiles; unsigned long long* tile_stats;
 };
 
 __device__ __forceinline__ uint64_t lower_bound_gt(const uint64_t* a, uint64_t lo, uint64_t hi, uint64_t key) {   // first i in [lo,hi) with a[i] > key
@@ -94,6 +92,24 @@ __device__ __forceinline__ uint64_t lower_bound_gt(const uint64_t* a, uint64_t l
 
 __device__ __forceinline__ uint32_t base_class(uint32_t code) {   // nt16 code -> A,C,G,T,other
     return (uint32_t)(0x4444444344424104ull >> (code * 4)) & 0xFu;  // 1->0 2->1 4->2 8->3 else 4
+}
+
+// One thread per window: the record range that can touch it (exact halo).  Done here, massively
+// parallel, because the two ~25-step dependent binary searches are pure latency.
+struct TileB { uint64_t i_lo, i_hi; };
+__global__ __launch_bounds__(256) void k4_bounds(const uint64_t* pmax_end, const uint64_t* pmax_pos, const RunDev* runs, uint32_t n_runs, uint64_t n_tiles, TileB* out) {
+    const uint64_t tile = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tile >= n_tiles) return;
+    uint32_t lo_r = 0, hi_r = n_runs;
+    while (hi_r - lo_r > 1) { const uint32_t m = (lo_r + hi_r) >> 1; if (runs[m].tile_base <= tile) lo_r = m; else hi_r = m; }
+    const RunDev run = runs[lo_r];
+    const uint32_t T0 = (uint32_t)(run.start_pos + (tile - run.tile_base) * (uint64_t)W);
+    const uint32_t Tend = (uint32_t)min((uint64_t)T0 + W, run.end_pos);
+    const uint64_t rk = ref_key(run.ref_id) << 32;
+    TileB b;
+    b.i_lo = lower_bound_gt(pmax_end, run.first_record, run.end_record, rk | T0);             // first record whose running max end_position exceeds T0
+    b.i_hi = lower_bound_gt(pmax_pos, run.first_record, run.end_record, rk | (Tend - 1));     // first record starting at/after Tend
+    out[tile] = b;
 }
 
 // ---- K4: per-position column summary ----------------------------------------------------------
@@ -201,10 +217,7 @@ __global__ __launch_bounds__(K4_T) void k4_tile(K4Args a) {
     const uint32_t T0 = (uint32_t)(run.start_pos + (tile - run.tile_base) * (uint64_t)W);
     const uint32_t Tend = (uint32_t)min((uint64_t)T0 + W, run.end_pos);
     for (int i = threadIdx.x; i < LIST; i += K4_T) lds[i] = 0;
-    const uint64_t rk = ref_key(run.ref_id) << 32;
-    // exact halo: first record whose running max end_position exceeds T0; last: first record starting at/after Tend
-    const uint64_t i_lo = lower_bound_gt(a.pmax_end, run.first_record, run.end_record, rk | T0);
-    const uint64_t i_hi = lower_bound_gt(a.pmax_pos, run.first_record, run.end_record, rk | (Tend - 1));
+    const uint64_t i_lo = a.tiles[tile].i_lo, i_hi = a.tiles[tile].i_hi;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     uint32_t* list = lds + LIST;
@@ -270,27 +283,36 @@ __global__ __launch_bounds__(K4_T) void k4_tile(K4Args a) {
                     fast = ok && qsum <= l_seq;
                 }
             }
-            // lane-parallel walk: all lanes step the same query index q
+            // lane-parallel walk: all lanes step the same query index q.  Each CIGAR op slot k of a lane
+            // becomes (if it is M/=/X) one window-clipped query interval [sq_k, sq_k + sl_k) whose bases
+            // land on LDS word sb_k + q; D/N ops are two adds on the difference array, done here, once.
             uint32_t maxq = fast ? qsum : 0;
             for (int d = 32; d >= 1; d >>= 1) maxq = max(maxq, (uint32_t)__shfl_xor((int)maxq, d, 64));
             if (maxq || __ballot(fast)) {
                 const uint32_t need_hi = min(covered, Tend - pos), need_lo = T0 > pos ? T0 - pos : 0;
-                const uint32_t colbase = pos - T0;                         // (wraps; only used when p >= need_lo)
-                uint32_t opk = 0, rem = 0, p = 0; bool is_m = false, act = fast;
-                auto advance = [&]() {                                      // enter the next op that consumes query bases
-                    while (rem == 0 && opk < n_cig) {
-                        const uint32_t op = opk == 0 ? o0 : opk == 1 ? o1 : opk == 2 ? o2 : o3;
-                        ++opk;
-                        const uint32_t len = op >> 4;
-                        if (cig_qc(op)) { rem = len; is_m = cig_rc(op) != 0; }
-                        else if (cig_rc(op)) {                              // D, N: '-' over [p, p+len), pileup.d:119-121
-                            const uint32_t lo = max(p, need_lo), hi = min(p + len, need_hi);
-                            if (lo < hi) { atomicAdd(&lds[DELD + colbase + lo], 1u); atomicAdd(&lds[DELD + colbase + hi], 0xFFFFFFFFu); }
-                            p += len;
+                const uint32_t colbase = pos - T0;                         // wraps for pos < T0; sums below are exact mod 2^32
+                uint32_t sq[4], sl[4], sb[4];
+                {
+                    uint32_t q = 0, p = 0;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        sq[k] = 0; sl[k] = 0; sb[k] = 0;
+                        const uint32_t op = k == 0 ? o0 : k == 1 ? o1 : k == 2 ? o2 : o3;
+                        if (fast && (uint32_t)k < n_cig) {
+                            const uint32_t len = op >> 4, qc = cig_qc(op), rc = cig_rc(op);
+                            if (rc) {
+                                const uint32_t lo = max(p, need_lo), hi = min(p + len, need_hi);   // columns of this op inside the window
+                                if (lo < hi) {
+                                    if (qc) { sq[k] = q + (lo - p); sl[k] = hi - lo; sb[k] = (colbase + p - q) * 4; }   // pileup.d:117-118
+                                    else { atomicAdd(&lds[DELD + colbase + lo], 1u); atomicAdd(&lds[DELD + colbase + hi], 0xFFFFFFFFu); }   // pileup.d:119-121
+                                }
+                                p += len;
+                            }
+                            if (qc) q += len;
                         }
                     }
-                    if (rem == 0) act = false;
-                };
+                }
+                const bool use1 = __ballot(sl[1] != 0) != 0, use2 = __ballot(sl[2] != 0) != 0, use3 = __ballot(sl[3] != 0) != 0;
                 const uint32_t nwords = (maxq + 7) >> 3;
                 for (uint32_t wi = 0; wi < nwords; ++wi) {
                     uint32_t cur;                                           // dword wi of this lane's packed SEQ (wi is wave-uniform)
@@ -301,25 +323,22 @@ __global__ __launch_bounds__(K4_T) void k4_tile(K4Args a) {
                         case 12: cur = w3.x; break; case 13: cur = w3.y; break; case 14: cur = w3.z; break; case 15: cur = w3.w; break;
                         case 16: cur = w4.x; break; case 17: cur = w4.y; break; case 18: cur = w4.z; break; default: cur = w4.w; break;
                     }
+                    const uint32_t q0 = wi * 8;
 #pragma unroll
                     for (int b = 0; b < 8; ++b) {
-                        if (act) {
-                            if (rem == 0) advance();
-                            if (act) {
-                                if (is_m) {
-                                    if (p >= need_lo && p < need_hi) {
-                                        const uint32_t byte = (cur >> ((b >> 1) * 8)) & 0xFFu;
-                                        const uint32_t cls = base_class((b & 1) ? (byte & 0xFu) : (byte >> 4));   // read.d:368-373
-                                        atomicAdd(&lds[cls * W + colbase + p], 1u);
-                                    }
-                                    ++p;
-                                }
-                                --rem;
-                            }
-                        }
+                        const uint32_t q = q0 + b;
+                        bool in = (q - sq[0]) < sl[0];
+                        uint32_t base = sb[0];
+                        if (use1) { const bool i1 = (q - sq[1]) < sl[1]; base = i1 ? sb[1] : base; in |= i1; }
+                        if (use2) { const bool i2 = (q - sq[2]) < sl[2]; base = i2 ? sb[2] : base; in |= i2; }
+                        if (use3) { const bool i3 = (q - sq[3]) < sl[3]; base = i3 ? sb[3] : base; in |= i3; }
+                        const uint32_t code = (cur >> ((b >> 1) * 8 + ((b & 1) ? 0 : 4))) & 0xFu;      // read.d:368-373
+                        const uint32_t tab = (code & 8u) ? 0x44444443u : 0x44424104u;                 // nt16 -> A,C,G,T,other
+                        const uint32_t cls = (tab >> ((code & 7u) * 4)) & 0xFu;
+                        const uint32_t addr = (cls << 13) + base + q * 4;                               // byte address of cnt[cls][column]
+                        atomicAdd(reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(lds) + (in ? addr : 0u)), in ? 1u : 0u);
                     }
                 }
-                if (fast) { rem = 0; act = true; advance(); }               // trailing D/N after the last query base
             }
             // everything else, one read at a time with lanes along the read
             unsigned long long slow = __ballot(have && !fast);
@@ -364,14 +383,31 @@ __global__ __launch_bounds__(K4_T) void k4_tile(K4Args a) {
         if (cov < HB) atomicAdd(&lds[HIST + cov], 1u);
         else atomicAdd(&a.hist[min(cov, (uint32_t)BGP_DEPTH_BINS - 1)], 1ull);
     }
-    for (int d = 32; d >= 1; d >>= 1) { ncol += __shfl_down(ncol, d, 64); scov += __shfl_down(scov, d, 64); mx = max(mx, (uint32_t)__shfl_down(mx, d, 64)); }
-    if (lane == 0) {
-        if (ncol) atomicAdd(&a.pstats[0], (unsigned long long)ncol);
-        if (scov) atomicAdd(&a.pstats[1], (unsigned long long)scov);
-        if (mx) atomicMax(&a.pstats[2], (unsigned long long)mx);
+    // per-window totals go to a per-window slot (same-address global atomics from every wave cost
+    // more than the whole rest of the kernel); k4_stats folds the slots afterwards
+    uint64_t nst = 0;
+    for (uint32_t p = threadIdx.x; p < np; p += K4_T) nst += lds[NST + p];
+    for (int d = 32; d >= 1; d >>= 1) { ncol += __shfl_down(ncol, d, 64); scov += __shfl_down(scov, d, 64); nst += __shfl_down(nst, d, 64); mx = max(mx, (uint32_t)__shfl_down(mx, d, 64)); }
+    __shared__ unsigned long long part[K4_T / 64][4];
+    if (lane == 0) { part[wave][0] = ncol; part[wave][1] = scov; part[wave][2] = mx; part[wave][3] = nst; }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        unsigned long long v = 0;
+        for (int w = 0; w < K4_T / 64; ++w) v = threadIdx.x == 2 ? max(v, part[w][2]) : v + part[w][threadIdx.x];
+        a.tile_stats[tile * 4 + threadIdx.x] = v;
     }
     __syncthreads();
     for (int b = threadIdx.x; b < HB; b += K4_T) { const uint32_t h = lds[HIST + b]; if (h) atomicAdd(&a.hist[b], (unsigned long long)h); }
+}
+
+// folds the per-window totals: [0] columns with coverage, [1] sum of coverage, [2] max coverage, [4] reads used
+__global__ __launch_bounds__(256) void k4_stats(const unsigned long long* ts, uint64_t n_tiles, unsigned long long* pstats) {
+    unsigned long long c = 0, s = 0, m = 0, u = 0;
+    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n_tiles; t += (uint64_t)gridDim.x * blockDim.x) {
+        c += ts[t * 4]; s += ts[t * 4 + 1]; m = max(m, ts[t * 4 + 2]); u += ts[t * 4 + 3];
+    }
+    for (int d = 32; d >= 1; d >>= 1) { c += __shfl_down(c, d, 64); s += __shfl_down(s, d, 64); u += __shfl_down(u, d, 64); m = max(m, (unsigned long long)__shfl_down(m, d, 64)); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&pstats[0], c); atomicAdd(&pstats[1], s); atomicMax(&pstats[2], m); atomicAdd(&pstats[4], u); }
 }
 
 // ---------------------------------------------------------------------------------------------- K5
@@ -452,9 +488,9 @@ int k34_pileup(bgp_ctx* c) {
     const uint64_t n = c->n_records;
     c->runs.clear();
     memset(&c->pinfo, 0, sizeof c->pinfo);
-    BGP_TRY(c->d_pstats.reserve(64));
+    BGP_TRY(c->d_pstats.reserve(256));
     BGP_TRY(c->d_depth_hist.reserve((size_t)BGP_DEPTH_BINS * 8));
-    BGP_HIP(hipMemsetAsync(c->d_pstats.p, 0, 64, c->stream));
+    BGP_HIP(hipMemsetAsync(c->d_pstats.p, 0, 256, c->stream));
     BGP_HIP(hipMemsetAsync(c->d_depth_hist.p, 0, (size_t)BGP_DEPTH_BINS * 8, c->stream));
     BGP_HIP(hipMemsetAsync(c->d_status.p, 0, 64, c->stream));
     if (n == 0) { BGP_HIP(hipStreamSynchronize(c->stream)); c->pinfo.device_depth_hist = c->d_depth_hist.as<uint64_t>(); return BGP_OK; }
@@ -514,12 +550,21 @@ int k34_pileup(bgp_ctx* c) {
         const uint64_t grid = tile_base < 64 ? tile_base : ((tile_base + 7) / 8) * 8;
         uint64_t used = 0;   // algorithmic bytes: record table + CIGAR + packed SEQ per read, 32 B per position
         used = c->n_records * 32 + c->sum_ncig * 4 + (c->sum_lseq + 1) / 2 + col_base * 32;
+        BGP_TRY(c->d_tiles.reserve(tile_base * sizeof(TileB)));
+        a.tiles = c->d_tiles.as<TileB>();
+        {
+            TimedRegion tb(c, "k4_bounds", tile_base * 16);
+            hipLaunchKernelGGL(k4_bounds, dim3((unsigned)((tile_base + 255) / 256)), dim3(256), 0, c->stream, a.pmax_end, a.pmax_pos, a.runs, n_runs, tile_base, c->d_tiles.as<TileB>());
+        }
+        BGP_TRY(c->d_col_lo.reserve(tile_base * 32));
+        a.tile_stats = (unsigned long long*)c->d_col_lo.p;
         TimedRegion t(c, "k4_tile", used);
         hipLaunchKernelGGL(k4_tile, dim3((unsigned)grid), dim3(K4_T), lds_bytes, c->stream, a);
+        hipLaunchKernelGGL(k4_stats, dim3(32), dim3(256), 0, c->stream, a.tile_stats, tile_base, a.pstats);
         BGP_HIP(hipGetLastError());
     }
-    uint64_t ps[8];
-    BGP_HIP(hipMemcpyAsync(ps, c->d_pstats.p, 64, hipMemcpyDeviceToHost, c->stream));
+    uint64_t ps[16];
+    BGP_HIP(hipMemcpyAsync(ps, c->d_pstats.p, 128, hipMemcpyDeviceToHost, c->stream));
     BGP_HIP(hipMemcpyAsync(st, status, 16, hipMemcpyDeviceToHost, c->stream));
     BGP_HIP(hipStreamSynchronize(c->stream));
     rc = bgp_status_from_bits(st[0]);
