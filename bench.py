@@ -35,6 +35,7 @@ def parse():
     ap.add_argument("--reads", type=int, default=0, help="reads per GPU (0 = the config's own size, reduced only if HBM is short)")
     ap.add_argument("--cpu-sample-reads", type=int, default=0, help="reads in the CPU-baseline sample (0 = auto, about 10-30 s of CPU work)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--strong", action="store_true", help="split ONE --reads-sized BAM by contig over the ranks (strong scaling) instead of one full shard per rank")
     return ap.parse_args()
 
 
@@ -88,7 +89,12 @@ def main():
     need_per_read = 1000 if a.config != "cfg5" else 600_000       # stream + tables + arenas + columns, generous
     while n_reads * need_per_read > free * 0.9 and n_reads > 1000:
         n_reads //= 2
-    cfg = scaled(a.config, n_reads, first_ref=rank * CONFIGS[a.config]["n_ref"])
+    from biod_amd.shard import strong_cfg, weak_cfg
+    if a.strong:        # BASELINE.json config 4 literally: the same BAM split by contig over the ranks
+        cfg = strong_cfg(a.config, n_reads, rank, world)
+        n_reads = int(cfg.n_reads)
+    else:               # default: every rank owns a full-size shard of its own contigs
+        cfg = weak_cfg(a.config, n_reads, rank)
 
     ctx = Context(local)
     t0 = time.perf_counter()
@@ -140,7 +146,7 @@ def main():
 
     if rank == 0:
         ms_step = dt / a.steps * 1e3
-        job_reads = n_reads * world
+        job_reads = n_reads * world      # (strong: ranks hold equal contig shares of the one BAM)
         # roofline of the dominant kernel (largest share of kernel time), algorithmic bytes per launch / mean launch time
         kt = {k: v for k, v in timers.items() if v["launches"]}
         dom = max(kt, key=lambda k: kt[k]["total_ms"])
@@ -154,7 +160,7 @@ def main():
             "metric": "Mreads/s decoded + piled up (BAM record decode -> CIGAR walk -> per-base pileup, input resident in HBM)",
             "value": round(job_reads / dt * a.steps / 1e6, 3), "unit": "Mreads/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_step, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/u32 integer", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong" if a.strong else "weak", "vs_baseline": None, "dtype": "u8/u32 integer", "data": "synthetic",
             "config": {"workload": f"{a.config}: {n_reads} reads/GPU synthetic coordinate-sorted BAM record stream "
                                    f"({'mixed M/I/D/S/N CIGAR' if cfg.profile == 1 else 'M-only CIGAR' if cfg.profile == 0 else 'long indel-heavy reads'}, "
                                    f"l_seq {cfg.len_min}-{cfg.len_max}, {cfg.n_ref} contigs x {cfg.ref_len} bp per GPU)",

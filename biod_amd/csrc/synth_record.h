@@ -36,7 +36,7 @@ struct bgp_synth_cfg {
     uint32_t len_min;       // l_seq (profiles 0/1: fixed = len_min)
     uint32_t len_max;
     uint32_t profile;       // 0 M-only, 1 mixed, 2 long
-    uint32_t first_ref;     // global id of this shard's first contig (ref_id written = local index)
+    uint32_t first_ref;     // global id of this shard's first contig; record ref_id = first_ref + local index
 };
 
 namespace synth {
@@ -205,7 +205,7 @@ template <class S> SYNTH_HD void emit_md(const bgp_synth_cfg& g, const Read& r, 
 // record_size() returned minus 4.
 template <class S> SYNTH_HD void emit_record(const bgp_synth_cfg& g, uint64_t i, const Read& r, uint32_t body_size, uint32_t n_cigar, uint32_t ref_span, S& s) {
     put_u32(s, body_size);
-    put_u32(s, r.contig_local);
+    put_u32(s, r.contig_global);
     put_u32(s, (uint32_t)r.pos);
     put_u32(s, (reg2bin(r.pos, r.pos + (int32_t)ref_span) << 16) | (r.mapq << 8) | 11u);
     put_u32(s, (r.flag << 16) | n_cigar);

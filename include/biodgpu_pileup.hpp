@@ -1,0 +1,150 @@
+// biodgpu_pileup.hpp -- header-only C++ mirror of BioD's pileup range API over the libbiodgpu C ABI.
+//
+// BioD (D) exposes input ranges: `foreach (column; makePileup(bam.reads, ...))` with
+// empty/front/popFront (bio/std/hts/bam/pileup.d:335-397).  This header keeps that shape in C++ --
+// same function names, parameter order and defaults as pileup.d:683-687 (makePileup) and pileup.d:509
+// (pileupColumns) -- for hosts that cannot run D (this image has no D compiler).  The D module a BioD
+// maintainer would add is shown in INTEGRATION.md; both are thin: every column comes from the HIP
+// kernels behind include/biodgpu.h.
+#pragma once
+#include <cstdint>
+#include <limits>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "biodgpu.h"
+
+namespace biodgpu {
+
+// The D facade rethrows status codes as Exception (cf. ZlibException, bio/core/utils/zlib.d:247-273).
+struct Error : std::runtime_error {
+    int code;
+    Error(int c, bgp_ctx* ctx) : std::runtime_error(std::string(bgp_strerror(c)) + " [" + (bgp_last_error(ctx) ? bgp_last_error(ctx) : "") + "]"), code(c) {}
+};
+inline int check(int rc, bgp_ctx* ctx = nullptr) { if (rc < 0) throw Error(rc, ctx); return rc; }
+
+// `new BamReader(filename[, taskPool])`, bio/std/hts/bam/reader.d:127-138; `.reads` feeds the pileup.
+class BamReader {
+public:
+    explicit BamReader(const std::string& filename, int n_threads = 0, int device = 0) {
+        check(bgp_init(device, &ctx_));
+        try { check(bgp_load_bam(ctx_, filename.c_str(), n_threads), ctx_); check(bgp_flush(ctx_), ctx_); }
+        catch (...) { bgp_destroy(ctx_); throw; }
+    }
+    // reads given as inflated record bytes (what BamReadRange consumes, readrange.d:118-173)
+    BamReader(const uint8_t* records, size_t len, int device = 0) {
+        check(bgp_init(device, &ctx_));
+        try { check(bgp_push_inflated(ctx_, records, len, 0, BGP_UOFFSET_UNKNOWN), ctx_); check(bgp_flush(ctx_), ctx_); }
+        catch (...) { bgp_destroy(ctx_); throw; }
+    }
+    ~BamReader() { bgp_destroy(ctx_); }
+    BamReader(const BamReader&) = delete;
+    BamReader& operator=(const BamReader&) = delete;
+
+    struct ReferenceSequenceInfo { std::string name; int32_t length; };       // referenceinfo.d
+    std::vector<ReferenceSequenceInfo> reference_sequences() const {           // reader.d:189-199
+        int32_t n = 0; check(bgp_n_ref(ctx_, &n), ctx_);
+        std::vector<ReferenceSequenceInfo> v;
+        for (int32_t i = 0; i < n; ++i) { const char* nm; int32_t len; check(bgp_ref_info(ctx_, i, &nm, &len), ctx_); v.push_back({nm, len}); }
+        return v;
+    }
+    uint64_t num_reads() const { uint64_t n; check(bgp_num_records(ctx_, &n), ctx_); return n; }
+    BamReader& reads() { return *this; }                                       // reader.d:228-231
+    bgp_ctx* ctx() const { return ctx_; }
+
+private:
+    bgp_ctx* ctx_ = nullptr;
+};
+
+// PileupRead, pileup.d:86-230 (a view into the window the range currently holds)
+struct PileupRead {
+    const bgp_entry* e; const bgp_records* recs;
+    uint32_t read_ordinal() const { return e->read_ordinal; }
+    uint32_t cigar_operation_offset() const { return e->cigar_op_offset; }     // pileup.d:99
+    int query_offset() const { return (int)e->query_offset; }                  // pileup.d:146
+    char current_base() const { return (char)e->base; }                        // pileup.d:115
+    uint8_t current_base_quality() const { return e->qual; }                   // pileup.d:127
+    const bgp_record& record() const { return recs->rec[e->read_ordinal]; }
+    int ref_id() const { return record().ref_id; }
+    int position() const { return record().pos; }
+    int end_position() const { return record().end_pos; }
+    uint8_t mapping_quality() const { return (record().bin_mq_nl >> 8) & 0xFF; }
+    uint16_t flag() const { return (uint16_t)(record().flag_nc >> 16); }
+    bool is_reverse_strand() const { return flag() & 0x10; }
+    uint32_t cigar_operation() const { return recs->cigar[recs->cigar_off[e->read_ordinal] + e->cigar_op_index]; }   // raw len<<4|op, pileup.d:94
+    const uint32_t* cigar_begin() const { return recs->cigar + recs->cigar_off[e->read_ordinal]; }
+    const uint32_t* cigar_end() const { return recs->cigar + recs->cigar_off[e->read_ordinal + 1]; }
+    uint16_t cigar_operation_index() const { return e->cigar_op_index; }       // cigar_before = [begin, begin+index), cigar_after = (begin+index, end)
+};
+
+// PileupColumn, pileup.d:236-290
+struct PileupColumn {
+    int ref_id_; uint64_t position_; const bgp_column* c; const bgp_entry* ents; size_t n_ents; const bgp_records* recs;
+    size_t coverage() const { return c->coverage; }                            // pileup.d:252
+    int ref_id() const { return ref_id_; }                                     // pileup.d:257
+    uint64_t position() const { return position_; }                            // pileup.d:262
+    char reference_base() const { return 'N'; }                                // pileup.d:245 (MD path: next round)
+    size_t n_starting_here() const { return c->n_starting_here; }
+    std::vector<PileupRead> reads() const { std::vector<PileupRead> v; for (size_t i = 0; i < n_ents; ++i) v.push_back({ents + i, recs}); return v; }
+    std::vector<PileupRead> reads_starting_here() const {                      // pileup.d:272-274
+        std::vector<PileupRead> v; for (size_t i = n_ents - c->n_starting_here; i < n_ents; ++i) v.push_back({ents + i, recs}); return v;
+    }
+    std::string bases() const { std::string s; for (size_t i = 0; i < n_ents; ++i) s.push_back((char)ents[i].base); return s; }   // pileup.d:277
+};
+
+// The input range (empty/front/popFront, pileup.d:335-397) over device-computed windows.
+class PileupRange {
+public:
+    PileupRange(BamReader& r, int mode, bool use_md_tag, uint64_t start_from, uint64_t end_at, bool skip_zero_coverage, bool want_entries, uint32_t window)
+        : ctx_(r.ctx()), skip_zero_(skip_zero_coverage), want_entries_(want_entries), start_(start_from), end_(end_at) {
+        if (want_entries) check(bgp_decode_fetch(ctx_, BGP_FETCH_ALL, &recs_), ctx_);
+        check(bgp_pileup_begin(ctx_, mode, use_md_tag, start_from, end_at, skip_zero_coverage, want_entries, window), ctx_);
+        if (mode == BGP_MAKE_PILEUP) check(bgp_pileup_ref_id(ctx_, &ref_id_), ctx_);
+        fetch(); settle();
+    }
+    bool empty() const { return done_; }
+    PileupColumn front() const {
+        const uint64_t a = want_entries_ ? w_.entry_off[k_] : 0, b = want_entries_ ? w_.entry_off[k_ + 1] : 0;
+        return PileupColumn{w_.ref_id, w_.first_position + k_, w_.columns + k_, want_entries_ ? w_.entries + a : nullptr, (size_t)(b - a), &recs_};
+    }
+    void popFront() { ++k_; settle(); }
+    uint64_t start_position() const { return start_; }                         // pileup.d:445
+    uint64_t end_position() const { return end_; }                             // pileup.d:450
+    int ref_id() const { return ref_id_; }                                     // pileup.d:455
+
+    struct iterator {                                                          // for range-for, the `foreach` of D
+        PileupRange* r;
+        bool operator!=(const iterator&) const { return !r->empty(); }
+        void operator++() { r->popFront(); }
+        PileupColumn operator*() const { return r->front(); }
+    };
+    iterator begin() { return {this}; }
+    iterator end() { return {this}; }
+
+private:
+    void fetch() { const int rc = check(bgp_pileup_next_window(ctx_, &w_), ctx_); done_ = rc == BGP_EOF; k_ = 0; }
+    void settle() {            // skip zero-coverage positions the way PileupRange.popFront jumps over them, pileup.d:388-392
+        while (!done_) {
+            if (k_ >= w_.n_positions) { fetch(); continue; }
+            if (skip_zero_ && w_.columns[k_].coverage == 0) { ++k_; continue; }
+            return;
+        }
+    }
+    bgp_ctx* ctx_; bool skip_zero_, want_entries_; uint64_t start_, end_;
+    bgp_columns w_{}; bgp_records recs_{}; uint32_t k_ = 0; bool done_ = false; int32_t ref_id_ = -1;
+};
+
+// makePileup(reads, use_md_tag=false, start_from=0, end_at=ulong.max, skip_zero_coverage=true), pileup.d:683-694
+inline PileupRange makePileup(BamReader& reads, bool use_md_tag = false, uint64_t start_from = 0,
+                              uint64_t end_at = std::numeric_limits<uint64_t>::max(), bool skip_zero_coverage = true,
+                              bool want_entries = true, uint32_t window = 0) {
+    return PileupRange(reads, BGP_MAKE_PILEUP, use_md_tag, start_from, end_at, skip_zero_coverage, want_entries, window);
+}
+// pileupColumns(reads, use_md_tag=false, skip_zero_coverage=true), pileup.d:509-519
+inline PileupRange pileupColumns(BamReader& reads, bool use_md_tag = false, bool skip_zero_coverage = true,
+                                 bool want_entries = true, uint32_t window = 0) {
+    return PileupRange(reads, BGP_PILEUP_COLUMNS, use_md_tag, 0, std::numeric_limits<uint64_t>::max(), skip_zero_coverage, want_entries, window);
+}
+
+}  // namespace biodgpu

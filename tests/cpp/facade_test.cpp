@@ -1,0 +1,57 @@
+// C++ rendering of the reference's own pileup checks through the range facade:
+//   test/unittests.d:320-366 (makePileup -> chr1 only; pileupColumns -> 1470 + 1567 columns, first columns)
+//   examples/make_pileup.d:20-30 (joined reads_starting_here == all reads)
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+#include <vector>
+
+#include "biodgpu_pileup.hpp"
+
+#define REQUIRE(x) do { if (!(x)) { std::fprintf(stderr, "FAILED %s:%d: %s\n", __FILE__, __LINE__, #x); return 1; } } while (0)
+
+int main(int argc, char** argv) {
+    if (argc < 3) { std::fprintf(stderr, "usage: %s ex1_header.bam illu_20_chunk.bam\n", argv[0]); return 2; }
+    using namespace biodgpu;
+    {
+        BamReader bam(argv[1], 2);
+        auto refs = bam.reference_sequences();
+        REQUIRE(refs.size() == 2 && refs[0].name == "chr1" && refs[1].name == "chr2");
+        REQUIRE(bam.num_reads() == 3270);
+        size_t n = 0;
+        for (auto column : makePileup(bam.reads())) {                    // unittests.d:324-330
+            REQUIRE(column.ref_id() == 0);
+            for (auto& read : column.reads()) { REQUIRE(read.ref_id() == column.ref_id()); REQUIRE(!(read.flag() & 4)); }
+            ++n;
+        }
+        REQUIRE(n == 1470);
+        int expected[2] = {1470, 1567}, current = -1;
+        for (auto column : pileupColumns(bam.reads())) {                 // unittests.d:334-366
+            const int r = column.ref_id();
+            --expected[r];
+            if (r != current) {
+                REQUIRE(r > current);
+                if (r == 0) REQUIRE(column.position() == 99);
+                if (r == 1) REQUIRE(column.position() == 0);
+                current = r;
+            }
+            REQUIRE(column.coverage() == column.reads().size());
+        }
+        REQUIRE(expected[0] == 0 && expected[1] == 0);
+        auto clipped = makePileup(bam.reads(), false, 500, 700, false);
+        REQUIRE(clipped.start_position() == 500 && clipped.end_position() == 700 && clipped.ref_id() == 0);
+        size_t k = 0; uint64_t last = 0;
+        for (auto column : clipped) { REQUIRE(column.position() >= 500 && column.position() < 700); last = column.position(); ++k; }
+        REQUIRE(k == 200 && last == 699);
+    }
+    {
+        BamReader bam(argv[2], 2);                                       // make_pileup.d:20-30
+        std::vector<uint32_t> starting;
+        for (auto column : makePileup(bam.reads()))
+            for (auto& read : column.reads_starting_here()) starting.push_back(read.read_ordinal());
+        REQUIRE(starting.size() == 29);
+        for (uint32_t i = 0; i < 29; ++i) REQUIRE(starting[i] == i);
+    }
+    std::puts("facade ok");
+    return 0;
+}

@@ -337,3 +337,15 @@ def test_scale_properties(ctx):
     st = host_stream(cfg, 0, k)
     stage(ctx, st)
     check_pileup(ctx, st, entries=False)
+
+
+def test_cpp_facade(tmp_path, data_dir):
+    """include/biodgpu_pileup.hpp: the reference's own pileup checks (test/unittests.d:320-366,
+    examples/make_pileup.d:20-30) through the C++ mirror of BioD's range API."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "facade_test")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-I" + os.path.join(root, "include"), os.path.join(root, "tests", "cpp", "facade_test.cpp"),
+                           "-o", exe, "-L" + os.path.join(root, "biod_amd"), "-lbiodgpu", "-Wl,-rpath," + os.path.join(root, "biod_amd")])
+    out = subprocess.run([exe, os.path.join(data_dir, "ex1_header.bam"), os.path.join(data_dir, "illu_20_chunk.bam")], capture_output=True, text=True)
+    assert out.returncode == 0 and "facade ok" in out.stdout, out.stderr
