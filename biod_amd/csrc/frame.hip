@@ -188,7 +188,10 @@ int k0_frame(bgp_ctx* c) {
     uint32_t bs0 = 0;
     BGP_HIP(hipMemcpyAsync(&bs0, c->d_stream, 4, hipMemcpyDeviceToHost, c->stream));
     BGP_HIP(hipStreamSynchronize(c->stream));
-    uint64_t want = 8ull * (4ull + (bs0 & 0x3FFFFFFFu));
+    // ~32 records per segment: k0_guess costs one wave per segment, the chase is a per-lane serial
+    // chain per segment (measured on cfg3: 8 -> 32 records/segment cuts the guess 4x, chase unchanged)
+    const uint64_t recs_per_seg = getenv("BGP_SEG_RECORDS") ? (uint64_t)atoi(getenv("BGP_SEG_RECORDS")) : 32ull;
+    uint64_t want = recs_per_seg * (4ull + (bs0 & 0x3FFFFFFFu));
     uint32_t seg = pow2_ceil(want);
     if (seg < 4096u) seg = 4096u;
     if (seg > (1u << 20)) seg = 1u << 20;
