@@ -26,6 +26,21 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
 
 
+def pmc_traffic(kernel, config, n_reads):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE
+    collected separately, KB units, FETCH doubled for gfx950 as MI355X_MICROARCH.md prescribes).  Counters
+    cannot be read from inside this process, so the number is only reported when the workload is the one the
+    profile was taken on (cfg3, 100 M reads); otherwise null."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic_cfg3_100M.csv")
+    if config != "cfg3" or n_reads != 100_000_000 or not os.path.exists(path):
+        return None
+    for line in open(path):
+        f = line.strip().split(",")
+        if f and f[0] == kernel:
+            return int(f[4])
+    return None
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -170,7 +185,8 @@ def main():
             "columns_per_step": job_columns, "sum_coverage_per_step": job_cov,
             "decode_Mreads_per_s_kernel_only": round(n_reads / (dec_ms * 1e-3) / 1e6, 2) if dec_ms else None,
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None},
+                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "algorithmic_bytes_per_launch": d["algorithmic_bytes"] // d["launches"],
+                         "traffic": pmc_traffic(dom, a.config, n_reads)},
             "kernels": per_kernel,
             "setup_s": round(gen_s, 2),
         }

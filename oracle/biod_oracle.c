@@ -835,23 +835,58 @@ typedef struct {
 
 static void plan_free(chunk_plan* p) { free(p->rec_off); free(p->ref); free(p->pos); free(p->endp); free(p->covered); free(p->pmax); free(p->chunks); }
 
-/* chunksConsumingLessThan, splitter.d:35-101 (size_in_bytes = 4 + block_size, read.d:609-611) */
-static int plan_build(chunk_plan* p, const uint8_t* s, uint64_t len, uint64_t chunk_bytes) {
+typedef struct { chunk_plan* p; uint64_t lo, hi; int rc; } fields_job;
+static void* fields_worker(void* arg) {
+    fields_job* j = (fields_job*)arg; chunk_plan* p = j->p;
+    for (uint64_t i = j->lo; i < j->hi; ++i) {
+        orc_fields f; orc_fields_at(p->s, p->rec_off[i], &f);
+        if (!record_well_formed(&f)) { j->rc = ORC_EINVAL; return NULL; }
+        p->ref[i] = f.ref_id; p->pos[i] = f.pos; p->endp[i] = f.end_pos; p->covered[i] = f.bases_covered;
+    }
+    return NULL;
+}
+
+/* chunksConsumingLessThan, splitter.d:35-101 (size_in_bytes = 4 + block_size, read.d:609-611).
+ * Framing stays one serial pass (it is a pointer chase; BioD's reader thread does the same); the
+ * per-record fields are computed on n_threads workers. */
+static int plan_build(chunk_plan* p, const uint8_t* s, uint64_t len, uint64_t chunk_bytes, int n_threads) {
     memset(p, 0, sizeof *p); p->s = s; p->len = len;
-    int64_t n = orc_frame(s, len, NULL, 0);
-    if (n < 0) return (int)n;
-    p->n = (uint64_t)n;
-    size_t a = (size_t)n + 1;
-    p->rec_off = (uint64_t*)malloc(a * 8); p->ref = (int32_t*)malloc(a * 4); p->pos = (int32_t*)malloc(a * 4);
+    {
+        size_t cap = 0; uint64_t off = 0, n = 0;
+        while (off < len) {                                   /* readrange.d:118-173 */
+            if (len - off < 4) break;
+            int32_t bs = rd_i32(s + off);
+            if (bs < 0) return ORC_EINVAL;
+            if ((uint64_t)bs > len - off - 4) return ORC_ETRUNC;
+            GROW(p->rec_off, cap, n + 2, uint64_t);
+            p->rec_off[n++] = off;
+            off += 4 + (uint64_t)bs;
+        }
+        p->n = n;
+    }
+    size_t a = (size_t)p->n + 1;
+    if (!p->rec_off) p->rec_off = (uint64_t*)malloc(8);
+    p->ref = (int32_t*)malloc(a * 4); p->pos = (int32_t*)malloc(a * 4);
     p->endp = (int32_t*)malloc(a * 4); p->covered = (int32_t*)malloc(a * 4); p->pmax = (int32_t*)malloc(a * 4);
     if (!p->rec_off || !p->ref || !p->pos || !p->endp || !p->covered || !p->pmax) return ORC_ENOMEM;
-    orc_frame(s, len, p->rec_off, p->n);
+    {
+        if (n_threads < 1) n_threads = 1;
+        if ((uint64_t)n_threads > p->n / 4096 + 1) n_threads = (int)(p->n / 4096 + 1);
+        pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * (size_t)n_threads);
+        fields_job* jobs = (fields_job*)calloc((size_t)n_threads, sizeof(fields_job));
+        if (!th || !jobs) { free(th); free(jobs); return ORC_ENOMEM; }
+        for (int t = 0; t < n_threads; ++t) {
+            jobs[t].p = p; jobs[t].lo = p->n * (uint64_t)t / (uint64_t)n_threads; jobs[t].hi = p->n * (uint64_t)(t + 1) / (uint64_t)n_threads;
+            pthread_create(&th[t], NULL, fields_worker, &jobs[t]);
+        }
+        int rc = ORC_OK;
+        for (int t = 0; t < n_threads; ++t) { pthread_join(th[t], NULL); if (jobs[t].rc) rc = jobs[t].rc; }
+        free(th); free(jobs);
+        if (rc) return rc;
+    }
     for (uint64_t i = 0; i < p->n; ++i) {
-        orc_fields f; orc_fields_at(s, p->rec_off[i], &f);
-        if (!record_well_formed(&f)) return ORC_EINVAL;
-        p->ref[i] = f.ref_id; p->pos[i] = f.pos; p->endp[i] = f.end_pos; p->covered[i] = f.bases_covered;
-        int32_t prev = (i > 0 && p->ref[i - 1] == f.ref_id) ? p->pmax[i - 1] : INT32_MIN;
-        int32_t mine = f.bases_covered > 0 ? f.end_pos : INT32_MIN;
+        int32_t prev = (i > 0 && p->ref[i - 1] == p->ref[i]) ? p->pmax[i - 1] : INT32_MIN;
+        int32_t mine = p->covered[i] > 0 ? p->endp[i] : INT32_MIN;
         p->pmax[i] = prev > mine ? prev : mine;
     }
     size_t cap = 0;
@@ -982,7 +1017,7 @@ int orc_pileup_bench(const uint8_t* stream, uint64_t len, int n_threads, uint64_
         return rc;
     }
     chunk_plan plan;
-    int rc = plan_build(&plan, stream, len, chunk_bytes);
+    int rc = plan_build(&plan, stream, len, chunk_bytes, n_threads);
     if (rc) { plan_free(&plan); out->status = rc; return rc; }
     pool_job job; memset(&job, 0, sizeof job);
     job.plan = &plan; job.bench_mode = 1;
@@ -1029,7 +1064,7 @@ int orc_pileup_chunked(const uint8_t* stream, uint64_t len, uint64_t chunk_bytes
     memset(out, 0, sizeof *out); out->pileup_ref_id = -1;
     if (chunk_bytes == 0) chunk_bytes = 16384000;
     chunk_plan plan;
-    int rc = plan_build(&plan, stream, len, chunk_bytes);
+    int rc = plan_build(&plan, stream, len, chunk_bytes, n_threads);
     if (rc) { plan_free(&plan); out->status = rc; return rc; }
     pool_job job; memset(&job, 0, sizeof job);
     job.plan = &plan; job.want_entries = want_entries;
