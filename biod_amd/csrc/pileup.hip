@@ -39,16 +39,19 @@ __device__ __forceinline__ uint64_t ref_key(int32_t ref_id) { return ref_id < 0 
 
 struct RunDev { int32_t ref_id; uint32_t pad; uint64_t first_record, end_record, start_pos, end_pos, column_base, tile_base; };
 
-struct K3Args { const bgp_record* rec; uint64_t n; uint64_t* key_end; uint64_t* key_pos; };
+struct K3Args { const bgp_record* rec; uint64_t n; uint64_t* key_end; uint64_t* key_pos; uint32_t* status; /* [3] any long read */ };
+
+constexpr int FAST_LSEQ = 160;         // reads up to 20 dwords of packed SEQ and 4 CIGAR ops take K4's lane = read path
+__device__ __forceinline__ bool is_long_read(uint32_t n_cig, uint32_t l_seq) { return n_cig > 4 || l_seq > (uint32_t)FAST_LSEQ; }
 
 __global__ __launch_bounds__(256) void k3_keys(K3Args a) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= a.n) return;
-    const bgp_record r = a.rec[i];
-    const bool cov = r.end_pos != r.pos;                         // basesCovered() > 0, pileup.d:481,510
+    bgp_record r{};
+    if (i < a.n) r = a.rec[i];
+    const bool cov = i < a.n && r.end_pos != r.pos;              // basesCovered() > 0, pileup.d:481,510
     const uint64_t rk = ref_key(r.ref_id) << 32;
-    a.key_end[i] = cov ? (rk | (uint32_t)r.end_pos) : 0;
-    a.key_pos[i] = cov ? (rk | (uint32_t)r.pos) : 0;
+    if (i < a.n) { a.key_end[i] = cov ? (rk | (uint32_t)r.end_pos) : 0; a.key_pos[i] = cov ? (rk | (uint32_t)r.pos) : 0; }
+    if (__ballot(cov && is_long_read(r.flag_nc & 0xFFFFu, (uint32_t)r.l_seq)) && (threadIdx.x & 63) == 0) atomicOr(&a.status[3], 1u);
 }
 
 struct K3bArgs { const bgp_record* rec; uint64_t n; const uint64_t* pmax_pos; RunDev* runs; uint32_t* status; /* [0] bits [2] n_runs */ unsigned long long* n_used; };
@@ -83,6 +86,7 @@ struct K4Args {
     const RunDev* runs; uint32_t n_runs; uint64_t n_tiles; uint64_t stream_len;
     bgp_column* cols; unsigned long long* hist; unsigned long long* pstats; /* [0] n_columns [1] sum_cov [2] max_cov */
     uint32_t* status; const struct TileB* tiles; unsigned long long* tile_stats;
+    const uint64_t* ck_off; const struct Ckpt* ck;      // long-read checkpoints (null when the stream has no long read)
 };
 
 __device__ __forceinline__ uint64_t lower_bound_gt(const uint64_t* a, uint64_t lo, uint64_t hi, uint64_t key) {   // first i in [lo,hi) with a[i] > key
@@ -112,6 +116,96 @@ __global__ __launch_bounds__(256) void k4_bounds(const uint64_t* pmax_end, const
     out[tile] = b;
 }
 
+// ---- long reads: CIGAR checkpoints ------------------------------------------------------------
+// A read with thousands of CIGAR ops overlaps many windows; walking its ops from the start in every
+// window is O(n_cigar) dependent loads per visit.  One pre-pass walks each long read ONCE, 64 ops per
+// coalesced load with a wave prefix scan over the ops' column / query lengths (the closed form of
+// pileup.d:175-222), and records for every window the read overlaps the cursor state
+// (op index, columns before it, query bases before it) of the op that owns the window's first column.
+struct Ckpt { uint32_t k, cs, qs, pad; };
+
+__device__ __forceinline__ uint32_t wave_incl_u32(uint32_t v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(v, d, 64); if (lane >= d) v += o; }
+    return v;
+}
+
+// column / query length an op contributes, given whether the cursor has started (pileup.d:180-189,196-217)
+__device__ __forceinline__ void op_lens(uint32_t op, bool active, bool started, uint32_t* rlen, uint32_t* qlen) {
+    const uint32_t len = op >> 4, qc = cig_qc(op), rc = cig_rc(op);
+    *rlen = 0; *qlen = 0;
+    if (!active) return;
+    if (started) { const uint32_t elen = len ? len : 1u; if (rc) { *rlen = elen; if (qc) *qlen = elen; } else if (qc) *qlen = len; }
+    else if (qc && !rc) *qlen = len;                               // leading S / I; a leading N contributes nothing
+}
+
+__device__ __forceinline__ uint32_t run_of_record(const RunDev* runs, uint32_t n_runs, uint64_t i) {
+    uint32_t lo = 0, hi = n_runs;
+    while (hi - lo > 1) { const uint32_t m = (lo + hi) >> 1; if (runs[m].first_record <= i) lo = m; else hi = m; }
+    return lo;
+}
+
+__global__ __launch_bounds__(256) void k4_ck_count(const bgp_record* rec, uint64_t n, const RunDev* runs, uint32_t n_runs, uint64_t* n_ck) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const bgp_record r = rec[i];
+    uint64_t c = 0;
+    if (r.end_pos != r.pos && is_long_read(r.flag_nc & 0xFFFFu, (uint32_t)r.l_seq)) {
+        const RunDev& run = runs[run_of_record(runs, n_runs, i)];
+        c = ((uint64_t)(uint32_t)r.end_pos - 1 - run.start_pos) / W - ((uint64_t)(uint32_t)r.pos - run.start_pos) / W + 1;
+    }
+    n_ck[i] = c;
+}
+
+__global__ __launch_bounds__(256) void k4_ck_build(const uint8_t* s, const bgp_record* rec, uint64_t n, const RunDev* runs, uint32_t n_runs,
+                                                   const uint64_t* ck_off, Ckpt* ck) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    bgp_record r{};
+    bool lng = false;
+    if (i < n) { r = rec[i]; lng = r.end_pos != r.pos && is_long_read(r.flag_nc & 0xFFFFu, (uint32_t)r.l_seq); }
+    unsigned long long m = __ballot(lng);
+    while (m) {
+        const int src = __ffsll((long long)m) - 1;
+        m &= m - 1;
+        const uint64_t ri = (uint64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63) + src;
+        const uint32_t pos = (uint32_t)__shfl(r.pos, src, 64), covered = (uint32_t)__shfl(r.end_pos, src, 64) - pos;
+        const uint32_t n_cig = (uint32_t)__shfl((int)r.flag_nc, src, 64) & 0xFFFFu, l_name = (uint32_t)__shfl((int)r.bin_mq_nl, src, 64) & 0xFFu;
+        const uint64_t rec_off = ((uint64_t)(uint32_t)__shfl((int)(r.rec_off >> 32), src, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)r.rec_off, src, 64);
+        const uint8_t* cg = s + rec_off + 36 + l_name;
+        const RunDev& run = runs[run_of_record(runs, n_runs, ri)];
+        const uint64_t t_first = ((uint64_t)pos - run.start_pos) / W;
+        const uint32_t n_ck = (uint32_t)(ck_off[ri + 1] - ck_off[ri]);
+        Ckpt* out = ck + ck_off[ri];
+        // window j (j >= 1) starts at column offset D + j*W of this read (D <= 0)
+        const int64_t D = (int64_t)(run.start_pos + t_first * W) - (int64_t)pos;
+        uint32_t cs = 0, qs = 0; bool started = false;
+        for (uint32_t c0 = 0; c0 < n_cig && cs < covered; c0 += 64) {
+            const bool active = c0 + lane < n_cig;
+            const uint32_t op = active ? ld_u32(cg + 4ull * (c0 + lane)) : 0u;
+            // the first reference-consuming non-N op starts the cursor (pileup.d:180-189)
+            int fl = 64;
+            if (!started) {
+                const unsigned long long st = __ballot(active && cig_rc(op) && (op & 15u) != 3u);
+                fl = st ? __ffsll((long long)st) - 1 : 64;
+            }
+            const bool lane_started = started || lane >= fl;
+            uint32_t rlen, qlen;
+            op_lens(op, active, lane_started, &rlen, &qlen);
+            const uint32_t ir = wave_incl_u32(rlen, lane), iq = wave_incl_u32(qlen, lane);
+            const uint32_t cs_b = cs + ir - rlen, qs_b = qs + iq - qlen;
+            if (rlen) {
+                if (cs_b == 0 && n_ck) { Ckpt e{c0 + (uint32_t)lane, 0u, qs_b, 0u}; out[0] = e; }      // window of the read's first column
+                int64_t j = (int64_t)cs_b - D <= 0 ? 1 : ((int64_t)cs_b - D + W - 1) / W;              // first window starting at/after cs_b
+                if (j < 1) j = 1;
+                for (; j < (int64_t)n_ck && D + j * W < (int64_t)(cs_b + rlen); ++j) { Ckpt e{c0 + (uint32_t)lane, cs_b, qs_b, 0u}; out[j] = e; }
+            }
+            cs += __shfl(ir, 63, 64); qs += __shfl(iq, 63, 64);
+            started = started || fl < 64;
+        }
+    }
+}
+
 // ---- K4: per-position column summary ----------------------------------------------------------
 // LDS tile (u32 words): cnt[5][W] (A,C,G,T,other) | deld[W+4] ('-' as a difference array: +1 where a
 // D/N op starts, -1 where it ends, summed at flush) | nst[W] (n_starting_here) | hist[HB] | list[LCAP].
@@ -133,7 +227,6 @@ constexpr int HIST = 7 * W + 4;
 constexpr int LIST = HIST + HB;
 constexpr int LCAP = 2048;
 constexpr int LDS_WORDS = LIST + LCAP;
-constexpr int FAST_LSEQ = 160;         // 20 dwords of packed SEQ per lane
 
 __device__ __forceinline__ uint32_t rl(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
 
@@ -199,6 +292,90 @@ __device__ __forceinline__ void pile_read_coop(const K4Args& a, uint32_t* lds, u
         cs += elen;
     }
     if (k == n_cig && cs < need_hi && lane == 0) atomicOr(a.status, ST_ECIGAR);   // assertCigarIndexIsValid, pileup.d:224-228
+}
+
+// Long read against the window: resume from the window's checkpoint and take the CIGAR 64 ops at a
+// time with LANE = OP.  A wave prefix scan over the ops' column / query lengths gives every lane its
+// op's first column and first query base; D/N ops are two adds on the difference array per lane; the
+// M/=/X ops of the chunk are then stepped together (step t = base t of every lane's op), their bases
+// looked up with ds_bpermute in a 1024-base window of packed SEQ held two dwords per lane.
+// An op longer than 64 columns (rare in indel-dense long reads) is handed to the lanes-along-the-read
+// walk of pile_read_coop's inner loop.
+__device__ __forceinline__ void pile_read_long(const K4Args& a, uint32_t* lds, uint32_t T0, uint32_t Tend, int lane,
+                                               uint32_t pos, uint32_t covered, uint32_t n_cig, uint32_t l_seq, uint64_t cig_off, Ckpt ck) {
+    const uint64_t seq_off = cig_off + 4ull * n_cig;
+    const uint32_t seq_bytes = (l_seq + 1) / 2;
+    const uint32_t need_hi = min(covered, Tend - pos), need_lo = T0 > pos ? T0 - pos : 0;
+    if (ck.k == 0xFFFFFFFFu) { if (lane == 0 && need_lo < need_hi) atomicOr(a.status, ST_ECIGAR); return; }   // cursor ran off before this window
+    uint32_t cs = ck.cs, qs = ck.qs;
+    uint32_t c0 = ck.k;
+    for (; c0 < n_cig && cs < need_hi; c0 += 64) {
+        const bool active = c0 + lane < n_cig;
+        const uint32_t op = active ? ld_u32(a.s + cig_off + 4ull * (c0 + lane)) : 0u;
+        uint32_t rlen, qlen;
+        op_lens(op, active, true, &rlen, &qlen);
+        const uint32_t ir = wave_incl_u32(rlen, lane), iq = wave_incl_u32(qlen, lane);
+        const uint32_t cs_b = cs + ir - rlen, qs_b = qs + iq - qlen;
+        const uint32_t lo = max(cs_b, need_lo), hi = min(cs_b + rlen, need_hi);
+        const bool in_win = rlen && lo < hi;
+        const bool is_m = cig_qc(op) != 0;
+        if (in_win && !is_m) {                                                   // D, N: '-' over [lo, hi), pileup.d:119-121
+            atomicAdd(&lds[DELD + (pos + lo - T0)], 1u);
+            atomicAdd(&lds[DELD + (pos + hi - T0)], 0xFFFFFFFFu);
+        }
+        const uint32_t mlen = (in_win && is_m) ? hi - lo : 0u;
+        uint32_t maxlen = mlen;
+        for (int d = 32; d >= 1; d >>= 1) maxlen = max(maxlen, (uint32_t)__shfl_xor((int)maxlen, d, 64));
+        if (maxlen) {
+            const uint32_t q_first = qs_b + (lo - cs_b);                           // query offset of this lane's first base in the window
+            // query span of the chunk's M bases
+            uint32_t qmin = mlen ? q_first : 0xFFFFFFFFu, qmax = mlen ? q_first + mlen - 1 : 0u;
+            for (int d = 32; d >= 1; d >>= 1) { qmin = min(qmin, (uint32_t)__shfl_xor((int)qmin, d, 64)); qmax = max(qmax, (uint32_t)__shfl_xor((int)qmax, d, 64)); }
+            if (maxlen <= 64 && (qmax >> 3) - (qmin >> 3) < 128) {
+                const uint32_t win0 = qmin >> 3;
+                const uint32_t wa = load_seq_words(a.s, a.stream_len, seq_off, seq_bytes, win0, lane);
+                const uint32_t wb = load_seq_words(a.s, a.stream_len, seq_off, seq_bytes, win0 + 64, lane);
+                for (uint32_t t = 0; t < maxlen; ++t) {
+                    const uint32_t q = q_first + t;
+                    const uint32_t idx = (q >> 3) - win0;
+                    const uint32_t va = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((idx & 63u) << 2), (int)wa);
+                    const uint32_t vb = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((idx & 63u) << 2), (int)wb);
+                    if (t < mlen) {
+                        uint32_t cls = 4;
+                        if (q < l_seq) {
+                            const uint32_t wv = idx < 64 ? va : vb;
+                            const uint32_t byte = (wv >> (((q >> 1) & 3u) * 8)) & 0xFFu;
+                            cls = base_class((q & 1u) ? (byte & 0xFu) : (byte >> 4));       // read.d:368-373
+                        } else atomicOr(a.status, ST_ESEQ);
+                        atomicAdd(&lds[cls * W + (pos + lo + t - T0)], 1u);
+                    }
+                }
+            } else {
+                // long M ops: one op at a time with lanes along the read
+                unsigned long long mm = __ballot(mlen != 0);
+                while (mm) {
+                    const int o = __ffsll((long long)mm) - 1;
+                    mm &= mm - 1;
+                    const uint32_t olo = rl(lo, o), ohi = rl(hi, o), oq = rl(q_first, o);
+                    uint32_t win0 = 0xFFFFFFFFu, words = 0;
+                    for (uint32_t r0 = olo; r0 < ohi; r0 += 64) {
+                        const uint32_t qa = oq + (r0 - olo), qb = qa + min(ohi - r0, 64u) - 1;
+                        if (win0 == 0xFFFFFFFFu || (qa >> 3) < win0 || (qb >> 3) >= win0 + 64) { win0 = qa >> 3; words = load_seq_words(a.s, a.stream_len, seq_off, seq_bytes, win0, lane); }
+                        const uint32_t q = qa + lane;
+                        const uint32_t wv = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((q >> 3) - win0) << 2), (int)words);
+                        if (r0 + lane < ohi) {
+                            uint32_t cls = 4;
+                            if (q < l_seq) { const uint32_t byte = (wv >> (((q >> 1) & 3u) * 8)) & 0xFFu; cls = base_class((q & 1u) ? (byte & 0xFu) : (byte >> 4)); }
+                            else atomicOr(a.status, ST_ESEQ);
+                            atomicAdd(&lds[cls * W + (pos + r0 + lane - T0)], 1u);
+                        }
+                    }
+                }
+            }
+        }
+        cs += __shfl(ir, 63, 64); qs += __shfl(iq, 63, 64);
+    }
+    if (c0 >= n_cig && cs < need_hi && lane == 0) atomicOr(a.status, ST_ECIGAR);      // assertCigarIndexIsValid, pileup.d:224-228
 }
 
 __global__ __launch_bounds__(K4_T) void k4_tile(K4Args a) {
@@ -346,7 +523,14 @@ __global__ __launch_bounds__(K4_T) void k4_tile(K4Args a) {
                 const int r = __ffsll((long long)slow) - 1;
                 slow &= slow - 1;
                 const uint64_t co = ((uint64_t)rl((uint32_t)(cig_off >> 32), r) << 32) | rl((uint32_t)cig_off, r);
-                pile_read_coop(a, lds, T0, Tend, lane, rl(pos, r), rl(covered, r), rl(n_cig, r), rl(l_seq, r), co);
+                const uint32_t rpos = rl(pos, r), rncig = rl(n_cig, r), rlseq = rl(l_seq, r);
+                if (a.ck && is_long_read(rncig, rlseq)) {
+                    const uint64_t ri = i_lo + list[b0 + r];
+                    const uint64_t j = (uint64_t)(T0 - (uint32_t)run.start_pos) / W - ((uint64_t)rpos - run.start_pos) / W;   // window index within the read
+                    const Ckpt ck = a.ck[a.ck_off[ri] + j];
+                    pile_read_long(a, lds, T0, Tend, lane, rpos, rl(covered, r), rncig, rlseq, co, ck);
+                } else
+                    pile_read_coop(a, lds, T0, Tend, lane, rpos, rl(covered, r), rncig, rlseq, co);
             }
         }
         __syncthreads();
@@ -502,7 +686,7 @@ int k34_pileup(bgp_ctx* c) {
     unsigned long long* n_used = (unsigned long long*)(c->d_pstats.as<uint64_t>() + 4);
     {
         TimedRegion t(c, "k3_keys_scan", n * (32 + 16 + 32));
-        K3Args a{c->d_rec.as<bgp_record>(), n, c->d_pmax_end.as<uint64_t>(), c->d_pmax_pos.as<uint64_t>()};
+        K3Args a{c->d_rec.as<bgp_record>(), n, c->d_pmax_end.as<uint64_t>(), c->d_pmax_pos.as<uint64_t>(), status};
         hipLaunchKernelGGL(k3_keys, dim3(nb), dim3(256), 0, c->stream, a);
         BGP_TRY(scan_inclusive_max_u64(c, a.key_end, a.key_end, n));
         BGP_TRY(scan_inclusive_max_u64(c, a.key_pos, a.key_pos, n));
@@ -558,6 +742,19 @@ int k34_pileup(bgp_ctx* c) {
         }
         BGP_TRY(c->d_col_lo.reserve(tile_base * 32));
         a.tile_stats = (unsigned long long*)c->d_col_lo.p;
+        a.ck = nullptr; a.ck_off = nullptr;
+        if (st[3]) {                                   // the stream holds long reads: build their per-window CIGAR checkpoints
+            TimedRegion tc(c, "k4_checkpoints", c->sum_ncig * 4);
+            BGP_TRY(c->d_ck_off.reserve((n + 2) * 8));
+            uint64_t* ck_off = c->d_ck_off.as<uint64_t>();
+            hipLaunchKernelGGL(k4_ck_count, dim3(nb), dim3(256), 0, c->stream, a.rec, n, a.runs, n_runs, ck_off);
+            uint64_t total_ck = 0;
+            BGP_TRY(scan_exclusive_u64(c, ck_off, ck_off, n, &total_ck));
+            BGP_TRY(c->d_ck.reserve((total_ck + 1) * sizeof(Ckpt)));
+            BGP_HIP(hipMemsetAsync(c->d_ck.p, 0xFF, (total_ck + 1) * sizeof(Ckpt), c->stream));
+            hipLaunchKernelGGL(k4_ck_build, dim3(nb), dim3(256), 0, c->stream, a.s, a.rec, n, a.runs, n_runs, ck_off, c->d_ck.as<Ckpt>());
+            a.ck = c->d_ck.as<Ckpt>(); a.ck_off = ck_off;
+        }
         TimedRegion t(c, "k4_tile", used);
         hipLaunchKernelGGL(k4_tile, dim3((unsigned)grid), dim3(K4_T), lds_bytes, c->stream, a);
         hipLaunchKernelGGL(k4_stats, dim3(32), dim3(256), 0, c->stream, a.tile_stats, tile_base, a.pstats);
