@@ -22,6 +22,8 @@ namespace {
 
 constexpr uint64_t NONE = ~0ull;        // entry/end not known (speculation found nothing)
 constexpr uint64_t STOP = ~0ull - 1;    // chain is over (error upstream); segment holds no records
+constexpr uint32_t ST_LONGCIG = 1u << 16; // not an error: some record has more than LONG_CIGAR ops
+constexpr uint32_t LONG_CIGAR = 32;     // more ops than this: basesCovered is summed by a whole wave (k1_long_cigar)
 
 struct FrameArgs {
     const uint8_t* s; uint64_t len; uint32_t seg_bytes; uint64_t n_seg; int32_t ref_bound;
@@ -82,6 +84,7 @@ __global__ __launch_bounds__(256) void k0_chase(FrameArgs a) {
     const uint64_t seg_end = min((k + 1) * (uint64_t)a.seg_bytes, a.len);
     uint64_t off = a.entry[k], cnt = 0, ls = 0, nc = 0;
     uint32_t err = 0;
+    bool long_seen = false;
     if (off == NONE || off == STOP) { a.end[k] = off; a.cnt[k] = 0; a.lseq[k] = 0; a.ncig[k] = 0; a.seg_err[k] = 0; return; }
     while (off < seg_end) {
         if (a.len - off < 4) { off = a.len; break; }                       // readrange.d:139-149: short prefix ends the range
@@ -94,8 +97,10 @@ __global__ __launch_bounds__(256) void k0_chase(FrameArgs a) {
         const uint32_t l_name = bmn & 0xFFu, n_cig = fnc & 0xFFFFu;
         if (lseq < 0 || l_name == 0 || 32ull + l_name + 4ull * n_cig + (uint64_t)((lseq + 1) / 2) + (uint64_t)lseq > (uint64_t)bs) { err = ST_EINVAL; break; }
         ++cnt; ls += (uint64_t)lseq; nc += n_cig;
+        long_seen |= n_cig > LONG_CIGAR;
         off += 4 + (uint64_t)bs;
     }
+    if (long_seen) atomicOr(&a.status[0], ST_LONGCIG);
     a.end[k] = err ? STOP : off;
     a.cnt[k] = cnt; a.lseq[k] = ls; a.ncig[k] = nc; a.seg_err[k] = err;
 }
@@ -151,7 +156,7 @@ __global__ __launch_bounds__(256) void k1_emit(EmitArgs a) {
         rec.rec_off = off;
         const uint32_t l_name = rec.bin_mq_nl & 0xFFu, n_cig = rec.flag_nc & 0xFFFFu;
         uint32_t covered = 0;
-        if (!((rec.flag_nc >> 16) & 0x4u)) {                      // read.d:257-259 is_unmapped -> 0
+        if (!((rec.flag_nc >> 16) & 0x4u) && n_cig <= LONG_CIGAR) { // read.d:257-259 is_unmapped -> 0; long CIGARs: k1_long_cigar
             const uint8_t* cg = p + 36 + l_name;                  // read.d:988-990 _cigar_offset
             for (uint32_t j = 0; j < n_cig; ++j) {
                 const uint32_t op = ld_u32(cg + 4 * j);
@@ -165,6 +170,30 @@ __global__ __launch_bounds__(256) void k1_emit(EmitArgs a) {
         so += (uint64_t)rec.l_seq; co += n_cig; ++r;
         off += 4 + (uint64_t)bs;
     }
+}
+
+// basesCovered() of records with long CIGARs (read.d:255-262): a lane summing thousands of ops serially
+// stalls its whole wave in k1_emit, so those records are finished here, one wave per record, 64 ops per
+// coalesced load and a wave reduction.
+__global__ __launch_bounds__(256) void k1_long_cigar(const uint8_t* s, bgp_record* rec, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    bgp_record r{};
+    bool lng = false;
+    if (i < n) { r = rec[i]; lng = (r.flag_nc & 0xFFFFu) > LONG_CIGAR && !((r.flag_nc >> 16) & 0x4u); }
+    unsigned long long m = __ballot(lng);
+    while (m) {
+        const int src = __ffsll((long long)m) - 1;
+        m &= m - 1;
+        const uint32_t n_cig = (uint32_t)__shfl((int)r.flag_nc, src, 64) & 0xFFFFu, l_name = (uint32_t)__shfl((int)r.bin_mq_nl, src, 64) & 0xFFu;
+        const uint64_t rec_off = ((uint64_t)(uint32_t)__shfl((int)(r.rec_off >> 32), src, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)r.rec_off, src, 64);
+        const uint8_t* cg = s + rec_off + 36 + l_name;
+        uint32_t acc = 0;
+        for (uint32_t j = lane; j < n_cig; j += 64) { const uint32_t op = ld_u32(cg + 4ull * j); acc += cig_rc(op) ? (op >> 4) : 0u; }
+        for (int d = 32; d >= 1; d >>= 1) acc += (uint32_t)__shfl_xor((int)acc, d, 64);
+        if (lane == src) r.end_pos = (int32_t)((uint32_t)r.pos + acc);     // read.d:1382
+    }
+    if (lng) rec[i].end_pos = r.end_pos;
 }
 
 uint32_t pow2_ceil(uint64_t v) { uint32_t p = 1; while (p < v && p < (1u << 30)) p <<= 1; return p; }
@@ -256,6 +285,8 @@ int k0_frame(bgp_ctx* c) {
     {
         TimedRegion t(c, "k1_emit", n * (36 + 32 + 16) + sc * 4);
         hipLaunchKernelGGL(k1_emit, dim3(lane_blocks), dim3(256), 0, c->stream, e);
+        if (bits & ST_LONGCIG)            // only streams that hold a long CIGAR pay for the extra pass
+            hipLaunchKernelGGL(k1_long_cigar, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->d_stream, e.rec, n);
     }
     BGP_HIP(hipGetLastError());
     return BGP_OK;
