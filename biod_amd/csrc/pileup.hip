@@ -226,7 +226,8 @@ constexpr int NST = 6 * W + 4;
 constexpr int HIST = 7 * W + 4;
 constexpr int LIST = HIST + HB;
 constexpr int LCAP = 2048;
-constexpr int LDS_WORDS = LIST + LCAP;
+constexpr int SLIST = LIST + LCAP;       // second list: reads for the wave-cooperative paths
+constexpr int LDS_WORDS = SLIST + LCAP;
 
 __device__ __forceinline__ uint32_t rl(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
 
@@ -381,6 +382,7 @@ __device__ __forceinline__ void pile_read_long(const K4Args& a, uint32_t* lds, u
 __global__ __launch_bounds__(K4_T) void k4_tile(K4Args a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     __shared__ uint32_t s_n;           // entries in the LDS list
+    __shared__ uint32_t s_nslow;       // entries in the second list
     __shared__ uint32_t wsum[K4_T / 64];
     // XCD-aware order: consecutive tiles of a reference go to the same XCD (block b runs on XCD b % 8)
     const uint64_t nb = a.n_tiles;
@@ -398,9 +400,10 @@ __global__ __launch_bounds__(K4_T) void k4_tile(K4Args a) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     uint32_t* list = lds + LIST;
+    uint32_t* slist = lds + SLIST;
 
     for (uint64_t scan = i_lo; scan < i_hi;) {
-        if (threadIdx.x == 0) s_n = 0;
+        if (threadIdx.x == 0) { s_n = 0; s_nslow = 0; }
         __syncthreads();
         // ---- scan: compact the reads that overlap the window
         for (;;) {
@@ -518,20 +521,32 @@ __global__ __launch_bounds__(K4_T) void k4_tile(K4Args a) {
                 }
             }
             // everything else, one read at a time with lanes along the read
-            unsigned long long slow = __ballot(have && !fast);
-            while (slow) {
-                const int r = __ffsll((long long)slow) - 1;
-                slow &= slow - 1;
-                const uint64_t co = ((uint64_t)rl((uint32_t)(cig_off >> 32), r) << 32) | rl((uint32_t)cig_off, r);
-                const uint32_t rpos = rl(pos, r), rncig = rl(n_cig, r), rlseq = rl(l_seq, r);
-                if (a.ck && is_long_read(rncig, rlseq)) {
-                    const uint64_t ri = i_lo + list[b0 + r];
-                    const uint64_t j = (uint64_t)(T0 - (uint32_t)run.start_pos) / W - ((uint64_t)rpos - run.start_pos) / W;   // window index within the read
-                    const Ckpt ck = a.ck[a.ck_off[ri] + j];
-                    pile_read_long(a, lds, T0, Tend, lane, rpos, rl(covered, r), rncig, rlseq, co, ck);
-                } else
-                    pile_read_coop(a, lds, T0, Tend, lane, rpos, rl(covered, r), rncig, rlseq, co);
+            // everything else goes to a second list so that ALL waves share it (a window's long reads
+            // would otherwise sit in one batch and be walked by one wave while seven idle)
+            const bool is_slow = have && !fast;
+            const unsigned long long sm = __ballot(is_slow);
+            if (sm) {
+                uint32_t slot = 0;
+                if (lane == 0) slot = atomicAdd(&s_nslow, (uint32_t)__popcll(sm));
+                slot = rl(slot, 0);
+                if (is_slow) slist[slot + __popcll(sm & ((1ull << lane) - 1))] = list[b0 + lane];
             }
+        }
+        __syncthreads();
+        // one read at a time per wave, whole wave on the read
+        const uint32_t n_slow = s_nslow;
+        for (uint32_t j = (uint32_t)wave; j < n_slow; j += K4_T / 64) {
+            const uint64_t ri = i_lo + slist[j];
+            const uint4* rp = reinterpret_cast<const uint4*>(a.rec + ri);
+            const uint4 x = rp[0], y = rp[1];
+            const uint32_t rpos = rl(x.y, 0), rcov = rl(x.z - x.y, 0), rncig = rl(y.x & 0xFFFFu, 0), rlseq = rl(y.y, 0);
+            const uint64_t co = (((uint64_t)rl(y.w, 0) << 32) | rl(y.z, 0)) + 36 + rl(x.w & 0xFFu, 0);
+            if (a.ck && is_long_read(rncig, rlseq)) {
+                const uint64_t wj = (uint64_t)(T0 - (uint32_t)run.start_pos) / W - ((uint64_t)rpos - run.start_pos) / W;   // window index within the read
+                const Ckpt ck = a.ck[a.ck_off[ri] + wj];
+                pile_read_long(a, lds, T0, Tend, lane, rpos, rcov, rncig, rlseq, co, ck);
+            } else
+                pile_read_coop(a, lds, T0, Tend, lane, rpos, rcov, rncig, rlseq, co);
         }
         __syncthreads();
     }
