@@ -8,7 +8,13 @@
 // The same third-party arithmetic as the reference: system zlib (bio/core/utils/zlib.d:6-245).
 #include "common.h"
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
+
+#include <algorithm>
 
 #include <atomic>
 #include <cstdio>
@@ -70,58 +76,83 @@ int inflate_block(const uint8_t* f, const Blk& b, uint8_t* dst) {         // blo
 
 }  // namespace
 
+// BAM magic + header text + reference table (reader.d:111-116,579-597) from the first `avail` inflated bytes.
+// Returns 1 and the offset of the first record when complete, 0 when more bytes are needed, <0 on error.
+static int parse_bam_header(const uint8_t* p, uint64_t avail, std::vector<RefInfo>& refs, uint64_t* records_off, std::string& err) {
+    if (avail < 12) return 0;
+    if (memcmp(p, "BAM\1", 4) != 0) { err = "wrong BAM magic"; return BGP_EINVAL; }
+    int32_t l_text; memcpy(&l_text, p + 4, 4);
+    if (l_text < 0) { err = "negative header length"; return BGP_EINVAL; }
+    uint64_t q = 8 + (uint64_t)(uint32_t)l_text;
+    if (q + 4 > avail) return 0;
+    int32_t n_ref; memcpy(&n_ref, p + q, 4); q += 4;
+    if (n_ref < 0) { err = "negative reference count"; return BGP_EINVAL; }
+    refs.clear();
+    for (int32_t i = 0; i < n_ref; ++i) {
+        if (q + 4 > avail) return 0;
+        int32_t l_name; memcpy(&l_name, p + q, 4); q += 4;
+        if (l_name < 1) { err = "bad reference name length"; return BGP_EINVAL; }
+        if (q + (uint64_t)l_name + 4 > avail) return 0;
+        RefInfo ri; ri.name.assign((const char*)p + q, (size_t)l_name - 1); q += (uint64_t)l_name;
+        memcpy(&ri.length, p + q, 4); q += 4;
+        refs.push_back(ri);
+    }
+    *records_off = q;
+    return 1;
+}
+
 int bgzf_load_bam(bgp_ctx* c, const char* path, int n_threads) {
-    FILE* fp = fopen(path, "rb");
-    if (!fp) { c->last_error = std::string("cannot open ") + path; return BGP_EINVAL; }
-    fseek(fp, 0, SEEK_END); const long fsz = ftell(fp); fseek(fp, 0, SEEK_SET);
-    std::vector<uint8_t> file((size_t)fsz);
-    if (fsz && fread(file.data(), 1, (size_t)fsz, fp) != (size_t)fsz) { fclose(fp); c->last_error = "short read"; return BGP_EINVAL; }
-    fclose(fp);
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) { c->last_error = std::string("cannot open ") + path; return BGP_EINVAL; }
+    struct stat sb;
+    if (fstat(fd, &sb) != 0) { close(fd); c->last_error = "fstat failed"; return BGP_EINVAL; }
+    const size_t fsz = (size_t)sb.st_size;
+    const uint8_t* file = fsz ? (const uint8_t*)mmap(nullptr, fsz, PROT_READ, MAP_PRIVATE, fd, 0) : nullptr;
+    close(fd);
+    if (fsz && file == (const uint8_t*)MAP_FAILED) { c->last_error = "mmap failed"; return BGP_EINVAL; }
+    struct Unmap { const uint8_t* p; size_t n; ~Unmap() { if (p && n) munmap((void*)p, n); } } unmap{file, fsz};
+
     std::vector<Blk> blocks;
-    int rc = parse_blocks(file.data(), file.size(), blocks, c->last_error);
+    int rc = parse_blocks(file, fsz, blocks, c->last_error);
     if (rc < 0) return rc;
     const uint64_t total = blocks.empty() ? 0 : blocks.back().uoff + blocks.back().isize;
-    std::vector<uint8_t> inflated((size_t)total + 16);
+
+    // the header lives in the first block(s): inflate serially until it parses
+    std::vector<uint8_t> head;
+    uint64_t q = 0; size_t jh = 0; int got = 0;
+    while (jh < blocks.size() && got == 0) {
+        head.resize((size_t)(blocks[jh].uoff + blocks[jh].isize));
+        rc = inflate_block(file, blocks[jh], head.data() + blocks[jh].uoff);
+        if (rc < 0) { c->last_error = "zlib: corrupted BGZF block"; return rc; }
+        ++jh;
+        got = parse_bam_header(head.data(), head.size(), c->refs, &q, c->last_error);
+        if (got < 0) return got;
+    }
+    if (got == 0) { c->last_error = total < 4 ? "wrong BAM magic" : "truncated BAM header"; return total < 4 ? BGP_EINVAL : BGP_ETRUNC; }
+    c->n_ref_hint = (int32_t)c->refs.size();
+
+    // every worker inflates straight into the pinned staging buffer (record byte b lands at b - q)
+    const uint64_t rec_bytes = total - q;
+    BGP_TRY(c->h_stage.reserve_keep(c->h_stage_len + rec_bytes + 16, c->h_stage_len));
+    uint8_t* dst = c->h_stage.as<uint8_t>() + c->h_stage_len;
+    if (head.size() > q) memcpy(dst, head.data() + q, head.size() - (size_t)q);       // tail of the last header block
     if (n_threads <= 0) n_threads = (int)std::thread::hardware_concurrency();
     if (n_threads < 1) n_threads = 1;
-    std::atomic<size_t> next{0}; std::atomic<int> status{BGP_OK};
+    std::atomic<size_t> next{jh}; std::atomic<int> status{BGP_OK};
     auto worker = [&]() {
         for (;;) {
             const size_t j = next.fetch_add(1);
             if (j >= blocks.size() || status.load() < 0) return;
-            const int e = inflate_block(file.data(), blocks[j], inflated.data() + blocks[j].uoff);
+            const int e = inflate_block(file, blocks[j], dst + (blocks[j].uoff - q));
             if (e < 0) status.store(e);
         }
     };
     std::vector<std::thread> th;
-    for (int t = 1; t < n_threads; ++t) th.emplace_back(worker);
+    const int nt = (int)std::min<size_t>((size_t)n_threads, blocks.size() - jh + 1);
+    for (int t = 1; t < nt; ++t) th.emplace_back(worker);
     worker();
     for (auto& t : th) t.join();
     if (status.load() < 0) { c->last_error = "zlib: corrupted BGZF block"; return status.load(); }
-
-    // BAM header, reader.d:111-116,579-597
-    const uint8_t* p = inflated.data();
-    if (total < 12 || memcmp(p, "BAM\1", 4) != 0) { c->last_error = "wrong BAM magic"; return BGP_EINVAL; }
-    int32_t l_text; memcpy(&l_text, p + 4, 4);
-    uint64_t q = 8 + (uint64_t)(uint32_t)l_text;
-    if (l_text < 0 || q + 4 > total) { c->last_error = "truncated BAM header"; return BGP_ETRUNC; }
-    int32_t n_ref; memcpy(&n_ref, p + q, 4); q += 4;
-    c->refs.clear();
-    for (int32_t i = 0; i < n_ref; ++i) {
-        if (q + 4 > total) return BGP_ETRUNC;
-        int32_t l_name; memcpy(&l_name, p + q, 4); q += 4;
-        if (l_name < 1 || q + (uint64_t)l_name + 4 > total) return BGP_ETRUNC;
-        RefInfo ri; ri.name.assign((const char*)p + q, (size_t)l_name - 1); q += (uint64_t)l_name;
-        memcpy(&ri.length, p + q, 4); q += 4;
-        c->refs.push_back(ri);
-    }
-    c->n_ref_hint = n_ref;
-    // hand the record bytes over block by block (coffset / first-record hints are advisory)
-    size_t j = 0;
-    while (j < blocks.size() && blocks[j].uoff + blocks[j].isize <= q) ++j;
-    for (; j < blocks.size(); ++j) {
-        const uint64_t b0 = std::max<uint64_t>(blocks[j].uoff, q), b1 = blocks[j].uoff + blocks[j].isize;
-        if (b1 > b0) BGP_TRY(bgp_push_inflated(c, p + b0, (size_t)(b1 - b0), blocks[j].coff, BGP_UOFFSET_UNKNOWN));
-    }
+    c->h_stage_len += rec_bytes;
     return BGP_OK;
 }

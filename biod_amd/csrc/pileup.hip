@@ -406,22 +406,31 @@ __global__ __launch_bounds__(K4_T) void k4_tile(K4Args a) {
         if (threadIdx.x == 0) { s_n = 0; s_nslow = 0; }
         __syncthreads();
         // ---- scan: compact the reads that overlap the window
-        for (;;) {
-            const uint64_t i = scan + threadIdx.x;
-            bool valid = false;
-            if (i < i_hi) {
-                const uint4 x = *reinterpret_cast<const uint4*>(a.rec + i);     // ref_id, pos, end_pos, bin_mq_nl
-                valid = x.z != x.y && x.z > T0 && x.y < Tend;                   // basesCovered() > 0 and overlaps the window
-                if (valid && x.y >= T0) atomicAdd(&lds[NST + (x.y - T0)], 1u);  // n_starting_here, pileup.d:386,422
+        for (bool more = true; more;) {
+            // four rounds of candidate rows are requested before the first is looked at: one HBM round trip, not four
+            uint4 xs[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const uint64_t i = scan + (uint64_t)r * K4_T + threadIdx.x;
+                xs[r] = make_uint4(0, 0, 0, 0);
+                if (i < i_hi) xs[r] = *reinterpret_cast<const uint4*>(a.rec + i);   // ref_id, pos, end_pos, bin_mq_nl
             }
-            const unsigned long long m = __ballot(valid);
-            uint32_t slot = 0;
-            if (lane == 0 && m) slot = atomicAdd(&s_n, (uint32_t)__popcll(m));
-            slot = rl(slot, 0);
-            if (valid) list[slot + __popcll(m & ((1ull << lane) - 1))] = (uint32_t)(i - i_lo);
-            scan += K4_T;
-            __syncthreads();
-            if (scan >= i_hi || s_n > LCAP - K4_T) break;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (!more) break;
+                const uint64_t i = scan + threadIdx.x;
+                const uint4 x = xs[r];
+                const bool valid = i < i_hi && x.z != x.y && x.z > T0 && x.y < Tend;   // basesCovered() > 0 and overlaps the window
+                if (valid && x.y >= T0) atomicAdd(&lds[NST + (x.y - T0)], 1u);      // n_starting_here, pileup.d:386,422
+                const unsigned long long m = __ballot(valid);
+                uint32_t slot = 0;
+                if (lane == 0 && m) slot = atomicAdd(&s_n, (uint32_t)__popcll(m));
+                slot = rl(slot, 0);
+                if (valid) list[slot + __popcll(m & ((1ull << lane) - 1))] = (uint32_t)(i - i_lo);
+                scan += K4_T;
+                __syncthreads();
+                if (scan >= i_hi || s_n > LCAP - K4_T) more = false;
+            }
         }
         const uint32_t n_list = s_n;
         // ---- process: 64 listed reads per wave, lane = read
@@ -471,20 +480,25 @@ __global__ __launch_bounds__(K4_T) void k4_tile(K4Args a) {
             if (maxq || __ballot(fast)) {
                 const uint32_t need_hi = min(covered, Tend - pos), need_lo = T0 > pos ? T0 - pos : 0;
                 const uint32_t colbase = pos - T0;                         // wraps for pos < T0; sums below are exact mod 2^32
-                uint32_t sq[4], sl[4], sb[4];
+                // slots are COMPACT: slot m = the m-th M/=/X interval of the lane that touches the window
+                // (ordinary reads have one or two), so the hot loop below tests as few slots as possible
+                uint32_t sq[4] = {0, 0, 0, 0}, sl[4] = {0, 0, 0, 0}, sb[4] = {0, 0, 0, 0};
                 {
-                    uint32_t q = 0, p = 0;
+                    uint32_t q = 0, p = 0, m = 0;
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
-                        sq[k] = 0; sl[k] = 0; sb[k] = 0;
                         const uint32_t op = k == 0 ? o0 : k == 1 ? o1 : k == 2 ? o2 : o3;
                         if (fast && (uint32_t)k < n_cig) {
                             const uint32_t len = op >> 4, qc = cig_qc(op), rc = cig_rc(op);
                             if (rc) {
                                 const uint32_t lo = max(p, need_lo), hi = min(p + len, need_hi);   // columns of this op inside the window
                                 if (lo < hi) {
-                                    if (qc) { sq[k] = q + (lo - p); sl[k] = hi - lo; sb[k] = (colbase + p - q) * 4; }   // pileup.d:117-118
-                                    else { atomicAdd(&lds[DELD + colbase + lo], 1u); atomicAdd(&lds[DELD + colbase + hi], 0xFFFFFFFFu); }   // pileup.d:119-121
+                                    if (qc) {                                                       // pileup.d:117-118
+                                        const uint32_t vq = q + (lo - p), vl = hi - lo, vb = (colbase + p - q) * 4;
+#pragma unroll
+                                        for (int j = 0; j <= k; ++j) if (m == (uint32_t)j) { sq[j] = vq; sl[j] = vl; sb[j] = vb; }
+                                        ++m;
+                                    } else { atomicAdd(&lds[DELD + colbase + lo], 1u); atomicAdd(&lds[DELD + colbase + hi], 0xFFFFFFFFu); }   // pileup.d:119-121
                                 }
                                 p += len;
                             }
