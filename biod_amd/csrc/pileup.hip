@@ -44,34 +44,135 @@ struct K3Args { const bgp_record* rec; uint64_t n; uint64_t* key_end; uint64_t* 
 constexpr int FAST_LSEQ = 160;         // reads up to 20 dwords of packed SEQ and 4 CIGAR ops take K4's lane = read path
 __device__ __forceinline__ bool is_long_read(uint32_t n_cig, uint32_t l_seq) { return n_cig > 4 || l_seq > (uint32_t)FAST_LSEQ; }
 
-__global__ __launch_bounds__(256) void k3_keys(K3Args a) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    bgp_record r{};
-    if (i < a.n) r = a.rec[i];
-    const bool cov = i < a.n && r.end_pos != r.pos;              // basesCovered() > 0, pileup.d:481,510
-    const uint64_t rk = ref_key(r.ref_id) << 32;
-    if (i < a.n) { a.key_end[i] = cov ? (rk | (uint32_t)r.end_pos) : 0; a.key_pos[i] = cov ? (rk | (uint32_t)r.pos) : 0; }
-    if (__ballot(cov && is_long_read(r.flag_nc & 0xFFFFu, (uint32_t)r.l_seq)) && (threadIdx.x & 63) == 0) atomicOr(&a.status[3], 1u);
+// K3 is one two-pass inclusive max-scan over two keys derived on the fly from the record table
+// (reference key << 32 | end_position, ... | position; 0 for reads with basesCovered() == 0):
+// pass 1 reduces 2048-record tiles, a single workgroup scans the tile maxima, pass 2 rescans each
+// tile with its carry-in, writes both prefix-maximum arrays and -- because the running maximum of the
+// position key just before record i is exactly "the last covering read before i" -- checks sortedness
+// (makePileup's precondition, pileup.d:25-27), finds the first read of every reference run
+// (pileup.d:399-424) and notes whether any long read exists.
+constexpr int K3_T = 256, K3_ITEMS = 8, K3_TILE = K3_T * K3_ITEMS;
+
+struct K3Key { uint64_t e, p; };
+__device__ __forceinline__ K3Key k3_max(K3Key a, K3Key b) { K3Key r; r.e = a.e > b.e ? a.e : b.e; r.p = a.p > b.p ? a.p : b.p; return r; }
+
+__device__ __forceinline__ K3Key k3_key_of(const bgp_record& r) {
+    K3Key k; k.e = 0; k.p = 0;
+    if (r.end_pos != r.pos) {                                            // basesCovered() > 0, pileup.d:481,510
+        const uint64_t rk = ref_key(r.ref_id) << 32;
+        k.e = rk | (uint32_t)r.end_pos; k.p = rk | (uint32_t)r.pos;
+    }
+    return k;
 }
 
-struct K3bArgs { const bgp_record* rec; uint64_t n; const uint64_t* pmax_pos; RunDev* runs; uint32_t* status; /* [0] bits [2] n_runs */ unsigned long long* n_used; };
+// exclusive prefix (max) of per-thread values across the workgroup + workgroup total
+__device__ __forceinline__ K3Key k3_block_excl(K3Key mine, K3Key* total, K3Key* lds /* K3_T/64 */) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    K3Key inc = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        K3Key o; o.e = __shfl_up(inc.e, d, 64); o.p = __shfl_up(inc.p, d, 64);
+        if (lane >= d) inc = k3_max(inc, o);
+    }
+    if (lane == 63) lds[w] = inc;
+    __syncthreads();
+    K3Key carry{0, 0}, tot{0, 0};
+#pragma unroll
+    for (int k = 0; k < K3_T / 64; ++k) { if (k < w) carry = k3_max(carry, lds[k]); tot = k3_max(tot, lds[k]); }
+    *total = tot;
+    K3Key ex; ex.e = __shfl_up(inc.e, 1, 64); ex.p = __shfl_up(inc.p, 1, 64);
+    if (lane == 0) { ex.e = 0; ex.p = 0; }
+    __syncthreads();
+    return k3_max(carry, ex);
+}
 
-__global__ __launch_bounds__(256) void k3_bounds(K3bArgs a) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < a.n) {
-        const bgp_record r = a.rec[i];
-        const bool cov = r.end_pos != r.pos;
-        if (cov) {
-            if (r.pos < 0 || r.end_pos < r.pos) atomicOr(&a.status[0], ST_EINVAL);
-            const uint64_t key = (ref_key(r.ref_id) << 32) | (uint32_t)r.pos;
-            const uint64_t prev = i ? a.pmax_pos[i - 1] : 0;
-            if (key < prev) atomicOr(&a.status[0], ST_EUNSORTED);      // makePileup precondition, pileup.d:25-27
-            if ((prev >> 32) != (key >> 32)) {                          // first read of a reference run, pileup.d:399-424
-                const uint32_t slot = atomicAdd(&a.status[2], 1u);
-                if (slot < MAX_RUNS) { RunDev rd{}; rd.ref_id = r.ref_id; rd.first_record = i; rd.start_pos = (uint64_t)r.pos; a.runs[slot] = rd; }
-            }
+// Layout: a tile is 2048 records = 4 waves x 8 rows x 64 lanes; lane = record inside a row, so every
+// load of the 32-byte rows is a coalesced 2 KiB per wave (a thread owning 8 consecutive rows' worth of
+// records would stride 256 B between lanes).  Scan order = record order: rows of a wave in sequence,
+// waves in sequence.
+__device__ __forceinline__ K3Key k3_wave_incl(K3Key v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        K3Key o; o.e = __shfl_up(v.e, d, 64); o.p = __shfl_up(v.p, d, 64);
+        if (lane >= d) v = k3_max(v, o);
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(K3_T) void k3_reduce(K3Args a, K3Key* bsum) {
+    __shared__ K3Key lds[K3_T / 64];
+    const uint64_t base = (uint64_t)blockIdx.x * K3_TILE + threadIdx.x;
+    K3Key acc{0, 0};
+#pragma unroll
+    for (int k = 0; k < K3_ITEMS; ++k) { const uint64_t i = base + (uint64_t)k * K3_T; if (i < a.n) acc = k3_max(acc, k3_key_of(a.rec[i])); }
+    K3Key tot;
+    (void)k3_block_excl(acc, &tot, lds);
+    if (threadIdx.x == 0) bsum[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(K3_T) void k3_bsum(K3Key* bsum, uint64_t nb) {      // single workgroup: exclusive scan of the tile maxima
+    __shared__ K3Key lds[K3_T / 64];
+    K3Key carry{0, 0};
+    for (uint64_t base = 0; base < nb; base += K3_T) {
+        const uint64_t i = base + threadIdx.x;
+        K3Key v{0, 0};
+        if (i < nb) v = bsum[i];
+        K3Key tot;
+        const K3Key ex = k3_block_excl(v, &tot, lds);
+        if (i < nb) bsum[i] = k3_max(carry, ex);
+        carry = k3_max(carry, tot);
+    }
+}
+
+__global__ __launch_bounds__(K3_T) void k3_down(K3Args a, const K3Key* bsum, RunDev* runs) {
+    __shared__ K3Key lds[K3_T / 64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint64_t wbase = (uint64_t)blockIdx.x * K3_TILE + (uint64_t)w * (K3_ITEMS * 64) + lane;
+    K3Key key[K3_ITEMS]; int32_t ref[K3_ITEMS]; uint32_t flg[K3_ITEMS];           // flg: bit0 long read, bit1 bad coordinates
+    K3Key mine{0, 0};
+#pragma unroll
+    for (int k = 0; k < K3_ITEMS; ++k) {
+        const uint64_t i = wbase + (uint64_t)k * 64;
+        key[k] = K3Key{0, 0}; ref[k] = 0; flg[k] = 0;
+        if (i < a.n) {
+            const bgp_record r = a.rec[i];
+            key[k] = k3_key_of(r); ref[k] = r.ref_id;
+            flg[k] = (is_long_read(r.flag_nc & 0xFFFFu, (uint32_t)r.l_seq) ? 1u : 0u) | ((r.pos < 0 || r.end_pos < r.pos) ? 2u : 0u);
+            mine = k3_max(mine, key[k]);
         }
     }
+    // maxima over every record before this wave's first: tile carry-in + the waves in front
+    K3Key wtot = mine;
+    for (int d = 32; d >= 1; d >>= 1) { K3Key o; o.e = __shfl_xor(wtot.e, d, 64); o.p = __shfl_xor(wtot.p, d, 64); wtot = k3_max(wtot, o); }
+    if (lane == 0) lds[w] = wtot;
+    __syncthreads();
+    K3Key carry = bsum[blockIdx.x];
+    for (int k = 0; k < w; ++k) carry = k3_max(carry, lds[k]);
+    bool any_long = false;
+#pragma unroll
+    for (int k = 0; k < K3_ITEMS; ++k) {
+        const uint64_t i = wbase + (uint64_t)k * 64;
+        const K3Key inc = k3_wave_incl(key[k], lane);
+        K3Key before; before.e = __shfl_up(inc.e, 1, 64); before.p = __shfl_up(inc.p, 1, 64);
+        if (lane == 0) before = K3Key{0, 0};
+        before = k3_max(before, carry);                                       // maxima over every record before record i
+        if (i < a.n) {
+            if (key[k].p) {                                                   // a covering read
+                if (flg[k] & 2u) atomicOr(&a.status[0], ST_EINVAL);
+                if (key[k].p < before.p) atomicOr(&a.status[0], ST_EUNSORTED); // pileup.d:25-27
+                if ((before.p >> 32) != (key[k].p >> 32)) {                    // first read of a reference run, pileup.d:399-424
+                    const uint32_t slot = atomicAdd(&a.status[2], 1u);
+                    if (slot < MAX_RUNS) { RunDev rd{}; rd.ref_id = ref[k]; rd.first_record = i; rd.start_pos = (uint64_t)(uint32_t)key[k].p; runs[slot] = rd; }
+                }
+                any_long |= (flg[k] & 1u) != 0;
+            }
+            const K3Key out = k3_max(before, key[k]);
+            a.key_end[i] = out.e; a.key_pos[i] = out.p;
+        }
+        K3Key last; last.e = __shfl(inc.e, 63, 64); last.p = __shfl(inc.p, 63, 64);
+        carry = k3_max(carry, last);
+    }
+    if (__ballot(any_long) && lane == 0) atomicOr(&a.status[3], 1u);
 }
 
 __global__ void k3_run_ends(RunDev* runs, uint32_t n_runs, const uint64_t* pmax_end, uint64_t n) {
@@ -712,15 +813,15 @@ int k34_pileup(bgp_ctx* c) {
     BGP_TRY(c->d_runs.reserve(sizeof(RunDev) * MAX_RUNS));
     const unsigned nb = (unsigned)((n + 255) / 256);
     uint32_t* status = c->d_status.as<uint32_t>();
-    unsigned long long* n_used = (unsigned long long*)(c->d_pstats.as<uint64_t>() + 4);
     {
         TimedRegion t(c, "k3_keys_scan", n * (32 + 16 + 32));
         K3Args a{c->d_rec.as<bgp_record>(), n, c->d_pmax_end.as<uint64_t>(), c->d_pmax_pos.as<uint64_t>(), status};
-        hipLaunchKernelGGL(k3_keys, dim3(nb), dim3(256), 0, c->stream, a);
-        BGP_TRY(scan_inclusive_max_u64(c, a.key_end, a.key_end, n));
-        BGP_TRY(scan_inclusive_max_u64(c, a.key_pos, a.key_pos, n));
-        K3bArgs b{c->d_rec.as<bgp_record>(), n, c->d_pmax_pos.as<uint64_t>(), c->d_runs.as<RunDev>(), status, n_used};
-        hipLaunchKernelGGL(k3_bounds, dim3(nb), dim3(256), 0, c->stream, b);
+        const uint64_t nt = (n + K3_TILE - 1) / K3_TILE;
+        BGP_TRY(c->d_scan_tmp.reserve((nt + 2) * sizeof(K3Key)));
+        K3Key* bsum = c->d_scan_tmp.as<K3Key>();
+        hipLaunchKernelGGL(k3_reduce, dim3((unsigned)nt), dim3(K3_T), 0, c->stream, a, bsum);
+        hipLaunchKernelGGL(k3_bsum, dim3(1), dim3(K3_T), 0, c->stream, bsum, nt);
+        hipLaunchKernelGGL(k3_down, dim3((unsigned)nt), dim3(K3_T), 0, c->stream, a, bsum, c->d_runs.as<RunDev>());
     }
     uint32_t st[4] = {0, 0, 0, 0};
     BGP_HIP(hipMemcpyAsync(st, status, 16, hipMemcpyDeviceToHost, c->stream));
