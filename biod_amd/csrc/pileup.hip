@@ -16,13 +16,14 @@
 // A column is the set of such reads, in file order (:351-359 stable compaction, :377-386 appends).
 //
 // MI355X design.  K4 is a histogram-shaped scatter (integer, HBM/LDS-bound, no MFMA): one workgroup
-// owns a window of W reference positions with seven u32 counters per position in LDS
-// (A,C,G,T,other,'-',n_starting_here; coverage is their sum), finds the contiguous record range that
-// can touch the window by binary search over two prefix-maximum arrays (exact halo: first record
-// whose running max end_position exceeds the window start -- SURVEY.md 3.3), and lets each wave
-// walk one read at a time with LANES ALONG THE READ: consecutive lanes hit consecutive positions =
-// consecutive LDS banks, so the ds_add_u32 traffic is conflict-free regardless of base class.
-// The window is flushed once, 32 contiguous bytes per position, fully coalesced.
+// owns a window of W reference positions with its counters in LDS (A,C,G,T,other, a difference array
+// for '-', n_starting_here; coverage is their sum) and is handed the contiguous record range that can
+// touch the window (exact halo: first record whose running max end_position exceeds the window start
+// -- SURVEY.md 3.3 -- from two prefix-maximum arrays built by K3).  Three ways to walk a read, picked
+// per read: LANE = READ for ordinary short reads (64 reads per wave step the same query index; the
+// bulk of the work), LANE = OP for long reads (64 CIGAR ops per coalesced load, wave prefix scan,
+// resumed from per-window checkpoints), lanes along the read for the odd rest.  The window is
+// flushed once, 32 contiguous bytes per position, fully coalesced.  Details at each kernel.
 #include "common.h"
 
 #include <algorithm>

@@ -349,3 +349,65 @@ def test_cpp_facade(tmp_path, data_dir):
                            "-o", exe, "-L" + os.path.join(root, "biod_amd"), "-lbiodgpu", "-Wl,-rpath," + os.path.join(root, "biod_amd")])
     out = subprocess.run([exe, os.path.join(data_dir, "ex1_header.bam"), os.path.join(data_dir, "illu_20_chunk.bam")], capture_output=True, text=True)
     assert out.returncode == 0 and "facade ok" in out.stdout, out.stderr
+
+
+def test_records_larger_than_framing_segments(ctx):
+    """The first record is tiny (so segments are 4 KiB) and later records are hundreds of KB: interior
+    segments hold no record start, the guesser finds nothing there, and the verify/re-chase fixpoint has
+    to carry the chain across them.  Also a long soft-clipped read and a 30 000-op CIGAR."""
+    rng = np.random.default_rng(7)
+
+    def seq(n):
+        return "".join("ACGT"[int(x)] for x in rng.integers(0, 4, n))
+
+    recs = [bamio.pack_record("tiny", "ACGT", [(4, "M")], ref_id=0, pos=1)]
+    pos = 10
+    for k, n in enumerate((70_000, 300_000, 5, 120_000)):
+        if k == 1:      # many small ops
+            ops, left = [], n
+            while left > 0:
+                m = min(left, 7); ops.append((m, "M")); left -= m
+                if left > 0:
+                    ops.append((2, "D")); i = min(left, 3); ops.append((i, "I")); left -= i
+            if ops[-1][1] == "I":
+                ops.append((0, "P"))
+            cigar = ops
+        elif k == 3:
+            cigar = [(20_000, "S"), (n - 20_000, "M")]
+        else:
+            cigar = [(n, "M")]
+        recs.append(bamio.pack_record(f"big{k}", seq(n), cigar, ref_id=0, pos=pos, qual=bytes(rng.integers(0, 42, n).astype(np.uint8))))
+        pos += 1000
+    st = b"".join(recs)
+    assert len(O.frame(st)) == 5
+    stage(ctx, st)
+    check_decode(ctx, st)
+    info, ora = check_pileup(ctx, st, entries=False)
+    assert info.max_coverage >= 3
+
+
+def test_hist_reduce_single_rank_rccl(ctx):
+    """bgp_hist_reduce through a real RCCL communicator (one rank): resolves librccl at run time,
+    sums uint64 in place -- with one rank the histogram must come back unchanged."""
+    import torch
+    rccl = C.CDLL("librccl.so.1")
+    comm = C.c_void_p()
+    dev = (C.c_int * 1)(0)
+    assert rccl.ncclCommInitAll(C.byref(comm), 1, dev) == 0
+    try:
+        cfg = make_cfg(n_reads=4000, n_ref=2, ref_len=40_000, read_len=150, profile=1, seed=21)
+        st = host_stream(cfg)
+        stage(ctx, st)
+        info = ctx.pileup_run()
+        hist = torch.zeros(L.BGP_DEPTH_BINS, dtype=torch.int64, device="cuda:0")
+        hip = C.CDLL("libamdhip64.so")
+        assert hip.hipMemcpy(C.c_void_p(hist.data_ptr()), C.c_void_p(info.device_depth_hist), C.c_size_t(L.BGP_DEPTH_BINS * 8), 3) == 0
+        before = hist.cpu().numpy().copy()
+        L.check(L.lib().bgp_hist_reduce(ctx.handle, comm, C.c_void_p(hist.data_ptr()), L.BGP_DEPTH_BINS), ctx.handle)
+        after = hist.cpu().numpy()
+        assert np.array_equal(before, after)
+        ora = O.pileup(st, skip_zero=False)
+        from biod_amd.shard import depth_histogram
+        assert np.array_equal(after, depth_histogram(ora.cov))
+    finally:
+        rccl.ncclCommDestroy(comm)
