@@ -386,6 +386,58 @@ def test_records_larger_than_framing_segments(ctx):
     assert info.max_coverage >= 3
 
 
+def _random_stream(rng, n_reads, quirks):
+    """Coordinate-sorted random records: every CIGAR op type, optional zero-length ops, SEQ shorter or
+    longer than the CIGAR's query length, unmapped reads, three references."""
+    recs, pos, ref = [], 0, 0
+    for i in range(n_reads):
+        if rng.random() < 0.01 and ref < 2:
+            ref += 1; pos = int(rng.integers(0, 50))
+        pos += int(rng.integers(0, 6))
+        n_ops = int(rng.integers(1, 8))
+        ops = []
+        for k in range(n_ops):
+            op = "MIDNSHP=X"[int(rng.choice(9, p=[0.45, 0.08, 0.08, 0.04, 0.08, 0.03, 0.03, 0.1, 0.11]))]
+            ln = int(rng.integers(1, 25))
+            if quirks and rng.random() < 0.03:
+                ln = 0
+            ops.append((ln, op))
+        # no leading N (that is the ECIGAR case, tested separately): make the first reference-consuming op an M
+        for k, (ln, op) in enumerate(ops):
+            if op in "MDN=X":
+                if op == "N":
+                    ops[k] = (max(ln, 1), "M")
+                break
+        qlen = sum(ln for ln, op in ops if op in "MIS=X")
+        l_seq = qlen
+        if quirks and rng.random() < 0.05:
+            l_seq = max(0, qlen + int(rng.integers(-10, 11)))
+        seq = "".join("ACGTNRYK="[int(x)] for x in rng.choice(9, size=l_seq, p=[0.23, 0.23, 0.23, 0.23, 0.03, 0.01, 0.01, 0.01, 0.02]))
+        flag = 4 if rng.random() < 0.03 else (16 if rng.random() < 0.5 else 0)
+        qual = bytes(rng.integers(0, 60, l_seq).astype(np.uint8))
+        name = f"q{i}" + "x" * int(rng.integers(0, 20))
+        recs.append(bamio.pack_record(name, seq, ops, ref_id=ref, pos=pos, flag=flag, qual=qual, mapq=int(rng.integers(0, 61)),
+                                      tags=bamio.tag_z("XY", "z" * int(rng.integers(0, 30)))))
+    return b"".join(recs)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_cigars_match_oracle(ctx, seed):
+    rng = np.random.default_rng(1000 + seed)
+    st = _random_stream(rng, 400, quirks=seed % 2 == 1)
+    stage(ctx, st)
+    check_decode(ctx, st)
+    try:
+        ora = O.pileup(st, want_entries=True)
+    except O.OracleError as e:                 # zero-length ops can starve the cursor: BioD's assert (pileup.d:224-228)
+        assert e.code == O.ORC_ECIGAR
+        with pytest.raises(L.BiodGpuError) as g:
+            ctx.pileup_run()
+        assert g.value.code == L.BGP_ECIGAR
+        return
+    check_pileup(ctx, st, entries=True, window=1021)
+
+
 def test_hist_reduce_single_rank_rccl(ctx):
     """bgp_hist_reduce through a real RCCL communicator (one rank): resolves librccl at run time,
     sums uint64 in place -- with one rank the histogram must come back unchanged."""
