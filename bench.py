@@ -91,10 +91,16 @@ def main():
     from biod_amd.pileup import Context
     from biod_amd.synth import CONFIGS, scaled
 
+    if torch.cuda.device_count() and local >= torch.cuda.device_count():
+        local %= torch.cuda.device_count()          # (only for dry runs of the N>1 path on a box with fewer GPUs)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        backend = os.environ.get("BGP_BENCH_BACKEND", "nccl")      # nccl = RCCL over xGMI; gloo only to dry-run the control flow
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     else:
         torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
