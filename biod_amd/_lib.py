@@ -80,6 +80,7 @@ SYMBOLS = {
     "bgp_pileup_begin": (C.c_int, [_P, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_uint32]),
     "bgp_pileup_next_window": (C.c_int, [_P, C.POINTER(Columns)]),
     "bgp_pileup_ref_id": (C.c_int, [_P, C.POINTER(C.c_int32)]),
+    "bgp_read_dna": (C.c_int, [_P, C.c_uint64, C.c_char_p, C.c_uint32, C.POINTER(C.c_uint32)]),
     "bgp_hist_reduce": (C.c_int, [_P, _P, _P, C.c_size_t]),
     "bgp_timing_enable": (C.c_int, [_P, C.c_int]),
     "bgp_timing_reset": (C.c_int, [_P]),

@@ -100,7 +100,8 @@ static void release_all(bgp_ctx* c) {
     DevBuf* d[] = {&c->d_stream_own, &c->d_synth, &c->d_seg_entry, &c->d_seg_end, &c->d_seg_cnt, &c->d_seg_lseq, &c->d_seg_ncig, &c->d_seg_dirty,
                    &c->d_seg_rec_base, &c->d_seg_seq_base, &c->d_seg_cig_base, &c->d_scan_tmp, &c->d_status, &c->d_rec, &c->d_seq_off, &c->d_cigar_off,
                    &c->d_seq, &c->d_qual, &c->d_cigar, &c->d_pmax_end, &c->d_pmax_pos, &c->d_runs, &c->d_columns, &c->d_depth_hist, &c->d_pstats,
-                   &c->d_tiles, &c->d_ck_off, &c->d_ck, &c->d_entry_off, &c->d_entries, &c->d_col_lo};
+                   &c->d_tiles, &c->d_ck_off, &c->d_ck, &c->d_entry_off, &c->d_entries, &c->d_col_lo,
+                   &c->d_md_len, &c->d_md_iv, &c->d_md_state, &c->d_refbase};
     for (auto* b : d) b->release();
     HostBuf* h[] = {&c->h_stage, &c->h_rec, &c->h_seq_off, &c->h_cigar_off, &c->h_seq, &c->h_qual, &c->h_cigar, &c->h_cols, &c->h_entry_off, &c->h_entries, &c->h_refbase};
     for (auto* b : h) b->release();
@@ -284,6 +285,16 @@ int bgp_pileup_next_window(bgp_ctx* c, bgp_columns* o) {
         it.next_pos = b;
         return BGP_OK;
     }
+}
+
+int bgp_read_dna(bgp_ctx* c, uint64_t record, char* out, uint32_t cap, uint32_t* len) {
+    if (!c || !len || (!out && cap)) return BGP_EINVAL;
+    if (!c->flushed) return BGP_ESTATE;
+    BGP_HIP(hipSetDevice(c->device));
+    uint32_t flags = 0;
+    BGP_TRY(k6_dna_of_record(c, record, (uint8_t*)out, cap, len, &flags));
+    if (flags & 2u) return BGP_EINVAL;
+    return (flags & 1u) ? BGP_EMD : BGP_OK;
 }
 
 int bgp_hist_reduce(bgp_ctx* c, void* comm, uint64_t* device_hist, size_t n) {

@@ -129,6 +129,8 @@ struct bgp_ctx {
     } it;
     HostBuf h_cols, h_entry_off, h_entries, h_refbase;
     DevBuf d_entry_off, d_entries, d_col_lo;
+    DevBuf d_md_len, d_md_iv, d_md_state, d_refbase;   // MD path: dna(read) lengths, provider intervals, per-run controller state, dense reference bases
+    bool refbase_ready = false; int refbase_skip_zero = -1; uint64_t refbase_first_record = ~0ull;
 
     // timing
     bool timing = false;
@@ -154,6 +156,9 @@ int k34_first_survivor(bgp_ctx* c, uint32_t run, uint64_t start_from, uint64_t* 
 int k5_entries(bgp_ctx* c, uint32_t run, uint64_t pos_begin, uint64_t pos_end, uint64_t* n_entries);  // pileup.hip : CSR for a window
 int scan_exclusive_u64(bgp_ctx* c, const uint64_t* in, uint64_t* out, uint64_t n, uint64_t* total_host);   // scan.hip (out has n+1 entries)
 int scan_inclusive_max_u64(bgp_ctx* c, const uint64_t* in, uint64_t* out, uint64_t n);
+int k6_md_lengths(bgp_ctx* c);                              // md.hip
+int k6_dna_of_record(bgp_ctx* c, uint64_t i, uint8_t* host_out, uint32_t cap, uint32_t* len, uint32_t* flags);
+int k6_reference_bases(bgp_ctx* c, int skip_zero, uint32_t run_first, uint32_t run_end, uint64_t first_record);   // md.hip: fills d_refbase
 int synth_device(bgp_ctx* c, const bgp_synth_cfg_c* cfg, uint64_t* bytes);   // synth.hip
 int synth_host(const bgp_synth_cfg_c* cfg, uint64_t first, uint64_t count, uint8_t* out, uint64_t cap, uint64_t* bytes);
 int bgzf_load_bam(bgp_ctx* c, const char* path, int n_threads);               // bgzf_host.cpp

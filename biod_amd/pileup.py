@@ -128,6 +128,19 @@ class Context:
             ents = L.as_array(cw.entries, int(eoff[-1]), L.ENTRY_DTYPE) if eoff is not None else None
             yield Window(cw.ref_id, cw.first_position, cols, eoff, ents)
 
+    def read_dna(self, record: int, cap: int = 1 << 16, strict: bool = True) -> str:
+        """dna(read), md/reconstruct.d:38-214: reference bases spanned by a read, from CIGAR + MD.
+        With strict=False the chars BioD's lazy range yields before it stalls are returned instead of
+        raising BGP_EMD."""
+        buf = C.create_string_buffer(max(cap, 1))
+        n = C.c_uint32()
+        rc = L.lib().bgp_read_dna(self._h, record, buf, cap, C.byref(n))
+        if rc != L.BGP_EMD or strict:
+            L.check(rc, self._h)
+        if n.value > cap:
+            return self.read_dna(record, n.value, strict)
+        return buf.raw[:n.value].decode("latin-1")
+
     def pileup_ref_id(self) -> int:
         r = C.c_int32()
         L.check(L.lib().bgp_pileup_ref_id(self._h, C.byref(r)), self._h)

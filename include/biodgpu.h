@@ -186,6 +186,12 @@ int bgp_pileup_begin(bgp_ctx* ctx, int mode, int use_md_tag, uint64_t start_from
 int bgp_pileup_next_window(bgp_ctx* ctx, bgp_columns* out);   /* BGP_OK, BGP_EOF, or error */
 int bgp_pileup_ref_id(bgp_ctx* ctx, int32_t* ref_id);          /* AbstractPileup.ref_id, pileup.d:455 */
 
+/* dna(read): the reference bases a read spans, rebuilt from its CIGAR and MD tag
+ * (bio/std/hts/bam/md/reconstruct.d:38-214, mdOperations bio/std/hts/bam/md/parse.d:13-142).
+ * Writes at most `cap` chars to `out`; *len is the full length.  Returns BGP_EMD when the lazy range
+ * BioD builds would run into an exhausted query (MD longer than the CIGAR's M/=/X bases). */
+int bgp_read_dna(bgp_ctx* ctx, uint64_t record, char* out, uint32_t cap, uint32_t* len);
+
 /* Whole-BAM histogram reduce across ranks (the only collective of the path): sums `n` uint64
  * values in HBM over all ranks of an RCCL communicator (ncclComm_t passed as void*).
  * CPU equivalent: a fold over column.coverage (pileup.d:252). */

@@ -438,6 +438,78 @@ def test_random_cigars_match_oracle(ctx, seed):
     check_pileup(ctx, st, entries=True, window=1021)
 
 
+# ------------------------------------------------------------------------------------------ MD tags / reference_base
+def _check_read_dna(ctx, st, limit=None):
+    """The oracle materialises the chars BioD's lazy range yields (also when it then stalls on an exhausted
+    query -- the device flags that case BGP_EMD; the flag itself is checked through reference_base parity)."""
+    offs = O.frame(st)
+    n_ok = n_bad = 0
+    for k, off in enumerate(offs[:limit]):
+        exp = O.dna_read(st, int(off))
+        assert ctx.read_dna(k, cap=64, strict=False) == exp, k       # cap=64 also exercises the grow-and-retry path
+        try:
+            ctx.read_dna(k)
+            n_ok += 1
+        except L.BiodGpuError as e:
+            assert e.code == L.BGP_EMD
+            n_bad += 1
+    return n_ok, n_bad
+
+
+@pytest.mark.parametrize("name", ["illu_20_chunk.bam", "ion_20_chunk.bam", "b7_295_chunk.bam", "mg1655_chunk.bam", "tags.bam"])
+def test_read_dna_fixtures(ctx, data_dir, name):
+    """dna(read) on the device == the oracle's (md/reconstruct.d:38-214) for every record of the fixtures."""
+    _, st = bamio.read_bam(os.path.join(data_dir, name))
+    stage(ctx, st)
+    n_ok, _ = _check_read_dna(ctx, st, limit=400)
+    assert n_ok > 0
+
+
+def test_read_dna_kats_and_odd_md(ctx):
+    """M1 of SURVEY.md 8c (reconstruct.d:216-279) plus MD strings BioD accepts silently: lower case, digits as
+    bases, leading/trailing zeros, empty deletions, MD shorter / longer than the CIGAR, H-typed MD, no MD."""
+    cases = [("AGGTTTTGTGAGTGGGACAGTTGCAGCAAAACACAACCATAGGTGCCCATCCACCAAGGCAGGCTCTCCATCTTGCTCAGAGTGGCTCTA",
+              [(89, "M")], "16", "AGGTTTTGTGAGTGGGACAGTTGCAGCAAAACACAACCATAGGTGCCCATCCACCAAGGCAGGCTCTCCATCTTGCTCAGAGTGGCTCTA"[:16]),
+             ("GAGACGGGGTGACAGAGTGAGACCCTGTCTCAAAAACAAAAACAAACAAAAATTAGGCATGGTGGTGCATG", [(53, "M"), (1, "I"), (17, "M")], "53^A17", None),
+             ("ACGTACGTAC", [(10, "M")], "4t5", None), ("ACGTACGTAC", [(10, "M")], "0A0C8", None), ("ACGTACGTAC", [(10, "M")], "3^5", None),
+             ("ACGTACGTAC", [(4, "M"), (2, "D"), (6, "M")], "4^AC6", None), ("ACGTACGTAC", [(4, "M"), (2, "D"), (6, "M")], "4^ac6", None),
+             ("ACGTACGTAC", [(10, "M")], "25", None), ("ACGTACGTAC", [(10, "M")], "2", None), ("ACGTACGTAC", [(10, "M")], "", None),
+             ("ACGTACGTAC", [(10, "M")], "10A", None), ("ACGTACGTAC", [(10, "M")], "A", None), ("ACGTACGTAC", [(10, "M")], "^", None),
+             ("ACGTACGTAC", [(10, "M")], "5^", None), ("ACGTACGTAC", [(10, "M")], "00010", None), ("ACGTACGTAC", [(10, "M")], "1Z2*3", None),
+             ("ACGTACGTAC", [(2, "S"), (3, "M"), (1, "I"), (2, "N"), (4, "M")], "3^GG4", None),
+             ("ACGTACGTAC", [(3, "M"), (7, "S")], "1^ACGTACGT2", None), ("", [(5, "M")], "5", None), ("AC", [(5, "M")], "1A3", None)]
+    recs = []
+    for i, (seq, ops, md, _) in enumerate(cases):
+        recs.append(bamio.pack_record(f"k{i}", seq, ops, ref_id=0, pos=10 + i, tags=bamio.tag_z("XA", "q") + bamio.tag_z("MD", md)))
+    recs.append(bamio.pack_record("nomd", "ACGT", [(4, "M")], ref_id=0, pos=100, tags=bamio.tag_z("XA", "q")))
+    recs.append(bamio.pack_record("hmd", "ACGT", [(4, "M")], ref_id=0, pos=101, tags=b"MDH" + b"4\0"))
+    recs.append(bamio.pack_record("imd", "ACGT", [(4, "M")], ref_id=0, pos=102, tags=b"MDi" + (4).to_bytes(4, "little")))
+    recs.append(bamio.pack_record("bmd", "ACGT", [(4, "M")], ref_id=0, pos=103, tags=b"XBBs" + (3).to_bytes(4, "little") + b"\1\0\2\0\3\0" + bamio.tag_z("MD", "2A1")))
+    st = b"".join(recs)
+    stage(ctx, st)
+    _check_read_dna(ctx, st)
+    assert ctx.read_dna(0) == cases[0][3]
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_read_dna_random_md(ctx, seed):
+    rng = np.random.default_rng(4000 + seed)
+    recs = []
+    alphabet = "0123456789ACGTN^acgt="
+    for i in range(300):
+        n = int(rng.integers(0, 24))
+        md = "".join(alphabet[int(x)] for x in rng.integers(0, len(alphabet), n))
+        ln = int(rng.integers(1, 40))
+        ops = [(ln, "M")] if rng.random() < 0.5 else [(ln // 2 + 1, "M"), (2, "D"), (3, "I"), (ln // 2 + 1, "=")]
+        qlen = sum(l for l, o in ops if o in "MIS=X")
+        seq = "".join("ACGTN"[int(x)] for x in rng.integers(0, 5, qlen))
+        recs.append(bamio.pack_record(f"r{i}", seq, ops, ref_id=0, pos=i, tags=bamio.tag_z("MD", md)))
+    st = b"".join(recs)
+    stage(ctx, st)
+    n_ok, n_bad = _check_read_dna(ctx, st)
+    assert n_ok > 50
+
+
 def test_hist_reduce_single_rank_rccl(ctx):
     """bgp_hist_reduce through a real RCCL communicator (one rank): resolves librccl at run time,
     sums uint64 in place -- with one rank the histogram must come back unchanged."""
