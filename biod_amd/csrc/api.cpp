@@ -101,7 +101,7 @@ static void release_all(bgp_ctx* c) {
                    &c->d_seg_rec_base, &c->d_seg_seq_base, &c->d_seg_cig_base, &c->d_scan_tmp, &c->d_status, &c->d_rec, &c->d_seq_off, &c->d_cigar_off,
                    &c->d_seq, &c->d_qual, &c->d_cigar, &c->d_pmax_end, &c->d_pmax_pos, &c->d_runs, &c->d_columns, &c->d_depth_hist, &c->d_pstats,
                    &c->d_tiles, &c->d_ck_off, &c->d_ck, &c->d_entry_off, &c->d_entries, &c->d_col_lo,
-                   &c->d_md_len, &c->d_md_iv, &c->d_md_state, &c->d_refbase};
+                   &c->d_md_row, &c->d_md_iv, &c->d_md_state, &c->d_refbase};
     for (auto* b : d) b->release();
     HostBuf* h[] = {&c->h_stage, &c->h_rec, &c->h_seq_off, &c->h_cigar_off, &c->h_seq, &c->h_qual, &c->h_cigar, &c->h_cols, &c->h_entry_off, &c->h_entries, &c->h_refbase};
     for (auto* b : h) b->release();
@@ -131,7 +131,7 @@ int bgp_reset(bgp_ctx* c) {
     if (!c) return BGP_EINVAL;
     BGP_HIP(hipStreamSynchronize(c->stream));
     c->h_stage_len = 0; c->d_stream = nullptr; c->stream_len = 0; c->stream_on_device = false;
-    c->flushed = false; c->piled = false; c->n_records = 0; c->decoded_what = 0; c->it = bgp_ctx::Iter();
+    c->flushed = false; c->piled = false; c->md_rows_ready = false; c->n_records = 0; c->decoded_what = 0; c->it = bgp_ctx::Iter();
     c->runs.clear();
     return BGP_OK;
 }
@@ -161,7 +161,7 @@ int bgp_flush(bgp_ctx* c) {
         if (c->h_stage_len) BGP_HIP(hipMemcpyAsync(c->d_stream_own.p, c->h_stage.p, c->h_stage_len, hipMemcpyHostToDevice, c->stream));
         c->d_stream = c->d_stream_own.as<uint8_t>(); c->stream_len = c->h_stage_len; c->stream_on_device = true;
     }
-    c->piled = false; c->decoded_what = 0;
+    c->piled = false; c->md_rows_ready = false; c->decoded_what = 0;
     int rc = k0_frame(c);
     if (rc < 0) return rc;
     c->flushed = true;
@@ -211,7 +211,7 @@ int bgp_pileup_run(bgp_ctx* c, bgp_pileup_info* info) {
     if (!c->flushed) return BGP_ESTATE;
     BGP_HIP(hipSetDevice(c->device));
     BGP_TRY(k34_pileup(c));
-    c->piled = true;
+    c->piled = true; c->md_rows_ready = false;
     if (info) *info = c->pinfo;
     return BGP_OK;
 }
@@ -219,7 +219,7 @@ int bgp_pileup_run(bgp_ctx* c, bgp_pileup_info* info) {
 int bgp_pileup_begin(bgp_ctx* c, int mode, int use_md_tag, uint64_t start_from, uint64_t end_at, int skip_zero, int want_entries, uint32_t window) {
     if (!c || (mode != BGP_PILEUP_COLUMNS && mode != BGP_MAKE_PILEUP)) return BGP_EINVAL;
     if (!c->flushed) return BGP_ESTATE;
-    if (use_md_tag) { c->last_error = "reference_base from MD tags is not on the device path yet"; return BGP_EMD; }
+    BGP_HIP(hipSetDevice(c->device));
     if (!c->piled) BGP_TRY(bgp_pileup_run(c, nullptr));
     auto& it = c->it;
     it = bgp_ctx::Iter();
@@ -239,14 +239,29 @@ int bgp_pileup_begin(bgp_ctx* c, int mode, int use_md_tag, uint64_t start_from, 
         else { it.run = it.run_end; }
     }
     if (it.run < it.run_end) {
-        uint64_t first = c->runs[it.run].start_pos;
+        uint64_t first = c->runs[it.run].start_pos, first_record = ~0ull;
         if (mode == BGP_MAKE_PILEUP && it.start_from > first) {
             // the sweep starts at the first surviving read, not at the run's first read (matters for
-            // zero-coverage columns when skip_zero_coverage is false)
-            BGP_TRY(k34_first_survivor(c, it.run, it.start_from, &first));
+            // zero-coverage columns when skip_zero_coverage is false, and for the MD provider chain)
+            BGP_TRY(k34_first_survivor(c, it.run, it.start_from, &first, &first_record));
             if (first == ~0ull) { it.run = it.run_end; return BGP_OK; }
         }
         it.next_pos = std::max<uint64_t>(first, it.start_from);
+        if (use_md_tag) {
+            // PileupRangeUsingMdTag (pileup.d:522-654): the whole provider chain is built here, windows slice it.
+            int md_err = 0; int64_t md_from = -1;
+            BGP_TRY(k6_reference_bases(c, skip_zero, it.run, it.run_end, first_record, &md_err, &md_from));
+            if (md_err) {
+                // BioD throws from the popFront that trips over the tag; makePileup stops popping at end_at
+                // (pileup.d:497-505), so an error further right is never reached.
+                const uint64_t reach = std::max(it.start_from, it.end_at);
+                if (mode == BGP_PILEUP_COLUMNS || md_from < 0 || (uint64_t)md_from < reach) {
+                    it.active = false;
+                    c->last_error = "MD tag inconsistent with CIGAR/SEQ while reconstructing reference bases";
+                    return md_err;
+                }
+            }
+        }
     }
     return BGP_OK;
 }
@@ -279,6 +294,11 @@ int bgp_pileup_next_window(bgp_ctx* c, bgp_columns* o) {
             BGP_HIP(hipMemcpyAsync(c->h_entry_off.p, c->d_entry_off.p, (np + 1) * 8, hipMemcpyDeviceToHost, c->stream));
             if (ne) BGP_HIP(hipMemcpyAsync(c->h_entries.p, c->d_entries.p, ne * sizeof(bgp_entry), hipMemcpyDeviceToHost, c->stream));
             o->entry_off = c->h_entry_off.as<uint64_t>(); o->entries = c->h_entries.as<bgp_entry>();
+        }
+        if (it.use_md) {
+            BGP_TRY(c->h_refbase.reserve(np + 1));
+            BGP_HIP(hipMemcpyAsync(c->h_refbase.p, c->d_refbase.as<uint8_t>() + r.column_base + (a - r.start_pos), np, hipMemcpyDeviceToHost, c->stream));
+            o->reference_base = c->h_refbase.as<uint8_t>();
         }
         BGP_HIP(hipStreamSynchronize(c->stream));
         o->ref_id = r.ref_id; o->n_positions = (uint32_t)np; o->first_position = a; o->columns = c->h_cols.as<bgp_column>();

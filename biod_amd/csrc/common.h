@@ -129,8 +129,8 @@ struct bgp_ctx {
     } it;
     HostBuf h_cols, h_entry_off, h_entries, h_refbase;
     DevBuf d_entry_off, d_entries, d_col_lo;
-    DevBuf d_md_len, d_md_iv, d_md_state, d_refbase;   // MD path: dna(read) lengths, provider intervals, per-run controller state, dense reference bases
-    bool refbase_ready = false; int refbase_skip_zero = -1; uint64_t refbase_first_record = ~0ull;
+    DevBuf d_md_row, d_md_iv, d_md_state, d_refbase;   // MD path: per-record rows, provider intervals, per-run controller state, dense reference bases
+    bool md_rows_ready = false;
 
     // timing
     bool timing = false;
@@ -152,13 +152,12 @@ void bgp_timing_collect(bgp_ctx* c);
 int k0_frame(bgp_ctx* c);                                   // frame.hip : segments, guess/chase/verify, scans, record table
 int k2_decode(bgp_ctx* c, uint32_t what);                   // decode.hip
 int k34_pileup(bgp_ctx* c);                                 // pileup.hip : runs + dense columns
-int k34_first_survivor(bgp_ctx* c, uint32_t run, uint64_t start_from, uint64_t* pos);
+int k34_first_survivor(bgp_ctx* c, uint32_t run, uint64_t start_from, uint64_t* pos, uint64_t* record);
 int k5_entries(bgp_ctx* c, uint32_t run, uint64_t pos_begin, uint64_t pos_end, uint64_t* n_entries);  // pileup.hip : CSR for a window
 int scan_exclusive_u64(bgp_ctx* c, const uint64_t* in, uint64_t* out, uint64_t n, uint64_t* total_host);   // scan.hip (out has n+1 entries)
 int scan_inclusive_max_u64(bgp_ctx* c, const uint64_t* in, uint64_t* out, uint64_t n);
-int k6_md_lengths(bgp_ctx* c);                              // md.hip
 int k6_dna_of_record(bgp_ctx* c, uint64_t i, uint8_t* host_out, uint32_t cap, uint32_t* len, uint32_t* flags);
-int k6_reference_bases(bgp_ctx* c, int skip_zero, uint32_t run_first, uint32_t run_end, uint64_t first_record);   // md.hip: fills d_refbase
+int k6_reference_bases(bgp_ctx* c, int skip_zero, uint32_t run_first, uint32_t run_end, uint64_t first_record, int* md_err, int64_t* md_err_from);   // md.hip: fills d_refbase
 int synth_device(bgp_ctx* c, const bgp_synth_cfg_c* cfg, uint64_t* bytes);   // synth.hip
 int synth_host(const bgp_synth_cfg_c* cfg, uint64_t first, uint64_t count, uint8_t* out, uint64_t cap, uint64_t* bytes);
 int bgzf_load_bam(bgp_ctx* c, const char* path, int n_threads);               // bgzf_host.cpp
@@ -170,6 +169,8 @@ __device__ __forceinline__ uint32_t ld_u32(const uint8_t* p) {   // unaligned li
     __builtin_memcpy(&v, p, 4);
     return v;
 }
+// sort key of a reference id: unmapped (-1) sorts last, as in a coordinate-sorted BAM
+__device__ __forceinline__ uint64_t ref_key(int32_t ref_id) { return ref_id < 0 ? 0x7FFFFFFFull : (uint64_t)(uint32_t)(ref_id + 1); }
 // CIGAR_TYPE bit pairs (cigar.d:113-116): bit0 query consuming, bit1 reference consuming
 __device__ __forceinline__ uint32_t cig_qc(uint32_t raw) { return (0x3C1A7u >> ((raw & 15u) * 2)) & 1u; }
 __device__ __forceinline__ uint32_t cig_rc(uint32_t raw) { return (0x3C1A7u >> ((raw & 15u) * 2 + 1)) & 1u; }

@@ -8,7 +8,8 @@
 // order except "first arg-max of end_position among the reads that pass add()'s filter", and the chunk
 // cursor moves one base per visited column, i.e. in closed form.
 //
-//   k6_md_len   one lane per record : length of dna(read) and its "would hit an empty query" flag
+//   k6_prep     one lane per record : a 16-byte row -- position, end, length of dna(read) + flags, and the
+//               max end_position of the earlier position groups (is the previous column uncovered?)
 //   k6_chain    one wave per reference run : the event loop (fetch to fetch), emits provider intervals
 //   k6_fill     one lane per interval : dna(provider)[c0 ...] written to the dense reference_base array
 //
@@ -210,20 +211,204 @@ __device__ uint32_t dna_walk(const uint8_t* s, const bgp_record& r, uint32_t fro
     }
 }
 
-constexpr uint32_t MD_BAD = 1u << 31;
+// ---------------------------------------------------------------------------------------------- k6_prep
+// One 16-byte row per record: what the controller needs, and nothing it has to chase pointers for.
+//   lf : dna(read) length | MD_COV (basesCovered() > 0) | MD_GST (first read of a position group)
+//        | MD_ERR (malformed aux data: EINVAL if ever fetched) | MD_BAD (range stalls on an empty query)
+//   mb : max end_position over the reads of EARLIER position groups of the same reference (0 if none), so
+//        "_prev_coverage == 0" at the read's column (pileup.d:565,625) is  mb < pos.
+struct MdRow { uint32_t pos, end, lf, mb; };
+constexpr uint32_t MD_BAD = 1u << 31, MD_ERR = 1u << 30, MD_COV = 1u << 29, MD_GST = 1u << 28, MD_LMASK = (1u << 28) - 1;
 
-__global__ __launch_bounds__(256) void k6_md_len(const uint8_t* s, const bgp_record* rec, uint64_t n, uint32_t* md_len, uint32_t* status) {
+__global__ __launch_bounds__(256) void k6_prep(const uint8_t* s, const bgp_record* rec, const uint64_t* pmax_end, const uint64_t* pmax_pos, uint64_t n, MdRow* rows) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const bgp_record r = rec[i];
-    uint32_t v = 0;
+    MdRow o{(uint32_t)r.pos, (uint32_t)r.end_pos, 0u, 0u};
     if (r.end_pos != r.pos) {
         bool bad, err;
-        const uint32_t L = dna_walk(s, r, 0, 0, nullptr, &bad, &err);
-        if (err) atomicOr(&status[0], ST_EINVAL);
-        v = (L & ~MD_BAD) | (bad ? MD_BAD : 0u);
+        uint32_t L = dna_walk(s, r, 0, 0, nullptr, &bad, &err);
+        if (L > MD_LMASK) L = MD_LMASK;
+        // first record of this read's position group: the prefix maximum of the position key reaches the
+        // read's own key exactly there (records are sorted; K3 has already rejected unsorted input).
+        const uint64_t key = (ref_key(r.ref_id) << 32) | (uint32_t)r.pos;
+        uint64_t hi = i, lo = 0, step = 1;
+        while (hi > 0) {
+            const uint64_t t = hi > step ? hi - step : 0;
+            if (pmax_pos[t] >= key) { hi = t; step <<= 1; } else { lo = t + 1; break; }
+        }
+        while (lo < hi) { const uint64_t m = (lo + hi) >> 1; if (pmax_pos[m] >= key) hi = m; else lo = m + 1; }
+        uint32_t mb = 0;
+        if (hi > 0) { const uint64_t e = pmax_end[hi - 1]; if ((e >> 32) == (key >> 32)) mb = (uint32_t)e; }
+        o.lf = L | MD_COV | (hi == i ? MD_GST : 0u) | (bad ? MD_BAD : 0u) | (err ? MD_ERR : 0u);
+        o.mb = mb;
     }
-    md_len[i] = v;
+    rows[i] = o;
+}
+
+// ---------------------------------------------------------------------------------------------- k6_chain
+// The provider chain of one reference run, one wave per run.  Lanes hold a batch of 64 consecutive rows;
+// every decision is a ballot / wave arg-max over that batch, the state itself is wave-uniform.
+//
+// Restatement of PileupRangeUsingMdTag at event granularity.  With the chunk of provider P fetched (cursor
+// ci, chunk_end_position CE) and the sweep at column y, nothing observable happens until the first of
+//   FETCH at F = max(first column whose check sees an empty chunk, position of the first read that add()
+//           would accept under CE)                                         (pileup.d:627-635, 563-596)
+//   GAP   at E = where coverage ends before the next position group (skip_zero_coverage only): the sweep
+//           jumps and re-initialises there, chunk or not                    (pileup.d:382-393, 598-611)
+//   END   of the run at E = max end_position.
+// add() keeps "the first read with the largest end_position among those it accepts", which does not
+// depend on the order the reads are looked at -- so a batch is reduced with one arg-max.
+struct ChainRun { uint64_t first, endrec, iv_base; uint32_t run_end, ce_in, active, pad; };
+struct ChainOut { uint32_t ce_out, n_iv; int32_t err; uint32_t pad; int64_t err_from; };
+struct MdIv { uint32_t col, c0; uint64_t prov; };
+constexpr uint64_t MD_NONE = ~0ull, MD_INF = 1ull << 62;
+
+__device__ __forceinline__ uint64_t wave_max_u64(uint64_t v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { const uint64_t o = __shfl_xor(v, d, 64); v = o > v ? o : v; }
+    return v;
+}
+
+__global__ __launch_bounds__(64) void k6_chain(const MdRow* rows, const ChainRun* cr, ChainOut* co, MdIv* iv, int skip_zero) {
+    const ChainRun R = cr[blockIdx.x];
+    if (!R.active) return;
+    const int lane = threadIdx.x;
+    // chunk state (pileup.d:523-533)
+    uint64_t P = MD_NONE; uint32_t L = 0, ci = 0, CE = R.ce_in; bool bad = false;
+    bool has_next = false; uint64_t NX = MD_NONE; uint32_t NXend = 0, NXpos = 0, NXlf = 0;
+    uint64_t y = 0, i = R.first;
+    uint32_t n_iv = 0; int err = 0; int64_t err_from = -1;
+    const uint64_t iv_cap = R.endrec - R.first + 2;
+    uint64_t b = MD_NONE; MdRow row{0, 0, 0, 0};
+
+    auto load = [&](uint64_t base) { b = base; const uint64_t idx = base + lane; row = idx < R.endrec ? rows[idx] : MdRow{0, 0, 0, 0}; };
+    auto emit = [&](uint64_t col, uint32_t c0, uint64_t prov) {
+        if (n_iv < iv_cap) { if (lane == 0) iv[R.iv_base + n_iv] = MdIv{(uint32_t)col, c0, prov}; ++n_iv; }
+        else if (!err) { err = BGP_EINVAL; }
+    };
+    // add() over the lanes with `pass` set: first arg-max of end_position; an earlier candidate wins ties
+    auto take = [&](bool pass) {
+        if (!__ballot(pass)) return;
+        const uint64_t key = wave_max_u64(pass ? ((uint64_t)row.end << 32) | (uint32_t)(63 - lane) : 0ull);
+        const int wl = 63 - (int)(key & 63u);
+        const uint32_t e = (uint32_t)(key >> 32);
+        const uint32_t wp = __shfl(row.pos, wl, 64), wf = __shfl(row.lf, wl, 64);
+        if (!has_next || e > NXend) { has_next = true; NX = b + wl; NXend = e; NXpos = wp; NXlf = wf; }
+    };
+    // initNewReference (pileup.d:399-424 + 598-611) at the position group that starts at record j
+    auto init_at = [&](uint64_t j, bool new_ref) -> bool {
+        if (j < b || j >= b + 64) load(j);
+        const uint32_t x = __shfl(row.pos, (int)(j - b), 64);
+        uint64_t k = j, ge;
+        for (;;) {
+            if (k >= b + 64) load(k);
+            const uint64_t idx = b + lane;
+            const bool cov = idx >= k && idx < R.endrec && (row.lf & MD_COV);
+            const uint64_t stop = __ballot(cov && row.pos != x);
+            const int fs = stop ? __ffsll((unsigned long long)stop) - 1 : 64;
+            const bool ing = cov && lane < fs;
+            if (new_ref && j >= b && j < b + 64 && k == j) {
+                // the first read of a new reference is taken unconditionally (pileup.d:568-575)
+                const int fl = (int)(j - b);
+                has_next = true; NX = j; NXend = __shfl(row.end, fl, 64); NXpos = x; NXlf = __shfl(row.lf, fl, 64);
+                take(ing && idx != j && row.end > CE);
+            } else take(ing && row.end > CE);
+            if (fs < 64) { ge = b + fs; break; }
+            if (b + 64 >= R.endrec) { ge = R.endrec; break; }
+            k = b + 64;
+        }
+        if (has_next) {
+            P = NX; L = NXlf & MD_LMASK; bad = (NXlf & MD_BAD) != 0; ci = 0; CE = NXend; has_next = false;
+            if (NXlf & MD_ERR) { err = BGP_EINVAL; return false; }
+            if (L == 0) { err = BGP_EMD; return false; }          // chunk.front of an empty chunk
+            emit(x, 0, P); ci = 1;
+        } else {
+            emit(x, 0, MD_NONE);                                   // 'N' here ...
+            if (P != MD_NONE && ci < L) emit((uint64_t)x + 1, ci, P);   // ... and the old chunk simply goes on
+        }
+        y = x; i = ge;
+        return true;
+    };
+
+    if (init_at(R.first, true)) {
+        for (;;) {
+            const uint64_t empty_at = bad ? MD_INF : y + (L > ci + 1 ? L - ci : 1u);
+            bool found = false; uint64_t F = MD_INF;
+            int outcome = 0; uint64_t jn = R.endrec; uint32_t egap = 0;            // 1 FETCH, 2 GAP, 3 END
+            uint64_t j = i;
+            for (;;) {
+                if (j >= R.endrec) { const uint64_t E = R.run_end > y + 1 ? R.run_end : y + 1; outcome = (found && F < E) ? 1 : 3; jn = R.endrec; break; }
+                if (j < b || j >= b + 64) load(j);
+                const uint64_t idx = b + lane;
+                const bool valid = idx >= j && idx < R.endrec;
+                const bool cov = valid && (row.lf & MD_COV);
+                const bool hz = row.mb < row.pos;
+                const bool cand = cov && (row.pos <= CE || hz) && row.end > CE;      // add()'s filter, pileup.d:583-588
+                uint64_t mg = __ballot(skip_zero && cov && (row.lf & MD_GST) && hz);
+                int from = 0;
+                if (!found) {
+                    const uint64_t mc = __ballot(cand);
+                    const int fc = mc ? __ffsll((unsigned long long)mc) - 1 : 64, fg = mg ? __ffsll((unsigned long long)mg) - 1 : 64;
+                    if (fg < 64 && fg <= fc) { outcome = 2; jn = b + fg; egap = __shfl(row.mb, fg, 64); break; }
+                    if (fc == 64) { j = b + 64; continue; }
+                    found = true; from = fc;
+                    const uint64_t pc = __shfl(row.pos, fc, 64);
+                    F = empty_at > pc ? empty_at : pc;
+                }
+                const bool in_b = valid && lane >= from;
+                const uint64_t mbey = __ballot(in_b && cov && (uint64_t)row.pos > F);
+                mg &= ~0ull << from;
+                const int fb = mbey ? __ffsll((unsigned long long)mbey) - 1 : 64, fg = mg ? __ffsll((unsigned long long)mg) - 1 : 64;
+                if (fg < 64 && fg <= fb) {
+                    const uint32_t mbv = __shfl(row.mb, fg, 64);
+                    const uint64_t E = mbv > y + 1 ? mbv : y + 1;
+                    if (fg < fb || E <= F) { take(in_b && cand && lane < fg); outcome = 2; jn = b + fg; egap = mbv; break; }
+                    take(in_b && cand && lane < fb); outcome = 1; jn = b + fb; break;
+                }
+                if (fb < 64) { take(in_b && cand && lane < fb); outcome = 1; jn = b + fb; break; }
+                take(in_b && cand);
+                j = b + 64;
+            }
+            if (outcome == 1) {                                       // pileup.d:627-652
+                P = NX; L = NXlf & MD_LMASK; bad = (NXlf & MD_BAD) != 0; CE = NXend; has_next = false;
+                if (NXlf & MD_ERR) { err = BGP_EINVAL; err_from = (int64_t)F - 1; break; }
+                const uint64_t skip = F - NXpos;                      // popFrontN(position - next_provider.position)
+                ci = skip < L ? (uint32_t)skip : L;
+                if (ci >= L) { err = BGP_EMD; err_from = (int64_t)F - 1; break; }
+                emit(F, ci, P); ci += 1; y = F; i = jn;
+                continue;
+            }
+            const uint64_t E = outcome == 2 ? (egap > y + 1 ? egap : y + 1) : (R.run_end > y + 1 ? R.run_end : y + 1);
+            const uint64_t adv = E - y;                               // every popFront consumed a char first (pileup.d:615-622)
+            if (bad && ci + adv > L) { err = BGP_EMD; err_from = (int64_t)(y + (L > ci ? L - ci : 0)); break; }
+            ci = ci + adv < L ? (uint32_t)(ci + adv) : L;
+            if (outcome == 3) break;
+            if (!init_at(jn, false)) { err_from = (int64_t)E - 1; break; }
+        }
+    }
+    if (lane == 0) co[blockIdx.x] = ChainOut{CE, n_iv, err, 0u, err_from};
+}
+
+// ---------------------------------------------------------------------------------------------- k6_fill
+// One lane per provider interval: dna(provider)[c0 ...] into the dense reference_base array, up to the next
+// interval of the run (or the run's end).  The array is pre-filled with 'N' (empty chunk, pileup.d:620-622).
+struct FillRun { uint64_t iv_base, iv_prefix, column_base; uint32_t start_pos, end_pos, n_iv, pad; };
+
+__global__ __launch_bounds__(256) void k6_fill(const uint8_t* s, const bgp_record* rec, const MdIv* iv, const FillRun* fr, uint32_t n_runs, uint64_t total, uint8_t* refbase) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    uint32_t lo = 0, hi = n_runs;                                      // last run with iv_prefix <= t
+    while (hi - lo > 1) { const uint32_t m = (lo + hi) >> 1; if (fr[m].iv_prefix <= t) lo = m; else hi = m; }
+    const FillRun R = fr[lo];
+    const uint64_t k = t - R.iv_prefix;
+    const MdIv v = iv[R.iv_base + k];
+    if (v.prov == MD_NONE) return;
+    uint64_t endc = k + 1 < R.n_iv ? iv[R.iv_base + k + 1].col : R.end_pos;
+    if (endc > R.end_pos) endc = R.end_pos;
+    if (v.col >= endc) return;
+    bool bad, err;
+    dna_walk(s, rec[v.prov], v.c0, (uint32_t)(endc - v.col), refbase + R.column_base + (v.col - R.start_pos), &bad, &err);
 }
 
 // debug/test hook: dna(read) of one record into a host-visible buffer
@@ -236,14 +421,18 @@ __global__ void k6_dna_one(const uint8_t* s, const bgp_record* rec, uint64_t i, 
 
 }  // namespace
 
-int k6_md_lengths(bgp_ctx* c) {
+// rows for every record of the staged stream (needs K3's prefix maxima: call after k34_pileup)
+static int k6_rows(bgp_ctx* c) {
+    if (c->md_rows_ready) return BGP_OK;
     const uint64_t n = c->n_records;
-    BGP_TRY(c->d_md_len.reserve((n + 1) * 4));
-    if (n == 0) return BGP_OK;
-    BGP_HIP(hipMemsetAsync(c->d_status.p, 0, 64, c->stream));
-    TimedRegion t(c, "k6_md_len", n * 32);
-    hipLaunchKernelGGL(k6_md_len, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->d_stream, c->d_rec.as<bgp_record>(), n, c->d_md_len.as<uint32_t>(), c->d_status.as<uint32_t>());
-    BGP_HIP(hipGetLastError());
+    BGP_TRY(c->d_md_row.reserve((n + 1) * sizeof(MdRow)));
+    if (n) {
+        TimedRegion t(c, "k6_prep", n * (32 + sizeof(MdRow)));
+        hipLaunchKernelGGL(k6_prep, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->d_stream, c->d_rec.as<bgp_record>(),
+                           c->d_pmax_end.as<uint64_t>(), c->d_pmax_pos.as<uint64_t>(), n, c->d_md_row.as<MdRow>());
+        BGP_HIP(hipGetLastError());
+    }
+    c->md_rows_ready = true;
     return BGP_OK;
 }
 
@@ -264,7 +453,74 @@ int k6_dna_of_record(bgp_ctx* c, uint64_t i, uint8_t* host_out, uint32_t cap, ui
     return BGP_OK;
 }
 
-int k6_reference_bases(bgp_ctx* c, int skip_zero, uint32_t run_first, uint32_t run_end, uint64_t first_record) {
-    (void)c; (void)skip_zero; (void)run_first; (void)run_end; (void)first_record;
-    return BGP_EMD;     // stage 2
+// reference_base for the runs [run_first, run_end) into the dense array d_refbase (indexed like d_columns).
+// `first_record` != ~0 makes the sweep of run_first start at that record (makePileup's first survivor,
+// pileup.d:482-489).  An error BioD would raise while sweeping is returned in *md_err together with the
+// column whose popFront raises it (*md_err_from, -1 = at construction); the caller decides whether the
+// sweep it mirrors gets that far.
+//
+// Runs are independent except for one scalar: chunk_end_position is NOT reset between references, and
+// add() compares the reads of a new reference's first position group against the stale value
+// (pileup.d:583-595).  Each run is chained with a guess (the previous run's max end_position, which is what
+// the previous chain ends on unless an MD tag is inconsistent), the guesses are checked against the
+// chains' real final values in order, and wrong ones are re-chained.
+int k6_reference_bases(bgp_ctx* c, int skip_zero, uint32_t run_first, uint32_t run_end, uint64_t first_record, int* md_err, int64_t* md_err_from) {
+    *md_err = 0; *md_err_from = -1;
+    if (c->n_records >= 0xFFFFFFF0ull) { c->last_error = "too many records for the MD path"; return BGP_EINVAL; }
+    BGP_TRY(k6_rows(c));
+    const uint64_t n_pos = c->pinfo.n_positions;
+    BGP_TRY(c->d_refbase.reserve(n_pos + 16));
+    if (n_pos) BGP_HIP(hipMemsetAsync(c->d_refbase.p, 'N', n_pos, c->stream));
+    const uint32_t nr = run_end > run_first ? run_end - run_first : 0;
+    if (nr == 0) return BGP_OK;
+    std::vector<ChainRun> cr(nr);
+    std::vector<ChainOut> co(nr);
+    for (uint32_t k = 0; k < nr; ++k) {
+        const bgp_run& r = c->runs[run_first + k];
+        ChainRun& x = cr[k];
+        x.first = (k == 0 && first_record != ~0ull) ? first_record : r.first_record;
+        x.endrec = r.end_record; x.iv_base = x.first + 2ull * k; x.run_end = (uint32_t)r.end_pos;
+        x.ce_in = k == 0 ? 0u : (uint32_t)c->runs[run_first + k - 1].end_pos;
+        x.active = 1; x.pad = 0;
+    }
+    const size_t off_out = (sizeof(ChainRun) * nr + 15) & ~(size_t)15, off_fill = off_out + ((sizeof(ChainOut) * nr + 15) & ~(size_t)15);
+    BGP_TRY(c->d_md_state.reserve(off_fill + sizeof(FillRun) * nr));
+    BGP_TRY(c->d_md_iv.reserve((c->n_records + 2ull * nr + 2) * sizeof(MdIv)));
+    uint8_t* st = c->d_md_state.as<uint8_t>();
+    for (uint32_t round = 0; round <= nr; ++round) {
+        BGP_HIP(hipMemcpyAsync(st, cr.data(), sizeof(ChainRun) * nr, hipMemcpyHostToDevice, c->stream));
+        {
+            TimedRegion t(c, "k6_chain", 0);
+            hipLaunchKernelGGL(k6_chain, dim3(nr), dim3(64), 0, c->stream, c->d_md_row.as<MdRow>(), (const ChainRun*)st, (ChainOut*)(st + off_out), c->d_md_iv.as<MdIv>(), skip_zero);
+            BGP_HIP(hipGetLastError());
+        }
+        std::vector<ChainOut> got(nr);
+        BGP_HIP(hipMemcpyAsync(got.data(), st + off_out, sizeof(ChainOut) * nr, hipMemcpyDeviceToHost, c->stream));
+        BGP_HIP(hipStreamSynchronize(c->stream));
+        for (uint32_t k = 0; k < nr; ++k) if (cr[k].active) { co[k] = got[k]; cr[k].active = 0; }
+        bool again = false;
+        for (uint32_t k = 1; k < nr; ++k) {
+            if (co[k - 1].err) break;                                   // the sweep never gets past that run
+            if (cr[k].ce_in != co[k - 1].ce_out) { cr[k].ce_in = co[k - 1].ce_out; cr[k].active = 1; again = true; break; }   // later runs wait for this one's real value
+        }
+        if (!again) break;
+    }
+    uint64_t total = 0;
+    std::vector<FillRun> fr(nr);
+    uint32_t n_ok = nr;
+    for (uint32_t k = 0; k < nr; ++k) {
+        const bgp_run& r = c->runs[run_first + k];
+        fr[k] = FillRun{cr[k].iv_base, total, r.column_base, (uint32_t)r.start_pos, (uint32_t)r.end_pos, co[k].n_iv, 0u};
+        total += co[k].n_iv;
+        if (co[k].err) { *md_err = co[k].err; *md_err_from = co[k].err_from; n_ok = k + 1; break; }
+    }
+    if (total) {
+        BGP_HIP(hipMemcpyAsync(st + off_fill, fr.data(), sizeof(FillRun) * n_ok, hipMemcpyHostToDevice, c->stream));
+        TimedRegion t(c, "k6_fill", n_pos);
+        hipLaunchKernelGGL(k6_fill, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, c->d_stream, c->d_rec.as<bgp_record>(), c->d_md_iv.as<MdIv>(),
+                           (const FillRun*)(st + off_fill), n_ok, total, c->d_refbase.as<uint8_t>());
+        BGP_HIP(hipGetLastError());
+        BGP_HIP(hipStreamSynchronize(c->stream));          // fr is a host vector: keep it alive until the copy is done
+    }
+    return BGP_OK;
 }

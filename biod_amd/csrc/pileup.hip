@@ -36,7 +36,6 @@ constexpr int HB = 1024;               // depth-histogram bins kept in LDS
 constexpr int K4_T = 512;
 constexpr uint32_t MAX_RUNS = 1u << 16;
 
-__device__ __forceinline__ uint64_t ref_key(int32_t ref_id) { return ref_id < 0 ? 0x7FFFFFFFull : (uint64_t)(uint32_t)(ref_id + 1); }
 
 struct RunDev { int32_t ref_id; uint32_t pad; uint64_t first_record, end_record, start_pos, end_pos, column_base, tile_base; };
 
@@ -911,18 +910,22 @@ __global__ void k_first_survivor(const uint64_t* pmax_end, const bgp_record* rec
     uint64_t lo = first, hi = end;
     while (lo < hi) { const uint64_t m = (lo + hi) >> 1; if (pmax_end[m] >= key) hi = m; else lo = m + 1; }
     out[0] = lo < end ? (uint64_t)(uint32_t)rec[lo].pos : ~0ull;
+    out[1] = lo < end ? lo : ~0ull;
 }
 }  // namespace
 
 // position of the first read of run `run_idx` with position + basesCovered >= start_from (pileup.d:482-489)
-int k34_first_survivor(bgp_ctx* c, uint32_t run_idx, uint64_t start_from, uint64_t* pos) {
+int k34_first_survivor(bgp_ctx* c, uint32_t run_idx, uint64_t start_from, uint64_t* pos, uint64_t* record) {
     const bgp_run& r = c->runs[run_idx];
+    *record = ~0ull;
     if (start_from > 0x7FFFFFFFull) { *pos = ~0ull; return BGP_OK; }
     const uint64_t key = (((uint64_t)(r.ref_id < 0 ? 0x7FFFFFFFu : (uint32_t)(r.ref_id + 1))) << 32) | (uint32_t)start_from;
     uint64_t* out = c->d_pstats.as<uint64_t>() + 6;
     hipLaunchKernelGGL(k_first_survivor, dim3(1), dim3(1), 0, c->stream, c->d_pmax_end.as<uint64_t>(), c->d_rec.as<bgp_record>(), r.first_record, r.end_record, key, out);
-    BGP_HIP(hipMemcpyAsync(pos, out, 8, hipMemcpyDeviceToHost, c->stream));
+    uint64_t h[2] = {~0ull, ~0ull};
+    BGP_HIP(hipMemcpyAsync(h, out, 16, hipMemcpyDeviceToHost, c->stream));
     BGP_HIP(hipStreamSynchronize(c->stream));
+    *pos = h[0]; *record = h[1];
     return BGP_OK;
 }
 

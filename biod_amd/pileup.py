@@ -126,7 +126,8 @@ class Context:
             cols = L.as_array(cw.columns, cw.n_positions, L.COLUMN_DTYPE)
             eoff = L.as_array(cw.entry_off, cw.n_positions + 1, "<u8") if cw.entry_off else None
             ents = L.as_array(cw.entries, int(eoff[-1]), L.ENTRY_DTYPE) if eoff is not None else None
-            yield Window(cw.ref_id, cw.first_position, cols, eoff, ents)
+            refb = L.as_array(cw.reference_base, cw.n_positions, "u1") if cw.reference_base else None
+            yield Window(cw.ref_id, cw.first_position, cols, eoff, ents, refb)
 
     def read_dna(self, record: int, cap: int = 1 << 16, strict: bool = True) -> str:
         """dna(read), md/reconstruct.d:38-214: reference bases spanned by a read, from CIGAR + MD.
@@ -178,8 +179,9 @@ class PileupInfo:
 
 
 class Window:
-    def __init__(self, ref_id, first_position, columns, entry_off, entries):
+    def __init__(self, ref_id, first_position, columns, entry_off, entries, reference_base=None):
         self.ref_id, self.first_position, self.columns, self.entry_off, self.entries = ref_id, first_position, columns, entry_off, entries
+        self.reference_base = reference_base          # uint8 per position (use_md_tag) or None
 
 
 # ------------------------------------------------------------------------------------------ reads
@@ -394,7 +396,10 @@ class _Pileup:
                 if skip and c["coverage"] == 0:          # PileupRange.popFront jumps over these, pileup.d:388-392
                     continue
                 ents = w.entries[int(w.entry_off[k]):int(w.entry_off[k + 1])] if w.entries is not None else None
-                yield PileupColumn(w.ref_id, int(w.first_position) + k, c, ents, records, getattr(self.reads, "data", None))
+                col = PileupColumn(w.ref_id, int(w.first_position) + k, c, ents, records, getattr(self.reads, "data", None))
+                if w.reference_base is not None:
+                    col.reference_base = chr(int(w.reference_base[k]))     # pileup.d:245-249
+                yield col
 
 
 def makePileup(reads, use_md_tag=False, start_from=0, end_at=ULONG_MAX, skip_zero_coverage=True, *, want_entries=True, window_positions=0):

@@ -510,6 +510,134 @@ def test_read_dna_random_md(ctx, seed):
     assert n_ok > 50
 
 
+def _check_refbase(ctx, st, mode=L.BGP_PILEUP_COLUMNS, skip_zero=True, start_from=0, end_at=O.U64_MAX, window=777):
+    """reference_base of every column the sweep visits (PileupRangeUsingMdTag, pileup.d:522-654) == oracle's;
+    where BioD would throw, the device path must fail with the same status."""
+    try:
+        ora = O.pileup(st, mode, use_md=True, start_from=start_from, end_at=end_at, skip_zero=skip_zero)
+    except O.OracleError as e:
+        assert e.code in (O.ORC_EMD, O.ORC_EINVAL)
+        with pytest.raises(L.BiodGpuError) as g:
+            list(ctx.pileup_windows(mode, True, start_from, end_at, skip_zero, window_positions=window))
+        assert g.value.code == (L.BGP_EMD if e.code == O.ORC_EMD else L.BGP_EINVAL)
+        return None
+    refs, poss, bases = [], [], []
+    for w in ctx.pileup_windows(mode, True, start_from, end_at, skip_zero, window_positions=window):
+        assert w.reference_base is not None and len(w.reference_base) == len(w.columns)
+        keep = w.columns["coverage"] > 0 if skip_zero else np.ones(len(w.columns), bool)
+        p = (w.first_position + np.arange(len(w.columns), dtype=np.uint64))[keep]
+        refs.append(np.full(len(p), w.ref_id, np.int32)); poss.append(p); bases.append(w.reference_base[keep])
+    refs = np.concatenate(refs) if refs else np.zeros(0, np.int32)
+    poss = np.concatenate(poss) if poss else np.zeros(0, np.uint64)
+    bases = np.concatenate(bases) if bases else np.zeros(0, np.uint8)
+    assert np.array_equal(refs, ora.ref) and np.array_equal(poss, ora.pos.astype(np.uint64))
+    bad = np.nonzero(bases != ora.refbase)[0]
+    assert len(bad) == 0, [(int(refs[k]), int(poss[k]), chr(bases[k]), chr(ora.refbase[k])) for k in bad[:8]]
+    return ora
+
+
+@pytest.mark.parametrize("name", ["illu_20_chunk.bam", "ion_20_chunk.bam", "b7_295_chunk.bam", "mg1655_chunk.bam", "ex1_header.bam", "tags.bam"])
+@pytest.mark.parametrize("skip_zero", [True, False])
+def test_reference_base_fixtures(ctx, data_dir, name, skip_zero):
+    _, st = bamio.read_bam(os.path.join(data_dir, name))
+    stage(ctx, st)
+    _check_refbase(ctx, st, skip_zero=skip_zero)
+    _check_refbase(ctx, st, mode=L.BGP_MAKE_PILEUP, skip_zero=skip_zero)
+
+
+def test_P1_P2_reference_base_through_api(ctx):
+    """The pileup unittest's stream (pileup.d:696-760): reference_base of every column with use_md_tag."""
+    s89 = "AGGTTTTGTGAGTGGGACAGTTGCAGCAAAACACAACCATAGGTGCCCATCCACCAAGGCAGGCTCTCCATCTTGCTCAGAGTGGCTCTA"[:89]
+    reads = [("r1", s89, [(89, "M")], 60, "89"), ("r2", s89[1:], [(1, "S"), (87, "M")], 61, "87"),
+             ("r3", "CCAAGGCAGGCTCTCCATCTTGCTCAGAGTGGCTCTAGGTTTTGTGAGTGGGACAGTTGC", [(20, "M"), (2, "I"), (10, "M"), (3, "D"), (28, "M")], 70, "30^ACG28")]
+    st = b"".join(bamio.pack_record(n, s, ops, ref_id=0, pos=p, tags=bamio.tag_z("MD", md)) for n, s, ops, p, md in reads)
+    stage(ctx, st)
+    for skip in (True, False):
+        ora = _check_refbase(ctx, st, skip_zero=skip)
+        assert ora is not None and ora.n_columns > 0
+        _check_refbase(ctx, st, mode=L.BGP_MAKE_PILEUP, skip_zero=skip, start_from=75, end_at=120)
+
+
+def _md_stream(rng, n_reads, p_gap=0.02, p_nomd=0.0, p_n=0.0, p_short=0.0, p_long=0.0, nref=2, p_ref=0.01):
+    """Sorted reads whose MD is derived from their own CIGAR (with mismatches and deletions), optionally
+    damaged: missing, truncated (chunk runs out early) or over-long (BioD's range stalls: EMD)."""
+    recs, pos, ref = [], 0, 0
+    for i in range(n_reads):
+        if rng.random() < p_ref and ref < nref - 1:
+            ref += 1; pos = int(rng.integers(0, 30))
+        pos += int(rng.integers(0, 8))
+        if rng.random() < p_gap:
+            pos += int(rng.integers(30, 200))
+        kind, ln = rng.random(), int(rng.integers(20, 60))
+        if kind < 0.6: ops = [(ln, "M")]
+        elif kind < 0.7: ops = [(int(rng.integers(1, 8)), "S"), (ln, "M")]
+        elif kind < 0.8: ops = [(ln // 2, "M"), (int(rng.integers(1, 4)), "I"), (ln - ln // 2, "M")]
+        elif kind < 0.9: ops = [(ln // 2, "M"), (int(rng.integers(1, 6)), "D"), (ln - ln // 2, "M")]
+        else: ops = [(ln // 2, "="), (ln - ln // 2, "X")]
+        if rng.random() < p_n:
+            ops = [(ln // 2, "M"), (int(rng.integers(5, 40)), "N"), (ln - ln // 2, "M")]
+        qlen = sum(l for l, o in ops if o in "MIS=X")
+        seq = "".join("ACGT"[int(x)] for x in rng.integers(0, 4, qlen))
+        md, run = "", 0
+        for l, o in ops:
+            if o in "M=X":
+                for _ in range(l):
+                    if rng.random() < 0.05:
+                        md += str(run) + "ACGT"[int(rng.integers(0, 4))]; run = 0
+                    else:
+                        run += 1
+            elif o == "D":
+                md += str(run) + "^" + "".join("ACGT"[int(x)] for x in rng.integers(0, 4, l)); run = 0
+        md += str(run)
+        u = rng.random()
+        if u < p_short:
+            md = md[:max(1, len(md) // 2)]
+        elif u < p_short + p_long:
+            md += "A" + str(int(rng.integers(1, 30)))
+        tags = bamio.tag_z("XQ", "pad") if rng.random() < p_nomd else bamio.tag_z("MD", md)
+        recs.append(bamio.pack_record(f"r{i}", seq, ops, ref_id=ref, pos=pos, tags=tags))
+    return b"".join(recs)
+
+
+_MD_CFGS = [dict(), dict(p_gap=0.1), dict(p_n=0.1), dict(p_nomd=0.03), dict(p_short=0.05), dict(p_long=0.02),
+            dict(p_gap=0.05, p_short=0.01, nref=6, p_ref=0.03), dict(p_short=0.05, nref=8, p_ref=0.05),
+            dict(p_gap=0.05, p_n=0.05, p_short=0.03, p_long=0.01, nref=6, p_ref=0.03)]
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_reference_base_random_streams(ctx, seed):
+    rng = np.random.default_rng(7000 + seed)
+    st = _md_stream(rng, int(rng.integers(5, 400)), **_MD_CFGS[seed % len(_MD_CFGS)])
+    stage(ctx, st)
+    for skip in (True, False):
+        _check_refbase(ctx, st, skip_zero=skip, window=int(rng.integers(50, 5000)))
+    info = ctx.pileup_run()
+    lo, hi = int(info.runs[0]["start_pos"]), int(info.runs[0]["end_pos"])
+    for _ in range(3):
+        a = int(rng.integers(lo, hi + 1)); b = int(rng.integers(a, hi + 50))
+        _check_refbase(ctx, st, mode=L.BGP_MAKE_PILEUP, skip_zero=bool(rng.integers(0, 2)), start_from=a, end_at=b)
+
+
+def test_reference_base_stale_chunk_end_across_references(ctx):
+    """chunk_end_position is not reset between references (pileup.d:583-595): the first position group of a
+    new reference is filtered against the previous reference's LAST provider -- which is not the read with the
+    largest end when a chunk is longer than its read's span (here: a 32-base deletion string on a 20M read)."""
+    long_md = "10^" + "ACGT" * 8 + "10"
+    recs = [bamio.pack_record("a", "A" * 20, [(20, "M")], ref_id=0, pos=0, tags=bamio.tag_z("MD", long_md)),
+            bamio.pack_record("b", "C" * 30, [(30, "M")], ref_id=0, pos=5, tags=bamio.tag_z("MD", "30")),
+            bamio.pack_record("c", "G" * 10, [(10, "M")], ref_id=1, pos=3, tags=bamio.tag_z("MD", "10")),
+            bamio.pack_record("d", "T" * 25, [(25, "M")], ref_id=1, pos=3, tags=bamio.tag_z("MD", "25")),
+            bamio.pack_record("e", "A" * 12, [(12, "M")], ref_id=2, pos=7, tags=bamio.tag_z("MD", "12")),
+            bamio.pack_record("f", "C" * 40, [(40, "M")], ref_id=2, pos=7, tags=bamio.tag_z("MD", "40"))]
+    st = b"".join(recs)
+    stage(ctx, st)
+    for skip in (True, False):
+        ora = _check_refbase(ctx, st, skip_zero=skip)
+        assert ora is not None
+        col = {(int(r), int(p)): chr(b) for r, p, b in zip(ora.ref, ora.pos, ora.refbase)}
+        assert col[(1, 3)] == "T" and col[(2, 7)] == "C"          # d (end 28 > stale 20) and f (end 47 > stale 28) win
+
+
 def test_hist_reduce_single_rank_rccl(ctx):
     """bgp_hist_reduce through a real RCCL communicator (one rank): resolves librccl at run time,
     sums uint64 in place -- with one rank the histogram must come back unchanged."""
