@@ -169,7 +169,16 @@ int bgp_pileup_run(bgp_ctx* ctx, bgp_pileup_info* info);
  *   mode BGP_PILEUP_COLUMNS = pileupColumns(reads, use_md_tag, skip_zero_coverage),                   pileup.d:509-519
  * next_window hands out consecutive dense windows (zero-coverage positions included -- the D/C++
  * facade skips them when skip_zero_coverage is set, exactly the columns PileupRange.popFront
- * pileup.d:345-397 would have yielded). */
+ * pileup.d:345-397 would have yielded).
+ *
+ * use_md_tag != 0 selects PileupRangeUsingMdTag (pileup.d:522-654): every window also carries
+ * reference_base, the base BioD's column.reference_base (pileup.d:245-249) reports -- rebuilt from the MD
+ * tags by the same provider chain (add() pileup.d:563-596, chunk refill :627-652), including its quirks
+ * ('N' while no chunk is available; chunk_end_position carried over from the previous reference).
+ * Where BioD's popFront would throw on an MD tag that disagrees with its read, bgp_pileup_begin returns
+ * BGP_EMD (or BGP_EINVAL for malformed aux data) -- for BGP_MAKE_PILEUP only if that popFront lies before
+ * end_at, as BioD stops popping there (pileup.d:497-505).  With skip_zero_coverage the bytes at
+ * zero-coverage positions (columns BioD never yields) are unspecified. */
 #define BGP_PILEUP_COLUMNS 0
 #define BGP_MAKE_PILEUP 1
 typedef struct bgp_columns {

@@ -80,11 +80,11 @@ struct PileupRead {
 
 // PileupColumn, pileup.d:236-290
 struct PileupColumn {
-    int ref_id_; uint64_t position_; const bgp_column* c; const bgp_entry* ents; size_t n_ents; const bgp_records* recs;
+    int ref_id_; uint64_t position_; const bgp_column* c; const bgp_entry* ents; size_t n_ents; const bgp_records* recs; char refbase_;
     size_t coverage() const { return c->coverage; }                            // pileup.d:252
     int ref_id() const { return ref_id_; }                                     // pileup.d:257
     uint64_t position() const { return position_; }                            // pileup.d:262
-    char reference_base() const { return 'N'; }                                // pileup.d:245 (MD path: next round)
+    char reference_base() const { return refbase_; }                           // pileup.d:245-249 ('N' unless use_md_tag)
     size_t n_starting_here() const { return c->n_starting_here; }
     std::vector<PileupRead> reads() const { std::vector<PileupRead> v; for (size_t i = 0; i < n_ents; ++i) v.push_back({ents + i, recs}); return v; }
     std::vector<PileupRead> reads_starting_here() const {                      // pileup.d:272-274
@@ -106,7 +106,8 @@ public:
     bool empty() const { return done_; }
     PileupColumn front() const {
         const uint64_t a = want_entries_ ? w_.entry_off[k_] : 0, b = want_entries_ ? w_.entry_off[k_ + 1] : 0;
-        return PileupColumn{w_.ref_id, w_.first_position + k_, w_.columns + k_, want_entries_ ? w_.entries + a : nullptr, (size_t)(b - a), &recs_};
+        return PileupColumn{w_.ref_id, w_.first_position + k_, w_.columns + k_, want_entries_ ? w_.entries + a : nullptr, (size_t)(b - a), &recs_,
+                            w_.reference_base ? (char)w_.reference_base[k_] : 'N'};
     }
     void popFront() { ++k_; settle(); }
     uint64_t start_position() const { return start_; }                         // pileup.d:445

@@ -51,6 +51,20 @@ int main(int argc, char** argv) {
             for (auto& read : column.reads_starting_here()) starting.push_back(read.read_ordinal());
         REQUIRE(starting.size() == 29);
         for (uint32_t i = 0; i < 29; ++i) REQUIRE(starting[i] == i);
+        // make_pileup.d:16: makePileup(reads, true) -- reference_base rebuilt from the MD tags.  Bit-parity with
+        // the oracle is tested through the Python binding; here: a base, and the one most reads agree with.
+        size_t cols = 0, agree = 0;
+        for (auto column : makePileup(bam.reads(), true)) {
+            const char rb = column.reference_base();
+            REQUIRE(rb == 'A' || rb == 'C' || rb == 'G' || rb == 'T' || rb == 'N');
+            size_t same = 0;
+            const std::string b = column.bases();
+            for (char c : b) same += c == rb;
+            agree += 2 * same > b.size();
+            ++cols;
+        }
+        REQUIRE(cols > 100 && agree * 10 > cols * 9);
+        for (auto column : makePileup(bam.reads(), false)) REQUIRE(column.reference_base() == 'N');      // pileup.d:245-249
     }
     std::puts("facade ok");
     return 0;

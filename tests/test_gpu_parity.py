@@ -339,6 +339,56 @@ def test_scale_properties(ctx):
     check_pileup(ctx, st, entries=False)
 
 
+def _synth_ref_chars(seed, contig, pos):
+    """The generator's reference (synth_record.h: ref2): 2-bit base of contig `contig` at positions `pos`."""
+    M = np.uint64
+    def mix64(z):
+        z = z + M(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> M(30))) * M(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> M(27))) * M(0x94D049BB133111EB)
+        return z ^ (z >> M(31))
+    pos = pos.astype(np.uint64)
+    with np.errstate(over="ignore"):
+        h = mix64(M(seed) ^ M(0x5EEDBA5E) ^ (M(contig) << M(36)) ^ (pos >> M(5)))
+    b2 = ((h >> ((pos & M(31)) * M(2))) & M(3)).astype(np.int64)
+    return np.frombuffer(b"ACGT", np.uint8)[b2]
+
+
+@pytest.mark.parametrize("model,n_reads", [("cfg3", 1_000_000), ("cfg2", 1_000_000), ("cfg5", 3_000)])
+def test_reference_base_synthetic_prefix_matches_oracle(ctx, model, n_reads):
+    """Prefix shards of the bench models against the oracle (cfg3 has N skips: dna(read) leaves the skipped
+    bases out, md/reconstruct.d:199, so chunks drift off the reference there -- in BioD and here alike)."""
+    cfg = scaled(model, n_reads)
+    st = host_stream(cfg, 0, 6000 if model != "cfg5" else 40)
+    stage(ctx, st)
+    for skip in (True, False):
+        _check_refbase(ctx, st, skip_zero=skip, window=100_000)
+
+
+@pytest.mark.parametrize("model,n_reads", [("cfg2", 1_000_000), ("cfg5", 3_000)])
+def test_scale_reference_base_equals_generator_reference(ctx, model, n_reads):
+    """The synthetic reads carry MD tags consistent with a hash-defined reference, so whatever read provides a
+    column, reference_base must be that reference -- at a size far beyond the oracle's reach (short reads:
+    one chunk fetch per ~read length; long reads with indels: deletion strings and insertion skips)."""
+    cfg = scaled(model, n_reads)
+    ctx.reset()
+    ctx.synth_device(cfg)
+    ctx.flush()
+    n_cols = 0
+    for skip in (True, False):
+        for w in ctx.pileup_windows(L.BGP_PILEUP_COLUMNS, use_md_tag=True, skip_zero_coverage=skip, window_positions=1 << 22):
+            keep = w.columns["coverage"] > 0
+            p = (w.first_position + np.arange(len(w.columns), dtype=np.uint64))[keep]
+            exp = _synth_ref_chars(cfg.seed, w.ref_id, p)
+            got = w.reference_base[keep]
+            bad = np.nonzero(got != exp)[0]
+            assert len(bad) == 0, (w.ref_id, [(int(p[k]), chr(got[k]), chr(exp[k])) for k in bad[:8]])
+            if not skip:
+                assert (w.reference_base[~keep] == ord("N")).all()       # uncovered columns: empty chunk, pileup.d:620-622
+            n_cols += int(keep.sum())
+    assert n_cols > n_reads
+
+
 def test_cpp_facade(tmp_path, data_dir):
     """include/biodgpu_pileup.hpp: the reference's own pileup checks (test/unittests.d:320-366,
     examples/make_pileup.d:20-30) through the C++ mirror of BioD's range API."""
