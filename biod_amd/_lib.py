@@ -81,6 +81,19 @@ SYMBOLS = {
     "bgp_pileup_next_window": (C.c_int, [_P, C.POINTER(Columns)]),
     "bgp_pileup_ref_id": (C.c_int, [_P, C.POINTER(C.c_int32)]),
     "bgp_read_dna": (C.c_int, [_P, C.c_uint64, C.c_char_p, C.c_uint32, C.POINTER(C.c_uint32)]),
+    "bgp_bai_open": (C.c_int, [C.c_char_p, C.POINTER(_P)]),
+    "bgp_bai_close": (None, [_P]),
+    "bgp_bai_n_ref": (C.c_int, [_P, C.POINTER(C.c_int32)]),
+    "bgp_bai_shape": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "bgp_bai_min_offset": (C.c_int, [_P, C.c_int32, C.c_int32, C.POINTER(C.c_uint64)]),
+    "bgp_bai_chunks": (C.c_int, [_P, C.c_int32, C.c_uint32, C.c_uint32, C.POINTER(_P), C.POINTER(C.c_uint32)]),
+    "bgp_reg2bin": (C.c_int, [C.c_int32, C.c_int32]),
+    "bgp_bin_can_overlap": (C.c_int, [C.c_uint32, C.c_int32, C.c_int32]),
+    "bgp_bgzf_read_chunks": (C.c_int, [C.c_char_p, _P, C.c_uint32, C.c_int, _P, C.c_uint64, C.POINTER(C.c_uint64)]),
+    "bgp_load_bam_region": (C.c_int, [_P, C.c_char_p, _P, C.c_int32, C.c_uint32, C.c_uint32, C.c_int]),
+    "bgp_filter_region": (C.c_int, [_P, C.c_int32, C.c_uint32, C.c_uint32]),
+    "bgp_load_bam_read_at": (C.c_int, [_P, C.c_char_p, C.c_uint64]),
+    "bgp_record_voffset": (C.c_int, [_P, C.c_uint64, C.POINTER(C.c_uint64)]),
     "bgp_hist_reduce": (C.c_int, [_P, _P, _P, C.c_size_t]),
     "bgp_timing_enable": (C.c_int, [_P, C.c_int]),
     "bgp_timing_reset": (C.c_int, [_P]),

@@ -101,7 +101,8 @@ static void release_all(bgp_ctx* c) {
                    &c->d_seg_rec_base, &c->d_seg_seq_base, &c->d_seg_cig_base, &c->d_scan_tmp, &c->d_status, &c->d_rec, &c->d_seq_off, &c->d_cigar_off,
                    &c->d_seq, &c->d_qual, &c->d_cigar, &c->d_pmax_end, &c->d_pmax_pos, &c->d_runs, &c->d_columns, &c->d_depth_hist, &c->d_pstats,
                    &c->d_tiles, &c->d_ck_off, &c->d_ck, &c->d_entry_off, &c->d_entries, &c->d_col_lo,
-                   &c->d_md_row, &c->d_md_iv, &c->d_md_state, &c->d_refbase};
+                   &c->d_md_row, &c->d_md_iv, &c->d_md_state, &c->d_refbase, &c->d_rec2, &c->d_seq_off2, &c->d_cigar_off2,
+                   &c->d_flt[0], &c->d_flt[1], &c->d_flt[2], &c->d_flt[3], &c->d_flt[4], &c->d_flt[5]};
     for (auto* b : d) b->release();
     HostBuf* h[] = {&c->h_stage, &c->h_rec, &c->h_seq_off, &c->h_cigar_off, &c->h_seq, &c->h_qual, &c->h_cigar, &c->h_cols, &c->h_entry_off, &c->h_entries, &c->h_refbase};
     for (auto* b : h) b->release();
@@ -132,7 +133,7 @@ int bgp_reset(bgp_ctx* c) {
     BGP_HIP(hipStreamSynchronize(c->stream));
     c->h_stage_len = 0; c->d_stream = nullptr; c->stream_len = 0; c->stream_on_device = false;
     c->flushed = false; c->piled = false; c->md_rows_ready = false; c->n_records = 0; c->decoded_what = 0; c->it = bgp_ctx::Iter();
-    c->runs.clear();
+    c->runs.clear(); c->stage_map.clear(); c->region_pending = false;
     return BGP_OK;
 }
 
@@ -165,6 +166,7 @@ int bgp_flush(bgp_ctx* c) {
     int rc = k0_frame(c);
     if (rc < 0) return rc;
     c->flushed = true;
+    if (c->region_pending) BGP_TRY(k_region_filter(c, c->region_ref, c->region_beg, c->region_end));   // bam[ref][beg..end]
     return BGP_OK;
 }
 
@@ -369,6 +371,40 @@ int bgp_load_bam(bgp_ctx* c, const char* path, int n_threads) {
     if (!c || !path) return BGP_EINVAL;
     if (c->flushed || c->stream_on_device) return BGP_ESTATE;
     return bgzf_load_bam(c, path, n_threads);
+}
+int bgp_load_bam_region(bgp_ctx* c, const char* path, bgp_bai* bai, int32_t ref_id, uint32_t beg, uint32_t end, int n_threads) {
+    if (!c || !path || !bai) return BGP_EINVAL;
+    if (c->flushed || c->stream_on_device || c->h_stage_len) return BGP_ESTATE;
+    if (!(beg < end)) { c->last_error = "start must be less than end"; return BGP_EINVAL; }          // reference.d:76
+    if (ref_id < 0) { c->last_error = "invalid reference id"; return BGP_EINVAL; }                   // reference.d:78
+    BGP_TRY(bai_load_header(c, path));
+    const bgp_chunk* ch = nullptr; uint32_t n = 0;
+    const int rc = bgp_bai_chunks(bai, ref_id, beg, end, &ch, &n);
+    if (rc < 0) { c->last_error = "Invalid reference sequence index"; return rc; }                   // randomaccessmanager.d:205-207
+    BGP_TRY(bai_stage_chunks(c, path, ch, n, n_threads));
+    c->region_pending = true; c->region_ref = (uint32_t)ref_id; c->region_beg = beg; c->region_end = end;
+    return BGP_OK;
+}
+int bgp_filter_region(bgp_ctx* c, int32_t ref_id, uint32_t beg, uint32_t end) {
+    if (!c) return BGP_EINVAL;
+    if (!c->flushed) return BGP_ESTATE;
+    BGP_HIP(hipSetDevice(c->device));
+    return k_region_filter(c, (uint32_t)ref_id, beg, end);
+}
+int bgp_load_bam_read_at(bgp_ctx* c, const char* path, uint64_t voffset) {
+    if (!c || !path) return BGP_EINVAL;
+    if (c->flushed || c->stream_on_device) return BGP_ESTATE;
+    if (c->refs.empty()) BGP_TRY(bai_load_header(c, path));
+    return bai_stage_read_at(c, path, voffset);
+}
+int bgp_record_voffset(bgp_ctx* c, uint64_t record, uint64_t* voffset) {
+    if (!c || !voffset) return BGP_EINVAL;
+    if (!c->flushed || record >= c->n_records) return c && c->flushed ? BGP_EINVAL : BGP_ESTATE;
+    BGP_HIP(hipSetDevice(c->device));
+    bgp_record r;
+    BGP_HIP(hipMemcpyAsync(&r, c->d_rec.as<bgp_record>() + record, sizeof r, hipMemcpyDeviceToHost, c->stream));
+    BGP_HIP(hipStreamSynchronize(c->stream));
+    return bai_record_voffset(c, r.rec_off, voffset);
 }
 int bgp_n_ref(bgp_ctx* c, int32_t* n) { if (!c || !n) return BGP_EINVAL; *n = (int32_t)c->refs.size(); return BGP_OK; }
 int bgp_ref_info(bgp_ctx* c, int32_t id, const char** name, int32_t* length) {

@@ -78,7 +78,7 @@ int inflate_block(const uint8_t* f, const Blk& b, uint8_t* dst) {         // blo
 
 // BAM magic + header text + reference table (reader.d:111-116,579-597) from the first `avail` inflated bytes.
 // Returns 1 and the offset of the first record when complete, 0 when more bytes are needed, <0 on error.
-static int parse_bam_header(const uint8_t* p, uint64_t avail, std::vector<RefInfo>& refs, uint64_t* records_off, std::string& err) {
+int bgp_parse_bam_header(const uint8_t* p, uint64_t avail, std::vector<RefInfo>& refs, uint64_t* records_off, std::string& err) {
     if (avail < 12) return 0;
     if (memcmp(p, "BAM\1", 4) != 0) { err = "wrong BAM magic"; return BGP_EINVAL; }
     int32_t l_text; memcpy(&l_text, p + 4, 4);
@@ -125,7 +125,7 @@ int bgzf_load_bam(bgp_ctx* c, const char* path, int n_threads) {
         rc = inflate_block(file, blocks[jh], head.data() + blocks[jh].uoff);
         if (rc < 0) { c->last_error = "zlib: corrupted BGZF block"; return rc; }
         ++jh;
-        got = parse_bam_header(head.data(), head.size(), c->refs, &q, c->last_error);
+        got = bgp_parse_bam_header(head.data(), head.size(), c->refs, &q, c->last_error);
         if (got < 0) return got;
     }
     if (got == 0) { c->last_error = total < 4 ? "wrong BAM magic" : "truncated BAM header"; return total < 4 ? BGP_EINVAL : BGP_ETRUNC; }
@@ -153,6 +153,11 @@ int bgzf_load_bam(bgp_ctx* c, const char* path, int n_threads) {
     worker();
     for (auto& t : th) t.join();
     if (status.load() < 0) { c->last_error = "zlib: corrupted BGZF block"; return status.load(); }
+    for (const Blk& b : blocks) {                         // where every staged byte came from (withOffsets, readrange.d:64-86)
+        if (b.uoff + b.isize <= q) continue;
+        const uint32_t skip = b.uoff < q ? (uint32_t)(q - b.uoff) : 0u;
+        c->stage_map.push_back(bgp_ctx::StageSeg{c->h_stage_len + (b.uoff + skip - q), b.isize - skip, b.coff, skip});
+    }
     c->h_stage_len += rec_bytes;
     return BGP_OK;
 }

@@ -92,6 +92,9 @@ struct bgp_ctx {
 
     // staged stream
     HostBuf h_stage; uint64_t h_stage_len = 0;        // pushed host bytes
+    struct StageSeg { uint64_t staged; uint32_t len; uint64_t coff; uint32_t skip; };   // staged bytes [staged, +len) = block at coff, from uoffset skip
+    std::vector<StageSeg> stage_map;                  // filled by the BGZF loaders (virtual offsets of records)
+    bool region_pending = false; uint32_t region_ref = 0, region_beg = 0, region_end = 0;   // bam[ref][beg..end]: filter applied by bgp_flush
     DevBuf d_stream_own;                              // device copy of pushed bytes
     const uint8_t* d_stream = nullptr; uint64_t stream_len = 0;
     bool stream_on_device = false;                    // d_stream valid
@@ -109,6 +112,7 @@ struct bgp_ctx {
 
     // record table (K1)
     DevBuf d_rec, d_seq_off, d_cigar_off;
+    DevBuf d_rec2, d_seq_off2, d_cigar_off2, d_flt[6];   // region filter: compaction targets (swapped in) and scan scratch
     // decode arenas (K2)
     DevBuf d_seq, d_qual, d_cigar;
     uint32_t decoded_what = 0;
@@ -161,6 +165,12 @@ int k6_reference_bases(bgp_ctx* c, int skip_zero, uint32_t run_first, uint32_t r
 int synth_device(bgp_ctx* c, const bgp_synth_cfg_c* cfg, uint64_t* bytes);   // synth.hip
 int synth_host(const bgp_synth_cfg_c* cfg, uint64_t first, uint64_t count, uint8_t* out, uint64_t cap, uint64_t* bytes);
 int bgzf_load_bam(bgp_ctx* c, const char* path, int n_threads);               // bgzf_host.cpp
+int bgp_parse_bam_header(const uint8_t* p, uint64_t avail, std::vector<RefInfo>& refs, uint64_t* records_off, std::string& err);
+int k_region_filter(bgp_ctx* c, uint32_t ref, uint32_t beg, uint32_t end);    // region.hip
+int bai_stage_chunks(bgp_ctx* c, const char* path, const bgp_chunk* chunks, uint32_t n, int n_threads);   // bai_host.cpp
+int bai_load_header(bgp_ctx* c, const char* path);
+int bai_stage_read_at(bgp_ctx* c, const char* path, uint64_t voffset);
+int bai_record_voffset(bgp_ctx* c, uint64_t staged_off, uint64_t* voffset);
 
 // device helpers shared by kernels
 #if defined(__HIPCC__)

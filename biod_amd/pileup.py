@@ -67,6 +67,30 @@ class Context:
     def load_bam(self, path: str, n_threads: int = 0):
         L.check(L.lib().bgp_load_bam(self._h, path.encode(), n_threads), self._h)
 
+    def load_bam_region(self, path: str, bai: "BaiFile", ref_id: int, beg: int, end: int, n_threads: int = 0):
+        """bam[ref][beg .. end] (reference.d:73-81): stage the BAI chunks' records; flush() then keeps the overlapping reads."""
+        L.check(L.lib().bgp_load_bam_region(self._h, path.encode(), bai.handle, ref_id, beg, end, n_threads), self._h)
+
+    def filter_region(self, ref_id: int, beg: int, end: int):
+        """BamReadFilter (randomaccessmanager.d:366-462) on the flushed record table."""
+        L.check(L.lib().bgp_filter_region(self._h, ref_id, beg, end), self._h)
+
+    def load_bam_read_at(self, path: str, voffset: int):
+        """getReadAt (randomaccessmanager.d:156-164)."""
+        L.check(L.lib().bgp_load_bam_read_at(self._h, path.encode(), voffset), self._h)
+
+    def record_voffset(self, record: int) -> int:
+        """read.start_virtual_offset (reads!withOffsets, readrange.d:64-86)."""
+        v = C.c_uint64()
+        L.check(L.lib().bgp_record_voffset(self._h, record, C.byref(v)), self._h)
+        return v.value
+
+    def staged_bytes(self) -> np.ndarray:
+        """Host copy of the staged (inflated) record bytes; record i starts at rec['rec_off'][i]."""
+        r = L.Records()
+        L.check(L.lib().bgp_decode_fetch(self._h, 0, C.byref(r)), self._h)
+        return L.as_array(r.stream, r.stream_len, "u1")
+
     def references(self):
         n = C.c_int32()
         L.check(L.lib().bgp_n_ref(self._h, C.byref(n)), self._h)
@@ -212,17 +236,179 @@ class RecordStream:
         return self.records
 
 
+class BaiFile:
+    """``BaiFile(filename)`` (baifile.d:87-169) -- host side, no GPU needed."""
+
+    def __init__(self, filename: str):
+        self._h = C.c_void_p()
+        L.check(L.lib().bgp_bai_open(filename.encode(), C.byref(self._h)))
+
+    @property
+    def handle(self):
+        return self._h
+
+    def close(self):
+        if self._h:
+            L.lib().bgp_bai_close(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def n_ref(self) -> int:
+        n = C.c_int32()
+        L.check(L.lib().bgp_bai_n_ref(self._h, C.byref(n)))
+        return n.value
+
+    def shape(self, ref_id: int):
+        """(bins, chunks, linear-index intervals) of one reference."""
+        a, b, c = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        L.check(L.lib().bgp_bai_shape(self._h, ref_id, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    def min_offset(self, ref_id: int, position: int) -> int:
+        """Index.getMinimumOffset, baifile.d:77-82."""
+        v = C.c_uint64()
+        L.check(L.lib().bgp_bai_min_offset(self._h, ref_id, position, C.byref(v)))
+        return v.value
+
+    def chunks(self, ref_id: int, beg: int, end: int) -> np.ndarray:
+        """RandomAccessManager.getChunks, randomaccessmanager.d:222-244: (n, 2) uint64 virtual offsets."""
+        p, n = C.c_void_p(), C.c_uint32()
+        L.check(L.lib().bgp_bai_chunks(self._h, ref_id, beg, end, C.byref(p), C.byref(n)))
+        return L.as_array(p.value, 2 * n.value, "<u8").reshape(-1, 2)
+
+
+def read_chunks(bam_path: str, chunks: np.ndarray, n_threads: int = 0) -> bytes:
+    """The inflated bytes a chunk list stands for (StreamChunksSupplier, inputstream.d:254-330)."""
+    ch = np.ascontiguousarray(chunks, dtype="<u8").reshape(-1, 2)
+    n = C.c_uint64()
+    L.check(L.lib().bgp_bgzf_read_chunks(bam_path.encode(), ch.ctypes.data, len(ch), n_threads, None, 0, C.byref(n)))
+    buf = np.zeros(max(n.value, 1), np.uint8)
+    L.check(L.lib().bgp_bgzf_read_chunks(bam_path.encode(), ch.ctypes.data, len(ch), n_threads, buf.ctypes.data, n.value, C.byref(n)))
+    return buf[:n.value].tobytes()
+
+
+class _RegionReads:
+    """``bam["chr1"][beg .. end]`` (reference.d:73-81): reads overlapping the region, staged through the BAI."""
+
+    def __init__(self, reader: "BamReader", ref_id: int, beg: int, end: int):
+        self.reader, self.ref_id, self.beg, self.end = reader, ref_id, beg, end
+        self.data = None
+        self.records = None
+        self.ctx = None
+
+    def _stage(self):
+        r = self.reader
+        ctx = r._region_context()
+        if r._region_owner is not self:
+            ctx.reset()
+            ctx.load_bam_region(r.filename, r.bai, self.ref_id, self.beg, self.end, r.n_threads)
+            ctx.flush()
+            r._region_owner = self
+        self.ctx = ctx
+        return ctx
+
+    def decode(self, what=L.BGP_FETCH_ALL):
+        self.records = self._stage().decode_fetch(what)
+        return self.records
+
+    def __len__(self):
+        return self._stage().num_records()
+
+    @property
+    def empty(self) -> bool:
+        return len(self) == 0
+
+    def names(self) -> List[str]:
+        ctx = self._stage()
+        rec = ctx.decode_fetch(0).rec
+        data = ctx.staged_bytes()
+        out = []
+        for r in rec:
+            off, ln = int(r["rec_off"]) + 36, int(r["bin_mq_nl"]) & 0xFF
+            out.append(data[off:off + ln - 1].tobytes().decode("latin-1"))
+        return out
+
+
+class ReferenceSequence:
+    """reference.d:40-221: ``bam["chr1"]``; slicing gives the reads overlapping ``[start, end)``."""
+
+    def __init__(self, reader: "BamReader", ref_id: int, name: str, length: int):
+        self._reader, self.id, self.name, self.length = reader, ref_id, name, length
+
+    def __getitem__(self, sl) -> _RegionReads:
+        if not isinstance(sl, slice) or sl.step is not None:
+            raise TypeError("use bam[name][start:end]")
+        start = 0 if sl.start is None else int(sl.start)
+        end = self.length if sl.stop is None else int(sl.stop)
+        return _RegionReads(self._reader, self.id, start, end)
+
+    def reads(self) -> _RegionReads:                     # opSlice(), reference.d:84-86
+        return self[0:self.length]
+
+    def startVirtualOffset(self) -> int:                 # reference.d:96-104 (empty -> EOF offset is the host's business)
+        rr = self.reads()
+        if rr.empty:
+            raise ValueError("no reads on this reference")
+        return rr._stage().record_voffset(0)
+
+    def firstPosition(self) -> int:                      # reference.d:147-153
+        rr = self.reads()
+        return -1 if rr.empty else int(rr._stage().decode_fetch(0).rec["pos"][0])
+
+
 class BamReader:
-    """``new BamReader(filename)`` (reader.d:127-138): ``.reads`` is the range handed to makePileup."""
+    """``new BamReader(filename)`` (reader.d:127-138): ``.reads`` is the range handed to makePileup;
+    ``reader["chr1"][a:b]`` (reader.d opIndex -> reference.d:73-81) needs the ``.bai`` next to the file."""
 
     def __init__(self, filename: str, n_threads: int = 0, ctx: Optional[Context] = None):
         self.filename = filename
+        self.n_threads = n_threads
         self.ctx = ctx or Context()
         self.ctx.reset()
         self.ctx.load_bam(filename, n_threads)
         self.reference_sequences = self.ctx.references()
         self.ctx.flush()
         self.reads = _LoadedReads(self.ctx)
+        self._bai = None
+        self._rctx = None
+        self._region_owner = None
+
+    @property
+    def bai(self) -> BaiFile:
+        if self._bai is None:
+            self._bai = BaiFile(self.filename)          # "BAM index file (.bai) must be provided", randomaccessmanager.d:201-203
+        return self._bai
+
+    def _region_context(self) -> Context:
+        if self._rctx is None:
+            self._rctx = Context()
+        return self._rctx
+
+    def __getitem__(self, name: str) -> ReferenceSequence:
+        for i, (nm, ln) in enumerate(self.reference_sequences):
+            if nm == name:
+                return ReferenceSequence(self, i, nm, ln)
+        raise KeyError(name)
+
+    def reference(self, ref_id: int) -> ReferenceSequence:
+        nm, ln = self.reference_sequences[ref_id]
+        return ReferenceSequence(self, ref_id, nm, ln)
+
+    def getReadAt(self, voffset: int) -> "RecordStream":
+        """randomaccessmanager.d:156-164: the single read starting at a virtual offset."""
+        ctx = self._region_context()
+        ctx.reset()
+        ctx.load_bam_read_at(self.filename, voffset)
+        ctx.flush()
+        self._region_owner = None
+        rs = _LoadedReads(ctx)
+        return rs
 
 
 class _LoadedReads:

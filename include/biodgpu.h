@@ -201,6 +201,42 @@ int bgp_pileup_ref_id(bgp_ctx* ctx, int32_t* ref_id);          /* AbstractPileup
  * BioD builds would run into an exhausted query (MD longer than the CIGAR's M/=/X bases). */
 int bgp_read_dna(bgp_ctx* ctx, uint64_t record, char* out, uint32_t cap, uint32_t* len);
 
+/* ---- BAI index and region queries: bam["chr"][beg .. end] feeding the device path (host side) ----
+ * Virtual offsets are coffset << 16 | uoffset (bio/core/bgzf/virtualoffset.d:30-52); a chunk is a pair of
+ * them (bio/core/bgzf/chunk.d:28-40). */
+typedef struct bgp_bai bgp_bai;
+typedef struct bgp_chunk { uint64_t beg, end; } bgp_chunk;
+/* BaiFile(filename): accepts x.bam (tries x.bam.bai, then x.bai) or the .bai itself; parses section 4.2
+ * (bio/std/hts/bam/baifile.d:92-169). */
+int bgp_bai_open(const char* bam_or_bai_path, bgp_bai** out);
+void bgp_bai_close(bgp_bai* bai);
+int bgp_bai_n_ref(const bgp_bai* bai, int32_t* n_ref);
+int bgp_bai_shape(const bgp_bai* bai, int32_t ref_id, uint32_t* n_bins, uint32_t* n_chunks, uint32_t* n_intervals);
+/* Index.getMinimumOffset (baifile.d:77-82): linear-index lower bound for reads overlapping `position`. */
+int bgp_bai_min_offset(const bgp_bai* bai, int32_t ref_id, int32_t position, uint64_t* voffset);
+/* RandomAccessManager.getChunks (randomaccessmanager.d:209-244): bins that can overlap [beg, end), their
+ * chunks ending after the linear-index offset (clamped to it), sorted, overlaps merged (algo.d:95-147).
+ * The array is owned by `bai` and valid until the next call. */
+int bgp_bai_chunks(bgp_bai* bai, int32_t ref_id, uint32_t beg, uint32_t end, const bgp_chunk** chunks, uint32_t* n);
+int bgp_reg2bin(int32_t beg, int32_t end);                       /* bai/bin.d:82-92 */
+int bgp_bin_can_overlap(uint32_t bin_id, int32_t beg, int32_t end);   /* Bin.canOverlapWith, bai/bin.d:55-77 */
+/* The inflated bytes a chunk list stands for (StreamChunksSupplier, bio/core/bgzf/inputstream.d:254-330): every
+ * block from beg.coffset to end.coffset, minus beg.uoffset leading bytes of the first and everything from
+ * end.uoffset on in the last.  *len is always set; bytes are written only when cap >= *len. */
+int bgp_bgzf_read_chunks(const char* bam_path, const bgp_chunk* chunks, uint32_t n, int n_threads,
+                         uint8_t* out, uint64_t cap, uint64_t* len);
+/* bam[ref_id][beg .. end] (reference.d:73-81 -> getReads, randomaccessmanager.d:330-336): reads the BAM
+ * header, stages the records of getChunks(region); the following bgp_flush frames them and keeps exactly
+ * the reads BamReadFilter (randomaccessmanager.d:366-462) yields.  beg < end is enforced (reference.d:76). */
+int bgp_load_bam_region(bgp_ctx* ctx, const char* bam_path, bgp_bai* bai, int32_t ref_id, uint32_t beg, uint32_t end, int n_threads);
+/* BamReadFilter applied to the flushed record table in place (any staged stream, e.g. a whole file). */
+int bgp_filter_region(bgp_ctx* ctx, int32_t ref_id, uint32_t beg, uint32_t end);
+/* getReadAt (randomaccessmanager.d:156-164): stages the single record that starts at `voffset`. */
+int bgp_load_bam_read_at(bgp_ctx* ctx, const char* bam_path, uint64_t voffset);
+/* BamReadBlock.start_virtual_offset of record i (reads!withOffsets, readrange.d:64-86); needs a stream
+ * staged by bgp_load_bam / bgp_load_bam_region / bgp_load_bam_read_at. */
+int bgp_record_voffset(bgp_ctx* ctx, uint64_t record, uint64_t* voffset);
+
 /* Whole-BAM histogram reduce across ranks (the only collective of the path): sums `n` uint64
  * values in HBM over all ranks of an RCCL communicator (ncclComm_t passed as void*).
  * CPU equivalent: a fold over column.coverage (pileup.d:252). */

@@ -51,6 +51,21 @@ public:
     }
     uint64_t num_reads() const { uint64_t n; check(bgp_num_records(ctx_, &n), ctx_); return n; }
     BamReader& reads() { return *this; }                                       // reader.d:228-231
+    // bam["chr1"][beg .. end] (reader.d opIndex -> reference.d:73-81): re-stages this reader with the reads that
+    // overlap the region, found through the .bai next to the file (RandomAccessManager.getReads, :330-336).
+    BamReader& fetch(const std::string& filename, const std::string& ref_name, uint32_t beg, uint32_t end, int n_threads = 0) {
+        bgp_bai* bai = nullptr;
+        check(bgp_bai_open(filename.c_str(), &bai), ctx_);                     // "BAM index file (.bai) must be provided"
+        struct Close { bgp_bai* b; ~Close() { bgp_bai_close(b); } } guard{bai};
+        int32_t id = -1; const auto refs = reference_sequences();
+        for (size_t i = 0; i < refs.size(); ++i) if (refs[i].name == ref_name) id = (int32_t)i;
+        if (id < 0) throw std::out_of_range("no such reference: " + ref_name);
+        check(bgp_reset(ctx_), ctx_);
+        check(bgp_load_bam_region(ctx_, filename.c_str(), bai, id, beg, end, n_threads), ctx_);
+        check(bgp_flush(ctx_), ctx_);
+        return *this;
+    }
+    uint64_t start_virtual_offset(uint64_t read_index) const { uint64_t v; check(bgp_record_voffset(ctx_, read_index, &v), ctx_); return v; }   // readrange.d:64-86
     bgp_ctx* ctx() const { return ctx_; }
 
 private:

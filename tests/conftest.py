@@ -7,6 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))            # bai_oracle.py: the checker, imported by tests only
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 DATA = os.path.join(GOLDEN, "data")

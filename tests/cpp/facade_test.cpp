@@ -66,6 +66,18 @@ int main(int argc, char** argv) {
         REQUIRE(cols > 100 && agree * 10 > cols * 9);
         for (auto column : makePileup(bam.reads(), false)) REQUIRE(column.reference_base() == 'N');      // pileup.d:245-249
     }
+    if (argc > 3) {                                                      // unittests.d:145-185: bam["large"][beg .. end] == naive filter
+        BamReader all(argv[3], 2);
+        bgp_records recs; check(bgp_decode_fetch(all.ctx(), 0, &recs), all.ctx());
+        const int regions[][2] = {{1400, 1500}, {10, 123}, {135, 1236}, {0, 3000}, {50000, 50100}, {950000, 950100}};
+        BamReader bam(argv[3], 2);
+        for (auto& rg : regions) {
+            size_t naive = 0;
+            for (uint64_t i = 0; i < recs.n; ++i)
+                naive += recs.rec[i].ref_id == 2 && recs.rec[i].pos < rg[1] && recs.rec[i].end_pos > rg[0];
+            REQUIRE(bam.fetch(argv[3], "large", (uint32_t)rg[0], (uint32_t)rg[1], 2).num_reads() == naive);
+        }
+    }
     std::puts("facade ok");
     return 0;
 }

@@ -397,7 +397,8 @@ def test_cpp_facade(tmp_path, data_dir):
     exe = str(tmp_path / "facade_test")
     subprocess.check_call(["g++", "-std=c++17", "-O2", "-I" + os.path.join(root, "include"), os.path.join(root, "tests", "cpp", "facade_test.cpp"),
                            "-o", exe, "-L" + os.path.join(root, "biod_amd"), "-lbiodgpu", "-Wl,-rpath," + os.path.join(root, "biod_amd")])
-    out = subprocess.run([exe, os.path.join(data_dir, "ex1_header.bam"), os.path.join(data_dir, "illu_20_chunk.bam")], capture_output=True, text=True)
+    out = subprocess.run([exe, os.path.join(data_dir, "ex1_header.bam"), os.path.join(data_dir, "illu_20_chunk.bam"), os.path.join(data_dir, "bins.bam")],
+                         capture_output=True, text=True)
     assert out.returncode == 0 and "facade ok" in out.stdout, out.stderr
 
 
@@ -686,6 +687,114 @@ def test_reference_base_stale_chunk_end_across_references(ctx):
         assert ora is not None
         col = {(int(r), int(p)): chr(b) for r, p, b in zip(ora.ref, ora.pos, ora.refbase)}
         assert col[(1, 3)] == "T" and col[(2, 7)] == "C"          # d (end 28 > stale 20) and f (end 47 > stale 28) win
+
+
+# ------------------------------------------------------------------------------------------ BAI / region queries (f3)
+def _expected_region(st_all_records, ref_id, beg, end):
+    import bai_oracle as B
+    kept = B.region_filter(B.frame(st_all_records), ref_id, beg, end)
+    sizes = {r[0]: 4 + int(np.frombuffer(st_all_records, "<i4", 1, r[0])[0]) for r in kept}
+    return kept, b"".join(st_all_records[r[0]:r[0] + sizes[r[0]]] for r in kept)
+
+
+def _check_subset_decode(dec, exp_stream):
+    soa = O.decode_soa(exp_stream)
+    assert len(dec) == len(soa.rec_off)
+    for f in ("ref_id", "pos", "end_pos", "bin_mq_nl", "flag_nc", "l_seq"):
+        assert np.array_equal(dec.rec[f], getattr(soa, f)), f
+    assert np.array_equal(dec.seq_off, soa.seq_off) and np.array_equal(dec.cigar_off, soa.cigar_off)
+    e = np.zeros(0, np.uint8)
+    assert np.array_equal(dec.seq if dec.seq is not None else e, soa.seq) and np.array_equal(dec.qual if dec.qual is not None else e, soa.qual)
+    assert np.array_equal(dec.cigar if dec.cigar is not None else np.zeros(0, np.uint32), soa.cigar)
+
+
+def test_region_queries_match_reference_checks(data_dir):
+    """test/unittests.d:145-206 through the device path: bam["large"][beg .. end] == naive filter for the reference's
+    40 regions (names, decoded fields, and the pileup of the region's reads), and the first read of every reference
+    found through startVirtualOffset + getReadAt."""
+    import bai_oracle as B
+    from test_oracle_bai import REGIONS
+    path = os.path.join(data_dir, "bins.bam")
+    hdr, st = bamio.read_bam(path)
+    recs = B.frame(st)
+    bam = BamReader(path, n_threads=2)
+    large = bam["large"]
+    for beg, end in REGIONS:
+        rr = large[beg:end]
+        exp = [r for r in recs if r[1] == large.id and r[2] < end and r[3] > beg]          # unittests.d:152-157
+        assert rr.names() == [r[4] for r in exp], (beg, end)
+        kept, exp_stream = _expected_region(st, large.id, beg, end)
+        assert [r[4] for r in kept] == [r[4] for r in exp]
+        _check_subset_decode(rr.decode(), exp_stream)
+        if exp:
+            info = rr._stage().pileup_run()
+            ora = O.pileup(exp_stream)
+            assert (info.n_columns, info.sum_coverage, info.max_coverage) == (ora.n_columns, ora.sum_coverage, ora.max_coverage)
+    for name in ("tiny", "small", "large"):
+        vo = bam[name].startVirtualOffset()
+        one = bam.getReadAt(vo)
+        rec = one.ctx.decode_fetch(0).rec
+        data = one.ctx.staged_bytes()
+        assert len(rec) == 1
+        off, ln = int(rec["rec_off"][0]) + 36, int(rec["bin_mq_nl"][0]) & 0xFF
+        assert data[off:off + ln - 1].tobytes().decode() == f"{name}:r1:0..1:len1:bin4681:hexbin0x1249"
+        assert one.ctx.record_voffset(0) == vo
+    # virtual offsets of a whole-file load: the first record sits right behind the header
+    v0 = bam.ctx.record_voffset(0)
+    assert bam.getReadAt(v0).ctx.decode_fetch(0).rec["pos"][0] == bam.ctx.decode_fetch(0).rec["pos"][0]
+
+
+@pytest.mark.parametrize("name", ["ex1_header.bam", "tags.bam", "bins.bam"])
+def test_region_load_and_filter_match_oracle(ctx, data_dir, name):
+    """Index-driven load (getChunks + StreamChunksSupplier + BamReadFilter) == the oracle's restatement of it, and
+    BamReadFilter over the whole file == the oracle's filter.  The two differ where the index says so: ex1's first
+    read (unmapped, placed at 99) lies before the linear index's first offset, so bam["chr1"][0 .. $] starts at the
+    second read in BioD (chunk.beg is clamped to it, randomaccessmanager.d:209-219) -- and here."""
+    import bai_oracle as B
+    from biod_amd.pileup import BaiFile
+    path = os.path.join(data_dir, name)
+    hdr, st = bamio.read_bam(path)
+    bai = BaiFile(path)
+    obai = B.parse_bai(path)
+    rng = np.random.default_rng(17)
+    for rid, (rname, rlen) in enumerate(hdr.refs):
+        for beg, end in [(0, max(rlen, 1)), (0, 1), (10, 11)] + [(int(a), int(a) + int(b)) for a, b in zip(rng.integers(0, max(rlen, 2), 6), rng.integers(1, 3000, 6))]:
+            cst, ckept = B.region_reads(path, obai, rid, beg, end)
+            _, exp_index = _expected_region(cst, rid, beg, end)
+            ctx.reset(); ctx.load_bam_region(path, bai, rid, beg, end, 2); ctx.flush()
+            _check_subset_decode(ctx.decode_fetch(), exp_index)
+            kept, exp_stream = _expected_region(st, rid, beg, end)
+            ctx.reset(); ctx.load_bam(path, 2); ctx.flush(); ctx.filter_region(rid, beg, end)
+            _check_subset_decode(ctx.decode_fetch(), exp_stream)
+            if kept:
+                check_pileup_subset = O.pileup(exp_stream)
+                info = ctx.pileup_run()
+                assert (info.n_columns, info.sum_coverage) == (check_pileup_subset.n_columns, check_pileup_subset.sum_coverage)
+    with pytest.raises(L.BiodGpuError):
+        ctx.reset(); ctx.load_bam_region(path, bai, 0, 5, 5, 1)          # enforce(start < end), reference.d:76
+    with pytest.raises(L.BiodGpuError):
+        ctx.reset(); ctx.load_bam_region(path, bai, len(hdr.refs), 0, 5, 1)   # checkRefId, randomaccessmanager.d:205-207
+    ctx.reset()
+
+
+def test_filter_region_stops_like_the_range(ctx):
+    """BamReadFilter ends at the first read past the region (randomaccessmanager.d:398-431) -- on unsorted input
+    that is not the same as a predicate, and unmapped reads (ref_id -1 = uint.max) end it too."""
+    import bai_oracle as B
+    rng = np.random.default_rng(23)
+    recs = []
+    for i in range(600):
+        ref = int(rng.choice([0, 1, 1, 1, 2, -1], p=[0.1, 0.3, 0.3, 0.2, 0.05, 0.05])) if i > 50 else int(rng.integers(0, 2))
+        pos = int(rng.integers(0, 3000))
+        ln = int(rng.integers(0, 80))
+        ops = [(ln, "M")] if ln else []
+        recs.append(bamio.pack_record(f"u{i}", "A" * ln, ops, ref_id=ref, pos=pos))
+    st = b"".join(recs)
+    for beg, end in [(0, 3000), (100, 200), (1500, 1501), (2999, 5000), (0, 1)]:
+        stage(ctx, st)
+        ctx.filter_region(1, beg, end)
+        kept, exp_stream = _expected_region(st, 1, beg, end)
+        _check_subset_decode(ctx.decode_fetch(), exp_stream)
 
 
 def test_hist_reduce_single_rank_rccl(ctx):
