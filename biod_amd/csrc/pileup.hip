@@ -31,9 +31,20 @@
 
 namespace {
 
-constexpr int W = 2048;                // reference positions per workgroup
-constexpr int HB = 1024;               // depth-histogram bins kept in LDS
-constexpr int K4_T = 512;
+// Window geometry.  A window's life is a chain of dependent memory round trips (candidate rows -> record rows ->
+// CIGAR + SEQ) that does not shrink with the window, so the biggest window LDS can hold wins: measured on cfg3
+// (50 M reads) 2048 positions / 512 threads (2 workgroups per CU) 10.0 ms, 1024 / 256 (4 per CU) 10.6 ms,
+// 4096 / 1024 (148 KB of LDS, one workgroup of 16 waves per CU) 8.9 ms.
+#ifndef BGP_K4_W
+#define BGP_K4_W 4096
+#define BGP_K4_T 1024
+#define BGP_K4_HB 1024
+#endif
+constexpr int W = BGP_K4_W;            // reference positions per workgroup (power of two)
+constexpr int HB = BGP_K4_HB;          // depth-histogram bins kept in LDS
+constexpr int K4_T = BGP_K4_T;
+constexpr int CLS_SHIFT = W == 2048 ? 13 : W == 1024 ? 12 : W == 512 ? 11 : 14;   // log2(bytes of one class array)
+static_assert((1 << CLS_SHIFT) == W * 4, "W must be 512, 1024, 2048 or 4096");
 constexpr uint32_t MAX_RUNS = 1u << 16;
 
 
@@ -186,7 +197,7 @@ struct K4Args {
     const uint8_t* s; const bgp_record* rec; const uint64_t* pmax_end; const uint64_t* pmax_pos;
     const RunDev* runs; uint32_t n_runs; uint64_t n_tiles; uint64_t stream_len;
     bgp_column* cols; unsigned long long* hist; unsigned long long* pstats; /* [0] n_columns [1] sum_cov [2] max_cov */
-    uint32_t* status; const struct TileB* tiles; unsigned long long* tile_stats;
+    uint32_t* status; const struct TileB* tiles; unsigned long long* tile_stats; unsigned long long* phases;   // phases: debug build only (BGP_K4_PHASES)
     const uint64_t* ck_off; const struct Ckpt* ck;      // long-read checkpoints (null when the stream has no long read)
 };
 
@@ -201,7 +212,7 @@ __device__ __forceinline__ uint32_t base_class(uint32_t code) {   // nt16 code -
 
 // One thread per window: the record range that can touch it (exact halo).  Done here, massively
 // parallel, because the two ~25-step dependent binary searches are pure latency.
-struct TileB { uint64_t i_lo, i_hi; };
+struct TileB { uint64_t i_lo, i_hi, col_out; uint32_t T0, Tend, run_start, pad; };   // everything a window needs in one 40-byte (scalar) load
 __global__ __launch_bounds__(256) void k4_bounds(const uint64_t* pmax_end, const uint64_t* pmax_pos, const RunDev* runs, uint32_t n_runs, uint64_t n_tiles, TileB* out) {
     const uint64_t tile = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (tile >= n_tiles) return;
@@ -214,6 +225,7 @@ __global__ __launch_bounds__(256) void k4_bounds(const uint64_t* pmax_end, const
     TileB b;
     b.i_lo = lower_bound_gt(pmax_end, run.first_record, run.end_record, rk | T0);             // first record whose running max end_position exceeds T0
     b.i_hi = lower_bound_gt(pmax_pos, run.first_record, run.end_record, rk | (Tend - 1));     // first record starting at/after Tend
+    b.col_out = run.column_base + (T0 - run.start_pos); b.T0 = T0; b.Tend = Tend; b.run_start = (uint32_t)run.start_pos; b.pad = 0;
     out[tile] = b;
 }
 
@@ -326,9 +338,10 @@ constexpr int DELD = 5 * W;            // word offsets inside the tile
 constexpr int NST = 6 * W + 4;
 constexpr int HIST = 7 * W + 4;
 constexpr int LIST = HIST + HB;
-constexpr int LCAP = 2048;
+constexpr int LCAP = W;
 constexpr int SLIST = LIST + LCAP;       // second list: reads for the wave-cooperative paths
-constexpr int LDS_WORDS = SLIST + LCAP;
+constexpr int LDS_PAD = 8;               // words in front of the tile (see k4_tile's hot loop)
+constexpr int LDS_WORDS = SLIST + LCAP + LDS_PAD;
 
 __device__ __forceinline__ uint32_t rl(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
 
@@ -481,7 +494,8 @@ __device__ __forceinline__ void pile_read_long(const K4Args& a, uint32_t* lds, u
 }
 
 __global__ __launch_bounds__(K4_T) void k4_tile(K4Args a) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_raw[];
+    uint32_t* const lds = lds_raw + LDS_PAD;      // counters of masked-off bases may land up to 7 words below cnt[0][0]
     __shared__ uint32_t s_n;           // entries in the LDS list
     __shared__ uint32_t s_nslow;       // entries in the second list
     __shared__ uint32_t wsum[K4_T / 64];
@@ -491,13 +505,17 @@ __global__ __launch_bounds__(K4_T) void k4_tile(K4Args a) {
     uint64_t tile = (blockIdx.x % 8) * per + blockIdx.x / 8;
     if (nb < 64) tile = blockIdx.x;
     if (tile >= nb) return;
-    uint32_t lo_r = 0, hi_r = a.n_runs;
-    while (hi_r - lo_r > 1) { const uint32_t m = (lo_r + hi_r) >> 1; if (a.runs[m].tile_base <= tile) lo_r = m; else hi_r = m; }
-    const RunDev run = a.runs[lo_r];
-    const uint32_t T0 = (uint32_t)(run.start_pos + (tile - run.tile_base) * (uint64_t)W);
-    const uint32_t Tend = (uint32_t)min((uint64_t)T0 + W, run.end_pos);
+    const TileB tb = a.tiles[tile];                      // window geometry + record range, precomputed by k4_bounds
+    const uint32_t T0 = tb.T0, Tend = tb.Tend;
+#ifdef BGP_K4_PHASES
+    unsigned long long ph_t = clock64(), ph[6] = {0, 0, 0, 0, 0, 0};
+    const unsigned long long ph_w0 = wall_clock64();
+#define PH(k) do { const unsigned long long now_ = clock64(); ph[k] += now_ - ph_t; ph_t = now_; } while (0)
+#else
+#define PH(k) do {} while (0)
+#endif
     for (int i = threadIdx.x; i < LIST; i += K4_T) lds[i] = 0;
-    const uint64_t i_lo = a.tiles[tile].i_lo, i_hi = a.tiles[tile].i_hi;
+    const uint64_t i_lo = tb.i_lo, i_hi = tb.i_hi;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     uint32_t* list = lds + LIST;
@@ -534,8 +552,13 @@ __global__ __launch_bounds__(K4_T) void k4_tile(K4Args a) {
             }
         }
         const uint32_t n_list = s_n;
+        PH(0);
         // ---- process: 64 listed reads per wave, lane = read
+#ifdef BGP_K4_NOPROC
+        for (uint32_t b0 = n_list; b0 < n_list; b0 += (K4_T / 64) * 64) {
+#else
         for (uint32_t b0 = (uint32_t)wave * 64; b0 < n_list; b0 += (K4_T / 64) * 64) {
+#endif
             const bool have = b0 + lane < n_list;
             uint32_t pos = 0, covered = 0, n_cig = 0, l_seq = 0, o0 = 0, o1 = 0, o2 = 0, o3 = 0;
             uint64_t cig_off = 0;
@@ -607,8 +630,36 @@ __global__ __launch_bounds__(K4_T) void k4_tile(K4Args a) {
                         }
                     }
                 }
+                // The hot loop works a packed-SEQ dword (8 bases) at a time, wi wave-uniform.  Per dword and lane:
+                // the 8 nt16 codes become 8 class nibbles with word-parallel bit tricks, the dword is given to ONE
+                // interval slot -- the last one that starts at or before its last base -- whose clip against the
+                // dword is an 8-bit validity mask, and every base then costs three VALU ops (class extract,
+                // address, validity bit) and one ds_add (invalid bases add 0 within 7 words of a valid counter:
+                // the tile's LDS starts 8 words into the allocation for that).  The bases a dword holds of an
+                // EARLIER slot (an indel inside the dword) are done afterwards, one extra dword step per slot.
                 const bool use1 = __ballot(sl[1] != 0) != 0, use2 = __ballot(sl[2] != 0) != 0, use3 = __ballot(sl[3] != 0) != 0;
                 const uint32_t nwords = (maxq + 7) >> 3;
+                auto dword_step = [&](uint32_t cur, uint32_t q0, uint32_t vq, uint32_t vl, uint32_t vb) {
+                    // nibbles into base order (SEQ keeps the first base of a byte in the high nibble, read.d:368-373)
+                    const uint32_t x = ((cur & 0x0F0F0F0Fu) << 4) | ((cur >> 4) & 0x0F0F0F0Fu);
+                    // nt16 -> A,C,G,T,other per nibble: one-hot codes 1,2,4,8 -> 0,1,2,3 (= b1 + 2 b2 + 3 b3), anything else -> 4
+                    const uint32_t b0 = x & 0x11111111u, b1 = (x >> 1) & 0x11111111u, b2 = (x >> 2) & 0x11111111u, b3 = (x >> 3) & 0x11111111u;
+                    const uint32_t e = (b0 + b1 + b2 + b3) ^ 0x11111111u;                   // nibble == 0 <=> exactly one bit set
+                    const uint32_t f = (e | (e >> 1) | (e >> 2)) & 0x11111111u;             // 1 where the code is not one-hot
+                    const uint32_t m7 = f * 7u;
+                    const uint32_t cw = ((b1 + (b2 << 1) + b3 * 3u) & ~m7) | (f << 2);
+                    // bases [lo, hi) of the dword lie in the slot's query interval [vq, vq + vl)
+                    const int32_t d0 = (int32_t)(vq - q0), d1 = (int32_t)(vq + vl - q0);
+                    const uint32_t lo = (uint32_t)min(max(d0, 0), 8), hi = (uint32_t)min(max(d1, 0), 8);
+                    const uint32_t vm = hi > lo ? (((1u << (hi - lo)) - 1u) << lo) : 0u;
+                    const uint32_t bq = vm ? vb + q0 * 4u : 0u;                             // byte address of cnt[0][column of base 0]
+                    char* const l8 = reinterpret_cast<char*>(lds);
+#pragma unroll
+                    for (int b = 0; b < 8; ++b) {
+                        const uint32_t cls = (cw >> (4 * b)) & 7u;
+                        atomicAdd(reinterpret_cast<uint32_t*>(l8 + (int32_t)((cls << CLS_SHIFT) + bq) + 4 * b), (vm >> b) & 1u);
+                    }
+                };
                 for (uint32_t wi = 0; wi < nwords; ++wi) {
                     uint32_t cur;                                           // dword wi of this lane's packed SEQ (wi is wave-uniform)
                     switch (wi) {
@@ -618,22 +669,31 @@ __global__ __launch_bounds__(K4_T) void k4_tile(K4Args a) {
                         case 12: cur = w3.x; break; case 13: cur = w3.y; break; case 14: cur = w3.z; break; case 15: cur = w3.w; break;
                         case 16: cur = w4.x; break; case 17: cur = w4.y; break; case 18: cur = w4.z; break; default: cur = w4.w; break;
                     }
-                    const uint32_t q0 = wi * 8;
-#pragma unroll
-                    for (int b = 0; b < 8; ++b) {
-                        const uint32_t q = q0 + b;
-                        bool in = (q - sq[0]) < sl[0];
-                        uint32_t base = sb[0];
-                        if (use1) { const bool i1 = (q - sq[1]) < sl[1]; base = i1 ? sb[1] : base; in |= i1; }
-                        if (use2) { const bool i2 = (q - sq[2]) < sl[2]; base = i2 ? sb[2] : base; in |= i2; }
-                        if (use3) { const bool i3 = (q - sq[3]) < sl[3]; base = i3 ? sb[3] : base; in |= i3; }
-                        const uint32_t code = (cur >> ((b >> 1) * 8 + ((b & 1) ? 0 : 4))) & 0xFu;      // read.d:368-373
-                        const uint32_t tab = (code & 8u) ? 0x44444443u : 0x44424104u;                 // nt16 -> A,C,G,T,other
-                        const uint32_t cls = (tab >> ((code & 7u) * 4)) & 0xFu;
-                        const uint32_t addr = (cls << 13) + base + q * 4;                               // byte address of cnt[cls][column]
-                        atomicAdd(reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(lds) + (in ? addr : 0u)), in ? 1u : 0u);
-                    }
+                    const uint32_t q0 = wi * 8, qlast = q0 + 7;
+                    uint32_t vq = sq[0], vl = sl[0], vb = sb[0];
+                    if (use1) { const bool t = sl[1] != 0 && sq[1] <= qlast; vq = t ? sq[1] : vq; vl = t ? sl[1] : vl; vb = t ? sb[1] : vb; }
+                    if (use2) { const bool t = sl[2] != 0 && sq[2] <= qlast; vq = t ? sq[2] : vq; vl = t ? sl[2] : vl; vb = t ? sb[2] : vb; }
+                    if (use3) { const bool t = sl[3] != 0 && sq[3] <= qlast; vq = t ? sq[3] : vq; vl = t ? sl[3] : vl; vb = t ? sb[3] : vb; }
+#ifndef BGP_K4_NOQ
+                    dword_step(cur, q0, vq, vl, vb);
+#endif
                 }
+                // what a slot's first dword holds of the slot before it
+                auto fixup = [&](uint32_t sqm, uint32_t slm, uint32_t pq, uint32_t pl, uint32_t pb) {
+                    const uint32_t wf = slm ? sqm >> 3 : 0u;
+                    // lane-varying pick of one of the 20 preloaded dwords: a select tree on the index BITS (written
+                    // as element compares the compiler turns it into a scratch-indexed vector extract)
+                    const bool k0 = wf & 1u, k1 = wf & 2u;
+                    auto pick4 = [&](const uint4& w) { const uint32_t a = k0 ? w.y : w.x, b = k0 ? w.w : w.z; return k1 ? b : a; };
+                    const uint32_t p0 = pick4(w0), p1 = pick4(w1), p2 = pick4(w2), p3 = pick4(w3), p4 = pick4(w4);
+                    const uint32_t g = wf >> 2;
+                    const uint32_t lo01 = (g & 1u) ? p1 : p0, lo23 = (g & 1u) ? p3 : p2;
+                    const uint32_t cur = g >= 4 ? p4 : ((g & 2u) ? lo23 : lo01);
+                    dword_step(cur, wf * 8, pq, slm ? pl : 0u, pb);
+                };
+                if (use1) fixup(sq[1], sl[1], sq[0], sl[0], sb[0]);
+                if (use2) fixup(sq[2], sl[2], sq[1], sl[1], sb[1]);
+                if (use3) fixup(sq[3], sl[3], sq[2], sl[2], sb[2]);
             }
             // everything else, one read at a time with lanes along the read
             // everything else goes to a second list so that ALL waves share it (a window's long reads
@@ -647,7 +707,9 @@ __global__ __launch_bounds__(K4_T) void k4_tile(K4Args a) {
                 if (is_slow) slist[slot + __popcll(sm & ((1ull << lane) - 1))] = list[b0 + lane];
             }
         }
+        PH(1);
         __syncthreads();
+        PH(2);
         // one read at a time per wave, whole wave on the read
         const uint32_t n_slow = s_nslow;
         for (uint32_t j = (uint32_t)wave; j < n_slow; j += K4_T / 64) {
@@ -657,7 +719,7 @@ __global__ __launch_bounds__(K4_T) void k4_tile(K4Args a) {
             const uint32_t rpos = rl(x.y, 0), rcov = rl(x.z - x.y, 0), rncig = rl(y.x & 0xFFFFu, 0), rlseq = rl(y.y, 0);
             const uint64_t co = (((uint64_t)rl(y.w, 0) << 32) | rl(y.z, 0)) + 36 + rl(x.w & 0xFFu, 0);
             if (a.ck && is_long_read(rncig, rlseq)) {
-                const uint64_t wj = (uint64_t)(T0 - (uint32_t)run.start_pos) / W - ((uint64_t)rpos - run.start_pos) / W;   // window index within the read
+                const uint64_t wj = (uint64_t)(T0 - tb.run_start) / W - ((uint64_t)rpos - tb.run_start) / W;   // window index within the read
                 const Ckpt ck = a.ck[a.ck_off[ri] + wj];
                 pile_read_long(a, lds, T0, Tend, lane, rpos, rcov, rncig, rlseq, co, ck);
             } else
@@ -665,6 +727,7 @@ __global__ __launch_bounds__(K4_T) void k4_tile(K4Args a) {
         }
         __syncthreads();
     }
+    PH(3);
     // ---- flush: prefix-sum the '-' difference array, then 32 contiguous bytes per position
     const uint32_t np = Tend - T0;
     {
@@ -685,14 +748,18 @@ __global__ __launch_bounds__(K4_T) void k4_tile(K4Args a) {
         for (int j = 0; j < PER; ++j) lds[DELD + p0 + j] = ex + loc[j];
         __syncthreads();
     }
-    bgp_column* out = a.cols + run.column_base + (T0 - run.start_pos);
+    bgp_column* out = a.cols + tb.col_out;
     uint64_t ncol = 0, scov = 0; uint32_t mx = 0;
     for (uint32_t p = threadIdx.x; p < np; p += K4_T) {
         const uint32_t A = lds[p], C = lds[W + p], G = lds[2 * W + p], Tt = lds[3 * W + p], O = lds[4 * W + p], D = lds[DELD + p], S = lds[NST + p];
         const uint32_t cov = A + C + G + Tt + O + D;
         uint4* o4 = reinterpret_cast<uint4*>(out + p);
+#ifndef BGP_K4_NOFLUSH
         o4[0] = make_uint4(cov, S, A, C);
         o4[1] = make_uint4(G, Tt, O, D);
+#else
+        if (cov == 0xFFFFFFFFu) o4[0] = make_uint4(cov, S, A, C);
+#endif
         ncol += cov > 0; scov += cov; mx = max(mx, cov);
         if (cov < HB) atomicAdd(&lds[HIST + cov], 1u);
         else atomicAdd(&a.hist[min(cov, (uint32_t)BGP_DEPTH_BINS - 1)], 1ull);
@@ -711,7 +778,13 @@ __global__ __launch_bounds__(K4_T) void k4_tile(K4Args a) {
         a.tile_stats[tile * 4 + threadIdx.x] = v;
     }
     __syncthreads();
+#ifndef BGP_K4_NOHIST
     for (int b = threadIdx.x; b < HB; b += K4_T) { const uint32_t h = lds[HIST + b]; if (h) atomicAdd(&a.hist[b], (unsigned long long)h); }
+#endif
+    PH(4);
+#ifdef BGP_K4_PHASES
+    if ((threadIdx.x & 63) == 0 && wave < 2) { for (int k = 0; k < 5; ++k) a.phases[(tile * 2 + wave) * 8 + k] = ph[k]; a.phases[(tile * 2 + wave) * 8 + 5] = wall_clock64() - ph_w0; a.phases[(tile * 2 + wave) * 8 + 6] = ph_w0; }
+#endif
 }
 
 // folds the per-window totals: [0] columns with coverage, [1] sum of coverage, [2] max coverage, [4] reads used
@@ -867,12 +940,18 @@ int k34_pileup(bgp_ctx* c) {
         BGP_TRY(c->d_tiles.reserve(tile_base * sizeof(TileB)));
         a.tiles = c->d_tiles.as<TileB>();
         {
-            TimedRegion tb(c, "k4_bounds", tile_base * 16);
+            TimedRegion tb(c, "k4_bounds", tile_base * sizeof(TileB));
             hipLaunchKernelGGL(k4_bounds, dim3((unsigned)((tile_base + 255) / 256)), dim3(256), 0, c->stream, a.pmax_end, a.pmax_pos, a.runs, n_runs, tile_base, c->d_tiles.as<TileB>());
         }
         BGP_TRY(c->d_col_lo.reserve(tile_base * 32));
         a.tile_stats = (unsigned long long*)c->d_col_lo.p;
-        a.ck = nullptr; a.ck_off = nullptr;
+        a.ck = nullptr; a.ck_off = nullptr; a.phases = nullptr;
+#ifdef BGP_K4_PHASES
+        static DevBuf d_ph;
+        BGP_TRY(d_ph.reserve(tile_base * 16 * 8));
+        BGP_HIP(hipMemsetAsync(d_ph.p, 0, tile_base * 16 * 8, c->stream));
+        a.phases = (unsigned long long*)d_ph.p;
+#endif
         if (st[3]) {                                   // the stream holds long reads: build their per-window CIGAR checkpoints
             TimedRegion tc(c, "k4_checkpoints", c->sum_ncig * 4);
             BGP_TRY(c->d_ck_off.reserve((n + 2) * 8));
@@ -889,6 +968,23 @@ int k34_pileup(bgp_ctx* c) {
         hipLaunchKernelGGL(k4_tile, dim3((unsigned)grid), dim3(K4_T), lds_bytes, c->stream, a);
         hipLaunchKernelGGL(k4_stats, dim3(32), dim3(256), 0, c->stream, a.tile_stats, tile_base, a.pstats);
         BGP_HIP(hipGetLastError());
+#ifdef BGP_K4_PHASES
+        {
+            std::vector<unsigned long long> h(tile_base * 16);
+            BGP_HIP(hipMemcpy(h.data(), a.phases, tile_base * 16 * 8, hipMemcpyDeviceToHost));
+            double sum[2][5] = {};
+            for (uint64_t t = 0; t < tile_base; ++t) for (int w = 0; w < 2; ++w) for (int k = 0; k < 5; ++k) sum[w][k] += (double)h[(t * 2 + w) * 8 + k];
+            double wall = 0; unsigned long long first = ~0ull, last = 0;
+            for (uint64_t t = 0; t < tile_base; ++t) { if (!h[t * 16 + 6]) continue; wall += (double)h[t * 16 + 5]; first = std::min(first, h[t * 16 + 6]); last = std::max(last, h[t * 16 + 6] + h[t * 16 + 5]); }
+            int occ = 0; (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k4_tile, K4_T, lds_bytes);
+            fprintf(stderr, "[k4 occupancy] %d workgroups per CU (LDS %zu B)\n", occ, lds_bytes);
+            fprintf(stderr, "[k4 tiles] %llu tiles, mean tile life %.2f us (100 MHz wall clock), kernel span %.2f ms, mean tiles in flight %.1f\n", (unsigned long long)tile_base,
+                    wall / tile_base / 100.0, (double)(last - first) / 1e5, wall / (double)(last - first));
+            for (int w = 0; w < 2; ++w)
+                fprintf(stderr, "[k4 phases, wave %d, mean cycles/tile] zero+scan %.0f  process(own batches) %.0f  barrier %.0f  slow lists %.0f  flush %.0f\n", w,
+                        sum[w][0] / tile_base, sum[w][1] / tile_base, sum[w][2] / tile_base, sum[w][3] / tile_base, sum[w][4] / tile_base);
+        }
+#endif
     }
     uint64_t ps[16];
     BGP_HIP(hipMemcpyAsync(ps, c->d_pstats.p, 128, hipMemcpyDeviceToHost, c->stream));
