@@ -211,6 +211,35 @@ __device__ uint32_t dna_walk(const uint8_t* s, const bgp_record& r, uint32_t fro
     }
 }
 
+// Length of dna(read) and its `bad` flag without touching SEQ: the walk above only asks the query iterator
+// "is there another M/=/X base", so the answer is a function of the MD operations and of the number of such
+// bases in the CIGAR (a match run takes min(run, bases left) and stalls if it wanted more; a mismatch is
+// yielded and then stalls on an empty query; an empty deletion stalls).
+__device__ uint32_t dna_length(const uint8_t* s, const bgp_record& r, bool* bad, bool* err) {
+    *bad = false; *err = false;
+    const uint8_t* md = nullptr; uint32_t mdn = 0;
+    const int f = find_md(s, r, &md, &mdn);
+    if (f < 0) { *err = true; return 0; }
+    if (f == 0) mdn = 0;
+    const uint32_t l_name = r.bin_mq_nl & 0xFFu, n_cig = r.flag_nc & 0xFFFFu;
+    const uint8_t* cg = s + r.rec_off + 36 + l_name;
+    uint64_t qleft = 0;
+    for (uint32_t k = 0; k < n_cig; ++k) { const uint32_t raw = ld_u32(cg + 4ull * k); if (cig_qc(raw) && cig_rc(raw)) qleft += raw >> 4; }
+    MdRes m;
+    mdf_init(m, md, mdn);
+    uint64_t n = 0;
+    while (!md_empty(m)) {
+        const MdOp cur = m.front; mdf_pop_front(m);
+        if (cur.type == 1) { ++n; if (qleft == 0) { *bad = true; break; } --qleft; }
+        else if (cur.type == 0) {
+            const uint64_t take = cur.match < qleft ? cur.match : qleft;
+            n += take; qleft -= take;
+            if (take < cur.match) { *bad = true; break; }
+        } else { if (cur.del_len == 0) { *bad = true; break; } n += cur.del_len; }
+    }
+    return n > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)n;
+}
+
 // ---------------------------------------------------------------------------------------------- k6_prep
 // One 16-byte row per record: what the controller needs, and nothing it has to chase pointers for.
 //   lf : dna(read) length | MD_COV (basesCovered() > 0) | MD_GST (first read of a position group)
@@ -227,7 +256,7 @@ __global__ __launch_bounds__(256) void k6_prep(const uint8_t* s, const bgp_recor
     MdRow o{(uint32_t)r.pos, (uint32_t)r.end_pos, 0u, 0u};
     if (r.end_pos != r.pos) {
         bool bad, err;
-        uint32_t L = dna_walk(s, r, 0, 0, nullptr, &bad, &err);
+        uint32_t L = dna_length(s, r, &bad, &err);
         if (L > MD_LMASK) L = MD_LMASK;
         // first record of this read's position group: the prefix maximum of the position key reaches the
         // read's own key exactly there (records are sorted; K3 has already rejected unsorted input).
@@ -411,12 +440,206 @@ __global__ __launch_bounds__(256) void k6_fill(const uint8_t* s, const bgp_recor
     dna_walk(s, rec[v.prov], v.c0, (uint32_t)(endc - v.col), refbase + R.column_base + (v.col - R.start_pos), &bad, &err);
 }
 
+// ---------------------------------------------------------------------------------------------- the chain, in parallel
+// k6_chain walks one run fetch by fetch; 2*10^5 dependent steps per run is 10^2 ms.  But the step is a FUNCTION:
+// in the regular regime the next provider depends on the current provider alone.  Proof sketch (state after a
+// fetch = provider P fetched at column F, cursor F - pos_P + 1, chunk_end CE = end_P; "regular" = F < pos_P + L_P - 1
+// and F < end_P):
+//   * the chunk runs empty at A_P = pos_P + L_P - 1 whatever F was;
+//   * add() only ever looks at reads behind the ones it has seen.  Reads between P and the fetch column were seen
+//     under the old chunk_end: those it accepted lost to P (end <= end_P, so they fail the new filter too); those
+//     it ignored (position beyond the old chunk_end, covered predecessor column) are the one way F can matter --
+//     so a step is only trusted if NO read of its window, accepted or not, ends beyond the winner;
+//   * a skip_zero_coverage jump re-initialises on the first arg-max of the gap's position group, and every read
+//     of that group passes add() because coverage was zero in front of it: independent of the state altogether.
+// So: k6_succ computes succ(P) = (next provider, its fetch column) for EVERY read at once and flags the steps
+// whose premises fail; k6_exit composes succ within 2048-record segments by pointer doubling in LDS (exit(P) =
+// first provider outside P's segment); k6_top walks a run segment by segment (10^3 dependent loads instead of
+// 10^5) and notes where the real chain enters each segment; k6_emit re-walks each segment from its entry and
+// expands the chunks.  A run whose chain touches a flagged step (inconsistent MD, bad chunk, the corner where a
+// chunk is fetched on its last base, ...) is redone by k6_chain -- the exact event loop stays the authority,
+// and every BGP_EMD comes from it.
+constexpr uint32_t SX_END = 0xFFFFFFFFu, SX_NONE = 0xFFFFFFFEu, SX_FLAG = 1u << 31;
+constexpr int SEG = 2048, SUCC_CAP = 4096;
+struct Succ { uint32_t nxt, fcol; };              // fcol: fetch column of nxt | SX_FLAG
+
+struct ParRun { uint64_t first, endrec; uint32_t run_end, ce_in, active, pad; };
+struct ParOut { uint32_t ce_out, flagged, n_nodes, pad; };
+
+__device__ __forceinline__ uint32_t par_run_of(const ParRun* pr, uint32_t n_runs, uint64_t i) {   // last run with first <= i
+    uint32_t lo = 0, hi = n_runs;
+    while (hi - lo > 1) { const uint32_t m = (lo + hi) >> 1; if (pr[m].first <= i) lo = m; else hi = m; }
+    return lo;
+}
+
+// arrival checks for provider row r fetched at column F (the premises of the next step)
+__device__ __forceinline__ bool arrival_irregular(const MdRow& r, uint32_t F) {
+    const uint32_t L = r.lf & MD_LMASK;
+    if ((r.lf & (MD_BAD | MD_ERR)) || L < 2) return true;
+    return !((uint64_t)F + 1 < (uint64_t)r.pos + L && F < r.end);
+}
+
+__global__ __launch_bounds__(256) void k6_succ(const MdRow* rows, uint64_t n, const ParRun* pr, uint32_t n_runs, int skip_zero, Succ* succ) {
+    const uint64_t P = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (P >= n) return;
+    const MdRow rp = rows[P];
+    if (!(rp.lf & MD_COV)) { succ[P] = Succ{SX_NONE, 0u}; return; }
+    const ParRun R = pr[par_run_of(pr, n_runs, P)];
+    if (P < R.first || P >= R.endrec) { succ[P] = Succ{SX_NONE, 0u}; return; }
+    const uint32_t CE = rp.end, A = rp.pos + (rp.lf & MD_LMASK) - 1u;
+    bool found = false, flag = false;
+    uint32_t F = 0, best = SX_END, best_end = 0, allmax = 0;
+    MdRow bestrow{0, 0, 0, 0};
+    uint32_t out_n = SX_END, out_f = 0;
+    uint64_t j = P + 1;
+    int budget = SUCC_CAP;
+    for (; j < R.endrec; ++j) {
+        if (--budget < 0) { flag = true; break; }
+        const MdRow r = rows[j];
+        if (!(r.lf & MD_COV)) continue;
+        const bool hz = r.mb < r.pos;
+        const bool isg = skip_zero && (r.lf & MD_GST) && hz;
+        const bool cand = (r.pos <= CE || hz) && r.end > CE;
+        const bool gap_here = isg && (!found || r.pos <= F || r.mb <= F);     // GAP: before any candidate, inside the window, or the window's successor group uncovered by F
+        if (gap_here) {
+            // initNewReference on this position group: first arg-max of end_position (every read of it passes add())
+            uint32_t g = (uint32_t)j, ge = r.end; MdRow gr = r;
+            for (uint64_t k = j + 1; k < R.endrec; ++k) {
+                if (--budget < 0) { flag = true; break; }
+                const MdRow q = rows[k];
+                if (!(q.lf & MD_COV)) continue;
+                if (q.pos != r.pos) break;
+                if (q.end > ge) { g = (uint32_t)k; ge = q.end; gr = q; }
+            }
+            out_n = g; out_f = r.pos;
+            flag |= arrival_irregular(gr, r.pos) || gr.pos != r.pos;
+            goto done;
+        }
+        if (!found) {
+            if (!cand) { allmax = max(allmax, r.end); continue; }
+            found = true; F = max(A, r.pos);
+        }
+        if (r.pos > F) break;                                               // first read beyond the fetch column
+        allmax = max(allmax, r.end);
+        if (cand && r.end > best_end) { best = (uint32_t)j; best_end = r.end; bestrow = r; }
+    }
+    if (found && (j < R.endrec || F < R.run_end) && !(flag && best == SX_END)) {   // FETCH at F (pileup.d:627-652); at the run's end only if it comes before the end of coverage
+        out_n = best; out_f = F;
+        flag |= best == SX_END || arrival_irregular(bestrow, F) || allmax > best_end;
+    }
+done:
+    succ[P] = Succ{out_n, out_f | (flag ? SX_FLAG : 0u)};
+}
+
+// exit(P): the first provider behind P's segment on the chain from P (or SX_END), its fetch column, and the OR of
+// the flags on the way -- pointer doubling over the segment's 2048 entries in LDS (a hop advances by at least
+// one record, so 11 rounds always suffice; typical chains need 7).
+__global__ __launch_bounds__(256) void k6_exit(const Succ* succ, uint64_t n, Succ* ex) {
+    __shared__ Succ buf[2][SEG];
+    __shared__ int changed;
+    const uint64_t lo = (uint64_t)blockIdx.x * SEG;
+    for (int t = threadIdx.x; t < SEG; t += 256) buf[0][t] = lo + t < n ? succ[lo + t] : Succ{SX_NONE, 0u};
+    __syncthreads();
+    int cur = 0;
+    for (int round = 0; round < 12; ++round) {
+        if (threadIdx.x == 0) changed = 0;
+        __syncthreads();
+        bool any = false;
+        for (int t = threadIdx.x; t < SEG; t += 256) {
+            Succ e = buf[cur][t];
+            if (e.nxt < SX_NONE && e.nxt >= lo && e.nxt < lo + SEG) {
+                const Succ f = buf[cur][e.nxt - lo];
+                e = Succ{f.nxt, f.fcol | (e.fcol & SX_FLAG) | (f.nxt == SX_NONE ? SX_FLAG : 0u)};
+                any = true;
+            }
+            buf[cur ^ 1][t] = e;
+        }
+        if (any) changed = 1;
+        __syncthreads();
+        cur ^= 1;
+        if (!changed) break;
+        __syncthreads();
+    }
+    for (int t = threadIdx.x; t < SEG; t += 256) if (lo + t < n) ex[lo + t] = buf[cur][t];
+}
+
+// One wave per run: the first provider (initNewReference on the run's first position group, filtered against the
+// chunk_end carried over from the previous reference), then segment to segment through the exit table.
+__global__ __launch_bounds__(64) void k6_top(const MdRow* rows, const Succ* ex, const ParRun* pr, ParOut* po, Succ* seg_entry) {
+    const ParRun R = pr[blockIdx.x];
+    if (!R.active || threadIdx.x != 0) return;
+    bool flag = false;
+    // add() of the first group: the first read unconditionally, a later one if it ends beyond the stale chunk_end and beyond the best so far
+    const MdRow r0 = rows[R.first];
+    uint32_t node = (uint32_t)R.first, best_end = r0.end; MdRow nr = r0;
+    int budget = SUCC_CAP;
+    for (uint64_t k = R.first + 1; k < R.endrec; ++k) {
+        if (--budget < 0) { flag = true; break; }
+        const MdRow q = rows[k];
+        if (!(q.lf & MD_COV)) continue;
+        if (q.pos != r0.pos) break;
+        if (q.end > R.ce_in && q.end > best_end) { node = (uint32_t)k; best_end = q.end; nr = q; }
+    }
+    uint32_t F = r0.pos;
+    flag |= arrival_irregular(nr, F);
+    uint32_t hops = 0;
+    for (;;) {
+        seg_entry[node / SEG + blockIdx.x] = Succ{node, F};       // slot = segment + run ordinal: two runs may share a segment
+        const Succ e = ex[node];
+        flag |= (e.fcol & SX_FLAG) != 0;
+        ++hops;
+        if (e.nxt >= SX_NONE || flag) { flag |= e.nxt == SX_NONE; break; }
+        node = e.nxt; F = e.fcol & ~SX_FLAG;
+    }
+    po[blockIdx.x] = ParOut{0u, flag ? 1u : 0u, hops, 0u};
+}
+
+// One wave per segment the chain enters: lane 0 re-walks the segment from its entry (nodes to LDS), then the
+// lanes expand dna(provider)[F - pos ...] up to the next provider's fetch column.
+struct EmitRun { uint64_t first, endrec, column_base; uint32_t start_pos, end_pos; };
+__global__ __launch_bounds__(64) void k6_emit(const uint8_t* s, const bgp_record* rec, const MdRow* rows, const Succ* succ, const Succ* seg_entry, uint64_t slot_lo, uint64_t slot_n,
+                                              const EmitRun* er, uint32_t n_runs, ParOut* po, uint8_t* refbase) {
+    __shared__ uint32_t nd[SEG + 1], fc[SEG + 1];
+    __shared__ uint32_t s_cnt, s_run;
+    if (blockIdx.x >= slot_n) return;
+    const Succ ent = seg_entry[slot_lo + blockIdx.x];
+    if (ent.nxt >= SX_NONE) return;
+    const uint64_t seg = ent.nxt / SEG;
+    if (threadIdx.x == 0) {
+        uint32_t lo_r = 0, hi_r = n_runs;
+        while (hi_r - lo_r > 1) { const uint32_t m = (lo_r + hi_r) >> 1; if (er[m].first <= ent.nxt) lo_r = m; else hi_r = m; }
+        const EmitRun R = er[lo_r];
+        uint32_t node = ent.nxt, F = ent.fcol, k = 0;
+        const uint64_t lo = seg * SEG, hi = lo + SEG;
+        for (;;) {
+            nd[k] = node; fc[k] = F; ++k;
+            const Succ e = succ[node];
+            if (e.nxt >= SX_NONE) { fc[k] = R.end_pos; po[lo_r].ce_out = rows[node].end; break; }     // the chain ends here: this run's chunk_end carried to the next reference
+            node = e.nxt; F = e.fcol & ~SX_FLAG;
+            if (node >= hi || k >= SEG) { fc[k] = F; break; }
+        }
+        s_cnt = k; s_run = lo_r;
+    }
+    __syncthreads();
+    const EmitRun R = er[s_run];
+    for (uint32_t k = threadIdx.x; k < s_cnt; k += 64) {
+        const uint32_t F = fc[k];
+        uint32_t endc = fc[k + 1];
+        if (endc > R.end_pos) endc = R.end_pos;
+        if (F >= endc) continue;
+        bool bad, err;
+        dna_walk(s, rec[nd[k]], F - rows[nd[k]].pos, endc - F, refbase + R.column_base + (F - R.start_pos), &bad, &err);
+    }
+}
+
 // debug/test hook: dna(read) of one record into a host-visible buffer
 __global__ void k6_dna_one(const uint8_t* s, const bgp_record* rec, uint64_t i, uint8_t* out, uint32_t cap, uint32_t* len_bad) {
     bool bad, err, b2, e2;
     const uint32_t L = dna_walk(s, rec[i], 0, 0, nullptr, &bad, &err);        // full length (no early stop)
     if (cap) dna_walk(s, rec[i], 0, cap, out, &b2, &e2);
-    len_bad[0] = L; len_bad[1] = (bad ? 1u : 0u) | (err ? 2u : 0u);
+    bool b3, e3;                                                               // self-check: the SEQ-free length pass agrees with the walk
+    const uint32_t L3 = dna_length(s, rec[i], &b3, &e3);
+    len_bad[0] = L; len_bad[1] = (bad ? 1u : 0u) | (err ? 2u : 0u) | ((L3 != L || b3 != bad || e3 != err) ? 4u : 0u);
 }
 
 }  // namespace
@@ -475,19 +698,78 @@ int k6_reference_bases(bgp_ctx* c, int skip_zero, uint32_t run_first, uint32_t r
     if (nr == 0) return BGP_OK;
     std::vector<ChainRun> cr(nr);
     std::vector<ChainOut> co(nr);
+    std::vector<ParRun> pr(nr);
+    std::vector<EmitRun> er(nr);
     for (uint32_t k = 0; k < nr; ++k) {
         const bgp_run& r = c->runs[run_first + k];
         ChainRun& x = cr[k];
         x.first = (k == 0 && first_record != ~0ull) ? first_record : r.first_record;
         x.endrec = r.end_record; x.iv_base = x.first + 2ull * k; x.run_end = (uint32_t)r.end_pos;
         x.ce_in = k == 0 ? 0u : (uint32_t)c->runs[run_first + k - 1].end_pos;
-        x.active = 1; x.pad = 0;
+        x.active = 0; x.pad = 0;
+        pr[k] = ParRun{x.first, x.endrec, x.run_end, x.ce_in, 0u, 0u};
+        er[k] = EmitRun{x.first, x.endrec, r.column_base, (uint32_t)r.start_pos, (uint32_t)r.end_pos};
     }
-    const size_t off_out = (sizeof(ChainRun) * nr + 15) & ~(size_t)15, off_fill = off_out + ((sizeof(ChainOut) * nr + 15) & ~(size_t)15);
-    BGP_TRY(c->d_md_state.reserve(off_fill + sizeof(FillRun) * nr));
+    auto al16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
+    const size_t off_out = al16(sizeof(ChainRun) * nr), off_fill = off_out + al16(sizeof(ChainOut) * nr), off_pr = off_fill + al16(sizeof(FillRun) * nr),
+                 off_po = off_pr + al16(sizeof(ParRun) * nr), off_er = off_po + al16(sizeof(ParOut) * nr);
+    BGP_TRY(c->d_md_state.reserve(off_er + sizeof(EmitRun) * nr));
     BGP_TRY(c->d_md_iv.reserve((c->n_records + 2ull * nr + 2) * sizeof(MdIv)));
     uint8_t* st = c->d_md_state.as<uint8_t>();
-    for (uint32_t round = 0; round <= nr; ++round) {
+    const uint64_t n = c->n_records;
+    const char* mode = getenv("BGP_MD_CHAIN");                 // "seq": the event loop only; default: composed successors, event loop where premises fail
+    const bool use_par = !(mode && !strcmp(mode, "seq"));
+    const uint64_t n_slots = (n + SEG - 1) / SEG + nr + 1;
+    if (use_par) {
+        BGP_TRY(c->d_md_succ.reserve((n + 1) * sizeof(Succ))); BGP_TRY(c->d_md_exit.reserve((n + 1) * sizeof(Succ))); BGP_TRY(c->d_md_entry.reserve(n_slots * sizeof(Succ)));
+        BGP_HIP(hipMemcpyAsync(st + off_pr, pr.data(), sizeof(ParRun) * nr, hipMemcpyHostToDevice, c->stream));
+        BGP_HIP(hipMemcpyAsync(st + off_er, er.data(), sizeof(EmitRun) * nr, hipMemcpyHostToDevice, c->stream));
+        {
+            TimedRegion t(c, "k6_succ", n * (sizeof(MdRow) + sizeof(Succ)));
+            hipLaunchKernelGGL(k6_succ, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->d_md_row.as<MdRow>(), n, (const ParRun*)(st + off_pr), nr, skip_zero, c->d_md_succ.as<Succ>());
+        }
+        {
+            TimedRegion t(c, "k6_exit", n * 2 * sizeof(Succ));
+            hipLaunchKernelGGL(k6_exit, dim3((unsigned)((n + SEG - 1) / SEG)), dim3(256), 0, c->stream, c->d_md_succ.as<Succ>(), n, c->d_md_exit.as<Succ>());
+        }
+        BGP_HIP(hipGetLastError());
+    }
+    // (re)solve the runs in `ks` under their current carried-in chunk_end
+    auto solve = [&](const std::vector<uint32_t>& ks, bool clear) -> int {
+        std::vector<uint32_t> seq;
+        if (clear) for (uint32_t k : ks) { const bgp_run& r = c->runs[run_first + k]; if (r.end_pos > r.start_pos) BGP_HIP(hipMemsetAsync(c->d_refbase.as<uint8_t>() + r.column_base, 'N', r.end_pos - r.start_pos, c->stream)); }
+        if (use_par) {
+            for (uint32_t k = 0; k < nr; ++k) pr[k].active = 0;
+            for (uint32_t k : ks) { pr[k].active = 1; pr[k].ce_in = cr[k].ce_in; }
+            BGP_HIP(hipMemcpyAsync(st + off_pr, pr.data(), sizeof(ParRun) * nr, hipMemcpyHostToDevice, c->stream));
+            for (uint32_t k : ks) {
+                const uint64_t lo = cr[k].first / SEG + k, hi = (cr[k].endrec ? (cr[k].endrec - 1) / SEG : 0) + k + 1;
+                BGP_HIP(hipMemsetAsync(c->d_md_entry.as<Succ>() + lo, 0xFF, (hi - lo) * sizeof(Succ), c->stream));
+            }
+            {
+                TimedRegion t(c, "k6_top", 0);
+                hipLaunchKernelGGL(k6_top, dim3(nr), dim3(64), 0, c->stream, c->d_md_row.as<MdRow>(), c->d_md_exit.as<Succ>(), (const ParRun*)(st + off_pr), (ParOut*)(st + off_po), c->d_md_entry.as<Succ>());
+            }
+            for (uint32_t k : ks) {
+                const uint64_t lo = cr[k].first / SEG + k, hi = (cr[k].endrec ? (cr[k].endrec - 1) / SEG : 0) + k + 1;
+                TimedRegion t(c, "k6_emit", c->runs[run_first + k].end_pos - c->runs[run_first + k].start_pos);
+                hipLaunchKernelGGL(k6_emit, dim3((unsigned)(hi - lo)), dim3(64), 0, c->stream, c->d_stream, c->d_rec.as<bgp_record>(), c->d_md_row.as<MdRow>(), c->d_md_succ.as<Succ>(),
+                                   c->d_md_entry.as<Succ>(), lo, hi - lo, (const EmitRun*)(st + off_er), nr, (ParOut*)(st + off_po), c->d_refbase.as<uint8_t>());
+            }
+            BGP_HIP(hipGetLastError());
+            std::vector<ParOut> po(nr);
+            BGP_HIP(hipMemcpyAsync(po.data(), st + off_po, sizeof(ParOut) * nr, hipMemcpyDeviceToHost, c->stream));
+            BGP_HIP(hipStreamSynchronize(c->stream));
+            for (uint32_t k : ks) {
+                if (po[k].flagged) seq.push_back(k);
+                else { co[k] = ChainOut{po[k].ce_out, 0u, 0, 0u, -1}; }
+            }
+            if (getenv("BGP_VERBOSE")) fprintf(stderr, "[biodgpu] MD chain: %zu run(s) composed, %zu redone by the event loop\n", ks.size() - seq.size(), seq.size());
+            for (uint32_t k : seq) { const bgp_run& r = c->runs[run_first + k]; if (r.end_pos > r.start_pos) BGP_HIP(hipMemsetAsync(c->d_refbase.as<uint8_t>() + r.column_base, 'N', r.end_pos - r.start_pos, c->stream)); }
+        } else seq = ks;
+        if (seq.empty()) return BGP_OK;
+        for (uint32_t k = 0; k < nr; ++k) cr[k].active = 0;
+        for (uint32_t k : seq) cr[k].active = 1;
         BGP_HIP(hipMemcpyAsync(st, cr.data(), sizeof(ChainRun) * nr, hipMemcpyHostToDevice, c->stream));
         {
             TimedRegion t(c, "k6_chain", 0);
@@ -497,30 +779,36 @@ int k6_reference_bases(bgp_ctx* c, int skip_zero, uint32_t run_first, uint32_t r
         std::vector<ChainOut> got(nr);
         BGP_HIP(hipMemcpyAsync(got.data(), st + off_out, sizeof(ChainOut) * nr, hipMemcpyDeviceToHost, c->stream));
         BGP_HIP(hipStreamSynchronize(c->stream));
-        for (uint32_t k = 0; k < nr; ++k) if (cr[k].active) { co[k] = got[k]; cr[k].active = 0; }
-        bool again = false;
-        for (uint32_t k = 1; k < nr; ++k) {
-            if (co[k - 1].err) break;                                   // the sweep never gets past that run
-            if (cr[k].ce_in != co[k - 1].ce_out) { cr[k].ce_in = co[k - 1].ce_out; cr[k].active = 1; again = true; break; }   // later runs wait for this one's real value
+        uint64_t total = 0;
+        std::vector<FillRun> fr;
+        for (uint32_t k : seq) {
+            co[k] = got[k];
+            const bgp_run& r = c->runs[run_first + k];
+            fr.push_back(FillRun{cr[k].iv_base, total, r.column_base, (uint32_t)r.start_pos, (uint32_t)r.end_pos, co[k].n_iv, 0u});
+            total += co[k].n_iv;
         }
-        if (!again) break;
+        if (total) {
+            BGP_HIP(hipMemcpyAsync(st + off_fill, fr.data(), sizeof(FillRun) * fr.size(), hipMemcpyHostToDevice, c->stream));
+            TimedRegion t(c, "k6_fill", n_pos);
+            hipLaunchKernelGGL(k6_fill, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, c->d_stream, c->d_rec.as<bgp_record>(), c->d_md_iv.as<MdIv>(),
+                               (const FillRun*)(st + off_fill), (uint32_t)fr.size(), total, c->d_refbase.as<uint8_t>());
+            BGP_HIP(hipGetLastError());
+            BGP_HIP(hipStreamSynchronize(c->stream));          // fr is a host vector: keep it alive until the copy is done
+        }
+        return BGP_OK;
+    };
+    std::vector<uint32_t> all(nr);
+    for (uint32_t k = 0; k < nr; ++k) all[k] = k;
+    BGP_TRY(solve(all, false));
+    for (uint32_t round = 0; round <= nr; ++round) {           // check the carried-in guesses in order; a wrong one is re-solved, later runs wait for its real value
+        uint32_t redo = nr;
+        for (uint32_t k = 1; k < nr; ++k) {
+            if (co[k - 1].err) break;                           // the sweep never gets past that run
+            if (cr[k].ce_in != co[k - 1].ce_out) { cr[k].ce_in = co[k - 1].ce_out; redo = k; break; }
+        }
+        if (redo == nr) break;
+        BGP_TRY(solve(std::vector<uint32_t>{redo}, true));
     }
-    uint64_t total = 0;
-    std::vector<FillRun> fr(nr);
-    uint32_t n_ok = nr;
-    for (uint32_t k = 0; k < nr; ++k) {
-        const bgp_run& r = c->runs[run_first + k];
-        fr[k] = FillRun{cr[k].iv_base, total, r.column_base, (uint32_t)r.start_pos, (uint32_t)r.end_pos, co[k].n_iv, 0u};
-        total += co[k].n_iv;
-        if (co[k].err) { *md_err = co[k].err; *md_err_from = co[k].err_from; n_ok = k + 1; break; }
-    }
-    if (total) {
-        BGP_HIP(hipMemcpyAsync(st + off_fill, fr.data(), sizeof(FillRun) * n_ok, hipMemcpyHostToDevice, c->stream));
-        TimedRegion t(c, "k6_fill", n_pos);
-        hipLaunchKernelGGL(k6_fill, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, c->d_stream, c->d_rec.as<bgp_record>(), c->d_md_iv.as<MdIv>(),
-                           (const FillRun*)(st + off_fill), n_ok, total, c->d_refbase.as<uint8_t>());
-        BGP_HIP(hipGetLastError());
-        BGP_HIP(hipStreamSynchronize(c->stream));          // fr is a host vector: keep it alive until the copy is done
-    }
+    for (uint32_t k = 0; k < nr; ++k) if (co[k].err) { *md_err = co[k].err; *md_err_from = co[k].err_from; break; }
     return BGP_OK;
 }

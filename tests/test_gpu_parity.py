@@ -365,6 +365,26 @@ def test_reference_base_synthetic_prefix_matches_oracle(ctx, model, n_reads):
         _check_refbase(ctx, st, skip_zero=skip, window=100_000)
 
 
+@pytest.mark.parametrize("model,n_reads", [("cfg2", 2_000_000), ("cfg3", 2_000_000), ("cfg5", 6_000)])
+def test_scale_composed_chain_equals_event_loop(ctx, model, n_reads):
+    """md.hip's two routes to the same bytes: succ/exit/top/emit (function composition) vs k6_chain (the event
+    loop), on shards far beyond the oracle's reach, both skip_zero_coverage modes."""
+    cfg = scaled(model, n_reads)
+    ctx.reset()
+    ctx.synth_device(cfg)
+    ctx.flush()
+    for skip in (True, False):
+        got = {}
+        for chain in ("seq", "par"):
+            os.environ["BGP_MD_CHAIN"] = chain
+            try:
+                got[chain] = np.concatenate([w.reference_base for w in ctx.pileup_windows(L.BGP_PILEUP_COLUMNS, use_md_tag=True, skip_zero_coverage=skip, window_positions=1 << 22)])
+            finally:
+                os.environ.pop("BGP_MD_CHAIN", None)
+        bad = np.nonzero(got["seq"] != got["par"])[0]
+        assert len(bad) == 0, (len(bad), bad[:10])
+
+
 @pytest.mark.parametrize("model,n_reads", [("cfg2", 1_000_000), ("cfg5", 3_000)])
 def test_scale_reference_base_equals_generator_reference(ctx, model, n_reads):
     """The synthetic reads carry MD tags consistent with a hash-defined reference, so whatever read provides a
@@ -562,6 +582,19 @@ def test_read_dna_random_md(ctx, seed):
 
 
 def _check_refbase(ctx, st, mode=L.BGP_PILEUP_COLUMNS, skip_zero=True, start_from=0, end_at=O.U64_MAX, window=777):
+    """Both provider-chain implementations (the event loop alone; composed successors with the event loop where
+    their premises fail) against the oracle."""
+    ora = None
+    for chain in ("seq", "par"):
+        os.environ["BGP_MD_CHAIN"] = chain
+        try:
+            ora = _check_refbase_one(ctx, st, mode, skip_zero, start_from, end_at, window)
+        finally:
+            os.environ.pop("BGP_MD_CHAIN", None)
+    return ora
+
+
+def _check_refbase_one(ctx, st, mode, skip_zero, start_from, end_at, window):
     """reference_base of every column the sweep visits (PileupRangeUsingMdTag, pileup.d:522-654) == oracle's;
     where BioD would throw, the device path must fail with the same status."""
     try:
