@@ -18,6 +18,7 @@ BGP_EINVAL, BGP_ETRUNC, BGP_ECIGAR, BGP_EDEVICE, BGP_ENOMEM, BGP_ESTATE, BGP_EMD
 BGP_FETCH_SEQ, BGP_FETCH_QUAL, BGP_FETCH_CIGAR, BGP_FETCH_ALL = 1, 2, 4, 7
 BGP_PILEUP_COLUMNS, BGP_MAKE_PILEUP = 0, 1
 BGP_DEPTH_BINS = 65536
+BGP_SNP_NO, BGP_SNP_YES, BGP_SNP_TIE, BGP_SNP_NEEDS_ENTRIES = 0, 1, 2, 3
 BGP_UOFFSET_UNKNOWN = 0xFFFFFFFF
 
 RECORD_DTYPE = np.dtype([("ref_id", "<i4"), ("pos", "<i4"), ("end_pos", "<i4"), ("bin_mq_nl", "<u4"),
@@ -44,7 +45,7 @@ class PileupInfo(C.Structure):
 
 class Columns(C.Structure):
     _fields_ = [("ref_id", C.c_int32), ("n_positions", C.c_uint32), ("first_position", C.c_uint64), ("columns", C.c_void_p),
-                ("entry_off", C.c_void_p), ("entries", C.c_void_p), ("reference_base", C.c_void_p)]
+                ("entry_off", C.c_void_p), ("entries", C.c_void_p), ("reference_base", C.c_void_p), ("snp", C.c_void_p)]
 
 
 class KernelTime(C.Structure):
@@ -80,6 +81,7 @@ SYMBOLS = {
     "bgp_pileup_begin": (C.c_int, [_P, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_uint32]),
     "bgp_pileup_next_window": (C.c_int, [_P, C.POINTER(Columns)]),
     "bgp_pileup_ref_id": (C.c_int, [_P, C.POINTER(C.c_int32)]),
+    "bgp_pileup_snp": (C.c_int, [_P, C.c_int, C.c_int]),
     "bgp_read_dna": (C.c_int, [_P, C.c_uint64, C.c_char_p, C.c_uint32, C.POINTER(C.c_uint32)]),
     "bgp_bai_open": (C.c_int, [C.c_char_p, C.POINTER(_P)]),
     "bgp_bai_close": (None, [_P]),

@@ -101,10 +101,10 @@ static void release_all(bgp_ctx* c) {
                    &c->d_seg_rec_base, &c->d_seg_seq_base, &c->d_seg_cig_base, &c->d_scan_tmp, &c->d_status, &c->d_rec, &c->d_seq_off, &c->d_cigar_off,
                    &c->d_seq, &c->d_qual, &c->d_cigar, &c->d_pmax_end, &c->d_pmax_pos, &c->d_runs, &c->d_columns, &c->d_depth_hist, &c->d_pstats,
                    &c->d_tiles, &c->d_ck_off, &c->d_ck, &c->d_entry_off, &c->d_entries, &c->d_col_lo,
-                   &c->d_md_row, &c->d_md_iv, &c->d_md_state, &c->d_refbase, &c->d_md_succ, &c->d_md_exit, &c->d_md_entry, &c->d_rec2, &c->d_seq_off2, &c->d_cigar_off2,
+                   &c->d_md_row, &c->d_md_iv, &c->d_md_state, &c->d_refbase, &c->d_md_succ, &c->d_md_exit, &c->d_md_entry, &c->d_snp, &c->d_rec2, &c->d_seq_off2, &c->d_cigar_off2,
                    &c->d_flt[0], &c->d_flt[1], &c->d_flt[2], &c->d_flt[3], &c->d_flt[4], &c->d_flt[5]};
     for (auto* b : d) b->release();
-    HostBuf* h[] = {&c->h_stage, &c->h_rec, &c->h_seq_off, &c->h_cigar_off, &c->h_seq, &c->h_qual, &c->h_cigar, &c->h_cols, &c->h_entry_off, &c->h_entries, &c->h_refbase};
+    HostBuf* h[] = {&c->h_stage, &c->h_rec, &c->h_seq_off, &c->h_cigar_off, &c->h_seq, &c->h_qual, &c->h_cigar, &c->h_cols, &c->h_entry_off, &c->h_entries, &c->h_refbase, &c->h_snp};
     for (auto* b : h) b->release();
 }
 
@@ -268,6 +268,12 @@ int bgp_pileup_begin(bgp_ctx* c, int mode, int use_md_tag, uint64_t start_from, 
     return BGP_OK;
 }
 
+int bgp_pileup_snp(bgp_ctx* c, int min_cov, int min_wit) {
+    if (!c) return BGP_EINVAL;
+    if (!c->it.active || !c->it.use_md) return BGP_ESTATE;     // findSNPs piles up with reference bases (simple.d:37-41)
+    c->it.snp = 1; c->it.snp_min_cov = min_cov; c->it.snp_min_wit = min_wit;
+    return BGP_OK;
+}
 int bgp_pileup_ref_id(bgp_ctx* c, int32_t* ref_id) { if (!c || !ref_id) return BGP_EINVAL; if (!c->it.active) return BGP_ESTATE; *ref_id = c->it.ref_id; return BGP_OK; }
 
 int bgp_pileup_next_window(bgp_ctx* c, bgp_columns* o) {
@@ -301,6 +307,12 @@ int bgp_pileup_next_window(bgp_ctx* c, bgp_columns* o) {
             BGP_TRY(c->h_refbase.reserve(np + 1));
             BGP_HIP(hipMemcpyAsync(c->h_refbase.p, c->d_refbase.as<uint8_t>() + r.column_base + (a - r.start_pos), np, hipMemcpyDeviceToHost, c->stream));
             o->reference_base = c->h_refbase.as<uint8_t>();
+        }
+        if (it.use_md && it.snp) {
+            BGP_TRY(k7_snp_simple(c, r.column_base + (a - r.start_pos), np, it.snp_min_cov, it.snp_min_wit));
+            BGP_TRY(c->h_snp.reserve(np + 1));
+            BGP_HIP(hipMemcpyAsync(c->h_snp.p, c->d_snp.p, np, hipMemcpyDeviceToHost, c->stream));
+            o->snp = c->h_snp.as<uint8_t>();
         }
         BGP_HIP(hipStreamSynchronize(c->stream));
         o->ref_id = r.ref_id; o->n_positions = (uint32_t)np; o->first_position = a; o->columns = c->h_cols.as<bgp_column>();

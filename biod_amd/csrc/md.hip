@@ -632,6 +632,32 @@ __global__ __launch_bounds__(64) void k6_emit(const uint8_t* s, const bgp_record
     }
 }
 
+// ---------------------------------------------------------------------------------------------- isSNP
+// simple.isSNP (bio/std/hts/snpcallers/simple.d:15-41) from the column summary + reference_base; see biodgpu.h for
+// the two cases that are reported instead of guessed.
+__global__ __launch_bounds__(256) void k7_snp(const bgp_column* cols, const uint8_t* refbase, uint64_t np, long long min_cov, int min_wit, uint8_t* out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= np) return;
+    const bgp_column c = cols[i];
+    const uint8_t rb = refbase[i];
+    uint8_t res = BGP_SNP_NO;
+    const unsigned long long cov = c.coverage;
+    const bool enough = !(cov < (unsigned long long)min_cov);          // size_t < int: the int is converted (simple.d:17)
+    if (enough && (c.a | c.c | c.g | c.t | c.other)) {
+        const uint32_t m4 = max(max(c.a, c.c), max(c.g, c.t));
+        const long long wit = min_wit;
+        if (c.other != 0 && c.other >= m4) {
+            // some ambiguity code may hold the largest count: undecidable here unless every count is below the witness bar
+            res = ((long long)c.other < wit && (long long)m4 < wit) ? BGP_SNP_NO : BGP_SNP_NEEDS_ENTRIES;
+        } else if (!((long long)m4 < wit)) {
+            const int n_top = (c.a == m4) + (c.c == m4) + (c.g == m4) + (c.t == m4);
+            const bool ref_top = (rb == 'A' && c.a == m4) || (rb == 'C' && c.c == m4) || (rb == 'G' && c.g == m4) || (rb == 'T' && c.t == m4);
+            res = !ref_top ? BGP_SNP_YES : (n_top == 1 ? BGP_SNP_NO : BGP_SNP_TIE);
+        }
+    }
+    out[i] = res;
+}
+
 // debug/test hook: dna(read) of one record into a host-visible buffer
 __global__ void k6_dna_one(const uint8_t* s, const bgp_record* rec, uint64_t i, uint8_t* out, uint32_t cap, uint32_t* len_bad) {
     bool bad, err, b2, e2;
@@ -643,6 +669,15 @@ __global__ void k6_dna_one(const uint8_t* s, const bgp_record* rec, uint64_t i, 
 }
 
 }  // namespace
+
+int k7_snp_simple(bgp_ctx* c, uint64_t col_index, uint64_t np, int min_cov, int min_wit) {
+    BGP_TRY(c->d_snp.reserve(np + 16));
+    if (!np) return BGP_OK;
+    hipLaunchKernelGGL(k7_snp, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, c->stream, c->d_columns.as<bgp_column>() + col_index, c->d_refbase.as<uint8_t>() + col_index, np,
+                       (long long)min_cov, min_wit, c->d_snp.as<uint8_t>());
+    BGP_HIP(hipGetLastError());
+    return BGP_OK;
+}
 
 // rows for every record of the staged stream (needs K3's prefix maxima: call after k34_pileup)
 static int k6_rows(bgp_ctx* c) {

@@ -140,8 +140,13 @@ class Context:
                           n_reads_used=info.n_reads_used, device_columns=info.device_columns or 0, device_depth_hist=info.device_depth_hist or 0)
 
     def pileup_windows(self, mode: int, use_md_tag=False, start_from=0, end_at=ULONG_MAX, skip_zero_coverage=True,
-                       want_entries=False, window_positions=0):
+                       want_entries=False, window_positions=0, snp=None):
+        """Dense windows of columns.  snp=(minimum_coverage, minimum_witnesses) adds simple.isSNP flags per position
+        (snpcallers/simple.d:15-41, needs use_md_tag): window.snp, resolved against the entries where the device says
+        BGP_SNP_NEEDS_ENTRIES and entries were requested."""
         L.check(L.lib().bgp_pileup_begin(self._h, mode, int(use_md_tag), start_from, end_at, int(skip_zero_coverage), int(want_entries), window_positions), self._h)
+        if snp is not None:
+            L.check(L.lib().bgp_pileup_snp(self._h, int(snp[0]), int(snp[1])), self._h)
         while True:
             cw = L.Columns()
             rc = L.check(L.lib().bgp_pileup_next_window(self._h, C.byref(cw)), self._h)
@@ -151,7 +156,13 @@ class Context:
             eoff = L.as_array(cw.entry_off, cw.n_positions + 1, "<u8") if cw.entry_off else None
             ents = L.as_array(cw.entries, int(eoff[-1]), L.ENTRY_DTYPE) if eoff is not None else None
             refb = L.as_array(cw.reference_base, cw.n_positions, "u1") if cw.reference_base else None
-            yield Window(cw.ref_id, cw.first_position, cols, eoff, ents, refb)
+            w = Window(cw.ref_id, cw.first_position, cols, eoff, ents, refb)
+            if snp is not None and cw.snp:
+                w.snp = L.as_array(cw.snp, cw.n_positions, "u1")
+                if ents is not None:
+                    for k in np.nonzero(w.snp == L.BGP_SNP_NEEDS_ENTRIES)[0]:
+                        w.snp[k] = is_snp_from_bases(bytes(ents["base"][int(eoff[k]):int(eoff[k + 1])]), int(cols["coverage"][k]), int(refb[k]), int(snp[0]), int(snp[1]))
+            yield w
 
     def read_dna(self, record: int, cap: int = 1 << 16, strict: bool = True) -> str:
         """dna(read), md/reconstruct.d:38-214: reference bases spanned by a read, from CIGAR + MD.
@@ -202,10 +213,32 @@ class PileupInfo:
         self.__dict__.update(kw)
 
 
+def is_snp_from_bases(bases: bytes, coverage: int, reference_base: int, minimum_coverage: int = 5, minimum_witnesses: int = 2) -> int:
+    """simple.isSNP (snpcallers/simple.d:15-41) on the current_base chars of one column; BGP_SNP_TIE where BioD's
+    answer hangs on the iteration order of druntime's associative array (several bases share the largest count and
+    reference_base is one of them)."""
+    if coverage < minimum_coverage % (1 << 64):         # size_t < int: D converts the int (simple.d:17)
+        return L.BGP_SNP_NO
+    cnt = {}
+    for b in bases:
+        if b != 0x2D:                                   # '-'
+            cnt[b] = cnt.get(b, 0) + 1
+    if not cnt:
+        return L.BGP_SNP_NO
+    top = max(cnt.values())
+    if top < minimum_witnesses:
+        return L.BGP_SNP_NO
+    tops = [b for b, v in cnt.items() if v == top]
+    if reference_base not in tops:
+        return L.BGP_SNP_YES
+    return L.BGP_SNP_NO if len(tops) == 1 else L.BGP_SNP_TIE
+
+
 class Window:
     def __init__(self, ref_id, first_position, columns, entry_off, entries, reference_base=None):
         self.ref_id, self.first_position, self.columns, self.entry_off, self.entries = ref_id, first_position, columns, entry_off, entries
         self.reference_base = reference_base          # uint8 per position (use_md_tag) or None
+        self.snp = None                               # uint8 per position of BGP_SNP_* (pileup_windows(snp=...)) or None
 
 
 # ------------------------------------------------------------------------------------------ reads

@@ -189,11 +189,28 @@ typedef struct bgp_columns {
     const uint64_t* entry_off;   /* host, n_positions+1, or NULL when entries were not requested  */
     const bgp_entry* entries;    /* host, reads of column k: entries[entry_off[k] .. entry_off[k+1]) in file order */
     const uint8_t* reference_base; /* host, n_positions (use_md_tag) or NULL                      */
+    const uint8_t* snp;          /* host, n_positions of BGP_SNP_* after bgp_pileup_snp, else NULL */
 } bgp_columns;
 int bgp_pileup_begin(bgp_ctx* ctx, int mode, int use_md_tag, uint64_t start_from, uint64_t end_at,
                      int skip_zero_coverage, int want_entries, uint32_t window_positions);
 int bgp_pileup_next_window(bgp_ctx* ctx, bgp_columns* out);   /* BGP_OK, BGP_EOF, or error */
 int bgp_pileup_ref_id(bgp_ctx* ctx, int32_t* ref_id);          /* AbstractPileup.ref_id, pileup.d:455 */
+
+/* isSNP(column, settings) of bio/std/hts/snpcallers/simple.d:15-41 for every position of the windows that
+ * follow (call after bgp_pileup_begin with use_md_tag = 1; defaults of SimpleCallerSettings: 5, 2).
+ * coverage < minimum_coverage -> no; no base other than '-' -> no; consensus = the base with the largest
+ * count; fewer than minimum_witnesses of it -> no; else consensus != reference_base.
+ * BioD takes the consensus with argmax over `int[char].byKey` (bio/core/utils/algo.d:79-93): the FIRST largest
+ * count in druntime's hash-table iteration order, which nothing in the reference pins.  Where that order decides
+ * the answer (several bases share the largest count and reference_base is one of them) the result is BGP_SNP_TIE
+ * instead of a guess.  The column summary merges the IUPAC ambiguity codes and '=' into one counter; where they
+ * could hold the largest count the result is BGP_SNP_NEEDS_ENTRIES and the caller decides from the per-read
+ * entries (the C++ / Python facades do). */
+#define BGP_SNP_NO 0
+#define BGP_SNP_YES 1
+#define BGP_SNP_TIE 2
+#define BGP_SNP_NEEDS_ENTRIES 3
+int bgp_pileup_snp(bgp_ctx* ctx, int minimum_coverage, int minimum_witnesses);
 
 /* dna(read): the reference bases a read spans, rebuilt from its CIGAR and MD tag
  * (bio/std/hts/bam/md/reconstruct.d:38-214, mdOperations bio/std/hts/bam/md/parse.d:13-142).

@@ -95,7 +95,7 @@ struct PileupRead {
 
 // PileupColumn, pileup.d:236-290
 struct PileupColumn {
-    int ref_id_; uint64_t position_; const bgp_column* c; const bgp_entry* ents; size_t n_ents; const bgp_records* recs; char refbase_;
+    int ref_id_; uint64_t position_; const bgp_column* c; const bgp_entry* ents; size_t n_ents; const bgp_records* recs; char refbase_; int snp_ = -1;
     size_t coverage() const { return c->coverage; }                            // pileup.d:252
     int ref_id() const { return ref_id_; }                                     // pileup.d:257
     uint64_t position() const { return position_; }                            // pileup.d:262
@@ -104,6 +104,20 @@ struct PileupColumn {
     std::vector<PileupRead> reads() const { std::vector<PileupRead> v; for (size_t i = 0; i < n_ents; ++i) v.push_back({ents + i, recs}); return v; }
     std::vector<PileupRead> reads_starting_here() const {                      // pileup.d:272-274
         std::vector<PileupRead> v; for (size_t i = n_ents - c->n_starting_here; i < n_ents; ++i) v.push_back({ents + i, recs}); return v;
+    }
+    // isSNP(column, settings), snpcallers/simple.d:15-41: BGP_SNP_NO / BGP_SNP_YES / BGP_SNP_TIE (BioD's answer would depend
+    // on druntime's associative-array order); -1 unless PileupRange::callSNPs was used.  Columns the device could not
+    // decide from the summary (ambiguity codes may hold the top count) are decided here from the per-read bases.
+    int is_snp(int minimum_coverage = 5, int minimum_witnesses = 2) const {
+        if (snp_ != BGP_SNP_NEEDS_ENTRIES || !ents) return snp_;
+        if ((unsigned long long)coverage() < (unsigned long long)(long long)minimum_coverage) return BGP_SNP_NO;
+        int cnt[256] = {0}, top = 0, n_top = 0;
+        for (size_t i = 0; i < n_ents; ++i) if (ents[i].base != '-') ++cnt[ents[i].base];
+        for (int b = 0; b < 256; ++b) top = cnt[b] > top ? cnt[b] : top;
+        if (top == 0 || top < minimum_witnesses) return BGP_SNP_NO;
+        for (int b = 0; b < 256; ++b) n_top += cnt[b] == top;
+        if (cnt[(unsigned char)refbase_] != top) return BGP_SNP_YES;
+        return n_top == 1 ? BGP_SNP_NO : BGP_SNP_TIE;
     }
     std::string bases() const { std::string s; for (size_t i = 0; i < n_ents; ++i) s.push_back((char)ents[i].base); return s; }   // pileup.d:277
 };
@@ -122,9 +136,14 @@ public:
     PileupColumn front() const {
         const uint64_t a = want_entries_ ? w_.entry_off[k_] : 0, b = want_entries_ ? w_.entry_off[k_ + 1] : 0;
         return PileupColumn{w_.ref_id, w_.first_position + k_, w_.columns + k_, want_entries_ ? w_.entries + a : nullptr, (size_t)(b - a), &recs_,
-                            w_.reference_base ? (char)w_.reference_base[k_] : 'N'};
+                            w_.reference_base ? (char)w_.reference_base[k_] : 'N', w_.snp ? (int)w_.snp[k_] : -1};
     }
     void popFront() { ++k_; settle(); }
+    // findSNPs' settings (simple.d:8-13,37-41); call right after construction with use_md_tag = true
+    PileupRange& callSNPs(int minimum_coverage = 5, int minimum_witnesses = 2) {
+        check(bgp_pileup_snp(ctx_, minimum_coverage, minimum_witnesses), ctx_);
+        return *this;
+    }
     uint64_t start_position() const { return start_; }                         // pileup.d:445
     uint64_t end_position() const { return end_; }                             // pileup.d:450
     int ref_id() const { return ref_id_; }                                     // pileup.d:455

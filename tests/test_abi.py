@@ -41,7 +41,7 @@ def test_header_cites_reference_for_every_entry_point():
 
 
 def test_struct_layouts_match_header():
-    assert C.sizeof(L.Records) == 72 and C.sizeof(L.Columns) == 48 and C.sizeof(L.SynthCfg) == 40
+    assert C.sizeof(L.Records) == 72 and C.sizeof(L.Columns) == 56 and C.sizeof(L.SynthCfg) == 40
     assert L.RECORD_DTYPE.itemsize == 32 and L.COLUMN_DTYPE.itemsize == 32 and L.ENTRY_DTYPE.itemsize == 16
 
 

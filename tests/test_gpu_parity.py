@@ -457,6 +457,32 @@ def test_records_larger_than_framing_segments(ctx):
     assert info.max_coverage >= 3
 
 
+def test_deep_pile(ctx):
+    """12 000 reads stacked on ~150 columns: more reads in one window than its LDS list holds (several
+    scan/process rounds), coverage beyond the depth-histogram bins kept in LDS, position groups of hundreds of
+    reads, and -- with use_md_tag -- provider windows longer than k6_succ will scan (the event loop takes over)."""
+    rng = np.random.default_rng(77)
+    recs, pos = [], 1000
+    for i in range(12_000):
+        pos += int(rng.random() < 0.004)
+        ln = int(rng.integers(60, 140))
+        seq = "".join("ACGT"[int(x)] for x in rng.integers(0, 4, ln))
+        recs.append(bamio.pack_record(f"d{i}", seq, [(ln, "M")], ref_id=0, pos=pos, tags=bamio.tag_z("MD", str(ln))))
+    st = b"".join(recs)
+    stage(ctx, st)
+    check_decode(ctx, st)
+    info, ora = check_pileup(ctx, st, entries=False)
+    assert info.max_coverage > 8000
+    from biod_amd.shard import depth_histogram
+    hist = np.zeros(L.BGP_DEPTH_BINS, np.uint64)
+    import ctypes as C2
+    hip = C2.CDLL("libamdhip64.so")
+    assert hip.hipMemcpy(hist.ctypes.data_as(C2.c_void_p), C2.c_void_p(info.device_depth_hist), C2.c_size_t(hist.nbytes), 2) == 0
+    assert np.array_equal(hist.astype(np.int64), depth_histogram(O.pileup(st, skip_zero=False).cov))
+    for skip in (True, False):
+        _check_refbase(ctx, st, skip_zero=skip, window=64)
+
+
 def _random_stream(rng, n_reads, quirks):
     """Coordinate-sorted random records: every CIGAR op type, optional zero-length ops, SEQ shorter or
     longer than the CIGAR's query length, unmapped reads, three references."""
@@ -720,6 +746,80 @@ def test_reference_base_stale_chunk_end_across_references(ctx):
         assert ora is not None
         col = {(int(r), int(p)): chr(b) for r, p, b in zip(ora.ref, ora.pos, ora.refbase)}
         assert col[(1, 3)] == "T" and col[(2, 7)] == "C"          # d (end 28 > stale 20) and f (end 47 > stale 28) win
+
+
+# ------------------------------------------------------------------------------------------ isSNP (f4)
+def _expected_snp(bases, coverage, refbase, min_cov, min_wit):
+    """simple.d:15-41 restated for the test: 0 no, 1 yes, 2 = the answer depends on which of several top-count
+    bases druntime's associative array yields first (one of them is reference_base)."""
+    if coverage < min_cov % (1 << 64):                      # size_t < int: D converts the int (simple.d:17)
+        return 0
+    cnt = {}
+    for b in bases:
+        if b != ord("-"):
+            cnt[b] = cnt.get(b, 0) + 1
+    if not cnt:
+        return 0
+    top = max(cnt.values())
+    if top < min_wit:
+        return 0
+    tops = {b for b, v in cnt.items() if v == top}
+    if refbase not in tops:
+        return 1
+    return 0 if len(tops) == 1 else 2
+
+
+def _check_snp(ctx, st, min_cov, min_wit, with_entries):
+    ora = O.pileup(st, use_md=True, want_entries=True)
+    exp = {}
+    for k in range(ora.n_columns):
+        e = ora.entries[int(ora.entry_off[k]):int(ora.entry_off[k + 1])]
+        exp[(int(ora.ref[k]), int(ora.pos[k]))] = _expected_snp(bytes(e["base"]), int(ora.cov[k]), int(ora.refbase[k]), min_cov, min_wit)
+    seen = {0: 0, 1: 0, 2: 0, 3: 0}
+    for w in ctx.pileup_windows(L.BGP_PILEUP_COLUMNS, use_md_tag=True, want_entries=with_entries, window_positions=333, snp=(min_cov, min_wit)):
+        assert w.snp is not None and len(w.snp) == len(w.columns)
+        for k in np.nonzero(w.columns["coverage"])[0]:
+            got, want = int(w.snp[k]), exp[(w.ref_id, int(w.first_position) + int(k))]
+            seen[got] += 1
+            if got == L.BGP_SNP_NEEDS_ENTRIES:
+                assert not with_entries                     # with entries the facade resolves these
+                continue
+            assert got == want, (w.ref_id, int(w.first_position) + int(k), got, want)
+    return seen
+
+
+@pytest.mark.parametrize("name", ["illu_20_chunk.bam", "ion_20_chunk.bam", "b7_295_chunk.bam", "mg1655_chunk.bam"])
+def test_is_snp_fixtures(ctx, data_dir, name):
+    _, st = bamio.read_bam(os.path.join(data_dir, name))
+    stage(ctx, st)
+    for min_cov, min_wit in ((5, 2), (1, 1), (3, 3), (0, 0), (-1, 2)):
+        seen = _check_snp(ctx, st, min_cov, min_wit, with_entries=True)
+        assert seen[3] == 0
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_is_snp_random_low_coverage_ties_and_ambiguity_codes(ctx, seed):
+    """Shallow random piles: ties between bases at most positions; IUPAC codes and '=' in SEQ so that the merged
+    'other' counter can hold the top count (resolved from the entries, or reported as such without them)."""
+    rng = np.random.default_rng(9100 + seed)
+    recs, pos = [], 10
+    for i in range(300):
+        pos += int(rng.integers(0, 4))
+        ln = int(rng.integers(8, 30))
+        seq = "".join("ACGTNRYM="[int(x)] for x in rng.choice(9, size=ln, p=[0.22, 0.22, 0.22, 0.22, 0.04, 0.02, 0.02, 0.02, 0.02]))
+        ops = [(ln, "M")] if rng.random() < 0.8 else [(ln // 2, "M"), (2, "D"), (ln - ln // 2, "M")]
+        md = str(ln) if len(ops) == 1 else f"{ln // 2}^AC{ln - ln // 2}"
+        recs.append(bamio.pack_record(f"s{i}", seq, ops, ref_id=0, pos=pos, tags=bamio.tag_z("MD", md)))
+    st = b"".join(recs)
+    stage(ctx, st)
+    tot = {0: 0, 1: 0, 2: 0, 3: 0}
+    for min_cov, min_wit in ((5, 2), (1, 1), (2, 2)):
+        a = _check_snp(ctx, st, min_cov, min_wit, with_entries=True)
+        b = _check_snp(ctx, st, min_cov, min_wit, with_entries=False)
+        assert a[3] == 0
+        for k in tot:
+            tot[k] += a[k] + b[k]
+    assert tot[1] > 0 and tot[2] > 0 and tot[3] > 0 and tot[0] > 0
 
 
 # ------------------------------------------------------------------------------------------ BAI / region queries (f3)
