@@ -126,11 +126,9 @@ struct PileupColumn {
 class PileupRange {
 public:
     PileupRange(BamReader& r, int mode, bool use_md_tag, uint64_t start_from, uint64_t end_at, bool skip_zero_coverage, bool want_entries, uint32_t window)
-        : ctx_(r.ctx()), skip_zero_(skip_zero_coverage), want_entries_(want_entries), start_(start_from), end_(end_at) {
+        : ctx_(r.ctx()), skip_zero_(skip_zero_coverage), want_entries_(want_entries), start_(start_from), end_(end_at), mode_(mode), use_md_(use_md_tag), window_(window) {
         if (want_entries) check(bgp_decode_fetch(ctx_, BGP_FETCH_ALL, &recs_), ctx_);
-        check(bgp_pileup_begin(ctx_, mode, use_md_tag, start_from, end_at, skip_zero_coverage, want_entries, window), ctx_);
-        if (mode == BGP_MAKE_PILEUP) check(bgp_pileup_ref_id(ctx_, &ref_id_), ctx_);
-        fetch(); settle();
+        restart();
     }
     bool empty() const { return done_; }
     PileupColumn front() const {
@@ -141,7 +139,8 @@ public:
     void popFront() { ++k_; settle(); }
     // findSNPs' settings (simple.d:8-13,37-41); call right after construction with use_md_tag = true
     PileupRange& callSNPs(int minimum_coverage = 5, int minimum_witnesses = 2) {
-        check(bgp_pileup_snp(ctx_, minimum_coverage, minimum_witnesses), ctx_);
+        snp_ = true; snp_cov_ = minimum_coverage; snp_wit_ = minimum_witnesses;
+        restart();                                                             // the first window was fetched without verdicts
         return *this;
     }
     uint64_t start_position() const { return start_; }                         // pileup.d:445
@@ -158,6 +157,13 @@ public:
     iterator end() { return {this}; }
 
 private:
+    void restart() {
+        check(bgp_pileup_begin(ctx_, mode_, use_md_, start_, end_, skip_zero_, want_entries_, window_), ctx_);
+        if (snp_) check(bgp_pileup_snp(ctx_, snp_cov_, snp_wit_), ctx_);
+        if (mode_ == BGP_MAKE_PILEUP) check(bgp_pileup_ref_id(ctx_, &ref_id_), ctx_);
+        done_ = false;
+        fetch(); settle();
+    }
     void fetch() { const int rc = check(bgp_pileup_next_window(ctx_, &w_), ctx_); done_ = rc == BGP_EOF; k_ = 0; }
     void settle() {            // skip zero-coverage positions the way PileupRange.popFront jumps over them, pileup.d:388-392
         while (!done_) {
@@ -167,6 +173,7 @@ private:
         }
     }
     bgp_ctx* ctx_; bool skip_zero_, want_entries_; uint64_t start_, end_;
+    int mode_; bool use_md_; uint32_t window_; bool snp_ = false; int snp_cov_ = 5, snp_wit_ = 2;
     bgp_columns w_{}; bgp_records recs_{}; uint32_t k_ = 0; bool done_ = false; int32_t ref_id_ = -1;
 };
 

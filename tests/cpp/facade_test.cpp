@@ -65,6 +65,20 @@ int main(int argc, char** argv) {
         }
         REQUIRE(cols > 100 && agree * 10 > cols * 9);
         for (auto column : makePileup(bam.reads(), false)) REQUIRE(column.reference_base() == 'N');      // pileup.d:245-249
+        // snpcallers/simple.d:15-41 through the facade: every covered column gets a verdict; a column whose reads all
+        // agree with the reference is never a SNP
+        size_t verdicts = 0;
+        auto snps = makePileup(bam.reads(), true);
+        snps.callSNPs();
+        for (auto column : snps) {
+            const int v = column.is_snp();
+            REQUIRE(v == BGP_SNP_NO || v == BGP_SNP_YES || v == BGP_SNP_TIE);
+            bool all_ref = true;
+            for (char c : column.bases()) all_ref = all_ref && c == column.reference_base();
+            if (all_ref) REQUIRE(v == BGP_SNP_NO);
+            ++verdicts;
+        }
+        REQUIRE(verdicts == cols);
     }
     if (argc > 3) {                                                      // unittests.d:145-185: bam["large"][beg .. end] == naive filter
         BamReader all(argv[3], 2);
