@@ -98,7 +98,7 @@ int bgp_init(int device, bgp_ctx** out) {
 
 static void release_all(bgp_ctx* c) {
     DevBuf* d[] = {&c->d_stream_own, &c->d_synth, &c->d_seg_entry, &c->d_seg_end, &c->d_seg_cnt, &c->d_seg_lseq, &c->d_seg_ncig, &c->d_seg_dirty,
-                   &c->d_seg_rec_base, &c->d_seg_seq_base, &c->d_seg_cig_base, &c->d_scan_tmp, &c->d_status, &c->d_rec, &c->d_seq_off, &c->d_cigar_off,
+                   &c->d_seg_rec_base, &c->d_seg_seq_base, &c->d_seg_cig_base, &c->d_seg_side, &c->d_scan_tmp, &c->d_status, &c->d_rec, &c->d_seq_off, &c->d_cigar_off,
                    &c->d_seq, &c->d_qual, &c->d_cigar, &c->d_pmax_end, &c->d_pmax_pos, &c->d_runs, &c->d_columns, &c->d_depth_hist, &c->d_pstats,
                    &c->d_tiles, &c->d_ck_off, &c->d_ck, &c->d_entry_off, &c->d_entries, &c->d_col_lo,
                    &c->d_md_row, &c->d_md_iv, &c->d_md_state, &c->d_refbase, &c->d_md_succ, &c->d_md_exit, &c->d_md_entry, &c->d_snp, &c->d_rec2, &c->d_seq_off2, &c->d_cigar_off2,
@@ -132,7 +132,7 @@ int bgp_reset(bgp_ctx* c) {
     if (!c) return BGP_EINVAL;
     BGP_HIP(hipStreamSynchronize(c->stream));
     c->h_stage_len = 0; c->d_stream = nullptr; c->stream_len = 0; c->stream_on_device = false;
-    c->flushed = false; c->piled = false; c->md_rows_ready = false; c->n_records = 0; c->decoded_what = 0; c->it = bgp_ctx::Iter();
+    c->flushed = false; c->piled = false; c->md_rows_ready = false; c->table_pending = false; c->n_records = 0; c->decoded_what = 0; c->it = bgp_ctx::Iter();
     c->runs.clear(); c->stage_map.clear(); c->region_pending = false;
     return BGP_OK;
 }
@@ -154,6 +154,15 @@ int bgp_attach_device_stream(bgp_ctx* c, const void* dptr, uint64_t len) {
     return BGP_OK;
 }
 
+// K1, three ways (measured on cfg3, 100 M reads, K1 + K2 time):
+//   0  k1_emit: one lane per segment re-chases the length prefixes and writes its records' rows (9.0 + 12.7 ms)
+//   1  k12_fused: rows and unpack in one kernel, the stream is read once (19.2 ms: 90 VGPRs and a three-phase
+//      workgroup cost more than the second read of the stream)
+//   2  k12_fused<no unpack>: one lane per RECORD from the offsets k0_chase left behind, rows written coalesced,
+//      then k2_unpack as before (5.0 + 13.1 ms) -- the default.
+static int fuse_mode() { const char* e = getenv("BGP_FUSE_MODE"); return e ? atoi(e) : 2; }   // 0: chase-based K1, then K2; 1: K1+K2 fused; 2: parallel K1 from the side offsets, then K2
+static int ensure_table(bgp_ctx* c) { return !c->table_pending ? BGP_OK : (fuse_mode() == 0 ? k1_table(c) : k12_fused_decode(c, 0)); }
+
 int bgp_flush(bgp_ctx* c) {
     if (!c) return BGP_EINVAL;
     BGP_HIP(hipSetDevice(c->device));
@@ -166,7 +175,8 @@ int bgp_flush(bgp_ctx* c) {
     int rc = k0_frame(c);
     if (rc < 0) return rc;
     c->flushed = true;
-    if (c->region_pending) BGP_TRY(k_region_filter(c, c->region_ref, c->region_beg, c->region_end));   // bam[ref][beg..end]
+    if (fuse_mode() != 1) BGP_TRY(ensure_table(c));      // K1; only the fused experiment (BGP_FUSE_MODE=1) defers it to the decode
+    if (c->region_pending) { BGP_TRY(ensure_table(c)); BGP_TRY(k_region_filter(c, c->region_ref, c->region_beg, c->region_end)); }   // bam[ref][beg..end]
     return BGP_OK;
 }
 
@@ -177,7 +187,8 @@ int bgp_decode_device(bgp_ctx* c, uint32_t what, bgp_records* o) {
     if (!c->flushed) return BGP_ESTATE;
     BGP_HIP(hipSetDevice(c->device));
     const uint32_t todo = what & ~c->decoded_what & BGP_FETCH_ALL;
-    if (todo) BGP_TRY(k2_decode(c, todo));
+    if (c->table_pending && fuse_mode() == 1) BGP_TRY(k12_fused_decode(c, todo));      // K1 + K2 in one pass
+    else { BGP_TRY(ensure_table(c)); if (todo) BGP_TRY(k2_decode(c, todo)); }
     memset(o, 0, sizeof *o);
     o->n = c->n_records; o->rec = c->d_rec.as<bgp_record>(); o->seq_off = c->d_seq_off.as<uint64_t>(); o->cigar_off = c->d_cigar_off.as<uint64_t>();
     o->seq = (what & BGP_FETCH_SEQ) ? c->d_seq.as<uint8_t>() : nullptr;
@@ -212,6 +223,7 @@ int bgp_pileup_run(bgp_ctx* c, bgp_pileup_info* info) {
     if (!c) return BGP_EINVAL;
     if (!c->flushed) return BGP_ESTATE;
     BGP_HIP(hipSetDevice(c->device));
+    BGP_TRY(ensure_table(c));
     BGP_TRY(k34_pileup(c));
     c->piled = true; c->md_rows_ready = false;
     if (info) *info = c->pinfo;
@@ -326,6 +338,7 @@ int bgp_read_dna(bgp_ctx* c, uint64_t record, char* out, uint32_t cap, uint32_t*
     if (!c->flushed) return BGP_ESTATE;
     BGP_HIP(hipSetDevice(c->device));
     uint32_t flags = 0;
+    BGP_TRY(ensure_table(c));
     BGP_TRY(k6_dna_of_record(c, record, (uint8_t*)out, cap, len, &flags));
     if (flags & 4u) { c->last_error = "internal: dna_length disagrees with dna_walk"; return BGP_ESTATE; }
     if (flags & 2u) return BGP_EINVAL;
@@ -402,6 +415,7 @@ int bgp_filter_region(bgp_ctx* c, int32_t ref_id, uint32_t beg, uint32_t end) {
     if (!c) return BGP_EINVAL;
     if (!c->flushed) return BGP_ESTATE;
     BGP_HIP(hipSetDevice(c->device));
+    BGP_TRY(ensure_table(c));
     return k_region_filter(c, (uint32_t)ref_id, beg, end);
 }
 int bgp_load_bam_read_at(bgp_ctx* c, const char* path, uint64_t voffset) {
@@ -414,6 +428,7 @@ int bgp_record_voffset(bgp_ctx* c, uint64_t record, uint64_t* voffset) {
     if (!c || !voffset) return BGP_EINVAL;
     if (!c->flushed || record >= c->n_records) return c && c->flushed ? BGP_EINVAL : BGP_ESTATE;
     BGP_HIP(hipSetDevice(c->device));
+    BGP_TRY(ensure_table(c));
     bgp_record r;
     BGP_HIP(hipMemcpyAsync(&r, c->d_rec.as<bgp_record>() + record, sizeof r, hipMemcpyDeviceToHost, c->stream));
     BGP_HIP(hipStreamSynchronize(c->stream));

@@ -105,6 +105,8 @@ struct bgp_ctx {
     uint32_t seg_bytes = 0; uint64_t n_seg = 0;
     DevBuf d_seg_entry, d_seg_end, d_seg_cnt, d_seg_lseq, d_seg_ncig, d_seg_dirty;   // per segment
     DevBuf d_seg_rec_base, d_seg_seq_base, d_seg_cig_base;
+    DevBuf d_seg_side; uint32_t side_cap = 0;         // per segment: offsets of its records relative to the segment start (written by k0_chase)
+    bool table_pending = false, long_cigar = false;   // the record table is written lazily: by k1_table, or by the fused K1+K2 if a decode comes first
     DevBuf d_scan_tmp;
     DevBuf d_status;                                  // uint32 status bits + counters
     bool flushed = false;
@@ -157,7 +159,11 @@ void bgp_timing_collect(bgp_ctx* c);
 
 // ---- per-file entry points (implemented in the .hip units) ----
 int k0_frame(bgp_ctx* c);                                   // frame.hip : segments, guess/chase/verify, scans, record table
+int k1_table(bgp_ctx* c);                                   // frame.hip : K1 alone (record table + arena offsets)
+int k1_finish_long_cigars(bgp_ctx* c);
 int k2_decode(bgp_ctx* c, uint32_t what);                   // decode.hip
+int k12_fused_decode(bgp_ctx* c, uint32_t what);            // decode.hip : K1 + K2 in one pass over the stream
+constexpr uint32_t BGP_LONG_CIGAR = 32;                      // more ops than this: basesCovered is summed by a whole wave (k1_long_cigar)
 int k34_pileup(bgp_ctx* c);                                 // pileup.hip : runs + dense columns
 int k34_first_survivor(bgp_ctx* c, uint32_t run, uint64_t start_from, uint64_t* pos, uint64_t* record);
 int k5_entries(bgp_ctx* c, uint32_t run, uint64_t pos_begin, uint64_t pos_end, uint64_t* n_entries);  // pileup.hip : CSR for a window

@@ -75,27 +75,9 @@ __device__ __forceinline__ uint4 merge16(uint4 a, uint4 b, uint32_t n) {
     return make_uint4((a.x & m0) | (b.x & ~m0), (a.y & m1) | (b.y & ~m1), (a.z & m2) | (b.z & ~m2), (a.w & m3) | (b.w & ~m3));
 }
 
+// Unpacks the `cnt` consecutive records whose arena offsets and section pointers sit in LDS.
 template <bool SEQ, bool QUAL, bool CIG>
-__global__ __launch_bounds__(256) void k2_unpack(DecArgs a) {
-    __shared__ uint64_t s_seq_off[RB + 1];
-    __shared__ uint64_t s_cig_off[RB + 1];
-    __shared__ RecInfo s_info[RB];
-    const uint64_t r0 = (uint64_t)blockIdx.x * RB;
-    const int cnt = (int)min((uint64_t)RB, a.n - r0);
-    for (int j = threadIdx.x; j <= cnt; j += blockDim.x) {
-        s_seq_off[j] = a.seq_off[r0 + j];
-        s_cig_off[j] = a.cigar_off[r0 + j];
-        if (j < cnt) {
-            const bgp_record r = a.rec[r0 + j];
-            RecInfo ri;
-            ri.cig_ptr = r.rec_off + 36 + (r.bin_mq_nl & 0xFFu);                    // read.d:988-990
-            ri.seq_ptr = ri.cig_ptr + 4ull * (r.flag_nc & 0xFFFFu);                 // read.d:992-994
-            ri.qual_ptr = ri.seq_ptr + (uint64_t)((r.l_seq + 1) / 2);               // read.d:996-998
-            s_info[j] = ri;
-        }
-    }
-    __syncthreads();
-
+__device__ __forceinline__ void unpack_group(const DecArgs& a, int cnt, const uint64_t* s_seq_off, const uint64_t* s_cig_off, const RecInfo* s_info) {
     if (CIG) {
         const uint64_t c0 = s_cig_off[0], c1 = s_cig_off[cnt];
         const float inv = c1 > c0 ? (float)cnt / (float)(c1 - c0) : 0.f;
@@ -154,6 +136,125 @@ __global__ __launch_bounds__(256) void k2_unpack(DecArgs a) {
     }
 }
 
+template <bool SEQ, bool QUAL, bool CIG>
+__global__ __launch_bounds__(256) void k2_unpack(DecArgs a) {
+    __shared__ uint64_t s_seq_off[RB + 1];
+    __shared__ uint64_t s_cig_off[RB + 1];
+    __shared__ RecInfo s_info[RB];
+    const uint64_t r0 = (uint64_t)blockIdx.x * RB;
+    const int cnt = (int)min((uint64_t)RB, a.n - r0);
+    for (int j = threadIdx.x; j <= cnt; j += blockDim.x) {
+        s_seq_off[j] = a.seq_off[r0 + j];
+        s_cig_off[j] = a.cigar_off[r0 + j];
+        if (j < cnt) {
+            const bgp_record r = a.rec[r0 + j];
+            RecInfo ri;
+            ri.cig_ptr = r.rec_off + 36 + (r.bin_mq_nl & 0xFFu);                    // read.d:988-990
+            ri.seq_ptr = ri.cig_ptr + 4ull * (r.flag_nc & 0xFFFFu);                 // read.d:992-994
+            ri.qual_ptr = ri.seq_ptr + (uint64_t)((r.l_seq + 1) / 2);               // read.d:996-998
+            s_info[j] = ri;
+        }
+    }
+    __syncthreads();
+    unpack_group<SEQ, QUAL, CIG>(a, cnt, s_seq_off, s_cig_off, s_info);
+}
+
+// ---------------------------------------------------------------------------------------------- K1 + K2 in one pass
+// When a decode follows the framing directly, the record table does not need its own pass over the stream: k0_chase
+// left every record's offset (relative to its segment) in a side array, the scans gave every segment its base record
+// index and arena offsets, so a workgroup that owns G_SEG consecutive segments can compute its records' table rows
+// with one lane per record (header + CIGAR are in the lines the unpack is about to read anyway), turn l_seq / n_cigar
+// into arena offsets with a block scan, write the rows coalesced, and unpack -- the 29 GB stream is read once
+// instead of twice.
+constexpr int G_SEG = 8;
+
+struct FusedArgs {
+    DecArgs d;
+    const uint64_t* entry; const uint64_t* rec_base; const uint64_t* seq_base; const uint64_t* cig_base; const uint32_t* side;
+    uint32_t side_cap, seg_bytes; uint64_t n_seg, sum_lseq, sum_ncig;
+    bgp_record* rec_out; uint64_t* seq_off_out; uint64_t* cig_off_out;
+};
+
+// exclusive prefix sums of two per-thread values over the 256 threads of the block + the block totals
+__device__ __forceinline__ void block_excl2(uint64_t v0, uint64_t v1, uint64_t* e0, uint64_t* e1, uint64_t* t0, uint64_t* t1, uint64_t (*ws)[4]) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint64_t i0 = v0, i1 = v1;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint64_t o0 = __shfl_up(i0, d, 64), o1 = __shfl_up(i1, d, 64);
+        if (lane >= d) { i0 += o0; i1 += o1; }
+    }
+    if (lane == 63) { ws[0][w] = i0; ws[1][w] = i1; }
+    __syncthreads();
+    uint64_t c0 = 0, c1 = 0, s0 = 0, s1 = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { if (k < w) { c0 += ws[0][k]; c1 += ws[1][k]; } s0 += ws[0][k]; s1 += ws[1][k]; }
+    *e0 = c0 + i0 - v0; *e1 = c1 + i1 - v1; *t0 = s0; *t1 = s1;
+    __syncthreads();
+}
+
+template <bool SEQ, bool QUAL, bool CIG>
+__global__ __launch_bounds__(256) void k12_fused(FusedArgs a) {
+    __shared__ uint64_t s_seq_off[RB + 1];
+    __shared__ uint64_t s_cig_off[RB + 1];
+    __shared__ RecInfo s_info[RB];
+    __shared__ uint64_t s_rb[G_SEG + 1];
+    __shared__ uint64_t s_ws[2][4];
+    const uint64_t k0 = (uint64_t)blockIdx.x * G_SEG;
+    const int g_n = (int)min((uint64_t)G_SEG, a.n_seg - k0);
+    if ((int)threadIdx.x <= g_n) s_rb[threadIdx.x] = a.rec_base[k0 + threadIdx.x];
+    if (blockIdx.x == 0 && threadIdx.x == 0) { a.seq_off_out[a.d.n] = a.sum_lseq; a.cig_off_out[a.d.n] = a.sum_ncig; }
+    __syncthreads();
+    const uint64_t r_lo = s_rb[0], r_hi = s_rb[g_n];
+    uint64_t carry_seq = a.seq_base[k0], carry_cig = a.cig_base[k0];
+    for (uint64_t b0 = r_lo; b0 < r_hi; b0 += RB) {
+        const int cnt = (int)min((uint64_t)RB, r_hi - b0);
+        const uint64_t i = b0 + threadIdx.x;
+        const bool valid = (int)threadIdx.x < cnt;
+        bgp_record rec{};
+        uint64_t lseq = 0, ncig = 0;
+        if (valid) {
+            int g = 0;
+#pragma unroll
+            for (int k = 1; k < G_SEG; ++k) if (k < g_n && s_rb[k] <= i) g = k;
+            const uint64_t seg = k0 + g;
+            const uint64_t off = seg * a.seg_bytes + a.side[seg * a.side_cap + (i - s_rb[g])];
+            const uint8_t* p = a.d.s + off;
+            rec.ref_id = (int32_t)ld_u32(p + 4);                     // read.d:907
+            rec.pos = (int32_t)ld_u32(p + 8);                        // read.d:911
+            rec.bin_mq_nl = ld_u32(p + 12);                          // read.d:915
+            rec.flag_nc = ld_u32(p + 16);                            // read.d:919
+            rec.l_seq = (int32_t)ld_u32(p + 20);                     // read.d:923
+            rec.rec_off = off;
+            const uint32_t l_name = rec.bin_mq_nl & 0xFFu, n_cig = rec.flag_nc & 0xFFFFu;
+            uint32_t covered = 0;
+            if (!((rec.flag_nc >> 16) & 0x4u) && n_cig <= BGP_LONG_CIGAR) {   // read.d:257-259; long CIGARs: k1_long_cigar afterwards
+                const uint8_t* cg = p + 36 + l_name;                  // read.d:988-990
+                for (uint32_t j = 0; j < n_cig; ++j) { const uint32_t op = ld_u32(cg + 4 * j); covered += cig_rc(op) ? (op >> 4) : 0u; }   // read.d:261
+            }
+            rec.end_pos = (int32_t)((uint32_t)rec.pos + covered);     // read.d:1382
+            lseq = (uint64_t)(uint32_t)rec.l_seq; ncig = n_cig;
+        }
+        uint64_t es, ec, ts, tc;
+        block_excl2(lseq, ncig, &es, &ec, &ts, &tc, s_ws);
+        if (valid) {
+            const uint64_t so = carry_seq + es, co = carry_cig + ec;
+            a.rec_out[i] = rec; a.seq_off_out[i] = so; a.cig_off_out[i] = co;
+            s_seq_off[threadIdx.x] = so; s_cig_off[threadIdx.x] = co;
+            RecInfo ri;
+            ri.cig_ptr = rec.rec_off + 36 + (rec.bin_mq_nl & 0xFFu);
+            ri.seq_ptr = ri.cig_ptr + 4ull * (rec.flag_nc & 0xFFFFu);
+            ri.qual_ptr = ri.seq_ptr + (uint64_t)((rec.l_seq + 1) / 2);
+            s_info[threadIdx.x] = ri;
+        }
+        if ((int)threadIdx.x == cnt - 1 || (cnt == 0 && threadIdx.x == 0)) { s_seq_off[cnt] = carry_seq + ts; s_cig_off[cnt] = carry_cig + tc; }
+        __syncthreads();
+        unpack_group<SEQ, QUAL, CIG>(a.d, cnt, s_seq_off, s_cig_off, s_info);
+        __syncthreads();
+        carry_seq += ts; carry_cig += tc;
+    }
+}
+
 }  // namespace
 
 int k2_decode(bgp_ctx* c, uint32_t what) {
@@ -182,6 +283,47 @@ int k2_decode(bgp_ctx* c, uint32_t what) {
     else if (Q) LAUNCH(false, true, false);
     else if (C) LAUNCH(false, false, true);
 #undef LAUNCH
+    BGP_HIP(hipGetLastError());
+    return BGP_OK;
+}
+
+// K1 and K2 fused: used by bgp_decode_* when the record table has not been written yet (api.cpp).
+int k12_fused_decode(bgp_ctx* c, uint32_t what) {
+    const uint64_t n = c->n_records;
+    c->table_pending = false;
+    BGP_TRY(c->d_rec.reserve((n + 1) * sizeof(bgp_record)));
+    BGP_TRY(c->d_seq_off.reserve((n + 1) * 8)); BGP_TRY(c->d_cigar_off.reserve((n + 1) * 8));
+    if (what & BGP_FETCH_SEQ) BGP_TRY(c->d_seq.reserve(c->sum_lseq + 16));
+    if (what & BGP_FETCH_QUAL) BGP_TRY(c->d_qual.reserve(c->sum_lseq + 16));
+    if (what & BGP_FETCH_CIGAR) BGP_TRY(c->d_cigar.reserve(c->sum_ncig * 4 + 16));
+    c->decoded_what |= what;
+    if (c->stream_len < 4) return BGP_OK;
+    FusedArgs a;
+    a.d.s = c->d_stream; a.d.stream_len = c->stream_len; a.d.rec = nullptr; a.d.seq_off = nullptr; a.d.cigar_off = nullptr; a.d.n = n;
+    a.d.seq = c->d_seq.as<uint8_t>(); a.d.qual = c->d_qual.as<uint8_t>(); a.d.cigar = c->d_cigar.as<uint32_t>();
+    a.entry = c->d_seg_entry.as<uint64_t>(); a.rec_base = c->d_seg_rec_base.as<uint64_t>(); a.seq_base = c->d_seg_seq_base.as<uint64_t>(); a.cig_base = c->d_seg_cig_base.as<uint64_t>();
+    a.side = c->d_seg_side.as<uint32_t>(); a.side_cap = c->side_cap; a.seg_bytes = c->seg_bytes; a.n_seg = c->n_seg; a.sum_lseq = c->sum_lseq; a.sum_ncig = c->sum_ncig;
+    a.rec_out = c->d_rec.as<bgp_record>(); a.seq_off_out = c->d_seq_off.as<uint64_t>(); a.cig_off_out = c->d_cigar_off.as<uint64_t>();
+    const unsigned blocks = (unsigned)((c->n_seg + G_SEG - 1) / G_SEG);
+    const bool S = what & BGP_FETCH_SEQ, Q = what & BGP_FETCH_QUAL, C = what & BGP_FETCH_CIGAR;
+    uint64_t alg = n * (36 + 32 + 16) + c->sum_ncig * 4;    // what k1_emit accounts for ...
+    if (S) alg += (c->sum_lseq + 1) / 2 + c->sum_lseq;      // ... plus what k2_unpack accounts for, minus the table read back
+    if (Q) alg += 2 * c->sum_lseq;
+    if (C) alg += 8 * c->sum_ncig;
+    {
+        TimedRegion t(c, what ? "k12_fused" : "k1_rows", alg);
+#define LAUNCH(s_, q_, c_) hipLaunchKernelGGL((k12_fused<s_, q_, c_>), dim3(blocks), dim3(256), 0, c->stream, a)
+        if (S && Q && C) LAUNCH(true, true, true);
+        else if (S && Q) LAUNCH(true, true, false);
+        else if (S && C) LAUNCH(true, false, true);
+        else if (Q && C) LAUNCH(false, true, true);
+        else if (S) LAUNCH(true, false, false);
+        else if (Q) LAUNCH(false, true, false);
+        else if (C) LAUNCH(false, false, true);
+        else LAUNCH(false, false, false);
+#undef LAUNCH
+        BGP_TRY(k1_finish_long_cigars(c));
+    }
     BGP_HIP(hipGetLastError());
     return BGP_OK;
 }

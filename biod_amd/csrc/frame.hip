@@ -23,12 +23,13 @@ namespace {
 constexpr uint64_t NONE = ~0ull;        // entry/end not known (speculation found nothing)
 constexpr uint64_t STOP = ~0ull - 1;    // chain is over (error upstream); segment holds no records
 constexpr uint32_t ST_LONGCIG = 1u << 16; // not an error: some record has more than LONG_CIGAR ops
-constexpr uint32_t LONG_CIGAR = 32;     // more ops than this: basesCovered is summed by a whole wave (k1_long_cigar)
+constexpr uint32_t LONG_CIGAR = BGP_LONG_CIGAR;
 
 struct FrameArgs {
     const uint8_t* s; uint64_t len; uint32_t seg_bytes; uint64_t n_seg; int32_t ref_bound;
     uint64_t* entry; uint64_t* fix; uint64_t* end; uint64_t* cnt; uint64_t* lseq; uint64_t* ncig; uint32_t* dirty; uint32_t* seg_err;
     uint32_t* status; /* [0] status bits, [1] dirty counter */
+    uint32_t* side; uint32_t side_cap;   // side[k * side_cap + j] = offset of segment k's j-th record relative to the segment start
 };
 
 __device__ __forceinline__ bool plausible(const uint8_t* s, uint64_t len, uint64_t o, int32_t ref_bound, uint32_t* bs_out) {
@@ -96,6 +97,7 @@ __global__ __launch_bounds__(256) void k0_chase(FrameArgs a) {
         const int32_t lseq = (int32_t)ld_u32(a.s + off + 20);
         const uint32_t l_name = bmn & 0xFFu, n_cig = fnc & 0xFFFFu;
         if (lseq < 0 || l_name == 0 || 32ull + l_name + 4ull * n_cig + (uint64_t)((lseq + 1) / 2) + (uint64_t)lseq > (uint64_t)bs) { err = ST_EINVAL; break; }
+        if (cnt < a.side_cap) a.side[k * a.side_cap + cnt] = (uint32_t)(off - k * (uint64_t)a.seg_bytes);   // 128 contiguous bytes per 32 records: the fused K1+K2 finds every record without a second chase
         ++cnt; ls += (uint64_t)lseq; nc += n_cig;
         long_seen |= n_cig > LONG_CIGAR;
         off += 4 + (uint64_t)bs;
@@ -211,6 +213,7 @@ int k0_frame(bgp_ctx* c) {
         BGP_HIP(hipMemsetAsync(c->d_seq_off.p, 0, 8, c->stream));
         BGP_HIP(hipMemsetAsync(c->d_cigar_off.p, 0, 8, c->stream));
         BGP_HIP(hipStreamSynchronize(c->stream));
+        c->table_pending = false; c->long_cigar = false;
         return BGP_OK;
     }
     // segment size: ~8 average records, from the first record's size (any value is correct)
@@ -240,6 +243,10 @@ int k0_frame(bgp_ctx* c) {
     a.cnt = c->d_seg_cnt.as<uint64_t>(); a.lseq = c->d_seg_lseq.as<uint64_t>(); a.ncig = c->d_seg_ncig.as<uint64_t>();
     a.dirty = c->d_seg_dirty.as<uint32_t>(); a.seg_err = a.dirty + n_seg;
     a.status = c->d_status.as<uint32_t>();
+    a.side_cap = seg / 36u + 2u;                     // a record is at least 36 bytes (block_size >= 32 is enforced by the chase)
+    BGP_TRY(c->d_seg_side.reserve((n_seg + 1) * (size_t)a.side_cap * 4));
+    a.side = c->d_seg_side.as<uint32_t>();
+    c->side_cap = a.side_cap;
 
     const unsigned lane_blocks = (unsigned)((n_seg + 255) / 256);
     {
@@ -275,19 +282,39 @@ int k0_frame(bgp_ctx* c) {
     BGP_TRY(scan_exclusive_u64(c, a.ncig, c->d_seg_cig_base.as<uint64_t>(), n_seg, &sc));
     c->n_records = n; c->sum_lseq = sl; c->sum_ncig = sc;
 
+    c->long_cigar = (bits & ST_LONGCIG) != 0;
+    c->table_pending = true;             // the record table is written by whoever needs it first: k1_table, or the fused K1+K2 when a decode follows
+    return BGP_OK;
+}
+
+// K1 alone: the record table and arena offsets (second, L2-warm chase).  Used when the table is needed
+// before -- or without -- a decode; bgp_decode_* right after bgp_flush takes the fused kernel in decode.hip.
+int k1_table(bgp_ctx* c) {
+    const uint64_t n = c->n_records, n_seg = c->n_seg, sl = c->sum_lseq, sc = c->sum_ncig;
+    c->table_pending = false;
+    if (c->stream_len < 4) return BGP_OK;
+    const unsigned lane_blocks = (unsigned)((n_seg + 255) / 256);
     BGP_TRY(c->d_rec.reserve((n + 1) * sizeof(bgp_record)));
     BGP_TRY(c->d_seq_off.reserve((n + 1) * 8)); BGP_TRY(c->d_cigar_off.reserve((n + 1) * 8));
     EmitArgs e;
-    e.s = c->d_stream; e.len = len; e.seg_bytes = seg; e.n_seg = n_seg; e.entry = a.entry;
+    e.s = c->d_stream; e.len = c->stream_len; e.seg_bytes = c->seg_bytes; e.n_seg = n_seg; e.entry = c->d_seg_entry.as<uint64_t>();
     e.rec_base = c->d_seg_rec_base.as<uint64_t>(); e.seq_base = c->d_seg_seq_base.as<uint64_t>(); e.cig_base = c->d_seg_cig_base.as<uint64_t>();
     e.rec = c->d_rec.as<bgp_record>(); e.seq_off = c->d_seq_off.as<uint64_t>(); e.cigar_off = c->d_cigar_off.as<uint64_t>();
     e.n_records = n; e.sum_lseq = sl; e.sum_ncig = sc;
     {
         TimedRegion t(c, "k1_emit", n * (36 + 32 + 16) + sc * 4);
         hipLaunchKernelGGL(k1_emit, dim3(lane_blocks), dim3(256), 0, c->stream, e);
-        if (bits & ST_LONGCIG)            // only streams that hold a long CIGAR pay for the extra pass
+        if (c->long_cigar)                // only streams that hold a long CIGAR pay for the extra pass
             hipLaunchKernelGGL(k1_long_cigar, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->d_stream, e.rec, n);
     }
+    BGP_HIP(hipGetLastError());
+    return BGP_OK;
+}
+
+// basesCovered() of long-CIGAR records after the fused K1+K2 wrote the table (same pass k1_table runs)
+int k1_finish_long_cigars(bgp_ctx* c) {
+    if (!c->long_cigar || !c->n_records) return BGP_OK;
+    hipLaunchKernelGGL(k1_long_cigar, dim3((unsigned)((c->n_records + 255) / 256)), dim3(256), 0, c->stream, c->d_stream, c->d_rec.as<bgp_record>(), c->n_records);
     BGP_HIP(hipGetLastError());
     return BGP_OK;
 }
