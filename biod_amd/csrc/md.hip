@@ -246,13 +246,19 @@ __device__ uint32_t dna_length(const uint8_t* s, const bgp_record& r, bool* bad,
 //        | MD_ERR (malformed aux data: EINVAL if ever fetched) | MD_BAD (range stalls on an empty query)
 //   mb : max end_position over the reads of EARLIER position groups of the same reference (0 if none), so
 //        "_prev_coverage == 0" at the read's column (pileup.d:565,625) is  mb < pos.
-struct MdRow { uint32_t pos, end, lf, mb; };
+struct alignas(16) MdRow { uint32_t pos, end, lf, mb; };      // one dwordx4 / ds_read_b128 per row
 constexpr uint32_t MD_BAD = 1u << 31, MD_ERR = 1u << 30, MD_COV = 1u << 29, MD_GST = 1u << 28, MD_LMASK = (1u << 28) - 1;
 
-__global__ __launch_bounds__(256) void k6_prep(const uint8_t* s, const bgp_record* rec, const uint64_t* pmax_end, const uint64_t* pmax_pos, uint64_t n, MdRow* rows) {
+__global__ __launch_bounds__(256) void k6_prep(const uint8_t* s, const bgp_record* rec, const uint64_t* pmax_end, const uint64_t* pmax_pos, uint64_t n, MdRow* rows, uint32_t* bmax) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bgp_record r{};
+    if (i < n) r = rec[i];
+    {   // largest end_position of every 64 consecutive rows: lets k6_succ step over stretches in which nothing ends beyond a chunk
+        uint32_t m = (i < n && r.end_pos != r.pos) ? (uint32_t)r.end_pos : 0u;
+        for (int d = 32; d >= 1; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d, 64));
+        if ((threadIdx.x & 63) == 0 && i < n) bmax[i >> 6] = m;
+    }
     if (i >= n) return;
-    const bgp_record r = rec[i];
     MdRow o{(uint32_t)r.pos, (uint32_t)r.end_pos, 0u, 0u};
     if (r.end_pos != r.pos) {
         bool bad, err;
@@ -479,23 +485,118 @@ __device__ __forceinline__ bool arrival_irregular(const MdRow& r, uint32_t F) {
     return !((uint64_t)F + 1 < (uint64_t)r.pos + L && F < r.end);
 }
 
-__global__ __launch_bounds__(256) void k6_succ(const MdRow* rows, uint64_t n, const ParRun* pr, uint32_t n_runs, int skip_zero, Succ* succ) {
-    const uint64_t P = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (P >= n) return;
-    const MdRow rp = rows[P];
-    if (!(rp.lf & MD_COV)) { succ[P] = Succ{SX_NONE, 0u}; return; }
-    const ParRun R = pr[par_run_of(pr, n_runs, P)];
-    if (P < R.first || P >= R.endrec) { succ[P] = Succ{SX_NONE, 0u}; return; }
+// The same successor, computed by a whole wave (64 rows per step, ballots + one arg-max): for the few providers whose
+// window is long -- a read with a 5 kb N skip has chunk_end 5 kb away and must look at a thousand rows before one
+// ends beyond it.  Left to its own lane such a read would hold its 63 neighbours for a thousand iterations.
+__device__ Succ succ_coop(const MdRow* rows, const ParRun& R, uint64_t P, const MdRow& rp, int skip_zero, int lane) {
     const uint32_t CE = rp.end, A = rp.pos + (rp.lf & MD_LMASK) - 1u;
     bool found = false, flag = false;
     uint32_t F = 0, best = SX_END, best_end = 0, allmax = 0;
     MdRow bestrow{0, 0, 0, 0};
-    uint32_t out_n = SX_END, out_f = 0;
-    uint64_t j = P + 1;
+    auto wmax32 = [](uint32_t v) { for (int d = 32; d >= 1; d >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, d, 64)); return v; };
+    auto bcast_row = [](const MdRow& r, int l) { return MdRow{(uint32_t)__shfl((int)r.pos, l, 64), (uint32_t)__shfl((int)r.end, l, 64), (uint32_t)__shfl((int)r.lf, l, 64), (uint32_t)__shfl((int)r.mb, l, 64)}; };
+    uint64_t jb = P + 1;
     int budget = SUCC_CAP;
-    for (; j < R.endrec; ++j) {
-        if (--budget < 0) { flag = true; break; }
-        const MdRow r = rows[j];
+    for (; jb < R.endrec; jb += 64) {
+        if ((budget -= 64) < 0) { flag = true; break; }
+        const uint64_t idx = jb + lane;
+        const MdRow r = idx < R.endrec ? rows[idx] : MdRow{0, 0, 0, 0};
+        const bool cov = idx < R.endrec && (r.lf & MD_COV);
+        const bool hz = r.mb < r.pos;
+        const bool isg = cov && skip_zero && (r.lf & MD_GST) && hz;
+        const bool cand = cov && (r.pos <= CE || hz) && r.end > CE;
+        int from = 0;
+        int gap_at = 64;
+        if (!found) {
+            const uint64_t mc = __ballot(cand), mg = __ballot(isg);
+            const int fc = mc ? __ffsll((unsigned long long)mc) - 1 : 64, fg = mg ? __ffsll((unsigned long long)mg) - 1 : 64;
+            if (fg < 64 && fg <= fc) gap_at = fg;
+            else if (fc == 64) { allmax = max(allmax, wmax32(cov ? r.end : 0u)); continue; }
+            else {
+                found = true; from = fc;
+                const uint32_t pc = (uint32_t)__shfl((int)r.pos, fc, 64);
+                F = max(A, pc);
+                allmax = max(allmax, wmax32(cov && lane < fc ? r.end : 0u));
+            }
+        }
+        int fb = 64;
+        if (gap_at == 64) {
+            const uint64_t mb_ = __ballot(cov && lane >= from && r.pos > F);
+            fb = mb_ ? __ffsll((unsigned long long)mb_) - 1 : 64;
+            const uint64_t mg2 = __ballot(isg && lane >= from && lane <= fb && (r.pos <= F || r.mb <= F));
+            if (mg2) gap_at = __ffsll((unsigned long long)mg2) - 1;
+        }
+        const int upto = min(gap_at, fb);                                   // lanes [from, upto) are inside the window
+        if (found) {
+            const bool in_w = cov && lane >= from && lane < upto;
+            allmax = max(allmax, wmax32(in_w ? r.end : 0u));
+            const bool c2 = in_w && cand;
+            const uint64_t key = wave_max_u64(c2 ? ((uint64_t)r.end << 32) | (uint32_t)(63 - lane) : 0ull);
+            if (key && (uint32_t)(key >> 32) > best_end) { const int wl = 63 - (int)(key & 63u); best = (uint32_t)(jb + wl); best_end = (uint32_t)(key >> 32); bestrow = bcast_row(r, wl); }
+        }
+        if (gap_at < 64) {
+            // initNewReference on the gap's position group: first arg-max of end_position
+            const MdRow g0 = bcast_row(r, gap_at);
+            uint32_t g = (uint32_t)(jb + gap_at), ge = g0.end; MdRow gr = g0;
+            for (uint64_t kb = jb + gap_at + 1; kb < R.endrec; kb += 64) {
+                if ((budget -= 64) < 0) { flag = true; break; }
+                const uint64_t ik = kb + lane;
+                const MdRow q = ik < R.endrec ? rows[ik] : MdRow{0, 0, 0, 0};
+                const bool qc = ik < R.endrec && (q.lf & MD_COV);
+                const uint64_t stop = __ballot(qc && q.pos != g0.pos);
+                const int fs = stop ? __ffsll((unsigned long long)stop) - 1 : 64;
+                const bool ing = qc && lane < fs;
+                const uint64_t key = wave_max_u64(ing ? ((uint64_t)q.end << 32) | (uint32_t)(63 - lane) : 0ull);
+                if (key && (uint32_t)(key >> 32) > ge) { const int wl = 63 - (int)(key & 63u); g = (uint32_t)(kb + wl); ge = (uint32_t)(key >> 32); gr = bcast_row(q, wl); }
+                if (fs < 64) break;
+            }
+            flag |= arrival_irregular(gr, g0.pos) || gr.pos != g0.pos;
+            return Succ{g, g0.pos | (flag ? SX_FLAG : 0u)};
+        }
+        if (fb < 64) {                                                      // FETCH at F
+            flag |= best == SX_END || arrival_irregular(bestrow, F) || allmax > best_end;
+            return Succ{best, F | (flag ? SX_FLAG : 0u)};
+        }
+    }
+    if (found && F < R.run_end && !(flag && best == SX_END)) {              // the run's reads are exhausted: FETCH only if it comes before the end of coverage
+        flag |= best == SX_END || arrival_irregular(bestrow, F) || allmax > best_end;
+        return Succ{best, F | (flag ? SX_FLAG : 0u)};
+    }
+    return Succ{SX_END, flag ? SX_FLAG : 0u};
+}
+
+__global__ __launch_bounds__(256) void k6_succ(const MdRow* rows, const uint32_t* bmax, uint64_t n, const ParRun* pr, uint32_t n_runs, int skip_zero, Succ* succ) {
+    // the window a lane scans is the ~50 rows behind its own: the block's 256 rows + 256 more sit in LDS (adjacent
+    // lanes read adjacent rows, conflict free); a lane that needs more than LANE_CAP rows hands its read to the wave
+    constexpr int STAGE = 512, LANE_CAP = 128;
+    __shared__ MdRow s_rows[STAGE];
+    const uint64_t base = (uint64_t)blockIdx.x * blockDim.x;
+    for (int t = threadIdx.x; t < STAGE; t += 256) s_rows[t] = base + t < n ? rows[base + t] : MdRow{0, 0, 0, 0};
+    __syncthreads();
+    auto row_at = [&](uint64_t j) -> MdRow { const uint64_t d = j - base; return d < (uint64_t)STAGE ? s_rows[d] : rows[j]; };
+    const int lane = threadIdx.x & 63;
+    const uint64_t P = base + threadIdx.x;
+    const MdRow rp = s_rows[threadIdx.x];
+    ParRun R{0, 0, 0, 0, 0, 0};
+    bool node = P < n && (rp.lf & MD_COV);
+    if (node) { R = pr[par_run_of(pr, n_runs, P)]; node = P >= R.first && P < R.endrec; }
+    const uint32_t CE = rp.end, A = rp.pos + (rp.lf & MD_LMASK) - 1u;
+    bool found = false, flag = false, deferred = false, done = !node;
+    uint32_t F = 0, best = SX_END, best_end = 0, allmax = 0;
+    MdRow bestrow{0, 0, 0, 0};
+    uint32_t out_n = node ? SX_END : SX_NONE, out_f = 0;
+    uint64_t j = P + 1;
+    int budget = LANE_CAP;
+    for (; !done && j < R.endrec; ++j) {
+        if (--budget < 0) { deferred = true; done = true; break; }
+        if (!found && (j & 63) == 0) {
+            // nothing a row must be looked at for -- a candidate, a position group behind uncovered ground, an end beyond
+            // the winner's -- exists in a block of 64 rows none of which ends beyond this read (a read with a 5 kb N skip
+            // would otherwise walk a thousand rows, and hold its 63 neighbours for as long)
+            while (j + 64 <= R.endrec && bmax[j >> 6] <= CE) j += 64;
+            if (j >= R.endrec) break;
+        }
+        const MdRow r = row_at(j);
         if (!(r.lf & MD_COV)) continue;
         const bool hz = r.mb < r.pos;
         const bool isg = skip_zero && (r.lf & MD_GST) && hz;
@@ -505,15 +606,16 @@ __global__ __launch_bounds__(256) void k6_succ(const MdRow* rows, uint64_t n, co
             // initNewReference on this position group: first arg-max of end_position (every read of it passes add())
             uint32_t g = (uint32_t)j, ge = r.end; MdRow gr = r;
             for (uint64_t k = j + 1; k < R.endrec; ++k) {
-                if (--budget < 0) { flag = true; break; }
-                const MdRow q = rows[k];
+                if (--budget < 0) { deferred = true; break; }
+                const MdRow q = row_at(k);
                 if (!(q.lf & MD_COV)) continue;
                 if (q.pos != r.pos) break;
                 if (q.end > ge) { g = (uint32_t)k; ge = q.end; gr = q; }
             }
             out_n = g; out_f = r.pos;
             flag |= arrival_irregular(gr, r.pos) || gr.pos != r.pos;
-            goto done;
+            done = true;
+            break;
         }
         if (!found) {
             if (!cand) { allmax = max(allmax, r.end); continue; }
@@ -523,12 +625,22 @@ __global__ __launch_bounds__(256) void k6_succ(const MdRow* rows, uint64_t n, co
         allmax = max(allmax, r.end);
         if (cand && r.end > best_end) { best = (uint32_t)j; best_end = r.end; bestrow = r; }
     }
-    if (found && (j < R.endrec || F < R.run_end) && !(flag && best == SX_END)) {   // FETCH at F (pileup.d:627-652); at the run's end only if it comes before the end of coverage
+    if (!done && found && (j < R.endrec || F < R.run_end)) {                // FETCH at F (pileup.d:627-652); at the run's end only if it comes before the end of coverage
         out_n = best; out_f = F;
         flag |= best == SX_END || arrival_irregular(bestrow, F) || allmax > best_end;
     }
-done:
-    succ[P] = Succ{out_n, out_f | (flag ? SX_FLAG : 0u)};
+    Succ res{out_n, out_f | (flag ? SX_FLAG : 0u)};
+    // long windows: one read at a time, the whole wave on it
+    for (uint64_t dm = __ballot(deferred); dm; dm &= dm - 1) {
+        const int src = __ffsll((unsigned long long)dm) - 1;
+        const uint64_t Ps = base + (threadIdx.x & ~63u) + src;
+        const MdRow rs = s_rows[(threadIdx.x & ~63u) + src];
+        ParRun Rs;
+        Rs.first = __shfl(R.first, src, 64); Rs.endrec = __shfl(R.endrec, src, 64); Rs.run_end = (uint32_t)__shfl((int)R.run_end, src, 64); Rs.ce_in = 0; Rs.active = 0; Rs.pad = 0;
+        const Succ c = succ_coop(rows, Rs, Ps, rs, skip_zero, lane);
+        if (lane == src) res = c;
+    }
+    if (P < n) succ[P] = res;
 }
 
 // exit(P): the first provider behind P's segment on the chain from P (or SX_END), its fetch column, and the OR of
@@ -684,10 +796,11 @@ static int k6_rows(bgp_ctx* c) {
     if (c->md_rows_ready) return BGP_OK;
     const uint64_t n = c->n_records;
     BGP_TRY(c->d_md_row.reserve((n + 1) * sizeof(MdRow)));
+    BGP_TRY(c->d_md_bmax.reserve((n / 64 + 2) * 4));
     if (n) {
         TimedRegion t(c, "k6_prep", n * (32 + sizeof(MdRow)));
         hipLaunchKernelGGL(k6_prep, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->d_stream, c->d_rec.as<bgp_record>(),
-                           c->d_pmax_end.as<uint64_t>(), c->d_pmax_pos.as<uint64_t>(), n, c->d_md_row.as<MdRow>());
+                           c->d_pmax_end.as<uint64_t>(), c->d_pmax_pos.as<uint64_t>(), n, c->d_md_row.as<MdRow>(), c->d_md_bmax.as<uint32_t>());
         BGP_HIP(hipGetLastError());
     }
     c->md_rows_ready = true;
@@ -761,7 +874,7 @@ int k6_reference_bases(bgp_ctx* c, int skip_zero, uint32_t run_first, uint32_t r
         BGP_HIP(hipMemcpyAsync(st + off_er, er.data(), sizeof(EmitRun) * nr, hipMemcpyHostToDevice, c->stream));
         {
             TimedRegion t(c, "k6_succ", n * (sizeof(MdRow) + sizeof(Succ)));
-            hipLaunchKernelGGL(k6_succ, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->d_md_row.as<MdRow>(), n, (const ParRun*)(st + off_pr), nr, skip_zero, c->d_md_succ.as<Succ>());
+            hipLaunchKernelGGL(k6_succ, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->d_md_row.as<MdRow>(), c->d_md_bmax.as<uint32_t>(), n, (const ParRun*)(st + off_pr), nr, skip_zero, c->d_md_succ.as<Succ>());
         }
         {
             TimedRegion t(c, "k6_exit", n * 2 * sizeof(Succ));
