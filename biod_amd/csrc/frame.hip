@@ -102,9 +102,9 @@ __global__ __launch_bounds__(256) void k0_chase(FrameArgs a) {
         long_seen |= n_cig > LONG_CIGAR;
         off += 4 + (uint64_t)bs;
     }
-    if (long_seen) atomicOr(&a.status[0], ST_LONGCIG);
     a.end[k] = err ? STOP : off;
-    a.cnt[k] = cnt; a.lseq[k] = ls; a.ncig[k] = nc; a.seg_err[k] = err;
+    // per segment, not a sticky global bit: a chase from a wrong guess reads garbage and must not leave a trace
+    a.cnt[k] = cnt; a.lseq[k] = ls; a.ncig[k] = nc; a.seg_err[k] = err | (long_seen ? ST_LONGCIG : 0u);
 }
 
 // A link k is consistent when entry[k] == end[k-1].  A broken link is repaired only when the
@@ -220,9 +220,10 @@ int k0_frame(bgp_ctx* c) {
     uint32_t bs0 = 0;
     BGP_HIP(hipMemcpyAsync(&bs0, c->d_stream, 4, hipMemcpyDeviceToHost, c->stream));
     BGP_HIP(hipStreamSynchronize(c->stream));
-    // ~32 records per segment: k0_guess costs one wave per segment, the chase is a per-lane serial
-    // chain per segment (measured on cfg3: 8 -> 32 records/segment cuts the guess 4x, chase unchanged)
-    const uint64_t recs_per_seg = getenv("BGP_SEG_RECORDS") ? (uint64_t)atoi(getenv("BGP_SEG_RECORDS")) : 32ull;
+    // ~64 records per segment: k0_guess costs one wave per segment, the chase is a per-lane serial chain per
+    // segment that is bound by line fetches, not by its length (measured on cfg3, guess / chase / step: 8 records
+    // 7.4 / 1.2 ms; 32: 1.87 / 1.58 / 43.8 ms; 64: 0.94 / 1.60 / 42.5 ms; 128: 0.48 / 1.66 / 43.0 ms)
+    const uint64_t recs_per_seg = getenv("BGP_SEG_RECORDS") ? (uint64_t)atoi(getenv("BGP_SEG_RECORDS")) : 64ull;
     uint64_t want = recs_per_seg * (4ull + (bs0 & 0x3FFFFFFFu));
     uint32_t seg = pow2_ceil(want);
     if (seg < 4096u) seg = 4096u;
