@@ -38,7 +38,7 @@ namespace {
 #ifndef BGP_K4_W
 #define BGP_K4_W 4096
 #define BGP_K4_T 1024
-#define BGP_K4_HB 1024
+#define BGP_K4_HB 512
 #endif
 constexpr int W = BGP_K4_W;            // reference positions per workgroup (power of two)
 constexpr int HB = BGP_K4_HB;          // depth-histogram bins kept in LDS
@@ -337,9 +337,9 @@ __global__ __launch_bounds__(256) void k4_ck_build(const uint8_t* s, const bgp_r
 constexpr int DELD = 5 * W;            // word offsets inside the tile
 constexpr int NST = 6 * W + 4;
 constexpr int HIST = 7 * W + 4;
-constexpr int LIST = HIST + HB;
-constexpr int LCAP = W;
-constexpr int SLIST = LIST + LCAP;       // second list: reads for the wave-cooperative paths
+constexpr int LIST = (HIST + HB + 3) & ~3;  // 16-byte entries: (position, record index, cigar offset low, n_cigar | min(l_seq,255) << 16 | cigar offset high << 24)
+constexpr int LCAP = 2 * K4_T;           // a scan round adds at most K4_T entries
+constexpr int SLIST = LIST + 4 * LCAP;   // second list: reads for the wave-cooperative paths (record indices)
 constexpr int LDS_PAD = 8;               // words in front of the tile (see k4_tile's hot loop)
 constexpr int LDS_WORDS = SLIST + LCAP + LDS_PAD;
 
@@ -518,7 +518,7 @@ __global__ __launch_bounds__(K4_T) void k4_tile(K4Args a) {
     const uint64_t i_lo = tb.i_lo, i_hi = tb.i_hi;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    uint32_t* list = lds + LIST;
+    uint4* list = reinterpret_cast<uint4*>(lds + LIST);
     uint32_t* slist = lds + SLIST;
 
     for (uint64_t scan = i_lo; scan < i_hi;) {
@@ -527,12 +527,14 @@ __global__ __launch_bounds__(K4_T) void k4_tile(K4Args a) {
         // ---- scan: compact the reads that overlap the window
         for (bool more = true; more;) {
             // four rounds of candidate rows are requested before the first is looked at: one HBM round trip, not four
-            uint4 xs[4];
+            // (both halves of the row: the list entry then carries what the process phase needs to address the read's
+            // CIGAR and SEQ, which saves that phase a dependent round trip through the record table)
+            uint4 xs[4], ys[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const uint64_t i = scan + (uint64_t)r * K4_T + threadIdx.x;
-                xs[r] = make_uint4(0, 0, 0, 0);
-                if (i < i_hi) xs[r] = *reinterpret_cast<const uint4*>(a.rec + i);   // ref_id, pos, end_pos, bin_mq_nl
+                xs[r] = make_uint4(0, 0, 0, 0); ys[r] = make_uint4(0, 0, 0, 0);
+                if (i < i_hi) { const uint4* rp = reinterpret_cast<const uint4*>(a.rec + i); xs[r] = rp[0]; ys[r] = rp[1]; }   // ref_id,pos,end_pos,bin_mq_nl | flag_nc,l_seq,rec_off
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -545,7 +547,12 @@ __global__ __launch_bounds__(K4_T) void k4_tile(K4Args a) {
                 uint32_t slot = 0;
                 if (lane == 0 && m) slot = atomicAdd(&s_n, (uint32_t)__popcll(m));
                 slot = rl(slot, 0);
-                if (valid) list[slot + __popcll(m & ((1ull << lane) - 1))] = (uint32_t)(i - i_lo);
+                if (valid) {
+                    const uint4 y = ys[r];
+                    const uint64_t cg = (((uint64_t)y.w << 32) | y.z) + 36 + (x.w & 0xFFu);      // read.d:988-990
+                    list[slot + __popcll(m & ((1ull << lane) - 1))] =
+                        make_uint4(x.y, (uint32_t)(i - i_lo), (uint32_t)cg, (y.x & 0xFFFFu) | (min(y.y, 255u) << 16) | ((uint32_t)(cg >> 32) << 24));
+                }
                 scan += K4_T;
                 __syncthreads();
                 if (scan >= i_hi || s_n > LCAP - K4_T) more = false;
@@ -565,11 +572,11 @@ __global__ __launch_bounds__(K4_T) void k4_tile(K4Args a) {
             uint4 w0 = {}, w1 = {}, w2 = {}, w3 = {}, w4 = {};
             bool fast = false;
             uint32_t qsum = 0;
+            uint32_t ridx = 0;
             if (have) {
-                const uint4* rp = reinterpret_cast<const uint4*>(a.rec + i_lo + list[b0 + lane]);
-                const uint4 x = rp[0], y = rp[1];             // ref_id,pos,end_pos,bin_mq_nl | flag_nc,l_seq,rec_off
-                pos = x.y; covered = x.z - x.y; n_cig = y.x & 0xFFFFu; l_seq = y.y;
-                cig_off = (((uint64_t)y.w << 32) | y.z) + 36 + (x.w & 0xFFu);
+                const uint4 e = list[b0 + lane];
+                pos = e.x; ridx = e.y; n_cig = e.w & 0xFFFFu; l_seq = (e.w >> 16) & 0xFFu;        // l_seq saturates at 255: not a fast read then
+                cig_off = ((uint64_t)(e.w >> 24) << 32) | e.z;
                 const uint64_t seq_off = cig_off + 4ull * n_cig;
                 fast = n_cig >= 1 && n_cig <= 4 && l_seq <= FAST_LSEQ && seq_off + 80 <= a.stream_len;
                 if (fast) {
@@ -589,7 +596,7 @@ __global__ __launch_bounds__(K4_T) void k4_tile(K4Args a) {
                         const uint32_t op = k == 0 ? o0 : k == 1 ? o1 : k == 2 ? o2 : o3;
                         if ((uint32_t)k < n_cig) {
                             const uint32_t len = op >> 4;
-                            if (cig_rc(op)) { if (len == 0 || (!seen_ref && (op & 15u) == 3u)) ok = false; seen_ref = true; }
+                            if (cig_rc(op)) { if (len == 0 || (!seen_ref && (op & 15u) == 3u)) ok = false; seen_ref = true; covered += len; }   // basesCovered, read.d:255-262
                             if (cig_qc(op)) qsum += len;
                         }
                     }
@@ -704,7 +711,7 @@ __global__ __launch_bounds__(K4_T) void k4_tile(K4Args a) {
                 uint32_t slot = 0;
                 if (lane == 0) slot = atomicAdd(&s_nslow, (uint32_t)__popcll(sm));
                 slot = rl(slot, 0);
-                if (is_slow) slist[slot + __popcll(sm & ((1ull << lane) - 1))] = list[b0 + lane];
+                if (is_slow) slist[slot + __popcll(sm & ((1ull << lane) - 1))] = ridx;
             }
         }
         PH(1);

@@ -39,6 +39,17 @@ template <int MODE> __global__ __launch_bounds__(T) void k(uint32_t* out, int re
                     if (col < W) atomicAdd(&lds[cls * W + col], 1u);
                 }
             }
+        } else if (MODE == 5) {                // rotated inside each dword (8 bases): bank mod 8 = (lane + b) mod 8
+            for (uint32_t q0 = 0; q0 < 160; q0 += 8) {
+                const uint32_t rot = (lane - pos - q0) & 7u;
+#pragma unroll
+                for (uint32_t b = 0; b < 8; ++b) {
+                    const uint32_t q = q0 + ((b + rot) & 7u);
+                    const uint32_t cls = (seed >> ((q & 15) * 2)) & 3u;
+                    const uint32_t col = pos + q;
+                    if (col < W) atomicAdd(&lds[cls * W + col], 1u);
+                }
+            }
         } else if (MODE == 3) {                // ideal: lane-consecutive words
 #pragma unroll 8
             for (uint32_t q = 0; q < 160; ++q) {
@@ -83,6 +94,7 @@ int main() {
     run<2>("arithmetic only", out);
     run<0>("uniform q (K4 today)", out);
     run<1>("rotated, 2 lanes per bank", out);
+    run<5>("rotated inside a dword (mod 8)", out);
     run<3>("lane-consecutive words", out);
     run<4>("one bank for all lanes", out);
     return 0;
