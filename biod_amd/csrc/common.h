@@ -122,7 +122,7 @@ struct bgp_ctx {
 
     // pileup (K3/K4)
     DevBuf d_pmax_end, d_pmax_pos;                    // prefix maxima (u64 keys)
-    DevBuf d_runs, d_columns, d_depth_hist, d_pstats, d_tiles, d_ck_off, d_ck;
+    DevBuf d_runs, d_columns, d_depth_hist, d_pstats, d_tiles, d_ck_off, d_ck, d_deep;
     std::vector<bgp_run> runs;
     bgp_pileup_info pinfo{};
     bool piled = false;

@@ -38,14 +38,20 @@ namespace {
 #ifndef BGP_K4_W
 #define BGP_K4_W 4096
 #define BGP_K4_T 1024
+#define BGP_K4_T16 512
 #define BGP_K4_HB 512
 #endif
 constexpr int W = BGP_K4_W;            // reference positions per workgroup (power of two)
 constexpr int HB = BGP_K4_HB;          // depth-histogram bins kept in LDS
-constexpr int K4_T = BGP_K4_T;
+constexpr int K4_T = BGP_K4_T;         // threads of a workgroup on the 32-bit layout
+constexpr int K4_T16 = BGP_K4_T16;     // ... on the 16-bit layout (two workgroups per CU)
 constexpr int CLS_SHIFT = W == 2048 ? 13 : W == 1024 ? 12 : W == 512 ? 11 : 14;   // log2(bytes of one class array)
 static_assert((1 << CLS_SHIFT) == W * 4, "W must be 512, 1024, 2048 or 4096");
 constexpr uint32_t MAX_RUNS = 1u << 16;
+#ifndef BGP_DEEP_WINDOW
+#define BGP_DEEP_WINDOW 65535
+#endif
+constexpr uint32_t DEEP_WINDOW = BGP_DEEP_WINDOW; // candidate records from which a window takes K4's 32-bit LDS layout (0: every window, for tests)
 
 
 struct RunDev { int32_t ref_id; uint32_t pad; uint64_t first_record, end_record, start_pos, end_pos, column_base, tile_base; };
@@ -197,7 +203,8 @@ struct K4Args {
     const uint8_t* s; const bgp_record* rec; const uint64_t* pmax_end; const uint64_t* pmax_pos;
     const RunDev* runs; uint32_t n_runs; uint64_t n_tiles; uint64_t stream_len;
     bgp_column* cols; unsigned long long* hist; unsigned long long* pstats; /* [0] n_columns [1] sum_cov [2] max_cov */
-    uint32_t* status; const struct TileB* tiles; unsigned long long* tile_stats; unsigned long long* phases;   // phases: debug build only (BGP_K4_PHASES)
+    uint32_t* status; const struct TileB* tiles; unsigned long long* tile_stats;
+    const uint32_t* deep; const uint32_t* n_deep;       // windows with too many candidate records for the 16-bit layout
     const uint64_t* ck_off; const struct Ckpt* ck;      // long-read checkpoints (null when the stream has no long read)
 };
 
@@ -212,8 +219,8 @@ __device__ __forceinline__ uint32_t base_class(uint32_t code) {   // nt16 code -
 
 // One thread per window: the record range that can touch it (exact halo).  Done here, massively
 // parallel, because the two ~25-step dependent binary searches are pure latency.
-struct TileB { uint64_t i_lo, i_hi, col_out; uint32_t T0, Tend, run_start, pad; };   // everything a window needs in one 40-byte (scalar) load
-__global__ __launch_bounds__(256) void k4_bounds(const uint64_t* pmax_end, const uint64_t* pmax_pos, const RunDev* runs, uint32_t n_runs, uint64_t n_tiles, TileB* out) {
+struct TileB { uint64_t i_lo, i_hi, col_out; uint32_t T0, Tend, run_start, pad; };   // everything a window needs in one 40-byte (scalar) load; pad = 1: deep window
+__global__ __launch_bounds__(256) void k4_bounds(const uint64_t* pmax_end, const uint64_t* pmax_pos, const RunDev* runs, uint32_t n_runs, uint64_t n_tiles, TileB* out, uint32_t* deep, uint32_t* n_deep) {
     const uint64_t tile = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (tile >= n_tiles) return;
     uint32_t lo_r = 0, hi_r = n_runs;
@@ -225,7 +232,9 @@ __global__ __launch_bounds__(256) void k4_bounds(const uint64_t* pmax_end, const
     TileB b;
     b.i_lo = lower_bound_gt(pmax_end, run.first_record, run.end_record, rk | T0);             // first record whose running max end_position exceeds T0
     b.i_hi = lower_bound_gt(pmax_pos, run.first_record, run.end_record, rk | (Tend - 1));     // first record starting at/after Tend
-    b.col_out = run.column_base + (T0 - run.start_pos); b.T0 = T0; b.Tend = Tend; b.run_start = (uint32_t)run.start_pos; b.pad = 0;
+    b.col_out = run.column_base + (T0 - run.start_pos); b.T0 = T0; b.Tend = Tend; b.run_start = (uint32_t)run.start_pos;
+    b.pad = b.i_hi - b.i_lo >= DEEP_WINDOW ? 1u : 0u;     // a count per position and class is bounded by the candidates: 16 bits are enough below this
+    if (b.pad) deep[atomicAdd(n_deep, 1u)] = (uint32_t)tile;
     out[tile] = b;
 }
 
@@ -334,14 +343,40 @@ __global__ __launch_bounds__(256) void k4_ck_build(const uint8_t* s, const bgp_r
 // wave-cooperative path below, which implements the closed form of pileup.d:175-222 in full generality
 // with lanes along the read.
 
-constexpr int DELD = 5 * W;            // word offsets inside the tile
-constexpr int NST = 6 * W + 4;
-constexpr int HIST = 7 * W + 4;
-constexpr int LIST = (HIST + HB + 3) & ~3;  // 16-byte entries: (position, record index, cigar offset low, n_cigar | min(l_seq,255) << 16 | cigar offset high << 24)
-constexpr int LCAP = 2 * K4_T;           // a scan round adds at most K4_T entries
-constexpr int SLIST = LIST + 4 * LCAP;   // second list: reads for the wave-cooperative paths (record indices)
 constexpr int LDS_PAD = 8;               // words in front of the tile (see k4_tile's hot loop)
-constexpr int LDS_WORDS = SLIST + LCAP + LDS_PAD;
+// Two layouts of the window in LDS.  P16: the five class counters and n_starting_here are 16 bits wide, two
+// positions to a word (an add is 1 << 16 * (position & 1); a half never carries because a window whose candidate
+// range holds 65 535 records or more is not given to this layout) -- half the LDS, so two workgroups share a CU and
+// one window's memory waits overlap the other's arithmetic.  P32: plain 32-bit counters, for those deep windows.
+template <bool P16_, int T_> struct Lay {
+    static constexpr bool P16 = P16_;
+    static constexpr int T = T_;
+    static constexpr int CNT = P16_ ? 5 * W / 2 : 5 * W;          // word offsets inside the tile
+    static constexpr int DELD = CNT;
+    static constexpr int NST = DELD + W + 4;
+    static constexpr int HIST = NST + (P16_ ? W / 2 : W);
+    static constexpr int LIST = HIST + HB;
+    static constexpr int LCAP = 2 * T_;                            // a scan round adds at most T entries
+    static constexpr int SLIST = LIST + LCAP;                      // second list: reads for the wave-cooperative paths
+    static constexpr int WORDS = SLIST + LCAP + LDS_PAD;
+    static constexpr int CSH = P16_ ? CLS_SHIFT - 1 : CLS_SHIFT;   // log2(bytes of one class array)
+    __device__ __forceinline__ static void add_cls(uint32_t* lds, uint32_t cls, uint32_t col) {
+        const uint32_t i = cls * W + col;
+        if (P16_) atomicAdd(&lds[i >> 1], 1u << ((i & 1u) * 16)); else atomicAdd(&lds[i], 1u);
+    }
+    __device__ __forceinline__ static void add_nst(uint32_t* lds, uint32_t col) {
+        if (P16_) atomicAdd(&lds[NST + (col >> 1)], 1u << ((col & 1u) * 16)); else atomicAdd(&lds[NST + col], 1u);
+    }
+    __device__ __forceinline__ static uint32_t get_cls(const uint32_t* lds, uint32_t cls, uint32_t col) {
+        const uint32_t i = cls * W + col;
+        return P16_ ? (lds[i >> 1] >> ((i & 1u) * 16)) & 0xFFFFu : lds[i];
+    }
+    __device__ __forceinline__ static uint32_t get_nst(const uint32_t* lds, uint32_t col) {
+        return P16_ ? (lds[NST + (col >> 1)] >> ((col & 1u) * 16)) & 0xFFFFu : lds[NST + col];
+    }
+};
+using L16 = Lay<true, K4_T16>;
+using L32 = Lay<false, K4_T>;
 
 __device__ __forceinline__ uint32_t rl(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
 
@@ -358,7 +393,7 @@ __device__ __forceinline__ uint32_t load_seq_words(const uint8_t* s, uint64_t st
 
 // General path: one read against the window, executed by a whole wave with lanes along the read.
 // All arguments are wave-uniform.
-__device__ __forceinline__ void pile_read_coop(const K4Args& a, uint32_t* lds, uint32_t T0, uint32_t Tend, int lane,
+template <class L> __device__ __forceinline__ void pile_read_coop(const K4Args& a, uint32_t* lds, uint32_t T0, uint32_t Tend, int lane,
                                                uint32_t pos, uint32_t covered, uint32_t n_cig, uint32_t l_seq, uint64_t cig_off) {
     const uint64_t seq_off = cig_off + 4ull * n_cig;
     const uint32_t seq_bytes = (l_seq + 1) / 2;
@@ -395,12 +430,12 @@ __device__ __forceinline__ void pile_read_coop(const K4Args& a, uint32_t* lds, u
                             const uint32_t byte = (wv >> (((q >> 1) & 3u) * 8)) & 0xFFu;
                             cls = base_class((q & 1u) ? (byte & 0xFu) : (byte >> 4));   // read.d:368-373
                         } else atomicOr(a.status, ST_ESEQ);
-                        atomicAdd(&lds[cls * W + (pos + r0 + lane - T0)], 1u);
+                        L::add_cls(lds, cls, pos + r0 + lane - T0);
                     }
                 }
             } else if (lane == 0) {                                       // D, N : '-' over [lo, hi), pileup.d:119-121
-                atomicAdd(&lds[DELD + (pos + lo - T0)], 1u);
-                atomicAdd(&lds[DELD + (pos + hi - T0)], 0xFFFFFFFFu);
+                atomicAdd(&lds[L::DELD + (pos + lo - T0)], 1u);
+                atomicAdd(&lds[L::DELD + (pos + hi - T0)], 0xFFFFFFFFu);
             }
         }
         if (qc) qs += elen;
@@ -416,7 +451,7 @@ __device__ __forceinline__ void pile_read_coop(const K4Args& a, uint32_t* lds, u
 // looked up with ds_bpermute in a 1024-base window of packed SEQ held two dwords per lane.
 // An op longer than 64 columns (rare in indel-dense long reads) is handed to the lanes-along-the-read
 // walk of pile_read_coop's inner loop.
-__device__ __forceinline__ void pile_read_long(const K4Args& a, uint32_t* lds, uint32_t T0, uint32_t Tend, int lane,
+template <class L> __device__ __forceinline__ void pile_read_long(const K4Args& a, uint32_t* lds, uint32_t T0, uint32_t Tend, int lane,
                                                uint32_t pos, uint32_t covered, uint32_t n_cig, uint32_t l_seq, uint64_t cig_off, Ckpt ck) {
     const uint64_t seq_off = cig_off + 4ull * n_cig;
     const uint32_t seq_bytes = (l_seq + 1) / 2;
@@ -435,8 +470,8 @@ __device__ __forceinline__ void pile_read_long(const K4Args& a, uint32_t* lds, u
         const bool in_win = rlen && lo < hi;
         const bool is_m = cig_qc(op) != 0;
         if (in_win && !is_m) {                                                   // D, N: '-' over [lo, hi), pileup.d:119-121
-            atomicAdd(&lds[DELD + (pos + lo - T0)], 1u);
-            atomicAdd(&lds[DELD + (pos + hi - T0)], 0xFFFFFFFFu);
+            atomicAdd(&lds[L::DELD + (pos + lo - T0)], 1u);
+            atomicAdd(&lds[L::DELD + (pos + hi - T0)], 0xFFFFFFFFu);
         }
         const uint32_t mlen = (in_win && is_m) ? hi - lo : 0u;
         uint32_t maxlen = mlen;
@@ -462,7 +497,7 @@ __device__ __forceinline__ void pile_read_long(const K4Args& a, uint32_t* lds, u
                             const uint32_t byte = (wv >> (((q >> 1) & 3u) * 8)) & 0xFFu;
                             cls = base_class((q & 1u) ? (byte & 0xFu) : (byte >> 4));       // read.d:368-373
                         } else atomicOr(a.status, ST_ESEQ);
-                        atomicAdd(&lds[cls * W + (pos + lo + t - T0)], 1u);
+                        L::add_cls(lds, cls, pos + lo + t - T0);
                     }
                 }
             } else {
@@ -482,7 +517,7 @@ __device__ __forceinline__ void pile_read_long(const K4Args& a, uint32_t* lds, u
                             uint32_t cls = 4;
                             if (q < l_seq) { const uint32_t byte = (wv >> (((q >> 1) & 3u) * 8)) & 0xFFu; cls = base_class((q & 1u) ? (byte & 0xFu) : (byte >> 4)); }
                             else atomicOr(a.status, ST_ESEQ);
-                            atomicAdd(&lds[cls * W + (pos + r0 + lane - T0)], 1u);
+                            L::add_cls(lds, cls, pos + r0 + lane - T0);
                         }
                     }
                 }
@@ -493,7 +528,8 @@ __device__ __forceinline__ void pile_read_long(const K4Args& a, uint32_t* lds, u
     if (c0 >= n_cig && cs < need_hi && lane == 0) atomicOr(a.status, ST_ECIGAR);      // assertCigarIndexIsValid, pileup.d:224-228
 }
 
-__global__ __launch_bounds__(K4_T) void k4_tile(K4Args a) {
+template <class L> __global__ __launch_bounds__(L::T) void k4_tile(K4Args a, int deep_pass) {
+    constexpr int K4_T = L::T, LIST = L::LIST, SLIST = L::SLIST, LCAP = L::LCAP, HIST = L::HIST;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_raw[];
     uint32_t* const lds = lds_raw + LDS_PAD;      // counters of masked-off bases may land up to 7 words below cnt[0][0]
     __shared__ uint32_t s_n;           // entries in the LDS list
@@ -502,23 +538,25 @@ __global__ __launch_bounds__(K4_T) void k4_tile(K4Args a) {
     // XCD-aware order: consecutive tiles of a reference go to the same XCD (block b runs on XCD b % 8)
     const uint64_t nb = a.n_tiles;
     const uint64_t per = (nb + 7) / 8;
-    uint64_t tile = (blockIdx.x % 8) * per + blockIdx.x / 8;
-    if (nb < 64) tile = blockIdx.x;
-    if (tile >= nb) return;
+  for (uint64_t it = blockIdx.x;; it += gridDim.x) {     // one window per workgroup; the deep pass walks its (short) list
+    uint64_t tile;
+    if (!deep_pass) {
+        if (it != blockIdx.x) break;
+        tile = (blockIdx.x % 8) * per + blockIdx.x / 8;
+        if (nb < 64) tile = blockIdx.x;
+        if (tile >= nb) break;
+    } else {
+        if (it >= *a.n_deep) break;
+        tile = a.deep[it];
+    }
     const TileB tb = a.tiles[tile];                      // window geometry + record range, precomputed by k4_bounds
+    if (!deep_pass && L::P16 && tb.pad) break;           // too many candidates for 16-bit counters: left to the deep pass
     const uint32_t T0 = tb.T0, Tend = tb.Tend;
-#ifdef BGP_K4_PHASES
-    unsigned long long ph_t = clock64(), ph[6] = {0, 0, 0, 0, 0, 0};
-    const unsigned long long ph_w0 = wall_clock64();
-#define PH(k) do { const unsigned long long now_ = clock64(); ph[k] += now_ - ph_t; ph_t = now_; } while (0)
-#else
-#define PH(k) do {} while (0)
-#endif
     for (int i = threadIdx.x; i < LIST; i += K4_T) lds[i] = 0;
     const uint64_t i_lo = tb.i_lo, i_hi = tb.i_hi;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    uint4* list = reinterpret_cast<uint4*>(lds + LIST);
+    uint32_t* list = lds + LIST;
     uint32_t* slist = lds + SLIST;
 
     for (uint64_t scan = i_lo; scan < i_hi;) {
@@ -527,14 +565,12 @@ __global__ __launch_bounds__(K4_T) void k4_tile(K4Args a) {
         // ---- scan: compact the reads that overlap the window
         for (bool more = true; more;) {
             // four rounds of candidate rows are requested before the first is looked at: one HBM round trip, not four
-            // (both halves of the row: the list entry then carries what the process phase needs to address the read's
-            // CIGAR and SEQ, which saves that phase a dependent round trip through the record table)
-            uint4 xs[4], ys[4];
+            uint4 xs[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const uint64_t i = scan + (uint64_t)r * K4_T + threadIdx.x;
-                xs[r] = make_uint4(0, 0, 0, 0); ys[r] = make_uint4(0, 0, 0, 0);
-                if (i < i_hi) { const uint4* rp = reinterpret_cast<const uint4*>(a.rec + i); xs[r] = rp[0]; ys[r] = rp[1]; }   // ref_id,pos,end_pos,bin_mq_nl | flag_nc,l_seq,rec_off
+                xs[r] = make_uint4(0, 0, 0, 0);
+                if (i < i_hi) xs[r] = *reinterpret_cast<const uint4*>(a.rec + i);   // ref_id, pos, end_pos, bin_mq_nl
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -542,24 +578,20 @@ __global__ __launch_bounds__(K4_T) void k4_tile(K4Args a) {
                 const uint64_t i = scan + threadIdx.x;
                 const uint4 x = xs[r];
                 const bool valid = i < i_hi && x.z != x.y && x.z > T0 && x.y < Tend;   // basesCovered() > 0 and overlaps the window
-                if (valid && x.y >= T0) atomicAdd(&lds[NST + (x.y - T0)], 1u);      // n_starting_here, pileup.d:386,422
+                if (valid && x.y >= T0) L::add_nst(lds, x.y - T0);      // n_starting_here, pileup.d:386,422
                 const unsigned long long m = __ballot(valid);
                 uint32_t slot = 0;
                 if (lane == 0 && m) slot = atomicAdd(&s_n, (uint32_t)__popcll(m));
                 slot = rl(slot, 0);
-                if (valid) {
-                    const uint4 y = ys[r];
-                    const uint64_t cg = (((uint64_t)y.w << 32) | y.z) + 36 + (x.w & 0xFFu);      // read.d:988-990
-                    list[slot + __popcll(m & ((1ull << lane) - 1))] =
-                        make_uint4(x.y, (uint32_t)(i - i_lo), (uint32_t)cg, (y.x & 0xFFFFu) | (min(y.y, 255u) << 16) | ((uint32_t)(cg >> 32) << 24));
-                }
+                if (valid) list[slot + __popcll(m & ((1ull << lane) - 1))] = (uint32_t)(i - i_lo);
                 scan += K4_T;
                 __syncthreads();
-                if (scan >= i_hi || s_n > LCAP - K4_T) more = false;
+                const uint32_t sn = s_n;                              // every wave must take the same decision: read the counter ...
+                __syncthreads();                                      // ... before a faster wave's next round adds to it
+                if (scan >= i_hi || sn > LCAP - K4_T) more = false;
             }
         }
         const uint32_t n_list = s_n;
-        PH(0);
         // ---- process: 64 listed reads per wave, lane = read
 #ifdef BGP_K4_NOPROC
         for (uint32_t b0 = n_list; b0 < n_list; b0 += (K4_T / 64) * 64) {
@@ -572,11 +604,11 @@ __global__ __launch_bounds__(K4_T) void k4_tile(K4Args a) {
             uint4 w0 = {}, w1 = {}, w2 = {}, w3 = {}, w4 = {};
             bool fast = false;
             uint32_t qsum = 0;
-            uint32_t ridx = 0;
             if (have) {
-                const uint4 e = list[b0 + lane];
-                pos = e.x; ridx = e.y; n_cig = e.w & 0xFFFFu; l_seq = (e.w >> 16) & 0xFFu;        // l_seq saturates at 255: not a fast read then
-                cig_off = ((uint64_t)(e.w >> 24) << 32) | e.z;
+                const uint4* rp = reinterpret_cast<const uint4*>(a.rec + i_lo + list[b0 + lane]);
+                const uint4 x = rp[0], y = rp[1];             // ref_id,pos,end_pos,bin_mq_nl | flag_nc,l_seq,rec_off
+                pos = x.y; covered = x.z - x.y; n_cig = y.x & 0xFFFFu; l_seq = y.y;
+                cig_off = (((uint64_t)y.w << 32) | y.z) + 36 + (x.w & 0xFFu);
                 const uint64_t seq_off = cig_off + 4ull * n_cig;
                 fast = n_cig >= 1 && n_cig <= 4 && l_seq <= FAST_LSEQ && seq_off + 80 <= a.stream_len;
                 if (fast) {
@@ -596,7 +628,7 @@ __global__ __launch_bounds__(K4_T) void k4_tile(K4Args a) {
                         const uint32_t op = k == 0 ? o0 : k == 1 ? o1 : k == 2 ? o2 : o3;
                         if ((uint32_t)k < n_cig) {
                             const uint32_t len = op >> 4;
-                            if (cig_rc(op)) { if (len == 0 || (!seen_ref && (op & 15u) == 3u)) ok = false; seen_ref = true; covered += len; }   // basesCovered, read.d:255-262
+                            if (cig_rc(op)) { if (len == 0 || (!seen_ref && (op & 15u) == 3u)) ok = false; seen_ref = true; }
                             if (cig_qc(op)) qsum += len;
                         }
                     }
@@ -629,7 +661,7 @@ __global__ __launch_bounds__(K4_T) void k4_tile(K4Args a) {
 #pragma unroll
                                         for (int j = 0; j <= k; ++j) if (m == (uint32_t)j) { sq[j] = vq; sl[j] = vl; sb[j] = vb; }
                                         ++m;
-                                    } else { atomicAdd(&lds[DELD + colbase + lo], 1u); atomicAdd(&lds[DELD + colbase + hi], 0xFFFFFFFFu); }   // pileup.d:119-121
+                                    } else { atomicAdd(&lds[L::DELD + colbase + lo], 1u); atomicAdd(&lds[L::DELD + colbase + hi], 0xFFFFFFFFu); }   // pileup.d:119-121
                                 }
                                 p += len;
                             }
@@ -664,7 +696,11 @@ __global__ __launch_bounds__(K4_T) void k4_tile(K4Args a) {
 #pragma unroll
                     for (int b = 0; b < 8; ++b) {
                         const uint32_t cls = (cw >> (4 * b)) & 7u;
-                        atomicAdd(reinterpret_cast<uint32_t*>(l8 + (int32_t)((cls << CLS_SHIFT) + bq) + 4 * b), (vm >> b) & 1u);
+                        if (L::P16) {                                                     // two positions to a word: byte 4 * column -> word (column >> 1), half (column & 1)
+                            const int32_t t = (int32_t)(bq + 4u * b);
+                            atomicAdd(reinterpret_cast<uint32_t*>(l8 + (int32_t)(cls << L::CSH) + ((t >> 1) & ~3)), ((vm >> b) & 1u) << ((t & 4) << 2));
+                        } else
+                            atomicAdd(reinterpret_cast<uint32_t*>(l8 + (int32_t)((cls << CLS_SHIFT) + bq) + 4 * b), (vm >> b) & 1u);
                     }
                 };
                 for (uint32_t wi = 0; wi < nwords; ++wi) {
@@ -711,12 +747,10 @@ __global__ __launch_bounds__(K4_T) void k4_tile(K4Args a) {
                 uint32_t slot = 0;
                 if (lane == 0) slot = atomicAdd(&s_nslow, (uint32_t)__popcll(sm));
                 slot = rl(slot, 0);
-                if (is_slow) slist[slot + __popcll(sm & ((1ull << lane) - 1))] = ridx;
+                if (is_slow) slist[slot + __popcll(sm & ((1ull << lane) - 1))] = list[b0 + lane];
             }
         }
-        PH(1);
         __syncthreads();
-        PH(2);
         // one read at a time per wave, whole wave on the read
         const uint32_t n_slow = s_nslow;
         for (uint32_t j = (uint32_t)wave; j < n_slow; j += K4_T / 64) {
@@ -728,13 +762,12 @@ __global__ __launch_bounds__(K4_T) void k4_tile(K4Args a) {
             if (a.ck && is_long_read(rncig, rlseq)) {
                 const uint64_t wj = (uint64_t)(T0 - tb.run_start) / W - ((uint64_t)rpos - tb.run_start) / W;   // window index within the read
                 const Ckpt ck = a.ck[a.ck_off[ri] + wj];
-                pile_read_long(a, lds, T0, Tend, lane, rpos, rcov, rncig, rlseq, co, ck);
+                pile_read_long<L>(a, lds, T0, Tend, lane, rpos, rcov, rncig, rlseq, co, ck);
             } else
-                pile_read_coop(a, lds, T0, Tend, lane, rpos, rcov, rncig, rlseq, co);
+                pile_read_coop<L>(a, lds, T0, Tend, lane, rpos, rcov, rncig, rlseq, co);
         }
         __syncthreads();
     }
-    PH(3);
     // ---- flush: prefix-sum the '-' difference array, then 32 contiguous bytes per position
     const uint32_t np = Tend - T0;
     {
@@ -742,7 +775,7 @@ __global__ __launch_bounds__(K4_T) void k4_tile(K4Args a) {
         const uint32_t p0 = threadIdx.x * PER;
         uint32_t loc[PER]; uint32_t run_sum = 0;
 #pragma unroll
-        for (int j = 0; j < PER; ++j) { run_sum += lds[DELD + p0 + j]; loc[j] = run_sum; }
+        for (int j = 0; j < PER; ++j) { run_sum += lds[L::DELD + p0 + j]; loc[j] = run_sum; }
         uint32_t inc = run_sum;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(inc, d, 64); if (lane >= d) inc += o; }
@@ -752,13 +785,13 @@ __global__ __launch_bounds__(K4_T) void k4_tile(K4Args a) {
         for (int w = 0; w < wave; ++w) carry += wsum[w];
         const uint32_t ex = carry + inc - run_sum;
 #pragma unroll
-        for (int j = 0; j < PER; ++j) lds[DELD + p0 + j] = ex + loc[j];
+        for (int j = 0; j < PER; ++j) lds[L::DELD + p0 + j] = ex + loc[j];
         __syncthreads();
     }
     bgp_column* out = a.cols + tb.col_out;
     uint64_t ncol = 0, scov = 0; uint32_t mx = 0;
     for (uint32_t p = threadIdx.x; p < np; p += K4_T) {
-        const uint32_t A = lds[p], C = lds[W + p], G = lds[2 * W + p], Tt = lds[3 * W + p], O = lds[4 * W + p], D = lds[DELD + p], S = lds[NST + p];
+        const uint32_t A = L::get_cls(lds, 0, p), C = L::get_cls(lds, 1, p), G = L::get_cls(lds, 2, p), Tt = L::get_cls(lds, 3, p), O = L::get_cls(lds, 4, p), D = lds[L::DELD + p], S = L::get_nst(lds, p);
         const uint32_t cov = A + C + G + Tt + O + D;
         uint4* o4 = reinterpret_cast<uint4*>(out + p);
 #ifndef BGP_K4_NOFLUSH
@@ -774,7 +807,7 @@ __global__ __launch_bounds__(K4_T) void k4_tile(K4Args a) {
     // per-window totals go to a per-window slot (same-address global atomics from every wave cost
     // more than the whole rest of the kernel); k4_stats folds the slots afterwards
     uint64_t nst = 0;
-    for (uint32_t p = threadIdx.x; p < np; p += K4_T) nst += lds[NST + p];
+    for (uint32_t p = threadIdx.x; p < np; p += K4_T) nst += L::get_nst(lds, p);
     for (int d = 32; d >= 1; d >>= 1) { ncol += __shfl_down(ncol, d, 64); scov += __shfl_down(scov, d, 64); nst += __shfl_down(nst, d, 64); mx = max(mx, (uint32_t)__shfl_down(mx, d, 64)); }
     __shared__ unsigned long long part[K4_T / 64][4];
     if (lane == 0) { part[wave][0] = ncol; part[wave][1] = scov; part[wave][2] = mx; part[wave][3] = nst; }
@@ -788,10 +821,8 @@ __global__ __launch_bounds__(K4_T) void k4_tile(K4Args a) {
 #ifndef BGP_K4_NOHIST
     for (int b = threadIdx.x; b < HB; b += K4_T) { const uint32_t h = lds[HIST + b]; if (h) atomicAdd(&a.hist[b], (unsigned long long)h); }
 #endif
-    PH(4);
-#ifdef BGP_K4_PHASES
-    if ((threadIdx.x & 63) == 0 && wave < 2) { for (int k = 0; k < 5; ++k) a.phases[(tile * 2 + wave) * 8 + k] = ph[k]; a.phases[(tile * 2 + wave) * 8 + 5] = wall_clock64() - ph_w0; a.phases[(tile * 2 + wave) * 8 + 6] = ph_w0; }
-#endif
+    __syncthreads();                                     // the deep pass reuses the tile's LDS for its next window
+  }
 }
 
 // folds the per-window totals: [0] columns with coverage, [1] sum of coverage, [2] max coverage, [4] reads used
@@ -940,25 +971,23 @@ int k34_pileup(bgp_ctx* c) {
         a.s = c->d_stream; a.rec = c->d_rec.as<bgp_record>(); a.pmax_end = c->d_pmax_end.as<uint64_t>(); a.pmax_pos = c->d_pmax_pos.as<uint64_t>();
         a.runs = c->d_runs.as<RunDev>(); a.n_runs = n_runs; a.n_tiles = tile_base; a.stream_len = c->stream_len;
         a.cols = c->d_columns.as<bgp_column>(); a.hist = (unsigned long long*)c->d_depth_hist.p; a.pstats = (unsigned long long*)c->d_pstats.p; a.status = status;
-        const size_t lds_bytes = (size_t)LDS_WORDS * 4;
+        const size_t lds16 = (size_t)L16::WORDS * 4, lds32 = (size_t)L32::WORDS * 4;
         const uint64_t grid = tile_base < 64 ? tile_base : ((tile_base + 7) / 8) * 8;
         uint64_t used = 0;   // algorithmic bytes: record table + CIGAR + packed SEQ per read, 32 B per position
         used = c->n_records * 32 + c->sum_ncig * 4 + (c->sum_lseq + 1) / 2 + col_base * 32;
         BGP_TRY(c->d_tiles.reserve(tile_base * sizeof(TileB)));
+        BGP_TRY(c->d_deep.reserve((tile_base + 2) * 4));                 // [0] count, [1..] window indices
+        BGP_HIP(hipMemsetAsync(c->d_deep.p, 0, 4, c->stream));
+        a.n_deep = c->d_deep.as<uint32_t>(); a.deep = c->d_deep.as<uint32_t>() + 1;
         a.tiles = c->d_tiles.as<TileB>();
         {
             TimedRegion tb(c, "k4_bounds", tile_base * sizeof(TileB));
-            hipLaunchKernelGGL(k4_bounds, dim3((unsigned)((tile_base + 255) / 256)), dim3(256), 0, c->stream, a.pmax_end, a.pmax_pos, a.runs, n_runs, tile_base, c->d_tiles.as<TileB>());
+            hipLaunchKernelGGL(k4_bounds, dim3((unsigned)((tile_base + 255) / 256)), dim3(256), 0, c->stream, a.pmax_end, a.pmax_pos, a.runs, n_runs, tile_base, c->d_tiles.as<TileB>(),
+                               c->d_deep.as<uint32_t>() + 1, c->d_deep.as<uint32_t>());
         }
         BGP_TRY(c->d_col_lo.reserve(tile_base * 32));
         a.tile_stats = (unsigned long long*)c->d_col_lo.p;
-        a.ck = nullptr; a.ck_off = nullptr; a.phases = nullptr;
-#ifdef BGP_K4_PHASES
-        static DevBuf d_ph;
-        BGP_TRY(d_ph.reserve(tile_base * 16 * 8));
-        BGP_HIP(hipMemsetAsync(d_ph.p, 0, tile_base * 16 * 8, c->stream));
-        a.phases = (unsigned long long*)d_ph.p;
-#endif
+        a.ck = nullptr; a.ck_off = nullptr;
         if (st[3]) {                                   // the stream holds long reads: build their per-window CIGAR checkpoints
             TimedRegion tc(c, "k4_checkpoints", c->sum_ncig * 4);
             BGP_TRY(c->d_ck_off.reserve((n + 2) * 8));
@@ -972,26 +1001,10 @@ int k34_pileup(bgp_ctx* c) {
             a.ck = c->d_ck.as<Ckpt>(); a.ck_off = ck_off;
         }
         TimedRegion t(c, "k4_tile", used);
-        hipLaunchKernelGGL(k4_tile, dim3((unsigned)grid), dim3(K4_T), lds_bytes, c->stream, a);
+        hipLaunchKernelGGL(k4_tile<L16>, dim3((unsigned)grid), dim3(L16::T), lds16, c->stream, a, 0);
+        hipLaunchKernelGGL(k4_tile<L32>, dim3(256), dim3(L32::T), lds32, c->stream, a, 1);          // deep windows only: exits at once when there are none
         hipLaunchKernelGGL(k4_stats, dim3(32), dim3(256), 0, c->stream, a.tile_stats, tile_base, a.pstats);
         BGP_HIP(hipGetLastError());
-#ifdef BGP_K4_PHASES
-        {
-            std::vector<unsigned long long> h(tile_base * 16);
-            BGP_HIP(hipMemcpy(h.data(), a.phases, tile_base * 16 * 8, hipMemcpyDeviceToHost));
-            double sum[2][5] = {};
-            for (uint64_t t = 0; t < tile_base; ++t) for (int w = 0; w < 2; ++w) for (int k = 0; k < 5; ++k) sum[w][k] += (double)h[(t * 2 + w) * 8 + k];
-            double wall = 0; unsigned long long first = ~0ull, last = 0;
-            for (uint64_t t = 0; t < tile_base; ++t) { if (!h[t * 16 + 6]) continue; wall += (double)h[t * 16 + 5]; first = std::min(first, h[t * 16 + 6]); last = std::max(last, h[t * 16 + 6] + h[t * 16 + 5]); }
-            int occ = 0; (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k4_tile, K4_T, lds_bytes);
-            fprintf(stderr, "[k4 occupancy] %d workgroups per CU (LDS %zu B)\n", occ, lds_bytes);
-            fprintf(stderr, "[k4 tiles] %llu tiles, mean tile life %.2f us (100 MHz wall clock), kernel span %.2f ms, mean tiles in flight %.1f\n", (unsigned long long)tile_base,
-                    wall / tile_base / 100.0, (double)(last - first) / 1e5, wall / (double)(last - first));
-            for (int w = 0; w < 2; ++w)
-                fprintf(stderr, "[k4 phases, wave %d, mean cycles/tile] zero+scan %.0f  process(own batches) %.0f  barrier %.0f  slow lists %.0f  flush %.0f\n", w,
-                        sum[w][0] / tile_base, sum[w][1] / tile_base, sum[w][2] / tile_base, sum[w][3] / tile_base, sum[w][4] / tile_base);
-        }
-#endif
     }
     uint64_t ps[16];
     BGP_HIP(hipMemcpyAsync(ps, c->d_pstats.p, 128, hipMemcpyDeviceToHost, c->stream));

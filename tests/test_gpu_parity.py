@@ -483,6 +483,22 @@ def test_deep_pile(ctx):
         _check_refbase(ctx, st, skip_zero=skip, window=64)
 
 
+def test_very_deep_pile_takes_the_32_bit_layout(ctx):
+    """70 000 reads on ~60 columns: the window's candidate range exceeds what 16-bit LDS counters can hold, so it is
+    left to K4's deep pass (32-bit counters); coverage itself passes 65 535."""
+    rng = np.random.default_rng(78)
+    recs, pos = [], 500
+    for i in range(70_000):
+        pos += int(rng.random() < 0.0005)
+        ln = int(rng.integers(20, 50))
+        seq = "".join("ACGT"[int(x)] for x in rng.integers(0, 4, ln))
+        recs.append(bamio.pack_record(f"v{i}", seq, [(ln, "M")], ref_id=0, pos=pos))
+    st = b"".join(recs)
+    stage(ctx, st)
+    info, ora = check_pileup(ctx, st, entries=False)
+    assert info.max_coverage > 65_535
+
+
 def _random_stream(rng, n_reads, quirks):
     """Coordinate-sorted random records: every CIGAR op type, optional zero-length ops, SEQ shorter or
     longer than the CIGAR's query length, unmapped reads, three references."""
