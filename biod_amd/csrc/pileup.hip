@@ -693,16 +693,34 @@ template <class L> __global__ __launch_bounds__(L::T) void k4_tile(K4Args a, int
                     const uint32_t vm = hi > lo ? (((1u << (hi - lo)) - 1u) << lo) : 0u;
                     const uint32_t bq = vm ? vb + q0 * 4u : 0u;                             // byte address of cnt[0][column of base 0]
                     char* const l8 = reinterpret_cast<char*>(lds);
+                    if (L::P16) {
+                        // two positions to a word.  With C the column of base 0: base b sits in word (C >> 1) + ((b + (C & 1)) >> 1),
+                        // half (C + b) & 1 -- the word offset is an immediate for even b and immediate + 4 * (C & 1) for odd b,
+                        // the half alternates; both depend on the lane only through C's parity, fixed once per dword
+                        const int32_t w0b = ((int32_t)bq >> 1) & ~3;                      // byte offset of word (C >> 1)
+                        const uint32_t par4 = bq & 4u;                                    // 4 * (C & 1)
+                        const uint32_t sh_even = par4 << 2, sh_odd = sh_even ^ 16u;       // 16 * half
+                        char* const pe = l8 + w0b;
+                        char* const po = pe + par4;
 #pragma unroll
-                    for (int b = 0; b < 8; ++b) {
-                        const uint32_t cls = (cw >> (4 * b)) & 7u;
-                        if (L::P16) {                                                     // two positions to a word: byte 4 * column -> word (column >> 1), half (column & 1)
-                            const int32_t t = (int32_t)(bq + 4u * b);
-                            atomicAdd(reinterpret_cast<uint32_t*>(l8 + (int32_t)(cls << L::CSH) + ((t >> 1) & ~3)), ((vm >> b) & 1u) << ((t & 4) << 2));
-                        } else
-                            atomicAdd(reinterpret_cast<uint32_t*>(l8 + (int32_t)((cls << CLS_SHIFT) + bq) + 4 * b), (vm >> b) & 1u);
+                        for (int b = 0; b < 8; ++b) {
+                            const uint32_t cls = __builtin_amdgcn_ubfe(cw, 4 * b, 3);
+                            atomicAdd(reinterpret_cast<uint32_t*>(((b & 1) ? po : pe) + (int32_t)(cls << L::CSH) + 4 * (b >> 1)), __builtin_amdgcn_ubfe(vm, b, 1) << ((b & 1) ? sh_odd : sh_even));
+                        }
+                    } else {
+#pragma unroll
+                        for (int b = 0; b < 8; ++b) {
+                            const uint32_t cls = __builtin_amdgcn_ubfe(cw, 4 * b, 3);
+                            atomicAdd(reinterpret_cast<uint32_t*>(l8 + (int32_t)((cls << CLS_SHIFT) + bq) + 4 * b), __builtin_amdgcn_ubfe(vm, b, 1));
+                        }
                     }
                 };
+                // the slot a dword is given to only ever moves forward: keep the current one and a queue of the next ones
+                // (an unused slot never starts), advance when the next one starts at or before the dword's last base
+                uint32_t cq = sq[0], cl = sl[0], cb = sb[0];
+                uint32_t n1q = sl[1] ? sq[1] : 0xFFFFFFFFu, n1l = sl[1], n1b = sb[1];
+                uint32_t n2q = sl[2] ? sq[2] : 0xFFFFFFFFu, n2l = sl[2], n2b = sb[2];
+                uint32_t n3q = sl[3] ? sq[3] : 0xFFFFFFFFu, n3l = sl[3], n3b = sb[3];
                 for (uint32_t wi = 0; wi < nwords; ++wi) {
                     uint32_t cur;                                           // dword wi of this lane's packed SEQ (wi is wave-uniform)
                     switch (wi) {
@@ -713,12 +731,20 @@ template <class L> __global__ __launch_bounds__(L::T) void k4_tile(K4Args a, int
                         case 16: cur = w4.x; break; case 17: cur = w4.y; break; case 18: cur = w4.z; break; default: cur = w4.w; break;
                     }
                     const uint32_t q0 = wi * 8, qlast = q0 + 7;
-                    uint32_t vq = sq[0], vl = sl[0], vb = sb[0];
-                    if (use1) { const bool t = sl[1] != 0 && sq[1] <= qlast; vq = t ? sq[1] : vq; vl = t ? sl[1] : vl; vb = t ? sb[1] : vb; }
-                    if (use2) { const bool t = sl[2] != 0 && sq[2] <= qlast; vq = t ? sq[2] : vq; vl = t ? sl[2] : vl; vb = t ? sb[2] : vb; }
-                    if (use3) { const bool t = sl[3] != 0 && sq[3] <= qlast; vq = t ? sq[3] : vq; vl = t ? sl[3] : vl; vb = t ? sb[3] : vb; }
+                    if (use1) {                                             // as many advances per dword as a wave can need: 1, 2 or 3
+                        const bool t = n1q <= qlast;
+                        cq = t ? n1q : cq; cl = t ? n1l : cl; cb = t ? n1b : cb;
+                        if (use2) { n1q = t ? n2q : n1q; n1l = t ? n2l : n1l; n1b = t ? n2b : n1b; n2q = t ? n3q : n2q; n2l = t ? n3l : n2l; n2b = t ? n3b : n2b; n3q = t ? 0xFFFFFFFFu : n3q; }
+                        else n1q = t ? 0xFFFFFFFFu : n1q;
+                    }
+                    if (use2) {
+                        const bool t = n1q <= qlast;
+                        cq = t ? n1q : cq; cl = t ? n1l : cl; cb = t ? n1b : cb;
+                        n1q = t ? n2q : n1q; n1l = t ? n2l : n1l; n1b = t ? n2b : n1b; n2q = t ? 0xFFFFFFFFu : n2q;
+                    }
+                    if (use3) { const bool t = n1q <= qlast; cq = t ? n1q : cq; cl = t ? n1l : cl; cb = t ? n1b : cb; n1q = t ? 0xFFFFFFFFu : n1q; }
 #ifndef BGP_K4_NOQ
-                    dword_step(cur, q0, vq, vl, vb);
+                    dword_step(cur, q0, cq, cl, cb);
 #endif
                 }
                 // what a slot's first dword holds of the slot before it
