@@ -25,7 +25,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
             if r["Counter_Name"] != c:
                 continue
             k = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "")
-            k = re.sub(r"[<(].*", "", k).strip()
+            k = re.sub(r"\(.*", "", k).strip().replace(",", ";")      # template arguments stay: k4_tile has two instantiations per step
             acc[k][0] += float(r["Counter_Value"]); acc[k][1] += 1
     vals[c] = acc
 with open(f"{out}/r01_pmc_hbm_traffic_cfg3_100M.csv", "w") as w:
