@@ -330,18 +330,20 @@ __global__ __launch_bounds__(256) void k4_ck_build(const uint8_t* s, const bgp_r
 
 // ---- K4: per-position column summary ----------------------------------------------------------
 // LDS tile (u32 words): cnt[5][W] (A,C,G,T,other) | deld[W+4] ('-' as a difference array: +1 where a
-// D/N op starts, -1 where it ends, summed at flush) | nst[W] (n_starting_here) | hist[HB] | list[LCAP].
+// D/N op starts, -1 where it ends, summed at flush) | nst[W] (n_starting_here) | hist[HB] | list[LCAP] |
+// slist[LCAP]; cnt and nst are 16 bits wide in the layout ordinary windows use (struct Lay below).
 //
-// Per window: (1) SCAN the candidate record range 512 at a time (one coalesced 16-byte read per lane),
-// count n_starting_here and compact the indices of the reads that really overlap the window into an
-// LDS list; (2) PROCESS the list 64 reads per wave with LANE = READ: a lane loads its read's whole
-// packed SEQ up front (five unaligned 16-byte loads, all in flight together -- this is what hides HBM
-// latency) and then every lane of the wave steps the same query index q, walking its own CIGAR with a
-// tiny state machine: an M/=/X base becomes one ds_add_u32 on cnt[class][position], an I/S base is
-// skipped, a D/N op is two adds on the difference array.  Reads that do not fit that mould (longer than
-// 160 bases, more than 4 CIGAR ops, zero-length or leading-N ops, CIGAR longer than SEQ) take the
-// wave-cooperative path below, which implements the closed form of pileup.d:175-222 in full generality
-// with lanes along the read.
+// Per window: (1) SCAN the candidate record range one workgroup-width at a time (one coalesced 16-byte read
+// per lane, four rounds requested before the first is looked at), count n_starting_here and compact the
+// indices of the reads that really overlap the window into an LDS list; (2) PROCESS the list 64 reads per
+// wave with LANE = READ: a lane loads its read's CIGAR ops and whole packed SEQ up front (five unaligned
+// 16-byte loads, all in flight together), turns its <= 4 ops into window-clipped query intervals, and then
+// all lanes step the same packed-SEQ dword -- 8 bases classified with word-parallel bit tricks, one ds_add
+// per base; a D/N op is two adds on the difference array.  Reads that do not fit that mould (longer than
+// 160 bases, more than 4 CIGAR ops, zero-length or leading-N ops, CIGAR longer than SEQ) go to a second list
+// dealt to all waves: long reads resume from per-window CIGAR checkpoints with LANE = OP (pile_read_long),
+// the odd rest takes the fully general lanes-along-the-read walk (pile_read_coop), both the closed form of
+// pileup.d:175-222; (3) FLUSH: block scan of the difference array, 32 contiguous bytes per position.
 
 constexpr int LDS_PAD = 8;               // words in front of the tile (see k4_tile's hot loop)
 // Two layouts of the window in LDS.  P16: the five class counters and n_starting_here are 16 bits wide, two
