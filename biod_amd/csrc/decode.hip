@@ -220,17 +220,26 @@ __global__ __launch_bounds__(256) void k12_fused(FusedArgs a) {
             const uint64_t seg = k0 + g;
             const uint64_t off = seg * a.seg_bytes + a.side[seg * a.side_cap + (i - s_rb[g])];
             const uint8_t* p = a.d.s + off;
-            rec.ref_id = (int32_t)ld_u32(p + 4);                     // read.d:907
-            rec.pos = (int32_t)ld_u32(p + 8);                        // read.d:911
-            rec.bin_mq_nl = ld_u32(p + 12);                          // read.d:915
-            rec.flag_nc = ld_u32(p + 16);                            // read.d:919
+            // few wide loads instead of many dword loads: the lanes' records are ~300 bytes apart, so every load
+            // instruction costs the address coalescer 64 separate lines whatever its width
+            uint4 h; __builtin_memcpy(&h, p + 4, 16);                // ref_id, pos, bin_mq_nl, flag_nc: read.d:907-919
+            rec.ref_id = (int32_t)h.x; rec.pos = (int32_t)h.y; rec.bin_mq_nl = h.z; rec.flag_nc = h.w;
             rec.l_seq = (int32_t)ld_u32(p + 20);                     // read.d:923
             rec.rec_off = off;
             const uint32_t l_name = rec.bin_mq_nl & 0xFFu, n_cig = rec.flag_nc & 0xFFFFu;
             uint32_t covered = 0;
             if (!((rec.flag_nc >> 16) & 0x4u) && n_cig <= BGP_LONG_CIGAR) {   // read.d:257-259; long CIGARs: k1_long_cigar afterwards
                 const uint8_t* cg = p + 36 + l_name;                  // read.d:988-990
-                for (uint32_t j = 0; j < n_cig; ++j) { const uint32_t op = ld_u32(cg + 4 * j); covered += cig_rc(op) ? (op >> 4) : 0u; }   // read.d:261
+                uint32_t j0 = 0;
+                if (n_cig && off + 36 + l_name + 16 <= a.d.stream_len) {       // the first four ops in one load
+                    uint4 c4; __builtin_memcpy(&c4, cg, 16);
+                    covered += cig_rc(c4.x) ? (c4.x >> 4) : 0u;
+                    if (n_cig > 1) covered += cig_rc(c4.y) ? (c4.y >> 4) : 0u;
+                    if (n_cig > 2) covered += cig_rc(c4.z) ? (c4.z >> 4) : 0u;
+                    if (n_cig > 3) covered += cig_rc(c4.w) ? (c4.w >> 4) : 0u;
+                    j0 = 4;
+                }
+                for (uint32_t j = j0; j < n_cig; ++j) { const uint32_t op = ld_u32(cg + 4 * j); covered += cig_rc(op) ? (op >> 4) : 0u; }   // read.d:261
             }
             rec.end_pos = (int32_t)((uint32_t)rec.pos + covered);     // read.d:1382
             lseq = (uint64_t)(uint32_t)rec.l_seq; ncig = n_cig;

@@ -93,8 +93,9 @@ __global__ __launch_bounds__(256) void k0_chase(FrameArgs a) {
         if (bs < 0) { err = ST_EINVAL; break; }
         if ((uint64_t)bs > a.len - off - 4) { err = ST_ETRUNC; break; }    // readrange.d:169
         if (bs < 32) { err = ST_EINVAL; break; }
-        const uint32_t bmn = ld_u32(a.s + off + 12), fnc = ld_u32(a.s + off + 16);
-        const int32_t lseq = (int32_t)ld_u32(a.s + off + 20);
+        uint32_t f3[3]; __builtin_memcpy(f3, a.s + off + 12, 12);            // bin_mq_nl, flag_nc, l_seq in one load (bs >= 32: in bounds)
+        const uint32_t bmn = f3[0], fnc = f3[1];
+        const int32_t lseq = (int32_t)f3[2];
         const uint32_t l_name = bmn & 0xFFu, n_cig = fnc & 0xFFFFu;
         if (lseq < 0 || l_name == 0 || 32ull + l_name + 4ull * n_cig + (uint64_t)((lseq + 1) / 2) + (uint64_t)lseq > (uint64_t)bs) { err = ST_EINVAL; break; }
         if (cnt < a.side_cap) a.side[k * a.side_cap + cnt] = (uint32_t)(off - k * (uint64_t)a.seg_bytes);   // 128 contiguous bytes per 32 records: the fused K1+K2 finds every record without a second chase

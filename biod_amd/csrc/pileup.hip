@@ -614,11 +614,11 @@ template <class L> __global__ __launch_bounds__(L::T) void k4_tile(K4Args a, int
                 const uint64_t seq_off = cig_off + 4ull * n_cig;
                 fast = n_cig >= 1 && n_cig <= 4 && l_seq <= FAST_LSEQ && seq_off + 80 <= a.stream_len;
                 if (fast) {
-                    const uint8_t* c = a.s + cig_off;
-                    o0 = ld_u32(c);
-                    if (n_cig > 1) o1 = ld_u32(c + 4);
-                    if (n_cig > 2) o2 = ld_u32(c + 8);
-                    if (n_cig > 3) o3 = ld_u32(c + 12);
+                    uint4 c4; __builtin_memcpy(&c4, a.s + cig_off, 16);   // <= 4 ops in one load (SEQ follows: in bounds)
+                    o0 = c4.x;
+                    if (n_cig > 1) o1 = c4.y;
+                    if (n_cig > 2) o2 = c4.z;
+                    if (n_cig > 3) o3 = c4.w;
                     const uint8_t* sp = a.s + seq_off;
                     __builtin_memcpy(&w0, sp, 16); __builtin_memcpy(&w1, sp + 16, 16); __builtin_memcpy(&w2, sp + 32, 16);
                     __builtin_memcpy(&w3, sp + 48, 16); __builtin_memcpy(&w4, sp + 64, 16);
