@@ -683,15 +683,20 @@ __global__ __launch_bounds__(64) void k6_top(const MdRow* rows, const Succ* ex, 
     bool flag = false;
     // add() of the first group: the first read unconditionally, a later one if it ends beyond the stale chunk_end and beyond the best so far
     const MdRow r0 = rows[R.first];
-    uint32_t node = (uint32_t)R.first, best_end = r0.end; MdRow nr = r0;
+    uint32_t node = (uint32_t)R.first, best_end = r0.end, later_max = 0; MdRow nr = r0;
     int budget = SUCC_CAP;
     for (uint64_t k = R.first + 1; k < R.endrec; ++k) {
         if (--budget < 0) { flag = true; break; }
         const MdRow q = rows[k];
         if (!(q.lf & MD_COV)) continue;
         if (q.pos != r0.pos) break;
-        if (q.end > R.ce_in && q.end > best_end) { node = (uint32_t)k; best_end = q.end; nr = q; }
+        if (q.end > R.ce_in && q.end > best_end) { node = (uint32_t)k; best_end = q.end; nr = q; later_max = 0; }
+        else later_max = max(later_max, q.end);
     }
+    // The one place where chunk_end can DROP is here: the stale value of the previous reference may exceed the winner's
+    // end.  A read of this group that add() turned down for not ending beyond the stale value, but that ends beyond the
+    // winner, would look like a candidate to succ() although the sweep never sees it again: not a regular start.
+    flag |= later_max > best_end;
     uint32_t F = r0.pos;
     flag |= arrival_irregular(nr, F);
     uint32_t hops = 0;
@@ -913,6 +918,7 @@ int k6_reference_bases(bgp_ctx* c, int skip_zero, uint32_t run_first, uint32_t r
                 else { co[k] = ChainOut{po[k].ce_out, 0u, 0, 0u, -1}; }
             }
             if (getenv("BGP_VERBOSE")) fprintf(stderr, "[biodgpu] MD chain: %zu run(s) composed, %zu redone by the event loop\n", ks.size() - seq.size(), seq.size());
+            if (getenv("BGP_VERBOSE") && nr <= 16) for (uint32_t k : ks) fprintf(stderr, "[biodgpu]   run %u: first %llu endrec %llu ce_in %u -> ce_out %u flagged %u nodes %u\n", k, (unsigned long long)cr[k].first, (unsigned long long)cr[k].endrec, cr[k].ce_in, po[k].ce_out, po[k].flagged, po[k].n_nodes);
             for (uint32_t k : seq) { const bgp_run& r = c->runs[run_first + k]; if (r.end_pos > r.start_pos) BGP_HIP(hipMemsetAsync(c->d_refbase.as<uint8_t>() + r.column_base, 'N', r.end_pos - r.start_pos, c->stream)); }
         } else seq = ks;
         if (seq.empty()) return BGP_OK;

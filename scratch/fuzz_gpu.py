@@ -1,0 +1,34 @@
+"""One-off differential fuzz on the GPU box: random record streams through decode / pileup (entries) / reference_base,
+device vs oracle.  usage: python scratch/fuzz_gpu.py [n_rounds] [seed0]"""
+import sys, time
+sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests'); sys.path.insert(0, '/root/repo/oracle')
+import numpy as np
+import oracle_lib as O
+import test_gpu_parity as T
+from biod_amd import _lib as L
+from biod_amd.pileup import Context
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 50_000
+ctx = Context(0)
+t0 = time.time(); bad = 0
+for k in range(n):
+    rng = np.random.default_rng(seed0 + k)
+    try:
+        st = T._random_stream(rng, int(rng.integers(50, 3000)), quirks=bool(k % 2))
+        T.stage(ctx, st)
+        T.check_decode(ctx, st)
+        try:
+            O.pileup(st)
+            T.check_pileup(ctx, st, entries=(k % 3 == 0), window=int(rng.integers(100, 9000)))
+        except O.OracleError as e:
+            assert e.code == O.ORC_ECIGAR
+        st = T._md_stream(rng, int(rng.integers(50, 1500)), **T._MD_CFGS[k % len(T._MD_CFGS)])
+        T.stage(ctx, st)
+        T.check_pileup(ctx, st, entries=False)
+        for skip in (True, False):
+            T._check_refbase(ctx, st, skip_zero=skip, window=int(rng.integers(50, 5000)))
+    except Exception as e:          # noqa
+        bad += 1
+        print('MISMATCH at seed', seed0 + k, type(e).__name__, str(e)[:300], flush=True)
+print(f'{n} rounds, {bad} failures, {time.time() - t0:.1f} s')

@@ -946,6 +946,23 @@ def test_filter_region_stops_like_the_range(ctx):
         _check_subset_decode(ctx.decode_fetch(), exp_stream)
 
 
+def test_reference_base_stale_chunk_end_above_the_new_winner(ctx):
+    """Found by scratch/fuzz_gpu.py: the stale chunk_end can also be LARGER than the end of the new reference's first
+    provider.  add() then turns down a longer read of the first position group (it does not end beyond the stale
+    value) and the sweep never looks at it again -- columns past the short provider are 'N' -- while the composed
+    successor function would have picked it up as a candidate.  Such a start is flagged and redone by the event loop."""
+    recs = [bamio.pack_record("a", "A" * 100, [(100, "M")], ref_id=0, pos=0, tags=bamio.tag_z("MD", "100")),
+            bamio.pack_record("c", "G" * 35, [(35, "M")], ref_id=1, pos=6, tags=bamio.tag_z("MD", "35")),
+            bamio.pack_record("d", "T" * 56, [(56, "M")], ref_id=1, pos=6, tags=bamio.tag_z("MD", "56")),
+            bamio.pack_record("e", "C" * 30, [(30, "M")], ref_id=1, pos=50, tags=bamio.tag_z("MD", "30"))]
+    st = b"".join(recs)
+    stage(ctx, st)
+    for skip in (True, False):
+        ora = _check_refbase(ctx, st, skip_zero=skip)
+        col = {(int(r), int(p)): chr(b) for r, p, b in zip(ora.ref, ora.pos, ora.refbase)}
+        assert col[(1, 40)] == "G" and col[(1, 41)] == "N" and col[(1, 49)] == "N"
+
+
 def test_hist_reduce_single_rank_rccl(ctx):
     """bgp_hist_reduce through a real RCCL communicator (one rank): resolves librccl at run time,
     sums uint64 in place -- with one rank the histogram must come back unchanged."""
