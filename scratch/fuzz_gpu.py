@@ -28,6 +28,28 @@ for k in range(n):
         T.check_pileup(ctx, st, entries=False)
         for skip in (True, False):
             T._check_refbase(ctx, st, skip_zero=skip, window=int(rng.integers(50, 5000)))
+        info = ctx.pileup_run()
+        if len(info.runs):
+            lo, hi = int(info.runs[0]["start_pos"]), int(info.runs[0]["end_pos"])
+            a0 = int(rng.integers(lo, hi + 1)); b0 = int(rng.integers(a0, hi + 60))
+            T._check_refbase(ctx, st, mode=L.BGP_MAKE_PILEUP, skip_zero=bool(rng.integers(0, 2)), start_from=a0, end_at=b0)
+        try:
+            O.pileup(st, use_md=True)
+            T._check_snp(ctx, st, int(rng.integers(0, 6)), int(rng.integers(0, 4)), with_entries=bool(k % 2))
+        except O.OracleError:
+            pass
+        # region filter on a stacked stream: many reads per window (several scan rounds), random region
+        deep = T._md_stream(rng, int(rng.integers(1500, 4000)), p_gap=0.0, nref=2, p_ref=0.0005)
+        T.stage(ctx, deep)
+        T.check_pileup(ctx, deep, entries=False)
+        rid = int(rng.integers(0, 2)); rb = int(rng.integers(0, 9000)); re_ = rb + int(rng.integers(1, 4000))
+        T.stage(ctx, deep)
+        ctx.filter_region(rid, rb, re_)
+        kept, exp_stream = T._expected_region(deep, rid, rb, re_)
+        T._check_subset_decode(ctx.decode_fetch(), exp_stream)
+        if kept:
+            inf2 = ctx.pileup_run(); o2 = O.pileup(exp_stream)
+            assert (inf2.n_columns, inf2.sum_coverage, inf2.max_coverage) == (o2.n_columns, o2.sum_coverage, o2.max_coverage)
     except Exception as e:          # noqa
         bad += 1
         print('MISMATCH at seed', seed0 + k, type(e).__name__, str(e)[:300], flush=True)
