@@ -96,6 +96,7 @@ SYMBOLS = {
     "bgp_filter_region": (C.c_int, [_P, C.c_int32, C.c_uint32, C.c_uint32]),
     "bgp_load_bam_read_at": (C.c_int, [_P, C.c_char_p, C.c_uint64]),
     "bgp_record_voffset": (C.c_int, [_P, C.c_uint64, C.POINTER(C.c_uint64)]),
+    "bgp_bai_build": (C.c_int, [_P, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_uint64)]),
     "bgp_hist_reduce": (C.c_int, [_P, _P, _P, C.c_size_t]),
     "bgp_timing_enable": (C.c_int, [_P, C.c_int]),
     "bgp_timing_reset": (C.c_int, [_P]),

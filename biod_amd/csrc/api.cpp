@@ -133,7 +133,7 @@ int bgp_reset(bgp_ctx* c) {
     BGP_HIP(hipStreamSynchronize(c->stream));
     c->h_stage_len = 0; c->d_stream = nullptr; c->stream_len = 0; c->stream_on_device = false;
     c->flushed = false; c->piled = false; c->md_rows_ready = false; c->table_pending = false; c->n_records = 0; c->decoded_what = 0; c->it = bgp_ctx::Iter();
-    c->runs.clear(); c->stage_map.clear(); c->region_pending = false;
+    c->runs.clear(); c->stage_map.clear(); c->region_pending = false; c->bai_buildable = false;
     return BGP_OK;
 }
 
@@ -141,6 +141,7 @@ int bgp_push_inflated(bgp_ctx* c, const uint8_t* data, size_t len, uint64_t coff
     (void)coffset; (void)first_record_uoffset;   // boundaries are found and verified on the device (frame.hip)
     if (!c || (!data && len)) return BGP_EINVAL;
     if (c->flushed || c->stream_on_device) return BGP_ESTATE;
+    c->bai_buildable = false;
     BGP_TRY(c->h_stage.reserve_keep(c->h_stage_len + len, c->h_stage_len));
     memcpy(c->h_stage.as<uint8_t>() + c->h_stage_len, data, len);
     c->h_stage_len += len;
@@ -408,6 +409,7 @@ int bgp_load_bam_region(bgp_ctx* c, const char* path, bgp_bai* bai, int32_t ref_
     const int rc = bgp_bai_chunks(bai, ref_id, beg, end, &ch, &n);
     if (rc < 0) { c->last_error = "Invalid reference sequence index"; return rc; }                   // randomaccessmanager.d:205-207
     BGP_TRY(bai_stage_chunks(c, path, ch, n, n_threads));
+    c->bai_buildable = false;
     c->region_pending = true; c->region_ref = (uint32_t)ref_id; c->region_beg = beg; c->region_end = end;
     return BGP_OK;
 }
@@ -416,12 +418,14 @@ int bgp_filter_region(bgp_ctx* c, int32_t ref_id, uint32_t beg, uint32_t end) {
     if (!c->flushed) return BGP_ESTATE;
     BGP_HIP(hipSetDevice(c->device));
     BGP_TRY(ensure_table(c));
+    c->bai_buildable = false;
     return k_region_filter(c, (uint32_t)ref_id, beg, end);
 }
 int bgp_load_bam_read_at(bgp_ctx* c, const char* path, uint64_t voffset) {
     if (!c || !path) return BGP_EINVAL;
     if (c->flushed || c->stream_on_device) return BGP_ESTATE;
     if (c->refs.empty()) BGP_TRY(bai_load_header(c, path));
+    c->bai_buildable = false;
     return bai_stage_read_at(c, path, voffset);
 }
 int bgp_record_voffset(bgp_ctx* c, uint64_t record, uint64_t* voffset) {
@@ -433,6 +437,15 @@ int bgp_record_voffset(bgp_ctx* c, uint64_t record, uint64_t* voffset) {
     BGP_HIP(hipMemcpyAsync(&r, c->d_rec.as<bgp_record>() + record, sizeof r, hipMemcpyDeviceToHost, c->stream));
     BGP_HIP(hipStreamSynchronize(c->stream));
     return bai_record_voffset(c, r.rec_off, voffset);
+}
+int bgp_bai_build(bgp_ctx* c, const uint8_t** bytes, uint64_t* n_bytes) {
+    if (!c || !bytes || !n_bytes) return BGP_EINVAL;
+    if (!c->flushed) return BGP_ESTATE;
+    BGP_HIP(hipSetDevice(c->device));
+    BGP_TRY(ensure_table(c));
+    BGP_TRY(bai_build(c, c->bai_bytes));
+    *bytes = c->bai_bytes.data(); *n_bytes = c->bai_bytes.size();
+    return BGP_OK;
 }
 int bgp_n_ref(bgp_ctx* c, int32_t* n) { if (!c || !n) return BGP_EINVAL; *n = (int32_t)c->refs.size(); return BGP_OK; }
 int bgp_ref_info(bgp_ctx* c, int32_t id, const char** name, int32_t* length) {

@@ -158,6 +158,9 @@ int bgzf_load_bam(bgp_ctx* c, const char* path, int n_threads) {
         const uint32_t skip = b.uoff < q ? (uint32_t)(q - b.uoff) : 0u;
         c->stage_map.push_back(bgp_ctx::StageSeg{c->h_stage_len + (b.uoff + skip - q), b.isize - skip, b.coff, skip});
     }
+    c->bai_buildable = c->h_stage_len == 0;               // virtual offsets of ONE file: what createIndex needs
+    c->stage_end_coff = 0;
+    for (const Blk& b : blocks) if (b.isize) c->stage_end_coff = b.coff + b.cdata_off + b.cdata_len + 8;   // inputstream.d:447-450
     c->h_stage_len += rec_bytes;
     return BGP_OK;
 }

@@ -94,6 +94,8 @@ struct bgp_ctx {
     HostBuf h_stage; uint64_t h_stage_len = 0;        // pushed host bytes
     struct StageSeg { uint64_t staged; uint32_t len; uint64_t coff; uint32_t skip; };   // staged bytes [staged, +len) = block at coff, from uoffset skip
     std::vector<StageSeg> stage_map;                  // filled by the BGZF loaders (virtual offsets of records)
+    bool bai_buildable = false; uint64_t stage_end_coff = 0;   // one whole file staged: createIndex can run (bai_build.hip)
+    std::vector<uint8_t> bai_bytes;
     bool region_pending = false; uint32_t region_ref = 0, region_beg = 0, region_end = 0;   // bam[ref][beg..end]: filter applied by bgp_flush
     DevBuf d_stream_own;                              // device copy of pushed bytes
     const uint8_t* d_stream = nullptr; uint64_t stream_len = 0;
@@ -181,6 +183,7 @@ int bai_stage_chunks(bgp_ctx* c, const char* path, const bgp_chunk* chunks, uint
 int bai_load_header(bgp_ctx* c, const char* path);
 int bai_stage_read_at(bgp_ctx* c, const char* path, uint64_t voffset);
 int bai_record_voffset(bgp_ctx* c, uint64_t staged_off, uint64_t* voffset);
+int bai_build(bgp_ctx* c, std::vector<uint8_t>& out);         // bai_build.hip : createIndex over the staged file
 
 // device helpers shared by kernels
 #if defined(__HIPCC__)

@@ -85,6 +85,12 @@ class Context:
         L.check(L.lib().bgp_record_voffset(self._h, record, C.byref(v)), self._h)
         return v.value
 
+    def bai_build(self) -> bytes:
+        """createIndex (bai/indexing.d:353-366): the .bai bytes of the one whole file this context staged."""
+        p, n = C.POINTER(C.c_uint8)(), C.c_uint64()
+        L.check(L.lib().bgp_bai_build(self._h, C.byref(p), C.byref(n)), self._h)
+        return C.string_at(p, n.value)
+
     def staged_bytes(self) -> np.ndarray:
         """Host copy of the staged (inflated) record bytes; record i starts at rec['rec_off'][i]."""
         r = L.Records()
@@ -417,6 +423,21 @@ class BamReader:
         if self._bai is None:
             self._bai = BaiFile(self.filename)          # "BAM index file (.bai) must be provided", randomaccessmanager.d:201-203
         return self._bai
+
+    @property
+    def has_index(self) -> bool:                        # reader.d:150-152
+        import os
+        stem = self.filename.rsplit(".", 1)[0]             # baifile.d:92-121: x.bam.bai, then x.bai
+        return os.path.exists(self.filename + ".bai") or os.path.exists(stem + ".bai")
+
+    def createIndex(self, overwrite: bool = False, path: Optional[str] = None):
+        """reader.d:158-168: writes filename + ".bai" unless an index is there already."""
+        if self.has_index and not overwrite and path is None:
+            return
+        data = self.ctx.bai_build()
+        with open(path or self.filename + ".bai", "wb") as f:
+            f.write(data)
+        self._bai = None
 
     def _region_context(self) -> Context:
         if self._rctx is None:

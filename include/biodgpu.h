@@ -254,6 +254,16 @@ int bgp_load_bam_read_at(bgp_ctx* ctx, const char* bam_path, uint64_t voffset);
  * staged by bgp_load_bam / bgp_load_bam_region / bgp_load_bam_read_at. */
 int bgp_record_voffset(bgp_ctx* ctx, uint64_t record, uint64_t* voffset);
 
+/* createIndex (bio/std/hts/bam/bai/indexing.d:353-366; BamReader.createIndex, reader.d:158-164): the .bai of
+ * the file staged by ONE bgp_load_bam, after bgp_flush.  Evaluates IndexBuilder.put/finish (indexing.d:56-350,
+ * check_bins off) over the device record table: bin runs -> chunks with the same-block merge rule (:221-246),
+ * the 16 kb linear index with holes filled from the left (:134-185), the 37450 pseudo-bin (:197-202) and
+ * n_no_coor (:347).  Bins are written in ascending id order (the reference's order is druntime's hash order,
+ * :193).  *bytes is owned by ctx and valid until the next call.  BGP_EUNSORTED = the builder's "not
+ * coordinate-sorted" enforce (:253-268); BGP_EINVAL = a reference id beyond the header's table or a position
+ * beyond the linear index (a RangeError in the reference); BGP_ESTATE = anything but one whole file staged. */
+int bgp_bai_build(bgp_ctx* ctx, const uint8_t** bytes, uint64_t* n_bytes);
+
 /* Whole-BAM histogram reduce across ranks (the only collective of the path): sums `n` uint64
  * values in HBM over all ranks of an RCCL communicator (ncclComm_t passed as void*).
  * CPU equivalent: a fold over column.coverage (pileup.d:252). */

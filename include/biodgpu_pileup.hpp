@@ -8,6 +8,7 @@
 // kernels behind include/biodgpu.h.
 #pragma once
 #include <cstdint>
+#include <cstdio>
 #include <limits>
 #include <stdexcept>
 #include <string>
@@ -66,6 +67,19 @@ public:
         return *this;
     }
     uint64_t start_virtual_offset(uint64_t read_index) const { uint64_t v; check(bgp_record_voffset(ctx_, read_index, &v), ctx_); return v; }   // readrange.d:64-86
+    // createIndex (reader.d:158-168 -> bai/indexing.d:353-366): the .bai of the file this reader was opened on.
+    std::vector<uint8_t> index_bytes() const {
+        const uint8_t* p = nullptr; uint64_t n = 0;
+        check(bgp_bai_build(ctx_, &p, &n), ctx_);
+        return std::vector<uint8_t>(p, p + n);
+    }
+    void createIndex(const std::string& bai_filename) const {
+        const std::vector<uint8_t> b = index_bytes();
+        std::FILE* f = std::fopen(bai_filename.c_str(), "wb");
+        if (!f) throw std::runtime_error("cannot write " + bai_filename);
+        const size_t w = std::fwrite(b.data(), 1, b.size(), f);
+        if (std::fclose(f) != 0 || w != b.size()) throw std::runtime_error("short write to " + bai_filename);
+    }
     bgp_ctx* ctx() const { return ctx_; }
 
 private:

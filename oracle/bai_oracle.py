@@ -13,9 +13,15 @@ Follows, function by function:
   non_overlapping      bio/core/utils/algo.d:95-147
   read_chunks          bio/core/bgzf/inputstream.d:254-330    (StreamChunksSupplier: which bytes a chunk list yields)
   region_filter        bio/std/hts/bam/randomaccessmanager.d:366-462 (BamReadFilter, one region)
-Pinned by tests/test_oracle_bai.py against the reference's own checks: test/unittests.d:145-185
+  records_with_offsets readrange.d:51-68 + bgzf/inputstream.d:425-452,497-530 (reads!withOffsets)
+  build_index          bio/std/hts/bam/bai/indexing.d:56-350  (IndexBuilder.put / finish, check_bins off)
+  serialise_index      indexing.d:164-218,276-277,347         (bins ascending; the reference's order is hash order)
+The reader half is pinned by tests/test_oracle_bai.py against the reference's own checks: test/unittests.d:145-185
 (bam["large"][beg .. end] == naive filter for its 40 regions on bins.bam) and :192-206 (names of the first
 read of every reference found through startVirtualOffset + getReadAt).
+The WRITER half (build_index) is PARITY UNPINNED: the reference has no test, golden vector or fixture for
+createIndex (test/data's .bai files were written by another tool and differ in two spots).  It is checked by hand
+cases and through the reference's index consumers: the checks above must hold on the index it writes.
 """
 import os
 import struct
@@ -223,3 +229,160 @@ def region_filter(records, ref_id, beg, end):
 def region_reads(bam_path, bai, ref_id, beg, end):
     st = read_chunks(bam_path, get_chunks(bai, ref_id, beg, end))
     return st, region_filter(frame(st), ref_id, beg, end)
+
+
+# ---- BAI writer: IndexBuilder / createIndex (bio/std/hts/bam/bai/indexing.d:56-366) ---------------------------
+
+def records_with_offsets(bam_path):
+    """readsWithProgress!withOffsets (readrange.d:51-68, bgzf/inputstream.d:425-452,497-530) over a whole file:
+    -> (n_refs, [dict(ref, pos, end_pos, bin, unmapped, start_vo, end_vo)]).  The virtual offset of a stream
+    position on a block boundary is (start of the NEXT block, 0) -- readBlock moves on as soon as a block is spent."""
+    f = open(bam_path, "rb").read()
+    blocks, off, data = [], 0, bytearray()
+    while off + 4 <= len(f):
+        isize, d, nxt = _block_at(f, off)
+        blocks.append((len(data), isize, off, nxt))
+        data += d
+        off = nxt
+    assert data[:4] == b"BAM\1"
+    (l_text,) = struct.unpack_from("<i", data, 4)
+    q = 8 + l_text
+    (n_ref,) = struct.unpack_from("<i", data, q); q += 4
+    for _ in range(n_ref):
+        (l_name,) = struct.unpack_from("<i", data, q); q += 4 + l_name + 4
+    filled = [b for b in blocks if b[1] > 0]
+    end_coff = filled[-1][3] if filled else 0
+
+    def vo(u):
+        for ustart, isize, coff, _ in filled:
+            if ustart <= u < ustart + isize:
+                return (coff << 16) | (u - ustart)
+        return end_coff << 16
+
+    out = []
+    for off, ref, pos, end_pos, _ in frame(bytes(data[q:])):
+        bmn, fnc = struct.unpack_from("<II", data, q + off + 12)
+        (bs,) = struct.unpack_from("<i", data, q + off)
+        unmapped = bool((fnc >> 16) & 4)
+        out.append(dict(ref=ref, pos=pos, end_pos=pos if unmapped else end_pos, bin=bmn >> 16, unmapped=unmapped,
+                        start_vo=vo(q + off), end_vo=vo(q + off + 4 + bs)))
+    return n_ref, out
+
+
+class NotSorted(Exception):
+    pass
+
+
+def build_index(n_refs, reads):
+    """IndexBuilder.put / finish (indexing.d:281-350) with check_bins off, statement by statement.
+    -> (refs, no_coord): refs[i] = None for writeEmptyReference, else dict(bins={id: [[beg, end], ...]},
+    meta=(beg_vo, end_vo, mapped, unmapped), ioffsets=[...]).  The reference writes bins in druntime's
+    associative-array order (:193), which nothing pins -- callers compare the mapping, or serialise ascending."""
+    size = 37449 - 4680 + 1                                           # :273
+    st = dict(first=True, prev=None, chunks={}, beg=None, lin=[0] * size, wl=0,
+              no_coord=0, beg_vo=(1 << 64) - 1, end_vo=0, unmapped=0, mapped=0)
+    refs = []
+
+    def tolin(p):                                                     # :51-53
+        return 0 if p < 0 else p // WINDOW
+
+    def update_linear():                                              # :134-162
+        p = st["prev"]
+        b = tolin(p["pos"])
+        e = b if p["unmapped"] else tolin(p["pos"] + (p["end_pos"] - p["pos"]) - 1)
+        for i in range(b, e + 1):
+            if st["lin"][i] == 0:                                     # a D RangeError past the array: IndexError here
+                st["lin"][i] = p["start_vo"]
+        st["wl"] = max(st["wl"], e + 1)
+
+    def update_chunks():                                              # :221-246
+        p = st["prev"]
+        end = p["end_vo"]
+        cs = st["chunks"].setdefault(p["bin"], [])
+        if not cs or (cs[-1][1] >> 16) != (st["beg"] >> 16):
+            cs.append([st["beg"], end])
+        else:
+            cs[-1][1] = end
+        st["beg"] = end
+
+    def dump():                                                       # :164-218
+        io, last = [], 0
+        for v in st["lin"][:st["wl"]]:
+            if v == 0:
+                v = last
+            else:
+                last = v
+            io.append(v)
+        refs.append(dict(bins=st["chunks"], meta=(st["beg_vo"], st["end_vo"], st["mapped"], st["unmapped"]), ioffsets=io))
+        st["lin"] = [0] * size; st["wl"] = 0; st["chunks"] = {}
+        st["beg"] = st["prev"]["end_vo"]
+        st["beg_vo"] = st["end_vo"] = st["beg"]
+        st["unmapped"] = st["mapped"] = 0
+
+    def meta(r):                                                      # :118-132, scope(exit) of put
+        if r["ref"] == -1:
+            st["no_coord"] += 1
+        else:
+            if r["unmapped"]:
+                st["unmapped"] += 1
+            else:
+                st["mapped"] += 1
+            if st["beg_vo"] == (1 << 64) - 1:
+                st["beg_vo"] = r["start_vo"]
+            st["end_vo"] = r["end_vo"]
+
+    def put(r):
+        p = st["prev"]
+        if not st["first"] and r["ref"] != -1 and not (p["ref"] < r["ref"]):          # :253-268
+            if not (r["ref"] == p["ref"] and r["pos"] >= p["pos"]):
+                raise NotSorted()
+        try:
+            if r["ref"] < 0 or r["pos"] < 0:
+                return
+            if st["first"]:
+                st["prev"] = r; st["first"] = False; st["beg"] = r["start_vo"]
+                refs.extend([None] * r["ref"])
+                return
+            if r["ref"] > p["ref"]:
+                update_linear(); update_chunks(); dump()
+                refs.extend([None] * (r["ref"] - p["ref"] - 1))
+            if r["ref"] == p["ref"]:
+                update_linear()
+                if r["bin"] != p["bin"]:
+                    update_chunks()
+            st["prev"] = r
+        finally:
+            meta(r)
+
+    for r in reads:
+        put(r)
+    if not st["first"]:                                               # finish, :336-350
+        update_linear(); update_chunks(); dump()
+    last = st["prev"]["ref"] if st["prev"] else -1
+    refs.extend([None] * (n_refs - last - 1))
+    return refs, st["no_coord"]
+
+
+def serialise_index(n_refs, refs, no_coord):
+    """The bytes IndexBuilder streams out (:170-218,276-277,347), bins in ascending id order."""
+    out = bytearray(b"BAI\1") + struct.pack("<i", n_refs)
+    for r in refs:
+        if r is None:
+            out += struct.pack("<ii", 0, 0)
+            continue
+        out += struct.pack("<i", len(r["bins"]) + 1)
+        for bid in sorted(r["bins"]):
+            cs = r["bins"][bid]
+            out += struct.pack("<Ii", bid, len(cs))
+            for b, e in cs:
+                out += struct.pack("<QQ", b, e)
+        out += struct.pack("<IiQQQQ", 37450, 2, *r["meta"])
+        out += struct.pack("<i", len(r["ioffsets"])) + struct.pack(f"<{len(r['ioffsets'])}Q", *r["ioffsets"])
+    out += struct.pack("<Q", no_coord)
+    return bytes(out)
+
+
+def create_index(bam_path):
+    n_refs, reads = records_with_offsets(bam_path)
+    refs, no_coord = build_index(n_refs, reads)
+    return serialise_index(n_refs, refs, no_coord)

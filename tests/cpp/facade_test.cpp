@@ -11,7 +11,7 @@
 #define REQUIRE(x) do { if (!(x)) { std::fprintf(stderr, "FAILED %s:%d: %s\n", __FILE__, __LINE__, #x); return 1; } } while (0)
 
 int main(int argc, char** argv) {
-    if (argc < 3) { std::fprintf(stderr, "usage: %s ex1_header.bam illu_20_chunk.bam\n", argv[0]); return 2; }
+    if (argc < 3) { std::fprintf(stderr, "usage: %s ex1_header.bam illu_20_chunk.bam [bins.bam [copy_of_bins.bam]]\n", argv[0]); return 2; }
     using namespace biodgpu;
     {
         BamReader bam(argv[1], 2);
@@ -90,6 +90,20 @@ int main(int argc, char** argv) {
             for (uint64_t i = 0; i < recs.n; ++i)
                 naive += recs.rec[i].ref_id == 2 && recs.rec[i].pos < rg[1] && recs.rec[i].end_pos > rg[0];
             REQUIRE(bam.fetch(argv[3], "large", (uint32_t)rg[0], (uint32_t)rg[1], 2).num_reads() == naive);
+        }
+    }
+    if (argc > 4) {                                                      // createIndex, then the same region checks through the new index
+        std::string copy = argv[4];                                      // a copy of bins.bam with no .bai beside it
+        BamReader whole(copy, 2);
+        whole.createIndex(copy + ".bai");
+        BamReader all(copy, 2), bam(copy, 2);
+        bgp_records recs; check(bgp_decode_fetch(all.ctx(), 0, &recs), all.ctx());
+        const int regions[][2] = {{1400, 1500}, {0, 3000}, {50000, 50100}, {950000, 950100}};
+        for (auto& rg : regions) {
+            size_t naive = 0;
+            for (uint64_t i = 0; i < recs.n; ++i)
+                naive += recs.rec[i].ref_id == 2 && recs.rec[i].pos < rg[1] && recs.rec[i].end_pos > rg[0];
+            REQUIRE(bam.fetch(copy, "large", (uint32_t)rg[0], (uint32_t)rg[1], 2).num_reads() == naive);
         }
     }
     std::puts("facade ok");

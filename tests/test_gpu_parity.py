@@ -417,7 +417,10 @@ def test_cpp_facade(tmp_path, data_dir):
     exe = str(tmp_path / "facade_test")
     subprocess.check_call(["g++", "-std=c++17", "-O2", "-I" + os.path.join(root, "include"), os.path.join(root, "tests", "cpp", "facade_test.cpp"),
                            "-o", exe, "-L" + os.path.join(root, "biod_amd"), "-lbiodgpu", "-Wl,-rpath," + os.path.join(root, "biod_amd")])
-    out = subprocess.run([exe, os.path.join(data_dir, "ex1_header.bam"), os.path.join(data_dir, "illu_20_chunk.bam"), os.path.join(data_dir, "bins.bam")],
+    import shutil
+    copy = str(tmp_path / "bins_copy.bam")
+    shutil.copy(os.path.join(data_dir, "bins.bam"), copy)
+    out = subprocess.run([exe, os.path.join(data_dir, "ex1_header.bam"), os.path.join(data_dir, "illu_20_chunk.bam"), os.path.join(data_dir, "bins.bam"), copy],
                          capture_output=True, text=True)
     assert out.returncode == 0 and "facade ok" in out.stdout, out.stderr
 
@@ -988,3 +991,135 @@ def test_hist_reduce_single_rank_rccl(ctx):
         assert np.array_equal(after, depth_histogram(ora.cov))
     finally:
         rccl.ncclCommDestroy(comm)
+
+
+# ---- f3: createIndex (bai/indexing.d:56-366) -- the .bai of a staged file built from the device record table --------
+
+def _write_bgzf(path, payload, rng, eof=True, small=False):
+    """payload cut into BGZF blocks of random sizes: records straddle block boundaries freely."""
+    with open(path, "wb") as f:
+        at = 0
+        while at < len(payload):
+            n = int(rng.integers(1, 400)) if small else int(rng.integers(200, 65000))
+            f.write(bamio.bgzf_block(payload[at:at + n]))
+            at += n
+        if eof:
+            f.write(bamio.BGZF_EOF)
+
+
+def _check_created_index(path):
+    import bai_oracle as B
+    bam = BamReader(path, 2)
+    got = bam.ctx.bai_build()
+    exp = B.create_index(path)
+    assert got == exp
+    return bam, got
+
+
+@pytest.mark.parametrize("name", ["ex1_header.bam", "bins.bam", "tags.bam", "illu_20_chunk.bam", "ion_20_chunk.bam", "mg1655_chunk.bam", "b7_295_chunk.bam"])
+def test_create_index_fixtures(data_dir, name):
+    _check_created_index(os.path.join(data_dir, name))
+
+
+def test_created_index_answers_the_reference_region_checks(data_dir, tmp_path):
+    """unittests.d:145-185 again, this time through the index this library wrote."""
+    import shutil
+    src = os.path.join(data_dir, "bins.bam")
+    dst = str(tmp_path / "bins.bam")
+    shutil.copy(src, dst)
+    bam = BamReader(dst, 2)
+    assert not bam.has_index
+    bam.createIndex()
+    assert bam.has_index
+    all_rec = bam.reads.decode(0).rec
+    for beg, end in [(1400, 1500), (10, 123), (135, 1236), (0, 3000), (50000, 50100), (950000, 950100), (2**20 - 5, 2**20 + 40)]:
+        naive = int(np.sum((all_rec["ref_id"] == 2) & (all_rec["pos"] < end) & (all_rec["end_pos"] > beg)))
+        assert len(bam["large"][beg:end].names()) == naive, (beg, end)
+
+
+def _index_stream(rng, n_reads, n_ref, quirks):
+    recs, ref, pos = [], int(rng.integers(0, 2)), 0
+    if quirks:                                         # reads the builder skips, ahead of the first one it takes
+        for k in range(int(rng.integers(0, 3))):
+            recs.append(bamio.pack_record(f"pre{k}", "ACGT", [(4, "M")], ref_id=ref, pos=-1, flag=int(rng.choice([0, 4]))))
+    for i in range(n_reads):
+        if rng.random() < 0.02 and ref < n_ref - 1:
+            ref += int(rng.integers(1, 3)); ref = min(ref, n_ref - 1); pos = int(rng.integers(0, 100))
+            if quirks and rng.random() < 0.5:          # skipped read of the NEW reference: still counted for the old one
+                recs.append(bamio.pack_record(f"neg{i}", "AC", [(2, "M")], ref_id=ref, pos=-1))
+        pos += int(rng.choice([0, 1, 7, 300, 5000, 40000], p=[0.2, 0.3, 0.3, 0.1, 0.07, 0.03]))
+        ln = int(rng.choice([1, 30, 100, 20000, 70000], p=[0.05, 0.5, 0.35, 0.07, 0.03]))
+        ops = [(10, "M"), (ln, "N"), (10, "M")] if ln > 1000 else [(ln, "M")]
+        flag = 4 if rng.random() < 0.05 else 0
+        if quirks and rng.random() < 0.03:
+            ops = []                                   # nothing covered: end window = (pos - 1) / 16384
+        seq = "A" * sum(l for l, o in ops if o == "M")
+        rec = bytearray(bamio.pack_record(f"r{i}", seq, ops, ref_id=ref, pos=pos, flag=flag))
+        if quirks and rng.random() < 0.05:             # the bin field is taken as it is (check_bins off)
+            struct_bin = int(rng.choice([0, 1, 9, 73, 585, 4681, 4700, 37449, 40000]))
+            rec[14:16] = struct_bin.to_bytes(2, "little")
+        recs.append(bytes(rec))
+    for k in range(int(rng.integers(0, 4))):
+        recs.append(bamio.pack_record(f"u{k}", "ACGT", [], ref_id=-1, pos=-1, flag=4))
+    return recs
+
+
+def test_create_index_synthetic_file(tmp_path):
+    """A generator file (cfg3 read model, 60k reads, BamWriter block layout): device index == oracle index, bytes."""
+    from biod_amd.synth import CONFIGS
+    m = CONFIGS["cfg3"]                                # spliced reads: parent bins break the leaf runs
+    cfg = make_cfg(n_reads=60_000, n_ref=3, ref_len=20_000_000, read_len=m["read_len"], profile=m["profile"], seed=5)
+    st = host_stream(cfg)
+    offs = O.frame(st)
+    recs = [bytes(st[int(offs[i]):int(offs[i + 1]) if i + 1 < len(offs) else len(st)]) for i in range(len(offs))]
+    path = str(tmp_path / "synth.bam")
+    bamio.write_bam(path, [(f"chr{i + 1}", 1 << 28) for i in range(max(1, cfg.n_ref))], recs)
+    _check_created_index(path)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_create_index_random_files(tmp_path, seed):
+    rng = np.random.default_rng(7700 + seed)
+    n_ref = int(rng.integers(3, 9))
+    refs = [(f"c{i}", 1 << 29) for i in range(n_ref)]
+    recs = _index_stream(rng, int(rng.integers(50, 1500)), n_ref, quirks=seed % 2 == 1)
+    path = str(tmp_path / f"r{seed}.bam")
+    _write_bgzf(path, bamio.bam_header_bytes(refs) + b"".join(recs), rng, eof=seed % 3 != 2, small=seed % 4 == 3)
+    _check_created_index(path)
+
+
+def test_create_index_edges(tmp_path):
+    import bai_oracle as B
+    rng = np.random.default_rng(5)
+    refs = [("a", 1000), ("b", 1000), ("c", 1000)]
+    for tag, recs in {
+        "none": [],
+        "unplaced_only": [bamio.pack_record("u", "AC", [], ref_id=-1, pos=-1, flag=4)] * 3,
+        "skipped_only": [bamio.pack_record("s", "AC", [(2, "M")], ref_id=1, pos=-1)] * 2,
+        "last_reference": [bamio.pack_record("x", "ACGT", [(4, "M")], ref_id=2, pos=7)],
+    }.items():
+        path = str(tmp_path / f"{tag}.bam")
+        _write_bgzf(path, bamio.bam_header_bytes(refs) + b"".join(recs), rng)
+        _check_created_index(path)
+    # not coordinate-sorted: the builder's enforce (indexing.d:253-268)
+    bad = [bamio.pack_record("x", "ACGT", [(4, "M")], ref_id=1, pos=70), bamio.pack_record("y", "ACGT", [(4, "M")], ref_id=1, pos=69)]
+    path = str(tmp_path / "unsorted.bam")
+    _write_bgzf(path, bamio.bam_header_bytes(refs) + b"".join(bad), rng)
+    with pytest.raises(B.NotSorted):
+        B.create_index(path)
+    with pytest.raises(L.BiodGpuError) as e:
+        BamReader(path, 1).ctx.bai_build()
+    assert e.value.code == L.BGP_EUNSORTED
+    back = [bamio.pack_record("x", "ACGT", [(4, "M")], ref_id=1, pos=70), bamio.pack_record("y", "ACGT", [(4, "M")], ref_id=0, pos=90)]
+    path = str(tmp_path / "refback.bam")
+    _write_bgzf(path, bamio.bam_header_bytes(refs) + b"".join(back), rng)
+    with pytest.raises(B.NotSorted):
+        B.create_index(path)
+    with pytest.raises(L.BiodGpuError):
+        BamReader(path, 1).ctx.bai_build()
+    # anything but one whole file staged
+    c = Context()
+    c.push_inflated(bad[0]); c.flush()
+    with pytest.raises(L.BiodGpuError) as e:
+        c.bai_build()
+    assert e.value.code == L.BGP_ESTATE

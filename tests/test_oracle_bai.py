@@ -114,3 +114,68 @@ def test_abi_read_chunks_bytes(bins):
     hand = [[(a[0], a[0] + 40), (a[0] + 40, a[1])], [(a[0], (b[1] >> 16) << 16)], [(a[0] + 10, a[0] + 300)]]
     for ch in hand:
         assert read_chunks(path, np.array(ch, dtype=np.uint64).reshape(-1, 2)) == B.read_chunks(path, ch)
+
+
+# ---- the index writer (bai/indexing.d:56-366): restatement checks that need no GPU --------------------------------
+# The reference holds no test and no fixture for createIndex (the .bai files in test/data come from another tool:
+# their linear index starts at the second read and their last chunk ends behind the EOF block), so the writer's
+# oracle is pinned only through what the reference DOES check with an index: unittests.d:145-206 must hold on it.
+
+def test_built_index_answers_the_reference_region_checks(bins, tmp_path):
+    path, refs, st, recs, _ = bins
+    out = str(tmp_path / "bins.bam.bai")
+    open(out, "wb").write(B.create_index(path))
+    bai = B.parse_bai(out)
+    large = [n for n, _ in refs].index("large")
+    for beg, end in REGIONS:
+        _, got = B.region_reads(path, bai, large, beg, end)
+        assert [r[4] for r in got] == [r[4] for r in naive(recs, large, beg, end)], (beg, end)
+    for name in ("tiny", "small", "large"):
+        rid = [n for n, _ in refs].index(name)
+        _, got = B.region_reads(path, bai, rid, 0, refs[rid][1])
+        assert got[0][4] == f"{name}:r1:0..1:len1:bin4681:hexbin0x1249"
+
+
+def test_built_index_against_the_fixture_index(data_dir):
+    """Same bins and chunk starts as the test/data index on ex1 (the two writers differ in two documented spots)."""
+    path = os.path.join(data_dir, "ex1_header.bam")
+    n, reads = B.records_with_offsets(path)
+    mine, no_coord = B.build_index(n, reads)
+    fx = B.parse_bai(path)
+    assert no_coord == 0 and len(mine) == len(fx) == 2
+    for a, b in zip(mine, fx):
+        theirs = {k: v for k, v in b["bins"]}
+        assert sorted(a["bins"]) + [37450] == sorted(theirs)
+        for k, cs in a["bins"].items():
+            assert [c[0] for c in cs] == [c[0] for c in theirs[k]]
+        assert tuple(theirs[37450][1]) == a["meta"][2:]                       # mapped / unmapped counts
+        assert len(a["ioffsets"]) == len(b["ioffsets"])
+    assert sum(r["meta"][2] + r["meta"][3] for r in mine) == len(reads)
+
+
+def test_index_builder_by_hand():
+    """Five reads, offsets chosen by hand: one bin run merged across a block edge, one not, a hole in the linear index."""
+    K = 1 << 16
+    def rd(ref, pos, span, b, s, e, unmapped=False):
+        return dict(ref=ref, pos=pos, end_pos=pos + span, bin=b, unmapped=unmapped, start_vo=s, end_vo=e)
+    reads = [rd(1, 10, 50, 4681, 5 * K, 5 * K + 100),
+             rd(1, 20, 50, 4681, 5 * K + 100, 5 * K + 200),
+             rd(1, 16000, 1000, 585, 5 * K + 200, 9 * K + 7),              # straddles two 16 kb windows: parent bin
+             rd(1, 16390, 10, 4682, 9 * K + 7, 9 * K + 90),
+             rd(1, 70000, 10, 4685, 9 * K + 90, 12 * K),                   # windows 2 and 3 stay untouched
+             rd(-1, -1, 0, 4680, 12 * K, 12 * K + 50, True)]
+    refs, no_coord = B.build_index(3, reads)
+    assert no_coord == 1 and refs[0] is None and refs[2] is None
+    r = refs[1]
+    assert r["bins"] == {4681: [[5 * K, 5 * K + 200]], 585: [[5 * K + 200, 9 * K + 7]], 4682: [[9 * K + 7, 9 * K + 90]], 4685: [[9 * K + 90, 12 * K]]}
+    assert r["meta"] == (5 * K, 12 * K, 5, 0)
+    assert r["ioffsets"] == [5 * K, 5 * K + 200, 5 * K + 200, 5 * K + 200, 9 * K + 90]
+    raw = B.serialise_index(3, refs, no_coord)
+    assert raw[:8] == b"BAI\x01\x03\x00\x00\x00" and raw[-8:] == (1).to_bytes(8, "little")
+    # same bin again later in the file: joined only when the new chunk starts in the block the old one ended in
+    again = [rd(0, 5, 10, 4681, 2 * K, 2 * K + 40), rd(0, 6, 40000, 0, 2 * K + 40, 2 * K + 80), rd(0, 7, 10, 4681, 2 * K + 80, 3 * K),
+             rd(0, 8, 40000, 0, 3 * K, 4 * K + 1), rd(0, 9, 10, 4681, 4 * K + 1, 4 * K + 30)]
+    r0 = B.build_index(1, again)[0][0]
+    assert r0["bins"][4681] == [[2 * K, 3 * K], [4 * K + 1, 4 * K + 30]] and r0["bins"][0] == [[2 * K + 40, 2 * K + 80], [3 * K, 4 * K + 1]]
+    with pytest.raises(B.NotSorted):
+        B.build_index(1, [rd(0, 9, 1, 4681, K, K + 1), rd(0, 8, 1, 4681, K + 1, K + 2)])
