@@ -55,12 +55,30 @@ def parse():
     return ap.parse_args()
 
 
+def usable_cores():
+    """Host cores this process can really run on: the scheduler's affinity mask, cut by the cgroup CPU quota
+    (the GPU boxes show 256 logical CPUs under a 16-CPU cpu.max)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def cpu_baseline(cfg_name, n_sample):
     """The oracle (a C restatement of BioD's algorithm -- BioD itself is D and cannot be built here)
     timed on this box's host cores on a bounded sample of the same workload."""
     import oracle_lib as O
     from biod_amd.synth import host_stream_np, scaled
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     if n_sample <= 0:
         probe = host_stream_np(scaled(cfg_name, 20_000 if cfg_name != "cfg5" else 60))
         n_probe = 20_000 if cfg_name != "cfg5" else 60
@@ -76,7 +94,8 @@ def cpu_baseline(cfg_name, n_sample):
     out = {"value": round(n_sample / tp / 1e6, 4), "unit": "Mreads/s", "cores": cores, "kind": "port",
            "columns_per_s": round(rp.n_columns / tp, 1),
            "sample": f"{n_sample} reads of {cfg_name}'s read model at its coverage depth ({len(stream) / 1e6:.0f} MB inflated), "
-                     f"pileupChunks-style decomposition over {cores} threads, consumer touches coverage/n_starting_here/every base+quality"}
+                     f"pileupChunks-style decomposition over {cores} threads (= usable cores: {os.cpu_count()} logical CPUs, affinity and cgroup quota applied), "
+                     f"consumer touches coverage/n_starting_here/every base+quality"}
     if rs is not None:
         out["serial_value"] = round(n_sample / ts / 1e6, 4)
     return out

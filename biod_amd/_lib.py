@@ -16,6 +16,7 @@ SO_PATH = os.path.join(_HERE, "libbiodgpu.so")
 BGP_OK, BGP_EOF = 0, 1
 BGP_EINVAL, BGP_ETRUNC, BGP_ECIGAR, BGP_EDEVICE, BGP_ENOMEM, BGP_ESTATE, BGP_EMD, BGP_EUNSORTED, BGP_ESEQ = -1, -2, -3, -4, -5, -6, -7, -8, -9
 BGP_FETCH_SEQ, BGP_FETCH_QUAL, BGP_FETCH_CIGAR, BGP_FETCH_ALL = 1, 2, 4, 7
+BGP_FETCH_STREAM = 8
 BGP_PILEUP_COLUMNS, BGP_MAKE_PILEUP = 0, 1
 BGP_DEPTH_BINS = 65536
 BGP_SNP_NO, BGP_SNP_YES, BGP_SNP_TIE, BGP_SNP_NEEDS_ENTRIES = 0, 1, 2, 3
@@ -71,6 +72,7 @@ SYMBOLS = {
     "bgp_push_inflated": (C.c_int, [_P, _P, C.c_size_t, C.c_uint64, C.c_uint32]),
     "bgp_attach_device_stream": (C.c_int, [_P, _P, C.c_uint64]),
     "bgp_load_bam": (C.c_int, [_P, C.c_char_p, C.c_int]),
+    "bgp_load_bam_device": (C.c_int, [_P, C.c_char_p]),
     "bgp_n_ref": (C.c_int, [_P, C.POINTER(C.c_int32)]),
     "bgp_ref_info": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_char_p), C.POINTER(C.c_int32)]),
     "bgp_flush": (C.c_int, [_P]),

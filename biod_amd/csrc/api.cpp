@@ -102,9 +102,9 @@ static void release_all(bgp_ctx* c) {
                    &c->d_seq, &c->d_qual, &c->d_cigar, &c->d_pmax_end, &c->d_pmax_pos, &c->d_runs, &c->d_columns, &c->d_depth_hist, &c->d_pstats,
                    &c->d_tiles, &c->d_ck_off, &c->d_ck, &c->d_deep, &c->d_entry_off, &c->d_entries, &c->d_col_lo,
                    &c->d_md_row, &c->d_md_iv, &c->d_md_state, &c->d_refbase, &c->d_md_succ, &c->d_md_exit, &c->d_md_entry, &c->d_md_bmax, &c->d_snp, &c->d_rec2, &c->d_seq_off2, &c->d_cigar_off2,
-                   &c->d_flt[0], &c->d_flt[1], &c->d_flt[2], &c->d_flt[3], &c->d_flt[4], &c->d_flt[5]};
+                   &c->d_flt[0], &c->d_flt[1], &c->d_flt[2], &c->d_flt[3], &c->d_flt[4], &c->d_flt[5], &c->d_comp, &c->d_inf_blk};
     for (auto* b : d) b->release();
-    HostBuf* h[] = {&c->h_stage, &c->h_rec, &c->h_seq_off, &c->h_cigar_off, &c->h_seq, &c->h_qual, &c->h_cigar, &c->h_cols, &c->h_entry_off, &c->h_entries, &c->h_refbase, &c->h_snp};
+    HostBuf* h[] = {&c->h_stage, &c->h_rec, &c->h_seq_off, &c->h_cigar_off, &c->h_seq, &c->h_qual, &c->h_cigar, &c->h_cols, &c->h_entry_off, &c->h_entries, &c->h_refbase, &c->h_snp, &c->h_ring, &c->h_stream_copy};
     for (auto* b : h) b->release();
 }
 
@@ -217,6 +217,12 @@ int bgp_decode_fetch(bgp_ctx* c, uint32_t what, bgp_records* o) {
     o->qual = (what & BGP_FETCH_QUAL) ? c->h_qual.as<uint8_t>() : nullptr;
     o->cigar = (what & BGP_FETCH_CIGAR) ? c->h_cigar.as<uint32_t>() : nullptr;
     o->stream = c->h_stage_len ? c->h_stage.as<uint8_t>() : nullptr; o->stream_len = c->h_stage_len;
+    if (!c->h_stage_len && (what & BGP_FETCH_STREAM) && c->stream_len) {          // device-inflated or attached stream: copy on request
+        BGP_TRY(c->h_stream_copy.reserve(c->stream_len));
+        BGP_HIP(hipMemcpyAsync(c->h_stream_copy.p, c->d_stream, c->stream_len, hipMemcpyDeviceToHost, c->stream));
+        BGP_HIP(hipStreamSynchronize(c->stream));
+        o->stream = c->h_stream_copy.as<uint8_t>(); o->stream_len = c->stream_len;
+    }
     return BGP_OK;
 }
 
@@ -398,6 +404,12 @@ int bgp_load_bam(bgp_ctx* c, const char* path, int n_threads) {
     if (!c || !path) return BGP_EINVAL;
     if (c->flushed || c->stream_on_device) return BGP_ESTATE;
     return bgzf_load_bam(c, path, n_threads);
+}
+int bgp_load_bam_device(bgp_ctx* c, const char* path) {
+    if (!c || !path) return BGP_EINVAL;
+    if (c->flushed || c->stream_on_device || c->h_stage_len) return BGP_ESTATE;
+    BGP_HIP(hipSetDevice(c->device));
+    return bgzf_load_bam_device(c, path);
 }
 int bgp_load_bam_region(bgp_ctx* c, const char* path, bgp_bai* bai, int32_t ref_id, uint32_t beg, uint32_t end, int n_threads) {
     if (!c || !path || !bai) return BGP_EINVAL;

@@ -278,7 +278,7 @@ int inflate_piece(const uint8_t* f, const Piece& b, uint8_t* dst, uint8_t* scrat
 }
 
 int inflate_pieces(const MappedFile& mf, const std::vector<Piece>& pieces, uint8_t* dst, int n_threads) {
-    if (n_threads <= 0) n_threads = (int)std::thread::hardware_concurrency();
+    if (n_threads <= 0) n_threads = bgp_default_threads();
     n_threads = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_threads, pieces.size()));
     std::atomic<size_t> next{0}; std::atomic<int> status{BGP_OK};
     auto worker = [&]() {

@@ -9,6 +9,7 @@
 #include "common.h"
 
 #include <fcntl.h>
+#include <sched.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -17,6 +18,7 @@
 #include <algorithm>
 
 #include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <thread>
 
@@ -24,9 +26,10 @@ namespace {
 
 struct Blk { uint64_t coff; uint32_t cdata_off, cdata_len, crc, isize; uint64_t uoff; };
 
-int parse_blocks(const uint8_t* f, uint64_t n, std::vector<Blk>& out, std::string& err) {
-    uint64_t off = 0, uoff = 0;
-    while (off < n) {
+// Block headers from file offset `off` on, while off < stop; f[x] is readable for x < n (n = file size, or the end
+// of the bytes read so far -- a block is at most 64 KB, so a reader that holds 128 KB past `stop` sees it whole).
+int scan_blocks(const uint8_t* f, uint64_t n, uint64_t stop, uint64_t& off, uint64_t& uoff, std::vector<Blk>& out, std::string& err) {
+    while (off < stop) {
         if (n - off < 4) break;                                          // inputstream.d:76-84: short magic read -> end
         if (!(f[off] == 0x1F && f[off + 1] == 0x8B && f[off + 2] == 8 && f[off + 3] == 4)) { err = "wrong BGZF magic"; return BGP_EINVAL; }
         if (n - off < 12) { err = "truncated BGZF header"; return BGP_ETRUNC; }
@@ -60,6 +63,11 @@ int parse_blocks(const uint8_t* f, uint64_t n, std::vector<Blk>& out, std::strin
     return BGP_OK;
 }
 
+int parse_blocks(const uint8_t* f, uint64_t n, std::vector<Blk>& out, std::string& err) {
+    uint64_t off = 0, uoff = 0;
+    return scan_blocks(f, n, n, off, uoff, out, err);
+}
+
 int inflate_block(const uint8_t* f, const Blk& b, uint8_t* dst) {         // block.d:127-216
     if (b.isize == 0) return BGP_OK;
     z_stream zs; memset(&zs, 0, sizeof zs);
@@ -75,6 +83,20 @@ int inflate_block(const uint8_t* f, const Blk& b, uint8_t* dst) {         // blo
 }
 
 }  // namespace
+
+// Worker threads when the caller passes 0: the CPUs this process may run on (affinity mask), cut by the cgroup
+// CPU quota -- a container that shows 256 logical CPUs under a 16-CPU cpu.max inflates slower on 256 threads.
+int bgp_default_threads() {
+    int n = (int)std::thread::hardware_concurrency();
+    cpu_set_t set; CPU_ZERO(&set);
+    if (sched_getaffinity(0, sizeof set, &set) == 0 && CPU_COUNT(&set) > 0) n = std::min(n > 0 ? n : CPU_COUNT(&set), CPU_COUNT(&set));
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char q[32]; long long period = 0;
+        if (fscanf(f, "%31s %lld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) n = std::min<long long>(n, std::max<long long>(1, 2 * atoll(q) / period));
+        fclose(f);
+    }
+    return n < 1 ? 1 : n;
+}
 
 // BAM magic + header text + reference table (reader.d:111-116,579-597) from the first `avail` inflated bytes.
 // Returns 1 and the offset of the first record when complete, 0 when more bytes are needed, <0 on error.
@@ -102,13 +124,17 @@ int bgp_parse_bam_header(const uint8_t* p, uint64_t avail, std::vector<RefInfo>&
 }
 
 int bgzf_load_bam(bgp_ctx* c, const char* path, int n_threads) {
+    const bool verbose = getenv("BGP_VERBOSE") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    const auto t0 = now();
     const int fd = open(path, O_RDONLY);
     if (fd < 0) { c->last_error = std::string("cannot open ") + path; return BGP_EINVAL; }
     struct stat sb;
     if (fstat(fd, &sb) != 0) { close(fd); c->last_error = "fstat failed"; return BGP_EINVAL; }
     const size_t fsz = (size_t)sb.st_size;
     const uint8_t* file = fsz ? (const uint8_t*)mmap(nullptr, fsz, PROT_READ, MAP_PRIVATE, fd, 0) : nullptr;
-    close(fd);
+    struct CloseFd { int fd; ~CloseFd() { close(fd); } } close_fd{fd};
     if (fsz && file == (const uint8_t*)MAP_FAILED) { c->last_error = "mmap failed"; return BGP_EINVAL; }
     struct Unmap { const uint8_t* p; size_t n; ~Unmap() { if (p && n) munmap((void*)p, n); } } unmap{file, fsz};
 
@@ -116,6 +142,7 @@ int bgzf_load_bam(bgp_ctx* c, const char* path, int n_threads) {
     int rc = parse_blocks(file, fsz, blocks, c->last_error);
     if (rc < 0) return rc;
     const uint64_t total = blocks.empty() ? 0 : blocks.back().uoff + blocks.back().isize;
+    const auto t1 = now();
 
     // the header lives in the first block(s): inflate serially until it parses
     std::vector<uint8_t> head;
@@ -135,16 +162,32 @@ int bgzf_load_bam(bgp_ctx* c, const char* path, int n_threads) {
     const uint64_t rec_bytes = total - q;
     BGP_TRY(c->h_stage.reserve_keep(c->h_stage_len + rec_bytes + 16, c->h_stage_len));
     uint8_t* dst = c->h_stage.as<uint8_t>() + c->h_stage_len;
+    const auto t2 = now();
     if (head.size() > q) memcpy(dst, head.data() + q, head.size() - (size_t)q);       // tail of the last header block
-    if (n_threads <= 0) n_threads = (int)std::thread::hardware_concurrency();
+    if (n_threads <= 0) n_threads = bgp_default_threads();
     if (n_threads < 1) n_threads = 1;
     std::atomic<size_t> next{jh}; std::atomic<int> status{BGP_OK};
+    // Workers take BATCH consecutive blocks and pread their compressed bytes into a private buffer: touching the
+    // file through the mapping costs a page fault per 4 KB, and those serialise across threads (measured: the
+    // same 0.5 s on 16 and on 256 threads for 1.6 GB); a read() into memory that is already mapped does not.
+    constexpr size_t BATCH = 8;
     auto worker = [&]() {
+        std::vector<uint8_t> buf(BATCH * 65536 + 4096);
         for (;;) {
-            const size_t j = next.fetch_add(1);
-            if (j >= blocks.size() || status.load() < 0) return;
-            const int e = inflate_block(file, blocks[j], dst + (blocks[j].uoff - q));
-            if (e < 0) status.store(e);
+            const size_t j0 = next.fetch_add(BATCH);
+            if (j0 >= blocks.size() || status.load() < 0) return;
+            const size_t j1 = std::min(blocks.size(), j0 + BATCH);
+            const uint64_t beg = blocks[j0].coff, end = blocks[j1 - 1].coff + blocks[j1 - 1].cdata_off + blocks[j1 - 1].cdata_len + 8;
+            const uint8_t* base = file;                                                    // fallback: the mapping
+            if (end - beg <= buf.size()) {
+                size_t got = 0;
+                while (got < end - beg) { const ssize_t r = pread(fd, buf.data() + got, end - beg - got, (off_t)(beg + got)); if (r <= 0) break; got += (size_t)r; }
+                if (got == end - beg) base = buf.data() - beg;
+            }
+            for (size_t j = j0; j < j1; ++j) {
+                const int e = inflate_block(base, blocks[j], dst + (blocks[j].uoff - q));
+                if (e < 0) status.store(e);
+            }
         }
     };
     std::vector<std::thread> th;
@@ -152,6 +195,8 @@ int bgzf_load_bam(bgp_ctx* c, const char* path, int n_threads) {
     for (int t = 1; t < nt; ++t) th.emplace_back(worker);
     worker();
     for (auto& t : th) t.join();
+    if (verbose) fprintf(stderr, "[biodgpu] load_bam: %zu blocks, %.1f MB -> %.1f MB; block scan %.1f ms, header + pinned staging %.1f ms, inflate on %d threads %.1f ms\n",
+                         blocks.size(), fsz / 1e6, total / 1e6, ms(t0, t1), ms(t1, t2), nt, ms(t2, now()));
     if (status.load() < 0) { c->last_error = "zlib: corrupted BGZF block"; return status.load(); }
     for (const Blk& b : blocks) {                         // where every staged byte came from (withOffsets, readrange.d:64-86)
         if (b.uoff + b.isize <= q) continue;
@@ -162,5 +207,126 @@ int bgzf_load_bam(bgp_ctx* c, const char* path, int n_threads) {
     c->stage_end_coff = 0;
     for (const Blk& b : blocks) if (b.isize) c->stage_end_coff = b.coff + b.cdata_off + b.cdata_len + 8;   // inputstream.d:447-450
     c->h_stage_len += rec_bytes;
+    return BGP_OK;
+}
+
+// ---- device inflate: the file goes to HBM compressed, k_inflate (inflate.hip) does the rest -------------------------
+//
+// Phase A: reader threads pread 32 MB pieces into a pinned ring and push them to the device; the block headers are
+// walked on the host as the pieces arrive, in file order (each header names the next), from the ring itself.
+// Phase B: the BAM header is inflated on the host (its blocks only) to find the first record; every block from there
+// on gets a descriptor (CDATA offset, output offset = uncompressed offset - first record, ISIZE, CRC) and one wave.
+// No inflated byte exists on the host; the virtual-offset map is filled as in bgzf_load_bam.
+#include <condition_variable>
+#include <mutex>
+
+int bgzf_load_bam_device(bgp_ctx* c, const char* path) {
+    const bool verbose = getenv("BGP_VERBOSE") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    const auto t0 = now();
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) { c->last_error = std::string("cannot open ") + path; return BGP_EINVAL; }
+    struct CloseFd { int fd; ~CloseFd() { close(fd); } } close_fd{fd};
+    struct stat sb;
+    if (fstat(fd, &sb) != 0) { c->last_error = "fstat failed"; return BGP_EINVAL; }
+    const uint64_t fsz = (uint64_t)sb.st_size;
+    constexpr uint64_t CH = 32ull << 20, OV = 192ull << 10;
+    const uint64_t n_chunks = (fsz + CH - 1) / CH;
+    const int T = (int)std::max<uint64_t>(1, std::min<uint64_t>({8ull, (uint64_t)bgp_default_threads(), n_chunks}));
+    BGP_TRY(c->d_comp.reserve(fsz + 1024));
+    BGP_TRY(c->h_ring.reserve((size_t)T * (CH + OV)));
+    const auto t1 = now();
+
+    std::vector<Blk> blocks;
+    std::mutex mu; std::condition_variable cv;
+    uint64_t turn = 0, scan_off = 0, scan_uoff = 0; int scan_rc = BGP_OK; std::string scan_err;
+    std::atomic<uint64_t> next{0}; std::atomic<int> hip_rc{BGP_OK};
+    auto reader = [&](int t) {
+        if (hipSetDevice(c->device) != hipSuccess) { hip_rc.store(BGP_EDEVICE); }
+        hipStream_t s = nullptr;
+        if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) hip_rc.store(BGP_EDEVICE);
+        uint8_t* buf = c->h_ring.as<uint8_t>() + (size_t)t * (CH + OV);
+        for (;;) {
+            const uint64_t k = next.fetch_add(1);
+            if (k >= n_chunks) break;
+            if (s) (void)hipStreamSynchronize(s);                          // the previous piece has left this buffer
+            const uint64_t lo = k * CH, hi = std::min(fsz, lo + CH + OV);
+            uint64_t got = 0;
+            while (got < hi - lo) { const ssize_t r = pread(fd, buf + got, hi - lo - got, (off_t)(lo + got)); if (r <= 0) break; got += (uint64_t)r; }
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return turn == k; });
+                if (scan_rc == BGP_OK) {
+                    if (got < hi - lo) { scan_rc = BGP_ETRUNC; scan_err = "short read"; }
+                    else if (scan_off < lo) { scan_rc = BGP_EINVAL; scan_err = "BGZF block larger than 64 KB"; }
+                    else scan_rc = scan_blocks(buf - lo, hi, std::min(fsz, lo + CH), scan_off, scan_uoff, blocks, scan_err);
+                }
+                turn = k + 1;
+            }
+            cv.notify_all();
+            if (s && hip_rc.load() == BGP_OK &&
+                hipMemcpyAsync(c->d_comp.as<uint8_t>() + lo, buf, std::min(CH, fsz - lo), hipMemcpyHostToDevice, s) != hipSuccess) hip_rc.store(BGP_EDEVICE);
+        }
+        if (s) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < T; ++t) th.emplace_back(reader, t);
+    reader(0);
+    for (auto& x : th) x.join();
+    if (hip_rc.load() < 0) { c->last_error = "HIP error while uploading the compressed file"; return hip_rc.load(); }
+    if (scan_rc < 0) { c->last_error = scan_err; return scan_rc; }
+    const auto t2 = now();
+
+    // the BAM header: inflate its blocks on the host until it parses (reader.d:111-116,579-597)
+    const uint64_t total = blocks.empty() ? 0 : blocks.back().uoff + blocks.back().isize;
+    std::vector<uint8_t> head, cbuf(65536 + 64);
+    uint64_t q = 0; size_t jh = 0; int got = 0;
+    while (jh < blocks.size() && got == 0) {
+        const Blk& b = blocks[jh];
+        head.resize((size_t)(b.uoff + b.isize));
+        if ((uint64_t)pread(fd, cbuf.data(), b.cdata_len, (off_t)(b.coff + b.cdata_off)) != b.cdata_len) { c->last_error = "short read"; return BGP_ETRUNC; }
+        Blk local = b; local.coff = 0; local.cdata_off = 0;
+        memcpy(cbuf.data() + b.cdata_len, &b.crc, 4);
+        const int rc = inflate_block(cbuf.data(), local, head.data() + b.uoff);
+        if (rc < 0) { c->last_error = "zlib: corrupted BGZF block"; return rc; }
+        ++jh;
+        got = bgp_parse_bam_header(head.data(), head.size(), c->refs, &q, c->last_error);
+        if (got < 0) return got;
+    }
+    if (got == 0) { c->last_error = total < 4 ? "wrong BAM magic" : "truncated BAM header"; return total < 4 ? BGP_EINVAL : BGP_ETRUNC; }
+    c->n_ref_hint = (int32_t)c->refs.size();
+
+    constexpr uint64_t SLACK = 65536;                     // the block that holds the first record starts up to 64 KB before it
+    const uint64_t rec_bytes = total - q;
+    BGP_TRY(c->d_stream_own.reserve(SLACK + rec_bytes + 256));
+    std::vector<bgp_inflate_block> desc;
+    desc.reserve(blocks.size());
+    for (const Blk& b : blocks) {
+        if (!b.isize || b.uoff + b.isize <= q) continue;
+        desc.push_back(bgp_inflate_block{b.coff + b.cdata_off, SLACK + b.uoff - q, b.cdata_len, b.isize, b.crc, 0});
+    }
+    const uint32_t nb = (uint32_t)desc.size();
+    BGP_TRY(c->d_inf_blk.reserve((size_t)nb * (sizeof(bgp_inflate_block) + 4) + 64));
+    int32_t* d_status = (int32_t*)(c->d_inf_blk.as<uint8_t>() + (size_t)nb * sizeof(bgp_inflate_block));
+    std::vector<int32_t> st(nb, 0);
+    if (nb) {
+        BGP_HIP(hipMemcpyAsync(c->d_inf_blk.p, desc.data(), (size_t)nb * sizeof(bgp_inflate_block), hipMemcpyHostToDevice, c->stream));
+        BGP_TRY(inflate_blocks_device(c, c->d_comp.as<uint8_t>(), c->d_stream_own.as<uint8_t>(), c->d_inf_blk.as<bgp_inflate_block>(), nb, d_status, rec_bytes));
+        BGP_HIP(hipMemcpyAsync(st.data(), d_status, (size_t)nb * 4, hipMemcpyDeviceToHost, c->stream));
+    }
+    BGP_HIP(hipStreamSynchronize(c->stream));
+    for (uint32_t i = 0; i < nb; ++i)
+        if (st[i]) { c->last_error = "zlib: corrupted BGZF block (device inflate, block at " + std::to_string(desc[i].src) + ", reason " + std::to_string(st[i]) + ")"; return BGP_EINVAL; }
+    if (verbose) fprintf(stderr, "[biodgpu] load_bam_device: %zu blocks, %.1f MB -> %.1f MB; buffers %.1f ms, read + scan + upload on %d threads %.1f ms, header + inflate %.1f ms\n",
+                         blocks.size(), fsz / 1e6, total / 1e6, ms(t0, t1), T, ms(t1, t2), ms(t2, now()));
+    for (const Blk& b : blocks) {                         // where every stream byte came from (withOffsets, readrange.d:64-86)
+        if (b.uoff + b.isize <= q) continue;
+        const uint32_t skip = b.uoff < q ? (uint32_t)(q - b.uoff) : 0u;
+        c->stage_map.push_back(bgp_ctx::StageSeg{b.uoff + skip - q, b.isize - skip, b.coff, skip});
+    }
+    c->bai_buildable = true; c->stage_end_coff = 0;
+    for (const Blk& b : blocks) if (b.isize) c->stage_end_coff = b.coff + b.cdata_off + b.cdata_len + 8;
+    c->d_stream = c->d_stream_own.as<uint8_t>() + SLACK; c->stream_len = rec_bytes; c->stream_on_device = true;
     return BGP_OK;
 }

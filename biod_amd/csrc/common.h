@@ -98,6 +98,7 @@ struct bgp_ctx {
     std::vector<uint8_t> bai_bytes;
     bool region_pending = false; uint32_t region_ref = 0, region_beg = 0, region_end = 0;   // bam[ref][beg..end]: filter applied by bgp_flush
     DevBuf d_stream_own;                              // device copy of pushed bytes
+    DevBuf d_comp, d_inf_blk; HostBuf h_ring, h_stream_copy;         // device inflate: compressed file, block descriptors + status, pinned read ring
     const uint8_t* d_stream = nullptr; uint64_t stream_len = 0;
     bool stream_on_device = false;                    // d_stream valid
     std::vector<RefInfo> refs;
@@ -183,6 +184,10 @@ int bai_stage_chunks(bgp_ctx* c, const char* path, const bgp_chunk* chunks, uint
 int bai_load_header(bgp_ctx* c, const char* path);
 int bai_stage_read_at(bgp_ctx* c, const char* path, uint64_t voffset);
 int bai_record_voffset(bgp_ctx* c, uint64_t staged_off, uint64_t* voffset);
+struct bgp_inflate_block { uint64_t src, dst; uint32_t clen, isize, crc, pad; };   // CDATA at comp + src -> isize bytes at out + dst
+int inflate_blocks_device(bgp_ctx* c, const uint8_t* d_comp, uint8_t* d_out, const bgp_inflate_block* d_blk, uint32_t n_blk, int32_t* d_status, uint64_t out_bytes);   // inflate.hip
+int bgzf_load_bam_device(bgp_ctx* c, const char* path);      // bgzf_host.cpp : file -> HBM compressed -> k_inflate
+int bgp_default_threads();                                   // bgzf_host.cpp : affinity mask and cgroup quota applied
 int bai_build(bgp_ctx* c, std::vector<uint8_t>& out);         // bai_build.hip : createIndex over the staged file
 
 // device helpers shared by kernels

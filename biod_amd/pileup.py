@@ -67,6 +67,10 @@ class Context:
     def load_bam(self, path: str, n_threads: int = 0):
         L.check(L.lib().bgp_load_bam(self._h, path.encode(), n_threads), self._h)
 
+    def load_bam_device(self, path: str):
+        """bgp_load_bam with decompressBgzfBlock (block.d:127-216) on the device; no host copy of the stream."""
+        L.check(L.lib().bgp_load_bam_device(self._h, path.encode()), self._h)
+
     def load_bam_region(self, path: str, bai: "BaiFile", ref_id: int, beg: int, end: int, n_threads: int = 0):
         """bam[ref][beg .. end] (reference.d:73-81): stage the BAI chunks' records; flush() then keeps the overlapping reads."""
         L.check(L.lib().bgp_load_bam_region(self._h, path.encode(), bai.handle, ref_id, beg, end, n_threads), self._h)
@@ -94,7 +98,7 @@ class Context:
     def staged_bytes(self) -> np.ndarray:
         """Host copy of the staged (inflated) record bytes; record i starts at rec['rec_off'][i]."""
         r = L.Records()
-        L.check(L.lib().bgp_decode_fetch(self._h, 0, C.byref(r)), self._h)
+        L.check(L.lib().bgp_decode_fetch(self._h, L.BGP_FETCH_STREAM, C.byref(r)), self._h)
         return L.as_array(r.stream, r.stream_len, "u1")
 
     def references(self):

@@ -80,6 +80,11 @@ int bgp_attach_device_stream(bgp_ctx* ctx, const void* device_ptr, uint64_t len)
  * inputstream.d:386-483, block.d:127-216), BAM magic + header + reference table
  * (reader.d:111-116,579-597), then pushes every record block.  n_threads <= 0: all cores. */
 int bgp_load_bam(bgp_ctx* ctx, const char* path, int n_threads);
+/* The same file path with decompressBgzfBlock (block.d:127-216: raw DEFLATE, size check, CRC32 check) on the
+ * DEVICE: the file is read into HBM compressed, one wave inflates one BGZF block, the record stream never exists
+ * on the host (bgp_records.stream is NULL unless BGP_FETCH_STREAM asks for a copy).  For hosts with few cores per
+ * GPU.  Same errors as bgp_load_bam; a block that fails to inflate or fails its CRC is BGP_EINVAL. */
+int bgp_load_bam_device(bgp_ctx* ctx, const char* path);
 int bgp_n_ref(bgp_ctx* ctx, int32_t* n_ref);
 int bgp_ref_info(bgp_ctx* ctx, int32_t ref_id, const char** name, int32_t* length);   /* referenceinfo.d */
 
@@ -115,6 +120,7 @@ typedef struct bgp_records {
 #define BGP_FETCH_QUAL 2u
 #define BGP_FETCH_CIGAR 4u
 #define BGP_FETCH_ALL 7u
+#define BGP_FETCH_STREAM 8u   /* bgp_decode_fetch: also a host copy of the record stream when the loader kept none */
 /* Kernel K2 (4-bit seq -> chars, qual copy, CIGAR copy) + copy to host memory owned by the ctx. */
 int bgp_decode_fetch(bgp_ctx* ctx, uint32_t what, bgp_records* out);
 /* Same products left in HBM (device pointers); nothing is copied to the host. */

@@ -50,6 +50,14 @@ for k in range(n):
         if kept:
             inf2 = ctx.pileup_run(); o2 = O.pileup(exp_stream)
             assert (inf2.n_columns, inf2.sum_coverage, inf2.max_coverage) == (o2.n_columns, o2.sum_coverage, o2.max_coverage)
+        # createIndex: a random file with block edges anywhere, device bytes == oracle bytes
+        import os, tempfile
+        from biod_amd import bamio
+        n_ref = int(rng.integers(2, 9))
+        recs = T._index_stream(rng, int(rng.integers(20, 2500)), n_ref, quirks=bool(k % 2))
+        path = os.path.join(tempfile.gettempdir(), "fuzz_index.bam")
+        T._write_bgzf(path, bamio.bam_header_bytes([(f"c{i}", 1 << 29) for i in range(n_ref)]) + b"".join(recs), rng, eof=bool(k % 3), small=(k % 5 == 0))
+        T._check_created_index(path)
     except Exception as e:          # noqa
         bad += 1
         print('MISMATCH at seed', seed0 + k, type(e).__name__, str(e)[:300], flush=True)

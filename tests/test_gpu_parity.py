@@ -1123,3 +1123,93 @@ def test_create_index_edges(tmp_path):
     with pytest.raises(L.BiodGpuError) as e:
         c.bai_build()
     assert e.value.code == L.BGP_ESTATE
+
+
+# ---- f2: decompressBgzfBlock on the device (bgzf/block.d:127-216): k_inflate against zlib ---------------------------
+
+def _device_stream(path):
+    c = Context(0)
+    c.load_bam_device(path)
+    c.flush()
+    return c, c.staged_bytes().tobytes()
+
+
+@pytest.mark.parametrize("name", FIXTURES)
+def test_device_inflate_fixtures(data_dir, name):
+    path = os.path.join(data_dir, name)
+    hdr, st = bamio.read_bam(path)
+    c, got = _device_stream(path)
+    assert got == st
+    assert c.references() == [(n, l) for n, l in hdr.refs]
+    check_decode(c, st)
+    host = Context(0); host.load_bam(path, 2); host.flush()
+    n = host.num_records()
+    assert c.num_records() == n
+    for i in sorted({0, n // 2, n - 1} if n else set()):
+        assert c.record_voffset(i) == host.record_voffset(i)
+    assert c.bai_build() == host.bai_build()
+
+
+@pytest.mark.parametrize("name", ["corrupted_zlib_archive.bam", "duplicated_block_size.bam", "no_block_size.bam", "wrong_bc_subfield_length.bam", "wrong_extra_gzip_length.bam"])
+def test_device_inflate_negative_fixtures(data_dir, name):
+    """test/unittests.d:132-142: every malformed container is refused, on this path too."""
+    c = Context(0)
+    with pytest.raises(L.BiodGpuError):
+        c.load_bam_device(os.path.join(data_dir, name))
+        c.flush()
+
+
+@pytest.mark.parametrize("level,block", [(0, 30000), (1, 65000), (6, 65280), (9, 65536), (6, 700), (9, 40), (1, 5)])
+def test_device_inflate_block_types_and_sizes(tmp_path, level, block):
+    """Stored, fixed-code and dynamic-code DEFLATE blocks, from 5-byte to 64 KB BGZF blocks, records straddling."""
+    import zlib
+    rng = np.random.default_rng(level * 1000 + block)
+    st = _random_stream(rng, 1500 if block > 1000 else 120, quirks=False)
+    payload = bamio.bam_header_bytes([("a", 1 << 20), ("b", 1 << 20), ("c", 1 << 20)]) + st
+    path = str(tmp_path / "x.bam")
+    with open(path, "wb") as f:
+        for at in range(0, len(payload), block):
+            chunk = payload[at:at + block]
+            co = zlib.compressobj(level, zlib.DEFLATED, -15, 8, zlib.Z_FIXED if (level == 9 and block == 40) else zlib.Z_DEFAULT_STRATEGY)
+            cdata = co.compress(chunk) + co.flush()
+            f.write(bytes([31, 139, 8, 4, 0, 0, 0, 0, 0, 255, 6, 0, 66, 67, 2, 0]) + (len(cdata) + 25).to_bytes(2, "little") + cdata
+                    + (zlib.crc32(chunk) & 0xFFFFFFFF).to_bytes(4, "little") + len(chunk).to_bytes(4, "little"))
+        f.write(bamio.BGZF_EOF)
+    c, got = _device_stream(path)
+    assert got == st
+    check_decode(c, st)
+
+
+def test_device_inflate_synthetic_and_damage(tmp_path):
+    """A 150k-read generator file (long runs of equal quality bytes: overlapping matches) equals the host inflate;
+    one flipped bit anywhere in a block's CDATA, CRC or ISIZE is refused."""
+    cfg = scaled("cfg2", 150_000)
+    st = host_stream(cfg)
+    path = str(tmp_path / "s.bam")
+    rng = np.random.default_rng(3)
+    _write_bgzf(path, bamio.bam_header_bytes([(f"chr{i + 1}", 1 << 28) for i in range(max(1, cfg.n_ref))]) + st, rng)
+    c, got = _device_stream(path)
+    assert got == st
+    info = c.pileup_run()
+    host = Context(0); host.load_bam(path, 2); host.flush()
+    hinfo = host.pileup_run()
+    assert (info.n_columns, info.sum_coverage, info.max_coverage) == (hinfo.n_columns, hinfo.sum_coverage, hinfo.max_coverage)
+    raw = bytearray(open(path, "rb").read())
+    size = len(raw)
+    for trial in range(12):
+        bad = bytearray(raw)
+        at = int(rng.integers(200, size - 40))
+        bad[at] ^= 1 << int(rng.integers(0, 8))
+        p2 = str(tmp_path / f"bad{trial}.bam")
+        open(p2, "wb").write(bytes(bad))
+        host_ok = True
+        try:
+            h = Context(0); h.load_bam(p2, 2)
+        except L.BiodGpuError:
+            host_ok = False
+        dev_ok = True
+        try:
+            d = Context(0); d.load_bam_device(p2)
+        except L.BiodGpuError:
+            dev_ok = False
+        assert dev_ok == host_ok, (trial, at)
