@@ -409,12 +409,15 @@ class BamReader:
     """``new BamReader(filename)`` (reader.d:127-138): ``.reads`` is the range handed to makePileup;
     ``reader["chr1"][a:b]`` (reader.d opIndex -> reference.d:73-81) needs the ``.bai`` next to the file."""
 
-    def __init__(self, filename: str, n_threads: int = 0, ctx: Optional[Context] = None):
+    def __init__(self, filename: str, n_threads: int = 0, ctx: Optional[Context] = None, device_inflate: bool = False):
         self.filename = filename
         self.n_threads = n_threads
         self.ctx = ctx or Context()
         self.ctx.reset()
-        self.ctx.load_bam(filename, n_threads)
+        if device_inflate:                              # decompressBgzfBlock on the GPU (inflate.hip), for hosts with few cores
+            self.ctx.load_bam_device(filename)
+        else:
+            self.ctx.load_bam(filename, n_threads)
         self.reference_sequences = self.ctx.references()
         self.ctx.flush()
         self.reads = _LoadedReads(self.ctx)

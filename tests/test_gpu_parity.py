@@ -1213,3 +1213,14 @@ def test_device_inflate_synthetic_and_damage(tmp_path):
         except L.BiodGpuError:
             dev_ok = False
         assert dev_ok == host_ok, (trial, at)
+
+
+def test_bam_reader_with_device_inflate(data_dir):
+    """BamReader(filename, device_inflate=True): the reference's pileup checks (unittests.d:320-366) hold unchanged."""
+    bam = BamReader(os.path.join(data_dir, "ex1_header.bam"), device_inflate=True)
+    assert [n for n, _ in bam.reference_sequences] == ["chr1", "chr2"]
+    expected = {0: 1470, 1: 1567}
+    for column in pileupColumns(bam.reads):
+        expected[column.ref_id] -= 1
+    assert expected == {0: 0, 1: 0}
+    assert bam["chr2"][100:200].names() == BamReader(os.path.join(data_dir, "ex1_header.bam"))["chr2"][100:200].names()
