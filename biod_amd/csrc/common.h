@@ -141,6 +141,7 @@ struct bgp_ctx {
     DevBuf d_snp;
     DevBuf d_entry_off, d_entries, d_col_lo;
     DevBuf d_md_row, d_md_iv, d_md_state, d_refbase;   // MD path: per-record rows, provider intervals, per-run controller state, dense reference bases
+    DevBuf d_md_long, d_md_ck;                                    // long chunks of the provider chain: node list + counters, checkpoints
     DevBuf d_md_succ, d_md_exit, d_md_entry, d_md_bmax;           // parallel provider chain: successor function, per-segment exits, segment entries
     bool md_rows_ready = false;
 

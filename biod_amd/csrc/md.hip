@@ -51,17 +51,24 @@ __device__ __forceinline__ uint32_t to_uint_(const uint8_t* p, uint32_t n) { uin
 __device__ bool md_cache_front(MdRes& r) {                      // md/parse.d:85-109
     if (r.b >= r.e) return false;
     const uint8_t* m = r.md;
+    // the first eight chars of the rest of the tag in one load: an operation is parsed from registers (a number and
+    // the letter after it rarely take more), the byte loop only continues where an operation runs past them
+    const uint32_t avail = r.e - r.b;
+    uint64_t w = 0;
+    if (avail >= 8) __builtin_memcpy(&w, m + r.b, 8);
+    else for (uint32_t i = 0; i < avail; ++i) w |= (uint64_t)m[r.b + i] << (8 * i);
+    auto at = [&](uint32_t i) -> uint8_t { return i < 8 ? (uint8_t)(w >> (8 * i)) : m[r.b + i]; };
+    const uint8_t c0 = (uint8_t)w;
     MdOp o{0, 0, 0, 0, 0};
-    if (m[r.b] == '^') {
-        r.b++;
+    if (c0 == '^') {
         uint32_t len = 0;
-        while (r.b + len < r.e && is_upper_(m[r.b + len])) ++len;
-        o.type = 2; o.del_off = r.b; o.del_len = len; r.b += len;
-    } else if (is_digit_(m[r.b])) {
-        uint32_t len = 0;
-        while (r.b + len < r.e && is_digit_(m[r.b + len])) ++len;
-        o.type = 0; o.match = to_uint_(m + r.b, len); r.b += len;
-    } else { o.type = 1; o.ch = base16_norm(m[r.b]); r.b++; }
+        while (1 + len < avail && is_upper_(at(1 + len))) ++len;
+        o.type = 2; o.del_off = r.b + 1; o.del_len = len; r.b += 1 + len;
+    } else if (is_digit_(c0)) {
+        uint32_t len = 0; uint64_t v = 0;
+        while (len < avail && is_digit_(at(len))) { v = v * 10 + (uint64_t)(at(len) - '0'); ++len; }
+        o.type = 0; o.match = (uint32_t)v; r.b += len;
+    } else { o.type = 1; o.ch = base16_norm(c0); r.b++; }
     r.front = o;
     return true;
 }
@@ -148,15 +155,17 @@ __device__ int find_md(const uint8_t* s, const bgp_record& r, const uint8_t** va
 
 // ---------------------------------------------------------------------------------------------- dna(read)
 // The query bases dna(read) draws from: SEQ under the M/=/X ops only (md/reconstruct.d:58-96,199).
-struct QIter { const uint8_t* cg; const uint8_t* sq; uint32_t n_cig, op, in_op, q; bool empty; };
+struct QIter { const uint8_t* cg; const uint8_t* sq; uint32_t n_cig, op, in_op, q, raw; bool empty; };   // raw: CIGAR op `op`, loaded once per op (not once per base)
+__device__ __forceinline__ void q_load(QIter& it) { it.raw = it.op < it.n_cig ? ld_u32(it.cg + 4ull * it.op) : 0u; }
 __device__ void q_settle(QIter& it) {
     while (it.op < it.n_cig) {
-        const uint32_t raw = ld_u32(it.cg + 4ull * it.op);
+        const uint32_t raw = it.raw;
         if (cig_qc(raw)) {
             if (cig_rc(raw) && it.in_op < (raw >> 4)) return;
             if (!cig_rc(raw)) it.q += raw >> 4;
         }
         it.op++; it.in_op = 0;
+        q_load(it);
     }
     it.empty = true;
 }
@@ -168,47 +177,121 @@ __device__ __forceinline__ uint8_t q_front(const QIter& it) {
 }
 __device__ __forceinline__ void q_pop(QIter& it) { it.q++; it.in_op++; q_settle(it); }
 
-// Walks dna(read) (md/reconstruct.d:98-182).  Chars with index in [from, from+count) are stored to out
-// (out may be null).  Returns the number of chars the lazy range yields before it ends; *bad is set when
-// the range would stall on an empty query (the oracle's `bad`), *err on malformed aux data.
-__device__ uint32_t dna_walk(const uint8_t* s, const bgp_record& r, uint32_t from, uint32_t count, uint8_t* out, bool* bad, bool* err) {
-    *bad = false; *err = false;
+// dna(read) (md/reconstruct.d:98-182) as a resumable walk.  The state at the top of the loop -- MD parser, current
+// operation, CIGAR cursor, chars yielded so far -- is everything the range carries, so a snapshot of it (DnaCk) lets
+// another lane continue from that char: long reads are emitted in pieces (k6_ck_build / k6_emit_long below).
+struct DnaState { MdRes m; MdOp cur; uint32_t del_i; QIter q; uint32_t n; bool live; };
+struct DnaCk { uint64_t md_off; uint32_t b, e; int32_t rem; MdOp front, back, cur; uint32_t del_i, q_op, q_in, q_q, q_empty, n, node, pad; };
+constexpr uint32_t DNA_CK = 512, DNA_LONG = 4096;     // checkpoint spacing; chunks longer than DNA_LONG are emitted in pieces
+
+__device__ void dna_begin(DnaState& st, const uint8_t* s, const bgp_record& r, bool* err) {
+    *err = false; st.live = false; st.n = 0; st.del_i = 0;
     const uint8_t* md = nullptr; uint32_t mdn = 0;
     const int f = find_md(s, r, &md, &mdn);
-    if (f < 0) { *err = true; return 0; }
+    if (f < 0) { *err = true; return; }
     if (f == 0) mdn = 0;
     const uint32_t l_name = r.bin_mq_nl & 0xFFu, n_cig = r.flag_nc & 0xFFFFu;
-    QIter q; q.cg = s + r.rec_off + 36 + l_name; q.sq = q.cg + 4ull * n_cig; q.n_cig = n_cig; q.op = 0; q.in_op = 0; q.q = 0; q.empty = false;
+    QIter& q = st.q; q.cg = s + r.rec_off + 36 + l_name; q.sq = q.cg + 4ull * n_cig; q.n_cig = n_cig; q.op = 0; q.in_op = 0; q.q = 0; q.empty = false;
+    q_load(q);
     q_settle(q);
-    MdRes m;
-    mdf_init(m, md, mdn);
-    uint32_t n = 0;
-    if (md_empty(m)) return 0;
-    MdOp cur = m.front; mdf_pop_front(m);
-    uint32_t del_i = 0;
-    const uint32_t stop = out ? from + count : 0xFFFFFFFFu;
-    auto put = [&](uint8_t c) { if (out && n >= from && n < stop) out[n - from] = c; ++n; };
+    mdf_init(st.m, md, mdn);
+    if (md_empty(st.m)) return;
+    st.cur = st.m.front; mdf_pop_front(st.m);
+    st.live = true;
+}
+__device__ void dna_save(const DnaState& st, const uint8_t* s, uint32_t node, DnaCk& ck) {
+    ck.md_off = (uint64_t)(st.m.md - s); ck.b = st.m.b; ck.e = st.m.e; ck.rem = st.m.rem; ck.front = st.m.front; ck.back = st.m.back; ck.cur = st.cur;
+    ck.del_i = st.del_i; ck.q_op = st.q.op; ck.q_in = st.q.in_op; ck.q_q = st.q.q; ck.q_empty = st.q.empty; ck.n = st.n; ck.node = node; ck.pad = st.live;
+}
+__device__ void dna_restore(DnaState& st, const uint8_t* s, const bgp_record& r, const DnaCk& ck) {
+    st.m.md = s + ck.md_off; st.m.b = ck.b; st.m.e = ck.e; st.m.rem = ck.rem; st.m.front = ck.front; st.m.back = ck.back; st.cur = ck.cur;
+    st.del_i = ck.del_i; st.n = ck.n; st.live = ck.pad != 0;
+    const uint32_t l_name = r.bin_mq_nl & 0xFFu, n_cig = r.flag_nc & 0xFFFFu;
+    QIter& q = st.q; q.cg = s + r.rec_off + 36 + l_name; q.sq = q.cg + 4ull * n_cig; q.n_cig = n_cig; q.op = ck.q_op; q.in_op = ck.q_in; q.q = ck.q_q; q.empty = ck.q_empty != 0;
+    q_load(q);
+}
+// Runs until `stop` chars have been yielded or the range ends; chars with index >= from go to out[index - from]
+// (out may be null: then SEQ is never read).
+__device__ void dna_run(DnaState& st, const uint8_t* s, uint32_t from, uint32_t stop, uint8_t* out, bool* bad) {
+    *bad = false;
+    if (!st.live) return;
+    const uint8_t* md = st.m.md;
     for (;;) {
-        if (out && n >= stop) return n;
-        if (cur.type == 1) {
-            put((uint8_t)cur.ch);
-            if (q.empty) { *bad = true; return n; }
-            q_pop(q);
-        } else if (cur.type == 0) {
-            if (q.empty) { *bad = true; return n; }
-            put(q_front(q));
-            --cur.match;
-            q_pop(q);
-            if (cur.match != 0) continue;
+        if (st.n >= stop) return;
+        const bool keep = out && st.n >= from;
+        if (st.cur.type == 1) {
+            if (keep) out[st.n - from] = (uint8_t)st.cur.ch;
+            ++st.n;
+            if (st.q.empty) { *bad = true; st.live = false; return; }
+            q_pop(st.q);
+        } else if (st.cur.type == 0) {
+            if (st.q.empty) { *bad = true; st.live = false; return; }
+            if (keep) out[st.n - from] = q_front(st.q);
+            ++st.n;
+            --st.cur.match;
+            q_pop(st.q);
+            if (st.cur.match != 0) continue;
         } else {
-            if (cur.del_len == 0) { *bad = true; return n; }
-            put(base16_norm(md[cur.del_off + del_i]));
-            if (++del_i < cur.del_len) continue;
-            del_i = 0;
+            if (st.cur.del_len == 0) { *bad = true; st.live = false; return; }
+            if (keep) out[st.n - from] = base16_norm(md[st.cur.del_off + st.del_i]);
+            ++st.n;
+            if (++st.del_i < st.cur.del_len) continue;
+            st.del_i = 0;
         }
-        if (md_empty(m)) return n;
-        cur = m.front; mdf_pop_front(m);
+        if (md_empty(st.m)) { st.live = false; return; }
+        st.cur = st.m.front; mdf_pop_front(st.m);
     }
+}
+
+// The same walk one MD OPERATION at a time, nothing stored: the state dna_run would have at char index `target`
+// (or where the range ends / stalls before it).  A char-at-a-time walk makes a wave pay one operation's parse
+// latency at almost every step -- some lane is always at an operation boundary -- so the checkpoint pass uses this.
+__device__ bool q_advance(QIter& q, uint32_t k, uint32_t* done) {      // k times q_pop, as far as the CIGAR allows
+    *done = 0;
+    while (k) {
+        if (q.empty) return false;
+        const uint32_t left = (q.raw >> 4) - q.in_op, t = left < k ? left : k;
+        q.q += t; q.in_op += t; k -= t; *done += t;
+        q_settle(q);
+    }
+    return true;
+}
+__device__ void dna_skip(DnaState& st, uint32_t target) {
+    while (st.live && st.n < target) {
+        if (st.cur.type == 1) {
+            ++st.n;
+            if (st.q.empty) { st.live = false; return; }
+            q_pop(st.q);
+        } else if (st.cur.type == 0) {
+            if (st.q.empty) { st.live = false; return; }
+            const uint32_t want = st.cur.match < target - st.n ? st.cur.match : target - st.n;
+            uint32_t got;
+            const bool all = q_advance(st.q, want, &got);
+            st.n += got; st.cur.match -= got;
+            if (!all) { st.live = false; return; }
+            if (st.cur.match != 0) continue;
+        } else {
+            if (st.cur.del_len == 0) { st.live = false; return; }
+            const uint32_t left = st.cur.del_len - st.del_i, t = left < target - st.n ? left : target - st.n;
+            st.n += t; st.del_i += t;
+            if (st.del_i < st.cur.del_len) continue;
+            st.del_i = 0;
+        }
+        if (md_empty(st.m)) { st.live = false; return; }
+        st.cur = st.m.front; mdf_pop_front(st.m);
+    }
+}
+
+// Chars with index in [from, from+count) are stored to out (out may be null: the whole range is walked).  Returns
+// the number of chars the lazy range yields before it ends (or from+count when out stops it there); *bad is set
+// when the range would stall on an empty query (the oracle's `bad`), *err on malformed aux data.
+__device__ uint32_t dna_walk(const uint8_t* s, const bgp_record& r, uint32_t from, uint32_t count, uint8_t* out, bool* bad, bool* err) {
+    *bad = false;
+    DnaState st;
+    dna_begin(st, s, r, err);
+    if (*err) return 0;
+    dna_run(st, s, from, out ? from + count : 0xFFFFFFFFu, out, bad);
+    return st.n;
 }
 
 // Length of dna(read) and its `bad` flag without touching SEQ: the walk above only asks the query iterator
@@ -714,8 +797,12 @@ __global__ __launch_bounds__(64) void k6_top(const MdRow* rows, const Succ* ex, 
 // One wave per segment the chain enters: lane 0 re-walks the segment from its entry (nodes to LDS), then the
 // lanes expand dna(provider)[F - pos ...] up to the next provider's fetch column.
 struct EmitRun { uint64_t first, endrec, column_base; uint32_t start_pos, end_pos; };
+// A chunk longer than DNA_LONG chars (one long read providing tens of kilobases) is not walked here: it goes to
+// `longs`, gets one checkpoint per DNA_CK chars from k6_ck_build (a walk that never touches SEQ), and k6_emit_long
+// emits the pieces one lane each.  ctr[0] = long nodes, ctr[1] = pieces.
+struct LongNode { uint32_t rec, from, count, ck_base; uint64_t out_off; };
 __global__ __launch_bounds__(64) void k6_emit(const uint8_t* s, const bgp_record* rec, const MdRow* rows, const Succ* succ, const Succ* seg_entry, uint64_t slot_lo, uint64_t slot_n,
-                                              const EmitRun* er, uint32_t n_runs, ParOut* po, uint8_t* refbase) {
+                                              const EmitRun* er, uint32_t n_runs, ParOut* po, uint8_t* refbase, LongNode* longs, uint32_t longs_cap, unsigned int* ctr) {
     __shared__ uint32_t nd[SEG + 1], fc[SEG + 1];
     __shared__ uint32_t s_cnt, s_run;
     if (blockIdx.x >= slot_n) return;
@@ -744,9 +831,45 @@ __global__ __launch_bounds__(64) void k6_emit(const uint8_t* s, const bgp_record
         uint32_t endc = fc[k + 1];
         if (endc > R.end_pos) endc = R.end_pos;
         if (F >= endc) continue;
+        if (endc - F > DNA_LONG) {
+            const uint32_t at = atomicAdd(&ctr[0], 1u), pieces = (endc - F + DNA_CK - 1) / DNA_CK;
+            const uint32_t base = atomicAdd(&ctr[1], pieces);
+            if (at < longs_cap) longs[at] = LongNode{nd[k], F - rows[nd[k]].pos, endc - F, base, R.column_base + (F - R.start_pos)};
+            continue;
+        }
         bool bad, err;
         dna_walk(s, rec[nd[k]], F - rows[nd[k]].pos, endc - F, refbase + R.column_base + (F - R.start_pos), &bad, &err);
     }
+}
+
+__global__ __launch_bounds__(64) void k6_ck_build(const uint8_t* s, const bgp_record* rec, const LongNode* longs, uint32_t n_long, DnaCk* ck, uint32_t* piece_node) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_long) return;
+    const LongNode L = longs[i];
+    const uint32_t pieces = (L.count + DNA_CK - 1) / DNA_CK;
+    for (uint32_t j = 0; j < pieces; ++j) piece_node[L.ck_base + j] = i;
+    DnaState st; bool err, bad;
+    dna_begin(st, s, rec[L.rec], &err);
+    if (err) return;                                              // the pool is zero-filled: every piece of this node stays dead
+    (void)bad;
+    for (uint32_t j = 0; j < pieces; ++j) {
+        dna_skip(st, L.from + j * DNA_CK);
+        if (!st.live) return;                                     // the range ends (or stalls) before this piece
+        dna_save(st, s, i, ck[L.ck_base + j]);
+    }
+}
+
+__global__ __launch_bounds__(64) void k6_emit_long(const uint8_t* s, const bgp_record* rec, const LongNode* longs, const DnaCk* ck, const uint32_t* piece_node, uint32_t n_pieces, uint8_t* refbase) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_pieces) return;
+    const LongNode L = longs[piece_node[p]];
+    const uint32_t j = p - L.ck_base;
+    const DnaCk c = ck[p];
+    if (!c.pad) return;                                           // the range ended before this piece
+    DnaState st; bool bad;
+    dna_restore(st, s, rec[L.rec], c);
+    const uint32_t lo = L.from + j * DNA_CK, hi = min(L.from + L.count, lo + DNA_CK);
+    dna_run(st, s, lo, hi, refbase + L.out_off + (uint64_t)j * DNA_CK, &bad);
 }
 
 // ---------------------------------------------------------------------------------------------- isSNP
@@ -873,7 +996,9 @@ int k6_reference_bases(bgp_ctx* c, int skip_zero, uint32_t run_first, uint32_t r
     const char* mode = getenv("BGP_MD_CHAIN");                 // "seq": the event loop only; default: composed successors, event loop where premises fail
     const bool use_par = !(mode && !strcmp(mode, "seq"));
     const uint64_t n_slots = (n + SEG - 1) / SEG + nr + 1;
+    const uint32_t longs_cap = (uint32_t)std::min<uint64_t>(n_pos / DNA_LONG + nr + 64, 0x7FFFFFFFull);    // a long chunk covers > DNA_LONG columns of its run
     if (use_par) {
+        BGP_TRY(c->d_md_long.reserve(16 + (size_t)longs_cap * sizeof(LongNode)));
         BGP_TRY(c->d_md_succ.reserve((n + 1) * sizeof(Succ))); BGP_TRY(c->d_md_exit.reserve((n + 1) * sizeof(Succ))); BGP_TRY(c->d_md_entry.reserve(n_slots * sizeof(Succ)));
         BGP_HIP(hipMemcpyAsync(st + off_pr, pr.data(), sizeof(ParRun) * nr, hipMemcpyHostToDevice, c->stream));
         BGP_HIP(hipMemcpyAsync(st + off_er, er.data(), sizeof(EmitRun) * nr, hipMemcpyHostToDevice, c->stream));
@@ -899,6 +1024,7 @@ int k6_reference_bases(bgp_ctx* c, int skip_zero, uint32_t run_first, uint32_t r
                 const uint64_t lo = cr[k].first / SEG + k, hi = (cr[k].endrec ? (cr[k].endrec - 1) / SEG : 0) + k + 1;
                 BGP_HIP(hipMemsetAsync(c->d_md_entry.as<Succ>() + lo, 0xFF, (hi - lo) * sizeof(Succ), c->stream));
             }
+            BGP_HIP(hipMemsetAsync(c->d_md_long.p, 0, 16, c->stream));
             {
                 TimedRegion t(c, "k6_top", 0);
                 hipLaunchKernelGGL(k6_top, dim3(nr), dim3(64), 0, c->stream, c->d_md_row.as<MdRow>(), c->d_md_exit.as<Succ>(), (const ParRun*)(st + off_pr), (ParOut*)(st + off_po), c->d_md_entry.as<Succ>());
@@ -907,12 +1033,26 @@ int k6_reference_bases(bgp_ctx* c, int skip_zero, uint32_t run_first, uint32_t r
                 const uint64_t lo = cr[k].first / SEG + k, hi = (cr[k].endrec ? (cr[k].endrec - 1) / SEG : 0) + k + 1;
                 TimedRegion t(c, "k6_emit", c->runs[run_first + k].end_pos - c->runs[run_first + k].start_pos);
                 hipLaunchKernelGGL(k6_emit, dim3((unsigned)(hi - lo)), dim3(64), 0, c->stream, c->d_stream, c->d_rec.as<bgp_record>(), c->d_md_row.as<MdRow>(), c->d_md_succ.as<Succ>(),
-                                   c->d_md_entry.as<Succ>(), lo, hi - lo, (const EmitRun*)(st + off_er), nr, (ParOut*)(st + off_po), c->d_refbase.as<uint8_t>());
+                                   c->d_md_entry.as<Succ>(), lo, hi - lo, (const EmitRun*)(st + off_er), nr, (ParOut*)(st + off_po), c->d_refbase.as<uint8_t>(),
+                                   (LongNode*)(c->d_md_long.as<uint8_t>() + 16), longs_cap, c->d_md_long.as<unsigned int>());
             }
             BGP_HIP(hipGetLastError());
             std::vector<ParOut> po(nr);
+            unsigned int ctr[2] = {0, 0};
             BGP_HIP(hipMemcpyAsync(po.data(), st + off_po, sizeof(ParOut) * nr, hipMemcpyDeviceToHost, c->stream));
+            BGP_HIP(hipMemcpyAsync(ctr, c->d_md_long.p, sizeof ctr, hipMemcpyDeviceToHost, c->stream));
             BGP_HIP(hipStreamSynchronize(c->stream));
+            if (ctr[0]) {                                          // long chunks: checkpoints, then one lane per DNA_CK chars
+                if (ctr[0] > longs_cap) { c->last_error = "MD: more long chunks than columns / DNA_LONG"; return BGP_EDEVICE; }
+                BGP_TRY(c->d_md_ck.reserve((size_t)ctr[1] * (sizeof(DnaCk) + 4) + 64));
+                DnaCk* ck = c->d_md_ck.as<DnaCk>(); uint32_t* piece_node = (uint32_t*)(ck + ctr[1]);
+                BGP_HIP(hipMemsetAsync(ck, 0, (size_t)ctr[1] * sizeof(DnaCk), c->stream));
+                const LongNode* longs = (const LongNode*)(c->d_md_long.as<uint8_t>() + 16);
+                TimedRegion t(c, "k6_emit_long", (uint64_t)ctr[1] * DNA_CK);
+                hipLaunchKernelGGL(k6_ck_build, dim3((ctr[0] + 63) / 64), dim3(64), 0, c->stream, c->d_stream, c->d_rec.as<bgp_record>(), longs, ctr[0], ck, piece_node);
+                hipLaunchKernelGGL(k6_emit_long, dim3((ctr[1] + 63) / 64), dim3(64), 0, c->stream, c->d_stream, c->d_rec.as<bgp_record>(), longs, ck, piece_node, ctr[1], c->d_refbase.as<uint8_t>());
+                BGP_HIP(hipGetLastError());
+            }
             for (uint32_t k : ks) {
                 if (po[k].flagged) seq.push_back(k);
                 else { co[k] = ChainOut{po[k].ce_out, 0u, 0, 0u, -1}; }

@@ -39,6 +39,13 @@ with open(f"{out}/r01_pmc_hbm_traffic_cfg3_100M.csv", "w") as w:
         w.write(f"{k},{fk:.0f},{wk:.0f},{n},{int((2 * fk + wk) * 1024)}\n")
 print(open(f"{out}/r01_pmc_hbm_traffic_cfg3_100M.csv").read())
 PY
-rm -rf $OUT/stats $OUT/FETCH_SIZE $OUT/WRITE_SIZE
+# file-E2E with both loaders (host zlib / k_inflate), and the same run under rocprofv3 for k_inflate's launch time
+cd /root/repo
+BGP_VERBOSE=1 timeout 600 python scratch/e2e_file.py 10000000 2>&1 | grep -v "framing round" > $OUT/r01_file_e2e_10M.log
+cd /tmp
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/e2e -- python /root/repo/scratch/e2e_file.py 10000000 > /dev/null 2>&1
+find $OUT/e2e -name "*kernel_stats.csv" -exec cp {} $OUT/r01_rocprofv3_kernel_stats_file_e2e_10M.csv \;
+timeout 300 python /root/repo/scratch/bai_scale.py 4000000 > $OUT/r01_create_index_4M.log 2>&1
+rm -rf $OUT/stats $OUT/FETCH_SIZE $OUT/WRITE_SIZE $OUT/e2e
 cat $OUT/r01_bench_cfg3_100M.json | cut -c1-1200
 ls -la $OUT

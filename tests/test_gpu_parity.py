@@ -1224,3 +1224,61 @@ def test_bam_reader_with_device_inflate(data_dir):
         expected[column.ref_id] -= 1
     assert expected == {0: 0, 1: 0}
     assert bam["chr2"][100:200].names() == BamReader(os.path.join(data_dir, "ex1_header.bam"))["chr2"][100:200].names()
+
+
+def _long_md_read(rng, name, ref, pos, length, md_mode="full"):
+    """A long read (indel every ~40 bases) with its MD tag; md_mode: full | short (tag ends early) | over (claims more
+    than the CIGAR has) | none."""
+    ops, md, run, seq = [], "", 0, []
+    left = length
+    while left > 0:
+        m = int(min(left, rng.integers(10, 80)))
+        ops.append((m, "M")); left -= m
+        for _ in range(m):
+            if rng.random() < 0.04:
+                md += str(run) + "ACGT"[int(rng.integers(0, 4))]; run = 0
+            else:
+                run += 1
+        seq.append("".join("ACGT"[int(x)] for x in rng.integers(0, 4, m)))
+        if left > 0:
+            if rng.random() < 0.5:
+                k = int(rng.integers(1, 4)); ops.append((k, "I")); seq.append("".join("ACGT"[int(x)] for x in rng.integers(0, 4, k)))
+            else:
+                k = int(rng.integers(1, 5)); ops.append((k, "D"))
+                md += str(run) + "^" + "".join("ACGT"[int(x)] for x in rng.integers(0, 4, k)); run = 0
+    md += str(run)
+    if md_mode == "short":
+        md = md[:len(md) // 3]
+    elif md_mode == "over":
+        md += "A999"
+    tags = bamio.tag_z("XQ", "pad") if md_mode == "none" else bamio.tag_z("MD", md)
+    return bamio.pack_record(name, "".join(seq), ops, ref_id=ref, pos=pos, tags=tags)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_reference_base_long_chunks_in_pieces(ctx, seed):
+    """Chunks longer than 4096 chars go through checkpoints and one lane per 512 chars (k6_ck_build / k6_emit_long):
+    full tags, tags that end early (the pieces behind the end stay 'N'), tags that claim more than the CIGAR, short
+    reads in between, two references."""
+    rng = np.random.default_rng(880 + seed)
+    recs, pos, ref = [], 0, 0
+    for i in range(14):
+        if i == 8:
+            ref, pos = 1, 5
+        mode = ["full", "full", "short", "full", "over"][int(rng.integers(0, 5))] if seed else "full"
+        length = int(rng.integers(5000, 16000)) if i % 3 != 2 else int(rng.integers(30, 200))
+        recs.append(_long_md_read(rng, f"L{i}", ref, pos, length, mode))
+        pos += int(rng.integers(200, 7000))
+    st = b"".join(recs)
+    stage(ctx, st)
+    ctx.timing_enable(True); ctx.timing_reset()
+    try:
+        for skip in (True, False):
+            _check_refbase(ctx, st, skip_zero=skip, window=int(rng.integers(500, 9000)))
+        assert ctx.timing_get().get("k6_emit_long", {}).get("launches", 0) > 0      # the path under test did run
+    finally:
+        ctx.timing_enable(False)
+    info = ctx.pileup_run()
+    lo, hi = int(info.runs[0]["start_pos"]), int(info.runs[0]["end_pos"])
+    a = int(rng.integers(lo, hi)); b = int(rng.integers(a, hi + 50))
+    _check_refbase(ctx, st, mode=L.BGP_MAKE_PILEUP, skip_zero=False, start_from=a, end_at=b)
