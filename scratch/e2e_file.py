@@ -29,5 +29,6 @@ for rep in range(6):
     info = ctx.pileup_run(); t3 = time.perf_counter()
     if dev:
         k = ctx.timing_get().get("k_inflate")
-        print(f"   k_inflate {k['total_ms']:.2f} ms -> {k['algorithmic_bytes'] / k['total_ms'] / 1e6:.1f} GB/s of inflated bytes", flush=True)
+        if k:                                       # (only timed when the loader falls back to one launch)
+            print(f"   k_inflate {k['total_ms']:.2f} ms -> {k['algorithmic_bytes'] / k['total_ms'] / 1e6:.1f} GB/s of inflated bytes", flush=True)
     print(f"rep {rep} ({'device' if dev else 'host'} inflate): load {t1 - t0:.3f} s, flush (H2D + framing) {t2 - t1:.3f} s, pileup {t3 - t2:.3f} s -> {n / (t3 - t0) / 1e6:.1f} Mreads/s file-E2E, columns {info.n_columns}", flush=True)
