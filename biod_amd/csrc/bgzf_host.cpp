@@ -287,7 +287,6 @@ int bgzf_load_bam_device(bgp_ctx* c, const char* path) {
         head.resize((size_t)(b.uoff + b.isize));
         if ((uint64_t)pread(fd, cbuf.data(), b.cdata_len, (off_t)(b.coff + b.cdata_off)) != b.cdata_len) { c->last_error = "short read"; return BGP_ETRUNC; }
         Blk local = b; local.coff = 0; local.cdata_off = 0;
-        memcpy(cbuf.data() + b.cdata_len, &b.crc, 4);
         const int rc = inflate_block(cbuf.data(), local, head.data() + b.uoff);
         if (rc < 0) { c->last_error = "zlib: corrupted BGZF block"; return rc; }
         ++jh;
