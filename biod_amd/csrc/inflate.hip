@@ -19,9 +19,9 @@
 //   * short codes (<= 10 bits literal/length, <= 9 bits distance) resolve through a per-wave LDS table filled by
 //     decoding every prefix once in parallel; longer codes take the lane-parallel path above.
 // All decoder state is wave-uniform and lives in SGPRs (the wave index is passed through readfirstlane so the
-// compiler can see that).  What bounds the kernel is instruction issue, not memory: ~25 scalar instructions per
-// literal and ~100 per match at one SALU issue per SIMD every four cycles; measured 26 GB/s of inflated bytes on
-// a generator file (45 k blocks, 1.4 G symbols, 111 ms), 5x the 16-core host it replaces.  Two waits mattered:
+// compiler can see that).  What bounds the kernel is the serial chain per symbol (table lookup -> readfirstlane ->
+// scalar shifts -> branch), not memory: measured 26 GB/s of inflated bytes on a generator file (45 k blocks, 1.4 G
+// symbols, 111 ms), 5x the 16-core host it replaces; DESIGN.md lists what did and did not move it.  Two waits mattered:
 // on gfx9 one vmcnt counter covers loads and stores, so the input-chunk load is consumed inside its own branch
 // (not at every refill), and a match loads its source before the pending literals are stored.
 // Malformed input ends in a status code, never in a write outside [dst, dst + isize): every store is bounds-checked
