@@ -20,8 +20,8 @@
 //     decoding every prefix once in parallel; longer codes take the lane-parallel path above.
 // All decoder state is wave-uniform and lives in SGPRs (the wave index is passed through readfirstlane so the
 // compiler can see that).  What bounds the kernel is the serial chain per symbol (table lookup -> readfirstlane ->
-// scalar shifts -> branch), not memory: measured 26 GB/s of inflated bytes on a generator file (45 k blocks, 1.4 G
-// symbols, 111 ms), 5x the 16-core host it replaces; DESIGN.md lists what did and did not move it.  Two waits mattered:
+// scalar shifts -> branch), not memory: measured 30 GB/s of inflated bytes on a generator file (45 k blocks, 1.4 G
+// symbols, 96 ms), 6x the 16-core host it replaces; DESIGN.md lists what did and did not move it.  Two waits mattered:
 // on gfx9 one vmcnt counter covers loads and stores, so the input-chunk load is consumed inside its own branch
 // (not at every refill), and a match loads its source before the pending literals are stored.
 // Malformed input ends in a status code, never in a write outside [dst, dst + isize): every store is bounds-checked
@@ -68,11 +68,17 @@ __device__ unsigned long long g_stats[8];   // matches, dist <= 1k / 2k / 4k / 8
 __device__ __forceinline__ uint32_t rfl(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 __device__ __forceinline__ uint32_t rdl(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
 
+// The decoder's state is wave-uniform, and left alone the compiler keeps all of it in SGPRs: the profile then shows
+// the scalar pipe saturated (one SALU issue per SIMD every four cycles, 87 % busy) next to an idle vector pipe.  So
+// the bit buffer is made to LOOK lane-varying (every refill ORs in a zero the compiler cannot see through): shifts,
+// masks and table addresses become VALU work that issues beside the scalar control flow.
+__device__ __forceinline__ uint32_t opaque_zero() { uint32_t z; asm volatile("v_mov_b32 %0, 0" : "=v"(z)); return z; }
+
 struct Bits {                                       // wave-uniform bit reader over aligned dwords
-    const uint32_t* base; uint32_t n_dw; int lane;
+    const uint32_t* base; uint32_t n_dw; int lane; uint32_t vz;
     uint32_t chunk; int cur;                        // per lane: dword (cur * 64 + lane)
     uint64_t bb; int nb; uint32_t widx;
-    __device__ __forceinline__ uint64_t bitpos() const { return (uint64_t)widx * 32u - (uint32_t)nb; }   // bits consumed, from the aligned base
+    __device__ __forceinline__ uint64_t bitpos() const { return (uint64_t)widx * 32u - rfl((uint32_t)nb); }   // bits consumed, from the aligned base
     __device__ __forceinline__ uint32_t fetch() {
         const int ch = (int)(widx >> 6);
         if (ch != cur) {
@@ -87,10 +93,10 @@ struct Bits {                                       // wave-uniform bit reader o
         ++widx;
         return w;
     }
-    __device__ __forceinline__ void need32() { if (nb <= 32) { bb |= (uint64_t)fetch() << nb; nb += 32; } }
-    __device__ __forceinline__ uint32_t take(int n) { const uint32_t v = (uint32_t)bb & ((1u << n) - 1u); bb >>= n; nb -= n; return v; }
+    __device__ __forceinline__ void need32() { if ((int)rfl((uint32_t)nb) <= 32) { bb |= (uint64_t)(fetch() | vz) << nb; nb += 32; } }
+    __device__ __forceinline__ uint32_t take(int n) { const uint32_t v = rfl((uint32_t)bb & ((1u << n) - 1u)); bb >>= n; nb -= n; return v; }
     __device__ __forceinline__ void seek(uint64_t bit) {
-        widx = (uint32_t)(bit >> 5); nb = 0; bb = 0;
+        widx = (uint32_t)(bit >> 5); nb = (int)vz; bb = vz;
         need32();
         (void)take((int)(bit & 31u));
     }
@@ -134,7 +140,7 @@ __device__ bool build_code(const uint8_t* lens, int n, uint16_t* sym, Code& cd, 
 
 // one symbol: needs >= 15 bits in the buffer (zero-filled past the end of input).  ~0u: no code matches.
 __device__ __forceinline__ uint32_t decode_sym(Bits& B, const Code& cd, const uint16_t* sym, int lane) {
-    const uint32_t rev = __brev((uint32_t)B.bb & 0x7FFFu) >> 17;          // first stream bit = most significant of 15
+    const uint32_t rev = __brev(rfl((uint32_t)B.bb) & 0x7FFFu) >> 17;     // first stream bit = most significant of 15
     const uint32_t c = rev >> (15 - (lane & 15));
     const bool hit = lane >= 1 && lane <= 15 && (c - cd.first) < cd.count;
     const uint64_t m = __ballot(hit);
@@ -165,8 +171,9 @@ template <int BITS> __device__ void fill_lut(const Code& cd, const uint16_t* sym
 }
 
 template <int BITS> __device__ __forceinline__ uint32_t lookup_sym(Bits& B, const uint16_t* lut, const Code& cd, const uint16_t* sym, int lane) {
-    const uint32_t e = rfl(lut[(uint32_t)B.bb & ((1u << BITS) - 1u)]);
-    if (e & 15u) { (void)B.take((int)(e & 15u)); return e >> 4; }
+    const uint32_t ev = lut[(uint32_t)B.bb & ((1u << BITS) - 1u)];      // address and entry stay in VGPRs
+    const uint32_t e = rfl(ev);
+    if (e & 15u) { const uint32_t l = ev & 15u; B.bb >>= l; B.nb -= (int)l; return e >> 4; }
     return decode_sym(B, cd, sym, lane);
 }
 
@@ -188,7 +195,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_inflate(const uint8_t* __restric
 
     Bits B;
     const uint64_t a0 = bk.src & ~3ull;
-    B.base = (const uint32_t*)(comp + a0); B.n_dw = (uint32_t)(((bk.src & 3u) + bk.clen + 3u) >> 2); B.lane = lane; B.chunk = 0; B.cur = -1;
+    B.base = (const uint32_t*)(comp + a0); B.n_dw = (uint32_t)(((bk.src & 3u) + bk.clen + 3u) >> 2); B.lane = lane; B.chunk = 0; B.cur = -1; B.vz = opaque_zero();
     B.seek((bk.src & 3u) * 8u);
     const uint64_t end_bit = ((bk.src & 3u) + (uint64_t)bk.clen) * 8u;
 
@@ -263,9 +270,28 @@ __global__ __launch_bounds__(64 * WAVES) void k_inflate(const uint8_t* __restric
         fill_lut<DBITS>(dc, lds.dsym, lds.dlut, lane);
         // literal / length + distance symbols until end-of-block
         for (;;) {
-            B.need32();
-            uint32_t s = lookup_sym<LBITS>(B, lds.llut, lc, lds.lsym, lane);
-            if (s < 256u) {
+            // literals with short codes, the bulk of the symbols, stay in this inner loop: table hit, one byte into
+            // the lane register, a 64-byte store when it is full
+            uint32_t e, ev;
+            for (;;) {
+                B.need32();
+                ev = lds.llut[(uint32_t)B.bb & ((1u << LBITS) - 1u)];
+                e = rfl(ev);
+                if (e - 1u >= (256u << 4) - 1u) break;             // not a short-code literal (0: long code; >= 256 << 4: length / end of block)
+                const uint32_t l = ev & 15u;
+                B.bb >>= l; B.nb -= (int)l;
+                if ((uint32_t)lane == npend) lit = ev >> 4;
+                if (++npend == 64u) {
+                    if (pos + 64u > isize) break;                  // flush() reports the overrun below
+                    outp[pos + lane] = (uint8_t)lit;
+                    pos += 64u; npend = 0;
+                }
+            }
+            if (npend == 64u) { flush(); break; }
+            uint32_t s;
+            if (e & 15u) { const uint32_t l = ev & 15u; B.bb >>= l; B.nb -= (int)l; s = e >> 4; }
+            else s = decode_sym(B, lc, lds.lsym, lane);
+            if (s < 256u) {                                        // a literal with a long code
                 if ((uint32_t)lane == npend) lit = s;
                 if (++npend == 64u) { flush(); if (err) break; }
                 continue;
@@ -274,13 +300,25 @@ __global__ __launch_bounds__(64 * WAVES) void k_inflate(const uint8_t* __restric
             if (s == ~0u) { err = B.bitpos() > end_bit ? INF_OVERRUN_IN : INF_BAD_CODE; break; }
             s -= 257u;
             if (s >= 29u) { err = INF_BAD_CODE; break; }
-            const uint32_t le = s < 8u || s == 28u ? 0u : (s >> 2) - 1u;                   // RFC 1951 3.2.5, in closed form
-            const uint32_t len = (s < 8u ? 3u + s : s == 28u ? 258u : 3u + ((4u + (s & 3u)) << le)) + B.take((int)le);
+            // length and distance (RFC 1951 3.2.5 in closed form) on the vector pipe: the values are uniform, but the
+            // arithmetic runs in VGPRs (B.vz taints it) and only the two results are read back
+            const uint32_t sv = s | B.vz;
+            const uint32_t le = (sv < 8u || sv == 28u) ? 0u : (sv >> 2) - 1u;
+            const uint32_t lbase = sv < 8u ? 3u + sv : sv == 28u ? 258u : 3u + ((4u + (sv & 3u)) << le);
+            const uint32_t lextra = (uint32_t)B.bb & ((1u << le) - 1u);
+            B.bb >>= le; B.nb -= (int)le;
             B.need32();
-            const uint32_t ds = lookup_sym<DBITS>(B, lds.dlut, dc, lds.dsym, lane);
+            const uint32_t dev = lds.dlut[(uint32_t)B.bb & ((1u << DBITS) - 1u)];
+            const uint32_t du = rfl(dev);
+            uint32_t dsv, ds;
+            if (du & 15u) { const uint32_t l = dev & 15u; B.bb >>= l; B.nb -= (int)l; dsv = dev >> 4; ds = du >> 4; }
+            else { ds = decode_sym(B, dc, lds.dsym, lane); dsv = ds | B.vz; }
             if (ds >= 30u) { err = INF_BAD_CODE; break; }
-            const uint32_t de = ds < 4u ? 0u : (ds >> 1) - 1u;
-            const uint32_t dist = (ds < 4u ? 1u + ds : 1u + ((2u + (ds & 1u)) << de)) + B.take((int)de);
+            const uint32_t de = dsv < 4u ? 0u : (dsv >> 1) - 1u;
+            const uint32_t dbase = dsv < 4u ? 1u + dsv : 1u + ((2u + (dsv & 1u)) << de);
+            const uint32_t dextra = (uint32_t)B.bb & ((1u << de) - 1u);
+            B.bb >>= de; B.nb -= (int)de;
+            const uint32_t len = rfl(lbase + lextra), dist = rfl(dbase + dextra);
             // the common match (one step, source entirely in bytes already stored): its load is issued BEFORE the
             // pending literals' store, so the wait for the data is vmcnt(1) and does not sit behind that store
             if (len <= 64u && dist >= len + npend && dist <= pos + npend && pos + npend + len <= isize) {
