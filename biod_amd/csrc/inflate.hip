@@ -20,8 +20,8 @@
 //     decoding every prefix once in parallel; longer codes take the lane-parallel path above.
 // All decoder state is wave-uniform and lives in SGPRs (the wave index is passed through readfirstlane so the
 // compiler can see that).  What bounds the kernel is the serial chain per symbol (table lookup -> readfirstlane ->
-// scalar shifts -> branch), not memory: measured 30 GB/s of inflated bytes on a generator file (45 k blocks, 1.4 G
-// symbols, 96 ms), 6x the 16-core host it replaces; DESIGN.md lists what did and did not move it.  Two waits mattered:
+// scalar shifts -> branch), not memory: measured 32 GB/s of inflated bytes on a generator file (45 k blocks, 1.4 G
+// symbols, 89 ms), 6x the 16-core host it replaces; DESIGN.md lists what did and did not move it.  Two waits mattered:
 // on gfx9 one vmcnt counter covers loads and stores, so the input-chunk load is consumed inside its own branch
 // (not at every refill), and a match loads its source before the pending literals are stored.
 // Malformed input ends in a status code, never in a write outside [dst, dst + isize): every store is bounds-checked
@@ -303,8 +303,11 @@ __global__ __launch_bounds__(64 * WAVES) void k_inflate(const uint8_t* __restric
             // length and distance (RFC 1951 3.2.5 in closed form) on the vector pipe: the values are uniform, but the
             // arithmetic runs in VGPRs (B.vz taints it) and only the two results are read back
             const uint32_t sv = s | B.vz;
-            const uint32_t le = (sv < 8u || sv == 28u) ? 0u : (sv >> 2) - 1u;
-            const uint32_t lbase = sv < 8u ? 3u + sv : sv == 28u ? 258u : 3u + ((4u + (sv & 3u)) << le);
+            // branch-free: the extra-bit count and the base, selected by masks (a ?: on these "lane-varying" values
+            // would be compiled as divergent control flow)
+            const uint32_t l_small = 0u - (uint32_t)(sv < 8u), l_top = 0u - (uint32_t)(sv == 28u);
+            const uint32_t le = ((sv >> 2) - 1u) & ~(l_small | l_top);
+            const uint32_t lbase = ((3u + sv) & l_small) | (258u & l_top) | ((3u + ((4u + (sv & 3u)) << le)) & ~(l_small | l_top));
             const uint32_t lextra = (uint32_t)B.bb & ((1u << le) - 1u);
             B.bb >>= le; B.nb -= (int)le;
             B.need32();
@@ -314,23 +317,27 @@ __global__ __launch_bounds__(64 * WAVES) void k_inflate(const uint8_t* __restric
             if (du & 15u) { const uint32_t l = dev & 15u; B.bb >>= l; B.nb -= (int)l; dsv = dev >> 4; ds = du >> 4; }
             else { ds = decode_sym(B, dc, lds.dsym, lane); dsv = ds | B.vz; }
             if (ds >= 30u) { err = INF_BAD_CODE; break; }
-            const uint32_t de = dsv < 4u ? 0u : (dsv >> 1) - 1u;
-            const uint32_t dbase = dsv < 4u ? 1u + dsv : 1u + ((2u + (dsv & 1u)) << de);
+            const uint32_t d_small = 0u - (uint32_t)(dsv < 4u);
+            const uint32_t de = ((dsv >> 1) - 1u) & ~d_small;
+            const uint32_t dbase = ((1u + dsv) & d_small) | ((1u + ((2u + (dsv & 1u)) << de)) & ~d_small);
             const uint32_t dextra = (uint32_t)B.bb & ((1u << de) - 1u);
             B.bb >>= de; B.nb -= (int)de;
-            const uint32_t len = rfl(lbase + lextra), dist = rfl(dbase + dextra);
+            const uint32_t lenv = lbase + lextra, distv = dbase + dextra;
             // the common match (one step, source entirely in bytes already stored): its load is issued BEFORE the
-            // pending literals' store, so the wait for the data is vmcnt(1) and does not sit behind that store
-            if (len <= 64u && dist >= len + npend && dist <= pos + npend && pos + npend + len <= isize) {
-                const uint8_t* from = outp + pos + npend - dist;
+            // pending literals' store, so the wait for the data does not sit behind that store.  The four conditions
+            // len <= 64, dist >= len + npend, dist <= pos + npend, pos + npend + len <= isize as one sign test
+            // (all operands are below 2^17), evaluated on the vector pipe.
+            const uint32_t have = pos + npend;
+            const uint32_t neg = (64u - lenv) | (distv - lenv - npend) | (have - distv) | (isize - have - lenv);
+            if (__ballot((int32_t)neg >= 0)) {
                 uint8_t v = 0;
-                if ((uint32_t)lane < len) v = from[lane];
+                if ((uint32_t)lane < lenv) v = outp[have - distv + (uint32_t)lane];
                 if ((uint32_t)lane < npend) outp[pos + lane] = (uint8_t)lit;
-                pos += npend; npend = 0;
-                if ((uint32_t)lane < len) outp[pos + lane] = v;
-                pos += len;
+                if ((uint32_t)lane < lenv) outp[have + (uint32_t)lane] = v;
+                pos = have + rfl(lenv); npend = 0;
                 continue;
             }
+            const uint32_t len = rfl(lenv), dist = rfl(distv);
             flush();
             if (err) break;
             if (dist > pos) { err = INF_BAD_DISTANCE; break; }
