@@ -20,8 +20,8 @@
 //     decoding every prefix once in parallel; longer codes take the lane-parallel path above.
 // All decoder state is wave-uniform and lives in SGPRs (the wave index is passed through readfirstlane so the
 // compiler can see that).  What bounds the kernel is the serial chain per symbol (table lookup -> readfirstlane ->
-// scalar shifts -> branch), not memory: measured 32 GB/s of inflated bytes on a generator file (45 k blocks, 1.4 G
-// symbols, 89 ms), 6x the 16-core host it replaces; DESIGN.md lists what did and did not move it.  Two waits mattered:
+// scalar shifts -> branch), not memory: measured 42 GB/s of inflated bytes on a generator file (45 k blocks, 1.4 G
+// symbols, 69 ms), 8x the 16-core host it replaces; DESIGN.md lists what did and did not move it.  Two waits mattered:
 // on gfx9 one vmcnt counter covers loads and stores, so the input-chunk load is consumed inside its own branch
 // (not at every refill), and a match loads its source before the pending literals are stored.
 // Malformed input ends in a status code, never in a write outside [dst, dst + isize): every store is bounds-checked
@@ -179,7 +179,10 @@ template <int BITS> __device__ __forceinline__ uint32_t lookup_sym(Bits& B, cons
 
 constexpr int LBITS = 10, DBITS = 9;
 
-__global__ __launch_bounds__(64 * WAVES) void k_inflate(const uint8_t* __restrict__ comp, uint8_t* out, const bgp_inflate_block* __restrict__ blk, uint32_t n_blk, int32_t* status) {
+#ifndef BGP_INF_WAVES_PER_SIMD
+#define BGP_INF_WAVES_PER_SIMD 8   // 64 VGPRs (a few spills): once the scalar pipe stopped being the limit, occupancy became it (5: 90 ms, 6: 80, 7: 74, 8: 69)
+#endif
+__global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(BGP_INF_WAVES_PER_SIMD, BGP_INF_WAVES_PER_SIMD))) void k_inflate(const uint8_t* __restrict__ comp, uint8_t* out, const bgp_inflate_block* __restrict__ blk, uint32_t n_blk, int32_t* status) {
     __shared__ WaveLds lds_all[WAVES];
     __shared__ uint32_t crc_t[256];
     crc_t[threadIdx.x] = CRC.t[threadIdx.x];
