@@ -68,10 +68,10 @@ int parse_blocks(const uint8_t* f, uint64_t n, std::vector<Blk>& out, std::strin
     return scan_blocks(f, n, n, off, uoff, out, err);
 }
 
-int inflate_block(const uint8_t* f, const Blk& b, uint8_t* dst) {         // block.d:127-216
+int inflate_cdata(const uint8_t* cdata, const Blk& b, uint8_t* dst) {     // block.d:127-216; cdata = the block's compressed payload
     if (b.isize == 0) return BGP_OK;
     z_stream zs; memset(&zs, 0, sizeof zs);
-    zs.next_in = const_cast<Bytef*>(f + b.coff + b.cdata_off); zs.avail_in = b.cdata_len;
+    zs.next_in = const_cast<Bytef*>(cdata); zs.avail_in = b.cdata_len;
     if (inflateInit2(&zs, -15) != Z_OK) return BGP_ENOMEM;
     zs.next_out = dst; zs.avail_out = b.isize;
     const int e = inflate(&zs, Z_FINISH);
@@ -81,6 +81,7 @@ int inflate_block(const uint8_t* f, const Blk& b, uint8_t* dst) {         // blo
     if ((uint32_t)crc32(0, dst, b.isize) != b.crc) return BGP_EINVAL;
     return BGP_OK;
 }
+int inflate_block(const uint8_t* f, const Blk& b, uint8_t* dst) { return inflate_cdata(f + b.coff + b.cdata_off, b, dst); }   // f = the whole file
 
 }  // namespace
 
@@ -178,14 +179,16 @@ int bgzf_load_bam(bgp_ctx* c, const char* path, int n_threads) {
             if (j0 >= blocks.size() || status.load() < 0) return;
             const size_t j1 = std::min(blocks.size(), j0 + BATCH);
             const uint64_t beg = blocks[j0].coff, end = blocks[j1 - 1].coff + blocks[j1 - 1].cdata_off + blocks[j1 - 1].cdata_len + 8;
-            const uint8_t* base = file;                                                    // fallback: the mapping
+            bool local = false;                                                            // fallback: the mapping
             if (end - beg <= buf.size()) {
                 size_t got = 0;
                 while (got < end - beg) { const ssize_t r = pread(fd, buf.data() + got, end - beg - got, (off_t)(beg + got)); if (r <= 0) break; got += (size_t)r; }
-                if (got == end - beg) base = buf.data() - beg;
+                local = got == end - beg;
             }
             for (size_t j = j0; j < j1; ++j) {
-                const int e = inflate_block(base, blocks[j], dst + (blocks[j].uoff - q));
+                const Blk& b = blocks[j];
+                const uint8_t* cdata = local ? buf.data() + (b.coff - beg) + b.cdata_off : file + b.coff + b.cdata_off;
+                const int e = inflate_cdata(cdata, b, dst + (b.uoff - q));
                 if (e < 0) status.store(e);
             }
         }
@@ -286,8 +289,7 @@ int bgzf_load_bam_device(bgp_ctx* c, const char* path) {
         const Blk& b = blocks[jh];
         head.resize((size_t)(b.uoff + b.isize));
         if ((uint64_t)pread(fd, cbuf.data(), b.cdata_len, (off_t)(b.coff + b.cdata_off)) != b.cdata_len) { c->last_error = "short read"; return BGP_ETRUNC; }
-        Blk local = b; local.coff = 0; local.cdata_off = 0;
-        const int rc = inflate_block(cbuf.data(), local, head.data() + b.uoff);
+        const int rc = inflate_cdata(cbuf.data(), b, head.data() + b.uoff);
         if (rc < 0) { c->last_error = "zlib: corrupted BGZF block"; return rc; }
         ++jh;
         got = bgp_parse_bam_header(head.data(), head.size(), c->refs, &q, c->last_error);
