@@ -56,7 +56,7 @@ __constant__ CrcTables CRC = make_crc_tables();
 __constant__ uint8_t CLORDER[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
 constexpr int WAVES = 4;
-struct WaveLds { uint16_t llut[1024]; uint16_t dlut[512]; uint16_t lsym[288]; uint16_t dsym[32]; uint16_t csym[20]; uint8_t lens[352]; };
+struct WaveLds { uint16_t llut[1024]; uint16_t dlut[512]; uint16_t lsym[288]; uint16_t dsym[32]; uint16_t csym[20]; uint8_t lens[352]; uint32_t lcode[48], dcode[48]; };   // lcode/dcode: the two codes' first/count/offs per length, for the long-code path
 
 enum : int32_t { INF_OK = 0, INF_BAD_BLOCK_TYPE = 1, INF_BAD_STORED = 2, INF_BAD_CODE = 3, INF_BAD_LENGTHS = 4, INF_OVERRUN_OUT = 5, INF_BAD_DISTANCE = 6,
                  INF_OVERRUN_IN = 7, INF_SHORT_OUT = 8, INF_BAD_CRC = 9, INF_OVERSUBSCRIBED = 10 };
@@ -103,6 +103,10 @@ struct Bits {                                       // wave-uniform bit reader o
 };
 
 struct Code { uint32_t first, count, offs; };       // lane L (1..15): codes of length L
+// the literal/length and distance codes are only needed per lane when a code is longer than the table covers:
+// they wait in LDS instead of holding six VGPRs through the hot loop
+__device__ __forceinline__ void park_code(const Code& cd, uint32_t* at, int lane) { if (lane < 16) { at[lane] = cd.first; at[16 + lane] = cd.count; at[32 + lane] = cd.offs; } }
+__device__ __forceinline__ Code fetch_code(const uint32_t* at, int lane) { Code cd; cd.first = at[lane & 15]; cd.count = lane < 16 ? at[16 + lane] : 0u; cd.offs = at[32 + (lane & 15)]; return cd; }
 
 // lens[0..n) -> canonical code in lane registers + symbols sorted by (length, value) in sym.  false: over-subscribed.
 __device__ bool build_code(const uint8_t* lens, int n, uint16_t* sym, Code& cd, int lane) {
@@ -168,13 +172,6 @@ template <int BITS> __device__ void fill_lut(const Code& cd, const uint16_t* sym
         }
         lut[p] = len ? (uint16_t)((sym[idx] << 4) | len) : (uint16_t)0;
     }
-}
-
-template <int BITS> __device__ __forceinline__ uint32_t lookup_sym(Bits& B, const uint16_t* lut, const Code& cd, const uint16_t* sym, int lane) {
-    const uint32_t ev = lut[(uint32_t)B.bb & ((1u << BITS) - 1u)];      // address and entry stay in VGPRs
-    const uint32_t e = rfl(ev);
-    if (e & 15u) { const uint32_t l = ev & 15u; B.bb >>= l; B.nb -= (int)l; return e >> 4; }
-    return decode_sym(B, cd, sym, lane);
 }
 
 constexpr int LBITS = 10, DBITS = 9;
@@ -271,6 +268,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(BGP_
         }
         fill_lut<LBITS>(lc, lds.lsym, lds.llut, lane);
         fill_lut<DBITS>(dc, lds.dsym, lds.dlut, lane);
+        park_code(lc, lds.lcode, lane); park_code(dc, lds.dcode, lane);
         // literal / length + distance symbols until end-of-block
         for (;;) {
             // literals with short codes, the bulk of the symbols, stay in this inner loop: table hit, one byte into
@@ -293,7 +291,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(BGP_
             if (npend == 64u) { flush(); break; }
             uint32_t s;
             if (e & 15u) { const uint32_t l = ev & 15u; B.bb >>= l; B.nb -= (int)l; s = e >> 4; }
-            else s = decode_sym(B, lc, lds.lsym, lane);
+            else s = decode_sym(B, fetch_code(lds.lcode, lane), lds.lsym, lane);
             if (s < 256u) {                                        // a literal with a long code
                 if ((uint32_t)lane == npend) lit = s;
                 if (++npend == 64u) { flush(); if (err) break; }
@@ -318,7 +316,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(BGP_
             const uint32_t du = rfl(dev);
             uint32_t dsv, ds;
             if (du & 15u) { const uint32_t l = dev & 15u; B.bb >>= l; B.nb -= (int)l; dsv = dev >> 4; ds = du >> 4; }
-            else { ds = decode_sym(B, dc, lds.dsym, lane); dsv = ds | B.vz; }
+            else { ds = decode_sym(B, fetch_code(lds.dcode, lane), lds.dsym, lane); dsv = ds | B.vz; }
             if (ds >= 30u) { err = INF_BAD_CODE; break; }
             const uint32_t d_small = 0u - (uint32_t)(dsv < 4u);
             const uint32_t de = ((dsv >> 1) - 1u) & ~d_small;
