@@ -236,7 +236,9 @@ int bgzf_load_bam_device(bgp_ctx* c, const char* path) {
     const uint64_t fsz = (uint64_t)sb.st_size;
     constexpr uint64_t CH = 32ull << 20, OV = 192ull << 10;
     const uint64_t n_chunks = (fsz + CH - 1) / CH;
-    const int T = (int)std::max<uint64_t>(1, std::min<uint64_t>({8ull, (uint64_t)bgp_default_threads(), n_chunks}));
+    // readers: 4 and 8 threads both take ~65 ms for 1.6 GB on the measured box, 16 take 95, 24 take 140 (scratch/read_threads.sh)
+    const uint64_t t_max = getenv("BGP_READ_THREADS") ? (uint64_t)atoi(getenv("BGP_READ_THREADS")) : 8ull;
+    const int T = (int)std::max<uint64_t>(1, std::min<uint64_t>({t_max, (uint64_t)bgp_default_threads(), n_chunks}));
     BGP_TRY(c->d_comp.reserve(fsz + 1024));
     BGP_TRY(c->h_ring.reserve((size_t)T * (CH + OV)));
     const auto t1 = now();
