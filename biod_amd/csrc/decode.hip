@@ -51,7 +51,7 @@ __device__ __forceinline__ int find_rec(const uint64_t* off /*LDS, cnt+1*/, int 
 // swap the nibbles of every byte (stream order becomes little-endian nibble order), funnel-shift the
 // odd start away, spread 4 nibbles into 4 bytes, look the bytes up with two v_perm_b32.
 __device__ __forceinline__ uint4 expand16(const uint8_t* p, uint32_t odd) {
-    uint2 w; __builtin_memcpy(&w, p, 8);
+    uint2 w; __builtin_memcpy(&w, p, 8);                 // (non-temporal LOADS here cost 3 ms: neighbouring lanes' unaligned reads share lines)
     const uint32_t e = p[8];
     auto swp = [](uint32_t x) { return ((x & 0x0F0F0F0Fu) << 4) | ((x >> 4) & 0x0F0F0F0Fu); };
     const uint32_t s0 = swp(w.x), s1 = swp(w.y), s2 = swp(e);
@@ -116,8 +116,8 @@ __device__ __forceinline__ void unpack_group(const DecArgs& a, int cnt, const ui
                     if (SEQ) sv = merge16(sv, expand16(a.s + (s_info[j2].seq_ptr + (nq >> 1)), (uint32_t)nq & 1u), n1);
                     if (QUAL) { uint4 q2; __builtin_memcpy(&q2, a.s + (s_info[j2].qual_ptr - n1), 16); qv = merge16(qv, q2, n1); }
                 }
-                if (SEQ) *reinterpret_cast<uint4*>(a.seq + B) = sv;
-                if (QUAL) *reinterpret_cast<uint4*>(a.qual + B) = qv;
+                if (SEQ) nt_store16(a.seq + B, sv);
+                if (QUAL) nt_store16(a.qual + B, qv);
                 done = true;
             }
         }
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(256) void k12_fused(FusedArgs a) {
         block_excl2(lseq, ncig, &es, &ec, &ts, &tc, s_ws);
         if (valid) {
             const uint64_t so = carry_seq + es, co = carry_cig + ec;
-            a.rec_out[i] = rec; a.seq_off_out[i] = so; a.cig_off_out[i] = co;
+a.rec_out[i] = rec; a.seq_off_out[i] = so; a.cig_off_out[i] = co;       // (plain stores: K2 reads these rows right after, non-temporal ones cost it 0.3 ms)
             s_seq_off[threadIdx.x] = so; s_cig_off[threadIdx.x] = co;
             RecInfo ri;
             ri.cig_ptr = rec.rec_off + 36 + (rec.bin_mq_nl & 0xFFu);
