@@ -117,6 +117,7 @@ struct bgp_ctx {
 
     // record table (K1)
     DevBuf d_rec, d_seq_off, d_cigar_off;
+    DevBuf d_cig4; bool cig4_ok = false;              // first four raw CIGAR ops of every record (16 B, written by K1): K4's planner reads these, not the stream
     DevBuf d_rec2, d_seq_off2, d_cigar_off2, d_flt[6];   // region filter: compaction targets (swapped in) and scan scratch
     // decode arenas (K2)
     DevBuf d_seq, d_qual, d_cigar;
@@ -126,6 +127,7 @@ struct bgp_ctx {
     // pileup (K3/K4)
     DevBuf d_pmax_end, d_pmax_pos;                    // prefix maxima (u64 keys)
     DevBuf d_runs, d_columns, d_depth_hist, d_pstats, d_tiles, d_ck_off, d_ck, d_deep;
+    DevBuf d_slab, d_wcount, d_wdel, d_wslow;        // K4 plan: per-window descriptor slabs, counts, whole-window '-' levels, slow-read marks
     std::vector<bgp_run> runs;
     bgp_pileup_info pinfo{};
     bool piled = false;

@@ -172,7 +172,7 @@ struct FusedArgs {
     DecArgs d;
     const uint64_t* entry; const uint64_t* rec_base; const uint64_t* seq_base; const uint64_t* cig_base; const uint32_t* side;
     uint32_t side_cap, seg_bytes; uint64_t n_seg, sum_lseq, sum_ncig;
-    bgp_record* rec_out; uint64_t* seq_off_out; uint64_t* cig_off_out;
+    bgp_record* rec_out; uint64_t* seq_off_out; uint64_t* cig_off_out; uint4* cig4_out;
 };
 
 // exclusive prefix sums of two per-thread values over the 256 threads of the block + the block totals
@@ -213,6 +213,7 @@ __global__ __launch_bounds__(256) void k12_fused(FusedArgs a) {
         const bool valid = (int)threadIdx.x < cnt;
         bgp_record rec{};
         uint64_t lseq = 0, ncig = 0;
+        uint4 c4v = make_uint4(0, 0, 0, 0);                          // the record's first four CIGAR ops (the planner of K4 reads them from here)
         if (valid) {
             int g = 0;
 #pragma unroll
@@ -238,8 +239,12 @@ __global__ __launch_bounds__(256) void k12_fused(FusedArgs a) {
                     if (n_cig > 2) covered += cig_rc(c4.z) ? (c4.z >> 4) : 0u;
                     if (n_cig > 3) covered += cig_rc(c4.w) ? (c4.w >> 4) : 0u;
                     j0 = 4;
+                    c4v = make_uint4(c4.x, n_cig > 1 ? c4.y : 0u, n_cig > 2 ? c4.z : 0u, n_cig > 3 ? c4.w : 0u);
                 }
-                for (uint32_t j = j0; j < n_cig; ++j) { const uint32_t op = ld_u32(cg + 4 * j); covered += cig_rc(op) ? (op >> 4) : 0u; }   // read.d:261
+                for (uint32_t j = j0; j < n_cig; ++j) {                                                                                      // read.d:261
+                    const uint32_t op = ld_u32(cg + 4 * j); covered += cig_rc(op) ? (op >> 4) : 0u;
+                    if (j == 0) c4v.x = op; else if (j == 1) c4v.y = op; else if (j == 2) c4v.z = op; else if (j == 3) c4v.w = op;
+                }
             }
             rec.end_pos = (int32_t)((uint32_t)rec.pos + covered);     // read.d:1382
             lseq = (uint64_t)(uint32_t)rec.l_seq; ncig = n_cig;
@@ -248,7 +253,8 @@ __global__ __launch_bounds__(256) void k12_fused(FusedArgs a) {
         block_excl2(lseq, ncig, &es, &ec, &ts, &tc, s_ws);
         if (valid) {
             const uint64_t so = carry_seq + es, co = carry_cig + ec;
-a.rec_out[i] = rec; a.seq_off_out[i] = so; a.cig_off_out[i] = co;       // (plain stores: K2 reads these rows right after, non-temporal ones cost it 0.3 ms)
+            a.rec_out[i] = rec; a.seq_off_out[i] = so; a.cig_off_out[i] = co;       // (plain stores: K2 reads these rows right after, non-temporal ones cost it 0.3 ms)
+            a.cig4_out[i] = c4v;
             s_seq_off[threadIdx.x] = so; s_cig_off[threadIdx.x] = co;
             RecInfo ri;
             ri.cig_ptr = rec.rec_off + 36 + (rec.bin_mq_nl & 0xFFu);
@@ -302,6 +308,7 @@ int k12_fused_decode(bgp_ctx* c, uint32_t what) {
     c->table_pending = false;
     BGP_TRY(c->d_rec.reserve((n + 1) * sizeof(bgp_record)));
     BGP_TRY(c->d_seq_off.reserve((n + 1) * 8)); BGP_TRY(c->d_cigar_off.reserve((n + 1) * 8));
+    BGP_TRY(c->d_cig4.reserve((n + 1) * 16)); c->cig4_ok = true;
     if (what & BGP_FETCH_SEQ) BGP_TRY(c->d_seq.reserve(c->sum_lseq + 16));
     if (what & BGP_FETCH_QUAL) BGP_TRY(c->d_qual.reserve(c->sum_lseq + 16));
     if (what & BGP_FETCH_CIGAR) BGP_TRY(c->d_cigar.reserve(c->sum_ncig * 4 + 16));
@@ -313,6 +320,7 @@ int k12_fused_decode(bgp_ctx* c, uint32_t what) {
     a.entry = c->d_seg_entry.as<uint64_t>(); a.rec_base = c->d_seg_rec_base.as<uint64_t>(); a.seq_base = c->d_seg_seq_base.as<uint64_t>(); a.cig_base = c->d_seg_cig_base.as<uint64_t>();
     a.side = c->d_seg_side.as<uint32_t>(); a.side_cap = c->side_cap; a.seg_bytes = c->seg_bytes; a.n_seg = c->n_seg; a.sum_lseq = c->sum_lseq; a.sum_ncig = c->sum_ncig;
     a.rec_out = c->d_rec.as<bgp_record>(); a.seq_off_out = c->d_seq_off.as<uint64_t>(); a.cig_off_out = c->d_cigar_off.as<uint64_t>();
+    a.cig4_out = c->d_cig4.as<uint4>();
     const unsigned blocks = (unsigned)((c->n_seg + G_SEG - 1) / G_SEG);
     const bool S = what & BGP_FETCH_SEQ, Q = what & BGP_FETCH_QUAL, C = what & BGP_FETCH_CIGAR;
     uint64_t alg = n * (36 + 32 + 16) + c->sum_ncig * 4;    // what k1_emit accounts for ...

@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256) void k0_collect_errors(FrameArgs a) {
 struct EmitArgs {
     const uint8_t* s; uint64_t len; uint32_t seg_bytes; uint64_t n_seg;
     const uint64_t* entry; const uint64_t* rec_base; const uint64_t* seq_base; const uint64_t* cig_base;
-    bgp_record* rec; uint64_t* seq_off; uint64_t* cigar_off; uint64_t n_records, sum_lseq, sum_ncig;
+    bgp_record* rec; uint64_t* seq_off; uint64_t* cigar_off; uint4* cig4; uint64_t n_records, sum_lseq, sum_ncig;
 };
 
 // one lane per segment: second (L2-warm) chase that writes the record table
@@ -159,13 +159,16 @@ __global__ __launch_bounds__(256) void k1_emit(EmitArgs a) {
         rec.rec_off = off;
         const uint32_t l_name = rec.bin_mq_nl & 0xFFu, n_cig = rec.flag_nc & 0xFFFFu;
         uint32_t covered = 0;
+        uint32_t c4[4] = {0, 0, 0, 0};
         if (!((rec.flag_nc >> 16) & 0x4u) && n_cig <= LONG_CIGAR) { // read.d:257-259 is_unmapped -> 0; long CIGARs: k1_long_cigar
             const uint8_t* cg = p + 36 + l_name;                  // read.d:988-990 _cigar_offset
             for (uint32_t j = 0; j < n_cig; ++j) {
                 const uint32_t op = ld_u32(cg + 4 * j);
                 covered += cig_rc(op) ? (op >> 4) : 0u;           // read.d:261
+                if (j < 4) c4[j] = op;
             }
         }
+        a.cig4[r] = make_uint4(c4[0], c4[1], c4[2], c4[3]);
         rec.end_pos = (int32_t)((uint32_t)rec.pos + covered);     // read.d:1382
         a.rec[r] = rec;
         a.seq_off[r] = so;
@@ -298,10 +301,11 @@ int k1_table(bgp_ctx* c) {
     const unsigned lane_blocks = (unsigned)((n_seg + 255) / 256);
     BGP_TRY(c->d_rec.reserve((n + 1) * sizeof(bgp_record)));
     BGP_TRY(c->d_seq_off.reserve((n + 1) * 8)); BGP_TRY(c->d_cigar_off.reserve((n + 1) * 8));
+    BGP_TRY(c->d_cig4.reserve((n + 1) * 16)); c->cig4_ok = true;
     EmitArgs e;
     e.s = c->d_stream; e.len = c->stream_len; e.seg_bytes = c->seg_bytes; e.n_seg = n_seg; e.entry = c->d_seg_entry.as<uint64_t>();
     e.rec_base = c->d_seg_rec_base.as<uint64_t>(); e.seq_base = c->d_seg_seq_base.as<uint64_t>(); e.cig_base = c->d_seg_cig_base.as<uint64_t>();
-    e.rec = c->d_rec.as<bgp_record>(); e.seq_off = c->d_seq_off.as<uint64_t>(); e.cigar_off = c->d_cigar_off.as<uint64_t>();
+    e.rec = c->d_rec.as<bgp_record>(); e.seq_off = c->d_seq_off.as<uint64_t>(); e.cigar_off = c->d_cigar_off.as<uint64_t>(); e.cig4 = c->d_cig4.as<uint4>();
     e.n_records = n; e.sum_lseq = sl; e.sum_ncig = sc;
     {
         TimedRegion t(c, "k1_emit", n * (36 + 32 + 16) + sc * 4);

@@ -36,7 +36,7 @@ namespace {
 // (50 M reads) 2048 positions / 512 threads (2 workgroups per CU) 10.0 ms, 1024 / 256 (4 per CU) 10.6 ms,
 // 4096 / 1024 (148 KB of LDS, one workgroup of 16 waves per CU) 8.9 ms.
 #ifndef BGP_K4_W
-#define BGP_K4_W 4096
+#define BGP_K4_W 1024
 #define BGP_K4_T 1024
 #define BGP_K4_T16 512
 #define BGP_K4_HB 512
@@ -220,7 +220,7 @@ __device__ __forceinline__ uint32_t base_class(uint32_t code) {   // nt16 code -
 // One thread per window: the record range that can touch it (exact halo).  Done here, massively
 // parallel, because the two ~25-step dependent binary searches are pure latency.
 struct TileB { uint64_t i_lo, i_hi, col_out; uint32_t T0, Tend, run_start, pad; };   // everything a window needs in one 40-byte (scalar) load; pad = 1: deep window
-__global__ __launch_bounds__(256) void k4_bounds(const uint64_t* pmax_end, const uint64_t* pmax_pos, const RunDev* runs, uint32_t n_runs, uint64_t n_tiles, TileB* out, uint32_t* deep, uint32_t* n_deep) {
+__global__ __launch_bounds__(256) void k4_bounds(const uint64_t* pmax_end, const uint64_t* pmax_pos, const RunDev* runs, uint32_t n_runs, uint64_t n_tiles, TileB* out) {
     const uint64_t tile = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (tile >= n_tiles) return;
     uint32_t lo_r = 0, hi_r = n_runs;
@@ -233,9 +233,8 @@ __global__ __launch_bounds__(256) void k4_bounds(const uint64_t* pmax_end, const
     b.i_lo = lower_bound_gt(pmax_end, run.first_record, run.end_record, rk | T0);             // first record whose running max end_position exceeds T0
     b.i_hi = lower_bound_gt(pmax_pos, run.first_record, run.end_record, rk | (Tend - 1));     // first record starting at/after Tend
     b.col_out = run.column_base + (T0 - run.start_pos); b.T0 = T0; b.Tend = Tend; b.run_start = (uint32_t)run.start_pos;
-    b.pad = b.i_hi - b.i_lo >= DEEP_WINDOW ? 1u : 0u;     // a count per position and class is bounded by the candidates: 16 bits are enough below this
-    if (b.pad) deep[atomicAdd(n_deep, 1u)] = (uint32_t)tile;
-    out[tile] = b;
+    b.pad = b.i_hi - b.i_lo >= DEEP_WINDOW ? 1u : 0u;     // bit 0: a count per position and class is bounded by the candidates, 16 bits are enough below this
+    out[tile] = b;                                        // (bit 1, "not for the gather path", is set by k4_wscan, which also builds the list of such windows)
 }
 
 // ---- long reads: CIGAR checkpoints ------------------------------------------------------------
@@ -537,22 +536,14 @@ template <class L> __global__ __launch_bounds__(L::T) void k4_tile(K4Args a, int
     __shared__ uint32_t s_n;           // entries in the LDS list
     __shared__ uint32_t s_nslow;       // entries in the second list
     __shared__ uint32_t wsum[K4_T / 64];
-    // XCD-aware order: consecutive tiles of a reference go to the same XCD (block b runs on XCD b % 8)
-    const uint64_t nb = a.n_tiles;
-    const uint64_t per = (nb + 7) / 8;
-  for (uint64_t it = blockIdx.x;; it += gridDim.x) {     // one window per workgroup; the deep pass walks its (short) list
-    uint64_t tile;
-    if (!deep_pass) {
-        if (it != blockIdx.x) break;
-        tile = (blockIdx.x % 8) * per + blockIdx.x / 8;
-        if (nb < 64) tile = blockIdx.x;
-        if (tile >= nb) break;
-    } else {
-        if (it >= *a.n_deep) break;
-        tile = a.deep[it];
-    }
+    // The general kernel: it runs only the windows the gather path (k4_plan / k4_exec below) leaves on the list --
+    // windows touched by a long read or an odd CIGAR, windows too deep for a descriptor slab.  A window whose
+    // candidate range could overflow 16-bit counters takes the 32-bit layout, every other one the 16-bit layout.
+  for (uint64_t it = blockIdx.x; it < *a.n_deep; it += gridDim.x) {
+    (void)deep_pass;
+    const uint64_t tile = a.deep[it];
     const TileB tb = a.tiles[tile];                      // window geometry + record range, precomputed by k4_bounds
-    if (!deep_pass && L::P16 && tb.pad) break;           // too many candidates for 16-bit counters: left to the deep pass
+    if (L::P16 != ((tb.pad & 1u) == 0u)) continue;       // (uniform: no barrier has been passed yet in this iteration)
     const uint32_t T0 = tb.T0, Tend = tb.Tend;
     for (int i = threadIdx.x; i < LIST; i += K4_T) lds[i] = 0;
     const uint64_t i_lo = tb.i_lo, i_hi = tb.i_hi;
@@ -863,6 +854,415 @@ __global__ __launch_bounds__(256) void k4_stats(const unsigned long long* ts, ui
     if ((threadIdx.x & 63) == 0) { atomicAdd(&pstats[0], c); atomicAdd(&pstats[1], s); atomicMax(&pstats[2], m); atomicAdd(&pstats[4], u); }
 }
 
+// ---------------------------------------------------------------------------------------------- K4, gather path
+//
+// The same closed form (file header), turned around: instead of every BASE finding its counter (one LDS atomic per
+// base, lanes = reads, counters wherever the positions say: 77 % of the LDS cycles of that kernel were bank
+// conflicts), every POSITION gathers its bases.  Two kernels:
+//
+//   k4_plan   one lane per READ, one pass over the record table and the first-four-ops side array K1 leaves
+//             (no window ever scans a candidate range: the ~1000-row halo of N-skip reads is gone).  An ordinary
+//             read (1..4 ops, l_seq <= 160, first reference-consuming op M/=/X, nothing zero-length) becomes 8-byte
+//             DESCRIPTORS appended to the slabs of the windows it touches: one SEG per (M/=/X op, window) --
+//             where the bases are in the stream, where they land in the window -- and one DEL per (D/N op, edge
+//             window); windows an N/D op covers completely get +1 through a difference array over windows.  Any
+//             other read marks the windows it overlaps for the general kernel (k4_tile above).
+//   k4_exec   one workgroup per WINDOW of 1024 positions.  Stage: every SEG's packed bases are fetched (lanes
+//             along the read, 16 bases per lane), turned into one byte per base = the BIT POSITION of its class
+//             counter (A 0, C 6, G 12, T 18, other 24; bytes outside the segment 0xFF) with three v_perm lookups
+//             per four bases, and written to LDS with 64 bytes of 0xFF between segments.  Gather: a wave owns 64
+//             consecutive positions and walks the list of segments overlapping them (built in LDS while staging);
+//             per (segment, 64 positions) pair it costs one v_readlane (the segment's address delta), one add, one
+//             ds_read_u8 -- consecutive lanes read consecutive bytes: conflict free -- and one v_lshl_add into a
+//             packed counter register (5 x 6 bits, unpacked into five 32-bit registers every 56 pairs).  Lanes beyond
+//             a segment's ends read its 0xFF padding and add to bit 31.  D/N ops stay two adds on a difference
+//             array, n_starting_here one add per read.  No atomic per base anywhere.
+//
+// Descriptor (64 bits): [1:0] kind (0 none, 1 SEG, 2 DEL)
+//   SEG  [2] the read starts here (n_starting_here)  [13:3] first position in the window  [21:14] bases (1..255)
+//        [22] the first base is the LOW nibble of its byte  [63:23] stream offset of that byte
+//   DEL  [13:3] first position  [25:14] one past the last position (<= W)
+constexpr int GT = 512;                       // threads of a k4_exec workgroup
+constexpr int GNW = GT / 64;                  // waves
+constexpr int GNB = W / 64;                   // 64-position blocks per window
+constexpr int GBPW = GNB / GNW;               // blocks per wave
+constexpr int GCAP = GT;                      // descriptors per round (one per thread)
+constexpr uint32_t SLAB_CAP = 1024;           // descriptors a window's slab holds; more: the window goes to k4_tile
+constexpr int PAIRCAP = 128;                  // segments per 64-position block and round
+constexpr int G_STAGE = 56 * 1024;            // staged class bytes per round
+constexpr int SEG_SLOTS = 6, SEG_PER_WAVE = 10;   // staging: 6 lanes (32 bases each) per segment, 10 segments per wave step
+constexpr int STAGE_IT = (GCAP + GNW * SEG_PER_WAVE - 1) / (GNW * SEG_PER_WAVE);   // wave steps per round
+static_assert(GBPW >= 1 && GNB % GNW == 0, "window / workgroup geometry");
+static_assert(W <= 2048, "descriptor fields");
+// LDS map of k4_exec (bytes)
+constexpr int G_TAIL = G_STAGE;                               // 17 x 16: tail masks
+constexpr int G_DELD = G_TAIL + 17 * 16;                      // (W + 4) x u32
+constexpr int G_NST = G_DELD + (W + 4) * 4;                   // W x u16, two to a word
+constexpr int G_HIST = G_NST + W * 2;                         // HB x u32
+constexpr int G_BLKN = G_HIST + HB * 4;                       // GNB x u32
+constexpr int G_BLKL = G_BLKN + GNB * 4;                      // GNB x PAIRCAP x u16
+constexpr int G_SEGI = G_BLKL + GNB * PAIRCAP * 2;            // GCAP x uint4
+constexpr int G_MISC = G_SEGI + GCAP * 16;                    // wave totals, flags
+constexpr int G_LDS = G_MISC + 256;
+static_assert(G_SEGI % 16 == 0 && G_DELD % 16 == 0, "alignment");
+constexpr int FAST_SEG = 160;                 // longest read of the gather path (<= 6 staging lanes with an odd start)
+
+struct PlanArgs {
+    const bgp_record* rec; const uint4* cig4; const uint8_t* s; uint64_t stream_len, n;
+    const RunDev* runs; uint32_t n_runs; uint64_t n_tiles;
+    unsigned long long* slab; uint32_t* wcount; int32_t* wdel; int32_t* wslow;
+};
+
+__global__ __launch_bounds__(256) void k4_plan(PlanArgs a) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    unsigned long long dsc[8]; uint32_t win[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { dsc[j] = 0; win[j] = 0xFFFFFFFFu; }
+    uint32_t wf = 0xFFFFFFFFu;
+    bool any = false;
+    if (i < a.n) {
+        const uint4* rp = reinterpret_cast<const uint4*>(a.rec + i);
+        const uint4 x = rp[0], y = rp[1];                 // ref_id,pos,end_pos,bin_mq_nl | flag_nc,l_seq,rec_off
+        if (x.z != x.y) {                                 // basesCovered() > 0, pileup.d:481,510
+            const RunDev& run = a.runs[run_of_record(a.runs, a.n_runs, i)];
+            const uint32_t rel0 = x.y - (uint32_t)run.start_pos;
+            const uint32_t tb = (uint32_t)run.tile_base;
+            wf = tb + rel0 / W;
+            const uint32_t wl = tb + (x.z - 1 - (uint32_t)run.start_pos) / W;
+            const uint32_t n_cig = y.x & 0xFFFFu, l_seq = y.y;
+            const uint64_t cig_off = (((uint64_t)y.w << 32) | y.z) + 36 + (x.w & 0xFFu);
+            const uint64_t seq_off = cig_off + 4ull * n_cig;
+            bool simple = n_cig >= 1 && n_cig <= 4 && l_seq >= 1 && l_seq <= (uint32_t)FAST_SEG && seq_off + (l_seq + 1) / 2 + 16 <= a.stream_len;   // (staging reads 16 bytes per lane)
+            uint32_t ops[4] = {0, 0, 0, 0};
+            if (simple) {
+                if (a.cig4) { const uint4 c4 = a.cig4[i]; ops[0] = c4.x; ops[1] = c4.y; ops[2] = c4.z; ops[3] = c4.w; }
+                else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) if ((uint32_t)k < n_cig) ops[k] = ld_u32(a.s + cig_off + 4 * k);
+                }
+                // the mould: no zero-length reference-consuming op, the first reference-consuming op is M/=/X (so the
+                // read's first column is its first staged base), the CIGAR does not consume more query than SEQ holds
+                bool seen_ref = false; uint32_t qsum = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) if ((uint32_t)k < n_cig) {
+                    const uint32_t op = ops[k], len = op >> 4;
+                    if (cig_rc(op)) { if (len == 0 || (!seen_ref && !cig_qc(op))) simple = false; seen_ref = true; }
+                    if (cig_qc(op)) qsum += len;
+                }
+                if (qsum > l_seq) simple = false;
+            }
+            if (!simple) {                                // left to the general kernel, with every window it overlaps
+                atomicAdd(&a.wslow[wf], 1); atomicAdd(&a.wslow[wl + 1], -1);
+            } else {
+                uint32_t p = 0, q = 0;                    // columns / query bases before the op (file header: cstart, qstart)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) if ((uint32_t)k < n_cig) {
+                    const uint32_t op = ops[k], len = op >> 4, qc = cig_qc(op), rc = cig_rc(op);
+                    if (rc) {
+                        const uint32_t a0 = rel0 + p, a1 = a0 + len;                 // run-relative columns [a0, a1) of the op
+                        const uint32_t w0 = a0 / W, w1 = (a1 - 1) / W;
+                        const uint32_t lo0 = a0 - w0 * W, n0 = min(a1, (w0 + 1) * W) - a0;
+                        if (qc) {                                                     // M, =, X: pileup.d:117-118; len <= 160 < W: at most two windows
+                            const uint64_t src = seq_off + (q >> 1);
+                            dsc[2 * k] = 1ull | (p == 0 ? 4ull : 0ull) | ((unsigned long long)lo0 << 3) | ((unsigned long long)n0 << 14) | ((unsigned long long)(q & 1u) << 22) | (src << 23);
+                            win[2 * k] = tb + w0;
+                            if (w1 > w0) {
+                                const uint32_t q1 = q + n0;
+                                dsc[2 * k + 1] = 1ull | ((unsigned long long)(len - n0) << 14) | ((unsigned long long)(q1 & 1u) << 22) | ((seq_off + (q1 >> 1)) << 23);
+                                win[2 * k + 1] = tb + w1;
+                            }
+                        } else {                                                      // D, N: '-', pileup.d:119-121
+                            dsc[2 * k] = 2ull | ((unsigned long long)lo0 << 3) | ((unsigned long long)(lo0 + n0) << 14);
+                            win[2 * k] = tb + w0;
+                            if (w1 > w0) {
+                                dsc[2 * k + 1] = 2ull | ((unsigned long long)(a1 - w1 * W) << 14);
+                                win[2 * k + 1] = tb + w1;
+                                if (w1 - w0 >= 2) { atomicAdd(&a.wdel[tb + w0 + 1], 1); atomicAdd(&a.wdel[tb + w1], -1); }   // windows covered end to end
+                            }
+                        }
+                        p += len;
+                    }
+                    if (qc) q += len;
+                }
+                any = true;
+            }
+        }
+    }
+    // slots in the windows' slabs.  Reads are sorted, so nearly every descriptor of a wave goes to the wave's first
+    // window A or to A + 1: those two are claimed with one atomic each for the whole wave; the few others (second
+    // halves of N-skip reads) claim theirs one by one.  All atomics are in flight together.
+    const unsigned long long am = __ballot(any);
+    if (!am) return;
+    const uint32_t A = (uint32_t)__shfl((int)wf, __ffsll((long long)am) - 1, 64);
+    uint32_t pk = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) pk += (win[j] == A ? 1u : 0u) + (win[j] == A + 1 ? 0x10000u : 0u);
+    const uint32_t inc = wave_incl_u32(pk, lane);
+    const uint32_t tot = (uint32_t)__shfl((int)inc, 63, 64);
+    uint32_t base0 = 0, base1 = 0;
+    if (lane == 0) {
+        if (tot & 0xFFFFu) base0 = atomicAdd(&a.wcount[A], tot & 0xFFFFu);
+        if (tot >> 16) base1 = atomicAdd(&a.wcount[A + 1], tot >> 16);
+    }
+    uint32_t far_slot[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { far_slot[j] = 0; if (win[j] != 0xFFFFFFFFu && win[j] != A && win[j] != A + 1) far_slot[j] = atomicAdd(&a.wcount[win[j]], 1u); }
+    uint32_t o0 = rl(base0, 0) + ((inc - pk) & 0xFFFFu), o1 = rl(base1, 0) + ((inc - pk) >> 16);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        if (win[j] == 0xFFFFFFFFu) continue;
+        const uint32_t slot = win[j] == A ? o0++ : win[j] == A + 1 ? o1++ : far_slot[j];
+        if (slot < SLAB_CAP) a.slab[(uint64_t)win[j] * SLAB_CAP + slot] = dsc[j];
+    }
+}
+
+// Prefix sums over windows of the two difference arrays (whole-window '-' levels, slow-read marks), then the verdict
+// per window -- bit 1 of TileB.pad = "not for the gather path" -- and the list of such windows.  Three small launches:
+// per-block totals, their exclusive scan by one workgroup, the prefix proper.
+__device__ __forceinline__ void wscan_block(int32_t d, int32_t sl, int32_t* id_out, int32_t* is_out, int32_t* pd, int32_t* ps, int32_t* td, int32_t* ts, int32_t (*ws)[16]) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int32_t id = d, is = sl;
+#pragma unroll
+    for (int k = 1; k < 64; k <<= 1) { const int32_t od = __shfl_up(id, k, 64), os = __shfl_up(is, k, 64); if (lane >= k) { id += od; is += os; } }
+    if (lane == 63) { ws[0][w] = id; ws[1][w] = is; }
+    __syncthreads();
+    int32_t a = 0, b = 0, c = 0, e = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { if (k < w) { a += ws[0][k]; b += ws[1][k]; } c += ws[0][k]; e += ws[1][k]; }
+    *id_out = id; *is_out = is; *pd = a; *ps = b; *td = c; *ts = e;
+    __syncthreads();
+}
+__global__ __launch_bounds__(1024) void k4_wscan_tot(const int32_t* wdel, const int32_t* wslow, uint64_t n_tiles, int32_t* btot) {
+    __shared__ int32_t ws[2][16];
+    const uint64_t i = (uint64_t)blockIdx.x * 1024 + threadIdx.x;
+    int32_t id, is, pd, ps, td, ts;
+    wscan_block(i < n_tiles ? wdel[i] : 0, i < n_tiles ? wslow[i] : 0, &id, &is, &pd, &ps, &td, &ts, ws);
+    if (threadIdx.x == 0) { btot[2 * blockIdx.x] = td; btot[2 * blockIdx.x + 1] = ts; }
+}
+__global__ __launch_bounds__(1024) void k4_wscan_mid(int32_t* btot, uint32_t nb) {
+    __shared__ int32_t ws[2][16];
+    int32_t cd = 0, cs = 0;
+    for (uint32_t base = 0; base < nb; base += 1024) {
+        const uint32_t i = base + threadIdx.x;
+        const int32_t d = i < nb ? btot[2 * i] : 0, sl = i < nb ? btot[2 * i + 1] : 0;
+        int32_t id, is, pd, ps, td, ts;
+        wscan_block(d, sl, &id, &is, &pd, &ps, &td, &ts, ws);
+        if (i < nb) { btot[2 * i] = cd + pd + id - d; btot[2 * i + 1] = cs + ps + is - sl; }     // exclusive
+        cd += td; cs += ts;
+    }
+}
+__global__ __launch_bounds__(1024) void k4_wscan(int32_t* wdel, const int32_t* wslow, const uint32_t* wcount, TileB* tiles, uint64_t n_tiles, const int32_t* btot, uint32_t* deep, uint32_t* n_deep) {
+    __shared__ int32_t ws[2][16];
+    const uint64_t i = (uint64_t)blockIdx.x * 1024 + threadIdx.x;
+    int32_t id, is, pd, ps, td, ts;
+    wscan_block(i < n_tiles ? wdel[i] : 0, i < n_tiles ? wslow[i] : 0, &id, &is, &pd, &ps, &td, &ts, ws);
+    if (i < n_tiles) {
+        wdel[i] = btot[2 * blockIdx.x] + pd + id;
+        const uint32_t pad = (tiles[i].pad & 1u) | ((btot[2 * blockIdx.x + 1] + ps + is > 0 || wcount[i] > SLAB_CAP) ? 2u : 0u);
+        tiles[i].pad = pad;
+        if (pad) deep[atomicAdd(n_deep, 1u)] = (uint32_t)i;
+    }
+}
+
+// four nt16 codes, one per byte -> the bit positions of their class counters (A 0, C 6, G 12, T 18, anything else 24)
+__device__ __forceinline__ uint32_t class_bits4(uint32_t x) {
+    const uint32_t idx = x & 0x07070707u;
+    const uint32_t lo = __builtin_amdgcn_perm(0x1818180Cu, 0x18060018u, idx);      // codes 0..7 : 24 0 6 24 | 12 24 24 24
+    const uint32_t hi = __builtin_amdgcn_perm(0x18181818u, 0x18181812u, idx);      // codes 8..15: 18 24 24 24 | 24 24 24 24
+    const uint32_t sel = ((x >> 1) & 0x04040404u) | 0x03020100u;                   // byte i: i (from lo) or 4 + i (from hi)
+    return __builtin_amdgcn_perm(hi, lo, sel);
+}
+// eight packed bases (read.d:368-373: the first base of a byte is its high nibble) -> eight class bytes in base order
+__device__ __forceinline__ uint2 class_bits8(uint32_t cur) {
+    const uint32_t ev = class_bits4((cur >> 4) & 0x0F0F0F0Fu), od = class_bits4(cur & 0x0F0F0F0Fu);   // bases 0,2,4,6 | 1,3,5,7
+    return make_uint2(__builtin_amdgcn_perm(od, ev, 0x05010400u), __builtin_amdgcn_perm(od, ev, 0x07030602u));
+}
+
+struct GArgs {
+    const uint8_t* s; const unsigned long long* slab; const uint32_t* wcount; const int32_t* wdel; const TileB* tiles; uint64_t n_tiles;
+    bgp_column* cols; unsigned long long* hist; unsigned long long* tile_stats; uint32_t* deep; uint32_t* n_deep;
+};
+
+__global__ __launch_bounds__(GT) void k4_exec(GArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t glds[];
+    uint8_t* const stage = glds;
+    uint4* const tailm = reinterpret_cast<uint4*>(glds + G_TAIL);
+    uint32_t* const deld = reinterpret_cast<uint32_t*>(glds + G_DELD);
+    uint32_t* const nst = reinterpret_cast<uint32_t*>(glds + G_NST);
+    uint32_t* const hist = reinterpret_cast<uint32_t*>(glds + G_HIST);
+    uint32_t* const blk_n = reinterpret_cast<uint32_t*>(glds + G_BLKN);
+    uint16_t* const blk_l = reinterpret_cast<uint16_t*>(glds + G_BLKL);
+    uint4* const segi = reinterpret_cast<uint4*>(glds + G_SEGI);
+    uint32_t* const misc = reinterpret_cast<uint32_t*>(glds + G_MISC);     // [0..7] wave totals, [8] overflow flag
+    // XCD-aware order: consecutive windows of a reference go to the same XCD (block b runs on XCD b % 8), so a read
+    // staged by two neighbouring windows is fetched from HBM once
+    const uint64_t nbt = a.n_tiles, per = (nbt + 7) / 8;
+    uint64_t tile = (blockIdx.x % 8) * per + blockIdx.x / 8;
+    if (nbt < 64) tile = blockIdx.x;
+    if (tile >= nbt) return;
+    const TileB tb = a.tiles[tile];
+    if (tb.pad) return;                                   // on the general kernel's list
+    const uint32_t n_desc = a.wcount[tile];
+    const int32_t wd = a.wdel[tile];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    for (int i = t; i < (G_BLKL - G_DELD) / 4; i += GT) deld[i] = 0;      // deld, nst, hist, blk_n
+    if (t < 17) { uint32_t m[4]; for (int k = 0; k < 4; ++k) { const int v = t - 4 * k; m[k] = v >= 4 ? 0u : v <= 0 ? 0xFFFFFFFFu : 0xFFFFFFFFu << (8 * v); } tailm[t] = make_uint4(m[0], m[1], m[2], m[3]); }
+    if (t < 4) reinterpret_cast<uint4*>(stage)[t] = make_uint4(~0u, ~0u, ~0u, ~0u);     // the 64 padding bytes in front of the first segment
+    if (t == 0) misc[8] = 0;
+    uint32_t cA[GBPW], cC[GBPW], cG[GBPW], cT[GBPW], cO[GBPW];
+#pragma unroll
+    for (int b = 0; b < GBPW; ++b) { cA[b] = 0; cC[b] = 0; cG[b] = 0; cT[b] = 0; cO[b] = 0; }
+    const unsigned long long* slab = a.slab + tile * (uint64_t)SLAB_CAP;
+    const int sl = lane / SEG_SLOTS, sj = lane - sl * SEG_SLOTS;
+    __syncthreads();
+
+    for (uint32_t base = 0; base < n_desc; base += GCAP) {
+        const uint32_t nr = min((uint32_t)GCAP, n_desc - base);
+        // ---- lay out: a place in LDS for every segment's class bytes, the per-block segment lists, '-' and start marks
+        unsigned long long d = 0;
+        if ((uint32_t)t < nr) d = slab[base + t];
+        const uint32_t kind = (uint32_t)d & 3u;
+        const uint32_t lo = ((uint32_t)d >> 3) & 0x7FFu, f14 = (uint32_t)(d >> 14);
+        const uint32_t len = f14 & 0xFFu, nib = (f14 >> 8) & 1u;
+        const uint32_t nch = kind == 1 ? (len + nib + 15) >> 4 : 0u;
+        const uint32_t units = kind == 1 ? nch + 4 : 0u;                     // 16-byte units: the bytes + 64 of padding behind them
+        const uint32_t inc = wave_incl_u32(units, lane);
+        if (lane == 63) misc[wave] = inc;
+        __syncthreads();
+        uint32_t carry = 0, total = 0;
+#pragma unroll
+        for (int k = 0; k < GNW; ++k) { const uint32_t v = misc[k]; if (k < wave) carry += v; total += v; }
+        const uint32_t data_off = 64 + 16 * (carry + inc - units);
+        const bool fits = 64 + 16 * total <= (uint32_t)G_STAGE;
+        if (kind == 1 && fits) {
+            const uint64_t src = d >> 23;
+            segi[t] = make_uint4((uint32_t)src, (uint32_t)(src >> 32) | (nib << 16) | (len << 20), data_off, 0u);
+            uint4* padp = reinterpret_cast<uint4*>(stage + data_off + 16 * nch);
+            const uint4 ff = make_uint4(~0u, ~0u, ~0u, ~0u);
+            padp[0] = ff; padp[1] = ff; padp[2] = ff; padp[3] = ff;
+            const uint32_t cdel = data_off + nib - lo + W;                 // staged byte of position p: stage[p - W + cdel]
+            const uint32_t b1 = (lo + len - 1) >> 6;
+            for (uint32_t b = lo >> 6; b <= b1; ++b) {
+                const uint32_t slot = atomicAdd(&blk_n[b], 1u);
+                if (slot < (uint32_t)PAIRCAP) blk_l[b * PAIRCAP + slot] = (uint16_t)cdel; else misc[8] = 1;
+            }
+            if (d & 4u) atomicAdd(&nst[lo >> 1], 1u << ((lo & 1u) * 16));   // n_starting_here, pileup.d:386,422 (a count per position stays below 2^16: the slab holds 1024 descriptors)
+        } else if ((uint32_t)t < (uint32_t)GCAP) segi[t] = make_uint4(0, 0, 0, 0);
+        if (kind == 2) { atomicAdd(&deld[lo], 1u); atomicAdd(&deld[f14 & 0xFFFu], 0xFFFFFFFFu); }
+        __syncthreads();
+        if (!fits || misc[8]) {                                // more segments than a round's LDS holds: the general kernel takes the window
+            if (t == 0) a.deep[atomicAdd(a.n_deep, 1u)] = (uint32_t)tile;
+            return;
+        }
+        // ---- stage: 32 bases per lane, 6 lanes per segment, 10 segments per wave step.  Every load of the round is
+        // requested before the first is looked at: one HBM round trip per round, not one per step.
+        uint4 pk[STAGE_IT];
+#pragma unroll
+        for (int it = 0; it < STAGE_IT; ++it) {
+            const uint32_t si = (uint32_t)(it * GNW + wave) * SEG_PER_WAVE + sl;
+            pk[it] = make_uint4(0, 0, 0, 0);
+            if (sl < SEG_PER_WAVE && si < nr) {
+                const uint4 g = segi[si];
+                const uint32_t glen = g.y >> 20, gnib = (g.y >> 16) & 1u;
+                if (glen && (int32_t)(glen + gnib) - 32 * sj > 0) __builtin_memcpy(&pk[it], a.s + ((((uint64_t)(g.y & 0xFFFFu)) << 32) | g.x) + 16u * sj, 16);
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < STAGE_IT; ++it) {
+            const uint32_t si = (uint32_t)(it * GNW + wave) * SEG_PER_WAVE + sl;
+            if (sl < SEG_PER_WAVE && si < nr) {
+                const uint4 g = segi[si];
+                const uint32_t glen = g.y >> 20, gnib = (g.y >> 16) & 1u;
+                const int32_t valid = (int32_t)(glen + gnib) - 32 * sj;          // staged bytes of this lane that belong to the segment (incl. the skipped nibble)
+                if (glen && valid > 0) {
+                    const uint2 c0 = class_bits8(pk[it].x), c1 = class_bits8(pk[it].y), c2 = class_bits8(pk[it].z), c3 = class_bits8(pk[it].w);
+                    const uint4 t0 = tailm[min(valid, 16)], t1 = tailm[min(max(valid - 16, 0), 16)];
+                    uint4 o0 = make_uint4(c0.x | t0.x, c0.y | t0.y, c1.x | t0.z, c1.y | t0.w);
+                    const uint4 o1 = make_uint4(c2.x | t1.x, c2.y | t1.y, c3.x | t1.z, c3.y | t1.w);
+                    if (sj == 0 && gnib) o0.x |= 0xFFu;
+                    uint4* dst = reinterpret_cast<uint4*>(stage + g.z + 32 * sj);
+                    dst[0] = o0; dst[1] = o1;                                     // (a second half past the segment lands in its own padding)
+                }
+            }
+        }
+        __syncthreads();
+        // ---- gather: a wave walks the segment list of each of its 64-position blocks
+#pragma unroll
+        for (int bb = 0; bb < GBPW; ++bb) {
+            const int b = wave * GBPW + bb;
+            const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)min(blk_n[b], (uint32_t)PAIRCAP));
+            const int pbi = 64 * b + lane - W;                                // + cdel = this lane's byte of the segment
+            const uint32_t csent = (uint32_t)(W - 64 * b);                    // + pbi = the padding in front of the first segment
+            for (uint32_t p0 = 0; p0 < n; p0 += 56) {
+                const uint32_t cnt = min(56u, n - p0);
+                const uint32_t vc = (uint32_t)lane < cnt ? (uint32_t)blk_l[b * PAIRCAP + p0 + lane] : csent;
+                uint32_t acc = 0;
+#pragma unroll
+                for (int g = 0; g < 7; ++g) {
+                    if ((uint32_t)(g * 8) >= cnt) break;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const uint32_t cd8 = rl(vc, g * 8 + k);
+                        const uint32_t code = stage[pbi + (int)cd8];
+                        acc = (1u << (code & 31u)) + acc;
+                    }
+                }
+                cA[bb] += acc & 63u; cC[bb] += (acc >> 6) & 63u; cG[bb] += (acc >> 12) & 63u; cT[bb] += (acc >> 18) & 63u; cO[bb] += (acc >> 24) & 63u;
+            }
+        }
+        __syncthreads();
+        if (t < GNB) blk_n[t] = 0;
+        // (the next round's first barrier orders this reset before its atomics)
+    }
+    // ---- flush: prefix-sum the '-' difference array, then 32 contiguous bytes per position
+    const uint32_t np = tb.Tend - tb.T0;
+    {
+        constexpr int PER = W / GT;
+        const uint32_t p0 = t * PER;
+        uint32_t loc[PER]; uint32_t run_sum = 0;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) { run_sum += deld[p0 + j]; loc[j] = run_sum; }
+        const uint32_t inc = wave_incl_u32(run_sum, lane);
+        __syncthreads();
+        if (lane == 63) misc[wave] = inc;
+        __syncthreads();
+        uint32_t carry = 0;
+        for (int k = 0; k < wave; ++k) carry += misc[k];
+        const uint32_t ex = carry + inc - run_sum;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) deld[p0 + j] = ex + loc[j];
+        __syncthreads();
+    }
+    bgp_column* out = a.cols + tb.col_out;
+    uint64_t ncol = 0, scov = 0, nsum = 0; uint32_t mx = 0;
+#pragma unroll
+    for (int bb = 0; bb < GBPW; ++bb) {
+        const uint32_t p = 64 * (wave * GBPW + bb) + lane;
+        if (p < np) {
+            const uint32_t D = deld[p] + (uint32_t)wd, S = (nst[p >> 1] >> ((p & 1u) * 16)) & 0xFFFFu;
+            const uint32_t cov = cA[bb] + cC[bb] + cG[bb] + cT[bb] + cO[bb] + D;
+            uint4* o4 = reinterpret_cast<uint4*>(out + p);
+            o4[0] = make_uint4(cov, S, cA[bb], cC[bb]);
+            o4[1] = make_uint4(cG[bb], cT[bb], cO[bb], D);
+            ncol += cov > 0; scov += cov; mx = max(mx, cov); nsum += S;
+            if (cov < (uint32_t)HB) atomicAdd(&hist[cov], 1u);
+            else atomicAdd(&a.hist[min(cov, (uint32_t)BGP_DEPTH_BINS - 1)], 1ull);
+        }
+    }
+    for (int dd = 32; dd >= 1; dd >>= 1) { ncol += __shfl_down(ncol, dd, 64); scov += __shfl_down(scov, dd, 64); nsum += __shfl_down(nsum, dd, 64); mx = max(mx, (uint32_t)__shfl_down(mx, dd, 64)); }
+    __shared__ unsigned long long part[GNW][4];
+    if (lane == 0) { part[wave][0] = ncol; part[wave][1] = scov; part[wave][2] = mx; part[wave][3] = nsum; }
+    __syncthreads();
+    if (t < 4) {
+        unsigned long long v = 0;
+        for (int k = 0; k < GNW; ++k) v = t == 2 ? max(v, part[k][2]) : v + part[k][t];
+        a.tile_stats[tile * 4 + t] = v;
+    }
+    for (int b = t; b < HB; b += GT) { const uint32_t h = hist[b]; if (h) atomicAdd(&a.hist[b], (unsigned long long)h); }
+}
+
 // ---------------------------------------------------------------------------------------------- K5
 
 struct K5Args {
@@ -1010,11 +1410,30 @@ int k34_pileup(bgp_ctx* c) {
         a.tiles = c->d_tiles.as<TileB>();
         {
             TimedRegion tb(c, "k4_bounds", tile_base * sizeof(TileB));
-            hipLaunchKernelGGL(k4_bounds, dim3((unsigned)((tile_base + 255) / 256)), dim3(256), 0, c->stream, a.pmax_end, a.pmax_pos, a.runs, n_runs, tile_base, c->d_tiles.as<TileB>(),
-                               c->d_deep.as<uint32_t>() + 1, c->d_deep.as<uint32_t>());
+            hipLaunchKernelGGL(k4_bounds, dim3((unsigned)((tile_base + 255) / 256)), dim3(256), 0, c->stream, a.pmax_end, a.pmax_pos, a.runs, n_runs, tile_base, c->d_tiles.as<TileB>());
         }
         BGP_TRY(c->d_col_lo.reserve(tile_base * 32));
         a.tile_stats = (unsigned long long*)c->d_col_lo.p;
+        // the gather path's plan: descriptor slabs per window, from one pass over the reads
+        BGP_TRY(c->d_slab.reserve(tile_base * (size_t)SLAB_CAP * 8));
+        BGP_TRY(c->d_wcount.reserve((tile_base + 1) * 4)); BGP_TRY(c->d_wdel.reserve((tile_base + 2) * 4)); BGP_TRY(c->d_wslow.reserve((tile_base + 2) * 4));
+        BGP_HIP(hipMemsetAsync(c->d_wcount.p, 0, (tile_base + 1) * 4, c->stream));
+        BGP_HIP(hipMemsetAsync(c->d_wdel.p, 0, (tile_base + 2) * 4, c->stream));
+        BGP_HIP(hipMemsetAsync(c->d_wslow.p, 0, (tile_base + 2) * 4, c->stream));
+        {
+            TimedRegion tp(c, "k4_plan", c->n_records * 48);
+            PlanArgs pa;
+            pa.rec = a.rec; pa.cig4 = c->cig4_ok ? c->d_cig4.as<uint4>() : nullptr; pa.s = a.s; pa.stream_len = a.stream_len; pa.n = n;
+            pa.runs = a.runs; pa.n_runs = n_runs; pa.n_tiles = tile_base;
+            pa.slab = (unsigned long long*)c->d_slab.p; pa.wcount = c->d_wcount.as<uint32_t>(); pa.wdel = c->d_wdel.as<int32_t>(); pa.wslow = c->d_wslow.as<int32_t>();
+            hipLaunchKernelGGL(k4_plan, dim3(nb), dim3(256), 0, c->stream, pa);
+            const unsigned wb = (unsigned)((tile_base + 1023) / 1024);
+            BGP_TRY(c->d_scan_tmp.reserve((size_t)wb * 8 + 16));
+            int32_t* btot = c->d_scan_tmp.as<int32_t>();
+            hipLaunchKernelGGL(k4_wscan_tot, dim3(wb), dim3(1024), 0, c->stream, pa.wdel, pa.wslow, tile_base, btot);
+            hipLaunchKernelGGL(k4_wscan_mid, dim3(1), dim3(1024), 0, c->stream, btot, wb);
+            hipLaunchKernelGGL(k4_wscan, dim3(wb), dim3(1024), 0, c->stream, pa.wdel, pa.wslow, pa.wcount, c->d_tiles.as<TileB>(), tile_base, btot, c->d_deep.as<uint32_t>() + 1, c->d_deep.as<uint32_t>());
+        }
         a.ck = nullptr; a.ck_off = nullptr;
         if (st[3]) {                                   // the stream holds long reads: build their per-window CIGAR checkpoints
             TimedRegion tc(c, "k4_checkpoints", c->sum_ncig * 4);
@@ -1029,8 +1448,16 @@ int k34_pileup(bgp_ctx* c) {
             a.ck = c->d_ck.as<Ckpt>(); a.ck_off = ck_off;
         }
         TimedRegion t(c, "k4_tile", used);
-        hipLaunchKernelGGL(k4_tile<L16>, dim3((unsigned)grid), dim3(L16::T), lds16, c->stream, a, 0);
-        hipLaunchKernelGGL(k4_tile<L32>, dim3(256), dim3(L32::T), lds32, c->stream, a, 1);          // deep windows only: exits at once when there are none
+        {
+            GArgs g;
+            g.s = a.s; g.slab = (const unsigned long long*)c->d_slab.p; g.wcount = c->d_wcount.as<uint32_t>(); g.wdel = c->d_wdel.as<int32_t>(); g.tiles = a.tiles; g.n_tiles = tile_base;
+            g.cols = a.cols; g.hist = a.hist; g.tile_stats = a.tile_stats; g.deep = c->d_deep.as<uint32_t>() + 1; g.n_deep = c->d_deep.as<uint32_t>();
+            hipLaunchKernelGGL(k4_exec, dim3((unsigned)grid), dim3(GT), (size_t)G_LDS, c->stream, g);
+        }
+        // windows the gather path left on the list (long reads, odd CIGARs, too deep): the general kernel
+        const unsigned dgrid = (unsigned)std::min<uint64_t>(tile_base, 2048);
+        hipLaunchKernelGGL(k4_tile<L16>, dim3(dgrid), dim3(L16::T), lds16, c->stream, a, 1);
+        hipLaunchKernelGGL(k4_tile<L32>, dim3(std::min(dgrid, 512u)), dim3(L32::T), lds32, c->stream, a, 1);
         hipLaunchKernelGGL(k4_stats, dim3(32), dim3(256), 0, c->stream, a.tile_stats, tile_base, a.pstats);
         BGP_HIP(hipGetLastError());
     }
