@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libbiodgpu.so")
+SO_PATH = os.environ.get("BIODGPU_SO") or os.path.join(_HERE, "libbiodgpu.so")      # (BIODGPU_SO: A/B builds of the same library for kernel experiments)
 
 BGP_OK, BGP_EOF = 0, 1
 BGP_EINVAL, BGP_ETRUNC, BGP_ECIGAR, BGP_EDEVICE, BGP_ENOMEM, BGP_ESTATE, BGP_EMD, BGP_EUNSORTED, BGP_ESEQ = -1, -2, -3, -4, -5, -6, -7, -8, -9

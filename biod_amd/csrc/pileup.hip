@@ -882,30 +882,44 @@ __global__ __launch_bounds__(256) void k4_stats(const unsigned long long* ts, ui
 //   SEG  [2] the read starts here (n_starting_here)  [13:3] first position in the window  [21:14] bases (1..255)
 //        [22] the first base is the LOW nibble of its byte  [63:23] stream offset of that byte
 //   DEL  [13:3] first position  [25:14] one past the last position (<= W)
-constexpr int GT = 512;                       // threads of a k4_exec workgroup
+#ifndef BGP_G_ABL
+#define BGP_G_ABL 0                           // timing experiments: 1 no gather, 2 no staging either, 3 no layout either, 4 window header only
+#endif
+#ifdef BGP_G_PROF                              // phase clocks of k4_exec (thread 0 of every workgroup), one row of 16 per window
+__device__ unsigned long long* g_prof_buf;
+#define GSTAMP(k) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); pacc_[k] += now_ - stamp_; stamp_ = now_; if ((k) == 11 && threadIdx.x == 0) for (int q_ = 0; q_ < 12; ++q_) g_prof_buf[tile * 16 + q_] = pacc_[q_]; } while (0)
+#else
+#define GSTAMP(k) do { } while (0)
+#endif
+#ifndef BGP_G_T
+#define BGP_G_T (BGP_K4_W / 2)
+#endif
+constexpr int GT = BGP_G_T;                   // threads of a k4_exec workgroup
 constexpr int GNW = GT / 64;                  // waves
 constexpr int GNB = W / 64;                   // 64-position blocks per window
 constexpr int GBPW = GNB / GNW;               // blocks per wave
 constexpr int GCAP = GT;                      // descriptors per round (one per thread)
-constexpr uint32_t SLAB_CAP = 1024;           // descriptors a window's slab holds; more: the window goes to k4_tile
-constexpr int PAIRCAP = 128;                  // segments per 64-position block and round
-constexpr int G_STAGE = 56 * 1024;            // staged class bytes per round
-constexpr int SEG_SLOTS = 6, SEG_PER_WAVE = 10;   // staging: 6 lanes (32 bases each) per segment, 10 segments per wave step
-constexpr int STAGE_IT = (GCAP + GNW * SEG_PER_WAVE - 1) / (GNW * SEG_PER_WAVE);   // wave steps per round
-static_assert(GBPW >= 1 && GNB % GNW == 0, "window / workgroup geometry");
-static_assert(W <= 2048, "descriptor fields");
+constexpr uint32_t SLAB_CAP = W;              // descriptors a window's slab holds (~3 x the ordinary count at 30-fold coverage); more: the window goes to k4_tile
+constexpr int PAIRCAP = 128;                  // entries of a block's segment list (a fuller list is worked off in pieces)
+constexpr int G_STAGE = 52 * W;               // staged class bytes per round (what does not fit waits for the next round)
+constexpr int CH_CAP = G_STAGE / 32;          // 32-base staging chunks per round
+constexpr int STAGE_IT = (CH_CAP + GT - 1) / GT;
+constexpr int GD_STEPS = GCAP / 64;
+static_assert(GBPW >= 1 && GNB % GNW == 0 && GNB <= 32, "window / workgroup geometry");
+static_assert(W <= 2048 && GCAP <= 1024, "descriptor fields");
 // LDS map of k4_exec (bytes)
 constexpr int G_TAIL = G_STAGE;                               // 17 x 16: tail masks
 constexpr int G_DELD = G_TAIL + 17 * 16;                      // (W + 4) x u32
 constexpr int G_NST = G_DELD + (W + 4) * 4;                   // W x u16, two to a word
 constexpr int G_HIST = G_NST + W * 2;                         // HB x u32
-constexpr int G_BLKN = G_HIST + HB * 4;                       // GNB x u32
-constexpr int G_BLKL = G_BLKN + GNB * 4;                      // GNB x PAIRCAP x u16
-constexpr int G_SEGI = G_BLKL + GNB * PAIRCAP * 2;            // GCAP x uint4
-constexpr int G_MISC = G_SEGI + GCAP * 16;                    // wave totals, flags
+constexpr int G_BLKL = G_HIST + HB * 4;                       // GNB x PAIRCAP x u16: a block's segment list, private to the wave that owns the block
+constexpr int G_SEGI = G_BLKL + GNB * PAIRCAP * 2;            // GCAP x uint4: where a segment's bases are, where its class bytes go
+constexpr int G_GD = G_SEGI + GCAP * 16;                      // GCAP x u32: address delta | first block << 16 | last block << 21
+constexpr int G_CMAP = G_GD + GCAP * 4;                       // CH_CAP x u16: staging chunk -> segment << 3 | chunk of the segment
+constexpr int G_MISC = G_CMAP + CH_CAP * 2;                   // wave totals, flags
 constexpr int G_LDS = G_MISC + 256;
-static_assert(G_SEGI % 16 == 0 && G_DELD % 16 == 0, "alignment");
-constexpr int FAST_SEG = 160;                 // longest read of the gather path (<= 6 staging lanes with an odd start)
+static_assert(G_SEGI % 16 == 0 && G_DELD % 16 == 0 && G_GD % 4 == 0 && G_MISC % 8 == 0, "alignment");
+constexpr int FAST_SEG = 160;                 // longest read of the gather path (<= 6 staging chunks with an odd start)
 
 struct PlanArgs {
     const bgp_record* rec; const uint4* cig4; const uint8_t* s; uint64_t stream_len, n;
@@ -1084,164 +1098,268 @@ struct GArgs {
     bgp_column* cols; unsigned long long* hist; unsigned long long* tile_stats; uint32_t* deep; uint32_t* n_deep;
 };
 
-__global__ __launch_bounds__(GT) void k4_exec(GArgs a) {
+// sum / max over the 64 lanes of a wave with DPP (row reductions, then row_bcast15 / row_bcast31); result in every lane
+#define BGP_DPP(v, ctrl, rmask) (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), ctrl, rmask, 0xF, false)
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
+    v += BGP_DPP(v, 0xB1, 0xF); v += BGP_DPP(v, 0x4E, 0xF); v += BGP_DPP(v, 0x141, 0xF); v += BGP_DPP(v, 0x140, 0xF);
+    v += BGP_DPP(v, 0x142, 0xA); v += BGP_DPP(v, 0x143, 0xC);
+    return rl(v, 63);
+}
+// inclusive prefix sum over the 64 lanes: shifts inside the rows of 16, then the rows' totals carried over
+__device__ __forceinline__ uint32_t wave_scan_u32(uint32_t v) {
+    v += BGP_DPP(v, 0x111, 0xF); v += BGP_DPP(v, 0x112, 0xF); v += BGP_DPP(v, 0x114, 0xF); v += BGP_DPP(v, 0x118, 0xF);
+    v += BGP_DPP(v, 0x142, 0xA); v += BGP_DPP(v, 0x143, 0xC);
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+    v = max(v, BGP_DPP(v, 0xB1, 0xF)); v = max(v, BGP_DPP(v, 0x4E, 0xF)); v = max(v, BGP_DPP(v, 0x141, 0xF)); v = max(v, BGP_DPP(v, 0x140, 0xF));
+    v = max(v, BGP_DPP(v, 0x142, 0xA)); v = max(v, BGP_DPP(v, 0x143, 0xC));
+    return rl(v, 63);
+}
+
+// Eight (segment, 64 positions) pairs of the gather, scheduled by hand: the segments' address deltas come out of lanes
+// L0 .. L0+7 of `vc` with v_readlane, eight ds_read_u8 are in flight together, every byte read is the bit position the
+// lane's packed counter grows at (v_lshl_add_u32).  Left to the compiler under register pressure this became
+// read - wait - use with one temporary, i.e. one LDS latency per pair.
+template <int L0> __device__ __forceinline__ void gather8(uint32_t& acc, uint32_t vc, uint32_t addr) {
+    uint32_t t0, t1, t2, t3, t4, t5, t6, t7, s0, s1, s2, s3, s4, s5, s6, s7;
+    asm volatile(
+        "v_readlane_b32 %[s0], %[vc], %[l0]\n\tv_readlane_b32 %[s1], %[vc], %[l1]\n\tv_readlane_b32 %[s2], %[vc], %[l2]\n\tv_readlane_b32 %[s3], %[vc], %[l3]\n\t"
+        "v_readlane_b32 %[s4], %[vc], %[l4]\n\tv_readlane_b32 %[s5], %[vc], %[l5]\n\tv_readlane_b32 %[s6], %[vc], %[l6]\n\tv_readlane_b32 %[s7], %[vc], %[l7]\n\t"
+        "v_add_u32 %[t0], %[s0], %[ad]\n\tv_add_u32 %[t1], %[s1], %[ad]\n\tv_add_u32 %[t2], %[s2], %[ad]\n\tv_add_u32 %[t3], %[s3], %[ad]\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "ds_read_u8 %[t0], %[t0]\n\tds_read_u8 %[t1], %[t1]\n\tds_read_u8 %[t2], %[t2]\n\tds_read_u8 %[t3], %[t3]\n\t"
+        "v_add_u32 %[t4], %[s4], %[ad]\n\tv_add_u32 %[t5], %[s5], %[ad]\n\tv_add_u32 %[t6], %[s6], %[ad]\n\tv_add_u32 %[t7], %[s7], %[ad]\n\t"
+        "ds_read_u8 %[t4], %[t4]\n\tds_read_u8 %[t5], %[t5]\n\tds_read_u8 %[t6], %[t6]\n\tds_read_u8 %[t7], %[t7]\n\t"
+        "s_waitcnt lgkmcnt(7)\n\tv_lshl_add_u32 %[acc], 1, %[t0], %[acc]\n\t"
+        "s_waitcnt lgkmcnt(6)\n\tv_lshl_add_u32 %[acc], 1, %[t1], %[acc]\n\t"
+        "s_waitcnt lgkmcnt(5)\n\tv_lshl_add_u32 %[acc], 1, %[t2], %[acc]\n\t"
+        "s_waitcnt lgkmcnt(4)\n\tv_lshl_add_u32 %[acc], 1, %[t3], %[acc]\n\t"
+        "s_waitcnt lgkmcnt(3)\n\tv_lshl_add_u32 %[acc], 1, %[t4], %[acc]\n\t"
+        "s_waitcnt lgkmcnt(2)\n\tv_lshl_add_u32 %[acc], 1, %[t5], %[acc]\n\t"
+        "s_waitcnt lgkmcnt(1)\n\tv_lshl_add_u32 %[acc], 1, %[t6], %[acc]\n\t"
+        "s_waitcnt lgkmcnt(0)\n\tv_lshl_add_u32 %[acc], 1, %[t7], %[acc]"
+        : [acc] "+v"(acc), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [t4] "=&v"(t4), [t5] "=&v"(t5), [t6] "=&v"(t6), [t7] "=&v"(t7),
+          [s0] "=&s"(s0), [s1] "=&s"(s1), [s2] "=&s"(s2), [s3] "=&s"(s3), [s4] "=&s"(s4), [s5] "=&s"(s5), [s6] "=&s"(s6), [s7] "=&s"(s7)
+        : [vc] "v"(vc), [ad] "v"(addr), [l0] "n"(L0), [l1] "n"(L0 + 1), [l2] "n"(L0 + 2), [l3] "n"(L0 + 3), [l4] "n"(L0 + 4), [l5] "n"(L0 + 5), [l6] "n"(L0 + 6), [l7] "n"(L0 + 7)
+        : "memory");
+}
+
+#ifndef BGP_G_MINW
+#define BGP_G_MINW (GNW / 2)                  // two workgroups per CU: their waves per SIMD bound the registers (128 for 8-wave workgroups)
+#endif
+__global__ __launch_bounds__(GT, BGP_G_MINW) void k4_exec(GArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t glds[];
     uint8_t* const stage = glds;
     uint4* const tailm = reinterpret_cast<uint4*>(glds + G_TAIL);
     uint32_t* const deld = reinterpret_cast<uint32_t*>(glds + G_DELD);
     uint32_t* const nst = reinterpret_cast<uint32_t*>(glds + G_NST);
     uint32_t* const hist = reinterpret_cast<uint32_t*>(glds + G_HIST);
-    uint32_t* const blk_n = reinterpret_cast<uint32_t*>(glds + G_BLKN);
     uint16_t* const blk_l = reinterpret_cast<uint16_t*>(glds + G_BLKL);
     uint4* const segi = reinterpret_cast<uint4*>(glds + G_SEGI);
-    uint32_t* const misc = reinterpret_cast<uint32_t*>(glds + G_MISC);     // [0..7] wave totals, [8] overflow flag
-    // XCD-aware order: consecutive windows of a reference go to the same XCD (block b runs on XCD b % 8), so a read
-    // staged by two neighbouring windows is fetched from HBM once
-    const uint64_t nbt = a.n_tiles, per = (nbt + 7) / 8;
-    uint64_t tile = (blockIdx.x % 8) * per + blockIdx.x / 8;
-    if (nbt < 64) tile = blockIdx.x;
-    if (tile >= nbt) return;
-    const TileB tb = a.tiles[tile];
-    if (tb.pad) return;                                   // on the general kernel's list
-    const uint32_t n_desc = a.wcount[tile];
-    const int32_t wd = a.wdel[tile];
+    uint32_t* const gd = reinterpret_cast<uint32_t*>(glds + G_GD);
+    uint16_t* const cmap = reinterpret_cast<uint16_t*>(glds + G_CMAP);
+    uint32_t* const misc = reinterpret_cast<uint32_t*>(glds + G_MISC);     // [0..15] wave totals, [16] descriptors of the round that fit
+    // Persistent: a workgroup owns a contiguous range of windows and walks it, so a read staged by two neighbouring
+    // windows is fetched from HBM once, and -- the point -- the NEXT window's header and first descriptors are
+    // requested before the current window is worked on: that round trip hides behind a whole window of work
+    // instead of standing in front of it (with two 76 KB workgroups per CU nothing else would overlap it).
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    for (int i = t; i < (G_BLKL - G_DELD) / 4; i += GT) deld[i] = 0;      // deld, nst, hist, blk_n
+    const uint64_t nbt = a.n_tiles, per = (nbt + gridDim.x - 1) / gridDim.x;
+    const uint64_t tile_end = min(nbt, ((uint64_t)blockIdx.x + 1) * per);
+    uint64_t tile = (uint64_t)blockIdx.x * per;
+    if (tile >= tile_end) return;
     if (t < 17) { uint32_t m[4]; for (int k = 0; k < 4; ++k) { const int v = t - 4 * k; m[k] = v >= 4 ? 0u : v <= 0 ? 0xFFFFFFFFu : 0xFFFFFFFFu << (8 * v); } tailm[t] = make_uint4(m[0], m[1], m[2], m[3]); }
-    if (t < 4) reinterpret_cast<uint4*>(stage)[t] = make_uint4(~0u, ~0u, ~0u, ~0u);     // the 64 padding bytes in front of the first segment
-    if (t == 0) misc[8] = 0;
+    if (t < 4) reinterpret_cast<uint4*>(stage)[t] = make_uint4(~0u, ~0u, ~0u, ~0u);     // the 64 padding bytes in front of the first segment (no round writes them)
+    for (int i = t; i < (G_BLKL - G_DELD) / 4; i += GT) deld[i] = 0;      // deld, nst (a window leaves them zeroed again), hist (kept for the whole range of windows)
+    unsigned long long d_pre = a.slab[tile * (uint64_t)SLAB_CAP + t];
+    TileB tb_pre = a.tiles[tile];
+    uint32_t n_pre = a.wcount[tile];
+    int32_t wd_pre = a.wdel[tile];
+  for (; tile < tile_end; ++tile) {
+#ifdef BGP_G_PROF
+    unsigned long long pacc_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long stamp_ = __builtin_amdgcn_s_memtime();
+#endif
+    const unsigned long long d_first = d_pre;
+    const TileB tb = tb_pre;
+    const uint32_t n_desc = n_pre;
+    const int32_t wd = wd_pre;
+    if (tile + 1 < tile_end) {
+        d_pre = a.slab[(tile + 1) * (uint64_t)SLAB_CAP + t];
+        tb_pre = a.tiles[tile + 1]; n_pre = a.wcount[tile + 1]; wd_pre = a.wdel[tile + 1];
+    }
+    if (tb.pad) continue;                                 // on the general kernel's list
+#if BGP_G_ABL >= 4
+    if (tb.T0 != 0xFFFFFFFFu) continue;
+#endif
+    const unsigned long long* slab = a.slab + tile * (uint64_t)SLAB_CAP;
     uint32_t cA[GBPW], cC[GBPW], cG[GBPW], cT[GBPW], cO[GBPW];
 #pragma unroll
     for (int b = 0; b < GBPW; ++b) { cA[b] = 0; cC[b] = 0; cG[b] = 0; cT[b] = 0; cO[b] = 0; }
-    const unsigned long long* slab = a.slab + tile * (uint64_t)SLAB_CAP;
-    const int sl = lane / SEG_SLOTS, sj = lane - sl * SEG_SLOTS;
-    __syncthreads();
+    GSTAMP(0);        // (the header and the first descriptors were requested a window ago)
 
-    for (uint32_t base = 0; base < n_desc; base += GCAP) {
+    for (uint32_t base = 0; base < (BGP_G_ABL >= 3 ? 0u : n_desc);) {
         const uint32_t nr = min((uint32_t)GCAP, n_desc - base);
-        // ---- lay out: a place in LDS for every segment's class bytes, the per-block segment lists, '-' and start marks
+        // ---- lay out: a place in LDS for every segment's class bytes, '-' and start marks
         unsigned long long d = 0;
-        if ((uint32_t)t < nr) d = slab[base + t];
-        const uint32_t kind = (uint32_t)d & 3u;
+        if ((uint32_t)t < nr) d = base == 0 ? d_first : slab[base + t];
+        uint32_t kind = (uint32_t)d & 3u;
         const uint32_t lo = ((uint32_t)d >> 3) & 0x7FFu, f14 = (uint32_t)(d >> 14);
         const uint32_t len = f14 & 0xFFu, nib = (f14 >> 8) & 1u;
-        const uint32_t nch = kind == 1 ? (len + nib + 15) >> 4 : 0u;
-        const uint32_t units = kind == 1 ? nch + 4 : 0u;                     // 16-byte units: the bytes + 64 of padding behind them
+        const uint32_t nch = kind == 1 ? (len + nib + 15) >> 4 : 0u;        // 16-byte units of class bytes
+        const uint32_t c32 = (nch + 1) >> 1;                                  // 32-base staging chunks
+        const uint32_t units = kind == 1 ? (nch + 4) | (c32 << 16) : 0u;      // low half: the bytes + 64 of padding behind them
         const uint32_t inc = wave_incl_u32(units, lane);
         if (lane == 63) misc[wave] = inc;
+        GSTAMP(1);    // descriptors arrived, wave scan
         __syncthreads();
         uint32_t carry = 0, total = 0;
 #pragma unroll
         for (int k = 0; k < GNW; ++k) { const uint32_t v = misc[k]; if (k < wave) carry += v; total += v; }
-        const uint32_t data_off = 64 + 16 * (carry + inc - units);
-        const bool fits = 64 + 16 * total <= (uint32_t)G_STAGE;
-        if (kind == 1 && fits) {
+        const uint32_t ex = carry + inc - units;
+        const uint32_t data_off = 64 + 16 * (ex & 0xFFFFu);
+        uint32_t n_fit = nr, n_chunks = total >> 16;
+        if (64 + 16 * (total & 0xFFFFu) > (uint32_t)G_STAGE) {                // the round is cut where LDS ends; the rest waits for the next one
+            const bool fit = (uint32_t)t < nr && data_off + 16 * (nch + 4) <= (uint32_t)G_STAGE;
+            if (t == 0) { misc[16] = 0; misc[17] = 0; }
+            __syncthreads();
+            const unsigned long long fm = __ballot(fit);
+            if (lane == 0 && fm) { atomicAdd(&misc[16], (uint32_t)__popcll(fm)); }
+            if (fit) atomicMax(&misc[17], (ex >> 16) + c32);
+            __syncthreads();
+            n_fit = misc[16]; n_chunks = misc[17];
+        }
+        if ((uint32_t)t >= n_fit) kind = 0;
+        if (kind == 1) {
             const uint64_t src = d >> 23;
             segi[t] = make_uint4((uint32_t)src, (uint32_t)(src >> 32) | (nib << 16) | (len << 20), data_off, 0u);
             uint4* padp = reinterpret_cast<uint4*>(stage + data_off + 16 * nch);
             const uint4 ff = make_uint4(~0u, ~0u, ~0u, ~0u);
             padp[0] = ff; padp[1] = ff; padp[2] = ff; padp[3] = ff;
-            const uint32_t cdel = data_off + nib - lo + W;                 // staged byte of position p: stage[p - W + cdel]
-            const uint32_t b1 = (lo + len - 1) >> 6;
-            for (uint32_t b = lo >> 6; b <= b1; ++b) {
-                const uint32_t slot = atomicAdd(&blk_n[b], 1u);
-                if (slot < (uint32_t)PAIRCAP) blk_l[b * PAIRCAP + slot] = (uint16_t)cdel; else misc[8] = 1;
-            }
-            if (d & 4u) atomicAdd(&nst[lo >> 1], 1u << ((lo & 1u) * 16));   // n_starting_here, pileup.d:386,422 (a count per position stays below 2^16: the slab holds 1024 descriptors)
-        } else if ((uint32_t)t < (uint32_t)GCAP) segi[t] = make_uint4(0, 0, 0, 0);
-        if (kind == 2) { atomicAdd(&deld[lo], 1u); atomicAdd(&deld[f14 & 0xFFFu], 0xFFFFFFFFu); }
+            const uint32_t cdel = data_off + nib - lo + W;                   // staged byte of position p: stage[p - W + cdel]
+            gd[t] = cdel | ((lo >> 6) << 16) | (((lo + len - 1) >> 6) << 21);
+            const uint32_t c0 = ex >> 16;
+            for (uint32_t j = 0; j < c32; ++j) cmap[c0 + j] = (uint16_t)((t << 3) | j);
+            if (d & 4u) atomicAdd(&nst[lo >> 1], 1u << ((lo & 1u) * 16));   // n_starting_here, pileup.d:386,422 (a count per position stays below 2^16: the slab holds W descriptors)
+        } else {
+            gd[t] = 1u << 16;                                                 // first block 1, last block 0: overlaps nothing
+            if (kind == 2) { atomicAdd(&deld[lo], 1u); atomicAdd(&deld[f14 & 0xFFFu], 0xFFFFFFFFu); }
+        }
+        GSTAMP(2);    // layout
         __syncthreads();
-        if (!fits || misc[8]) {                                // more segments than a round's LDS holds: the general kernel takes the window
-            if (t == 0) a.deep[atomicAdd(a.n_deep, 1u)] = (uint32_t)tile;
-            return;
-        }
-        // ---- stage: 32 bases per lane, 6 lanes per segment, 10 segments per wave step.  Every load of the round is
-        // requested before the first is looked at: one HBM round trip per round, not one per step.
-        uint4 pk[STAGE_IT];
+        GSTAMP(3);
+        // ---- stage: 32 bases per lane, lane after lane along the segments.  Every load of the round is requested
+        // before the first is looked at: one HBM round trip per round.
+        uint4 pk[STAGE_IT]; uint32_t ce[STAGE_IT];
+#if BGP_G_ABL >= 2
+        if (n_desc != 0xFFFFFFFFu) { base += n_fit; continue; }
+#endif
 #pragma unroll
         for (int it = 0; it < STAGE_IT; ++it) {
-            const uint32_t si = (uint32_t)(it * GNW + wave) * SEG_PER_WAVE + sl;
-            pk[it] = make_uint4(0, 0, 0, 0);
-            if (sl < SEG_PER_WAVE && si < nr) {
-                const uint4 g = segi[si];
-                const uint32_t glen = g.y >> 20, gnib = (g.y >> 16) & 1u;
-                if (glen && (int32_t)(glen + gnib) - 32 * sj > 0) __builtin_memcpy(&pk[it], a.s + ((((uint64_t)(g.y & 0xFFFFu)) << 32) | g.x) + 16u * sj, 16);
+            const uint32_t c = (uint32_t)(it * GT + t);
+            pk[it] = make_uint4(0, 0, 0, 0); ce[it] = 0xFFFFFFFFu;
+            if (c < n_chunks) {
+                const uint32_t e = cmap[c];
+                const uint4 g = segi[e >> 3];
+                __builtin_memcpy(&pk[it], a.s + ((((uint64_t)(g.y & 0xFFFFu)) << 32) | g.x) + 16u * (e & 7u), 16);
+                ce[it] = e;
             }
         }
+        GSTAMP(4);    // staging loads issued
 #pragma unroll
         for (int it = 0; it < STAGE_IT; ++it) {
-            const uint32_t si = (uint32_t)(it * GNW + wave) * SEG_PER_WAVE + sl;
-            if (sl < SEG_PER_WAVE && si < nr) {
-                const uint4 g = segi[si];
-                const uint32_t glen = g.y >> 20, gnib = (g.y >> 16) & 1u;
-                const int32_t valid = (int32_t)(glen + gnib) - 32 * sj;          // staged bytes of this lane that belong to the segment (incl. the skipped nibble)
-                if (glen && valid > 0) {
-                    const uint2 c0 = class_bits8(pk[it].x), c1 = class_bits8(pk[it].y), c2 = class_bits8(pk[it].z), c3 = class_bits8(pk[it].w);
-                    const uint4 t0 = tailm[min(valid, 16)], t1 = tailm[min(max(valid - 16, 0), 16)];
-                    uint4 o0 = make_uint4(c0.x | t0.x, c0.y | t0.y, c1.x | t0.z, c1.y | t0.w);
-                    const uint4 o1 = make_uint4(c2.x | t1.x, c2.y | t1.y, c3.x | t1.z, c3.y | t1.w);
-                    if (sj == 0 && gnib) o0.x |= 0xFFu;
-                    uint4* dst = reinterpret_cast<uint4*>(stage + g.z + 32 * sj);
-                    dst[0] = o0; dst[1] = o1;                                     // (a second half past the segment lands in its own padding)
+            if (ce[it] != 0xFFFFFFFFu) {
+                const uint4 g = segi[ce[it] >> 3];
+                const uint32_t sj = ce[it] & 7u, glen = g.y >> 20, gnib = (g.y >> 16) & 1u;
+                const int32_t valid = (int32_t)(glen + gnib) - 32 * (int32_t)sj;     // staged bytes of this lane that belong to the segment (incl. the skipped nibble): > 0
+                const uint2 c0 = class_bits8(pk[it].x), c1 = class_bits8(pk[it].y), c2 = class_bits8(pk[it].z), c3 = class_bits8(pk[it].w);
+                const uint4 t0 = tailm[min(valid, 16)], t1 = tailm[min(max(valid - 16, 0), 16)];
+                uint4 o0 = make_uint4(c0.x | t0.x, c0.y | t0.y, c1.x | t0.z, c1.y | t0.w);
+                const uint4 o1 = make_uint4(c2.x | t1.x, c2.y | t1.y, c3.x | t1.z, c3.y | t1.w);
+                if (sj == 0 && gnib) o0.x |= 0xFFu;
+                uint4* dst = reinterpret_cast<uint4*>(stage + g.z + 32 * sj);
+                dst[0] = o0; dst[1] = o1;                                         // (a second half past the segment lands in its own padding)
+            }
+        }
+        GSTAMP(5);    // staged
+        __syncthreads();
+        GSTAMP(6);
+        // ---- gather: a wave picks the segments that overlap each of its 64-position blocks (list private to the
+        // wave: a ballot, no atomics) and walks them
+#pragma unroll
+        for (int bb = 0; bb < (BGP_G_ABL >= 1 ? 0 : GBPW); ++bb) {
+            const int b = wave * GBPW + bb;
+            const uint32_t paddr = (uint32_t)reinterpret_cast<uintptr_t>(stage) + (uint32_t)(64 * b + lane - W);   // LDS address + delta = this lane's byte of the segment
+            const uint32_t csent = (uint32_t)(W - 64 * b);                    // + paddr = the padding in front of the first segment
+            uint16_t* const bl = blk_l + b * PAIRCAP;
+            uint32_t n = 0;
+            auto walk = [&]() {
+                for (uint32_t p0 = 0; p0 < n; p0 += 56) {
+                    const uint32_t cnt = min(56u, n - p0);
+                    const uint32_t vc = (uint32_t)lane < cnt ? (uint32_t)bl[p0 + lane] : csent;
+                    uint32_t acc = 0;
+                    gather8<0>(acc, vc, paddr);
+                    if (cnt > 8) gather8<8>(acc, vc, paddr);
+                    if (cnt > 16) gather8<16>(acc, vc, paddr);
+                    if (cnt > 24) gather8<24>(acc, vc, paddr);
+                    if (cnt > 32) gather8<32>(acc, vc, paddr);
+                    if (cnt > 40) gather8<40>(acc, vc, paddr);
+                    if (cnt > 48) gather8<48>(acc, vc, paddr);
+                    cA[bb] += acc & 63u; cC[bb] += (acc >> 6) & 63u; cG[bb] += (acc >> 12) & 63u; cT[bb] += (acc >> 18) & 63u; cO[bb] += (acc >> 24) & 63u;
                 }
+                n = 0;
+            };
+#pragma unroll
+            for (int k = 0; k < GD_STEPS; ++k) {
+                if ((uint32_t)(k * 64) >= n_fit) break;
+                const uint32_t v = gd[k * 64 + lane];
+                const bool in = ((v >> 16) & 31u) <= (uint32_t)b && (uint32_t)b <= (v >> 21);
+                const unsigned long long m = __ballot(in);
+                if (!m) continue;
+                if (in) bl[n + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = (uint16_t)v;
+                n += (uint32_t)__popcll(m);
+                if (n > (uint32_t)PAIRCAP - 64) walk();
             }
+            walk();
         }
-        __syncthreads();
-        // ---- gather: a wave walks the segment list of each of its 64-position blocks
+        GSTAMP(7);    // gathered (no barrier here: whatever overwrites the tables or the staged bytes next does so behind a barrier of its own)
+        base += n_fit;
+    }
+    // ---- flush: the '-' difference array summed up (a wave scans its own positions with DPP, the waves before it
+    // enter as one number each), then 32 contiguous bytes per position.  What a lane reads of deld / nst it zeroes for
+    // the next window (whose first barrier comes before anything is added again).
+    const uint32_t np = tb.Tend - tb.T0;
+    uint32_t dl[GBPW];
+    {
+        uint32_t run = 0;
 #pragma unroll
         for (int bb = 0; bb < GBPW; ++bb) {
-            const int b = wave * GBPW + bb;
-            const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)min(blk_n[b], (uint32_t)PAIRCAP));
-            const int pbi = 64 * b + lane - W;                                // + cdel = this lane's byte of the segment
-            const uint32_t csent = (uint32_t)(W - 64 * b);                    // + pbi = the padding in front of the first segment
-            for (uint32_t p0 = 0; p0 < n; p0 += 56) {
-                const uint32_t cnt = min(56u, n - p0);
-                const uint32_t vc = (uint32_t)lane < cnt ? (uint32_t)blk_l[b * PAIRCAP + p0 + lane] : csent;
-                uint32_t acc = 0;
-#pragma unroll
-                for (int g = 0; g < 7; ++g) {
-                    if ((uint32_t)(g * 8) >= cnt) break;
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        const uint32_t cd8 = rl(vc, g * 8 + k);
-                        const uint32_t code = stage[pbi + (int)cd8];
-                        acc = (1u << (code & 31u)) + acc;
-                    }
-                }
-                cA[bb] += acc & 63u; cC[bb] += (acc >> 6) & 63u; cG[bb] += (acc >> 12) & 63u; cT[bb] += (acc >> 18) & 63u; cO[bb] += (acc >> 24) & 63u;
-            }
+            const uint32_t p = 64 * (wave * GBPW + bb) + lane;
+            const uint32_t e = deld[p];
+            deld[p] = 0;
+            const uint32_t sc = wave_scan_u32(e);
+            dl[bb] = run + sc;
+            run += rl(sc, 63);
         }
+        if (t == 0) deld[W] = 0;                                             // (an op that ends with the window leaves its -1 here)
+        if (lane == 0) misc[32 + wave] = run;                                // (slots of their own: a wave ahead may already be scanning the next window's descriptors into misc[0..])
         __syncthreads();
-        if (t < GNB) blk_n[t] = 0;
-        // (the next round's first barrier orders this reset before its atomics)
-    }
-    // ---- flush: prefix-sum the '-' difference array, then 32 contiguous bytes per position
-    const uint32_t np = tb.Tend - tb.T0;
-    {
-        constexpr int PER = W / GT;
-        const uint32_t p0 = t * PER;
-        uint32_t loc[PER]; uint32_t run_sum = 0;
+        uint32_t carry = (uint32_t)wd;
+        for (int k = 0; k < wave; ++k) carry += misc[32 + k];
 #pragma unroll
-        for (int j = 0; j < PER; ++j) { run_sum += deld[p0 + j]; loc[j] = run_sum; }
-        const uint32_t inc = wave_incl_u32(run_sum, lane);
-        __syncthreads();
-        if (lane == 63) misc[wave] = inc;
-        __syncthreads();
-        uint32_t carry = 0;
-        for (int k = 0; k < wave; ++k) carry += misc[k];
-        const uint32_t ex = carry + inc - run_sum;
-#pragma unroll
-        for (int j = 0; j < PER; ++j) deld[p0 + j] = ex + loc[j];
-        __syncthreads();
+        for (int bb = 0; bb < GBPW; ++bb) dl[bb] += carry;
     }
+    GSTAMP(9);        // '-' scan
     bgp_column* out = a.cols + tb.col_out;
-    uint64_t ncol = 0, scov = 0, nsum = 0; uint32_t mx = 0;
+    uint32_t ncol = 0, scov = 0, nsum = 0, mx = 0;      // per lane: GBPW positions, sums below 2^32
 #pragma unroll
     for (int bb = 0; bb < GBPW; ++bb) {
         const uint32_t p = 64 * (wave * GBPW + bb) + lane;
+        const uint32_t sw = nst[p >> 1];
         if (p < np) {
-            const uint32_t D = deld[p] + (uint32_t)wd, S = (nst[p >> 1] >> ((p & 1u) * 16)) & 0xFFFFu;
+            const uint32_t D = dl[bb], S = (sw >> ((p & 1u) * 16)) & 0xFFFFu;
             const uint32_t cov = cA[bb] + cC[bb] + cG[bb] + cT[bb] + cO[bb] + D;
             uint4* o4 = reinterpret_cast<uint4*>(out + p);
             o4[0] = make_uint4(cov, S, cA[bb], cC[bb]);
@@ -1251,16 +1369,27 @@ __global__ __launch_bounds__(GT) void k4_exec(GArgs a) {
             else atomicAdd(&a.hist[min(cov, (uint32_t)BGP_DEPTH_BINS - 1)], 1ull);
         }
     }
-    for (int dd = 32; dd >= 1; dd >>= 1) { ncol += __shfl_down(ncol, dd, 64); scov += __shfl_down(scov, dd, 64); nsum += __shfl_down(nsum, dd, 64); mx = max(mx, (uint32_t)__shfl_down(mx, dd, 64)); }
-    __shared__ unsigned long long part[GNW][4];
-    if (lane == 0) { part[wave][0] = ncol; part[wave][1] = scov; part[wave][2] = mx; part[wave][3] = nsum; }
-    __syncthreads();
-    if (t < 4) {
-        unsigned long long v = 0;
-        for (int k = 0; k < GNW; ++k) v = t == 2 ? max(v, part[k][2]) : v + part[k][t];
-        a.tile_stats[tile * 4 + t] = v;
+    // (two lanes share a word of nst: both have read it before either zeroes it -- the wave runs in lockstep)
+#pragma unroll
+    for (int bb = 0; bb < GBPW; ++bb) { const uint32_t p = 64 * (wave * GBPW + bb) + lane; if ((p & 1u) == 0) nst[p >> 1] = 0; }
+    GSTAMP(10);       // columns written
+    // per-window totals: wave reductions with DPP, then one atomic per wave and total (the slots were zeroed by the host)
+    {
+        const uint32_t w_ncol = wave_sum_u32(ncol), w_nsum = wave_sum_u32(nsum), w_mx = wave_max_u32(mx);
+        const uint32_t s_lo = wave_sum_u32(scov & 0xFFFFu), s_hi = wave_sum_u32(scov >> 16);
+        if (lane == 0) {
+            unsigned long long* ts = a.tile_stats + tile * 4;
+            if (w_ncol) atomicAdd(&ts[0], (unsigned long long)w_ncol);
+            const unsigned long long sc = ((unsigned long long)s_hi << 16) + s_lo;
+            if (sc) atomicAdd(&ts[1], sc);
+            if (w_mx) atomicMax(&ts[2], (unsigned long long)w_mx);
+            if (w_nsum) atomicAdd(&ts[3], (unsigned long long)w_nsum);
+        }
     }
-    for (int b = t; b < HB; b += GT) { const uint32_t h = hist[b]; if (h) atomicAdd(&a.hist[b], (unsigned long long)h); }
+    GSTAMP(11);       // totals
+  }
+  __syncthreads();
+  for (int b = t; b < HB; b += GT) { const uint32_t h = hist[b]; if (h) atomicAdd(&a.hist[b], (unsigned long long)h); }     // the range's depth histogram, once
 }
 
 // ---------------------------------------------------------------------------------------------- K5
@@ -1400,7 +1529,6 @@ int k34_pileup(bgp_ctx* c) {
         a.runs = c->d_runs.as<RunDev>(); a.n_runs = n_runs; a.n_tiles = tile_base; a.stream_len = c->stream_len;
         a.cols = c->d_columns.as<bgp_column>(); a.hist = (unsigned long long*)c->d_depth_hist.p; a.pstats = (unsigned long long*)c->d_pstats.p; a.status = status;
         const size_t lds16 = (size_t)L16::WORDS * 4, lds32 = (size_t)L32::WORDS * 4;
-        const uint64_t grid = tile_base < 64 ? tile_base : ((tile_base + 7) / 8) * 8;
         uint64_t used = 0;   // algorithmic bytes: record table + CIGAR + packed SEQ per read, 32 B per position
         used = c->n_records * 32 + c->sum_ncig * 4 + (c->sum_lseq + 1) / 2 + col_base * 32;
         BGP_TRY(c->d_tiles.reserve(tile_base * sizeof(TileB)));
@@ -1447,12 +1575,20 @@ int k34_pileup(bgp_ctx* c) {
             hipLaunchKernelGGL(k4_ck_build, dim3(nb), dim3(256), 0, c->stream, a.s, a.rec, n, a.runs, n_runs, ck_off, c->d_ck.as<Ckpt>());
             a.ck = c->d_ck.as<Ckpt>(); a.ck_off = ck_off;
         }
+#ifdef BGP_G_PROF
+        unsigned long long* g_prof_dev = nullptr;
+        BGP_HIP(hipMalloc(&g_prof_dev, tile_base * 128));
+        BGP_HIP(hipMemset(g_prof_dev, 0, tile_base * 128));
+        BGP_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_prof_buf), &g_prof_dev, sizeof g_prof_dev));
+#endif
         TimedRegion t(c, "k4_tile", used);
+        BGP_HIP(hipMemsetAsync(a.tile_stats, 0, tile_base * 32, c->stream));      // the gather path adds its per-window totals wave by wave
         {
             GArgs g;
             g.s = a.s; g.slab = (const unsigned long long*)c->d_slab.p; g.wcount = c->d_wcount.as<uint32_t>(); g.wdel = c->d_wdel.as<int32_t>(); g.tiles = a.tiles; g.n_tiles = tile_base;
             g.cols = a.cols; g.hist = a.hist; g.tile_stats = a.tile_stats; g.deep = c->d_deep.as<uint32_t>() + 1; g.n_deep = c->d_deep.as<uint32_t>();
-            hipLaunchKernelGGL(k4_exec, dim3((unsigned)grid), dim3(GT), (size_t)G_LDS, c->stream, g);
+            static const unsigned g_blocks = getenv("BGP_G_BLOCKS") ? (unsigned)atoi(getenv("BGP_G_BLOCKS")) : 512u;     // two 76 KB workgroups per CU x 256 CUs
+            hipLaunchKernelGGL(k4_exec, dim3((unsigned)std::min<uint64_t>(tile_base, g_blocks)), dim3(GT), (size_t)G_LDS, c->stream, g);
         }
         // windows the gather path left on the list (long reads, odd CIGARs, too deep): the general kernel
         const unsigned dgrid = (unsigned)std::min<uint64_t>(tile_base, 2048);
@@ -1460,6 +1596,26 @@ int k34_pileup(bgp_ctx* c) {
         hipLaunchKernelGGL(k4_tile<L32>, dim3(std::min(dgrid, 512u)), dim3(L32::T), lds32, c->stream, a, 1);
         hipLaunchKernelGGL(k4_stats, dim3(32), dim3(256), 0, c->stream, a.tile_stats, tile_base, a.pstats);
         BGP_HIP(hipGetLastError());
+#ifdef BGP_G_PROF
+        {
+            BGP_HIP(hipStreamSynchronize(c->stream));
+            std::vector<unsigned long long> hb(tile_base * 16);
+            BGP_HIP(hipMemcpy(hb.data(), g_prof_dev, tile_base * 128, hipMemcpyDeviceToHost));
+            double h[16] = {0};
+            for (uint64_t w = 0; w < tile_base; ++w) for (int k = 0; k < 16; ++k) h[k] += (double)hb[w * 16 + k];
+            fprintf(stderr, "[k4_exec phase clocks / window]");
+            double tot = 0;
+            for (int k = 0; k < 12; ++k) { fprintf(stderr, " %d:%.0f", k, h[k] / (double)tile_base); tot += h[k]; }
+            fprintf(stderr, " total:%.0f\n", tot / (double)tile_base);
+            (void)hipFree(g_prof_dev);
+        }
+#endif
+    }
+    if (getenv("BGP_VERBOSE") && n_runs) {
+        uint32_t nd = 0;
+        BGP_HIP(hipMemcpyAsync(&nd, c->d_deep.p, 4, hipMemcpyDeviceToHost, c->stream));
+        BGP_HIP(hipStreamSynchronize(c->stream));
+        fprintf(stderr, "[biodgpu] K4: %u of %llu windows left to the general kernel\n", nd, (unsigned long long)tile_base);
     }
     uint64_t ps[16];
     BGP_HIP(hipMemcpyAsync(ps, c->d_pstats.p, 128, hipMemcpyDeviceToHost, c->stream));

@@ -14,11 +14,11 @@ for f in sorted(glob.glob("/root/repo/gpurun_out/sq_pmc/**/*counter_collection.c
         k = re.sub(r"\(.*", "", r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "")).strip().replace(",", ";")
         acc[k][r["Counter_Name"]] = acc[k].get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
 names = sorted({c for v in acc.values() for c in v})
-with open("/root/repo/gpurun_out/sq_pmc/r01_pmc_sq_per_kernel_cfg3_100M.csv", "w") as w:
+with open("/root/repo/gpurun_out/sq_pmc/r02_pmc_sq_per_kernel_cfg3_100M.csv", "w") as w:
     w.write("# rocprofv3 --kernel-trace --pmc <4 SQ counters per pass>, bench.py --steps 1 --warmup 0, cfg3 100 M reads; sums over a kernel's dispatches in the step\n")
     w.write("kernel," + ",".join(names) + "\n")
     for k in sorted(acc):
         if any(x in k for x in ("k0_", "k1", "k2_", "k3_", "k4_", "k12")):
             w.write(k + "," + ",".join(f"{acc[k].get(c, 0):.0f}" for c in names) + "\n")
-print(open("/root/repo/gpurun_out/sq_pmc/r01_pmc_sq_per_kernel_cfg3_100M.csv").read())
+print(open("/root/repo/gpurun_out/sq_pmc/r02_pmc_sq_per_kernel_cfg3_100M.csv").read())
 PY
