@@ -3,19 +3,28 @@
 
 One "step" = one full pass of the hot path over one synthetic coordinate-sorted BAM record stream that
 is already resident in HBM: record framing (K0), fixed fields + end_position (K1), SEQ/QUAL/CIGAR
-unpack (K2), reference-run keys (K3) and the per-position pileup (K4).  Nothing is cached between
-steps (bgp_reset drops every result).  At N GPUs every rank processes its own shard of contigs
-(weak scaling, no data-path collective) and the whole-BAM depth histogram is summed over RCCL.
+unpack (K2), reference-run keys (K3) and the per-position pileup (K4: plan + gather).  Nothing is cached
+between steps (bgp_reset drops every result).
+
+N GPUs (BASELINE.json config 4): the SAME 100 M-read BAM split by reference contig over the ranks (strong
+scaling; `--weak` gives every rank a full-size shard instead), no data-path collective; the path's only
+exchange is the whole-BAM depth histogram, summed inside the timed step by the product's own
+bgp_hist_reduce on an RCCL communicator this script creates (ncclGetUniqueId -> ncclCommInitRank).
 
     python bench.py --gpus 1 --steps 5 --warmup 2
+    python bench.py --gpus 8                     # spawns its 8 ranks itself when WORLD_SIZE is unset
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import ctypes as C
+import glob
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -24,20 +33,35 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
+STAGES = {"K0 framing": ("k0_",), "K1 record table": ("k1_",), "K2 unpack": ("k2_", "k12_"), "K3 run keys": ("k3_",),
+          "K4 pileup columns": ("k4_",)}
 
 
-def pmc_traffic(kernel, config, n_reads):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE
-    collected separately, KB units, FETCH doubled for gfx950 as MI355X_MICROARCH.md prescribes).  Counters
-    cannot be read from inside this process, so the number is only reported when the workload is the one the
-    profile was taken on (cfg3, 100 M reads); otherwise null."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic_cfg3_100M.csv")
+def kernels_sha():
+    """Hash of the kernel sources: a committed PMC profile is only quoted while it describes these kernels."""
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "biod_amd", "csrc", "*"))):
+        if f.endswith((".hip", ".h", ".cpp")):
+            h.update(os.path.basename(f).encode()); h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(prefixes, config, n_reads):
+    """HBM bytes per step of the kernels whose names start with `prefixes`, from the committed rocprofv3 PMC
+    passes (FETCH_SIZE and WRITE_SIZE collected separately, FETCH doubled for gfx950 as MI355X_MICROARCH.md
+    prescribes).  Counters cannot be read from inside this process, so the number is only reported when the
+    workload is the one the profile was taken on (cfg3, 100 M reads) AND the profile's header carries the hash
+    of the kernel sources as they are now (scratch/refresh_profiles.sh writes it); otherwise null."""
+    path = os.path.join(ROOT, "profiles", "r02_pmc_hbm_traffic_cfg3_100M.csv")
     if config != "cfg3" or n_reads != 100_000_000 or not os.path.exists(path):
         return None
+    lines = open(path).read().splitlines()
+    if not any(("kernels_sha=" + kernels_sha()) in ln for ln in lines if ln.startswith("#")):
+        return None
     total = None
-    for line in open(path):
+    for line in lines:
         f = line.strip().split(",")
-        if f and (f[0] == kernel or f[0].startswith(kernel + "<")):      # template instantiations of one timed region add up
+        if len(f) >= 5 and f[0].startswith(tuple(prefixes)) and f[4].isdigit():
             total = (total or 0) + int(f[4])
     return total
 
@@ -48,10 +72,12 @@ def parse():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="cfg3", choices=["cfg2", "cfg3", "cfg5"], help="BASELINE.json config (cfg3 = the 100M-read mixed-CIGAR BAM the metric is quoted on)")
-    ap.add_argument("--reads", type=int, default=0, help="reads per GPU (0 = the config's own size, reduced only if HBM is short)")
+    ap.add_argument("--reads", type=int, default=0, help="reads of the whole BAM (0 = the config's own size, reduced only if HBM is short)")
     ap.add_argument("--cpu-sample-reads", type=int, default=0, help="reads in the CPU-baseline sample (0 = auto, about 10-30 s of CPU work)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--strong", action="store_true", help="split ONE --reads-sized BAM by contig over the ranks (strong scaling) instead of one full shard per rank")
+    ap.add_argument("--no-checks", action="store_true", help="skip the full-size invariants after the timed region")
+    ap.add_argument("--weak", action="store_true", help="weak scaling: every rank gets a full --reads-sized shard of its own contigs (default: strong, ONE BAM split by contig)")
+    ap.add_argument("--strong", action="store_true", help="(default) kept for older command lines")
     return ap.parse_args()
 
 
@@ -75,35 +101,129 @@ def usable_cores():
 
 def cpu_baseline(cfg_name, n_sample):
     """The oracle (a C restatement of BioD's algorithm -- BioD itself is D and cannot be built here)
-    timed on this box's host cores on a bounded sample of the same workload."""
+    timed on this box's host cores on a bounded sample of the same workload: median of three runs."""
     import oracle_lib as O
     from biod_amd.synth import host_stream_np, scaled
     cores = usable_cores()
     if n_sample <= 0:
-        probe = host_stream_np(scaled(cfg_name, 20_000 if cfg_name != "cfg5" else 60))
         n_probe = 20_000 if cfg_name != "cfg5" else 60
+        probe = host_stream_np(scaled(cfg_name, n_probe))
         t0 = time.perf_counter(); O.pileup_bench(probe, 1); dt = max(time.perf_counter() - t0, 1e-4)
-        n_sample = int(min(max(20.0 / (dt / n_probe), n_probe), 3_000_000))      # ~20 CPU-seconds of pileup work
+        n_sample = int(min(max(8.0 / (dt / n_probe), n_probe), 3_000_000))      # ~8 CPU-seconds of pileup work per run, three runs
         if cfg_name != "cfg5":
             # every thread needs work: pileupChunks cuts 16 384 000-byte chunks (~56k reads); give each core two
             n_sample = int(min(max(n_sample, cores * 2 * 56_000), 32_000_000))
     stream = host_stream_np(scaled(cfg_name, n_sample))
-    t0 = time.perf_counter(); rs = O.pileup_bench(stream[: len(stream)], 1) if n_sample <= 400_000 else None; ts = time.perf_counter() - t0
-    t0 = time.perf_counter(); rp = O.pileup_bench(stream, cores); tp = time.perf_counter() - t0
-    assert rp.status in (0, -9), rp.status
-    out = {"value": round(n_sample / tp / 1e6, 4), "unit": "Mreads/s", "cores": cores, "kind": "port",
-           "columns_per_s": round(rp.n_columns / tp, 1),
+    rates, rp = [], None
+    for _ in range(3):
+        t0 = time.perf_counter(); rp = O.pileup_bench(stream, cores); tp = time.perf_counter() - t0
+        assert rp.status in (0, -9), rp.status
+        rates.append(n_sample / tp / 1e6)
+    rates.sort()
+    out = {"value": round(rates[1], 4), "unit": "Mreads/s", "cores": cores, "kind": "port", "runs": 3,
+           "min": round(rates[0], 4), "max": round(rates[2], 4),
+           "columns_per_s": round(rp.n_columns * rates[1] * 1e6 / n_sample, 1),
            "sample": f"{n_sample} reads of {cfg_name}'s read model at its coverage depth ({len(stream) / 1e6:.0f} MB inflated), "
                      f"pileupChunks-style decomposition over {cores} threads (= usable cores: {os.cpu_count()} logical CPUs, affinity and cgroup quota applied), "
-                     f"consumer touches coverage/n_starting_here/every base+quality"}
-    if rs is not None:
+                     f"consumer touches coverage/n_starting_here/every base+quality; median of 3 runs"}
+    if n_sample <= 400_000:
+        t0 = time.perf_counter(); O.pileup_bench(stream, 1); ts = time.perf_counter() - t0
         out["serial_value"] = round(n_sample / ts / 1e6, 4)
     return out
 
 
+def oracle_prefix_check(ctx, cfg_name, n=20_000):
+    """Columns of a 20 k-read shard of the workload's read model: device == oracle, every field of every position."""
+    import numpy as np
+    import oracle_lib as O
+    from biod_amd import _lib as L
+    from biod_amd.synth import host_stream, scaled
+    n = n if cfg_name != "cfg5" else 60
+    st = host_stream(scaled(cfg_name, n))
+    ctx.reset(); ctx.push_inflated(st); ctx.flush()
+    info = ctx.pileup_run()
+    ora = O.pileup(st, skip_zero=False)
+    dense = np.concatenate([w.columns for w in ctx.pileup_windows(L.BGP_PILEUP_COLUMNS, skip_zero_coverage=False, window_positions=1 << 20)])
+    base = {int(r["ref_id"]): (int(r["column_base"]), int(r["start_pos"])) for r in info.runs}
+    idx = np.array([base[int(r)][0] - base[int(r)][1] for r in ora.ref], dtype=np.int64) + ora.pos.astype(np.int64)
+    exp = np.zeros(len(dense), L.COLUMN_DTYPE)
+    exp["coverage"][idx] = ora.cov; exp["n_starting_here"][idx] = ora.nstart
+    for j, f in enumerate(("a", "c", "g", "t", "other", "del")):
+        exp[f][idx] = ora.counts[:, j]
+    ok = len(dense) == info.n_positions and all(np.array_equal(dense[f], exp[f]) for f in L.COLUMN_DTYPE.names)
+    return {"reads": n, "positions": int(info.n_positions), "columns_equal_oracle": bool(ok)}
+
+
+class _DevArray:
+    """A device pointer as something torch.as_tensor understands (zero copy)."""
+    def __init__(self, ptr, shape, typestr):
+        self.__cuda_array_interface__ = {"data": (int(ptr), False), "shape": tuple(shape), "typestr": typestr, "version": 2}
+
+
+def full_size_invariants(torch, dev, ctx, info, n_reads):
+    """Size-independent properties on the WHOLE result, computed on the device outside the timed region:
+    sum n_starting_here = reads used, sum coverage = sum basesCovered of the record table, coverage = sum of the
+    class counts at every position, the header totals = what the columns say."""
+    r = ctx.decode_device(0)
+    rec = torch.as_tensor(_DevArray(r.rec, (int(r.n), 8), "<i4"), device=dev)       # ref_id,pos,end_pos,bin_mq_nl,flag_nc,l_seq,rec_off(2)
+    covered = (rec[:, 2] - rec[:, 1]).to(torch.int64)
+    reads_used, bases_covered = int((covered != 0).sum().item()), int(covered.sum().item())
+    cols = torch.as_tensor(_DevArray(info.device_columns, (int(info.n_positions), 8), "<i4"), device=dev)
+    s_cov = s_nst = n_col = 0; cls_ok = True; mx = 0
+    step = 1 << 25
+    for o in range(0, int(info.n_positions), step):
+        c = cols[o:o + step]
+        cov = c[:, 0].to(torch.int64)
+        s_cov += int(cov.sum().item()); s_nst += int(c[:, 1].to(torch.int64).sum().item()); n_col += int((cov > 0).sum().item())
+        mx = max(mx, int(cov.max().item()))
+        cls_ok = cls_ok and bool((c[:, 2:8].to(torch.int64).sum(dim=1) == cov).all().item())
+    return {"reads_used": reads_used, "sum_n_starting_here": s_nst, "sum_basesCovered": bases_covered, "sum_coverage": s_cov,
+            "ok": bool(s_nst == reads_used == info.n_reads_used and s_cov == bases_covered == info.sum_coverage and n_col == info.n_columns
+                       and mx == info.max_coverage and cls_ok and int(r.n) == n_reads),
+            "coverage_equals_class_sum_everywhere": cls_ok}
+
+
+def rccl_communicator(torch, dist, rank, world, dev):
+    """An RCCL communicator of this script's own (the product takes it as a void*): rank 0's unique id goes round
+    through torch.distributed, every rank joins with ncclCommInitRank."""
+    try:                   # the same library bgp_hist_reduce resolves at run time (api.cpp: librccl.so.1, then librccl.so)
+        rccl = C.CDLL("librccl.so.1", mode=C.RTLD_GLOBAL)
+    except OSError:
+        rccl = C.CDLL("librccl.so", mode=C.RTLD_GLOBAL)
+
+    class UniqueId(C.Structure):
+        _fields_ = [("internal", C.c_char * 128)]
+    uid = UniqueId()
+    if rank == 0:
+        assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+    t = torch.tensor(list(bytes(uid)), dtype=torch.uint8, device=dev)
+    dist.broadcast(t, 0)
+    C.memmove(C.byref(uid), bytes(t.cpu().tolist()), 128)
+    comm = C.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+    rc = rccl.ncclCommInitRank(C.byref(comm), world, uid, rank)
+    if rc != 0:
+        raise RuntimeError(f"ncclCommInitRank failed: {rc}")
+    return rccl, comm
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` with no launcher around it: become the launcher."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ); env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    sys.exit(subprocess.call(cmd, env=env))
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(a.gpus)
     rank = int(os.environ.get("RANK", "0")); local = int(os.environ.get("LOCAL_RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        sys.exit(f"bench.py: --gpus {a.gpus} but the launcher started {world} rank(s); start it as `python bench.py --gpus N` "
+                 f"or under torch.distributed.run with --nproc-per-node equal to --gpus")
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -113,29 +233,30 @@ def main():
 
     if torch.cuda.device_count() and local >= torch.cuda.device_count():
         local %= torch.cuda.device_count()          # (only for dry runs of the N>1 path on a box with fewer GPUs)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local)
-        backend = os.environ.get("BGP_BENCH_BACKEND", "nccl")      # nccl = RCCL over xGMI; gloo only to dry-run the control flow
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-        else:
-            dist.init_process_group(backend)
-    else:
-        torch.cuda.set_device(local)
+    torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    rccl = comm = None
+    with_comm = world > 1 or bool(os.environ.get("BGP_BENCH_FORCE_COMM"))    # (FORCE_COMM: the N > 1 code path on a one-GPU box, one-rank communicator)
+    if with_comm:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:
+            s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); os.environ["MASTER_PORT"] = str(s_.getsockname()[1]); s_.close()
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)      # nccl = RCCL over xGMI
+        rccl, comm = rccl_communicator(torch, dist, rank, world, dev)
 
-    n_reads = a.reads or CONFIGS[a.config]["n_reads"]
-    free, _total = torch.cuda.mem_get_info(dev)
-    need_per_read = 1000 if a.config != "cfg5" else 600_000       # stream + tables + arenas + columns, generous
-    while n_reads * need_per_read > free * 0.9 and n_reads > 1000:
-        n_reads //= 2
+    total_reads = a.reads or CONFIGS[a.config]["n_reads"]
     from biod_amd.shard import strong_cfg, weak_cfg
-    if a.strong:        # BASELINE.json config 4 literally: the same BAM split by contig over the ranks
-        cfg = strong_cfg(a.config, n_reads, rank, world)
-        n_reads = int(cfg.n_reads)
-    else:               # default: every rank owns a full-size shard of its own contigs
-        cfg = weak_cfg(a.config, n_reads, rank)
+    strong = not a.weak
+    free, _total = torch.cuda.mem_get_info(dev)
+    need_per_read = 1000 if a.config != "cfg5" else 600_000       # stream + tables + arenas + columns + slabs, generous
+    per_rank = total_reads if a.weak else -(-total_reads // world)
+    while per_rank * need_per_read > free * 0.9 and total_reads > 1000:
+        total_reads //= 2; per_rank //= 2
+    if strong:          # BASELINE.json config 4 literally: the same BAM split by contig over the ranks
+        cfg = strong_cfg(a.config, total_reads, rank, world)
+    else:               # every rank owns a full-size shard of its own contigs
+        cfg = weak_cfg(a.config, total_reads, rank)
+    n_reads = int(cfg.n_reads)
 
     ctx = Context(local)
     t0 = time.perf_counter()
@@ -143,9 +264,9 @@ def main():
     ctx.flush()
     r = ctx.decode_device(0)
     sptr, slen = r.stream, r.stream_len
+    sum_lseq = int(torch.as_tensor(_DevArray(r.seq_off, (int(r.n) + 1,), "<i8"), device=dev)[-1].item())
+    sum_ncig = int(torch.as_tensor(_DevArray(r.cigar_off, (int(r.n) + 1,), "<i8"), device=dev)[-1].item())
     gen_s = time.perf_counter() - t0
-    hist = torch.zeros(L.BGP_DEPTH_BINS, dtype=torch.int64, device=dev)
-    hip = C.CDLL("libamdhip64.so")
 
     def step():
         ctx.reset()
@@ -153,14 +274,13 @@ def main():
         ctx.flush()                                                # K0 framing + K1 record table
         ctx.decode_device(L.BGP_FETCH_ALL)                         # K2 seq/qual/cigar arenas
         info = ctx.pileup_run()                                    # K3 + K4 dense columns
-        if world > 1:                                              # the path's only exchange: whole-BAM depth histogram over RCCL
-            hip.hipMemcpy(C.c_void_p(hist.data_ptr()), C.c_void_p(info.device_depth_hist), C.c_size_t(L.BGP_DEPTH_BINS * 8), 3)
-            dist.all_reduce(hist)
+        if with_comm:                                              # the path's only exchange: whole-BAM depth histogram, RCCL over xGMI, in place
+            L.check(L.lib().bgp_hist_reduce(ctx.handle, comm, C.c_void_p(info.device_depth_hist), L.BGP_DEPTH_BINS), ctx.handle)
         return info
 
     def sync():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if with_comm:
             dist.barrier()
 
     for _ in range(a.warmup):
@@ -174,54 +294,93 @@ def main():
     dt = time.perf_counter() - t0
     timers = ctx.timing_get()
     ctx.timing_enable(False)
-    if world > 1:
+
+    # ---- outside the timed region: what the ranks produced, checked
+    checks = None
+    if not a.no_checks:
+        checks = full_size_invariants(torch, dev, ctx, info, n_reads)
+    hist_ok = None
+    if with_comm:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        tot = torch.tensor([info.n_columns, info.sum_coverage], dtype=torch.int64, device=dev)
+        tot = torch.tensor([info.n_columns, info.sum_coverage, n_reads, int(bool(checks is None or checks["ok"]))], dtype=torch.int64, device=dev)
         dist.all_reduce(tot)
-        job_columns, job_cov = int(tot[0].item()), int(tot[1].item())
-        assert int(hist.sum().item()) > 0
+        job_columns, job_cov, job_reads, n_ok = (int(x) for x in tot.tolist())
+        # the reduced histogram the product left behind == the sum of the ranks' own histograms (recomputed, summed by torch)
+        reduced = torch.as_tensor(_DevArray(info.device_depth_hist, (L.BGP_DEPTH_BINS,), "<i8"), device=dev).clone()
+        ctx.reset(); ctx.attach_device_stream(sptr, slen); ctx.flush()
+        mine = torch.as_tensor(_DevArray(ctx.pileup_run().device_depth_hist, (L.BGP_DEPTH_BINS,), "<i8"), device=dev).clone()
+        dist.all_reduce(mine)
+        hist_ok = bool(torch.equal(mine, reduced)) and int(reduced.sum().item()) > 0
+        if checks is not None:
+            checks["ok_on_ranks"] = n_ok
+            checks["ok"] = n_ok == world
     else:
-        job_columns, job_cov = info.n_columns, info.sum_coverage
+        job_columns, job_cov, job_reads = info.n_columns, info.sum_coverage, n_reads
 
     if rank == 0:
         ms_step = dt / a.steps * 1e3
-        job_reads = n_reads * world      # (strong: ranks hold equal contig shares of the one BAM)
-        # roofline of the dominant kernel (largest share of kernel time), algorithmic bytes per launch / mean launch time
         kt = {k: v for k, v in timers.items() if v["launches"]}
-        dom = max(kt, key=lambda k: kt[k]["total_ms"])
         per_kernel = {k: {"ms_per_launch": round(v["total_ms"] / v["launches"], 4), "launches_per_step": v["launches"] // a.steps,
                           "algorithmic_GBps": round(v["algorithmic_bytes"] / v["launches"] / (v["total_ms"] / v["launches"] * 1e-3) / 1e9, 1) if v["total_ms"] > 0 else None}
                       for k, v in kt.items()}
-        d = kt[dom]
-        achieved = d["algorithmic_bytes"] / d["launches"] / (d["total_ms"] / d["launches"] * 1e-3) / 1e9
-        dec_ms = sum(kt[k]["total_ms"] for k in kt if k.startswith(("k0", "k1", "k2"))) / a.steps
+        # a stage = the kernels that together produce one product of the path; its roofline figure is the stage's
+        # algorithmic bytes over ALL of its kernels' time
+        stages = {}
+        for name, pre in STAGES.items():
+            ks = [k for k in kt if k.startswith(pre)]
+            if ks:
+                stages[name] = {"ms_per_step": sum(kt[k]["total_ms"] for k in ks) / a.steps, "kernels": ks, "prefixes": pre}
+        for name, st in stages.items():
+            st["bytes"] = sum(kt[k]["algorithmic_bytes"] for k in st["kernels"]) // a.steps
+        if "k4_tile" in kt:      # K4's algorithmic bytes (row + CIGAR + packed SEQ per read, 32 B per position) are booked on k4_tile; the plan's own reads are not algorithmic
+            stages["K4 pileup columns"]["bytes"] = kt["k4_tile"]["algorithmic_bytes"] // a.steps
+        dec_bytes = stream_bytes + 32 * n_reads + 2 * sum_lseq + 4 * sum_ncig      # whole record in, row + seq + qual + cigar out
+        dom = max(stages, key=lambda s: stages[s]["ms_per_step"])
+        dom_bytes = stages[dom]["bytes"]
+        achieved = dom_bytes / (stages[dom]["ms_per_step"] * 1e-3) / 1e9
+        dec_ms = sum(stages[s]["ms_per_step"] for s in stages if s[:2] in ("K0", "K1", "K2"))
         out = {
             "metric": "Mreads/s decoded + piled up (BAM record decode -> CIGAR walk -> per-base pileup, input resident in HBM)",
             "value": round(job_reads / dt * a.steps / 1e6, 3), "unit": "Mreads/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_step, 3),
-            "higher_is_better": True, "scaling": "strong" if a.strong else "weak", "vs_baseline": None, "dtype": "u8/u32 integer", "data": "synthetic",
-            "config": {"workload": f"{a.config}: {n_reads} reads/GPU synthetic coordinate-sorted BAM record stream "
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "u8/u32 integer", "data": "synthetic",
+            "config": {"workload": f"{a.config}: {job_reads if strong else n_reads} reads{'' if strong else '/GPU'} synthetic coordinate-sorted BAM record stream "
                                    f"({'mixed M/I/D/S/N CIGAR' if cfg.profile == 1 else 'M-only CIGAR' if cfg.profile == 0 else 'long indel-heavy reads'}, "
-                                   f"l_seq {cfg.len_min}-{cfg.len_max}, {cfg.n_ref} contigs x {cfg.ref_len} bp per GPU)",
+                                   f"l_seq {cfg.len_min}-{cfg.len_max}, {cfg.n_ref * (world if strong else 1)} contigs x {cfg.ref_len} bp"
+                                   f"{', split by contig over the ranks' if strong and world > 1 else ''})",
                        "reads_per_gpu": n_reads, "inflated_bytes_per_gpu": stream_bytes, "parallelism": f"contig-sharded x{world}",
-                       "step": "K0 framing + K1 record table + K2 seq/qual/cigar unpack + K3 run keys + K4 pileup columns"},
+                       "step": "K0 framing + K1 record table + K2 seq/qual/cigar unpack + K3 run keys + K4 pileup columns (plan + gather)"
+                               + (" + depth-histogram all-reduce (bgp_hist_reduce, RCCL)" if with_comm else "")},
             "pileup_columns_per_s": round(job_columns / dt * a.steps, 1),
             "columns_per_step": job_columns, "sum_coverage_per_step": job_cov,
             "decode_Mreads_per_s_kernel_only": round(n_reads / (dec_ms * 1e-3) / 1e6, 2) if dec_ms else None,
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "algorithmic_bytes_per_launch": d["algorithmic_bytes"] // d["launches"],
-                         "traffic": pmc_traffic(dom, a.config, n_reads)},
+            "roofline": {"bound": "hbm", "kernel": dom + " = " + " + ".join(stages[dom]["kernels"]), "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "algorithmic_bytes_per_launch": dom_bytes,
+                         "traffic": pmc_traffic(stages[dom]["prefixes"], a.config, n_reads)},
+            "roofline_decode_8d": {"what": "K0 + K1 + K2 by SURVEY 8(d)'s bytes: whole record in, 32-byte row + seq + qual + cigar out", "ms": round(dec_ms, 3),
+                                   "achieved": round(dec_bytes / (dec_ms * 1e-3) / 1e9, 1) if dec_ms else None, "frac": round(dec_bytes / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if dec_ms else None},
+            "stages_ms": {s: round(v["ms_per_step"], 3) for s, v in stages.items()},
             "kernels": per_kernel,
             "setup_s": round(gen_s, 2),
         }
+        if checks is not None:
+            out["checks_full_size"] = checks
+        if hist_ok is not None:
+            out["hist_reduce_equals_sum_of_ranks"] = hist_ok
         if world == 1 and not a.no_cpu_baseline:
+            out["parity_prefix"] = oracle_prefix_check(ctx, a.config)
             out["cpu_baseline"] = cpu_baseline(a.config, a.cpu_sample_reads)
             out["speedup_vs_cpu_baseline"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
         print(json.dumps(out), flush=True)
+        if (checks is not None and not checks["ok"]) or hist_ok is False or ("parity_prefix" in out and not out["parity_prefix"]["columns_equal_oracle"]):
+            sys.stderr.write("bench.py: a result check FAILED (see checks_full_size / hist_reduce_equals_sum_of_ranks / parity_prefix)\n")
+            ctx.close()
+            sys.exit(3)
     ctx.close()
-    if world > 1:
+    if with_comm:
+        rccl.ncclCommDestroy(comm)
         dist.destroy_process_group()
 
 
