@@ -154,33 +154,7 @@ def oracle_prefix_check(ctx, cfg_name, n=20_000):
     return {"reads": n, "positions": int(info.n_positions), "columns_equal_oracle": bool(ok)}
 
 
-class _DevArray:
-    """A device pointer as something torch.as_tensor understands (zero copy)."""
-    def __init__(self, ptr, shape, typestr):
-        self.__cuda_array_interface__ = {"data": (int(ptr), False), "shape": tuple(shape), "typestr": typestr, "version": 2}
-
-
-def full_size_invariants(torch, dev, ctx, info, n_reads):
-    """Size-independent properties on the WHOLE result, computed on the device outside the timed region:
-    sum n_starting_here = reads used, sum coverage = sum basesCovered of the record table, coverage = sum of the
-    class counts at every position, the header totals = what the columns say."""
-    r = ctx.decode_device(0)
-    rec = torch.as_tensor(_DevArray(r.rec, (int(r.n), 8), "<i4"), device=dev)       # ref_id,pos,end_pos,bin_mq_nl,flag_nc,l_seq,rec_off(2)
-    covered = (rec[:, 2] - rec[:, 1]).to(torch.int64)
-    reads_used, bases_covered = int((covered != 0).sum().item()), int(covered.sum().item())
-    cols = torch.as_tensor(_DevArray(info.device_columns, (int(info.n_positions), 8), "<i4"), device=dev)
-    s_cov = s_nst = n_col = 0; cls_ok = True; mx = 0
-    step = 1 << 25
-    for o in range(0, int(info.n_positions), step):
-        c = cols[o:o + step]
-        cov = c[:, 0].to(torch.int64)
-        s_cov += int(cov.sum().item()); s_nst += int(c[:, 1].to(torch.int64).sum().item()); n_col += int((cov > 0).sum().item())
-        mx = max(mx, int(cov.max().item()))
-        cls_ok = cls_ok and bool((c[:, 2:8].to(torch.int64).sum(dim=1) == cov).all().item())
-    return {"reads_used": reads_used, "sum_n_starting_here": s_nst, "sum_basesCovered": bases_covered, "sum_coverage": s_cov,
-            "ok": bool(s_nst == reads_used == info.n_reads_used and s_cov == bases_covered == info.sum_coverage and n_col == info.n_columns
-                       and mx == info.max_coverage and cls_ok and int(r.n) == n_reads),
-            "coverage_equals_class_sum_everywhere": cls_ok}
+from biod_amd.checks import DevArray as _DevArray, full_size_invariants      # device-side identities of the result (no oracle)
 
 
 def rccl_communicator(torch, dist, rank, world, dev):

@@ -17,6 +17,11 @@ void bgp_note_hip_error(hipError_t e, const char* what, const char* file, int li
     if (getenv("BGP_VERBOSE")) fprintf(stderr, "[biodgpu] %s\n", buf);
 }
 
+int bgp_api_caught(bgp_ctx* c, int status, const char* what) {
+    try { if (c) c->last_error = what; else g_last_hip_error = what; } catch (...) { }
+    return status;
+}
+
 int bgp_status_from_bits(uint32_t bits) {
     if (bits & ST_ETRUNC) return BGP_ETRUNC;
     if (bits & ST_EINVAL) return BGP_EINVAL;
@@ -75,6 +80,7 @@ const char* bgp_strerror(int s) {
 int bgp_abi_version(void) { return BGP_ABI_VERSION; }
 
 int bgp_init(int device, bgp_ctx** out) {
+    BGP_API_TRY
     if (!out) return BGP_EINVAL;
     *out = nullptr;
     int n = 0;
@@ -94,6 +100,7 @@ int bgp_init(int device, bgp_ctx** out) {
     if (c->d_status.reserve(64) < 0) { (void)hipStreamDestroy(c->stream); delete c; return BGP_ENOMEM; }
     *out = c;
     return BGP_OK;
+    BGP_API_CATCH((bgp_ctx*)nullptr)
 }
 
 static void release_all(bgp_ctx* c) {
@@ -119,25 +126,31 @@ void bgp_destroy(bgp_ctx* c) {
 }
 
 int bgp_set_stream(bgp_ctx* c, void* s) {
+    BGP_API_TRY
     if (!c) return BGP_EINVAL;
     BGP_HIP(hipStreamSynchronize(c->stream));
     if (s) { if (c->own_stream) { (void)hipStreamDestroy(c->stream); c->own_stream = false; } c->stream = (hipStream_t)s; }
     else if (!c->own_stream) { BGP_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
     return BGP_OK;
+    BGP_API_CATCH(c)
 }
 
 int bgp_set_n_ref(bgp_ctx* c, int32_t n_ref) { if (!c || n_ref < 0) return BGP_EINVAL; c->n_ref_hint = n_ref; return BGP_OK; }
 
 int bgp_reset(bgp_ctx* c) {
+    BGP_API_TRY
     if (!c) return BGP_EINVAL;
     BGP_HIP(hipStreamSynchronize(c->stream));
     c->h_stage_len = 0; c->d_stream = nullptr; c->stream_len = 0; c->stream_on_device = false;
     c->flushed = false; c->piled = false; c->md_rows_ready = false; c->table_pending = false; c->n_records = 0; c->decoded_what = 0; c->it = bgp_ctx::Iter();
     c->runs.clear(); c->stage_map.clear(); c->region_pending = false; c->bai_buildable = false; c->cig4_ok = false;
+    c->refs.clear(); c->n_ref_hint = 0; c->last_error.clear(); c->bai_bytes.clear();      // nothing of the previous file survives: the loaders and bgp_set_n_ref re-establish these
     return BGP_OK;
+    BGP_API_CATCH(c)
 }
 
 int bgp_push_inflated(bgp_ctx* c, const uint8_t* data, size_t len, uint64_t coffset, uint32_t first_record_uoffset) {
+    BGP_API_TRY
     (void)coffset; (void)first_record_uoffset;   // boundaries are found and verified on the device (frame.hip)
     if (!c || (!data && len)) return BGP_EINVAL;
     if (c->flushed || c->stream_on_device) return BGP_ESTATE;
@@ -146,13 +159,16 @@ int bgp_push_inflated(bgp_ctx* c, const uint8_t* data, size_t len, uint64_t coff
     memcpy(c->h_stage.as<uint8_t>() + c->h_stage_len, data, len);
     c->h_stage_len += len;
     return BGP_OK;
+    BGP_API_CATCH(c)
 }
 
 int bgp_attach_device_stream(bgp_ctx* c, const void* dptr, uint64_t len) {
+    BGP_API_TRY
     if (!c || (!dptr && len)) return BGP_EINVAL;
     if (c->flushed || c->h_stage_len) return BGP_ESTATE;
     c->d_stream = (const uint8_t*)dptr; c->stream_len = len; c->stream_on_device = true;
     return BGP_OK;
+    BGP_API_CATCH(c)
 }
 
 // K1, three ways (measured on cfg3, 100 M reads, K1 + K2 time):
@@ -165,6 +181,7 @@ static int fuse_mode() { const char* e = getenv("BGP_FUSE_MODE"); return e ? ato
 static int ensure_table(bgp_ctx* c) { return !c->table_pending ? BGP_OK : (fuse_mode() == 0 ? k1_table(c) : k12_fused_decode(c, 0)); }
 
 int bgp_flush(bgp_ctx* c) {
+    BGP_API_TRY
     if (!c) return BGP_EINVAL;
     BGP_HIP(hipSetDevice(c->device));
     if (!c->stream_on_device) {
@@ -179,11 +196,13 @@ int bgp_flush(bgp_ctx* c) {
     if (fuse_mode() != 1) BGP_TRY(ensure_table(c));      // K1; only the fused experiment (BGP_FUSE_MODE=1) defers it to the decode
     if (c->region_pending) { BGP_TRY(ensure_table(c)); BGP_TRY(k_region_filter(c, c->region_ref, c->region_beg, c->region_end)); }   // bam[ref][beg..end]
     return BGP_OK;
+    BGP_API_CATCH(c)
 }
 
 int bgp_num_records(bgp_ctx* c, uint64_t* n) { if (!c || !n) return BGP_EINVAL; if (!c->flushed) return BGP_ESTATE; *n = c->n_records; return BGP_OK; }
 
 int bgp_decode_device(bgp_ctx* c, uint32_t what, bgp_records* o) {
+    BGP_API_TRY
     if (!c || !o) return BGP_EINVAL;
     if (!c->flushed) return BGP_ESTATE;
     BGP_HIP(hipSetDevice(c->device));
@@ -197,9 +216,11 @@ int bgp_decode_device(bgp_ctx* c, uint32_t what, bgp_records* o) {
     o->cigar = (what & BGP_FETCH_CIGAR) ? c->d_cigar.as<uint32_t>() : nullptr;
     o->stream = c->d_stream; o->stream_len = c->stream_len;
     return BGP_OK;
+    BGP_API_CATCH(c)
 }
 
 int bgp_decode_fetch(bgp_ctx* c, uint32_t what, bgp_records* o) {
+    BGP_API_TRY
     bgp_records d;
     BGP_TRY(bgp_decode_device(c, what, &d));
     const uint64_t n = c->n_records;
@@ -224,9 +245,11 @@ int bgp_decode_fetch(bgp_ctx* c, uint32_t what, bgp_records* o) {
         o->stream = c->h_stream_copy.as<uint8_t>(); o->stream_len = c->stream_len;
     }
     return BGP_OK;
+    BGP_API_CATCH(c)
 }
 
 int bgp_pileup_run(bgp_ctx* c, bgp_pileup_info* info) {
+    BGP_API_TRY
     if (!c) return BGP_EINVAL;
     if (!c->flushed) return BGP_ESTATE;
     BGP_HIP(hipSetDevice(c->device));
@@ -235,9 +258,11 @@ int bgp_pileup_run(bgp_ctx* c, bgp_pileup_info* info) {
     c->piled = true; c->md_rows_ready = false;
     if (info) *info = c->pinfo;
     return BGP_OK;
+    BGP_API_CATCH(c)
 }
 
 int bgp_pileup_begin(bgp_ctx* c, int mode, int use_md_tag, uint64_t start_from, uint64_t end_at, int skip_zero, int want_entries, uint32_t window) {
+    BGP_API_TRY
     if (!c || (mode != BGP_PILEUP_COLUMNS && mode != BGP_MAKE_PILEUP)) return BGP_EINVAL;
     if (!c->flushed) return BGP_ESTATE;
     BGP_HIP(hipSetDevice(c->device));
@@ -285,17 +310,21 @@ int bgp_pileup_begin(bgp_ctx* c, int mode, int use_md_tag, uint64_t start_from, 
         }
     }
     return BGP_OK;
+    BGP_API_CATCH(c)
 }
 
 int bgp_pileup_snp(bgp_ctx* c, int min_cov, int min_wit) {
+    BGP_API_TRY
     if (!c) return BGP_EINVAL;
     if (!c->it.active || !c->it.use_md) return BGP_ESTATE;     // findSNPs piles up with reference bases (simple.d:37-41)
     c->it.snp = 1; c->it.snp_min_cov = min_cov; c->it.snp_min_wit = min_wit;
     return BGP_OK;
+    BGP_API_CATCH(c)
 }
 int bgp_pileup_ref_id(bgp_ctx* c, int32_t* ref_id) { if (!c || !ref_id) return BGP_EINVAL; if (!c->it.active) return BGP_ESTATE; *ref_id = c->it.ref_id; return BGP_OK; }
 
 int bgp_pileup_next_window(bgp_ctx* c, bgp_columns* o) {
+    BGP_API_TRY
     if (!c || !o) return BGP_EINVAL;
     auto& it = c->it;
     if (!it.active) return BGP_ESTATE;
@@ -338,9 +367,11 @@ int bgp_pileup_next_window(bgp_ctx* c, bgp_columns* o) {
         it.next_pos = b;
         return BGP_OK;
     }
+    BGP_API_CATCH(c)
 }
 
 int bgp_read_dna(bgp_ctx* c, uint64_t record, char* out, uint32_t cap, uint32_t* len) {
+    BGP_API_TRY
     if (!c || !len || (!out && cap)) return BGP_EINVAL;
     if (!c->flushed) return BGP_ESTATE;
     BGP_HIP(hipSetDevice(c->device));
@@ -350,9 +381,11 @@ int bgp_read_dna(bgp_ctx* c, uint64_t record, char* out, uint32_t cap, uint32_t*
     if (flags & 4u) { c->last_error = "internal: dna_length disagrees with dna_walk"; return BGP_ESTATE; }
     if (flags & 2u) return BGP_EINVAL;
     return (flags & 1u) ? BGP_EMD : BGP_OK;
+    BGP_API_CATCH(c)
 }
 
 int bgp_hist_reduce(bgp_ctx* c, void* comm, uint64_t* device_hist, size_t n) {
+    BGP_API_TRY
     if (!c || !comm || !device_hist) return BGP_EINVAL;
     // RCCL is resolved at run time so that single-GPU users need no librccl.
     typedef int (*allreduce_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
@@ -369,17 +402,21 @@ int bgp_hist_reduce(bgp_ctx* c, void* comm, uint64_t* device_hist, size_t n) {
     if (rc != 0) { c->last_error = "ncclAllReduce failed"; return BGP_EDEVICE; }
     BGP_HIP(hipStreamSynchronize(c->stream));
     return BGP_OK;
+    BGP_API_CATCH(c)
 }
 
 int bgp_timing_enable(bgp_ctx* c, int on) { if (!c) return BGP_EINVAL; c->timing = on != 0; return BGP_OK; }
 int bgp_timing_reset(bgp_ctx* c) {
+    BGP_API_TRY
     if (!c) return BGP_EINVAL;
     BGP_HIP(hipStreamSynchronize(c->stream));
     bgp_timing_collect(c);
     c->timers.clear();
     return BGP_OK;
+    BGP_API_CATCH(c)
 }
 int bgp_timing_get(bgp_ctx* c, const bgp_kernel_time** out, uint32_t* n) {
+    BGP_API_TRY
     if (!c || !out || !n) return BGP_EINVAL;
     BGP_HIP(hipStreamSynchronize(c->stream));
     bgp_timing_collect(c);
@@ -387,31 +424,41 @@ int bgp_timing_get(bgp_ctx* c, const bgp_kernel_time** out, uint32_t* n) {
     for (auto& t : c->timers) c->timing_out.push_back(bgp_kernel_time{t.name.c_str(), t.total_ms, t.launches, t.algorithmic_bytes});
     *out = c->timing_out.data(); *n = (uint32_t)c->timing_out.size();
     return BGP_OK;
+    BGP_API_CATCH(c)
 }
 
 int bgp_synth_host(const bgp_synth_cfg_c* cfg, uint64_t first, uint64_t count, uint8_t* out, uint64_t cap, uint64_t* bytes) {
+    BGP_API_TRY
     if (!cfg || !bytes) return BGP_EINVAL;
     return synth_host(cfg, first, count, out, cap, bytes);
+    BGP_API_CATCH((bgp_ctx*)nullptr)
 }
 int bgp_synth_device(bgp_ctx* c, const bgp_synth_cfg_c* cfg, uint64_t* bytes) {
+    BGP_API_TRY
     if (!c || !cfg) return BGP_EINVAL;
     if (c->flushed || c->h_stage_len) return BGP_ESTATE;
     BGP_HIP(hipSetDevice(c->device));
     return synth_device(c, cfg, bytes);
+    BGP_API_CATCH(c)
 }
 
 int bgp_load_bam(bgp_ctx* c, const char* path, int n_threads) {
+    BGP_API_TRY
     if (!c || !path) return BGP_EINVAL;
     if (c->flushed || c->stream_on_device) return BGP_ESTATE;
     return bgzf_load_bam(c, path, n_threads);
+    BGP_API_CATCH(c)
 }
 int bgp_load_bam_device(bgp_ctx* c, const char* path) {
+    BGP_API_TRY
     if (!c || !path) return BGP_EINVAL;
     if (c->flushed || c->stream_on_device || c->h_stage_len) return BGP_ESTATE;
     BGP_HIP(hipSetDevice(c->device));
     return bgzf_load_bam_device(c, path);
+    BGP_API_CATCH(c)
 }
 int bgp_load_bam_region(bgp_ctx* c, const char* path, bgp_bai* bai, int32_t ref_id, uint32_t beg, uint32_t end, int n_threads) {
+    BGP_API_TRY
     if (!c || !path || !bai) return BGP_EINVAL;
     if (c->flushed || c->stream_on_device || c->h_stage_len) return BGP_ESTATE;
     if (!(beg < end)) { c->last_error = "start must be less than end"; return BGP_EINVAL; }          // reference.d:76
@@ -424,23 +471,29 @@ int bgp_load_bam_region(bgp_ctx* c, const char* path, bgp_bai* bai, int32_t ref_
     c->bai_buildable = false;
     c->region_pending = true; c->region_ref = (uint32_t)ref_id; c->region_beg = beg; c->region_end = end;
     return BGP_OK;
+    BGP_API_CATCH(c)
 }
 int bgp_filter_region(bgp_ctx* c, int32_t ref_id, uint32_t beg, uint32_t end) {
+    BGP_API_TRY
     if (!c) return BGP_EINVAL;
     if (!c->flushed) return BGP_ESTATE;
     BGP_HIP(hipSetDevice(c->device));
     BGP_TRY(ensure_table(c));
     c->bai_buildable = false;
     return k_region_filter(c, (uint32_t)ref_id, beg, end);
+    BGP_API_CATCH(c)
 }
 int bgp_load_bam_read_at(bgp_ctx* c, const char* path, uint64_t voffset) {
+    BGP_API_TRY
     if (!c || !path) return BGP_EINVAL;
     if (c->flushed || c->stream_on_device) return BGP_ESTATE;
     if (c->refs.empty()) BGP_TRY(bai_load_header(c, path));
     c->bai_buildable = false;
     return bai_stage_read_at(c, path, voffset);
+    BGP_API_CATCH(c)
 }
 int bgp_record_voffset(bgp_ctx* c, uint64_t record, uint64_t* voffset) {
+    BGP_API_TRY
     if (!c || !voffset) return BGP_EINVAL;
     if (!c->flushed || record >= c->n_records) return c && c->flushed ? BGP_EINVAL : BGP_ESTATE;
     BGP_HIP(hipSetDevice(c->device));
@@ -449,8 +502,10 @@ int bgp_record_voffset(bgp_ctx* c, uint64_t record, uint64_t* voffset) {
     BGP_HIP(hipMemcpyAsync(&r, c->d_rec.as<bgp_record>() + record, sizeof r, hipMemcpyDeviceToHost, c->stream));
     BGP_HIP(hipStreamSynchronize(c->stream));
     return bai_record_voffset(c, r.rec_off, voffset);
+    BGP_API_CATCH(c)
 }
 int bgp_bai_build(bgp_ctx* c, const uint8_t** bytes, uint64_t* n_bytes) {
+    BGP_API_TRY
     if (!c || !bytes || !n_bytes) return BGP_EINVAL;
     if (!c->flushed) return BGP_ESTATE;
     BGP_HIP(hipSetDevice(c->device));
@@ -458,13 +513,16 @@ int bgp_bai_build(bgp_ctx* c, const uint8_t** bytes, uint64_t* n_bytes) {
     BGP_TRY(bai_build(c, c->bai_bytes));
     *bytes = c->bai_bytes.data(); *n_bytes = c->bai_bytes.size();
     return BGP_OK;
+    BGP_API_CATCH(c)
 }
 int bgp_n_ref(bgp_ctx* c, int32_t* n) { if (!c || !n) return BGP_EINVAL; *n = (int32_t)c->refs.size(); return BGP_OK; }
 int bgp_ref_info(bgp_ctx* c, int32_t id, const char** name, int32_t* length) {
+    BGP_API_TRY
     if (!c || id < 0 || (size_t)id >= c->refs.size()) return BGP_EINVAL;
     if (name) *name = c->refs[id].name.c_str();
     if (length) *length = c->refs[id].length;
     return BGP_OK;
+    BGP_API_CATCH(c)
 }
 
 const char* bgp_last_error(bgp_ctx* c) { return c && !c->last_error.empty() ? c->last_error.c_str() : g_last_hip_error.c_str(); }

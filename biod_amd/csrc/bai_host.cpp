@@ -19,6 +19,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cstdio>
+#include <memory>
 #include <thread>
 
 struct BaiBin { uint32_t id; std::vector<bgp_chunk> chunks; };
@@ -54,6 +55,7 @@ bool chunk_less(const bgp_chunk& a, const bgp_chunk& b) { return a.beg != b.beg 
 extern "C" {
 
 int bgp_reg2bin(int32_t beg, int32_t end) {                    // bai/bin.d:82-92
+    BGP_API_TRY
     if (end == beg) end = beg + 1;
     --end;
     if (beg >> 14 == end >> 14) return (uint16_t)(((1 << 15) - 1) / 7 + (beg >> 14));
@@ -62,9 +64,11 @@ int bgp_reg2bin(int32_t beg, int32_t end) {                    // bai/bin.d:82-9
     if (beg >> 23 == end >> 23) return (uint16_t)(((1 << 6) - 1) / 7 + (beg >> 23));
     if (beg >> 26 == end >> 26) return (uint16_t)(((1 << 3) - 1) / 7 + (beg >> 26));
     return 0;
+    BGP_API_CATCH((bgp_ctx*)nullptr)
 }
 
 int bgp_bin_can_overlap(uint32_t id, int32_t begin, int32_t end) {   // Bin.canOverlapWith, bai/bin.d:55-77
+    BGP_API_TRY
     if (id == 0) return 1;
     if (id > BAI_MAX_BIN_ID) return 0;
     if (begin < 0) begin = 0;
@@ -78,9 +82,11 @@ int bgp_bin_can_overlap(uint32_t id, int32_t begin, int32_t end) {   // Bin.canO
         if (magic == 0) return 0;
         b >>= 3; e >>= 3;
     }
+    BGP_API_CATCH((bgp_ctx*)nullptr)
 }
 
 int bgp_bai_open(const char* path, bgp_bai** out) {            // BaiFile(filename), baifile.d:92-169
+    BGP_API_TRY
     if (!path || !out) return BGP_EINVAL;
     *out = nullptr;
     std::string fn(path), use;
@@ -100,8 +106,9 @@ int bgp_bai_open(const char* path, bgp_bai** out) {            // BaiFile(filena
     if (buf.size() < 8 || memcmp(buf.data(), "BAI\1", 4) != 0) return BGP_EINVAL;
     c.off = 4;
     const int32_t n_ref = c.get<int32_t>();
-    if (!c.ok || n_ref < 0) return BGP_EINVAL;
-    bgp_bai* b = new bgp_bai();
+    if (!c.ok || n_ref < 0 || (size_t)n_ref > (buf.size() - 8) / 8) return BGP_EINVAL;     // every reference takes at least n_bin + n_intv = 8 bytes
+    std::unique_ptr<bgp_bai> bp(new bgp_bai());       // (an allocation failure further down unwinds through the ABI guard)
+    bgp_bai* b = bp.get();
     b->indices.resize((size_t)n_ref);
     for (int32_t i = 0; i < n_ref && c.ok; ++i) {
         const int32_t n_bin = c.get<int32_t>();
@@ -120,9 +127,10 @@ int bgp_bai_open(const char* path, bgp_bai** out) {            // BaiFile(filena
         b->indices[i].ioffsets.resize((size_t)n_intv);
         for (int32_t j = 0; j < n_intv && c.ok; ++j) b->indices[i].ioffsets[j] = c.get<uint64_t>();
     }
-    if (!c.ok) { delete b; return BGP_ETRUNC; }
-    *out = b;
+    if (!c.ok) return BGP_ETRUNC;
+    *out = bp.release();
     return BGP_OK;
+    BGP_API_CATCH((bgp_ctx*)nullptr)
 }
 
 void bgp_bai_close(bgp_bai* b) { delete b; }
@@ -130,6 +138,7 @@ void bgp_bai_close(bgp_bai* b) { delete b; }
 int bgp_bai_n_ref(const bgp_bai* b, int32_t* n) { if (!b || !n) return BGP_EINVAL; *n = (int32_t)b->indices.size(); return BGP_OK; }
 
 int bgp_bai_shape(const bgp_bai* b, int32_t ref_id, uint32_t* n_bins, uint32_t* n_chunks, uint32_t* n_intervals) {
+    BGP_API_TRY
     if (!b || ref_id < 0 || (size_t)ref_id >= b->indices.size()) return BGP_EINVAL;
     const BaiIndex& ix = b->indices[ref_id];
     uint32_t nc = 0;
@@ -138,18 +147,22 @@ int bgp_bai_shape(const bgp_bai* b, int32_t ref_id, uint32_t* n_bins, uint32_t* 
     if (n_chunks) *n_chunks = nc;
     if (n_intervals) *n_intervals = (uint32_t)ix.ioffsets.size();
     return BGP_OK;
+    BGP_API_CATCH((bgp_ctx*)nullptr)
 }
 
 int bgp_bai_min_offset(const bgp_bai* b, int32_t ref_id, int32_t position, uint64_t* voffset) {   // baifile.d:77-82
+    BGP_API_TRY
     if (!b || !voffset || ref_id < 0 || (size_t)ref_id >= b->indices.size()) return BGP_EINVAL;
     const BaiIndex& ix = b->indices[ref_id];
     const int pos = std::max(0, position);
     const int i = std::min(pos / BAI_LINEAR_INDEX_WINDOW_SIZE, (int)ix.ioffsets.size() - 1);
     *voffset = i == -1 ? 0 : ix.ioffsets[(size_t)i];
     return BGP_OK;
+    BGP_API_CATCH((bgp_ctx*)nullptr)
 }
 
 int bgp_bai_chunks(bgp_bai* b, int32_t ref_id, uint32_t beg, uint32_t end, const bgp_chunk** chunks, uint32_t* n) {   // getChunks, randomaccessmanager.d:222-244
+    BGP_API_TRY
     if (!b || !chunks || !n) return BGP_EINVAL;
     if (ref_id < 0 || (size_t)ref_id >= b->indices.size()) return BGP_EINVAL;          // checkRefId, :205-207
     uint64_t min_offset = 0;
@@ -169,6 +182,7 @@ int bgp_bai_chunks(bgp_bai* b, int32_t ref_id, uint32_t beg, uint32_t end, const
     }
     *chunks = b->out.data(); *n = (uint32_t)b->out.size();
     return BGP_OK;
+    BGP_API_CATCH((bgp_ctx*)nullptr)
 }
 
 }  // extern "C"
@@ -247,6 +261,10 @@ int plan_chunks(const MappedFile& mf, const bgp_chunk* chunks, uint32_t n, std::
             const int rc = block_at(mf.p, mf.n, off, b, &next, err);
             if (rc < 0) return rc;
             const uint32_t skip_start = off == (ch.beg >> 16) ? (uint32_t)(ch.beg & 0xFFFF) : 0u;
+            if (skip_start > b.isize || (off == (ch.end >> 16) && (uint32_t)(ch.end & 0xFFFF) > b.isize)) {     // an index that does not belong to this file
+                err = "chunk offset past the end of its BGZF block";
+                return BGP_EINVAL;
+            }
             const int64_t skip_end = off == (ch.end >> 16) ? (int64_t)b.isize - (int64_t)(ch.end & 0xFFFF) : 0;
             const int64_t keep = (int64_t)b.isize - skip_start - skip_end;
             if (keep > 0) { b.skip = skip_start; b.keep = (uint32_t)keep; b.dst = dst; dst += (uint64_t)keep; pieces.push_back(b); }
@@ -300,6 +318,7 @@ int inflate_pieces(const MappedFile& mf, const std::vector<Piece>& pieces, uint8
 }  // namespace
 
 extern "C" int bgp_bgzf_read_chunks(const char* path, const bgp_chunk* chunks, uint32_t n, int n_threads, uint8_t* out, uint64_t cap, uint64_t* len) {
+    BGP_API_TRY
     if (!path || (!chunks && n) || !len) return BGP_EINVAL;
     MappedFile mf; std::string err;
     BGP_TRY(mf.open(path, err));
@@ -308,6 +327,7 @@ extern "C" int bgp_bgzf_read_chunks(const char* path, const bgp_chunk* chunks, u
     *len = total;
     if (!out || cap < total) return BGP_OK;                 // size query
     return inflate_pieces(mf, pieces, out, n_threads);
+    BGP_API_CATCH((bgp_ctx*)nullptr)
 }
 
 // Stage the records of a chunk list into the ctx (like bgzf_load_bam) and remember where every staged byte came

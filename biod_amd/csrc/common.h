@@ -6,6 +6,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <new>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -23,6 +25,13 @@
     } while (0)
 
 void bgp_note_hip_error(hipError_t e, const char* what, const char* file, int line);
+// No C++ exception crosses the C ABI (a D / C caller cannot catch it: std::terminate would take the host process
+// down): every extern "C" entry with a body worth the name runs inside this pair.
+int bgp_api_caught(struct bgp_ctx* c, int status, const char* what);
+#define BGP_API_TRY try {
+#define BGP_API_CATCH(ctx) } catch (const std::bad_alloc&) { return bgp_api_caught(ctx, BGP_ENOMEM, "out of host memory"); } \
+                           catch (const std::exception& e_) { return bgp_api_caught(ctx, BGP_EINVAL, e_.what()); } \
+                           catch (...) { return bgp_api_caught(ctx, BGP_EINVAL, "unknown C++ exception"); }
 
 // A growable device allocation (never shrinks; reused across bgp_reset).
 struct DevBuf {

@@ -76,36 +76,47 @@ __global__ __launch_bounds__(256) void k0_guess(FrameArgs a) {
 
 // one lane per segment
 __global__ __launch_bounds__(256) void k0_chase(FrameArgs a) {
-    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= a.n_seg) return;
     const uint32_t d = a.dirty[k];
     if (!d) return;
     if (d == 2) a.entry[k] = a.fix[k];                                     // repaired by k0_verify
     a.dirty[k] = 0;
-    const uint64_t seg_end = min((k + 1) * (uint64_t)a.seg_bytes, a.len);
-    uint64_t off = a.entry[k], cnt = 0, ls = 0, nc = 0;
-    uint32_t err = 0;
-    bool long_seen = false;
-    if (off == NONE || off == STOP) { a.end[k] = off; a.cnt[k] = 0; a.lseq[k] = 0; a.ncig[k] = 0; a.seg_err[k] = 0; return; }
-    while (off < seg_end) {
-        if (a.len - off < 4) { off = a.len; break; }                       // readrange.d:139-149: short prefix ends the range
-        const int32_t bs = (int32_t)ld_u32(a.s + off);
-        if (bs < 0) { err = ST_EINVAL; break; }
-        if ((uint64_t)bs > a.len - off - 4) { err = ST_ETRUNC; break; }    // readrange.d:169
-        if (bs < 32) { err = ST_EINVAL; break; }
-        uint32_t f3[3]; __builtin_memcpy(f3, a.s + off + 12, 12);            // bin_mq_nl, flag_nc, l_seq in one load (bs >= 32: in bounds)
-        const uint32_t bmn = f3[0], fnc = f3[1];
-        const int32_t lseq = (int32_t)f3[2];
-        const uint32_t l_name = bmn & 0xFFu, n_cig = fnc & 0xFFFFu;
-        if (lseq < 0 || l_name == 0 || 32ull + l_name + 4ull * n_cig + (uint64_t)((lseq + 1) / 2) + (uint64_t)lseq > (uint64_t)bs) { err = ST_EINVAL; break; }
-        if (cnt < a.side_cap) a.side[k * a.side_cap + cnt] = (uint32_t)(off - k * (uint64_t)a.seg_bytes);   // 128 contiguous bytes per 32 records: the fused K1+K2 finds every record without a second chase
-        ++cnt; ls += (uint64_t)lseq; nc += n_cig;
-        long_seen |= n_cig > LONG_CIGAR;
-        off += 4 + (uint64_t)bs;
+    uint64_t off = a.entry[k];
+    if (off == NONE) return;                                               // no guess: end/cnt/... keep their initial NONE/0 unless a chase from the left walks in (below)
+    if (off == STOP) { a.end[k] = off; a.cnt[k] = 0; a.lseq[k] = 0; a.ncig[k] = 0; a.seg_err[k] = 0; return; }
+    for (;;) {
+        const uint64_t seg_end = min((k + 1) * (uint64_t)a.seg_bytes, a.len);
+        uint64_t cnt = 0, ls = 0, nc = 0;
+        uint32_t err = 0;
+        bool long_seen = false;
+        while (off < seg_end) {
+            if (a.len - off < 4) { off = a.len; break; }                       // readrange.d:139-149: short prefix ends the range
+            const int32_t bs = (int32_t)ld_u32(a.s + off);
+            if (bs < 0) { err = ST_EINVAL; break; }
+            if ((uint64_t)bs > a.len - off - 4) { err = ST_ETRUNC; break; }    // readrange.d:169
+            if (bs < 32) { err = ST_EINVAL; break; }
+            uint32_t f3[3]; __builtin_memcpy(f3, a.s + off + 12, 12);            // bin_mq_nl, flag_nc, l_seq in one load (bs >= 32: in bounds)
+            const uint32_t bmn = f3[0], fnc = f3[1];
+            const int32_t lseq = (int32_t)f3[2];
+            const uint32_t l_name = bmn & 0xFFu, n_cig = fnc & 0xFFFFu;
+            if (lseq < 0 || l_name == 0 || 32ull + l_name + 4ull * n_cig + (uint64_t)((lseq + 1) / 2) + (uint64_t)lseq > (uint64_t)bs) { err = ST_EINVAL; break; }
+            if (cnt < a.side_cap) a.side[k * a.side_cap + cnt] = (uint32_t)(off - k * (uint64_t)a.seg_bytes);   // 128 contiguous bytes per 32 records: the fused K1+K2 finds every record without a second chase
+            ++cnt; ls += (uint64_t)lseq; nc += n_cig;
+            long_seen |= n_cig > LONG_CIGAR;
+            off += 4 + (uint64_t)bs;
+        }
+        a.end[k] = err ? STOP : off;
+        // per segment, not a sticky global bit: a chase from a wrong guess reads garbage and must not leave a trace
+        a.cnt[k] = cnt; a.lseq[k] = ls; a.ncig[k] = nc; a.seg_err[k] = err | (long_seen ? ST_LONGCIG : 0u);
+        // A following segment the guesser found nothing in (inside a record longer than a segment, or bytes that
+        // look like no header) is chased right away from where this chain stands -- otherwise every such segment
+        // would cost k0_verify one more round, host round trip included.  Its own lane wrote nothing (see above);
+        // should it read the entry set here it chases the same bytes to the same values.
+        if (err || k + 1 >= a.n_seg || a.entry[k + 1] != NONE) break;
+        ++k;
+        a.entry[k] = off; a.dirty[k] = 0;
     }
-    a.end[k] = err ? STOP : off;
-    // per segment, not a sticky global bit: a chase from a wrong guess reads garbage and must not leave a trace
-    a.cnt[k] = cnt; a.lseq[k] = ls; a.ncig[k] = nc; a.seg_err[k] = err | (long_seen ? ST_LONGCIG : 0u);
 }
 
 // A link k is consistent when entry[k] == end[k-1].  A broken link is repaired only when the
@@ -257,6 +268,9 @@ int k0_frame(bgp_ctx* c) {
     {
         TimedRegion t(c, "k0_guess", n_seg * 64);
         BGP_HIP(hipMemsetAsync(a.dirty, 0x01, n_seg * 4, c->stream));        // every segment dirty (any non-zero)
+        BGP_HIP(hipMemsetAsync(a.seg_err, 0, n_seg * 4, c->stream));         // what a segment without an entry keeps: end NONE, no records
+        BGP_HIP(hipMemsetAsync(a.end, 0xFF, n_seg * 8, c->stream));
+        BGP_HIP(hipMemsetAsync(a.cnt, 0, n_seg * 8, c->stream)); BGP_HIP(hipMemsetAsync(a.lseq, 0, n_seg * 8, c->stream)); BGP_HIP(hipMemsetAsync(a.ncig, 0, n_seg * 8, c->stream));
         hipLaunchKernelGGL(k0_guess, dim3((unsigned)((n_seg + 3) / 4)), dim3(256), 0, c->stream, a);
     }
     uint64_t rounds = 0;

@@ -3,6 +3,11 @@ import sys
 
 import pytest
 
+try:                      # torch bundles its own HIP runtime: it has to be the first one loaded into the process, or torch.cuda
+    import torch  # noqa: F401   # finds no device once libbiodgpu.so has pulled in the system's libamdhip64 (tests that hand torch tensors over need both)
+except ImportError:
+    pass
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -111,3 +111,31 @@ def test_bamio_roundtrip(tmp_path):
     bamio.write_bam(path, [("chr1", 30_000), ("chr2", 30_000)], recs, text="@HD\tVN:1.6\tSO:coordinate\n")
     hdr, back = bamio.read_bam(path)
     assert back == st and hdr.refs == [("chr1", 30_000), ("chr2", 30_000)]
+
+
+def test_bai_open_rejects_reference_count_the_file_cannot_hold(tmp_path):
+    """A .bai whose n_ref promises more references than its bytes can describe is refused with a status code
+    (every reference takes >= 8 bytes); no C++ exception may cross the C ABI (baifile.d:126-169 throws a
+    catchable exception here)."""
+    import struct
+    from biod_amd import _lib as L
+    p = tmp_path / "x.bai"
+    p.write_bytes(b"BAI\1" + struct.pack("<i", 0x7FFFFFFF))
+    h = C.c_void_p()
+    assert L.lib().bgp_bai_open(str(p).encode(), C.byref(h)) == L.BGP_EINVAL
+    p.write_bytes(b"BAI\1" + struct.pack("<i", 2) + struct.pack("<ii", 0, 0))          # second reference missing
+    assert L.lib().bgp_bai_open(str(p).encode(), C.byref(h)) < 0
+
+
+def test_chunk_offsets_past_their_block_are_refused(data_dir):
+    """StreamChunksSupplier (inputstream.d:254-330) with a chunk whose uoffset lies beyond the block's ISIZE: an
+    index that does not belong to the file.  Status code, not stale bytes."""
+    import os
+    from biod_amd import _lib as L
+    bam = os.path.join(data_dir, "ex1_header.bam").encode()
+    n = C.c_uint64()
+    for beg, end in ((0, 65000), (65000, (1 << 16) | 5)):
+        chunk = (C.c_uint64 * 2)(beg, end)
+        assert L.lib().bgp_bgzf_read_chunks(bam, chunk, 1, 1, None, 0, C.byref(n)) == L.BGP_EINVAL
+    chunk = (C.c_uint64 * 2)(0, 100)                        # inside the first block (103 bytes): fine
+    assert L.lib().bgp_bgzf_read_chunks(bam, chunk, 1, 1, None, 0, C.byref(n)) == 0 and n.value == 100

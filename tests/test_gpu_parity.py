@@ -1282,3 +1282,104 @@ def test_reference_base_long_chunks_in_pieces(ctx, seed):
     lo, hi = int(info.runs[0]["start_pos"]), int(info.runs[0]["end_pos"])
     a = int(rng.integers(lo, hi)); b = int(rng.integers(a, hi + 50))
     _check_refbase(ctx, st, mode=L.BGP_MAKE_PILEUP, skip_zero=False, start_from=a, end_at=b)
+
+
+# ---- the gather path of K4 (k4_plan / k4_exec): rounds, cuts, fallbacks; framing repairs; full-size properties ----
+
+@pytest.mark.parametrize("n_reads,ref_len,profile", [(8000, 12_000, 1), (5000, 6_000, 0), (14_000, 12_000, 1)])
+def test_gather_path_rounds_and_cuts(ctx, n_reads, ref_len, profile):
+    """Coverage of 100-170: a 1024-position window holds 500-1000 descriptors (more than one round of one per
+    thread) and more class bytes than a round's LDS (the round is cut and continued); at 170-fold some windows
+    outgrow their slab and go to the general kernel, next to windows that do not.  Columns == oracle everywhere."""
+    cfg = make_cfg(n_reads=n_reads, n_ref=1, ref_len=ref_len, read_len=150, profile=profile, seed=77 + n_reads)
+    st = host_stream(cfg)
+    stage(ctx, st)
+    info, ora = check_pileup(ctx, st, entries=False)
+    assert info.max_coverage > 100
+
+
+def test_gather_path_next_to_long_reads(ctx):
+    """Short reads (gather path) and long indel-heavy reads (general kernel) on one reference: windows are handed
+    to one path or the other as a whole, neighbours differ."""
+    short = make_cfg(n_reads=6000, n_ref=1, ref_len=60_000, read_len=150, profile=1, seed=3)
+    recs = O.frame(host_stream(short))
+    long_cfg = make_cfg(n_reads=12, n_ref=1, ref_len=60_000, read_len=(2000, 6000), profile=2, seed=4)
+    st_long = host_stream(long_cfg)
+    st_short = host_stream(short)
+    lrec = O.frame(st_long)
+    # merge by position (both streams are sorted): (pos, bytes)
+    def items(st, fr):
+        soa = O.decode_soa(st)
+        return [(int(soa.pos[i]), st[int(fr[i][0]):int(fr[i][0]) + int(fr[i][1])]) for i in range(len(fr))]
+    def spans(st):
+        off = O.decode_soa(st).rec_off
+        ends = list(off[1:]) + [len(st)]
+        return [(int(o), int(e - o)) for o, e in zip(off, ends)]
+    merged = sorted(items(st_short, spans(st_short)) + items(st_long, spans(st_long)), key=lambda x: x[0])
+    st = b"".join(b for _, b in merged)
+    stage(ctx, st)
+    check_decode(ctx, st)
+    check_pileup(ctx, st, entries=False)
+
+
+def test_framing_with_a_wrong_reference_bound(ctx):
+    """bgp_set_n_ref smaller than the ids the records carry: the boundary guesser rejects every true header, no
+    segment but the first has an entry, and one chase carries the chain through all of them (instead of one
+    verify round per segment).  Results do not depend on the hint."""
+    cfg = make_cfg(n_reads=30_000, n_ref=6, ref_len=30_000, read_len=150, profile=1, seed=11)
+    st = host_stream(cfg)
+    stage(ctx, st, n_ref=1)
+    check_decode(ctx, st)
+    check_pileup(ctx, st, entries=False)
+
+
+def test_cfg5_read_lengths_columns_and_entries(ctx):
+    """BASELINE config 5 at its own read lengths (10-50 kb, an indel every ~15 bases): 48 reads, every column against
+    the oracle, per-read entries on sampled windows."""
+    cfg = scaled("cfg5", 48)
+    assert cfg.len_min == 10_000 and cfg.len_max == 50_000
+    st = host_stream(cfg)
+    stage(ctx, st)
+    check_decode(ctx, st)
+    info, _ = check_pileup(ctx, st, entries=False)
+    ora = O.pileup(st, want_entries=True)
+    k, seen = 0, 0
+    for wi, w in enumerate(ctx.pileup_windows(L.BGP_PILEUP_COLUMNS, want_entries=True, window_positions=1500)):
+        nz = np.nonzero(w.columns["coverage"])[0]
+        if wi % 23 == 0:
+            for jj, j in enumerate(nz):
+                e = w.entries[int(w.entry_off[j]):int(w.entry_off[j + 1])]
+                oe = ora.entries[int(ora.entry_off[k + jj]):int(ora.entry_off[k + jj + 1])]
+                assert np.array_equal(e["read_ordinal"], oe["read_ordinal"].astype(np.uint32))
+                assert np.array_equal(e["cigar_op_index"], oe["cigar_op_index"].astype(np.uint16)) and np.array_equal(e["cigar_op_offset"], oe["cigar_op_offset"])
+                assert np.array_equal(e["query_offset"], oe["query_offset"]) and np.array_equal(e["base"], oe["base"]) and np.array_equal(e["qual"], oe["qual"])
+                seen += 1
+        k += len(nz)
+    assert seen > 5000
+
+
+@pytest.mark.parametrize("name", ["cfg2", "cfg3", "cfg5"])
+def test_full_size_properties(ctx, name):
+    """The BASELINE configurations at their FULL sizes (10 M, 100 M, 200 k reads; the stream is generated in HBM):
+    identities of the result checked on the device -- sum n_starting_here = reads used, sum coverage = sum
+    basesCovered of the record table = the header's total, coverage = sum of classes at every position, the depth
+    histogram adds up -- and a prefix shard against the oracle."""
+    import torch
+    from biod_amd.checks import full_size_invariants
+    from biod_amd.synth import CONFIGS
+    n = CONFIGS[name]["n_reads"]
+    free, _ = torch.cuda.mem_get_info(0)
+    if n * (1000 if name != "cfg5" else 600_000) > free * 0.9:
+        pytest.skip("not enough free HBM for the full configuration")
+    cfg = scaled(name, n)
+    ctx.reset()
+    ctx.synth_device(cfg)
+    ctx.flush()
+    info = ctx.pileup_run()
+    res = full_size_invariants(torch, torch.device("cuda", 0), ctx, info, n)
+    assert res["ok"], res
+    assert res["reads_used"] == n
+    k = 20_000 if name != "cfg5" else 40
+    st = host_stream(cfg, 0, k)
+    stage(ctx, st)
+    check_pileup(ctx, st, entries=False)
