@@ -49,6 +49,11 @@ class Columns(C.Structure):
                 ("entry_off", C.c_void_p), ("entries", C.c_void_p), ("reference_base", C.c_void_p), ("snp", C.c_void_p)]
 
 
+class ChunkInfo(C.Structure):
+    _fields_ = [("ref_id", C.c_int32), ("_pad", C.c_uint32), ("first_record", C.c_uint64), ("last_record", C.c_uint64),
+                ("start_position", C.c_uint64), ("end_position", C.c_uint64)]
+
+
 class KernelTime(C.Structure):
     _fields_ = [("name", C.c_char_p), ("total_ms", C.c_double), ("launches", C.c_uint64), ("algorithmic_bytes", C.c_uint64)]
 
@@ -84,6 +89,8 @@ SYMBOLS = {
     "bgp_pileup_next_window": (C.c_int, [_P, C.POINTER(Columns)]),
     "bgp_pileup_ref_id": (C.c_int, [_P, C.POINTER(C.c_int32)]),
     "bgp_pileup_snp": (C.c_int, [_P, C.c_int, C.c_int]),
+    "bgp_pileup_chunks_begin": (C.c_int, [_P, C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_uint32, C.POINTER(C.c_uint64)]),
+    "bgp_pileup_chunk": (C.c_int, [_P, C.c_uint64, C.POINTER(ChunkInfo)]),
     "bgp_read_dna": (C.c_int, [_P, C.c_uint64, C.c_char_p, C.c_uint32, C.POINTER(C.c_uint32)]),
     "bgp_bai_open": (C.c_int, [C.c_char_p, C.POINTER(_P)]),
     "bgp_bai_close": (None, [_P]),

@@ -143,7 +143,7 @@ int bgp_reset(bgp_ctx* c) {
     BGP_HIP(hipStreamSynchronize(c->stream));
     c->h_stage_len = 0; c->d_stream = nullptr; c->stream_len = 0; c->stream_on_device = false;
     c->flushed = false; c->piled = false; c->md_rows_ready = false; c->table_pending = false; c->n_records = 0; c->decoded_what = 0; c->it = bgp_ctx::Iter();
-    c->runs.clear(); c->stage_map.clear(); c->region_pending = false; c->bai_buildable = false; c->cig4_ok = false;
+    c->runs.clear(); c->chunks.clear(); c->chunks_ready = false; c->stage_map.clear(); c->region_pending = false; c->bai_buildable = false; c->cig4_ok = false;
     c->refs.clear(); c->n_ref_hint = 0; c->last_error.clear(); c->bai_bytes.clear();      // nothing of the previous file survives: the loaders and bgp_set_n_ref re-establish these
     return BGP_OK;
     BGP_API_CATCH(c)
@@ -309,6 +309,45 @@ int bgp_pileup_begin(bgp_ctx* c, int mode, int use_md_tag, uint64_t start_from, 
             }
         }
     }
+    return BGP_OK;
+    BGP_API_CATCH(c)
+}
+
+int bgp_pileup_chunks_begin(bgp_ctx* c, int use_md_tag, uint64_t block_size, uint64_t start_from, uint64_t end_at, int want_entries, uint32_t window, uint64_t* n_chunks) {
+    BGP_API_TRY
+    if (!c || !n_chunks) return BGP_EINVAL;
+    if (!c->flushed) return BGP_ESTATE;
+    BGP_HIP(hipSetDevice(c->device));
+    c->chunks_ready = false; c->it = bgp_ctx::Iter();
+    if (!c->piled) BGP_TRY(bgp_pileup_run(c, nullptr));
+    BGP_TRY(chunks_plan(c, block_size, start_from, end_at));
+    if (use_md_tag && !c->runs.empty()) {          // the provider chain of the whole stream (pileupColumns' chain); the chunks slice it
+        int md_err = 0; int64_t md_from = -1;
+        BGP_TRY(k6_reference_bases(c, 1, 0, (uint32_t)c->runs.size(), ~0ull, &md_err, &md_from));
+        if (md_err) { c->last_error = "MD tag inconsistent with CIGAR/SEQ while reconstructing reference bases"; return md_err; }
+    }
+    c->chunks_use_md = use_md_tag; c->chunks_want_entries = want_entries; c->chunks_window = window; c->chunks_ready = true;
+    *n_chunks = c->chunks.size();
+    return BGP_OK;
+    BGP_API_CATCH(c)
+}
+
+int bgp_pileup_chunk(bgp_ctx* c, uint64_t k, bgp_chunk_info* out) {
+    BGP_API_TRY
+    if (!c || !out) return BGP_EINVAL;
+    if (!c->chunks_ready || !c->piled) return BGP_ESTATE;
+    if (k >= c->chunks.size()) return BGP_EOF;
+    const bgp_chunk_info& ci = c->chunks[k];
+    *out = ci;
+    auto& it = c->it;
+    it = bgp_ctx::Iter();
+    it.active = true; it.mode = BGP_MAKE_PILEUP; it.use_md = c->chunks_use_md; it.skip_zero = 1; it.want_entries = c->chunks_want_entries;
+    it.window = c->chunks_window ? c->chunks_window : 65536u;
+    it.start_from = ci.start_position; it.end_at = ci.end_position; it.ref_id = ci.ref_id;
+    it.run = it.run_end = (uint32_t)c->runs.size();                             // no columns unless the reference has covering reads
+    if (ci.start_position < ci.end_position)
+        for (uint32_t j = 0; j < c->runs.size(); ++j)
+            if (c->runs[j].ref_id == ci.ref_id) { it.run = j; it.run_end = j + 1; it.next_pos = std::max<uint64_t>(c->runs[j].start_pos, ci.start_position); break; }
     return BGP_OK;
     BGP_API_CATCH(c)
 }

@@ -148,6 +148,7 @@ struct bgp_ctx {
         uint32_t run = 0, run_end = 0; uint64_t next_pos = 0; int32_t ref_id = -1;
         int snp = 0, snp_min_cov = 5, snp_min_wit = 2;
     } it;
+    std::vector<bgp_chunk_info> chunks; int chunks_use_md = 0, chunks_want_entries = 0; uint32_t chunks_window = 0; bool chunks_ready = false;   // pileupChunks: the planned chunks
     HostBuf h_cols, h_entry_off, h_entries, h_refbase, h_snp;
     DevBuf d_snp;
     DevBuf d_entry_off, d_entries, d_col_lo;
@@ -200,7 +201,8 @@ struct bgp_inflate_block { uint64_t src, dst; uint32_t clen, isize, crc, pad; };
 int inflate_blocks_device(bgp_ctx* c, const uint8_t* d_comp, uint8_t* d_out, const bgp_inflate_block* d_blk, uint32_t n_blk, int32_t* d_status, uint64_t out_bytes);   // inflate.hip
 int bgzf_load_bam_device(bgp_ctx* c, const char* path);      // bgzf_host.cpp : file -> HBM compressed -> k_inflate
 int bgp_default_threads();                                   // bgzf_host.cpp : affinity mask and cgroup quota applied
-int bai_build(bgp_ctx* c, std::vector<uint8_t>& out);         // bai_build.hip : createIndex over the staged file
+int bai_build(bgp_ctx* c, std::vector<uint8_t>& out);
+int chunks_plan(bgp_ctx* c, uint64_t block_size, uint64_t start_from, uint64_t end_at);   // chunks.hip : fills c->chunks         // bai_build.hip : createIndex over the staged file
 
 // device helpers shared by kernels
 #if defined(__HIPCC__)

@@ -157,6 +157,25 @@ class Context:
         L.check(L.lib().bgp_pileup_begin(self._h, mode, int(use_md_tag), start_from, end_at, int(skip_zero_coverage), int(want_entries), window_positions), self._h)
         if snp is not None:
             L.check(L.lib().bgp_pileup_snp(self._h, int(snp[0]), int(snp[1])), self._h)
+        yield from self._windows(snp)
+
+    def pileup_chunks_begin(self, use_md_tag=False, block_size=16_384_000, start_from=0, end_at=ULONG_MAX, want_entries=False, window_positions=0) -> int:
+        """Plans pileupChunks (pileup.d:1011-1015); returns the number of chunks."""
+        n = C.c_uint64()
+        L.check(L.lib().bgp_pileup_chunks_begin(self._h, int(use_md_tag), block_size, start_from, end_at, int(want_entries), window_positions, C.byref(n)), self._h)
+        return int(n.value)
+
+    def pileup_chunk(self, k: int) -> "L.ChunkInfo":
+        """Selects chunk k: its windows follow from chunk_windows()."""
+        ci = L.ChunkInfo()
+        L.check(L.lib().bgp_pileup_chunk(self._h, k, C.byref(ci)), self._h)
+        return ci
+
+    def chunk_windows(self, k: int):
+        self.pileup_chunk(k)
+        yield from self._windows(None)
+
+    def _windows(self, snp):
         while True:
             cw = L.Columns()
             rc = L.check(L.lib().bgp_pileup_next_window(self._h, C.byref(cw)), self._h)
@@ -652,6 +671,30 @@ class _Pileup:
 def makePileup(reads, use_md_tag=False, start_from=0, end_at=ULONG_MAX, skip_zero_coverage=True, *, want_entries=True, window_positions=0):
     """pileup.d:683-694.  Only the first reference of `reads` is processed (pileup.d:490-494)."""
     return _Pileup(reads, L.BGP_MAKE_PILEUP, use_md_tag, start_from, end_at, skip_zero_coverage, want_entries, window_positions)
+
+
+class _ChunkPileup(_Pileup):
+    """One element of PileupChunkRange (pileup.d:859-987): the pileup of a chunk, clipped by the seam rule."""
+
+    def __init__(self, reads, ctx, k, info, use_md_tag, want_entries, window_positions):
+        self.reads, self._ctx, self._k = reads, ctx, k
+        self.ref_id, self.start_position, self.end_position = int(info.ref_id), int(info.start_position), int(info.end_position)
+        self.first_record, self.last_record = int(info.first_record), int(info.last_record)
+        self._args = (L.BGP_MAKE_PILEUP, use_md_tag, self.start_position, self.end_position, True, want_entries, window_positions)
+
+    def windows(self) -> Iterator[Window]:
+        return self._ctx.chunk_windows(self._k)
+
+
+def pileupChunks(reads, use_md_tag=False, block_size=16_384_000, start_from=0, end_at=ULONG_MAX, *, want_entries=True, window_positions=0):
+    """pileup.d:1011-1015: consecutive non-overlapping pileups (chunks cut as chunksConsumingLessThan does, splitter.d:65-91;
+    seams as PileupChunkRange sets them, pileup.d:905-913,932-939).  The elements may be consumed in any order."""
+    ctx = reads._stage()
+    n = ctx.pileup_chunks_begin(use_md_tag, block_size, start_from, end_at, want_entries, window_positions)
+    if want_entries and n and getattr(reads, "records", None) is None:
+        reads.decode()
+        ctx.pileup_chunks_begin(use_md_tag, block_size, start_from, end_at, want_entries, window_positions)
+    return [_ChunkPileup(reads, ctx, k, ctx.pileup_chunk(k), use_md_tag, want_entries, window_positions) for k in range(n)]
 
 
 def pileupColumns(reads, use_md_tag=False, skip_zero_coverage=True, *, want_entries=True, window_positions=0):

@@ -202,6 +202,30 @@ int bgp_pileup_begin(bgp_ctx* ctx, int mode, int use_md_tag, uint64_t start_from
 int bgp_pileup_next_window(bgp_ctx* ctx, bgp_columns* out);   /* BGP_OK, BGP_EOF, or error */
 int bgp_pileup_ref_id(bgp_ctx* ctx, int32_t* ref_id);          /* AbstractPileup.ref_id, pileup.d:455 */
 
+/* pileupChunks(reads, use_md_tag, block_size = 16_384_000, start_from = 0, end_at = ulong.max), pileup.d:1011-1015:
+ * consecutive non-overlapping pileups a caller maps over in parallel.  The chunks are cut exactly as
+ * chunksConsumingLessThan does (splitter.d:65-91: size_in_bytes of the records, never across a ref_id), walked as
+ * PileupChunkRange does (pileup.d:859-939: chunks of unmapped reads skipped, leading chunks ending at or before
+ * start_from dropped, empty when the first kept chunk begins at or after end_at), and chunk j's columns are those of
+ * makePileup(..., start_position, end_position) with BioD's seam rule: start_position = position of the previous
+ * chunk's last read (same reference) or of the chunk's own first read, end_position = position of the chunk's last
+ * read, or the right end when the reference ends with the chunk -- each clipped by start_from / end_at.
+ * Two deviations, stated: every read overlapping a chunk's columns is counted (BioD keeps the previous chunk's reads
+ * that start within twice a SAMPLED median read length, pileup.d:944-985), and the last chunk of a reference ends at
+ * the largest end_position of the reference, not of that chunk; with them the chunks' columns concatenate to exactly
+ * pileupColumns'.  With use_md_tag the reference bases are those of the whole-stream provider chain (a fresh chain per
+ * chunk, as BioD runs it, can differ where MD tags disagree with each other).
+ * bgp_pileup_chunks_begin plans the chunks (*n_chunks of them); bgp_pileup_chunk selects chunk k (any order, any number
+ * of times): its description goes to *out and bgp_pileup_next_window then hands out its windows until BGP_EOF. */
+typedef struct bgp_chunk_info {
+    int32_t ref_id; uint32_t _pad;
+    uint64_t first_record, last_record;     /* the chunk's own reads (ordinals in the record table), inclusive */
+    uint64_t start_position, end_position;  /* AbstractPileup.start_position / end_position, pileup.d:439-452 */
+} bgp_chunk_info;
+int bgp_pileup_chunks_begin(bgp_ctx* ctx, int use_md_tag, uint64_t block_size, uint64_t start_from, uint64_t end_at,
+                            int want_entries, uint32_t window_positions, uint64_t* n_chunks);
+int bgp_pileup_chunk(bgp_ctx* ctx, uint64_t k, bgp_chunk_info* out);
+
 /* isSNP(column, settings) of bio/std/hts/snpcallers/simple.d:15-41 for every position of the windows that
  * follow (call after bgp_pileup_begin with use_md_tag = 1; defaults of SimpleCallerSettings: 5, 2).
  * coverage < minimum_coverage -> no; no base other than '-' -> no; consensus = the base with the largest

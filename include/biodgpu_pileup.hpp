@@ -144,6 +144,14 @@ public:
         if (want_entries) check(bgp_decode_fetch(ctx_, BGP_FETCH_ALL, &recs_), ctx_);
         restart();
     }
+    // element `chunk` of pileupChunks (below): the chunk's columns, [start_position, end_position) of its reference
+    PileupRange(BamReader& r, uint64_t chunk, bool want_entries)
+        : ctx_(r.ctx()), skip_zero_(true), want_entries_(want_entries), start_(0), end_(0), mode_(BGP_MAKE_PILEUP), use_md_(false), window_(0), chunk_((int64_t)chunk) {
+        if (want_entries) check(bgp_decode_fetch(ctx_, BGP_FETCH_ALL, &recs_), ctx_);
+        restart();
+    }
+    uint64_t first_record() const { return ci_.first_record; }
+    uint64_t last_record() const { return ci_.last_record; }
     bool empty() const { return done_; }
     PileupColumn front() const {
         const uint64_t a = want_entries_ ? w_.entry_off[k_] : 0, b = want_entries_ ? w_.entry_off[k_ + 1] : 0;
@@ -172,6 +180,13 @@ public:
 
 private:
     void restart() {
+        if (chunk_ >= 0) {                                                     // a chunk of pileupChunks: select it, its windows follow
+            check(bgp_pileup_chunk(ctx_, (uint64_t)chunk_, &ci_), ctx_);
+            start_ = ci_.start_position; end_ = ci_.end_position; ref_id_ = ci_.ref_id;
+            done_ = false;
+            fetch(); settle();
+            return;
+        }
         check(bgp_pileup_begin(ctx_, mode_, use_md_, start_, end_, skip_zero_, want_entries_, window_), ctx_);
         if (snp_) check(bgp_pileup_snp(ctx_, snp_cov_, snp_wit_), ctx_);
         if (mode_ == BGP_MAKE_PILEUP) check(bgp_pileup_ref_id(ctx_, &ref_id_), ctx_);
@@ -189,6 +204,7 @@ private:
     bgp_ctx* ctx_; bool skip_zero_, want_entries_; uint64_t start_, end_;
     int mode_; bool use_md_; uint32_t window_; bool snp_ = false; int snp_cov_ = 5, snp_wit_ = 2;
     bgp_columns w_{}; bgp_records recs_{}; uint32_t k_ = 0; bool done_ = false; int32_t ref_id_ = -1;
+    int64_t chunk_ = -1; bgp_chunk_info ci_{};
 };
 
 // makePileup(reads, use_md_tag=false, start_from=0, end_at=ulong.max, skip_zero_coverage=true), pileup.d:683-694
@@ -201,6 +217,34 @@ inline PileupRange makePileup(BamReader& reads, bool use_md_tag = false, uint64_
 inline PileupRange pileupColumns(BamReader& reads, bool use_md_tag = false, bool skip_zero_coverage = true,
                                  bool want_entries = true, uint32_t window = 0) {
     return PileupRange(reads, BGP_PILEUP_COLUMNS, use_md_tag, 0, std::numeric_limits<uint64_t>::max(), skip_zero_coverage, want_entries, window);
+}
+
+// pileupChunks(reads, use_md_tag=false, block_size=16_384_000, start_from=0, end_at=ulong.max), pileup.d:1011-1015:
+// consecutive non-overlapping pileups.  Each element is positioned on its chunk when it is created (here: when the
+// vector is walked with `for (auto& chunk : ...)` the elements were created in order; to revisit one, construct
+// PileupRange(reads, k, want_entries) again) -- one ctx serves one chunk at a time.
+class PileupChunks {
+public:
+    PileupChunks(BamReader& r, bool use_md_tag, uint64_t block_size, uint64_t start_from, uint64_t end_at, bool want_entries, uint32_t window)
+        : r_(r), want_entries_(want_entries) {
+        check(bgp_pileup_chunks_begin(r.ctx(), use_md_tag, block_size, start_from, end_at, want_entries, window, &n_), r.ctx());
+    }
+    uint64_t size() const { return n_; }
+    PileupRange operator[](uint64_t k) const { return PileupRange(r_, k, want_entries_); }
+    struct iterator {
+        const PileupChunks* p; uint64_t k;
+        bool operator!=(const iterator& o) const { return k != o.k; }
+        void operator++() { ++k; }
+        PileupRange operator*() const { return (*p)[k]; }
+    };
+    iterator begin() const { return {this, 0}; }
+    iterator end() const { return {this, n_}; }
+private:
+    BamReader& r_; bool want_entries_; uint64_t n_ = 0;
+};
+inline PileupChunks pileupChunks(BamReader& reads, bool use_md_tag = false, uint64_t block_size = 16384000, uint64_t start_from = 0,
+                                 uint64_t end_at = std::numeric_limits<uint64_t>::max(), bool want_entries = true, uint32_t window = 0) {
+    return PileupChunks(reads, use_md_tag, block_size, start_from, end_at, want_entries, window);
 }
 
 }  // namespace biodgpu

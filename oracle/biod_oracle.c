@@ -907,13 +907,9 @@ static int plan_build(chunk_plan* p, const uint8_t* s, uint64_t len, uint64_t ch
     return ORC_OK;
 }
 
-/* One PileupChunkRange element (pileup.d:859-987): the pileup of chunk j clipped to
- * [beg, end_pos).  The halo is EXACT (every earlier read of the same reference run with
- * end_position > beg) instead of BioD's 2 x median-read-length heuristic (pileup.d:944-985);
- * see SURVEY.md section 3.3 for why. */
-static int chunk_run(const chunk_plan* p, size_t j, column_sink sink, void* user) {
+/* [beg, end_pos) of PileupChunkRange's element for chunk j: _beg (pileup.d:932-939) and front()'s end_pos (:905-908). */
+static void chunk_bounds(const chunk_plan* p, size_t j, int* same_prev_out, size_t* jp_out, uint64_t* beg_out, uint64_t* end_out) {
     const chunk_t* c = &p->chunks[j];
-    if (c->ref_id < 0) return ORC_OK;                                    /* pileup.d:886,926 */
     int same_prev = 0; size_t jp = j;
     while (jp > 0) { --jp; if (p->chunks[jp].ref_id >= 0) { same_prev = p->chunks[jp].ref_id == c->ref_id; break; } }
     uint64_t beg = same_prev ? (uint64_t)(int64_t)p->pos[p->chunks[jp].last] : (uint64_t)(int64_t)p->pos[c->first]; /* pileup.d:932-939 */
@@ -927,6 +923,18 @@ static int chunk_run(const chunk_plan* p, size_t j, column_sink sink, void* user
     size_t jn = j + 1;
     while (jn < p->n_chunks && p->chunks[jn].ref_id < 0) ++jn;           /* popFront skips ref_id < 0 chunks */
     if (jn >= p->n_chunks || p->chunks[jn].ref_id != p->ref[c->last]) end_pos = (uint64_t)(int64_t)right_end; /* pileup.d:907-908 */
+    *same_prev_out = same_prev; *jp_out = jp; *beg_out = beg; *end_out = end_pos;
+}
+
+/* One PileupChunkRange element (pileup.d:859-987): the pileup of chunk j clipped to
+ * [beg, end_pos).  The halo is EXACT (every earlier read of the same reference run with
+ * end_position > beg) instead of BioD's 2 x median-read-length heuristic (pileup.d:944-985);
+ * see SURVEY.md section 3.3 for why. */
+static int chunk_run(const chunk_plan* p, size_t j, column_sink sink, void* user) {
+    const chunk_t* c = &p->chunks[j];
+    if (c->ref_id < 0) return ORC_OK;                                    /* pileup.d:886,926 */
+    int same_prev; size_t jp; uint64_t beg, end_pos;
+    chunk_bounds(p, j, &same_prev, &jp, &beg, &end_pos);
     /* exact halo: earlier reads of this reference run with end_position > beg */
     uint64_t run_lo = c->first;
     if (same_prev) {
@@ -1085,4 +1093,23 @@ done:
     free(job.results); free(job.rcs); plan_free(&plan);
     out->status = rc;
     return rc;
+}
+
+/* The chunks pileupChunks(reads, use_md, chunk_bytes) walks (chunks whose first read has ref_id < 0 are skipped,
+ * pileup.d:886,926) with the [beg, end_pos) each one's pileup is clipped to -- start_from = 0, end_at = ulong.max. */
+int64_t orc_chunk_plan(const uint8_t* stream, uint64_t len, uint64_t chunk_bytes, orc_chunk* out, uint64_t cap) {
+    if (chunk_bytes == 0) chunk_bytes = 16384000;
+    chunk_plan plan;
+    int rc = plan_build(&plan, stream, len, chunk_bytes, 1);
+    if (rc) { plan_free(&plan); return rc; }
+    int64_t n = 0;
+    for (size_t j = 0; j < plan.n_chunks; ++j) {
+        if (plan.chunks[j].ref_id < 0) continue;
+        int same_prev; size_t jp; uint64_t beg, end_pos;
+        chunk_bounds(&plan, j, &same_prev, &jp, &beg, &end_pos);
+        if ((uint64_t)n < cap) { out[n].first = plan.chunks[j].first; out[n].last = plan.chunks[j].last; out[n].ref_id = plan.chunks[j].ref_id; out[n].beg = beg; out[n].end = end_pos; }
+        ++n;
+    }
+    plan_free(&plan);
+    return n;
 }

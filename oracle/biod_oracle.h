@@ -149,6 +149,11 @@ int orc_pileup_bench(const uint8_t* stream, uint64_t len, int n_threads, uint64_
 int orc_pileup_chunked(const uint8_t* stream, uint64_t len, uint64_t chunk_bytes, int n_threads,
                        int want_entries, orc_pileup_result* out);
 
+/* The chunk walk of pileupChunks (splitter.d:65-91, pileup.d:878-939): records [first, last] of every chunk it
+ * yields a pileup for, and that pileup's column range [beg, end).  Returns the number of chunks (may exceed cap). */
+typedef struct { uint64_t first, last; int32_t ref_id; int32_t _pad; uint64_t beg, end; } orc_chunk;
+int64_t orc_chunk_plan(const uint8_t* stream, uint64_t len, uint64_t chunk_bytes, orc_chunk* out, uint64_t cap);
+
 #ifdef __cplusplus
 }
 #endif

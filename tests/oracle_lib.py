@@ -235,6 +235,22 @@ def pileup_chunked(stream: bytes, chunk_bytes=16384000, n_threads=2, want_entrie
     return _take(res, want_entries)
 
 
+class _Chunk(C.Structure):
+    _fields_ = [("first", C.c_uint64), ("last", C.c_uint64), ("ref_id", C.c_int32), ("_pad", C.c_int32), ("beg", C.c_uint64), ("end", C.c_uint64)]
+
+
+def chunk_plan(stream: bytes, chunk_bytes=16384000):
+    """[(first, last, ref_id, beg, end)] of the chunks pileupChunks yields pileups for (start_from 0, end_at max)."""
+    f = lib().orc_chunk_plan
+    f.restype = C.c_int64; f.argtypes = [C.c_char_p, C.c_uint64, C.c_uint64, C.POINTER(_Chunk), C.c_uint64]
+    n = f(stream, len(stream), chunk_bytes, None, 0)
+    if n < 0:
+        raise OracleError(int(n))
+    arr = (_Chunk * max(int(n), 1))()
+    f(stream, len(stream), chunk_bytes, arr, n)
+    return [(int(c.first), int(c.last), int(c.ref_id), int(c.beg), int(c.end)) for c in arr[:int(n)]]
+
+
 def pileup_bench(stream, n_threads=1, chunk_bytes=16384000):
     r = _BenchResult()
     if isinstance(stream, np.ndarray):

@@ -14,6 +14,7 @@ from biod_amd.synth import host_stream, host_stream_np, make_cfg, scaled
 
 pytestmark = pytest.mark.gpu
 
+L_ULONG_MAX = (1 << 64) - 1
 FIXTURES = ["ex1_header.bam", "illu_20_chunk.bam", "ion_20_chunk.bam", "b7_295_chunk.bam", "mg1655_chunk.bam", "tags.bam", "bins.bam"]
 
 
@@ -1383,3 +1384,78 @@ def test_full_size_properties(ctx, name):
     st = host_stream(cfg, 0, k)
     stage(ctx, st)
     check_pileup(ctx, st, entries=False)
+
+
+# ---- a14: pileupChunks (splitter.d:35-101, pileup.d:859-1015) ----------------------------------------------------------
+
+def _chunk_columns(chunks, want_refbase=False):
+    """Columns of the chunks, in chunk order: (ref, pos, coverage, n_starting_here, six counts[, reference_base])."""
+    ref, pos, cols, rb = [], [], [], []
+    for ch in chunks:
+        for w in ch.windows():
+            nz = np.nonzero(w.columns["coverage"])[0]
+            ref.append(np.full(len(nz), w.ref_id, np.int64)); pos.append(w.first_position + nz.astype(np.int64)); cols.append(w.columns[nz])
+            if want_refbase:
+                rb.append(w.reference_base[nz])
+            assert ch.start_position <= w.first_position and w.first_position + w.n_positions <= ch.end_position if hasattr(w, "n_positions") else True
+    cat = lambda xs, dt: np.concatenate(xs) if xs else np.zeros(0, dt)
+    return cat(ref, np.int64), cat(pos, np.int64), cat(cols, L.COLUMN_DTYPE), (cat(rb, np.uint8) if want_refbase else None)
+
+
+def _assert_columns_equal_oracle(ref, pos, cols, ora):
+    assert len(pos) == ora.n_columns
+    assert np.array_equal(ref, ora.ref.astype(np.int64)) and np.array_equal(pos, ora.pos.astype(np.int64))
+    assert np.array_equal(cols["coverage"], ora.cov) and np.array_equal(cols["n_starting_here"], ora.nstart)
+    for j, f in enumerate(("a", "c", "g", "t", "other", "del")):
+        assert np.array_equal(cols[f], ora.counts[:, j]), f
+
+
+@pytest.mark.parametrize("block", [20_000, 150_000, 16_384_000])
+def test_pileup_chunks_plan_and_concatenation(ctx, block):
+    """Chunks cut and seamed as BioD does (against the oracle's plan), their columns concatenated == pileupColumns;
+    three references, reads without coverage and unmapped reads (ref_id -1) at the end."""
+    from biod_amd.pileup import pileupChunks
+    cfg = make_cfg(n_reads=9000, n_ref=3, ref_len=40_000, read_len=150, profile=1, seed=31)
+    tail = [bamio.pack_record(f"u{k}", "ACGTACGT", [], ref_id=-1, pos=-1, flag=4) for k in range(40)]
+    st = host_stream(cfg) + b"".join(tail)
+    reads = RecordStream(st, ctx)
+    chunks = pileupChunks(reads, False, block, want_entries=False)
+    plan = O.chunk_plan(st, block)
+    assert [(c.first_record, c.last_record, c.ref_id, c.start_position, c.end_position) for c in chunks] == plan
+    if block < 16_384_000:
+        assert len(chunks) > 6
+    ref, pos, cols, _ = _chunk_columns(chunks)
+    _assert_columns_equal_oracle(ref, pos, cols, O.pileup(st))
+    # any order, any number of times
+    k = len(chunks) // 2
+    a = _chunk_columns([chunks[k]]); b = _chunk_columns([chunks[0]]); c2 = _chunk_columns([chunks[k]])
+    assert np.array_equal(a[1], c2[1]) and np.array_equal(a[2], c2[2]) and (k == 0 or not np.array_equal(a[1], b[1]))
+
+
+@pytest.mark.parametrize("name", ["ex1_header.bam", "b7_295_chunk.bam", "tags.bam"])
+def test_pileup_chunks_fixtures(ctx, data_dir, name):
+    from biod_amd.pileup import pileupChunks
+    _, st = bamio.read_bam(os.path.join(data_dir, name))
+    for block in (30_000, 16_384_000):
+        chunks = pileupChunks(RecordStream(st, ctx), False, block, want_entries=False)
+        assert [(c.first_record, c.last_record, c.ref_id, c.start_position, c.end_position) for c in chunks] == O.chunk_plan(st, block)
+        ref, pos, cols, _ = _chunk_columns(chunks)
+        _assert_columns_equal_oracle(ref, pos, cols, O.pileup(st))
+
+
+def test_pileup_chunks_clipping_and_reference_bases(ctx):
+    """start_from / end_at: the constructor drops leading chunks, later chunks are clipped (pileup.d:878-913); on one
+    reference the concatenation is makePileup(reads, use_md, start_from, end_at).  With use_md_tag every column carries
+    the reference base (consistent MD tags: any provider gives the same base)."""
+    from biod_amd.pileup import pileupChunks
+    cfg = make_cfg(n_reads=6000, n_ref=1, ref_len=60_000, read_len=150, profile=0, seed=8)
+    st = host_stream(cfg)
+    for s, e in ((0, L_ULONG_MAX), (20_000, 41_234), (59_000, L_ULONG_MAX), (100, 101), (70_000, 80_000)):
+        chunks = pileupChunks(RecordStream(st, ctx), True, 40_000, s, e, want_entries=False)
+        ref, pos, cols, rb = _chunk_columns(chunks, want_refbase=True)
+        ora = O.pileup(st, mode=O.MODE_MAKE_PILEUP, use_md=True, start_from=s, end_at=e)
+        _assert_columns_equal_oracle(ref, pos, cols, ora)
+        assert np.array_equal(rb, ora.refbase)
+        for c in chunks:
+            assert c.start_position >= s and c.end_position <= e
+    assert pileupChunks(RecordStream(b"", ctx), False, want_entries=False) == []          # (BioD's constructor would spin here, pileup.d:878-900)
