@@ -47,7 +47,7 @@ constexpr int K4_T = BGP_K4_T;         // threads of a workgroup on the 32-bit l
 constexpr int K4_T16 = BGP_K4_T16;     // ... on the 16-bit layout (two workgroups per CU)
 constexpr int CLS_SHIFT = W == 2048 ? 13 : W == 1024 ? 12 : W == 512 ? 11 : 14;   // log2(bytes of one class array)
 static_assert((1 << CLS_SHIFT) == W * 4, "W must be 512, 1024, 2048 or 4096");
-constexpr uint32_t MAX_RUNS = 1u << 16;
+constexpr uint32_t RUNS_FIRST = 1u << 16;   // entries of the run table to begin with (a stream with more reference runs grows it and repeats K3)
 #ifndef BGP_DEEP_WINDOW
 #define BGP_DEEP_WINDOW 65535
 #endif
@@ -56,7 +56,7 @@ constexpr uint32_t DEEP_WINDOW = BGP_DEEP_WINDOW; // candidate records from whic
 
 struct RunDev { int32_t ref_id; uint32_t pad; uint64_t first_record, end_record, start_pos, end_pos, column_base, tile_base; };
 
-struct K3Args { const bgp_record* rec; uint64_t n; uint64_t* key_end; uint64_t* key_pos; uint32_t* status; /* [3] any long read */ };
+struct K3Args { const bgp_record* rec; uint64_t n; uint64_t* key_end; uint64_t* key_pos; uint32_t* status; /* [3] any long read */ uint32_t run_cap; };
 
 constexpr int FAST_LSEQ = 160;         // reads up to 20 dwords of packed SEQ and 4 CIGAR ops take K4's lane = read path
 __device__ __forceinline__ bool is_long_read(uint32_t n_cig, uint32_t l_seq) { return n_cig > 4 || l_seq > (uint32_t)FAST_LSEQ; }
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(K3_T) void k3_down(K3Args a, const K3Key* bsum, Run
                 if (key[k].p < before.p) atomicOr(&a.status[0], ST_EUNSORTED); // pileup.d:25-27
                 if ((before.p >> 32) != (key[k].p >> 32)) {                    // first read of a reference run, pileup.d:399-424
                     const uint32_t slot = atomicAdd(&a.status[2], 1u);
-                    if (slot < MAX_RUNS) { RunDev rd{}; rd.ref_id = ref[k]; rd.first_record = i; rd.start_pos = (uint64_t)(uint32_t)key[k].p; runs[slot] = rd; }
+                    if (slot < a.run_cap) { RunDev rd{}; rd.ref_id = ref[k]; rd.first_record = i; rd.start_pos = (uint64_t)(uint32_t)key[k].p; runs[slot] = rd; }
                 }
                 any_long |= (flg[k] & 1u) != 0;
             }
@@ -1478,26 +1478,31 @@ int k34_pileup(bgp_ctx* c) {
     if (n == 0) { BGP_HIP(hipStreamSynchronize(c->stream)); c->pinfo.device_depth_hist = c->d_depth_hist.as<uint64_t>(); return BGP_OK; }
     if (n >= (1ull << 32)) return BGP_EINVAL;                  // read_ordinal is 32 bit
     BGP_TRY(c->d_pmax_end.reserve(n * 8)); BGP_TRY(c->d_pmax_pos.reserve(n * 8));
-    BGP_TRY(c->d_runs.reserve(sizeof(RunDev) * MAX_RUNS));
     const unsigned nb = (unsigned)((n + 255) / 256);
     uint32_t* status = c->d_status.as<uint32_t>();
-    {
-        TimedRegion t(c, "k3_keys_scan", n * (32 + 16 + 32));
-        K3Args a{c->d_rec.as<bgp_record>(), n, c->d_pmax_end.as<uint64_t>(), c->d_pmax_pos.as<uint64_t>(), status};
-        const uint64_t nt = (n + K3_TILE - 1) / K3_TILE;
-        BGP_TRY(c->d_scan_tmp.reserve((nt + 2) * sizeof(K3Key)));
-        K3Key* bsum = c->d_scan_tmp.as<K3Key>();
-        hipLaunchKernelGGL(k3_reduce, dim3((unsigned)nt), dim3(K3_T), 0, c->stream, a, bsum);
-        hipLaunchKernelGGL(k3_bsum, dim3(1), dim3(K3_T), 0, c->stream, bsum, nt);
-        hipLaunchKernelGGL(k3_down, dim3((unsigned)nt), dim3(K3_T), 0, c->stream, a, bsum, c->d_runs.as<RunDev>());
-    }
     uint32_t st[4] = {0, 0, 0, 0};
-    BGP_HIP(hipMemcpyAsync(st, status, 16, hipMemcpyDeviceToHost, c->stream));
-    BGP_HIP(hipStreamSynchronize(c->stream));
-    int rc = bgp_status_from_bits(st[0]);
-    if (rc < 0 && rc != BGP_ESEQ) return rc;
+    int rc = BGP_OK;
+    for (uint32_t run_cap = std::max<uint32_t>(RUNS_FIRST, (uint32_t)(c->d_runs.cap / sizeof(RunDev)));;) {
+        BGP_TRY(c->d_runs.reserve(sizeof(RunDev) * (size_t)run_cap));
+        {
+            TimedRegion t(c, "k3_keys_scan", n * (32 + 16 + 32));
+            K3Args a{c->d_rec.as<bgp_record>(), n, c->d_pmax_end.as<uint64_t>(), c->d_pmax_pos.as<uint64_t>(), status, run_cap};
+            const uint64_t nt = (n + K3_TILE - 1) / K3_TILE;
+            BGP_TRY(c->d_scan_tmp.reserve((nt + 2) * sizeof(K3Key)));
+            K3Key* bsum = c->d_scan_tmp.as<K3Key>();
+            hipLaunchKernelGGL(k3_reduce, dim3((unsigned)nt), dim3(K3_T), 0, c->stream, a, bsum);
+            hipLaunchKernelGGL(k3_bsum, dim3(1), dim3(K3_T), 0, c->stream, bsum, nt);
+            hipLaunchKernelGGL(k3_down, dim3((unsigned)nt), dim3(K3_T), 0, c->stream, a, bsum, c->d_runs.as<RunDev>());
+        }
+        BGP_HIP(hipMemcpyAsync(st, status, 16, hipMemcpyDeviceToHost, c->stream));
+        BGP_HIP(hipStreamSynchronize(c->stream));
+        rc = bgp_status_from_bits(st[0]);
+        if (rc < 0 && rc != BGP_ESEQ) return rc;
+        if (st[2] <= run_cap) break;
+        run_cap = st[2] + (st[2] >> 3) + 16;            // more reference runs than the table holds (assemblies with 10^5..10^6 contigs): once more, with room
+        BGP_HIP(hipMemsetAsync(c->d_status.p, 0, 64, c->stream));
+    }
     const uint32_t n_runs = st[2];
-    if (n_runs > MAX_RUNS) { c->last_error = "too many reference runs"; return BGP_EINVAL; }
     std::vector<RunDev> runs(n_runs);
     if (n_runs) BGP_HIP(hipMemcpy(runs.data(), c->d_runs.p, sizeof(RunDev) * n_runs, hipMemcpyDeviceToHost));
     std::sort(runs.begin(), runs.end(), [](const RunDev& x, const RunDev& y) { return x.first_record < y.first_record; });

@@ -1459,3 +1459,13 @@ def test_pileup_chunks_clipping_and_reference_bases(ctx):
         for c in chunks:
             assert c.start_position >= s and c.end_position <= e
     assert pileupChunks(RecordStream(b"", ctx), False, want_entries=False) == []          # (BioD's constructor would spin here, pileup.d:878-900)
+
+
+def test_more_reference_runs_than_the_first_run_table(ctx):
+    """70 000 references with one read each (an assembly of many small contigs): the run table K3 fills starts at
+    65 536 entries and is grown."""
+    recs = [bamio.pack_record(f"r{k}", "ACGTACGTAC", [(10, "M")], ref_id=k, pos=k % 50) for k in range(70_000)]
+    st = b"".join(recs)
+    stage(ctx, st)
+    info, ora = check_pileup(ctx, st, entries=False)
+    assert len(info.runs) == 70_000 and info.n_columns == 700_000
