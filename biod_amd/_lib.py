@@ -13,7 +13,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.environ.get("BIODGPU_SO") or os.path.join(_HERE, "libbiodgpu.so")      # (BIODGPU_SO: A/B builds of the same library for kernel experiments)
 
-BGP_OK, BGP_EOF = 0, 1
+BGP_OK, BGP_EOF, BGP_EAGAIN = 0, 1, 2
 BGP_EINVAL, BGP_ETRUNC, BGP_ECIGAR, BGP_EDEVICE, BGP_ENOMEM, BGP_ESTATE, BGP_EMD, BGP_EUNSORTED, BGP_ESEQ = -1, -2, -3, -4, -5, -6, -7, -8, -9
 BGP_FETCH_SEQ, BGP_FETCH_QUAL, BGP_FETCH_CIGAR, BGP_FETCH_ALL = 1, 2, 4, 7
 BGP_FETCH_STREAM = 8
@@ -89,6 +89,11 @@ SYMBOLS = {
     "bgp_pileup_next_window": (C.c_int, [_P, C.POINTER(Columns)]),
     "bgp_pileup_ref_id": (C.c_int, [_P, C.POINTER(C.c_int32)]),
     "bgp_pileup_snp": (C.c_int, [_P, C.c_int, C.c_int]),
+    "bgp_batch_begin": (C.c_int, [_P, C.c_uint64, C.c_int, C.c_uint32]),
+    "bgp_batch_push": (C.c_int, [_P, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "bgp_batch_end": (C.c_int, [_P]),
+    "bgp_batch_next_window": (C.c_int, [_P, C.POINTER(Columns)]),
+    "bgp_batch_ordinal_base": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
     "bgp_pileup_chunks_begin": (C.c_int, [_P, C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_uint32, C.POINTER(C.c_uint64)]),
     "bgp_pileup_chunk": (C.c_int, [_P, C.c_uint64, C.POINTER(ChunkInfo)]),
     "bgp_read_dna": (C.c_int, [_P, C.c_uint64, C.c_char_p, C.c_uint32, C.POINTER(C.c_uint32)]),

@@ -17,6 +17,20 @@ void bgp_note_hip_error(hipError_t e, const char* what, const char* file, int li
     if (getenv("BGP_VERBOSE")) fprintf(stderr, "[biodgpu] %s\n", buf);
 }
 
+static int fuse_mode() { const char* e = getenv("BGP_FUSE_MODE"); return e ? atoi(e) : 2; }   // 0: chase-based K1, then K2; 1: K1+K2 fused; 2: parallel K1 from the side offsets, then K2
+static int ensure_table(bgp_ctx* c) { return !c->table_pending ? BGP_OK : (fuse_mode() == 0 ? k1_table(c) : k12_fused_decode(c, 0)); }
+
+// framing + record table of the stream c->d_stream points at (bgp_flush after its upload; a batch of batch.cpp)
+int flush_core(bgp_ctx* c) {
+    c->piled = false; c->md_rows_ready = false; c->decoded_what = 0;
+    int rc = k0_frame(c);
+    if (rc < 0) return rc;
+    c->flushed = true;
+    if (fuse_mode() != 1) BGP_TRY(ensure_table(c));      // K1; only the fused experiment (BGP_FUSE_MODE=1) defers it to the decode
+    if (c->region_pending) { BGP_TRY(ensure_table(c)); BGP_TRY(k_region_filter(c, c->region_ref, c->region_beg, c->region_end)); }   // bam[ref][beg..end]
+    return BGP_OK;
+}
+
 int bgp_api_caught(bgp_ctx* c, int status, const char* what) {
     try { if (c) c->last_error = what; else g_last_hip_error = what; } catch (...) { }
     return status;
@@ -58,12 +72,44 @@ void bgp_timing_collect(bgp_ctx* c) {
     }
 }
 
+// columns [a, b) of run `run_idx` copied to the host (ctx-owned buffers), with entries / reference bases / SNP verdicts on request
+int emit_window(bgp_ctx* c, uint32_t run_idx, uint64_t a, uint64_t b, int want_entries, int use_md, int snp, bgp_columns* o) {
+    const bgp_run& r = c->runs[run_idx];
+    const uint64_t np = b - a;
+    BGP_TRY(c->h_cols.reserve(np * sizeof(bgp_column)));
+    BGP_HIP(hipMemcpyAsync(c->h_cols.p, c->d_columns.as<bgp_column>() + r.column_base + (a - r.start_pos), np * sizeof(bgp_column), hipMemcpyDeviceToHost, c->stream));
+    memset(o, 0, sizeof *o);
+    if (want_entries) {
+        uint64_t ne = 0;
+        BGP_TRY(k5_entries(c, run_idx, a, b, &ne));
+        BGP_TRY(c->h_entry_off.reserve((np + 1) * 8)); BGP_TRY(c->h_entries.reserve((ne + 1) * sizeof(bgp_entry)));
+        BGP_HIP(hipMemcpyAsync(c->h_entry_off.p, c->d_entry_off.p, (np + 1) * 8, hipMemcpyDeviceToHost, c->stream));
+        if (ne) BGP_HIP(hipMemcpyAsync(c->h_entries.p, c->d_entries.p, ne * sizeof(bgp_entry), hipMemcpyDeviceToHost, c->stream));
+        o->entry_off = c->h_entry_off.as<uint64_t>(); o->entries = c->h_entries.as<bgp_entry>();
+    }
+    if (use_md) {
+        BGP_TRY(c->h_refbase.reserve(np + 1));
+        BGP_HIP(hipMemcpyAsync(c->h_refbase.p, c->d_refbase.as<uint8_t>() + r.column_base + (a - r.start_pos), np, hipMemcpyDeviceToHost, c->stream));
+        o->reference_base = c->h_refbase.as<uint8_t>();
+    }
+    if (use_md && snp) {
+        BGP_TRY(k7_snp_simple(c, r.column_base + (a - r.start_pos), np, c->it.snp_min_cov, c->it.snp_min_wit));
+        BGP_TRY(c->h_snp.reserve(np + 1));
+        BGP_HIP(hipMemcpyAsync(c->h_snp.p, c->d_snp.p, np, hipMemcpyDeviceToHost, c->stream));
+        o->snp = c->h_snp.as<uint8_t>();
+    }
+    BGP_HIP(hipStreamSynchronize(c->stream));
+    o->ref_id = r.ref_id; o->n_positions = (uint32_t)np; o->first_position = a; o->columns = c->h_cols.as<bgp_column>();
+    return BGP_OK;
+}
+
 extern "C" {
 
 const char* bgp_strerror(int s) {
     switch (s) {
         case BGP_OK: return "ok";
         case BGP_EOF: return "end of iteration";
+        case BGP_EAGAIN: return "more input needed (batched staging)";
         case BGP_EINVAL: return "invalid argument or malformed BAM record";
         case BGP_ETRUNC: return "record runs past the end of the data";
         case BGP_ECIGAR: return "pileup cursor ran off the CIGAR (invalid read)";
@@ -119,6 +165,7 @@ void bgp_destroy(bgp_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    batch_release(c);
     bgp_timing_collect(c);
     release_all(c);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
@@ -141,6 +188,7 @@ int bgp_reset(bgp_ctx* c) {
     BGP_API_TRY
     if (!c) return BGP_EINVAL;
     BGP_HIP(hipStreamSynchronize(c->stream));
+    batch_release(c);
     c->h_stage_len = 0; c->d_stream = nullptr; c->stream_len = 0; c->stream_on_device = false;
     c->flushed = false; c->piled = false; c->md_rows_ready = false; c->table_pending = false; c->n_records = 0; c->decoded_what = 0; c->it = bgp_ctx::Iter();
     c->runs.clear(); c->chunks.clear(); c->chunks_ready = false; c->stage_map.clear(); c->region_pending = false; c->bai_buildable = false; c->cig4_ok = false;
@@ -177,8 +225,6 @@ int bgp_attach_device_stream(bgp_ctx* c, const void* dptr, uint64_t len) {
 //      workgroup cost more than the second read of the stream)
 //   2  k12_fused<no unpack>: one lane per RECORD from the offsets k0_chase left behind, rows written coalesced,
 //      then k2_unpack as before (5.0 + 13.1 ms) -- the default.
-static int fuse_mode() { const char* e = getenv("BGP_FUSE_MODE"); return e ? atoi(e) : 2; }   // 0: chase-based K1, then K2; 1: K1+K2 fused; 2: parallel K1 from the side offsets, then K2
-static int ensure_table(bgp_ctx* c) { return !c->table_pending ? BGP_OK : (fuse_mode() == 0 ? k1_table(c) : k12_fused_decode(c, 0)); }
 
 int bgp_flush(bgp_ctx* c) {
     BGP_API_TRY
@@ -189,13 +235,7 @@ int bgp_flush(bgp_ctx* c) {
         if (c->h_stage_len) BGP_HIP(hipMemcpyAsync(c->d_stream_own.p, c->h_stage.p, c->h_stage_len, hipMemcpyHostToDevice, c->stream));
         c->d_stream = c->d_stream_own.as<uint8_t>(); c->stream_len = c->h_stage_len; c->stream_on_device = true;
     }
-    c->piled = false; c->md_rows_ready = false; c->decoded_what = 0;
-    int rc = k0_frame(c);
-    if (rc < 0) return rc;
-    c->flushed = true;
-    if (fuse_mode() != 1) BGP_TRY(ensure_table(c));      // K1; only the fused experiment (BGP_FUSE_MODE=1) defers it to the decode
-    if (c->region_pending) { BGP_TRY(ensure_table(c)); BGP_TRY(k_region_filter(c, c->region_ref, c->region_beg, c->region_end)); }   // bam[ref][beg..end]
-    return BGP_OK;
+    return flush_core(c);
     BGP_API_CATCH(c)
 }
 
@@ -378,31 +418,7 @@ int bgp_pileup_next_window(bgp_ctx* c, bgp_columns* o) {
             continue;
         }
         const uint64_t a = it.next_pos, b = std::min<uint64_t>(hi, a + it.window);
-        const uint64_t np = b - a;
-        BGP_TRY(c->h_cols.reserve(np * sizeof(bgp_column)));
-        BGP_HIP(hipMemcpyAsync(c->h_cols.p, c->d_columns.as<bgp_column>() + r.column_base + (a - r.start_pos), np * sizeof(bgp_column), hipMemcpyDeviceToHost, c->stream));
-        memset(o, 0, sizeof *o);
-        if (it.want_entries) {
-            uint64_t ne = 0;
-            BGP_TRY(k5_entries(c, it.run, a, b, &ne));
-            BGP_TRY(c->h_entry_off.reserve((np + 1) * 8)); BGP_TRY(c->h_entries.reserve((ne + 1) * sizeof(bgp_entry)));
-            BGP_HIP(hipMemcpyAsync(c->h_entry_off.p, c->d_entry_off.p, (np + 1) * 8, hipMemcpyDeviceToHost, c->stream));
-            if (ne) BGP_HIP(hipMemcpyAsync(c->h_entries.p, c->d_entries.p, ne * sizeof(bgp_entry), hipMemcpyDeviceToHost, c->stream));
-            o->entry_off = c->h_entry_off.as<uint64_t>(); o->entries = c->h_entries.as<bgp_entry>();
-        }
-        if (it.use_md) {
-            BGP_TRY(c->h_refbase.reserve(np + 1));
-            BGP_HIP(hipMemcpyAsync(c->h_refbase.p, c->d_refbase.as<uint8_t>() + r.column_base + (a - r.start_pos), np, hipMemcpyDeviceToHost, c->stream));
-            o->reference_base = c->h_refbase.as<uint8_t>();
-        }
-        if (it.use_md && it.snp) {
-            BGP_TRY(k7_snp_simple(c, r.column_base + (a - r.start_pos), np, it.snp_min_cov, it.snp_min_wit));
-            BGP_TRY(c->h_snp.reserve(np + 1));
-            BGP_HIP(hipMemcpyAsync(c->h_snp.p, c->d_snp.p, np, hipMemcpyDeviceToHost, c->stream));
-            o->snp = c->h_snp.as<uint8_t>();
-        }
-        BGP_HIP(hipStreamSynchronize(c->stream));
-        o->ref_id = r.ref_id; o->n_positions = (uint32_t)np; o->first_position = a; o->columns = c->h_cols.as<bgp_column>();
+        BGP_TRY(emit_window(c, it.run, a, b, it.want_entries, it.use_md, it.use_md && it.snp, o));
         it.next_pos = b;
         return BGP_OK;
     }

@@ -1,0 +1,216 @@
+// batch.cpp -- batched staging: a record stream larger than HBM (or simply arriving over time) piled up a batch at a
+// time, with the reads that overlap the seam carried over (the staging pipeline of the path).
+//
+// Reference shape: BgzfInputStream keeps a bounded ring of decompressed blocks in flight (bio/core/bgzf/inputstream.d:
+// 386-447) and BamReadRange / PileupRange consume them as a stream; nothing of BioD needs the whole file in memory.
+// Here the unit is a BATCH of inflated bytes (any cut points, also inside a record):
+//   * two pinned host buffers take the pushes; a full one goes to HBM with an asynchronous copy on its own stream, to
+//     a FIXED offset of one of two device buffers -- behind an area reserved for the carry -- so the copy can start
+//     while the previous batch is still in its kernels (its carry is not known yet);
+//   * a batch = carry + new bytes is framed (the chain of records may stop in front of a partial record: that tail is
+//     carried too), decoded and piled up like any stream.  K3's prefix maxima then give, exactly, the first read that
+//     still overlaps the position of the batch's LAST covering read (the same halo rule as the windows and the shards):
+//     every column before that position is final and handed out; the reads from that first one on -- a contiguous
+//     suffix of the batch, so record ordinals stay consecutive -- are copied, device to device, in front of the next
+//     batch's bytes;
+//   * the last batch hands out everything.
+// Columns (and per-read entries, with stream-wide read ordinals) are identical to the one-shot result (tested).
+#include "common.h"
+
+#include <algorithm>
+
+struct Batch {
+    uint64_t batch_bytes = 0, reserve = 0;
+    int want_entries = 0; uint32_t window = 65536;
+    HostBuf host[2]; uint64_t host_len[2] = {0, 0}; hipEvent_t host_free[2] = {nullptr, nullptr};
+    int fill = 0;                                       // host buffer taking the pushes
+    DevBuf dev[2]; uint64_t new_off[2] = {0, 0}, new_len[2] = {0, 0}; hipEvent_t loaded_ev[2] = {nullptr, nullptr};
+    enum { FREE, LOADED, CURRENT } state[2] = {FREE, FREE};
+    int queue[2] = {0, 0}; int n_queue = 0;             // loaded device buffers, oldest first
+    hipStream_t copy_stream = nullptr;
+    bool ended = false, any_batch = false;
+    int cur = -1; bool cur_final = false;
+    uint64_t carry_off = 0, carry_len = 0;              // suffix of the current batch's stream the next batch begins with
+    uint64_t ord_base = 0, next_ord_base = 0;           // stream-wide ordinal of the current batch's record 0
+    bool resume = false; int32_t resume_ref = 0; uint64_t resume_pos = 0;      // where handing out stopped before this batch
+    bool cut = false; int32_t cut_ref = 0; uint64_t cut_pos = 0;                // where it stops in this one
+    uint32_t run = 0; uint64_t next_pos = 0; bool run_open = false;
+};
+
+void batch_release(bgp_ctx* c) {
+    Batch* b = c->batch;
+    if (!b) return;
+    if (b->copy_stream) { (void)hipStreamSynchronize(b->copy_stream); (void)hipStreamDestroy(b->copy_stream); }
+    for (int q = 0; q < 2; ++q) {
+        if (b->host_free[q]) (void)hipEventDestroy(b->host_free[q]);
+        if (b->loaded_ev[q]) (void)hipEventDestroy(b->loaded_ev[q]);
+        b->host[q].release(); b->dev[q].release();
+    }
+    delete b;
+    c->batch = nullptr;
+    c->frame_tolerant_tail = false;
+}
+
+// the host buffer that takes the pushes goes to a free device buffer (asynchronous copy); BGP_EAGAIN when both device
+// buffers are taken
+static int ship(bgp_ctx* c, Batch* b) {
+    int q = -1;
+    for (int k = 0; k < 2; ++k) if (b->state[k] == Batch::FREE) { q = k; break; }
+    if (q < 0) return BGP_EAGAIN;
+    const int h = b->fill;
+    BGP_TRY(b->dev[q].reserve(b->reserve + b->batch_bytes + 256));
+    b->new_off[q] = b->reserve; b->new_len[q] = b->host_len[h];
+    if (b->host_len[h]) BGP_HIP(hipMemcpyAsync(b->dev[q].as<uint8_t>() + b->reserve, b->host[h].p, b->host_len[h], hipMemcpyHostToDevice, b->copy_stream));
+    BGP_HIP(hipEventRecord(b->loaded_ev[q], b->copy_stream));
+    BGP_HIP(hipEventRecord(b->host_free[h], b->copy_stream));
+    b->state[q] = Batch::LOADED; b->queue[b->n_queue++] = q;
+    b->host_len[h] = 0;
+    b->fill ^= 1;
+    BGP_HIP(hipEventSynchronize(b->host_free[b->fill]));          // the buffer about to be filled was the source of the copy before last: long done
+    return BGP_OK;
+}
+
+// the oldest loaded batch becomes the current one: carry in front, framing (tolerant of a partial last record unless it
+// is the last batch), record table, pileup, the cut
+static int process_next(bgp_ctx* c, Batch* b) {
+    const int q = b->queue[0];
+    b->queue[0] = b->queue[1]; --b->n_queue;
+    const bool final = b->ended && b->n_queue == 0 && b->host_len[b->fill] == 0;
+    BGP_HIP(hipStreamWaitEvent(c->stream, b->loaded_ev[q], 0));
+    if (b->carry_len > b->new_off[q]) {                              // a carry longer than the room in front of the new bytes: a bigger buffer, once
+        DevBuf bigger;
+        const uint64_t room = b->carry_len + (b->carry_len >> 2) + 256;
+        BGP_TRY(bigger.reserve(room + b->new_len[q] + 256));
+        if (b->new_len[q]) BGP_HIP(hipMemcpyAsync(bigger.as<uint8_t>() + room, b->dev[q].as<uint8_t>() + b->new_off[q], b->new_len[q], hipMemcpyDeviceToDevice, c->stream));
+        BGP_HIP(hipStreamSynchronize(c->stream));
+        b->dev[q].release(); b->dev[q] = bigger; b->new_off[q] = room;
+        b->reserve = std::max(b->reserve, room);
+    }
+    uint8_t* base = b->dev[q].as<uint8_t>() + b->new_off[q] - b->carry_len;
+    if (b->carry_len) BGP_HIP(hipMemcpyAsync(base, c->d_stream + b->carry_off, b->carry_len, hipMemcpyDeviceToDevice, c->stream));
+    if (b->cur >= 0) { BGP_HIP(hipStreamSynchronize(c->stream)); b->state[b->cur] = Batch::FREE; }     // the carry is out: the old batch's buffer can take the next load
+    b->cur = q; b->state[q] = Batch::CURRENT; b->cur_final = final; b->any_batch = true;
+    c->d_stream = base; c->stream_len = b->carry_len + b->new_len[q]; c->stream_on_device = true;
+    c->frame_tolerant_tail = !final;
+    c->cig4_ok = false;
+    BGP_TRY(flush_core(c));
+    BGP_TRY(k34_pileup(c));
+    c->piled = true; c->md_rows_ready = false;
+    b->ord_base = b->next_ord_base;
+    b->cut = false; b->carry_off = c->frame_tail; b->carry_len = c->stream_len - c->frame_tail;
+    b->next_ord_base = b->ord_base + c->n_records;
+    if (!final) {
+        uint64_t last_key = 0, carry_record = 0, carry_off = 0;
+        BGP_TRY(batch_cut(c, &last_key, &carry_record, &carry_off));
+        if (last_key) {                                              // the batch holds a covering read: everything before its position is final
+            b->cut = true; b->cut_ref = c->runs.back().ref_id; b->cut_pos = (uint32_t)last_key;
+            b->carry_off = carry_off; b->carry_len = c->stream_len - carry_off;
+            b->next_ord_base = b->ord_base + carry_record;
+        }
+    } else { b->carry_off = 0; b->carry_len = 0; }
+    b->run = 0; b->run_open = false;
+    return BGP_OK;
+}
+
+extern "C" {
+
+int bgp_batch_begin(bgp_ctx* c, uint64_t batch_bytes, int want_entries, uint32_t window_positions) {
+    BGP_API_TRY
+    if (!c) return BGP_EINVAL;
+    BGP_HIP(hipSetDevice(c->device));
+    BGP_TRY(bgp_reset(c));
+    Batch* b = new Batch();
+    c->batch = b;
+    b->batch_bytes = std::max<uint64_t>(batch_bytes ? batch_bytes : (256ull << 20), 1ull << 12);
+    b->reserve = std::max<uint64_t>(b->batch_bytes / 8, 1ull << 16);         // room for the carry in front of a batch's new bytes (grown when a carry is longer)
+    b->want_entries = want_entries; b->window = window_positions ? window_positions : 65536u;
+    BGP_HIP(hipStreamCreateWithFlags(&b->copy_stream, hipStreamNonBlocking));
+    for (int q = 0; q < 2; ++q) {
+        BGP_HIP(hipEventCreateWithFlags(&b->host_free[q], hipEventDisableTiming)); BGP_HIP(hipEventCreateWithFlags(&b->loaded_ev[q], hipEventDisableTiming));
+        BGP_HIP(hipEventRecord(b->host_free[q], b->copy_stream));
+        BGP_TRY(b->host[q].reserve(b->batch_bytes));
+    }
+    return BGP_OK;
+    BGP_API_CATCH(c)
+}
+
+int bgp_batch_push(bgp_ctx* c, const uint8_t* data, size_t len, size_t* taken) {
+    BGP_API_TRY
+    if (!c || (!data && len) || !taken) return BGP_EINVAL;
+    Batch* b = c->batch;
+    if (!b || b->ended) return BGP_ESTATE;
+    BGP_HIP(hipSetDevice(c->device));
+    *taken = 0;
+    while (*taken < len) {
+        const int h = b->fill;
+        if (b->host_len[h] == b->batch_bytes) { const int rc = ship(c, b); if (rc != BGP_OK) return rc; continue; }
+        const uint64_t n = std::min<uint64_t>(len - *taken, b->batch_bytes - b->host_len[h]);
+        memcpy(b->host[h].as<uint8_t>() + b->host_len[h], data + *taken, n);
+        b->host_len[h] += n; *taken += n;
+    }
+    return BGP_OK;
+    BGP_API_CATCH(c)
+}
+
+int bgp_batch_end(bgp_ctx* c) {
+    BGP_API_TRY
+    if (!c || !c->batch) return BGP_ESTATE;
+    c->batch->ended = true;
+    return BGP_OK;
+    BGP_API_CATCH(c)
+}
+
+int bgp_batch_next_window(bgp_ctx* c, bgp_columns* o) {
+    BGP_API_TRY
+    if (!c || !o) return BGP_EINVAL;
+    Batch* b = c->batch;
+    if (!b) return BGP_ESTATE;
+    BGP_HIP(hipSetDevice(c->device));
+    for (;;) {
+        if (b->cur >= 0) {                                               // hand out the current batch's final columns, run after run
+            while (b->run < c->runs.size()) {
+                const bgp_run& r = c->runs[b->run];
+                uint64_t lo = r.start_pos, hi = r.end_pos;
+                if (b->resume && b->run == 0 && r.ref_id == b->resume_ref) lo = std::max(lo, b->resume_pos);
+                if (b->cut && b->run + 1 == c->runs.size() && r.ref_id == b->cut_ref) hi = std::min(hi, b->cut_pos);
+                if (!b->run_open) { b->next_pos = lo; b->run_open = true; }
+                if (b->next_pos >= hi) { ++b->run; b->run_open = false; continue; }
+                const uint64_t a = b->next_pos, e = std::min(hi, a + b->window);
+                BGP_TRY(emit_window(c, b->run, a, e, b->want_entries, 0, 0, o));
+                if (b->want_entries && b->ord_base) {                    // stream-wide read ordinals
+                    bgp_entry* en = c->h_entries.as<bgp_entry>();
+                    const uint64_t ne = o->entry_off[o->n_positions];
+                    for (uint64_t k = 0; k < ne; ++k) en[k].read_ordinal += (uint32_t)b->ord_base;
+                }
+                b->next_pos = e;
+                return BGP_OK;
+            }
+            if (b->cut) { b->resume = true; b->resume_ref = b->cut_ref; b->resume_pos = b->cut_pos; }      // (a batch without covering reads leaves the mark where it was)
+            if (b->cur_final) return BGP_EOF;
+        }
+        // the next batch
+        if (b->n_queue == 0) {
+            if (!b->ended) return BGP_EAGAIN;                            // push more, or say the stream is over
+            if (b->host_len[b->fill] || !b->any_batch) {                 // what is left in the host buffer is the last batch (an empty stream is one, too)
+                const int rc = ship(c, b);
+                if (rc != BGP_OK) return rc == BGP_EAGAIN ? BGP_ESTATE : rc;
+            } else if (b->cur >= 0 && !b->cur_final) {                   // the stream ended exactly on a batch: what was carried is the last batch
+                const int rc = ship(c, b);
+                if (rc != BGP_OK) return rc == BGP_EAGAIN ? BGP_ESTATE : rc;
+            } else return BGP_EOF;
+        }
+        BGP_TRY(process_next(c, b));
+    }
+    BGP_API_CATCH(c)
+}
+
+/* record ordinal of the current batch's first record in the whole stream (bgp_decode_fetch's tables are per batch) */
+int bgp_batch_ordinal_base(bgp_ctx* c, uint64_t* base) {
+    BGP_API_TRY
+    if (!c || !c->batch || !base) return BGP_ESTATE;
+    *base = c->batch->ord_base;
+    return BGP_OK;
+    BGP_API_CATCH(c)
+}
+
+}  // extern "C"

@@ -118,6 +118,7 @@ struct bgp_ctx {
     DevBuf d_seg_entry, d_seg_end, d_seg_cnt, d_seg_lseq, d_seg_ncig, d_seg_dirty;   // per segment
     DevBuf d_seg_rec_base, d_seg_seq_base, d_seg_cig_base;
     DevBuf d_seg_side; uint32_t side_cap = 0;         // per segment: offsets of its records relative to the segment start (written by k0_chase)
+    bool frame_tolerant_tail = false; uint64_t frame_tail = 0;   // batched staging (batch.cpp): a stream may end inside a record; where the record chain stopped
     bool table_pending = false, long_cigar = false;   // the record table is written lazily: by k1_table, or by the fused K1+K2 if a decode comes first
     DevBuf d_scan_tmp;
     DevBuf d_status;                                  // uint32 status bits + counters
@@ -156,6 +157,9 @@ struct bgp_ctx {
     DevBuf d_md_long, d_md_ck;                                    // long chunks of the provider chain: node list + counters, checkpoints
     DevBuf d_md_succ, d_md_exit, d_md_entry, d_md_bmax;           // parallel provider chain: successor function, per-segment exits, segment entries
     bool md_rows_ready = false;
+
+    // batched staging (batch.cpp): streams larger than HBM, a batch at a time with the overlapping reads carried over
+    struct Batch* batch = nullptr;
 
     // timing
     bool timing = false;
@@ -202,7 +206,11 @@ int inflate_blocks_device(bgp_ctx* c, const uint8_t* d_comp, uint8_t* d_out, con
 int bgzf_load_bam_device(bgp_ctx* c, const char* path);      // bgzf_host.cpp : file -> HBM compressed -> k_inflate
 int bgp_default_threads();                                   // bgzf_host.cpp : affinity mask and cgroup quota applied
 int bai_build(bgp_ctx* c, std::vector<uint8_t>& out);
-int chunks_plan(bgp_ctx* c, uint64_t block_size, uint64_t start_from, uint64_t end_at);   // chunks.hip : fills c->chunks         // bai_build.hip : createIndex over the staged file
+int chunks_plan(bgp_ctx* c, uint64_t block_size, uint64_t start_from, uint64_t end_at);
+int emit_window(bgp_ctx* c, uint32_t run, uint64_t a, uint64_t b, int want_entries, int use_md, int snp, bgp_columns* o);   // api.cpp: columns [a, b) of a run to the host
+int batch_cut(bgp_ctx* c, uint64_t* last_key, uint64_t* carry_record, uint64_t* carry_off);   // pileup.hip: last covering read of the staged stream and where its exact halo starts
+void batch_release(bgp_ctx* c);   // batch.cpp
+int flush_core(bgp_ctx* c);        // api.cpp: K0 + K1 on the stream c->d_stream points at   // chunks.hip : fills c->chunks         // bai_build.hip : createIndex over the staged file
 
 // device helpers shared by kernels
 #if defined(__HIPCC__)

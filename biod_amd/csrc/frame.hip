@@ -30,6 +30,7 @@ struct FrameArgs {
     uint64_t* entry; uint64_t* fix; uint64_t* end; uint64_t* cnt; uint64_t* lseq; uint64_t* ncig; uint32_t* dirty; uint32_t* seg_err;
     uint32_t* status; /* [0] status bits, [1] dirty counter */
     uint32_t* side; uint32_t side_cap;   // side[k * side_cap + j] = offset of segment k's j-th record relative to the segment start
+    int tolerant_tail;                   // batched staging: the data may end inside a record -- the chain stops in front of it instead of ETRUNC
 };
 
 __device__ __forceinline__ bool plausible(const uint8_t* s, uint64_t len, uint64_t o, int32_t ref_bound, uint32_t* bs_out) {
@@ -91,10 +92,10 @@ __global__ __launch_bounds__(256) void k0_chase(FrameArgs a) {
         uint32_t err = 0;
         bool long_seen = false;
         while (off < seg_end) {
-            if (a.len - off < 4) { off = a.len; break; }                       // readrange.d:139-149: short prefix ends the range
+            if (a.len - off < 4) { if (!a.tolerant_tail) off = a.len; break; }  // readrange.d:139-149: short prefix ends the range (a batch keeps it for the next one)
             const int32_t bs = (int32_t)ld_u32(a.s + off);
             if (bs < 0) { err = ST_EINVAL; break; }
-            if ((uint64_t)bs > a.len - off - 4) { err = ST_ETRUNC; break; }    // readrange.d:169
+            if ((uint64_t)bs > a.len - off - 4) { if (!a.tolerant_tail) err = ST_ETRUNC; break; }    // readrange.d:169 (a batch: the rest of the record is still to come)
             if (bs < 32) { err = ST_EINVAL; break; }
             uint32_t f3[3]; __builtin_memcpy(f3, a.s + off + 12, 12);            // bin_mq_nl, flag_nc, l_seq in one load (bs >= 32: in bounds)
             const uint32_t bmn = f3[0], fnc = f3[1];
@@ -229,6 +230,7 @@ int k0_frame(bgp_ctx* c) {
         BGP_HIP(hipMemsetAsync(c->d_cigar_off.p, 0, 8, c->stream));
         BGP_HIP(hipStreamSynchronize(c->stream));
         c->table_pending = false; c->long_cigar = false;
+        c->frame_tail = c->frame_tolerant_tail ? 0 : len;      // (a batch keeps the few bytes for the next one)
         return BGP_OK;
     }
     // segment size: ~8 average records, from the first record's size (any value is correct)
@@ -255,6 +257,7 @@ int k0_frame(bgp_ctx* c) {
     FrameArgs a;
     a.s = c->d_stream; a.len = len; a.seg_bytes = seg; a.n_seg = n_seg;
     a.ref_bound = c->n_ref_hint > 0 ? c->n_ref_hint : (1 << 24);
+    a.tolerant_tail = c->frame_tolerant_tail ? 1 : 0;
     a.entry = c->d_seg_entry.as<uint64_t>(); a.fix = a.entry + n_seg + 1; a.end = c->d_seg_end.as<uint64_t>();
     a.cnt = c->d_seg_cnt.as<uint64_t>(); a.lseq = c->d_seg_lseq.as<uint64_t>(); a.ncig = c->d_seg_ncig.as<uint64_t>();
     a.dirty = c->d_seg_dirty.as<uint32_t>(); a.seg_err = a.dirty + n_seg;
@@ -300,6 +303,12 @@ int k0_frame(bgp_ctx* c) {
     BGP_TRY(scan_exclusive_u64(c, a.lseq, c->d_seg_seq_base.as<uint64_t>(), n_seg, &sl));
     BGP_TRY(scan_exclusive_u64(c, a.ncig, c->d_seg_cig_base.as<uint64_t>(), n_seg, &sc));
     c->n_records = n; c->sum_lseq = sl; c->sum_ncig = sc;
+    c->frame_tail = len;
+    if (c->frame_tolerant_tail) {                     // where the chain of records stopped: the bytes behind it belong to the next batch
+        BGP_HIP(hipMemcpyAsync(&c->frame_tail, a.end + (n_seg - 1), 8, hipMemcpyDeviceToHost, c->stream));
+        BGP_HIP(hipStreamSynchronize(c->stream));
+        if (c->frame_tail > len) c->frame_tail = len;
+    }
 
     c->long_cigar = (bits & ST_LONGCIG) != 0;
     c->table_pending = true;             // the record table is written by whoever needs it first: k1_table, or the fused K1+K2 when a decode follows

@@ -1646,6 +1646,31 @@ __global__ void k_first_survivor(const uint64_t* pmax_end, const bgp_record* rec
 }
 }  // namespace
 
+namespace {
+__global__ void k_batch_cut(const uint64_t* pmax_end, const uint64_t* pmax_pos, const bgp_record* rec, uint64_t n, uint64_t first, uint64_t end, uint64_t* out) {
+    const uint64_t key = pmax_pos[n - 1];                        // (reference key << 32 | position) of the last covering read; 0: none
+    uint64_t lo = first, hi = end;
+    if (key) { while (lo < hi) { const uint64_t m = (lo + hi) >> 1; if (pmax_end[m] > key) hi = m; else lo = m + 1; } }
+    out[0] = key; out[1] = lo; out[2] = key && lo < end ? rec[lo].rec_off : 0;
+}
+}  // namespace
+
+// batched staging: the position of the stream's last covering read and the first record of its run whose running maximum
+// of end_position exceeds it -- the exact halo of that position: every column before it is final, every read that
+// matters from there on comes at or after that record
+int batch_cut(bgp_ctx* c, uint64_t* last_key, uint64_t* carry_record, uint64_t* carry_off) {
+    *last_key = 0; *carry_record = 0; *carry_off = 0;
+    if (c->runs.empty() || !c->n_records) return BGP_OK;
+    const bgp_run& r = c->runs.back();
+    uint64_t* out = c->d_pstats.as<uint64_t>() + 8;
+    hipLaunchKernelGGL(k_batch_cut, dim3(1), dim3(1), 0, c->stream, c->d_pmax_end.as<uint64_t>(), c->d_pmax_pos.as<uint64_t>(), c->d_rec.as<bgp_record>(), c->n_records, r.first_record, r.end_record, out);
+    uint64_t h[3] = {0, 0, 0};
+    BGP_HIP(hipMemcpyAsync(h, out, 24, hipMemcpyDeviceToHost, c->stream));
+    BGP_HIP(hipStreamSynchronize(c->stream));
+    *last_key = h[0]; *carry_record = h[1]; *carry_off = h[2];
+    return BGP_OK;
+}
+
 // position of the first read of run `run_idx` with position + basesCovered >= start_from (pileup.d:482-489)
 int k34_first_survivor(bgp_ctx* c, uint32_t run_idx, uint64_t start_from, uint64_t* pos, uint64_t* record) {
     const bgp_run& r = c->runs[run_idx];

@@ -175,6 +175,52 @@ class Context:
         self.pileup_chunk(k)
         yield from self._windows(None)
 
+    # -- batched staging (streams larger than HBM): include/biodgpu.h, bgp_batch_*
+    def batch_begin(self, batch_bytes: int = 0, want_entries: bool = False, window_positions: int = 0):
+        L.check(L.lib().bgp_batch_begin(self._h, batch_bytes, int(want_entries), window_positions), self._h)
+
+    def batch_push(self, data) -> tuple:
+        """Returns (bytes taken, status): status BGP_EAGAIN = hand out windows first, then push the rest."""
+        mv = memoryview(data)
+        buf = (C.c_char * len(mv)).from_buffer_copy(mv) if len(mv) else None
+        taken = C.c_size_t()
+        rc = L.check(L.lib().bgp_batch_push(self._h, buf, len(mv), C.byref(taken)), self._h)
+        return int(taken.value), rc
+
+    def batch_end(self):
+        L.check(L.lib().bgp_batch_end(self._h), self._h)
+
+    def batch_ordinal_base(self) -> int:
+        n = C.c_uint64()
+        L.check(L.lib().bgp_batch_ordinal_base(self._h, C.byref(n)), self._h)
+        return int(n.value)
+
+    def batch_drain(self):
+        """Windows of final columns until the library wants more input (or, after batch_end, until the stream is done)."""
+        while True:
+            cw = L.Columns()
+            rc = L.check(L.lib().bgp_batch_next_window(self._h, C.byref(cw)), self._h)
+            if rc != L.BGP_OK:
+                return
+            cols = L.as_array(cw.columns, cw.n_positions, L.COLUMN_DTYPE)
+            eoff = L.as_array(cw.entry_off, cw.n_positions + 1, "<u8") if cw.entry_off else None
+            ents = L.as_array(cw.entries, int(eoff[-1]), L.ENTRY_DTYPE) if eoff is not None else None
+            yield Window(cw.ref_id, cw.first_position, cols, eoff, ents, None)
+
+    def batched_windows(self, pieces, batch_bytes: int = 0, want_entries: bool = False, window_positions: int = 0):
+        """pileupColumns over a stream handed over piece by piece (any cut points): dense windows of final columns."""
+        self.batch_begin(batch_bytes, want_entries, window_positions)
+        for piece in pieces:
+            mv = memoryview(piece)
+            off = 0
+            while off < len(mv):
+                taken, rc = self.batch_push(mv[off:])
+                off += taken
+                if rc == L.BGP_EAGAIN:
+                    yield from self.batch_drain()
+        self.batch_end()
+        yield from self.batch_drain()
+
     def _windows(self, snp):
         while True:
             cw = L.Columns()

@@ -38,6 +38,58 @@ def strong_cfg(name: str, total_reads: int, rank: int, world: int) -> L.SynthCfg
                     profile=whole.profile, seed=whole.seed, first_ref=first)
 
 
+def plan_interval_shards(ref_id: np.ndarray, pos: np.ndarray, end_pos: np.ndarray, rec_off: np.ndarray, stream_len: int, world: int):
+    """Equal-read-count shards INSIDE contigs, with the exact halo ("refinement for balance").
+
+    Shard r owns the records [cut[r], cut[r+1]) -- cuts at multiples of n / world, moved forward to the first record
+    of a position group so that reads starting at one position stay together -- and hands out the columns from the
+    (ref, position) of its first read up to the (ref, position) of the next shard's first read.  The reads it needs are
+    its own plus every earlier read of the same reference whose end_position exceeds the shard's first position: the
+    first record whose running maximum of end_position does (the rule the windows of K4 and the batches use; BioD's own
+    rule, pileup.d:944-985, keeps reads that start within twice a sampled read length and is not exact).  That set is a
+    contiguous range of records, so a shard is a byte range of the stream plus a clip.
+
+    Returns a list of dicts: byte_lo, byte_hi (the sub-stream), first_record (ordinal of its record 0), lo, hi
+    ((ref_key, position) keys: keep columns with lo <= key < hi; ref_key = ref_id as unsigned, unmapped last)."""
+    n = len(pos)
+    key = (np.where(ref_id < 0, 0x7FFFFFFF, ref_id.astype(np.int64) + 1) << 32) | (pos.astype(np.int64) & 0xFFFFFFFF)
+    covering = end_pos != pos
+    cuts = [0]
+    for r in range(1, world):
+        c = min(max(r * n // world, cuts[-1]), n)
+        while c < n and (not covering[c] or (c > 0 and key[c] == key[c - 1])):       # a shard starts with the first read of a position group, a covering one
+            c += 1
+        cuts.append(c)
+    cuts.append(n)
+    ends = np.append(rec_off[1:], stream_len).astype(np.int64) if n else np.zeros(0, np.int64)
+    shards = []
+    top = (0x7FFFFFFF + 1) << 32
+    for r in range(world):
+        a, b = cuts[r], cuts[r + 1]
+        if a >= b:
+            shards.append(dict(byte_lo=0, byte_hi=0, first_record=a, lo=top, hi=top))
+            continue
+        lo_key = int(key[a]) if r > 0 else 0
+        hi_key = int(key[b]) if b < n else top
+        i_lo = a
+        if r > 0:
+            same = np.nonzero(ref_id[:a] == ref_id[a])[0]                       # earlier records of the shard's first reference
+            if len(same):
+                f = int(same[0])
+                run_max = np.maximum.accumulate(np.where(covering[f:a], end_pos[f:a], np.iinfo(np.int32).min).astype(np.int64))
+                hit = np.nonzero(run_max > int(pos[a]))[0]
+                if len(hit):
+                    i_lo = f + int(hit[0])
+        shards.append(dict(byte_lo=int(rec_off[i_lo]), byte_hi=int(ends[b - 1]), first_record=i_lo, lo=lo_key, hi=hi_key))
+    return shards
+
+
+def clip_columns(ref: np.ndarray, pos: np.ndarray, lo: int, hi: int) -> np.ndarray:
+    """Mask of the columns (ref, pos) a shard of plan_interval_shards hands out."""
+    key = (np.where(ref < 0, 0x7FFFFFFF, ref.astype(np.int64) + 1) << 32) | (pos.astype(np.int64) & 0xFFFFFFFF)
+    return (key >= lo) & (key < hi)
+
+
 def depth_histogram(coverage: np.ndarray) -> np.ndarray:
     """hist[d] = number of positions with coverage d (d clipped to DEPTH_BINS-1), as the device computes it."""
     return np.bincount(np.minimum(coverage.astype(np.int64), DEPTH_BINS - 1), minlength=DEPTH_BINS).astype(np.int64)

@@ -42,7 +42,8 @@ enum {
     BGP_EUNSORTED = -8, /* reads not coordinate sorted -- precondition of makePileup, pileup.d:25-27 */
     BGP_ESEQ = -9,      /* soft: a query offset ran past l_seq (RangeError in read.d:364-383);
                            results are still produced, such bases counted as "other"                 */
-    BGP_EOF = 1         /* iteration finished                                                        */
+    BGP_EOF = 1,        /* iteration finished                                                        */
+    BGP_EAGAIN = 2      /* batched staging: push more input / hand out windows first                 */
 };
 
 typedef struct bgp_ctx bgp_ctx;
@@ -201,6 +202,25 @@ int bgp_pileup_begin(bgp_ctx* ctx, int mode, int use_md_tag, uint64_t start_from
                      int skip_zero_coverage, int want_entries, uint32_t window_positions);
 int bgp_pileup_next_window(bgp_ctx* ctx, bgp_columns* out);   /* BGP_OK, BGP_EOF, or error */
 int bgp_pileup_ref_id(bgp_ctx* ctx, int32_t* ref_id);          /* AbstractPileup.ref_id, pileup.d:455 */
+
+/* ---- batched staging: streams larger than HBM, or arriving over time ---------------------------------------------
+ * The shape of BgzfInputStream's bounded ring of blocks in flight (inputstream.d:386-447) under pileupColumns(reads)
+ * (pileup.d:509-519; use_md_tag = false): push inflated record bytes in file order with any cut points, take dense
+ * windows of FINAL columns out as they become final.  A batch (batch_bytes of input, 0 = 256 MiB) is copied to HBM
+ * while the previous one is still in its kernels (two pinned host buffers, two device buffers, a copy stream of its
+ * own); the reads that still overlap the position of a batch's last covering read -- found exactly, with the prefix
+ * maxima of K3 -- and a partial last record are carried over to the next batch on the device.  Columns and entries
+ * (read_ordinal counts over the whole stream) are identical to staging everything at once.
+ *   bgp_batch_push         BGP_OK (all bytes taken) or BGP_EAGAIN with *taken < len: both batches in flight are waiting
+ *                          to be handed out -- call bgp_batch_next_window until it says BGP_EAGAIN, push the rest
+ *   bgp_batch_next_window  BGP_OK (a window), BGP_EAGAIN (push more or bgp_batch_end), BGP_EOF (after bgp_batch_end)
+ * Between windows the ctx describes the CURRENT batch: bgp_decode_fetch etc. see its records; bgp_batch_ordinal_base
+ * gives the stream-wide ordinal of its record 0.  bgp_reset leaves the mode. */
+int bgp_batch_begin(bgp_ctx* ctx, uint64_t batch_bytes, int want_entries, uint32_t window_positions);
+int bgp_batch_push(bgp_ctx* ctx, const uint8_t* data, size_t len, size_t* taken);
+int bgp_batch_end(bgp_ctx* ctx);
+int bgp_batch_next_window(bgp_ctx* ctx, bgp_columns* out);
+int bgp_batch_ordinal_base(bgp_ctx* ctx, uint64_t* base);
 
 /* pileupChunks(reads, use_md_tag, block_size = 16_384_000, start_from = 0, end_at = ulong.max), pileup.d:1011-1015:
  * consecutive non-overlapping pileups a caller maps over in parallel.  The chunks are cut exactly as

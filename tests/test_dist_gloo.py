@@ -11,7 +11,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 import oracle_lib as O
-from biod_amd.shard import allreduce_histogram, depth_histogram, strong_cfg, weak_cfg
+from biod_amd.shard import allreduce_histogram, clip_columns, depth_histogram, plan_interval_shards, strong_cfg, weak_cfg
 from biod_amd.synth import host_stream, scaled
 
 
@@ -61,3 +61,40 @@ def test_two_rank_histogram_reduce_matches_single_process(tmp_path):
     assert list(r0[65536:65539]) == [p.n_columns, p.sum_coverage, int((p.cov > 0).sum())]
     assert r0[65539] == 2                                    # max over ranks of the timings
     assert r0[-1] + r1[-1] == len(whole)
+
+
+def _interval_worker(rank, world, port, n_reads, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    st = host_stream(scaled("cfg3", n_reads))                 # (every rank can make the stream: records are functions of their index)
+    soa = O.decode_soa(st)
+    sh = plan_interval_shards(soa.ref_id, soa.pos, soa.end_pos, soa.rec_off, len(st), world)[rank]
+    p = O.pileup(st[sh["byte_lo"]:sh["byte_hi"]])
+    keep = clip_columns(p.ref, p.pos, sh["lo"], sh["hi"])
+    np.savez(os.path.join(out_dir, f"s{rank}.npz"), ref=p.ref[keep], pos=p.pos[keep], cov=p.cov[keep], nstart=p.nstart[keep], counts=p.counts[keep])
+    hist = torch.from_numpy(depth_histogram(p.cov[keep]))
+    allreduce_histogram(hist)
+    np.save(os.path.join(out_dir, f"h{rank}.npy"), hist.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("world", [2, 3])
+def test_contig_split_by_interval_with_exact_halo(tmp_path, world):
+    """SURVEY 8(e), refinement for balance: the contigs of one BAM cut into equal-read-count intervals (cuts fall INSIDE
+    contigs), every rank piles up its interval plus the exact halo and keeps its own columns; the ranks' columns
+    concatenate to the serial result -- n_starting_here and N-skip reads reaching across cuts included -- and the
+    reduced depth histogram is the serial one's."""
+    n = 9_000
+    port = _free_port()
+    mp.spawn(_interval_worker, args=(world, port, n, str(tmp_path)), nprocs=world, join=True)
+    st = host_stream(scaled("cfg3", n))
+    p = O.pileup(st)
+    parts = [np.load(tmp_path / f"s{r}.npz") for r in range(world)]
+    for f in ("ref", "pos", "cov", "nstart", "counts"):
+        assert np.array_equal(np.concatenate([q[f] for q in parts]), getattr(p, f)), f
+    assert all(len(q["pos"]) > 0 for q in parts)
+    h = depth_histogram(p.cov); h[0] = 0
+    got = np.load(tmp_path / "h0.npy"); got[0] = 0
+    assert np.array_equal(got, h)

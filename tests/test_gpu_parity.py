@@ -1397,7 +1397,7 @@ def _chunk_columns(chunks, want_refbase=False):
             ref.append(np.full(len(nz), w.ref_id, np.int64)); pos.append(w.first_position + nz.astype(np.int64)); cols.append(w.columns[nz])
             if want_refbase:
                 rb.append(w.reference_base[nz])
-            assert ch.start_position <= w.first_position and w.first_position + w.n_positions <= ch.end_position if hasattr(w, "n_positions") else True
+            assert ch.start_position <= w.first_position and w.first_position + len(w.columns) <= ch.end_position
     cat = lambda xs, dt: np.concatenate(xs) if xs else np.zeros(0, dt)
     return cat(ref, np.int64), cat(pos, np.int64), cat(cols, L.COLUMN_DTYPE), (cat(rb, np.uint8) if want_refbase else None)
 
@@ -1469,3 +1469,112 @@ def test_more_reference_runs_than_the_first_run_table(ctx):
     stage(ctx, st)
     info, ora = check_pileup(ctx, st, entries=False)
     assert len(info.runs) == 70_000 and info.n_columns == 700_000
+
+
+# ---- batched staging with carry-over (bgp_batch_*): a stream in several batches == the stream at once == the oracle ----
+
+def _covered(windows, want_entries=False):
+    ref, pos, cols, ents, npos = [], [], [], [], 0
+    for w in windows:
+        nz = np.nonzero(w.columns["coverage"])[0]
+        ref.append(np.full(len(nz), w.ref_id, np.int64)); pos.append(w.first_position + nz.astype(np.int64)); cols.append(w.columns[nz])
+        npos += len(w.columns)
+        if want_entries:
+            for j in nz:
+                ents.append(w.entries[int(w.entry_off[j]):int(w.entry_off[j + 1])])
+    cat = lambda xs, dt: np.concatenate(xs) if xs else np.zeros(0, dt)
+    return cat(ref, np.int64), cat(pos, np.int64), cat(cols, L.COLUMN_DTYPE), ents, npos
+
+
+def _pieces(st, size):
+    return [st[o:o + size] for o in range(0, len(st), size)] or [b""]
+
+
+@pytest.mark.parametrize("name,batch", [("ex1_header.bam", 150_000), ("b7_295_chunk.bam", 40_000), ("bins.bam", 30_000)])
+def test_batched_staging_fixtures(ctx, data_dir, name, batch):
+    _, st = bamio.read_bam(os.path.join(data_dir, name))
+    assert len(st) > 3 * batch
+    ref, pos, cols, _, npos = _covered(ctx.batched_windows(_pieces(st, 7777), batch))
+    ora = O.pileup(st)
+    if name != "bins.bam":
+        _assert_columns_equal_oracle(ref, pos, cols, ora)
+    else:                                               # empty SEQ: coverage only (test_bins_bam_coverage_parity)
+        assert np.array_equal(pos, ora.pos.astype(np.int64)) and np.array_equal(cols["coverage"], ora.cov) and np.array_equal(cols["n_starting_here"], ora.nstart)
+    stage(ctx, st)
+    assert npos == ctx.pileup_run().n_positions        # the zero-coverage positions inside the runs are handed out too, once
+
+
+def test_batched_staging_200k_reads_in_batches(ctx):
+    """200 000 reads of cfg3's model (58 MB) in 16 MiB batches: columns == the stream staged at once, and == the oracle
+    on a prefix; cut points of the pushes fall anywhere, also inside records."""
+    cfg = scaled("cfg3", 200_000)
+    st = host_stream_np(cfg)
+    batch = 16 << 20
+    assert len(st) > 3 * batch
+    ref, pos, cols, _, npos = _covered(ctx.batched_windows(_pieces(st, 5_000_003), batch))
+    ctx.reset(); ctx.push_inflated(st.tobytes()); ctx.flush()
+    info = ctx.pileup_run()
+    dense = device_columns(ctx, info)
+    assert npos == info.n_positions == len(dense)
+    nz = np.nonzero(dense["coverage"])[0]
+    assert len(nz) == len(pos) == info.n_columns
+    for f in L.COLUMN_DTYPE.names:
+        assert np.array_equal(cols[f], dense[f][nz]), f
+    k = 30_000
+    pre = host_stream(cfg, 0, k)
+    ora = O.pileup(pre)
+    last = int(ora.pos[-1]) - 400                       # columns the rest of the stream cannot touch
+    m = (ora.ref == 0) & (ora.pos < last)
+    assert m.sum() > 1000 and np.array_equal(cols["coverage"][:m.sum()], ora.cov[m]) and np.array_equal(pos[:m.sum()], ora.pos[m].astype(np.int64))
+
+
+@pytest.mark.parametrize("batch", [4096, 9000, 70_000])
+def test_batched_staging_entries_and_small_batches(ctx, batch):
+    """Batches of a few dozen records, N-skip reads reaching across several of them, per-read entries with stream-wide
+    ordinals; a batch size the stream length is a multiple of (the stream ends exactly on a batch)."""
+    cfg = make_cfg(n_reads=1500, n_ref=2, ref_len=9_000, read_len=100, profile=1, seed=13)
+    st = host_stream(cfg)
+    ora = O.pileup(st, want_entries=True)
+    ref, pos, cols, ents, _ = _covered(ctx.batched_windows(_pieces(st, 1013), batch, want_entries=True, window_positions=700), want_entries=True)
+    _assert_columns_equal_oracle(ref, pos, cols, ora)
+    assert len(ents) == ora.n_columns
+    for k in range(0, ora.n_columns, 7):
+        oe = ora.entries[int(ora.entry_off[k]):int(ora.entry_off[k + 1])]
+        assert np.array_equal(ents[k]["read_ordinal"], oe["read_ordinal"].astype(np.uint32)), k
+        assert np.array_equal(ents[k]["query_offset"], oe["query_offset"]) and np.array_equal(ents[k]["base"], oe["base"]) and np.array_equal(ents[k]["qual"], oe["qual"])
+
+
+def test_batched_staging_edges(ctx):
+    """Empty stream; a stream of exactly two batches; records larger than a batch (the carry outgrows its reserve);
+    reads without coverage and unmapped reads at the end; a truncated last record is an error, as it is at once."""
+    assert list(ctx.batched_windows([b""], 4096)) == []
+    cfg = make_cfg(n_reads=400, n_ref=1, ref_len=5_000, read_len=150, profile=0, seed=2)
+    st = host_stream(cfg)
+    ref, pos, cols, _, _ = _covered(ctx.batched_windows([st], max(4096, -(-len(st) // 2))))      # exactly two batches: the stream ends on a batch
+    _assert_columns_equal_oracle(ref, pos, cols, O.pileup(st))
+    rng = np.random.default_rng(5)
+    big = [bamio.pack_record(f"L{k}", "".join("ACGT"[int(x)] for x in rng.integers(0, 4, 90_000)), [(90_000, "M")], ref_id=0, pos=10 + 500 * k) for k in range(4)]
+    tail = [bamio.pack_record("nocov", "ACGT", [(4, "S")], ref_id=0, pos=2600), bamio.pack_record("u", "ACGT", [], ref_id=-1, pos=-1, flag=4)]
+    st2 = b"".join(big + tail)
+    ref, pos, cols, _, _ = _covered(ctx.batched_windows(_pieces(st2, 30_011), 65_536))
+    _assert_columns_equal_oracle(ref, pos, cols, O.pileup(st2))
+    with pytest.raises(L.BiodGpuError) as e:
+        list(ctx.batched_windows([st[:-7]], 20_000))
+    assert e.value.code == L.BGP_ETRUNC
+
+
+def test_interval_shards_with_exact_halo_on_the_device(ctx):
+    """plan_interval_shards: three equal-read-count shards of a two-contig stream, each piled up on the
+    device from its byte range (own reads + exact halo) and clipped; concatenation == oracle on the whole stream."""
+    from biod_amd.shard import clip_columns, plan_interval_shards
+    cfg = make_cfg(n_reads=6000, n_ref=2, ref_len=40_000, read_len=150, profile=1, seed=41)
+    st = host_stream(cfg)
+    soa = O.decode_soa(st)
+    parts = []
+    for sh in plan_interval_shards(soa.ref_id, soa.pos, soa.end_pos, soa.rec_off, len(st), 3):
+        stage(ctx, st[sh["byte_lo"]:sh["byte_hi"]])
+        assert sh["byte_lo"] == int(soa.rec_off[sh["first_record"]])
+        ref, pos, cols, _, _ = _covered(ctx.pileup_windows(L.BGP_PILEUP_COLUMNS, skip_zero_coverage=False, window_positions=1 << 20))
+        keep = clip_columns(ref, pos, sh["lo"], sh["hi"])
+        parts.append((ref[keep], pos[keep], cols[keep]))
+    _assert_columns_equal_oracle(np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts]), np.concatenate([p[2] for p in parts]), O.pileup(st))
