@@ -139,6 +139,7 @@ struct bgp_ctx {
     DevBuf d_runs, d_columns, d_depth_hist, d_pstats, d_tiles, d_ck_off, d_ck, d_deep;
     DevBuf d_slab, d_wcount, d_wdel, d_wslow;        // K4 plan: per-window descriptor slabs, counts, whole-window '-' levels, slow-read marks
     std::vector<bgp_run> runs;
+    uint32_t ck_w = 0;                                // window width the long-read checkpoints (d_ck_off / d_ck) were built for; 0: none
     bgp_pileup_info pinfo{};
     bool piled = false;
 

@@ -41,12 +41,13 @@ namespace {
 #define BGP_K4_T16 512
 #define BGP_K4_HB 512
 #endif
-constexpr int W = BGP_K4_W;            // reference positions per workgroup (power of two)
+constexpr int W = BGP_K4_W;            // reference positions per window of the gather path (k4_plan / k4_exec), power of two
+constexpr int WO = 4096;               // ... of the general kernel when a stream is left to it entirely (long reads): the biggest window LDS holds wins there
 constexpr int HB = BGP_K4_HB;          // depth-histogram bins kept in LDS
 constexpr int K4_T = BGP_K4_T;         // threads of a workgroup on the 32-bit layout
 constexpr int K4_T16 = BGP_K4_T16;     // ... on the 16-bit layout (two workgroups per CU)
-constexpr int CLS_SHIFT = W == 2048 ? 13 : W == 1024 ? 12 : W == 512 ? 11 : 14;   // log2(bytes of one class array)
-static_assert((1 << CLS_SHIFT) == W * 4, "W must be 512, 1024, 2048 or 4096");
+constexpr int cls_shift_of(int w) { return w == 4096 ? 14 : w == 2048 ? 13 : w == 1024 ? 12 : w == 512 ? 11 : -1; }   // log2(bytes of one class array)
+static_assert(cls_shift_of(W) > 0 && cls_shift_of(WO) > 0, "windows must be 512, 1024, 2048 or 4096 positions");
 constexpr uint32_t RUNS_FIRST = 1u << 16;   // entries of the run table to begin with (a stream with more reference runs grows it and repeats K3)
 #ifndef BGP_DEEP_WINDOW
 #define BGP_DEEP_WINDOW 65535
@@ -165,7 +166,7 @@ __global__ __launch_bounds__(K3_T) void k3_down(K3Args a, const K3Key* bsum, Run
     __syncthreads();
     K3Key carry = bsum[blockIdx.x];
     for (int k = 0; k < w; ++k) carry = k3_max(carry, lds[k]);
-    bool any_long = false;
+    uint32_t n_long = 0;                                                   // long covering reads of this wave (wave-uniform)
 #pragma unroll
     for (int k = 0; k < K3_ITEMS; ++k) {
         const uint64_t i = wbase + (uint64_t)k * 64;
@@ -173,6 +174,7 @@ __global__ __launch_bounds__(K3_T) void k3_down(K3Args a, const K3Key* bsum, Run
         K3Key before; before.e = __shfl_up(inc.e, 1, 64); before.p = __shfl_up(inc.p, 1, 64);
         if (lane == 0) before = K3Key{0, 0};
         before = k3_max(before, carry);                                       // maxima over every record before record i
+        n_long += (uint32_t)__popcll(__ballot(i < a.n && key[k].p && (flg[k] & 1u)));
         if (i < a.n) {
             if (key[k].p) {                                                   // a covering read
                 if (flg[k] & 2u) atomicOr(&a.status[0], ST_EINVAL);
@@ -181,7 +183,6 @@ __global__ __launch_bounds__(K3_T) void k3_down(K3Args a, const K3Key* bsum, Run
                     const uint32_t slot = atomicAdd(&a.status[2], 1u);
                     if (slot < a.run_cap) { RunDev rd{}; rd.ref_id = ref[k]; rd.first_record = i; rd.start_pos = (uint64_t)(uint32_t)key[k].p; runs[slot] = rd; }
                 }
-                any_long |= (flg[k] & 1u) != 0;
             }
             const K3Key out = k3_max(before, key[k]);
             a.key_end[i] = out.e; a.key_pos[i] = out.p;
@@ -189,7 +190,7 @@ __global__ __launch_bounds__(K3_T) void k3_down(K3Args a, const K3Key* bsum, Run
         K3Key last; last.e = __shfl(inc.e, 63, 64); last.p = __shfl(inc.p, 63, 64);
         carry = k3_max(carry, last);
     }
-    if (__ballot(any_long) && lane == 0) atomicOr(&a.status[3], 1u);
+    if (n_long && lane == 0) atomicAdd(&a.status[3], n_long);                 // [3]: long covering reads of the stream
 }
 
 __global__ void k3_run_ends(RunDev* runs, uint32_t n_runs, const uint64_t* pmax_end, uint64_t n) {
@@ -220,14 +221,14 @@ __device__ __forceinline__ uint32_t base_class(uint32_t code) {   // nt16 code -
 // One thread per window: the record range that can touch it (exact halo).  Done here, massively
 // parallel, because the two ~25-step dependent binary searches are pure latency.
 struct TileB { uint64_t i_lo, i_hi, col_out; uint32_t T0, Tend, run_start, pad; };   // everything a window needs in one 40-byte (scalar) load; pad = 1: deep window
-__global__ __launch_bounds__(256) void k4_bounds(const uint64_t* pmax_end, const uint64_t* pmax_pos, const RunDev* runs, uint32_t n_runs, uint64_t n_tiles, TileB* out) {
+__global__ __launch_bounds__(256) void k4_bounds(const uint64_t* pmax_end, const uint64_t* pmax_pos, const RunDev* runs, uint32_t n_runs, uint64_t n_tiles, TileB* out, uint32_t w) {
     const uint64_t tile = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (tile >= n_tiles) return;
     uint32_t lo_r = 0, hi_r = n_runs;
     while (hi_r - lo_r > 1) { const uint32_t m = (lo_r + hi_r) >> 1; if (runs[m].tile_base <= tile) lo_r = m; else hi_r = m; }
     const RunDev run = runs[lo_r];
-    const uint32_t T0 = (uint32_t)(run.start_pos + (tile - run.tile_base) * (uint64_t)W);
-    const uint32_t Tend = (uint32_t)min((uint64_t)T0 + W, run.end_pos);
+    const uint32_t T0 = (uint32_t)(run.start_pos + (tile - run.tile_base) * (uint64_t)w);
+    const uint32_t Tend = (uint32_t)min((uint64_t)T0 + w, run.end_pos);
     const uint64_t rk = ref_key(run.ref_id) << 32;
     TileB b;
     b.i_lo = lower_bound_gt(pmax_end, run.first_record, run.end_record, rk | T0);             // first record whose running max end_position exceeds T0
@@ -266,7 +267,7 @@ __device__ __forceinline__ uint32_t run_of_record(const RunDev* runs, uint32_t n
     return lo;
 }
 
-__global__ __launch_bounds__(256) void k4_ck_count(const bgp_record* rec, uint64_t n, const RunDev* runs, uint32_t n_runs, uint64_t* n_ck) {
+__global__ __launch_bounds__(256) void k4_ck_count(const bgp_record* rec, uint64_t n, const RunDev* runs, uint32_t n_runs, uint64_t* n_ck, uint32_t W) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const bgp_record r = rec[i];
@@ -279,7 +280,8 @@ __global__ __launch_bounds__(256) void k4_ck_count(const bgp_record* rec, uint64
 }
 
 __global__ __launch_bounds__(256) void k4_ck_build(const uint8_t* s, const bgp_record* rec, uint64_t n, const RunDev* runs, uint32_t n_runs,
-                                                   const uint64_t* ck_off, Ckpt* ck) {
+                                                   const uint64_t* ck_off, Ckpt* ck, uint32_t W_) {
+    const int64_t W = (int64_t)W_;
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
     bgp_record r{};
@@ -349,35 +351,39 @@ constexpr int LDS_PAD = 8;               // words in front of the tile (see k4_t
 // positions to a word (an add is 1 << 16 * (position & 1); a half never carries because a window whose candidate
 // range holds 65 535 records or more is not given to this layout) -- half the LDS, so two workgroups share a CU and
 // one window's memory waits overlap the other's arithmetic.  P32: plain 32-bit counters, for those deep windows.
-template <bool P16_, int T_> struct Lay {
+template <bool P16_, int T_, int WIN_> struct Lay {
+    static constexpr int WIN = WIN_;                              // reference positions of the window
+    static constexpr int CLS_SHIFT = cls_shift_of(WIN_);
     static constexpr bool P16 = P16_;
     static constexpr int T = T_;
-    static constexpr int CNT = P16_ ? 5 * W / 2 : 5 * W;          // word offsets inside the tile
+    static constexpr int CNT = P16_ ? 5 * WIN_ / 2 : 5 * WIN_;          // word offsets inside the tile
     static constexpr int DELD = CNT;
-    static constexpr int NST = DELD + W + 4;
-    static constexpr int HIST = NST + (P16_ ? W / 2 : W);
+    static constexpr int NST = DELD + WIN_ + 4;
+    static constexpr int HIST = NST + (P16_ ? WIN_ / 2 : WIN_);
     static constexpr int LIST = HIST + HB;
     static constexpr int LCAP = 2 * T_;                            // a scan round adds at most T entries
     static constexpr int SLIST = LIST + LCAP;                      // second list: reads for the wave-cooperative paths
     static constexpr int WORDS = SLIST + LCAP + LDS_PAD;
     static constexpr int CSH = P16_ ? CLS_SHIFT - 1 : CLS_SHIFT;   // log2(bytes of one class array)
     __device__ __forceinline__ static void add_cls(uint32_t* lds, uint32_t cls, uint32_t col) {
-        const uint32_t i = cls * W + col;
+        const uint32_t i = cls * WIN_ + col;
         if (P16_) atomicAdd(&lds[i >> 1], 1u << ((i & 1u) * 16)); else atomicAdd(&lds[i], 1u);
     }
     __device__ __forceinline__ static void add_nst(uint32_t* lds, uint32_t col) {
         if (P16_) atomicAdd(&lds[NST + (col >> 1)], 1u << ((col & 1u) * 16)); else atomicAdd(&lds[NST + col], 1u);
     }
     __device__ __forceinline__ static uint32_t get_cls(const uint32_t* lds, uint32_t cls, uint32_t col) {
-        const uint32_t i = cls * W + col;
+        const uint32_t i = cls * WIN_ + col;
         return P16_ ? (lds[i >> 1] >> ((i & 1u) * 16)) & 0xFFFFu : lds[i];
     }
     __device__ __forceinline__ static uint32_t get_nst(const uint32_t* lds, uint32_t col) {
         return P16_ ? (lds[NST + (col >> 1)] >> ((col & 1u) * 16)) & 0xFFFFu : lds[NST + col];
     }
 };
-using L16 = Lay<true, K4_T16>;
-using L32 = Lay<false, K4_T>;
+using L16 = Lay<true, K4_T16, W>;          // the general kernel on the gather path's tiling (windows that path leaves behind)
+using L32 = Lay<false, K4_T, W>;
+using L16o = Lay<true, K4_T16, WO>;        // ... on its own tiling (streams of long reads)
+using L32o = Lay<false, K4_T, WO>;
 
 __device__ __forceinline__ uint32_t rl(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
 
@@ -704,7 +710,7 @@ template <class L> __global__ __launch_bounds__(L::T) void k4_tile(K4Args a, int
 #pragma unroll
                         for (int b = 0; b < 8; ++b) {
                             const uint32_t cls = __builtin_amdgcn_ubfe(cw, 4 * b, 3);
-                            atomicAdd(reinterpret_cast<uint32_t*>(l8 + (int32_t)((cls << CLS_SHIFT) + bq) + 4 * b), __builtin_amdgcn_ubfe(vm, b, 1));
+                            atomicAdd(reinterpret_cast<uint32_t*>(l8 + (int32_t)((cls << L::CLS_SHIFT) + bq) + 4 * b), __builtin_amdgcn_ubfe(vm, b, 1));
                         }
                     }
                 };
@@ -779,7 +785,7 @@ template <class L> __global__ __launch_bounds__(L::T) void k4_tile(K4Args a, int
             const uint32_t rpos = rl(x.y, 0), rcov = rl(x.z - x.y, 0), rncig = rl(y.x & 0xFFFFu, 0), rlseq = rl(y.y, 0);
             const uint64_t co = (((uint64_t)rl(y.w, 0) << 32) | rl(y.z, 0)) + 36 + rl(x.w & 0xFFu, 0);
             if (a.ck && is_long_read(rncig, rlseq)) {
-                const uint64_t wj = (uint64_t)(T0 - tb.run_start) / W - ((uint64_t)rpos - tb.run_start) / W;   // window index within the read
+                const uint64_t wj = (uint64_t)(T0 - tb.run_start) / L::WIN - ((uint64_t)rpos - tb.run_start) / L::WIN;   // window index within the read
                 const Ckpt ck = a.ck[a.ck_off[ri] + wj];
                 pile_read_long<L>(a, lds, T0, Tend, lane, rpos, rcov, rncig, rlseq, co, ck);
             } else
@@ -790,7 +796,7 @@ template <class L> __global__ __launch_bounds__(L::T) void k4_tile(K4Args a, int
     // ---- flush: prefix-sum the '-' difference array, then 32 contiguous bytes per position
     const uint32_t np = Tend - T0;
     {
-        constexpr int PER = W / K4_T;
+        constexpr int PER = L::WIN / K4_T;
         const uint32_t p0 = threadIdx.x * PER;
         uint32_t loc[PER]; uint32_t run_sum = 0;
 #pragma unroll
@@ -842,6 +848,13 @@ template <class L> __global__ __launch_bounds__(L::T) void k4_tile(K4Args a, int
 #endif
     __syncthreads();                                     // the deep pass reuses the tile's LDS for its next window
   }
+}
+
+// a stream left to the general kernel entirely: every window is on its list
+__global__ __launch_bounds__(256) void k4_all_listed(uint32_t* deep, uint32_t* n_deep, uint32_t n_tiles) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_tiles) deep[i] = i;
+    if (i == 0) *n_deep = n_tiles;
 }
 
 // folds the per-window totals: [0] columns with coverage, [1] sum of coverage, [2] max coverage, [4] reads used
@@ -935,15 +948,24 @@ __global__ __launch_bounds__(256) void k4_plan(PlanArgs a) {
     for (int j = 0; j < 8; ++j) { dsc[j] = 0; win[j] = 0xFFFFFFFFu; }
     uint32_t wf = 0xFFFFFFFFu;
     bool any = false;
+    // the reference run of a record: reads are sorted, so a wave nearly always lies inside one run -- the first lane's
+    // run is looked up once (a binary search of dependent loads) and only lanes beyond its end search for themselves
+    const uint64_t i0 = i - lane;
+    uint32_t ri = 0; uint64_t r_end = 0, r_start_pos = 0, r_tile_base = 0;
+    if (i0 < a.n) {
+        ri = run_of_record(a.runs, a.n_runs, i0);
+        const RunDev rd = a.runs[ri];
+        r_end = rd.end_record; r_start_pos = rd.start_pos; r_tile_base = rd.tile_base;
+    }
     if (i < a.n) {
         const uint4* rp = reinterpret_cast<const uint4*>(a.rec + i);
         const uint4 x = rp[0], y = rp[1];                 // ref_id,pos,end_pos,bin_mq_nl | flag_nc,l_seq,rec_off
         if (x.z != x.y) {                                 // basesCovered() > 0, pileup.d:481,510
-            const RunDev& run = a.runs[run_of_record(a.runs, a.n_runs, i)];
-            const uint32_t rel0 = x.y - (uint32_t)run.start_pos;
-            const uint32_t tb = (uint32_t)run.tile_base;
+            if (i >= r_end) { const RunDev& rd = a.runs[run_of_record(a.runs, a.n_runs, i)]; r_start_pos = rd.start_pos; r_tile_base = rd.tile_base; }
+            const uint32_t rel0 = x.y - (uint32_t)r_start_pos;
+            const uint32_t tb = (uint32_t)r_tile_base;
             wf = tb + rel0 / W;
-            const uint32_t wl = tb + (x.z - 1 - (uint32_t)run.start_pos) / W;
+            const uint32_t wl = tb + (x.z - 1 - (uint32_t)r_start_pos) / W;
             const uint32_t n_cig = y.x & 0xFFFFu, l_seq = y.y;
             const uint64_t cig_off = (((uint64_t)y.w << 32) | y.z) + 36 + (x.w & 0xFFu);
             const uint64_t seq_off = cig_off + 4ull * n_cig;
@@ -1397,6 +1419,7 @@ __global__ __launch_bounds__(GT, BGP_G_MINW) void k4_exec(GArgs a) {
 struct K5Args {
     const uint8_t* s; const bgp_record* rec; const uint64_t* pmax_end; const uint64_t* pmax_pos;
     RunDev run; uint64_t pos_begin, pos_end; const bgp_column* cols; uint64_t* cov64; const uint64_t* col_off; bgp_entry* entries;
+    const uint64_t* ck_off; const Ckpt* ck; uint32_t ck_w;      // K4's long-read checkpoints (null / 0: none): per read and window, the cursor at the window's first column
 };
 
 __global__ __launch_bounds__(256) void k5_cov(K5Args a) {
@@ -1406,14 +1429,23 @@ __global__ __launch_bounds__(256) void k5_cov(K5Args a) {
 }
 
 // closed-form cursor of read r at column offset rr (see file header)
-__device__ __forceinline__ bgp_entry entry_of(const uint8_t* s, const bgp_record& r, uint32_t rr, uint32_t ordinal) {
+__device__ __forceinline__ bgp_entry entry_of(const uint8_t* s, const bgp_record& r, uint32_t rr, uint32_t ordinal, const K5Args& a) {
     const uint32_t l_name = r.bin_mq_nl & 0xFFu, n_cig = r.flag_nc & 0xFFFFu;
     const uint8_t* cg = s + r.rec_off + 36 + l_name;
     const uint8_t* sq = cg + 4ull * n_cig;
     const uint8_t* ql = sq + (uint32_t)((r.l_seq + 1) / 2);
     bgp_entry e; e.read_ordinal = ordinal; e.cigar_op_offset = 0; e.query_offset = 0; e.cigar_op_index = 0xFFFF; e.base = 0xFF; e.qual = 0xFF;
-    uint32_t cs = 0, qs = 0; bool started = false;
-    for (uint32_t k = 0; k < n_cig; ++k) {
+    uint32_t cs = 0, qs = 0, k = 0; bool started = false;
+    if (a.ck && is_long_read(n_cig, (uint32_t)r.l_seq)) {
+        // a long read is not walked from its first op for every column: the walk resumes from the cursor K4 recorded for
+        // the window the column lies in (op index, columns before it, query bases before it; the op owns a column, so
+        // the cursor has started) -- O(ops inside a window) per entry instead of O(ops of the read)
+        const uint64_t wj = ((uint64_t)(uint32_t)r.pos + rr - a.run.start_pos) / a.ck_w - ((uint64_t)(uint32_t)r.pos - a.run.start_pos) / a.ck_w;
+        const Ckpt c = a.ck[a.ck_off[ordinal] + wj];
+        if (c.k != 0xFFFFFFFFu) { k = c.k; cs = c.cs; qs = c.qs; started = true; }
+        else k = n_cig;                                                      // the cursor ran off the CIGAR before this window (pileup.d:224-228)
+    }
+    for (; k < n_cig; ++k) {
         const uint32_t op = ld_u32(cg + 4 * k);
         const uint32_t len = op >> 4, qc = cig_qc(op), rc = cig_rc(op);
         if (!started) {
@@ -1458,7 +1490,7 @@ __global__ __launch_bounds__(256) void k5_fill(K5Args a) {
         const unsigned long long m = __ballot(alive);
         if (alive) {
             const uint32_t rank = __popcll(m & ((1ull << lane) - 1));
-            a.entries[w + rank] = entry_of(a.s, r, (uint32_t)(p - (uint32_t)r.pos), (uint32_t)i);
+            a.entries[w + rank] = entry_of(a.s, r, (uint32_t)(p - (uint32_t)r.pos), (uint32_t)i, a);
         }
         w += __popcll(m);
     }
@@ -1513,11 +1545,15 @@ int k34_pileup(bgp_ctx* c) {
         BGP_HIP(hipMemcpyAsync(runs.data(), c->d_runs.p, sizeof(RunDev) * n_runs, hipMemcpyDeviceToHost, c->stream));
         BGP_HIP(hipStreamSynchronize(c->stream));
     }
+    // A stream of long reads (a quarter of its reads or more) is left to the general kernel entirely, on its own tiling of
+    // 4096 positions; every other stream is tiled for the gather path, the general kernel taking the windows that leaves.
+    const bool long_stream = (uint64_t)st[3] * 4 >= n && st[3] > 0;
+    const uint32_t tw = long_stream ? (uint32_t)WO : (uint32_t)W;
     uint64_t col_base = 0, tile_base = 0;
     for (auto& r : runs) {
         r.column_base = col_base; r.tile_base = tile_base;
         const uint64_t span = r.end_pos - r.start_pos;
-        col_base += span; tile_base += (span + W - 1) / W;
+        col_base += span; tile_base += (span + tw - 1) / tw;
     }
     if (tile_base >= (1ull << 31)) return BGP_EINVAL;
     c->runs.resize(n_runs);
@@ -1533,7 +1569,7 @@ int k34_pileup(bgp_ctx* c) {
         a.s = c->d_stream; a.rec = c->d_rec.as<bgp_record>(); a.pmax_end = c->d_pmax_end.as<uint64_t>(); a.pmax_pos = c->d_pmax_pos.as<uint64_t>();
         a.runs = c->d_runs.as<RunDev>(); a.n_runs = n_runs; a.n_tiles = tile_base; a.stream_len = c->stream_len;
         a.cols = c->d_columns.as<bgp_column>(); a.hist = (unsigned long long*)c->d_depth_hist.p; a.pstats = (unsigned long long*)c->d_pstats.p; a.status = status;
-        const size_t lds16 = (size_t)L16::WORDS * 4, lds32 = (size_t)L32::WORDS * 4;
+        const size_t lds16 = (size_t)(long_stream ? L16o::WORDS : L16::WORDS) * 4, lds32 = (size_t)(long_stream ? L32o::WORDS : L32::WORDS) * 4;
         uint64_t used = 0;   // algorithmic bytes: record table + CIGAR + packed SEQ per read, 32 B per position
         used = c->n_records * 32 + c->sum_ncig * 4 + (c->sum_lseq + 1) / 2 + col_base * 32;
         BGP_TRY(c->d_tiles.reserve(tile_base * sizeof(TileB)));
@@ -1543,10 +1579,13 @@ int k34_pileup(bgp_ctx* c) {
         a.tiles = c->d_tiles.as<TileB>();
         {
             TimedRegion tb(c, "k4_bounds", tile_base * sizeof(TileB));
-            hipLaunchKernelGGL(k4_bounds, dim3((unsigned)((tile_base + 255) / 256)), dim3(256), 0, c->stream, a.pmax_end, a.pmax_pos, a.runs, n_runs, tile_base, c->d_tiles.as<TileB>());
+            hipLaunchKernelGGL(k4_bounds, dim3((unsigned)((tile_base + 255) / 256)), dim3(256), 0, c->stream, a.pmax_end, a.pmax_pos, a.runs, n_runs, tile_base, c->d_tiles.as<TileB>(), tw);
         }
         BGP_TRY(c->d_col_lo.reserve(tile_base * 32));
         a.tile_stats = (unsigned long long*)c->d_col_lo.p;
+        if (long_stream) {
+            hipLaunchKernelGGL(k4_all_listed, dim3((unsigned)((tile_base + 255) / 256)), dim3(256), 0, c->stream, c->d_deep.as<uint32_t>() + 1, c->d_deep.as<uint32_t>(), (uint32_t)tile_base);
+        } else {
         // the gather path's plan: descriptor slabs per window, from one pass over the reads
         BGP_TRY(c->d_slab.reserve(tile_base * (size_t)SLAB_CAP * 8));
         BGP_TRY(c->d_wcount.reserve((tile_base + 1) * 4)); BGP_TRY(c->d_wdel.reserve((tile_base + 2) * 4)); BGP_TRY(c->d_wslow.reserve((tile_base + 2) * 4));
@@ -1567,17 +1606,18 @@ int k34_pileup(bgp_ctx* c) {
             hipLaunchKernelGGL(k4_wscan_mid, dim3(1), dim3(1024), 0, c->stream, btot, wb);
             hipLaunchKernelGGL(k4_wscan, dim3(wb), dim3(1024), 0, c->stream, pa.wdel, pa.wslow, pa.wcount, c->d_tiles.as<TileB>(), tile_base, btot, c->d_deep.as<uint32_t>() + 1, c->d_deep.as<uint32_t>());
         }
+        }
         a.ck = nullptr; a.ck_off = nullptr;
         if (st[3]) {                                   // the stream holds long reads: build their per-window CIGAR checkpoints
             TimedRegion tc(c, "k4_checkpoints", c->sum_ncig * 4);
             BGP_TRY(c->d_ck_off.reserve((n + 2) * 8));
             uint64_t* ck_off = c->d_ck_off.as<uint64_t>();
-            hipLaunchKernelGGL(k4_ck_count, dim3(nb), dim3(256), 0, c->stream, a.rec, n, a.runs, n_runs, ck_off);
+            hipLaunchKernelGGL(k4_ck_count, dim3(nb), dim3(256), 0, c->stream, a.rec, n, a.runs, n_runs, ck_off, tw);
             uint64_t total_ck = 0;
             BGP_TRY(scan_exclusive_u64(c, ck_off, ck_off, n, &total_ck));
             BGP_TRY(c->d_ck.reserve((total_ck + 1) * sizeof(Ckpt)));
             BGP_HIP(hipMemsetAsync(c->d_ck.p, 0xFF, (total_ck + 1) * sizeof(Ckpt), c->stream));
-            hipLaunchKernelGGL(k4_ck_build, dim3(nb), dim3(256), 0, c->stream, a.s, a.rec, n, a.runs, n_runs, ck_off, c->d_ck.as<Ckpt>());
+            hipLaunchKernelGGL(k4_ck_build, dim3(nb), dim3(256), 0, c->stream, a.s, a.rec, n, a.runs, n_runs, ck_off, c->d_ck.as<Ckpt>(), tw);
             a.ck = c->d_ck.as<Ckpt>(); a.ck_off = ck_off;
         }
 #ifdef BGP_G_PROF
@@ -1586,9 +1626,10 @@ int k34_pileup(bgp_ctx* c) {
         BGP_HIP(hipMemset(g_prof_dev, 0, tile_base * 128));
         BGP_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_prof_buf), &g_prof_dev, sizeof g_prof_dev));
 #endif
+        c->ck_w = a.ck ? tw : 0;                     // K5 resumes long reads from these checkpoints
         TimedRegion t(c, "k4_tile", used);
         BGP_HIP(hipMemsetAsync(a.tile_stats, 0, tile_base * 32, c->stream));      // the gather path adds its per-window totals wave by wave
-        {
+        if (!long_stream) {
             GArgs g;
             g.s = a.s; g.slab = (const unsigned long long*)c->d_slab.p; g.wcount = c->d_wcount.as<uint32_t>(); g.wdel = c->d_wdel.as<int32_t>(); g.tiles = a.tiles; g.n_tiles = tile_base;
             g.cols = a.cols; g.hist = a.hist; g.tile_stats = a.tile_stats; g.deep = c->d_deep.as<uint32_t>() + 1; g.n_deep = c->d_deep.as<uint32_t>();
@@ -1597,8 +1638,13 @@ int k34_pileup(bgp_ctx* c) {
         }
         // windows the gather path left on the list (long reads, odd CIGARs, too deep): the general kernel
         const unsigned dgrid = (unsigned)std::min<uint64_t>(tile_base, 2048);
-        hipLaunchKernelGGL(k4_tile<L16>, dim3(dgrid), dim3(L16::T), lds16, c->stream, a, 1);
-        hipLaunchKernelGGL(k4_tile<L32>, dim3(std::min(dgrid, 512u)), dim3(L32::T), lds32, c->stream, a, 1);
+        if (long_stream) {
+            hipLaunchKernelGGL(k4_tile<L16o>, dim3(dgrid), dim3(L16o::T), lds16, c->stream, a, 1);
+            hipLaunchKernelGGL(k4_tile<L32o>, dim3(std::min(dgrid, 512u)), dim3(L32o::T), lds32, c->stream, a, 1);
+        } else {
+            hipLaunchKernelGGL(k4_tile<L16>, dim3(dgrid), dim3(L16::T), lds16, c->stream, a, 1);
+            hipLaunchKernelGGL(k4_tile<L32>, dim3(std::min(dgrid, 512u)), dim3(L32::T), lds32, c->stream, a, 1);
+        }
         hipLaunchKernelGGL(k4_stats, dim3(32), dim3(256), 0, c->stream, a.tile_stats, tile_base, a.pstats);
         BGP_HIP(hipGetLastError());
 #ifdef BGP_G_PROF
@@ -1698,6 +1744,7 @@ int k5_entries(bgp_ctx* c, uint32_t run_idx, uint64_t pos_begin, uint64_t pos_en
     a.run.column_base = r.column_base; a.run.tile_base = 0; a.run.pad = 0;
     a.pos_begin = pos_begin; a.pos_end = pos_end; a.cols = c->d_columns.as<bgp_column>(); a.cov64 = c->d_col_lo.as<uint64_t>();
     a.col_off = c->d_entry_off.as<uint64_t>(); a.entries = nullptr;
+    a.ck_w = c->ck_w; a.ck = c->ck_w ? c->d_ck.as<Ckpt>() : nullptr; a.ck_off = c->ck_w ? c->d_ck_off.as<uint64_t>() : nullptr;
     hipLaunchKernelGGL(k5_cov, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, c->stream, a);
     uint64_t total = 0;
     BGP_TRY(scan_exclusive_u64(c, a.cov64, c->d_entry_off.as<uint64_t>(), np, &total));
