@@ -47,7 +47,8 @@ def kernels_sha():
 
 
 def pmc_traffic(prefixes, config, n_reads):
-    """HBM bytes per step of the kernels whose names start with `prefixes`, from the committed rocprofv3 PMC
+    """HBM bytes of one dispatch of each kernel whose name starts with `prefixes` (= per step for K2 and K4, whose kernels
+    run once a step), from the committed rocprofv3 PMC
     passes (FETCH_SIZE and WRITE_SIZE collected separately, FETCH doubled for gfx950 as MI355X_MICROARCH.md
     prescribes).  Counters cannot be read from inside this process, so the number is only reported when the
     workload is the one the profile was taken on (cfg3, 100 M reads) AND the profile's header carries the hash
