@@ -106,6 +106,8 @@ struct bgp_ctx {
     bool bai_buildable = false; uint64_t stage_end_coff = 0;   // one whole file staged: createIndex can run (bai_build.hip)
     std::vector<uint8_t> bai_bytes;
     bool region_pending = false; uint32_t region_ref = 0, region_beg = 0, region_end = 0;   // bam[ref][beg..end]: filter applied by bgp_flush
+    std::vector<uint64_t> hints;                      // staged offsets where, by the caller's word (first_record_uoffset), a record starts: candidates for the boundary guesser, verified like its own
+    DevBuf d_seg_hint;
     DevBuf d_stream_own;                              // device copy of pushed bytes
     DevBuf d_comp, d_inf_blk; HostBuf h_ring, h_stream_copy;         // device inflate: compressed file, block descriptors + status, pinned read ring
     const uint8_t* d_stream = nullptr; uint64_t stream_len = 0;

@@ -30,6 +30,7 @@ struct FrameArgs {
     uint64_t* entry; uint64_t* fix; uint64_t* end; uint64_t* cnt; uint64_t* lseq; uint64_t* ncig; uint32_t* dirty; uint32_t* seg_err;
     uint32_t* status; /* [0] status bits, [1] dirty counter */
     uint32_t* side; uint32_t side_cap;   // side[k * side_cap + j] = offset of segment k's j-th record relative to the segment start
+    const uint64_t* seg_hint;            // per segment: the smallest offset inside it where the caller says a record starts (NONE: no word), or null
     int tolerant_tail;                   // batched staging: the data may end inside a record -- the chain stops in front of it instead of ETRUNC
 };
 
@@ -58,6 +59,14 @@ __global__ __launch_bounds__(256) void k0_guess(FrameArgs a) {
     const uint64_t beg = k * a.seg_bytes;
     const uint64_t lim = min(beg + a.seg_bytes, a.len);
     uint64_t found = NONE;
+    if (a.seg_hint) {                                   // the caller's hint (bgp_push_inflated: first_record_uoffset): tried first, by the same test as any candidate
+        const uint64_t h = a.seg_hint[k];
+        uint32_t bs = 0, dummy;
+        if (h != NONE && h >= beg && h < lim && plausible(a.s, a.len, h, a.ref_bound, &bs)) {
+            const uint64_t nxt = h + 4 + bs;
+            if (a.len - nxt < 4 || plausible(a.s, a.len, nxt, a.ref_bound, &dummy)) found = h;
+        }
+    }
     for (uint64_t base = beg; base < lim && found == NONE; base += 64) {
         const uint64_t o = base + lane;
         uint32_t bs = 0;
@@ -258,6 +267,7 @@ int k0_frame(bgp_ctx* c) {
     a.s = c->d_stream; a.len = len; a.seg_bytes = seg; a.n_seg = n_seg;
     a.ref_bound = c->n_ref_hint > 0 ? c->n_ref_hint : (1 << 24);
     a.tolerant_tail = c->frame_tolerant_tail ? 1 : 0;
+    a.seg_hint = nullptr;
     a.entry = c->d_seg_entry.as<uint64_t>(); a.fix = a.entry + n_seg + 1; a.end = c->d_seg_end.as<uint64_t>();
     a.cnt = c->d_seg_cnt.as<uint64_t>(); a.lseq = c->d_seg_lseq.as<uint64_t>(); a.ncig = c->d_seg_ncig.as<uint64_t>();
     a.dirty = c->d_seg_dirty.as<uint32_t>(); a.seg_err = a.dirty + n_seg;
@@ -267,6 +277,14 @@ int k0_frame(bgp_ctx* c) {
     a.side = c->d_seg_side.as<uint32_t>();
     c->side_cap = a.side_cap;
 
+    if (!c->hints.empty()) {
+        std::vector<uint64_t> sh(n_seg, NONE);
+        for (uint64_t h : c->hints) if (h < len) { uint64_t& e = sh[h / seg]; if (h < e) e = h; }
+        BGP_TRY(c->d_seg_hint.reserve(n_seg * 8));
+        BGP_HIP(hipMemcpyAsync(c->d_seg_hint.p, sh.data(), n_seg * 8, hipMemcpyHostToDevice, c->stream));
+        BGP_HIP(hipStreamSynchronize(c->stream));
+        a.seg_hint = c->d_seg_hint.as<uint64_t>();
+    }
     const unsigned lane_blocks = (unsigned)((n_seg + 255) / 256);
     {
         TimedRegion t(c, "k0_guess", n_seg * 64);

@@ -69,8 +69,9 @@ int bgp_reset(bgp_ctx* ctx);
  * the caller hands over already-inflated BGZF payloads in file order, starting at the first record
  * (after the BAM header, reader.d:121-123).  `coffset` is the block's compressed file offset (kept
  * for virtual offsets, virtualoffset.d:29-59).  `first_record_uoffset` is a hint: offset inside this
- * block of the first record that STARTS in it, or BGP_UOFFSET_UNKNOWN.  The hint is never trusted --
- * record boundaries are verified on the device -- it only saves guessing work. */
+ * block of the first record that STARTS in it, or BGP_UOFFSET_UNKNOWN.  The hint is never trusted: the boundary
+ * guesser tries the hinted offset first, by the same plausibility test it applies to its own candidates, and every
+ * boundary is verified by the chain of records on the device -- a wrong hint costs time, never correctness. */
 #define BGP_UOFFSET_UNKNOWN 0xFFFFFFFFu
 int bgp_push_inflated(bgp_ctx* ctx, const uint8_t* data, size_t len, uint64_t coffset, uint32_t first_record_uoffset);
 /* Zero-copy variant: the record stream is already resident in HBM (device pointer, caller keeps it

@@ -1578,3 +1578,25 @@ def test_interval_shards_with_exact_halo_on_the_device(ctx):
         keep = clip_columns(ref, pos, sh["lo"], sh["hi"])
         parts.append((ref[keep], pos[keep], cols[keep]))
     _assert_columns_equal_oracle(np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts]), np.concatenate([p[2] for p in parts]), O.pileup(st))
+
+
+def test_first_record_hints_right_wrong_and_wild(ctx, data_dir):
+    """bgp_push_inflated's first_record_uoffset: blocks pushed with the true offset of the first record that starts in
+    them, with offsets that are no record starts, and with offsets past the block -- the record table is the same."""
+    _, st = bamio.read_bam(os.path.join(data_dir, "mg1655_chunk.bam"))
+    st = st * 40                                       # several framing segments
+    soa = O.decode_soa(st)
+    offs = soa.rec_off.astype(np.int64)
+    block = 0xFF00
+    rng = np.random.default_rng(3)
+    for mode in ("right", "wrong", "wild"):
+        ctx.reset()
+        for b0 in range(0, len(st), block):
+            blk = st[b0:b0 + block]
+            i = int(np.searchsorted(offs, b0))
+            true_u = int(offs[i] - b0) if i < len(offs) and offs[i] < b0 + len(blk) else L.BGP_UOFFSET_UNKNOWN
+            u = true_u if mode == "right" else int(rng.integers(0, len(blk))) if mode == "wrong" else int(rng.integers(len(blk), 1 << 20))
+            ctx.push_inflated(blk, b0, u)
+        ctx.flush()
+        dec = ctx.decode_fetch(0)
+        assert np.array_equal(dec.rec["rec_off"], soa.rec_off) and np.array_equal(dec.rec["end_pos"], soa.end_pos), mode
