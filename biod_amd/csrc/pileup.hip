@@ -1562,6 +1562,19 @@ int k34_pileup(bgp_ctx* c) {
         o.ref_id = r.ref_id; o._pad = 0; o.first_record = r.first_record; o.end_record = r.end_record;
         o.start_pos = r.start_pos; o.end_pos = r.end_pos; o.column_base = r.column_base;
     }
+    {   // columns are dense over every reference's [first position, largest end_position): 32 bytes per position, covered or not
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && (col_base + 1) * sizeof(bgp_column) > c->d_columns.cap + free_b) {
+            uint64_t widest = 0; int32_t wref = 0;
+            for (const auto& r : runs) if (r.end_pos - r.start_pos > widest) { widest = r.end_pos - r.start_pos; wref = r.ref_id; }
+            char msg[256];
+            snprintf(msg, sizeof msg, "dense columns need %.1f GB for %llu reference positions (widest: reference %d spans %llu positions) and %.1f GB are free: "
+                     "pile up region by region (bgp_load_bam_region / bgp_filter_region) or in batches (bgp_batch_*)",
+                     (double)(col_base * 32) / 1e9, (unsigned long long)col_base, wref, (unsigned long long)widest, (double)free_b / 1e9);
+            c->last_error = msg;
+            return BGP_ENOMEM;
+        }
+    }
     BGP_TRY(c->d_columns.reserve((col_base + 1) * sizeof(bgp_column)));
     if (n_runs) {
         BGP_HIP(hipMemcpyAsync(c->d_runs.p, runs.data(), sizeof(RunDev) * n_runs, hipMemcpyHostToDevice, c->stream));
