@@ -129,6 +129,7 @@ struct bgp_ctx {
 
     // record table (K1)
     DevBuf d_rec, d_seq_off, d_cigar_off;
+    DevBuf d_tilemax; bool tilemax_ok = false;        // per 2048-record tile: maxima of K3's two keys, left by K1 (K3 then skips its own first pass)
     DevBuf d_cig4; bool cig4_ok = false;              // first four raw CIGAR ops of every record (16 B, written by K1): K4's planner reads these, not the stream
     DevBuf d_rec2, d_seq_off2, d_cigar_off2, d_flt[6];   // region filter: compaction targets (swapped in) and scan scratch
     // decode arenas (K2)
@@ -231,6 +232,17 @@ __device__ __forceinline__ void nt_store16(void* p, uint4 v) {
 }
 // sort key of a reference id: unmapped (-1) sorts last, as in a coordinate-sorted BAM
 __device__ __forceinline__ uint64_t ref_key(int32_t ref_id) { return ref_id < 0 ? 0x7FFFFFFFull : (uint64_t)(uint32_t)(ref_id + 1); }
+// K3's scan keys of a record: (reference key << 32 | end_position) and (... | position); 0 for reads with basesCovered() == 0
+struct K3Key { uint64_t e, p; };
+constexpr int K3_TILE_RECORDS = 2048;
+__device__ __forceinline__ K3Key k3_key_of(int32_t ref_id, int32_t pos, int32_t end_pos) {
+    K3Key k; k.e = 0; k.p = 0;
+    if (end_pos != pos) {                                                  // basesCovered() > 0, pileup.d:481,510
+        const uint64_t rk = ref_key(ref_id) << 32;
+        k.e = rk | (uint32_t)end_pos; k.p = rk | (uint32_t)pos;
+    }
+    return k;
+}
 // CIGAR_TYPE bit pairs (cigar.d:113-116): bit0 query consuming, bit1 reference consuming
 __device__ __forceinline__ uint32_t cig_qc(uint32_t raw) { return (0x3C1A7u >> ((raw & 15u) * 2)) & 1u; }
 __device__ __forceinline__ uint32_t cig_rc(uint32_t raw) { return (0x3C1A7u >> ((raw & 15u) * 2 + 1)) & 1u; }

@@ -173,6 +173,7 @@ struct FusedArgs {
     const uint64_t* entry; const uint64_t* rec_base; const uint64_t* seq_base; const uint64_t* cig_base; const uint32_t* side;
     uint32_t side_cap, seg_bytes; uint64_t n_seg, sum_lseq, sum_ncig;
     bgp_record* rec_out; uint64_t* seq_off_out; uint64_t* cig_off_out; uint4* cig4_out;
+    unsigned long long* tilemax;      // K3's keys, maximum per 2048-record tile (two u64 per tile), or null
 };
 
 // exclusive prefix sums of two per-thread values over the 256 threads of the block + the block totals
@@ -251,10 +252,29 @@ __global__ __launch_bounds__(256) void k12_fused(FusedArgs a) {
         }
         uint64_t es, ec, ts, tc;
         block_excl2(lseq, ncig, &es, &ec, &ts, &tc, s_ws);
+        const uint64_t so = carry_seq + es, co = carry_cig + ec;
         if (valid) {
-            const uint64_t so = carry_seq + es, co = carry_cig + ec;
             a.rec_out[i] = rec; a.seq_off_out[i] = so; a.cig_off_out[i] = co;       // (plain stores: K2 reads these rows right after, non-temporal ones cost it 0.3 ms)
             a.cig4_out[i] = c4v;
+        }
+        if (a.tilemax) {            // what K3's first pass would compute from these rows: a wave covers 64 consecutive records, i.e. one or two tiles
+            K3Key k{0, 0};
+            if (valid) k = k3_key_of(rec.ref_id, rec.pos, rec.end_pos);
+            const uint64_t tile = i / K3_TILE_RECORDS;
+            const uint64_t t0 = __shfl(tile, 0, 64);
+            K3Key m0 = tile == t0 ? k : K3Key{0, 0}, m1 = tile == t0 ? K3Key{0, 0} : k;
+            for (int d = 32; d >= 1; d >>= 1) {
+                const uint64_t e0 = __shfl_xor(m0.e, d, 64), p0 = __shfl_xor(m0.p, d, 64), e1 = __shfl_xor(m1.e, d, 64), p1 = __shfl_xor(m1.p, d, 64);
+                m0.e = max(m0.e, e0); m0.p = max(m0.p, p0); m1.e = max(m1.e, e1); m1.p = max(m1.p, p1);
+            }
+            if ((threadIdx.x & 63) == 0) {
+                if (m0.e) atomicMax(&a.tilemax[2 * t0], (unsigned long long)m0.e);
+                if (m0.p) atomicMax(&a.tilemax[2 * t0 + 1], (unsigned long long)m0.p);
+                if (m1.e) atomicMax(&a.tilemax[2 * (t0 + 1)], (unsigned long long)m1.e);
+                if (m1.p) atomicMax(&a.tilemax[2 * (t0 + 1) + 1], (unsigned long long)m1.p);
+            }
+        }
+        if (valid) {
             s_seq_off[threadIdx.x] = so; s_cig_off[threadIdx.x] = co;
             RecInfo ri;
             ri.cig_ptr = rec.rec_off + 36 + (rec.bin_mq_nl & 0xFFu);
@@ -321,6 +341,14 @@ int k12_fused_decode(bgp_ctx* c, uint32_t what) {
     a.side = c->d_seg_side.as<uint32_t>(); a.side_cap = c->side_cap; a.seg_bytes = c->seg_bytes; a.n_seg = c->n_seg; a.sum_lseq = c->sum_lseq; a.sum_ncig = c->sum_ncig;
     a.rec_out = c->d_rec.as<bgp_record>(); a.seq_off_out = c->d_seq_off.as<uint64_t>(); a.cig_off_out = c->d_cigar_off.as<uint64_t>();
     a.cig4_out = c->d_cig4.as<uint4>();
+    // K3's tile maxima on the way -- unless some record's end_position is finished later (CIGARs longer than the inline loop)
+    a.tilemax = nullptr; c->tilemax_ok = false;
+    if (!c->long_cigar) {
+        const uint64_t nt = (n + K3_TILE_RECORDS - 1) / K3_TILE_RECORDS;
+        BGP_TRY(c->d_tilemax.reserve((nt + 2) * 16));
+        BGP_HIP(hipMemsetAsync(c->d_tilemax.p, 0, (nt + 2) * 16, c->stream));
+        a.tilemax = (unsigned long long*)c->d_tilemax.p; c->tilemax_ok = true;
+    }
     const unsigned blocks = (unsigned)((c->n_seg + G_SEG - 1) / G_SEG);
     const bool S = what & BGP_FETCH_SEQ, Q = what & BGP_FETCH_QUAL, C = what & BGP_FETCH_CIGAR;
     uint64_t alg = n * (36 + 32 + 16) + c->sum_ncig * 4;    // what k1_emit accounts for ...

@@ -71,17 +71,10 @@ __device__ __forceinline__ bool is_long_read(uint32_t n_cig, uint32_t l_seq) { r
 // (pileup.d:399-424) and notes whether any long read exists.
 constexpr int K3_T = 256, K3_ITEMS = 8, K3_TILE = K3_T * K3_ITEMS;
 
-struct K3Key { uint64_t e, p; };
 __device__ __forceinline__ K3Key k3_max(K3Key a, K3Key b) { K3Key r; r.e = a.e > b.e ? a.e : b.e; r.p = a.p > b.p ? a.p : b.p; return r; }
 
-__device__ __forceinline__ K3Key k3_key_of(const bgp_record& r) {
-    K3Key k; k.e = 0; k.p = 0;
-    if (r.end_pos != r.pos) {                                            // basesCovered() > 0, pileup.d:481,510
-        const uint64_t rk = ref_key(r.ref_id) << 32;
-        k.e = rk | (uint32_t)r.end_pos; k.p = rk | (uint32_t)r.pos;
-    }
-    return k;
-}
+__device__ __forceinline__ K3Key k3_key_of(const bgp_record& r) { return ::k3_key_of(r.ref_id, r.pos, r.end_pos); }
+static_assert(K3_TILE_RECORDS == 256 * 8, "K1 leaves its tile maxima for K3's tiles");
 
 // exclusive prefix (max) of per-thread values across the workgroup + workgroup total
 __device__ __forceinline__ K3Key k3_block_excl(K3Key mine, K3Key* total, K3Key* lds /* K3_T/64 */) {
@@ -1522,7 +1515,10 @@ int k34_pileup(bgp_ctx* c) {
             const uint64_t nt = (n + K3_TILE - 1) / K3_TILE;
             BGP_TRY(c->d_scan_tmp.reserve((nt + 2) * sizeof(K3Key)));
             K3Key* bsum = c->d_scan_tmp.as<K3Key>();
-            hipLaunchKernelGGL(k3_reduce, dim3((unsigned)nt), dim3(K3_T), 0, c->stream, a, bsum);
+            if (c->tilemax_ok)      // K1 left the tiles' maxima behind (it had every row in registers): no first pass over the table
+                BGP_HIP(hipMemcpyAsync(bsum, c->d_tilemax.p, nt * sizeof(K3Key), hipMemcpyDeviceToDevice, c->stream));
+            else
+                hipLaunchKernelGGL(k3_reduce, dim3((unsigned)nt), dim3(K3_T), 0, c->stream, a, bsum);
             hipLaunchKernelGGL(k3_bsum, dim3(1), dim3(K3_T), 0, c->stream, bsum, nt);
             hipLaunchKernelGGL(k3_down, dim3((unsigned)nt), dim3(K3_T), 0, c->stream, a, bsum, c->d_runs.as<RunDev>());
         }
