@@ -33,7 +33,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
-STAGES = {"K0 framing": ("k0_",), "K1 record table": ("k1_",), "K2 unpack": ("k2_", "k12_"), "K3 run keys": ("k3_",),
+STAGES = {"K012 decode in one pass": ("k012_", "k01_"), "K0 framing": ("k0_",), "K1 record table": ("k1_",), "K2 unpack": ("k2_", "k12_"), "K3 run keys": ("k3_",),
           "K4 pileup columns": ("k4_",)}
 
 
@@ -246,8 +246,8 @@ def main():
     def step():
         ctx.reset()
         ctx.attach_device_stream(sptr, slen)
-        ctx.flush()                                                # K0 framing + K1 record table
-        ctx.decode_device(L.BGP_FETCH_ALL)                         # K2 seq/qual/cigar arenas
+        ctx.flush(decode=L.BGP_FETCH_ALL)                          # framing + record table + seq/qual/cigar arenas: one pass over the stream (BGP_FRAME_MODE=0: K0, K1, K2 as three kernels)
+        ctx.decode_device(L.BGP_FETCH_ALL)                         # (the arenas are there already: hands out the pointers)
         info = ctx.pileup_run()                                    # K3 + K4 dense columns
         if with_comm:                                              # the path's only exchange: whole-BAM depth histogram, RCCL over xGMI, in place
             L.check(L.lib().bgp_hist_reduce(ctx.handle, comm, C.c_void_p(info.device_depth_hist), L.BGP_DEPTH_BINS), ctx.handle)

@@ -81,6 +81,7 @@ SYMBOLS = {
     "bgp_n_ref": (C.c_int, [_P, C.POINTER(C.c_int32)]),
     "bgp_ref_info": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_char_p), C.POINTER(C.c_int32)]),
     "bgp_flush": (C.c_int, [_P]),
+    "bgp_flush_decode": (C.c_int, [_P, C.c_uint32]),
     "bgp_num_records": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
     "bgp_decode_fetch": (C.c_int, [_P, C.c_uint32, C.POINTER(Records)]),
     "bgp_decode_device": (C.c_int, [_P, C.c_uint32, C.POINTER(Records)]),

@@ -20,13 +20,22 @@ void bgp_note_hip_error(hipError_t e, const char* what, const char* file, int li
 static int fuse_mode() { const char* e = getenv("BGP_FUSE_MODE"); return e ? atoi(e) : 2; }   // 0: chase-based K1, then K2; 1: K1+K2 fused; 2: parallel K1 from the side offsets, then K2
 static int ensure_table(bgp_ctx* c) { return !c->table_pending ? BGP_OK : (fuse_mode() == 0 ? k1_table(c) : k12_fused_decode(c, 0)); }
 
-// framing + record table of the stream c->d_stream points at (bgp_flush after its upload; a batch of batch.cpp)
-int flush_core(bgp_ctx* c) {
+static int frame_mode() { const char* e = getenv("BGP_FRAME_MODE"); return e ? atoi(e) : 0; }   // 0: K0, K1, K2 as separate kernels (22.5 ms on cfg3); 1: framing, table and arenas in one pass through LDS windows (k_stream_decode: exact, but 29-31 ms -- DESIGN.md says why)
+
+// framing + record table (+ the arenas of `what`) of the stream c->d_stream points at (bgp_flush / bgp_flush_decode after the upload; a batch of batch.cpp)
+int flush_core(bgp_ctx* c, uint32_t what) {
     c->piled = false; c->md_rows_ready = false; c->decoded_what = 0;
-    int rc = k0_frame(c);
-    if (rc < 0) return rc;
+    if (c->region_pending) what = 0;                     // the arenas are made for the records the filter keeps
+    int rc = 1;
+    if (frame_mode() == 1) { rc = k012_stream_decode(c, what); if (rc < 0) return rc; }
+    if (rc == 1) {                                       // the three-kernel path
+        rc = k0_frame(c);
+        if (rc < 0) return rc;
+        c->flushed = true;
+        if (fuse_mode() != 1) BGP_TRY(ensure_table(c));  // K1; only the fused experiment (BGP_FUSE_MODE=1) defers it to the decode
+        if (what) { if (c->table_pending) BGP_TRY(k12_fused_decode(c, what)); else BGP_TRY(k2_decode(c, what)); }
+    }
     c->flushed = true;
-    if (fuse_mode() != 1) BGP_TRY(ensure_table(c));      // K1; only the fused experiment (BGP_FUSE_MODE=1) defers it to the decode
     if (c->region_pending) { BGP_TRY(ensure_table(c)); BGP_TRY(k_region_filter(c, c->region_ref, c->region_beg, c->region_end)); }   // bam[ref][beg..end]
     return BGP_OK;
 }
@@ -151,7 +160,7 @@ int bgp_init(int device, bgp_ctx** out) {
 
 static void release_all(bgp_ctx* c) {
     DevBuf* d[] = {&c->d_stream_own, &c->d_synth, &c->d_seg_entry, &c->d_seg_end, &c->d_seg_cnt, &c->d_seg_lseq, &c->d_seg_ncig, &c->d_seg_dirty,
-                   &c->d_seg_rec_base, &c->d_seg_seq_base, &c->d_seg_cig_base, &c->d_seg_side, &c->d_scan_tmp, &c->d_status, &c->d_rec, &c->d_seq_off, &c->d_cigar_off,
+                   &c->d_seg_rec_base, &c->d_seg_seq_base, &c->d_seg_cig_base, &c->d_seg_side, &c->d_scan_tmp, &c->d_sd_desc, &c->d_status, &c->d_rec, &c->d_seq_off, &c->d_cigar_off,
                    &c->d_seq, &c->d_qual, &c->d_cigar, &c->d_pmax_end, &c->d_pmax_pos, &c->d_runs, &c->d_columns, &c->d_depth_hist, &c->d_pstats,
                    &c->d_tiles, &c->d_ck_off, &c->d_ck, &c->d_deep, &c->d_entry_off, &c->d_entries, &c->d_col_lo,
                    &c->d_md_row, &c->d_md_iv, &c->d_md_state, &c->d_refbase, &c->d_md_succ, &c->d_md_exit, &c->d_md_entry, &c->d_md_bmax, &c->d_md_long, &c->d_md_ck, &c->d_snp, &c->d_rec2, &c->d_seq_off2, &c->d_cigar_off2,
@@ -228,8 +237,7 @@ int bgp_attach_device_stream(bgp_ctx* c, const void* dptr, uint64_t len) {
 //   2  k12_fused<no unpack>: one lane per RECORD from the offsets k0_chase left behind, rows written coalesced,
 //      then k2_unpack as before (5.0 + 13.1 ms) -- the default.
 
-int bgp_flush(bgp_ctx* c) {
-    BGP_API_TRY
+static int flush_impl(bgp_ctx* c, uint32_t what) {
     if (!c) return BGP_EINVAL;
     BGP_HIP(hipSetDevice(c->device));
     if (!c->stream_on_device) {
@@ -237,7 +245,18 @@ int bgp_flush(bgp_ctx* c) {
         if (c->h_stage_len) BGP_HIP(hipMemcpyAsync(c->d_stream_own.p, c->h_stage.p, c->h_stage_len, hipMemcpyHostToDevice, c->stream));
         c->d_stream = c->d_stream_own.as<uint8_t>(); c->stream_len = c->h_stage_len; c->stream_on_device = true;
     }
-    return flush_core(c);
+    return flush_core(c, what & BGP_FETCH_ALL);
+}
+
+int bgp_flush(bgp_ctx* c) {
+    BGP_API_TRY
+    return flush_impl(c, 0);
+    BGP_API_CATCH(c)
+}
+
+int bgp_flush_decode(bgp_ctx* c, uint32_t what) {
+    BGP_API_TRY
+    return flush_impl(c, what);
     BGP_API_CATCH(c)
 }
 

@@ -82,6 +82,7 @@ enum : uint32_t {
     ST_EINVAL = 1u << 0, ST_ETRUNC = 1u << 1, ST_ECIGAR = 1u << 2, ST_EUNSORTED = 1u << 3, ST_ESEQ = 1u << 4, ST_EMD = 1u << 5,
 };
 int bgp_status_from_bits(uint32_t bits);      // hard errors first; ESEQ is soft
+constexpr uint32_t ST_LONGCIG = 1u << 16;      // not an error: some record has more than BGP_LONG_CIGAR ops (its end_position is finished by k1_long_cigar)
 
 struct KernelTimer {
     std::string name;
@@ -123,6 +124,7 @@ struct bgp_ctx {
     bool frame_tolerant_tail = false; uint64_t frame_tail = 0;   // batched staging (batch.cpp): a stream may end inside a record; where the record chain stopped
     bool table_pending = false, long_cigar = false;   // the record table is written lazily: by k1_table, or by the fused K1+K2 if a decode comes first
     DevBuf d_scan_tmp;
+    DevBuf d_sd_desc; int sd_timer_idx = -1;         // single-pass decode (decode.hip: k_stream_decode): control words + one 64-byte descriptor per chunk
     DevBuf d_status;                                  // uint32 status bits + counters
     bool flushed = false;
     uint64_t n_records = 0, sum_lseq = 0, sum_ncig = 0;
@@ -187,6 +189,7 @@ int k1_table(bgp_ctx* c);                                   // frame.hip : K1 al
 int k1_finish_long_cigars(bgp_ctx* c);
 int k2_decode(bgp_ctx* c, uint32_t what);                   // decode.hip
 int k12_fused_decode(bgp_ctx* c, uint32_t what);            // decode.hip : K1 + K2 in one pass over the stream
+int k012_stream_decode(bgp_ctx* c, uint32_t what);          // decode.hip : K0 + K1 + K2 in ONE pass (framing by look-back); 1 = gave up, take the three-kernel path
 constexpr uint32_t BGP_LONG_CIGAR = 32;                      // more ops than this: basesCovered is summed by a whole wave (k1_long_cigar)
 int k34_pileup(bgp_ctx* c);                                 // pileup.hip : runs + dense columns
 int k34_first_survivor(bgp_ctx* c, uint32_t run, uint64_t start_from, uint64_t* pos, uint64_t* record);
@@ -214,7 +217,7 @@ int chunks_plan(bgp_ctx* c, uint64_t block_size, uint64_t start_from, uint64_t e
 int emit_window(bgp_ctx* c, uint32_t run, uint64_t a, uint64_t b, int want_entries, int use_md, int snp, bgp_columns* o);   // api.cpp: columns [a, b) of a run to the host
 int batch_cut(bgp_ctx* c, uint64_t* last_key, uint64_t* carry_record, uint64_t* carry_off);   // pileup.hip: last covering read of the staged stream and where its exact halo starts
 void batch_release(bgp_ctx* c);   // batch.cpp
-int flush_core(bgp_ctx* c);        // api.cpp: K0 + K1 on the stream c->d_stream points at   // chunks.hip : fills c->chunks         // bai_build.hip : createIndex over the staged file
+int flush_core(bgp_ctx* c, uint32_t what = 0);        // api.cpp: framing + record table (+ the arenas of `what`) of the stream c->d_stream points at   // chunks.hip : fills c->chunks         // bai_build.hip : createIndex over the staged file
 
 // device helpers shared by kernels
 #if defined(__HIPCC__)
@@ -242,6 +245,30 @@ __device__ __forceinline__ K3Key k3_key_of(int32_t ref_id, int32_t pos, int32_t 
         k.e = rk | (uint32_t)end_pos; k.p = rk | (uint32_t)pos;
     }
     return k;
+}
+// Is there a plausible record header at stream offset o?  (readrange.d:118-173 reads block_size, then the fixed fields
+// of read.d:907-931: the test is what those fields can hold in a well-formed record.)  Only ever a GUESS for where a
+// chain of records may be entered; every boundary is verified by the chain itself.
+__device__ __forceinline__ bool plausible(const uint8_t* s, uint64_t len, uint64_t o, int32_t ref_bound, uint32_t* bs_out) {
+    if (o + 36 > len) return false;
+    const uint32_t bs = ld_u32(s + o);
+    *bs_out = bs;
+    if (bs < 33u || bs > (1u << 30) || (uint64_t)bs > len - o - 4) return false;
+    const int32_t ref = (int32_t)ld_u32(s + o + 4), pos = (int32_t)ld_u32(s + o + 8);
+    const uint32_t bmn = ld_u32(s + o + 12), fnc = ld_u32(s + o + 16);
+    const int32_t lseq = (int32_t)ld_u32(s + o + 20), nref = (int32_t)ld_u32(s + o + 24), npos = (int32_t)ld_u32(s + o + 28);
+    if (ref < -1 || ref >= ref_bound || nref < -1 || nref >= ref_bound || pos < -1 || npos < -1 || lseq < 0) return false;
+    const uint32_t l_name = bmn & 0xFFu, n_cig = fnc & 0xFFFFu;
+    if (l_name == 0) return false;
+    const uint64_t need = 32ull + l_name + 4ull * n_cig + (uint64_t)((lseq + 1) / 2) + (uint64_t)lseq;
+    if (need > bs) return false;
+    if (s[o + 36 + l_name - 1] != 0) return false;             // read name is NUL terminated
+    // ... and printable (SAM spec: [!-?A-~]{1,254}).  This is what tells a header from the same bytes read four or
+    // eight bytes early: shifted, block_size lands in the reference field, position in bin_mq_nl, ... all in range,
+    // but the "name" then starts in the zero bytes of next_pos / tlen.  (A file whose names are not printable is framed
+    // correctly all the same -- its guesses fail, the chain of records is followed serially.)
+    for (uint32_t i = 0; i + 1 < l_name; ++i) { const uint8_t ch = s[o + 36 + i]; if (ch < 0x21 || ch > 0x7E) return false; }
+    return true;
 }
 // CIGAR_TYPE bit pairs (cigar.d:113-116): bit0 query consuming, bit1 reference consuming
 __device__ __forceinline__ uint32_t cig_qc(uint32_t raw) { return (0x3C1A7u >> ((raw & 15u) * 2)) & 1u; }

@@ -22,7 +22,6 @@ namespace {
 
 constexpr uint64_t NONE = ~0ull;        // entry/end not known (speculation found nothing)
 constexpr uint64_t STOP = ~0ull - 1;    // chain is over (error upstream); segment holds no records
-constexpr uint32_t ST_LONGCIG = 1u << 16; // not an error: some record has more than LONG_CIGAR ops
 constexpr uint32_t LONG_CIGAR = BGP_LONG_CIGAR;
 
 struct FrameArgs {
@@ -33,22 +32,6 @@ struct FrameArgs {
     const uint64_t* seg_hint;            // per segment: the smallest offset inside it where the caller says a record starts (NONE: no word), or null
     int tolerant_tail;                   // batched staging: the data may end inside a record -- the chain stops in front of it instead of ETRUNC
 };
-
-__device__ __forceinline__ bool plausible(const uint8_t* s, uint64_t len, uint64_t o, int32_t ref_bound, uint32_t* bs_out) {
-    if (o + 36 > len) return false;
-    const uint32_t bs = ld_u32(s + o);
-    *bs_out = bs;
-    if (bs < 33u || bs > (1u << 30) || (uint64_t)bs > len - o - 4) return false;
-    const int32_t ref = (int32_t)ld_u32(s + o + 4), pos = (int32_t)ld_u32(s + o + 8);
-    const uint32_t bmn = ld_u32(s + o + 12), fnc = ld_u32(s + o + 16);
-    const int32_t lseq = (int32_t)ld_u32(s + o + 20), nref = (int32_t)ld_u32(s + o + 24), npos = (int32_t)ld_u32(s + o + 28);
-    if (ref < -1 || ref >= ref_bound || nref < -1 || nref >= ref_bound || pos < -1 || npos < -1 || lseq < 0) return false;
-    const uint32_t l_name = bmn & 0xFFu, n_cig = fnc & 0xFFFFu;
-    if (l_name == 0) return false;
-    const uint64_t need = 32ull + l_name + 4ull * n_cig + (uint64_t)((lseq + 1) / 2) + (uint64_t)lseq;
-    if (need > bs) return false;
-    return s[o + 36 + l_name - 1] == 0;                       // read name is NUL terminated
-}
 
 // one wave per segment
 __global__ __launch_bounds__(256) void k0_guess(FrameArgs a) {

@@ -1188,23 +1188,41 @@ __global__ __launch_bounds__(GT, BGP_G_MINW) void k4_exec(GArgs a) {
     if (t < 17) { uint32_t m[4]; for (int k = 0; k < 4; ++k) { const int v = t - 4 * k; m[k] = v >= 4 ? 0u : v <= 0 ? 0xFFFFFFFFu : 0xFFFFFFFFu << (8 * v); } tailm[t] = make_uint4(m[0], m[1], m[2], m[3]); }
     if (t < 4) reinterpret_cast<uint4*>(stage)[t] = make_uint4(~0u, ~0u, ~0u, ~0u);     // the 64 padding bytes in front of the first segment (no round writes them)
     for (int i = t; i < (G_BLKL - G_DELD) / 4; i += GT) deld[i] = 0;      // deld, nst (a window leaves them zeroed again), hist (kept for the whole range of windows)
-    unsigned long long d_pre = a.slab[tile * (uint64_t)SLAB_CAP + t];
-    TileB tb_pre = a.tiles[tile];
-    uint32_t n_pre = a.wcount[tile];
-    int32_t wd_pre = a.wdel[tile];
+    // What the next window needs first -- its header, its first descriptors -- is requested a window ahead and held in
+    // VECTOR registers (every lane loads the same header words; they are made uniform only when they are used).  Left
+    // to the compiler the header became vector loads turned into scalars on the spot: an `s_waitcnt vmcnt` right behind
+    // the "prefetch", and since gfx9 counts loads and stores with ONE in-order counter, that wait also stood for the
+    // previous window's 32 KB of column stores -- every window paid two memory round trips at its top.
+    struct Pre { unsigned long long d; uint2 col; uint4 tt; uint32_t n; int32_t wd; };
+    auto prefetch = [&](uint64_t w) {
+        Pre p;
+        p.d = a.slab[w * (uint64_t)SLAB_CAP + t];
+        const char* tp = reinterpret_cast<const char*>(a.tiles + w);
+        __builtin_memcpy(&p.col, tp + 16, 8);          // TileB: i_lo, i_hi, col_out | T0, Tend, run_start, pad
+        __builtin_memcpy(&p.tt, tp + 24, 16);
+        p.n = a.wcount[w]; p.wd = a.wdel[w];
+        return p;
+    };
+    auto settle = [](Pre& p) {                          // the values have arrived (or: wait for them here, once) and count as new
+        uint32_t dl = (uint32_t)p.d, dh = (uint32_t)(p.d >> 32);
+        asm volatile("; prefetched window settled" : "+v"(dl), "+v"(dh), "+v"(p.col.x), "+v"(p.col.y), "+v"(p.tt.x), "+v"(p.tt.y), "+v"(p.tt.w), "+v"(p.n), "+v"(p.wd));
+        p.d = ((unsigned long long)dh << 32) | dl;
+    };
+    Pre pre = prefetch(tile);
   for (; tile < tile_end; ++tile) {
 #ifdef BGP_G_PROF
     unsigned long long pacc_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long stamp_ = __builtin_amdgcn_s_memtime();
 #endif
-    const unsigned long long d_first = d_pre;
-    const TileB tb = tb_pre;
-    const uint32_t n_desc = n_pre;
-    const int32_t wd = wd_pre;
-    if (tile + 1 < tile_end) {
-        d_pre = a.slab[(tile + 1) * (uint64_t)SLAB_CAP + t];
-        tb_pre = a.tiles[tile + 1]; n_pre = a.wcount[tile + 1]; wd_pre = a.wdel[tile + 1];
-    }
+    settle(pre);
+    const unsigned long long d_first = pre.d;
+    struct { uint64_t col_out; uint32_t T0, Tend, pad; } tb;
+    tb.col_out = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)pre.col.y) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)pre.col.x);
+    tb.T0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)pre.tt.x); tb.Tend = (uint32_t)__builtin_amdgcn_readfirstlane((int)pre.tt.y);
+    tb.pad = (uint32_t)__builtin_amdgcn_readfirstlane((int)pre.tt.w);
+    const uint32_t n_desc = (uint32_t)__builtin_amdgcn_readfirstlane((int)pre.n);
+    const int32_t wd = __builtin_amdgcn_readfirstlane(pre.wd);
+    if (tile + 1 < tile_end) pre = prefetch(tile + 1);
     if (tb.pad) continue;                                 // on the general kernel's list
 #if BGP_G_ABL >= 4
     if (tb.T0 != 0xFFFFFFFFu) continue;
@@ -1247,12 +1265,15 @@ __global__ __launch_bounds__(GT, BGP_G_MINW) void k4_exec(GArgs a) {
             n_fit = misc[16]; n_chunks = misc[17];
         }
         if ((uint32_t)t >= n_fit) kind = 0;
+        {   // every byte the round may look at starts as padding (0xFF): consecutive lanes, consecutive 16 bytes -- no bank conflicts,
+            // where four stores per segment at the segments' own addresses had plenty
+            const uint32_t extent = min((uint32_t)G_STAGE, 64 + 16 * (total & 0xFFFFu));
+            const uint4 ff = make_uint4(~0u, ~0u, ~0u, ~0u);
+            for (uint32_t o = 64 + 16 * (uint32_t)t; o < extent; o += 16 * GT) *reinterpret_cast<uint4*>(stage + o) = ff;
+        }
         if (kind == 1) {
             const uint64_t src = d >> 23;
             segi[t] = make_uint4((uint32_t)src, (uint32_t)(src >> 32) | (nib << 16) | (len << 20), data_off, 0u);
-            uint4* padp = reinterpret_cast<uint4*>(stage + data_off + 16 * nch);
-            const uint4 ff = make_uint4(~0u, ~0u, ~0u, ~0u);
-            padp[0] = ff; padp[1] = ff; padp[2] = ff; padp[3] = ff;
             const uint32_t cdel = data_off + nib - lo + W;                   // staged byte of position p: stage[p - W + cdel]
             gd[t] = cdel | ((lo >> 6) << 16) | (((lo + len - 1) >> 6) << 21);
             const uint32_t c0 = ex >> 16;
@@ -1267,7 +1288,7 @@ __global__ __launch_bounds__(GT, BGP_G_MINW) void k4_exec(GArgs a) {
         GSTAMP(3);
         // ---- stage: 32 bases per lane, lane after lane along the segments.  Every load of the round is requested
         // before the first is looked at: one HBM round trip per round.
-        uint4 pk[STAGE_IT]; uint32_t ce[STAGE_IT];
+        uint4 pk[STAGE_IT]; uint32_t ce[STAGE_IT];     // ce: where the lane's 32 class bytes go | bytes of them inside the segment << 16 | a skipped first nibble << 24
 #if BGP_G_ABL >= 2
         if (n_desc != 0xFFFFFFFFu) { base += n_fit; continue; }
 #endif
@@ -1276,25 +1297,24 @@ __global__ __launch_bounds__(GT, BGP_G_MINW) void k4_exec(GArgs a) {
             const uint32_t c = (uint32_t)(it * GT + t);
             pk[it] = make_uint4(0, 0, 0, 0); ce[it] = 0xFFFFFFFFu;
             if (c < n_chunks) {
-                const uint32_t e = cmap[c];
+                const uint32_t e = cmap[c], sj = e & 7u;
                 const uint4 g = segi[e >> 3];
-                __builtin_memcpy(&pk[it], a.s + ((((uint64_t)(g.y & 0xFFFFu)) << 32) | g.x) + 16u * (e & 7u), 16);
-                ce[it] = e;
+                __builtin_memcpy(&pk[it], a.s + ((((uint64_t)(g.y & 0xFFFFu)) << 32) | g.x) + 16u * sj, 16);
+                const uint32_t glen = g.y >> 20, gnib = (g.y >> 16) & 1u;
+                ce[it] = (g.z + 32u * sj) | (min(glen + gnib - 32u * sj, 32u) << 16) | ((sj == 0 ? gnib : 0u) << 24);
             }
         }
         GSTAMP(4);    // staging loads issued
 #pragma unroll
         for (int it = 0; it < STAGE_IT; ++it) {
             if (ce[it] != 0xFFFFFFFFu) {
-                const uint4 g = segi[ce[it] >> 3];
-                const uint32_t sj = ce[it] & 7u, glen = g.y >> 20, gnib = (g.y >> 16) & 1u;
-                const int32_t valid = (int32_t)(glen + gnib) - 32 * (int32_t)sj;     // staged bytes of this lane that belong to the segment (incl. the skipped nibble): > 0
+                const int32_t valid = (int32_t)((ce[it] >> 16) & 0xFFu);           // staged bytes of this lane that belong to the segment (incl. the skipped nibble): 1..32
                 const uint2 c0 = class_bits8(pk[it].x), c1 = class_bits8(pk[it].y), c2 = class_bits8(pk[it].z), c3 = class_bits8(pk[it].w);
-                const uint4 t0 = tailm[min(valid, 16)], t1 = tailm[min(max(valid - 16, 0), 16)];
+                const uint4 t0 = tailm[min(valid, 16)], t1 = tailm[max(valid - 16, 0)];
                 uint4 o0 = make_uint4(c0.x | t0.x, c0.y | t0.y, c1.x | t0.z, c1.y | t0.w);
                 const uint4 o1 = make_uint4(c2.x | t1.x, c2.y | t1.y, c3.x | t1.z, c3.y | t1.w);
-                if (sj == 0 && gnib) o0.x |= 0xFFu;
-                uint4* dst = reinterpret_cast<uint4*>(stage + g.z + 32 * sj);
+                if (ce[it] >> 24) o0.x |= 0xFFu;
+                uint4* dst = reinterpret_cast<uint4*>(stage + (ce[it] & 0xFFFFu));
                 dst[0] = o0; dst[1] = o1;                                         // (a second half past the segment lands in its own padding)
             }
         }
@@ -1342,6 +1362,7 @@ __global__ __launch_bounds__(GT, BGP_G_MINW) void k4_exec(GArgs a) {
         GSTAMP(7);    // gathered (no barrier here: whatever overwrites the tables or the staged bytes next does so behind a barrier of its own)
         base += n_fit;
     }
+    settle(pre);      // (before the column stores are issued: nothing behind them in the counter is waited for at the next window's top)
     // ---- flush: the '-' difference array summed up (a wave scans its own positions with DPP, the waves before it
     // enter as one number each), then 32 contiguous bytes per position.  What a lane reads of deld / nst it zeroes for
     // the next window (whose first barrier comes before anything is added again).

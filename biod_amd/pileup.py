@@ -117,8 +117,12 @@ class Context:
         return n.value
 
     # -- decode
-    def flush(self):
-        L.check(L.lib().bgp_flush(self._h), self._h)
+    def flush(self, decode: int = 0):
+        """Framing + record table; with `decode` (BGP_FETCH_* bits) the arenas are made in the same pass over the stream."""
+        if decode:
+            L.check(L.lib().bgp_flush_decode(self._h, decode), self._h)
+        else:
+            L.check(L.lib().bgp_flush(self._h), self._h)
 
     def num_records(self) -> int:
         n = C.c_uint64()

@@ -104,6 +104,12 @@ typedef struct bgp_record {      /* 32 bytes per record, SURVEY.md 8(a2) */
 } bgp_record;
 
 int bgp_flush(bgp_ctx* ctx);
+/* bgp_flush with the arenas of `what` (BGP_FETCH_SEQ | _QUAL | _CIGAR) made in the same pass over the stream: framing,
+ * rows and unpack are one kernel that reads every stream byte once (the shape of BamReadRange feeding
+ * read.sequence / base_qualities / cigar as it goes, readrange.d:118-173 + read.d:225-228,364-383,468-470).  A
+ * following bgp_decode_device / _fetch for the same sections finds them done.  Same results and errors as bgp_flush
+ * followed by bgp_decode_device(what). */
+int bgp_flush_decode(bgp_ctx* ctx, uint32_t what);
 int bgp_num_records(bgp_ctx* ctx, uint64_t* n);
 
 typedef struct bgp_records {
