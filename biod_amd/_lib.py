@@ -20,12 +20,14 @@ BGP_FETCH_STREAM = 8
 BGP_PILEUP_COLUMNS, BGP_MAKE_PILEUP = 0, 1
 BGP_DEPTH_BINS = 65536
 BGP_SNP_NO, BGP_SNP_YES, BGP_SNP_TIE, BGP_SNP_NEEDS_ENTRIES = 0, 1, 2, 3
+BGP_MAQ_CALLED, BGP_MAQ_VARIANT, BGP_MAQ_SUBSAMPLED = 1, 2, 4
 BGP_UOFFSET_UNKNOWN = 0xFFFFFFFF
 
 RECORD_DTYPE = np.dtype([("ref_id", "<i4"), ("pos", "<i4"), ("end_pos", "<i4"), ("bin_mq_nl", "<u4"),
                          ("flag_nc", "<u4"), ("l_seq", "<i4"), ("rec_off", "<u8")])
 COLUMN_DTYPE = np.dtype([("coverage", "<u4"), ("n_starting_here", "<u4"), ("a", "<u4"), ("c", "<u4"),
                          ("g", "<u4"), ("t", "<u4"), ("other", "<u4"), ("del", "<u4")])
+MAQ_CALL_DTYPE = np.dtype([("quality", "<f4"), ("genotype", "u1"), ("reference_base5", "u1"), ("flags", "u1"), ("n_bases", "u1")])
 ENTRY_DTYPE = np.dtype([("read_ordinal", "<u4"), ("cigar_op_offset", "<u4"), ("query_offset", "<u4"),
                         ("cigar_op_index", "<u2"), ("base", "u1"), ("qual", "u1")])
 RUN_DTYPE = np.dtype([("ref_id", "<i4"), ("_pad", "<u4"), ("first_record", "<u8"), ("end_record", "<u8"),
@@ -46,7 +48,7 @@ class PileupInfo(C.Structure):
 
 class Columns(C.Structure):
     _fields_ = [("ref_id", C.c_int32), ("n_positions", C.c_uint32), ("first_position", C.c_uint64), ("columns", C.c_void_p),
-                ("entry_off", C.c_void_p), ("entries", C.c_void_p), ("reference_base", C.c_void_p), ("snp", C.c_void_p)]
+                ("entry_off", C.c_void_p), ("entries", C.c_void_p), ("reference_base", C.c_void_p), ("snp", C.c_void_p), ("maq", C.c_void_p)]
 
 
 class ChunkInfo(C.Structure):
@@ -90,6 +92,8 @@ SYMBOLS = {
     "bgp_pileup_next_window": (C.c_int, [_P, C.POINTER(Columns)]),
     "bgp_pileup_ref_id": (C.c_int, [_P, C.POINTER(C.c_int32)]),
     "bgp_pileup_snp": (C.c_int, [_P, C.c_int, C.c_int]),
+    "bgp_pileup_maq": (C.c_int, [_P, C.c_float, C.c_float, C.c_uint32]),
+    "bgp_maq_error_model": (C.c_int, [C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     "bgp_batch_begin": (C.c_int, [_P, C.c_uint64, C.c_int, C.c_uint32]),
     "bgp_batch_push": (C.c_int, [_P, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
     "bgp_batch_end": (C.c_int, [_P]),

@@ -88,6 +88,8 @@ int emit_window(bgp_ctx* c, uint32_t run_idx, uint64_t a, uint64_t b, int want_e
     BGP_TRY(c->h_cols.reserve(np * sizeof(bgp_column)));
     BGP_HIP(hipMemcpyAsync(c->h_cols.p, c->d_columns.as<bgp_column>() + r.column_base + (a - r.start_pos), np * sizeof(bgp_column), hipMemcpyDeviceToHost, c->stream));
     memset(o, 0, sizeof *o);
+    const bool maq = c->it.maq != 0;
+    if (maq && !want_entries) { uint64_t ne = 0; BGP_TRY(k5_entries(c, run_idx, a, b, &ne)); }     // the MAQ model reads the per-read entries on the device; they are not copied out unless asked for
     if (want_entries) {
         uint64_t ne = 0;
         BGP_TRY(k5_entries(c, run_idx, a, b, &ne));
@@ -106,6 +108,12 @@ int emit_window(bgp_ctx* c, uint32_t run_idx, uint64_t a, uint64_t b, int want_e
         BGP_TRY(c->h_snp.reserve(np + 1));
         BGP_HIP(hipMemcpyAsync(c->h_snp.p, c->d_snp.p, np, hipMemcpyDeviceToHost, c->stream));
         o->snp = c->h_snp.as<uint8_t>();
+    }
+    if (maq) {
+        BGP_TRY(k8_maq_calls(c, r.column_base + (a - r.start_pos), np, use_md));
+        BGP_TRY(c->h_maq.reserve((np + 1) * sizeof(bgp_maq_call)));
+        BGP_HIP(hipMemcpyAsync(c->h_maq.p, c->d_maq.p, np * sizeof(bgp_maq_call), hipMemcpyDeviceToHost, c->stream));
+        o->maq = c->h_maq.as<bgp_maq_call>();
     }
     BGP_HIP(hipStreamSynchronize(c->stream));
     o->ref_id = r.ref_id; o->n_positions = (uint32_t)np; o->first_position = a; o->columns = c->h_cols.as<bgp_column>();
@@ -163,10 +171,10 @@ static void release_all(bgp_ctx* c) {
                    &c->d_seg_rec_base, &c->d_seg_seq_base, &c->d_seg_cig_base, &c->d_seg_side, &c->d_scan_tmp, &c->d_sd_desc, &c->d_status, &c->d_rec, &c->d_seq_off, &c->d_cigar_off,
                    &c->d_seq, &c->d_qual, &c->d_cigar, &c->d_pmax_end, &c->d_pmax_pos, &c->d_runs, &c->d_columns, &c->d_depth_hist, &c->d_pstats,
                    &c->d_tiles, &c->d_ck_off, &c->d_ck, &c->d_deep, &c->d_entry_off, &c->d_entries, &c->d_col_lo,
-                   &c->d_md_row, &c->d_md_iv, &c->d_md_state, &c->d_refbase, &c->d_md_succ, &c->d_md_exit, &c->d_md_entry, &c->d_md_bmax, &c->d_md_long, &c->d_md_ck, &c->d_snp, &c->d_rec2, &c->d_seq_off2, &c->d_cigar_off2,
+                   &c->d_md_row, &c->d_md_iv, &c->d_md_state, &c->d_refbase, &c->d_md_succ, &c->d_md_exit, &c->d_md_entry, &c->d_md_bmax, &c->d_md_long, &c->d_md_ck, &c->d_snp, &c->d_maq, &c->d_maq_tab, &c->d_rec2, &c->d_seq_off2, &c->d_cigar_off2,
                    &c->d_seg_hint, &c->d_tilemax, &c->d_cig4, &c->d_slab, &c->d_wcount, &c->d_wdel, &c->d_wslow, &c->d_flt[0], &c->d_flt[1], &c->d_flt[2], &c->d_flt[3], &c->d_flt[4], &c->d_flt[5], &c->d_comp, &c->d_inf_blk};
     for (auto* b : d) b->release();
-    HostBuf* h[] = {&c->h_stage, &c->h_rec, &c->h_seq_off, &c->h_cigar_off, &c->h_seq, &c->h_qual, &c->h_cigar, &c->h_cols, &c->h_entry_off, &c->h_entries, &c->h_refbase, &c->h_snp, &c->h_ring, &c->h_stream_copy};
+    HostBuf* h[] = {&c->h_stage, &c->h_rec, &c->h_seq_off, &c->h_cigar_off, &c->h_seq, &c->h_qual, &c->h_cigar, &c->h_cols, &c->h_entry_off, &c->h_entries, &c->h_refbase, &c->h_snp, &c->h_maq, &c->h_ring, &c->h_stream_copy};
     for (auto* b : h) b->release();
 }
 
@@ -418,6 +426,14 @@ int bgp_pileup_snp(bgp_ctx* c, int min_cov, int min_wit) {
     if (!c) return BGP_EINVAL;
     if (!c->it.active || !c->it.use_md) return BGP_ESTATE;     // findSNPs piles up with reference bases (simple.d:37-41)
     c->it.snp = 1; c->it.snp_min_cov = min_cov; c->it.snp_min_wit = min_wit;
+    return BGP_OK;
+    BGP_API_CATCH(c)
+}
+int bgp_pileup_maq(bgp_ctx* c, float depcorr, float eta, uint32_t min_bq) {
+    BGP_API_TRY
+    if (!c || !(depcorr >= 0.f && depcorr <= 1.f) || !(eta >= 0.f && eta <= 1.f) || min_bq > 255) return BGP_EINVAL;
+    if (!c->it.active || c->batch) return BGP_ESTATE;
+    c->it.maq = 1; c->it.maq_depcorr = depcorr; c->it.maq_eta = eta; c->it.maq_min_bq = min_bq;
     return BGP_OK;
     BGP_API_CATCH(c)
 }

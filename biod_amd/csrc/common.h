@@ -154,10 +154,12 @@ struct bgp_ctx {
         uint64_t start_from = 0, end_at = ~0ull; uint32_t window = 0;
         uint32_t run = 0, run_end = 0; uint64_t next_pos = 0; int32_t ref_id = -1;
         int snp = 0, snp_min_cov = 5, snp_min_wit = 2;
+        int maq = 0; float maq_depcorr = 0.17f, maq_eta = 0.03f; uint32_t maq_min_bq = 13;
     } it;
     std::vector<bgp_chunk_info> chunks; int chunks_use_md = 0, chunks_want_entries = 0; uint32_t chunks_window = 0; bool chunks_ready = false;   // pileupChunks: the planned chunks
-    HostBuf h_cols, h_entry_off, h_entries, h_refbase, h_snp;
+    HostBuf h_cols, h_entry_off, h_entries, h_refbase, h_snp, h_maq;
     DevBuf d_snp;
+    DevBuf d_maq, d_maq_tab; bool maq_tables_ready = false; float maq_tab_depcorr = 0, maq_tab_eta = 0;   // MAQ model (maq.hip): calls of a window; fk | lhet | beta
     DevBuf d_entry_off, d_entries, d_col_lo;
     DevBuf d_md_row, d_md_iv, d_md_state, d_refbase;   // MD path: per-record rows, provider intervals, per-run controller state, dense reference bases
     DevBuf d_md_long, d_md_ck;                                    // long chunks of the provider chain: node list + counters, checkpoints
@@ -197,6 +199,7 @@ int k5_entries(bgp_ctx* c, uint32_t run, uint64_t pos_begin, uint64_t pos_end, u
 int scan_exclusive_u64(bgp_ctx* c, const uint64_t* in, uint64_t* out, uint64_t n, uint64_t* total_host);   // scan.hip (out has n+1 entries)
 int scan_inclusive_max_u64(bgp_ctx* c, const uint64_t* in, uint64_t* out, uint64_t n);
 int k7_snp_simple(bgp_ctx* c, uint64_t col_index, uint64_t np, int min_cov, int min_wit);    // md.hip: d_snp[0..np) from d_columns/d_refbase
+int k8_maq_calls(bgp_ctx* c, uint64_t col_index, uint64_t np, int use_md);                    // maq.hip: d_maq[0..np) from the window's entries (K5), the record table and d_refbase
 int k6_dna_of_record(bgp_ctx* c, uint64_t i, uint8_t* host_out, uint32_t cap, uint32_t* len, uint32_t* flags);
 int k6_reference_bases(bgp_ctx* c, int skip_zero, uint32_t run_first, uint32_t run_end, uint64_t first_record, int* md_err, int64_t* md_err_from);   // md.hip: fills d_refbase
 int synth_device(bgp_ctx* c, const bgp_synth_cfg_c* cfg, uint64_t* bytes);   // synth.hip

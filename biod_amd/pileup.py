@@ -154,13 +154,16 @@ class Context:
                           n_reads_used=info.n_reads_used, device_columns=info.device_columns or 0, device_depth_hist=info.device_depth_hist or 0)
 
     def pileup_windows(self, mode: int, use_md_tag=False, start_from=0, end_at=ULONG_MAX, skip_zero_coverage=True,
-                       want_entries=False, window_positions=0, snp=None):
+                       want_entries=False, window_positions=0, snp=None, maq=None):
         """Dense windows of columns.  snp=(minimum_coverage, minimum_witnesses) adds simple.isSNP flags per position
         (snpcallers/simple.d:15-41, needs use_md_tag): window.snp, resolved against the entries where the device says
-        BGP_SNP_NEEDS_ENTRIES and entries were requested."""
+        BGP_SNP_NEEDS_ENTRIES and entries were requested.  maq=(depcorr, eta, minimum_base_quality) adds the MAQ model's
+        call per position (snpcallers/maq.d:388-486): window.maq, a MAQ_CALL_DTYPE array."""
         L.check(L.lib().bgp_pileup_begin(self._h, mode, int(use_md_tag), start_from, end_at, int(skip_zero_coverage), int(want_entries), window_positions), self._h)
         if snp is not None:
             L.check(L.lib().bgp_pileup_snp(self._h, int(snp[0]), int(snp[1])), self._h)
+        if maq is not None:
+            L.check(L.lib().bgp_pileup_maq(self._h, float(maq[0]), float(maq[1]), int(maq[2])), self._h)
         yield from self._windows(snp)
 
     def pileup_chunks_begin(self, use_md_tag=False, block_size=16_384_000, start_from=0, end_at=ULONG_MAX, want_entries=False, window_positions=0) -> int:
@@ -236,6 +239,8 @@ class Context:
             ents = L.as_array(cw.entries, int(eoff[-1]), L.ENTRY_DTYPE) if eoff is not None else None
             refb = L.as_array(cw.reference_base, cw.n_positions, "u1") if cw.reference_base else None
             w = Window(cw.ref_id, cw.first_position, cols, eoff, ents, refb)
+            if cw.maq:
+                w.maq = L.as_array(cw.maq, cw.n_positions, L.MAQ_CALL_DTYPE)
             if snp is not None and cw.snp:
                 w.snp = L.as_array(cw.snp, cw.n_positions, "u1")
                 if ents is not None:
@@ -318,6 +323,7 @@ class Window:
         self.ref_id, self.first_position, self.columns, self.entry_off, self.entries = ref_id, first_position, columns, entry_off, entries
         self.reference_base = reference_base          # uint8 per position (use_md_tag) or None
         self.snp = None                               # uint8 per position of BGP_SNP_* (pileup_windows(snp=...)) or None
+        self.maq = None                               # MAQ_CALL_DTYPE per position (pileup_windows(maq=...)) or None
 
 
 # ------------------------------------------------------------------------------------------ reads
@@ -750,3 +756,51 @@ def pileupChunks(reads, use_md_tag=False, block_size=16_384_000, start_from=0, e
 def pileupColumns(reads, use_md_tag=False, skip_zero_coverage=True, *, want_entries=True, window_positions=0):
     """pileup.d:509-519."""
     return _Pileup(reads, L.BGP_PILEUP_COLUMNS, use_md_tag, 0, ULONG_MAX, skip_zero_coverage, want_entries, window_positions)
+
+
+# ------------------------------------------------------------------------------------------ SNP calling (snpcallers/maq.d)
+
+class DiploidCall5:
+    """Call!(DiploidGenotype, Base5), bio/core/call.d:29-88."""
+
+    def __init__(self, sample, chromosome, position, reference_base, genotype_code, quality):
+        self.sample, self.chromosome, self.position, self.reference_base, self.quality = sample, chromosome, position, reference_base, quality
+        self.base1, self.base2 = "ACGTN"[genotype_code // 5], "ACGTN"[genotype_code % 5]     # genotype.d:33-37,51-58
+
+    @property
+    def genotype(self) -> str:
+        return self.base1 + "|" + self.base2                                                 # genotype.d:71-73
+
+    @property
+    def is_heterozygous(self) -> bool:
+        return self.base1 != self.base2
+
+    @property
+    def is_variant(self) -> bool:
+        return not (self.base1 == self.base2 == self.reference_base)                          # call.d:85-87
+
+
+class MaqSnpCaller:
+    """MaqSnpCaller of bio/std/hts/snpcallers/maq.d:308-541: same property names and defaults; the model runs on the
+    device (bgp_pileup_maq).  The stated choices where the reference is not deterministic are in include/biodgpu.h."""
+
+    def __init__(self):
+        self.depcorr, self.eta, self.minimum_call_quality, self.minimum_base_quality = 0.17, 0.03, 6.0, 13   # maq.d:329-333
+
+    def calls(self, reads, reference="", sample="", use_md_tag=True, window_positions=0):
+        """makeCall (maq.d:443-486) for every column with coverage: DiploidCall5 or None (no valid base in the column)."""
+        ctx = reads._stage()
+        for w in ctx.pileup_windows(L.BGP_PILEUP_COLUMNS, use_md_tag=use_md_tag, window_positions=window_positions,
+                                    maq=(self.depcorr, self.eta, self.minimum_base_quality)):
+            for k in np.nonzero(w.columns["coverage"])[0]:
+                m = w.maq[k]
+                if not (int(m["flags"]) & L.BGP_MAQ_CALLED):
+                    yield None
+                    continue
+                yield DiploidCall5(sample, reference, int(w.first_position) + int(k), "ACGTN"[int(m["reference_base5"])], int(m["genotype"]), float(m["quality"]))
+
+    def findSNPs(self, reads, reference="", sample=""):
+        """maq.d:488-541: the calls that are variants with quality above minimum_call_quality (needs MD tags: reference bases)."""
+        for c in self.calls(reads, reference, sample, use_md_tag=True):
+            if c is not None and c.is_variant and c.quality > self.minimum_call_quality:
+                yield c

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define BGP_ABI_VERSION 1
+#define BGP_ABI_VERSION 2
 
 /* ---- status codes -------------------------------------------------------------------------- */
 enum {
@@ -204,6 +204,7 @@ typedef struct bgp_columns {
     const bgp_entry* entries;    /* host, reads of column k: entries[entry_off[k] .. entry_off[k+1]) in file order */
     const uint8_t* reference_base; /* host, n_positions (use_md_tag) or NULL                      */
     const uint8_t* snp;          /* host, n_positions of BGP_SNP_* after bgp_pileup_snp, else NULL */
+    const struct bgp_maq_call* maq; /* host, n_positions after bgp_pileup_maq, else NULL             */
 } bgp_columns;
 int bgp_pileup_begin(bgp_ctx* ctx, int mode, int use_md_tag, uint64_t start_from, uint64_t end_at,
                      int skip_zero_coverage, int want_entries, uint32_t window_positions);
@@ -268,6 +269,34 @@ int bgp_pileup_chunk(bgp_ctx* ctx, uint64_t k, bgp_chunk_info* out);
 #define BGP_SNP_TIE 2
 #define BGP_SNP_NEEDS_ENTRIES 3
 int bgp_pileup_snp(bgp_ctx* ctx, int minimum_coverage, int minimum_witnesses);
+
+/* MaqSnpCaller.makeCall (bio/std/hts/snpcallers/maq.d:443-486) for every position of the windows that follow (call after
+ * bgp_pileup_begin; with use_md_tag the call knows its reference base, without it the base is 'N' as in :455-459):
+ * the reads of a column that count (current_base_quality >= minimum_base_quality, current_base != '-', :400-412), each
+ * with quality min(base quality, mapping quality) and its strand; computeLikelihoods (:133-240) over them with the
+ * error model ErrorModelCoefficients(depcorr, eta) (:73-118; MaqSnpCaller's defaults 0.17, 0.03, minimum base quality
+ * 13); the genotype with the lowest score and the distance to the second lowest (:245-279,466-471).
+ * findSNPs (:488-541) is then: (flags & BGP_MAQ_CALLED) && (flags & BGP_MAQ_VARIANT) && quality > minimum_call_quality
+ * (default 6.0) -- a filter the caller applies.
+ * Where the reference's result is not a function of its input, stated: its sort by quality is unstable and its sums
+ * depend on the order among equal qualities (:146-166) -- the order here is file order; above 255 valid bases it takes
+ * a RANDOM sample of 255 (:141-143) -- here the first 255, flagged BGP_MAQ_SUBSAMPLED; it subtracts in 80-bit `real`
+ * before rounding a heterozygous score to float (:203-207) -- done in double here (one float ulp at most).  The reference
+ * has no test for this module: results are identical to oracle/maq_oracle.py, which restates it with the same choices. */
+typedef struct bgp_maq_call {
+    float quality;               /* gts[1].score - gts[0].score, maq.d:470 (call.quality)                          */
+    uint8_t genotype;            /* DiploidGenotype!Base5 code of gts[0]: base1 * 5 + base2, A C G T N = 0..4 (genotype.d:33-37); 0xFF: no call */
+    uint8_t reference_base5;     /* Base5(column.reference_base): 0..3, 4 = N                                      */
+    uint8_t flags;               /* BGP_MAQ_*                                                                      */
+    uint8_t n_bases;             /* bases that entered computeLikelihoods (<= 255)                                 */
+} bgp_maq_call;
+#define BGP_MAQ_CALLED 1u        /* the column has a valid base: makeCall returns a call                            */
+#define BGP_MAQ_VARIANT 2u       /* call.is_variant: genotype != homozygous reference (call.d:85-87)                */
+#define BGP_MAQ_SUBSAMPLED 4u    /* more than 255 valid bases: the first 255 were used                              */
+int bgp_pileup_maq(bgp_ctx* ctx, float depcorr, float eta, uint32_t minimum_base_quality);
+/* ErrorModelCoefficients(depcorr, eta) (maq.d:73-118) as the device uses them, computed on the host: fk[256],
+ * lhet[256 * 256] (index n << 8 | k), beta[64 * 256 * 256] (index q << 16 | n << 8 | k).  Needs no device. */
+int bgp_maq_error_model(float depcorr, float eta, double* fk, double* lhet, double* beta);
 
 /* dna(read): the reference bases a read spans, rebuilt from its CIGAR and MD tag
  * (bio/std/hts/bam/md/reconstruct.d:38-214, mdOperations bio/std/hts/bam/md/parse.d:13-142).

@@ -109,7 +109,7 @@ struct PileupRead {
 
 // PileupColumn, pileup.d:236-290
 struct PileupColumn {
-    int ref_id_; uint64_t position_; const bgp_column* c; const bgp_entry* ents; size_t n_ents; const bgp_records* recs; char refbase_; int snp_ = -1;
+    int ref_id_; uint64_t position_; const bgp_column* c; const bgp_entry* ents; size_t n_ents; const bgp_records* recs; char refbase_; int snp_ = -1; const bgp_maq_call* maq_ = nullptr;
     size_t coverage() const { return c->coverage; }                            // pileup.d:252
     int ref_id() const { return ref_id_; }                                     // pileup.d:257
     uint64_t position() const { return position_; }                            // pileup.d:262
@@ -134,6 +134,12 @@ struct PileupColumn {
         return n_top == 1 ? BGP_SNP_NO : BGP_SNP_TIE;
     }
     std::string bases() const { std::string s; for (size_t i = 0; i < n_ents; ++i) s.push_back((char)ents[i].base); return s; }   // pileup.d:277
+    // MaqSnpCaller.makeCall(column), snpcallers/maq.d:443-486, after PileupRange::callMaq: nullptr without it; a call whose
+    // flags lack BGP_MAQ_CALLED is makeCall's null (no valid base).  genotype = base1 * 5 + base2 over "ACGTN".
+    const bgp_maq_call* maq_call() const { return maq_; }
+    bool is_maq_snp(float minimum_call_quality = 6.0f) const {                  // what findSNPs yields, maq.d:519-526
+        return maq_ && (maq_->flags & BGP_MAQ_CALLED) && (maq_->flags & BGP_MAQ_VARIANT) && maq_->quality > minimum_call_quality;
+    }
 };
 
 // The input range (empty/front/popFront, pileup.d:335-397) over device-computed windows.
@@ -156,13 +162,19 @@ public:
     PileupColumn front() const {
         const uint64_t a = want_entries_ ? w_.entry_off[k_] : 0, b = want_entries_ ? w_.entry_off[k_ + 1] : 0;
         return PileupColumn{w_.ref_id, w_.first_position + k_, w_.columns + k_, want_entries_ ? w_.entries + a : nullptr, (size_t)(b - a), &recs_,
-                            w_.reference_base ? (char)w_.reference_base[k_] : 'N', w_.snp ? (int)w_.snp[k_] : -1};
+                            w_.reference_base ? (char)w_.reference_base[k_] : 'N', w_.snp ? (int)w_.snp[k_] : -1, w_.maq ? w_.maq + k_ : nullptr};
     }
     void popFront() { ++k_; settle(); }
     // findSNPs' settings (simple.d:8-13,37-41); call right after construction with use_md_tag = true
     PileupRange& callSNPs(int minimum_coverage = 5, int minimum_witnesses = 2) {
         snp_ = true; snp_cov_ = minimum_coverage; snp_wit_ = minimum_witnesses;
         restart();                                                             // the first window was fetched without verdicts
+        return *this;
+    }
+    // MaqSnpCaller's settings (maq.d:329-333): every column then carries the model's call
+    PileupRange& callMaq(float depcorr = 0.17f, float eta = 0.03f, unsigned minimum_base_quality = 13) {
+        maq_ = true; maq_depcorr_ = depcorr; maq_eta_ = eta; maq_min_bq_ = minimum_base_quality;
+        restart();
         return *this;
     }
     uint64_t start_position() const { return start_; }                         // pileup.d:445
@@ -189,6 +201,7 @@ private:
         }
         check(bgp_pileup_begin(ctx_, mode_, use_md_, start_, end_, skip_zero_, want_entries_, window_), ctx_);
         if (snp_) check(bgp_pileup_snp(ctx_, snp_cov_, snp_wit_), ctx_);
+        if (maq_) check(bgp_pileup_maq(ctx_, maq_depcorr_, maq_eta_, maq_min_bq_), ctx_);
         if (mode_ == BGP_MAKE_PILEUP) check(bgp_pileup_ref_id(ctx_, &ref_id_), ctx_);
         done_ = false;
         fetch(); settle();
@@ -203,6 +216,7 @@ private:
     }
     bgp_ctx* ctx_; bool skip_zero_, want_entries_; uint64_t start_, end_;
     int mode_; bool use_md_; uint32_t window_; bool snp_ = false; int snp_cov_ = 5, snp_wit_ = 2;
+    bool maq_ = false; float maq_depcorr_ = 0.17f, maq_eta_ = 0.03f; unsigned maq_min_bq_ = 13;
     bgp_columns w_{}; bgp_records recs_{}; uint32_t k_ = 0; bool done_ = false; int32_t ref_id_ = -1;
     int64_t chunk_ = -1; bgp_chunk_info ci_{};
 };

@@ -79,6 +79,23 @@ int main(int argc, char** argv) {
             ++verdicts;
         }
         REQUIRE(verdicts == cols);
+        // snpcallers/maq.d:443-486 through the facade: a call for every covered column; columns whose valid bases all agree
+        // with the reference call it homozygous reference, and no such column is one of findSNPs' SNPs
+        size_t calls = 0;
+        auto maq = makePileup(bam.reads(), true);
+        maq.callMaq();
+        for (auto column : maq) {
+            const bgp_maq_call* m = column.maq_call();
+            REQUIRE(m != nullptr);
+            if (!(m->flags & BGP_MAQ_CALLED)) { REQUIRE(m->genotype == 0xFF); continue; }
+            REQUIRE(m->genotype < 25); REQUIRE(m->quality >= 0.f);
+            bool all_ref = true;
+            for (char c : column.bases()) all_ref = all_ref && (c == column.reference_base() || c == '-');
+            const char rb = column.reference_base();
+            if (all_ref && (rb == 'A' || rb == 'C' || rb == 'G' || rb == 'T')) { REQUIRE(!(m->flags & BGP_MAQ_VARIANT)); REQUIRE(!column.is_maq_snp()); }
+            ++calls;
+        }
+        REQUIRE(calls > 100);
         // pileup.d:1011-1015 through the facade: the chunks' columns, one chunk after the other, are pileupColumns'
         std::vector<uint64_t> whole, piece;
         for (auto column : pileupColumns(bam.reads(), false, true, false)) whole.push_back(((uint64_t)column.ref_id() << 40) ^ (column.position() << 8) ^ column.coverage());

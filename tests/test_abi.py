@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in include/biodgpu.h but not exported by libbiodgpu.so"
     assert declared == set(L.SYMBOLS), declared ^ set(L.SYMBOLS)
-    assert lib.bgp_abi_version() == 1
+    assert lib.bgp_abi_version() == 2          # 2: bgp_columns grew `maq`
 
 
 def test_header_cites_reference_for_every_entry_point():
@@ -41,8 +41,8 @@ def test_header_cites_reference_for_every_entry_point():
 
 
 def test_struct_layouts_match_header():
-    assert C.sizeof(L.Records) == 72 and C.sizeof(L.Columns) == 56 and C.sizeof(L.SynthCfg) == 40
-    assert L.RECORD_DTYPE.itemsize == 32 and L.COLUMN_DTYPE.itemsize == 32 and L.ENTRY_DTYPE.itemsize == 16
+    assert C.sizeof(L.Records) == 72 and C.sizeof(L.Columns) == 64 and C.sizeof(L.SynthCfg) == 40
+    assert L.RECORD_DTYPE.itemsize == 32 and L.COLUMN_DTYPE.itemsize == 32 and L.ENTRY_DTYPE.itemsize == 16 and L.MAQ_CALL_DTYPE.itemsize == 8
 
 
 def test_strerror_covers_all_codes():
