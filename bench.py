@@ -246,7 +246,7 @@ def main():
     def step():
         ctx.reset()
         ctx.attach_device_stream(sptr, slen)
-        ctx.flush(decode=L.BGP_FETCH_ALL)                          # framing + record table + seq/qual/cigar arenas: one pass over the stream (BGP_FRAME_MODE=0: K0, K1, K2 as three kernels)
+        ctx.flush(decode=L.BGP_FETCH_ALL)                          # K0 framing, then record table + seq/qual/cigar arenas in one kernel over LDS windows (BGP_LDS_DECODE=0: k1_rows, k2_unpack)
         ctx.decode_device(L.BGP_FETCH_ALL)                         # (the arenas are there already: hands out the pointers)
         info = ctx.pileup_run()                                    # K3 + K4 dense columns
         if with_comm:                                              # the path's only exchange: whole-BAM depth histogram, RCCL over xGMI, in place
@@ -326,7 +326,7 @@ def main():
                                    f"l_seq {cfg.len_min}-{cfg.len_max}, {cfg.n_ref * (world if strong else 1)} contigs x {cfg.ref_len} bp"
                                    f"{', split by contig over the ranks' if strong and world > 1 else ''})",
                        "reads_per_gpu": n_reads, "inflated_bytes_per_gpu": stream_bytes, "parallelism": f"contig-sharded x{world}",
-                       "step": "K0 framing + K1 record table + K2 seq/qual/cigar unpack + K3 run keys + K4 pileup columns (plan + gather)"
+                       "step": "K0 framing + K1 record table and K2 seq/qual/cigar unpack (one kernel over LDS windows, k12_lds) + K3 run keys + K4 pileup columns (plan + gather)"
                                + (" + depth-histogram all-reduce (bgp_hist_reduce, RCCL)" if with_comm else "")},
             "pileup_columns_per_s": round(job_columns / dt * a.steps, 1),
             "columns_per_step": job_columns, "sum_coverage_per_step": job_cov,

@@ -20,6 +20,7 @@ void bgp_note_hip_error(hipError_t e, const char* what, const char* file, int li
 static int fuse_mode() { const char* e = getenv("BGP_FUSE_MODE"); return e ? atoi(e) : 2; }   // 0: chase-based K1, then K2; 1: K1+K2 fused; 2: parallel K1 from the side offsets, then K2
 static int ensure_table(bgp_ctx* c) { return !c->table_pending ? BGP_OK : (fuse_mode() == 0 ? k1_table(c) : k12_fused_decode(c, 0)); }
 
+static int lds_mode() { const char* e = getenv("BGP_LDS_DECODE"); return e ? atoi(e) : 1; }      // bgp_flush_decode(all sections): K1 + K2 as one kernel over LDS windows (k12_lds) when K0's segments allow it; 0: k1_rows, k2_unpack
 static int frame_mode() { const char* e = getenv("BGP_FRAME_MODE"); return e ? atoi(e) : 0; }   // 0: K0, K1, K2 as separate kernels (22.5 ms on cfg3); 1: framing, table and arenas in one pass through LDS windows (k_stream_decode: exact, but 29-31 ms -- DESIGN.md says why)
 
 // framing + record table (+ the arenas of `what`) of the stream c->d_stream points at (bgp_flush / bgp_flush_decode after the upload; a batch of batch.cpp)
@@ -28,12 +29,18 @@ int flush_core(bgp_ctx* c, uint32_t what) {
     if (c->region_pending) what = 0;                     // the arenas are made for the records the filter keeps
     int rc = 1;
     if (frame_mode() == 1) { rc = k012_stream_decode(c, what); if (rc < 0) return rc; }
-    if (rc == 1) {                                       // the three-kernel path
+    if (rc == 1) {                                       // K0, then K1 and K2
+        const bool lds = lds_mode() && (what & BGP_FETCH_ALL) == BGP_FETCH_ALL;
+        c->seg_bytes_wanted = lds ? k12_lds_segment_bytes() : 0;
         rc = k0_frame(c);
+        c->seg_bytes_wanted = 0;
         if (rc < 0) return rc;
         c->flushed = true;
-        if (fuse_mode() != 1) BGP_TRY(ensure_table(c));  // K1; only the fused experiment (BGP_FUSE_MODE=1) defers it to the decode
-        if (what) { if (c->table_pending) BGP_TRY(k12_fused_decode(c, what)); else BGP_TRY(k2_decode(c, what)); }
+        if (lds && k12_lds_applies(c, what)) BGP_TRY(k12_lds_decode(c, what));      // rows and arenas from LDS windows: the stream is read once more, not twice
+        else {
+            if (fuse_mode() != 1) BGP_TRY(ensure_table(c));  // K1; only the fused experiment (BGP_FUSE_MODE=1) defers it to the decode
+            if (what) { if (c->table_pending) BGP_TRY(k12_fused_decode(c, what)); else BGP_TRY(k2_decode(c, what)); }
+        }
     }
     c->flushed = true;
     if (c->region_pending) { BGP_TRY(ensure_table(c)); BGP_TRY(k_region_filter(c, c->region_ref, c->region_beg, c->region_end)); }   // bam[ref][beg..end]

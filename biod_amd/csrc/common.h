@@ -121,6 +121,7 @@ struct bgp_ctx {
     DevBuf d_seg_entry, d_seg_end, d_seg_cnt, d_seg_lseq, d_seg_ncig, d_seg_dirty;   // per segment
     DevBuf d_seg_rec_base, d_seg_seq_base, d_seg_cig_base;
     DevBuf d_seg_side; uint32_t side_cap = 0;         // per segment: offsets of its records relative to the segment start (written by k0_chase)
+    uint32_t seg_bytes_wanted = 0;                    // K0: segment size asked for (0: its own choice)
     bool frame_tolerant_tail = false; uint64_t frame_tail = 0;   // batched staging (batch.cpp): a stream may end inside a record; where the record chain stopped
     bool table_pending = false, long_cigar = false;   // the record table is written lazily: by k1_table, or by the fused K1+K2 if a decode comes first
     DevBuf d_scan_tmp;
@@ -191,6 +192,7 @@ int k1_table(bgp_ctx* c);                                   // frame.hip : K1 al
 int k1_finish_long_cigars(bgp_ctx* c);
 int k2_decode(bgp_ctx* c, uint32_t what);                   // decode.hip
 int k12_fused_decode(bgp_ctx* c, uint32_t what);            // decode.hip : K1 + K2 in one pass over the stream
+bool k12_lds_applies(const bgp_ctx* c, uint32_t what); uint32_t k12_lds_segment_bytes(); int k12_lds_decode(bgp_ctx* c, uint32_t what);   // decode.hip : K1 + K2 through LDS windows, framing from K0
 int k012_stream_decode(bgp_ctx* c, uint32_t what);          // decode.hip : K0 + K1 + K2 in ONE pass (framing by look-back); 1 = gave up, take the three-kernel path
 constexpr uint32_t BGP_LONG_CIGAR = 32;                      // more ops than this: basesCovered is summed by a whole wave (k1_long_cigar)
 int k34_pileup(bgp_ctx* c);                                 // pileup.hip : runs + dense columns
@@ -269,8 +271,22 @@ __device__ __forceinline__ bool plausible(const uint8_t* s, uint64_t len, uint64
     // ... and printable (SAM spec: [!-?A-~]{1,254}).  This is what tells a header from the same bytes read four or
     // eight bytes early: shifted, block_size lands in the reference field, position in bin_mq_nl, ... all in range,
     // but the "name" then starts in the zero bytes of next_pos / tlen.  (A file whose names are not printable is framed
-    // correctly all the same -- its guesses fail, the chain of records is followed serially.)
-    for (uint32_t i = 0; i + 1 < l_name; ++i) { const uint8_t ch = s[o + 36 + i]; if (ch < 0x21 || ch > 0x7E) return false; }
+    // correctly all the same -- its guesses fail, the chain of records is followed serially.)  Eight bytes a load: a
+    // byte b is in [0x21, 0x7E] iff its top bit is clear, b + 0x5F carries into the top bit and b + 0x01 does not.
+    const uint32_t nl = l_name - 1;
+    const uint8_t* nm = s + o + 36;
+    auto printable8 = [](unsigned long long v, unsigned long long keep) {
+        const unsigned long long H = 0x8080808080808080ull, t7 = v & ~H;
+        const unsigned long long bad = (v & H) | (~(t7 + 0x5F5F5F5F5F5F5F5Full) & H) | ((t7 + 0x0101010101010101ull) & H);
+        return (bad & keep) == 0;
+    };
+    uint32_t i = 0;
+    for (; i + 8 <= nl; i += 8) { unsigned long long v; __builtin_memcpy(&v, nm + i, 8); if (!printable8(v, ~0ull)) return false; }
+    if (i < nl) {
+        if (nl >= 8) { unsigned long long v; __builtin_memcpy(&v, nm + nl - 8, 8); return printable8(v, ~0ull); }           // the last eight (overlapping what was seen)
+        if (o + 36 + 8 <= len) { unsigned long long v; __builtin_memcpy(&v, nm, 8); return printable8(v, (1ull << (8 * nl)) - 1); }
+        for (; i < nl; ++i) { const uint8_t ch = nm[i]; if (ch < 0x21 || ch > 0x7E) return false; }
+    }
     return true;
 }
 // CIGAR_TYPE bit pairs (cigar.d:113-116): bit0 query consuming, bit1 reference consuming

@@ -169,6 +169,9 @@ __global__ __launch_bounds__(256) void k2_unpack(DecArgs a) {
 // into arena offsets with a block scan, write the rows coalesced, and unpack -- the 29 GB stream is read once
 // instead of twice.
 constexpr int G_SEG = 8;
+#ifndef BGP_K12_MINW
+#define BGP_K12_MINW 4
+#endif
 
 struct FusedArgs {
     DecArgs d;
@@ -197,7 +200,7 @@ __device__ __forceinline__ void block_excl2(uint64_t v0, uint64_t v1, uint64_t* 
 }
 
 template <bool SEQ, bool QUAL, bool CIG>
-__global__ __launch_bounds__(256) void k12_fused(FusedArgs a) {
+__global__ __launch_bounds__(256, BGP_K12_MINW) void k12_fused(FusedArgs a) {
     __shared__ uint64_t s_seq_off[RB + 1];
     __shared__ uint64_t s_cig_off[RB + 1];
     __shared__ RecInfo s_info[RB];
@@ -321,14 +324,17 @@ __global__ __launch_bounds__(256) void k12_fused(FusedArgs a) {
 #ifndef BGP_SD_NW
 #define BGP_SD_NW 8
 #define BGP_SD_NS 4
-#define BGP_SD_SC 9216
-#define BGP_SD_MINW 6
+#define BGP_SD_SC 8192
+#define BGP_SD_MINW 8                          // four 512-thread workgroups per CU (40 KB of LDS each, <= 64 VGPRs): k12_lds 14.7 -> 13.5 ms against three
+#endif
+#ifndef BGP_SD_OV
+#define BGP_SD_OV 2048
 #endif
 constexpr int SD_NW = BGP_SD_NW;                   // waves of a workgroup
 constexpr int SD_NS = BGP_SD_NS;                   // sub-chunks framed side by side (one wave each; fewer sub-chunks: fewer guesses -- the kernel is bound by VALU issue -- but longer serial chases)
 constexpr uint32_t SD_SC = BGP_SD_SC;              // bytes of a sub-chunk
 constexpr uint32_t SD_C = SD_NS * SD_SC;           // stream bytes a workgroup owns at a time
-constexpr uint32_t SD_OV = 4096;                   // how far past its chunk the LDS window reaches
+constexpr uint32_t SD_OV = BGP_SD_OV;                   // how far past its chunk the LDS window reaches
 constexpr uint32_t SD_WIN = SD_C + SD_OV;
 constexpr int SD_T = 64 * SD_NW;
 constexpr int SD_RB = 256;                         // records per emission round (rows: one lane each)
@@ -338,13 +344,14 @@ typedef unsigned long long u64;
 constexpr u64 G_VAL = (1ull << 56) - 1, G_NONE = G_VAL, G_STOP = G_VAL - 1, G_A = 1ull << 56, G_P = 2ull << 56, G_TAG = 0xFFull << 56;
 // LDS map (bytes)
 constexpr uint32_t L_ROFF = SD_WIN + 32;                              // u16[SD_RMAX]: where the chunk's records start (window offsets)
-constexpr uint32_t L_TAB = (L_ROFF + 2 * SD_RMAX + 15) & ~15u;        // emission tables: soff u32[257] | coff u32[257] | info u32[3 x 256] -- before that, the sub-chunks' own offset lists
+constexpr uint32_t L_TAB = (L_ROFF + 2 * SD_RMAX + 15) & ~15u;        // emission tables: soff u32[257] | coff u32[257] | info u16[3 x 256] -- before that, the sub-chunks' own offset lists
 constexpr uint32_t L_SOFF = L_TAB, L_COFF = L_TAB + 1040, L_INFO = L_TAB + 2080;
 constexpr uint32_t L_SUB = L_TAB;                                     // u16[SD_NS][SD_SUBCAP]
-constexpr uint32_t L_MISC = L_INFO + 3072;                            // u64[84]
+constexpr uint32_t L_MISC = L_INFO + 1536;                            // u64[84]
 constexpr uint32_t L_TOTAL = L_MISC + 8 * 84;
-static_assert(SD_NS * SD_SUBCAP * 2 <= 2080 + 3072, "the sub-chunk lists overlay the emission tables");
+static_assert(SD_WIN + 32 <= 65535 && SD_NS * SD_SUBCAP * 2 <= 2080 + 1536, "the sub-chunk lists overlay the emission tables");
 static_assert(SD_C % 16 == 0 && SD_T <= 1024 && SD_RB <= SD_T, "geometry");
+static_assert(BGP_SD_MINW * 4 / SD_NW * L_TOTAL <= 160 * 1024, "the workgroups the launch bounds promise must fit the LDS");
 enum { M_TICKET = 0, M_FOUND, M_CNT, M_EXIT, M_ERR, M_BAD, M_LS, M_NC, M_FLAGS, M_ENT, M_PN, M_PLS, M_PNC, M_ABORT, M_TM = 16 /* 4 tile maxima */, M_WS = 20 /* 2 x 8 u64 of scan scratch */,
        M_SUBG = 36 /* SD_NS guesses */, M_SUBX = 44 /* exits */, M_SUBC = 52 /* records | status << 32 */, M_EFF = 60 /* records the chunk's chain takes from the sub-chunk */, M_SUBLS = 68 /* bases */, M_SUBNC = 76 /* CIGAR ops | a CIGAR longer than BGP_LONG_CIGAR << 63 */, M_N = 84 };
 static_assert(SD_NS <= 8 && SD_NS <= SD_NW, "misc slots; a wave per sub-chunk");
@@ -455,7 +462,7 @@ __device__ __forceinline__ int find_rec32(const uint32_t* off, int cnt, uint32_t
 // unpack_group for records that lie in the LDS window: soff / coff are relative to the group's first arena offsets B0 / C0,
 // info[3j..] = window offsets of record j's CIGAR, SEQ and QUAL sections
 template <bool SEQ, bool QUAL, bool CIG>
-__device__ __forceinline__ void unpack_lds(const SdArgs& a, const uint32_t* w, int cnt, uint64_t B0, uint64_t C0, const uint32_t* soff, const uint32_t* coff, const uint32_t* info) {
+__device__ __forceinline__ void unpack_lds(const SdArgs& a, const uint32_t* w, int cnt, uint64_t B0, uint64_t C0, const uint32_t* soff, const uint32_t* coff, const uint16_t* info) {
     const uint8_t* wb = reinterpret_cast<const uint8_t*>(w);
     if (CIG) {
         const uint32_t ctot = coff[cnt];
@@ -490,7 +497,7 @@ __device__ __forceinline__ void unpack_lds(const SdArgs& a, const uint32_t* w, i
                 if (QUAL) qv = wl128(w, info[3 * j + 2] + q0);
                 if (two) {
                     const int32_t nq = -(int32_t)n1;
-                    if (SEQ) sv = merge16(sv, expand16_w(w, (uint32_t)((int32_t)info[3 * j2 + 1] + (nq >> 1)), (uint32_t)nq & 1u), n1);
+                    if (SEQ) sv = merge16(sv, expand16_w(w, (uint32_t)((int32_t)(uint32_t)info[3 * j2 + 1] + (nq >> 1)), (uint32_t)nq & 1u), n1);
                     if (QUAL) qv = merge16(qv, wl128(w, info[3 * j2 + 2] - n1), n1);
                 }
                 if (SEQ) nt_store16(a.seq + B, sv);
@@ -714,6 +721,120 @@ __device__ __forceinline__ void sd_excl2(uint32_t v0, uint32_t v1, uint32_t* e0,
     __syncthreads();
 }
 
+// The emission of a chunk whose records' window offsets sit in roff: rows with one lane per record (fields and CIGAR
+// from the LDS window, block scan for the arena offsets, coalesced stores), then the arenas with one lane per 16-byte
+// chunk.  pn / pls / pnc: records, bases, CIGAR ops in front of the chunk.  A last record that runs past the window
+// (last_long) is unpacked from global memory by the whole workgroup.
+template <bool SEQ, bool QUAL, bool CIG>
+__device__ __forceinline__ void sd_emit(const SdArgs& a, uint8_t* sd_lds, uint64_t wbase, uint32_t cnt, bool last_long, u64 pn, u64 pls, u64 pnc
+#ifdef BGP_SD_PROF
+                                        , unsigned long long& stamp_
+#endif
+                                        ) {
+    uint32_t* const w = reinterpret_cast<uint32_t*>(sd_lds);
+    uint16_t* const roff = reinterpret_cast<uint16_t*>(sd_lds + L_ROFF);
+    uint32_t* const soff = reinterpret_cast<uint32_t*>(sd_lds + L_SOFF);
+    uint32_t* const coff = reinterpret_cast<uint32_t*>(sd_lds + L_COFF);
+    uint16_t* const info = reinterpret_cast<uint16_t*>(sd_lds + L_INFO);
+    u64* const misc = reinterpret_cast<u64*>(sd_lds + L_MISC);
+    const int t = threadIdx.x, lane = t & 63;
+    (void)lane;
+
+    // ---- emit: rows (lane = record), then the arenas (lane = 16-byte chunk)
+    const uint32_t nfast = cnt - (last_long ? 1u : 0u);
+    u64 carry_seq = pls, carry_cig = pnc;
+    for (uint32_t r0 = 0; r0 < nfast; r0 += SD_RB) {
+        const int rc = (int)min((uint32_t)SD_RB, nfast - r0);
+        const bool valid = t < rc;
+        bgp_record rec{};
+        uint32_t lseq = 0, ncig = 0, cig_o = 0;
+        uint4 c4v = make_uint4(0, 0, 0, 0);
+        if (t < 4) misc[M_TM + t] = 0;
+        if (valid) {
+            const uint32_t o = roff[r0 + t];
+            rec.ref_id = (int32_t)wl32(w, o + 4); rec.pos = (int32_t)wl32(w, o + 8);              // read.d:907-911
+            rec.bin_mq_nl = wl32(w, o + 12); rec.flag_nc = wl32(w, o + 16); rec.l_seq = (int32_t)wl32(w, o + 20);   // read.d:915-923
+            rec.rec_off = wbase + o;
+            const uint32_t l_name = rec.bin_mq_nl & 0xFFu, n_cig = rec.flag_nc & 0xFFFFu;
+            cig_o = o + 36 + l_name;                                                                // read.d:988-990
+            uint32_t covered = 0;
+            if (!((rec.flag_nc >> 16) & 0x4u) && n_cig <= BGP_LONG_CIGAR) {                         // read.d:257-259; long CIGARs: k1_long_cigar afterwards
+                const uint4 c4 = wl128(w, cig_o);                                                   // (a record has tags or at least SEQ/QUAL behind a short CIGAR; the window has 32 spare bytes)
+                if (n_cig > 0) { c4v.x = c4.x; covered += cig_rc(c4.x) ? (c4.x >> 4) : 0u; }      // read.d:261
+                if (n_cig > 1) { c4v.y = c4.y; covered += cig_rc(c4.y) ? (c4.y >> 4) : 0u; }
+                if (n_cig > 2) { c4v.z = c4.z; covered += cig_rc(c4.z) ? (c4.z >> 4) : 0u; }
+                if (n_cig > 3) { c4v.w = c4.w; covered += cig_rc(c4.w) ? (c4.w >> 4) : 0u; }
+                for (uint32_t j = 4; j < n_cig; ++j) { const uint32_t op = wl32(w, cig_o + 4 * j); covered += cig_rc(op) ? (op >> 4) : 0u; }
+            }
+            rec.end_pos = (int32_t)((uint32_t)rec.pos + covered);                                   // read.d:1382
+            lseq = (uint32_t)rec.l_seq; ncig = n_cig;
+        }
+        uint32_t es, ec, ts, tc;
+        sd_excl2(lseq, ncig, &es, &ec, &ts, &tc, misc + M_WS);
+        const uint64_t i = pn + r0 + t;
+        const uint64_t tile0 = (pn + r0) / K3_TILE_RECORDS;
+        if (valid) {
+            a.rec[i] = rec; a.seq_off[i] = carry_seq + es; a.cig_off[i] = carry_cig + ec; a.cig4[i] = c4v;
+            soff[t] = es; coff[t] = ec;
+            info[3 * t] = (uint16_t)cig_o; info[3 * t + 1] = (uint16_t)(cig_o + 4 * ncig); info[3 * t + 2] = (uint16_t)(cig_o + 4 * ncig + (uint32_t)((rec.l_seq + 1) / 2));   // read.d:992-998
+            if (t == rc - 1) { soff[rc] = ts; coff[rc] = tc; }
+            if (a.tilemax) {            // K3's tile maxima: a round of 256 records touches one or two 2048-record tiles
+                const K3Key kk = k3_key_of(rec.ref_id, rec.pos, rec.end_pos);
+                const int sl = (i / K3_TILE_RECORDS == tile0) ? 0 : 2;
+                if (kk.e) atomicMax(&misc[M_TM + sl], (u64)kk.e);
+                if (kk.p) atomicMax(&misc[M_TM + sl + 1], (u64)kk.p);
+            }
+        }
+        __syncthreads();
+        if (a.tilemax && t < 4 && misc[M_TM + t]) atomicMax(&a.tilemax[2 * tile0 + t], misc[M_TM + t]);
+        SDSTAMP(5);   // rows
+        unpack_lds<SEQ, QUAL, CIG>(a, w, rc, carry_seq, carry_cig, soff, coff, info);
+        __syncthreads();
+        SDSTAMP(6);   // arenas
+        carry_seq += ts; carry_cig += tc;
+    }
+    if (last_long) {                    // the chunk's last record runs past the window: from global memory, by the whole workgroup
+        uint64_t* const l_soff = reinterpret_cast<uint64_t*>(sd_lds + L_SOFF);      // [2]
+        uint64_t* const l_coff = l_soff + 2;                                         // [2]
+        RecInfo* const l_info = reinterpret_cast<RecInfo*>(l_soff + 4);
+        if (t == 0) {
+            const uint64_t off = wbase + roff[cnt - 1];
+            const uint8_t* p = a.s + off;
+            bgp_record rec;
+            uint4 h; __builtin_memcpy(&h, p + 4, 16);
+            rec.ref_id = (int32_t)h.x; rec.pos = (int32_t)h.y; rec.bin_mq_nl = h.z; rec.flag_nc = h.w;
+            rec.l_seq = (int32_t)ld_u32(p + 20); rec.rec_off = off;
+            const uint32_t l_name = rec.bin_mq_nl & 0xFFu, n_cig = rec.flag_nc & 0xFFFFu;
+            uint32_t covered = 0;
+            uint4 c4v = make_uint4(0, 0, 0, 0);
+            if (!((rec.flag_nc >> 16) & 0x4u) && n_cig <= BGP_LONG_CIGAR) {
+                const uint8_t* cg = p + 36 + l_name;
+                for (uint32_t j = 0; j < n_cig; ++j) {
+                    const uint32_t op = ld_u32(cg + 4 * j); covered += cig_rc(op) ? (op >> 4) : 0u;
+                    if (j == 0) c4v.x = op; else if (j == 1) c4v.y = op; else if (j == 2) c4v.z = op; else if (j == 3) c4v.w = op;
+                }
+            }
+            rec.end_pos = (int32_t)((uint32_t)rec.pos + covered);
+            const uint64_t i = pn + cnt - 1;
+            a.rec[i] = rec; a.seq_off[i] = carry_seq; a.cig_off[i] = carry_cig; a.cig4[i] = c4v;
+            if (a.tilemax) {
+                const K3Key kk = k3_key_of(rec.ref_id, rec.pos, rec.end_pos);
+                if (kk.e) atomicMax(&a.tilemax[2 * (i / K3_TILE_RECORDS)], (unsigned long long)kk.e);
+                if (kk.p) atomicMax(&a.tilemax[2 * (i / K3_TILE_RECORDS) + 1], (unsigned long long)kk.p);
+            }
+            l_soff[0] = carry_seq; l_soff[1] = carry_seq + (uint64_t)(uint32_t)rec.l_seq;
+            l_coff[0] = carry_cig; l_coff[1] = carry_cig + n_cig;
+            RecInfo ri;
+            ri.cig_ptr = off + 36 + l_name; ri.seq_ptr = ri.cig_ptr + 4ull * n_cig; ri.qual_ptr = ri.seq_ptr + (uint64_t)((rec.l_seq + 1) / 2);
+            l_info[0] = ri;
+        }
+        __syncthreads();
+        DecArgs d;
+        d.s = a.s; d.stream_len = a.len; d.rec = nullptr; d.seq_off = nullptr; d.cigar_off = nullptr; d.n = 0; d.seq = a.seq; d.qual = a.qual; d.cigar = a.cigar;
+        unpack_group<SEQ, QUAL, CIG>(d, 1, l_soff, l_coff, l_info);
+    }
+}
+
 template <bool SEQ, bool QUAL, bool CIG>
 __global__ __launch_bounds__(SD_T, BGP_SD_MINW) void k_stream_decode(SdArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t sd_lds[];
@@ -722,7 +843,7 @@ __global__ __launch_bounds__(SD_T, BGP_SD_MINW) void k_stream_decode(SdArgs a) {
     uint16_t* const sub = reinterpret_cast<uint16_t*>(sd_lds + L_SUB);
     uint32_t* const soff = reinterpret_cast<uint32_t*>(sd_lds + L_SOFF);
     uint32_t* const coff = reinterpret_cast<uint32_t*>(sd_lds + L_COFF);
-    uint32_t* const info = reinterpret_cast<uint32_t*>(sd_lds + L_INFO);
+    uint16_t* const info = reinterpret_cast<uint16_t*>(sd_lds + L_INFO);
     u64* const misc = reinterpret_cast<u64*>(sd_lds + L_MISC);
 #ifdef BGP_SD_PROF
     unsigned long long stamp_ = __builtin_amdgcn_s_memtime();
@@ -855,99 +976,64 @@ __global__ __launch_bounds__(SD_T, BGP_SD_MINW) void k_stream_decode(SdArgs a) {
     if (pn + cnt > a.cap_n || pls + ls_tot > a.cap_ls || pnc + nc_tot > a.cap_nc) { if (t == 0) a.ctl[2] = 1; return; }   // (sized from the first records: the host runs the pass again with what this one found)
 
     // ---- emit: rows (lane = record), then the arenas (lane = 16-byte chunk)
-    const uint32_t nfast = cnt - (last_long ? 1u : 0u);
-    u64 carry_seq = pls, carry_cig = pnc;
-    for (uint32_t r0 = 0; r0 < nfast; r0 += SD_RB) {
-        const int rc = (int)min((uint32_t)SD_RB, nfast - r0);
-        const bool valid = t < rc;
-        bgp_record rec{};
-        uint32_t lseq = 0, ncig = 0, cig_o = 0;
-        uint4 c4v = make_uint4(0, 0, 0, 0);
-        if (t < 4) misc[M_TM + t] = 0;
-        if (valid) {
-            const uint32_t o = roff[r0 + t];
-            rec.ref_id = (int32_t)wl32(w, o + 4); rec.pos = (int32_t)wl32(w, o + 8);              // read.d:907-911
-            rec.bin_mq_nl = wl32(w, o + 12); rec.flag_nc = wl32(w, o + 16); rec.l_seq = (int32_t)wl32(w, o + 20);   // read.d:915-923
-            rec.rec_off = wbase + o;
-            const uint32_t l_name = rec.bin_mq_nl & 0xFFu, n_cig = rec.flag_nc & 0xFFFFu;
-            cig_o = o + 36 + l_name;                                                                // read.d:988-990
-            uint32_t covered = 0;
-            if (!((rec.flag_nc >> 16) & 0x4u) && n_cig <= BGP_LONG_CIGAR) {                         // read.d:257-259; long CIGARs: k1_long_cigar afterwards
-                const uint4 c4 = wl128(w, cig_o);                                                   // (a record has tags or at least SEQ/QUAL behind a short CIGAR; the window has 32 spare bytes)
-                if (n_cig > 0) { c4v.x = c4.x; covered += cig_rc(c4.x) ? (c4.x >> 4) : 0u; }      // read.d:261
-                if (n_cig > 1) { c4v.y = c4.y; covered += cig_rc(c4.y) ? (c4.y >> 4) : 0u; }
-                if (n_cig > 2) { c4v.z = c4.z; covered += cig_rc(c4.z) ? (c4.z >> 4) : 0u; }
-                if (n_cig > 3) { c4v.w = c4.w; covered += cig_rc(c4.w) ? (c4.w >> 4) : 0u; }
-                for (uint32_t j = 4; j < n_cig; ++j) { const uint32_t op = wl32(w, cig_o + 4 * j); covered += cig_rc(op) ? (op >> 4) : 0u; }
-            }
-            rec.end_pos = (int32_t)((uint32_t)rec.pos + covered);                                   // read.d:1382
-            lseq = (uint32_t)rec.l_seq; ncig = n_cig;
-        }
-        uint32_t es, ec, ts, tc;
-        sd_excl2(lseq, ncig, &es, &ec, &ts, &tc, misc + M_WS);
-        const uint64_t i = pn + r0 + t;
-        const uint64_t tile0 = (pn + r0) / K3_TILE_RECORDS;
-        if (valid) {
-            a.rec[i] = rec; a.seq_off[i] = carry_seq + es; a.cig_off[i] = carry_cig + ec; a.cig4[i] = c4v;
-            soff[t] = es; coff[t] = ec;
-            info[3 * t] = cig_o; info[3 * t + 1] = cig_o + 4 * ncig; info[3 * t + 2] = cig_o + 4 * ncig + (uint32_t)((rec.l_seq + 1) / 2);   // read.d:992-998
-            if (t == rc - 1) { soff[rc] = ts; coff[rc] = tc; }
-            if (a.tilemax) {            // K3's tile maxima: a round of 256 records touches one or two 2048-record tiles
-                const K3Key kk = k3_key_of(rec.ref_id, rec.pos, rec.end_pos);
-                const int sl = (i / K3_TILE_RECORDS == tile0) ? 0 : 2;
-                if (kk.e) atomicMax(&misc[M_TM + sl], (u64)kk.e);
-                if (kk.p) atomicMax(&misc[M_TM + sl + 1], (u64)kk.p);
-            }
-        }
-        __syncthreads();
-        if (a.tilemax && t < 4 && misc[M_TM + t]) atomicMax(&a.tilemax[2 * tile0 + t], misc[M_TM + t]);
-        SDSTAMP(5);   // rows
-        unpack_lds<SEQ, QUAL, CIG>(a, w, rc, carry_seq, carry_cig, soff, coff, info);
-        __syncthreads();
-        SDSTAMP(6);   // arenas
-        carry_seq += ts; carry_cig += tc;
-    }
-    if (last_long) {                    // the chunk's last record runs past the window: from global memory, by the whole workgroup
-        uint64_t* const l_soff = reinterpret_cast<uint64_t*>(sd_lds + L_SOFF);      // [2]
-        uint64_t* const l_coff = l_soff + 2;                                         // [2]
-        RecInfo* const l_info = reinterpret_cast<RecInfo*>(l_soff + 4);
-        if (t == 0) {
-            const uint64_t off = wbase + roff[cnt - 1];
-            const uint8_t* p = a.s + off;
-            bgp_record rec;
-            uint4 h; __builtin_memcpy(&h, p + 4, 16);
-            rec.ref_id = (int32_t)h.x; rec.pos = (int32_t)h.y; rec.bin_mq_nl = h.z; rec.flag_nc = h.w;
-            rec.l_seq = (int32_t)ld_u32(p + 20); rec.rec_off = off;
-            const uint32_t l_name = rec.bin_mq_nl & 0xFFu, n_cig = rec.flag_nc & 0xFFFFu;
-            uint32_t covered = 0;
-            uint4 c4v = make_uint4(0, 0, 0, 0);
-            if (!((rec.flag_nc >> 16) & 0x4u) && n_cig <= BGP_LONG_CIGAR) {
-                const uint8_t* cg = p + 36 + l_name;
-                for (uint32_t j = 0; j < n_cig; ++j) {
-                    const uint32_t op = ld_u32(cg + 4 * j); covered += cig_rc(op) ? (op >> 4) : 0u;
-                    if (j == 0) c4v.x = op; else if (j == 1) c4v.y = op; else if (j == 2) c4v.z = op; else if (j == 3) c4v.w = op;
-                }
-            }
-            rec.end_pos = (int32_t)((uint32_t)rec.pos + covered);
-            const uint64_t i = pn + cnt - 1;
-            a.rec[i] = rec; a.seq_off[i] = carry_seq; a.cig_off[i] = carry_cig; a.cig4[i] = c4v;
-            if (a.tilemax) {
-                const K3Key kk = k3_key_of(rec.ref_id, rec.pos, rec.end_pos);
-                if (kk.e) atomicMax(&a.tilemax[2 * (i / K3_TILE_RECORDS)], (unsigned long long)kk.e);
-                if (kk.p) atomicMax(&a.tilemax[2 * (i / K3_TILE_RECORDS) + 1], (unsigned long long)kk.p);
-            }
-            l_soff[0] = carry_seq; l_soff[1] = carry_seq + (uint64_t)(uint32_t)rec.l_seq;
-            l_coff[0] = carry_cig; l_coff[1] = carry_cig + n_cig;
-            RecInfo ri;
-            ri.cig_ptr = off + 36 + l_name; ri.seq_ptr = ri.cig_ptr + 4ull * n_cig; ri.qual_ptr = ri.seq_ptr + (uint64_t)((rec.l_seq + 1) / 2);
-            l_info[0] = ri;
-        }
-        __syncthreads();
-        DecArgs d;
-        d.s = a.s; d.stream_len = a.len; d.rec = nullptr; d.seq_off = nullptr; d.cigar_off = nullptr; d.n = 0; d.seq = a.seq; d.qual = a.qual; d.cigar = a.cigar;
-        unpack_group<SEQ, QUAL, CIG>(d, 1, l_soff, l_coff, l_info);
-    }
+#ifdef BGP_SD_PROF
+    sd_emit<SEQ, QUAL, CIG>(a, sd_lds, wbase, cnt, last_long, pn, pls, pnc, stamp_);
+#else
+    sd_emit<SEQ, QUAL, CIG>(a, sd_lds, wbase, cnt, last_long, pn, pls, pnc);
+#endif
   }
+}
+
+
+// ---------------------------------------------------------------------------------------------- K1 + K2 through LDS windows
+// The record table and the arenas in one pass over the stream, framing taken from K0: when K0's segments are SD_C bytes,
+// a workgroup copies its segment (+ SD_OV) into LDS with coalesced 16-byte loads -- every stream byte is read from HBM
+// once, where k1_rows and k2_unpack fetch the header lines twice and k12_fused pays for its rows with registers -- takes
+// the records' offsets from the side array k0_chase left, and emits exactly as the one-pass kernel does (sd_emit).
+struct LdsArgs {
+    SdArgs d;                         // stream, outputs (capacities unused: the sizes are known)
+    const uint64_t* rec_base; const uint64_t* seq_base; const uint64_t* cig_base; const uint32_t* side; uint32_t side_cap;
+    uint64_t n_seg, n_records, sum_lseq, sum_ncig;
+};
+
+template <bool SEQ, bool QUAL, bool CIG>
+__global__ __launch_bounds__(SD_T, BGP_SD_MINW) void k12_lds(LdsArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t sd_lds[];
+    uint16_t* const roff = reinterpret_cast<uint16_t*>(sd_lds + L_ROFF);
+    const uint32_t* const w = reinterpret_cast<const uint32_t*>(sd_lds);
+#ifdef BGP_SD_PROF
+    unsigned long long stamp_ = __builtin_amdgcn_s_memtime();
+#endif
+    const int t = threadIdx.x;
+    const uint64_t k = blockIdx.x;
+    if (k == 0 && t == 0) { a.d.seq_off[a.n_records] = a.sum_lseq; a.d.cig_off[a.n_records] = a.sum_ncig; }
+    const uint64_t pn = a.rec_base[k];
+    const uint32_t cnt = (uint32_t)(a.rec_base[k + 1] - pn);
+    if (!cnt) return;                                      // (inside a record longer than a segment, or behind the end of the chain)
+    const uint64_t wbase = k * SD_C;
+    const uint32_t wlen = (uint32_t)min((uint64_t)SD_WIN, a.d.len - wbase);
+    {   // the window: every load in flight before the first store
+        constexpr int NL = (SD_WIN + 32 + 16 * SD_T - 1) / (16 * SD_T);
+        uint4 v[NL];
+#pragma unroll
+        for (int i = 0; i < NL; ++i) { const uint32_t o = 16u * (uint32_t)(t + SD_T * i); v[i] = make_uint4(0, 0, 0, 0); if (o + 16 <= wlen) __builtin_memcpy(&v[i], a.d.s + wbase + o, 16); }
+        for (uint32_t j = t; j < cnt; j += SD_T) roff[j] = (uint16_t)a.side[k * a.side_cap + j];
+#pragma unroll
+        for (int i = 0; i < NL; ++i) { const uint32_t o = 16u * (uint32_t)(t + SD_T * i); if (o < SD_WIN + 32) *reinterpret_cast<uint4*>(sd_lds + o) = v[i]; }
+    }
+    __syncthreads();
+    if (wlen & 15u) {                                      // the last few bytes of the stream, one by one
+        const uint32_t tail0 = wlen & ~15u;
+        if (tail0 + t < wlen) sd_lds[tail0 + t] = a.d.s[wbase + tail0 + t];
+        __syncthreads();
+    }
+    SDSTAMP(0);
+    const bool last_long = (uint64_t)roff[cnt - 1] + 4 + (uint64_t)wl32(w, roff[cnt - 1]) > wlen;
+#ifdef BGP_SD_PROF
+    sd_emit<SEQ, QUAL, CIG>(a.d, sd_lds, wbase, cnt, last_long, pn, a.seq_base[k], a.cig_base[k], stamp_);
+#else
+    sd_emit<SEQ, QUAL, CIG>(a.d, sd_lds, wbase, cnt, last_long, pn, a.seq_base[k], a.cig_base[k]);
+#endif
 }
 
 }  // namespace
@@ -1163,4 +1249,50 @@ int k012_stream_decode(bgp_ctx* c, uint32_t what) {
         return BGP_OK;
     }
     return BGP_EDEVICE;
+}
+
+// K1 + K2 through LDS windows (k12_lds): when K0 framed the stream in SD_C-byte segments and every section is wanted
+bool k12_lds_applies(const bgp_ctx* c, uint32_t what) { return c->table_pending && c->seg_bytes == SD_C && (what & BGP_FETCH_ALL) == BGP_FETCH_ALL && c->n_seg < 0x7FFFFFFFull; }
+uint32_t k12_lds_segment_bytes() { return SD_C; }
+int k12_lds_decode(bgp_ctx* c, uint32_t what) {
+    const uint64_t n = c->n_records;
+    c->table_pending = false;
+    BGP_TRY(c->d_rec.reserve((n + 1) * sizeof(bgp_record)));
+    BGP_TRY(c->d_seq_off.reserve((n + 1) * 8)); BGP_TRY(c->d_cigar_off.reserve((n + 1) * 8));
+    BGP_TRY(c->d_cig4.reserve((n + 1) * 16)); c->cig4_ok = true;
+    BGP_TRY(c->d_seq.reserve(c->sum_lseq + 16)); BGP_TRY(c->d_qual.reserve(c->sum_lseq + 16)); BGP_TRY(c->d_cigar.reserve(c->sum_ncig * 4 + 16));
+    c->decoded_what |= BGP_FETCH_ALL;
+    if (c->stream_len < 4) return BGP_OK;
+    LdsArgs a;
+    a.d.s = c->d_stream; a.d.len = c->stream_len; a.d.n_chunks = c->n_seg; a.d.ref_bound = 0; a.d.tolerant = 0; a.d.hint = nullptr; a.d.desc = nullptr; a.d.ctl = nullptr; a.d.status = nullptr;
+    a.d.rec = c->d_rec.as<bgp_record>(); a.d.seq_off = c->d_seq_off.as<uint64_t>(); a.d.cig_off = c->d_cigar_off.as<uint64_t>(); a.d.cig4 = c->d_cig4.as<uint4>();
+    a.d.seq = c->d_seq.as<uint8_t>(); a.d.qual = c->d_qual.as<uint8_t>(); a.d.cigar = c->d_cigar.as<uint32_t>();
+    a.d.cap_n = ~0ull; a.d.cap_ls = ~0ull; a.d.cap_nc = ~0ull;
+    a.d.tilemax = nullptr; c->tilemax_ok = false;
+    if (!c->long_cigar) {             // K3's tile maxima on the way (see k12_fused_decode)
+        const uint64_t nt = (n + K3_TILE_RECORDS - 1) / K3_TILE_RECORDS;
+        BGP_TRY(c->d_tilemax.reserve((nt + 2) * 16));
+        BGP_HIP(hipMemsetAsync(c->d_tilemax.p, 0, (nt + 2) * 16, c->stream));
+        a.d.tilemax = (unsigned long long*)c->d_tilemax.p; c->tilemax_ok = true;
+    }
+    a.rec_base = c->d_seg_rec_base.as<uint64_t>(); a.seq_base = c->d_seg_seq_base.as<uint64_t>(); a.cig_base = c->d_seg_cig_base.as<uint64_t>();
+    a.side = c->d_seg_side.as<uint32_t>(); a.side_cap = c->side_cap; a.n_seg = c->n_seg; a.n_records = n; a.sum_lseq = c->sum_lseq; a.sum_ncig = c->sum_ncig;
+    {
+        TimedRegion t(c, "k12_lds", c->stream_len + n * 32 + 2 * c->sum_lseq + 4 * c->sum_ncig);      // SURVEY 8(d) without the framing: the record in, row + seq + qual + cigar out
+        hipLaunchKernelGGL((k12_lds<true, true, true>), dim3((unsigned)c->n_seg), dim3(SD_T), L_TOTAL, c->stream, a);
+        BGP_TRY(k1_finish_long_cigars(c));
+    }
+    BGP_HIP(hipGetLastError());
+#ifdef BGP_SD_PROF
+    {
+        unsigned long long pr[16];
+        BGP_HIP(hipStreamSynchronize(c->stream));
+        BGP_HIP(hipMemcpyFromSymbol(pr, HIP_SYMBOL(g_sd_prof), sizeof pr));
+        fprintf(stderr, "[k12_lds prof] per segment: load %.0f rows %.0f arenas %.0f (s_memtime ticks, %llu segments)\n", (double)pr[0] * 64 / c->n_seg, (double)pr[5] * 64 / c->n_seg, (double)pr[6] * 64 / c->n_seg, (unsigned long long)c->n_seg);
+        unsigned long long z[16] = {0};
+        BGP_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_sd_prof), z, sizeof z));
+    }
+#endif
+    (void)what;
+    return BGP_OK;
 }

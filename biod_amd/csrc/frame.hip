@@ -237,6 +237,7 @@ int k0_frame(bgp_ctx* c) {
     uint32_t seg = pow2_ceil(want);
     if (seg < 4096u) seg = 4096u;
     if (seg > (1u << 20)) seg = 1u << 20;
+    if (c->seg_bytes_wanted && seg <= c->seg_bytes_wanted) seg = c->seg_bytes_wanted;     // the LDS-window decode wants its own segment size (any value is correct)
     c->seg_bytes = seg;
     const uint64_t n_seg = (len + seg - 1) / seg;
     c->n_seg = n_seg;
