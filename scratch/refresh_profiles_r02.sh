@@ -11,7 +11,7 @@ cd $R
 timeout 900 python bench.py --steps 10 --warmup 3 > $OUT/r02_bench_cfg3_100M.json 2> $OUT/bench_cfg3.err
 timeout 600 python bench.py --steps 5 --warmup 2 --config cfg2 --no-cpu-baseline > $OUT/r02_bench_cfg2_10M.json 2> $OUT/bench_cfg2.err
 timeout 600 python bench.py --steps 5 --warmup 2 --config cfg5 --no-cpu-baseline > $OUT/r02_bench_cfg5_200k.json 2> $OUT/bench_cfg5.err
-BGP_BENCH_FORCE_COMM=1 timeout 600 python bench.py --steps 5 --warmup 2 --no-cpu-baseline 2> $OUT/bench_comm.err | tail -1 > $OUT/r02_bench_cfg3_100M_one_rank_communicator.json
+BGP_BENCH_FORCE_COMM=1 timeout 600 python bench.py --steps 5 --warmup 2 --no-cpu-baseline 2> $OUT/bench_comm.err | grep "^{" | tail -1 > $OUT/r02_bench_cfg3_100M_one_rank_communicator.json
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/r02_bench_under_rocprofv3_cfg3_100M.json 2> $OUT/stats.err
 find $OUT/stats -name "*kernel_stats.csv" -exec cp {} $OUT/r02_rocprofv3_kernel_stats_cfg3_100M.csv \;

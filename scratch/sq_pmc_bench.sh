@@ -18,7 +18,7 @@ with open("${GRAFT_REPO_ROOT:-/root/repo}/gpurun_out/sq_pmc/r02_pmc_sq_per_kerne
     w.write("# rocprofv3 --kernel-trace --pmc <4 SQ counters per pass>, bench.py --steps 1 --warmup 0, cfg3 100 M reads; sums over a kernel's dispatches in the step\n")
     w.write("kernel," + ",".join(names) + "\n")
     for k in sorted(acc):
-        if any(x in k for x in ("k0_", "k1", "k2_", "k3_", "k4_", "k12")):
+        if any(x in k for x in ("k0_", "k1", "k2_", "k3_", "k4_", "k12", "k8_")):
             w.write(k + "," + ",".join(f"{acc[k].get(c, 0):.0f}" for c in names) + "\n")
 print(open("${GRAFT_REPO_ROOT:-/root/repo}/gpurun_out/sq_pmc/r02_pmc_sq_per_kernel_cfg3_100M.csv").read())
 PY
