@@ -23,6 +23,7 @@ constexpr int RB = 256;   // records per workgroup
 struct DecArgs {
     const uint8_t* s; uint64_t stream_len; const bgp_record* rec; const uint64_t* seq_off; const uint64_t* cigar_off; uint64_t n;
     uint8_t* seq; uint8_t* qual; uint32_t* cigar;
+    uint32_t rb;          // records per workgroup of k2_unpack (<= RB): fewer when records are long, so that the grid still fills the device
 };
 
 __device__ __forceinline__ uint8_t nt16_char(uint32_t code) {      // base.d:85
@@ -143,8 +144,8 @@ __global__ __launch_bounds__(256) void k2_unpack(DecArgs a) {
     __shared__ uint64_t s_seq_off[RB + 1];
     __shared__ uint64_t s_cig_off[RB + 1];
     __shared__ RecInfo s_info[RB];
-    const uint64_t r0 = (uint64_t)blockIdx.x * RB;
-    const int cnt = (int)min((uint64_t)RB, a.n - r0);
+    const uint64_t r0 = (uint64_t)blockIdx.x * a.rb;
+    const int cnt = (int)min((uint64_t)a.rb, a.n - r0);
     for (int j = threadIdx.x; j <= cnt; j += blockDim.x) {
         s_seq_off[j] = a.seq_off[r0 + j];
         s_cig_off[j] = a.cigar_off[r0 + j];
@@ -830,7 +831,7 @@ __device__ __forceinline__ void sd_emit(const SdArgs& a, uint8_t* sd_lds, uint64
         }
         __syncthreads();
         DecArgs d;
-        d.s = a.s; d.stream_len = a.len; d.rec = nullptr; d.seq_off = nullptr; d.cigar_off = nullptr; d.n = 0; d.seq = a.seq; d.qual = a.qual; d.cigar = a.cigar;
+        d.s = a.s; d.stream_len = a.len; d.rec = nullptr; d.seq_off = nullptr; d.cigar_off = nullptr; d.n = 0; d.seq = a.seq; d.qual = a.qual; d.cigar = a.cigar; d.rb = 1;
         unpack_group<SEQ, QUAL, CIG>(d, 1, l_soff, l_coff, l_info);
     }
 }
@@ -1048,7 +1049,10 @@ int k2_decode(bgp_ctx* c, uint32_t what) {
     DecArgs a;
     a.s = c->d_stream; a.stream_len = c->stream_len; a.rec = c->d_rec.as<bgp_record>(); a.seq_off = c->d_seq_off.as<uint64_t>(); a.cigar_off = c->d_cigar_off.as<uint64_t>();
     a.n = n; a.seq = c->d_seq.as<uint8_t>(); a.qual = c->d_qual.as<uint8_t>(); a.cigar = c->d_cigar.as<uint32_t>();
-    const unsigned blocks = (unsigned)((n + RB - 1) / RB);
+    // 256 records a workgroup -- unless that leaves the device short of workgroups (200 k reads of 30 kb: 780 of them for 2048
+    // slots, 9.5 ms): then as few records each as it takes to have ~16 k workgroups
+    a.rb = (uint32_t)std::min<uint64_t>(RB, std::max<uint64_t>(1, n / 16384));
+    const unsigned blocks = (unsigned)((n + a.rb - 1) / a.rb);
     const bool S = what & BGP_FETCH_SEQ, Q = what & BGP_FETCH_QUAL, C = what & BGP_FETCH_CIGAR;
     uint64_t alg = n * 48;    // record table + two offsets read
     if (S) alg += (c->sum_lseq + 1) / 2 + c->sum_lseq;
@@ -1081,7 +1085,7 @@ int k12_fused_decode(bgp_ctx* c, uint32_t what) {
     c->decoded_what |= what;
     if (c->stream_len < 4) return BGP_OK;
     FusedArgs a;
-    a.d.s = c->d_stream; a.d.stream_len = c->stream_len; a.d.rec = nullptr; a.d.seq_off = nullptr; a.d.cigar_off = nullptr; a.d.n = n;
+    a.d.s = c->d_stream; a.d.stream_len = c->stream_len; a.d.rec = nullptr; a.d.seq_off = nullptr; a.d.cigar_off = nullptr; a.d.n = n; a.d.rb = RB;
     a.d.seq = c->d_seq.as<uint8_t>(); a.d.qual = c->d_qual.as<uint8_t>(); a.d.cigar = c->d_cigar.as<uint32_t>();
     a.entry = c->d_seg_entry.as<uint64_t>(); a.rec_base = c->d_seg_rec_base.as<uint64_t>(); a.seq_base = c->d_seg_seq_base.as<uint64_t>(); a.cig_base = c->d_seg_cig_base.as<uint64_t>();
     a.side = c->d_seg_side.as<uint32_t>(); a.side_cap = c->side_cap; a.seg_bytes = c->seg_bytes; a.n_seg = c->n_seg; a.sum_lseq = c->sum_lseq; a.sum_ncig = c->sum_ncig;

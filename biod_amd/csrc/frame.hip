@@ -67,6 +67,53 @@ __global__ __launch_bounds__(256) void k0_guess(FrameArgs a) {
     if (lane == 0) a.entry[k] = found;
 }
 
+// The same guess with a whole workgroup per segment, 256 candidates a step: for streams of few, large segments (long
+// reads: 1 MiB segments, the first record start tens of KB in), where one wave per segment leaves the device idle and
+// walks ~500 dependent steps (cfg5: 2.5 ms).
+__global__ __launch_bounds__(256) void k0_guess_wide(FrameArgs a) {
+    __shared__ unsigned long long s_found;
+    const uint64_t k = blockIdx.x;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (k >= a.n_seg) return;
+    if (k == 0) { if (threadIdx.x == 0) a.entry[0] = 0; return; }
+    const uint64_t beg = k * a.seg_bytes;
+    const uint64_t lim = min(beg + a.seg_bytes, a.len);
+    if (threadIdx.x == 0) {
+        uint64_t f = NONE;
+        if (a.seg_hint) {
+            const uint64_t h = a.seg_hint[k];
+            uint32_t bs = 0, dummy;
+            if (h != NONE && h >= beg && h < lim && plausible(a.s, a.len, h, a.ref_bound, &bs)) {
+                const uint64_t nxt = h + 4 + bs;
+                if (a.len - nxt < 4 || plausible(a.s, a.len, nxt, a.ref_bound, &dummy)) f = h;
+            }
+        }
+        s_found = f;
+    }
+    __syncthreads();
+    uint64_t found = s_found;
+    for (uint64_t base = beg + 64 * wv; found == NONE && base - 64 * wv < lim; base += 256) {
+        uint64_t mine = NONE;
+        const uint64_t o = base + lane;
+        uint32_t bs = 0;
+        const bool ok = o < lim && plausible(a.s, a.len, o, a.ref_bound, &bs);
+        unsigned long long m = __ballot(ok);
+        while (m) {
+            const int l = __ffsll((long long)m) - 1;
+            const uint32_t bsl = __shfl(bs, l, 64);
+            const uint64_t nxt = base + l + 4 + bsl;
+            uint32_t dummy;
+            if (a.len - nxt < 4 || plausible(a.s, a.len, nxt, a.ref_bound, &dummy)) { mine = base + l; break; }
+            m &= m - 1;
+        }
+        if (lane == 0 && mine != NONE) atomicMin(&s_found, (unsigned long long)mine);
+        __syncthreads();
+        found = s_found;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) a.entry[k] = found;
+}
+
 // one lane per segment
 __global__ __launch_bounds__(256) void k0_chase(FrameArgs a) {
     uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -276,7 +323,8 @@ int k0_frame(bgp_ctx* c) {
         BGP_HIP(hipMemsetAsync(a.seg_err, 0, n_seg * 4, c->stream));         // what a segment without an entry keeps: end NONE, no records
         BGP_HIP(hipMemsetAsync(a.end, 0xFF, n_seg * 8, c->stream));
         BGP_HIP(hipMemsetAsync(a.cnt, 0, n_seg * 8, c->stream)); BGP_HIP(hipMemsetAsync(a.lseq, 0, n_seg * 8, c->stream)); BGP_HIP(hipMemsetAsync(a.ncig, 0, n_seg * 8, c->stream));
-        hipLaunchKernelGGL(k0_guess, dim3((unsigned)((n_seg + 3) / 4)), dim3(256), 0, c->stream, a);
+        if (n_seg <= 32768) hipLaunchKernelGGL(k0_guess_wide, dim3((unsigned)n_seg), dim3(256), 0, c->stream, a);      // few, large segments: a workgroup each
+        else hipLaunchKernelGGL(k0_guess, dim3((unsigned)((n_seg + 3) / 4)), dim3(256), 0, c->stream, a);
     }
     uint64_t rounds = 0;
     for (;;) {
