@@ -842,9 +842,6 @@ __global__ __launch_bounds__(SD_T, BGP_SD_MINW) void k_stream_decode(SdArgs a) {
     uint32_t* const w = reinterpret_cast<uint32_t*>(sd_lds);
     uint16_t* const roff = reinterpret_cast<uint16_t*>(sd_lds + L_ROFF);
     uint16_t* const sub = reinterpret_cast<uint16_t*>(sd_lds + L_SUB);
-    uint32_t* const soff = reinterpret_cast<uint32_t*>(sd_lds + L_SOFF);
-    uint32_t* const coff = reinterpret_cast<uint32_t*>(sd_lds + L_COFF);
-    uint16_t* const info = reinterpret_cast<uint16_t*>(sd_lds + L_INFO);
     u64* const misc = reinterpret_cast<u64*>(sd_lds + L_MISC);
 #ifdef BGP_SD_PROF
     unsigned long long stamp_ = __builtin_amdgcn_s_memtime();

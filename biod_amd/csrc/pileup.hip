@@ -231,6 +231,20 @@ __global__ __launch_bounds__(256) void k4_bounds(const uint64_t* pmax_end, const
     out[tile] = b;                                        // (bit 1, "not for the gather path", is set by k4_wscan, which also builds the list of such windows)
 }
 
+// four nt16 codes, one per byte -> the bit positions of their class counters: A 0, C 6, G 12, T 18, anything else 24 --
+// or, when the stream holds long reads (ROWS), five bits a counter so that a sixth fits: A 0, C 5, G 10, T 15, else 20, '-' 25
+template <bool ROWS> __device__ __forceinline__ uint32_t class_bits4(uint32_t x) {
+    const uint32_t idx = x & 0x07070707u;
+    const uint32_t lo = ROWS ? __builtin_amdgcn_perm(0x1414140Au, 0x14050014u, idx) : __builtin_amdgcn_perm(0x1818180Cu, 0x18060018u, idx);      // codes 0..7 : other A C other | G other other other
+    const uint32_t hi = ROWS ? __builtin_amdgcn_perm(0x14141414u, 0x1414140Fu, idx) : __builtin_amdgcn_perm(0x18181818u, 0x18181812u, idx);      // codes 8..15: T other other other | other ...
+    const uint32_t sel = ((x >> 1) & 0x04040404u) | 0x03020100u;                   // byte i: i (from lo) or 4 + i (from hi)
+    return __builtin_amdgcn_perm(hi, lo, sel);
+}
+// eight packed bases (read.d:368-373: the first base of a byte is its high nibble) -> eight class bytes in base order
+template <bool ROWS> __device__ __forceinline__ uint2 class_bits8(uint32_t cur) {
+    const uint32_t ev = class_bits4<ROWS>((cur >> 4) & 0x0F0F0F0Fu), od = class_bits4<ROWS>(cur & 0x0F0F0F0Fu);   // bases 0,2,4,6 | 1,3,5,7
+    return make_uint2(__builtin_amdgcn_perm(od, ev, 0x05010400u), __builtin_amdgcn_perm(od, ev, 0x07030602u));
+}
 // ---- long reads: CIGAR checkpoints ------------------------------------------------------------
 // A read with thousands of CIGAR ops overlaps many windows; walking its ops from the start in every
 // window is O(n_cigar) dependent loads per visit.  One pre-pass walks each long read ONCE, 64 ops per
@@ -238,6 +252,7 @@ __global__ __launch_bounds__(256) void k4_bounds(const uint64_t* pmax_end, const
 // pileup.d:175-222), and records for every window the read overlaps the cursor state
 // (op index, columns before it, query bases before it) of the op that owns the window's first column.
 struct Ckpt { uint32_t k, cs, qs, pad; };
+constexpr uint32_t ROW_OTHER = 20, ROW_DEL = 25;      // class bytes of a long read's row (the ROWS layout of k4_exec: A 0, C 5, G 10, T 15)
 
 __device__ __forceinline__ uint32_t wave_incl_u32(uint32_t v, int lane) {
 #pragma unroll
@@ -260,20 +275,24 @@ __device__ __forceinline__ uint32_t run_of_record(const RunDev* runs, uint32_t n
     return lo;
 }
 
-__global__ __launch_bounds__(256) void k4_ck_count(const bgp_record* rec, uint64_t n, const RunDev* runs, uint32_t n_runs, uint64_t* n_ck, uint32_t W) {
+__global__ __launch_bounds__(256) void k4_ck_count(const bgp_record* rec, uint64_t n, const RunDev* runs, uint32_t n_runs, uint64_t* n_ck, uint64_t* n_cols, uint32_t W) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const bgp_record r = rec[i];
-    uint64_t c = 0;
+    uint64_t c = 0, cols = 0;
     if (r.end_pos != r.pos && is_long_read(r.flag_nc & 0xFFFFu, (uint32_t)r.l_seq)) {
         const RunDev& run = runs[run_of_record(runs, n_runs, i)];
         c = ((uint64_t)(uint32_t)r.end_pos - 1 - run.start_pos) / W - ((uint64_t)(uint32_t)r.pos - run.start_pos) / W + 1;
+        cols = (uint32_t)r.end_pos - (uint32_t)r.pos;
     }
     n_ck[i] = c;
+    if (n_cols) n_cols[i] = cols;          // a long read's row in the arena: one class byte per column it covers
 }
 
-__global__ __launch_bounds__(256) void k4_ck_build(const uint8_t* s, const bgp_record* rec, uint64_t n, const RunDev* runs, uint32_t n_runs,
-                                                   const uint64_t* ck_off, Ckpt* ck, uint32_t W_) {
+__global__ __launch_bounds__(256) void k4_ck_build(const uint8_t* s, uint64_t stream_len, const bgp_record* rec, uint64_t n, const RunDev* runs, uint32_t n_runs,
+                                                   const uint64_t* ck_off, Ckpt* ck, uint32_t W_, const uint64_t* row_off, uint8_t* rows) {
+    constexpr int RB_CAP = 4096;
+    __shared__ __attribute__((aligned(16))) uint8_t s_row[4][RB_CAP];
     const int64_t W = (int64_t)W_;
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
@@ -296,6 +315,10 @@ __global__ __launch_bounds__(256) void k4_ck_build(const uint8_t* s, const bgp_r
         // window j (j >= 1) starts at column offset D + j*W of this read (D <= 0)
         const int64_t D = (int64_t)(run.start_pos + t_first * W) - (int64_t)pos;
         uint32_t cs = 0, qs = 0; bool started = false;
+        // what the gather path asks of a read (k4_plan: "the mould"): the first reference-consuming op is M/=/X (so the
+        // read's first column is a base of it: no leading N, D), no zero-length reference-consuming op, no M base past SEQ
+        bool plain = true;
+        const uint32_t l_seq_r = (uint32_t)__shfl(r.l_seq, src, 64);
         for (uint32_t c0 = 0; c0 < n_cig && cs < covered; c0 += 64) {
             const bool active = c0 + lane < n_cig;
             const uint32_t op = active ? ld_u32(cg + 4ull * (c0 + lane)) : 0u;
@@ -304,12 +327,74 @@ __global__ __launch_bounds__(256) void k4_ck_build(const uint8_t* s, const bgp_r
             if (!started) {
                 const unsigned long long st = __ballot(active && cig_rc(op) && (op & 15u) != 3u);
                 fl = st ? __ffsll((long long)st) - 1 : 64;
+                const unsigned long long anyrc = __ballot(active && cig_rc(op));
+                if (anyrc) { const int f0 = __ffsll((long long)anyrc) - 1; if (f0 != fl || !cig_qc((uint32_t)__shfl((int)op, f0, 64))) plain = false; }   // a leading N, or a first column that is a D
             }
             const bool lane_started = started || lane >= fl;
             uint32_t rlen, qlen;
             op_lens(op, active, lane_started, &rlen, &qlen);
             const uint32_t ir = wave_incl_u32(rlen, lane), iq = wave_incl_u32(qlen, lane);
             const uint32_t cs_b = cs + ir - rlen, qs_b = qs + iq - qlen;
+            if (__ballot(active && cig_rc(op) && (op >> 4) == 0) || __ballot(rlen && cig_qc(op) && qs_b + qlen > l_seq_r)) plain = false;
+            if (rows) {
+                // the read's row for the gather path: one class byte per COLUMN, in the ROWS layout of k4_exec (A 0, C 5, G 10,
+                // T 15, anything else 20, '-' 25).  A lane writes its own op's columns -- into LDS: the chunk's 64 ops cover a few
+                // hundred consecutive columns, which then leave as 16-byte stores (byte stores straight to the arena, 64 lanes
+                // on a handful of lines each, cost four times the walk itself).  A chunk with an op of more than 512 columns
+                // (an intron, a long match) or more than RB_CAP columns altogether writes to the arena directly.
+                const uint64_t seq_off = rec_off + 36 + l_name + 4ull * n_cig;
+                const int wv = threadIdx.x >> 6;
+                const uint32_t total = (uint32_t)__shfl((int)ir, 63, 64);
+                uint8_t* const rbase = rows + row_off[ri];
+                const bool is_m = cig_qc(op) != 0;
+                const bool via_lds = total <= (uint32_t)RB_CAP && !__ballot(rlen > 512);
+                auto base_byte = [&](uint32_t q) -> uint8_t {
+                    if (q >= l_seq_r) return (uint8_t)ROW_OTHER;
+                    const uint32_t byte = s[seq_off + (q >> 1)], nib = (q & 1u) ? (byte & 0xFu) : (byte >> 4);
+                    return (uint8_t)(((nib & 8u) ? 0x141414141414140Full : 0x1414140A14050014ull) >> ((nib & 7u) * 8));
+                };
+                const uint32_t wlen = cs_b >= covered ? 0u : min(rlen, covered - cs_b);     // (covered: a malformed read's zero-length ops hold columns its row has no room for)
+                if (via_lds) {
+                    uint8_t* const dst = &s_row[wv][cs_b - cs];
+                    if (wlen && !is_m) { for (uint32_t t = 0; t < wlen; ++t) dst[t] = (uint8_t)ROW_DEL; }
+                    else if (wlen) {
+                        for (uint32_t t0 = 0; t0 < wlen; t0 += 14) {                     // 14 bases a piece: 8 packed bytes hold them whatever the first nibble
+                            const uint32_t q = qs_b + t0, odd = q & 1u, lim = min(14u, wlen - t0);
+                            const uint64_t src = seq_off + (q >> 1);
+                            if (src + 8 <= stream_len && q + lim <= l_seq_r) {
+                                uint2 v; __builtin_memcpy(&v, s + src, 8);
+                                const uint2 c0 = class_bits8<true>(v.x), c1 = class_bits8<true>(v.y);      // 16 class bytes, three v_perm for four of them
+                                uint32_t wd[4];
+                                wd[0] = odd ? __builtin_amdgcn_alignbyte(c0.y, c0.x, 1) : c0.x; wd[1] = odd ? __builtin_amdgcn_alignbyte(c1.x, c0.y, 1) : c0.y;
+                                wd[2] = odd ? __builtin_amdgcn_alignbyte(c1.y, c1.x, 1) : c1.x; wd[3] = odd ? (c1.y >> 8) : c1.y;
+#pragma unroll
+                                for (uint32_t b = 0; b < 14; ++b) if (b < lim) dst[t0 + b] = (uint8_t)(wd[b >> 2] >> (8 * (b & 3u)));
+                            } else for (uint32_t b = 0; b < lim; ++b) dst[t0 + b] = base_byte(q + b);
+                        }
+                    }
+                } else if (wlen && rlen <= 512) {                                        // (rare: straight to the arena)
+                    uint8_t* const dst = rbase + cs_b;
+                    for (uint32_t t = 0; t < wlen; ++t) dst[t] = is_m ? base_byte(qs_b + t) : (uint8_t)ROW_DEL;
+                }
+                if (via_lds) {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    const uint32_t out_n = cs >= covered ? 0u : min(total, covered - cs);
+                    for (uint32_t u = 16u * (uint32_t)lane; u < out_n; u += 1024) {
+                        if (u + 16 <= out_n) { const uint4 v = *reinterpret_cast<const uint4*>(&s_row[wv][u]); __builtin_memcpy(rbase + cs + u, &v, 16); }
+                        else for (uint32_t b = u; b < out_n; ++b) rbase[cs + b] = s_row[wv][b];
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                } else {
+                    unsigned long long big = __ballot(rlen > 512);
+                    while (big) {
+                        const int o = __ffsll((long long)big) - 1;
+                        big &= big - 1;
+                        const uint32_t blen = (uint32_t)__shfl((int)wlen, o, 64), bcs = (uint32_t)__shfl((int)cs_b, o, 64), bqs = (uint32_t)__shfl((int)qs_b, o, 64);
+                        const bool bm = cig_qc((uint32_t)__shfl((int)op, o, 64)) != 0;
+                        for (uint32_t t = lane; t < blen; t += 64) rbase[bcs + t] = bm ? base_byte(bqs + t) : (uint8_t)ROW_DEL;
+                    }
+                }
+            }
             if (rlen) {
                 if (cs_b == 0 && n_ck) { Ckpt e{c0 + (uint32_t)lane, 0u, qs_b, 0u}; out[0] = e; }      // window of the read's first column
                 int64_t j = (int64_t)cs_b - D <= 0 ? 1 : ((int64_t)cs_b - D + W - 1) / W;              // first window starting at/after cs_b
@@ -319,6 +404,7 @@ __global__ __launch_bounds__(256) void k4_ck_build(const uint8_t* s, const bgp_r
             cs += __shfl(ir, 63, 64); qs += __shfl(iq, 63, 64);
             started = started || fl < 64;
         }
+        if (lane == 0 && n_ck) out[0].pad = (plain && cs >= covered) ? 0u : 1u;      // the verdict rides on the read's first checkpoint (k4_plan reads it)
     }
 }
 
@@ -888,6 +974,9 @@ __global__ __launch_bounds__(256) void k4_stats(const unsigned long long* ts, ui
 //   SEG  [2] the read starts here (n_starting_here)  [13:3] first position in the window  [21:14] bases (1..255)
 //        [22] the first base is the LOW nibble of its byte  [63:23] stream offset of that byte
 //   DEL  [13:3] first position  [25:14] one past the last position (<= W)
+//   ROW  (kind 3) a long read's stretch of the window, one class byte per COLUMN (k4_ck_build walks every long read's
+//        CIGAR once and writes them: an M/=/X column its base's class, a D / N column '-'), copied to LDS as it is
+//        [2] the read starts here  [13:3] first position  [23:14] positions - 1  [63:24] offset of the first byte in the row arena
 #ifndef BGP_G_ABL
 #define BGP_G_ABL 0                           // timing experiments: 1 no gather, 2 no staging either, 3 no layout either, 4 window header only
 #endif
@@ -922,8 +1011,10 @@ constexpr int G_BLKL = G_HIST + HB * 4;                       // GNB x PAIRCAP x
 constexpr int G_SEGI = G_BLKL + GNB * PAIRCAP * 2;            // GCAP x uint4: where a segment's bases are, where its class bytes go
 constexpr int G_GD = G_SEGI + GCAP * 16;                      // GCAP x u32: address delta | first block << 16 | last block << 21
 constexpr int G_CMAP = G_GD + GCAP * 4;                       // CH_CAP x u16: staging chunk -> segment << 3 | chunk of the segment
-constexpr int G_MISC = G_CMAP + CH_CAP * 2;                   // wave totals, flags
+constexpr int G_ROWL = G_CMAP + CH_CAP * 2;                   // GCAP x u16: the round's ROW descriptors (long reads)
+constexpr int G_MISC = (G_ROWL + GCAP * 2 + 15) & ~15;        // wave totals, flags
 constexpr int G_LDS = G_MISC + 256;
+static_assert(2 * G_LDS <= 160 * 1024, "two workgroups per CU");
 static_assert(G_SEGI % 16 == 0 && G_DELD % 16 == 0 && G_GD % 4 == 0 && G_MISC % 8 == 0, "alignment");
 constexpr int FAST_SEG = 160;                 // longest read of the gather path (<= 6 staging chunks with an odd start)
 
@@ -931,6 +1022,8 @@ struct PlanArgs {
     const bgp_record* rec; const uint4* cig4; const uint8_t* s; uint64_t stream_len, n;
     const RunDev* runs; uint32_t n_runs; uint64_t n_tiles;
     unsigned long long* slab; uint32_t* wcount; int32_t* wdel; int32_t* wslow;
+    const uint64_t* ck_off; const Ckpt* ck;       // long reads' checkpoints on this tiling (null: none, or long reads are left to the general kernel)
+    const uint64_t* row_off;                      // ... and where each one's row of class bytes starts in the arena
 };
 
 __global__ __launch_bounds__(256) void k4_plan(PlanArgs a) {
@@ -981,7 +1074,17 @@ __global__ __launch_bounds__(256) void k4_plan(PlanArgs a) {
                 }
                 if (qsum > l_seq) simple = false;
             }
-            if (!simple) {                                // left to the general kernel, with every window it overlaps
+            if (!simple && a.ck && is_long_read(n_cig, l_seq) && a.ck[a.ck_off[i]].pad == 0) {
+                // a long read that fits the mould (k4_ck_build walked its CIGAR): one ROW descriptor per window it touches
+                const uint32_t rel1 = x.z - (uint32_t)r_start_pos;
+                for (uint32_t w = wf; w <= wl; ++w) {
+                    const uint32_t w0 = (w - tb) * (uint32_t)W;
+                    const uint32_t lo = max(rel0, w0) - w0, hi = min(rel1, w0 + (uint32_t)W) - w0;
+                    const uint32_t slot = atomicAdd(&a.wcount[w], 1u);
+                    if (slot < SLAB_CAP) a.slab[(uint64_t)w * SLAB_CAP + slot] = 3ull | (w == wf ? 4ull : 0ull) | ((unsigned long long)lo << 3) | ((unsigned long long)(hi - lo - 1) << 14) | ((a.row_off[i] + (w0 + lo - rel0)) << 24);
+                }
+                wf = 0xFFFFFFFFu;
+            } else if (!simple) {                         // left to the general kernel, with every window it overlaps
                 atomicAdd(&a.wslow[wf], 1); atomicAdd(&a.wslow[wl + 1], -1);
             } else {
                 uint32_t p = 0, q = 0;                    // columns / query bases before the op (file header: cstart, qstart)
@@ -1094,23 +1197,10 @@ __global__ __launch_bounds__(1024) void k4_wscan(int32_t* wdel, const int32_t* w
     }
 }
 
-// four nt16 codes, one per byte -> the bit positions of their class counters (A 0, C 6, G 12, T 18, anything else 24)
-__device__ __forceinline__ uint32_t class_bits4(uint32_t x) {
-    const uint32_t idx = x & 0x07070707u;
-    const uint32_t lo = __builtin_amdgcn_perm(0x1818180Cu, 0x18060018u, idx);      // codes 0..7 : 24 0 6 24 | 12 24 24 24
-    const uint32_t hi = __builtin_amdgcn_perm(0x18181818u, 0x18181812u, idx);      // codes 8..15: 18 24 24 24 | 24 24 24 24
-    const uint32_t sel = ((x >> 1) & 0x04040404u) | 0x03020100u;                   // byte i: i (from lo) or 4 + i (from hi)
-    return __builtin_amdgcn_perm(hi, lo, sel);
-}
-// eight packed bases (read.d:368-373: the first base of a byte is its high nibble) -> eight class bytes in base order
-__device__ __forceinline__ uint2 class_bits8(uint32_t cur) {
-    const uint32_t ev = class_bits4((cur >> 4) & 0x0F0F0F0Fu), od = class_bits4(cur & 0x0F0F0F0Fu);   // bases 0,2,4,6 | 1,3,5,7
-    return make_uint2(__builtin_amdgcn_perm(od, ev, 0x05010400u), __builtin_amdgcn_perm(od, ev, 0x07030602u));
-}
-
 struct GArgs {
     const uint8_t* s; const unsigned long long* slab; const uint32_t* wcount; const int32_t* wdel; const TileB* tiles; uint64_t n_tiles;
     bgp_column* cols; unsigned long long* hist; unsigned long long* tile_stats; uint32_t* deep; uint32_t* n_deep;
+    const uint8_t* rows;          // long reads (ROW descriptors): their class bytes in reference coordinates, one byte per column, written by k4_ck_build
 };
 
 // sum / max over the 64 lanes of a wave with DPP (row reductions, then row_bcast15 / row_bcast31); result in every lane
@@ -1163,7 +1253,10 @@ template <int L0> __device__ __forceinline__ void gather8(uint32_t& acc, uint32_
 #ifndef BGP_G_MINW
 #define BGP_G_MINW (GNW / 2)                  // two workgroups per CU: their waves per SIMD bound the registers (128 for 8-wave workgroups)
 #endif
-__global__ __launch_bounds__(GT, BGP_G_MINW) void k4_exec(GArgs a) {
+template <bool ROWS> __global__ __launch_bounds__(GT, BGP_G_MINW) void k4_exec(GArgs a) {
+    constexpr int FSH = ROWS ? 5 : 6;                  // bits of a packed class counter
+    constexpr uint32_t FM = (1u << FSH) - 1u;
+    constexpr uint32_t PAIRS = ROWS ? 24 : 56;         // (segment, 64 positions) pairs a packed counter takes before it is unpacked
     extern __shared__ __attribute__((aligned(16))) uint8_t glds[];
     uint8_t* const stage = glds;
     uint4* const tailm = reinterpret_cast<uint4*>(glds + G_TAIL);
@@ -1174,6 +1267,7 @@ __global__ __launch_bounds__(GT, BGP_G_MINW) void k4_exec(GArgs a) {
     uint4* const segi = reinterpret_cast<uint4*>(glds + G_SEGI);
     uint32_t* const gd = reinterpret_cast<uint32_t*>(glds + G_GD);
     uint16_t* const cmap = reinterpret_cast<uint16_t*>(glds + G_CMAP);
+    uint16_t* const rowl = reinterpret_cast<uint16_t*>(glds + G_ROWL);
     uint32_t* const misc = reinterpret_cast<uint32_t*>(glds + G_MISC);     // [0..15] wave totals, [16] descriptors of the round that fit
     // Persistent: a workgroup owns a contiguous range of windows and walks it, so a read staged by two neighbouring
     // windows is fetched from HBM once, and -- the point -- the NEXT window's header and first descriptors are
@@ -1205,7 +1299,7 @@ __global__ __launch_bounds__(GT, BGP_G_MINW) void k4_exec(GArgs a) {
     };
     auto settle = [](Pre& p) {                          // the values have arrived (or: wait for them here, once) and count as new
         uint32_t dl = (uint32_t)p.d, dh = (uint32_t)(p.d >> 32);
-        asm volatile("; prefetched window settled" : "+v"(dl), "+v"(dh), "+v"(p.col.x), "+v"(p.col.y), "+v"(p.tt.x), "+v"(p.tt.y), "+v"(p.tt.w), "+v"(p.n), "+v"(p.wd));
+        asm volatile("; prefetched window settled" : "+v"(dl), "+v"(dh), "+v"(p.col.x), "+v"(p.col.y), "+v"(p.tt.x), "+v"(p.tt.y), "+v"(p.tt.z), "+v"(p.tt.w), "+v"(p.n), "+v"(p.wd));
         p.d = ((unsigned long long)dh << 32) | dl;
     };
     Pre pre = prefetch(tile);
@@ -1216,10 +1310,10 @@ __global__ __launch_bounds__(GT, BGP_G_MINW) void k4_exec(GArgs a) {
 #endif
     settle(pre);
     const unsigned long long d_first = pre.d;
-    struct { uint64_t col_out; uint32_t T0, Tend, pad; } tb;
+    struct { uint64_t col_out; uint32_t T0, Tend, run_start, pad; } tb;
     tb.col_out = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)pre.col.y) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)pre.col.x);
     tb.T0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)pre.tt.x); tb.Tend = (uint32_t)__builtin_amdgcn_readfirstlane((int)pre.tt.y);
-    tb.pad = (uint32_t)__builtin_amdgcn_readfirstlane((int)pre.tt.w);
+    tb.pad = (uint32_t)__builtin_amdgcn_readfirstlane((int)pre.tt.w); tb.run_start = (uint32_t)__builtin_amdgcn_readfirstlane((int)pre.tt.z);
     const uint32_t n_desc = (uint32_t)__builtin_amdgcn_readfirstlane((int)pre.n);
     const int32_t wd = __builtin_amdgcn_readfirstlane(pre.wd);
     if (tile + 1 < tile_end) pre = prefetch(tile + 1);
@@ -1228,9 +1322,9 @@ __global__ __launch_bounds__(GT, BGP_G_MINW) void k4_exec(GArgs a) {
     if (tb.T0 != 0xFFFFFFFFu) continue;
 #endif
     const unsigned long long* slab = a.slab + tile * (uint64_t)SLAB_CAP;
-    uint32_t cA[GBPW], cC[GBPW], cG[GBPW], cT[GBPW], cO[GBPW];
+    uint32_t cA[GBPW], cC[GBPW], cG[GBPW], cT[GBPW], cO[GBPW], cD[GBPW];        // (cD: '-' of long reads' rows; ROWS only)
 #pragma unroll
-    for (int b = 0; b < GBPW; ++b) { cA[b] = 0; cC[b] = 0; cG[b] = 0; cT[b] = 0; cO[b] = 0; }
+    for (int b = 0; b < GBPW; ++b) { cA[b] = 0; cC[b] = 0; cG[b] = 0; cT[b] = 0; cO[b] = 0; cD[b] = 0; }
     GSTAMP(0);        // (the header and the first descriptors were requested a window ago)
 
     for (uint32_t base = 0; base < (BGP_G_ABL >= 3 ? 0u : n_desc);) {
@@ -1240,10 +1334,13 @@ __global__ __launch_bounds__(GT, BGP_G_MINW) void k4_exec(GArgs a) {
         if ((uint32_t)t < nr) d = base == 0 ? d_first : slab[base + t];
         uint32_t kind = (uint32_t)d & 3u;
         const uint32_t lo = ((uint32_t)d >> 3) & 0x7FFu, f14 = (uint32_t)(d >> 14);
-        const uint32_t len = f14 & 0xFFu, nib = (f14 >> 8) & 1u;
-        const uint32_t nch = kind == 1 ? (len + nib + 15) >> 4 : 0u;        // 16-byte units of class bytes
-        const uint32_t c32 = (nch + 1) >> 1;                                  // 32-base staging chunks
-        const uint32_t units = kind == 1 ? (nch + 4) | (c32 << 16) : 0u;      // low half: the bytes + 64 of padding behind them
+        const bool is_row = ROWS && kind == 3;                                // (only a stream with long reads has them: the other instantiation carries none of this)
+        if (!ROWS && kind == 3) kind = 0;
+        const uint32_t len = is_row ? (f14 & 0x3FFu) + 1u : f14 & 0xFFu, nib = is_row ? 0u : (f14 >> 8) & 1u;      // (ROW: up to W positions)
+        const uint32_t nch = (kind == 1 || is_row) ? (len + nib + 15) >> 4 : 0u;      // 16-byte units of class bytes (SEG, ROW)
+        const uint32_t c32 = kind == 1 ? (nch + 1) >> 1 : 0u;                 // 32-base staging chunks (a ROW is copied as it is)
+        const uint32_t units = (kind == 1 || is_row) ? (nch + 4) | (c32 << 16) : 0u;    // low half: the bytes + 64 of padding behind them
+        if (ROWS && t == 0) misc[18] = 0;                                     // ROW descriptors of the round
         const uint32_t inc = wave_incl_u32(units, lane);
         if (lane == 63) misc[wave] = inc;
         GSTAMP(1);    // descriptors arrived, wave scan
@@ -1279,6 +1376,11 @@ __global__ __launch_bounds__(GT, BGP_G_MINW) void k4_exec(GArgs a) {
             const uint32_t c0 = ex >> 16;
             for (uint32_t j = 0; j < c32; ++j) cmap[c0 + j] = (uint16_t)((t << 3) | j);
             if (d & 4u) atomicAdd(&nst[lo >> 1], 1u << ((lo & 1u) * 16));   // n_starting_here, pileup.d:386,422 (a count per position stays below 2^16: the slab holds W descriptors)
+        } else if (is_row) {
+            { const uint64_t rsrc = d >> 24; segi[t] = make_uint4((uint32_t)rsrc, (uint32_t)(rsrc >> 32) | ((len - 1) << 16), data_off, 0u); }   // where the row's class bytes are (k4_ck_build wrote them) | its length | where they go
+            gd[t] = (data_off - lo + W) | ((lo >> 6) << 16) | (((lo + len - 1) >> 6) << 21);
+            rowl[atomicAdd(&misc[18], 1u)] = (uint16_t)t;
+            if (d & 4u) atomicAdd(&nst[lo >> 1], 1u << ((lo & 1u) * 16));
         } else {
             gd[t] = 1u << 16;                                                 // first block 1, last block 0: overlaps nothing
             if (kind == 2) { atomicAdd(&deld[lo], 1u); atomicAdd(&deld[f14 & 0xFFFu], 0xFFFFFFFFu); }
@@ -1309,13 +1411,26 @@ __global__ __launch_bounds__(GT, BGP_G_MINW) void k4_exec(GArgs a) {
         for (int it = 0; it < STAGE_IT; ++it) {
             if (ce[it] != 0xFFFFFFFFu) {
                 const int32_t valid = (int32_t)((ce[it] >> 16) & 0xFFu);           // staged bytes of this lane that belong to the segment (incl. the skipped nibble): 1..32
-                const uint2 c0 = class_bits8(pk[it].x), c1 = class_bits8(pk[it].y), c2 = class_bits8(pk[it].z), c3 = class_bits8(pk[it].w);
+                const uint2 c0 = class_bits8<ROWS>(pk[it].x), c1 = class_bits8<ROWS>(pk[it].y), c2 = class_bits8<ROWS>(pk[it].z), c3 = class_bits8<ROWS>(pk[it].w);
                 const uint4 t0 = tailm[min(valid, 16)], t1 = tailm[max(valid - 16, 0)];
                 uint4 o0 = make_uint4(c0.x | t0.x, c0.y | t0.y, c1.x | t0.z, c1.y | t0.w);
                 const uint4 o1 = make_uint4(c2.x | t1.x, c2.y | t1.y, c3.x | t1.z, c3.y | t1.w);
                 if (ce[it] >> 24) o0.x |= 0xFFu;
                 uint4* dst = reinterpret_cast<uint4*>(stage + (ce[it] & 0xFFFFu));
                 dst[0] = o0; dst[1] = o1;                                         // (a second half past the segment lands in its own padding)
+            }
+        }
+        // ---- long reads: a ROW is copied as it is (class bytes in reference coordinates), a wave per row, 16 bytes a lane
+        if (ROWS) {
+            const uint32_t n_rows = misc[18];
+            for (uint32_t rr = (uint32_t)wave; rr < n_rows; rr += GNW) {
+                const uint4 g = segi[rowl[rr]];
+                const uint32_t rlen = (g.y >> 16) + 1u, u = 16u * (uint32_t)lane;
+                if (u < rlen) {
+                    uint4 v; __builtin_memcpy(&v, a.rows + ((((uint64_t)(g.y & 0xFFu)) << 32) | g.x) + u, 16);
+                    const uint4 tm = tailm[min(rlen - u, 16u)];
+                    *reinterpret_cast<uint4*>(stage + g.z + u) = make_uint4(v.x | tm.x, v.y | tm.y, v.z | tm.z, v.w | tm.w);
+                }
             }
         }
         GSTAMP(5);    // staged
@@ -1331,18 +1446,21 @@ __global__ __launch_bounds__(GT, BGP_G_MINW) void k4_exec(GArgs a) {
             uint16_t* const bl = blk_l + b * PAIRCAP;
             uint32_t n = 0;
             auto walk = [&]() {
-                for (uint32_t p0 = 0; p0 < n; p0 += 56) {
-                    const uint32_t cnt = min(56u, n - p0);
+                for (uint32_t p0 = 0; p0 < n; p0 += PAIRS) {
+                    const uint32_t cnt = min(PAIRS, n - p0);
                     const uint32_t vc = (uint32_t)lane < cnt ? (uint32_t)bl[p0 + lane] : csent;
                     uint32_t acc = 0;
                     gather8<0>(acc, vc, paddr);
                     if (cnt > 8) gather8<8>(acc, vc, paddr);
                     if (cnt > 16) gather8<16>(acc, vc, paddr);
-                    if (cnt > 24) gather8<24>(acc, vc, paddr);
-                    if (cnt > 32) gather8<32>(acc, vc, paddr);
-                    if (cnt > 40) gather8<40>(acc, vc, paddr);
-                    if (cnt > 48) gather8<48>(acc, vc, paddr);
-                    cA[bb] += acc & 63u; cC[bb] += (acc >> 6) & 63u; cG[bb] += (acc >> 12) & 63u; cT[bb] += (acc >> 18) & 63u; cO[bb] += (acc >> 24) & 63u;
+                    if (!ROWS) {
+                        if (cnt > 24) gather8<24>(acc, vc, paddr);
+                        if (cnt > 32) gather8<32>(acc, vc, paddr);
+                        if (cnt > 40) gather8<40>(acc, vc, paddr);
+                        if (cnt > 48) gather8<48>(acc, vc, paddr);
+                    }
+                    cA[bb] += acc & FM; cC[bb] += (acc >> FSH) & FM; cG[bb] += (acc >> (2 * FSH)) & FM; cT[bb] += (acc >> (3 * FSH)) & FM; cO[bb] += (acc >> (4 * FSH)) & FM;
+                    if (ROWS) cD[bb] += (acc >> (5 * FSH)) & FM;
                 }
                 n = 0;
             };
@@ -1395,7 +1513,7 @@ __global__ __launch_bounds__(GT, BGP_G_MINW) void k4_exec(GArgs a) {
         const uint32_t p = 64 * (wave * GBPW + bb) + lane;
         const uint32_t sw = nst[p >> 1];
         if (p < np) {
-            const uint32_t D = dl[bb], S = (sw >> ((p & 1u) * 16)) & 0xFFFFu;
+            const uint32_t D = dl[bb] + (ROWS ? cD[bb] : 0u), S = (sw >> ((p & 1u) * 16)) & 0xFFFFu;
             const uint32_t cov = cA[bb] + cC[bb] + cG[bb] + cT[bb] + cO[bb] + D;
             uint4* o4 = reinterpret_cast<uint4*>(out + p);
             o4[0] = make_uint4(cov, S, cA[bb], cC[bb]);
@@ -1564,7 +1682,8 @@ int k34_pileup(bgp_ctx* c) {
     }
     // A stream of long reads (a quarter of its reads or more) is left to the general kernel entirely, on its own tiling of
     // 4096 positions; every other stream is tiled for the gather path, the general kernel taking the windows that leaves.
-    const bool long_stream = (uint64_t)st[3] * 4 >= n && st[3] > 0;
+    static const bool long_rows = !(getenv("BGP_LONG_ROWS") && atoi(getenv("BGP_LONG_ROWS")) == 0);     // long reads through the gather path as rows in reference coordinates (0: the general kernel, as before)
+    const bool long_stream = !long_rows && (uint64_t)st[3] * 4 >= n && st[3] > 0;
     const uint32_t tw = long_stream ? (uint32_t)WO : (uint32_t)W;
     uint64_t col_base = 0, tile_base = 0;
     for (auto& r : runs) {
@@ -1613,6 +1732,29 @@ int k34_pileup(bgp_ctx* c) {
         }
         BGP_TRY(c->d_col_lo.reserve(tile_base * 32));
         a.tile_stats = (unsigned long long*)c->d_col_lo.p;
+        a.ck = nullptr; a.ck_off = nullptr;
+        bool have_rows = false;
+        if (st[3]) {                                   // the stream holds long reads: build their per-window CIGAR checkpoints (the planner reads their verdicts)
+            TimedRegion tc(c, "k4_checkpoints", c->sum_ncig * 4);
+            BGP_TRY(c->d_ck_off.reserve((n + 2) * 8));
+            uint64_t* ck_off = c->d_ck_off.as<uint64_t>();
+            const bool rows = long_rows && !long_stream;    // ... and, for the gather path, every long read's row of class bytes (one per column)
+            uint64_t* row_off = nullptr;
+            if (rows) { BGP_TRY(c->d_row_off.reserve((n + 2) * 8)); row_off = c->d_row_off.as<uint64_t>(); }
+            hipLaunchKernelGGL(k4_ck_count, dim3(nb), dim3(256), 0, c->stream, a.rec, n, a.runs, n_runs, ck_off, row_off, tw);
+            uint64_t total_ck = 0, total_cols = 0;
+            BGP_TRY(scan_exclusive_u64(c, ck_off, ck_off, n, &total_ck));
+            if (rows) {
+                BGP_TRY(scan_exclusive_u64(c, row_off, row_off, n, &total_cols));
+                if (total_cols >= (1ull << 40)) return BGP_EINVAL;
+                BGP_TRY(c->d_rows.reserve(total_cols + 64));
+            }
+            BGP_TRY(c->d_ck.reserve((total_ck + 1) * sizeof(Ckpt)));
+            BGP_HIP(hipMemsetAsync(c->d_ck.p, 0xFF, (total_ck + 1) * sizeof(Ckpt), c->stream));
+            hipLaunchKernelGGL(k4_ck_build, dim3(nb), dim3(256), 0, c->stream, a.s, a.stream_len, a.rec, n, a.runs, n_runs, ck_off, c->d_ck.as<Ckpt>(), tw, row_off, rows ? c->d_rows.as<uint8_t>() : nullptr);
+            have_rows = rows;
+            a.ck = c->d_ck.as<Ckpt>(); a.ck_off = ck_off;
+        }
         if (long_stream) {
             hipLaunchKernelGGL(k4_all_listed, dim3((unsigned)((tile_base + 255) / 256)), dim3(256), 0, c->stream, c->d_deep.as<uint32_t>() + 1, c->d_deep.as<uint32_t>(), (uint32_t)tile_base);
         } else {
@@ -1628,6 +1770,7 @@ int k34_pileup(bgp_ctx* c) {
             pa.rec = a.rec; pa.cig4 = c->cig4_ok ? c->d_cig4.as<uint4>() : nullptr; pa.s = a.s; pa.stream_len = a.stream_len; pa.n = n;
             pa.runs = a.runs; pa.n_runs = n_runs; pa.n_tiles = tile_base;
             pa.slab = (unsigned long long*)c->d_slab.p; pa.wcount = c->d_wcount.as<uint32_t>(); pa.wdel = c->d_wdel.as<int32_t>(); pa.wslow = c->d_wslow.as<int32_t>();
+            pa.ck = have_rows ? a.ck : nullptr; pa.ck_off = a.ck_off; pa.row_off = have_rows ? c->d_row_off.as<uint64_t>() : nullptr;
             hipLaunchKernelGGL(k4_plan, dim3(nb), dim3(256), 0, c->stream, pa);
             const unsigned wb = (unsigned)((tile_base + 1023) / 1024);
             BGP_TRY(c->d_scan_tmp.reserve((size_t)wb * 8 + 16));
@@ -1636,19 +1779,6 @@ int k34_pileup(bgp_ctx* c) {
             hipLaunchKernelGGL(k4_wscan_mid, dim3(1), dim3(1024), 0, c->stream, btot, wb);
             hipLaunchKernelGGL(k4_wscan, dim3(wb), dim3(1024), 0, c->stream, pa.wdel, pa.wslow, pa.wcount, c->d_tiles.as<TileB>(), tile_base, btot, c->d_deep.as<uint32_t>() + 1, c->d_deep.as<uint32_t>());
         }
-        }
-        a.ck = nullptr; a.ck_off = nullptr;
-        if (st[3]) {                                   // the stream holds long reads: build their per-window CIGAR checkpoints
-            TimedRegion tc(c, "k4_checkpoints", c->sum_ncig * 4);
-            BGP_TRY(c->d_ck_off.reserve((n + 2) * 8));
-            uint64_t* ck_off = c->d_ck_off.as<uint64_t>();
-            hipLaunchKernelGGL(k4_ck_count, dim3(nb), dim3(256), 0, c->stream, a.rec, n, a.runs, n_runs, ck_off, tw);
-            uint64_t total_ck = 0;
-            BGP_TRY(scan_exclusive_u64(c, ck_off, ck_off, n, &total_ck));
-            BGP_TRY(c->d_ck.reserve((total_ck + 1) * sizeof(Ckpt)));
-            BGP_HIP(hipMemsetAsync(c->d_ck.p, 0xFF, (total_ck + 1) * sizeof(Ckpt), c->stream));
-            hipLaunchKernelGGL(k4_ck_build, dim3(nb), dim3(256), 0, c->stream, a.s, a.rec, n, a.runs, n_runs, ck_off, c->d_ck.as<Ckpt>(), tw);
-            a.ck = c->d_ck.as<Ckpt>(); a.ck_off = ck_off;
         }
 #ifdef BGP_G_PROF
         unsigned long long* g_prof_dev = nullptr;
@@ -1663,8 +1793,10 @@ int k34_pileup(bgp_ctx* c) {
             GArgs g;
             g.s = a.s; g.slab = (const unsigned long long*)c->d_slab.p; g.wcount = c->d_wcount.as<uint32_t>(); g.wdel = c->d_wdel.as<int32_t>(); g.tiles = a.tiles; g.n_tiles = tile_base;
             g.cols = a.cols; g.hist = a.hist; g.tile_stats = a.tile_stats; g.deep = c->d_deep.as<uint32_t>() + 1; g.n_deep = c->d_deep.as<uint32_t>();
+            g.rows = have_rows ? c->d_rows.as<uint8_t>() : nullptr;
             static const unsigned g_blocks = getenv("BGP_G_BLOCKS") ? (unsigned)atoi(getenv("BGP_G_BLOCKS")) : 512u;     // two 76 KB workgroups per CU x 256 CUs
-            hipLaunchKernelGGL(k4_exec, dim3((unsigned)std::min<uint64_t>(tile_base, g_blocks)), dim3(GT), (size_t)G_LDS, c->stream, g);
+            if (have_rows) hipLaunchKernelGGL(k4_exec<true>, dim3((unsigned)std::min<uint64_t>(tile_base, g_blocks)), dim3(GT), (size_t)G_LDS, c->stream, g);
+            else hipLaunchKernelGGL(k4_exec<false>, dim3((unsigned)std::min<uint64_t>(tile_base, g_blocks)), dim3(GT), (size_t)G_LDS, c->stream, g);
         }
         // windows the gather path left on the list (long reads, odd CIGARs, too deep): the general kernel
         const unsigned dgrid = (unsigned)std::min<uint64_t>(tile_base, 2048);
