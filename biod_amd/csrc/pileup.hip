@@ -275,7 +275,7 @@ __device__ __forceinline__ uint32_t run_of_record(const RunDev* runs, uint32_t n
     return lo;
 }
 
-__global__ __launch_bounds__(256) void k4_ck_count(const bgp_record* rec, uint64_t n, const RunDev* runs, uint32_t n_runs, uint64_t* n_ck, uint64_t* n_cols, uint32_t W) {
+__global__ __launch_bounds__(256) void k4_ck_count(const bgp_record* rec, uint64_t n, const RunDev* runs, uint32_t n_runs, uint64_t* n_ck, uint64_t* n_cols, uint64_t* n_chunks, uint32_t W) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const bgp_record r = rec[i];
@@ -286,13 +286,11 @@ __global__ __launch_bounds__(256) void k4_ck_count(const bgp_record* rec, uint64
         cols = (uint32_t)r.end_pos - (uint32_t)r.pos;
     }
     n_ck[i] = c;
-    if (n_cols) n_cols[i] = cols;          // a long read's row in the arena: one class byte per column it covers
+    if (n_cols) { n_cols[i] = cols; n_chunks[i] = cols ? ((r.flag_nc & 0xFFFFu) + 63) / 64 : 0; }      // a long read's row in the arena: one class byte per column it covers; its CIGAR in chunks of 64 ops
 }
 
 __global__ __launch_bounds__(256) void k4_ck_build(const uint8_t* s, uint64_t stream_len, const bgp_record* rec, uint64_t n, const RunDev* runs, uint32_t n_runs,
-                                                   const uint64_t* ck_off, Ckpt* ck, uint32_t W_, const uint64_t* row_off, uint8_t* rows) {
-    constexpr int RB_CAP = 4096;
-    __shared__ __attribute__((aligned(16))) uint8_t s_row[4][RB_CAP];
+                                                   const uint64_t* ck_off, Ckpt* ck, uint32_t W_, const uint64_t* chunk_off, uint4* cst) {
     const int64_t W = (int64_t)W_;
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
@@ -336,7 +334,48 @@ __global__ __launch_bounds__(256) void k4_ck_build(const uint8_t* s, uint64_t st
             const uint32_t ir = wave_incl_u32(rlen, lane), iq = wave_incl_u32(qlen, lane);
             const uint32_t cs_b = cs + ir - rlen, qs_b = qs + iq - qlen;
             if (__ballot(active && cig_rc(op) && (op >> 4) == 0) || __ballot(rlen && cig_qc(op) && qs_b + qlen > l_seq_r)) plain = false;
-            if (rows) {
+            if (cst && lane == 0) cst[chunk_off[ri] + c0 / 64] = make_uint4((uint32_t)ri, c0 | (started ? 0x80000000u : 0u), cs, qs);      // where the chunk starts: k4_rows_build writes its columns
+            if (rlen) {
+                if (cs_b == 0 && n_ck) { Ckpt e{c0 + (uint32_t)lane, 0u, qs_b, 0u}; out[0] = e; }      // window of the read's first column
+                int64_t j = (int64_t)cs_b - D <= 0 ? 1 : ((int64_t)cs_b - D + W - 1) / W;              // first window starting at/after cs_b
+                if (j < 1) j = 1;
+                for (; j < (int64_t)n_ck && D + j * W < (int64_t)(cs_b + rlen); ++j) { Ckpt e{c0 + (uint32_t)lane, cs_b, qs_b, 0u}; out[j] = e; }
+            }
+            cs += __shfl(ir, 63, 64); qs += __shfl(iq, 63, 64);
+            started = started || fl < 64;
+        }
+        if (lane == 0 && n_ck) out[0].pad = (plain && cs >= covered) ? 0u : 1u;      // the verdict rides on the read's first checkpoint (k4_plan reads it)
+    }
+}
+
+// The rows of the gather path (ROW descriptors): one class byte per COLUMN of every long read, in the ROWS layout of k4_exec.
+// One wave per chunk of 64 CIGAR ops, from the state k4_ck_build left where the chunk starts -- the walk itself is serial
+// per read, this part is not: written inside the walk it took 13 ms of cfg5's 18, the SIMDs half idle behind one read's
+// chain of chunks.
+__global__ __launch_bounds__(256) void k4_rows_build(const uint8_t* s, uint64_t stream_len, const bgp_record* rec, const uint4* cst, uint64_t n_chunks,
+                                                     const uint64_t* row_off, uint8_t* rows) {
+    constexpr int RB_CAP = 4096;
+    __shared__ __attribute__((aligned(16))) uint8_t s_row[4][RB_CAP];
+    const uint64_t ch = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (ch >= n_chunks) return;
+    const uint4 st = cst[ch];
+    if (st.x == 0xFFFFFFFFu) return;                       // (a chunk behind the read's last column: the walk never got there)
+    const uint64_t ri = st.x;
+    const uint32_t c0 = st.y & 0x7FFFFFFFu, cs = st.z, qs = st.w;
+    const bool started = (st.y >> 31) != 0;
+    const bgp_record r = rec[ri];
+    const uint32_t covered = (uint32_t)r.end_pos - (uint32_t)r.pos, n_cig = r.flag_nc & 0xFFFFu, l_name = r.bin_mq_nl & 0xFFu, l_seq_r = (uint32_t)r.l_seq;
+    const uint64_t rec_off = r.rec_off;
+    const bool active = c0 + lane < n_cig;
+    const uint32_t op = active ? ld_u32(s + rec_off + 36 + l_name + 4ull * (c0 + lane)) : 0u;
+    int fl = 64;
+    if (!started) { const unsigned long long stb = __ballot(active && cig_rc(op) && (op & 15u) != 3u); fl = stb ? __ffsll((long long)stb) - 1 : 64; }
+    uint32_t rlen, qlen;
+    op_lens(op, active, started || lane >= fl, &rlen, &qlen);
+    const uint32_t ir = wave_incl_u32(rlen, lane), iq = wave_incl_u32(qlen, lane);
+    const uint32_t cs_b = cs + ir - rlen, qs_b = qs + iq - qlen;
+        {
                 // the read's row for the gather path: one class byte per COLUMN, in the ROWS layout of k4_exec (A 0, C 5, G 10,
                 // T 15, anything else 20, '-' 25).  A lane writes its own op's columns -- into LDS: the chunk's 64 ops cover a few
                 // hundred consecutive columns, which then leave as 16-byte stores (byte stores straight to the arena, 64 lanes
@@ -395,17 +434,6 @@ __global__ __launch_bounds__(256) void k4_ck_build(const uint8_t* s, uint64_t st
                     }
                 }
             }
-            if (rlen) {
-                if (cs_b == 0 && n_ck) { Ckpt e{c0 + (uint32_t)lane, 0u, qs_b, 0u}; out[0] = e; }      // window of the read's first column
-                int64_t j = (int64_t)cs_b - D <= 0 ? 1 : ((int64_t)cs_b - D + W - 1) / W;              // first window starting at/after cs_b
-                if (j < 1) j = 1;
-                for (; j < (int64_t)n_ck && D + j * W < (int64_t)(cs_b + rlen); ++j) { Ckpt e{c0 + (uint32_t)lane, cs_b, qs_b, 0u}; out[j] = e; }
-            }
-            cs += __shfl(ir, 63, 64); qs += __shfl(iq, 63, 64);
-            started = started || fl < 64;
-        }
-        if (lane == 0 && n_ck) out[0].pad = (plain && cs >= covered) ? 0u : 1u;      // the verdict rides on the read's first checkpoint (k4_plan reads it)
-    }
 }
 
 // ---- K4: per-position column summary ----------------------------------------------------------
@@ -1334,7 +1362,7 @@ template <bool ROWS> __global__ __launch_bounds__(GT, BGP_G_MINW) void k4_exec(G
         if ((uint32_t)t < nr) d = base == 0 ? d_first : slab[base + t];
         uint32_t kind = (uint32_t)d & 3u;
         const uint32_t lo = ((uint32_t)d >> 3) & 0x7FFu, f14 = (uint32_t)(d >> 14);
-        const bool is_row = ROWS && kind == 3;                                // (only a stream with long reads has them: the other instantiation carries none of this)
+        bool is_row = ROWS && kind == 3;                                      // (only a stream with long reads has them: the other instantiation carries none of this)
         if (!ROWS && kind == 3) kind = 0;
         const uint32_t len = is_row ? (f14 & 0x3FFu) + 1u : f14 & 0xFFu, nib = is_row ? 0u : (f14 >> 8) & 1u;      // (ROW: up to W positions)
         const uint32_t nch = (kind == 1 || is_row) ? (len + nib + 15) >> 4 : 0u;      // 16-byte units of class bytes (SEG, ROW)
@@ -1361,7 +1389,7 @@ template <bool ROWS> __global__ __launch_bounds__(GT, BGP_G_MINW) void k4_exec(G
             __syncthreads();
             n_fit = misc[16]; n_chunks = misc[17];
         }
-        if ((uint32_t)t >= n_fit) kind = 0;
+        if ((uint32_t)t >= n_fit) { kind = 0; is_row = false; }
         {   // every byte the round may look at starts as padding (0xFF): consecutive lanes, consecutive 16 bytes -- no bank conflicts,
             // where four stores per segment at the segments' own addresses had plenty
             const uint32_t extent = min((uint32_t)G_STAGE, 64 + 16 * (total & 0xFFFFu));
@@ -1739,19 +1767,24 @@ int k34_pileup(bgp_ctx* c) {
             BGP_TRY(c->d_ck_off.reserve((n + 2) * 8));
             uint64_t* ck_off = c->d_ck_off.as<uint64_t>();
             const bool rows = long_rows && !long_stream;    // ... and, for the gather path, every long read's row of class bytes (one per column)
-            uint64_t* row_off = nullptr;
-            if (rows) { BGP_TRY(c->d_row_off.reserve((n + 2) * 8)); row_off = c->d_row_off.as<uint64_t>(); }
-            hipLaunchKernelGGL(k4_ck_count, dim3(nb), dim3(256), 0, c->stream, a.rec, n, a.runs, n_runs, ck_off, row_off, tw);
-            uint64_t total_ck = 0, total_cols = 0;
+            uint64_t* row_off = nullptr; uint64_t* chunk_off = nullptr;
+            if (rows) { BGP_TRY(c->d_row_off.reserve((n + 2) * 8)); BGP_TRY(c->d_chunk_off.reserve((n + 2) * 8)); row_off = c->d_row_off.as<uint64_t>(); chunk_off = c->d_chunk_off.as<uint64_t>(); }
+            hipLaunchKernelGGL(k4_ck_count, dim3(nb), dim3(256), 0, c->stream, a.rec, n, a.runs, n_runs, ck_off, row_off, chunk_off, tw);
+            uint64_t total_ck = 0, total_cols = 0, total_chunks = 0;
             BGP_TRY(scan_exclusive_u64(c, ck_off, ck_off, n, &total_ck));
             if (rows) {
                 BGP_TRY(scan_exclusive_u64(c, row_off, row_off, n, &total_cols));
-                if (total_cols >= (1ull << 40)) return BGP_EINVAL;
+                BGP_TRY(scan_exclusive_u64(c, chunk_off, chunk_off, n, &total_chunks));
+                if (total_cols >= (1ull << 40) || total_chunks >= (1ull << 33)) return BGP_EINVAL;
                 BGP_TRY(c->d_rows.reserve(total_cols + 64));
+                BGP_TRY(c->d_chunk_state.reserve((total_chunks + 1) * 16));
+                BGP_HIP(hipMemsetAsync(c->d_chunk_state.p, 0xFF, (total_chunks + 1) * 16, c->stream));
             }
             BGP_TRY(c->d_ck.reserve((total_ck + 1) * sizeof(Ckpt)));
             BGP_HIP(hipMemsetAsync(c->d_ck.p, 0xFF, (total_ck + 1) * sizeof(Ckpt), c->stream));
-            hipLaunchKernelGGL(k4_ck_build, dim3(nb), dim3(256), 0, c->stream, a.s, a.stream_len, a.rec, n, a.runs, n_runs, ck_off, c->d_ck.as<Ckpt>(), tw, row_off, rows ? c->d_rows.as<uint8_t>() : nullptr);
+            hipLaunchKernelGGL(k4_ck_build, dim3(nb), dim3(256), 0, c->stream, a.s, a.stream_len, a.rec, n, a.runs, n_runs, ck_off, c->d_ck.as<Ckpt>(), tw, chunk_off, rows ? c->d_chunk_state.as<uint4>() : nullptr);
+            if (rows && total_chunks) { TimedRegion tr(c, "k4_rows", total_cols);
+            hipLaunchKernelGGL(k4_rows_build, dim3((unsigned)((total_chunks + 3) / 4)), dim3(256), 0, c->stream, a.s, a.stream_len, a.rec, c->d_chunk_state.as<uint4>(), total_chunks, row_off, c->d_rows.as<uint8_t>()); }
             have_rows = rows;
             a.ck = c->d_ck.as<Ckpt>(); a.ck_off = ck_off;
         }
