@@ -1372,6 +1372,9 @@ template <bool ROWS> __global__ __launch_bounds__(GT, BGP_G_MINW) void k4_exec(G
         const uint32_t inc = wave_incl_u32(units, lane);
         if (lane == 63) misc[wave] = inc;
         GSTAMP(1);    // descriptors arrived, wave scan
+#ifdef BGP_G_PROF
+        pacc_[8] += 1;   // rounds of the window
+#endif
         __syncthreads();
         uint32_t carry = 0, total = 0;
 #pragma unroll
@@ -1763,14 +1766,16 @@ int k34_pileup(bgp_ctx* c) {
         a.ck = nullptr; a.ck_off = nullptr;
         bool have_rows = false;
         if (st[3]) {                                   // the stream holds long reads: build their per-window CIGAR checkpoints (the planner reads their verdicts)
+            uint64_t total_cols = 0, total_chunks = 0; uint64_t* row_off = nullptr; bool rows = false;
+            {
             TimedRegion tc(c, "k4_checkpoints", c->sum_ncig * 4);
             BGP_TRY(c->d_ck_off.reserve((n + 2) * 8));
             uint64_t* ck_off = c->d_ck_off.as<uint64_t>();
-            const bool rows = long_rows && !long_stream;    // ... and, for the gather path, every long read's row of class bytes (one per column)
-            uint64_t* row_off = nullptr; uint64_t* chunk_off = nullptr;
+            rows = long_rows && !long_stream;               // ... and, for the gather path, every long read's row of class bytes (one per column)
+            uint64_t* chunk_off = nullptr;
             if (rows) { BGP_TRY(c->d_row_off.reserve((n + 2) * 8)); BGP_TRY(c->d_chunk_off.reserve((n + 2) * 8)); row_off = c->d_row_off.as<uint64_t>(); chunk_off = c->d_chunk_off.as<uint64_t>(); }
             hipLaunchKernelGGL(k4_ck_count, dim3(nb), dim3(256), 0, c->stream, a.rec, n, a.runs, n_runs, ck_off, row_off, chunk_off, tw);
-            uint64_t total_ck = 0, total_cols = 0, total_chunks = 0;
+            uint64_t total_ck = 0;
             BGP_TRY(scan_exclusive_u64(c, ck_off, ck_off, n, &total_ck));
             if (rows) {
                 BGP_TRY(scan_exclusive_u64(c, row_off, row_off, n, &total_cols));
@@ -1783,10 +1788,11 @@ int k34_pileup(bgp_ctx* c) {
             BGP_TRY(c->d_ck.reserve((total_ck + 1) * sizeof(Ckpt)));
             BGP_HIP(hipMemsetAsync(c->d_ck.p, 0xFF, (total_ck + 1) * sizeof(Ckpt), c->stream));
             hipLaunchKernelGGL(k4_ck_build, dim3(nb), dim3(256), 0, c->stream, a.s, a.stream_len, a.rec, n, a.runs, n_runs, ck_off, c->d_ck.as<Ckpt>(), tw, chunk_off, rows ? c->d_chunk_state.as<uint4>() : nullptr);
+            a.ck = c->d_ck.as<Ckpt>(); a.ck_off = ck_off;
+            }
             if (rows && total_chunks) { TimedRegion tr(c, "k4_rows", total_cols);
             hipLaunchKernelGGL(k4_rows_build, dim3((unsigned)((total_chunks + 3) / 4)), dim3(256), 0, c->stream, a.s, a.stream_len, a.rec, c->d_chunk_state.as<uint4>(), total_chunks, row_off, c->d_rows.as<uint8_t>()); }
             have_rows = rows;
-            a.ck = c->d_ck.as<Ckpt>(); a.ck_off = ck_off;
         }
         if (long_stream) {
             hipLaunchKernelGGL(k4_all_listed, dim3((unsigned)((tile_base + 255) / 256)), dim3(256), 0, c->stream, c->d_deep.as<uint32_t>() + 1, c->d_deep.as<uint32_t>(), (uint32_t)tile_base);
@@ -1851,7 +1857,7 @@ int k34_pileup(bgp_ctx* c) {
             for (uint64_t w = 0; w < tile_base; ++w) for (int k = 0; k < 16; ++k) h[k] += (double)hb[w * 16 + k];
             fprintf(stderr, "[k4_exec phase clocks / window]");
             double tot = 0;
-            for (int k = 0; k < 12; ++k) { fprintf(stderr, " %d:%.0f", k, h[k] / (double)tile_base); tot += h[k]; }
+            for (int k = 0; k < 12; ++k) { if (k == 8) { fprintf(stderr, " rounds:%.3f", h[k] / (double)tile_base); continue; } fprintf(stderr, " %d:%.0f", k, h[k] / (double)tile_base); tot += h[k]; }
             fprintf(stderr, " total:%.0f\n", tot / (double)tile_base);
             (void)hipFree(g_prof_dev);
         }
