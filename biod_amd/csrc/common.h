@@ -121,7 +121,8 @@ struct bgp_ctx {
     DevBuf d_seg_entry, d_seg_end, d_seg_cnt, d_seg_lseq, d_seg_ncig, d_seg_dirty;   // per segment
     DevBuf d_seg_rec_base, d_seg_seq_base, d_seg_cig_base;
     DevBuf d_seg_side; uint32_t side_cap = 0;         // per segment: offsets of its records relative to the segment start (written by k0_chase)
-    uint32_t seg_bytes_wanted = 0;                    // K0: segment size asked for (0: its own choice)
+    uint32_t seg_bytes_wanted = 0, seg_window_shift = 0, seg_windows = 0;   // K0: segment size asked for (0: its own choice), split into windows of 1 << shift bytes whose prefix counts the chase records (k12_lds); windows per segment of the framing at hand
+    DevBuf d_seg_sub;
     bool frame_tolerant_tail = false; uint64_t frame_tail = 0;   // batched staging (batch.cpp): a stream may end inside a record; where the record chain stopped
     bool table_pending = false, long_cigar = false;   // the record table is written lazily: by k1_table, or by the fused K1+K2 if a decode comes first
     DevBuf d_scan_tmp;
@@ -194,7 +195,7 @@ int k1_table(bgp_ctx* c);                                   // frame.hip : K1 al
 int k1_finish_long_cigars(bgp_ctx* c);
 int k2_decode(bgp_ctx* c, uint32_t what);                   // decode.hip
 int k12_fused_decode(bgp_ctx* c, uint32_t what);            // decode.hip : K1 + K2 in one pass over the stream
-bool k12_lds_applies(const bgp_ctx* c, uint32_t what); uint32_t k12_lds_segment_bytes(); int k12_lds_decode(bgp_ctx* c, uint32_t what);   // decode.hip : K1 + K2 through LDS windows, framing from K0
+bool k12_lds_applies(const bgp_ctx* c, uint32_t what); uint32_t k12_lds_segment_bytes(); uint32_t k12_lds_window_shift(); int k12_lds_decode(bgp_ctx* c, uint32_t what);   // decode.hip : K1 + K2 through LDS windows, framing from K0
 int k012_stream_decode(bgp_ctx* c, uint32_t what);          // decode.hip : K0 + K1 + K2 in ONE pass (framing by look-back); 1 = gave up, take the three-kernel path
 constexpr uint32_t BGP_LONG_CIGAR = 32;                      // more ops than this: basesCovered is summed by a whole wave (k1_long_cigar)
 int k34_pileup(bgp_ctx* c);                                 // pileup.hip : runs + dense columns

@@ -992,6 +992,7 @@ struct LdsArgs {
     SdArgs d;                         // stream, outputs (capacities unused: the sizes are known)
     const uint64_t* rec_base; const uint64_t* seq_base; const uint64_t* cig_base; const uint32_t* side; uint32_t side_cap;
     uint64_t n_seg, n_records, sum_lseq, sum_ncig;
+    const uint4* sub; uint32_t sub_n;      // a K0 segment is sub_n windows: records / bases / ops of the segment in front of each (k0_chase)
 };
 
 template <bool SEQ, bool QUAL, bool CIG>
@@ -1005,9 +1006,15 @@ __global__ __launch_bounds__(SD_T, BGP_SD_MINW) void k12_lds(LdsArgs a) {
     const int t = threadIdx.x;
     const uint64_t k = blockIdx.x;
     if (k == 0 && t == 0) { a.d.seq_off[a.n_records] = a.sum_lseq; a.d.cig_off[a.n_records] = a.sum_ncig; }
-    const uint64_t pn = a.rec_base[k];
-    const uint32_t cnt = (uint32_t)(a.rec_base[k + 1] - pn);
-    if (!cnt) return;                                      // (inside a record longer than a segment, or behind the end of the chain)
+    // window k = window h of K0's segment sg (K0 frames in segments of several windows: a guess per segment, not per window)
+    const uint64_t sg = k / a.sub_n;
+    const uint32_t h = (uint32_t)(k % a.sub_n);
+    const uint32_t seg_cnt = (uint32_t)(a.rec_base[sg + 1] - a.rec_base[sg]);
+    const uint4 p0 = h ? a.sub[sg * a.sub_n + h] : make_uint4(0, 0, 0, 0);
+    const uint32_t c1 = h + 1 < a.sub_n ? a.sub[sg * a.sub_n + h + 1].x : seg_cnt;
+    const uint64_t pn = a.rec_base[sg] + p0.x;
+    const uint32_t cnt = c1 - p0.x;
+    if (!cnt) return;                                      // (inside a record longer than a window, or behind the end of the chain)
     const uint64_t wbase = k * SD_C;
     const uint32_t wlen = (uint32_t)min((uint64_t)SD_WIN, a.d.len - wbase);
     {   // the window: every load in flight before the first store
@@ -1015,7 +1022,7 @@ __global__ __launch_bounds__(SD_T, BGP_SD_MINW) void k12_lds(LdsArgs a) {
         uint4 v[NL];
 #pragma unroll
         for (int i = 0; i < NL; ++i) { const uint32_t o = 16u * (uint32_t)(t + SD_T * i); v[i] = make_uint4(0, 0, 0, 0); if (o + 16 <= wlen) __builtin_memcpy(&v[i], a.d.s + wbase + o, 16); }
-        for (uint32_t j = t; j < cnt; j += SD_T) roff[j] = (uint16_t)a.side[k * a.side_cap + j];
+        for (uint32_t j = t; j < cnt; j += SD_T) roff[j] = (uint16_t)(a.side[sg * a.side_cap + p0.x + j] - h * SD_C);
 #pragma unroll
         for (int i = 0; i < NL; ++i) { const uint32_t o = 16u * (uint32_t)(t + SD_T * i); if (o < SD_WIN + 32) *reinterpret_cast<uint4*>(sd_lds + o) = v[i]; }
     }
@@ -1028,9 +1035,9 @@ __global__ __launch_bounds__(SD_T, BGP_SD_MINW) void k12_lds(LdsArgs a) {
     SDSTAMP(0);
     const bool last_long = (uint64_t)roff[cnt - 1] + 4 + (uint64_t)wl32(w, roff[cnt - 1]) > wlen;
 #ifdef BGP_SD_PROF
-    sd_emit<SEQ, QUAL, CIG>(a.d, sd_lds, wbase, cnt, last_long, pn, a.seq_base[k], a.cig_base[k], stamp_);
+    sd_emit<SEQ, QUAL, CIG>(a.d, sd_lds, wbase, cnt, last_long, pn, a.seq_base[sg] + p0.y, a.cig_base[sg] + p0.z, stamp_);
 #else
-    sd_emit<SEQ, QUAL, CIG>(a.d, sd_lds, wbase, cnt, last_long, pn, a.seq_base[k], a.cig_base[k]);
+    sd_emit<SEQ, QUAL, CIG>(a.d, sd_lds, wbase, cnt, last_long, pn, a.seq_base[sg] + p0.y, a.cig_base[sg] + p0.z);
 #endif
 }
 
@@ -1253,8 +1260,13 @@ int k012_stream_decode(bgp_ctx* c, uint32_t what) {
 }
 
 // K1 + K2 through LDS windows (k12_lds): when K0 framed the stream in SD_C-byte segments and every section is wanted
-bool k12_lds_applies(const bgp_ctx* c, uint32_t what) { return c->table_pending && c->seg_bytes == SD_C && (what & BGP_FETCH_ALL) == BGP_FETCH_ALL && c->n_seg < 0x7FFFFFFFull; }
-uint32_t k12_lds_segment_bytes() { return SD_C; }
+#ifndef BGP_LDS_WIN_PER_SEG
+#define BGP_LDS_WIN_PER_SEG 2          // windows of k12_lds per framing segment of K0: a guess per 64 KiB instead of per 32 (cfg3 k0_guess 1.25 -> 0.64 ms, the chase 4.67 -> 4.86; with four windows 0.34 and 5.24: the chains of the chase get long)
+#endif
+static_assert((SD_C & (SD_C - 1)) == 0, "window = 1 << shift");
+bool k12_lds_applies(const bgp_ctx* c, uint32_t what) { return c->table_pending && c->seg_windows && c->seg_bytes == SD_C * c->seg_windows && (what & BGP_FETCH_ALL) == BGP_FETCH_ALL && c->n_seg * c->seg_windows < 0x7FFFFFFFull; }
+uint32_t k12_lds_segment_bytes() { return SD_C * BGP_LDS_WIN_PER_SEG; }
+uint32_t k12_lds_window_shift() { uint32_t s = 0; while ((1u << s) < SD_C) ++s; return s; }
 int k12_lds_decode(bgp_ctx* c, uint32_t what) {
     const uint64_t n = c->n_records;
     c->table_pending = false;
@@ -1278,9 +1290,11 @@ int k12_lds_decode(bgp_ctx* c, uint32_t what) {
     }
     a.rec_base = c->d_seg_rec_base.as<uint64_t>(); a.seq_base = c->d_seg_seq_base.as<uint64_t>(); a.cig_base = c->d_seg_cig_base.as<uint64_t>();
     a.side = c->d_seg_side.as<uint32_t>(); a.side_cap = c->side_cap; a.n_seg = c->n_seg; a.n_records = n; a.sum_lseq = c->sum_lseq; a.sum_ncig = c->sum_ncig;
+    a.sub = c->d_seg_sub.as<uint4>(); a.sub_n = c->seg_windows;
+    const uint64_t n_win = std::min<uint64_t>(c->n_seg * c->seg_windows, (c->stream_len + SD_C - 1) / SD_C);
     {
         TimedRegion t(c, "k12_lds", c->stream_len + n * 32 + 2 * c->sum_lseq + 4 * c->sum_ncig);      // SURVEY 8(d) without the framing: the record in, row + seq + qual + cigar out
-        hipLaunchKernelGGL((k12_lds<true, true, true>), dim3((unsigned)c->n_seg), dim3(SD_T), L_TOTAL, c->stream, a);
+        hipLaunchKernelGGL((k12_lds<true, true, true>), dim3((unsigned)n_win), dim3(SD_T), L_TOTAL, c->stream, a);
         BGP_TRY(k1_finish_long_cigars(c));
     }
     BGP_HIP(hipGetLastError());

@@ -31,6 +31,7 @@ struct FrameArgs {
     uint32_t* side; uint32_t side_cap;   // side[k * side_cap + j] = offset of segment k's j-th record relative to the segment start
     const uint64_t* seg_hint;            // per segment: the smallest offset inside it where the caller says a record starts (NONE: no word), or null
     int tolerant_tail;                   // batched staging: the data may end inside a record -- the chain stops in front of it instead of ETRUNC
+    uint4* sub; uint32_t sub_n, sub_shift;   // k12_lds: a segment is sub_n windows of 1 << sub_shift bytes; sub[k * sub_n + w] = records, bases, CIGAR ops of segment k in front of window w (null: not wanted)
 };
 
 // one wave per segment
@@ -130,7 +131,13 @@ __global__ __launch_bounds__(256) void k0_chase(FrameArgs a) {
         uint64_t cnt = 0, ls = 0, nc = 0;
         uint32_t err = 0;
         bool long_seen = false;
+        uint32_t wcur = 0;
+        const uint64_t seg0 = k * (uint64_t)a.seg_bytes;
         while (off < seg_end) {
+            if (a.sub) {                                                         // the windows this record's start has passed: what lay in front of them
+                const uint32_t w = (uint32_t)((off - seg0) >> a.sub_shift);
+                while (wcur < w && wcur + 1 < a.sub_n) { ++wcur; a.sub[k * a.sub_n + wcur] = make_uint4((uint32_t)cnt, (uint32_t)ls, (uint32_t)nc, 0u); }
+            }
             if (a.len - off < 4) { if (!a.tolerant_tail) off = a.len; break; }  // readrange.d:139-149: short prefix ends the range (a batch keeps it for the next one)
             const int32_t bs = (int32_t)ld_u32(a.s + off);
             if (bs < 0) { err = ST_EINVAL; break; }
@@ -146,6 +153,7 @@ __global__ __launch_bounds__(256) void k0_chase(FrameArgs a) {
             long_seen |= n_cig > LONG_CIGAR;
             off += 4 + (uint64_t)bs;
         }
+        if (a.sub) while (wcur + 1 < a.sub_n) { ++wcur; a.sub[k * a.sub_n + wcur] = make_uint4((uint32_t)cnt, (uint32_t)ls, (uint32_t)nc, 0u); }
         a.end[k] = err ? STOP : off;
         // per segment, not a sticky global bit: a chase from a wrong guess reads garbage and must not leave a trace
         a.cnt[k] = cnt; a.lseq[k] = ls; a.ncig[k] = nc; a.seg_err[k] = err | (long_seen ? ST_LONGCIG : 0u);
@@ -298,12 +306,19 @@ int k0_frame(bgp_ctx* c) {
     a.s = c->d_stream; a.len = len; a.seg_bytes = seg; a.n_seg = n_seg;
     a.ref_bound = c->n_ref_hint > 0 ? c->n_ref_hint : (1 << 24);
     a.tolerant_tail = c->frame_tolerant_tail ? 1 : 0;
+    a.sub = nullptr; a.sub_n = 0; a.sub_shift = 0; c->seg_windows = 0;
     a.seg_hint = nullptr;
     a.entry = c->d_seg_entry.as<uint64_t>(); a.fix = a.entry + n_seg + 1; a.end = c->d_seg_end.as<uint64_t>();
     a.cnt = c->d_seg_cnt.as<uint64_t>(); a.lseq = c->d_seg_lseq.as<uint64_t>(); a.ncig = c->d_seg_ncig.as<uint64_t>();
     a.dirty = c->d_seg_dirty.as<uint32_t>(); a.seg_err = a.dirty + n_seg;
     a.status = c->d_status.as<uint32_t>();
     a.side_cap = seg / 36u + 2u;                     // a record is at least 36 bytes (block_size >= 32 is enforced by the chase)
+    if (c->seg_bytes_wanted && seg == c->seg_bytes_wanted && c->seg_window_shift) {      // k12_lds follows: its windows' prefix counts inside every segment
+        a.sub_shift = c->seg_window_shift; a.sub_n = seg >> a.sub_shift;
+        BGP_TRY(c->d_seg_sub.reserve((n_seg + 1) * (size_t)a.sub_n * 16));
+        BGP_HIP(hipMemsetAsync(c->d_seg_sub.p, 0, (n_seg + 1) * (size_t)a.sub_n * 16, c->stream));
+        a.sub = c->d_seg_sub.as<uint4>(); c->seg_windows = a.sub_n;
+    }
     BGP_TRY(c->d_seg_side.reserve((n_seg + 1) * (size_t)a.side_cap * 4));
     a.side = c->d_seg_side.as<uint32_t>();
     c->side_cap = a.side_cap;
