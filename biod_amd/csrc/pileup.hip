@@ -1044,7 +1044,7 @@ constexpr int G_MISC = (G_ROWL + GCAP * 2 + 15) & ~15;        // wave totals, fl
 constexpr int G_LDS = G_MISC + 256;
 static_assert(2 * G_LDS <= 160 * 1024, "two workgroups per CU");
 static_assert(G_SEGI % 16 == 0 && G_DELD % 16 == 0 && G_GD % 4 == 0 && G_MISC % 8 == 0, "alignment");
-constexpr int FAST_SEG = 160;                 // longest read of the gather path (<= 6 staging chunks with an odd start)
+constexpr int FAST_SEG = 255;                 // longest read the planner turns into SEG descriptors (a descriptor's length field: 8 bits; <= 8 staging chunks); longer ones, or more than four ops: ROWs
 
 struct PlanArgs {
     const bgp_record* rec; const uint4* cig4; const uint8_t* s; uint64_t stream_len, n;

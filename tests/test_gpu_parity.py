@@ -260,6 +260,7 @@ def test_odd_cigars(ctx):
 # ------------------------------------------------------------------------------------------ synthetic configurations
 
 @pytest.mark.parametrize("profile,read_len,n_reads,ref_len", [(0, 150, 20000, 120_000), (1, 150, 20000, 150_000), (1, 100, 10000, 50_000),
+                                                              (0, 250, 8000, 80_000), (1, (170, 255), 8000, 80_000), (1, (240, 300), 6000, 80_000),
                                                               (2, (2000, 9000), 600, 400_000)])
 def test_synthetic_parity(ctx, profile, read_len, n_reads, ref_len):
     cfg = make_cfg(n_reads=n_reads, n_ref=2, ref_len=ref_len, read_len=read_len, profile=profile, seed=100 + profile)
