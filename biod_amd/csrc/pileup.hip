@@ -60,7 +60,11 @@ struct RunDev { int32_t ref_id; uint32_t pad; uint64_t first_record, end_record,
 struct K3Args { const bgp_record* rec; uint64_t n; uint64_t* key_end; uint64_t* key_pos; uint32_t* status; /* [3] any long read */ uint32_t run_cap; };
 
 constexpr int FAST_LSEQ = 160;         // reads up to 20 dwords of packed SEQ and 4 CIGAR ops take K4's lane = read path
-__device__ __forceinline__ bool is_long_read(uint32_t n_cig, uint32_t l_seq) { return n_cig > 4 || l_seq > (uint32_t)FAST_LSEQ; }
+constexpr int FAST_SEG = 255;          // longest read the planner turns into SEG descriptors (a descriptor's length field: 8 bits; <= 8 staging chunks)
+// Reads that get per-window CIGAR checkpoints and, on the gather path, a row of class bytes: more than four ops, or longer
+// than a SEG descriptor holds.  (A read of 161..255 bases with up to four ops needs neither: the planner takes it as SEGs,
+// and in a window left to the general kernel it walks from its start -- so a stream of 250-base reads costs no walk.)
+__device__ __forceinline__ bool wants_ckpt(uint32_t n_cig, uint32_t l_seq) { return n_cig > 4 || l_seq > (uint32_t)FAST_SEG; }
 
 // K3 is one two-pass inclusive max-scan over two keys derived on the fly from the record table
 // (reference key << 32 | end_position, ... | position; 0 for reads with basesCovered() == 0):
@@ -148,7 +152,7 @@ __global__ __launch_bounds__(K3_T) void k3_down(K3Args a, const K3Key* bsum, Run
         if (i < a.n) {
             const bgp_record r = a.rec[i];
             key[k] = k3_key_of(r); ref[k] = r.ref_id;
-            flg[k] = (is_long_read(r.flag_nc & 0xFFFFu, (uint32_t)r.l_seq) ? 1u : 0u) | ((r.pos < 0 || r.end_pos < r.pos) ? 2u : 0u);
+            flg[k] = (wants_ckpt(r.flag_nc & 0xFFFFu, (uint32_t)r.l_seq) ? 1u : 0u) | ((r.pos < 0 || r.end_pos < r.pos) ? 2u : 0u);
             mine = k3_max(mine, key[k]);
         }
     }
@@ -280,7 +284,7 @@ __global__ __launch_bounds__(256) void k4_ck_count(const bgp_record* rec, uint64
     if (i >= n) return;
     const bgp_record r = rec[i];
     uint64_t c = 0, cols = 0;
-    if (r.end_pos != r.pos && is_long_read(r.flag_nc & 0xFFFFu, (uint32_t)r.l_seq)) {
+    if (r.end_pos != r.pos && wants_ckpt(r.flag_nc & 0xFFFFu, (uint32_t)r.l_seq)) {
         const RunDev& run = runs[run_of_record(runs, n_runs, i)];
         c = ((uint64_t)(uint32_t)r.end_pos - 1 - run.start_pos) / W - ((uint64_t)(uint32_t)r.pos - run.start_pos) / W + 1;
         cols = (uint32_t)r.end_pos - (uint32_t)r.pos;
@@ -296,7 +300,7 @@ __global__ __launch_bounds__(256) void k4_ck_build(const uint8_t* s, uint64_t st
     const int lane = threadIdx.x & 63;
     bgp_record r{};
     bool lng = false;
-    if (i < n) { r = rec[i]; lng = r.end_pos != r.pos && is_long_read(r.flag_nc & 0xFFFFu, (uint32_t)r.l_seq); }
+    if (i < n) { r = rec[i]; lng = r.end_pos != r.pos && wants_ckpt(r.flag_nc & 0xFFFFu, (uint32_t)r.l_seq); }
     unsigned long long m = __ballot(lng);
     while (m) {
         const int src = __ffsll((long long)m) - 1;
@@ -891,7 +895,7 @@ template <class L> __global__ __launch_bounds__(L::T) void k4_tile(K4Args a, int
             const uint4 x = rp[0], y = rp[1];
             const uint32_t rpos = rl(x.y, 0), rcov = rl(x.z - x.y, 0), rncig = rl(y.x & 0xFFFFu, 0), rlseq = rl(y.y, 0);
             const uint64_t co = (((uint64_t)rl(y.w, 0) << 32) | rl(y.z, 0)) + 36 + rl(x.w & 0xFFu, 0);
-            if (a.ck && is_long_read(rncig, rlseq)) {
+            if (a.ck && wants_ckpt(rncig, rlseq)) {
                 const uint64_t wj = (uint64_t)(T0 - tb.run_start) / L::WIN - ((uint64_t)rpos - tb.run_start) / L::WIN;   // window index within the read
                 const Ckpt ck = a.ck[a.ck_off[ri] + wj];
                 pile_read_long<L>(a, lds, T0, Tend, lane, rpos, rcov, rncig, rlseq, co, ck);
@@ -1044,7 +1048,6 @@ constexpr int G_MISC = (G_ROWL + GCAP * 2 + 15) & ~15;        // wave totals, fl
 constexpr int G_LDS = G_MISC + 256;
 static_assert(2 * G_LDS <= 160 * 1024, "two workgroups per CU");
 static_assert(G_SEGI % 16 == 0 && G_DELD % 16 == 0 && G_GD % 4 == 0 && G_MISC % 8 == 0, "alignment");
-constexpr int FAST_SEG = 255;                 // longest read the planner turns into SEG descriptors (a descriptor's length field: 8 bits; <= 8 staging chunks); longer ones, or more than four ops: ROWs
 
 struct PlanArgs {
     const bgp_record* rec; const uint4* cig4; const uint8_t* s; uint64_t stream_len, n;
@@ -1102,7 +1105,7 @@ __global__ __launch_bounds__(256) void k4_plan(PlanArgs a) {
                 }
                 if (qsum > l_seq) simple = false;
             }
-            if (!simple && a.ck && is_long_read(n_cig, l_seq) && a.ck[a.ck_off[i]].pad == 0) {
+            if (!simple && a.ck && wants_ckpt(n_cig, l_seq) && a.ck[a.ck_off[i]].pad == 0) {
                 // a long read that fits the mould (k4_ck_build walked its CIGAR): one ROW descriptor per window it touches
                 const uint32_t rel1 = x.z - (uint32_t)r_start_pos;
                 for (uint32_t w = wf; w <= wl; ++w) {
@@ -1599,7 +1602,7 @@ __device__ __forceinline__ bgp_entry entry_of(const uint8_t* s, const bgp_record
     const uint8_t* ql = sq + (uint32_t)((r.l_seq + 1) / 2);
     bgp_entry e; e.read_ordinal = ordinal; e.cigar_op_offset = 0; e.query_offset = 0; e.cigar_op_index = 0xFFFF; e.base = 0xFF; e.qual = 0xFF;
     uint32_t cs = 0, qs = 0, k = 0; bool started = false;
-    if (a.ck && is_long_read(n_cig, (uint32_t)r.l_seq)) {
+    if (a.ck && wants_ckpt(n_cig, (uint32_t)r.l_seq)) {
         // a long read is not walked from its first op for every column: the walk resumes from the cursor K4 recorded for
         // the window the column lies in (op index, columns before it, query bases before it; the op owns a column, so
         // the cursor has started) -- O(ops inside a window) per entry instead of O(ops of the read)
