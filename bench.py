@@ -46,23 +46,30 @@ def kernels_sha():
     return h.hexdigest()[:16]
 
 
-def pmc_traffic(prefixes, config, n_reads):
-    """HBM bytes of one dispatch of each kernel whose name starts with `prefixes` (= per step for K2 and K4, whose kernels
-    run once a step), from the committed rocprofv3 PMC
-    passes (FETCH_SIZE and WRITE_SIZE collected separately, FETCH doubled for gfx950 as MI355X_MICROARCH.md
-    prescribes).  Counters cannot be read from inside this process, so the number is only reported when the
-    workload is the one the profile was taken on (cfg3, 100 M reads) AND the profile's header carries the hash
-    of the kernel sources as they are now (scratch/refresh_profiles.sh writes it); otherwise null."""
+# kernels behind the timers of a step (a timer can bracket several launches; kernels of the set-up, e.g. the flush before the
+# timed region, are not the step's)
+TIMER_KERNELS = {"k12_lds": ("k12_lds",), "k012_stream": ("k_stream_decode",), "k2_unpack": ("k2_unpack",), "k12_fused": ("k12_fused",), "k1_rows": ("k12_fused",),
+                 "k4_bounds": ("k4_bounds",), "k4_plan": ("k4_plan", "k4_wscan"), "k4_tile": ("k4_exec", "k4_tile", "k4_stats"),
+                 "k4_checkpoints": ("k4_ck_",), "k4_rows": ("k4_rows_build",)}
+
+
+def pmc_traffic(timers, config, n_reads):
+    """HBM bytes of one dispatch of each kernel behind the timers of the stage (= per step: these kernels run once a
+    step), from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected separately, FETCH doubled for
+    gfx950 as MI355X_MICROARCH.md prescribes).  Counters cannot be read from inside this process, so the number is only
+    reported when the workload is the one the profile was taken on (cfg3, 100 M reads) AND the profile's header carries
+    the hash of the kernel sources as they are now (scratch/refresh_profiles_r02.sh writes it); otherwise null."""
     path = os.path.join(ROOT, "profiles", "r02_pmc_hbm_traffic_cfg3_100M.csv")
     if config != "cfg3" or n_reads != 100_000_000 or not os.path.exists(path):
         return None
     lines = open(path).read().splitlines()
     if not any(("kernels_sha=" + kernels_sha()) in ln for ln in lines if ln.startswith("#")):
         return None
+    names = tuple(k for t in timers for k in TIMER_KERNELS.get(t, ()))
     total = None
     for line in lines:
         f = line.strip().split(",")
-        if len(f) >= 5 and f[0].startswith(tuple(prefixes)) and f[4].isdigit():
+        if len(f) >= 5 and names and f[0].startswith(names) and f[4].isdigit():
             total = (total or 0) + int(f[4])
     return total
 
@@ -333,10 +340,13 @@ def main():
             "decode_Mreads_per_s_kernel_only": round(n_reads / (dec_ms * 1e-3) / 1e6, 2) if dec_ms else None,
             "roofline": {"bound": "hbm", "kernel": dom + " = " + " + ".join(stages[dom]["kernels"]), "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "algorithmic_bytes_per_launch": dom_bytes,
-                         "traffic": pmc_traffic(stages[dom]["prefixes"], a.config, n_reads)},
+                         "traffic": pmc_traffic(stages[dom]["kernels"], a.config, n_reads)},
             "roofline_decode_8d": {"what": "K0 + K1 + K2 by SURVEY 8(d)'s bytes: whole record in, 32-byte row + seq + qual + cigar out", "ms": round(dec_ms, 3),
                                    "achieved": round(dec_bytes / (dec_ms * 1e-3) / 1e9, 1) if dec_ms else None, "frac": round(dec_bytes / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if dec_ms else None},
             "stages_ms": {s: round(v["ms_per_step"], 3) for s, v in stages.items()},
+            "stage_rooflines": {s: {"algorithmic_GBps": round(v["bytes"] / (v["ms_per_step"] * 1e-3) / 1e9, 1), "frac": round(v["bytes"] / (v["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                                    "algorithmic_bytes": v["bytes"], "traffic": pmc_traffic(v["kernels"], a.config, n_reads)}
+                                for s, v in stages.items() if v["bytes"] and v["ms_per_step"] > 0},
             "kernels": per_kernel,
             "setup_s": round(gen_s, 2),
         }

@@ -1683,7 +1683,7 @@ int k34_pileup(bgp_ctx* c) {
     for (uint32_t run_cap = std::max<uint32_t>(RUNS_FIRST, (uint32_t)(c->d_runs.cap / sizeof(RunDev)));;) {
         BGP_TRY(c->d_runs.reserve(sizeof(RunDev) * (size_t)run_cap));
         {
-            TimedRegion t(c, "k3_keys_scan", n * (32 + 16 + 32));
+            TimedRegion t(c, "k3_keys_scan", n * (c->tilemax_ok ? 32 + 16 : 32 + 16 + 32));      // (one pass over the table when K1 left the tile maxima)
             K3Args a{c->d_rec.as<bgp_record>(), n, c->d_pmax_end.as<uint64_t>(), c->d_pmax_pos.as<uint64_t>(), status, run_cap};
             const uint64_t nt = (n + K3_TILE - 1) / K3_TILE;
             BGP_TRY(c->d_scan_tmp.reserve((nt + 2) * sizeof(K3Key)));
