@@ -339,18 +339,18 @@ class RecordStream:
         self._staged = False
         self.records = None
 
-    def _stage(self):
+    def _stage(self, decode: int = 0):
         if not self._staged:
             self.ctx.reset()
             if self.n_ref:
                 self.ctx.set_n_ref(self.n_ref)
             self.ctx.push_inflated(self.data)
-            self.ctx.flush()
+            self.ctx.flush(decode)        # (decode != 0: the arenas in the same pass over the stream, bgp_flush_decode)
             self._staged = True
         return self.ctx
 
     def decode(self, what=L.BGP_FETCH_ALL) -> DecodedRecords:
-        self.records = self._stage().decode_fetch(what)
+        self.records = self._stage(what).decode_fetch(what)
         return self.records
 
 
