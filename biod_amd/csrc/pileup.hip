@@ -1334,6 +1334,7 @@ template <bool ROWS> __global__ __launch_bounds__(GT, BGP_G_MINW) void k4_exec(G
         p.d = ((unsigned long long)dh << 32) | dl;
     };
     Pre pre = prefetch(tile);
+    uint32_t r_ncol = 0, r_nsum = 0, r_mx = 0; unsigned long long r_scov = 0;      // the range's totals, per lane: reduced once, after the last window
   for (; tile < tile_end; ++tile) {
 #ifdef BGP_G_PROF
     unsigned long long pacc_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -1561,20 +1562,20 @@ template <bool ROWS> __global__ __launch_bounds__(GT, BGP_G_MINW) void k4_exec(G
 #pragma unroll
     for (int bb = 0; bb < GBPW; ++bb) { const uint32_t p = 64 * (wave * GBPW + bb) + lane; if ((p & 1u) == 0) nst[p >> 1] = 0; }
     GSTAMP(10);       // columns written
-    // per-window totals: wave reductions with DPP, then one atomic per wave and total (the slots were zeroed by the host)
-    {
-        const uint32_t w_ncol = wave_sum_u32(ncol), w_nsum = wave_sum_u32(nsum), w_mx = wave_max_u32(mx);
-        const uint32_t s_lo = wave_sum_u32(scov & 0xFFFFu), s_hi = wave_sum_u32(scov >> 16);
-        if (lane == 0) {
-            unsigned long long* ts = a.tile_stats + tile * 4;
-            if (w_ncol) atomicAdd(&ts[0], (unsigned long long)w_ncol);
-            const unsigned long long sc = ((unsigned long long)s_hi << 16) + s_lo;
-            if (sc) atomicAdd(&ts[1], sc);
-            if (w_mx) atomicMax(&ts[2], (unsigned long long)w_mx);
-            if (w_nsum) atomicAdd(&ts[3], (unsigned long long)w_nsum);
-        }
-    }
+    r_ncol += ncol; r_nsum += nsum; r_mx = max(r_mx, mx); r_scov += scov;     // (k4_stats only wants sums and a maximum over all windows: the range's go to its first window's slot)
     GSTAMP(11);       // totals
+  }
+  {   // the range's totals: wave reductions with DPP, then one atomic per wave and total (the slots were zeroed by the host)
+      const uint32_t w_ncol = wave_sum_u32(r_ncol), w_nsum = wave_sum_u32(r_nsum), w_mx = wave_max_u32(r_mx);
+      const uint32_t s0 = wave_sum_u32((uint32_t)r_scov & 0xFFFFu), s1 = wave_sum_u32((uint32_t)(r_scov >> 16) & 0xFFFFu), s2 = wave_sum_u32((uint32_t)(r_scov >> 32) & 0xFFFFu), s3 = wave_sum_u32((uint32_t)(r_scov >> 48));
+      if (lane == 0) {
+          unsigned long long* ts = a.tile_stats + (a.n_tiles + blockIdx.x) * 4;      // (slots of the workgroups, behind the windows': the general kernel stores its windows' totals in theirs)
+          if (w_ncol) atomicAdd(&ts[0], (unsigned long long)w_ncol);
+          const unsigned long long sc = ((unsigned long long)s3 << 48) + ((unsigned long long)s2 << 32) + ((unsigned long long)s1 << 16) + s0;
+          if (sc) atomicAdd(&ts[1], sc);
+          if (w_mx) atomicMax(&ts[2], (unsigned long long)w_mx);
+          if (w_nsum) atomicAdd(&ts[3], (unsigned long long)w_nsum);
+      }
   }
   __syncthreads();
   for (int b = t; b < HB; b += GT) { const uint32_t h = hist[b]; if (h) atomicAdd(&a.hist[b], (unsigned long long)h); }     // the range's depth histogram, once
@@ -1764,7 +1765,8 @@ int k34_pileup(bgp_ctx* c) {
             TimedRegion tb(c, "k4_bounds", tile_base * sizeof(TileB));
             hipLaunchKernelGGL(k4_bounds, dim3((unsigned)((tile_base + 255) / 256)), dim3(256), 0, c->stream, a.pmax_end, a.pmax_pos, a.runs, n_runs, tile_base, c->d_tiles.as<TileB>(), tw);
         }
-        BGP_TRY(c->d_col_lo.reserve(tile_base * 32));
+        constexpr uint64_t WG_SLOTS = 4096;            // k4_exec's workgroups leave their ranges' totals behind the windows' slots
+        BGP_TRY(c->d_col_lo.reserve((tile_base + WG_SLOTS) * 32));
         a.tile_stats = (unsigned long long*)c->d_col_lo.p;
         a.ck = nullptr; a.ck_off = nullptr;
         bool have_rows = false;
@@ -1830,13 +1832,13 @@ int k34_pileup(bgp_ctx* c) {
 #endif
         c->ck_w = a.ck ? tw : 0;                     // K5 resumes long reads from these checkpoints
         TimedRegion t(c, "k4_tile", used);
-        BGP_HIP(hipMemsetAsync(a.tile_stats, 0, tile_base * 32, c->stream));      // the gather path adds its per-window totals wave by wave
+        BGP_HIP(hipMemsetAsync(a.tile_stats, 0, (tile_base + WG_SLOTS) * 32, c->stream));      // the gather path adds its totals wave by wave
         if (!long_stream) {
             GArgs g;
             g.s = a.s; g.slab = (const unsigned long long*)c->d_slab.p; g.wcount = c->d_wcount.as<uint32_t>(); g.wdel = c->d_wdel.as<int32_t>(); g.tiles = a.tiles; g.n_tiles = tile_base;
             g.cols = a.cols; g.hist = a.hist; g.tile_stats = a.tile_stats; g.deep = c->d_deep.as<uint32_t>() + 1; g.n_deep = c->d_deep.as<uint32_t>();
             g.rows = have_rows ? c->d_rows.as<uint8_t>() : nullptr;
-            static const unsigned g_blocks = getenv("BGP_G_BLOCKS") ? (unsigned)atoi(getenv("BGP_G_BLOCKS")) : 512u;     // two 76 KB workgroups per CU x 256 CUs
+            static const unsigned g_blocks = std::min(4096u, getenv("BGP_G_BLOCKS") ? (unsigned)atoi(getenv("BGP_G_BLOCKS")) : 512u);     // two 76 KB workgroups per CU x 256 CUs
             if (have_rows) hipLaunchKernelGGL(k4_exec<true>, dim3((unsigned)std::min<uint64_t>(tile_base, g_blocks)), dim3(GT), (size_t)G_LDS, c->stream, g);
             else hipLaunchKernelGGL(k4_exec<false>, dim3((unsigned)std::min<uint64_t>(tile_base, g_blocks)), dim3(GT), (size_t)G_LDS, c->stream, g);
         }
@@ -1849,7 +1851,7 @@ int k34_pileup(bgp_ctx* c) {
             hipLaunchKernelGGL(k4_tile<L16>, dim3(dgrid), dim3(L16::T), lds16, c->stream, a, 1);
             hipLaunchKernelGGL(k4_tile<L32>, dim3(std::min(dgrid, 512u)), dim3(L32::T), lds32, c->stream, a, 1);
         }
-        hipLaunchKernelGGL(k4_stats, dim3(32), dim3(256), 0, c->stream, a.tile_stats, tile_base, a.pstats);
+        hipLaunchKernelGGL(k4_stats, dim3(32), dim3(256), 0, c->stream, a.tile_stats, tile_base + WG_SLOTS, a.pstats);
         BGP_HIP(hipGetLastError());
 #ifdef BGP_G_PROF
         {
