@@ -356,24 +356,25 @@ int k0_frame(bgp_ctx* c) {
         if (ndirty == 0) break;
         if (++rounds > n_seg + 2) { c->last_error = "record framing did not converge"; return BGP_EDEVICE; }
     }
+    // errors, the three exclusive scans (records, bases, CIGAR ops in front of every segment) and where the chain stopped:
+    // everything is queued, the host waits once
     hipLaunchKernelGGL(k0_collect_errors, dim3(lane_blocks), dim3(256), 0, c->stream, a);
     uint32_t bits = 0;
+    uint64_t n = 0, sl = 0, sc = 0;
     BGP_HIP(hipMemcpyAsync(&bits, a.status, 4, hipMemcpyDeviceToHost, c->stream));
+    BGP_TRY(scan_exclusive_u64(c, a.cnt, c->d_seg_rec_base.as<uint64_t>(), n_seg, nullptr));
+    BGP_TRY(scan_exclusive_u64(c, a.lseq, c->d_seg_seq_base.as<uint64_t>(), n_seg, nullptr));
+    BGP_TRY(scan_exclusive_u64(c, a.ncig, c->d_seg_cig_base.as<uint64_t>(), n_seg, nullptr));
+    BGP_HIP(hipMemcpyAsync(&n, c->d_seg_rec_base.as<uint64_t>() + n_seg, 8, hipMemcpyDeviceToHost, c->stream));
+    BGP_HIP(hipMemcpyAsync(&sl, c->d_seg_seq_base.as<uint64_t>() + n_seg, 8, hipMemcpyDeviceToHost, c->stream));
+    BGP_HIP(hipMemcpyAsync(&sc, c->d_seg_cig_base.as<uint64_t>() + n_seg, 8, hipMemcpyDeviceToHost, c->stream));
+    c->frame_tail = len;
+    if (c->frame_tolerant_tail) BGP_HIP(hipMemcpyAsync(&c->frame_tail, a.end + (n_seg - 1), 8, hipMemcpyDeviceToHost, c->stream));      // where the chain of records stopped: the bytes behind it belong to the next batch
     BGP_HIP(hipStreamSynchronize(c->stream));
     const int st = bgp_status_from_bits(bits);
     if (st < 0 && st != BGP_ESEQ) return st;
-
-    uint64_t n = 0, sl = 0, sc = 0;
-    BGP_TRY(scan_exclusive_u64(c, a.cnt, c->d_seg_rec_base.as<uint64_t>(), n_seg, &n));
-    BGP_TRY(scan_exclusive_u64(c, a.lseq, c->d_seg_seq_base.as<uint64_t>(), n_seg, &sl));
-    BGP_TRY(scan_exclusive_u64(c, a.ncig, c->d_seg_cig_base.as<uint64_t>(), n_seg, &sc));
     c->n_records = n; c->sum_lseq = sl; c->sum_ncig = sc;
-    c->frame_tail = len;
-    if (c->frame_tolerant_tail) {                     // where the chain of records stopped: the bytes behind it belong to the next batch
-        BGP_HIP(hipMemcpyAsync(&c->frame_tail, a.end + (n_seg - 1), 8, hipMemcpyDeviceToHost, c->stream));
-        BGP_HIP(hipStreamSynchronize(c->stream));
-        if (c->frame_tail > len) c->frame_tail = len;
-    }
+    if (c->frame_tail > len) c->frame_tail = len;
 
     c->long_cigar = (bits & ST_LONGCIG) != 0;
     c->table_pending = true;             // the record table is written by whoever needs it first: k1_table, or the fused K1+K2 when a decode follows
