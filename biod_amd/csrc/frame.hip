@@ -115,6 +115,8 @@ __global__ __launch_bounds__(256) void k0_guess_wide(FrameArgs a) {
     if (threadIdx.x == 0) a.entry[k] = found;
 }
 
+constexpr int SIDE_GROUP = 16;          // offsets a lane of k0_chase collects before it stores them (one 64-byte line)
+
 // one lane per segment
 __global__ __launch_bounds__(256) void k0_chase(FrameArgs a) {
     uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -133,25 +135,51 @@ __global__ __launch_bounds__(256) void k0_chase(FrameArgs a) {
         bool long_seen = false;
         uint32_t wcur = 0;
         const uint64_t seg0 = k * (uint64_t)a.seg_bytes;
-        while (off < seg_end) {
-            if (a.sub) {                                                         // the windows this record's start has passed: what lay in front of them
-                const uint32_t w = (uint32_t)((off - seg0) >> a.sub_shift);
-                while (wcur < w && wcur + 1 < a.sub_n) { ++wcur; a.sub[k * a.sub_n + wcur] = make_uint4((uint32_t)cnt, (uint32_t)ls, (uint32_t)nc, 0u); }
+        // The records' offsets (relative to the segment) go to the side array SIDE_GROUP at a time, from registers: every
+        // active lane of the wave is at the same record count, so the buffer's indices are static, and a lane's stores are
+        // whole 64-byte lines.  One 4-byte store per record -- 10^8 partial-sector writes the L2 cannot merge, ~20 us apart
+        // per lane -- cost this kernel 1.6 of its 4.6 ms (scratch/chase_probe.hip).
+        uint32_t* dst = a.side + k * a.side_cap;
+        bool live = off < seg_end;
+        while (live) {
+            uint32_t buf[SIDE_GROUP];
+#pragma unroll
+            for (int e = 0; e < SIDE_GROUP; ++e) {
+                buf[e] = 0;
+                if (live) {
+                    if (a.sub) {                                                     // the windows this record's start has passed: what lay in front of them
+                        const uint32_t w = (uint32_t)((off - seg0) >> a.sub_shift);
+                        while (wcur < w && wcur + 1 < a.sub_n) { ++wcur; a.sub[k * a.sub_n + wcur] = make_uint4((uint32_t)cnt, (uint32_t)ls, (uint32_t)nc, 0u); }
+                    }
+                    live = false;
+                    if (a.len - off < 4) { if (!a.tolerant_tail) off = a.len; }     // readrange.d:139-149: short prefix ends the range (a batch keeps it for the next one)
+                    else {
+                        const int32_t bs = (int32_t)ld_u32(a.s + off);
+                        if (bs < 0) err = ST_EINVAL;
+                        else if ((uint64_t)bs > a.len - off - 4) { if (!a.tolerant_tail) err = ST_ETRUNC; }    // readrange.d:169 (a batch: the rest of the record is still to come)
+                        else if (bs < 32) err = ST_EINVAL;
+                        else {
+                            uint32_t f3[3]; __builtin_memcpy(f3, a.s + off + 12, 12);    // bin_mq_nl, flag_nc, l_seq in one load (bs >= 32: in bounds)
+                            const uint32_t bmn = f3[0], fnc = f3[1];
+                            const int32_t lseq = (int32_t)f3[2];
+                            const uint32_t l_name = bmn & 0xFFu, n_cig = fnc & 0xFFFFu;
+                            if (lseq < 0 || l_name == 0 || 32ull + l_name + 4ull * n_cig + (uint64_t)((lseq + 1) / 2) + (uint64_t)lseq > (uint64_t)bs) err = ST_EINVAL;
+                            else {
+                                buf[e] = (uint32_t)(off - seg0);
+                                ++cnt; ls += (uint64_t)lseq; nc += n_cig;
+                                long_seen |= n_cig > LONG_CIGAR;
+                                off += 4 + (uint64_t)bs;
+                                live = off < seg_end;
+                            }
+                        }
+                    }
+                }
             }
-            if (a.len - off < 4) { if (!a.tolerant_tail) off = a.len; break; }  // readrange.d:139-149: short prefix ends the range (a batch keeps it for the next one)
-            const int32_t bs = (int32_t)ld_u32(a.s + off);
-            if (bs < 0) { err = ST_EINVAL; break; }
-            if ((uint64_t)bs > a.len - off - 4) { if (!a.tolerant_tail) err = ST_ETRUNC; break; }    // readrange.d:169 (a batch: the rest of the record is still to come)
-            if (bs < 32) { err = ST_EINVAL; break; }
-            uint32_t f3[3]; __builtin_memcpy(f3, a.s + off + 12, 12);            // bin_mq_nl, flag_nc, l_seq in one load (bs >= 32: in bounds)
-            const uint32_t bmn = f3[0], fnc = f3[1];
-            const int32_t lseq = (int32_t)f3[2];
-            const uint32_t l_name = bmn & 0xFFu, n_cig = fnc & 0xFFFFu;
-            if (lseq < 0 || l_name == 0 || 32ull + l_name + 4ull * n_cig + (uint64_t)((lseq + 1) / 2) + (uint64_t)lseq > (uint64_t)bs) { err = ST_EINVAL; break; }
-            if (cnt < a.side_cap) a.side[k * a.side_cap + cnt] = (uint32_t)(off - k * (uint64_t)a.seg_bytes);   // 128 contiguous bytes per 32 records: the fused K1+K2 finds every record without a second chase
-            ++cnt; ls += (uint64_t)lseq; nc += n_cig;
-            long_seen |= n_cig > LONG_CIGAR;
-            off += 4 + (uint64_t)bs;
+            if (dst + SIDE_GROUP <= a.side + (k + 1) * a.side_cap) {                 // (always: a record is at least 36 bytes and side_cap is sized for that)
+#pragma unroll
+                for (int q = 0; q < SIDE_GROUP / 4; ++q) reinterpret_cast<uint4*>(dst)[q] = make_uint4(buf[4 * q], buf[4 * q + 1], buf[4 * q + 2], buf[4 * q + 3]);
+            }
+            dst += SIDE_GROUP;
         }
         if (a.sub) while (wcur + 1 < a.sub_n) { ++wcur; a.sub[k * a.sub_n + wcur] = make_uint4((uint32_t)cnt, (uint32_t)ls, (uint32_t)nc, 0u); }
         a.end[k] = err ? STOP : off;
@@ -312,7 +340,7 @@ int k0_frame(bgp_ctx* c) {
     a.cnt = c->d_seg_cnt.as<uint64_t>(); a.lseq = c->d_seg_lseq.as<uint64_t>(); a.ncig = c->d_seg_ncig.as<uint64_t>();
     a.dirty = c->d_seg_dirty.as<uint32_t>(); a.seg_err = a.dirty + n_seg;
     a.status = c->d_status.as<uint32_t>();
-    a.side_cap = seg / 36u + 2u;                     // a record is at least 36 bytes (block_size >= 32 is enforced by the chase)
+    a.side_cap = (seg / 36u + 2u + 2u * SIDE_GROUP - 1u) / SIDE_GROUP * SIDE_GROUP;      // a record is at least 36 bytes (block_size >= 32 is enforced by the chase); whole groups, the last one may be written half empty
     if (c->seg_bytes_wanted && seg == c->seg_bytes_wanted && c->seg_window_shift) {      // k12_lds follows: its windows' prefix counts inside every segment
         a.sub_shift = c->seg_window_shift; a.sub_n = seg >> a.sub_shift;
         BGP_TRY(c->d_seg_sub.reserve((n_seg + 1) * (size_t)a.sub_n * 16));
@@ -375,6 +403,8 @@ int k0_frame(bgp_ctx* c) {
     if (st < 0 && st != BGP_ESEQ) return st;
     c->n_records = n; c->sum_lseq = sl; c->sum_ncig = sc;
     if (c->frame_tail > len) c->frame_tail = len;
+    if (c->timing)                       // what framing has to read: block_size and the 32 fixed bytes of every record (known only now)
+        for (auto& t : c->timers) if (t.name == "k0_chase") t.algorithmic_bytes += n * 36;
 
     c->long_cigar = (bits & ST_LONGCIG) != 0;
     c->table_pending = true;             // the record table is written by whoever needs it first: k1_table, or the fused K1+K2 when a decode follows

@@ -128,13 +128,17 @@ __global__ __launch_bounds__(K3_T) void k3_reduce(K3Args a, K3Key* bsum) {
 __global__ __launch_bounds__(K3_T) void k3_bsum(K3Key* bsum, uint64_t nb) {      // single workgroup: exclusive scan of the tile maxima
     __shared__ K3Key lds[K3_T / 64];
     K3Key carry{0, 0};
-    for (uint64_t base = 0; base < nb; base += K3_T) {
-        const uint64_t i = base + threadIdx.x;
-        K3Key v{0, 0};
-        if (i < nb) v = bsum[i];
+    for (uint64_t base = 0; base < nb; base += K3_TILE) {                        // a thread takes K3_ITEMS consecutive maxima: 24 rounds of two barriers for 10^8 records (one per round: 191, 0.2 ms)
+        const uint64_t i0 = base + (uint64_t)threadIdx.x * K3_ITEMS;
+        K3Key v[K3_ITEMS], mine{0, 0};
+#pragma unroll
+        for (int k = 0; k < K3_ITEMS; ++k) { v[k] = K3Key{0, 0}; if (i0 + k < nb) v[k] = bsum[i0 + k]; }
+#pragma unroll
+        for (int k = 0; k < K3_ITEMS; ++k) mine = k3_max(mine, v[k]);
         K3Key tot;
-        const K3Key ex = k3_block_excl(v, &tot, lds);
-        if (i < nb) bsum[i] = k3_max(carry, ex);
+        K3Key run = k3_max(carry, k3_block_excl(mine, &tot, lds));
+#pragma unroll
+        for (int k = 0; k < K3_ITEMS; ++k) { if (i0 + k < nb) bsum[i0 + k] = run; run = k3_max(run, v[k]); }
         carry = k3_max(carry, tot);
     }
 }
