@@ -1013,6 +1013,9 @@ __global__ __launch_bounds__(256) void k4_stats(const unsigned long long* ts, ui
 //   ROW  (kind 3) a long read's stretch of the window, one class byte per COLUMN (k4_ck_build walks every long read's
 //        CIGAR once and writes them: an M/=/X column its base's class, a D / N column '-'), copied to LDS as it is
 //        [2] the read starts here  [13:3] first position  [23:14] positions - 1  [63:24] offset of the first byte in the row arena
+#ifndef BGP_PLAN_ABL
+#define BGP_PLAN_ABL 0                        // timing experiments on k4_plan: 1 no '-' window atomics, 2 no far-slot atomics, 4 no descriptor stores
+#endif
 #ifndef BGP_G_ABL
 #define BGP_G_ABL 0                           // timing experiments: 1 no gather, 2 no staging either, 3 no layout either, 4 window header only
 #endif
@@ -1064,96 +1067,92 @@ struct PlanArgs {
 __global__ __launch_bounds__(256) void k4_plan(PlanArgs a) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
+    // Straight-line, selects instead of joins, descriptors in 32-bit halves: written with a branch per case and per op this
+    // kernel spent 600 VALU instructions a wave, four in ten of them register moves where the branches met -- and VALU
+    // issue is what bounds it (SQ counters: 78 % of its time).  Lanes behind the last record work on it a second time and
+    // keep nothing.
+    constexpr uint32_t SH = (uint32_t)__builtin_ctz((unsigned)W);             // log2(W)
     unsigned long long dsc[8]; uint32_t win[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { dsc[j] = 0; win[j] = 0xFFFFFFFFu; }
-    uint32_t wf = 0xFFFFFFFFu;
-    bool any = false;
     // the reference run of a record: reads are sorted, so a wave nearly always lies inside one run -- the first lane's
     // run is looked up once (a binary search of dependent loads) and only lanes beyond its end search for themselves
     const uint64_t i0 = i - lane;
-    uint32_t ri = 0; uint64_t r_end = 0, r_start_pos = 0, r_tile_base = 0;
-    if (i0 < a.n) {
-        ri = run_of_record(a.runs, a.n_runs, i0);
-        const RunDev rd = a.runs[ri];
-        r_end = rd.end_record; r_start_pos = rd.start_pos; r_tile_base = rd.tile_base;
+    if (i0 >= a.n) return;
+    uint64_t r_end, r_start_pos, r_tile_base;
+    { const RunDev rd = a.runs[run_of_record(a.runs, a.n_runs, i0)]; r_end = rd.end_record; r_start_pos = rd.start_pos; r_tile_base = rd.tile_base; }
+    const bool in = i < a.n;
+    const uint64_t ii = in ? i : a.n - 1;
+    const uint4* rp = reinterpret_cast<const uint4*>(a.rec + ii);
+    const uint4 x = rp[0], y = rp[1];                     // ref_id,pos,end_pos,bin_mq_nl | flag_nc,l_seq,rec_off
+    const bool covered = in && x.z != x.y;                // basesCovered() > 0, pileup.d:481,510
+    if (covered && ii >= r_end) { const RunDev& rd = a.runs[run_of_record(a.runs, a.n_runs, ii)]; r_start_pos = rd.start_pos; r_tile_base = rd.tile_base; }
+    const uint32_t rel0 = x.y - (uint32_t)r_start_pos;
+    const uint32_t tb = (uint32_t)r_tile_base;
+    const uint32_t wf0 = tb + (rel0 >> SH), wl = tb + ((x.z - 1 - (uint32_t)r_start_pos) >> SH);
+    const uint32_t n_cig = y.x & 0xFFFFu, l_seq = y.y;
+    const uint64_t cig_off = (((uint64_t)y.w << 32) | y.z) + 36 + (x.w & 0xFFu);
+    const uint64_t seq_off = cig_off + 4ull * n_cig;
+    bool simple = covered && n_cig >= 1 && n_cig <= 4 && l_seq >= 1 && l_seq <= (uint32_t)FAST_SEG && seq_off + (l_seq + 1) / 2 + 16 <= a.stream_len;   // (staging reads 16 bytes per lane)
+    uint32_t ops[4];
+    if (a.cig4) { const uint4 c4 = a.cig4[ii]; ops[0] = c4.x; ops[1] = c4.y; ops[2] = c4.z; ops[3] = c4.w; }
+    else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { ops[k] = 0; if (simple && (uint32_t)k < n_cig) ops[k] = ld_u32(a.s + cig_off + 4 * k); }
     }
-    if (i < a.n) {
-        const uint4* rp = reinterpret_cast<const uint4*>(a.rec + i);
-        const uint4 x = rp[0], y = rp[1];                 // ref_id,pos,end_pos,bin_mq_nl | flag_nc,l_seq,rec_off
-        if (x.z != x.y) {                                 // basesCovered() > 0, pileup.d:481,510
-            if (i >= r_end) { const RunDev& rd = a.runs[run_of_record(a.runs, a.n_runs, i)]; r_start_pos = rd.start_pos; r_tile_base = rd.tile_base; }
-            const uint32_t rel0 = x.y - (uint32_t)r_start_pos;
-            const uint32_t tb = (uint32_t)r_tile_base;
-            wf = tb + rel0 / W;
-            const uint32_t wl = tb + (x.z - 1 - (uint32_t)r_start_pos) / W;
-            const uint32_t n_cig = y.x & 0xFFFFu, l_seq = y.y;
-            const uint64_t cig_off = (((uint64_t)y.w << 32) | y.z) + 36 + (x.w & 0xFFu);
-            const uint64_t seq_off = cig_off + 4ull * n_cig;
-            bool simple = n_cig >= 1 && n_cig <= 4 && l_seq >= 1 && l_seq <= (uint32_t)FAST_SEG && seq_off + (l_seq + 1) / 2 + 16 <= a.stream_len;   // (staging reads 16 bytes per lane)
-            uint32_t ops[4] = {0, 0, 0, 0};
-            if (simple) {
-                if (a.cig4) { const uint4 c4 = a.cig4[i]; ops[0] = c4.x; ops[1] = c4.y; ops[2] = c4.z; ops[3] = c4.w; }
-                else {
+    {   // the mould: no zero-length reference-consuming op, the first reference-consuming op is M/=/X (so the read's first
+        // column is its first staged base), the CIGAR does not consume more query than SEQ holds
+        bool seen_ref = false, bad = false; uint32_t qsum = 0;
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) if ((uint32_t)k < n_cig) ops[k] = ld_u32(a.s + cig_off + 4 * k);
-                }
-                // the mould: no zero-length reference-consuming op, the first reference-consuming op is M/=/X (so the
-                // read's first column is its first staged base), the CIGAR does not consume more query than SEQ holds
-                bool seen_ref = false; uint32_t qsum = 0;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) if ((uint32_t)k < n_cig) {
-                    const uint32_t op = ops[k], len = op >> 4;
-                    if (cig_rc(op)) { if (len == 0 || (!seen_ref && !cig_qc(op))) simple = false; seen_ref = true; }
-                    if (cig_qc(op)) qsum += len;
-                }
-                if (qsum > l_seq) simple = false;
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t op = ops[k], len = op >> 4;
+            const bool on = (uint32_t)k < n_cig, rc = on && cig_rc(op), qc = on && cig_qc(op);
+            bad |= rc && (len == 0 || (!seen_ref && !qc));
+            seen_ref |= rc;
+            qsum += qc ? len : 0u;
+        }
+        simple = simple && !bad && qsum <= l_seq;
+    }
+    if (covered && !simple) {
+        if (a.ck && wants_ckpt(n_cig, l_seq) && a.ck[a.ck_off[ii]].pad == 0) {
+            // a long read that fits the mould (k4_ck_build walked its CIGAR): one ROW descriptor per window it touches
+            const uint32_t rel1 = x.z - (uint32_t)r_start_pos;
+            for (uint32_t w = wf0; w <= wl; ++w) {
+                const uint32_t w0 = (w - tb) * (uint32_t)W;
+                const uint32_t lo = max(rel0, w0) - w0, hi = min(rel1, w0 + (uint32_t)W) - w0;
+                const uint32_t slot = atomicAdd(&a.wcount[w], 1u);
+                if (slot < SLAB_CAP) a.slab[(uint64_t)w * SLAB_CAP + slot] = 3ull | (w == wf0 ? 4ull : 0ull) | ((unsigned long long)lo << 3) | ((unsigned long long)(hi - lo - 1) << 14) | ((a.row_off[ii] + (w0 + lo - rel0)) << 24);
             }
-            if (!simple && a.ck && wants_ckpt(n_cig, l_seq) && a.ck[a.ck_off[i]].pad == 0) {
-                // a long read that fits the mould (k4_ck_build walked its CIGAR): one ROW descriptor per window it touches
-                const uint32_t rel1 = x.z - (uint32_t)r_start_pos;
-                for (uint32_t w = wf; w <= wl; ++w) {
-                    const uint32_t w0 = (w - tb) * (uint32_t)W;
-                    const uint32_t lo = max(rel0, w0) - w0, hi = min(rel1, w0 + (uint32_t)W) - w0;
-                    const uint32_t slot = atomicAdd(&a.wcount[w], 1u);
-                    if (slot < SLAB_CAP) a.slab[(uint64_t)w * SLAB_CAP + slot] = 3ull | (w == wf ? 4ull : 0ull) | ((unsigned long long)lo << 3) | ((unsigned long long)(hi - lo - 1) << 14) | ((a.row_off[i] + (w0 + lo - rel0)) << 24);
-                }
-                wf = 0xFFFFFFFFu;
-            } else if (!simple) {                         // left to the general kernel, with every window it overlaps
-                atomicAdd(&a.wslow[wf], 1); atomicAdd(&a.wslow[wl + 1], -1);
-            } else {
-                uint32_t p = 0, q = 0;                    // columns / query bases before the op (file header: cstart, qstart)
+        } else {                                          // left to the general kernel, with every window it overlaps
+            atomicAdd(&a.wslow[wf0], 1); atomicAdd(&a.wslow[wl + 1], -1);
+        }
+    }
+    const uint32_t wf = simple ? wf0 : 0xFFFFFFFFu;
+    const bool any = simple;
+    {
+        const uint32_t n_ops = simple ? n_cig : 0u;
+        uint32_t p = 0, q = 0;                            // columns / query bases before the op (file header: cstart, qstart)
 #pragma unroll
-                for (int k = 0; k < 4; ++k) if ((uint32_t)k < n_cig) {
-                    const uint32_t op = ops[k], len = op >> 4, qc = cig_qc(op), rc = cig_rc(op);
-                    if (rc) {
-                        const uint32_t a0 = rel0 + p, a1 = a0 + len;                 // run-relative columns [a0, a1) of the op
-                        const uint32_t w0 = a0 / W, w1 = (a1 - 1) / W;
-                        const uint32_t lo0 = a0 - w0 * W, n0 = min(a1, (w0 + 1) * W) - a0;
-                        if (qc) {                                                     // M, =, X: pileup.d:117-118; len <= 160 < W: at most two windows
-                            const uint64_t src = seq_off + (q >> 1);
-                            dsc[2 * k] = 1ull | (p == 0 ? 4ull : 0ull) | ((unsigned long long)lo0 << 3) | ((unsigned long long)n0 << 14) | ((unsigned long long)(q & 1u) << 22) | (src << 23);
-                            win[2 * k] = tb + w0;
-                            if (w1 > w0) {
-                                const uint32_t q1 = q + n0;
-                                dsc[2 * k + 1] = 1ull | ((unsigned long long)(len - n0) << 14) | ((unsigned long long)(q1 & 1u) << 22) | ((seq_off + (q1 >> 1)) << 23);
-                                win[2 * k + 1] = tb + w1;
-                            }
-                        } else {                                                      // D, N: '-', pileup.d:119-121
-                            dsc[2 * k] = 2ull | ((unsigned long long)lo0 << 3) | ((unsigned long long)(lo0 + n0) << 14);
-                            win[2 * k] = tb + w0;
-                            if (w1 > w0) {
-                                dsc[2 * k + 1] = 2ull | ((unsigned long long)(a1 - w1 * W) << 14);
-                                win[2 * k + 1] = tb + w1;
-                                if (w1 - w0 >= 2) { atomicAdd(&a.wdel[tb + w0 + 1], 1); atomicAdd(&a.wdel[tb + w1], -1); }   // windows covered end to end
-                            }
-                        }
-                        p += len;
-                    }
-                    if (qc) q += len;
-                }
-                any = true;
-            }
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t op = ops[k], len = op >> 4;
+            const bool on = (uint32_t)k < n_ops, qc = on && cig_qc(op), rc = on && cig_rc(op);
+            const uint32_t a0 = rel0 + p, a1 = a0 + len;                             // run-relative columns [a0, a1) of the op
+            const uint32_t w0 = a0 >> SH, w1 = (a1 - 1) >> SH;
+            const uint32_t lo0 = a0 & (uint32_t)(W - 1), n0 = min(len, (uint32_t)W - lo0);
+            const bool two = rc && w1 > w0;
+            // M, =, X (pileup.d:117-118; len <= 255 < W: at most two windows): where the bases are; D, N ('-', :119-121): where the op ends
+            const uint32_t q1 = q + n0;
+            const uint64_t s0 = (seq_off + (q >> 1)) << 23, s1 = (seq_off + (q1 >> 1)) << 23;
+            const uint32_t seg0 = 1u | (p == 0 ? 4u : 0u) | (lo0 << 3) | (n0 << 14) | ((q & 1u) << 22) | (uint32_t)s0;
+            const uint32_t seg1 = 1u | ((len - n0) << 14) | ((q1 & 1u) << 22) | (uint32_t)s1;
+            const uint32_t del0 = 2u | (lo0 << 3) | ((lo0 + n0) << 14), del1 = 2u | ((a1 - (w1 << SH)) << 14);
+            dsc[2 * k] = qc ? ((unsigned long long)(uint32_t)(s0 >> 32) << 32) | seg0 : (unsigned long long)del0;
+            dsc[2 * k + 1] = qc ? ((unsigned long long)(uint32_t)(s1 >> 32) << 32) | seg1 : (unsigned long long)del1;
+            win[2 * k] = rc ? tb + w0 : 0xFFFFFFFFu;
+            win[2 * k + 1] = two ? tb + w1 : 0xFFFFFFFFu;
+#if !(BGP_PLAN_ABL & 1)
+            if (two && !qc && w1 - w0 >= 2) { atomicAdd(&a.wdel[tb + w0 + 1], 1); atomicAdd(&a.wdel[tb + w1], -1); }   // windows covered end to end
+#endif
+            p += rc ? len : 0u;
+            q += qc ? len : 0u;
         }
     }
     // slots in the windows' slabs.  Reads are sorted, so nearly every descriptor of a wave goes to the wave's first
@@ -1169,18 +1168,26 @@ __global__ __launch_bounds__(256) void k4_plan(PlanArgs a) {
     const uint32_t tot = (uint32_t)__shfl((int)inc, 63, 64);
     uint32_t base0 = 0, base1 = 0;
     if (lane == 0) {
-        if (tot & 0xFFFFu) base0 = atomicAdd(&a.wcount[A], tot & 0xFFFFu);
-        if (tot >> 16) base1 = atomicAdd(&a.wcount[A + 1], tot >> 16);
+        if (tot & 0xFFFFu) base0 = atomicAdd(&a.wcount[A], (BGP_PLAN_ABL & 4) ? 0u : tot & 0xFFFFu);
+        if (tot >> 16) base1 = atomicAdd(&a.wcount[A + 1], (BGP_PLAN_ABL & 4) ? 0u : tot >> 16);
     }
     uint32_t far_slot[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { far_slot[j] = 0; if (win[j] != 0xFFFFFFFFu && win[j] != A && win[j] != A + 1) far_slot[j] = atomicAdd(&a.wcount[win[j]], 1u); }
+    for (int j = 0; j < 8; ++j) { far_slot[j] = 0;
+#if !(BGP_PLAN_ABL & 2)
+        if (win[j] != 0xFFFFFFFFu && win[j] != A && win[j] != A + 1) far_slot[j] = atomicAdd(&a.wcount[win[j]], (BGP_PLAN_ABL & 4) ? 0u : 1u);
+#endif
+    }
     uint32_t o0 = rl(base0, 0) + ((inc - pk) & 0xFFFFu), o1 = rl(base1, 0) + ((inc - pk) >> 16);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         if (win[j] == 0xFFFFFFFFu) continue;
         const uint32_t slot = win[j] == A ? o0++ : win[j] == A + 1 ? o1++ : far_slot[j];
+#if !(BGP_PLAN_ABL & 4)
         if (slot < SLAB_CAP) a.slab[(uint64_t)win[j] * SLAB_CAP + slot] = dsc[j];
+#else
+        if (slot == 0xFFFFFFF0u) a.slab[(uint64_t)win[j] * SLAB_CAP] = dsc[j];
+#endif
     }
 }
 

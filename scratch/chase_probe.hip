@@ -54,7 +54,7 @@ template <int MODE> float run(const uint8_t* s, uint64_t len, uint32_t seg, uint
 }
 
 // 16 offsets in registers (the iteration count is the same for every active lane: static register indices), one 64-byte line per flush
-template <int NB> __global__ __launch_bounds__(256) void k_chase_buf(const uint8_t* s, uint64_t len, uint32_t seg, uint64_t n_seg, uint32_t rec, uint32_t* side, uint32_t side_cap, uint64_t* out) {
+template <int NB, int ST = 1> __global__ __launch_bounds__(256) void k_chase_buf(const uint8_t* s, uint64_t len, uint32_t seg, uint64_t n_seg, uint32_t rec, uint32_t* side, uint32_t side_cap, uint64_t* out) {
     const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n_seg) return;
     const uint64_t seg0 = k * (uint64_t)seg, seg_end = min(seg0 + seg, len);
@@ -77,19 +77,23 @@ template <int NB> __global__ __launch_bounds__(256) void k_chase_buf(const uint8
             }
         }
 #pragma unroll
-        for (int q = 0; q < NB / 4; ++q) reinterpret_cast<uint4*>(dst)[q] = make_uint4(buf[4 * q], buf[4 * q + 1], buf[4 * q + 2], buf[4 * q + 3]);
+        for (int q = 0; q < NB / 4; ++q) {
+            if (ST == 1) reinterpret_cast<uint4*>(dst)[q] = make_uint4(buf[4 * q], buf[4 * q + 1], buf[4 * q + 2], buf[4 * q + 3]);
+            if (ST == 2) { __builtin_nontemporal_store(buf[4 * q], dst + 4 * q); __builtin_nontemporal_store(buf[4 * q + 1], dst + 4 * q + 1); __builtin_nontemporal_store(buf[4 * q + 2], dst + 4 * q + 2); __builtin_nontemporal_store(buf[4 * q + 3], dst + 4 * q + 3); }
+            if (ST == 0) ls += buf[4 * q] ^ buf[4 * q + 1] ^ buf[4 * q + 2] ^ buf[4 * q + 3];
+        }
         dst += NB;
     }
     out[k] = cnt + ls;
 }
-template <int NB> float run_buf(const uint8_t* s, uint64_t len, uint32_t seg, uint32_t rec, uint32_t* side, uint64_t* out, int reps) {
+template <int NB, int ST = 1> float run_buf(const uint8_t* s, uint64_t len, uint32_t seg, uint32_t rec, uint32_t* side, uint64_t* out, int reps) {
     const uint64_t n_seg = (len + seg - 1) / seg;
     const uint32_t side_cap = ((seg / 36 + 2) + 63) & ~31u;
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
     float best = 1e9f;
     for (int r = 0; r < reps; ++r) {
         CK(hipEventRecord(a));
-        hipLaunchKernelGGL(k_chase_buf<NB>, dim3((unsigned)((n_seg + 255) / 256)), dim3(256), 0, 0, s, len, seg, n_seg, rec, side, side_cap, out);
+        hipLaunchKernelGGL((k_chase_buf<NB, ST>), dim3((unsigned)((n_seg + 255) / 256)), dim3(256), 0, 0, s, len, seg, n_seg, rec, side, side_cap, out);
         CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
         float ms; CK(hipEventElapsedTime(&ms, a, b)); if (ms < best) best = ms;
     }
@@ -102,8 +106,8 @@ int main(int argc, char** argv) {
     uint64_t* out; CK(hipMalloc(&out, ((len >> 12) + 2) * 8));
     uint32_t* side; CK(hipMalloc(&side, (len / 36 + (len >> 10) * 80 + 1024) * 4));
     CK(hipMemset(s, 0, len + 64));
-    const uint32_t recs[] = {290, 256, 291, 128, 580};
-    const uint32_t segs[] = {65536, 32768, 16384, 262144};
+    const uint32_t recs[] = {290};
+    const uint32_t segs[] = {65536};
     for (uint32_t rec : recs) {
         hipLaunchKernelGGL(k_fill, dim3((unsigned)((len / rec + 256) / 256)), dim3(256), 0, 0, s, len, rec);
         CK(hipDeviceSynchronize());
@@ -115,6 +119,7 @@ int main(int argc, char** argv) {
             printf("rec %3u B seg %6u: bs only %.2f ms (%.1f G hops/s) | +hdr12 %.2f | +hdr12 +side4 %.2f | +hdr12 +side16 %.2f | nt +hdr12 %.2f | bs +side4 %.2f\n",
                    rec, seg, t0, n_rec / t0 / 1e6, t1, t3, t5, t9, t2);
             printf("                     +hdr12 + 8 in registers (32 B) %.2f | 16 (64 B) %.2f | 32 (128 B) %.2f\n", run_buf<8>(s, len, seg, rec, side, out, 3), run_buf<16>(s, len, seg, rec, side, out, 3), run_buf<32>(s, len, seg, rec, side, out, 3));
+            printf("                     16 in registers: no store %.2f | nontemporal %.2f\n", run_buf<16, 0>(s, len, seg, rec, side, out, 3), run_buf<16, 2>(s, len, seg, rec, side, out, 3));
             fflush(stdout);
         }
     }
