@@ -50,12 +50,17 @@ def kernels_sha():
 # timed region, are not the step's)
 TIMER_KERNELS = {"k12_lds": ("k12_lds",), "k012_stream": ("k_stream_decode",), "k2_unpack": ("k2_unpack",), "k12_fused": ("k12_fused",), "k1_rows": ("k12_fused",),
                  "k4_bounds": ("k4_bounds",), "k4_plan": ("k4_plan", "k4_wscan"), "k4_tile": ("k4_exec", "k4_tile", "k4_stats"),
-                 "k4_checkpoints": ("k4_ck_",), "k4_rows": ("k4_rows_build",)}
+                 "k4_checkpoints": ("k4_ck_",), "k4_rows": ("k4_rows_build",),
+                 "k0_guess": ("k0_guess",), "k0_chase": ("k0_chase", "k0_verify"), "k3_keys_scan": ("k3_",)}
 
 
-def pmc_traffic(timers, config, n_reads):
-    """HBM bytes of one dispatch of each kernel behind the timers of the stage (= per step: these kernels run once a
-    step), from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected separately, FETCH doubled for
+FETCH_AS_COUNTED = ("k0_chase",)
+
+
+def pmc_traffic(timers, config, n_reads, launches=None):
+    """HBM bytes per step of the kernels behind the timers of the stage: the mean per dispatch of each kernel times the
+    timer's launches per step (1 for all but k0_chase, whose second round re-enters a few segments), from the committed
+    rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected separately, FETCH doubled for
     gfx950 as MI355X_MICROARCH.md prescribes).  Counters cannot be read from inside this process, so the number is only
     reported when the workload is the one the profile was taken on (cfg3, 100 M reads) AND the profile's header carries
     the hash of the kernel sources as they are now (scratch/refresh_profiles_r02.sh writes it); otherwise null."""
@@ -65,12 +70,16 @@ def pmc_traffic(timers, config, n_reads):
     lines = open(path).read().splitlines()
     if not any(("kernels_sha=" + kernels_sha()) in ln for ln in lines if ln.startswith("#")):
         return None
-    names = tuple(k for t in timers for k in TIMER_KERNELS.get(t, ()))
     total = None
-    for line in lines:
-        f = line.strip().split(",")
-        if len(f) >= 5 and names and f[0].startswith(names) and f[4].isdigit():
-            total = (total or 0) + int(f[4])
+    for t in timers:
+        names = tuple(TIMER_KERNELS.get(t, ()))
+        for line in lines:
+            f = line.strip().split(",")
+            if len(f) >= 5 and names and f[0].startswith(names) and f[4].isdigit():
+                per_dispatch = int(f[4])
+                if f[0].startswith(FETCH_AS_COUNTED):       # (the guide's doubling is calibrated on wide coalesced reads: on the chase's
+                    per_dispatch = (int(f[1]) + int(f[2])) * 1024   # 4-byte hops it would report twice the lines the stream has)
+                total = (total or 0) + per_dispatch * int((launches or {}).get(t, 1))
     return total
 
 
@@ -307,6 +316,7 @@ def main():
         per_kernel = {k: {"ms_per_launch": round(v["total_ms"] / v["launches"], 4), "launches_per_step": v["launches"] // a.steps,
                           "algorithmic_GBps": round(v["algorithmic_bytes"] / v["launches"] / (v["total_ms"] / v["launches"] * 1e-3) / 1e9, 1) if v["total_ms"] > 0 else None}
                       for k, v in kt.items()}
+        lps = {k: v["launches_per_step"] for k, v in per_kernel.items()}
         # a stage = the kernels that together produce one product of the path; its roofline figure is the stage's
         # algorithmic bytes over ALL of its kernels' time
         stages = {}
@@ -340,12 +350,12 @@ def main():
             "decode_Mreads_per_s_kernel_only": round(n_reads / (dec_ms * 1e-3) / 1e6, 2) if dec_ms else None,
             "roofline": {"bound": "hbm", "kernel": dom + " = " + " + ".join(stages[dom]["kernels"]), "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "algorithmic_bytes_per_launch": dom_bytes,
-                         "traffic": pmc_traffic(stages[dom]["kernels"], a.config, n_reads)},
+                         "traffic": pmc_traffic(stages[dom]["kernels"], a.config, n_reads, lps)},
             "roofline_decode_8d": {"what": "K0 + K1 + K2 by SURVEY 8(d)'s bytes: whole record in, 32-byte row + seq + qual + cigar out", "ms": round(dec_ms, 3),
                                    "achieved": round(dec_bytes / (dec_ms * 1e-3) / 1e9, 1) if dec_ms else None, "frac": round(dec_bytes / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if dec_ms else None},
             "stages_ms": {s: round(v["ms_per_step"], 3) for s, v in stages.items()},
             "stage_rooflines": {s: {"algorithmic_GBps": round(v["bytes"] / (v["ms_per_step"] * 1e-3) / 1e9, 1), "frac": round(v["bytes"] / (v["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
-                                    "algorithmic_bytes": v["bytes"], "traffic": pmc_traffic(v["kernels"], a.config, n_reads)}
+                                    "algorithmic_bytes": v["bytes"], "traffic": pmc_traffic(v["kernels"], a.config, n_reads, lps)}
                                 for s, v in stages.items() if v["bytes"] and v["ms_per_step"] > 0},
             "kernels": per_kernel,
             "setup_s": round(gen_s, 2),
