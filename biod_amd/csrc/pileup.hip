@@ -297,25 +297,30 @@ __global__ __launch_bounds__(256) void k4_ck_count(const bgp_record* rec, uint64
     if (n_cols) { n_cols[i] = cols; n_chunks[i] = cols ? ((r.flag_nc & 0xFFFFu) + 63) / 64 : 0; }      // a long read's row in the arena: one class byte per column it covers; its CIGAR in chunks of 64 ops
 }
 
-__global__ __launch_bounds__(256) void k4_ck_build(const uint8_t* s, uint64_t stream_len, const bgp_record* rec, uint64_t n, const RunDev* runs, uint32_t n_runs,
+// WPR: a wave per RECORD (a stream of long reads: with a lane per record a wave walks its 64 reads one after the other --
+// cfg5's 200 k reads are 3125 waves of 2000 serial steps on a device with 8192 wave slots); otherwise a lane per record
+// and the wave walks the few long reads among its 64.
+template <bool WPR> __global__ __launch_bounds__(256) void k4_ck_build(const uint8_t* s, uint64_t stream_len, const bgp_record* rec, uint64_t n, const RunDev* runs, uint32_t n_runs,
                                                    const uint64_t* ck_off, Ckpt* ck, uint32_t W_, const uint64_t* chunk_off, uint4* cst) {
     const int64_t W = (int64_t)W_;
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
+    const uint64_t wave0 = WPR ? (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6) : (uint64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63);   // the wave's (first) record
+    const uint64_t i = WPR ? wave0 : wave0 + lane;
     bgp_record r{};
     bool lng = false;
     if (i < n) { r = rec[i]; lng = r.end_pos != r.pos && wants_ckpt(r.flag_nc & 0xFFFFu, (uint32_t)r.l_seq); }
-    unsigned long long m = __ballot(lng);
+    unsigned long long m = WPR ? (lng ? 1ull : 0ull) : __ballot(lng);
     while (m) {
         const int src = __ffsll((long long)m) - 1;
         m &= m - 1;
-        const uint64_t ri = (uint64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63) + src;
+        const uint64_t ri = wave0 + src;
         const uint32_t pos = (uint32_t)__shfl(r.pos, src, 64), covered = (uint32_t)__shfl(r.end_pos, src, 64) - pos;
         const uint32_t n_cig = (uint32_t)__shfl((int)r.flag_nc, src, 64) & 0xFFFFu, l_name = (uint32_t)__shfl((int)r.bin_mq_nl, src, 64) & 0xFFu;
         const uint64_t rec_off = ((uint64_t)(uint32_t)__shfl((int)(r.rec_off >> 32), src, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)r.rec_off, src, 64);
         const uint8_t* cg = s + rec_off + 36 + l_name;
         const RunDev& run = runs[run_of_record(runs, n_runs, ri)];
-        const uint64_t t_first = ((uint64_t)pos - run.start_pos) / W;
+        const uint32_t wsh = (uint32_t)__builtin_ctz(W_);                                       // (windows are powers of two: no 64-bit division per op)
+        const uint64_t t_first = ((uint64_t)pos - run.start_pos) >> wsh;
         const uint32_t n_ck = (uint32_t)(ck_off[ri + 1] - ck_off[ri]);
         Ckpt* out = ck + ck_off[ri];
         // window j (j >= 1) starts at column offset D + j*W of this read (D <= 0)
@@ -325,9 +330,11 @@ __global__ __launch_bounds__(256) void k4_ck_build(const uint8_t* s, uint64_t st
         // read's first column is a base of it: no leading N, D), no zero-length reference-consuming op, no M base past SEQ
         bool plain = true;
         const uint32_t l_seq_r = (uint32_t)__shfl(r.l_seq, src, 64);
+        uint32_t op_next = (uint32_t)lane < n_cig ? ld_u32(cg + 4ull * lane) : 0u;
         for (uint32_t c0 = 0; c0 < n_cig && cs < covered; c0 += 64) {
             const bool active = c0 + lane < n_cig;
-            const uint32_t op = active ? ld_u32(cg + 4ull * (c0 + lane)) : 0u;
+            const uint32_t op = op_next;
+            op_next = c0 + 64 + lane < n_cig ? ld_u32(cg + 4ull * (c0 + 64 + lane)) : 0u;      // (the next chunk's ops are on their way while this one is scanned)
             // the first reference-consuming non-N op starts the cursor (pileup.d:180-189)
             int fl = 64;
             if (!started) {
@@ -345,7 +352,7 @@ __global__ __launch_bounds__(256) void k4_ck_build(const uint8_t* s, uint64_t st
             if (cst && lane == 0) cst[chunk_off[ri] + c0 / 64] = make_uint4((uint32_t)ri, c0 | (started ? 0x80000000u : 0u), cs, qs);      // where the chunk starts: k4_rows_build writes its columns
             if (rlen) {
                 if (cs_b == 0 && n_ck) { Ckpt e{c0 + (uint32_t)lane, 0u, qs_b, 0u}; out[0] = e; }      // window of the read's first column
-                int64_t j = (int64_t)cs_b - D <= 0 ? 1 : ((int64_t)cs_b - D + W - 1) / W;              // first window starting at/after cs_b
+                int64_t j = (int64_t)cs_b - D <= 0 ? 1 : (int64_t)((uint64_t)((int64_t)cs_b - D + W - 1) >> wsh);   // first window starting at/after cs_b
                 if (j < 1) j = 1;
                 for (; j < (int64_t)n_ck && D + j * W < (int64_t)(cs_b + rlen); ++j) { Ckpt e{c0 + (uint32_t)lane, cs_b, qs_b, 0u}; out[j] = e; }
             }
@@ -1803,7 +1810,10 @@ int k34_pileup(bgp_ctx* c) {
             }
             BGP_TRY(c->d_ck.reserve((total_ck + 1) * sizeof(Ckpt)));
             BGP_HIP(hipMemsetAsync(c->d_ck.p, 0xFF, (total_ck + 1) * sizeof(Ckpt), c->stream));
-            hipLaunchKernelGGL(k4_ck_build, dim3(nb), dim3(256), 0, c->stream, a.s, a.stream_len, a.rec, n, a.runs, n_runs, ck_off, c->d_ck.as<Ckpt>(), tw, chunk_off, rows ? c->d_chunk_state.as<uint4>() : nullptr);
+            if ((uint64_t)st[3] * 8 >= n)             // mostly long reads: a wave each
+                hipLaunchKernelGGL(k4_ck_build<true>, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, c->stream, a.s, a.stream_len, a.rec, n, a.runs, n_runs, ck_off, c->d_ck.as<Ckpt>(), tw, chunk_off, rows ? c->d_chunk_state.as<uint4>() : nullptr);
+            else
+                hipLaunchKernelGGL(k4_ck_build<false>, dim3(nb), dim3(256), 0, c->stream, a.s, a.stream_len, a.rec, n, a.runs, n_runs, ck_off, c->d_ck.as<Ckpt>(), tw, chunk_off, rows ? c->d_chunk_state.as<uint4>() : nullptr);
             a.ck = c->d_ck.as<Ckpt>(); a.ck_off = ck_off;
             }
             if (rows && total_chunks) { TimedRegion tr(c, "k4_rows", total_cols);
