@@ -371,6 +371,7 @@ __global__ __launch_bounds__(256) void k4_rows_build(const uint8_t* s, uint64_t 
                                                      const uint64_t* row_off, uint8_t* rows) {
     constexpr int RB_CAP = 4096;
     __shared__ __attribute__((aligned(16))) uint8_t s_row[4][RB_CAP];
+    __shared__ uint8_t s_map[4][512];                     // piece of 14 columns -> lane of its op (at most RB_CAP / 14 + 64 pieces a chunk)
     const uint64_t ch = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (ch >= n_chunks) return;
@@ -409,22 +410,46 @@ __global__ __launch_bounds__(256) void k4_rows_build(const uint8_t* s, uint64_t 
                 };
                 const uint32_t wlen = cs_b >= covered ? 0u : min(rlen, covered - cs_b);     // (covered: a malformed read's zero-length ops hold columns its row has no room for)
                 if (via_lds) {
-                    uint8_t* const dst = &s_row[wv][cs_b - cs];
-                    if (wlen && !is_m) { for (uint32_t t = 0; t < wlen; ++t) dst[t] = (uint8_t)ROW_DEL; }
-                    else if (wlen) {
-                        for (uint32_t t0 = 0; t0 < wlen; t0 += 14) {                     // 14 bases a piece: 8 packed bytes hold them whatever the first nibble
-                            const uint32_t q = qs_b + t0, odd = q & 1u, lim = min(14u, wlen - t0);
+                    // Not a lane per op -- the wave would run as long as its longest op while most lanes sit out (cfg5: ops of ~15
+                    // columns, the longest of 32 around 60) -- but a lane per PIECE of 14 columns: an op announces its pieces in
+                    // an LDS map (piece -> lane of its op), every lane then takes one piece, fetches that op's numbers with two
+                    // ds_bpermute and writes it.
+                    const uint32_t np = wlen ? (wlen + 13u) / 14u : 0u;
+                    const uint32_t ipc = wave_incl_u32(np, lane), p_first = ipc - np, p_total = (uint32_t)__shfl((int)ipc, 63, 64);
+                    for (uint32_t k = 0; k < np; ++k) s_map[wv][p_first + k] = (uint8_t)lane;
+                    const uint32_t packed = (cs_b - cs) | (wlen << 12) | ((is_m ? 1u : 0u) << 22) | (p_first << 23);      // row offset < 4096 | columns <= 512 | M/=/X | first piece < 512
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    for (uint32_t pb = 0; pb < p_total; pb += 64) {
+                        const uint32_t pc = pb + (uint32_t)lane;
+                        const bool mine = pc < p_total;
+                        const int ol = mine ? (int)s_map[wv][pc] : 0;
+                        const uint32_t pk = (uint32_t)__shfl((int)packed, ol, 64), oq = (uint32_t)__shfl((int)qs_b, ol, 64);
+                        if (!mine) continue;
+                        const uint32_t t0 = 14u * (pc - (pk >> 23)), owl = (pk >> 12) & 0x3FFu, lim = min(14u, owl - t0);
+                        uint8_t* const d = &s_row[wv][(pk & 0xFFFu) + t0];
+                        uint32_t wd[4];
+                        if (!((pk >> 22) & 1u)) { wd[0] = wd[1] = wd[2] = wd[3] = 0x01010101u * ROW_DEL; }
+                        else {
+                            const uint32_t q = oq + t0, odd = q & 1u;
                             const uint64_t src = seq_off + (q >> 1);
                             if (src + 8 <= stream_len && q + lim <= l_seq_r) {
                                 uint2 v; __builtin_memcpy(&v, s + src, 8);
                                 const uint2 c0 = class_bits8<true>(v.x), c1 = class_bits8<true>(v.y);      // 16 class bytes, three v_perm for four of them
-                                uint32_t wd[4];
                                 wd[0] = odd ? __builtin_amdgcn_alignbyte(c0.y, c0.x, 1) : c0.x; wd[1] = odd ? __builtin_amdgcn_alignbyte(c1.x, c0.y, 1) : c0.y;
                                 wd[2] = odd ? __builtin_amdgcn_alignbyte(c1.y, c1.x, 1) : c1.x; wd[3] = odd ? (c1.y >> 8) : c1.y;
-#pragma unroll
-                                for (uint32_t b = 0; b < 14; ++b) if (b < lim) dst[t0 + b] = (uint8_t)(wd[b >> 2] >> (8 * (b & 3u)));
-                            } else for (uint32_t b = 0; b < lim; ++b) dst[t0 + b] = base_byte(q + b);
+                            } else {
+                                wd[0] = wd[1] = wd[2] = wd[3] = 0;
+                                for (uint32_t b = 0; b < lim; ++b) wd[b >> 2] |= (uint32_t)base_byte(q + b) << (8 * (b & 3u));
+                            }
                         }
+                        // exactly `lim` bytes (the neighbours' columns are other lanes'), in as few LDS stores as that takes: gfx950's
+                        // DS unit takes unaligned addresses
+                        uint64_t rest = ((uint64_t)wd[1] << 32) | wd[0];
+                        uint32_t o = 0;
+                        if (lim & 8u) { __builtin_memcpy(d, &rest, 8); o = 8; rest = ((uint64_t)wd[3] << 32) | wd[2]; }
+                        if (lim & 4u) { const uint32_t x = (uint32_t)rest; __builtin_memcpy(d + o, &x, 4); o += 4; rest >>= 32; }
+                        if (lim & 2u) { const uint16_t x = (uint16_t)rest; __builtin_memcpy(d + o, &x, 2); o += 2; rest >>= 16; }
+                        if (lim & 1u) d[o] = (uint8_t)rest;
                     }
                 } else if (wlen && rlen <= 512) {                                        // (rare: straight to the arena)
                     uint8_t* const dst = rbase + cs_b;
