@@ -1601,3 +1601,44 @@ def test_first_record_hints_right_wrong_and_wild(ctx, data_dir):
         ctx.flush()
         dec = ctx.decode_fetch(0)
         assert np.array_equal(dec.rec["rec_off"], soa.rec_off) and np.array_equal(dec.rec["end_pos"], soa.end_pos), mode
+
+
+@pytest.mark.parametrize("m_len,n_long,n_short", [(100, 40, 0), (230, 30, 0), (700, 24, 0), (100, 6, 900), (37, 50, 0)])
+def test_long_read_rows_chunk_shapes(ctx, m_len, n_long, n_short):
+    """The long reads' pre-pass at the shapes its branches turn on: chunks of 64 ops with more than 64 pieces of 14
+    columns (m_len 100: several rounds of the piece loop), chunks wider than the 4096-byte LDS row (m_len 230: written
+    straight to the arena), ops wider than 512 columns (m_len 700: whole-wave copies), pieces that are not a multiple of
+    14 and odd query offsets (37); all reads long (a wave per record) and a few long reads among short ones (a lane per
+    record).  Columns against the oracle; entries on small windows."""
+    rng = np.random.default_rng(1000 + m_len + n_short)
+    ref_len = 120_000
+    items = []
+    for r in range(n_long):
+        cig, seq_len, cols = [], 0, 0
+        n_ops = int(rng.integers(150, 400))
+        if rng.random() < 0.5:
+            k = int(rng.integers(1, 30)); cig.append((k, "S")); seq_len += k
+        for j in range(n_ops):
+            k = max(1, int(rng.integers(m_len - m_len // 3, m_len + m_len // 3 + 1)))
+            cig.append((k, "M=X"[int(rng.integers(0, 3))])); seq_len += k; cols += k
+            t = rng.random()
+            if j == n_ops - 1:
+                break
+            if t < 0.45:
+                k = int(rng.integers(1, 4)); cig.append((k, "I")); seq_len += k
+            elif t < 0.9:
+                k = int(rng.integers(1, 4)); cig.append((k, "D")); cols += k
+            elif t < 0.95:
+                k = int(rng.integers(600, 3000)); cig.append((k, "N")); cols += k
+        pos = int(rng.integers(0, 5000))
+        seq = "".join(rng.choice(list("ACGTNRY"), size=seq_len, p=[0.24, 0.24, 0.24, 0.24, 0.02, 0.01, 0.01]))
+        items.append((pos, bamio.pack_record(f"L{r}", seq, cig, ref_id=0, pos=pos, qual=bytes(rng.integers(0, 60, size=seq_len, dtype=np.uint8)))))
+    for r in range(n_short):
+        pos = int(rng.integers(0, 60_000))
+        seq = "".join(rng.choice(list("ACGT"), size=100))
+        items.append((pos, bamio.pack_record(f"s{r}", seq, [(60, "M"), (2, "D"), (40, "M")], ref_id=0, pos=pos)))
+    items.sort(key=lambda x: x[0])
+    st = b"".join(b for _, b in items)
+    stage(ctx, st)
+    check_decode(ctx, st)
+    check_pileup(ctx, st, entries=(m_len == 37), window=700)
