@@ -8,15 +8,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/refresh
 rm -rf $OUT; mkdir -p $OUT
 cd $R
-timeout 900 python bench.py --steps 10 --warmup 3 > $OUT/r02_bench_cfg3_100M.json 2> $OUT/bench_cfg3.err
-timeout 600 python bench.py --steps 5 --warmup 2 --config cfg2 --no-cpu-baseline > $OUT/r02_bench_cfg2_10M.json 2> $OUT/bench_cfg2.err
-timeout 600 python bench.py --steps 5 --warmup 2 --config cfg5 --no-cpu-baseline > $OUT/r02_bench_cfg5_200k.json 2> $OUT/bench_cfg5.err
-BGP_BENCH_FORCE_COMM=1 timeout 600 python bench.py --steps 5 --warmup 2 --no-cpu-baseline 2> $OUT/bench_comm.err | grep "^{" | tail -1 > $OUT/r02_bench_cfg3_100M_one_rank_communicator.json
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/r02_bench_under_rocprofv3_cfg3_100M.json 2> $OUT/stats.err
-find $OUT/stats -name "*kernel_stats.csv" -exec cp {} $OUT/r02_rocprofv3_kernel_stats_cfg3_100M.csv \;
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats5 -- python $R/bench.py --steps 3 --warmup 1 --config cfg5 --no-cpu-baseline > /dev/null 2> $OUT/stats5.err
-find $OUT/stats5 -name "*kernel_stats.csv" -exec cp {} $OUT/r02_rocprofv3_kernel_stats_cfg5_200k.csv \;
 for C in FETCH_SIZE WRITE_SIZE; do
   timeout 600 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/$C -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-checks > $OUT/$C.log 2>&1
 done
@@ -48,6 +40,17 @@ with open(f"{out}/r02_pmc_hbm_traffic_cfg3_100M.csv", "w") as w:
         w.write(f"{k},{fk:.0f},{wk:.0f},{max(nf, nw, 1)},{int((2 * fk + wk) * 1024)}\n")
 print(open(f"{out}/r02_pmc_hbm_traffic_cfg3_100M.csv").read())
 PY
+cp $OUT/r02_pmc_hbm_traffic_cfg3_100M.csv $R/profiles/r02_pmc_hbm_traffic_cfg3_100M.csv      # (on the box: the bench lines below quote it)
+timeout 900 python bench.py --steps 10 --warmup 3 > $OUT/r02_bench_cfg3_100M.json 2> $OUT/bench_cfg3.err
+timeout 600 python bench.py --steps 5 --warmup 2 --config cfg2 --no-cpu-baseline > $OUT/r02_bench_cfg2_10M.json 2> $OUT/bench_cfg2.err
+timeout 600 python bench.py --steps 5 --warmup 2 --config cfg5 --no-cpu-baseline > $OUT/r02_bench_cfg5_200k.json 2> $OUT/bench_cfg5.err
+BGP_BENCH_FORCE_COMM=1 timeout 600 python bench.py --steps 5 --warmup 2 --no-cpu-baseline 2> $OUT/bench_comm.err | grep "^{" | tail -1 > $OUT/r02_bench_cfg3_100M_one_rank_communicator.json
+cd /tmp && export TMPDIR=/tmp
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/r02_bench_under_rocprofv3_cfg3_100M.json 2> $OUT/stats.err
+find $OUT/stats -name "*kernel_stats.csv" -exec cp {} $OUT/r02_rocprofv3_kernel_stats_cfg3_100M.csv \;
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats5 -- python $R/bench.py --steps 3 --warmup 1 --config cfg5 --no-cpu-baseline > /dev/null 2> $OUT/stats5.err
+find $OUT/stats5 -name "*kernel_stats.csv" -exec cp {} $OUT/r02_rocprofv3_kernel_stats_cfg5_200k.csv \;
+cd $R
 timeout 600 python scratch/e2e_batched.py 10000000 > $OUT/r02_device_e2e_batched_10M.log 2>&1
 BGP_VERBOSE=1 timeout 600 python scratch/e2e_file.py 10000000 2>&1 | grep -v "framing round" > $OUT/r02_file_e2e_10M.log
 rm -rf $OUT/stats $OUT/stats5 $OUT/FETCH_SIZE $OUT/WRITE_SIZE

@@ -7,18 +7,19 @@ for set in "SQ_WAVES SQ_INSTS_SALU SQ_INSTS_VALU SQ_INSTS_LDS" "SQ_INSTS_VMEM_RD
   timeout 400 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/$tag -- python /root/repo/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $OUT/$tag.log 2>&1
 done
 python - <<'PY'
-import csv, glob, collections, re
+import csv, glob, collections, re, os
+OUT = os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "gpurun_out", "sq_pmc")
 acc = collections.defaultdict(dict)
-for f in sorted(glob.glob("${GRAFT_REPO_ROOT:-/root/repo}/gpurun_out/sq_pmc/**/*counter_collection.csv", recursive=True)):
+for f in sorted(glob.glob(OUT + "/**/*counter_collection.csv", recursive=True)):
     for r in csv.DictReader(open(f)):
         k = re.sub(r"\(.*", "", r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "")).strip().replace(",", ";")
         acc[k][r["Counter_Name"]] = acc[k].get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
 names = sorted({c for v in acc.values() for c in v})
-with open("${GRAFT_REPO_ROOT:-/root/repo}/gpurun_out/sq_pmc/r02_pmc_sq_per_kernel_cfg3_100M.csv", "w") as w:
+with open(OUT + "/r02_pmc_sq_per_kernel_cfg3_100M.csv", "w") as w:
     w.write("# rocprofv3 --kernel-trace --pmc <4 SQ counters per pass>, bench.py --steps 1 --warmup 0, cfg3 100 M reads; sums over a kernel's dispatches in the step\n")
     w.write("kernel," + ",".join(names) + "\n")
     for k in sorted(acc):
         if any(x in k for x in ("k0_", "k1", "k2_", "k3_", "k4_", "k12", "k8_")):
             w.write(k + "," + ",".join(f"{acc[k].get(c, 0):.0f}" for c in names) + "\n")
-print(open("${GRAFT_REPO_ROOT:-/root/repo}/gpurun_out/sq_pmc/r02_pmc_sq_per_kernel_cfg3_100M.csv").read())
+print(open(OUT + "/r02_pmc_sq_per_kernel_cfg3_100M.csv").read())
 PY
