@@ -439,7 +439,8 @@ int bgp_pileup_snp(bgp_ctx* c, int min_cov, int min_wit) {
 int bgp_pileup_maq(bgp_ctx* c, float depcorr, float eta, uint32_t min_bq) {
     BGP_API_TRY
     if (!c || !(depcorr >= 0.f && depcorr <= 1.f) || !(eta >= 0.f && eta <= 1.f) || min_bq > 255) return BGP_EINVAL;
-    if (!c->it.active || c->batch) return BGP_ESTATE;
+    if (c->batch) { c->batch_maq = 1; c->batch_maq_depcorr = depcorr; c->batch_maq_eta = eta; c->batch_maq_min_bq = min_bq; return BGP_OK; }   // batched staging: the windows of every batch (reference_base is 'N' there: no use_md_tag across batches)
+    if (!c->it.active) return BGP_ESTATE;
     c->it.maq = 1; c->it.maq_depcorr = depcorr; c->it.maq_eta = eta; c->it.maq_min_bq = min_bq;
     return BGP_OK;
     BGP_API_CATCH(c)

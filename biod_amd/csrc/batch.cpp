@@ -48,7 +48,7 @@ void batch_release(bgp_ctx* c) {
     }
     delete b;
     c->batch = nullptr;
-    c->frame_tolerant_tail = false;
+    c->frame_tolerant_tail = false; c->batch_maq = 0;
 }
 
 // the host buffer that takes the pushes goes to a free device buffer (asynchronous copy); BGP_EAGAIN when both device
@@ -120,7 +120,7 @@ int bgp_batch_begin(bgp_ctx* c, uint64_t batch_bytes, int want_entries, uint32_t
     BGP_HIP(hipSetDevice(c->device));
     BGP_TRY(bgp_reset(c));
     Batch* b = new Batch();
-    c->batch = b;
+    c->batch = b; c->batch_maq = 0;
     b->batch_bytes = std::max<uint64_t>(batch_bytes ? batch_bytes : (256ull << 20), 1ull << 12);
     b->reserve = std::max<uint64_t>(b->batch_bytes / 8, 1ull << 16);         // room for the carry in front of a batch's new bytes (grown when a carry is longer)
     b->want_entries = want_entries; b->window = window_positions ? window_positions : 65536u;
@@ -176,6 +176,7 @@ int bgp_batch_next_window(bgp_ctx* c, bgp_columns* o) {
                 if (!b->run_open) { b->next_pos = lo; b->run_open = true; }
                 if (b->next_pos >= hi) { ++b->run; b->run_open = false; continue; }
                 const uint64_t a = b->next_pos, e = std::min(hi, a + b->window);
+                if (c->batch_maq) { c->it.maq = 1; c->it.maq_depcorr = c->batch_maq_depcorr; c->it.maq_eta = c->batch_maq_eta; c->it.maq_min_bq = c->batch_maq_min_bq; }
                 BGP_TRY(emit_window(c, b->run, a, e, b->want_entries, 0, 0, o));
                 if (b->want_entries && b->ord_base) {                    // stream-wide read ordinals
                     bgp_entry* en = c->h_entries.as<bgp_entry>();

@@ -172,6 +172,7 @@ struct bgp_ctx {
 
     // batched staging (batch.cpp): streams larger than HBM, a batch at a time with the overlapping reads carried over
     struct Batch* batch = nullptr;
+    int batch_maq = 0; float batch_maq_depcorr = 0.f, batch_maq_eta = 0.f; uint32_t batch_maq_min_bq = 0;   // bgp_pileup_maq between bgp_batch_begin and the windows: every batch's windows carry the calls
 
     // timing
     bool timing = false;

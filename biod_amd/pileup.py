@@ -183,8 +183,11 @@ class Context:
         yield from self._windows(None)
 
     # -- batched staging (streams larger than HBM): include/biodgpu.h, bgp_batch_*
-    def batch_begin(self, batch_bytes: int = 0, want_entries: bool = False, window_positions: int = 0):
+    def batch_begin(self, batch_bytes: int = 0, want_entries: bool = False, window_positions: int = 0, maq=None):
+        """maq=(depcorr, eta, minimum_base_quality): the MAQ model's call per position on every batch's windows (window.maq)."""
         L.check(L.lib().bgp_batch_begin(self._h, batch_bytes, int(want_entries), window_positions), self._h)
+        if maq is not None:
+            L.check(L.lib().bgp_pileup_maq(self._h, float(maq[0]), float(maq[1]), int(maq[2])), self._h)
 
     def batch_push(self, data) -> tuple:
         """Returns (bytes taken, status): status BGP_EAGAIN = hand out windows first, then push the rest."""
@@ -212,11 +215,14 @@ class Context:
             cols = L.as_array(cw.columns, cw.n_positions, L.COLUMN_DTYPE)
             eoff = L.as_array(cw.entry_off, cw.n_positions + 1, "<u8") if cw.entry_off else None
             ents = L.as_array(cw.entries, int(eoff[-1]), L.ENTRY_DTYPE) if eoff is not None else None
-            yield Window(cw.ref_id, cw.first_position, cols, eoff, ents, None)
+            w = Window(cw.ref_id, cw.first_position, cols, eoff, ents, None)
+            if cw.maq:
+                w.maq = L.as_array(cw.maq, cw.n_positions, L.MAQ_CALL_DTYPE)
+            yield w
 
-    def batched_windows(self, pieces, batch_bytes: int = 0, want_entries: bool = False, window_positions: int = 0):
+    def batched_windows(self, pieces, batch_bytes: int = 0, want_entries: bool = False, window_positions: int = 0, maq=None):
         """pileupColumns over a stream handed over piece by piece (any cut points): dense windows of final columns."""
-        self.batch_begin(batch_bytes, want_entries, window_positions)
+        self.batch_begin(batch_bytes, want_entries, window_positions, maq)
         for piece in pieces:
             mv = memoryview(piece)
             off = 0

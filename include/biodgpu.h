@@ -271,7 +271,8 @@ int bgp_pileup_chunk(bgp_ctx* ctx, uint64_t k, bgp_chunk_info* out);
 int bgp_pileup_snp(bgp_ctx* ctx, int minimum_coverage, int minimum_witnesses);
 
 /* MaqSnpCaller.makeCall (bio/std/hts/snpcallers/maq.d:443-486) for every position of the windows that follow (call after
- * bgp_pileup_begin; with use_md_tag the call knows its reference base, without it the base is 'N' as in :455-459):
+ * bgp_pileup_begin -- or after bgp_batch_begin, for the windows of every batch; with use_md_tag the call knows its
+ * reference base, without it -- and in batches -- the base is 'N' as in :455-459):
  * the reads of a column that count (current_base_quality >= minimum_base_quality, current_base != '-', :400-412), each
  * with quality min(base quality, mapping quality) and its strand; computeLikelihoods (:133-240) over them with the
  * error model ErrorModelCoefficients(depcorr, eta) (:73-118; MaqSnpCaller's defaults 0.17, 0.03, minimum base quality

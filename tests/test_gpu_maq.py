@@ -119,3 +119,24 @@ def test_maq_snp_caller_facade(ctx):
         if call is not None and call[3] and float(call[1]) > 6.0:
             want.append((int(ora.pos[k]), "ACGTN"[call[0] // 5] + "|" + "ACGTN"[call[0] % 5], "ACGTN"[call[2]]))
     assert got == want and len(got) > 0
+
+
+@pytest.mark.parametrize("name,batch", [("ex1_header.bam", 150_000), ("b7_295_chunk.bam", 40_000)])
+def test_maq_calls_across_batches(ctx, data_dir, name, batch):
+    """bgp_pileup_maq after bgp_batch_begin: the calls on a stream handed over in batches (reads carried over the seams)
+    are the calls of the one-shot pileup without MD tags, position by position."""
+    _, st = bamio.read_bam(os.path.join(data_dir, name))
+    ctx.reset(); ctx.push_inflated(st); ctx.flush(); ctx.pileup_run()
+    want = {}
+    for w in ctx.pileup_windows(L.BGP_PILEUP_COLUMNS, window_positions=500, maq=(0.17, 0.03, 13)):
+        for k in np.nonzero(w.columns["coverage"])[0]:
+            want[(w.ref_id, int(w.first_position) + int(k))] = w.maq[k].tobytes()
+    got = {}
+    pieces = [st[o:o + 7001] for o in range(0, len(st), 7001)]
+    for w in ctx.batched_windows(pieces, batch_bytes=batch, window_positions=333, maq=(0.17, 0.03, 13)):
+        assert w.maq is not None and len(w.maq) == len(w.columns)
+        for k in np.nonzero(w.columns["coverage"])[0]:
+            key = (w.ref_id, int(w.first_position) + int(k))
+            assert key not in got
+            got[key] = w.maq[k].tobytes()
+    assert len(want) > 500 and got == want
