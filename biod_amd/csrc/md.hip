@@ -670,43 +670,64 @@ __global__ __launch_bounds__(256) void k6_succ(const MdRow* rows, const uint32_t
     uint32_t out_n = node ? SX_END : SX_NONE, out_f = 0;
     uint64_t j = P + 1;
     int budget = LANE_CAP;
-    for (; !done && j < R.endrec; ++j) {
-        if (--budget < 0) { deferred = true; done = true; break; }
-        if (!found && (j & 63) == 0) {
+    // One loop for the wave, the cases of a row as predicates: written as a per-lane loop with a branch per case the kernel
+    // issued more scalar instructions (exec-mask bookkeeping at every `continue` / `break`: ~96 a row) than vector ones,
+    // and the scalar pipe -- one issue per SIMD every four cycles -- was what it waited for (SQ counters: 9.6 k SALU against
+    // 4.3 k VALU instructions a wave, 52 % of the wave cycles waiting for an issue slot).
+    bool run = !done;                                                        // this lane is still walking rows
+    while (__ballot(run && j < R.endrec)) {
+        bool act = run && j < R.endrec;
+        budget -= act ? 1 : 0;
+        if (act && budget < 0) { deferred = true; done = true; run = false; act = false; }
+        if (__ballot(act && !found && (j & 63) == 0)) {
             // nothing a row must be looked at for -- a candidate, a position group behind uncovered ground, an end beyond
             // the winner's -- exists in a block of 64 rows none of which ends beyond this read (a read with a 5 kb N skip
             // would otherwise walk a thousand rows, and hold its 63 neighbours for as long)
-            while (j + 64 <= R.endrec && bmax[j >> 6] <= CE) j += 64;
-            if (j >= R.endrec) break;
+            if (act && !found && (j & 63) == 0) {
+                while (j + 64 <= R.endrec && bmax[j >> 6] <= CE) j += 64;
+                if (j >= R.endrec) { run = false; act = false; }
+            }
         }
-        const MdRow r = row_at(j);
-        if (!(r.lf & MD_COV)) continue;
+        MdRow r{0, 0, 0, 0};
+        {
+            const uint64_t d = j - base;
+            const bool in_lds = d < (uint64_t)STAGE;
+            if (act && in_lds) r = s_rows[d];
+            if (__ballot(act && !in_lds)) { if (act && !in_lds) r = rows[j]; }
+        }
+        const bool cov = act && (r.lf & MD_COV);
         const bool hz = r.mb < r.pos;
         const bool isg = skip_zero && (r.lf & MD_GST) && hz;
         const bool cand = (r.pos <= CE || hz) && r.end > CE;
-        const bool gap_here = isg && (!found || r.pos <= F || r.mb <= F);     // GAP: before any candidate, inside the window, or the window's successor group uncovered by F
-        if (gap_here) {
-            // initNewReference on this position group: first arg-max of end_position (every read of it passes add())
-            uint32_t g = (uint32_t)j, ge = r.end; MdRow gr = r;
-            for (uint64_t k = j + 1; k < R.endrec; ++k) {
-                if (--budget < 0) { deferred = true; break; }
-                const MdRow q = row_at(k);
-                if (!(q.lf & MD_COV)) continue;
-                if (q.pos != r.pos) break;
-                if (q.end > ge) { g = (uint32_t)k; ge = q.end; gr = q; }
+        const bool gap_here = cov && isg && (!found || r.pos <= F || r.mb <= F);   // GAP: before any candidate, inside the window, or the window's successor group uncovered by F
+        if (__ballot(gap_here)) {
+            if (gap_here) {
+                // initNewReference on this position group: first arg-max of end_position (every read of it passes add())
+                uint32_t g = (uint32_t)j, ge = r.end; MdRow gr = r;
+                for (uint64_t k = j + 1; k < R.endrec; ++k) {
+                    if (--budget < 0) { deferred = true; break; }
+                    const MdRow q = row_at(k);
+                    if (!(q.lf & MD_COV)) continue;
+                    if (q.pos != r.pos) break;
+                    if (q.end > ge) { g = (uint32_t)k; ge = q.end; gr = q; }
+                }
+                out_n = g; out_f = r.pos;
+                flag |= arrival_irregular(gr, r.pos) || gr.pos != r.pos;
+                done = true; run = false;
             }
-            out_n = g; out_f = r.pos;
-            flag |= arrival_irregular(gr, r.pos) || gr.pos != r.pos;
-            done = true;
-            break;
         }
-        if (!found) {
-            if (!cand) { allmax = max(allmax, r.end); continue; }
-            found = true; F = max(A, r.pos);
+        const bool row = cov && !gap_here;                                    // a covering row that is not a gap's
+        const bool first = row && !found && cand;                              // the first candidate fixes the fetch column
+        if (row && !found && !cand) allmax = max(allmax, r.end);
+        if (first) { found = true; F = max(A, r.pos); }
+        const bool inwin = row && found;
+        const bool beyond = inwin && r.pos > F;                                 // first read beyond the fetch column: the walk ends ON it (j stays)
+        if (beyond) run = false;
+        if (inwin && !beyond) {
+            allmax = max(allmax, r.end);
+            if (cand && r.end > best_end) { best = (uint32_t)j; best_end = r.end; bestrow = r; }
         }
-        if (r.pos > F) break;                                               // first read beyond the fetch column
-        allmax = max(allmax, r.end);
-        if (cand && r.end > best_end) { best = (uint32_t)j; best_end = r.end; bestrow = r; }
+        if (act && run) ++j;
     }
     if (!done && found && (j < R.endrec || F < R.run_end)) {                // FETCH at F (pileup.d:627-652); at the run's end only if it comes before the end of coverage
         out_n = best; out_f = F;

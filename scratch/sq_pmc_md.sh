@@ -1,0 +1,33 @@
+#!/bin/bash
+# SQ counters + kernel stats of the MD path (cfg3 shard)
+R=${GRAFT_REPO_ROOT:-/root/repo}
+cd /tmp && export TMPDIR=/tmp
+OUT=$R/gpurun_out/sqmd; rm -rf $OUT; mkdir -p $OUT
+N=${1:-50000000}
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python $R/scratch/md_scale.py cfg3 $N > $OUT/stats.log 2>&1
+for set in "SQ_WAVES SQ_INSTS_SALU SQ_INSTS_VALU SQ_INSTS_LDS" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS"; do
+  tag=$(echo $set | tr ' ' '_' | cut -c1-40)
+  timeout 400 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/$tag -- python $R/scratch/md_scale.py cfg3 $N > $OUT/$tag.log 2>&1
+done
+for C in FETCH_SIZE WRITE_SIZE; do
+  timeout 400 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/$C -- python $R/scratch/md_scale.py cfg3 $N > $OUT/$C.log 2>&1
+done
+python - <<'PY'
+import csv, glob, collections, re, os
+OUT = os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "gpurun_out", "sqmd")
+f = glob.glob(OUT + "/stats/**/*kernel_stats.csv", recursive=True)
+for r in list(csv.DictReader(open(f[0])))[:14]:
+    n = re.sub(r"\(.*", "", r["Name"].replace("(anonymous namespace)::", "").replace("void ", ""))[:40]
+    print(f"{n:42s} calls {r['Calls']:>4s} avg {float(r['AverageNs'])/1e6:9.3f} ms")
+acc = collections.defaultdict(dict)
+for f in sorted(glob.glob(OUT + "/**/*counter_collection.csv", recursive=True)):
+    for r in csv.DictReader(open(f)):
+        k = re.sub(r"\(.*", "", r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "")).strip().replace(",", ";")
+        acc[k][r["Counter_Name"]] = acc[k].get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+names = sorted({c for v in acc.values() for c in v})
+print("kernel," + ",".join(names))
+for k in sorted(acc):
+    if k.startswith("k6_"):
+        print(k + "," + ",".join(f"{acc[k].get(c, 0):.0f}" for c in names))
+PY
+rm -rf $OUT/stats $OUT/SQ_* $OUT/FETCH_SIZE $OUT/WRITE_SIZE
