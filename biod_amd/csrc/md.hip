@@ -46,7 +46,6 @@ __device__ __forceinline__ uint8_t base16_norm(uint8_t c) {
     }
 }
 
-__device__ __forceinline__ uint32_t to_uint_(const uint8_t* p, uint32_t n) { uint64_t v = 0; for (uint32_t i = 0; i < n; ++i) v = v * 10 + (uint64_t)(p[i] - '0'); return (uint32_t)v; }
 
 __device__ bool md_cache_front(MdRes& r) {                      // md/parse.d:85-109
     if (r.b >= r.e) return false;
@@ -77,15 +76,19 @@ __device__ bool md_cache_back(MdRes& r) {                       // md/parse.d:11
     if (r.b >= r.e) return false;
     const uint8_t* m = r.md;
     MdOp o{0, 0, 0, 0, 0};
-    if (is_digit_(m[r.e - 1])) {
-        uint32_t len = 0;
-        while (r.e - len > r.b && is_digit_(m[r.e - 1 - len])) ++len;
-        o.type = 0; o.match = to_uint_(m + r.e - len, len); r.e -= len;
-    } else if (r.e - r.b == 1 || is_digit_(m[r.e - 2])) {
-        o.type = 1; o.ch = base16_norm(m[r.e - 1]); r.e -= 1;
+    // the last eight chars in front of `e` in one load (the value of a tag is never the first eight bytes of a record, so
+    // m + e - 8 is inside the stream): bk(k) is the char k places before the end
+    uint64_t w; __builtin_memcpy(&w, m + r.e - 8, 8);
+    auto bk = [&](uint32_t k) -> uint8_t { return k < 8 ? (uint8_t)(w >> (8 * (7 - k))) : m[r.e - 1 - k]; };
+    if (is_digit_(bk(0))) {
+        uint32_t len = 0; uint64_t v = 0, p10 = 1;
+        while (r.e - len > r.b && is_digit_(bk(len))) { v += p10 * (uint64_t)(bk(len) - '0'); p10 *= 10; ++len; }
+        o.type = 0; o.match = (uint32_t)v; r.e -= len;
+    } else if (r.e - r.b == 1 || is_digit_(bk(1))) {
+        o.type = 1; o.ch = base16_norm(bk(0)); r.e -= 1;
     } else {
         uint32_t len = 0;
-        while (r.e - len > r.b && m[r.e - 1 - len] != '^') ++len;
+        while (r.e - len > r.b && bk(len) != '^') ++len;
         o.type = 2; o.del_off = r.e - len; o.del_len = len;
         r.e = (r.e - len > r.b) ? r.e - len - 1 : r.b;
     }
@@ -112,12 +115,25 @@ __device__ void mdf_init(MdRes& r, const uint8_t* md, uint32_t n) {   // md/pars
 }
 __device__ void mdf_pop_front(MdRes& r) { do { md_pop_front(r); } while (!md_empty(r) && md_zero(r.front)); }
 
+// length of the NUL-terminated string at t[0 .. lim) (lim if there is no NUL): eight bytes a load while eight are there --
+// a byte a load is a dependent round trip per character of every MD tag
+__device__ __forceinline__ uint64_t strnlen8(const uint8_t* t, uint64_t lim) {
+    uint64_t n = 0;
+    while (n + 8 <= lim) {
+        uint64_t w; __builtin_memcpy(&w, t + n, 8);
+        const uint64_t z = (w - 0x0101010101010101ull) & ~w & 0x8080808080808080ull;      // the lowest set bit marks the first zero byte
+        if (z) return n + (uint64_t)(__ffsll((long long)z) - 1) / 8;
+        n += 8;
+    }
+    while (n < lim && t[n] != 0) ++n;
+    return n;
+}
+
 // ---------------------------------------------------------------------------------------------- tag lookup
 // BamRead.opIndex("MD") (read.d:1070-1087) with skipValue (read.d:1219-1230, tagvalue.d:78-119).
 // Returns 1 found (a Z/H string: *val, *len), 0 absent or not a string, -1 malformed aux data.
-__device__ int find_md(const uint8_t* s, const bgp_record& r, const uint8_t** val, uint32_t* len) {
-    const uint32_t block = ld_u32(s + r.rec_off);
-    const uint64_t end = r.rec_off + 4 + block;
+__device__ int find_md(const uint8_t* s, const bgp_record& r, const uint8_t** val, uint32_t* len, uint64_t rec_end = 0) {     // rec_end: where the record ends if the caller knows (the next record's offset in an uncompacted table), else 0: block_size is read
+    const uint64_t end = rec_end ? rec_end : r.rec_off + 4 + ld_u32(s + r.rec_off);
     const uint32_t l_name = r.bin_mq_nl & 0xFFu, n_cig = r.flag_nc & 0xFFFFu;
     const uint64_t tags = r.rec_off + 36 + l_name + 4ull * n_cig + (uint64_t)((r.l_seq + 1) / 2) + (uint64_t)r.l_seq;
     if (tags > end) return -1;
@@ -132,12 +148,11 @@ __device__ int find_md(const uint8_t* s, const bgp_record& r, const uint8_t** va
         const uint8_t ty = t[off++];
         if (match) {
             if (ty != 'Z' && ty != 'H') return 0;
-            uint32_t n = 0;
-            while (off + n < tl && t[off + n] != 0) ++n;
+            const uint32_t n = (uint32_t)strnlen8(t + off, tl - off);
             *val = t + off; *len = n;
             return 1;
         }
-        if (ty == 'Z' || ty == 'H') { while (off < tl && t[off] != 0) ++off; if (off >= tl) return -1; ++off; }
+        if (ty == 'Z' || ty == 'H') { off += strnlen8(t + off, tl - off); if (off >= tl) return -1; ++off; }
         else if (ty == 'B') {
             if (off + 5 > tl) return -1;
             const uint8_t et = t[off];
@@ -298,15 +313,21 @@ __device__ uint32_t dna_walk(const uint8_t* s, const bgp_record& r, uint32_t fro
 // "is there another M/=/X base", so the answer is a function of the MD operations and of the number of such
 // bases in the CIGAR (a match run takes min(run, bases left) and stalls if it wanted more; a mismatch is
 // yielded and then stalls on an empty query; an empty deletion stalls).
-__device__ uint32_t dna_length(const uint8_t* s, const bgp_record& r, bool* bad, bool* err) {
+__device__ uint32_t dna_length(const uint8_t* s, const bgp_record& r, bool* bad, bool* err, const uint4* c4 = nullptr, uint64_t rec_end = 0) {      // c4: the record's first four CIGAR ops (K1's side array) or null
     *bad = false; *err = false;
     const uint8_t* md = nullptr; uint32_t mdn = 0;
-    const int f = find_md(s, r, &md, &mdn);
+    const int f = find_md(s, r, &md, &mdn, rec_end);
     if (f < 0) { *err = true; return 0; }
     if (f == 0) mdn = 0;
     const uint32_t l_name = r.bin_mq_nl & 0xFFu, n_cig = r.flag_nc & 0xFFFFu;
     const uint8_t* cg = s + r.rec_off + 36 + l_name;
     uint64_t qleft = 0;
+    if (c4 && n_cig <= 4) {               // one coalesced 16-byte load instead of a dependent 4-byte read of the stream per op
+        const uint4 v = *c4;
+        const uint32_t ops[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k) if (k < n_cig && cig_qc(ops[k]) && cig_rc(ops[k])) qleft += ops[k] >> 4;
+    } else
     for (uint32_t k = 0; k < n_cig; ++k) { const uint32_t raw = ld_u32(cg + 4ull * k); if (cig_qc(raw) && cig_rc(raw)) qleft += raw >> 4; }
     MdRes m;
     mdf_init(m, md, mdn);
@@ -332,7 +353,7 @@ __device__ uint32_t dna_length(const uint8_t* s, const bgp_record& r, bool* bad,
 struct alignas(16) MdRow { uint32_t pos, end, lf, mb; };      // one dwordx4 / ds_read_b128 per row
 constexpr uint32_t MD_BAD = 1u << 31, MD_ERR = 1u << 30, MD_COV = 1u << 29, MD_GST = 1u << 28, MD_LMASK = (1u << 28) - 1;
 
-__global__ __launch_bounds__(256) void k6_prep(const uint8_t* s, const bgp_record* rec, const uint64_t* pmax_end, const uint64_t* pmax_pos, uint64_t n, MdRow* rows, uint32_t* bmax) {
+__global__ __launch_bounds__(256) void k6_prep(const uint8_t* s, const bgp_record* rec, const uint4* cig4, const uint64_t* pmax_end, const uint64_t* pmax_pos, uint64_t n, MdRow* rows, uint32_t* bmax) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     bgp_record r{};
     if (i < n) r = rec[i];
@@ -345,19 +366,23 @@ __global__ __launch_bounds__(256) void k6_prep(const uint8_t* s, const bgp_recor
     MdRow o{(uint32_t)r.pos, (uint32_t)r.end_pos, 0u, 0u};
     if (r.end_pos != r.pos) {
         bool bad, err;
-        uint32_t L = dna_length(s, r, &bad, &err);
+        // (requested before the MD tag is walked: the common case -- this read is alone at its position -- needs nothing else)
+        const uint64_t pm_prev = i ? pmax_pos[i - 1] : 0, pe_prev = i ? pmax_end[i - 1] : 0;
+        uint32_t L = dna_length(s, r, &bad, &err, cig4 ? cig4 + i : nullptr, cig4 && i + 1 < n ? (uint64_t)rec[i + 1].rec_off : 0);   // (cig4: the table is K1's own, record i ends where i + 1 begins -- its header line is not touched at all)
         if (L > MD_LMASK) L = MD_LMASK;
         // first record of this read's position group: the prefix maximum of the position key reaches the
         // read's own key exactly there (records are sorted; K3 has already rejected unsorted input).
         const uint64_t key = (ref_key(r.ref_id) << 32) | (uint32_t)r.pos;
         uint64_t hi = i, lo = 0, step = 1;
+        if (i && pm_prev < key) lo = i;                                      // the record before belongs to an earlier group: hi == i
+        else
         while (hi > 0) {
             const uint64_t t = hi > step ? hi - step : 0;
             if (pmax_pos[t] >= key) { hi = t; step <<= 1; } else { lo = t + 1; break; }
         }
         while (lo < hi) { const uint64_t m = (lo + hi) >> 1; if (pmax_pos[m] >= key) hi = m; else lo = m + 1; }
         uint32_t mb = 0;
-        if (hi > 0) { const uint64_t e = pmax_end[hi - 1]; if ((e >> 32) == (key >> 32)) mb = (uint32_t)e; }
+        if (hi > 0) { const uint64_t e = hi == i ? pe_prev : pmax_end[hi - 1]; if ((e >> 32) == (key >> 32)) mb = (uint32_t)e; }
         o.lf = L | MD_COV | (hi == i ? MD_GST : 0u) | (bad ? MD_BAD : 0u) | (err ? MD_ERR : 0u);
         o.mb = mb;
     }
@@ -948,7 +973,7 @@ static int k6_rows(bgp_ctx* c) {
     BGP_TRY(c->d_md_bmax.reserve((n / 64 + 2) * 4));
     if (n) {
         TimedRegion t(c, "k6_prep", n * (32 + sizeof(MdRow)));
-        hipLaunchKernelGGL(k6_prep, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->d_stream, c->d_rec.as<bgp_record>(),
+        hipLaunchKernelGGL(k6_prep, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->d_stream, c->d_rec.as<bgp_record>(), c->cig4_ok ? c->d_cig4.as<uint4>() : nullptr,
                            c->d_pmax_end.as<uint64_t>(), c->d_pmax_pos.as<uint64_t>(), n, c->d_md_row.as<MdRow>(), c->d_md_bmax.as<uint32_t>());
         BGP_HIP(hipGetLastError());
     }
