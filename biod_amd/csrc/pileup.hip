@@ -1683,6 +1683,62 @@ __device__ __forceinline__ bgp_entry entry_of(const uint8_t* s, const bgp_record
     return e;
 }
 
+// One wave per 64 consecutive COLUMNS, lane = column: the candidate rows of the block are scanned once (64 rows a step,
+// coalesced), every row that touches the block is handed to all lanes in file order, and a lane whose column the read
+// covers appends the read's entry to its own column -- a counter a lane, no ranks, no ballots per entry.  (With a wave per
+// column every column scanned the whole candidate range for itself: ~1000 rows on cfg3, where a read with an N skip keeps
+// every later read a candidate -- 32 KB of rows for ~50 entries, 200 GB/s of entries.)
+#ifndef BGP_K5R
+#define BGP_K5R 8
+#endif
+constexpr int K5R = BGP_K5R;            // entries of a column that leave together (a power of two)
+static_assert(sizeof(bgp_entry) == 16, "an entry is one 16-byte store");
+__global__ __launch_bounds__(256) void k5_fill_blk(K5Args a) {
+    const uint64_t np = a.pos_end - a.pos_begin;
+    const uint64_t col0 = ((uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;
+    const int lane = threadIdx.x & 63;
+    if (col0 >= np) return;
+    const uint64_t p0 = a.pos_begin + col0, p1 = min(p0 + 64, a.pos_end);           // the block's positions [p0, p1)
+    const uint64_t p = p0 + lane;
+    const bool valid = p < p1;
+    const uint64_t rk = ref_key(a.run.ref_id) << 32;
+    const uint64_t i_lo = lower_bound_gt(a.pmax_end, a.run.first_record, a.run.end_record, rk | (uint32_t)p0);          // first record whose running maximum of end_position exceeds p0
+    const uint64_t i_hi = lower_bound_gt(a.pmax_pos, a.run.first_record, a.run.end_record, rk | (uint32_t)(p1 - 1));    // first record that starts behind the block
+    uint64_t w = valid ? a.col_off[col0 + lane] : 0;
+    // A column's entries leave K5R at a time, from a ring in LDS (slot s of lane l at [s][l]: conflict free): one 16-byte
+    // store per entry and lane lands in 64 different lines whose other seven entries arrive microseconds later, long after
+    // the L2 has given the line up -- the partial-sector writes k0_chase had.
+    __shared__ uint4 s_ring[4][K5R][64];
+    uint4 (*ring)[64] = s_ring[threadIdx.x >> 6];
+    uint32_t cnt = 0;
+    for (uint64_t base = i_lo; base < i_hi; base += 64) {
+        const uint64_t i = base + lane;
+        bgp_record r{};
+        bool hit = false;
+        if (i < i_hi) { r = a.rec[i]; hit = r.end_pos != r.pos && (uint64_t)(uint32_t)r.pos < p1 && (uint64_t)(uint32_t)r.end_pos > p0; }
+        for (unsigned long long m = __ballot(hit); m; m &= m - 1) {
+            const int src = __ffsll((long long)m) - 1;
+            bgp_record q;                                                           // the read, the same in every lane (scalar registers)
+            q.ref_id = __builtin_amdgcn_readlane(r.ref_id, src); q.pos = __builtin_amdgcn_readlane(r.pos, src); q.end_pos = __builtin_amdgcn_readlane(r.end_pos, src);
+            q.bin_mq_nl = (uint32_t)__builtin_amdgcn_readlane((int)r.bin_mq_nl, src); q.flag_nc = (uint32_t)__builtin_amdgcn_readlane((int)r.flag_nc, src);
+            q.l_seq = __builtin_amdgcn_readlane(r.l_seq, src);
+            q.rec_off = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(r.rec_off >> 32), src) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)r.rec_off, src);
+            if (valid && (uint64_t)(uint32_t)q.pos <= p && (uint64_t)(uint32_t)q.end_pos > p) {
+                const bgp_entry e = entry_of(a.s, q, (uint32_t)(p - (uint32_t)q.pos), (uint32_t)(base + (uint64_t)src), a);
+                uint4 v; __builtin_memcpy(&v, &e, 16);
+                ring[cnt & (K5R - 1)][lane] = v;
+                ++cnt;
+                if ((cnt & (K5R - 1)) == 0) {
+#pragma unroll
+                    for (int k = 0; k < K5R; ++k) { const uint4 x = ring[k][lane]; __builtin_memcpy(a.entries + w + k, &x, 16); }
+                    w += K5R;
+                }
+            }
+        }
+    }
+    for (uint32_t k = 0; k < (cnt & (K5R - 1)); ++k) { const uint4 x = ring[k][lane]; __builtin_memcpy(a.entries + w + k, &x, 16); }
+}
+
 // one wave per column: stream-compact the overlapping reads in file order
 __global__ __launch_bounds__(256) void k5_fill(K5Args a) {
     const uint64_t col = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -2004,7 +2060,9 @@ int k5_entries(bgp_ctx* c, uint32_t run_idx, uint64_t pos_begin, uint64_t pos_en
     a.entries = c->d_entries.as<bgp_entry>();
     {
         TimedRegion t(c, "k5_fill", total * 16);
-        hipLaunchKernelGGL(k5_fill, dim3((unsigned)((np + 3) / 4)), dim3(256), 0, c->stream, a);
+        static const bool per_column = getenv("BGP_K5_PER_COLUMN") && atoi(getenv("BGP_K5_PER_COLUMN")) != 0;      // (the first version: a wave per column)
+        if (per_column) hipLaunchKernelGGL(k5_fill, dim3((unsigned)((np + 3) / 4)), dim3(256), 0, c->stream, a);
+        else hipLaunchKernelGGL(k5_fill_blk, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, c->stream, a);
     }
     BGP_HIP(hipGetLastError());
     *n_entries = total;
