@@ -55,13 +55,13 @@ __device__ __forceinline__ uint32_t base5_code(uint32_t ch) {           // Base5
     switch (ch | 0x20u) { case 'a': return 0; case 'c': return 1; case 'g': return 2; case 't': return 3; default: return 4; }
 }
 
-__global__ __launch_bounds__(MAQ_T) void k8_maq(MaqArgs a) {
-    __shared__ uint8_t s_q[4][256], s_c[4][256], s_sq[4][256], s_sc[4][256];
-    __shared__ double s_fs[4][16], s_bs[4][16];
-    __shared__ uint32_t s_w[4][32], s_cn[4][16];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const uint64_t p = (uint64_t)blockIdx.x * 4 + wv;
-    if (p >= a.np) return;
+struct MaqCoopLds { uint8_t q[256], c[256], sq[256], sc[256]; double fs[16], bs[16]; uint32_t w[32], cn[16]; };
+
+// One column by a whole wave (any depth): lanes pick and rank, lane 0 walks.  The first version of K8 ran every column
+// this way; k8_maq64 below keeps it for columns with more than 64 valid bases.
+__device__ void maq_column_coop(const MaqArgs& a, uint64_t p, int lane, MaqCoopLds& L) {
+    uint8_t* const s_q_ = L.q; uint8_t* const s_c_ = L.c; uint8_t* const s_sq_ = L.sq; uint8_t* const s_sc_ = L.sc;
+    double* const s_fs_ = L.fs; double* const s_bs_ = L.bs; uint32_t* const s_w_ = L.w; uint32_t* const s_cn_ = L.cn;
     const uint64_t e0 = a.entry_off[p], e1 = a.entry_off[p + 1];
     // ---- the column's valid bases, in file order (maq.d:400-412): base quality >= minimum, not '-'
     uint32_t n_valid = 0;
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(MAQ_T) void k8_maq(MaqArgs a) {
         }
         const unsigned long long m = __ballot(valid);
         const uint32_t idx = n_valid + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-        if (valid && idx < (uint32_t)MAQ_MAXB) { s_q[wv][idx] = (uint8_t)q; s_c[wv][idx] = (uint8_t)code; }
+        if (valid && idx < (uint32_t)MAQ_MAXB) { s_q_[idx] = (uint8_t)q; s_c_[idx] = (uint8_t)code; }
         n_valid += (uint32_t)__popcll(m);
     }
     const uint32_t ref5 = a.refbase ? base5_code(a.refbase[p]) : 4u;                                  // Base5(column.reference_base), :455-459 ('N' without reference bases)
@@ -90,37 +90,37 @@ __global__ __launch_bounds__(MAQ_T) void k8_maq(MaqArgs a) {
     const uint32_t n = min(n_valid, (uint32_t)MAQ_MAXB);
     // ---- stable rising sort by quality (:146): every element's rank counted directly
     for (uint32_t i = lane; i < n; i += 64) {
-        const uint32_t qi = s_q[wv][i];
+        const uint32_t qi = s_q_[i];
         uint32_t rank = 0;
-        for (uint32_t j = 0; j < n; ++j) { const uint32_t qj = s_q[wv][j]; rank += (qj < qi || (qj == qi && j < i)) ? 1u : 0u; }
-        s_sq[wv][rank] = (uint8_t)qi; s_sc[wv][rank] = s_c[wv][i];
+        for (uint32_t j = 0; j < n; ++j) { const uint32_t qj = s_q_[j]; rank += (qj < qi || (qj == qi && j < i)) ? 1u : 0u; }
+        s_sq_[rank] = (uint8_t)qi; s_sc_[rank] = s_c_[i];
     }
-    if (lane < 32) s_w[wv][lane] = 0;
-    if (lane < 16) { s_cn[wv][lane] = 0; s_fs[wv][lane] = 0.0; s_bs[wv][lane] = 0.0; }
+    if (lane < 32) s_w_[lane] = 0;
+    if (lane < 16) { s_cn_[lane] = 0; s_fs_[lane] = 0.0; s_bs_[lane] = 0.0; }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    if (lane != 0) return;
+    if (lane != 0) return;      // (the callers re-converge after the call)
     // ---- from the best base down (:153-166)
     for (int i = (int)n - 1; i >= 0; --i) {
-        uint32_t q = s_sq[wv][i];
+        uint32_t q = s_sq_[i];
         q = q < 4u ? 4u : q > 63u ? 63u : q;
-        const uint32_t bws = s_sc[wv][i], b = bws >> 1;
-        const double f = a.fk[s_w[wv][bws]];
-        s_fs[wv][b] += f;
-        s_bs[wv][b] += f * a.beta[(q << 16) | (n << 8) | s_cn[wv][b]];
-        s_cn[wv][b] += 1; s_w[wv][bws] += 1;
+        const uint32_t bws = s_sc_[i], b = bws >> 1;
+        const double f = a.fk[s_w_[bws]];
+        s_fs_[b] += f;
+        s_bs_[b] += f * a.beta[(q << 16) | (n << 8) | s_cn_[b]];
+        s_cn_[b] += 1; s_w_[bws] += 1;
     }
     // ---- the ten genotype scores (:170-228); Base codes of A, C, G, T are 1, 2, 4, 8; Base5 codes 0..3
     const double Cc = 10.0 / 2.30258509299404568401799145468436421;                                   // 10 / LN10
     float sc[4][4];                                                                                   // sc[j][i], j >= i: genotype code j * 5 + i
     for (int i = 0; i < 4; ++i) {
         float tmp1 = 0.f; int tmp2 = 0;
-        for (int k = 0; k < 4; ++k) if (k != i) { tmp1 = (float)((double)tmp1 + s_bs[wv][1 << k]); tmp2 += (int)s_cn[wv][1 << k]; }
+        for (int k = 0; k < 4; ++k) if (k != i) { tmp1 = (float)((double)tmp1 + s_bs_[1 << k]); tmp2 += (int)s_cn_[1 << k]; }
         sc[i][i] = tmp2 > 0 ? tmp1 : 0.f;
         for (int j = i + 1; j < 4; ++j) {
-            const uint32_t cij = s_cn[wv][1 << i] + s_cn[wv][1 << j];
+            const uint32_t cij = s_cn_[1 << i] + s_cn_[1 << j];
             tmp1 = 0.f; tmp2 = 0;
-            for (int k = 0; k < 4; ++k) if (k != i && k != j) { tmp1 = (float)((double)tmp1 + s_bs[wv][1 << k]); tmp2 += (int)s_cn[wv][1 << k]; }
-            const double lh = Cc * a.lhet[(cij << 8) | s_cn[wv][1 << j]];
+            for (int k = 0; k < 4; ++k) if (k != i && k != j) { tmp1 = (float)((double)tmp1 + s_bs_[1 << k]); tmp2 += (int)s_cn_[1 << k]; }
+            const double lh = Cc * a.lhet[(cij << 8) | s_cn_[1 << j]];
             sc[j][i] = tmp2 > 0 ? (float)((double)tmp1 - lh) : (float)(-lh);
         }
     }
@@ -139,6 +139,155 @@ __global__ __launch_bounds__(MAQ_T) void k8_maq(MaqArgs a) {
     o.flags = (uint8_t)(BGP_MAQ_CALLED | (g0 != (int)(ref5 * 5 + ref5) ? BGP_MAQ_VARIANT : 0) | (n_valid > (uint32_t)MAQ_MAXB ? BGP_MAQ_SUBSAMPLED : 0));   // is_variant: call.d:85-87
     o.n_bases = (uint8_t)n;
     a.out[p] = o;
+}
+
+// K8 as it runs: one wave per 64 consecutive columns.  Phase A takes the block's columns one after the other with
+// lane = entry: the valid bases are picked (one coalesced pass: a column with more than 64 entries is left to
+// maq_column_coop), ranked by (quality, arrival) with one ballot per bit of the quality -- a lane keeps the set of lanes
+// whose key agrees with its own so far and counts those that fell below -- and stored in rank order.  Phase B is
+// lane = COLUMN: every lane walks its own column's bases from the best one down, the per-base state (four sums, four
+// counts, eight strand counters: only A, C, G, T enter a genotype score; the other codes' counters never meet theirs) in
+// registers.  The sums are the same operations in the same order as before; what changed is that 64 columns share the
+// serial walk -- with a wave per column 63 lanes waited for one, a table load at a time (93 ms for 5e7 columns).
+__global__ __launch_bounds__(MAQ_T, 4) void k8_maq64(MaqArgs a) {      // (four workgroups a CU: 128 registers, under 40 KB of LDS)
+    __shared__ uint16_t s_srt[4][64][65];                 // [rank][column] (+1: the columns of a rank and the ranks of a column both fall into different banks); quality | code << 8
+    __shared__ MaqCoopLds s_coop[4];
+    __shared__ uint16_t s_tmp[4][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint64_t col0 = ((uint64_t)blockIdx.x * 4 + wv) * 64;
+    if (col0 >= a.np) return;
+    uint16_t (*srt)[65] = s_srt[wv];
+    uint32_t n = 0;                                        // valid bases of this lane's column
+    bool deep = false;
+    const int n_cols = (int)min<uint64_t>(64, a.np - col0);
+    // the block's 65 offsets at once (lane l holds column l's)
+    const uint64_t offl = a.entry_off[col0 + (uint64_t)min(lane, n_cols)];
+    auto off_of = [&](int c) -> uint64_t {
+        return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(offl >> 32), c) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)offl, c);
+    };
+    const uint64_t off_last = a.entry_off[col0 + (uint64_t)n_cols];
+    for (int c = 0; c < n_cols; ++c) {
+        const uint64_t e0 = off_of(c), e1 = c + 1 >= n_cols ? off_last : off_of(c + 1);
+        if (e1 - e0 > 128) { if (lane == c) deep = true; continue; }
+        // the entries that count (maq.d:400-412), compacted in file order: up to 128 entries a column ('-' entries of N skips
+        // and low qualities are a good part of a column), of which up to 64 may count
+        uint32_t nv = 0;
+        for (int h = 0; h < 2; ++h) {
+            if (h == 1 && e1 - e0 <= 64) break;
+            const uint64_t i = e0 + 64u * (uint32_t)h + lane;
+            bool ok = false; uint32_t el = 0;
+            if (i < e1) {
+                const bgp_entry en = a.entries[i];
+                ok = en.qual >= a.min_bq && en.base != '-';
+                if (ok) {
+                    uint2 rw; __builtin_memcpy(&rw, reinterpret_cast<const uint8_t*>(a.rec + en.read_ordinal) + 12, 8);      // bin_mq_nl, flag_nc
+                    const uint32_t qq = min((uint32_t)en.qual, (rw.x >> 8) & 0xFFu);                     // min(current_base_quality, mapping_quality), :406
+                    el = qq | ((base16_code(en.base) * 2u + ((rw.y >> 20) & 1u)) << 8);                // BaseWithStrand(base, is_reverse_strand), :32-34 (flag 0x10)
+                }
+            }
+            const unsigned long long mk = __ballot(ok);
+            const uint32_t idx = nv + __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
+            if (ok && idx < 64u) s_tmp[wv][idx] = (uint16_t)el;
+            nv += (uint32_t)__popcll(mk);
+        }
+        if (nv > 64u) { if (lane == c) deep = true; continue; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        const bool valid = (uint32_t)lane < nv;
+        const uint32_t el = valid ? s_tmp[wv][lane] : 0u;
+        const uint32_t q = el & 0xFFu, code = el >> 8;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        const unsigned long long m = __ballot(valid);
+        if (lane == c) n = (uint32_t)__popcll(m);
+        if (!m) continue;
+        // stable rising rank by quality (:146): most significant bit first
+        unsigned long long same = m; uint32_t less = 0;
+        const int top = __ballot(valid && q >= 64u) ? 7 : 5;
+        for (int b = top; b >= 0; --b) {
+            const unsigned long long B = __ballot(valid && ((q >> b) & 1u));
+            if ((q >> b) & 1u) { less += (uint32_t)__popcll(same & ~B); same &= B; } else same &= ~B;
+        }
+        const uint32_t rank = less + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+        if (valid) srt[rank][c] = (uint16_t)(q | (code << 8));
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    const uint64_t p = col0 + lane;
+    const bool mine = lane < n_cols && !deep;
+    // ---- from the best base down (:153-166), a column a lane
+    double bs[4] = {0.0, 0.0, 0.0, 0.0}; uint32_t cn[4] = {0, 0, 0, 0}, w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t nmax = mine ? n : 0u;
+    for (int d = 32; d >= 1; d >>= 1) nmax = max(nmax, (uint32_t)__shfl_xor((int)nmax, d, 64));
+    for (uint32_t t = 0; t < nmax; ++t) {
+        if (!mine || t >= n) continue;
+        const uint32_t e = srt[n - 1 - t][lane];
+        uint32_t q = e & 0xFFu;
+        q = q < 4u ? 4u : q > 63u ? 63u : q;
+        const uint32_t bws = e >> 8, b = bws >> 1, strand = bws & 1u;
+        if (b != 1u && b != 2u && b != 4u && b != 8u) continue;                                        // (an ambiguity code: its sums and counters are its own and enter no score)
+        const int bi = b == 1u ? 0 : b == 2u ? 1 : b == 4u ? 2 : 3;
+        const int wi = bi * 2 + (int)strand;
+        uint32_t wcur = 0, ccur = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) wcur = wi == k ? w[k] : wcur;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) ccur = bi == k ? cn[k] : ccur;
+        const double f = a.fk[wcur];
+        const double add = f * a.beta[(q << 16) | (n << 8) | ccur];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { if (bi == k) { bs[k] += add; cn[k] += 1; } }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) w[k] += wi == k ? 1u : 0u;
+    }
+    if (mine) {
+        const uint32_t ref5 = a.refbase ? base5_code(a.refbase[p]) : 4u;                              // Base5(column.reference_base), :455-459 ('N' without reference bases)
+        bgp_maq_call o;
+        if (n == 0) { o.quality = 0.f; o.genotype = 0xFF; o.reference_base5 = (uint8_t)ref5; o.flags = 0; o.n_bases = 0; }   // no genotype likelihoods: makeCall returns null, :436-439,451
+        else {
+            // ---- the ten genotype scores (:170-228)
+            const double Cc = 10.0 / 2.30258509299404568401799145468436421;                           // 10 / LN10
+            float sc[4][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float tmp1 = 0.f; int tmp2 = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) if (k != i) { tmp1 = (float)((double)tmp1 + bs[k]); tmp2 += (int)cn[k]; }
+                sc[i][i] = tmp2 > 0 ? tmp1 : 0.f;
+#pragma unroll
+                for (int j = i + 1; j < 4; ++j) {
+                    const uint32_t cij = cn[i] + cn[j];
+                    tmp1 = 0.f; tmp2 = 0;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) if (k != i && k != j) { tmp1 = (float)((double)tmp1 + bs[k]); tmp2 += (int)cn[k]; }
+                    const double lh = Cc * a.lhet[(cij << 8) | cn[j]];
+                    sc[j][i] = tmp2 > 0 ? (float)((double)tmp1 - lh) : (float)(-lh);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int i = 0; i <= j; ++i) if (sc[j][i] < 0.f) sc[j][i] = 0.f;                       // :221-226
+            float s0 = 0.f, s1 = 0.f; int g0 = -1, g1 = -1;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int i = 0; i <= j; ++i) {                                                        // rising code j * 5 + i (:251-268)
+                    const float v = sc[j][i]; const int code = j * 5 + i;
+                    if (g0 < 0 || v < s0) { s1 = s0; g1 = g0; s0 = v; g0 = code; }
+                    else if (g1 < 0 || v < s1) { s1 = v; g1 = code; }
+                }
+            o.quality = s1 - s0;                                                                      // gts[1].score - gts[0].score, :470
+            o.genotype = (uint8_t)g0;
+            o.reference_base5 = (uint8_t)ref5;
+            o.flags = (uint8_t)(BGP_MAQ_CALLED | (g0 != (int)(ref5 * 5 + ref5) ? BGP_MAQ_VARIANT : 0));    // is_variant: call.d:85-87
+            o.n_bases = (uint8_t)n;
+        }
+        a.out[p] = o;
+    }
+    // ---- the deep columns of the block, one after the other, the whole wave on each
+    for (unsigned long long dm = __ballot(deep); dm; dm &= dm - 1) {
+        const int c = __ffsll((long long)dm) - 1;
+        maq_column_coop(a, col0 + (uint64_t)c, lane, s_coop[wv]);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
 }
 
 }  // namespace
@@ -194,7 +343,7 @@ int k8_maq_calls(bgp_ctx* c, uint64_t col_index, uint64_t np, int use_md) {
     a.fk = d; a.lhet = d + 256; a.beta = d + 256 + 65536; a.min_bq = c->it.maq_min_bq;
     a.out = c->d_maq.as<bgp_maq_call>();
     TimedRegion t(c, "k8_maq", np * sizeof(bgp_maq_call));
-    hipLaunchKernelGGL(k8_maq, dim3((unsigned)((np + 3) / 4)), dim3(MAQ_T), 0, c->stream, a);
+    hipLaunchKernelGGL(k8_maq64, dim3((unsigned)((np + 255) / 256)), dim3(MAQ_T), 0, c->stream, a);
     BGP_HIP(hipGetLastError());
     return BGP_OK;
 }
