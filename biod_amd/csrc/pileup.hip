@@ -1630,6 +1630,7 @@ struct K5Args {
     const uint8_t* s; const bgp_record* rec; const uint64_t* pmax_end; const uint64_t* pmax_pos;
     RunDev run; uint64_t pos_begin, pos_end; const bgp_column* cols; uint64_t* cov64; const uint64_t* col_off; bgp_entry* entries;
     const uint64_t* ck_off; const Ckpt* ck; uint32_t ck_w;      // K4's long-read checkpoints (null / 0: none): per read and window, the cursor at the window's first column
+    const uint4* cig4;                                          // K1's side array of first CIGAR ops, or null (a compacted table)
 };
 
 __global__ __launch_bounds__(256) void k5_cov(K5Args a) {
@@ -1683,6 +1684,43 @@ __device__ __forceinline__ bgp_entry entry_of(const uint8_t* s, const bgp_record
     return e;
 }
 
+// entry_of for a read of at most four CIGAR ops that are already in registers (the same closed form, no CIGAR load)
+__device__ __forceinline__ bgp_entry entry_of_ops(const uint8_t* s, const bgp_record& r, const uint32_t (&ops)[4], uint32_t rr, uint32_t ordinal) {
+    const uint32_t l_name = r.bin_mq_nl & 0xFFu, n_cig = r.flag_nc & 0xFFFFu;
+    const uint8_t* sq = s + r.rec_off + 36 + l_name + 4ull * n_cig;
+    const uint8_t* ql = sq + (uint32_t)((r.l_seq + 1) / 2);
+    bgp_entry e; e.read_ordinal = ordinal; e.cigar_op_offset = 0; e.query_offset = 0; e.cigar_op_index = 0xFFFF; e.base = 0xFF; e.qual = 0xFF;
+    uint32_t cs = 0, qs = 0; bool started = false, hit = false, hit_qc = false;
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k) {
+        if (k >= n_cig || hit) continue;
+        const uint32_t op = ops[k], len = op >> 4, qc = cig_qc(op), rc = cig_rc(op);
+        if (!started) {
+            if (rc) { if ((op & 15u) != 3u) started = true; else continue; }
+            else { if (qc) qs += len; continue; }
+        }
+        if (!rc) { if (qc) qs += len; continue; }
+        const uint32_t elen = len ? len : 1u;
+        if (rr < cs + elen) {
+            e.cigar_op_index = (uint16_t)k; e.cigar_op_offset = rr - cs;
+            e.query_offset = qs + (qc ? rr - cs : 0u);
+            hit = true; hit_qc = qc != 0;
+        } else { cs += elen; if (qc) qs += elen; }
+    }
+    if (hit) {
+        if (hit_qc) {
+            if (e.query_offset < (uint32_t)r.l_seq) {
+                const uint32_t byte = sq[e.query_offset >> 1];
+                const uint32_t code = (e.query_offset & 1u) ? (byte & 0xFu) : (byte >> 4);
+                const uint64_t lo = 0x565352474D43413Dull, hi = 0x4E42444B48595754ull;   // "=ACMGRSVTWYHKDBN", base.d:85
+                e.base = (uint8_t)(((code & 8u) ? hi : lo) >> ((code & 7u) * 8));
+                e.qual = ql[e.query_offset];
+            }
+        } else { e.base = '-'; e.qual = 255; }                                         // pileup.d:119-121,131-133
+    }
+    return e;
+}
+
 // One wave per 64 consecutive COLUMNS, lane = column: the candidate rows of the block are scanned once (64 rows a step,
 // coalesced), every row that touches the block is handed to all lanes in file order, and a lane whose column the read
 // covers appends the read's entry to its own column -- a counter a lane, no ranks, no ballots per entry.  (With a wave per
@@ -1715,7 +1753,8 @@ __global__ __launch_bounds__(256) void k5_fill_blk(K5Args a) {
         const uint64_t i = base + lane;
         bgp_record r{};
         bool hit = false;
-        if (i < i_hi) { r = a.rec[i]; hit = r.end_pos != r.pos && (uint64_t)(uint32_t)r.pos < p1 && (uint64_t)(uint32_t)r.end_pos > p0; }
+        uint4 c4 = make_uint4(0, 0, 0, 0);
+        if (i < i_hi) { r = a.rec[i]; hit = r.end_pos != r.pos && (uint64_t)(uint32_t)r.pos < p1 && (uint64_t)(uint32_t)r.end_pos > p0; if (hit && a.cig4) c4 = a.cig4[i]; }
         for (unsigned long long m = __ballot(hit); m; m &= m - 1) {
             const int src = __ffsll((long long)m) - 1;
             bgp_record q;                                                           // the read, the same in every lane (scalar registers)
@@ -1723,8 +1762,12 @@ __global__ __launch_bounds__(256) void k5_fill_blk(K5Args a) {
             q.bin_mq_nl = (uint32_t)__builtin_amdgcn_readlane((int)r.bin_mq_nl, src); q.flag_nc = (uint32_t)__builtin_amdgcn_readlane((int)r.flag_nc, src);
             q.l_seq = __builtin_amdgcn_readlane(r.l_seq, src);
             q.rec_off = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(r.rec_off >> 32), src) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)r.rec_off, src);
+            const bool small = a.cig4 && (q.flag_nc & 0xFFFFu) <= 4u;           // its ops came with the row (K1's side array): no CIGAR load per entry
+            const uint32_t ops[4] = {(uint32_t)__builtin_amdgcn_readlane((int)c4.x, src), (uint32_t)__builtin_amdgcn_readlane((int)c4.y, src), (uint32_t)__builtin_amdgcn_readlane((int)c4.z, src), (uint32_t)__builtin_amdgcn_readlane((int)c4.w, src)};
             if (valid && (uint64_t)(uint32_t)q.pos <= p && (uint64_t)(uint32_t)q.end_pos > p) {
-                const bgp_entry e = entry_of(a.s, q, (uint32_t)(p - (uint32_t)q.pos), (uint32_t)(base + (uint64_t)src), a);
+                bgp_entry e;
+                if (small) e = entry_of_ops(a.s, q, ops, (uint32_t)(p - (uint32_t)q.pos), (uint32_t)(base + (uint64_t)src));
+                else e = entry_of(a.s, q, (uint32_t)(p - (uint32_t)q.pos), (uint32_t)(base + (uint64_t)src), a);
                 uint4 v; __builtin_memcpy(&v, &e, 16);
                 ring[cnt & (K5R - 1)][lane] = v;
                 ++cnt;
@@ -2053,6 +2096,7 @@ int k5_entries(bgp_ctx* c, uint32_t run_idx, uint64_t pos_begin, uint64_t pos_en
     a.pos_begin = pos_begin; a.pos_end = pos_end; a.cols = c->d_columns.as<bgp_column>(); a.cov64 = c->d_col_lo.as<uint64_t>();
     a.col_off = c->d_entry_off.as<uint64_t>(); a.entries = nullptr;
     a.ck_w = c->ck_w; a.ck = c->ck_w ? c->d_ck.as<Ckpt>() : nullptr; a.ck_off = c->ck_w ? c->d_ck_off.as<uint64_t>() : nullptr;
+    a.cig4 = c->cig4_ok ? c->d_cig4.as<uint4>() : nullptr;
     hipLaunchKernelGGL(k5_cov, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, c->stream, a);
     uint64_t total = 0;
     BGP_TRY(scan_exclusive_u64(c, a.cov64, c->d_entry_off.as<uint64_t>(), np, &total));
