@@ -230,7 +230,7 @@ int bgp_push_inflated(bgp_ctx* c, const uint8_t* data, size_t len, uint64_t coff
     if (first_record_uoffset != BGP_UOFFSET_UNKNOWN && first_record_uoffset < len) c->hints.push_back(c->h_stage_len + first_record_uoffset);
     c->bai_buildable = false;
     BGP_TRY(c->h_stage.reserve_keep(c->h_stage_len + len, c->h_stage_len));
-    memcpy(c->h_stage.as<uint8_t>() + c->h_stage_len, data, len);
+    bgp_staged_copy(c->h_stage.as<uint8_t>() + c->h_stage_len, data, len);
     c->h_stage_len += len;
     return BGP_OK;
     BGP_API_CATCH(c)

@@ -58,7 +58,7 @@ void batch_release(bgp_ctx* c) {
 // the caller's bytes into the pinned buffer: one thread copies ~10 GB/s on the GPU boxes' hosts, which made this memcpy the
 // whole of the device-E2E time (the H2D copy, the kernels and the D2H of the columns all hide behind it); large pushes are
 // split over a few threads
-static void staged_copy(uint8_t* dst, const uint8_t* src, uint64_t n) {
+void bgp_staged_copy(uint8_t* dst, const uint8_t* src, uint64_t n) {
     static const int n_thr = [] { const char* e = getenv("BGP_PUSH_THREADS"); int v = e ? atoi(e) : 4; return v < 1 ? 1 : v > 16 ? 16 : v; }();
     if (n_thr == 1 || n < (16ull << 20)) { memcpy(dst, src, n); return; }
     const uint64_t part = ((n / (uint64_t)n_thr) + 4095) & ~4095ull;
@@ -169,7 +169,7 @@ int bgp_batch_push(bgp_ctx* c, const uint8_t* data, size_t len, size_t* taken) {
         const int h = b->fill;
         if (b->host_len[h] == b->batch_bytes) { const int rc = ship(c, b); if (rc != BGP_OK) return rc; continue; }
         const uint64_t n = std::min<uint64_t>(len - *taken, b->batch_bytes - b->host_len[h]);
-        staged_copy(b->host[h].as<uint8_t>() + b->host_len[h], data + *taken, n);
+        bgp_staged_copy(b->host[h].as<uint8_t>() + b->host_len[h], data + *taken, n);
         b->host_len[h] += n; *taken += n;
     }
     return BGP_OK;

@@ -226,6 +226,7 @@ int chunks_plan(bgp_ctx* c, uint64_t block_size, uint64_t start_from, uint64_t e
 int emit_window(bgp_ctx* c, uint32_t run, uint64_t a, uint64_t b, int want_entries, int use_md, int snp, bgp_columns* o);   // api.cpp: columns [a, b) of a run to the host
 int batch_cut(bgp_ctx* c, uint64_t* last_key, uint64_t* carry_record, uint64_t* carry_off);   // pileup.hip: last covering read of the staged stream and where its exact halo starts
 void batch_release(bgp_ctx* c);   // batch.cpp
+void bgp_staged_copy(uint8_t* dst, const uint8_t* src, uint64_t n);   // batch.cpp: memcpy into pinned staging, large copies over a few threads
 int flush_core(bgp_ctx* c, uint32_t what = 0);        // api.cpp: framing + record table (+ the arenas of `what`) of the stream c->d_stream points at   // chunks.hip : fills c->chunks         // bai_build.hip : createIndex over the staged file
 
 // device helpers shared by kernels
