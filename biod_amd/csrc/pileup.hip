@@ -1639,23 +1639,14 @@ __global__ __launch_bounds__(256) void k5_cov(K5Args a) {
     a.cov64[k] = a.cols[a.run.column_base + (a.pos_begin - a.run.start_pos) + k].coverage;
 }
 
-// closed-form cursor of read r at column offset rr (see file header)
-__device__ __forceinline__ bgp_entry entry_of(const uint8_t* s, const bgp_record& r, uint32_t rr, uint32_t ordinal, const K5Args& a) {
+// the cursor of read r at column offset rr, walked from a cursor that stands at or before it: op k, cs columns and qs query
+// bases in front of it (pileup.d:175-222 in closed form, see the file header)
+__device__ __forceinline__ bgp_entry entry_walk(const uint8_t* s, const bgp_record& r, uint32_t k, uint32_t cs, uint32_t qs, bool started, uint32_t rr, uint32_t ordinal) {
     const uint32_t l_name = r.bin_mq_nl & 0xFFu, n_cig = r.flag_nc & 0xFFFFu;
     const uint8_t* cg = s + r.rec_off + 36 + l_name;
     const uint8_t* sq = cg + 4ull * n_cig;
     const uint8_t* ql = sq + (uint32_t)((r.l_seq + 1) / 2);
     bgp_entry e; e.read_ordinal = ordinal; e.cigar_op_offset = 0; e.query_offset = 0; e.cigar_op_index = 0xFFFF; e.base = 0xFF; e.qual = 0xFF;
-    uint32_t cs = 0, qs = 0, k = 0; bool started = false;
-    if (a.ck && wants_ckpt(n_cig, (uint32_t)r.l_seq)) {
-        // a long read is not walked from its first op for every column: the walk resumes from the cursor K4 recorded for
-        // the window the column lies in (op index, columns before it, query bases before it; the op owns a column, so
-        // the cursor has started) -- O(ops inside a window) per entry instead of O(ops of the read)
-        const uint64_t wj = ((uint64_t)(uint32_t)r.pos + rr - a.run.start_pos) / a.ck_w - ((uint64_t)(uint32_t)r.pos - a.run.start_pos) / a.ck_w;
-        const Ckpt c = a.ck[a.ck_off[ordinal] + wj];
-        if (c.k != 0xFFFFFFFFu) { k = c.k; cs = c.cs; qs = c.qs; started = true; }
-        else k = n_cig;                                                      // the cursor ran off the CIGAR before this window (pileup.d:224-228)
-    }
     for (; k < n_cig; ++k) {
         const uint32_t op = ld_u32(cg + 4 * k);
         const uint32_t len = op >> 4, qc = cig_qc(op), rc = cig_rc(op);
@@ -1682,6 +1673,27 @@ __device__ __forceinline__ bgp_entry entry_of(const uint8_t* s, const bgp_record
         cs += elen; if (qc) qs += elen;
     }
     return e;
+}
+
+// where the walk for column offset rr of a read starts: its first op, or -- a long read -- the cursor K4 recorded for the
+// window the column lies in (op index, columns before it, query bases before it; the op owns a column, so the cursor has
+// started): O(ops inside a window) per entry instead of O(ops of the read)
+__device__ __forceinline__ void entry_cursor(const bgp_record& r, uint32_t rr, uint32_t ordinal, const K5Args& a, uint32_t* k, uint32_t* cs, uint32_t* qs, bool* started) {
+    const uint32_t n_cig = r.flag_nc & 0xFFFFu;
+    *k = 0; *cs = 0; *qs = 0; *started = false;
+    if (a.ck && wants_ckpt(n_cig, (uint32_t)r.l_seq)) {
+        const uint64_t wj = ((uint64_t)(uint32_t)r.pos + rr - a.run.start_pos) / a.ck_w - ((uint64_t)(uint32_t)r.pos - a.run.start_pos) / a.ck_w;
+        const Ckpt c = a.ck[a.ck_off[ordinal] + wj];
+        if (c.k != 0xFFFFFFFFu) { *k = c.k; *cs = c.cs; *qs = c.qs; *started = true; }
+        else *k = n_cig;                                                     // the cursor ran off the CIGAR before this window (pileup.d:224-228)
+    }
+}
+
+// closed-form cursor of read r at column offset rr (see file header)
+__device__ __forceinline__ bgp_entry entry_of(const uint8_t* s, const bgp_record& r, uint32_t rr, uint32_t ordinal, const K5Args& a) {
+    uint32_t k, cs, qs; bool started;
+    entry_cursor(r, rr, ordinal, a, &k, &cs, &qs, &started);
+    return entry_walk(s, r, k, cs, qs, started, rr, ordinal);
 }
 
 // entry_of for a read of at most four CIGAR ops that are already in registers (the same closed form, no CIGAR load)
@@ -1764,10 +1776,38 @@ __global__ __launch_bounds__(256) void k5_fill_blk(K5Args a) {
             q.rec_off = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(r.rec_off >> 32), src) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)r.rec_off, src);
             const bool small = a.cig4 && (q.flag_nc & 0xFFFFu) <= 4u;           // its ops came with the row (K1's side array): no CIGAR load per entry
             const uint32_t ops[4] = {(uint32_t)__builtin_amdgcn_readlane((int)c4.x, src), (uint32_t)__builtin_amdgcn_readlane((int)c4.y, src), (uint32_t)__builtin_amdgcn_readlane((int)c4.z, src), (uint32_t)__builtin_amdgcn_readlane((int)c4.w, src)};
+            // any other read: the cursor at the block's first column of the read, found ONCE for the 64 lanes (for a long read from
+            // the window's checkpoint: every lane walking there by itself was ~35 dependent CIGAR loads per entry on cfg5)
+            uint32_t bk = 0, bcs = 0, bqs = 0; bool bst = false;
+            if (!small) {
+                const uint32_t rr0 = (uint32_t)(max(p0, (uint64_t)(uint32_t)q.pos) - (uint32_t)q.pos);
+                entry_cursor(q, rr0, (uint32_t)(base + (uint64_t)src), a, &bk, &bcs, &bqs, &bst);
+                if (bst) {
+                    const uint32_t n_cig = q.flag_nc & 0xFFFFu;
+                    const uint8_t* cg = a.s + q.rec_off + 36 + (q.bin_mq_nl & 0xFFu);
+                    while (bk < n_cig) {                                      // 64 ops a step, lane = op: the first column-owning op that reaches past rr0
+                        const uint32_t kk = bk + (uint32_t)lane;
+                        const uint32_t op = kk < n_cig ? ld_u32(cg + 4ull * kk) : 0u;
+                        const bool on = kk < n_cig, qc = on && cig_qc(op), rc = on && cig_rc(op);
+                        const uint32_t len = op >> 4, elen = len ? len : 1u;
+                        const uint32_t cl = rc ? elen : 0u, ql = qc ? (rc ? elen : len) : 0u;
+                        const uint32_t ic = wave_incl_u32(cl, lane), iq = wave_incl_u32(ql, lane);
+                        const unsigned long long hm = __ballot(rc && rr0 < bcs + ic);
+                        if (hm) {
+                            const int L = __ffsll((long long)hm) - 1;
+                            bcs += (uint32_t)__builtin_amdgcn_readlane((int)(ic - cl), L); bqs += (uint32_t)__builtin_amdgcn_readlane((int)(iq - ql), L);
+                            bk += (uint32_t)L;
+                            break;
+                        }
+                        bcs += (uint32_t)__builtin_amdgcn_readlane((int)ic, 63); bqs += (uint32_t)__builtin_amdgcn_readlane((int)iq, 63);
+                        bk = min(bk + 64u, n_cig);
+                    }
+                }
+            }
             if (valid && (uint64_t)(uint32_t)q.pos <= p && (uint64_t)(uint32_t)q.end_pos > p) {
                 bgp_entry e;
                 if (small) e = entry_of_ops(a.s, q, ops, (uint32_t)(p - (uint32_t)q.pos), (uint32_t)(base + (uint64_t)src));
-                else e = entry_of(a.s, q, (uint32_t)(p - (uint32_t)q.pos), (uint32_t)(base + (uint64_t)src), a);
+                else e = entry_walk(a.s, q, bk, bcs, bqs, bst, (uint32_t)(p - (uint32_t)q.pos), (uint32_t)(base + (uint64_t)src));
                 uint4 v; __builtin_memcpy(&v, &e, 16);
                 ring[cnt & (K5R - 1)][lane] = v;
                 ++cnt;
