@@ -889,8 +889,10 @@ __global__ __launch_bounds__(64) void k6_emit(const uint8_t* s, const bgp_record
 }
 
 __global__ __launch_bounds__(64) void k6_ck_build(const uint8_t* s, const bgp_record* rec, const LongNode* longs, uint32_t n_long, DnaCk* ck, uint32_t* piece_node) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_long) return;
+    // a WAVE per long chunk with one lane at work: the walk is a chain of dependent loads, a few thousand chunks are all a
+    // stream of long reads has, and 64 of them in the lanes of one wave ran one after the other's divergent steps
+    const uint32_t i = blockIdx.x;
+    if (threadIdx.x || i >= n_long) return;
     const LongNode L = longs[i];
     const uint32_t pieces = (L.count + DNA_CK - 1) / DNA_CK;
     for (uint32_t j = 0; j < pieces; ++j) piece_node[L.ck_base + j] = i;
@@ -1095,7 +1097,7 @@ int k6_reference_bases(bgp_ctx* c, int skip_zero, uint32_t run_first, uint32_t r
                 BGP_HIP(hipMemsetAsync(ck, 0, (size_t)ctr[1] * sizeof(DnaCk), c->stream));
                 const LongNode* longs = (const LongNode*)(c->d_md_long.as<uint8_t>() + 16);
                 TimedRegion t(c, "k6_emit_long", (uint64_t)ctr[1] * DNA_CK);
-                hipLaunchKernelGGL(k6_ck_build, dim3((ctr[0] + 63) / 64), dim3(64), 0, c->stream, c->d_stream, c->d_rec.as<bgp_record>(), longs, ctr[0], ck, piece_node);
+                hipLaunchKernelGGL(k6_ck_build, dim3(ctr[0]), dim3(64), 0, c->stream, c->d_stream, c->d_rec.as<bgp_record>(), longs, ctr[0], ck, piece_node);
                 hipLaunchKernelGGL(k6_emit_long, dim3((ctr[1] + 63) / 64), dim3(64), 0, c->stream, c->d_stream, c->d_rec.as<bgp_record>(), longs, ck, piece_node, ctr[1], c->d_refbase.as<uint8_t>());
                 BGP_HIP(hipGetLastError());
             }
