@@ -163,11 +163,13 @@ def check(rc: int, ctx=None) -> int:
     return rc
 
 
-def as_array(ptr, count, dtype):
-    """Copy `count` items of `dtype` from a host pointer owned by the ctx."""
+def as_array(ptr, count, dtype, copy=True):
+    """`count` items of `dtype` from a host pointer owned by the ctx: a copy, or (copy=False) a view of the ctx's own
+    pinned buffer -- valid until the next call that hands out a window, as the C ABI says."""
     count = int(count)
     if not ptr or count == 0:
         return np.zeros(0, dtype)
     dtype = np.dtype(dtype)
     buf = (C.c_char * (count * dtype.itemsize)).from_address(ptr)
-    return np.frombuffer(buf, dtype=dtype, count=count).copy()
+    a = np.frombuffer(buf, dtype=dtype, count=count)
+    return a.copy() if copy else a

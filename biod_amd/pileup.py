@@ -154,8 +154,9 @@ class Context:
                           n_reads_used=info.n_reads_used, device_columns=info.device_columns or 0, device_depth_hist=info.device_depth_hist or 0)
 
     def pileup_windows(self, mode: int, use_md_tag=False, start_from=0, end_at=ULONG_MAX, skip_zero_coverage=True,
-                       want_entries=False, window_positions=0, snp=None, maq=None):
-        """Dense windows of columns.  snp=(minimum_coverage, minimum_witnesses) adds simple.isSNP flags per position
+                       want_entries=False, window_positions=0, snp=None, maq=None, copy=True):
+        """Dense windows of columns (copy=False: the arrays are views of the ctx's pinned buffers, valid until the next
+        window -- BioD's own warning about column.reads, pileup.d:660-661 -- and a window costs no host copy).  snp=(minimum_coverage, minimum_witnesses) adds simple.isSNP flags per position
         (snpcallers/simple.d:15-41, needs use_md_tag): window.snp, resolved against the entries where the device says
         BGP_SNP_NEEDS_ENTRIES and entries were requested.  maq=(depcorr, eta, minimum_base_quality) adds the MAQ model's
         call per position (snpcallers/maq.d:388-486): window.maq, a MAQ_CALL_DTYPE array."""
@@ -164,7 +165,7 @@ class Context:
             L.check(L.lib().bgp_pileup_snp(self._h, int(snp[0]), int(snp[1])), self._h)
         if maq is not None:
             L.check(L.lib().bgp_pileup_maq(self._h, float(maq[0]), float(maq[1]), int(maq[2])), self._h)
-        yield from self._windows(snp)
+        yield from self._windows(snp, copy)
 
     def pileup_chunks_begin(self, use_md_tag=False, block_size=16_384_000, start_from=0, end_at=ULONG_MAX, want_entries=False, window_positions=0) -> int:
         """Plans pileupChunks (pileup.d:1011-1015); returns the number of chunks."""
@@ -234,19 +235,19 @@ class Context:
         self.batch_end()
         yield from self.batch_drain()
 
-    def _windows(self, snp):
+    def _windows(self, snp, copy=True):
         while True:
             cw = L.Columns()
             rc = L.check(L.lib().bgp_pileup_next_window(self._h, C.byref(cw)), self._h)
             if rc == L.BGP_EOF:
                 return
-            cols = L.as_array(cw.columns, cw.n_positions, L.COLUMN_DTYPE)
-            eoff = L.as_array(cw.entry_off, cw.n_positions + 1, "<u8") if cw.entry_off else None
-            ents = L.as_array(cw.entries, int(eoff[-1]), L.ENTRY_DTYPE) if eoff is not None else None
-            refb = L.as_array(cw.reference_base, cw.n_positions, "u1") if cw.reference_base else None
+            cols = L.as_array(cw.columns, cw.n_positions, L.COLUMN_DTYPE, copy)
+            eoff = L.as_array(cw.entry_off, cw.n_positions + 1, "<u8", copy) if cw.entry_off else None
+            ents = L.as_array(cw.entries, int(eoff[-1]), L.ENTRY_DTYPE, copy) if eoff is not None else None
+            refb = L.as_array(cw.reference_base, cw.n_positions, "u1", copy) if cw.reference_base else None
             w = Window(cw.ref_id, cw.first_position, cols, eoff, ents, refb)
             if cw.maq:
-                w.maq = L.as_array(cw.maq, cw.n_positions, L.MAQ_CALL_DTYPE)
+                w.maq = L.as_array(cw.maq, cw.n_positions, L.MAQ_CALL_DTYPE, copy)
             if snp is not None and cw.snp:
                 w.snp = L.as_array(cw.snp, cw.n_positions, "u1")
                 if ents is not None:

@@ -17,7 +17,7 @@ for mode in ('columns', 'maq', 'entries'):
     kw = dict(window_positions=wp)
     if mode == 'maq': kw['maq'] = (0.17, 0.03, 13)
     if mode == 'entries': kw['want_entries'] = True
-    for w in ctx.pileup_windows(L.BGP_PILEUP_COLUMNS, **kw):
+    for w in ctx.pileup_windows(L.BGP_PILEUP_COLUMNS, copy=False, **kw):
         nw += 1; npos += len(w.columns)
     dt = time.time() - t0
     tm = ctx.timing_get()

@@ -1642,3 +1642,20 @@ def test_long_read_rows_chunk_shapes(ctx, m_len, n_long, n_short):
     stage(ctx, st)
     check_decode(ctx, st)
     check_pileup(ctx, st, entries=(m_len == 37), window=700)
+
+
+def test_python_windows_as_views(ctx, data_dir):
+    """pileup_windows(copy=False): the arrays are views of the ctx's buffers, equal to the copies while their window is
+    the current one."""
+    _, st = bamio.read_bam(os.path.join(data_dir, "ex1_header.bam"))
+    stage(ctx, st)
+    ctx.pileup_run()
+    copies = [(w.ref_id, int(w.first_position), w.columns.copy(), w.entry_off.copy(), w.entries.copy())
+              for w in ctx.pileup_windows(L.BGP_PILEUP_COLUMNS, want_entries=True, window_positions=300)]
+    k = 0
+    for w in ctx.pileup_windows(L.BGP_PILEUP_COLUMNS, want_entries=True, window_positions=300, copy=False):
+        r, p, c, eo, en = copies[k]
+        assert (w.ref_id, int(w.first_position)) == (r, p)
+        assert np.array_equal(w.columns, c) and np.array_equal(w.entry_off, eo) and np.array_equal(w.entries, en)
+        k += 1
+    assert k == len(copies) and k > 5
