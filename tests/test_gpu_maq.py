@@ -100,6 +100,10 @@ def test_maq_columns_deeper_than_255(ctx):
     st = _random_pile(rng, 1500, 300, deep=True)
     seen = check_maq(ctx, st, min_bq=5)
     assert seen["sub"] > 20
+    # half of the bases below the bar: columns of 65 .. 128 entries with at most 64 that count (the two-pass pick of k8_maq64's
+    # fast path) next to columns that stay with the wave-per-column routine
+    seen = check_maq(ctx, _random_pile(np.random.default_rng(78), 900, 700, deep=True), min_bq=30, window=500)
+    assert seen["calls"] > 300
 
 
 def test_maq_snp_caller_facade(ctx):
