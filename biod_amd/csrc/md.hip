@@ -29,7 +29,16 @@ namespace {
 // dna(read), but the backward pre-parse decides where the forward parse stops, so it is kept literally.
 
 struct MdOp { uint32_t type; /* 0 match, 1 mismatch, 2 deletion */ uint32_t match; uint32_t ch; uint32_t del_off, del_len; };
-struct MdRes { const uint8_t* md; uint32_t b, e; MdOp front, back; int rem; };
+struct MdRes { const uint8_t* md; uint32_t b, e; MdOp front, back; int rem;
+               uint64_t wlo, whi; int32_t wbase; bool wok; };     // the tag's last 16 chars in registers: chars [wbase, wbase + 16) (wok: loaded)
+
+// char i of the tag: from the register window where it covers i (a tag of up to 16 chars -- "75A74" -- is parsed without
+// another load: every operation used to cost a dependent load of its own), else from memory
+__device__ __forceinline__ uint8_t md_ch(const MdRes& r, uint32_t i) {
+    const int32_t d = (int32_t)i - r.wbase;
+    if (r.wok && d >= 0 && d < 16) return (uint8_t)((d < 8 ? r.wlo : r.whi) >> (8 * (d & 7)));
+    return r.md[i];
+}
 
 __device__ __forceinline__ bool is_digit_(uint8_t c) { return c >= '0' && c <= '9'; }
 __device__ __forceinline__ bool is_upper_(uint8_t c) { return c >= 'A' && c <= 'Z'; }
@@ -49,15 +58,9 @@ __device__ __forceinline__ uint8_t base16_norm(uint8_t c) {
 
 __device__ bool md_cache_front(MdRes& r) {                      // md/parse.d:85-109
     if (r.b >= r.e) return false;
-    const uint8_t* m = r.md;
-    // the first eight chars of the rest of the tag in one load: an operation is parsed from registers (a number and
-    // the letter after it rarely take more), the byte loop only continues where an operation runs past them
     const uint32_t avail = r.e - r.b;
-    uint64_t w = 0;
-    if (avail >= 8) __builtin_memcpy(&w, m + r.b, 8);
-    else for (uint32_t i = 0; i < avail; ++i) w |= (uint64_t)m[r.b + i] << (8 * i);
-    auto at = [&](uint32_t i) -> uint8_t { return i < 8 ? (uint8_t)(w >> (8 * i)) : m[r.b + i]; };
-    const uint8_t c0 = (uint8_t)w;
+    auto at = [&](uint32_t i) -> uint8_t { return md_ch(r, r.b + i); };
+    const uint8_t c0 = at(0);
     MdOp o{0, 0, 0, 0, 0};
     if (c0 == '^') {
         uint32_t len = 0;
@@ -74,12 +77,9 @@ __device__ bool md_cache_front(MdRes& r) {                      // md/parse.d:85
 
 __device__ bool md_cache_back(MdRes& r) {                       // md/parse.d:111-131
     if (r.b >= r.e) return false;
-    const uint8_t* m = r.md;
     MdOp o{0, 0, 0, 0, 0};
-    // the last eight chars in front of `e` in one load (the value of a tag is never the first eight bytes of a record, so
-    // m + e - 8 is inside the stream): bk(k) is the char k places before the end
-    uint64_t w; __builtin_memcpy(&w, m + r.e - 8, 8);
-    auto bk = [&](uint32_t k) -> uint8_t { return k < 8 ? (uint8_t)(w >> (8 * (7 - k))) : m[r.e - 1 - k]; };
+    // bk(k) is the char k places before the end (from the register window mdf_init loaded, where it reaches)
+    auto bk = [&](uint32_t k) -> uint8_t { return md_ch(r, r.e - 1 - k); };
     if (is_digit_(bk(0))) {
         uint32_t len = 0; uint64_t v = 0, p10 = 1;
         while (r.e - len > r.b && is_digit_(bk(len))) { v += p10 * (uint64_t)(bk(len) - '0'); p10 *= 10; ++len; }
@@ -108,6 +108,10 @@ __device__ void md_pop_back(MdRes& r) {                         // md/parse.d:71
 __device__ __forceinline__ bool md_zero(const MdOp& o) { return o.type == 0 && o.match == 0; }
 __device__ void mdf_init(MdRes& r, const uint8_t* md, uint32_t n) {   // md/parse.d:23-33 + filterBidirectional ctor
     r.md = md; r.b = 0; r.e = n; r.rem = 255;
+    // the sixteen bytes in front of the tag's end in one load (a tag's value starts at least 39 bytes into its record, so
+    // md + n - 16 is inside the stream whatever n is)
+    r.wbase = (int32_t)n - 16; r.wok = n > 0;
+    if (r.wok) { uint64_t w2[2]; __builtin_memcpy(w2, md + (int64_t)r.wbase, 16); r.wlo = w2[0]; r.whi = w2[1]; } else { r.wlo = 0; r.whi = 0; }
     if (!md_cache_front(r)) r.rem = 0;
     else if (!md_cache_back(r)) { r.back = r.front; r.rem = 1; }
     while (!md_empty(r) && md_zero(r.front)) md_pop_front(r);
@@ -220,6 +224,7 @@ __device__ void dna_save(const DnaState& st, const uint8_t* s, uint32_t node, Dn
 }
 __device__ void dna_restore(DnaState& st, const uint8_t* s, const bgp_record& r, const DnaCk& ck) {
     st.m.md = s + ck.md_off; st.m.b = ck.b; st.m.e = ck.e; st.m.rem = ck.rem; st.m.front = ck.front; st.m.back = ck.back; st.cur = ck.cur;
+    st.m.wok = false; st.m.wlo = 0; st.m.whi = 0; st.m.wbase = 0;      // (a restored parser reads its chars from memory)
     st.del_i = ck.del_i; st.n = ck.n; st.live = ck.pad != 0;
     const uint32_t l_name = r.bin_mq_nl & 0xFFu, n_cig = r.flag_nc & 0xFFFFu;
     QIter& q = st.q; q.cg = s + r.rec_off + 36 + l_name; q.sq = q.cg + 4ull * n_cig; q.n_cig = n_cig; q.op = ck.q_op; q.in_op = ck.q_in; q.q = ck.q_q; q.empty = ck.q_empty != 0;
