@@ -709,7 +709,8 @@ __global__ __launch_bounds__(256) void k6_succ(const MdRow* rows, const uint32_t
         bool act = run && j < R.endrec;
         budget -= act ? 1 : 0;
         if (act && budget < 0) { deferred = true; done = true; run = false; act = false; }
-        if (__ballot(act && !found && (j & 63) == 0)) {
+        MdRow r{0, 0, 0, 0};
+        if (__ballot(act && ((!found && (j & 63) == 0) || j - base >= (uint64_t)STAGE))) {      // (one test for the two rare cases of a step)
             // nothing a row must be looked at for -- a candidate, a position group behind uncovered ground, an end beyond
             // the winner's -- exists in a block of 64 rows none of which ends beyond this read (a read with a 5 kb N skip
             // would otherwise walk a thousand rows, and hold its 63 neighbours for as long)
@@ -717,14 +718,9 @@ __global__ __launch_bounds__(256) void k6_succ(const MdRow* rows, const uint32_t
                 while (j + 64 <= R.endrec && bmax[j >> 6] <= CE) j += 64;
                 if (j >= R.endrec) { run = false; act = false; }
             }
+            if (act && j - base >= (uint64_t)STAGE) r = rows[j];                                      // a row behind the staged ones
         }
-        MdRow r{0, 0, 0, 0};
-        {
-            const uint64_t d = j - base;
-            const bool in_lds = d < (uint64_t)STAGE;
-            if (act && in_lds) r = s_rows[d];
-            if (__ballot(act && !in_lds)) { if (act && !in_lds) r = rows[j]; }
-        }
+        if (act && j - base < (uint64_t)STAGE) r = s_rows[j - base];
         const bool cov = act && (r.lf & MD_COV);
         const bool hz = r.mb < r.pos;
         const bool isg = skip_zero && (r.lf & MD_GST) && hz;
