@@ -1659,3 +1659,16 @@ def test_python_windows_as_views(ctx, data_dir):
         assert np.array_equal(w.columns, c) and np.array_equal(w.entry_off, eo) and np.array_equal(w.entries, en)
         k += 1
     assert k == len(copies) and k > 5
+
+
+@pytest.mark.parametrize("name,rid,beg,end", [("ex1_header.bam", 0, 100, 900), ("ex1_header.bam", 1, 0, 1500), ("tags.bam", 0, 0, 100000)])
+def test_entries_after_a_region_filter(ctx, data_dir, name, rid, beg, end):
+    """The record table is compacted by bgp_filter_region (K1's side array of first CIGAR ops is not): columns AND entries of
+    the kept reads against the oracle on the kept reads' stream; read ordinals count the kept reads."""
+    path = os.path.join(data_dir, name)
+    _, st = bamio.read_bam(path)
+    kept, exp_stream = _expected_region(st, rid, beg, end)
+    if not kept:
+        pytest.skip("no read in the region")
+    ctx.reset(); ctx.load_bam(path, 2); ctx.flush(); ctx.filter_region(rid, beg, end)
+    check_pileup(ctx, exp_stream, entries=True, window=257)
