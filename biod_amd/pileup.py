@@ -179,9 +179,9 @@ class Context:
         L.check(L.lib().bgp_pileup_chunk(self._h, k, C.byref(ci)), self._h)
         return ci
 
-    def chunk_windows(self, k: int):
+    def chunk_windows(self, k: int, copy=True):
         self.pileup_chunk(k)
-        yield from self._windows(None)
+        yield from self._windows(None, copy)
 
     # -- batched staging (streams larger than HBM): include/biodgpu.h, bgp_batch_*
     def batch_begin(self, batch_bytes: int = 0, want_entries: bool = False, window_positions: int = 0, maq=None):
