@@ -101,3 +101,67 @@ def allreduce_histogram(hist_tensor):
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.all_reduce(hist_tensor, op=dist.ReduceOp.SUM)
     return hist_tensor
+
+
+# ---------------------------------------------------------------------------------------------- a BAM FILE over N ranks
+# BioD's pieces for this: ReferenceSequence.startVirtualOffset (reference.d:96-104), Index.getMinimumOffset
+# (baifile.d:77-82) and bam[ref][beg .. end] (randomaccessmanager.d:222-244,366-462).  A rank that loads a REGION gets
+# every read overlapping it, so its columns inside [beg, end) are exact without any halo arithmetic: cutting a file is
+# choosing cut points, and the linear index says how many compressed bytes lie in front of each candidate.
+
+LINEAR_SHIFT = 14      # the BAI linear index has one entry per 16 384 positions (bai/indexing.d, samtools spec)
+
+
+def plan_file_shards(bai, ref_lengths, world: int):
+    """Regions (ref_id, beg, end) for each of `world` ranks: the references in file order, cut at linear-index windows
+    so that the COMPRESSED bytes of the ranks balance.  Returns a list of `world` lists; a reference without an entry in
+    the index (no reads) is given to nobody.  Every position of every indexed reference lies in exactly one region."""
+    cand = []                                           # (compressed offset, ref_id, position): possible region starts, file order
+    for r, rlen in enumerate(ref_lengths):
+        if r >= bai.n_ref or bai.shape(r)[2] == 0 or rlen <= 0:
+            continue
+        n_win = (int(rlen) + (1 << LINEAR_SHIFT) - 1) >> LINEAR_SHIFT
+        last = -1
+        for w in range(n_win):
+            off = bai.min_offset(r, w << LINEAR_SHIFT) >> 16
+            if w == 0 or off > last:                    # (windows without a read of their own repeat their neighbour's offset: no cut there)
+                cand.append((max(off, last), r, w << LINEAR_SHIFT))
+                last = max(off, last)
+    shards = [[] for _ in range(world)]
+    if not cand:
+        return shards
+    lo, hi = cand[0][0], cand[-1][0]
+    span = max(hi - lo, 1)
+    # the first candidate at or beyond k/world of the span starts rank k's share
+    starts = [0]
+    for k in range(1, world):
+        target = lo + span * k // world
+        j = starts[-1]
+        while j < len(cand) and cand[j][0] < target:
+            j += 1
+        starts.append(j)
+    starts.append(len(cand))
+    for k in range(world):
+        a, b = starts[k], starts[k + 1]
+        j = a
+        while j < b:
+            r = cand[j][1]
+            beg = cand[j][2]
+            while j < b and cand[j][1] == r:
+                j += 1
+            end = cand[j][2] if j < len(cand) and cand[j][1] == r else int(ref_lengths[r])     # up to the next rank's first cut in this reference, or its end
+            shards[k].append((r, int(beg), int(end)))
+    return shards
+
+
+def file_shard_windows(ctx, path: str, bai, regions, n_threads: int = 0, **window_args):
+    """The windows of one rank's regions: bam[ref][beg .. end] staged through the index, piled up, and the columns of
+    [beg, end) handed out (makePileup's start_from / end_at, pileup.d:683-694)."""
+    for ref_id, beg, end in regions:
+        ctx.reset()
+        ctx.load_bam_region(path, bai, ref_id, beg, end, n_threads)
+        ctx.flush()
+        if ctx.num_records() == 0:
+            continue
+        ctx.pileup_run()
+        yield from ctx.pileup_windows(L.BGP_MAKE_PILEUP, start_from=beg, end_at=end, **window_args)

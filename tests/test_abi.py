@@ -139,3 +139,31 @@ def test_chunk_offsets_past_their_block_are_refused(data_dir):
         assert L.lib().bgp_bgzf_read_chunks(bam, chunk, 1, 1, None, 0, C.byref(n)) == L.BGP_EINVAL
     chunk = (C.c_uint64 * 2)(0, 100)                        # inside the first block (103 bytes): fine
     assert L.lib().bgp_bgzf_read_chunks(bam, chunk, 1, 1, None, 0, C.byref(n)) == 0 and n.value == 100
+
+
+def test_file_shard_plan_covers_every_position_once():
+    """shard.plan_file_shards over the reference's indexed fixtures: whatever the number of ranks, every position of every
+    indexed reference lies in exactly one region, regions follow file order, and rank shares are contiguous."""
+    import os
+    from biod_amd import bamio, shard
+    from biod_amd.pileup import BaiFile
+    data = os.path.join(os.path.dirname(__file__), "golden", "data")
+    for name in ("ex1_header.bam", "tags.bam", "bins.bam"):
+        path = os.path.join(data, name)
+        hdr, _ = bamio.read_bam(path)
+        lens = [l for _, l in hdr.refs]
+        bai = BaiFile(path)
+        indexed = [r for r in range(min(bai.n_ref, len(lens))) if bai.shape(r)[2] > 0 and lens[r] > 0]
+        for world in (1, 2, 3, 5, 8):
+            plan = shard.plan_file_shards(bai, lens, world)
+            assert len(plan) == world
+            flat = [reg for rank in plan for reg in rank]
+            assert flat == sorted(flat)                                   # file order, rank after rank
+            per_ref = {}
+            for r, b, e in flat:
+                assert 0 <= b < e <= lens[r]
+                per_ref.setdefault(r, []).append((b, e))
+            assert sorted(per_ref) == indexed
+            for r, iv in per_ref.items():
+                assert iv[0][0] == 0 and iv[-1][1] == lens[r]
+                assert all(iv[k][1] == iv[k + 1][0] for k in range(len(iv) - 1))

@@ -1672,3 +1672,42 @@ def test_entries_after_a_region_filter(ctx, data_dir, name, rid, beg, end):
         pytest.skip("no read in the region")
     ctx.reset(); ctx.load_bam(path, 2); ctx.flush(); ctx.filter_region(rid, beg, end)
     check_pileup(ctx, exp_stream, entries=True, window=257)
+
+
+@pytest.mark.parametrize("world", [2, 3, 5])
+def test_file_shards_by_the_index_equal_the_whole_file(ctx, tmp_path, world):
+    """shard.plan_file_shards + file_shard_windows: a generator BAM with its index (written by the device index writer),
+    cut INSIDE its contigs at linear-index windows; the columns the ranks hand out, put together, are the columns of the
+    whole file -- every position once, none missing."""
+    from biod_amd import shard
+    from biod_amd.pileup import BaiFile
+    cfg = make_cfg(n_reads=40_000, n_ref=2, ref_len=1_500_000, read_len=(100, 150), profile=1, seed=23)
+    st = host_stream(cfg)
+    offs = O.frame(st)
+    o = [int(x) for x in offs] + [len(st)]
+    recs = [bytes(st[o[i]:o[i + 1]]) for i in range(len(offs))]
+    path = str(tmp_path / "shards.bam")
+    lens = [1_500_000, 1_500_000]
+    bamio.write_bam(path, [(f"chr{i + 1}", lens[i]) for i in range(2)], recs)
+    bam = BamReader(path, 2)
+    bam.createIndex(overwrite=True)
+    # the whole file
+    c2 = bam.ctx
+    c2.pileup_run()
+    whole = {}
+    for w in c2.pileup_windows(L.BGP_PILEUP_COLUMNS, window_positions=1 << 16):
+        nz = np.nonzero(w.columns["coverage"])[0]
+        for j in nz:
+            whole[(w.ref_id, int(w.first_position) + int(j))] = w.columns[j].tobytes()
+    bai = BaiFile(path)
+    plan = shard.plan_file_shards(bai, lens, world)
+    assert sum(len(r) for r in plan) >= world and any(b > 0 for rank in plan for _, b, _ in rank)       # cuts inside a contig
+    got = {}
+    for rank in plan:
+        for w in shard.file_shard_windows(ctx, path, bai, rank, 2, window_positions=1 << 16):
+            nz = np.nonzero(w.columns["coverage"])[0]
+            for j in nz:
+                key = (w.ref_id, int(w.first_position) + int(j))
+                assert key not in got
+                got[key] = w.columns[j].tobytes()
+    assert len(whole) > 100_000 and got == whole
