@@ -1947,7 +1947,7 @@ int k34_pileup(bgp_ctx* c) {
             TimedRegion tb(c, "k4_bounds", tile_base * sizeof(TileB));
             hipLaunchKernelGGL(k4_bounds, dim3((unsigned)((tile_base + 255) / 256)), dim3(256), 0, c->stream, a.pmax_end, a.pmax_pos, a.runs, n_runs, tile_base, c->d_tiles.as<TileB>(), tw);
         }
-        constexpr uint64_t WG_SLOTS = 4096;            // k4_exec's workgroups leave their ranges' totals behind the windows' slots
+        constexpr uint64_t WG_SLOTS = 16384;            // k4_exec's workgroups leave their ranges' totals behind the windows' slots
         BGP_TRY(c->d_col_lo.reserve((tile_base + WG_SLOTS) * 32));
         a.tile_stats = (unsigned long long*)c->d_col_lo.p;
         a.ck = nullptr; a.ck_off = nullptr;
@@ -2023,7 +2023,10 @@ int k34_pileup(bgp_ctx* c) {
             g.s = a.s; g.slab = (const unsigned long long*)c->d_slab.p; g.wcount = c->d_wcount.as<uint32_t>(); g.wdel = c->d_wdel.as<int32_t>(); g.tiles = a.tiles; g.n_tiles = tile_base;
             g.cols = a.cols; g.hist = a.hist; g.tile_stats = a.tile_stats; g.deep = c->d_deep.as<uint32_t>() + 1; g.n_deep = c->d_deep.as<uint32_t>();
             g.rows = have_rows ? c->d_rows.as<uint8_t>() : nullptr;
-            static const unsigned g_blocks = std::min(4096u, getenv("BGP_G_BLOCKS") ? (unsigned)atoi(getenv("BGP_G_BLOCKS")) : 512u);     // two 76 KB workgroups per CU x 256 CUs
+            // 512 workgroups are resident (two of 76 KB a CU); handing the device eight times as many, each with a shorter range of
+            // windows, lets it balance the ranges' unequal work at the tail (cfg3: 10.5 -> 10.3 ms); the rows' instantiation is best at 512
+            static const unsigned g_env = getenv("BGP_G_BLOCKS") ? (unsigned)atoi(getenv("BGP_G_BLOCKS")) : 0u;
+            const unsigned g_blocks = std::min(16384u, g_env ? g_env : have_rows ? 512u : 4096u);
             if (have_rows) hipLaunchKernelGGL(k4_exec<true>, dim3((unsigned)std::min<uint64_t>(tile_base, g_blocks)), dim3(GT), (size_t)G_LDS, c->stream, g);
             else hipLaunchKernelGGL(k4_exec<false>, dim3((unsigned)std::min<uint64_t>(tile_base, g_blocks)), dim3(GT), (size_t)G_LDS, c->stream, g);
         }
