@@ -149,26 +149,14 @@ def cpu_baseline(cfg_name, n_sample):
     return out
 
 
-def oracle_prefix_check(ctx, cfg_name, n=20_000):
-    """Columns of a 20 k-read shard of the workload's read model: device == oracle, every field of every position."""
-    import numpy as np
-    import oracle_lib as O
-    from biod_amd import _lib as L
-    from biod_amd.synth import host_stream, scaled
-    n = n if cfg_name != "cfg5" else 60
-    st = host_stream(scaled(cfg_name, n))
-    ctx.reset(); ctx.push_inflated(st); ctx.flush()
-    info = ctx.pileup_run()
-    ora = O.pileup(st, skip_zero=False)
-    dense = np.concatenate([w.columns for w in ctx.pileup_windows(L.BGP_PILEUP_COLUMNS, skip_zero_coverage=False, window_positions=1 << 20)])
-    base = {int(r["ref_id"]): (int(r["column_base"]), int(r["start_pos"])) for r in info.runs}
-    idx = np.array([base[int(r)][0] - base[int(r)][1] for r in ora.ref], dtype=np.int64) + ora.pos.astype(np.int64)
-    exp = np.zeros(len(dense), L.COLUMN_DTYPE)
-    exp["coverage"][idx] = ora.cov; exp["n_starting_here"][idx] = ora.nstart
-    for j, f in enumerate(("a", "c", "g", "t", "other", "del")):
-        exp[f][idx] = ora.counts[:, j]
-    ok = len(dense) == info.n_positions and all(np.array_equal(dense[f], exp[f]) for f in L.COLUMN_DTYPE.names)
-    return {"reads": n, "positions": int(info.n_positions), "columns_equal_oracle": bool(ok)}
+def oracle_interior_check(ctx, cfg, cfg_name, info, torch, dev):
+    """Interior-shard parity on the FULL-size result the timed steps left on the device: >= 16 record ranges (the first
+    and last records, ranges across 4 / 8 / 16 / 24 GiB of stream offset, across 4 / 8 GiB of the arenas and of the column
+    array, across contig boundaries, at the deepest column) regenerated on the host, run through the oracle and compared
+    bit for bit -- rows, stream bytes, SEQ / QUAL / CIGAR slices, every column the range determines, per-read entries on
+    two of them (tests/interior_parity.py)."""
+    import interior_parity as IP
+    return IP.run(ctx, cfg, info, 20_000 if cfg_name != "cfg5" else 200, torch, dev, want=16)
 
 
 from biod_amd.checks import DevArray as _DevArray, full_size_invariants      # device-side identities of the result (no oracle)
@@ -365,12 +353,12 @@ def main():
         if hist_ok is not None:
             out["hist_reduce_equals_sum_of_ranks"] = hist_ok
         if world == 1 and not a.no_cpu_baseline:
-            out["parity_prefix"] = oracle_prefix_check(ctx, a.config)
+            out["parity_interior"] = oracle_interior_check(ctx, cfg, a.config, info, torch, dev)
             out["cpu_baseline"] = cpu_baseline(a.config, a.cpu_sample_reads)
             out["speedup_vs_cpu_baseline"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
         print(json.dumps(out), flush=True)
-        if (checks is not None and not checks["ok"]) or hist_ok is False or ("parity_prefix" in out and not out["parity_prefix"]["columns_equal_oracle"]):
-            sys.stderr.write("bench.py: a result check FAILED (see checks_full_size / hist_reduce_equals_sum_of_ranks / parity_prefix)\n")
+        if (checks is not None and not checks["ok"]) or hist_ok is False or ("parity_interior" in out and not out["parity_interior"]["all_equal"]):
+            sys.stderr.write("bench.py: a result check FAILED (see checks_full_size / hist_reduce_equals_sum_of_ranks / parity_interior)\n")
             ctx.close()
             sys.exit(3)
     ctx.close()

@@ -87,8 +87,10 @@ SYMBOLS = {
     "bgp_num_records": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
     "bgp_decode_fetch": (C.c_int, [_P, C.c_uint32, C.POINTER(Records)]),
     "bgp_decode_device": (C.c_int, [_P, C.c_uint32, C.POINTER(Records)]),
+    "bgp_decode_fetch_range": (C.c_int, [_P, C.c_uint32, C.c_uint64, C.c_uint64, C.POINTER(Records)]),
     "bgp_pileup_run": (C.c_int, [_P, C.POINTER(PileupInfo)]),
     "bgp_pileup_begin": (C.c_int, [_P, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_uint32]),
+    "bgp_pileup_begin_ref": (C.c_int, [_P, C.c_int32, C.c_int, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_uint32]),
     "bgp_pileup_next_window": (C.c_int, [_P, C.POINTER(Columns)]),
     "bgp_pileup_ref_id": (C.c_int, [_P, C.POINTER(C.c_int32)]),
     "bgp_pileup_snp": (C.c_int, [_P, C.c_int, C.c_int]),

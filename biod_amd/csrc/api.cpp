@@ -324,6 +324,42 @@ int bgp_decode_fetch(bgp_ctx* c, uint32_t what, bgp_records* o) {
     BGP_API_CATCH(c)
 }
 
+int bgp_decode_fetch_range(bgp_ctx* c, uint32_t what, uint64_t first, uint64_t count, bgp_records* o) {
+    BGP_API_TRY
+    bgp_records d;
+    BGP_TRY(bgp_decode_device(c, what, &d));
+    const uint64_t n = c->n_records;
+    if (first > n || count > n - first) return BGP_EINVAL;
+    BGP_TRY(c->h_rec.reserve((count + 2) * sizeof(bgp_record))); BGP_TRY(c->h_seq_off.reserve((count + 1) * 8)); BGP_TRY(c->h_cigar_off.reserve((count + 1) * 8));
+    // rows first .. first + count (one more than asked for, when there is one: its rec_off ends the stream slice)
+    const uint64_t rows = count + (first + count < n ? 1 : 0);
+    if (rows) BGP_HIP(hipMemcpyAsync(c->h_rec.p, d.rec + first, rows * sizeof(bgp_record), hipMemcpyDeviceToHost, c->stream));
+    BGP_HIP(hipMemcpyAsync(c->h_seq_off.p, d.seq_off + first, (count + 1) * 8, hipMemcpyDeviceToHost, c->stream));
+    BGP_HIP(hipMemcpyAsync(c->h_cigar_off.p, d.cigar_off + first, (count + 1) * 8, hipMemcpyDeviceToHost, c->stream));
+    BGP_HIP(hipStreamSynchronize(c->stream));
+    const uint64_t* so = c->h_seq_off.as<uint64_t>(); const uint64_t* co = c->h_cigar_off.as<uint64_t>();
+    const uint64_t nb = so[count] - so[0], nc = co[count] - co[0];
+    if ((what & BGP_FETCH_SEQ) && nb) { BGP_TRY(c->h_seq.reserve(nb)); BGP_HIP(hipMemcpyAsync(c->h_seq.p, d.seq + so[0], nb, hipMemcpyDeviceToHost, c->stream)); }
+    if ((what & BGP_FETCH_QUAL) && nb) { BGP_TRY(c->h_qual.reserve(nb)); BGP_HIP(hipMemcpyAsync(c->h_qual.p, d.qual + so[0], nb, hipMemcpyDeviceToHost, c->stream)); }
+    if ((what & BGP_FETCH_CIGAR) && nc) { BGP_TRY(c->h_cigar.reserve(nc * 4)); BGP_HIP(hipMemcpyAsync(c->h_cigar.p, d.cigar + co[0], nc * 4, hipMemcpyDeviceToHost, c->stream)); }
+    memset(o, 0, sizeof *o);
+    if ((what & BGP_FETCH_STREAM) && count) {
+        const bgp_record* hr = c->h_rec.as<bgp_record>();
+        const uint64_t s0 = hr[0].rec_off, s1 = rows > count ? hr[count].rec_off : c->stream_len;
+        if (s1 < s0 || s1 > c->stream_len) return BGP_EINVAL;      // (a compacted table keeps file order: cannot happen on a framed stream)
+        BGP_TRY(c->h_stream_copy.reserve(s1 - s0 + 1));
+        if (s1 > s0) BGP_HIP(hipMemcpyAsync(c->h_stream_copy.p, c->d_stream + s0, s1 - s0, hipMemcpyDeviceToHost, c->stream));
+        o->stream = c->h_stream_copy.as<uint8_t>(); o->stream_len = s1 - s0;
+    }
+    BGP_HIP(hipStreamSynchronize(c->stream));
+    o->n = count; o->rec = c->h_rec.as<bgp_record>(); o->seq_off = so; o->cigar_off = co;
+    o->seq = (what & BGP_FETCH_SEQ) ? c->h_seq.as<uint8_t>() : nullptr;
+    o->qual = (what & BGP_FETCH_QUAL) ? c->h_qual.as<uint8_t>() : nullptr;
+    o->cigar = (what & BGP_FETCH_CIGAR) ? c->h_cigar.as<uint32_t>() : nullptr;
+    return BGP_OK;
+    BGP_API_CATCH(c)
+}
+
 int bgp_pileup_run(bgp_ctx* c, bgp_pileup_info* info) {
     BGP_API_TRY
     if (!c) return BGP_EINVAL;
@@ -337,8 +373,8 @@ int bgp_pileup_run(bgp_ctx* c, bgp_pileup_info* info) {
     BGP_API_CATCH(c)
 }
 
-int bgp_pileup_begin(bgp_ctx* c, int mode, int use_md_tag, uint64_t start_from, uint64_t end_at, int skip_zero, int want_entries, uint32_t window) {
-    BGP_API_TRY
+// bgp_pileup_begin / bgp_pileup_begin_ref: `one_ref` >= 0 restricts makePileup to the reads of that reference
+static int pileup_begin_impl(bgp_ctx* c, int mode, int32_t one_ref, int use_md_tag, uint64_t start_from, uint64_t end_at, int skip_zero, int want_entries, uint32_t window) {
     if (!c || (mode != BGP_PILEUP_COLUMNS && mode != BGP_MAKE_PILEUP)) return BGP_EINVAL;
     if (!c->flushed) return BGP_ESTATE;
     BGP_HIP(hipSetDevice(c->device));
@@ -356,7 +392,11 @@ int bgp_pileup_begin(bgp_ctx* c, int mode, int use_md_tag, uint64_t start_from, 
         // first survivor lives in the first run whose max end_position reaches start_from... unless an
         // earlier read of that run already qualifies, which is the same run.
         uint32_t j = 0;
-        while (j < it.run_end && c->runs[j].end_pos < start_from) ++j;
+        if (one_ref >= 0) {                              // the reads of one reference are the whole input
+            while (j < it.run_end && c->runs[j].ref_id != one_ref) ++j;
+            if (j < it.run_end && c->runs[j].end_pos < start_from) j = it.run_end;
+        } else
+            while (j < it.run_end && c->runs[j].end_pos < start_from) ++j;
         if (j < it.run_end) { it.run = j; it.run_end = j + 1; it.ref_id = c->runs[j].ref_id; }
         else { it.run = it.run_end; }
     }
@@ -386,6 +426,18 @@ int bgp_pileup_begin(bgp_ctx* c, int mode, int use_md_tag, uint64_t start_from, 
         }
     }
     return BGP_OK;
+}
+
+int bgp_pileup_begin(bgp_ctx* c, int mode, int use_md_tag, uint64_t start_from, uint64_t end_at, int skip_zero, int want_entries, uint32_t window) {
+    BGP_API_TRY
+    return pileup_begin_impl(c, mode, -1, use_md_tag, start_from, end_at, skip_zero, want_entries, window);
+    BGP_API_CATCH(c)
+}
+
+int bgp_pileup_begin_ref(bgp_ctx* c, int32_t ref_id, int use_md_tag, uint64_t start_from, uint64_t end_at, int skip_zero, int want_entries, uint32_t window) {
+    BGP_API_TRY
+    if (ref_id < 0) return BGP_EINVAL;
+    return pileup_begin_impl(c, BGP_MAKE_PILEUP, ref_id, use_md_tag, start_from, end_at, skip_zero, want_entries, window);
     BGP_API_CATCH(c)
 }
 

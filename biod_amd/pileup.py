@@ -140,6 +140,22 @@ class Context:
                               qual=L.as_array(r.qual, int(seq_off[n]), "u1") if r.qual else None,
                               cigar=L.as_array(r.cigar, int(cigar_off[n]), "<u4") if r.cigar else None)
 
+    def decode_fetch_range(self, first: int, count: int, what: int = L.BGP_FETCH_ALL, stream: bool = False) -> "DecodedRecords":
+        """Records [first, first + count): rows, arena slices (offsets keep their stream-wide values) and, with
+        stream=True, the records' own bytes (names, tags) as `.data`, record i at rec_off[i] - rec_off[0]."""
+        r = L.Records()
+        L.check(L.lib().bgp_decode_fetch_range(self._h, what | (L.BGP_FETCH_STREAM if stream else 0), first, count, C.byref(r)), self._h)
+        n = r.n
+        seq_off = L.as_array(r.seq_off, n + 1, "<u8")
+        cigar_off = L.as_array(r.cigar_off, n + 1, "<u8")
+        nb, nc = (int(seq_off[n] - seq_off[0]), int(cigar_off[n] - cigar_off[0])) if n else (0, 0)
+        d = DecodedRecords(rec=L.as_array(r.rec, n, L.RECORD_DTYPE), seq_off=seq_off, cigar_off=cigar_off,
+                           seq=L.as_array(r.seq, nb, "u1") if r.seq else None, qual=L.as_array(r.qual, nb, "u1") if r.qual else None,
+                           cigar=L.as_array(r.cigar, nc, "<u4") if r.cigar else None)
+        d.first = first
+        d.data = L.as_array(r.stream, r.stream_len, "u1") if stream and r.stream else None
+        return d
+
     def decode_device(self, what: int = L.BGP_FETCH_ALL) -> "L.Records":
         r = L.Records()
         L.check(L.lib().bgp_decode_device(self._h, what, C.byref(r)), self._h)
@@ -154,13 +170,16 @@ class Context:
                           n_reads_used=info.n_reads_used, device_columns=info.device_columns or 0, device_depth_hist=info.device_depth_hist or 0)
 
     def pileup_windows(self, mode: int, use_md_tag=False, start_from=0, end_at=ULONG_MAX, skip_zero_coverage=True,
-                       want_entries=False, window_positions=0, snp=None, maq=None, copy=True):
+                       want_entries=False, window_positions=0, snp=None, maq=None, copy=True, ref_id=None):
         """Dense windows of columns (copy=False: the arrays are views of the ctx's pinned buffers, valid until the next
         window -- BioD's own warning about column.reads, pileup.d:660-661 -- and a window costs no host copy).  snp=(minimum_coverage, minimum_witnesses) adds simple.isSNP flags per position
         (snpcallers/simple.d:15-41, needs use_md_tag): window.snp, resolved against the entries where the device says
         BGP_SNP_NEEDS_ENTRIES and entries were requested.  maq=(depcorr, eta, minimum_base_quality) adds the MAQ model's
         call per position (snpcallers/maq.d:388-486): window.maq, a MAQ_CALL_DTYPE array."""
-        L.check(L.lib().bgp_pileup_begin(self._h, mode, int(use_md_tag), start_from, end_at, int(skip_zero_coverage), int(want_entries), window_positions), self._h)
+        if ref_id is not None:       # makePileup over the reads of one reference of the stream (bgp_pileup_begin_ref)
+            L.check(L.lib().bgp_pileup_begin_ref(self._h, int(ref_id), int(use_md_tag), start_from, end_at, int(skip_zero_coverage), int(want_entries), window_positions), self._h)
+        else:
+            L.check(L.lib().bgp_pileup_begin(self._h, mode, int(use_md_tag), start_from, end_at, int(skip_zero_coverage), int(want_entries), window_positions), self._h)
         if snp is not None:
             L.check(L.lib().bgp_pileup_snp(self._h, int(snp[0]), int(snp[1])), self._h)
         if maq is not None:

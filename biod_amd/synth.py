@@ -59,3 +59,17 @@ def host_stream_np(cfg: L.SynthCfg, first: int = 0, count: int | None = None) ->
 
 def host_stream(cfg: L.SynthCfg, first: int = 0, count: int | None = None) -> bytes:
     return host_stream_np(cfg, first, count).tobytes()
+
+
+def reads_per_contig(cfg: L.SynthCfg) -> int:
+    """synth_record.h: reads_per_contig -- record i lies on local contig i // this."""
+    return (int(cfg.n_reads) + int(cfg.n_ref) - 1) // int(cfg.n_ref)
+
+
+def max_span(cfg: L.SynthCfg) -> int:
+    """synth_record.h: max_span -- no read of the configuration covers more reference positions than this."""
+    if cfg.profile == 0:
+        return int(cfg.len_max)
+    if cfg.profile == 1:
+        return int(cfg.len_max) + 5000 + 32
+    return int(cfg.len_max) + int(cfg.len_max) // 2 + 64

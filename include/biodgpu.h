@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define BGP_ABI_VERSION 2
+#define BGP_ABI_VERSION 3
 
 /* ---- status codes -------------------------------------------------------------------------- */
 enum {
@@ -133,6 +133,16 @@ typedef struct bgp_records {
 int bgp_decode_fetch(bgp_ctx* ctx, uint32_t what, bgp_records* out);
 /* Same products left in HBM (device pointers); nothing is copied to the host. */
 int bgp_decode_device(bgp_ctx* ctx, uint32_t what, bgp_records* out_device);
+/* bgp_decode_fetch for the records [first, first + count) only -- a slice of BamReader.reads (BioD's records are slices
+ * into the inflated blocks, readrange.d:176-187; a BamRead never owns its bytes, read.d:876-883).  out->n = count;
+ * rec has count rows (rec_off stays the offset in the WHOLE stream); seq_off / cigar_off have count + 1 entries and keep
+ * their stream-wide values, so record first + i owns seq[seq_off[i] - seq_off[0] .. seq_off[i + 1] - seq_off[0]) of the
+ * returned arena slice (same for qual; cigar with cigar_off).  With BGP_FETCH_STREAM out->stream is a host copy of the
+ * stream bytes from rec_off of record `first` up to the record behind the slice (or the end of the stream), so record
+ * first + i begins at stream + (rec[i].rec_off - rec[0].rec_off): read names (read.d:218-222) and tags (read.d:1070-1087)
+ * of the reads of a window of columns without copying a stream that may not fit host memory.  first + count beyond the
+ * table is BGP_EINVAL. */
+int bgp_decode_fetch_range(bgp_ctx* ctx, uint32_t what, uint64_t first, uint64_t count, bgp_records* out);
 
 /* ---- pileup -------------------------------------------------------------------------------- */
 typedef struct bgp_column {      /* per reference position, 32 bytes (SURVEY.md 8 a-out summary) */
@@ -208,6 +218,14 @@ typedef struct bgp_columns {
 } bgp_columns;
 int bgp_pileup_begin(bgp_ctx* ctx, int mode, int use_md_tag, uint64_t start_from, uint64_t end_at,
                      int skip_zero_coverage, int want_entries, uint32_t window_positions);
+/* makePileup(bam[ref_id].reads, use_md_tag, start_from, end_at, skip_zero_coverage): bgp_pileup_begin(BGP_MAKE_PILEUP)
+ * over the reads of ONE reference of the staged stream, whichever it is -- what a BioD caller writes as
+ * makePileup(bam.reference(ref_id)[], ...) (reference.d:84-86 feeding pileup.d:683-694); makePileup itself only ever
+ * sees the first reference of its input (pileup.d:490-494).  The provider chain of use_md_tag starts afresh at that
+ * reference, as it does for a range that begins there.  A reference without covering reads gives BGP_EOF at the first
+ * window. */
+int bgp_pileup_begin_ref(bgp_ctx* ctx, int32_t ref_id, int use_md_tag, uint64_t start_from, uint64_t end_at,
+                         int skip_zero_coverage, int want_entries, uint32_t window_positions);
 int bgp_pileup_next_window(bgp_ctx* ctx, bgp_columns* out);   /* BGP_OK, BGP_EOF, or error */
 int bgp_pileup_ref_id(bgp_ctx* ctx, int32_t* ref_id);          /* AbstractPileup.ref_id, pileup.d:455 */
 

@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in include/biodgpu.h but not exported by libbiodgpu.so"
     assert declared == set(L.SYMBOLS), declared ^ set(L.SYMBOLS)
-    assert lib.bgp_abi_version() == 2          # 2: bgp_columns grew `maq`
+    assert lib.bgp_abi_version() == 3          # 2: bgp_columns grew `maq`; 3: bgp_decode_fetch_range, bgp_pileup_begin_ref
 
 
 def test_header_cites_reference_for_every_entry_point():
