@@ -105,6 +105,19 @@ struct PileupRead {
     const uint32_t* cigar_begin() const { return recs->cigar + recs->cigar_off[e->read_ordinal]; }
     const uint32_t* cigar_end() const { return recs->cigar + recs->cigar_off[e->read_ordinal + 1]; }
     uint16_t cigar_operation_index() const { return e->cigar_op_index; }       // cigar_before = [begin, begin+index), cigar_after = (begin+index, end)
+    // The BamRead accessors PileupRead forwards with `alias _read this` (pileup.d:86-112), as BioD's consumers use them
+    // (examples/read_bam_file.d:33-41, snpcallers/simple.d:24-28, maq.d:396-412): views of the host copy of the records.
+    std::vector<uint32_t> cigar() const { return std::vector<uint32_t>(cigar_begin(), cigar_end()); }                    // read.d:225-228
+    int sequence_length() const { return record().l_seq; }                                                                // read.d:923
+    std::string sequence() const {                                                                                         // read.d:438-440, chars of base.d:85
+        return std::string((const char*)recs->seq + recs->seq_off[e->read_ordinal], (size_t)(recs->seq_off[e->read_ordinal + 1] - recs->seq_off[e->read_ordinal]));
+    }
+    const uint8_t* base_qualities_begin() const { return recs->qual + recs->seq_off[e->read_ordinal]; }                  // read.d:468-470
+    std::vector<uint8_t> base_qualities() const { return std::vector<uint8_t>(base_qualities_begin(), base_qualities_begin() + record().l_seq); }
+    std::string name() const {                                                                                             // read.d:218-222: l_read_name - 1 chars behind the 32 fixed bytes
+        if (!recs->stream) throw std::logic_error("read names need the host copy of the record stream (BGP_FETCH_STREAM)");
+        return std::string((const char*)recs->stream + record().rec_off + 36, (size_t)(record().bin_mq_nl & 0xFF) - 1);
+    }
 };
 
 // PileupColumn, pileup.d:236-290
@@ -134,6 +147,10 @@ struct PileupColumn {
         return n_top == 1 ? BGP_SNP_NO : BGP_SNP_TIE;
     }
     std::string bases() const { std::string s; for (size_t i = 0; i < n_ents; ++i) s.push_back((char)ents[i].base); return s; }   // pileup.d:277
+    std::vector<uint8_t> base_qualities() const { std::vector<uint8_t> v; for (size_t i = 0; i < n_ents; ++i) v.push_back(ents[i].qual); return v; }   // pileup.d:282-284
+    std::vector<uint8_t> read_qualities() const {                              // pileup.d:287-289: mapping quality of every read of the column
+        std::vector<uint8_t> v; for (size_t i = 0; i < n_ents; ++i) v.push_back((uint8_t)((recs->rec[ents[i].read_ordinal].bin_mq_nl >> 8) & 0xFF)); return v;
+    }
     // MaqSnpCaller.makeCall(column), snpcallers/maq.d:443-486, after PileupRange::callMaq: nullptr without it; a call whose
     // flags lack BGP_MAQ_CALLED is makeCall's null (no valid base).  genotype = base1 * 5 + base2 over "ACGTN".
     const bgp_maq_call* maq_call() const { return maq_; }
@@ -147,13 +164,13 @@ class PileupRange {
 public:
     PileupRange(BamReader& r, int mode, bool use_md_tag, uint64_t start_from, uint64_t end_at, bool skip_zero_coverage, bool want_entries, uint32_t window)
         : ctx_(r.ctx()), skip_zero_(skip_zero_coverage), want_entries_(want_entries), start_(start_from), end_(end_at), mode_(mode), use_md_(use_md_tag), window_(window) {
-        if (want_entries) check(bgp_decode_fetch(ctx_, BGP_FETCH_ALL, &recs_), ctx_);
+        if (want_entries) check(bgp_decode_fetch(ctx_, BGP_FETCH_ALL | BGP_FETCH_STREAM, &recs_), ctx_);
         restart();
     }
     // element `chunk` of pileupChunks (below): the chunk's columns, [start_position, end_position) of its reference
     PileupRange(BamReader& r, uint64_t chunk, bool want_entries)
         : ctx_(r.ctx()), skip_zero_(true), want_entries_(want_entries), start_(0), end_(0), mode_(BGP_MAKE_PILEUP), use_md_(false), window_(0), chunk_((int64_t)chunk) {
-        if (want_entries) check(bgp_decode_fetch(ctx_, BGP_FETCH_ALL, &recs_), ctx_);
+        if (want_entries) check(bgp_decode_fetch(ctx_, BGP_FETCH_ALL | BGP_FETCH_STREAM, &recs_), ctx_);
         restart();
     }
     uint64_t first_record() const { return ci_.first_record; }
@@ -195,6 +212,8 @@ private:
         if (chunk_ >= 0) {                                                     // a chunk of pileupChunks: select it, its windows follow
             check(bgp_pileup_chunk(ctx_, (uint64_t)chunk_, &ci_), ctx_);
             start_ = ci_.start_position; end_ = ci_.end_position; ref_id_ = ci_.ref_id;
+            if (snp_) check(bgp_pileup_snp(ctx_, snp_cov_, snp_wit_), ctx_);   // (selecting a chunk starts a new iteration: the callers are set again)
+            if (maq_) check(bgp_pileup_maq(ctx_, maq_depcorr_, maq_eta_, maq_min_bq_), ctx_);
             done_ = false;
             fetch(); settle();
             return;

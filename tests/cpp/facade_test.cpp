@@ -11,7 +11,7 @@
 #define REQUIRE(x) do { if (!(x)) { std::fprintf(stderr, "FAILED %s:%d: %s\n", __FILE__, __LINE__, #x); return 1; } } while (0)
 
 int main(int argc, char** argv) {
-    if (argc < 3) { std::fprintf(stderr, "usage: %s ex1_header.bam illu_20_chunk.bam [bins.bam [copy_of_bins.bam]]\n", argv[0]); return 2; }
+    if (argc < 3) { std::fprintf(stderr, "usage: %s ex1_header.bam illu_20_chunk.bam [bins.bam [copy_of_bins.bam [p1_records.bin]]]\n", argv[0]); return 2; }
     using namespace biodgpu;
     {
         BamReader bam(argv[1], 2);
@@ -101,9 +101,10 @@ int main(int argc, char** argv) {
         for (auto column : pileupColumns(bam.reads(), false, true, false)) whole.push_back(((uint64_t)column.ref_id() << 40) ^ (column.position() << 8) ^ column.coverage());
         auto chunks = pileupChunks(bam.reads(), false, 2000, 0, std::numeric_limits<uint64_t>::max(), false);
         REQUIRE(chunks.size() >= 2);
-        uint64_t prev_end = 0;
+        uint64_t prev_end = 0; int prev_ref = -1;
         for (auto chunk : chunks) {
-            REQUIRE(chunk.start_position() >= prev_end || chunk.start_position() == 0 || true);
+            if (chunk.ref_id() == prev_ref) REQUIRE(chunk.start_position() == prev_end);      // the seam rule: a chunk begins where the previous one of its reference ended (pileup.d:905-913)
+            prev_ref = chunk.ref_id();
             for (auto column : chunk) {
                 REQUIRE(column.position() >= chunk.start_position() && column.position() < chunk.end_position());
                 piece.push_back(((uint64_t)column.ref_id() << 40) ^ (column.position() << 8) ^ column.coverage());
@@ -111,6 +112,13 @@ int main(int argc, char** argv) {
             prev_end = chunk.end_position();
         }
         REQUIRE(whole == piece);
+        // mapping a caller over the chunks -- the reference's main use of pileupChunks: callMaq on an element holds
+        size_t chunk_calls = 0;
+        for (auto chunk : pileupChunks(bam.reads(), false, 2000)) {
+            chunk.callMaq();
+            for (auto column : chunk) { REQUIRE(column.maq_call() != nullptr); chunk_calls += (column.maq_call()->flags & BGP_MAQ_CALLED) != 0; }
+        }
+        REQUIRE(chunk_calls == calls);
     }
     if (argc > 3) {                                                      // unittests.d:145-185: bam["large"][beg .. end] == naive filter
         BamReader all(argv[3], 2);
@@ -137,6 +145,45 @@ int main(int argc, char** argv) {
                 naive += recs.rec[i].ref_id == 2 && recs.rec[i].pos < rg[1] && recs.rec[i].end_pos > rg[0];
             REQUIRE(bam.fetch(copy, "large", (uint32_t)rg[0], (uint32_t)rg[1], 2).num_reads() == naive);
         }
+    }
+    if (argc > 5) {                                                      // the reference's own pileup unittest (pileup.d:699-826) through the facade, accessors included
+        std::FILE* f = std::fopen(argv[5], "rb"); REQUIRE(f != nullptr);
+        std::vector<uint8_t> st(1 << 16); st.resize(std::fread(st.data(), 1, st.size(), f)); std::fclose(f);
+        BamReader bam(st.data(), st.size());
+        const char* seqs[10] = {"ATTATGGACATTGTTTCCGTTATCATCATCATCATCATCATCATCATTATCATC", "GACATTGTTTCCGTTATCATCATCATCATCATCATCATCATCATCATCATCATC",
+                                "ATTGTTTCCGTTATCATCATCATCATCATCATCATCATCATCATCATCATCACC", "TGTTTCCGTTATCATCATCATCATCATCATCATCATCATCATCATCATCACCAC",
+                                "TCCGTTATCATCATCATCATCATCATCATCATCATCATCATCATCACCACCACC", "GTTATCATCATCATCATCATCATCATCATCATCATCATCATCATCGTCACCCTG",
+                                "TCATCATCATCATAATCATCATCATCATCATCATCATCGTCACCCTGTGTTGAG", "TCATCATCATCGTCACCCTGTGTTGAGGACAGAAGTAATTTCCCTTTCTTGGCT",
+                                "TCATCATCATCATCACCACCACCACCCTGTGTTGAGGACAGAAGTAATATCCCT", "CACCACCACCCTGTGTTGAGGACAGAAGTAATTTCCCTTTCTTGGCTGGTCACC"};   // pileup.d:709-718
+        auto pileup = makePileup(bam.reads(), true, 796, 849, false);
+        REQUIRE(pileup.front().position() == 796 && pileup.start_position() == 796 && pileup.end_position() == 849);   // pileup.d:766-768
+        size_t seen = 0;
+        for (auto column : pileup) {
+            const auto reads = column.reads();
+            REQUIRE(reads.size() == column.coverage());
+            const auto bq = column.base_qualities(); const auto rq = column.read_qualities();
+            REQUIRE(bq.size() == reads.size() && rq.size() == reads.size());
+            for (size_t i = 0; i < reads.size(); ++i) {
+                const auto& r = reads[i];
+                REQUIRE(r.name() == "r" + std::to_string(r.read_ordinal()));                  // pileup.d:707
+                REQUIRE(r.sequence() == seqs[r.read_ordinal()] && r.sequence_length() == 54);
+                REQUIRE(r.base_qualities().size() == 54 && r.base_qualities()[0] == 0xFF);    // no qualities given: 0xFF, read.d:748
+                REQUIRE(rq[i] == r.mapping_quality() && bq[i] == r.current_base_quality());
+                if (r.current_base() != '-') REQUIRE(r.current_base() == r.sequence()[r.query_offset()]);   // pileup.d:115-122
+                REQUIRE(r.cigar().size() == (size_t)(r.cigar_end() - r.cigar_begin()) && r.cigar()[r.cigar_operation_index()] == r.cigar_operation());
+            }
+            switch (column.position()) {                                                       // pileup.d:785-822
+                case 796: REQUIRE(column.bases() == "CCCCCCAC"); ++seen; break;
+                case 805: REQUIRE(column.bases() == "TCCCCCCCC"); ++seen; break;
+                case 806: REQUIRE(column.bases() == "AAAAAAAGA"); ++seen; break;
+                case 810: { const auto& r = reads[column.coverage() - 2]; REQUIRE((r.cigar_begin()[r.cigar_operation_index() + 1] & 15) == 2); ++seen; break; }    // cigar_after.front.type == 'D'
+                case 817: { const auto& r = reads[column.coverage() - 2]; REQUIRE((r.cigar_begin()[r.cigar_operation_index() - 1] & 15) == 1); ++seen; break; }    // cigar_before.back.type == 'I'
+                case 821: REQUIRE((reads[column.coverage() - 3].cigar_operation() & 15) == 2); REQUIRE(column.bases() == "AAGG-AA"); ++seen; break;
+                case 826: REQUIRE(column.bases() == "CCCCCC"); ++seen; break;
+                default: break;
+            }
+        }
+        REQUIRE(seen == 7);
     }
     std::puts("facade ok");
     return 0;

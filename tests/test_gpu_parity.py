@@ -422,7 +422,10 @@ def test_cpp_facade(tmp_path, data_dir):
     import shutil
     copy = str(tmp_path / "bins_copy.bam")
     shutil.copy(os.path.join(data_dir, "bins.bam"), copy)
-    out = subprocess.run([exe, os.path.join(data_dir, "ex1_header.bam"), os.path.join(data_dir, "illu_20_chunk.bam"), os.path.join(data_dir, "bins.bam"), copy],
+    from test_oracle_kats import p1_stream
+    p1 = str(tmp_path / "p1_records.bin")            # the ten literal reads of the reference's pileup unittest (pileup.d:699-749) as record bytes
+    open(p1, "wb").write(p1_stream())
+    out = subprocess.run([exe, os.path.join(data_dir, "ex1_header.bam"), os.path.join(data_dir, "illu_20_chunk.bam"), os.path.join(data_dir, "bins.bam"), copy, p1],
                          capture_output=True, text=True)
     assert out.returncode == 0 and "facade ok" in out.stdout, out.stderr
 
