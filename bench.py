@@ -128,8 +128,9 @@ def cpu_baseline(cfg_name, n_sample):
         t0 = time.perf_counter(); O.pileup_bench(probe, 1); dt = max(time.perf_counter() - t0, 1e-4)
         n_sample = int(min(max(8.0 / (dt / n_probe), n_probe), 3_000_000))      # ~8 CPU-seconds of pileup work per run, three runs
         if cfg_name != "cfg5":
-            # every thread needs work: pileupChunks cuts 16 384 000-byte chunks (~56k reads); give each core two
-            n_sample = int(min(max(n_sample, cores * 2 * 56_000), 32_000_000))
+            # every thread needs work: pileupChunks cuts 16 384 000-byte chunks (~56k reads); and 10 M reads (a tenth of cfg3,
+            # ~3 s a run on 16 cores) keep the run-to-run spread of a 3 M-read sample out of the figure
+            n_sample = int(min(max(n_sample, cores * 2 * 56_000, 10_000_000), 32_000_000))
     stream = host_stream_np(scaled(cfg_name, n_sample))
     rates, rp = [], None
     for _ in range(3):
@@ -143,9 +144,12 @@ def cpu_baseline(cfg_name, n_sample):
            "sample": f"{n_sample} reads of {cfg_name}'s read model at its coverage depth ({len(stream) / 1e6:.0f} MB inflated), "
                      f"pileupChunks-style decomposition over {cores} threads (= usable cores: {os.cpu_count()} logical CPUs, affinity and cgroup quota applied), "
                      f"consumer touches coverage/n_starting_here/every base+quality; median of 3 runs"}
-    if n_sample <= 400_000:
-        t0 = time.perf_counter(); O.pileup_bench(stream, 1); ts = time.perf_counter() - t0
-        out["serial_value"] = round(n_sample / ts / 1e6, 4)
+    # the serial sweep (one thread, BioD's pileupColumns as it is written) beside the threaded decomposition
+    n_ser = min(n_sample, 1_000_000 if cfg_name != "cfg5" else n_sample)
+    ser = stream if n_ser == n_sample else host_stream_np(scaled(cfg_name, n_ser))
+    t0 = time.perf_counter(); O.pileup_bench(ser, 1); ts = time.perf_counter() - t0
+    out["serial_value"] = round(n_ser / ts / 1e6, 4)
+    out["serial_sample_reads"] = n_ser
     return out
 
 

@@ -167,7 +167,9 @@ def check(rc: int, ctx=None) -> int:
 
 def as_array(ptr, count, dtype, copy=True):
     """`count` items of `dtype` from a host pointer owned by the ctx: a copy, or (copy=False) a view of the ctx's own
-    pinned buffer -- valid until the next call that hands out a window, as the C ABI says."""
+    pinned buffer -- its CONTENT is valid until the next call that hands out a window, as the C ABI says; the memory
+    itself stays mapped until bgp_reset / bgp_destroy (a buffer a larger window replaces is retired, not freed), so a
+    view kept too long reads stale bytes, never freed memory."""
     count = int(count)
     if not ptr or count == 0:
         return np.zeros(0, dtype)

@@ -17,15 +17,27 @@ void bgp_note_hip_error(hipError_t e, const char* what, const char* file, int li
     if (getenv("BGP_VERBOSE")) fprintf(stderr, "[biodgpu] %s\n", buf);
 }
 
-static int fuse_mode() { const char* e = getenv("BGP_FUSE_MODE"); return e ? atoi(e) : 2; }   // 0: chase-based K1, then K2; 1: K1+K2 fused; 2: parallel K1 from the side offsets, then K2
+// Decode implementations that were measured and lost are kept out of the product: they are compiled only with
+// `make EXPERIMENTS=1` (-DBGP_EXPERIMENTS), where environment switches select them and tests/test_gpu_single_pass.py runs them
+// (DESIGN.md section 4 has their measurements).  The product has ONE path per call: bgp_flush = K0 + k1_rows,
+// bgp_decode_* = k2_unpack, bgp_flush_decode(all sections) = K0 + k12_lds (k1_rows + k2_unpack when the records are too long
+// for its windows).
+#ifdef BGP_EXPERIMENTS
+static int fuse_mode() { const char* e = getenv("BGP_FUSE_MODE"); return e ? atoi(e) : 2; }   // 0: chase-based K1 (k1_emit), then K2; 1: K1+K2 fused (k12_fused); 2: k1_rows from the side offsets, then k2_unpack
+static int lds_mode() { const char* e = getenv("BGP_LDS_DECODE"); return e ? atoi(e) : 1; }    // 0: bgp_flush_decode uses k1_rows + k2_unpack instead of k12_lds
+static int frame_mode() { const char* e = getenv("BGP_FRAME_MODE"); return e ? atoi(e) : 0; }  // 1: framing, table and arenas in one pass (k_stream_decode: exact, 29-31 ms against 17.7)
 static int ensure_table(bgp_ctx* c) { return !c->table_pending ? BGP_OK : (fuse_mode() == 0 ? k1_table(c) : k12_fused_decode(c, 0)); }
-
-static int lds_mode() { const char* e = getenv("BGP_LDS_DECODE"); return e ? atoi(e) : 1; }      // bgp_flush_decode(all sections): K1 + K2 as one kernel over LDS windows (k12_lds) when K0's segments allow it; 0: k1_rows, k2_unpack
-static int frame_mode() { const char* e = getenv("BGP_FRAME_MODE"); return e ? atoi(e) : 0; }   // 0: K0, K1, K2 as separate kernels (22.5 ms on cfg3); 1: framing, table and arenas in one pass through LDS windows (k_stream_decode: exact, but 29-31 ms -- DESIGN.md says why)
+extern "C" int bgp_experiments_built(void) { return 1; }       // (not part of the ABI: lets the tests see which build they drive)
+#else
+static constexpr int fuse_mode() { return 2; }
+static constexpr int lds_mode() { return 1; }
+static constexpr int frame_mode() { return 0; }
+static int ensure_table(bgp_ctx* c) { return !c->table_pending ? BGP_OK : k12_fused_decode(c, 0); }
+#endif
 
 // framing + record table (+ the arenas of `what`) of the stream c->d_stream points at (bgp_flush / bgp_flush_decode after the upload; a batch of batch.cpp)
 int flush_core(bgp_ctx* c, uint32_t what) {
-    c->piled = false; c->md_rows_ready = false; c->decoded_what = 0;
+    c->piled = false; c->md_rows_ready = false; c->decoded_what = 0; c->table_compacted = false;
     if (c->region_pending) what = 0;                     // the arenas are made for the records the filter keeps
     int rc = 1;
     if (frame_mode() == 1) { rc = k012_stream_decode(c, what); if (rc < 0) return rc; }
@@ -213,9 +225,10 @@ int bgp_reset(bgp_ctx* c) {
     if (!c) return BGP_EINVAL;
     BGP_HIP(hipStreamSynchronize(c->stream));
     batch_release(c);
+    for (HostBuf* hb : {&c->h_rec, &c->h_seq_off, &c->h_cigar_off, &c->h_seq, &c->h_qual, &c->h_cigar, &c->h_cols, &c->h_entry_off, &c->h_entries, &c->h_refbase, &c->h_snp, &c->h_maq, &c->h_stream_copy}) hb->trim();
     c->h_stage_len = 0; c->d_stream = nullptr; c->stream_len = 0; c->stream_on_device = false;
     c->flushed = false; c->piled = false; c->md_rows_ready = false; c->table_pending = false; c->n_records = 0; c->decoded_what = 0; c->it = bgp_ctx::Iter();
-    c->hints.clear(); c->runs.clear(); c->chunks.clear(); c->chunks_ready = false; c->stage_map.clear(); c->region_pending = false; c->bai_buildable = false; c->cig4_ok = false; c->tilemax_ok = false;
+    c->hints.clear(); c->runs.clear(); c->chunks.clear(); c->chunks_ready = false; c->stage_map.clear(); c->region_pending = false; c->table_compacted = false; c->bai_buildable = false; c->cig4_ok = false; c->tilemax_ok = false;
     c->refs.clear(); c->n_ref_hint = 0; c->last_error.clear(); c->bai_bytes.clear();      // nothing of the previous file survives: the loaders and bgp_set_n_ref re-establish these
     return BGP_OK;
     BGP_API_CATCH(c)

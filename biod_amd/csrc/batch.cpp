@@ -142,7 +142,9 @@ int bgp_batch_begin(bgp_ctx* c, uint64_t batch_bytes, int want_entries, uint32_t
     BGP_API_TRY
     if (!c) return BGP_EINVAL;
     BGP_HIP(hipSetDevice(c->device));
+    const int32_t n_ref_hint = c->n_ref_hint;                                // bgp_set_n_ref before bgp_batch_begin holds for every batch (bgp_reset forgets it)
     BGP_TRY(bgp_reset(c));
+    c->n_ref_hint = n_ref_hint;
     Batch* b = new Batch();
     c->batch = b; c->batch_maq = 0;
     b->batch_bytes = std::max<uint64_t>(batch_bytes ? batch_bytes : (256ull << 20), 1ull << 12);
@@ -202,6 +204,10 @@ int bgp_batch_next_window(bgp_ctx* c, bgp_columns* o) {
                 const uint64_t a = b->next_pos, e = std::min(hi, a + b->window);
                 if (c->batch_maq) { c->it.maq = 1; c->it.maq_depcorr = c->batch_maq_depcorr; c->it.maq_eta = c->batch_maq_eta; c->it.maq_min_bq = c->batch_maq_min_bq; }
                 BGP_TRY(emit_window(c, b->run, a, e, b->want_entries, 0, 0, o));
+                if (b->want_entries && b->ord_base + c->n_records > (1ull << 32)) {     // bgp_entry.read_ordinal is 32 bits wide
+                    c->last_error = "batched staging with per-read entries: the stream has more than 2^32 records (bgp_entry.read_ordinal would wrap)";
+                    return BGP_EINVAL;
+                }
                 if (b->want_entries && b->ord_base) {                    // stream-wide read ordinals
                     bgp_entry* en = c->h_entries.as<bgp_entry>();
                     const uint64_t ne = o->entry_off[o->n_positions];

@@ -53,13 +53,15 @@ struct DevBuf {
 struct HostBuf {                      // pinned host memory
     void* p = nullptr;
     size_t cap = 0;
+    std::vector<void*> retired;       // buffers a later, larger request replaced: a caller may still hold a view of one (the Python
+                                      // binding's copy=False windows, the facades' column.reads), so they live until trim() / release()
     int reserve(size_t bytes) {
         if (bytes <= cap) return BGP_OK;
         void* np = nullptr;
         size_t want = bytes + (bytes >> 3) + 4096;
         hipError_t e = hipHostMalloc(&np, want, hipHostMallocDefault);
         if (e != hipSuccess) { bgp_note_hip_error(e, "hipHostMalloc", __FILE__, __LINE__); return BGP_ENOMEM; }
-        if (p) { (void)hipHostFree(p); }
+        if (p) retire(p);
         p = np; cap = want;
         return BGP_OK;
     }
@@ -73,7 +75,9 @@ struct HostBuf {                      // pinned host memory
         p = np; cap = want;
         return BGP_OK;
     }
-    void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+    void retire(void* q) { try { retired.push_back(q); } catch (...) { (void)hipHostFree(q); } }
+    void trim() { for (void* q : retired) (void)hipHostFree(q); retired.clear(); }       // bgp_reset: every iteration over the old results is over
+    void release() { trim(); if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
     template <class T> T* as() const { return (T*)p; }
 };
 
@@ -124,6 +128,7 @@ struct bgp_ctx {
     uint32_t seg_bytes_wanted = 0, seg_window_shift = 0, seg_windows = 0;   // K0: segment size asked for (0: its own choice), split into windows of 1 << shift bytes whose prefix counts the chase records (k12_lds); windows per segment of the framing at hand
     DevBuf d_seg_sub;
     bool frame_tolerant_tail = false; uint64_t frame_tail = 0;   // batched staging (batch.cpp): a stream may end inside a record; where the record chain stopped
+    bool table_compacted = false;                     // a region filter compacted the record table: records the filter dropped still lie between the kept ones in the stream
     bool table_pending = false, long_cigar = false;   // the record table is written lazily: by k1_table, or by the fused K1+K2 if a decode comes first
     DevBuf d_scan_tmp;
     DevBuf d_sd_desc; int sd_timer_idx = -1;         // single-pass decode (decode.hip: k_stream_decode): control words + one 64-byte descriptor per chunk
@@ -259,7 +264,7 @@ __device__ __forceinline__ K3Key k3_key_of(int32_t ref_id, int32_t pos, int32_t 
 // Is there a plausible record header at stream offset o?  (readrange.d:118-173 reads block_size, then the fixed fields
 // of read.d:907-931: the test is what those fields can hold in a well-formed record.)  Only ever a GUESS for where a
 // chain of records may be entered; every boundary is verified by the chain itself.
-__device__ __forceinline__ bool plausible(const uint8_t* s, uint64_t len, uint64_t o, int32_t ref_bound, uint32_t* bs_out) {
+__device__ __forceinline__ bool plausible(const uint8_t* s, uint64_t len, uint64_t o, int32_t ref_bound, uint32_t* bs_out, bool printable_name = true) {
     if (o + 36 > len) return false;
     const uint32_t bs = ld_u32(s + o);
     *bs_out = bs;
@@ -273,6 +278,7 @@ __device__ __forceinline__ bool plausible(const uint8_t* s, uint64_t len, uint64
     const uint64_t need = 32ull + l_name + 4ull * n_cig + (uint64_t)((lseq + 1) / 2) + (uint64_t)lseq;
     if (need > bs) return false;
     if (s[o + 36 + l_name - 1] != 0) return false;             // read name is NUL terminated
+    if (!printable_name) return true;                          // (the second, relaxed pass of the guesser: frame.hip)
     // ... and printable (SAM spec: [!-?A-~]{1,254}).  This is what tells a header from the same bytes read four or
     // eight bytes early: shifted, block_size lands in the reference field, position in bin_mq_nl, ... all in range,
     // but the "name" then starts in the zero bytes of next_pos / tlen.  (A file whose names are not printable is framed

@@ -347,7 +347,7 @@ constexpr u64 G_VAL = (1ull << 56) - 1, G_NONE = G_VAL, G_STOP = G_VAL - 1, G_A 
 constexpr uint32_t L_ROFF = SD_WIN + 32;                              // u16[SD_RMAX]: where the chunk's records start (window offsets)
 constexpr uint32_t L_TAB = (L_ROFF + 2 * SD_RMAX + 15) & ~15u;        // emission tables: soff u32[257] | coff u32[257] | info u16[3 x 256] -- before that, the sub-chunks' own offset lists
 constexpr uint32_t L_SOFF = L_TAB, L_COFF = L_TAB + 1040, L_INFO = L_TAB + 2080;
-constexpr uint32_t L_SUB = L_TAB;                                     // u16[SD_NS][SD_SUBCAP]
+[[maybe_unused]] constexpr uint32_t L_SUB = L_TAB;                                     // u16[SD_NS][SD_SUBCAP]
 constexpr uint32_t L_MISC = L_INFO + 1536;                            // u64[84]
 constexpr uint32_t L_TOTAL = L_MISC + 8 * 84;
 static_assert(SD_WIN + 32 <= 65535 && SD_NS * SD_SUBCAP * 2 <= 2080 + 1536, "the sub-chunk lists overlay the emission tables");
@@ -435,7 +435,7 @@ __device__ __forceinline__ bool name_ok_wave(const uint32_t* w, uint32_t o, uint
     return __ballot(bad) == 0;
 }
 // `plausible` + a plausible successor for the candidate at stream offset o, evaluated by the whole wave (uniform)
-__device__ __forceinline__ bool candidate_ok_wave(const SdArgs& a, const uint32_t* w, uint64_t wbase, uint32_t lim, uint64_t o, int lane) {
+[[maybe_unused]] __device__ __forceinline__ bool candidate_ok_wave(const SdArgs& a, const uint32_t* w, uint64_t wbase, uint32_t lim, uint64_t o, int lane) {
     uint64_t cur = o;
     for (int d = 0; d < 2; ++d) {
         if (d && a.len - cur < 4) return true;                                       // the chain ends with the stream
@@ -556,7 +556,7 @@ __device__ __forceinline__ uint32_t sd_chase_sub(const SdArgs& a, const uint32_t
 
 // Sections of a sub-chunk's chased records checked (what k0_chase checks hop by hop: readrange.d:118-173 and the bounds
 // read.d's accessors rely on), l_seq and n_cigar_op summed up to the first bad record.  One wave, lane = record.
-__device__ __forceinline__ uint32_t sd_validate_sub(const uint32_t* w, const uint16_t* tab, uint32_t cq, int lane, u64* ls_out, u64* nc_out) {
+[[maybe_unused]] __device__ __forceinline__ uint32_t sd_validate_sub(const uint32_t* w, const uint16_t* tab, uint32_t cq, int lane, u64* ls_out, u64* nc_out) {
     uint32_t good = cq;
     u64 ls = 0, nc = 0; uint32_t lng = 0;
     for (int pass = 0; pass < 2; ++pass) {
@@ -597,7 +597,7 @@ __device__ __forceinline__ uint32_t sd_validate_sub_serial(const uint32_t* w, co
 // The chunk's chain of records put together from its sub-chunks (one thread).  The chain stands at `cur`; a sub-chunk it
 // enters exactly at the sub-chunk's own guess brings its list as it is, any other is chased again from where the chain
 // stands.  Leaves the sub-chunks' counts (M_SUBC), the chunk's count, exit, status and the end of its last record.
-__device__ __forceinline__ void sd_link(const SdArgs& a, const uint32_t* w, uint16_t* sub, u64* misc, uint64_t wbase, uint64_t cend, u64 cur) {
+[[maybe_unused]] __device__ __forceinline__ void sd_link(const SdArgs& a, const uint32_t* w, uint16_t* sub, u64* misc, uint64_t wbase, uint64_t cend, u64 cur) {
     uint32_t total = 0, err = 0;
     u64 ls = 0, nc = 0;
     bool ended = cur == G_NONE || cur == G_STOP || cur < wbase;
@@ -629,7 +629,7 @@ __device__ __forceinline__ void sd_link(const SdArgs& a, const uint32_t* w, uint
 }
 
 // The look-back of chunk k (> 0), one wave: true entry, records / bases / ops in front of the chunk -> misc[M_ENT .. M_PNC].
-__device__ __forceinline__ void sd_lookback(const SdArgs& a, uint64_t k, int lane, u64* misc) {
+[[maybe_unused]] __device__ __forceinline__ void sd_lookback(const SdArgs& a, uint64_t k, int lane, u64* misc) {
     uint32_t spins = 0;
     for (;;) {                                            // (again from the nearest predecessor after a wait)
         u64 acc_n = 0, acc_ls = 0, acc_nc = 0, e_cand = 0;
@@ -836,6 +836,7 @@ __device__ __forceinline__ void sd_emit(const SdArgs& a, uint8_t* sd_lds, uint64
     }
 }
 
+#ifdef BGP_EXPERIMENTS                         // the one-pass decode: exact, measured, slower -- not in the product build
 template <bool SEQ, bool QUAL, bool CIG>
 __global__ __launch_bounds__(SD_T, BGP_SD_MINW) void k_stream_decode(SdArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t sd_lds[];
@@ -981,6 +982,7 @@ __global__ __launch_bounds__(SD_T, BGP_SD_MINW) void k_stream_decode(SdArgs a) {
 #endif
   }
 }
+#endif
 
 
 // ---------------------------------------------------------------------------------------------- K1 + K2 through LDS windows
@@ -1129,6 +1131,9 @@ int k12_fused_decode(bgp_ctx* c, uint32_t what) {
 
 // K0 + K1 (+ K2 for `what`) in one pass over the stream: framing, record table, arenas (k_stream_decode above).
 // Returns 1 if the pass gave up (a look-back that never resolved: not expected; the caller then takes the three-kernel path).
+#ifndef BGP_EXPERIMENTS
+int k012_stream_decode(bgp_ctx*, uint32_t) { return 1; }     // not built: the caller takes K0 + K1 + K2
+#else
 int k012_stream_decode(bgp_ctx* c, uint32_t what) {
     const uint64_t len = c->stream_len;
     c->n_records = 0; c->sum_lseq = 0; c->sum_ncig = 0;
@@ -1258,6 +1263,7 @@ int k012_stream_decode(bgp_ctx* c, uint32_t what) {
     }
     return BGP_EDEVICE;
 }
+#endif
 
 // K1 + K2 through LDS windows (k12_lds): when K0 framed the stream in SD_C-byte segments and every section is wanted
 #ifndef BGP_LDS_WIN_PER_SEG

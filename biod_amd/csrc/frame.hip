@@ -31,6 +31,7 @@ struct FrameArgs {
     uint32_t* side; uint32_t side_cap;   // side[k * side_cap + j] = offset of segment k's j-th record relative to the segment start
     const uint64_t* seg_hint;            // per segment: the smallest offset inside it where the caller says a record starts (NONE: no word), or null
     int tolerant_tail;                   // batched staging: the data may end inside a record -- the chain stops in front of it instead of ETRUNC
+    int retry;                           // k0_guess, second pass: only segments the first pass found nothing in, names need not be printable (ref_bound is the widest then)
     uint4* sub; uint32_t sub_n, sub_shift;   // k12_lds: a segment is sub_n windows of 1 << sub_shift bytes; sub[k * sub_n + w] = records, bases, CIGAR ops of segment k in front of window w (null: not wanted)
 };
 
@@ -40,10 +41,12 @@ __global__ __launch_bounds__(256) void k0_guess(FrameArgs a) {
     const int lane = threadIdx.x & 63;
     if (k >= a.n_seg) return;
     if (k == 0) { if (lane == 0) a.entry[0] = 0; return; }
+    if (a.retry && a.entry[k] != NONE) return;
+    const bool names = !a.retry;
     const uint64_t beg = k * a.seg_bytes;
     const uint64_t lim = min(beg + a.seg_bytes, a.len);
     uint64_t found = NONE;
-    if (a.seg_hint) {                                   // the caller's hint (bgp_push_inflated: first_record_uoffset): tried first, by the same test as any candidate
+    if (a.seg_hint && !a.retry) {                       // the caller's hint (bgp_push_inflated: first_record_uoffset): tried first, by the same test as any candidate
         const uint64_t h = a.seg_hint[k];
         uint32_t bs = 0, dummy;
         if (h != NONE && h >= beg && h < lim && plausible(a.s, a.len, h, a.ref_bound, &bs)) {
@@ -54,14 +57,14 @@ __global__ __launch_bounds__(256) void k0_guess(FrameArgs a) {
     for (uint64_t base = beg; base < lim && found == NONE; base += 64) {
         const uint64_t o = base + lane;
         uint32_t bs = 0;
-        const bool ok = o < lim && plausible(a.s, a.len, o, a.ref_bound, &bs);
+        const bool ok = o < lim && plausible(a.s, a.len, o, a.ref_bound, &bs, names);
         unsigned long long m = __ballot(ok);
         while (m) {
             const int l = __ffsll((long long)m) - 1;
             const uint32_t bsl = __shfl(bs, l, 64);
             const uint64_t nxt = base + l + 4 + bsl;
             uint32_t dummy;
-            if (a.len - nxt < 4 || plausible(a.s, a.len, nxt, a.ref_bound, &dummy)) { found = base + l; break; }
+            if (a.len - nxt < 4 || plausible(a.s, a.len, nxt, a.ref_bound, &dummy, names)) { found = base + l; break; }
             m &= m - 1;
         }
     }
@@ -77,11 +80,13 @@ __global__ __launch_bounds__(256) void k0_guess_wide(FrameArgs a) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     if (k >= a.n_seg) return;
     if (k == 0) { if (threadIdx.x == 0) a.entry[0] = 0; return; }
+    if (a.retry && a.entry[k] != NONE) return;          // (the same word for every thread of the workgroup; written only by thread 0 after the last barrier)
+    const bool names = !a.retry;
     const uint64_t beg = k * a.seg_bytes;
     const uint64_t lim = min(beg + a.seg_bytes, a.len);
     if (threadIdx.x == 0) {
         uint64_t f = NONE;
-        if (a.seg_hint) {
+        if (a.seg_hint && !a.retry) {
             const uint64_t h = a.seg_hint[k];
             uint32_t bs = 0, dummy;
             if (h != NONE && h >= beg && h < lim && plausible(a.s, a.len, h, a.ref_bound, &bs)) {
@@ -97,14 +102,14 @@ __global__ __launch_bounds__(256) void k0_guess_wide(FrameArgs a) {
         uint64_t mine = NONE;
         const uint64_t o = base + lane;
         uint32_t bs = 0;
-        const bool ok = o < lim && plausible(a.s, a.len, o, a.ref_bound, &bs);
+        const bool ok = o < lim && plausible(a.s, a.len, o, a.ref_bound, &bs, names);
         unsigned long long m = __ballot(ok);
         while (m) {
             const int l = __ffsll((long long)m) - 1;
             const uint32_t bsl = __shfl(bs, l, 64);
             const uint64_t nxt = base + l + 4 + bsl;
             uint32_t dummy;
-            if (a.len - nxt < 4 || plausible(a.s, a.len, nxt, a.ref_bound, &dummy)) { mine = base + l; break; }
+            if (a.len - nxt < 4 || plausible(a.s, a.len, nxt, a.ref_bound, &dummy, names)) { mine = base + l; break; }
             m &= m - 1;
         }
         if (lane == 0 && mine != NONE) atomicMin(&s_found, (unsigned long long)mine);
@@ -156,7 +161,16 @@ __global__ __launch_bounds__(256) void k0_chase(FrameArgs a) {
                     else {
                         const int32_t bs = (int32_t)ld_u32(a.s + off);
                         if (bs < 0) err = ST_EINVAL;
-                        else if ((uint64_t)bs > a.len - off - 4) { if (!a.tolerant_tail) err = ST_ETRUNC; }    // readrange.d:169 (a batch: the rest of the record is still to come)
+                        else if ((uint64_t)bs > a.len - off - 4) {                   // readrange.d:169; in a batch the rest of the record may still be to come --
+                            if (!a.tolerant_tail) err = ST_ETRUNC;                    // but only a record that can exist is waited for: a corrupt block_size in the
+                            else if (bs < 32 || (uint32_t)bs > (1u << 30)) err = ST_EINVAL;   // middle of a stream would otherwise be carried from batch to batch, growing,
+                            else if (a.len - off >= 24) {                             // and surface only at bgp_batch_end (the bound plausible() uses; the header
+                                uint32_t f3[3]; __builtin_memcpy(f3, a.s + off + 12, 12);     // fields that are there pass the chase's own checks)
+                                const int32_t lseq = (int32_t)f3[2];
+                                const uint32_t l_name = f3[0] & 0xFFu, n_cig = f3[1] & 0xFFFFu;
+                                if (lseq < 0 || l_name == 0 || 32ull + l_name + 4ull * n_cig + (uint64_t)((lseq + 1) / 2) + (uint64_t)lseq > (uint64_t)bs) err = ST_EINVAL;
+                            }
+                        }
                         else if (bs < 32) err = ST_EINVAL;
                         else {
                             uint32_t f3[3]; __builtin_memcpy(f3, a.s + off + 12, 12);    // bin_mq_nl, flag_nc, l_seq in one load (bs >= 32: in bounds)
@@ -224,6 +238,7 @@ struct EmitArgs {
     bgp_record* rec; uint64_t* seq_off; uint64_t* cigar_off; uint4* cig4; uint64_t n_records, sum_lseq, sum_ncig;
 };
 
+#ifdef BGP_EXPERIMENTS
 // one lane per segment: second (L2-warm) chase that writes the record table
 __global__ __launch_bounds__(256) void k1_emit(EmitArgs a) {
     const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -264,6 +279,7 @@ __global__ __launch_bounds__(256) void k1_emit(EmitArgs a) {
         off += 4 + (uint64_t)bs;
     }
 }
+#endif
 
 // basesCovered() of records with long CIGARs (read.d:255-262): a lane summing thousands of ops serially
 // stalls its whole wave in k1_emit, so those records are finished here, one wave per record, 64 ops per
@@ -335,7 +351,7 @@ int k0_frame(bgp_ctx* c) {
     a.ref_bound = c->n_ref_hint > 0 ? c->n_ref_hint : (1 << 24);
     a.tolerant_tail = c->frame_tolerant_tail ? 1 : 0;
     a.sub = nullptr; a.sub_n = 0; a.sub_shift = 0; c->seg_windows = 0;
-    a.seg_hint = nullptr;
+    a.seg_hint = nullptr; a.retry = 0;
     a.entry = c->d_seg_entry.as<uint64_t>(); a.fix = a.entry + n_seg + 1; a.end = c->d_seg_end.as<uint64_t>();
     a.cnt = c->d_seg_cnt.as<uint64_t>(); a.lseq = c->d_seg_lseq.as<uint64_t>(); a.ncig = c->d_seg_ncig.as<uint64_t>();
     a.dirty = c->d_seg_dirty.as<uint32_t>(); a.seg_err = a.dirty + n_seg;
@@ -366,8 +382,16 @@ int k0_frame(bgp_ctx* c) {
         BGP_HIP(hipMemsetAsync(a.seg_err, 0, n_seg * 4, c->stream));         // what a segment without an entry keeps: end NONE, no records
         BGP_HIP(hipMemsetAsync(a.end, 0xFF, n_seg * 8, c->stream));
         BGP_HIP(hipMemsetAsync(a.cnt, 0, n_seg * 8, c->stream)); BGP_HIP(hipMemsetAsync(a.lseq, 0, n_seg * 8, c->stream)); BGP_HIP(hipMemsetAsync(a.ncig, 0, n_seg * 8, c->stream));
-        if (n_seg <= 32768) hipLaunchKernelGGL(k0_guess_wide, dim3((unsigned)n_seg), dim3(256), 0, c->stream, a);      // few, large segments: a workgroup each
-        else hipLaunchKernelGGL(k0_guess, dim3((unsigned)((n_seg + 3) / 4)), dim3(256), 0, c->stream, a);
+        // Second pass, only over segments the first found nothing in (their waves of the first pass have exited: same stream), with
+        // the widest reference bound and without the printable-name test: a caller's wrong bgp_set_n_ref, or a file whose read names
+        // are not printable, then costs this pass instead of one lane chasing the whole stream serially (measured on cfg3's model with
+        // n_ref set to 1 where there are 8: INTEGRATION.md "Limits").  A segment that holds no record start is scanned twice.
+        for (int pass = 0; pass < 2; ++pass) {
+            FrameArgs g = a;
+            g.retry = pass; if (pass) g.ref_bound = 1 << 24;
+            if (n_seg <= 32768) hipLaunchKernelGGL(k0_guess_wide, dim3((unsigned)n_seg), dim3(256), 0, c->stream, g);      // few, large segments: a workgroup each
+            else hipLaunchKernelGGL(k0_guess, dim3((unsigned)((n_seg + 3) / 4)), dim3(256), 0, c->stream, g);
+        }
     }
     uint64_t rounds = 0;
     for (;;) {
@@ -411,6 +435,7 @@ int k0_frame(bgp_ctx* c) {
     return BGP_OK;
 }
 
+#ifdef BGP_EXPERIMENTS
 // K1 alone: the record table and arena offsets (second, L2-warm chase).  Used when the table is needed
 // before -- or without -- a decode; bgp_decode_* right after bgp_flush takes the fused kernel in decode.hip.
 int k1_table(bgp_ctx* c) {
@@ -435,6 +460,7 @@ int k1_table(bgp_ctx* c) {
     BGP_HIP(hipGetLastError());
     return BGP_OK;
 }
+#endif
 
 // basesCovered() of long-CIGAR records after the fused K1+K2 wrote the table (same pass k1_table runs)
 int k1_finish_long_cigars(bgp_ctx* c) {

@@ -1690,7 +1690,7 @@ __device__ __forceinline__ void entry_cursor(const bgp_record& r, uint32_t rr, u
 }
 
 // closed-form cursor of read r at column offset rr (see file header)
-__device__ __forceinline__ bgp_entry entry_of(const uint8_t* s, const bgp_record& r, uint32_t rr, uint32_t ordinal, const K5Args& a) {
+[[maybe_unused]] __device__ __forceinline__ bgp_entry entry_of(const uint8_t* s, const bgp_record& r, uint32_t rr, uint32_t ordinal, const K5Args& a) {
     uint32_t k, cs, qs; bool started;
     entry_cursor(r, rr, ordinal, a, &k, &cs, &qs, &started);
     return entry_walk(s, r, k, cs, qs, started, rr, ordinal);
@@ -1823,6 +1823,7 @@ __global__ __launch_bounds__(256) void k5_fill_blk(K5Args a) {
 }
 
 // one wave per column: stream-compact the overlapping reads in file order
+#ifdef BGP_EXPERIMENTS
 __global__ __launch_bounds__(256) void k5_fill(K5Args a) {
     const uint64_t col = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -1844,6 +1845,7 @@ __global__ __launch_bounds__(256) void k5_fill(K5Args a) {
         w += __popcll(m);
     }
 }
+#endif
 
 }  // namespace
 
@@ -1899,7 +1901,12 @@ int k34_pileup(bgp_ctx* c) {
     }
     // A stream of long reads (a quarter of its reads or more) is left to the general kernel entirely, on its own tiling of
     // 4096 positions; every other stream is tiled for the gather path, the general kernel taking the windows that leaves.
-    static const bool long_rows = !(getenv("BGP_LONG_ROWS") && atoi(getenv("BGP_LONG_ROWS")) == 0);     // long reads through the gather path as rows in reference coordinates (0: the general kernel, as before)
+#ifdef BGP_EXPERIMENTS
+    static const bool long_rows = !(getenv("BGP_LONG_ROWS") && atoi(getenv("BGP_LONG_ROWS")) == 0);
+#else
+    constexpr bool long_rows = true;
+#endif
+        // long reads through the gather path as rows in reference coordinates (0: the general kernel, as before)
     const bool long_stream = !long_rows && (uint64_t)st[3] * 4 >= n && st[3] > 0;
     const uint32_t tw = long_stream ? (uint32_t)WO : (uint32_t)W;
     uint64_t col_base = 0, tile_base = 0;
@@ -2147,9 +2154,12 @@ int k5_entries(bgp_ctx* c, uint32_t run_idx, uint64_t pos_begin, uint64_t pos_en
     a.entries = c->d_entries.as<bgp_entry>();
     {
         TimedRegion t(c, "k5_fill", total * 16);
+#ifdef BGP_EXPERIMENTS
         static const bool per_column = getenv("BGP_K5_PER_COLUMN") && atoi(getenv("BGP_K5_PER_COLUMN")) != 0;      // (the first version: a wave per column)
         if (per_column) hipLaunchKernelGGL(k5_fill, dim3((unsigned)((np + 3) / 4)), dim3(256), 0, c->stream, a);
-        else hipLaunchKernelGGL(k5_fill_blk, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, c->stream, a);
+        else
+#endif
+        hipLaunchKernelGGL(k5_fill_blk, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, c->stream, a);
     }
     BGP_HIP(hipGetLastError());
     *n_entries = total;

@@ -13,7 +13,8 @@
  * TaskPool workers -- bio/core/bgzf/inputstream.d:414-428): one bgp_ctx per (host thread, GPU);
  * functions taking a ctx are not re-entrant.  Ownership (mirrors bio/std/hts/bam/pileup.d:396,
  * 660-661 "storage is reused"): every pointer returned through an out-struct is owned by the ctx and
- * stays valid until the next call that produces the same kind of result, or bgp_destroy.
+ * stays valid until the next call that produces the same kind of result, or bgp_destroy (the memory behind it stays
+ * mapped until bgp_reset / bgp_destroy: a pointer kept too long reads stale bytes, never freed memory).
  *
  * There is NO CPU fallback: without a usable gfx950 device bgp_init fails with BGP_EDEVICE.
  */
@@ -241,7 +242,11 @@ int bgp_pileup_ref_id(bgp_ctx* ctx, int32_t* ref_id);          /* AbstractPileup
  *                          to be handed out -- call bgp_batch_next_window until it says BGP_EAGAIN, push the rest
  *   bgp_batch_next_window  BGP_OK (a window), BGP_EAGAIN (push more or bgp_batch_end), BGP_EOF (after bgp_batch_end)
  * Between windows the ctx describes the CURRENT batch: bgp_decode_fetch etc. see its records; bgp_batch_ordinal_base
- * gives the stream-wide ordinal of its record 0.  bgp_reset leaves the mode. */
+ * gives the stream-wide ordinal of its record 0.  bgp_reset leaves the mode.  bgp_set_n_ref before bgp_batch_begin holds
+ * for every batch.  With want_entries a stream of more than 2^32 records is BGP_EINVAL at the window whose entries would
+ * no longer fit bgp_entry.read_ordinal (columns alone have no such bound).  A record whose block_size cannot belong to a
+ * BAM record (beyond 2^30, or smaller than the sections its header announces) is BGP_EINVAL in the batch it appears in,
+ * not "the rest is still to come". */
 int bgp_batch_begin(bgp_ctx* ctx, uint64_t batch_bytes, int want_entries, uint32_t window_positions);
 int bgp_batch_push(bgp_ctx* ctx, const uint8_t* data, size_t len, size_t* taken);
 int bgp_batch_end(bgp_ctx* ctx);

@@ -1565,6 +1565,22 @@ def test_batched_staging_edges(ctx):
     with pytest.raises(L.BiodGpuError) as e:
         list(ctx.batched_windows([st[:-7]], 20_000))
     assert e.value.code == L.BGP_ETRUNC
+    # a corrupt block_size in the MIDDLE of the stream is refused in the batch it appears in (the one-shot path says ETRUNC /
+    # EINVAL at once): it is not "a record whose rest is still to come", carried and re-framed batch after batch
+    import struct
+    offs = O.frame(st)
+    n_ok = len(list(ctx.batched_windows([st], 8192, window_positions=64)))
+    for bad in (0x7FFFFFF0, 40):                                         # beyond any record | smaller than the sections its header announces
+        dmg = bytearray(st); dmg[int(offs[60]):int(offs[60]) + 4] = struct.pack("<i", bad)
+        seen = 0
+        with pytest.raises(L.BiodGpuError) as e:
+            for w in ctx.batched_windows([bytes(dmg)], 8192, window_positions=64):
+                seen += 1
+        assert e.value.code == L.BGP_EINVAL and seen < n_ok // 2          # (record 60 of 400 lies in the second of ~15 batches)
+    # bgp_set_n_ref before bgp_batch_begin survives the reset inside it (the guesser keeps its bound): same columns
+    ctx.reset(); ctx.set_n_ref(1)
+    cov = np.concatenate([w.columns["coverage"] for w in ctx.batched_windows([st], 8192)])
+    assert np.array_equal(cov[cov > 0], O.pileup(st).cov)
 
 
 def test_interval_shards_with_exact_halo_on_the_device(ctx):
@@ -1675,6 +1691,12 @@ def test_entries_after_a_region_filter(ctx, data_dir, name, rid, beg, end):
         pytest.skip("no read in the region")
     ctx.reset(); ctx.load_bam(path, 2); ctx.flush(); ctx.filter_region(rid, beg, end)
     check_pileup(ctx, exp_stream, entries=True, window=257)
+    # pileupChunks over the region's reads: chunksConsumingLessThan adds up the sizes of the reads it is GIVEN (splitter.d:65-91),
+    # not the stream bytes between them (the reads the filter dropped still lie there)
+    for block in (3000, 20_000):
+        n = ctx.pileup_chunks_begin(False, block)
+        got = [ctx.pileup_chunk(k) for k in range(n)]
+        assert [(c.first_record, c.last_record, c.ref_id, c.start_position, c.end_position) for c in got] == O.chunk_plan(exp_stream, block)
 
 
 @pytest.mark.parametrize("world", [2, 3, 5])

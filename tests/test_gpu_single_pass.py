@@ -1,6 +1,9 @@
 """bgp_flush_decode, and the ONE-PASS decode kernel behind BGP_FRAME_MODE=1 (k_stream_decode: framing by look-back over
-LDS windows, record table and arenas in the same pass).  The default path is the three kernels K0 / K1 / K2; the one-pass
-kernel is kept as an exact alternative (DESIGN.md has its measurements).  Both must give the oracle's bytes."""
+LDS windows, record table and arenas in the same pass).  The product path is K0 + k12_lds (K0 / k1_rows / k2_unpack for
+records too long for its windows); the one-pass kernel is an experiment that was measured and lost:
+it is compiled only by `make -C biod_amd/csrc EXPERIMENTS=1` into biod_amd/libbiodgpu_exp.so, and its half of these tests
+runs when that library is the one loaded (`BIODGPU_SO=biod_amd/libbiodgpu_exp.so pytest tests/test_gpu_single_pass.py -m gpu`).
+Both must give the oracle's bytes."""
 import os
 
 import numpy as np
@@ -25,6 +28,8 @@ def ctx():
 
 @pytest.fixture(params=["0", "1"], ids=["three_kernels", "one_pass"])
 def mode(request):
+    if request.param == "1" and not hasattr(L.lib(), "bgp_experiments_built"):
+        pytest.skip("the one-pass kernel is not part of the product build (make EXPERIMENTS=1)")
     old = os.environ.get("BGP_FRAME_MODE")
     os.environ["BGP_FRAME_MODE"] = request.param
     yield request.param
@@ -142,6 +147,8 @@ def test_batches_hints_and_chunks_through_the_one_pass_kernel(ctx, data_dir):
     """Batched staging (a stream that ends inside a record: the chain stops in front of it), caller hints and the
     region / chunk paths all sit on flush_core: the same tests, framing by the one-pass kernel."""
     import test_gpu_parity as T
+    if not hasattr(L.lib(), "bgp_experiments_built"):
+        pytest.skip("the one-pass kernel is not part of the product build (make EXPERIMENTS=1)")
     old = os.environ.get("BGP_FRAME_MODE")
     os.environ["BGP_FRAME_MODE"] = "1"
     try:
