@@ -1624,6 +1624,258 @@ template <bool ROWS> __global__ __launch_bounds__(GT, BGP_G_MINW) void k4_exec(G
   for (int b = t; b < HB; b += GT) { const uint32_t h = hist[b]; if (h) atomicAdd(&a.hist[b], (unsigned long long)h); }     // the range's depth histogram, once
 }
 
+// ---------------------------------------------------------------------------------------------- K4, accumulate path (round 3)
+//
+// The gather path above makes every POSITION read its bases out of class bytes staged in LDS: two passes over every base
+// (stage, gather), per-block segment lists in between, six barriers a window and 76 KB of LDS a workgroup -- two
+// workgroups a CU, whose dependent phases leave the SIMDs waiting more than half of the time (round 2's counters).
+// k4_acc runs the same plan (k4_plan's descriptors) the other way round, with nothing staged:
+//
+//   lanes lie ALONG the reads ("consecutive positions -> consecutive LDS addresses"): a lane takes eight
+//   reference positions 8m .. 8m+7 of one SEG descriptor -- one 8-byte load of packed bases, nibble-aligned with one
+//   funnel shift, eight class indices with the v_perm tables -- and adds each base to its counter with one LDS atomic
+//   (ds_add_u32, no return).  Counters are 16 bits wide, positions 2i and 2i+1 share a word, and the words of one class
+//   are laid out  plane (k >> 1) x 132 + m  for position 8m + k: in the k-th add of a chunk the lanes of a segment hit
+//   consecutive words (consecutive m), so a wave's 64 adds fall on 3-4 runs of consecutive banks -- and a lane's two
+//   positions of one word are never touched by the same instruction.  Bases outside a segment's ends go to a dummy class.
+//   Which descriptor a lane-chunk belongs to comes from a marker byte per descriptor and a wave max-scan (64 chunks a
+//   step); the loads of eight steps are in flight before the first is used.
+//
+//   A workgroup is 4 waves and 33 KB of LDS: four per CU, 16 waves whose phases are independent of each other; a window
+//   costs three barriers.  Waves draw batches of 64 descriptors from a counter in LDS.
+//
+// Same closed form, same descriptors, same columns: bit-identical to k4_exec by construction of the sums (tested against
+// the oracle by every pileup test, and against each other under BGP_K4_GATHER=1 in the experiments build).
+constexpr int AT = 256;                       // threads of a k4_acc workgroup
+constexpr int ANW = AT / 64;                  // waves
+constexpr int ABPW = (W / 64) / ANW;          // 64-position blocks a wave flushes
+constexpr int A_PST = W / 8 + 4;              // words between the four planes of a class (the +4 spreads the flush's reads over the banks)
+constexpr int A_CSW = 4 * A_PST;              // words of one class array (W / 2 counters words + padding)
+constexpr int A_U = 8;                        // steps of 64 lane-chunks whose loads are in flight together
+constexpr int A_MCAP = 64 * ((FAST_SEG + 7 + 7) / 8 + 1) + 64;     // marker bytes of a batch: 64 descriptors x chunks of the longest SEG (a ROW is cut to this many chunks a descriptor by the planner's W)
+static_assert(W == 1024 && ABPW * ANW * 64 == W, "k4_acc geometry");
+template <bool ROWS> struct ALay {
+    static constexpr int NC = ROWS ? 6 : 5;                       // A C G T other ['-' of long reads' rows]; class NC: bases outside a segment
+    static constexpr int CNT = 0;                                 // (NC + 1) x A_CSW x u32
+    static constexpr int DELD = CNT + (NC + 1) * A_CSW * 4;       // (W + 4) x u32
+    static constexpr int NST = DELD + (W + 4) * 4;                // W x u16
+    static constexpr int HIST = NST + W * 2;                      // HB x u32
+    static constexpr int MARK = HIST + HB * 4;                    // ANW x MROW bytes
+    static constexpr int MROW = ROWS ? 64 * (W / 8 + 2) + 64 : A_MCAP;
+    static constexpr int DSC = (MARK + ANW * MROW + 15) & ~15;    // ANW x 64 x uint4
+    static constexpr int MISC = DSC + ANW * 64 * 16;              // 64 x u32
+    static constexpr int BYTES = MISC + 256;
+};
+static_assert(4 * ALay<false>::BYTES <= 160 * 1024, "four k4_acc workgroups per CU");
+
+__device__ __forceinline__ uint32_t wave_scan_max_u32(uint32_t v) {      // inclusive prefix maximum over the 64 lanes (values >= 0: a lane without a source sees 0)
+    v = max(v, BGP_DPP(v, 0x111, 0xF)); v = max(v, BGP_DPP(v, 0x112, 0xF)); v = max(v, BGP_DPP(v, 0x114, 0xF)); v = max(v, BGP_DPP(v, 0x118, 0xF));
+    v = max(v, BGP_DPP(v, 0x142, 0xA)); v = max(v, BGP_DPP(v, 0x143, 0xC));
+    return v;
+}
+// four nt16 codes, one per byte -> their class indices: A 0, C 1, G 2, T 3, anything else 4
+__device__ __forceinline__ uint32_t class_idx4(uint32_t x) {
+    const uint32_t idx = x & 0x07070707u;
+    const uint32_t lo = __builtin_amdgcn_perm(0x04040402u, 0x04010004u, idx);      // codes 0..7 : other A C other | G other other other
+    const uint32_t hi = __builtin_amdgcn_perm(0x04040404u, 0x04040403u, idx);      // codes 8..15: T other other other | other ...
+    const uint32_t sel = ((x >> 1) & 0x04040404u) | 0x03020100u;
+    return __builtin_amdgcn_perm(hi, lo, sel);
+}
+__device__ __forceinline__ uint2 class_idx8(uint32_t cur) {              // eight packed bases (high nibble first, read.d:368-373) -> eight class indices in base order
+    const uint32_t ev = class_idx4((cur >> 4) & 0x0F0F0F0Fu), od = class_idx4(cur & 0x0F0F0F0Fu);
+    return make_uint2(__builtin_amdgcn_perm(od, ev, 0x05010400u), __builtin_amdgcn_perm(od, ev, 0x07030602u));
+}
+
+template <bool ROWS> __global__ __launch_bounds__(AT, 4) void k4_acc(GArgs a) {
+    using L = ALay<ROWS>;
+    constexpr int NC = L::NC;
+    extern __shared__ __attribute__((aligned(16))) uint8_t alds[];
+    uint32_t* const cnt = reinterpret_cast<uint32_t*>(alds + L::CNT);
+    uint32_t* const deld = reinterpret_cast<uint32_t*>(alds + L::DELD);
+    uint32_t* const nst = reinterpret_cast<uint32_t*>(alds + L::NST);
+    uint32_t* const hist = reinterpret_cast<uint32_t*>(alds + L::HIST);
+    uint32_t* const misc = reinterpret_cast<uint32_t*>(alds + L::MISC);      // [0] next batch of the window, [8 ..] wave totals of the '-' scan
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    uint8_t* const mark = alds + L::MARK + wave * L::MROW;
+    uint4* const dsc = reinterpret_cast<uint4*>(alds + L::DSC) + wave * 64;
+    const uint64_t nbt = a.n_tiles, per = (nbt + gridDim.x - 1) / gridDim.x;
+    const uint64_t tile_end = min(nbt, ((uint64_t)blockIdx.x + 1) * per);
+    uint64_t tile = (uint64_t)blockIdx.x * per;
+    if (tile >= tile_end) return;
+    for (int i = t; i < (L::MARK - L::CNT) / 4; i += AT) cnt[i] = 0;           // counters, deld, nst (a window leaves them zeroed again), hist (kept for the whole range)
+    if (t == 0) misc[0] = 0;
+    struct Pre { uint2 col; uint4 tt; uint32_t n; int32_t wd; };                // the next window's header, requested a window ahead (see k4_exec)
+    auto prefetch = [&](uint64_t w) {
+        Pre p;
+        const char* tp = reinterpret_cast<const char*>(a.tiles + w);
+        __builtin_memcpy(&p.col, tp + 16, 8);
+        __builtin_memcpy(&p.tt, tp + 24, 16);
+        p.n = a.wcount[w]; p.wd = a.wdel[w];
+        return p;
+    };
+    Pre pre = prefetch(tile);
+    uint32_t r_ncol = 0, r_nsum = 0, r_mx = 0; unsigned long long r_scov = 0;
+    __syncthreads();
+    for (; tile < tile_end; ++tile) {
+        asm volatile("; window header settled" : "+v"(pre.col.x), "+v"(pre.col.y), "+v"(pre.tt.x), "+v"(pre.tt.y), "+v"(pre.tt.z), "+v"(pre.tt.w), "+v"(pre.n), "+v"(pre.wd));
+        const uint64_t col_out = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)pre.col.y) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)pre.col.x);
+        const uint32_t T0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)pre.tt.x), Tend = (uint32_t)__builtin_amdgcn_readfirstlane((int)pre.tt.y);
+        const uint32_t pad = (uint32_t)__builtin_amdgcn_readfirstlane((int)pre.tt.w);
+        const uint32_t n_desc = (uint32_t)__builtin_amdgcn_readfirstlane((int)pre.n);
+        const int32_t wd = __builtin_amdgcn_readfirstlane(pre.wd);
+        if (tile + 1 < tile_end) pre = prefetch(tile + 1);
+        if (pad) continue;                                   // on the general kernel's list
+        const unsigned long long* slab = a.slab + tile * (uint64_t)SLAB_CAP;
+        // ---- accumulate: batches of 64 descriptors, drawn from misc[0]
+        for (;;) {
+            uint32_t b = 0;
+            if (lane == 0) b = atomicAdd(&misc[0], 1u);
+            b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
+            const uint32_t base = b * 64u;
+            if (base >= n_desc) break;
+            unsigned long long d = 0;
+            if (base + (uint32_t)lane < n_desc) d = slab[base + lane];
+            uint32_t kind = (uint32_t)d & 3u;
+            const uint32_t lo = ((uint32_t)d >> 3) & 0x7FFu, f14 = (uint32_t)(d >> 14);
+            const bool is_row = ROWS && kind == 3;
+            if (!ROWS && kind == 3) kind = 0;
+            const uint32_t len = is_row ? (f14 & 0x3FFu) + 1u : f14 & 0xFFu, nib = is_row ? 0u : (f14 >> 8) & 1u;
+            const uint32_t nch = (kind == 1 || is_row) ? ((lo & 7u) + len + 7u) >> 3 : 0u;      // chunks of eight aligned positions the segment touches
+            if (kind == 2) { atomicAdd(&deld[lo], 1u); atomicAdd(&deld[f14 & 0xFFFu], 0xFFFFFFFFu); }       // D / N inside the window: '-' from lo up to the op's end (pileup.d:119-121)
+            if ((kind == 1 || is_row) && (d & 4u)) atomicAdd(&nst[lo >> 1], 1u << ((lo & 1u) * 16));        // n_starting_here, pileup.d:386,422
+            const uint32_t inc = wave_scan_u32(nch), ex = inc - nch, tot = rl(inc, 63);
+            for (uint32_t o = 4u * (uint32_t)lane; o < tot; o += 256u) *reinterpret_cast<uint32_t*>(mark + o) = 0u;
+            const uint64_t src = is_row ? d >> 24 : d >> 23;
+            dsc[lane] = make_uint4((uint32_t)src, (uint32_t)(src >> 32) | (nib << 16) | ((is_row ? 1u : 0u) << 17), lo | (len << 11), ex);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (nch) mark[ex] = (uint8_t)(lane + 1);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            uint32_t carry = 0;
+            for (uint32_t c0 = 0; c0 < tot; c0 += 64u * A_U) {
+                uint2 v[A_U]; uint32_t adr[A_U], klim[A_U];        // packed bases (or a row's class bytes) | LDS word of the chunk's position 8m, plane 0, class 0 | first valid k, one past the last << 4, odd nibble << 8, row << 9
+#pragma unroll
+                for (int u = 0; u < A_U; ++u) {
+                    const uint32_t c = c0 + 64u * u + (uint32_t)lane;
+                    v[u] = make_uint2(0, 0); adr[u] = 0; klim[u] = 0;
+                    if (c0 + 64u * u >= tot) continue;
+                    const uint32_t mk = c < tot ? (uint32_t)mark[c] : 0u;
+                    uint32_t sc = wave_scan_max_u32(mk);
+                    sc = max(sc, carry);
+                    carry = rl(sc, 63);
+                    if (c < tot) {
+                        const uint4 f = dsc[sc - 1];
+                        const uint32_t flo = f.z & 0x7FFu, flen = f.z >> 11;
+                        const uint32_t m = (flo >> 3) + (c - f.w);                       // chunk of the window: positions 8m .. 8m + 7
+                        const int32_t rel = (int32_t)(8u * m) - (int32_t)flo;             // segment-relative index of position 8m (negative in the first chunk)
+                        const uint32_t k_lo = rel < 0 ? (uint32_t)(-rel) : 0u, k_hi = min(8u, flen - (uint32_t)rel);
+                        const uint64_t sb = ((uint64_t)(f.y & 0xFFFFu) << 32) | f.x;
+                        const bool row = ROWS && ((f.y >> 17) & 1u);
+                        uint32_t odd = 0;
+                        const uint8_t* p;
+                        if (row) p = a.rows + sb + rel;                                  // a row holds one class index per column
+                        else { const int32_t n0 = (int32_t)((f.y >> 16) & 1u) + rel; odd = (uint32_t)n0 & 1u; p = a.s + sb + (n0 >> 1); }
+                        __builtin_memcpy(&v[u], p, 8);
+                        adr[u] = m; klim[u] = k_lo | (k_hi << 4) | (odd << 8) | ((row ? 1u : 0u) << 9);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < A_U; ++u) {
+                    if (c0 + 64u * u >= tot) continue;
+                    const uint32_t kl = klim[u];
+                    if ((kl >> 4 & 15u) == 0) continue;                                  // (a lane behind the batch's last chunk)
+                    uint2 cb;
+                    if (ROWS && (kl >> 9 & 1u)) cb = v[u];
+                    else {
+                        const uint32_t w = (kl >> 8 & 1u) ? ((v[u].x & 0x0F0F0F0Fu) << 4) | (__builtin_amdgcn_alignbit(v[u].y, v[u].x, 12) & 0x0F0F0F0Fu) : v[u].x;
+                        cb = class_idx8(w);
+                    }
+                    {   // bases outside the segment's ends count for the dummy class
+                        const uint32_t k_lo = kl & 15u, k_hi = kl >> 4 & 15u;
+                        const unsigned long long keep = (~0ull << (8u * k_lo)) & (~0ull >> (64u - 8u * k_hi));
+                        constexpr uint32_t PADW = (uint32_t)NC * 0x01010101u;
+                        cb.x = (cb.x & (uint32_t)keep) | (PADW & ~(uint32_t)keep);
+                        cb.y = (cb.y & (uint32_t)(keep >> 32)) | (PADW & ~(uint32_t)(keep >> 32));
+                    }
+                    uint32_t* const row0 = cnt + adr[u];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const uint32_t cls = ((k < 4 ? cb.x : cb.y) >> (8 * (k & 3))) & 0xFFu;
+                        atomicAdd(row0 + cls * (uint32_t)A_CSW + (k >> 1) * A_PST, 1u << (16 * (k & 1)));
+                    }
+                }
+            }
+        }
+        __syncthreads();                                     // every add of the window is in
+        // ---- flush (as k4_exec): '-' difference array summed up, 32 contiguous bytes per position; what a lane reads it zeroes
+        const uint32_t np = Tend - T0;
+        uint32_t dl[ABPW], cA[ABPW], cC[ABPW], cG[ABPW], cT[ABPW], cO[ABPW], cD[ABPW], sw[ABPW];
+        {
+            uint32_t run = 0;
+#pragma unroll
+            for (int bb = 0; bb < ABPW; ++bb) {
+                const uint32_t p = 64 * (wave * ABPW + bb) + lane;
+                const uint32_t e = deld[p];
+                deld[p] = 0;
+                const uint32_t sc = wave_scan_u32(e);
+                dl[bb] = run + sc;
+                run += rl(sc, 63);
+                const uint32_t wi = ((p & 7u) >> 1) * A_PST + (p >> 3), sh = (p & 1u) * 16;
+                cA[bb] = (cnt[wi] >> sh) & 0xFFFFu; cC[bb] = (cnt[A_CSW + wi] >> sh) & 0xFFFFu; cG[bb] = (cnt[2 * A_CSW + wi] >> sh) & 0xFFFFu;
+                cT[bb] = (cnt[3 * A_CSW + wi] >> sh) & 0xFFFFu; cO[bb] = (cnt[4 * A_CSW + wi] >> sh) & 0xFFFFu;
+                cD[bb] = ROWS ? (cnt[5 * A_CSW + wi] >> sh) & 0xFFFFu : 0u;
+                sw[bb] = nst[p >> 1];
+                if ((p & 1u) == 0) {                         // (two lanes share a word: both have read it -- the wave runs in lockstep)
+                    cnt[wi] = 0; cnt[A_CSW + wi] = 0; cnt[2 * A_CSW + wi] = 0; cnt[3 * A_CSW + wi] = 0; cnt[4 * A_CSW + wi] = 0;
+                    if (ROWS) cnt[5 * A_CSW + wi] = 0;
+                    nst[p >> 1] = 0;
+                }
+            }
+            if (t == 0) { deld[W] = 0; misc[0] = 0; }       // (an op that ends with the window leaves its -1 here) | the next window's batches
+            if (lane == 0) misc[8 + wave] = run;
+            __syncthreads();
+            uint32_t carry = (uint32_t)wd;
+            for (int k = 0; k < wave; ++k) carry += misc[8 + k];
+#pragma unroll
+            for (int bb = 0; bb < ABPW; ++bb) dl[bb] += carry;
+        }
+        bgp_column* out = a.cols + col_out;
+        uint32_t ncol = 0, scov = 0, nsum = 0, mx = 0;
+#pragma unroll
+        for (int bb = 0; bb < ABPW; ++bb) {
+            const uint32_t p = 64 * (wave * ABPW + bb) + lane;
+            if (p < np) {
+                const uint32_t D = dl[bb] + cD[bb], S = (sw[bb] >> ((p & 1u) * 16)) & 0xFFFFu;
+                const uint32_t cov = cA[bb] + cC[bb] + cG[bb] + cT[bb] + cO[bb] + D;
+                uint4* o4 = reinterpret_cast<uint4*>(out + p);
+                o4[0] = make_uint4(cov, S, cA[bb], cC[bb]);
+                o4[1] = make_uint4(cG[bb], cT[bb], cO[bb], D);
+                ncol += cov > 0; scov += cov; mx = max(mx, cov); nsum += S;
+                if (cov < (uint32_t)HB) atomicAdd(&hist[cov], 1u);
+                else atomicAdd(&a.hist[min(cov, (uint32_t)BGP_DEPTH_BINS - 1)], 1ull);
+            }
+        }
+        r_ncol += ncol; r_nsum += nsum; r_mx = max(r_mx, mx); r_scov += scov;
+        __syncthreads();                                     // the counters are zero again and misc[8..] is read: the next window may add
+    }
+    {   // the range's totals (see k4_exec)
+        const uint32_t w_ncol = wave_sum_u32(r_ncol), w_nsum = wave_sum_u32(r_nsum), w_mx = wave_max_u32(r_mx);
+        const uint32_t s0 = wave_sum_u32((uint32_t)r_scov & 0xFFFFu), s1 = wave_sum_u32((uint32_t)(r_scov >> 16) & 0xFFFFu), s2 = wave_sum_u32((uint32_t)(r_scov >> 32) & 0xFFFFu), s3 = wave_sum_u32((uint32_t)(r_scov >> 48));
+        if (lane == 0) {
+            unsigned long long* ts = a.tile_stats + (a.n_tiles + blockIdx.x) * 4;
+            if (w_ncol) atomicAdd(&ts[0], (unsigned long long)w_ncol);
+            const unsigned long long sc = ((unsigned long long)s3 << 48) + ((unsigned long long)s2 << 32) + ((unsigned long long)s1 << 16) + s0;
+            if (sc) atomicAdd(&ts[1], sc);
+            if (w_mx) atomicMax(&ts[2], (unsigned long long)w_mx);
+            if (w_nsum) atomicAdd(&ts[3], (unsigned long long)w_nsum);
+        }
+    }
+    __syncthreads();
+    for (int b = t; b < HB; b += AT) { const uint32_t h = hist[b]; if (h) atomicAdd(&a.hist[b], (unsigned long long)h); }
+}
+
 // ---------------------------------------------------------------------------------------------- K5
 
 struct K5Args {
@@ -2034,8 +2286,10 @@ int k34_pileup(bgp_ctx* c) {
             // windows, lets it balance the ranges' unequal work at the tail (cfg3: 10.5 -> 10.3 ms); the rows' instantiation is best at 512
             static const unsigned g_env = getenv("BGP_G_BLOCKS") ? (unsigned)atoi(getenv("BGP_G_BLOCKS")) : 0u;
             const unsigned g_blocks = std::min(16384u, g_env ? g_env : have_rows ? 512u : 4096u);
+            static const bool gather = getenv("BGP_K4_GATHER") && atoi(getenv("BGP_K4_GATHER")) != 0;      // round 2's k4_exec instead of k4_acc (A/B)
             if (have_rows) hipLaunchKernelGGL(k4_exec<true>, dim3((unsigned)std::min<uint64_t>(tile_base, g_blocks)), dim3(GT), (size_t)G_LDS, c->stream, g);
-            else hipLaunchKernelGGL(k4_exec<false>, dim3((unsigned)std::min<uint64_t>(tile_base, g_blocks)), dim3(GT), (size_t)G_LDS, c->stream, g);
+            else if (gather) hipLaunchKernelGGL(k4_exec<false>, dim3((unsigned)std::min<uint64_t>(tile_base, g_blocks)), dim3(GT), (size_t)G_LDS, c->stream, g);
+            else hipLaunchKernelGGL(k4_acc<false>, dim3((unsigned)std::min<uint64_t>(tile_base, g_blocks)), dim3(AT), (size_t)ALay<false>::BYTES, c->stream, g);
         }
         // windows the gather path left on the list (long reads, odd CIGARs, too deep): the general kernel
         const unsigned dgrid = (unsigned)std::min<uint64_t>(tile_base, 2048);
