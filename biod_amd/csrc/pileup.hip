@@ -1631,62 +1631,96 @@ template <bool ROWS> __global__ __launch_bounds__(GT, BGP_G_MINW) void k4_exec(G
 // workgroups a CU, whose dependent phases leave the SIMDs waiting more than half of the time (round 2's counters).
 // k4_acc runs the same plan (k4_plan's descriptors) the other way round, with nothing staged:
 //
-//   lanes lie ALONG the reads ("consecutive positions -> consecutive LDS addresses"): a lane takes eight
-//   reference positions 8m .. 8m+7 of one SEG descriptor -- one 8-byte load of packed bases, nibble-aligned with one
-//   funnel shift, eight class indices with the v_perm tables -- and adds each base to its counter with one LDS atomic
-//   (ds_add_u32, no return).  Counters are 16 bits wide, positions 2i and 2i+1 share a word, and the words of one class
-//   are laid out  plane (k >> 1) x 132 + m  for position 8m + k: in the k-th add of a chunk the lanes of a segment hit
-//   consecutive words (consecutive m), so a wave's 64 adds fall on 3-4 runs of consecutive banks -- and a lane's two
-//   positions of one word are never touched by the same instruction.  Bases outside a segment's ends go to a dummy class.
-//   Which descriptor a lane-chunk belongs to comes from a marker byte per descriptor and a wave max-scan (64 chunks a
-//   step); the loads of eight steps are in flight before the first is used.
+//   lanes lie ALONG the reads ("consecutive positions -> consecutive LDS addresses"): a lane takes the sixteen
+//   reference positions 16m .. 16m+15 of one SEG descriptor -- one 12-byte load of packed bases, nibble-aligned with a
+//   funnel shift, sixteen class offsets with the v_perm tables -- and adds each base to its counter with one LDS atomic
+//   (ds_add_u32, no return).  Counters are 16 bits wide, positions 2i and 2i+1 share a word, and the word of class c at
+//   position 16m + k is  plane (k >> 1) x 580 + 9m + c: the class offset is a byte of the table's result that goes
+//   straight into the address (v_add_u32_sdwa: one VALU instruction and one LDS instruction per base); in the k-th add of
+//   a chunk the lanes of a segment are nine words apart (any 32 consecutive m on 32 different banks), a lane's two positions
+//   of one word are never touched by the same instruction, and the flush reads 64 consecutive positions without a bank
+//   conflict.  Bases outside a segment's ends go to a dummy class.  Which descriptor a lane-chunk belongs to is a byte per
+//   chunk in LDS, written by the descriptor's lane; the loads of several steps of 64 chunks are in flight before the first
+//   is used, and a wave's next batch of descriptors is requested before it works on the current one.
 //
-//   A workgroup is 4 waves and 33 KB of LDS: four per CU, 16 waves whose phases are independent of each other; a window
-//   costs three barriers.  Waves draw batches of 64 descriptors from a counter in LDS.
+//   A workgroup is 4 waves and 31 KB of LDS: five per CU, 20 waves whose phases are independent of each other; a window
+//   costs three barriers.  Waves draw batches of 32 descriptors from a counter in LDS.
 //
-// Same closed form, same descriptors, same columns: bit-identical to k4_exec by construction of the sums (tested against
-// the oracle by every pileup test, and against each other under BGP_K4_GATHER=1 in the experiments build).
-constexpr int AT = 256;                       // threads of a k4_acc workgroup
+// Same closed form, same descriptors, same columns as k4_exec: every pileup test checks them against the oracle.
+#ifndef BGP_A_T
+#define BGP_A_T 256
+#endif
+#ifndef BGP_A_U
+#define BGP_A_U 8
+#endif
+#ifndef BGP_A_MINW
+#define BGP_A_MINW 5
+#endif
+#ifndef BGP_A_DB
+#define BGP_A_DB 32
+#endif
+constexpr int AT = BGP_A_T;                   // threads of a k4_acc workgroup
 constexpr int ANW = AT / 64;                  // waves
 constexpr int ABPW = (W / 64) / ANW;          // 64-position blocks a wave flushes
-constexpr int A_PST = W / 8 + 4;              // words between the four planes of a class (the +4 spreads the flush's reads over the banks)
-constexpr int A_CSW = 4 * A_PST;              // words of one class array (W / 2 counters words + padding)
-constexpr int A_U = 8;                        // steps of 64 lane-chunks whose loads are in flight together
-constexpr int A_MCAP = 64 * ((FAST_SEG + 7 + 7) / 8 + 1) + 64;     // marker bytes of a batch: 64 descriptors x chunks of the longest SEG (a ROW is cut to this many chunks a descriptor by the planner's W)
-static_assert(W == 1024 && ABPW * ANW * 64 == W, "k4_acc geometry");
+#ifndef BGP_A_CW
+#define BGP_A_CW 8
+#endif
+#ifndef BGP_A_LAY
+#define BGP_A_LAY 0
+#endif
+constexpr int A_CW = BGP_A_CW;                // reference positions a lane takes at a time (8 or 16): positions A_CW m .. A_CW m + A_CW - 1
+constexpr int A_NM = W / A_CW;                // chunks of a window
+constexpr int A_LAY = BGP_A_LAY;              // 0: a class array after the other, consecutive chunks in consecutive words; 1: the classes of a chunk next to each other, chunks nine words apart (the class offset goes into the address with one SDWA add)
+constexpr int A_NPL = A_CW / 2;               // planes: positions 2i and 2i + 1 of a chunk share a word (16-bit halves)
+constexpr int A_MW = 9;                       // LAY 1: words a chunk takes in a plane
+constexpr int A_PLW = A_LAY ? A_NM * A_MW + 4 : A_NM + 4;       // words of a plane (the +4 puts the planes on different banks for the flush)
+constexpr int A_CSW = A_NPL * A_PLW;          // LAY 0: words of one class array
+constexpr int A_U = BGP_A_U;                  // steps of 64 lane-chunks whose loads are in flight together
+constexpr int A_DB = BGP_A_DB;                // descriptors of a batch (<= 64: a lane each)
+constexpr int A_MCAP = A_DB * ((FAST_SEG + 2 * (A_CW - 1)) / A_CW + 1) + 64;   // map bytes of a batch: its descriptors x the chunks of the longest SEG
+static_assert(W == 1024 && ABPW * ANW * 64 == W && A_DB <= 64 && (A_CW == 8 || A_CW == 16), "k4_acc geometry");
 template <bool ROWS> struct ALay {
     static constexpr int NC = ROWS ? 6 : 5;                       // A C G T other ['-' of long reads' rows]; class NC: bases outside a segment
-    static constexpr int CNT = 0;                                 // (NC + 1) x A_CSW x u32
-    static constexpr int DELD = CNT + (NC + 1) * A_CSW * 4;       // (W + 4) x u32
+    static constexpr int CNT = 0;                                 // the counters
+    static constexpr int CNT_WORDS = A_LAY ? A_NPL * A_PLW : (NC + 1) * A_CSW;
+    static constexpr int DELD = CNT + CNT_WORDS * 4;              // (W + 4) x u32
     static constexpr int NST = DELD + (W + 4) * 4;                // W x u16
     static constexpr int HIST = NST + W * 2;                      // HB x u32
     static constexpr int MARK = HIST + HB * 4;                    // ANW x MROW bytes
-    static constexpr int MROW = ROWS ? 64 * (W / 8 + 2) + 64 : A_MCAP;
-    static constexpr int DSC = (MARK + ANW * MROW + 15) & ~15;    // ANW x 64 x uint4
-    static constexpr int MISC = DSC + ANW * 64 * 16;              // 64 x u32
+    static constexpr int MROW = ROWS ? A_DB * (A_NM + 2) + 64 : A_MCAP;
+    static constexpr int DSC = (MARK + ANW * MROW + 15) & ~15;    // ANW x A_DB x uint4
+    static constexpr int MISC = DSC + ANW * A_DB * 16;            // 64 x u32
     static constexpr int BYTES = MISC + 256;
+    static_assert(NC + 1 <= A_MW, "classes of a chunk");
 };
-static_assert(4 * ALay<false>::BYTES <= 160 * 1024, "four k4_acc workgroups per CU");
-
-__device__ __forceinline__ uint32_t wave_scan_max_u32(uint32_t v) {      // inclusive prefix maximum over the 64 lanes (values >= 0: a lane without a source sees 0)
-    v = max(v, BGP_DPP(v, 0x111, 0xF)); v = max(v, BGP_DPP(v, 0x112, 0xF)); v = max(v, BGP_DPP(v, 0x114, 0xF)); v = max(v, BGP_DPP(v, 0x118, 0xF));
-    v = max(v, BGP_DPP(v, 0x142, 0xA)); v = max(v, BGP_DPP(v, 0x143, 0xC));
-    return v;
+static_assert(ALay<false>::BYTES <= 64 * 1024, "k4_acc LDS");
+constexpr uint32_t A_CLS_UNIT = A_LAY ? 4u : 1u;                 // what the class tables count in: bytes inside a chunk's words | class indices
+// word of class c at window position p
+__device__ __forceinline__ uint32_t a_word(uint32_t p, uint32_t c) {
+    const uint32_t m = p / (uint32_t)A_CW, pl = (p % (uint32_t)A_CW) >> 1;
+    return A_LAY ? pl * (uint32_t)A_PLW + m * (uint32_t)A_MW + c : c * (uint32_t)A_CSW + pl * (uint32_t)A_PLW + m;
 }
-// four nt16 codes, one per byte -> their class indices: A 0, C 1, G 2, T 3, anything else 4
-__device__ __forceinline__ uint32_t class_idx4(uint32_t x) {
+
+// four nt16 codes, one per byte -> their classes in units of A_CLS_UNIT: A 0, C 1, G 2, T 3, anything else 4
+__device__ __forceinline__ uint32_t class_off4(uint32_t x) {
+    constexpr uint32_t U1 = A_CLS_UNIT, U2 = 2 * U1, U3 = 3 * U1, U4 = 4 * U1;
     const uint32_t idx = x & 0x07070707u;
-    const uint32_t lo = __builtin_amdgcn_perm(0x04040402u, 0x04010004u, idx);      // codes 0..7 : other A C other | G other other other
-    const uint32_t hi = __builtin_amdgcn_perm(0x04040404u, 0x04040403u, idx);      // codes 8..15: T other other other | other ...
+    const uint32_t lo = __builtin_amdgcn_perm(U4 * 0x01010100u | U2, (U4 << 24) | (U1 << 16) | U4, idx);      // codes 0..7 : other A C other | G other other other
+    const uint32_t hi = __builtin_amdgcn_perm(U4 * 0x01010101u, U4 * 0x01010100u | U3, idx);                  // codes 8..15: T other other other | other ...
     const uint32_t sel = ((x >> 1) & 0x04040404u) | 0x03020100u;
     return __builtin_amdgcn_perm(hi, lo, sel);
 }
-__device__ __forceinline__ uint2 class_idx8(uint32_t cur) {              // eight packed bases (high nibble first, read.d:368-373) -> eight class indices in base order
-    const uint32_t ev = class_idx4((cur >> 4) & 0x0F0F0F0Fu), od = class_idx4(cur & 0x0F0F0F0Fu);
+__device__ __forceinline__ uint2 class_off8(uint32_t cur) {              // eight packed bases (high nibble first, read.d:368-373) -> eight classes in base order
+    const uint32_t ev = class_off4((cur >> 4) & 0x0F0F0F0Fu), od = class_off4(cur & 0x0F0F0F0Fu);
     return make_uint2(__builtin_amdgcn_perm(od, ev, 0x05010400u), __builtin_amdgcn_perm(od, ev, 0x07030602u));
 }
+// bytes [lo, hi) of a 64-bit word keep `v`, the others become `padw`'s (0 <= lo, hi <= 8)
+__device__ __forceinline__ uint2 keep_bytes(uint2 v, uint32_t lo, uint32_t hi, uint32_t padw) {
+    const unsigned long long keep = hi > lo ? (~0ull << (8u * lo)) & (~0ull >> (64u - 8u * hi)) : 0ull;
+    return make_uint2((v.x & (uint32_t)keep) | (padw & ~(uint32_t)keep), (v.y & (uint32_t)(keep >> 32)) | (padw & ~(uint32_t)(keep >> 32)));
+}
 
-template <bool ROWS> __global__ __launch_bounds__(AT, 4) void k4_acc(GArgs a) {
+template <bool ROWS> __global__ __launch_bounds__(AT, BGP_A_MINW) void k4_acc(GArgs a) {
     using L = ALay<ROWS>;
     constexpr int NC = L::NC;
     extern __shared__ __attribute__((aligned(16))) uint8_t alds[];
@@ -1698,7 +1732,7 @@ template <bool ROWS> __global__ __launch_bounds__(AT, 4) void k4_acc(GArgs a) {
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     uint8_t* const mark = alds + L::MARK + wave * L::MROW;
-    uint4* const dsc = reinterpret_cast<uint4*>(alds + L::DSC) + wave * 64;
+    uint4* const dsc = reinterpret_cast<uint4*>(alds + L::DSC) + wave * A_DB;
     const uint64_t nbt = a.n_tiles, per = (nbt + gridDim.x - 1) / gridDim.x;
     const uint64_t tile_end = min(nbt, ((uint64_t)blockIdx.x + 1) * per);
     uint64_t tile = (uint64_t)blockIdx.x * per;
@@ -1727,83 +1761,90 @@ template <bool ROWS> __global__ __launch_bounds__(AT, 4) void k4_acc(GArgs a) {
         if (tile + 1 < tile_end) pre = prefetch(tile + 1);
         if (pad) continue;                                   // on the general kernel's list
         const unsigned long long* slab = a.slab + tile * (uint64_t)SLAB_CAP;
-        // ---- accumulate: batches of 64 descriptors, drawn from misc[0]
-        for (;;) {
+        // ---- accumulate: batches of A_DB descriptors, drawn from misc[0] (a wave's NEXT batch is requested before it works on the current one)
+        auto draw = [&](uint32_t* base_out) {
             uint32_t b = 0;
             if (lane == 0) b = atomicAdd(&misc[0], 1u);
             b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
-            const uint32_t base = b * 64u;
+            *base_out = b * (uint32_t)A_DB;
+            unsigned long long dd = 0;
+            if (*base_out < n_desc && lane < A_DB && *base_out + (uint32_t)lane < n_desc) dd = slab[*base_out + lane];
+            return dd;
+        };
+        uint32_t base_next = 0;
+        unsigned long long d_next = draw(&base_next);
+        for (;;) {
+            const uint32_t base = base_next;
             if (base >= n_desc) break;
-            unsigned long long d = 0;
-            if (base + (uint32_t)lane < n_desc) d = slab[base + lane];
+            const unsigned long long d = d_next;
+            d_next = draw(&base_next);
             uint32_t kind = (uint32_t)d & 3u;
             const uint32_t lo = ((uint32_t)d >> 3) & 0x7FFu, f14 = (uint32_t)(d >> 14);
             const bool is_row = ROWS && kind == 3;
             if (!ROWS && kind == 3) kind = 0;
             const uint32_t len = is_row ? (f14 & 0x3FFu) + 1u : f14 & 0xFFu, nib = is_row ? 0u : (f14 >> 8) & 1u;
-            const uint32_t nch = (kind == 1 || is_row) ? ((lo & 7u) + len + 7u) >> 3 : 0u;      // chunks of eight aligned positions the segment touches
+            const uint32_t nch = (kind == 1 || is_row) ? ((lo & (uint32_t)(A_CW - 1)) + len + (uint32_t)(A_CW - 1)) / (uint32_t)A_CW : 0u;    // chunks of A_CW aligned positions the segment touches
             if (kind == 2) { atomicAdd(&deld[lo], 1u); atomicAdd(&deld[f14 & 0xFFFu], 0xFFFFFFFFu); }       // D / N inside the window: '-' from lo up to the op's end (pileup.d:119-121)
             if ((kind == 1 || is_row) && (d & 4u)) atomicAdd(&nst[lo >> 1], 1u << ((lo & 1u) * 16));        // n_starting_here, pileup.d:386,422
             const uint32_t inc = wave_scan_u32(nch), ex = inc - nch, tot = rl(inc, 63);
-            for (uint32_t o = 4u * (uint32_t)lane; o < tot; o += 256u) *reinterpret_cast<uint32_t*>(mark + o) = 0u;
             const uint64_t src = is_row ? d >> 24 : d >> 23;
-            dsc[lane] = make_uint4((uint32_t)src, (uint32_t)(src >> 32) | (nib << 16) | ((is_row ? 1u : 0u) << 17), lo | (len << 11), ex);
+            if (lane < A_DB) dsc[lane] = make_uint4((uint32_t)src, (uint32_t)(src >> 32) | (nib << 16) | ((is_row ? 1u : 0u) << 17), lo | (len << 11), ex);
+            for (uint32_t j = 0; j < nch; ++j) mark[ex + j] = (uint8_t)lane;      // chunk -> descriptor of the batch (a byte per chunk; ~10 a descriptor)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            if (nch) mark[ex] = (uint8_t)(lane + 1);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            uint32_t carry = 0;
             for (uint32_t c0 = 0; c0 < tot; c0 += 64u * A_U) {
-                uint2 v[A_U]; uint32_t adr[A_U], klim[A_U];        // packed bases (or a row's class bytes) | LDS word of the chunk's position 8m, plane 0, class 0 | first valid k, one past the last << 4, odd nibble << 8, row << 9
+                uint32_t v0[A_U], v1[A_U], v2[A_U], adr[A_U], klim[A_U];     // twelve bytes of packed bases (a row: sixteen class offsets, v2 | .. in two loads) | byte offset of the chunk's words in a plane | first valid k, one past the last << 8, odd nibble << 16, row << 17
+                uint32_t v3[ROWS ? A_U : 1];
 #pragma unroll
                 for (int u = 0; u < A_U; ++u) {
+                    // (branch-free: a lane behind the batch's last chunk works on chunk 0 again and keeps nothing -- a load inside a branch
+                    // is waited for at the branch's end, one round trip per step instead of one per A_U steps)
                     const uint32_t c = c0 + 64u * u + (uint32_t)lane;
-                    v[u] = make_uint2(0, 0); adr[u] = 0; klim[u] = 0;
-                    if (c0 + 64u * u >= tot) continue;
-                    const uint32_t mk = c < tot ? (uint32_t)mark[c] : 0u;
-                    uint32_t sc = wave_scan_max_u32(mk);
-                    sc = max(sc, carry);
-                    carry = rl(sc, 63);
-                    if (c < tot) {
-                        const uint4 f = dsc[sc - 1];
-                        const uint32_t flo = f.z & 0x7FFu, flen = f.z >> 11;
-                        const uint32_t m = (flo >> 3) + (c - f.w);                       // chunk of the window: positions 8m .. 8m + 7
-                        const int32_t rel = (int32_t)(8u * m) - (int32_t)flo;             // segment-relative index of position 8m (negative in the first chunk)
-                        const uint32_t k_lo = rel < 0 ? (uint32_t)(-rel) : 0u, k_hi = min(8u, flen - (uint32_t)rel);
-                        const uint64_t sb = ((uint64_t)(f.y & 0xFFFFu) << 32) | f.x;
-                        const bool row = ROWS && ((f.y >> 17) & 1u);
-                        uint32_t odd = 0;
-                        const uint8_t* p;
-                        if (row) p = a.rows + sb + rel;                                  // a row holds one class index per column
-                        else { const int32_t n0 = (int32_t)((f.y >> 16) & 1u) + rel; odd = (uint32_t)n0 & 1u; p = a.s + sb + (n0 >> 1); }
-                        __builtin_memcpy(&v[u], p, 8);
-                        adr[u] = m; klim[u] = k_lo | (k_hi << 4) | (odd << 8) | ((row ? 1u : 0u) << 9);
-                    }
+                    const bool in = c < tot;
+                    const uint32_t cc = in ? c : 0u;
+                    const uint4 f = dsc[mark[cc]];
+                    const uint32_t flo = f.z & 0x7FFu, flen = f.z >> 11;
+                    const uint32_t m = flo / (uint32_t)A_CW + (cc - f.w);                // chunk of the window: positions A_CW m .. A_CW m + A_CW - 1
+                    const int32_t rel = (int32_t)((uint32_t)A_CW * m) - (int32_t)flo;     // segment-relative index of the chunk's first position (negative in the first chunk)
+                    const uint32_t k_lo = rel < 0 ? (uint32_t)(-rel) : 0u, k_hi = min((uint32_t)A_CW, flen - (uint32_t)rel);
+                    const uint64_t sb = ((uint64_t)(f.y & 0xFFFFu) << 32) | f.x;
+                    const bool row = ROWS && ((f.y >> 17) & 1u);
+                    const int32_t n0 = (int32_t)((f.y >> 16) & 1u) + rel;
+                    const uint32_t odd = row ? 0u : (uint32_t)n0 & 1u;
+                    const uint8_t* p = row ? a.rows + sb + rel : a.s + sb + (n0 >> 1);   // a row holds one class per column, a SEG two bases per byte
+                    if (A_CW == 16) {
+                        if (ROWS) { uint4 q; __builtin_memcpy(&q, p, 16); v0[u] = q.x; v1[u] = q.y; v2[u] = q.z; v3[u] = q.w; }
+                        else { uint32_t q[3]; __builtin_memcpy(q, p, 12); v0[u] = q[0]; v1[u] = q[1]; v2[u] = q[2]; }
+                    } else { uint2 q; __builtin_memcpy(&q, p, 8); v0[u] = q.x; v1[u] = q.y; v2[u] = 0; if (ROWS) v3[u] = 0; }
+                    adr[u] = m * (uint32_t)(A_LAY ? A_MW * 4 : 4);
+                    klim[u] = in ? k_lo | (k_hi << 8) | (odd << 16) | ((row ? 1u : 0u) << 17) : 0u;
                 }
 #pragma unroll
                 for (int u = 0; u < A_U; ++u) {
                     if (c0 + 64u * u >= tot) continue;
                     const uint32_t kl = klim[u];
-                    if ((kl >> 4 & 15u) == 0) continue;                                  // (a lane behind the batch's last chunk)
-                    uint2 cb;
-                    if (ROWS && (kl >> 9 & 1u)) cb = v[u];
+                    const uint32_t k_lo = kl & 0xFFu, k_hi = kl >> 8 & 0xFFu;
+                    if (k_hi == 0) continue;                                             // (a lane behind the batch's last chunk)
+                    uint2 ca, cb = make_uint2(0, 0);                                     // classes of the chunk's positions 0 .. 7 | 8 .. 15
+                    if (ROWS && (kl >> 17 & 1u)) { ca = make_uint2(v0[u], v1[u]); if (A_CW == 16) cb = make_uint2(v2[u], v3[ROWS ? u : 0]); }
                     else {
-                        const uint32_t w = (kl >> 8 & 1u) ? ((v[u].x & 0x0F0F0F0Fu) << 4) | (__builtin_amdgcn_alignbit(v[u].y, v[u].x, 12) & 0x0F0F0F0Fu) : v[u].x;
-                        cb = class_idx8(w);
+                        uint32_t w0 = v0[u], w1 = v1[u];
+                        if (kl >> 16 & 1u) {                                             // the chunk's first base is the low nibble of its byte: one nibble up
+                            w0 = ((v0[u] & 0x0F0F0F0Fu) << 4) | (__builtin_amdgcn_alignbit(v1[u], v0[u], 12) & 0x0F0F0F0Fu);
+                            if (A_CW == 16) w1 = ((v1[u] & 0x0F0F0F0Fu) << 4) | (__builtin_amdgcn_alignbit(v2[u], v1[u], 12) & 0x0F0F0F0Fu);
+                        }
+                        ca = class_off8(w0); if (A_CW == 16) cb = class_off8(w1);
                     }
-                    {   // bases outside the segment's ends count for the dummy class
-                        const uint32_t k_lo = kl & 15u, k_hi = kl >> 4 & 15u;
-                        const unsigned long long keep = (~0ull << (8u * k_lo)) & (~0ull >> (64u - 8u * k_hi));
-                        constexpr uint32_t PADW = (uint32_t)NC * 0x01010101u;
-                        cb.x = (cb.x & (uint32_t)keep) | (PADW & ~(uint32_t)keep);
-                        cb.y = (cb.y & (uint32_t)(keep >> 32)) | (PADW & ~(uint32_t)(keep >> 32));
-                    }
-                    uint32_t* const row0 = cnt + adr[u];
+                    constexpr uint32_t PADW = (uint32_t)NC * A_CLS_UNIT * 0x01010101u;   // bases outside the segment's ends count for the dummy class
+                    ca = keep_bytes(ca, min(k_lo, 8u), min(k_hi, 8u), PADW);
+                    if (A_CW == 16) cb = keep_bytes(cb, max(k_lo, 8u) - 8u, max(k_hi, 8u) - 8u, PADW);
+                    uint8_t* const row0 = reinterpret_cast<uint8_t*>(cnt) + adr[u];
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        const uint32_t cls = ((k < 4 ? cb.x : cb.y) >> (8 * (k & 3))) & 0xFFu;
-                        atomicAdd(row0 + cls * (uint32_t)A_CSW + (k >> 1) * A_PST, 1u << (16 * (k & 1)));
+                    for (int k = 0; k < A_CW; ++k) {
+                        const uint32_t word = k < 4 ? ca.x : k < 8 ? ca.y : k < 12 ? cb.x : cb.y;
+                        const uint32_t cls = (word >> (8 * (k & 3))) & 0xFFu;
+                        const uint32_t off = A_LAY ? cls : cls * (uint32_t)(A_CSW * 4);
+                        atomicAdd(reinterpret_cast<uint32_t*>(row0 + off + (k >> 1) * (A_PLW * 4)), 1u << (16 * (k & 1)));
                     }
                 }
             }
@@ -1822,14 +1863,14 @@ template <bool ROWS> __global__ __launch_bounds__(AT, 4) void k4_acc(GArgs a) {
                 const uint32_t sc = wave_scan_u32(e);
                 dl[bb] = run + sc;
                 run += rl(sc, 63);
-                const uint32_t wi = ((p & 7u) >> 1) * A_PST + (p >> 3), sh = (p & 1u) * 16;
-                cA[bb] = (cnt[wi] >> sh) & 0xFFFFu; cC[bb] = (cnt[A_CSW + wi] >> sh) & 0xFFFFu; cG[bb] = (cnt[2 * A_CSW + wi] >> sh) & 0xFFFFu;
-                cT[bb] = (cnt[3 * A_CSW + wi] >> sh) & 0xFFFFu; cO[bb] = (cnt[4 * A_CSW + wi] >> sh) & 0xFFFFu;
-                cD[bb] = ROWS ? (cnt[5 * A_CSW + wi] >> sh) & 0xFFFFu : 0u;
+                const uint32_t wi = a_word(p, 0), cs = A_LAY ? 1u : (uint32_t)A_CSW, sh = (p & 1u) * 16;
+                cA[bb] = (cnt[wi] >> sh) & 0xFFFFu; cC[bb] = (cnt[wi + cs] >> sh) & 0xFFFFu; cG[bb] = (cnt[wi + 2 * cs] >> sh) & 0xFFFFu;
+                cT[bb] = (cnt[wi + 3 * cs] >> sh) & 0xFFFFu; cO[bb] = (cnt[wi + 4 * cs] >> sh) & 0xFFFFu;
+                cD[bb] = ROWS ? (cnt[wi + 5 * cs] >> sh) & 0xFFFFu : 0u;
                 sw[bb] = nst[p >> 1];
                 if ((p & 1u) == 0) {                         // (two lanes share a word: both have read it -- the wave runs in lockstep)
-                    cnt[wi] = 0; cnt[A_CSW + wi] = 0; cnt[2 * A_CSW + wi] = 0; cnt[3 * A_CSW + wi] = 0; cnt[4 * A_CSW + wi] = 0;
-                    if (ROWS) cnt[5 * A_CSW + wi] = 0;
+                    cnt[wi] = 0; cnt[wi + cs] = 0; cnt[wi + 2 * cs] = 0; cnt[wi + 3 * cs] = 0; cnt[wi + 4 * cs] = 0;
+                    if (ROWS) cnt[wi + 5 * cs] = 0;
                     nst[p >> 1] = 0;
                 }
             }
@@ -2206,7 +2247,7 @@ int k34_pileup(bgp_ctx* c) {
             TimedRegion tb(c, "k4_bounds", tile_base * sizeof(TileB));
             hipLaunchKernelGGL(k4_bounds, dim3((unsigned)((tile_base + 255) / 256)), dim3(256), 0, c->stream, a.pmax_end, a.pmax_pos, a.runs, n_runs, tile_base, c->d_tiles.as<TileB>(), tw);
         }
-        constexpr uint64_t WG_SLOTS = 16384;            // k4_exec's workgroups leave their ranges' totals behind the windows' slots
+        constexpr uint64_t WG_SLOTS = 65536;            // k4_exec's workgroups leave their ranges' totals behind the windows' slots
         BGP_TRY(c->d_col_lo.reserve((tile_base + WG_SLOTS) * 32));
         a.tile_stats = (unsigned long long*)c->d_col_lo.p;
         a.ck = nullptr; a.ck_off = nullptr;
@@ -2284,9 +2325,9 @@ int k34_pileup(bgp_ctx* c) {
             g.rows = have_rows ? c->d_rows.as<uint8_t>() : nullptr;
             // 512 workgroups are resident (two of 76 KB a CU); handing the device eight times as many, each with a shorter range of
             // windows, lets it balance the ranges' unequal work at the tail (cfg3: 10.5 -> 10.3 ms); the rows' instantiation is best at 512
-            static const unsigned g_env = getenv("BGP_G_BLOCKS") ? (unsigned)atoi(getenv("BGP_G_BLOCKS")) : 0u;
-            const unsigned g_blocks = std::min(16384u, g_env ? g_env : have_rows ? 512u : 4096u);
             static const bool gather = getenv("BGP_K4_GATHER") && atoi(getenv("BGP_K4_GATHER")) != 0;      // round 2's k4_exec instead of k4_acc (A/B)
+            static const unsigned g_env = getenv("BGP_G_BLOCKS") ? (unsigned)atoi(getenv("BGP_G_BLOCKS")) : 0u;
+            const unsigned g_blocks = std::min(65536u, g_env ? g_env : have_rows ? 512u : gather ? 4096u : 16384u);
             if (have_rows) hipLaunchKernelGGL(k4_exec<true>, dim3((unsigned)std::min<uint64_t>(tile_base, g_blocks)), dim3(GT), (size_t)G_LDS, c->stream, g);
             else if (gather) hipLaunchKernelGGL(k4_exec<false>, dim3((unsigned)std::min<uint64_t>(tile_base, g_blocks)), dim3(GT), (size_t)G_LDS, c->stream, g);
             else hipLaunchKernelGGL(k4_acc<false>, dim3((unsigned)std::min<uint64_t>(tile_base, g_blocks)), dim3(AT), (size_t)ALay<false>::BYTES, c->stream, g);
