@@ -3,7 +3,7 @@
 
 One "step" = one full pass of the hot path over one synthetic coordinate-sorted BAM record stream that
 is already resident in HBM: record framing (K0), fixed fields + end_position (K1), SEQ/QUAL/CIGAR
-unpack (K2), reference-run keys (K3) and the per-position pileup (K4: plan + gather).  Nothing is cached
+unpack (K2), reference-run keys (K3) and the per-position pileup (K4: plan + accumulate).  Nothing is cached
 between steps (bgp_reset drops every result).
 
 N GPUs (BASELINE.json config 4): the SAME 100 M-read BAM split by reference contig over the ranks (strong
@@ -49,7 +49,7 @@ def kernels_sha():
 # kernels behind the timers of a step (a timer can bracket several launches; kernels of the set-up, e.g. the flush before the
 # timed region, are not the step's)
 TIMER_KERNELS = {"k12_lds": ("k12_lds",), "k012_stream": ("k_stream_decode",), "k2_unpack": ("k2_unpack",), "k12_fused": ("k12_fused",), "k1_rows": ("k12_fused",),
-                 "k4_bounds": ("k4_bounds",), "k4_plan": ("k4_plan", "k4_wscan"), "k4_tile": ("k4_exec", "k4_tile", "k4_stats"),
+                 "k4_bounds": ("k4_bounds",), "k4_plan": ("k4_plan", "k4_wscan"), "k4_tile": ("k4_acc", "k4_tile", "k4_stats"),
                  "k4_checkpoints": ("k4_ck_",), "k4_rows": ("k4_rows_build",),
                  "k0_guess": ("k0_guess",), "k0_chase": ("k0_chase", "k0_verify"), "k3_keys_scan": ("k3_",)}
 
@@ -335,7 +335,7 @@ def main():
                                    f"l_seq {cfg.len_min}-{cfg.len_max}, {cfg.n_ref * (world if strong else 1)} contigs x {cfg.ref_len} bp"
                                    f"{', split by contig over the ranks' if strong and world > 1 else ''})",
                        "reads_per_gpu": n_reads, "inflated_bytes_per_gpu": stream_bytes, "parallelism": f"contig-sharded x{world}",
-                       "step": "K0 framing + K1 record table and K2 seq/qual/cigar unpack (one kernel over LDS windows, k12_lds) + K3 run keys + K4 pileup columns (plan + gather)"
+                       "step": "K0 framing + K1 record table and K2 seq/qual/cigar unpack (one kernel over LDS windows, k12_lds) + K3 run keys + K4 pileup columns (plan + accumulate)"
                                + (" + depth-histogram all-reduce (bgp_hist_reduce, RCCL)" if with_comm else "")},
             "pileup_columns_per_s": round(job_columns / dt * a.steps, 1),
             "columns_per_step": job_columns, "sum_coverage_per_step": job_cov,

@@ -41,7 +41,7 @@ namespace {
 #define BGP_K4_T16 512
 #define BGP_K4_HB 512
 #endif
-constexpr int W = BGP_K4_W;            // reference positions per window of the gather path (k4_plan / k4_exec), power of two
+constexpr int W = BGP_K4_W;            // reference positions per window of the plan / accumulate path (k4_plan / k4_acc), power of two
 constexpr int WO = 4096;               // ... of the general kernel when a stream is left to it entirely (long reads): the biggest window LDS holds wins there
 constexpr int HB = BGP_K4_HB;          // depth-histogram bins kept in LDS
 constexpr int K4_T = BGP_K4_T;         // threads of a workgroup on the 32-bit layout
@@ -60,8 +60,9 @@ struct RunDev { int32_t ref_id; uint32_t pad; uint64_t first_record, end_record,
 struct K3Args { const bgp_record* rec; uint64_t n; uint64_t* key_end; uint64_t* key_pos; uint32_t* status; /* [3] any long read */ uint32_t run_cap; };
 
 constexpr int FAST_LSEQ = 160;         // reads up to 20 dwords of packed SEQ and 4 CIGAR ops take K4's lane = read path
+constexpr uint32_t ROW_PIECE = 256;     // positions of a ROW descriptor (a long read's stretch of a window goes in pieces of this many)
 constexpr int FAST_SEG = 255;          // longest read the planner turns into SEG descriptors (a descriptor's length field: 8 bits; <= 8 staging chunks)
-// Reads that get per-window CIGAR checkpoints and, on the gather path, a row of class bytes: more than four ops, or longer
+// Reads that get per-window CIGAR checkpoints and, on the accumulate path, a row of class bytes: more than four ops, or longer
 // than a SEG descriptor holds.  (A read of 161..255 bases with up to four ops needs neither: the planner takes it as SEGs,
 // and in a window left to the general kernel it walks from its start -- so a stream of 250-base reads costs no walk.)
 __device__ __forceinline__ bool wants_ckpt(uint32_t n_cig, uint32_t l_seq) { return n_cig > 4 || l_seq > (uint32_t)FAST_SEG; }
@@ -236,23 +237,9 @@ __global__ __launch_bounds__(256) void k4_bounds(const uint64_t* pmax_end, const
     b.i_hi = lower_bound_gt(pmax_pos, run.first_record, run.end_record, rk | (Tend - 1));     // first record starting at/after Tend
     b.col_out = run.column_base + (T0 - run.start_pos); b.T0 = T0; b.Tend = Tend; b.run_start = (uint32_t)run.start_pos;
     b.pad = b.i_hi - b.i_lo >= DEEP_WINDOW ? 1u : 0u;     // bit 0: a count per position and class is bounded by the candidates, 16 bits are enough below this
-    out[tile] = b;                                        // (bit 1, "not for the gather path", is set by k4_wscan, which also builds the list of such windows)
+    out[tile] = b;                                        // (bit 1, "not for the accumulate path", is set by k4_wscan, which also builds the list of such windows)
 }
 
-// four nt16 codes, one per byte -> the bit positions of their class counters: A 0, C 6, G 12, T 18, anything else 24 --
-// or, when the stream holds long reads (ROWS), five bits a counter so that a sixth fits: A 0, C 5, G 10, T 15, else 20, '-' 25
-template <bool ROWS> __device__ __forceinline__ uint32_t class_bits4(uint32_t x) {
-    const uint32_t idx = x & 0x07070707u;
-    const uint32_t lo = ROWS ? __builtin_amdgcn_perm(0x1414140Au, 0x14050014u, idx) : __builtin_amdgcn_perm(0x1818180Cu, 0x18060018u, idx);      // codes 0..7 : other A C other | G other other other
-    const uint32_t hi = ROWS ? __builtin_amdgcn_perm(0x14141414u, 0x1414140Fu, idx) : __builtin_amdgcn_perm(0x18181818u, 0x18181812u, idx);      // codes 8..15: T other other other | other ...
-    const uint32_t sel = ((x >> 1) & 0x04040404u) | 0x03020100u;                   // byte i: i (from lo) or 4 + i (from hi)
-    return __builtin_amdgcn_perm(hi, lo, sel);
-}
-// eight packed bases (read.d:368-373: the first base of a byte is its high nibble) -> eight class bytes in base order
-template <bool ROWS> __device__ __forceinline__ uint2 class_bits8(uint32_t cur) {
-    const uint32_t ev = class_bits4<ROWS>((cur >> 4) & 0x0F0F0F0Fu), od = class_bits4<ROWS>(cur & 0x0F0F0F0Fu);   // bases 0,2,4,6 | 1,3,5,7
-    return make_uint2(__builtin_amdgcn_perm(od, ev, 0x05010400u), __builtin_amdgcn_perm(od, ev, 0x07030602u));
-}
 // ---- long reads: CIGAR checkpoints ------------------------------------------------------------
 // A read with thousands of CIGAR ops overlaps many windows; walking its ops from the start in every
 // window is O(n_cigar) dependent loads per visit.  One pre-pass walks each long read ONCE, 64 ops per
@@ -260,7 +247,6 @@ template <bool ROWS> __device__ __forceinline__ uint2 class_bits8(uint32_t cur) 
 // pileup.d:175-222), and records for every window the read overlaps the cursor state
 // (op index, columns before it, query bases before it) of the op that owns the window's first column.
 struct Ckpt { uint32_t k, cs, qs, pad; };
-constexpr uint32_t ROW_OTHER = 20, ROW_DEL = 25;      // class bytes of a long read's row (the ROWS layout of k4_exec: A 0, C 5, G 10, T 15)
 
 __device__ __forceinline__ uint32_t wave_incl_u32(uint32_t v, int lane) {
 #pragma unroll
@@ -326,7 +312,7 @@ template <bool WPR> __global__ __launch_bounds__(256) void k4_ck_build(const uin
         // window j (j >= 1) starts at column offset D + j*W of this read (D <= 0)
         const int64_t D = (int64_t)(run.start_pos + t_first * W) - (int64_t)pos;
         uint32_t cs = 0, qs = 0; bool started = false;
-        // what the gather path asks of a read (k4_plan: "the mould"): the first reference-consuming op is M/=/X (so the
+        // what the accumulate path asks of a read (k4_plan: "the mould"): the first reference-consuming op is M/=/X (so the
         // read's first column is a base of it: no leading N, D), no zero-length reference-consuming op, no M base past SEQ
         bool plain = true;
         const uint32_t l_seq_r = (uint32_t)__shfl(r.l_seq, src, 64);
@@ -363,12 +349,15 @@ template <bool WPR> __global__ __launch_bounds__(256) void k4_ck_build(const uin
     }
 }
 
-// The rows of the gather path (ROW descriptors): one class byte per COLUMN of every long read, in the ROWS layout of k4_exec.
+// The rows of the accumulate path (ROW descriptors): one class byte per COLUMN of every long read (k4_acc's classes).
 // One wave per chunk of 64 CIGAR ops, from the state k4_ck_build left where the chunk starts -- the walk itself is serial
 // per read, this part is not: written inside the walk it took 13 ms of cfg5's 18, the SIMDs half idle behind one read's
 // chain of chunks.
+__device__ __forceinline__ uint2 class_of_packed8(uint32_t cur);
+// the row bytes are k4_acc's classes: 0 any other base, 1 A, 2 C, 3 G, 4 T, 5 '-'
 __global__ __launch_bounds__(256) void k4_rows_build(const uint8_t* s, uint64_t stream_len, const bgp_record* rec, const uint4* cst, uint64_t n_chunks,
                                                      const uint64_t* row_off, uint8_t* rows) {
+    constexpr uint32_t ROW_OTHER = 0u, ROW_DEL = 5u;
     constexpr int RB_CAP = 4096;
     __shared__ __attribute__((aligned(16))) uint8_t s_row[4][RB_CAP];
     __shared__ uint8_t s_map[4][512];                     // piece of 14 columns -> lane of its op (at most RB_CAP / 14 + 64 pieces a chunk)
@@ -392,7 +381,7 @@ __global__ __launch_bounds__(256) void k4_rows_build(const uint8_t* s, uint64_t 
     const uint32_t ir = wave_incl_u32(rlen, lane), iq = wave_incl_u32(qlen, lane);
     const uint32_t cs_b = cs + ir - rlen, qs_b = qs + iq - qlen;
         {
-                // the read's row for the gather path: one class byte per COLUMN, in the ROWS layout of k4_exec (A 0, C 5, G 10,
+                // the read's row for the accumulate path: one class byte per COLUMN, k4_acc's classes (A 1, C 2, G 3,
                 // T 15, anything else 20, '-' 25).  A lane writes its own op's columns -- into LDS: the chunk's 64 ops cover a few
                 // hundred consecutive columns, which then leave as 16-byte stores (byte stores straight to the arena, 64 lanes
                 // on a handful of lines each, cost four times the walk itself).  A chunk with an op of more than 512 columns
@@ -406,7 +395,7 @@ __global__ __launch_bounds__(256) void k4_rows_build(const uint8_t* s, uint64_t 
                 auto base_byte = [&](uint32_t q) -> uint8_t {
                     if (q >= l_seq_r) return (uint8_t)ROW_OTHER;
                     const uint32_t byte = s[seq_off + (q >> 1)], nib = (q & 1u) ? (byte & 0xFu) : (byte >> 4);
-                    return (uint8_t)(((nib & 8u) ? 0x141414141414140Full : 0x1414140A14050014ull) >> ((nib & 7u) * 8));
+                    return (uint8_t)(((nib & 8u) ? 0x0000000000000004ull : 0x0000000300020100ull) >> ((nib & 7u) * 8));
                 };
                 const uint32_t wlen = cs_b >= covered ? 0u : min(rlen, covered - cs_b);     // (covered: a malformed read's zero-length ops hold columns its row has no room for)
                 if (via_lds) {
@@ -434,7 +423,7 @@ __global__ __launch_bounds__(256) void k4_rows_build(const uint8_t* s, uint64_t 
                             const uint64_t src = seq_off + (q >> 1);
                             if (src + 8 <= stream_len && q + lim <= l_seq_r) {
                                 uint2 v; __builtin_memcpy(&v, s + src, 8);
-                                const uint2 c0 = class_bits8<true>(v.x), c1 = class_bits8<true>(v.y);      // 16 class bytes, three v_perm for four of them
+                                const uint2 c0 = class_of_packed8(v.x), c1 = class_of_packed8(v.y);      // 16 class bytes, three v_perm for four of them
                                 wd[0] = odd ? __builtin_amdgcn_alignbyte(c0.y, c0.x, 1) : c0.x; wd[1] = odd ? __builtin_amdgcn_alignbyte(c1.x, c0.y, 1) : c0.y;
                                 wd[2] = odd ? __builtin_amdgcn_alignbyte(c1.y, c1.x, 1) : c1.x; wd[3] = odd ? (c1.y >> 8) : c1.y;
                             } else {
@@ -527,7 +516,7 @@ template <bool P16_, int T_, int WIN_> struct Lay {
         return P16_ ? (lds[NST + (col >> 1)] >> ((col & 1u) * 16)) & 0xFFFFu : lds[NST + col];
     }
 };
-using L16 = Lay<true, K4_T16, W>;          // the general kernel on the gather path's tiling (windows that path leaves behind)
+using L16 = Lay<true, K4_T16, W>;          // the general kernel on the accumulate path's tiling (windows that path leaves behind)
 using L32 = Lay<false, K4_T, W>;
 using L16o = Lay<true, K4_T16, WO>;        // ... on its own tiling (streams of long reads)
 using L32o = Lay<false, K4_T, WO>;
@@ -689,7 +678,7 @@ template <class L> __global__ __launch_bounds__(L::T) void k4_tile(K4Args a, int
     __shared__ uint32_t s_n;           // entries in the LDS list
     __shared__ uint32_t s_nslow;       // entries in the second list
     __shared__ uint32_t wsum[K4_T / 64];
-    // The general kernel: it runs only the windows the gather path (k4_plan / k4_exec below) leaves on the list --
+    // The general kernel: it runs only the windows the accumulate path (k4_plan / k4_acc below) leaves on the list --
     // windows touched by a long read or an odd CIGAR, windows too deep for a descriptor slab.  A window whose
     // candidate range could overflow 16-bit counters takes the 32-bit layout, every other one the 16-bit layout.
   for (uint64_t it = blockIdx.x; it < *a.n_deep; it += gridDim.x) {
@@ -1014,29 +1003,22 @@ __global__ __launch_bounds__(256) void k4_stats(const unsigned long long* ts, ui
     if ((threadIdx.x & 63) == 0) { atomicAdd(&pstats[0], c); atomicAdd(&pstats[1], s); atomicMax(&pstats[2], m); atomicAdd(&pstats[4], u); }
 }
 
-// ---------------------------------------------------------------------------------------------- K4, gather path
+// ---------------------------------------------------------------------------------------------- K4: plan + accumulate
 //
-// The same closed form (file header), turned around: instead of every BASE finding its counter (one LDS atomic per
-// base, lanes = reads, counters wherever the positions say: 77 % of the LDS cycles of that kernel were bank
-// conflicts), every POSITION gathers its bases.  Two kernels:
+// The same closed form (file header) without a window ever scanning a candidate range.  Two kernels:
 //
 //   k4_plan   one lane per READ, one pass over the record table and the first-four-ops side array K1 leaves
-//             (no window ever scans a candidate range: the ~1000-row halo of N-skip reads is gone).  An ordinary
-//             read (1..4 ops, l_seq <= 160, first reference-consuming op M/=/X, nothing zero-length) becomes 8-byte
+//             (the ~1000-row halo a window had to scan because of N-skip reads is gone).  An ordinary
+//             read (1..4 ops, l_seq <= 255, first reference-consuming op M/=/X, nothing zero-length) becomes 8-byte
 //             DESCRIPTORS appended to the slabs of the windows it touches: one SEG per (M/=/X op, window) --
 //             where the bases are in the stream, where they land in the window -- and one DEL per (D/N op, edge
-//             window); windows an N/D op covers completely get +1 through a difference array over windows.  Any
-//             other read marks the windows it overlaps for the general kernel (k4_tile above).
-//   k4_exec   one workgroup per WINDOW of 1024 positions.  Stage: every SEG's packed bases are fetched (lanes
-//             along the read, 16 bases per lane), turned into one byte per base = the BIT POSITION of its class
-//             counter (A 0, C 6, G 12, T 18, other 24; bytes outside the segment 0xFF) with three v_perm lookups
-//             per four bases, and written to LDS with 64 bytes of 0xFF between segments.  Gather: a wave owns 64
-//             consecutive positions and walks the list of segments overlapping them (built in LDS while staging);
-//             per (segment, 64 positions) pair it costs one v_readlane (the segment's address delta), one add, one
-//             ds_read_u8 -- consecutive lanes read consecutive bytes: conflict free -- and one v_lshl_add into a
-//             packed counter register (5 x 6 bits, unpacked into five 32-bit registers every 56 pairs).  Lanes beyond
-//             a segment's ends read its 0xFF padding and add to bit 31.  D/N ops stay two adds on a difference
-//             array, n_starting_here one add per read.  No atomic per base anywhere.
+//             window); windows an N/D op covers completely get +1 through a difference array over windows.  A long read
+//             whose CIGAR walk (k4_ck_build) found it well formed becomes ROW descriptors (its row of one class byte per
+//             column, written by k4_rows_build).  Any other read marks the windows it overlaps for the general kernel
+//             (k4_tile above).
+//   k4_acc    (further down) walks the windows' slabs with lanes ALONG the reads and adds every base to a 16-bit counter
+//             in LDS.  Round 2's executor -- k4_exec: class bytes staged in LDS, then every POSITION gathering its bases
+//             out of them, 10.3 ms on cfg3 -- is gone; DESIGN.md section 4 keeps its measurements.
 //
 // Descriptor (64 bits): [1:0] kind (0 none, 1 SEG, 2 DEL)
 //   SEG  [2] the read starts here (n_starting_here)  [13:3] first position in the window  [21:14] bases (1..255)
@@ -1048,45 +1030,7 @@ __global__ __launch_bounds__(256) void k4_stats(const unsigned long long* ts, ui
 #ifndef BGP_PLAN_ABL
 #define BGP_PLAN_ABL 0                        // timing experiments on k4_plan: 1 no '-' window atomics, 2 no far-slot atomics, 4 no descriptor stores
 #endif
-#ifndef BGP_G_ABL
-#define BGP_G_ABL 0                           // timing experiments: 1 no gather, 2 no staging either, 3 no layout either, 4 window header only
-#endif
-#ifdef BGP_G_PROF                              // phase clocks of k4_exec (thread 0 of every workgroup), one row of 16 per window
-__device__ unsigned long long* g_prof_buf;
-#define GSTAMP(k) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); pacc_[k] += now_ - stamp_; stamp_ = now_; if ((k) == 11 && threadIdx.x == 0) for (int q_ = 0; q_ < 12; ++q_) g_prof_buf[tile * 16 + q_] = pacc_[q_]; } while (0)
-#else
-#define GSTAMP(k) do { } while (0)
-#endif
-#ifndef BGP_G_T
-#define BGP_G_T (BGP_K4_W / 2)
-#endif
-constexpr int GT = BGP_G_T;                   // threads of a k4_exec workgroup
-constexpr int GNW = GT / 64;                  // waves
-constexpr int GNB = W / 64;                   // 64-position blocks per window
-constexpr int GBPW = GNB / GNW;               // blocks per wave
-constexpr int GCAP = GT;                      // descriptors per round (one per thread)
 constexpr uint32_t SLAB_CAP = W;              // descriptors a window's slab holds (~3 x the ordinary count at 30-fold coverage); more: the window goes to k4_tile
-constexpr int PAIRCAP = 128;                  // entries of a block's segment list (a fuller list is worked off in pieces)
-constexpr int G_STAGE = 52 * W;               // staged class bytes per round (what does not fit waits for the next round)
-constexpr int CH_CAP = G_STAGE / 32;          // 32-base staging chunks per round
-constexpr int STAGE_IT = (CH_CAP + GT - 1) / GT;
-constexpr int GD_STEPS = GCAP / 64;
-static_assert(GBPW >= 1 && GNB % GNW == 0 && GNB <= 32, "window / workgroup geometry");
-static_assert(W <= 2048 && GCAP <= 1024, "descriptor fields");
-// LDS map of k4_exec (bytes)
-constexpr int G_TAIL = G_STAGE;                               // 17 x 16: tail masks
-constexpr int G_DELD = G_TAIL + 17 * 16;                      // (W + 4) x u32
-constexpr int G_NST = G_DELD + (W + 4) * 4;                   // W x u16, two to a word
-constexpr int G_HIST = G_NST + W * 2;                         // HB x u32
-constexpr int G_BLKL = G_HIST + HB * 4;                       // GNB x PAIRCAP x u16: a block's segment list, private to the wave that owns the block
-constexpr int G_SEGI = G_BLKL + GNB * PAIRCAP * 2;            // GCAP x uint4: where a segment's bases are, where its class bytes go
-constexpr int G_GD = G_SEGI + GCAP * 16;                      // GCAP x u32: address delta | first block << 16 | last block << 21
-constexpr int G_CMAP = G_GD + GCAP * 4;                       // CH_CAP x u16: staging chunk -> segment << 3 | chunk of the segment
-constexpr int G_ROWL = G_CMAP + CH_CAP * 2;                   // GCAP x u16: the round's ROW descriptors (long reads)
-constexpr int G_MISC = (G_ROWL + GCAP * 2 + 15) & ~15;        // wave totals, flags
-constexpr int G_LDS = G_MISC + 256;
-static_assert(2 * G_LDS <= 160 * 1024, "two workgroups per CU");
-static_assert(G_SEGI % 16 == 0 && G_DELD % 16 == 0 && G_GD % 4 == 0 && G_MISC % 8 == 0, "alignment");
 
 struct PlanArgs {
     const bgp_record* rec; const uint4* cig4; const uint8_t* s; uint64_t stream_len, n;
@@ -1147,11 +1091,16 @@ __global__ __launch_bounds__(256) void k4_plan(PlanArgs a) {
         if (a.ck && wants_ckpt(n_cig, l_seq) && a.ck[a.ck_off[ii]].pad == 0) {
             // a long read that fits the mould (k4_ck_build walked its CIGAR): one ROW descriptor per window it touches
             const uint32_t rel1 = x.z - (uint32_t)r_start_pos;
+            // (in pieces of at most ROW_PIECE positions: k4_acc's waves draw descriptors, and a window of long reads holds only a few dozen)
             for (uint32_t w = wf0; w <= wl; ++w) {
                 const uint32_t w0 = (w - tb) * (uint32_t)W;
                 const uint32_t lo = max(rel0, w0) - w0, hi = min(rel1, w0 + (uint32_t)W) - w0;
-                const uint32_t slot = atomicAdd(&a.wcount[w], 1u);
-                if (slot < SLAB_CAP) a.slab[(uint64_t)w * SLAB_CAP + slot] = 3ull | (w == wf0 ? 4ull : 0ull) | ((unsigned long long)lo << 3) | ((unsigned long long)(hi - lo - 1) << 14) | ((a.row_off[ii] + (w0 + lo - rel0)) << 24);
+                const uint32_t j0 = lo / ROW_PIECE, j1 = (hi - 1) / ROW_PIECE;
+                const uint32_t slot0 = atomicAdd(&a.wcount[w], j1 - j0 + 1);
+                for (uint32_t j = j0; j <= j1; ++j) {
+                    const uint32_t plo = max(lo, j * ROW_PIECE), phi = min(hi, (j + 1) * ROW_PIECE), slot = slot0 + (j - j0);
+                    if (slot < SLAB_CAP) a.slab[(uint64_t)w * SLAB_CAP + slot] = 3ull | (w == wf0 && j == j0 ? 4ull : 0ull) | ((unsigned long long)plo << 3) | ((unsigned long long)(phi - plo - 1) << 14) | ((a.row_off[ii] + (w0 + plo - rel0)) << 24);
+                }
             }
         } else {                                          // left to the general kernel, with every window it overlaps
             atomicAdd(&a.wslow[wf0], 1); atomicAdd(&a.wslow[wl + 1], -1);
@@ -1224,7 +1173,7 @@ __global__ __launch_bounds__(256) void k4_plan(PlanArgs a) {
 }
 
 // Prefix sums over windows of the two difference arrays (whole-window '-' levels, slow-read marks), then the verdict
-// per window -- bit 1 of TileB.pad = "not for the gather path" -- and the list of such windows.  Three small launches:
+// per window -- bit 1 of TileB.pad = "not for the accumulate path" -- and the list of such windows.  Three small launches:
 // per-block totals, their exclusive scan by one workgroup, the prefix proper.
 __device__ __forceinline__ void wscan_block(int32_t d, int32_t sl, int32_t* id_out, int32_t* is_out, int32_t* pd, int32_t* ps, int32_t* td, int32_t* ts, int32_t (*ws)[16]) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -1296,422 +1245,85 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
     return rl(v, 63);
 }
 
-// Eight (segment, 64 positions) pairs of the gather, scheduled by hand: the segments' address deltas come out of lanes
-// L0 .. L0+7 of `vc` with v_readlane, eight ds_read_u8 are in flight together, every byte read is the bit position the
-// lane's packed counter grows at (v_lshl_add_u32).  Left to the compiler under register pressure this became
-// read - wait - use with one temporary, i.e. one LDS latency per pair.
-template <int L0> __device__ __forceinline__ void gather8(uint32_t& acc, uint32_t vc, uint32_t addr) {
-    uint32_t t0, t1, t2, t3, t4, t5, t6, t7, s0, s1, s2, s3, s4, s5, s6, s7;
-    asm volatile(
-        "v_readlane_b32 %[s0], %[vc], %[l0]\n\tv_readlane_b32 %[s1], %[vc], %[l1]\n\tv_readlane_b32 %[s2], %[vc], %[l2]\n\tv_readlane_b32 %[s3], %[vc], %[l3]\n\t"
-        "v_readlane_b32 %[s4], %[vc], %[l4]\n\tv_readlane_b32 %[s5], %[vc], %[l5]\n\tv_readlane_b32 %[s6], %[vc], %[l6]\n\tv_readlane_b32 %[s7], %[vc], %[l7]\n\t"
-        "v_add_u32 %[t0], %[s0], %[ad]\n\tv_add_u32 %[t1], %[s1], %[ad]\n\tv_add_u32 %[t2], %[s2], %[ad]\n\tv_add_u32 %[t3], %[s3], %[ad]\n\t"
-        "s_waitcnt lgkmcnt(0)\n\t"
-        "ds_read_u8 %[t0], %[t0]\n\tds_read_u8 %[t1], %[t1]\n\tds_read_u8 %[t2], %[t2]\n\tds_read_u8 %[t3], %[t3]\n\t"
-        "v_add_u32 %[t4], %[s4], %[ad]\n\tv_add_u32 %[t5], %[s5], %[ad]\n\tv_add_u32 %[t6], %[s6], %[ad]\n\tv_add_u32 %[t7], %[s7], %[ad]\n\t"
-        "ds_read_u8 %[t4], %[t4]\n\tds_read_u8 %[t5], %[t5]\n\tds_read_u8 %[t6], %[t6]\n\tds_read_u8 %[t7], %[t7]\n\t"
-        "s_waitcnt lgkmcnt(7)\n\tv_lshl_add_u32 %[acc], 1, %[t0], %[acc]\n\t"
-        "s_waitcnt lgkmcnt(6)\n\tv_lshl_add_u32 %[acc], 1, %[t1], %[acc]\n\t"
-        "s_waitcnt lgkmcnt(5)\n\tv_lshl_add_u32 %[acc], 1, %[t2], %[acc]\n\t"
-        "s_waitcnt lgkmcnt(4)\n\tv_lshl_add_u32 %[acc], 1, %[t3], %[acc]\n\t"
-        "s_waitcnt lgkmcnt(3)\n\tv_lshl_add_u32 %[acc], 1, %[t4], %[acc]\n\t"
-        "s_waitcnt lgkmcnt(2)\n\tv_lshl_add_u32 %[acc], 1, %[t5], %[acc]\n\t"
-        "s_waitcnt lgkmcnt(1)\n\tv_lshl_add_u32 %[acc], 1, %[t6], %[acc]\n\t"
-        "s_waitcnt lgkmcnt(0)\n\tv_lshl_add_u32 %[acc], 1, %[t7], %[acc]"
-        : [acc] "+v"(acc), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [t4] "=&v"(t4), [t5] "=&v"(t5), [t6] "=&v"(t6), [t7] "=&v"(t7),
-          [s0] "=&s"(s0), [s1] "=&s"(s1), [s2] "=&s"(s2), [s3] "=&s"(s3), [s4] "=&s"(s4), [s5] "=&s"(s5), [s6] "=&s"(s6), [s7] "=&s"(s7)
-        : [vc] "v"(vc), [ad] "v"(addr), [l0] "n"(L0), [l1] "n"(L0 + 1), [l2] "n"(L0 + 2), [l3] "n"(L0 + 3), [l4] "n"(L0 + 4), [l5] "n"(L0 + 5), [l6] "n"(L0 + 6), [l7] "n"(L0 + 7)
-        : "memory");
-}
-
-#ifndef BGP_G_MINW
-#define BGP_G_MINW (GNW / 2)                  // two workgroups per CU: their waves per SIMD bound the registers (128 for 8-wave workgroups)
-#endif
-template <bool ROWS> __global__ __launch_bounds__(GT, BGP_G_MINW) void k4_exec(GArgs a) {
-    constexpr int FSH = ROWS ? 5 : 6;                  // bits of a packed class counter
-    constexpr uint32_t FM = (1u << FSH) - 1u;
-    constexpr uint32_t PAIRS = ROWS ? 24 : 56;         // (segment, 64 positions) pairs a packed counter takes before it is unpacked
-    extern __shared__ __attribute__((aligned(16))) uint8_t glds[];
-    uint8_t* const stage = glds;
-    uint4* const tailm = reinterpret_cast<uint4*>(glds + G_TAIL);
-    uint32_t* const deld = reinterpret_cast<uint32_t*>(glds + G_DELD);
-    uint32_t* const nst = reinterpret_cast<uint32_t*>(glds + G_NST);
-    uint32_t* const hist = reinterpret_cast<uint32_t*>(glds + G_HIST);
-    uint16_t* const blk_l = reinterpret_cast<uint16_t*>(glds + G_BLKL);
-    uint4* const segi = reinterpret_cast<uint4*>(glds + G_SEGI);
-    uint32_t* const gd = reinterpret_cast<uint32_t*>(glds + G_GD);
-    uint16_t* const cmap = reinterpret_cast<uint16_t*>(glds + G_CMAP);
-    uint16_t* const rowl = reinterpret_cast<uint16_t*>(glds + G_ROWL);
-    uint32_t* const misc = reinterpret_cast<uint32_t*>(glds + G_MISC);     // [0..15] wave totals, [16] descriptors of the round that fit
-    // Persistent: a workgroup owns a contiguous range of windows and walks it, so a read staged by two neighbouring
-    // windows is fetched from HBM once, and -- the point -- the NEXT window's header and first descriptors are
-    // requested before the current window is worked on: that round trip hides behind a whole window of work
-    // instead of standing in front of it (with two 76 KB workgroups per CU nothing else would overlap it).
-    const int t = threadIdx.x, lane = t & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const uint64_t nbt = a.n_tiles, per = (nbt + gridDim.x - 1) / gridDim.x;
-    const uint64_t tile_end = min(nbt, ((uint64_t)blockIdx.x + 1) * per);
-    uint64_t tile = (uint64_t)blockIdx.x * per;
-    if (tile >= tile_end) return;
-    if (t < 17) { uint32_t m[4]; for (int k = 0; k < 4; ++k) { const int v = t - 4 * k; m[k] = v >= 4 ? 0u : v <= 0 ? 0xFFFFFFFFu : 0xFFFFFFFFu << (8 * v); } tailm[t] = make_uint4(m[0], m[1], m[2], m[3]); }
-    if (t < 4) reinterpret_cast<uint4*>(stage)[t] = make_uint4(~0u, ~0u, ~0u, ~0u);     // the 64 padding bytes in front of the first segment (no round writes them)
-    for (int i = t; i < (G_BLKL - G_DELD) / 4; i += GT) deld[i] = 0;      // deld, nst (a window leaves them zeroed again), hist (kept for the whole range of windows)
-    // What the next window needs first -- its header, its first descriptors -- is requested a window ahead and held in
-    // VECTOR registers (every lane loads the same header words; they are made uniform only when they are used).  Left
-    // to the compiler the header became vector loads turned into scalars on the spot: an `s_waitcnt vmcnt` right behind
-    // the "prefetch", and since gfx9 counts loads and stores with ONE in-order counter, that wait also stood for the
-    // previous window's 32 KB of column stores -- every window paid two memory round trips at its top.
-    struct Pre { unsigned long long d; uint2 col; uint4 tt; uint32_t n; int32_t wd; };
-    auto prefetch = [&](uint64_t w) {
-        Pre p;
-        p.d = a.slab[w * (uint64_t)SLAB_CAP + t];
-        const char* tp = reinterpret_cast<const char*>(a.tiles + w);
-        __builtin_memcpy(&p.col, tp + 16, 8);          // TileB: i_lo, i_hi, col_out | T0, Tend, run_start, pad
-        __builtin_memcpy(&p.tt, tp + 24, 16);
-        p.n = a.wcount[w]; p.wd = a.wdel[w];
-        return p;
-    };
-    auto settle = [](Pre& p) {                          // the values have arrived (or: wait for them here, once) and count as new
-        uint32_t dl = (uint32_t)p.d, dh = (uint32_t)(p.d >> 32);
-        asm volatile("; prefetched window settled" : "+v"(dl), "+v"(dh), "+v"(p.col.x), "+v"(p.col.y), "+v"(p.tt.x), "+v"(p.tt.y), "+v"(p.tt.z), "+v"(p.tt.w), "+v"(p.n), "+v"(p.wd));
-        p.d = ((unsigned long long)dh << 32) | dl;
-    };
-    Pre pre = prefetch(tile);
-    uint32_t r_ncol = 0, r_nsum = 0, r_mx = 0; unsigned long long r_scov = 0;      // the range's totals, per lane: reduced once, after the last window
-  for (; tile < tile_end; ++tile) {
-#ifdef BGP_G_PROF
-    unsigned long long pacc_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    unsigned long long stamp_ = __builtin_amdgcn_s_memtime();
-#endif
-    settle(pre);
-    const unsigned long long d_first = pre.d;
-    struct { uint64_t col_out; uint32_t T0, Tend, run_start, pad; } tb;
-    tb.col_out = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)pre.col.y) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)pre.col.x);
-    tb.T0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)pre.tt.x); tb.Tend = (uint32_t)__builtin_amdgcn_readfirstlane((int)pre.tt.y);
-    tb.pad = (uint32_t)__builtin_amdgcn_readfirstlane((int)pre.tt.w); tb.run_start = (uint32_t)__builtin_amdgcn_readfirstlane((int)pre.tt.z);
-    const uint32_t n_desc = (uint32_t)__builtin_amdgcn_readfirstlane((int)pre.n);
-    const int32_t wd = __builtin_amdgcn_readfirstlane(pre.wd);
-    if (tile + 1 < tile_end) pre = prefetch(tile + 1);
-    if (tb.pad) continue;                                 // on the general kernel's list
-#if BGP_G_ABL >= 4
-    if (tb.T0 != 0xFFFFFFFFu) continue;
-#endif
-    const unsigned long long* slab = a.slab + tile * (uint64_t)SLAB_CAP;
-    uint32_t cA[GBPW], cC[GBPW], cG[GBPW], cT[GBPW], cO[GBPW], cD[GBPW];        // (cD: '-' of long reads' rows; ROWS only)
-#pragma unroll
-    for (int b = 0; b < GBPW; ++b) { cA[b] = 0; cC[b] = 0; cG[b] = 0; cT[b] = 0; cO[b] = 0; cD[b] = 0; }
-    GSTAMP(0);        // (the header and the first descriptors were requested a window ago)
-
-    for (uint32_t base = 0; base < (BGP_G_ABL >= 3 ? 0u : n_desc);) {
-        const uint32_t nr = min((uint32_t)GCAP, n_desc - base);
-        // ---- lay out: a place in LDS for every segment's class bytes, '-' and start marks
-        unsigned long long d = 0;
-        if ((uint32_t)t < nr) d = base == 0 ? d_first : slab[base + t];
-        uint32_t kind = (uint32_t)d & 3u;
-        const uint32_t lo = ((uint32_t)d >> 3) & 0x7FFu, f14 = (uint32_t)(d >> 14);
-        bool is_row = ROWS && kind == 3;                                      // (only a stream with long reads has them: the other instantiation carries none of this)
-        if (!ROWS && kind == 3) kind = 0;
-        const uint32_t len = is_row ? (f14 & 0x3FFu) + 1u : f14 & 0xFFu, nib = is_row ? 0u : (f14 >> 8) & 1u;      // (ROW: up to W positions)
-        const uint32_t nch = (kind == 1 || is_row) ? (len + nib + 15) >> 4 : 0u;      // 16-byte units of class bytes (SEG, ROW)
-        const uint32_t c32 = kind == 1 ? (nch + 1) >> 1 : 0u;                 // 32-base staging chunks (a ROW is copied as it is)
-        const uint32_t units = (kind == 1 || is_row) ? (nch + 4) | (c32 << 16) : 0u;    // low half: the bytes + 64 of padding behind them
-        if (ROWS && t == 0) misc[18] = 0;                                     // ROW descriptors of the round
-        const uint32_t inc = wave_incl_u32(units, lane);
-        if (lane == 63) misc[wave] = inc;
-        GSTAMP(1);    // descriptors arrived, wave scan
-#ifdef BGP_G_PROF
-        pacc_[8] += 1;   // rounds of the window
-#endif
-        __syncthreads();
-        uint32_t carry = 0, total = 0;
-#pragma unroll
-        for (int k = 0; k < GNW; ++k) { const uint32_t v = misc[k]; if (k < wave) carry += v; total += v; }
-        const uint32_t ex = carry + inc - units;
-        const uint32_t data_off = 64 + 16 * (ex & 0xFFFFu);
-        uint32_t n_fit = nr, n_chunks = total >> 16;
-        if (64 + 16 * (total & 0xFFFFu) > (uint32_t)G_STAGE) {                // the round is cut where LDS ends; the rest waits for the next one
-            const bool fit = (uint32_t)t < nr && data_off + 16 * (nch + 4) <= (uint32_t)G_STAGE;
-            if (t == 0) { misc[16] = 0; misc[17] = 0; }
-            __syncthreads();
-            const unsigned long long fm = __ballot(fit);
-            if (lane == 0 && fm) { atomicAdd(&misc[16], (uint32_t)__popcll(fm)); }
-            if (fit) atomicMax(&misc[17], (ex >> 16) + c32);
-            __syncthreads();
-            n_fit = misc[16]; n_chunks = misc[17];
-        }
-        if ((uint32_t)t >= n_fit) { kind = 0; is_row = false; }
-        {   // every byte the round may look at starts as padding (0xFF): consecutive lanes, consecutive 16 bytes -- no bank conflicts,
-            // where four stores per segment at the segments' own addresses had plenty
-            const uint32_t extent = min((uint32_t)G_STAGE, 64 + 16 * (total & 0xFFFFu));
-            const uint4 ff = make_uint4(~0u, ~0u, ~0u, ~0u);
-            for (uint32_t o = 64 + 16 * (uint32_t)t; o < extent; o += 16 * GT) *reinterpret_cast<uint4*>(stage + o) = ff;
-        }
-        if (kind == 1) {
-            const uint64_t src = d >> 23;
-            segi[t] = make_uint4((uint32_t)src, (uint32_t)(src >> 32) | (nib << 16) | (len << 20), data_off, 0u);
-            const uint32_t cdel = data_off + nib - lo + W;                   // staged byte of position p: stage[p - W + cdel]
-            gd[t] = cdel | ((lo >> 6) << 16) | (((lo + len - 1) >> 6) << 21);
-            const uint32_t c0 = ex >> 16;
-            for (uint32_t j = 0; j < c32; ++j) cmap[c0 + j] = (uint16_t)((t << 3) | j);
-            if (d & 4u) atomicAdd(&nst[lo >> 1], 1u << ((lo & 1u) * 16));   // n_starting_here, pileup.d:386,422 (a count per position stays below 2^16: the slab holds W descriptors)
-        } else if (is_row) {
-            { const uint64_t rsrc = d >> 24; segi[t] = make_uint4((uint32_t)rsrc, (uint32_t)(rsrc >> 32) | ((len - 1) << 16), data_off, 0u); }   // where the row's class bytes are (k4_ck_build wrote them) | its length | where they go
-            gd[t] = (data_off - lo + W) | ((lo >> 6) << 16) | (((lo + len - 1) >> 6) << 21);
-            rowl[atomicAdd(&misc[18], 1u)] = (uint16_t)t;
-            if (d & 4u) atomicAdd(&nst[lo >> 1], 1u << ((lo & 1u) * 16));
-        } else {
-            gd[t] = 1u << 16;                                                 // first block 1, last block 0: overlaps nothing
-            if (kind == 2) { atomicAdd(&deld[lo], 1u); atomicAdd(&deld[f14 & 0xFFFu], 0xFFFFFFFFu); }
-        }
-        GSTAMP(2);    // layout
-        __syncthreads();
-        GSTAMP(3);
-        // ---- stage: 32 bases per lane, lane after lane along the segments.  Every load of the round is requested
-        // before the first is looked at: one HBM round trip per round.
-        uint4 pk[STAGE_IT]; uint32_t ce[STAGE_IT];     // ce: where the lane's 32 class bytes go | bytes of them inside the segment << 16 | a skipped first nibble << 24
-#if BGP_G_ABL >= 2
-        if (n_desc != 0xFFFFFFFFu) { base += n_fit; continue; }
-#endif
-#pragma unroll
-        for (int it = 0; it < STAGE_IT; ++it) {
-            const uint32_t c = (uint32_t)(it * GT + t);
-            pk[it] = make_uint4(0, 0, 0, 0); ce[it] = 0xFFFFFFFFu;
-            if (c < n_chunks) {
-                const uint32_t e = cmap[c], sj = e & 7u;
-                const uint4 g = segi[e >> 3];
-                __builtin_memcpy(&pk[it], a.s + ((((uint64_t)(g.y & 0xFFFFu)) << 32) | g.x) + 16u * sj, 16);
-                const uint32_t glen = g.y >> 20, gnib = (g.y >> 16) & 1u;
-                ce[it] = (g.z + 32u * sj) | (min(glen + gnib - 32u * sj, 32u) << 16) | ((sj == 0 ? gnib : 0u) << 24);
-            }
-        }
-        GSTAMP(4);    // staging loads issued
-#pragma unroll
-        for (int it = 0; it < STAGE_IT; ++it) {
-            if (ce[it] != 0xFFFFFFFFu) {
-                const int32_t valid = (int32_t)((ce[it] >> 16) & 0xFFu);           // staged bytes of this lane that belong to the segment (incl. the skipped nibble): 1..32
-                const uint2 c0 = class_bits8<ROWS>(pk[it].x), c1 = class_bits8<ROWS>(pk[it].y), c2 = class_bits8<ROWS>(pk[it].z), c3 = class_bits8<ROWS>(pk[it].w);
-                const uint4 t0 = tailm[min(valid, 16)], t1 = tailm[max(valid - 16, 0)];
-                uint4 o0 = make_uint4(c0.x | t0.x, c0.y | t0.y, c1.x | t0.z, c1.y | t0.w);
-                const uint4 o1 = make_uint4(c2.x | t1.x, c2.y | t1.y, c3.x | t1.z, c3.y | t1.w);
-                if (ce[it] >> 24) o0.x |= 0xFFu;
-                uint4* dst = reinterpret_cast<uint4*>(stage + (ce[it] & 0xFFFFu));
-                dst[0] = o0; dst[1] = o1;                                         // (a second half past the segment lands in its own padding)
-            }
-        }
-        // ---- long reads: a ROW is copied as it is (class bytes in reference coordinates), a wave per row, 16 bytes a lane
-        if (ROWS) {
-            const uint32_t n_rows = misc[18];
-            for (uint32_t rr = (uint32_t)wave; rr < n_rows; rr += GNW) {
-                const uint4 g = segi[rowl[rr]];
-                const uint32_t rlen = (g.y >> 16) + 1u, u = 16u * (uint32_t)lane;
-                if (u < rlen) {
-                    uint4 v; __builtin_memcpy(&v, a.rows + ((((uint64_t)(g.y & 0xFFu)) << 32) | g.x) + u, 16);
-                    const uint4 tm = tailm[min(rlen - u, 16u)];
-                    *reinterpret_cast<uint4*>(stage + g.z + u) = make_uint4(v.x | tm.x, v.y | tm.y, v.z | tm.z, v.w | tm.w);
-                }
-            }
-        }
-        GSTAMP(5);    // staged
-        __syncthreads();
-        GSTAMP(6);
-        // ---- gather: a wave picks the segments that overlap each of its 64-position blocks (list private to the
-        // wave: a ballot, no atomics) and walks them
-#pragma unroll
-        for (int bb = 0; bb < (BGP_G_ABL >= 1 ? 0 : GBPW); ++bb) {
-            const int b = wave * GBPW + bb;
-            const uint32_t paddr = (uint32_t)reinterpret_cast<uintptr_t>(stage) + (uint32_t)(64 * b + lane - W);   // LDS address + delta = this lane's byte of the segment
-            const uint32_t csent = (uint32_t)(W - 64 * b);                    // + paddr = the padding in front of the first segment
-            uint16_t* const bl = blk_l + b * PAIRCAP;
-            uint32_t n = 0;
-            auto walk = [&]() {
-                for (uint32_t p0 = 0; p0 < n; p0 += PAIRS) {
-                    const uint32_t cnt = min(PAIRS, n - p0);
-                    const uint32_t vc = (uint32_t)lane < cnt ? (uint32_t)bl[p0 + lane] : csent;
-                    uint32_t acc = 0;
-                    gather8<0>(acc, vc, paddr);
-                    if (cnt > 8) gather8<8>(acc, vc, paddr);
-                    if (cnt > 16) gather8<16>(acc, vc, paddr);
-                    if (!ROWS) {
-                        if (cnt > 24) gather8<24>(acc, vc, paddr);
-                        if (cnt > 32) gather8<32>(acc, vc, paddr);
-                        if (cnt > 40) gather8<40>(acc, vc, paddr);
-                        if (cnt > 48) gather8<48>(acc, vc, paddr);
-                    }
-                    cA[bb] += acc & FM; cC[bb] += (acc >> FSH) & FM; cG[bb] += (acc >> (2 * FSH)) & FM; cT[bb] += (acc >> (3 * FSH)) & FM; cO[bb] += (acc >> (4 * FSH)) & FM;
-                    if (ROWS) cD[bb] += (acc >> (5 * FSH)) & FM;
-                }
-                n = 0;
-            };
-#pragma unroll
-            for (int k = 0; k < GD_STEPS; ++k) {
-                if ((uint32_t)(k * 64) >= n_fit) break;
-                const uint32_t v = gd[k * 64 + lane];
-                const bool in = ((v >> 16) & 31u) <= (uint32_t)b && (uint32_t)b <= (v >> 21);
-                const unsigned long long m = __ballot(in);
-                if (!m) continue;
-                if (in) bl[n + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = (uint16_t)v;
-                n += (uint32_t)__popcll(m);
-                if (n > (uint32_t)PAIRCAP - 64) walk();
-            }
-            walk();
-        }
-        GSTAMP(7);    // gathered (no barrier here: whatever overwrites the tables or the staged bytes next does so behind a barrier of its own)
-        base += n_fit;
-    }
-    settle(pre);      // (before the column stores are issued: nothing behind them in the counter is waited for at the next window's top)
-    // ---- flush: the '-' difference array summed up (a wave scans its own positions with DPP, the waves before it
-    // enter as one number each), then 32 contiguous bytes per position.  What a lane reads of deld / nst it zeroes for
-    // the next window (whose first barrier comes before anything is added again).
-    const uint32_t np = tb.Tend - tb.T0;
-    uint32_t dl[GBPW];
-    {
-        uint32_t run = 0;
-#pragma unroll
-        for (int bb = 0; bb < GBPW; ++bb) {
-            const uint32_t p = 64 * (wave * GBPW + bb) + lane;
-            const uint32_t e = deld[p];
-            deld[p] = 0;
-            const uint32_t sc = wave_scan_u32(e);
-            dl[bb] = run + sc;
-            run += rl(sc, 63);
-        }
-        if (t == 0) deld[W] = 0;                                             // (an op that ends with the window leaves its -1 here)
-        if (lane == 0) misc[32 + wave] = run;                                // (slots of their own: a wave ahead may already be scanning the next window's descriptors into misc[0..])
-        __syncthreads();
-        uint32_t carry = (uint32_t)wd;
-        for (int k = 0; k < wave; ++k) carry += misc[32 + k];
-#pragma unroll
-        for (int bb = 0; bb < GBPW; ++bb) dl[bb] += carry;
-    }
-    GSTAMP(9);        // '-' scan
-    bgp_column* out = a.cols + tb.col_out;
-    uint32_t ncol = 0, scov = 0, nsum = 0, mx = 0;      // per lane: GBPW positions, sums below 2^32
-#pragma unroll
-    for (int bb = 0; bb < GBPW; ++bb) {
-        const uint32_t p = 64 * (wave * GBPW + bb) + lane;
-        const uint32_t sw = nst[p >> 1];
-        if (p < np) {
-            const uint32_t D = dl[bb] + (ROWS ? cD[bb] : 0u), S = (sw >> ((p & 1u) * 16)) & 0xFFFFu;
-            const uint32_t cov = cA[bb] + cC[bb] + cG[bb] + cT[bb] + cO[bb] + D;
-            uint4* o4 = reinterpret_cast<uint4*>(out + p);
-            o4[0] = make_uint4(cov, S, cA[bb], cC[bb]);
-            o4[1] = make_uint4(cG[bb], cT[bb], cO[bb], D);
-            ncol += cov > 0; scov += cov; mx = max(mx, cov); nsum += S;
-            if (cov < (uint32_t)HB) atomicAdd(&hist[cov], 1u);
-            else atomicAdd(&a.hist[min(cov, (uint32_t)BGP_DEPTH_BINS - 1)], 1ull);
-        }
-    }
-    // (two lanes share a word of nst: both have read it before either zeroes it -- the wave runs in lockstep)
-#pragma unroll
-    for (int bb = 0; bb < GBPW; ++bb) { const uint32_t p = 64 * (wave * GBPW + bb) + lane; if ((p & 1u) == 0) nst[p >> 1] = 0; }
-    GSTAMP(10);       // columns written
-    r_ncol += ncol; r_nsum += nsum; r_mx = max(r_mx, mx); r_scov += scov;     // (k4_stats only wants sums and a maximum over all windows: the range's go to its first window's slot)
-    GSTAMP(11);       // totals
-  }
-  {   // the range's totals: wave reductions with DPP, then one atomic per wave and total (the slots were zeroed by the host)
-      const uint32_t w_ncol = wave_sum_u32(r_ncol), w_nsum = wave_sum_u32(r_nsum), w_mx = wave_max_u32(r_mx);
-      const uint32_t s0 = wave_sum_u32((uint32_t)r_scov & 0xFFFFu), s1 = wave_sum_u32((uint32_t)(r_scov >> 16) & 0xFFFFu), s2 = wave_sum_u32((uint32_t)(r_scov >> 32) & 0xFFFFu), s3 = wave_sum_u32((uint32_t)(r_scov >> 48));
-      if (lane == 0) {
-          unsigned long long* ts = a.tile_stats + (a.n_tiles + blockIdx.x) * 4;      // (slots of the workgroups, behind the windows': the general kernel stores its windows' totals in theirs)
-          if (w_ncol) atomicAdd(&ts[0], (unsigned long long)w_ncol);
-          const unsigned long long sc = ((unsigned long long)s3 << 48) + ((unsigned long long)s2 << 32) + ((unsigned long long)s1 << 16) + s0;
-          if (sc) atomicAdd(&ts[1], sc);
-          if (w_mx) atomicMax(&ts[2], (unsigned long long)w_mx);
-          if (w_nsum) atomicAdd(&ts[3], (unsigned long long)w_nsum);
-      }
-  }
-  __syncthreads();
-  for (int b = t; b < HB; b += GT) { const uint32_t h = hist[b]; if (h) atomicAdd(&a.hist[b], (unsigned long long)h); }     // the range's depth histogram, once
-}
-
 // ---------------------------------------------------------------------------------------------- K4, accumulate path (round 3)
 //
-// The gather path above makes every POSITION read its bases out of class bytes staged in LDS: two passes over every base
+// Round 2's executor (k4_exec, the "gather path") made every POSITION read its bases out of class bytes staged in LDS: two passes over every base
 // (stage, gather), per-block segment lists in between, six barriers a window and 76 KB of LDS a workgroup -- two
-// workgroups a CU, whose dependent phases leave the SIMDs waiting more than half of the time (round 2's counters).
+// workgroups a CU, whose dependent phases left the SIMDs waiting more than half of the time (round 2's counters).
 // k4_acc runs the same plan (k4_plan's descriptors) the other way round, with nothing staged:
 //
-//   lanes lie ALONG the reads ("consecutive positions -> consecutive LDS addresses"): a lane takes the sixteen
-//   reference positions 16m .. 16m+15 of one SEG descriptor -- one 12-byte load of packed bases, nibble-aligned with a
-//   funnel shift, sixteen class offsets with the v_perm tables -- and adds each base to its counter with one LDS atomic
-//   (ds_add_u32, no return).  Counters are 16 bits wide, positions 2i and 2i+1 share a word, and the word of class c at
-//   position 16m + k is  plane (k >> 1) x 580 + 9m + c: the class offset is a byte of the table's result that goes
-//   straight into the address (v_add_u32_sdwa: one VALU instruction and one LDS instruction per base); in the k-th add of
-//   a chunk the lanes of a segment are nine words apart (any 32 consecutive m on 32 different banks), a lane's two positions
-//   of one word are never touched by the same instruction, and the flush reads 64 consecutive positions without a bank
-//   conflict.  Bases outside a segment's ends go to a dummy class.  Which descriptor a lane-chunk belongs to is a byte per
-//   chunk in LDS, written by the descriptor's lane; the loads of several steps of 64 chunks are in flight before the first
-//   is used, and a wave's next batch of descriptors is requested before it works on the current one.
+//   lanes lie ALONG the reads ("consecutive positions -> consecutive LDS addresses"): a lane takes the eight
+//   reference positions 8m .. 8m+7 of one SEG descriptor -- one 8-byte load, eight classes with the v_perm tables -- and
+//   adds each base to its counter with one LDS atomic (ds_add_u32, no return).  Counters are 16 bits wide, positions 2i and
+//   2i+1 share a word, and the words of one class are laid out  plane (k >> 1) x 132 + m  for position 8m + k: in the k-th add
+//   of a chunk the lanes of a segment hit consecutive words, a lane's two positions of one word are never touched by the same
+//   instruction, and the flush reads 64 consecutive positions two lanes a bank.  Bases outside a segment's ends go to a dummy
+//   class.  Which descriptor a lane-chunk belongs to is a byte per chunk in LDS, written by the descriptor's lane; the loads
+//   of A_U steps of 64 chunks are in flight before the first is used (branch-free: a load inside a branch is waited for at
+//   the branch's end), and a wave's next batch of descriptors is requested before it works on the current one.
+//   (Sixteen positions a lane, and a layout with the classes of a chunk next to each other so that the class goes into the
+//   address with one SDWA add, were built and measured: 9.7 and 9.1 ms against 8.55 -- more LDS bank conflicts than they save
+//   in instructions.)
 //
-//   A workgroup is 4 waves and 31 KB of LDS: five per CU, 20 waves whose phases are independent of each other; a window
-//   costs three barriers.  Waves draw batches of 32 descriptors from a counter in LDS.
+//   The bases come from the packed SEQ inside the record stream (two bases a byte: a chunk that starts on a low nibble is moved
+//   one nibble up with a funnel shift).  (Taking them from the SEQ arena the decode leaves -- dense chars, 19 instead of 25 GB
+//   fetched on cfg3 -- was built and measured: the same 8.9 ms; the kernel is bound by instruction issue and LDS atomics, not
+//   by HBM, and the chars cost seven more VALU instructions a chunk.  Not kept.)
 //
-// Same closed form, same descriptors, same columns as k4_exec: every pileup test checks them against the oracle.
-#ifndef BGP_A_T
-#define BGP_A_T 256
-#endif
+//   A workgroup is 4 waves and 30 KB of LDS: five per CU, 20 waves whose phases are independent of each other; a window
+//   costs three barriers.  Waves draw batches of 64 descriptors from a counter in LDS.
+//
+// Same closed form, same descriptors, same columns: every pileup test checks them against the oracle.
 #ifndef BGP_A_U
-#define BGP_A_U 8
+#define BGP_A_U 5
+#endif
+#ifndef BGP_A_PLPAD
+#define BGP_A_PLPAD 8
 #endif
 #ifndef BGP_A_MINW
 #define BGP_A_MINW 5
 #endif
 #ifndef BGP_A_DB
-#define BGP_A_DB 32
+#define BGP_A_DB 64
 #endif
-constexpr int AT = BGP_A_T;                   // threads of a k4_acc workgroup
+#ifndef BGP_A_MAPCAP
+#define BGP_A_MAPCAP 1408
+#endif
+constexpr int AT = 256;                       // threads of a k4_acc workgroup
 constexpr int ANW = AT / 64;                  // waves
 constexpr int ABPW = (W / 64) / ANW;          // 64-position blocks a wave flushes
-#ifndef BGP_A_CW
-#define BGP_A_CW 8
-#endif
-#ifndef BGP_A_LAY
-#define BGP_A_LAY 0
-#endif
-constexpr int A_CW = BGP_A_CW;                // reference positions a lane takes at a time (8 or 16): positions A_CW m .. A_CW m + A_CW - 1
-constexpr int A_NM = W / A_CW;                // chunks of a window
-constexpr int A_LAY = BGP_A_LAY;              // 0: a class array after the other, consecutive chunks in consecutive words; 1: the classes of a chunk next to each other, chunks nine words apart (the class offset goes into the address with one SDWA add)
-constexpr int A_NPL = A_CW / 2;               // planes: positions 2i and 2i + 1 of a chunk share a word (16-bit halves)
-constexpr int A_MW = 9;                       // LAY 1: words a chunk takes in a plane
-constexpr int A_PLW = A_LAY ? A_NM * A_MW + 4 : A_NM + 4;       // words of a plane (the +4 puts the planes on different banks for the flush)
-constexpr int A_CSW = A_NPL * A_PLW;          // LAY 0: words of one class array
-constexpr int A_U = BGP_A_U;                  // steps of 64 lane-chunks whose loads are in flight together
+constexpr int A_PLW = W / 8 + BGP_A_PLPAD;    // words of a plane: one per chunk of eight positions; + 8: the four planes on different banks for the flush, and a class array a multiple of 32 words -- the class of a base does not move its bank, a segment's lanes hit consecutive banks
+constexpr int A_CSW = 4 * A_PLW;              // words of one class array
+constexpr int A_U = BGP_A_U;                  // steps of 64 lane-chunks whose loads are in flight together (six would spill under the 96 registers of five waves a SIMD)
 constexpr int A_DB = BGP_A_DB;                // descriptors of a batch (<= 64: a lane each)
-constexpr int A_MCAP = A_DB * ((FAST_SEG + 2 * (A_CW - 1)) / A_CW + 1) + 64;   // map bytes of a batch: its descriptors x the chunks of the longest SEG
-static_assert(W == 1024 && ABPW * ANW * 64 == W && A_DB <= 64 && (A_CW == 8 || A_CW == 16), "k4_acc geometry");
+static_assert(W == 1024 && ABPW * ANW * 64 == W && A_DB == 64, "k4_acc geometry");
+// classes: 0 any other base, 1 A, 2 C, 3 G, 4 T, [5 '-' of long reads' rows,] NC: bases outside a segment (never read)
 template <bool ROWS> struct ALay {
-    static constexpr int NC = ROWS ? 6 : 5;                       // A C G T other ['-' of long reads' rows]; class NC: bases outside a segment
-    static constexpr int CNT = 0;                                 // the counters
-    static constexpr int CNT_WORDS = A_LAY ? A_NPL * A_PLW : (NC + 1) * A_CSW;
-    static constexpr int DELD = CNT + CNT_WORDS * 4;              // (W + 4) x u32
+    static constexpr int NC = ROWS ? 6 : 5;
+    static constexpr int CNT = 0;                                 // (NC + 1) x A_CSW x u32
+    static constexpr int DELD = CNT + (NC + 1) * A_CSW * 4;       // (W + 4) x u32
     static constexpr int NST = DELD + (W + 4) * 4;                // W x u16
     static constexpr int HIST = NST + W * 2;                      // HB x u32
-    static constexpr int MARK = HIST + HB * 4;                    // ANW x MROW bytes
-    static constexpr int MROW = ROWS ? A_DB * (A_NM + 2) + 64 : A_MCAP;
+    static constexpr int MARK = HIST + HB * 4;                    // ANW x MROW bytes: chunk -> descriptor of the batch
+    static constexpr int MAXCH = ((int)ROW_PIECE + 14) / 8 + 1;                // chunks of the longest descriptor (SEG: 255 bases, ROW: ROW_PIECE positions)
+    static constexpr int DRAW = ROWS ? 16 : 64;                               // descriptors a wave draws at a time (a window of long reads holds only ~150 pieces: smaller batches keep the four waves busy)
+    static constexpr int MROW = (BGP_A_MAPCAP > MAXCH * (A_DB / 4) ? BGP_A_MAPCAP : MAXCH * (A_DB / 4)) + 64;      // typical batch: 64 x ~20 chunks; a fuller one goes in halves or quarters of its lanes: a quarter always fits
     static constexpr int DSC = (MARK + ANW * MROW + 15) & ~15;    // ANW x A_DB x uint4
     static constexpr int MISC = DSC + ANW * A_DB * 16;            // 64 x u32
     static constexpr int BYTES = MISC + 256;
-    static_assert(NC + 1 <= A_MW, "classes of a chunk");
 };
-static_assert(ALay<false>::BYTES <= 64 * 1024, "k4_acc LDS");
-constexpr uint32_t A_CLS_UNIT = A_LAY ? 4u : 1u;                 // what the class tables count in: bytes inside a chunk's words | class indices
-// word of class c at window position p
-__device__ __forceinline__ uint32_t a_word(uint32_t p, uint32_t c) {
-    const uint32_t m = p / (uint32_t)A_CW, pl = (p % (uint32_t)A_CW) >> 1;
-    return A_LAY ? pl * (uint32_t)A_PLW + m * (uint32_t)A_MW + c : c * (uint32_t)A_CSW + pl * (uint32_t)A_PLW + m;
-}
+static_assert(5 * ALay<false>::BYTES <= 160 * 1024, "five k4_acc workgroups per CU");
 
-// four nt16 codes, one per byte -> their classes in units of A_CLS_UNIT: A 0, C 1, G 2, T 3, anything else 4
-__device__ __forceinline__ uint32_t class_off4(uint32_t x) {
-    constexpr uint32_t U1 = A_CLS_UNIT, U2 = 2 * U1, U3 = 3 * U1, U4 = 4 * U1;
+// four nt16 codes, one per byte -> their classes (A 1, C 2, G 3, T 4, anything else 0)
+__device__ __forceinline__ uint32_t class_of_codes4(uint32_t x) {
     const uint32_t idx = x & 0x07070707u;
-    const uint32_t lo = __builtin_amdgcn_perm(U4 * 0x01010100u | U2, (U4 << 24) | (U1 << 16) | U4, idx);      // codes 0..7 : other A C other | G other other other
-    const uint32_t hi = __builtin_amdgcn_perm(U4 * 0x01010101u, U4 * 0x01010100u | U3, idx);                  // codes 8..15: T other other other | other ...
+    const uint32_t lo = __builtin_amdgcn_perm(0x00000003u, 0x00020100u, idx);      // codes 0..7 : other A C other | G other other other
+    const uint32_t hi = __builtin_amdgcn_perm(0x00000000u, 0x00000004u, idx);      // codes 8..15: T other other other | other ...
     const uint32_t sel = ((x >> 1) & 0x04040404u) | 0x03020100u;
     return __builtin_amdgcn_perm(hi, lo, sel);
 }
-__device__ __forceinline__ uint2 class_off8(uint32_t cur) {              // eight packed bases (high nibble first, read.d:368-373) -> eight classes in base order
-    const uint32_t ev = class_off4((cur >> 4) & 0x0F0F0F0Fu), od = class_off4(cur & 0x0F0F0F0Fu);
+__device__ __forceinline__ uint2 class_of_packed8(uint32_t cur) {        // eight packed bases (high nibble first, read.d:368-373) -> eight classes in base order
+    const uint32_t ev = class_of_codes4((cur >> 4) & 0x0F0F0F0Fu), od = class_of_codes4(cur & 0x0F0F0F0Fu);
     return make_uint2(__builtin_amdgcn_perm(od, ev, 0x05010400u), __builtin_amdgcn_perm(od, ev, 0x07030602u));
 }
 // bytes [lo, hi) of a 64-bit word keep `v`, the others become `padw`'s (0 <= lo, hi <= 8)
@@ -1720,6 +1332,7 @@ __device__ __forceinline__ uint2 keep_bytes(uint2 v, uint32_t lo, uint32_t hi, u
     return make_uint2((v.x & (uint32_t)keep) | (padw & ~(uint32_t)keep), (v.y & (uint32_t)(keep >> 32)) | (padw & ~(uint32_t)(keep >> 32)));
 }
 
+// ROWS: the stream holds long reads (ROW descriptors: a class byte per column from the row arena k4_rows_build wrote)
 template <bool ROWS> __global__ __launch_bounds__(AT, BGP_A_MINW) void k4_acc(GArgs a) {
     using L = ALay<ROWS>;
     constexpr int NC = L::NC;
@@ -1739,7 +1352,7 @@ template <bool ROWS> __global__ __launch_bounds__(AT, BGP_A_MINW) void k4_acc(GA
     if (tile >= tile_end) return;
     for (int i = t; i < (L::MARK - L::CNT) / 4; i += AT) cnt[i] = 0;           // counters, deld, nst (a window leaves them zeroed again), hist (kept for the whole range)
     if (t == 0) misc[0] = 0;
-    struct Pre { uint2 col; uint4 tt; uint32_t n; int32_t wd; };                // the next window's header, requested a window ahead (see k4_exec)
+    struct Pre { uint2 col; uint4 tt; uint32_t n; int32_t wd; };                // the next window's header, requested a window ahead, in VECTOR registers made uniform only when used: left to the compiler the loads became scalars with an s_waitcnt right behind the "prefetch" -- which, gfx9 counting loads and stores with ONE in-order counter, also stood for the previous window's column stores
     auto prefetch = [&](uint64_t w) {
         Pre p;
         const char* tp = reinterpret_cast<const char*>(a.tiles + w);
@@ -1766,9 +1379,9 @@ template <bool ROWS> __global__ __launch_bounds__(AT, BGP_A_MINW) void k4_acc(GA
             uint32_t b = 0;
             if (lane == 0) b = atomicAdd(&misc[0], 1u);
             b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
-            *base_out = b * (uint32_t)A_DB;
+            *base_out = b * (uint32_t)L::DRAW;
             unsigned long long dd = 0;
-            if (*base_out < n_desc && lane < A_DB && *base_out + (uint32_t)lane < n_desc) dd = slab[*base_out + lane];
+            if (*base_out < n_desc && lane < L::DRAW && *base_out + (uint32_t)lane < n_desc) dd = slab[*base_out + lane];
             return dd;
         };
         uint32_t base_next = 0;
@@ -1783,74 +1396,84 @@ template <bool ROWS> __global__ __launch_bounds__(AT, BGP_A_MINW) void k4_acc(GA
             const bool is_row = ROWS && kind == 3;
             if (!ROWS && kind == 3) kind = 0;
             const uint32_t len = is_row ? (f14 & 0x3FFu) + 1u : f14 & 0xFFu, nib = is_row ? 0u : (f14 >> 8) & 1u;
-            const uint32_t nch = (kind == 1 || is_row) ? ((lo & (uint32_t)(A_CW - 1)) + len + (uint32_t)(A_CW - 1)) / (uint32_t)A_CW : 0u;    // chunks of A_CW aligned positions the segment touches
+            const uint32_t nch = (kind == 1 || is_row) ? ((lo & 7u) + len + 7u) >> 3 : 0u;      // chunks of eight aligned positions the segment touches
             if (kind == 2) { atomicAdd(&deld[lo], 1u); atomicAdd(&deld[f14 & 0xFFFu], 0xFFFFFFFFu); }       // D / N inside the window: '-' from lo up to the op's end (pileup.d:119-121)
             if ((kind == 1 || is_row) && (d & 4u)) atomicAdd(&nst[lo >> 1], 1u << ((lo & 1u) * 16));        // n_starting_here, pileup.d:386,422
-            const uint32_t inc = wave_scan_u32(nch), ex = inc - nch, tot = rl(inc, 63);
+            const uint32_t inc = wave_scan_u32(nch), tot_all = rl(inc, 63);
+            // what a chunk needs of its descriptor, once per descriptor: "nibble address minus position" (two bases a byte; a byte a
+            // position: twice the byte address) so that position 8m of the window is nibble adj + 8m of the source, and chunk c of the
+            // batch is chunk mb + c of the window
             const uint64_t src = is_row ? d >> 24 : d >> 23;
-            if (lane < A_DB) dsc[lane] = make_uint4((uint32_t)src, (uint32_t)(src >> 32) | (nib << 16) | ((is_row ? 1u : 0u) << 17), lo | (len << 11), ex);
-            for (uint32_t j = 0; j < nch; ++j) mark[ex + j] = (uint8_t)lane;      // chunk -> descriptor of the batch (a byte per chunk; ~10 a descriptor)
+            const bool bytes_d = is_row;
+            const uint64_t origin = (uint64_t)(is_row ? a.rows : a.s) + src;
+            const uint64_t adj = (bytes_d ? origin : 2ull * origin + nib) - (uint64_t)lo;
+            // (a batch whose chunks do not fit the map goes in two halves or four quarters of its lanes: each fits by MROW's definition)
+            const uint32_t q1 = rl(inc, 15), q2 = rl(inc, 31), q3 = rl(inc, 47);
+            const uint32_t cap = (uint32_t)(L::MROW - 64);
+            const uint32_t parts = tot_all <= cap ? 1u : (q2 <= cap && tot_all - q2 <= cap) ? 2u : 4u;
+            for (uint32_t hv = 0; hv < parts; ++hv) {
+            const uint32_t l0 = hv * (64u / parts), l1 = l0 + 64u / parts;             // the part's lanes
+            const bool mine = (uint32_t)lane >= l0 && (uint32_t)lane < l1;
+            const uint32_t ex0 = l0 == 0 ? 0u : l0 == 16 ? q1 : l0 == 32 ? q2 : q3;
+            const uint32_t ex1 = l1 == 64 ? tot_all : l1 == 16 ? q1 : l1 == 32 ? q2 : q3;
+            const uint32_t ex = inc - nch - ex0, tot = ex1 - ex0;
+            if (mine) dsc[lane] = make_uint4((uint32_t)adj, (uint32_t)(adj >> 32), lo | (len << 11) | ((bytes_d ? 1u : 0u) << 22) | ((is_row ? 1u : 0u) << 23), (lo >> 3) - ex);
+            if (mine) for (uint32_t j = 0; j < nch; ++j) mark[ex + j] = (uint8_t)lane;      // chunk -> descriptor of the batch (a byte per chunk; ~20 a descriptor)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             for (uint32_t c0 = 0; c0 < tot; c0 += 64u * A_U) {
-                uint32_t v0[A_U], v1[A_U], v2[A_U], adr[A_U], klim[A_U];     // twelve bytes of packed bases (a row: sixteen class offsets, v2 | .. in two loads) | byte offset of the chunk's words in a plane | first valid k, one past the last << 8, odd nibble << 16, row << 17
-                uint32_t v3[ROWS ? A_U : 1];
+                uint32_t v0[A_U], v1[A_U], adr[A_U], klim[A_U];    // eight bytes of bases | byte offset of the chunk's word in a plane | first valid k, one past the last << 4, odd nibble << 8, a class byte per position << 9
 #pragma unroll
                 for (int u = 0; u < A_U; ++u) {
-                    // (branch-free: a lane behind the batch's last chunk works on chunk 0 again and keeps nothing -- a load inside a branch
-                    // is waited for at the branch's end, one round trip per step instead of one per A_U steps)
+                    // (branch-free: a lane behind the batch's last chunk works on chunk 0 again and keeps nothing)
                     const uint32_t c = c0 + 64u * u + (uint32_t)lane;
                     const bool in = c < tot;
                     const uint32_t cc = in ? c : 0u;
                     const uint4 f = dsc[mark[cc]];
-                    const uint32_t flo = f.z & 0x7FFu, flen = f.z >> 11;
-                    const uint32_t m = flo / (uint32_t)A_CW + (cc - f.w);                // chunk of the window: positions A_CW m .. A_CW m + A_CW - 1
-                    const int32_t rel = (int32_t)((uint32_t)A_CW * m) - (int32_t)flo;     // segment-relative index of the chunk's first position (negative in the first chunk)
-                    const uint32_t k_lo = rel < 0 ? (uint32_t)(-rel) : 0u, k_hi = min((uint32_t)A_CW, flen - (uint32_t)rel);
-                    const uint64_t sb = ((uint64_t)(f.y & 0xFFFFu) << 32) | f.x;
-                    const bool row = ROWS && ((f.y >> 17) & 1u);
-                    const int32_t n0 = (int32_t)((f.y >> 16) & 1u) + rel;
-                    const uint32_t odd = row ? 0u : (uint32_t)n0 & 1u;
-                    const uint8_t* p = row ? a.rows + sb + rel : a.s + sb + (n0 >> 1);   // a row holds one class per column, a SEG two bases per byte
-                    if (A_CW == 16) {
-                        if (ROWS) { uint4 q; __builtin_memcpy(&q, p, 16); v0[u] = q.x; v1[u] = q.y; v2[u] = q.z; v3[u] = q.w; }
-                        else { uint32_t q[3]; __builtin_memcpy(q, p, 12); v0[u] = q[0]; v1[u] = q[1]; v2[u] = q[2]; }
-                    } else { uint2 q; __builtin_memcpy(&q, p, 8); v0[u] = q.x; v1[u] = q.y; v2[u] = 0; if (ROWS) v3[u] = 0; }
-                    adr[u] = m * (uint32_t)(A_LAY ? A_MW * 4 : 4);
-                    klim[u] = in ? k_lo | (k_hi << 8) | (odd << 16) | ((row ? 1u : 0u) << 17) : 0u;
+                    const uint32_t flo = f.z & 0x7FFu, flen = (f.z >> 11) & 0x7FFu;
+                    const uint32_t m = f.w + cc;                                         // chunk of the window: positions 8m .. 8m + 7
+                    const int32_t rel = (int32_t)(8u * m) - (int32_t)flo;                 // segment-relative index of position 8m (negative in the first chunk)
+                    const uint32_t k_lo = (uint32_t)max(-rel, 0), k_hi = min(8u, flen - (uint32_t)rel);
+                    const bool bytes = ROWS && (f.z >> 22 & 1u);                        // one byte a position (a row's classes): loaded from the first valid one on, moved up again below
+                    const bool row = ROWS && (f.z >> 23 & 1u);
+                    const uint64_t n = (((uint64_t)f.y << 32) | f.x) + 8u * m;           // nibble (byte) address of position 8m in the source
+                    const uint32_t odd = bytes ? 0u : (uint32_t)n & 1u;
+                    const uint8_t* p = reinterpret_cast<const uint8_t*>(bytes ? n + k_lo : n >> 1);
+                    uint2 q; __builtin_memcpy(&q, p, 8);
+                    v0[u] = q.x; v1[u] = q.y;
+                    adr[u] = m * 4u;
+                    klim[u] = in ? k_lo | (k_hi << 4) | (odd << 8) | ((bytes ? 1u : 0u) << 9) | ((row ? 1u : 0u) << 10) : 0u;
                 }
 #pragma unroll
                 for (int u = 0; u < A_U; ++u) {
                     if (c0 + 64u * u >= tot) continue;
                     const uint32_t kl = klim[u];
-                    const uint32_t k_lo = kl & 0xFFu, k_hi = kl >> 8 & 0xFFu;
+                    const uint32_t k_lo = kl & 15u, k_hi = kl >> 4 & 15u;
                     if (k_hi == 0) continue;                                             // (a lane behind the batch's last chunk)
-                    uint2 ca, cb = make_uint2(0, 0);                                     // classes of the chunk's positions 0 .. 7 | 8 .. 15
-                    if (ROWS && (kl >> 17 & 1u)) { ca = make_uint2(v0[u], v1[u]); if (A_CW == 16) cb = make_uint2(v2[u], v3[ROWS ? u : 0]); }
-                    else {
-                        uint32_t w0 = v0[u], w1 = v1[u];
-                        if (kl >> 16 & 1u) {                                             // the chunk's first base is the low nibble of its byte: one nibble up
-                            w0 = ((v0[u] & 0x0F0F0F0Fu) << 4) | (__builtin_amdgcn_alignbit(v1[u], v0[u], 12) & 0x0F0F0F0Fu);
-                            if (A_CW == 16) w1 = ((v1[u] & 0x0F0F0F0Fu) << 4) | (__builtin_amdgcn_alignbit(v2[u], v1[u], 12) & 0x0F0F0F0Fu);
-                        }
-                        ca = class_off8(w0); if (A_CW == 16) cb = class_off8(w1);
+                    uint32_t w0 = v0[u], w1 = v1[u];
+                    if (ROWS && (kl >> 9 & 1u)) {                             // bytes were loaded from the first valid position on: back to their places
+                        const unsigned long long vv = (((unsigned long long)w1 << 32) | w0) << (8u * k_lo);
+                        w0 = (uint32_t)vv; w1 = (uint32_t)(vv >> 32);
                     }
-                    constexpr uint32_t PADW = (uint32_t)NC * A_CLS_UNIT * 0x01010101u;   // bases outside the segment's ends count for the dummy class
-                    ca = keep_bytes(ca, min(k_lo, 8u), min(k_hi, 8u), PADW);
-                    if (A_CW == 16) cb = keep_bytes(cb, max(k_lo, 8u) - 8u, max(k_hi, 8u) - 8u, PADW);
-                    uint8_t* const row0 = reinterpret_cast<uint8_t*>(cnt) + adr[u];
+                    uint2 cb;
+                    if (ROWS && (kl >> 10 & 1u)) cb = make_uint2(w0, w1);
+                    else {
+                        if (kl >> 8 & 1u) w0 = ((w0 & 0x0F0F0F0Fu) << 4) | (__builtin_amdgcn_alignbit(w1, w0, 12) & 0x0F0F0F0Fu);     // the chunk's first base is the low nibble of its byte: one nibble up
+                        cb = class_of_packed8(w0);
+                    }
+                    cb = keep_bytes(cb, k_lo, k_hi, (uint32_t)NC * 0x01010101u);         // bases outside the segment's ends count for the dummy class
+                    uint32_t* const row0 = cnt + (adr[u] >> 2);
 #pragma unroll
-                    for (int k = 0; k < A_CW; ++k) {
-                        const uint32_t word = k < 4 ? ca.x : k < 8 ? ca.y : k < 12 ? cb.x : cb.y;
-                        const uint32_t cls = (word >> (8 * (k & 3))) & 0xFFu;
-                        const uint32_t off = A_LAY ? cls : cls * (uint32_t)(A_CSW * 4);
-                        atomicAdd(reinterpret_cast<uint32_t*>(row0 + off + (k >> 1) * (A_PLW * 4)), 1u << (16 * (k & 1)));
+                    for (int k = 0; k < 8; ++k) {
+                        const uint32_t cls = ((k < 4 ? cb.x : cb.y) >> (8 * (k & 3))) & 0xFFu;
+                        atomicAdd(row0 + cls * (uint32_t)A_CSW + (k >> 1) * A_PLW, 1u << (16 * (k & 1)));
                     }
                 }
             }
+            }
         }
         __syncthreads();                                     // every add of the window is in
-        // ---- flush (as k4_exec): '-' difference array summed up, 32 contiguous bytes per position; what a lane reads it zeroes
+        // ---- flush: '-' difference array summed up (a wave scans its own positions with DPP, the waves before it enter as one number each), 32 contiguous bytes per position; what a lane reads it zeroes
         const uint32_t np = Tend - T0;
         uint32_t dl[ABPW], cA[ABPW], cC[ABPW], cG[ABPW], cT[ABPW], cO[ABPW], cD[ABPW], sw[ABPW];
         {
@@ -1863,14 +1486,14 @@ template <bool ROWS> __global__ __launch_bounds__(AT, BGP_A_MINW) void k4_acc(GA
                 const uint32_t sc = wave_scan_u32(e);
                 dl[bb] = run + sc;
                 run += rl(sc, 63);
-                const uint32_t wi = a_word(p, 0), cs = A_LAY ? 1u : (uint32_t)A_CSW, sh = (p & 1u) * 16;
-                cA[bb] = (cnt[wi] >> sh) & 0xFFFFu; cC[bb] = (cnt[wi + cs] >> sh) & 0xFFFFu; cG[bb] = (cnt[wi + 2 * cs] >> sh) & 0xFFFFu;
-                cT[bb] = (cnt[wi + 3 * cs] >> sh) & 0xFFFFu; cO[bb] = (cnt[wi + 4 * cs] >> sh) & 0xFFFFu;
-                cD[bb] = ROWS ? (cnt[wi + 5 * cs] >> sh) & 0xFFFFu : 0u;
+                const uint32_t wi = ((p & 7u) >> 1) * A_PLW + (p >> 3), sh = (p & 1u) * 16;
+                cO[bb] = (cnt[wi] >> sh) & 0xFFFFu; cA[bb] = (cnt[A_CSW + wi] >> sh) & 0xFFFFu; cC[bb] = (cnt[2 * A_CSW + wi] >> sh) & 0xFFFFu;
+                cG[bb] = (cnt[3 * A_CSW + wi] >> sh) & 0xFFFFu; cT[bb] = (cnt[4 * A_CSW + wi] >> sh) & 0xFFFFu;
+                cD[bb] = ROWS ? (cnt[5 * A_CSW + wi] >> sh) & 0xFFFFu : 0u;
                 sw[bb] = nst[p >> 1];
                 if ((p & 1u) == 0) {                         // (two lanes share a word: both have read it -- the wave runs in lockstep)
-                    cnt[wi] = 0; cnt[wi + cs] = 0; cnt[wi + 2 * cs] = 0; cnt[wi + 3 * cs] = 0; cnt[wi + 4 * cs] = 0;
-                    if (ROWS) cnt[wi + 5 * cs] = 0;
+                    cnt[wi] = 0; cnt[A_CSW + wi] = 0; cnt[2 * A_CSW + wi] = 0; cnt[3 * A_CSW + wi] = 0; cnt[4 * A_CSW + wi] = 0;
+                    if (ROWS) cnt[5 * A_CSW + wi] = 0;
                     nst[p >> 1] = 0;
                 }
             }
@@ -1901,7 +1524,7 @@ template <bool ROWS> __global__ __launch_bounds__(AT, BGP_A_MINW) void k4_acc(GA
         r_ncol += ncol; r_nsum += nsum; r_mx = max(r_mx, mx); r_scov += scov;
         __syncthreads();                                     // the counters are zero again and misc[8..] is read: the next window may add
     }
-    {   // the range's totals (see k4_exec)
+    {   // the range's totals: wave reductions with DPP, then one atomic per wave and total (the slots were zeroed by the host)
         const uint32_t w_ncol = wave_sum_u32(r_ncol), w_nsum = wave_sum_u32(r_nsum), w_mx = wave_max_u32(r_mx);
         const uint32_t s0 = wave_sum_u32((uint32_t)r_scov & 0xFFFFu), s1 = wave_sum_u32((uint32_t)(r_scov >> 16) & 0xFFFFu), s2 = wave_sum_u32((uint32_t)(r_scov >> 32) & 0xFFFFu), s3 = wave_sum_u32((uint32_t)(r_scov >> 48));
         if (lane == 0) {
@@ -2193,13 +1816,13 @@ int k34_pileup(bgp_ctx* c) {
         BGP_HIP(hipStreamSynchronize(c->stream));
     }
     // A stream of long reads (a quarter of its reads or more) is left to the general kernel entirely, on its own tiling of
-    // 4096 positions; every other stream is tiled for the gather path, the general kernel taking the windows that leaves.
+    // 4096 positions; every other stream is tiled for the accumulate path, the general kernel taking the windows that leaves.
 #ifdef BGP_EXPERIMENTS
     static const bool long_rows = !(getenv("BGP_LONG_ROWS") && atoi(getenv("BGP_LONG_ROWS")) == 0);
 #else
     constexpr bool long_rows = true;
 #endif
-        // long reads through the gather path as rows in reference coordinates (0: the general kernel, as before)
+        // long reads through the accumulate path as rows in reference coordinates (0: the general kernel, as before)
     const bool long_stream = !long_rows && (uint64_t)st[3] * 4 >= n && st[3] > 0;
     const uint32_t tw = long_stream ? (uint32_t)WO : (uint32_t)W;
     uint64_t col_base = 0, tile_base = 0;
@@ -2247,7 +1870,7 @@ int k34_pileup(bgp_ctx* c) {
             TimedRegion tb(c, "k4_bounds", tile_base * sizeof(TileB));
             hipLaunchKernelGGL(k4_bounds, dim3((unsigned)((tile_base + 255) / 256)), dim3(256), 0, c->stream, a.pmax_end, a.pmax_pos, a.runs, n_runs, tile_base, c->d_tiles.as<TileB>(), tw);
         }
-        constexpr uint64_t WG_SLOTS = 65536;            // k4_exec's workgroups leave their ranges' totals behind the windows' slots
+        constexpr uint64_t WG_SLOTS = 65536;            // k4_acc's workgroups leave their ranges' totals behind the windows' slots
         BGP_TRY(c->d_col_lo.reserve((tile_base + WG_SLOTS) * 32));
         a.tile_stats = (unsigned long long*)c->d_col_lo.p;
         a.ck = nullptr; a.ck_off = nullptr;
@@ -2258,7 +1881,7 @@ int k34_pileup(bgp_ctx* c) {
             TimedRegion tc(c, "k4_checkpoints", c->sum_ncig * 4);
             BGP_TRY(c->d_ck_off.reserve((n + 2) * 8));
             uint64_t* ck_off = c->d_ck_off.as<uint64_t>();
-            rows = long_rows && !long_stream;               // ... and, for the gather path, every long read's row of class bytes (one per column)
+            rows = long_rows && !long_stream;               // ... and, for the accumulate path, every long read's row of class bytes (one per column)
             uint64_t* chunk_off = nullptr;
             if (rows) { BGP_TRY(c->d_row_off.reserve((n + 2) * 8)); BGP_TRY(c->d_chunk_off.reserve((n + 2) * 8)); row_off = c->d_row_off.as<uint64_t>(); chunk_off = c->d_chunk_off.as<uint64_t>(); }
             hipLaunchKernelGGL(k4_ck_count, dim3(nb), dim3(256), 0, c->stream, a.rec, n, a.runs, n_runs, ck_off, row_off, chunk_off, tw);
@@ -2287,7 +1910,7 @@ int k34_pileup(bgp_ctx* c) {
         if (long_stream) {
             hipLaunchKernelGGL(k4_all_listed, dim3((unsigned)((tile_base + 255) / 256)), dim3(256), 0, c->stream, c->d_deep.as<uint32_t>() + 1, c->d_deep.as<uint32_t>(), (uint32_t)tile_base);
         } else {
-        // the gather path's plan: descriptor slabs per window, from one pass over the reads
+        // the plan: descriptor slabs per window, from one pass over the reads
         BGP_TRY(c->d_slab.reserve(tile_base * (size_t)SLAB_CAP * 8));
         BGP_TRY(c->d_wcount.reserve((tile_base + 1) * 4)); BGP_TRY(c->d_wdel.reserve((tile_base + 2) * 4)); BGP_TRY(c->d_wslow.reserve((tile_base + 2) * 4));
         BGP_HIP(hipMemsetAsync(c->d_wcount.p, 0, (tile_base + 1) * 4, c->stream));
@@ -2309,30 +1932,22 @@ int k34_pileup(bgp_ctx* c) {
             hipLaunchKernelGGL(k4_wscan, dim3(wb), dim3(1024), 0, c->stream, pa.wdel, pa.wslow, pa.wcount, c->d_tiles.as<TileB>(), tile_base, btot, c->d_deep.as<uint32_t>() + 1, c->d_deep.as<uint32_t>());
         }
         }
-#ifdef BGP_G_PROF
-        unsigned long long* g_prof_dev = nullptr;
-        BGP_HIP(hipMalloc(&g_prof_dev, tile_base * 128));
-        BGP_HIP(hipMemset(g_prof_dev, 0, tile_base * 128));
-        BGP_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_prof_buf), &g_prof_dev, sizeof g_prof_dev));
-#endif
         c->ck_w = a.ck ? tw : 0;                     // K5 resumes long reads from these checkpoints
         TimedRegion t(c, "k4_tile", used);
-        BGP_HIP(hipMemsetAsync(a.tile_stats, 0, (tile_base + WG_SLOTS) * 32, c->stream));      // the gather path adds its totals wave by wave
+        BGP_HIP(hipMemsetAsync(a.tile_stats, 0, (tile_base + WG_SLOTS) * 32, c->stream));      // the accumulate path adds its totals wave by wave
         if (!long_stream) {
             GArgs g;
             g.s = a.s; g.slab = (const unsigned long long*)c->d_slab.p; g.wcount = c->d_wcount.as<uint32_t>(); g.wdel = c->d_wdel.as<int32_t>(); g.tiles = a.tiles; g.n_tiles = tile_base;
             g.cols = a.cols; g.hist = a.hist; g.tile_stats = a.tile_stats; g.deep = c->d_deep.as<uint32_t>() + 1; g.n_deep = c->d_deep.as<uint32_t>();
             g.rows = have_rows ? c->d_rows.as<uint8_t>() : nullptr;
-            // 512 workgroups are resident (two of 76 KB a CU); handing the device eight times as many, each with a shorter range of
-            // windows, lets it balance the ranges' unequal work at the tail (cfg3: 10.5 -> 10.3 ms); the rows' instantiation is best at 512
-            static const bool gather = getenv("BGP_K4_GATHER") && atoi(getenv("BGP_K4_GATHER")) != 0;      // round 2's k4_exec instead of k4_acc (A/B)
+            // 1280 workgroups are resident (five of 30 KB a CU); handing the device a dozen times as many, each with a shorter range of
+            // windows, lets it balance the ranges' unequal work at the tail (cfg3: 9.1 ms with 4096, 8.55 with 16384, the same with 65536)
             static const unsigned g_env = getenv("BGP_G_BLOCKS") ? (unsigned)atoi(getenv("BGP_G_BLOCKS")) : 0u;
-            const unsigned g_blocks = std::min(65536u, g_env ? g_env : have_rows ? 512u : gather ? 4096u : 16384u);
-            if (have_rows) hipLaunchKernelGGL(k4_exec<true>, dim3((unsigned)std::min<uint64_t>(tile_base, g_blocks)), dim3(GT), (size_t)G_LDS, c->stream, g);
-            else if (gather) hipLaunchKernelGGL(k4_exec<false>, dim3((unsigned)std::min<uint64_t>(tile_base, g_blocks)), dim3(GT), (size_t)G_LDS, c->stream, g);
+            const unsigned g_blocks = std::min(65536u, g_env ? g_env : 16384u);
+            if (have_rows) hipLaunchKernelGGL(k4_acc<true>, dim3((unsigned)std::min<uint64_t>(tile_base, g_blocks)), dim3(AT), (size_t)ALay<true>::BYTES, c->stream, g);
             else hipLaunchKernelGGL(k4_acc<false>, dim3((unsigned)std::min<uint64_t>(tile_base, g_blocks)), dim3(AT), (size_t)ALay<false>::BYTES, c->stream, g);
         }
-        // windows the gather path left on the list (long reads, odd CIGARs, too deep): the general kernel
+        // windows the accumulate path left on the list (odd CIGARs, too deep): the general kernel
         const unsigned dgrid = (unsigned)std::min<uint64_t>(tile_base, 2048);
         if (long_stream) {
             hipLaunchKernelGGL(k4_tile<L16o>, dim3(dgrid), dim3(L16o::T), lds16, c->stream, a, 1);
@@ -2343,20 +1958,6 @@ int k34_pileup(bgp_ctx* c) {
         }
         hipLaunchKernelGGL(k4_stats, dim3(32), dim3(256), 0, c->stream, a.tile_stats, tile_base + WG_SLOTS, a.pstats);
         BGP_HIP(hipGetLastError());
-#ifdef BGP_G_PROF
-        {
-            BGP_HIP(hipStreamSynchronize(c->stream));
-            std::vector<unsigned long long> hb(tile_base * 16);
-            BGP_HIP(hipMemcpy(hb.data(), g_prof_dev, tile_base * 128, hipMemcpyDeviceToHost));
-            double h[16] = {0};
-            for (uint64_t w = 0; w < tile_base; ++w) for (int k = 0; k < 16; ++k) h[k] += (double)hb[w * 16 + k];
-            fprintf(stderr, "[k4_exec phase clocks / window]");
-            double tot = 0;
-            for (int k = 0; k < 12; ++k) { if (k == 8) { fprintf(stderr, " rounds:%.3f", h[k] / (double)tile_base); continue; } fprintf(stderr, " %d:%.0f", k, h[k] / (double)tile_base); tot += h[k]; }
-            fprintf(stderr, " total:%.0f\n", tot / (double)tile_base);
-            (void)hipFree(g_prof_dev);
-        }
-#endif
     }
     if (getenv("BGP_VERBOSE") && n_runs) {
         uint32_t nd = 0;

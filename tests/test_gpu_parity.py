@@ -1289,13 +1289,13 @@ def test_reference_base_long_chunks_in_pieces(ctx, seed):
     _check_refbase(ctx, st, mode=L.BGP_MAKE_PILEUP, skip_zero=False, start_from=a, end_at=b)
 
 
-# ---- the gather path of K4 (k4_plan / k4_exec): rounds, cuts, fallbacks; framing repairs; full-size properties ----
+# ---- the plan / accumulate path of K4 (k4_plan / k4_acc): batches, map overflow, fallbacks; framing repairs; full-size properties ----
 
 @pytest.mark.parametrize("n_reads,ref_len,profile", [(8000, 12_000, 1), (5000, 6_000, 0), (14_000, 12_000, 1)])
-def test_gather_path_rounds_and_cuts(ctx, n_reads, ref_len, profile):
-    """Coverage of 100-170: a 1024-position window holds 500-1000 descriptors (more than one round of one per
-    thread) and more class bytes than a round's LDS (the round is cut and continued); at 170-fold some windows
-    outgrow their slab and go to the general kernel, next to windows that do not.  Columns == oracle everywhere."""
+def test_accumulate_path_deep_windows(ctx, n_reads, ref_len, profile):
+    """Coverage of 100-170: a 1024-position window holds 500-1000 descriptors (a dozen batches a window, every wave
+    drawing several; counters well beyond a byte); at 170-fold some windows outgrow their slab and go to the general
+    kernel, next to windows that do not.  Columns == oracle everywhere."""
     cfg = make_cfg(n_reads=n_reads, n_ref=1, ref_len=ref_len, read_len=150, profile=profile, seed=77 + n_reads)
     st = host_stream(cfg)
     stage(ctx, st)
@@ -1303,9 +1303,9 @@ def test_gather_path_rounds_and_cuts(ctx, n_reads, ref_len, profile):
     assert info.max_coverage > 100
 
 
-def test_gather_path_next_to_long_reads(ctx):
-    """Short reads (gather path) and long indel-heavy reads (general kernel) on one reference: windows are handed
-    to one path or the other as a whole, neighbours differ."""
+def test_accumulate_path_short_reads_next_to_long_reads(ctx):
+    """Short reads (SEG descriptors) and long indel-heavy reads (ROW descriptors, in pieces of 256 positions) on one
+    reference, in the same windows and the same batches of k4_acc."""
     short = make_cfg(n_reads=6000, n_ref=1, ref_len=60_000, read_len=150, profile=1, seed=3)
     recs = O.frame(host_stream(short))
     long_cfg = make_cfg(n_reads=12, n_ref=1, ref_len=60_000, read_len=(2000, 6000), profile=2, seed=4)
@@ -1325,6 +1325,23 @@ def test_gather_path_next_to_long_reads(ctx):
     stage(ctx, st)
     check_decode(ctx, st)
     check_pileup(ctx, st, entries=False)
+
+
+def test_accumulate_path_long_segments_overflow_the_chunk_map(ctx):
+    """250-base reads at 90-fold coverage: 64 descriptors of 32-33 chunks each do not fit a wave's chunk map, the batch
+    is worked off in halves / quarters of its lanes; with soft clips so that segments start on odd nibbles."""
+    rng = np.random.default_rng(9)
+    recs, pos = [], 5
+    for i in range(1800):
+        n = int(rng.integers(236, 256)); sc = int(rng.integers(0, 4))
+        seq = "".join("ACGTN"[int(x)] for x in rng.integers(0, 5, n))
+        cig = ([(sc, "S")] if sc else []) + [(n - sc, "M")]
+        recs.append(bamio.pack_record("q%d" % i, seq, cig, ref_id=0, pos=pos, qual=bytes(int(x) for x in rng.integers(2, 40, n))))
+        pos += int(rng.integers(0, 6))
+    st = b"".join(recs)
+    stage(ctx, st)
+    info, ora = check_pileup(ctx, st, entries=False)
+    assert info.max_coverage > 80
 
 
 def test_framing_with_a_wrong_reference_bound(ctx):
