@@ -139,6 +139,31 @@ int emit_window(bgp_ctx* c, uint32_t run_idx, uint64_t a, uint64_t b, int want_e
     return BGP_OK;
 }
 
+// positions [a, b) of a reference that no read covers and no run holds: columns of zeros, reference_base 'N' (pileup.d:245-249),
+// no entries, isSNP "no" (coverage below any minimum, simple.d:17), no MAQ call (maq.d:447-451)
+int emit_gap_window(bgp_ctx* c, int32_t ref_id, uint64_t a, uint64_t b, int want_entries, int use_md, int snp, int maq, bgp_columns* o) {
+    const uint64_t np = b - a;
+    BGP_HIP(hipStreamSynchronize(c->stream));
+    BGP_TRY(c->h_cols.reserve(np * sizeof(bgp_column)));
+    memset(c->h_cols.p, 0, np * sizeof(bgp_column));
+    memset(o, 0, sizeof *o);
+    if (want_entries) {
+        BGP_TRY(c->h_entry_off.reserve((np + 1) * 8)); BGP_TRY(c->h_entries.reserve(sizeof(bgp_entry)));
+        memset(c->h_entry_off.p, 0, (np + 1) * 8);
+        o->entry_off = c->h_entry_off.as<uint64_t>(); o->entries = c->h_entries.as<bgp_entry>();
+    }
+    if (use_md) { BGP_TRY(c->h_refbase.reserve(np + 1)); memset(c->h_refbase.p, 'N', np); o->reference_base = c->h_refbase.as<uint8_t>(); }
+    if (use_md && snp) { BGP_TRY(c->h_snp.reserve(np + 1)); memset(c->h_snp.p, BGP_SNP_NO, np); o->snp = c->h_snp.as<uint8_t>(); }
+    if (maq) {
+        BGP_TRY(c->h_maq.reserve((np + 1) * sizeof(bgp_maq_call)));
+        bgp_maq_call none{}; none.quality = 0.f; none.genotype = 0xFF; none.reference_base5 = 4; none.flags = 0; none.n_bases = 0;
+        for (uint64_t k = 0; k < np; ++k) c->h_maq.as<bgp_maq_call>()[k] = none;
+        o->maq = c->h_maq.as<bgp_maq_call>();
+    }
+    o->ref_id = ref_id; o->n_positions = (uint32_t)np; o->first_position = a; o->columns = c->h_cols.as<bgp_column>();
+    return BGP_OK;
+}
+
 extern "C" {
 
 const char* bgp_strerror(int s) {
@@ -406,12 +431,14 @@ static int pileup_begin_impl(bgp_ctx* c, int mode, int32_t one_ref, int use_md_t
         // earlier read of that run already qualifies, which is the same run.
         uint32_t j = 0;
         if (one_ref >= 0) {                              // the reads of one reference are the whole input
-            while (j < it.run_end && c->runs[j].ref_id != one_ref) ++j;
-            if (j < it.run_end && c->runs[j].end_pos < start_from) j = it.run_end;
+            while (j < it.run_end && (c->runs[j].ref_id != one_ref || c->runs[j].end_pos < start_from)) ++j;
         } else
             while (j < it.run_end && c->runs[j].end_pos < start_from) ++j;
-        if (j < it.run_end) { it.run = j; it.run_end = j + 1; it.ref_id = c->runs[j].ref_id; }
-        else { it.run = it.run_end; }
+        if (j < it.run_end) {                               // every run of that reference (a reference is several runs where wide stretches of it are uncovered)
+            uint32_t e = j + 1;
+            while (e < it.run_end && c->runs[e].ref_id == c->runs[j].ref_id) ++e;
+            it.run = j; it.run_end = e; it.ref_id = c->runs[j].ref_id;
+        } else { it.run = it.run_end; }
     }
     if (it.run < it.run_end) {
         uint64_t first = c->runs[it.run].start_pos, first_record = ~0ull;
@@ -488,7 +515,11 @@ int bgp_pileup_chunk(bgp_ctx* c, uint64_t k, bgp_chunk_info* out) {
     it.run = it.run_end = (uint32_t)c->runs.size();                             // no columns unless the reference has covering reads
     if (ci.start_position < ci.end_position)
         for (uint32_t j = 0; j < c->runs.size(); ++j)
-            if (c->runs[j].ref_id == ci.ref_id) { it.run = j; it.run_end = j + 1; it.next_pos = std::max<uint64_t>(c->runs[j].start_pos, ci.start_position); break; }
+            if (c->runs[j].ref_id == ci.ref_id) {
+                uint32_t e = j + 1;
+                while (e < c->runs.size() && c->runs[e].ref_id == ci.ref_id) ++e;
+                it.run = j; it.run_end = e; it.next_pos = std::max<uint64_t>(c->runs[j].start_pos, ci.start_position); break;
+            }
     return BGP_OK;
     BGP_API_CATCH(c)
 }
@@ -522,9 +553,22 @@ int bgp_pileup_next_window(bgp_ctx* c, bgp_columns* o) {
         if (it.run >= it.run_end) return BGP_EOF;
         const bgp_run& r = c->runs[it.run];
         const uint64_t hi = std::min<uint64_t>(r.end_pos, it.end_at);
+        if (it.next_pos < r.start_pos) {
+            // between two runs of one reference lies a stretch without coverage that has no columns on the device.  The sweep walks it
+            // column by column when skip_zero_coverage is false (pileup.d:345-397: empty columns, reference_base 'N'): windows of zeros
+            const uint64_t a = it.next_pos, b = std::min<uint64_t>(std::min<uint64_t>(r.start_pos, it.end_at), a + it.window);
+            if (a >= b) { it.run = it.run_end; return BGP_EOF; }          // end_at lies inside the stretch
+            BGP_TRY(emit_gap_window(c, r.ref_id, a, b, it.want_entries, it.use_md, it.use_md && it.snp, it.maq, o));
+            it.next_pos = b;
+            return BGP_OK;
+        }
         if (it.next_pos >= hi) {
             ++it.run;
-            if (it.run < it.run_end) it.next_pos = std::max<uint64_t>(c->runs[it.run].start_pos, it.start_from);
+            if (it.run < it.run_end) {
+                const bgp_run& nx = c->runs[it.run];
+                const bool walk = !it.skip_zero && nx.ref_id == r.ref_id && it.next_pos >= r.end_pos;      // the same reference goes on behind an uncovered stretch
+                it.next_pos = walk ? std::max<uint64_t>(r.end_pos, it.start_from) : std::max<uint64_t>(nx.start_pos, it.start_from);
+            }
             continue;
         }
         const uint64_t a = it.next_pos, b = std::min<uint64_t>(hi, a + it.window);

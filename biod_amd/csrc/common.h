@@ -229,6 +229,7 @@ int bgp_default_threads();                                   // bgzf_host.cpp : 
 int bai_build(bgp_ctx* c, std::vector<uint8_t>& out);
 int chunks_plan(bgp_ctx* c, uint64_t block_size, uint64_t start_from, uint64_t end_at);
 int emit_window(bgp_ctx* c, uint32_t run, uint64_t a, uint64_t b, int want_entries, int use_md, int snp, bgp_columns* o);   // api.cpp: columns [a, b) of a run to the host
+int emit_gap_window(bgp_ctx* c, int32_t ref_id, uint64_t a, uint64_t b, int want_entries, int use_md, int snp, int maq, bgp_columns* o);   // api.cpp: an uncovered stretch between two runs of a reference
 int batch_cut(bgp_ctx* c, uint64_t* last_key, uint64_t* carry_record, uint64_t* carry_off);   // pileup.hip: last covering read of the staged stream and where its exact halo starts
 void batch_release(bgp_ctx* c);   // batch.cpp
 void bgp_staged_copy(uint8_t* dst, const uint8_t* src, uint64_t n);   // batch.cpp: memcpy into pinned staging, large copies over a few threads

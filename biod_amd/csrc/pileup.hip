@@ -57,7 +57,7 @@ constexpr uint32_t DEEP_WINDOW = BGP_DEEP_WINDOW; // candidate records from whic
 
 struct RunDev { int32_t ref_id; uint32_t pad; uint64_t first_record, end_record, start_pos, end_pos, column_base, tile_base; };
 
-struct K3Args { const bgp_record* rec; uint64_t n; uint64_t* key_end; uint64_t* key_pos; uint32_t* status; /* [3] any long read */ uint32_t run_cap; };
+struct K3Args { const bgp_record* rec; uint64_t n; uint64_t* key_end; uint64_t* key_pos; uint32_t* status; /* [3] any long read */ uint32_t run_cap; uint32_t gap; /* a run also begins behind this many positions without coverage (0: never) */ };
 
 constexpr int FAST_LSEQ = 160;         // reads up to 20 dwords of packed SEQ and 4 CIGAR ops take K4's lane = read path
 constexpr uint32_t ROW_PIECE = 256;     // positions of a ROW descriptor (a long read's stretch of a window goes in pieces of this many)
@@ -181,7 +181,11 @@ __global__ __launch_bounds__(K3_T) void k3_down(K3Args a, const K3Key* bsum, Run
             if (key[k].p) {                                                   // a covering read
                 if (flg[k] & 2u) atomicOr(&a.status[0], ST_EINVAL);
                 if (key[k].p < before.p) atomicOr(&a.status[0], ST_EUNSORTED); // pileup.d:25-27
-                if ((before.p >> 32) != (key[k].p >> 32)) {                    // first read of a reference run, pileup.d:399-424
+                // first read of a reference -- or of an ISLAND of it: nothing covers the a.gap positions in front of the read.  BioD's sweep
+                // jumps over such a stretch (initNewReference, pileup.d:388-392,399-424) or walks it column by column
+                // (skip_zero_coverage = false); here the dense columns of a run would otherwise span it (two reads 2^31 apart: 64 GB)
+                const bool island = a.gap && (before.p >> 32) == (key[k].p >> 32) && (uint64_t)(uint32_t)before.e + a.gap <= (uint64_t)(uint32_t)key[k].p;
+                if ((before.p >> 32) != (key[k].p >> 32) || island) {
                     const uint32_t slot = atomicAdd(&a.status[2], 1u);
                     if (slot < a.run_cap) { RunDev rd{}; rd.ref_id = ref[k]; rd.first_record = i; rd.start_pos = (uint64_t)(uint32_t)key[k].p; runs[slot] = rd; }
                 }
@@ -1785,7 +1789,8 @@ int k34_pileup(bgp_ctx* c) {
         BGP_TRY(c->d_runs.reserve(sizeof(RunDev) * (size_t)run_cap));
         {
             TimedRegion t(c, "k3_keys_scan", n * (c->tilemax_ok ? 32 + 16 : 32 + 16 + 32));      // (one pass over the table when K1 left the tile maxima)
-            K3Args a{c->d_rec.as<bgp_record>(), n, c->d_pmax_end.as<uint64_t>(), c->d_pmax_pos.as<uint64_t>(), status, run_cap};
+            static const uint32_t run_gap = getenv("BGP_RUN_GAP") ? (uint32_t)atoll(getenv("BGP_RUN_GAP")) : 65536u;      // (tests: small islands)
+            K3Args a{c->d_rec.as<bgp_record>(), n, c->d_pmax_end.as<uint64_t>(), c->d_pmax_pos.as<uint64_t>(), status, run_cap, run_gap};
             const uint64_t nt = (n + K3_TILE - 1) / K3_TILE;
             BGP_TRY(c->d_scan_tmp.reserve((nt + 2) * sizeof(K3Key)));
             K3Key* bsum = c->d_scan_tmp.as<K3Key>();

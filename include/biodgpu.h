@@ -163,7 +163,13 @@ typedef struct bgp_entry {       /* one (read, column) pair, 16 bytes (SURVEY.md
     uint8_t qual;                /* current_base_quality, pileup.d:127-134                        */
 } bgp_entry;
 
-typedef struct bgp_run {         /* one reference's worth of columns (a "run" of the sweep)       */
+/* A run of the sweep: a reference's reads from one stretch without coverage to the next.  A reference is ONE run unless
+ * 65 536 or more of its positions in a row are uncovered: BioD's sweep jumps over such a stretch (skip_zero_coverage,
+ * initNewReference, pileup.d:388-392,399-424) or walks it column by column; here it simply has no columns on the device (two
+ * reads 2^31 positions apart cost two windows, not 64 GB).  Runs are in file order; runs of one reference follow each other.
+ * The window iterators hand the stretch out as windows of zero columns (reference_base 'N') when skip_zero_coverage is 0, and
+ * step over it otherwise; bgp_batch_next_window does not hand such stretches out. */
+typedef struct bgp_run {
     int32_t ref_id;
     uint32_t _pad;
     uint64_t first_record, end_record;  /* record index range holding the run's reads            */

@@ -34,12 +34,26 @@ def stage(ctx, st, n_ref=0):
     return ctx
 
 
+class _OraView:
+    """The oracle's columns that lie inside a run (with skip_zero_coverage = false the oracle also walks the uncovered stretches
+    between two runs of a reference: zero columns the device keeps no storage for)."""
+
+    def __init__(self, ora, keep):
+        self.cov, self.nstart, self.counts = ora.cov[keep], ora.nstart[keep], ora.counts[keep]
+
+
 def dense_from_oracle(ora, runs, skip_zero=True):
     """Oracle columns scattered into the dense per-run layout the device produces."""
     n_pos = int(sum(int(r["end_pos"]) - int(r["start_pos"]) for r in runs))
     dense = np.zeros(n_pos, L.COLUMN_DTYPE)
-    base = {int(r["ref_id"]): (int(r["column_base"]), int(r["start_pos"])) for r in runs}
-    idx = np.array([base[int(r)][0] - base[int(r)][1] for r in ora.ref], dtype=np.int64) + ora.pos.astype(np.int64)
+    # (a reference is several runs where wide stretches of it are uncovered: a column belongs to the last run that starts at or before it)
+    rkey = np.array([(int(r["ref_id"]) + 1) << 40 | int(r["start_pos"]) for r in runs], dtype=np.int64)
+    ckey = ((ora.ref.astype(np.int64) + 1) << 40) | ora.pos.astype(np.int64)
+    j = np.searchsorted(rkey, ckey, side="right") - 1
+    inside = ora.pos.astype(np.int64) < runs["end_pos"][j].astype(np.int64) if len(ckey) else np.zeros(0, bool)
+    assert len(ckey) == 0 or ((j >= 0).all() and (runs["ref_id"][j] == ora.ref).all() and (ora.cov[~inside] == 0).all())
+    idx = (runs["column_base"][j].astype(np.int64) - runs["start_pos"][j].astype(np.int64) + ora.pos.astype(np.int64))[inside]
+    ora = _OraView(ora, inside)
     dense["coverage"][idx] = ora.cov
     dense["n_starting_here"][idx] = ora.nstart
     for j, f in enumerate(("a", "c", "g", "t", "other", "del")):
@@ -50,8 +64,8 @@ def dense_from_oracle(ora, runs, skip_zero=True):
 def device_columns(ctx, info):
     """Copy the dense column array out of HBM through the window iterator."""
     out = []
-    for w in ctx.pileup_windows(L.BGP_PILEUP_COLUMNS, skip_zero_coverage=False, window_positions=1 << 20):
-        out.append(w.columns)
+    for w in ctx.pileup_windows(L.BGP_PILEUP_COLUMNS, skip_zero_coverage=True, window_positions=1 << 20):      # (windows are dense inside a run either way; with
+        out.append(w.columns)                                                                                      # skip_zero_coverage = false the uncovered stretches BETWEEN runs would come too)
     return np.concatenate(out) if out else np.zeros(0, L.COLUMN_DTYPE)
 
 
@@ -206,6 +220,71 @@ def test_zero_coverage_gaps(ctx):
 
 
 # ------------------------------------------------------------------------------------------ edge cases of the record format
+
+def _shift_positions(st, shift_of_read):
+    """The stream with read i moved shift_of_read(i) positions to the right (MD tags and everything else stay valid)."""
+    import struct
+    out = bytearray(st)
+    for i, off in enumerate(O.frame(st)):
+        off = int(off)
+        (pos,) = struct.unpack_from("<i", out, off + 8)
+        struct.pack_into("<i", out, off + 8, pos + shift_of_read(i))
+    return bytes(out)
+
+
+def test_sparse_reads_two_billion_positions_apart(ctx):
+    """BioD streams such input (skip_zero_coverage jumps via initNewReference, pileup.d:388-392); dense columns over the whole
+    span would be 64 GB.  A reference is cut into runs at uncovered stretches of 65 536 positions and more."""
+    recs = [bamio.pack_record("a", "ACGTACGTAC", [(10, "M")], ref_id=0, pos=10), bamio.pack_record("b", "ACGTTTGTAC", [(4, "M"), (3, "D"), (6, "M")], ref_id=0, pos=1000),
+            bamio.pack_record("c", "ACGTA", [(5, "M")], ref_id=0, pos=1004), bamio.pack_record("d", "ACGTA", [(5, "M")], ref_id=1, pos=7)]
+    st = _shift_positions(b"".join(recs), lambda i: 1_999_999_000 if i in (1, 2) else 0)      # (beyond what a BAI bin can say, so not through pack_record)
+    stage(ctx, st)
+    info, ora = check_pileup(ctx, st, entries=True)
+    assert len(info.runs) == 3 and info.n_positions < 100
+    cols = list(makePileup(RecordStream(st, ctx), False, 0, L_ULONG_MAX, True))
+    assert [c.position for c in cols] == list(range(10, 20)) + list(range(2_000_000_000, 2_000_000_013))
+    assert [c.position for c in makePileup(RecordStream(st, ctx), False, 15, 2_000_000_002, True)] == list(range(15, 20)) + [2_000_000_000, 2_000_000_001]
+    # skip_zero_coverage = false walks the stretch: only a clipped look at it is affordable (BioD would pop two billion columns)
+    pile = makePileup(RecordStream(st, ctx), False, 15, 70_000, False, want_entries=False)
+    cols = list(pile)
+    assert [c.position for c in cols] == list(range(15, 70_000)) and all(c.coverage == 0 for c in cols[5:]) and cols[0].coverage == 1
+
+
+@pytest.mark.parametrize("use_md", [False, True])
+def test_amplicon_islands_match_oracle(ctx, use_md):
+    """Islands of 30 reads on a 250 Mbp contig, 250 kbp apart (1000 of them), and 40 islands 80 kbp apart walked with
+    skip_zero_coverage = false: columns, entries, reference_base against the oracle."""
+    base = host_stream(make_cfg(n_reads=30_000, n_ref=1, ref_len=200_000, read_len=100, profile=1, seed=5))
+    st = _shift_positions(base, lambda i: 249_000 * (i // 30))
+    stage(ctx, st)
+    info, ora = check_pileup(ctx, st, entries=False)
+    assert len(info.runs) == 1000 and info.n_positions < 8_000_000
+    if use_md:
+        _check_refbase(ctx, st, skip_zero=True, window=100_000)
+    small = host_stream(make_cfg(n_reads=1200, n_ref=2, ref_len=8_000, read_len=100, profile=1, seed=6))
+    st2 = _shift_positions(small, lambda i: 80_000 * ((i % 600) // 30))
+    stage(ctx, st2)
+    info, _ = check_pileup(ctx, st2, entries=True, window=5000)
+    assert len(info.runs) == 40
+    for skip in (True, False):
+        if use_md:                                   # (profile 1 has N skips: where BioD's chunk drifts off and its popFront throws, so must this)
+            _check_refbase(ctx, st2, skip_zero=skip, window=30_000)
+            continue
+        ora = O.pileup(st2, skip_zero=skip)
+        got_pos, got_cov = [], []
+        for w in ctx.pileup_windows(L.BGP_PILEUP_COLUMNS, skip_zero_coverage=skip, window_positions=30_000):
+            keep = w.columns["coverage"] > 0 if skip else np.ones(len(w.columns), bool)
+            got_pos.append((np.int64(w.ref_id) << 40) + w.first_position + np.nonzero(keep)[0]); got_cov.append(w.columns["coverage"][keep])
+        assert np.array_equal(np.concatenate(got_pos), (ora.ref.astype(np.int64) << 40) + ora.pos.astype(np.int64)), skip
+        assert np.array_equal(np.concatenate(got_cov), ora.cov)
+    # M-only reads with consistent MD tags: reference_base through the uncovered stretches, both modes
+    clean = host_stream(make_cfg(n_reads=1200, n_ref=2, ref_len=8_000, read_len=100, profile=0, seed=8))
+    st3 = _shift_positions(clean, lambda i: 80_000 * ((i % 600) // 30))
+    stage(ctx, st3)
+    if use_md:
+        for skip in (True, False):
+            assert _check_refbase(ctx, st3, skip_zero=skip, window=30_000) is not None
+
 
 def test_empty_and_ragged_streams(ctx):
     rec = bamio.pack_record("r", "ACGT", [(4, "M")], ref_id=0, pos=5)
