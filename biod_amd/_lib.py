@@ -98,6 +98,9 @@ SYMBOLS = {
     "bgp_maq_error_model": (C.c_int, [C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     "bgp_batch_begin": (C.c_int, [_P, C.c_uint64, C.c_int, C.c_uint32]),
     "bgp_batch_push": (C.c_int, [_P, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "bgp_batch_set_md": (C.c_int, [_P, C.c_int, C.c_int]),
+    "bgp_batch_acquire": (C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_size_t)]),
+    "bgp_batch_commit": (C.c_int, [_P, C.c_size_t]),
     "bgp_batch_end": (C.c_int, [_P]),
     "bgp_batch_next_window": (C.c_int, [_P, C.POINTER(Columns)]),
     "bgp_batch_ordinal_base": (C.c_int, [_P, C.POINTER(C.c_uint64)]),

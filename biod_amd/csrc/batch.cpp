@@ -16,6 +16,7 @@
 //   * the last batch hands out everything.
 // Columns (and per-read entries, with stream-wide read ordinals) are identical to the one-shot result (tested).
 #include "common.h"
+#include <cstddef>
 #include <thread>
 #include <vector>
 
@@ -37,6 +38,8 @@ struct Batch {
     bool resume = false; int32_t resume_ref = 0; uint64_t resume_pos = 0;      // where handing out stopped before this batch
     bool cut = false; int32_t cut_ref = 0; uint64_t cut_pos = 0;                // where it stops in this one
     uint32_t run = 0; uint64_t next_pos = 0; bool run_open = false;
+    // use_md_tag across batches: the provider chain's state at the last event in front of the cut (stream-wide record ordinals)
+    struct { bool have = false; uint64_t P_ord = 0, i_ord = 0; uint32_t ci = 0, y = 0, ce = 0; int32_t ref = -1; } md;
 };
 
 void batch_release(bgp_ctx* c) {
@@ -50,7 +53,7 @@ void batch_release(bgp_ctx* c) {
     }
     delete b;
     c->batch = nullptr;
-    c->frame_tolerant_tail = false; c->batch_maq = 0;
+    c->frame_tolerant_tail = false; c->batch_maq = 0; c->batch_md = 0; c->batch_md_skip_zero = 1;
 }
 
 // the host buffer that takes the pushes goes to a free device buffer (asynchronous copy); BGP_EAGAIN when both device
@@ -132,6 +135,44 @@ static int process_next(bgp_ctx* c, Batch* b) {
             b->next_ord_base = b->ord_base + carry_record;
         }
     } else { b->carry_off = 0; b->carry_len = 0; }
+    if (c->batch_md && !c->runs.empty()) {
+        // PileupRangeUsingMdTag (pileup.d:522-654) over the batch, its first run resumed where the previous batch's chain stood at its
+        // last event in front of the cut, its last run's state saved the same way.  Columns in front of the cut only depend on reads
+        // the batch holds, so they are final; the provider and every read the chain has not looked at yet are carried as well.
+        K6Batch bt;
+        bt.in_ce = b->md.ce;
+        if (b->md.have && c->runs[0].ref_id == b->md.ref && b->md.i_ord >= b->ord_base && (b->md.P_ord == ~0ull || b->md.P_ord >= b->ord_base)) {
+            bt.in_have = 1; bt.in_P = b->md.P_ord == ~0ull ? ~0ull : b->md.P_ord - b->ord_base; bt.in_i = b->md.i_ord - b->ord_base; bt.in_ci = b->md.ci; bt.in_y = b->md.y;
+        }
+        bt.stop_at = (!final && b->cut) ? (uint32_t)b->cut_pos : 0u;
+        int md_err = 0; int64_t md_from = -1;
+        BGP_TRY(k6_reference_bases(c, c->batch_md_skip_zero, 0, (uint32_t)c->runs.size(), ~0ull, &md_err, &md_from, &bt));
+        // (an error behind the cut may be an artefact of the reads the batch does not hold yet: the next batch looks at those columns again)
+        if (md_err && (final || !b->cut || md_from < 0 || (uint64_t)md_from < b->cut_pos)) {
+            c->last_error = "MD tag inconsistent with CIGAR/SEQ while reconstructing reference bases";
+            return md_err;
+        }
+        b->md.have = false; b->md.ce = bt.out_ce;
+        if (!final && b->cut && bt.out_have) {
+            b->md.have = true; b->md.ref = c->runs.back().ref_id; b->md.ci = bt.out_ci; b->md.y = bt.out_y;
+            b->md.P_ord = bt.out_P == ~0ull ? ~0ull : b->ord_base + bt.out_P; b->md.i_ord = b->ord_base + bt.out_i;
+            uint64_t first_needed = bt.out_i;
+            if (bt.out_P != ~0ull) first_needed = std::min(first_needed, bt.out_P);
+            {   // ... and every read that reaches beyond the saved column: the rows the chain looks at next ask "is the column in front of
+                // me covered" (add()'s _prev_coverage, pileup.d:583-588), which the reads that end before the cut still answer
+                uint64_t fpos = 0, frec = ~0ull;
+                BGP_TRY(k34_first_survivor(c, (uint32_t)c->runs.size() - 1, (uint64_t)bt.out_y + 1, &fpos, &frec));
+                if (frec != ~0ull) first_needed = std::min(first_needed, frec);
+            }
+            const uint64_t carried = b->next_ord_base - b->ord_base;                       // first record the cut carries
+            if (first_needed < carried) {                                                   // the chain still needs reads the columns no longer do
+                uint64_t off = 0;
+                BGP_HIP(hipMemcpyAsync(&off, reinterpret_cast<const uint8_t*>(c->d_rec.as<bgp_record>() + first_needed) + offsetof(bgp_record, rec_off), 8, hipMemcpyDeviceToHost, c->stream));
+                BGP_HIP(hipStreamSynchronize(c->stream));
+                b->carry_off = off; b->carry_len = c->stream_len - off; b->next_ord_base = b->ord_base + first_needed;
+            }
+        }
+    }
     b->run = 0; b->run_open = false;
     return BGP_OK;
 }
@@ -178,6 +219,44 @@ int bgp_batch_push(bgp_ctx* c, const uint8_t* data, size_t len, size_t* taken) {
     BGP_API_CATCH(c)
 }
 
+/* Zero-copy staging: the caller (an inflater, a reader) writes its bytes straight into the pinned buffer the next copy to HBM
+ * starts from -- the shape of decompressBgzfBlock writing into the block's own buffer (block.d:127-216) -- instead of handing them
+ * to bgp_batch_push to be copied there. */
+int bgp_batch_acquire(bgp_ctx* c, uint8_t** ptr, size_t* cap) {
+    BGP_API_TRY
+    if (!c || !ptr || !cap) return BGP_EINVAL;
+    Batch* b = c->batch;
+    if (!b || b->ended) return BGP_ESTATE;
+    BGP_HIP(hipSetDevice(c->device));
+    *ptr = nullptr; *cap = 0;
+    if (b->host_len[b->fill] == b->batch_bytes) { const int rc = ship(c, b); if (rc != BGP_OK) return rc; }      // BGP_EAGAIN: hand out windows first
+    const int h = b->fill;
+    *ptr = b->host[h].as<uint8_t>() + b->host_len[h]; *cap = (size_t)(b->batch_bytes - b->host_len[h]);
+    return BGP_OK;
+    BGP_API_CATCH(c)
+}
+int bgp_batch_commit(bgp_ctx* c, size_t n) {
+    BGP_API_TRY
+    if (!c) return BGP_EINVAL;
+    Batch* b = c->batch;
+    if (!b || b->ended) return BGP_ESTATE;
+    const int h = b->fill;
+    if (n > b->batch_bytes - b->host_len[h]) return BGP_EINVAL;
+    b->host_len[h] += n;
+    return BGP_OK;
+    BGP_API_CATCH(c)
+}
+
+int bgp_batch_set_md(bgp_ctx* c, int use_md_tag, int skip_zero_coverage) {
+    BGP_API_TRY
+    if (!c) return BGP_EINVAL;
+    Batch* b = c->batch;
+    if (!b || b->any_batch) return BGP_ESTATE;               // right after bgp_batch_begin
+    c->batch_md = use_md_tag != 0; c->batch_md_skip_zero = skip_zero_coverage != 0;
+    return BGP_OK;
+    BGP_API_CATCH(c)
+}
+
 int bgp_batch_end(bgp_ctx* c) {
     BGP_API_TRY
     if (!c || !c->batch) return BGP_ESTATE;
@@ -203,7 +282,7 @@ int bgp_batch_next_window(bgp_ctx* c, bgp_columns* o) {
                 if (b->next_pos >= hi) { ++b->run; b->run_open = false; continue; }
                 const uint64_t a = b->next_pos, e = std::min(hi, a + b->window);
                 if (c->batch_maq) { c->it.maq = 1; c->it.maq_depcorr = c->batch_maq_depcorr; c->it.maq_eta = c->batch_maq_eta; c->it.maq_min_bq = c->batch_maq_min_bq; }
-                BGP_TRY(emit_window(c, b->run, a, e, b->want_entries, 0, 0, o));
+                BGP_TRY(emit_window(c, b->run, a, e, b->want_entries, c->batch_md, 0, o));
                 if (b->want_entries && b->ord_base + c->n_records > (1ull << 32)) {     // bgp_entry.read_ordinal is 32 bits wide
                     c->last_error = "batched staging with per-read entries: the stream has more than 2^32 records (bgp_entry.read_ordinal would wrap)";
                     return BGP_EINVAL;

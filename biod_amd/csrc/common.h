@@ -177,6 +177,7 @@ struct bgp_ctx {
 
     // batched staging (batch.cpp): streams larger than HBM, a batch at a time with the overlapping reads carried over
     struct Batch* batch = nullptr;
+    int batch_md = 0, batch_md_skip_zero = 1;          // bgp_batch_set_md: reference_base on every batch's windows, the provider chain carried across the seams
     int batch_maq = 0; float batch_maq_depcorr = 0.f, batch_maq_eta = 0.f; uint32_t batch_maq_min_bq = 0;   // bgp_pileup_maq between bgp_batch_begin and the windows: every batch's windows carry the calls
 
     // timing
@@ -212,7 +213,12 @@ int scan_inclusive_max_u64(bgp_ctx* c, const uint64_t* in, uint64_t* out, uint64
 int k7_snp_simple(bgp_ctx* c, uint64_t col_index, uint64_t np, int min_cov, int min_wit);    // md.hip: d_snp[0..np) from d_columns/d_refbase
 int k8_maq_calls(bgp_ctx* c, uint64_t col_index, uint64_t np, int use_md);                    // maq.hip: d_maq[0..np) from the window's entries (K5), the record table and d_refbase
 int k6_dna_of_record(bgp_ctx* c, uint64_t i, uint8_t* host_out, uint32_t cap, uint32_t* len, uint32_t* flags);
-int k6_reference_bases(bgp_ctx* c, int skip_zero, uint32_t run_first, uint32_t run_end, uint64_t first_record, int* md_err, int64_t* md_err_from);   // md.hip: fills d_refbase
+struct K6Batch {                  // batched staging: the provider chain's state across the seam between two batches (md.hip: k6_chain)
+    uint32_t in_have = 0, in_ci = 0, in_y = 0, in_ce = 0; uint64_t in_P = 0, in_i = 0;      // resume the first run from this state (record indices of THIS batch) | chunk_end_position carried in
+    uint32_t stop_at = 0;                                                                     // save the last event boundary in front of this position of the LAST run (0: none)
+    uint32_t out_have = 0, out_ci = 0, out_y = 0, out_ce = 0; uint64_t out_P = 0, out_i = 0;
+};
+int k6_reference_bases(bgp_ctx* c, int skip_zero, uint32_t run_first, uint32_t run_end, uint64_t first_record, int* md_err, int64_t* md_err_from, K6Batch* bt = nullptr);   // md.hip: fills d_refbase
 int synth_device(bgp_ctx* c, const bgp_synth_cfg_c* cfg, uint64_t* bytes);   // synth.hip
 int synth_host(const bgp_synth_cfg_c* cfg, uint64_t first, uint64_t count, uint8_t* out, uint64_t cap, uint64_t* bytes);
 int bgzf_load_bam(bgp_ctx* c, const char* path, int n_threads);               // bgzf_host.cpp

@@ -407,8 +407,11 @@ __global__ __launch_bounds__(256) void k6_prep(const uint8_t* s, const bgp_recor
 //   END   of the run at E = max end_position.
 // add() keeps "the first read with the largest end_position among those it accepts", which does not
 // depend on the order the reads are looked at -- so a batch is reduced with one arg-max.
-struct ChainRun { uint64_t first, endrec, iv_base; uint32_t run_end, ce_in, active, pad; };
-struct ChainOut { uint32_t ce_out, n_iv; int32_t err; uint32_t pad; int64_t err_from; };
+// Batched staging (batch.cpp): the chain of a reference that began in an earlier batch is RESUMED -- between two events its whole
+// state is (provider, cursor, chunk_end_position, column, next record to look at), nothing of add()'s bookkeeping is pending --
+// and the last such state in front of `stop_at` (the position from which the next batch hands out columns) is saved for it.
+struct ChainRun { uint64_t first, endrec, iv_base; uint32_t run_end, ce_in, active, resume; uint64_t rs_P, rs_i; uint32_t rs_ci, rs_y, stop_at, pad; };
+struct ChainOut { uint32_t ce_out, n_iv; int32_t err; uint32_t sv_have; int64_t err_from; uint64_t sv_P, sv_i; uint32_t sv_ci, sv_CE, sv_y, pad; };
 struct MdIv { uint32_t col, c0; uint64_t prov; };
 constexpr uint64_t MD_NONE = ~0ull, MD_INF = 1ull << 62;
 
@@ -430,6 +433,8 @@ __global__ __launch_bounds__(64) void k6_chain(const MdRow* rows, const ChainRun
     const uint64_t iv_cap = R.endrec - R.first + 2;
     uint64_t b = MD_NONE; MdRow row{0, 0, 0, 0};
 
+    uint64_t svP = MD_NONE, svI = 0; uint32_t svci = 0, svCE = 0, svy = 0, svhave = 0;
+    auto save = [&]() { if (y < (uint64_t)R.stop_at) { svP = P; svI = i; svci = ci; svCE = CE; svy = (uint32_t)y; svhave = 1; } };      // an event boundary: has_next is false here
     auto load = [&](uint64_t base) { b = base; const uint64_t idx = base + lane; row = idx < R.endrec ? rows[idx] : MdRow{0, 0, 0, 0}; };
     auto emit = [&](uint64_t col, uint32_t c0, uint64_t prov) {
         if (n_iv < iv_cap) { if (lane == 0) iv[R.iv_base + n_iv] = MdIv{(uint32_t)col, c0, prov}; ++n_iv; }
@@ -476,10 +481,17 @@ __global__ __launch_bounds__(64) void k6_chain(const MdRow* rows, const ChainRun
             if (P != MD_NONE && ci < L) emit((uint64_t)x + 1, ci, P);   // ... and the old chunk simply goes on
         }
         y = x; i = ge;
+        save();
         return true;
     };
 
-    if (init_at(R.first, true)) {
+    bool started;
+    if (R.resume) {                                               // the state an earlier batch saved (record indices already in this batch's numbering)
+        P = R.rs_P; ci = R.rs_ci; y = R.rs_y; i = R.rs_i;
+        if (P != MD_NONE) { load(P); const uint32_t lf = __shfl(row.lf, 0, 64); L = lf & MD_LMASK; bad = (lf & MD_BAD) != 0; if (ci < L) emit(y + 1, ci, P); }
+        started = true;
+    } else started = init_at(R.first, true);
+    if (started) {
         for (;;) {
             const uint64_t empty_at = bad ? MD_INF : y + (L > ci + 1 ? L - ci : 1u);
             bool found = false; uint64_t F = MD_INF;
@@ -525,6 +537,7 @@ __global__ __launch_bounds__(64) void k6_chain(const MdRow* rows, const ChainRun
                 ci = skip < L ? (uint32_t)skip : L;
                 if (ci >= L) { err = BGP_EMD; err_from = (int64_t)F - 1; break; }
                 emit(F, ci, P); ci += 1; y = F; i = jn;
+                save();
                 continue;
             }
             const uint64_t E = outcome == 2 ? (egap > y + 1 ? egap : y + 1) : (R.run_end > y + 1 ? R.run_end : y + 1);
@@ -535,7 +548,7 @@ __global__ __launch_bounds__(64) void k6_chain(const MdRow* rows, const ChainRun
             if (!init_at(jn, false)) { err_from = (int64_t)E - 1; break; }
         }
     }
-    if (lane == 0) co[blockIdx.x] = ChainOut{CE, n_iv, err, 0u, err_from};
+    if (lane == 0) co[blockIdx.x] = ChainOut{CE, n_iv, err, svhave, err_from, svP, svI, svci, svCE, svy, 0u};
 }
 
 // ---------------------------------------------------------------------------------------------- k6_fill
@@ -1012,8 +1025,9 @@ int k6_dna_of_record(bgp_ctx* c, uint64_t i, uint8_t* host_out, uint32_t cap, ui
 // (pileup.d:583-595).  Each run is chained with a guess (the previous run's max end_position, which is what
 // the previous chain ends on unless an MD tag is inconsistent), the guesses are checked against the
 // chains' real final values in order, and wrong ones are re-chained.
-int k6_reference_bases(bgp_ctx* c, int skip_zero, uint32_t run_first, uint32_t run_end, uint64_t first_record, int* md_err, int64_t* md_err_from) {
+int k6_reference_bases(bgp_ctx* c, int skip_zero, uint32_t run_first, uint32_t run_end, uint64_t first_record, int* md_err, int64_t* md_err_from, K6Batch* bt) {
     *md_err = 0; *md_err_from = -1;
+    if (bt) { bt->out_have = 0; bt->out_ce = bt->in_ce; }
     if (c->n_records >= 0xFFFFFFF0ull) { c->last_error = "too many records for the MD path"; return BGP_EINVAL; }
     BGP_TRY(k6_rows(c));
     const uint64_t n_pos = c->pinfo.n_positions;
@@ -1030,8 +1044,10 @@ int k6_reference_bases(bgp_ctx* c, int skip_zero, uint32_t run_first, uint32_t r
         ChainRun& x = cr[k];
         x.first = (k == 0 && first_record != ~0ull) ? first_record : r.first_record;
         x.endrec = r.end_record; x.iv_base = x.first + 2ull * k; x.run_end = (uint32_t)r.end_pos;
-        x.ce_in = k == 0 ? 0u : (uint32_t)c->runs[run_first + k - 1].end_pos;
-        x.active = 0; x.pad = 0;
+        x.ce_in = k == 0 ? (bt ? bt->in_ce : 0u) : (uint32_t)c->runs[run_first + k - 1].end_pos;
+        x.active = 0; x.pad = 0; x.resume = 0; x.rs_P = 0; x.rs_i = 0; x.rs_ci = 0; x.rs_y = 0; x.stop_at = 0;
+        if (bt && k == 0 && bt->in_have) { x.resume = 1; x.rs_P = bt->in_P; x.rs_i = bt->in_i; x.rs_ci = bt->in_ci; x.rs_y = bt->in_y; }
+        if (bt && k + 1 == nr) x.stop_at = bt->stop_at;
         pr[k] = ParRun{x.first, x.endrec, x.run_end, x.ce_in, 0u, 0u};
         er[k] = EmitRun{x.first, x.endrec, r.column_base, (uint32_t)r.start_pos, (uint32_t)r.end_pos};
     }
@@ -1043,7 +1059,7 @@ int k6_reference_bases(bgp_ctx* c, int skip_zero, uint32_t run_first, uint32_t r
     uint8_t* st = c->d_md_state.as<uint8_t>();
     const uint64_t n = c->n_records;
     const char* mode = getenv("BGP_MD_CHAIN");                 // "seq": the event loop only; default: composed successors, event loop where premises fail
-    const bool use_par = !(mode && !strcmp(mode, "seq"));
+    const bool use_par = !(mode && !strcmp(mode, "seq")) && !bt;      // (a batch's chain resumes and saves state: the event loop)
     const uint64_t n_slots = (n + SEG - 1) / SEG + nr + 1;
     const uint32_t longs_cap = (uint32_t)std::min<uint64_t>(n_pos / DNA_LONG + nr + 64, 0x7FFFFFFFull);    // a long chunk covers > DNA_LONG columns of its run
     if (use_par) {
@@ -1153,5 +1169,10 @@ int k6_reference_bases(bgp_ctx* c, int skip_zero, uint32_t run_first, uint32_t r
         BGP_TRY(solve(std::vector<uint32_t>{redo}, true));
     }
     for (uint32_t k = 0; k < nr; ++k) if (co[k].err) { *md_err = co[k].err; *md_err_from = co[k].err_from; break; }
+    if (bt) {
+        const ChainOut& last = co[nr - 1];
+        bt->out_have = last.sv_have; bt->out_P = last.sv_P; bt->out_i = last.sv_i; bt->out_ci = last.sv_ci; bt->out_y = last.sv_y;
+        bt->out_ce = last.sv_have ? last.sv_CE : cr[nr - 1].ce_in;      // no boundary in front of stop_at: the run begins afresh in the next batch, under the chunk_end_position it began with here
+    }
     return BGP_OK;
 }

@@ -203,9 +203,12 @@ class Context:
         yield from self._windows(None, copy)
 
     # -- batched staging (streams larger than HBM): include/biodgpu.h, bgp_batch_*
-    def batch_begin(self, batch_bytes: int = 0, want_entries: bool = False, window_positions: int = 0, maq=None):
-        """maq=(depcorr, eta, minimum_base_quality): the MAQ model's call per position on every batch's windows (window.maq)."""
+    def batch_begin(self, batch_bytes: int = 0, want_entries: bool = False, window_positions: int = 0, maq=None, use_md_tag=False, skip_zero_coverage=True):
+        """maq=(depcorr, eta, minimum_base_quality): the MAQ model's call per position on every batch's windows (window.maq).
+        use_md_tag: window.reference_base, the provider chain carried across the batches (bgp_batch_set_md)."""
         L.check(L.lib().bgp_batch_begin(self._h, batch_bytes, int(want_entries), window_positions), self._h)
+        if use_md_tag:
+            L.check(L.lib().bgp_batch_set_md(self._h, 1, int(skip_zero_coverage)), self._h)
         if maq is not None:
             L.check(L.lib().bgp_pileup_maq(self._h, float(maq[0]), float(maq[1]), int(maq[2])), self._h)
 
@@ -235,14 +238,14 @@ class Context:
             cols = L.as_array(cw.columns, cw.n_positions, L.COLUMN_DTYPE)
             eoff = L.as_array(cw.entry_off, cw.n_positions + 1, "<u8") if cw.entry_off else None
             ents = L.as_array(cw.entries, int(eoff[-1]), L.ENTRY_DTYPE) if eoff is not None else None
-            w = Window(cw.ref_id, cw.first_position, cols, eoff, ents, None)
+            w = Window(cw.ref_id, cw.first_position, cols, eoff, ents, L.as_array(cw.reference_base, cw.n_positions, "u1") if cw.reference_base else None)
             if cw.maq:
                 w.maq = L.as_array(cw.maq, cw.n_positions, L.MAQ_CALL_DTYPE)
             yield w
 
-    def batched_windows(self, pieces, batch_bytes: int = 0, want_entries: bool = False, window_positions: int = 0, maq=None):
+    def batched_windows(self, pieces, batch_bytes: int = 0, want_entries: bool = False, window_positions: int = 0, maq=None, use_md_tag=False, skip_zero_coverage=True):
         """pileupColumns over a stream handed over piece by piece (any cut points): dense windows of final columns."""
-        self.batch_begin(batch_bytes, want_entries, window_positions, maq)
+        self.batch_begin(batch_bytes, want_entries, window_positions, maq, use_md_tag, skip_zero_coverage)
         for piece in pieces:
             mv = memoryview(piece)
             off = 0

@@ -177,7 +177,10 @@ extern (C) nothrow @nogc {
     int bgp_pileup_ref_id(bgp_ctx* ctx, int* ref_id);
 
     int bgp_batch_begin(bgp_ctx* ctx, ulong batch_bytes, int want_entries, uint window_positions);
+    int bgp_batch_set_md(bgp_ctx* ctx, int use_md_tag, int skip_zero_coverage);
     int bgp_batch_push(bgp_ctx* ctx, const(ubyte)* data, size_t len, size_t* taken);
+    int bgp_batch_acquire(bgp_ctx* ctx, ubyte** ptr, size_t* cap);
+    int bgp_batch_commit(bgp_ctx* ctx, size_t n);
     int bgp_batch_end(bgp_ctx* ctx);
     int bgp_batch_next_window(bgp_ctx* ctx, bgp_columns* out_);
     int bgp_batch_ordinal_base(bgp_ctx* ctx, ulong* base);

@@ -254,7 +254,20 @@ int bgp_pileup_ref_id(bgp_ctx* ctx, int32_t* ref_id);          /* AbstractPileup
  * BAM record (beyond 2^30, or smaller than the sections its header announces) is BGP_EINVAL in the batch it appears in,
  * not "the rest is still to come". */
 int bgp_batch_begin(bgp_ctx* ctx, uint64_t batch_bytes, int want_entries, uint32_t window_positions);
+/* use_md_tag for the batches (call right after bgp_batch_begin): every window carries reference_base as PileupRangeUsingMdTag
+ * (pileup.d:522-654) yields it over the WHOLE stream -- the provider chain's state (provider, cursor, chunk_end_position, the next
+ * read add() has not seen) is carried across the seam between two batches, so examples/make_pileup.d:16, makePileup(bam.reads,
+ * true), runs on a file that does not fit the device.  skip_zero_coverage says which sweep the chain belongs to (it re-initialises
+ * at uncovered columns only then, pileup.d:388-392).  BGP_EMD comes from the bgp_batch_next_window whose batch holds the column
+ * BioD's popFront would throw at. */
+int bgp_batch_set_md(bgp_ctx* ctx, int use_md_tag, int skip_zero_coverage);
 int bgp_batch_push(bgp_ctx* ctx, const uint8_t* data, size_t len, size_t* taken);
+/* bgp_batch_push without the copy: bgp_batch_acquire hands out the free tail of the pinned buffer the next batch is copied to HBM
+ * from (*cap bytes at *ptr; BGP_EAGAIN: hand out windows first), the caller -- an inflater, as decompressBgzfBlock writes into the
+ * block's own buffer, block.d:127-216 -- fills it, bgp_batch_commit says how many bytes it wrote (<= *cap).  Pushes and
+ * acquire / commit pairs may be mixed. */
+int bgp_batch_acquire(bgp_ctx* ctx, uint8_t** ptr, size_t* cap);
+int bgp_batch_commit(bgp_ctx* ctx, size_t n);
 int bgp_batch_end(bgp_ctx* ctx);
 int bgp_batch_next_window(bgp_ctx* ctx, bgp_columns* out);
 int bgp_batch_ordinal_base(bgp_ctx* ctx, uint64_t* base);

@@ -1,8 +1,13 @@
-"""Device-E2E through batched staging (NOT the headline: the input crosses PCIe): a synthetic record stream pushed from
-host memory in 64 MiB pieces -> bgp_batch_push -> final columns handed out window by window (read in place, pinned).
+"""Device-E2E through batched staging (NOT the headline: the input crosses PCIe): a synthetic record stream in host memory ->
+pinned staging -> HBM -> K0..K4 per batch -> final columns handed out window by window (pinned host memory, read in place).
+Three ways of getting the bytes into the pinned buffers, each with and without a consumer that reads every column:
+  push     bgp_batch_push copies the caller's bytes (its own threads, BGP_PUSH_THREADS)
+  acquire  bgp_batch_acquire / _commit: the producer writes straight into the pinned buffer (here: P threads copying from the
+           array, standing in for P inflate workers that would otherwise write into buffers of their own)
 Raw ctypes calls: the Python facade's copies would be the slowest thing measured."""
 import ctypes as C
 import sys, time
+from concurrent.futures import ThreadPoolExecutor
 import numpy as np
 sys.path.insert(0, "/root/repo")
 import torch  # noqa: F401  (first: its HIP runtime)
@@ -12,39 +17,71 @@ from biod_amd.synth import host_stream_np, scaled
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
 batch = int(sys.argv[2]) if len(sys.argv) > 2 else 256 << 20
+P = int(sys.argv[3]) if len(sys.argv) > 3 else 16
 st = host_stream_np(scaled("cfg3", n))
 ctx = Context(0)
 lib, h = L.lib(), ctx.handle
 piece = 64 << 20
+pool = ThreadPoolExecutor(P)
 
 
-def drain(stats):
+def drain(stats, touch):
     cw = L.Columns()
     while True:
         rc = L.check(lib.bgp_batch_next_window(h, C.byref(cw)), h)
         if rc != L.BGP_OK:
             return rc
-        cov = np.ctypeslib.as_array(C.cast(cw.columns, C.POINTER(C.c_uint32)), shape=(cw.n_positions, 8))[:, 0]
-        stats[0] += cw.n_positions; stats[1] += int(np.count_nonzero(cov)); stats[2] += int(cov.sum(dtype=np.int64))
+        stats[0] += cw.n_positions
+        if touch:
+            cov = np.ctypeslib.as_array(C.cast(cw.columns, C.POINTER(C.c_uint32)), shape=(cw.n_positions, 8))[:, 0]
+            stats[1] += int(np.count_nonzero(cov)); stats[2] += int(cov.sum(dtype=np.int64))
 
 
-for rep in range(3):
+def fill(dst_ptr, src, m):          # P threads, each its slice (np.copyto releases the GIL)
+    dst = np.ctypeslib.as_array(C.cast(dst_ptr, C.POINTER(C.c_uint8)), shape=(m,))
+    step = -(-m // P)
+    list(pool.map(lambda k: np.copyto(dst[k * step:min(m, (k + 1) * step)], src[k * step:min(m, (k + 1) * step)]), range(P)))
+
+
+def run(mode, touch):
     t0 = time.perf_counter()
     stats = [0, 0, 0]
     L.check(lib.bgp_batch_begin(h, batch, 0, 1 << 22), h)
     off, taken = 0, C.c_size_t()
     while off < len(st):
-        m = min(piece, len(st) - off)
-        rc = L.check(lib.bgp_batch_push(h, C.c_void_p(st.ctypes.data + off), m, C.byref(taken)), h)
-        off += taken.value
+        if mode == "push":
+            m = min(piece, len(st) - off)
+            rc = L.check(lib.bgp_batch_push(h, C.c_void_p(st.ctypes.data + off), m, C.byref(taken)), h)
+            off += taken.value
+        else:
+            ptr, cap = C.c_void_p(), C.c_size_t()
+            rc = L.check(lib.bgp_batch_acquire(h, C.byref(ptr), C.byref(cap)), h)
+            if rc == L.BGP_OK:
+                m = min(cap.value, len(st) - off)
+                fill(ptr.value, st[off:off + m], m)
+                L.check(lib.bgp_batch_commit(h, m), h)
+                off += m
         if rc == L.BGP_EAGAIN:
-            drain(stats)
+            drain(stats, touch)
     L.check(lib.bgp_batch_end(h), h)
-    drain(stats)
+    drain(stats, touch)
     dt = time.perf_counter() - t0
-    print(f"run {rep}: {n} reads, {len(st) / 1e9:.2f} GB inflated in {len(st) / batch:.1f} batches of {batch >> 20} MiB: {dt:.3f} s = {n / dt / 1e6:.1f} Mreads/s device-E2E "
-          f"({len(st) / dt / 1e9:.1f} GB/s of input; {stats[0]} positions, {stats[1]} columns, sum coverage {stats[2]}; columns copied to the host: {stats[0] * 32 / 1e9:.2f} GB)")
+    return dt, stats
+
+
+print(f"{n} reads of cfg3's model, {len(st) / 1e9:.2f} GB inflated, batches of {batch >> 20} MiB ({len(st) / batch:.1f}), producer threads {P}")
+last = None
+for mode in ("push", "acquire"):
+    for touch in (True, False):
+        best = None
+        for rep in range(3):
+            dt, stats = run(mode, touch)
+            best = dt if best is None or dt < best else best
+            if touch:
+                last = stats
+        print(f"{mode:8s} consumer {'reads every column' if touch else 'takes the windows only'}: best of 3 {best:.3f} s = {n / best / 1e6:.1f} Mreads/s device-E2E, "
+              f"{len(st) / best / 1e9:.1f} GB/s of input ({stats[0]} positions = {stats[0] * 32 / 1e9:.2f} GB of columns back)", flush=True)
 ctx.reset(); ctx.push_inflated(st.tobytes()); ctx.flush()
 info = ctx.pileup_run()
-assert (info.n_positions, info.n_columns, info.sum_coverage) == tuple(stats), "batched != one shot"
+assert (info.n_positions, info.n_columns, info.sum_coverage) == tuple(last), "batched != one shot"
 print("batched == one shot (positions, columns, sum of coverage)")

@@ -1679,6 +1679,57 @@ def test_batched_staging_edges(ctx):
     assert np.array_equal(cov[cov > 0], O.pileup(st).cov)
 
 
+def _batched_refbase(ctx, pieces, batch, skip):
+    ref, pos, rb = [], [], []
+    for w in ctx.batched_windows(pieces, batch, window_positions=3000, use_md_tag=True, skip_zero_coverage=skip):
+        nz = np.nonzero(w.columns["coverage"])[0]
+        ref.append(np.full(len(nz), w.ref_id, np.int64)); pos.append(w.first_position + nz.astype(np.int64)); rb.append(w.reference_base[nz])
+    cat = lambda xs, dt: np.concatenate(xs) if xs else np.zeros(0, dt)
+    return cat(ref, np.int64), cat(pos, np.int64), cat(rb, np.uint8)
+
+
+@pytest.mark.parametrize("skip", [True, False])
+@pytest.mark.parametrize("name,batch", [("illu_20_chunk.bam", 4096), ("b7_295_chunk.bam", 20_000), ("b7_295_chunk.bam", 70_000), ("ex1_header.bam", 30_000), ("tags.bam", 8192)])
+def test_batched_staging_reference_base_fixtures(ctx, data_dir, name, batch, skip):
+    """use_md_tag across batches (bgp_batch_set_md): the provider chain's state crosses every seam, reference_base of every
+    covered column == PileupRangeUsingMdTag over the whole stream (the oracle), in batches of a few dozen reads."""
+    _, st = bamio.read_bam(os.path.join(data_dir, name))
+    try:
+        ora = O.pileup(st, use_md=True, skip_zero=skip)
+    except O.OracleError as e:
+        assert e.code in (O.ORC_EMD, O.ORC_EINVAL)
+        with pytest.raises(L.BiodGpuError):
+            _batched_refbase(ctx, _pieces(st, 5000), batch, skip)
+        return
+    ref, pos, rb = _batched_refbase(ctx, _pieces(st, 5000), batch, skip)
+    keep = ora.cov > 0
+    assert np.array_equal(ref, ora.ref[keep].astype(np.int64)) and np.array_equal(pos, ora.pos[keep].astype(np.int64))
+    bad = np.nonzero(rb != ora.refbase[keep])[0]
+    assert len(bad) == 0, [(int(pos[k]), chr(rb[k]), chr(ora.refbase[keep][k])) for k in bad[:8]]
+
+
+@pytest.mark.parametrize("profile,batch", [(0, 40_000), (0, 300_000), (1, 60_000), (2, 400_000)])
+def test_batched_staging_reference_base_synthetic(ctx, profile, batch):
+    """The three read models in many batches, both sweeps: M-only reads with consistent MD tags, the mixed model (N skips: BioD's
+    chunk drifts off the reference there -- the same drift must come out), long indel-heavy reads (providers of tens of kb:
+    the chain's state reaches far in front of the cut)."""
+    cfg = make_cfg(n_reads=6000 if profile < 2 else 60, n_ref=2, ref_len=40_000 if profile < 2 else 300_000, read_len=150 if profile < 2 else (4000, 20_000), profile=profile, seed=70 + profile)
+    st = host_stream(cfg)
+    for skip in (True, False):
+        try:
+            ora = O.pileup(st, use_md=True, skip_zero=skip)
+        except O.OracleError as e:
+            assert e.code == O.ORC_EMD
+            with pytest.raises(L.BiodGpuError):
+                _batched_refbase(ctx, _pieces(st, 33_333), batch, skip)
+            continue
+        ref, pos, rb = _batched_refbase(ctx, _pieces(st, 33_333), batch, skip)
+        keep = ora.cov > 0
+        assert np.array_equal(pos, ora.pos[keep].astype(np.int64))
+        bad = np.nonzero(rb != ora.refbase[keep])[0]
+        assert len(bad) == 0, (skip, [(int(ref[k]), int(pos[k]), chr(rb[k]), chr(ora.refbase[keep][k])) for k in bad[:8]])
+
+
 def test_interval_shards_with_exact_halo_on_the_device(ctx):
     """plan_interval_shards: three equal-read-count shards of a two-contig stream, each piled up on the
     device from its byte range (own reads + exact halo) and clipped; concatenation == oracle on the whole stream."""
