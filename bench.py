@@ -62,13 +62,13 @@ def pmc_traffic(timers, config, n_reads, launches=None):
     timer's launches per step (1 for all but k0_chase, whose second round re-enters a few segments), from the committed
     rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected separately, FETCH doubled for
     gfx950 as MI355X_MICROARCH.md prescribes).  Counters cannot be read from inside this process, so the number is only
-    reported when the workload is the one the profile was taken on (cfg3, 100 M reads) AND the profile's header carries
-    the hash of the kernel sources as they are now (scratch/refresh_profiles_r02.sh writes it); otherwise null."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_hbm_traffic_cfg3_100M.csv")
-    if config != "cfg3" or n_reads != 100_000_000 or not os.path.exists(path):
+    reported when the workload is the one the profile was taken on (configuration and read count in the profile's header) AND
+    that header carries the hash of the kernel sources as they are now (scratch/refresh_profiles.sh writes it); otherwise null."""
+    path = os.path.join(ROOT, "profiles", f"r03_pmc_hbm_traffic_{config}.csv")
+    if not os.path.exists(path):
         return None
     lines = open(path).read().splitlines()
-    if not any(("kernels_sha=" + kernels_sha()) in ln for ln in lines if ln.startswith("#")):
+    if not any(("kernels_sha=" + kernels_sha()) in ln for ln in lines if ln.startswith("#")) or not any(f"reads={n_reads}" in ln for ln in lines if ln.startswith("#")):
         return None
     total = None
     for t in timers:

@@ -1,51 +1,70 @@
 #!/bin/bash
 # Regenerates everything under profiles/ that bench.py and DESIGN.md quote (run on the GPU box through gpurun):
-#   bench lines for cfg3 (with cpu_baseline), cfg2, cfg5; rocprofv3 --kernel-trace --stats of the cfg3 bench command;
-#   the two PMC passes (FETCH_SIZE, WRITE_SIZE -- separately, as MI355X_MICROARCH.md prescribes) folded into one CSV.
-OUT=/root/repo/gpurun_out/refresh
+#   usage: scratch/refresh_profiles.sh r03
+#   bench lines for cfg3 (with cpu_baseline and parity_interior), cfg2, cfg5; rocprofv3 --kernel-trace --stats of the cfg3 and cfg5
+#   bench commands; the PMC passes (FETCH_SIZE, WRITE_SIZE -- separately, as MI355X_MICROARCH.md prescribes) folded into one CSV per
+#   configuration whose header carries the read count and the hash of the kernel sources (bench.py quotes the traffic only while both
+#   match); SQ counters per kernel of the cfg3 step; device-E2E through batched staging; file-E2E.
+TAG=${1:-r03}
+R=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$R/gpurun_out/refresh
 rm -rf $OUT; mkdir -p $OUT
-cd /root/repo
-timeout 900 python bench.py --steps 5 --warmup 2 > $OUT/r01_bench_cfg3_100M.json 2> $OUT/bench_cfg3.err
-timeout 600 python bench.py --steps 5 --warmup 2 --config cfg2 --no-cpu-baseline > $OUT/r01_bench_cfg2_10M.json 2> $OUT/bench_cfg2.err
-timeout 600 python bench.py --steps 5 --warmup 2 --config cfg5 --no-cpu-baseline > $OUT/r01_bench_cfg5_200k.json 2> $OUT/bench_cfg5.err
-cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python /root/repo/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/r01_bench_under_rocprofv3_cfg3_100M.json 2> $OUT/stats.err
-find $OUT/stats -name "*kernel_stats.csv" -exec cp {} $OUT/r01_rocprofv3_kernel_stats_cfg3_100M.csv \;
-for C in FETCH_SIZE WRITE_SIZE; do
-  timeout 600 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/$C -- python /root/repo/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $OUT/$C.log 2>&1
-done
-python - <<'PY'
-import csv, glob, collections, re
-out = "/root/repo/gpurun_out/refresh"
+export TMPDIR=/tmp
+pmc() {   # config reads
+  cd /tmp
+  for C in FETCH_SIZE WRITE_SIZE; do
+    timeout 600 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/$1_$C -- python $R/bench.py --config $1 --steps 1 --warmup 0 --no-cpu-baseline --no-checks > $OUT/$1_$C.log 2>&1
+  done
+  cd $R
+  CFG=$1 READS=$2 TAG=$TAG python - <<'PY'
+import csv, glob, collections, re, os, sys
+R = os.environ.get("GRAFT_REPO_ROOT", "/root/repo"); sys.path.insert(0, R)
+import bench
+cfg, reads, tag = os.environ["CFG"], os.environ["READS"], os.environ["TAG"]
+out = os.path.join(R, "gpurun_out", "refresh")
 vals = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     acc = collections.defaultdict(lambda: [0.0, 0])
-    for f in glob.glob(f"{out}/{c}/**/*counter_collection.csv", recursive=True):
+    for f in glob.glob(f"{out}/{cfg}_{c}/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] != c:
                 continue
             k = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "")
-            k = re.sub(r"\(.*", "", k).strip().replace(",", ";")      # template arguments stay: k4_tile has two instantiations per step
+            k = re.sub(r"\(.*", "", k).strip().replace(",", ";")
             acc[k][0] += float(r["Counter_Value"]); acc[k][1] += 1
     vals[c] = acc
-with open(f"{out}/r01_pmc_hbm_traffic_cfg3_100M.csv", "w") as w:
-    w.write("# rocprofv3 --kernel-trace --pmc FETCH_SIZE | --pmc WRITE_SIZE (separate passes), bench.py --steps 1 --warmup 0, cfg3 100M reads\n")
-    w.write("# units: KB per dispatch as reported; gfx950 FETCH_SIZE under-reports wide coalesced reads by 2x (MI355X_MICROARCH.md, HBM section)\n")
+path = f"{out}/{tag}_pmc_hbm_traffic_{cfg}.csv"
+with open(path, "w") as w:
+    w.write(f"# rocprofv3 --kernel-trace --pmc FETCH_SIZE | --pmc WRITE_SIZE (separate passes), bench.py --config {cfg} --steps 1 --warmup 0\n")
+    w.write("# units: KB per dispatch (mean over the kernel's dispatches: the run holds the set-up flush and one step); gfx950 FETCH_SIZE under-reports wide coalesced reads by 2x (MI355X_MICROARCH.md, HBM section)\n")
+    w.write(f"# reads={reads}\n# kernels_sha={bench.kernels_sha()}\n")
     w.write("kernel,FETCH_SIZE_KB_per_dispatch,WRITE_SIZE_KB_per_dispatch,dispatches,hbm_bytes_per_dispatch_corrected(2*FETCH+WRITE)*1024\n")
     for k in sorted(set(vals["FETCH_SIZE"]) | set(vals["WRITE_SIZE"])):
         f, nf = vals["FETCH_SIZE"].get(k, [0.0, 0]); wv, nw = vals["WRITE_SIZE"].get(k, [0.0, 0])
-        n = max(nf, nw, 1)
         fk, wk = f / max(nf, 1), wv / max(nw, 1)
-        w.write(f"{k},{fk:.0f},{wk:.0f},{n},{int((2 * fk + wk) * 1024)}\n")
-print(open(f"{out}/r01_pmc_hbm_traffic_cfg3_100M.csv").read())
+        w.write(f"{k},{fk:.0f},{wk:.0f},{max(nf, nw, 1)},{int((2 * fk + wk) * 1024)}\n")
+print(open(path).read())
 PY
-# file-E2E with both loaders (host zlib / k_inflate), and the same run under rocprofv3 for k_inflate's launch time
-cd /root/repo
-BGP_VERBOSE=1 timeout 600 python scratch/e2e_file.py 10000000 2>&1 | grep -v "framing round" > $OUT/r01_file_e2e_10M.log
+  cp $OUT/${TAG}_pmc_hbm_traffic_$1.csv $R/profiles/      # (on the box: the bench lines below quote it)
+  rm -rf $OUT/$1_FETCH_SIZE $OUT/$1_WRITE_SIZE
+}
+pmc cfg3 100000000
+pmc cfg5 200000
+pmc cfg2 10000000
+cd $R
+timeout 900 python bench.py --steps 20 --warmup 5 > $OUT/${TAG}_bench_cfg3_100M.json 2> $OUT/bench_cfg3.err
+timeout 600 python bench.py --steps 10 --warmup 3 --config cfg2 > $OUT/${TAG}_bench_cfg2_10M.json 2> $OUT/bench_cfg2.err
+timeout 600 python bench.py --steps 10 --warmup 3 --config cfg5 > $OUT/${TAG}_bench_cfg5_200k.json 2> $OUT/bench_cfg5.err
+BGP_BENCH_FORCE_COMM=1 timeout 600 python bench.py --steps 5 --warmup 2 --no-cpu-baseline 2> $OUT/bench_comm.err | grep "^{" | tail -1 > $OUT/${TAG}_bench_cfg3_100M_one_rank_communicator.json
 cd /tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/e2e -- python /root/repo/scratch/e2e_file.py 10000000 > /dev/null 2>&1
-find $OUT/e2e -name "*kernel_stats.csv" -exec cp {} $OUT/r01_rocprofv3_kernel_stats_file_e2e_10M.csv \;
-timeout 300 python /root/repo/scratch/bai_scale.py 4000000 > $OUT/r01_create_index_4M.log 2>&1
-rm -rf $OUT/stats $OUT/FETCH_SIZE $OUT/WRITE_SIZE $OUT/e2e
-cat $OUT/r01_bench_cfg3_100M.json | cut -c1-1200
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/${TAG}_bench_under_rocprofv3_cfg3_100M.json 2> $OUT/stats.err
+find $OUT/stats -name "*kernel_stats.csv" -exec cp {} $OUT/${TAG}_rocprofv3_kernel_stats_cfg3_100M.csv \;
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats5 -- python $R/bench.py --steps 3 --warmup 1 --config cfg5 --no-cpu-baseline > /dev/null 2> $OUT/stats5.err
+find $OUT/stats5 -name "*kernel_stats.csv" -exec cp {} $OUT/${TAG}_rocprofv3_kernel_stats_cfg5_200k.csv \;
+rm -rf $OUT/stats $OUT/stats5
+cd $R
+scratch/sq_pmc_k4.sh refresh_sq > /dev/null 2>&1; cp $R/gpurun_out/pmc_refresh_sq/summary.csv $OUT/${TAG}_pmc_sq_per_kernel_cfg3_100M.csv
+timeout 600 python scratch/e2e_batched.py 10000000 2>&1 | grep -v amdgpu.ids > $OUT/${TAG}_device_e2e_batched_10M.log
+BGP_VERBOSE=1 timeout 600 python scratch/e2e_file.py 10000000 2>&1 | grep -v "framing round\|amdgpu.ids" > $OUT/${TAG}_file_e2e_10M.log
+cut -c1-700 $OUT/${TAG}_bench_cfg3_100M.json; tail -6 $OUT/${TAG}_device_e2e_batched_10M.log
 ls -la $OUT
