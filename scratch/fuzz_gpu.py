@@ -28,6 +28,15 @@ for k in range(n):
         T.check_pileup(ctx, st, entries=False)
         for skip in (True, False):
             T._check_refbase(ctx, st, skip_zero=skip, window=int(rng.integers(50, 5000)))
+        for skip in (True, False):                 # use_md_tag across batches of random size == the whole-stream chain
+            try:
+                ora = O.pileup(st, use_md=True, skip_zero=skip)
+            except O.OracleError:
+                continue
+            ref, pos, rb = T._batched_refbase(ctx, T._pieces(st, int(rng.integers(1000, 50_000))), int(rng.integers(4096, 60_000)), skip)
+            keep = ora.cov > 0
+            assert np.array_equal(pos, ora.pos[keep].astype(np.int64)) and np.array_equal(rb, ora.refbase[keep]), ("batched md", skip)
+        T.stage(ctx, st)
         info = ctx.pileup_run()
         if len(info.runs):
             lo, hi = int(info.runs[0]["start_pos"]), int(info.runs[0]["end_pos"])
