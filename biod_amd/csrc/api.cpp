@@ -100,6 +100,8 @@ void bgp_timing_collect(bgp_ctx* c) {
     }
 }
 
+static uint64_t md_ref_index(const bgp_ctx* c, uint32_t run_idx, uint64_t pos) { return (run_idx < c->md_run_base.size() ? c->md_run_base[run_idx] : 0) + (pos - c->runs[run_idx].start_pos); }
+
 // columns [a, b) of run `run_idx` copied to the host (ctx-owned buffers), with entries / reference bases / SNP verdicts on request
 int emit_window(bgp_ctx* c, uint32_t run_idx, uint64_t a, uint64_t b, int want_entries, int use_md, int snp, bgp_columns* o) {
     const bgp_run& r = c->runs[run_idx];
@@ -119,17 +121,17 @@ int emit_window(bgp_ctx* c, uint32_t run_idx, uint64_t a, uint64_t b, int want_e
     }
     if (use_md) {
         BGP_TRY(c->h_refbase.reserve(np + 1));
-        BGP_HIP(hipMemcpyAsync(c->h_refbase.p, c->d_refbase.as<uint8_t>() + r.column_base + (a - r.start_pos), np, hipMemcpyDeviceToHost, c->stream));
+        BGP_HIP(hipMemcpyAsync(c->h_refbase.p, c->d_refbase.as<uint8_t>() + md_ref_index(c, run_idx, a), np, hipMemcpyDeviceToHost, c->stream));
         o->reference_base = c->h_refbase.as<uint8_t>();
     }
     if (use_md && snp) {
-        BGP_TRY(k7_snp_simple(c, r.column_base + (a - r.start_pos), np, c->it.snp_min_cov, c->it.snp_min_wit));
+        BGP_TRY(k7_snp_simple(c, r.column_base + (a - r.start_pos), md_ref_index(c, run_idx, a), np, c->it.snp_min_cov, c->it.snp_min_wit));
         BGP_TRY(c->h_snp.reserve(np + 1));
         BGP_HIP(hipMemcpyAsync(c->h_snp.p, c->d_snp.p, np, hipMemcpyDeviceToHost, c->stream));
         o->snp = c->h_snp.as<uint8_t>();
     }
     if (maq) {
-        BGP_TRY(k8_maq_calls(c, r.column_base + (a - r.start_pos), np, use_md));
+        BGP_TRY(k8_maq_calls(c, r.column_base + (a - r.start_pos), use_md ? md_ref_index(c, run_idx, a) : 0, np, use_md));
         BGP_TRY(c->h_maq.reserve((np + 1) * sizeof(bgp_maq_call)));
         BGP_HIP(hipMemcpyAsync(c->h_maq.p, c->d_maq.p, np * sizeof(bgp_maq_call), hipMemcpyDeviceToHost, c->stream));
         o->maq = c->h_maq.as<bgp_maq_call>();

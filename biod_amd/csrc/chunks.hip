@@ -95,9 +95,11 @@ int chunks_plan(bgp_ctx* c, uint64_t block_size, uint64_t start_from, uint64_t e
     if (n_changes > ch_cap) { c->last_error = "pileupChunks: more than 2^20 changes of ref_id along the reads"; return BGP_EINVAL; }
     std::vector<uint64_t> changes(n_changes);
     if (n_changes) {
-        BGP_HIP(hipMemcpy(changes.data(), d_changes, (size_t)n_changes * 8, hipMemcpyDeviceToHost));
+        BGP_HIP(hipMemcpyAsync(changes.data(), d_changes, (size_t)n_changes * 8, hipMemcpyDeviceToHost, c->stream));
+        BGP_HIP(hipStreamSynchronize(c->stream));
         std::sort(changes.begin(), changes.end());
-        BGP_HIP(hipMemcpy(d_changes, changes.data(), (size_t)n_changes * 8, hipMemcpyHostToDevice));
+        BGP_HIP(hipMemcpyAsync(d_changes, changes.data(), (size_t)n_changes * 8, hipMemcpyHostToDevice, c->stream));
+        BGP_HIP(hipStreamSynchronize(c->stream));
     }
     const uint64_t cap64 = c->stream_len / block_size + n_changes + 2;
     if (cap64 > (1ull << 22)) { c->last_error = "pileupChunks: block_size too small for this stream (more than 4 M chunks)"; return BGP_EINVAL; }   // the cut is a serial walk: a chunk is meant to be megabytes
@@ -119,7 +121,7 @@ int chunks_plan(bgp_ctx* c, uint64_t block_size, uint64_t start_from, uint64_t e
     if (n_chunks) hipLaunchKernelGGL(k_chunk_right_end, dim3(n_chunks), dim3(256), 0, c->stream, rec, d_chunks, c->d_pmax_end.as<uint64_t>());
     BGP_HIP(hipGetLastError());
     std::vector<ChunkDev> raw(n_chunks);
-    if (n_chunks) BGP_HIP(hipMemcpy(raw.data(), d_chunks, (size_t)n_chunks * sizeof(ChunkDev), hipMemcpyDeviceToHost));
+    if (n_chunks) { BGP_HIP(hipMemcpyAsync(raw.data(), d_chunks, (size_t)n_chunks * sizeof(ChunkDev), hipMemcpyDeviceToHost, c->stream)); BGP_HIP(hipStreamSynchronize(c->stream)); }      // (on the kernels' stream: it is a non-blocking one, a plain hipMemcpy would not wait for k_chunk_right_end)
 
     // the maximum end_position of the reference so far (covering reads): the runs' prefix maxima K3 left in HBM, picked up
     // by k_chunk_right_end with the chunks (one copy for all of them)

@@ -174,6 +174,7 @@ struct bgp_ctx {
     DevBuf d_md_long, d_md_ck;                                    // long chunks of the provider chain: node list + counters, checkpoints
     DevBuf d_md_succ, d_md_exit, d_md_entry, d_md_bmax;           // parallel provider chain: successor function, per-segment exits, segment entries
     bool md_rows_ready = false;
+    std::vector<uint64_t> md_run_base;                            // per run: index of its start_pos in d_refbase (dense over whole REFERENCES: the provider chain walks or jumps a reference's uncovered stretches, the runs between them are views of it)
 
     // batched staging (batch.cpp): streams larger than HBM, a batch at a time with the overlapping reads carried over
     struct Batch* batch = nullptr;
@@ -210,8 +211,8 @@ int k34_first_survivor(bgp_ctx* c, uint32_t run, uint64_t start_from, uint64_t* 
 int k5_entries(bgp_ctx* c, uint32_t run, uint64_t pos_begin, uint64_t pos_end, uint64_t* n_entries);  // pileup.hip : CSR for a window
 int scan_exclusive_u64(bgp_ctx* c, const uint64_t* in, uint64_t* out, uint64_t n, uint64_t* total_host);   // scan.hip (out has n+1 entries)
 int scan_inclusive_max_u64(bgp_ctx* c, const uint64_t* in, uint64_t* out, uint64_t n);
-int k7_snp_simple(bgp_ctx* c, uint64_t col_index, uint64_t np, int min_cov, int min_wit);    // md.hip: d_snp[0..np) from d_columns/d_refbase
-int k8_maq_calls(bgp_ctx* c, uint64_t col_index, uint64_t np, int use_md);                    // maq.hip: d_maq[0..np) from the window's entries (K5), the record table and d_refbase
+int k7_snp_simple(bgp_ctx* c, uint64_t col_index, uint64_t ref_index, uint64_t np, int min_cov, int min_wit);    // md.hip: d_snp[0..np) from d_columns/d_refbase
+int k8_maq_calls(bgp_ctx* c, uint64_t col_index, uint64_t ref_index, uint64_t np, int use_md);                    // maq.hip: d_maq[0..np) from the window's entries (K5), the record table and d_refbase
 int k6_dna_of_record(bgp_ctx* c, uint64_t i, uint8_t* host_out, uint32_t cap, uint32_t* len, uint32_t* flags);
 struct K6Batch {                  // batched staging: the provider chain's state across the seam between two batches (md.hip: k6_chain)
     uint32_t in_have = 0, in_ci = 0, in_y = 0, in_ce = 0; uint64_t in_P = 0, in_i = 0;      // resume the first run from this state (record indices of THIS batch) | chunk_end_position carried in

@@ -322,7 +322,7 @@ static void maq_build_tables(double depcorr, double eta, std::vector<double>& fk
 }
 
 // d_maq[0 .. np) for the columns [col_index, col_index + np) of the window whose entries K5 has just made
-int k8_maq_calls(bgp_ctx* c, uint64_t col_index, uint64_t np, int use_md) {
+int k8_maq_calls(bgp_ctx* c, uint64_t col_index, uint64_t ref_index, uint64_t np, int use_md) {
     if (!c->maq_tables_ready || c->maq_tab_depcorr != c->it.maq_depcorr || c->maq_tab_eta != c->it.maq_eta) {
         std::vector<double> fk, beta, lhet;
         maq_build_tables((double)c->it.maq_depcorr, (double)c->it.maq_eta, fk, beta, lhet);         // (the caller's floats widened: MaqSnpCaller keeps float _depcorr, _eta, :329-330,320)
@@ -338,7 +338,7 @@ int k8_maq_calls(bgp_ctx* c, uint64_t col_index, uint64_t np, int use_md) {
     if (!np) return BGP_OK;
     MaqArgs a;
     a.entries = c->d_entries.as<bgp_entry>(); a.entry_off = c->d_entry_off.as<uint64_t>(); a.rec = c->d_rec.as<bgp_record>();
-    a.refbase = use_md ? c->d_refbase.as<uint8_t>() + col_index : nullptr; a.np = np;
+    a.refbase = use_md ? c->d_refbase.as<uint8_t>() + ref_index : nullptr; a.np = np;
     const double* d = c->d_maq_tab.as<double>();
     a.fk = d; a.lhet = d + 256; a.beta = d + 256 + 65536; a.min_bq = c->it.maq_min_bq;
     a.out = c->d_maq.as<bgp_maq_call>();

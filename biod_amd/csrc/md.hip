@@ -972,10 +972,10 @@ __global__ void k6_dna_one(const uint8_t* s, const bgp_record* rec, uint64_t i, 
 
 }  // namespace
 
-int k7_snp_simple(bgp_ctx* c, uint64_t col_index, uint64_t np, int min_cov, int min_wit) {
+int k7_snp_simple(bgp_ctx* c, uint64_t col_index, uint64_t ref_index, uint64_t np, int min_cov, int min_wit) {
     BGP_TRY(c->d_snp.reserve(np + 16));
     if (!np) return BGP_OK;
-    hipLaunchKernelGGL(k7_snp, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, c->stream, c->d_columns.as<bgp_column>() + col_index, c->d_refbase.as<uint8_t>() + col_index, np,
+    hipLaunchKernelGGL(k7_snp, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, c->stream, c->d_columns.as<bgp_column>() + col_index, c->d_refbase.as<uint8_t>() + ref_index, np,
                        (long long)min_cov, min_wit, c->d_snp.as<uint8_t>());
     BGP_HIP(hipGetLastError());
     return BGP_OK;
@@ -1030,21 +1030,42 @@ int k6_reference_bases(bgp_ctx* c, int skip_zero, uint32_t run_first, uint32_t r
     if (bt) { bt->out_have = 0; bt->out_ce = bt->in_ce; }
     if (c->n_records >= 0xFFFFFFF0ull) { c->last_error = "too many records for the MD path"; return BGP_EINVAL; }
     BGP_TRY(k6_rows(c));
-    const uint64_t n_pos = c->pinfo.n_positions;
+    // The chain runs over whole REFERENCES: PileupRangeUsingMdTag keeps its chunk across a reference's uncovered stretches (it
+    // walks them, or jumps and lets "the old chunk simply go on"), so the runs K3 cut at such stretches are put together again here
+    // -- `mr` -- and d_refbase is dense over every reference's [first position, largest end) (a byte a position: 2 GB at worst);
+    // c->md_run_base says where a run's first position lies in it.
+    struct MRun { int32_t ref_id; uint64_t first_record, end_record, start_pos, end_pos, column_base; };
+    std::vector<MRun> mr;
+    c->md_run_base.assign(c->runs.size(), 0);
+    uint64_t n_pos = 0;
+    for (uint32_t j = run_first; j < run_end; ++j) {
+        const bgp_run& r = c->runs[j];
+        if (mr.empty() || mr.back().ref_id != r.ref_id) { mr.push_back(MRun{r.ref_id, r.first_record, r.end_record, r.start_pos, r.end_pos, n_pos}); }
+        else { n_pos -= mr.back().end_pos - mr.back().start_pos; mr.back().end_record = r.end_record; mr.back().end_pos = r.end_pos; }
+        n_pos += mr.back().end_pos - mr.back().start_pos;
+    }
+    {
+        size_t k = 0;
+        for (uint32_t j = run_first; j < run_end; ++j) {
+            while (mr[k].ref_id != c->runs[j].ref_id || c->runs[j].first_record >= mr[k].end_record) ++k;
+            c->md_run_base[j] = mr[k].column_base + (c->runs[j].start_pos - mr[k].start_pos);
+        }
+    }
+    if (n_pos > (16ull << 30)) { c->last_error = "use_md_tag: the references' spans add up to more than 16 G positions"; return BGP_ENOMEM; }
     BGP_TRY(c->d_refbase.reserve(n_pos + 16));
     if (n_pos) BGP_HIP(hipMemsetAsync(c->d_refbase.p, 'N', n_pos, c->stream));
-    const uint32_t nr = run_end > run_first ? run_end - run_first : 0;
+    const uint32_t nr = (uint32_t)mr.size();
     if (nr == 0) return BGP_OK;
     std::vector<ChainRun> cr(nr);
     std::vector<ChainOut> co(nr);
     std::vector<ParRun> pr(nr);
     std::vector<EmitRun> er(nr);
     for (uint32_t k = 0; k < nr; ++k) {
-        const bgp_run& r = c->runs[run_first + k];
+        const MRun& r = mr[k];
         ChainRun& x = cr[k];
         x.first = (k == 0 && first_record != ~0ull) ? first_record : r.first_record;
         x.endrec = r.end_record; x.iv_base = x.first + 2ull * k; x.run_end = (uint32_t)r.end_pos;
-        x.ce_in = k == 0 ? (bt ? bt->in_ce : 0u) : (uint32_t)c->runs[run_first + k - 1].end_pos;
+        x.ce_in = k == 0 ? (bt ? bt->in_ce : 0u) : (uint32_t)mr[k - 1].end_pos;
         x.active = 0; x.pad = 0; x.resume = 0; x.rs_P = 0; x.rs_i = 0; x.rs_ci = 0; x.rs_y = 0; x.stop_at = 0;
         if (bt && k == 0 && bt->in_have) { x.resume = 1; x.rs_P = bt->in_P; x.rs_i = bt->in_i; x.rs_ci = bt->in_ci; x.rs_y = bt->in_y; }
         if (bt && k + 1 == nr) x.stop_at = bt->stop_at;
@@ -1080,7 +1101,7 @@ int k6_reference_bases(bgp_ctx* c, int skip_zero, uint32_t run_first, uint32_t r
     // (re)solve the runs in `ks` under their current carried-in chunk_end
     auto solve = [&](const std::vector<uint32_t>& ks, bool clear) -> int {
         std::vector<uint32_t> seq;
-        if (clear) for (uint32_t k : ks) { const bgp_run& r = c->runs[run_first + k]; if (r.end_pos > r.start_pos) BGP_HIP(hipMemsetAsync(c->d_refbase.as<uint8_t>() + r.column_base, 'N', r.end_pos - r.start_pos, c->stream)); }
+        if (clear) for (uint32_t k : ks) { const MRun& r = mr[k]; if (r.end_pos > r.start_pos) BGP_HIP(hipMemsetAsync(c->d_refbase.as<uint8_t>() + r.column_base, 'N', r.end_pos - r.start_pos, c->stream)); }
         if (use_par) {
             for (uint32_t k = 0; k < nr; ++k) pr[k].active = 0;
             for (uint32_t k : ks) { pr[k].active = 1; pr[k].ce_in = cr[k].ce_in; }
@@ -1096,7 +1117,7 @@ int k6_reference_bases(bgp_ctx* c, int skip_zero, uint32_t run_first, uint32_t r
             }
             for (uint32_t k : ks) {
                 const uint64_t lo = cr[k].first / SEG + k, hi = (cr[k].endrec ? (cr[k].endrec - 1) / SEG : 0) + k + 1;
-                TimedRegion t(c, "k6_emit", c->runs[run_first + k].end_pos - c->runs[run_first + k].start_pos);
+                TimedRegion t(c, "k6_emit", mr[k].end_pos - mr[k].start_pos);
                 hipLaunchKernelGGL(k6_emit, dim3((unsigned)(hi - lo)), dim3(64), 0, c->stream, c->d_stream, c->d_rec.as<bgp_record>(), c->d_md_row.as<MdRow>(), c->d_md_succ.as<Succ>(),
                                    c->d_md_entry.as<Succ>(), lo, hi - lo, (const EmitRun*)(st + off_er), nr, (ParOut*)(st + off_po), c->d_refbase.as<uint8_t>(),
                                    (LongNode*)(c->d_md_long.as<uint8_t>() + 16), longs_cap, c->d_md_long.as<unsigned int>());
@@ -1124,7 +1145,7 @@ int k6_reference_bases(bgp_ctx* c, int skip_zero, uint32_t run_first, uint32_t r
             }
             if (getenv("BGP_VERBOSE")) fprintf(stderr, "[biodgpu] MD chain: %zu run(s) composed, %zu redone by the event loop\n", ks.size() - seq.size(), seq.size());
             if (getenv("BGP_VERBOSE") && nr <= 16) for (uint32_t k : ks) fprintf(stderr, "[biodgpu]   run %u: first %llu endrec %llu ce_in %u -> ce_out %u flagged %u nodes %u\n", k, (unsigned long long)cr[k].first, (unsigned long long)cr[k].endrec, cr[k].ce_in, po[k].ce_out, po[k].flagged, po[k].n_nodes);
-            for (uint32_t k : seq) { const bgp_run& r = c->runs[run_first + k]; if (r.end_pos > r.start_pos) BGP_HIP(hipMemsetAsync(c->d_refbase.as<uint8_t>() + r.column_base, 'N', r.end_pos - r.start_pos, c->stream)); }
+            for (uint32_t k : seq) { const MRun& r = mr[k]; if (r.end_pos > r.start_pos) BGP_HIP(hipMemsetAsync(c->d_refbase.as<uint8_t>() + r.column_base, 'N', r.end_pos - r.start_pos, c->stream)); }
         } else seq = ks;
         if (seq.empty()) return BGP_OK;
         for (uint32_t k = 0; k < nr; ++k) cr[k].active = 0;
@@ -1142,7 +1163,7 @@ int k6_reference_bases(bgp_ctx* c, int skip_zero, uint32_t run_first, uint32_t r
         std::vector<FillRun> fr;
         for (uint32_t k : seq) {
             co[k] = got[k];
-            const bgp_run& r = c->runs[run_first + k];
+            const MRun& r = mr[k];
             fr.push_back(FillRun{cr[k].iv_base, total, r.column_base, (uint32_t)r.start_pos, (uint32_t)r.end_pos, co[k].n_iv, 0u});
             total += co[k].n_iv;
         }
@@ -1168,7 +1189,10 @@ int k6_reference_bases(bgp_ctx* c, int skip_zero, uint32_t run_first, uint32_t r
         if (redo == nr) break;
         BGP_TRY(solve(std::vector<uint32_t>{redo}, true));
     }
-    for (uint32_t k = 0; k < nr; ++k) if (co[k].err) { *md_err = co[k].err; *md_err_from = co[k].err_from; break; }
+    for (uint32_t k = 0; k < nr; ++k) if (co[k].err) {
+        *md_err = co[k].err; *md_err_from = co[k].err_from;
+        break;
+    }
     if (bt) {
         const ChainOut& last = co[nr - 1];
         bt->out_have = last.sv_have; bt->out_P = last.sv_P; bt->out_i = last.sv_i; bt->out_ci = last.sv_ci; bt->out_y = last.sv_y;

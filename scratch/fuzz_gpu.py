@@ -3,6 +3,7 @@ device vs oracle.  usage: python scratch/fuzz_gpu.py [n_rounds] [seed0]"""
 import sys, time
 sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests'); sys.path.insert(0, '/root/repo/oracle')
 import numpy as np
+import pytest
 import oracle_lib as O
 import test_gpu_parity as T
 from biod_amd import _lib as L
@@ -10,9 +11,10 @@ from biod_amd.pileup import Context
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 50_000
+k0 = int(sys.argv[3]) if len(sys.argv) > 3 else 0          # (replay: round k0 of an earlier run)
 ctx = Context(0)
 t0 = time.time(); bad = 0
-for k in range(n):
+for k in range(k0, k0 + n):
     rng = np.random.default_rng(seed0 + k)
     try:
         st = T._random_stream(rng, int(rng.integers(50, 3000)), quirks=bool(k % 2))
@@ -67,7 +69,9 @@ for k in range(n):
         path = os.path.join(tempfile.gettempdir(), "fuzz_index.bam")
         T._write_bgzf(path, bamio.bam_header_bytes([(f"c{i}", 1 << 29) for i in range(n_ref)]) + b"".join(recs), rng, eof=bool(k % 3), small=(k % 5 == 0))
         T._check_created_index(path)
-    except Exception as e:          # noqa
+    except (Exception, pytest.fail.Exception) as e:          # noqa
         bad += 1
         print('MISMATCH at seed', seed0 + k, type(e).__name__, str(e)[:300], flush=True)
+        if n == 1:
+            import traceback; traceback.print_exc()
 print(f'{n} rounds, {bad} failures, {time.time() - t0:.1f} s')
