@@ -252,9 +252,12 @@ __global__ __launch_bounds__(256) void k4_bounds(const uint64_t* pmax_end, const
 // (op index, columns before it, query bases before it) of the op that owns the window's first column.
 struct Ckpt { uint32_t k, cs, qs, pad; };
 
-__device__ __forceinline__ uint32_t wave_incl_u32(uint32_t v, int lane) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(v, d, 64); if (lane >= d) v += o; }
+// inclusive prefix sum over the 64 lanes with DPP: shifts inside the rows of 16, then the rows' totals carried over (six instructions;
+// with __shfl_up it was eighteen, and the long reads' walk and row writer do three of these per chunk of 64 ops)
+#define BGP_DPP(v, ctrl, rmask) (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), ctrl, rmask, 0xF, false)
+__device__ __forceinline__ uint32_t wave_incl_u32(uint32_t v, int) {
+    v += BGP_DPP(v, 0x111, 0xF); v += BGP_DPP(v, 0x112, 0xF); v += BGP_DPP(v, 0x114, 0xF); v += BGP_DPP(v, 0x118, 0xF);
+    v += BGP_DPP(v, 0x142, 0xA); v += BGP_DPP(v, 0x143, 0xC);
     return v;
 }
 
@@ -320,11 +323,18 @@ template <bool WPR> __global__ __launch_bounds__(256) void k4_ck_build(const uin
         // read's first column is a base of it: no leading N, D), no zero-length reference-consuming op, no M base past SEQ
         bool plain = true;
         const uint32_t l_seq_r = (uint32_t)__shfl(r.l_seq, src, 64);
-        uint32_t op_next = (uint32_t)lane < n_cig ? ld_u32(cg + 4ull * lane) : 0u;
+        // The walk is a chain of chunks per read, and a chunk's scan is a fraction of a microsecond: with ONE chunk of ops on its way
+        // while the current one is scanned every step waited out an HBM round trip (cfg5: 2.6 ms for 6 M steps).  Four chunks ahead.
+        constexpr int CK_AHEAD = 4;
+        uint32_t opq[CK_AHEAD];
+#pragma unroll
+        for (int q = 0; q < CK_AHEAD; ++q) opq[q] = 64u * q + (uint32_t)lane < n_cig ? ld_u32(cg + 4ull * (64u * q + lane)) : 0u;
         for (uint32_t c0 = 0; c0 < n_cig && cs < covered; c0 += 64) {
             const bool active = c0 + lane < n_cig;
-            const uint32_t op = op_next;
-            op_next = c0 + 64 + lane < n_cig ? ld_u32(cg + 4ull * (c0 + 64 + lane)) : 0u;      // (the next chunk's ops are on their way while this one is scanned)
+            const uint32_t op = opq[0];
+#pragma unroll
+            for (int q = 0; q + 1 < CK_AHEAD; ++q) opq[q] = opq[q + 1];
+            opq[CK_AHEAD - 1] = c0 + 64u * CK_AHEAD + lane < n_cig ? ld_u32(cg + 4ull * (c0 + 64u * CK_AHEAD + lane)) : 0u;
             // the first reference-consuming non-N op starts the cursor (pileup.d:180-189)
             int fl = 64;
             if (!started) {
@@ -1231,7 +1241,6 @@ struct GArgs {
 };
 
 // sum / max over the 64 lanes of a wave with DPP (row reductions, then row_bcast15 / row_bcast31); result in every lane
-#define BGP_DPP(v, ctrl, rmask) (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), ctrl, rmask, 0xF, false)
 __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
     v += BGP_DPP(v, 0xB1, 0xF); v += BGP_DPP(v, 0x4E, 0xF); v += BGP_DPP(v, 0x141, 0xF); v += BGP_DPP(v, 0x140, 0xF);
     v += BGP_DPP(v, 0x142, 0xA); v += BGP_DPP(v, 0x143, 0xC);
