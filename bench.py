@@ -204,6 +204,11 @@ def main():
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         spawn_ranks(a.gpus)
     rank = int(os.environ.get("RANK", "0")); local = int(os.environ.get("LOCAL_RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    # The result is ONE line on stdout.  Native libraries print there too (RCCL's version banner goes to the C stdout, which is
+    # flushed at exit -- after the JSON line): file descriptor 1 is pointed at stderr for everything but that line.
+    sys.stdout.flush()
+    result_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     if world != a.gpus:
         sys.exit(f"bench.py: --gpus {a.gpus} but the launcher started {world} rank(s); start it as `python bench.py --gpus N` "
                  f"or under torch.distributed.run with --nproc-per-node equal to --gpus")
@@ -360,7 +365,7 @@ def main():
             out["parity_interior"] = oracle_interior_check(ctx, cfg, a.config, info, torch, dev)
             out["cpu_baseline"] = cpu_baseline(a.config, a.cpu_sample_reads)
             out["speedup_vs_cpu_baseline"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=result_out, flush=True)
         if (checks is not None and not checks["ok"]) or hist_ok is False or ("parity_interior" in out and not out["parity_interior"]["all_equal"]):
             sys.stderr.write("bench.py: a result check FAILED (see checks_full_size / hist_reduce_equals_sum_of_ranks / parity_interior)\n")
             ctx.close()

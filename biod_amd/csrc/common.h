@@ -130,7 +130,7 @@ struct bgp_ctx {
     bool frame_tolerant_tail = false; uint64_t frame_tail = 0;   // batched staging (batch.cpp): a stream may end inside a record; where the record chain stopped
     bool table_compacted = false;                     // a region filter compacted the record table: records the filter dropped still lie between the kept ones in the stream
     bool table_pending = false, long_cigar = false;   // the record table is written lazily: by k1_table, or by the fused K1+K2 if a decode comes first
-    DevBuf d_scan_tmp;
+    DevBuf d_scan_tmp; HostBuf h_mail;                // (h_mail: pinned, written by k_mail)
     DevBuf d_sd_desc; int sd_timer_idx = -1;         // single-pass decode (decode.hip: k_stream_decode): control words + one 64-byte descriptor per chunk
     DevBuf d_status;                                  // uint32 status bits + counters
     bool flushed = false;
@@ -211,6 +211,9 @@ int k34_first_survivor(bgp_ctx* c, uint32_t run, uint64_t start_from, uint64_t* 
 int k5_entries(bgp_ctx* c, uint32_t run, uint64_t pos_begin, uint64_t pos_end, uint64_t* n_entries);  // pileup.hip : CSR for a window
 int scan_exclusive_u64(bgp_ctx* c, const uint64_t* in, uint64_t* out, uint64_t n, uint64_t* total_host);   // scan.hip (out has n+1 entries)
 int scan_inclusive_max_u64(bgp_ctx* c, const uint64_t* in, uint64_t* out, uint64_t n);
+int scan_exclusive_u64x3(bgp_ctx* c, const uint64_t* const in[3], uint64_t* const out[3], uint64_t n, uint64_t* totals_host /* [3] or null */);   // three scans, three launches
+struct MailItem { const void* src; void* dst; uint32_t n; };
+int mail_fetch(bgp_ctx* c, const MailItem* items, int n_items);   // scan.hip: up to 8 small values from device memory with one kernel and one wait (0 items: just the wait)
 int k7_snp_simple(bgp_ctx* c, uint64_t col_index, uint64_t ref_index, uint64_t np, int min_cov, int min_wit);    // md.hip: d_snp[0..np) from d_columns/d_refbase
 int k8_maq_calls(bgp_ctx* c, uint64_t col_index, uint64_t ref_index, uint64_t np, int use_md);                    // maq.hip: d_maq[0..np) from the window's entries (K5), the record table and d_refbase
 int k6_dna_of_record(bgp_ctx* c, uint64_t i, uint8_t* host_out, uint32_t cap, uint32_t* len, uint32_t* flags);

@@ -326,8 +326,7 @@ int k0_frame(bgp_ctx* c) {
     }
     // segment size: ~8 average records, from the first record's size (any value is correct)
     uint32_t bs0 = 0;
-    BGP_HIP(hipMemcpyAsync(&bs0, c->d_stream, 4, hipMemcpyDeviceToHost, c->stream));
-    BGP_HIP(hipStreamSynchronize(c->stream));
+    { const MailItem it{c->d_stream, &bs0, 4}; BGP_TRY(mail_fetch(c, &it, 1)); }
     // ~64 records per segment: k0_guess costs one wave per segment, the chase is a per-lane serial chain per
     // segment that is bound by line fetches, not by its length (measured on cfg3, guess / chase / step: 8 records
     // 7.4 / 1.2 ms; 32: 1.87 / 1.58 / 43.8 ms; 64: 0.94 / 1.60 / 42.5 ms; 128: 0.48 / 1.66 / 43.0 ms)
@@ -402,8 +401,7 @@ int k0_frame(bgp_ctx* c) {
         BGP_HIP(hipMemsetAsync(a.status + 1, 0, 4, c->stream));
         hipLaunchKernelGGL(k0_verify, dim3(lane_blocks), dim3(256), 0, c->stream, a);
         uint32_t ndirty = 0;
-        BGP_HIP(hipMemcpyAsync(&ndirty, a.status + 1, 4, hipMemcpyDeviceToHost, c->stream));
-        BGP_HIP(hipStreamSynchronize(c->stream));
+        { const MailItem it{a.status + 1, &ndirty, 4}; BGP_TRY(mail_fetch(c, &it, 1)); }
         if (getenv("BGP_VERBOSE") && rounds < 8) fprintf(stderr, "[biodgpu] framing round %llu: %u of %llu segments re-entered (seg %u B)\n", (unsigned long long)rounds, ndirty, (unsigned long long)n_seg, seg);
         if (ndirty == 0) break;
         if (++rounds > n_seg + 2) { c->last_error = "record framing did not converge"; return BGP_EDEVICE; }
@@ -413,16 +411,19 @@ int k0_frame(bgp_ctx* c) {
     hipLaunchKernelGGL(k0_collect_errors, dim3(lane_blocks), dim3(256), 0, c->stream, a);
     uint32_t bits = 0;
     uint64_t n = 0, sl = 0, sc = 0;
-    BGP_HIP(hipMemcpyAsync(&bits, a.status, 4, hipMemcpyDeviceToHost, c->stream));
-    BGP_TRY(scan_exclusive_u64(c, a.cnt, c->d_seg_rec_base.as<uint64_t>(), n_seg, nullptr));
-    BGP_TRY(scan_exclusive_u64(c, a.lseq, c->d_seg_seq_base.as<uint64_t>(), n_seg, nullptr));
-    BGP_TRY(scan_exclusive_u64(c, a.ncig, c->d_seg_cig_base.as<uint64_t>(), n_seg, nullptr));
-    BGP_HIP(hipMemcpyAsync(&n, c->d_seg_rec_base.as<uint64_t>() + n_seg, 8, hipMemcpyDeviceToHost, c->stream));
-    BGP_HIP(hipMemcpyAsync(&sl, c->d_seg_seq_base.as<uint64_t>() + n_seg, 8, hipMemcpyDeviceToHost, c->stream));
-    BGP_HIP(hipMemcpyAsync(&sc, c->d_seg_cig_base.as<uint64_t>() + n_seg, 8, hipMemcpyDeviceToHost, c->stream));
+    {
+        const uint64_t* const in[3] = {a.cnt, a.lseq, a.ncig};
+        uint64_t* const out[3] = {c->d_seg_rec_base.as<uint64_t>(), c->d_seg_seq_base.as<uint64_t>(), c->d_seg_cig_base.as<uint64_t>()};
+        BGP_TRY(scan_exclusive_u64x3(c, in, out, n_seg, nullptr));
+    }
     c->frame_tail = len;
-    if (c->frame_tolerant_tail) BGP_HIP(hipMemcpyAsync(&c->frame_tail, a.end + (n_seg - 1), 8, hipMemcpyDeviceToHost, c->stream));      // where the chain of records stopped: the bytes behind it belong to the next batch
-    BGP_HIP(hipStreamSynchronize(c->stream));
+    uint64_t tail = len;
+    {   // (where the chain of records stopped: in a batch the bytes behind it belong to the next one)
+        const MailItem it[5] = {{a.status, &bits, 4}, {c->d_seg_rec_base.as<uint64_t>() + n_seg, &n, 8}, {c->d_seg_seq_base.as<uint64_t>() + n_seg, &sl, 8},
+                                {c->d_seg_cig_base.as<uint64_t>() + n_seg, &sc, 8}, {a.end + (n_seg - 1), &tail, 8}};
+        BGP_TRY(mail_fetch(c, it, 5));
+    }
+    if (c->frame_tolerant_tail) c->frame_tail = tail;
     const int st = bgp_status_from_bits(bits);
     if (st < 0 && st != BGP_ESEQ) return st;
     c->n_records = n; c->sum_lseq = sl; c->sum_ncig = sc;

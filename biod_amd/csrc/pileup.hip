@@ -206,6 +206,37 @@ __global__ void k3_run_ends(RunDev* runs, uint32_t n_runs, const uint64_t* pmax_
     runs[j].end_pos = (uint64_t)(uint32_t)pmax_end[last];
 }
 
+// The run table finished on the device when it is small (nearly always: a run per reference and per island of coverage): the runs
+// in file order, where each one ends, its columns and windows in front of it -- the host did this between three round trips
+// (table down, sorted table up, ends down, bases up: ~0.15 ms of a 4.5 ms step on an eighth of cfg3).
+constexpr uint32_t RUNS_ON_DEVICE = 1024;
+__global__ __launch_bounds__(1024) void k3_finish(RunDev* runs, const uint32_t* status, uint32_t run_cap, const uint64_t* pmax_end, uint64_t n, uint32_t w) {
+    __shared__ uint64_t s_first[RUNS_ON_DEVICE], s_span[RUNS_ON_DEVICE];
+    const uint32_t n_runs = status[2];
+    if (n_runs == 0 || n_runs > RUNS_ON_DEVICE || n_runs > run_cap) return;       // (the host's own loop takes a larger table)
+    const uint32_t j = threadIdx.x;
+    RunDev my{};
+    if (j < n_runs) { my = runs[j]; s_first[j] = my.first_record; }
+    __syncthreads();
+    uint32_t rank = 0;
+    if (j < n_runs) for (uint32_t k = 0; k < n_runs; ++k) rank += s_first[k] < my.first_record ? 1u : 0u;
+    __syncthreads();
+    if (j < n_runs) s_first[rank] = my.first_record;
+    __syncthreads();
+    if (j < n_runs) {
+        my.end_record = rank + 1 < n_runs ? s_first[rank + 1] : n;
+        my.end_pos = (uint64_t)(uint32_t)pmax_end[my.end_record - 1];
+        s_span[rank] = my.end_pos - my.start_pos;
+    }
+    __syncthreads();
+    if (j < n_runs) {
+        uint64_t cb = 0, tb = 0;
+        for (uint32_t k = 0; k < rank; ++k) { cb += s_span[k]; tb += (s_span[k] + w - 1) / w; }
+        my.column_base = cb; my.tile_base = tb;
+        runs[rank] = my;
+    }
+}
+
 struct K4Args {
     const uint8_t* s; const bgp_record* rec; const uint64_t* pmax_end; const uint64_t* pmax_pos;
     const RunDev* runs; uint32_t n_runs; uint64_t n_tiles; uint64_t stream_len;
@@ -1793,6 +1824,8 @@ int k34_pileup(bgp_ctx* c) {
     const unsigned nb = (unsigned)((n + 255) / 256);
     uint32_t* status = c->d_status.as<uint32_t>();
     uint32_t st[4] = {0, 0, 0, 0};
+    constexpr uint32_t FIRST_RUNS = 16;
+    RunDev first_runs[FIRST_RUNS];
     int rc = BGP_OK;
     for (uint32_t run_cap = std::max<uint32_t>(RUNS_FIRST, (uint32_t)(c->d_runs.cap / sizeof(RunDev)));;) {
         BGP_TRY(c->d_runs.reserve(sizeof(RunDev) * (size_t)run_cap));
@@ -1810,8 +1843,8 @@ int k34_pileup(bgp_ctx* c) {
             hipLaunchKernelGGL(k3_bsum, dim3(1), dim3(K3_T), 0, c->stream, bsum, nt);
             hipLaunchKernelGGL(k3_down, dim3((unsigned)nt), dim3(K3_T), 0, c->stream, a, bsum, c->d_runs.as<RunDev>());
         }
-        BGP_HIP(hipMemcpyAsync(st, status, 16, hipMemcpyDeviceToHost, c->stream));
-        BGP_HIP(hipStreamSynchronize(c->stream));
+        hipLaunchKernelGGL(k3_finish, dim3(1), dim3(1024), 0, c->stream, c->d_runs.as<RunDev>(), status, run_cap, c->d_pmax_end.as<uint64_t>(), n, (uint32_t)W);
+        { const MailItem it[2] = {{status, st, 16}, {c->d_runs.p, first_runs, sizeof first_runs}}; BGP_TRY(mail_fetch(c, it, 2)); }      // (the table has room for RUNS_FIRST entries at least)
         rc = bgp_status_from_bits(st[0]);
         if (rc < 0 && rc != BGP_ESEQ) return rc;
         if (st[2] <= run_cap) break;
@@ -1820,10 +1853,14 @@ int k34_pileup(bgp_ctx* c) {
     }
     const uint32_t n_runs = st[2];
     std::vector<RunDev> runs(n_runs);
-    if (n_runs) BGP_HIP(hipMemcpy(runs.data(), c->d_runs.p, sizeof(RunDev) * n_runs, hipMemcpyDeviceToHost));
-    std::sort(runs.begin(), runs.end(), [](const RunDev& x, const RunDev& y) { return x.first_record < y.first_record; });
-    for (uint32_t j = 0; j < n_runs; ++j) runs[j].end_record = j + 1 < n_runs ? runs[j + 1].first_record : n;
-    if (n_runs) {
+    const bool finished_on_device = n_runs <= RUNS_ON_DEVICE;
+    if (finished_on_device) {                                  // k3_finish left the table sorted and complete
+        if (n_runs <= FIRST_RUNS) memcpy(runs.data(), first_runs, sizeof(RunDev) * n_runs);
+        else BGP_HIP(hipMemcpy(runs.data(), c->d_runs.p, sizeof(RunDev) * n_runs, hipMemcpyDeviceToHost));
+    } else {                                                   // (a table of more than RUNS_ON_DEVICE runs: by the host)
+        BGP_HIP(hipMemcpy(runs.data(), c->d_runs.p, sizeof(RunDev) * n_runs, hipMemcpyDeviceToHost));
+        std::sort(runs.begin(), runs.end(), [](const RunDev& x, const RunDev& y) { return x.first_record < y.first_record; });
+        for (uint32_t j = 0; j < n_runs; ++j) runs[j].end_record = j + 1 < n_runs ? runs[j + 1].first_record : n;
         BGP_HIP(hipMemcpyAsync(c->d_runs.p, runs.data(), sizeof(RunDev) * n_runs, hipMemcpyHostToDevice, c->stream));
         hipLaunchKernelGGL(k3_run_ends, dim3((n_runs + 63) / 64), dim3(64), 0, c->stream, c->d_runs.as<RunDev>(), n_runs, c->d_pmax_end.as<uint64_t>(), n);
         BGP_HIP(hipMemcpyAsync(runs.data(), c->d_runs.p, sizeof(RunDev) * n_runs, hipMemcpyDeviceToHost, c->stream));
@@ -1867,7 +1904,7 @@ int k34_pileup(bgp_ctx* c) {
     }
     BGP_TRY(c->d_columns.reserve((col_base + 1) * sizeof(bgp_column)));
     if (n_runs) {
-        BGP_HIP(hipMemcpyAsync(c->d_runs.p, runs.data(), sizeof(RunDev) * n_runs, hipMemcpyHostToDevice, c->stream));
+        if (!finished_on_device || tw != (uint32_t)W) BGP_HIP(hipMemcpyAsync(c->d_runs.p, runs.data(), sizeof(RunDev) * n_runs, hipMemcpyHostToDevice, c->stream));      // (k3_finish wrote the same bases)
         K4Args a;
         a.s = c->d_stream; a.rec = c->d_rec.as<bgp_record>(); a.pmax_end = c->d_pmax_end.as<uint64_t>(); a.pmax_pos = c->d_pmax_pos.as<uint64_t>();
         a.runs = c->d_runs.as<RunDev>(); a.n_runs = n_runs; a.n_tiles = tile_base; a.stream_len = c->stream_len;
@@ -1900,10 +1937,13 @@ int k34_pileup(bgp_ctx* c) {
             if (rows) { BGP_TRY(c->d_row_off.reserve((n + 2) * 8)); BGP_TRY(c->d_chunk_off.reserve((n + 2) * 8)); row_off = c->d_row_off.as<uint64_t>(); chunk_off = c->d_chunk_off.as<uint64_t>(); }
             hipLaunchKernelGGL(k4_ck_count, dim3(nb), dim3(256), 0, c->stream, a.rec, n, a.runs, n_runs, ck_off, row_off, chunk_off, tw);
             uint64_t total_ck = 0;
-            BGP_TRY(scan_exclusive_u64(c, ck_off, ck_off, n, &total_ck));
-            if (rows) {
-                BGP_TRY(scan_exclusive_u64(c, row_off, row_off, n, &total_cols));
-                BGP_TRY(scan_exclusive_u64(c, chunk_off, chunk_off, n, &total_chunks));
+            if (!rows) BGP_TRY(scan_exclusive_u64(c, ck_off, ck_off, n, &total_ck));
+            else {
+                const uint64_t* const in[3] = {ck_off, row_off, chunk_off};
+                uint64_t* const out[3] = {ck_off, row_off, chunk_off};
+                uint64_t tot[3];
+                BGP_TRY(scan_exclusive_u64x3(c, in, out, n, tot));
+                total_ck = tot[0]; total_cols = tot[1]; total_chunks = tot[2];
                 if (total_cols >= (1ull << 40) || total_chunks >= (1ull << 33)) return BGP_EINVAL;
                 BGP_TRY(c->d_rows.reserve(total_cols + 64));
                 BGP_TRY(c->d_chunk_state.reserve((total_chunks + 1) * 16));
@@ -1980,9 +2020,7 @@ int k34_pileup(bgp_ctx* c) {
         fprintf(stderr, "[biodgpu] K4: %u of %llu windows left to the general kernel\n", nd, (unsigned long long)tile_base);
     }
     uint64_t ps[16];
-    BGP_HIP(hipMemcpyAsync(ps, c->d_pstats.p, 128, hipMemcpyDeviceToHost, c->stream));
-    BGP_HIP(hipMemcpyAsync(st, status, 16, hipMemcpyDeviceToHost, c->stream));
-    BGP_HIP(hipStreamSynchronize(c->stream));
+    { const MailItem it[2] = {{c->d_pstats.p, ps, 128}, {status, st, 16}}; BGP_TRY(mail_fetch(c, it, 2)); }
     rc = bgp_status_from_bits(st[0]);
     if (rc < 0 && rc != BGP_ESEQ) return rc;
     bgp_pileup_info& pi = c->pinfo;

@@ -106,7 +106,99 @@ template <class Op, bool EXCL> int run_scan(bgp_ctx* c, const uint64_t* in, uint
     return BGP_OK;
 }
 
+// three exclusive sum scans of the same length in the same three launches (blockIdx.y picks the array): K0's records / bases /
+// CIGAR ops in front of every segment, the long reads' checkpoints / columns / chunks
+struct Scan3 { const uint64_t* in[3]; uint64_t* out[3]; uint64_t* bsum; uint64_t n, nb; };
+__global__ __launch_bounds__(T) void k_reduce3(Scan3 a) {
+    __shared__ uint64_t lds[T / 64];
+    const uint64_t* in = a.in[blockIdx.y];
+    const uint64_t base = (uint64_t)blockIdx.x * TILE + (uint64_t)threadIdx.x * ITEMS;
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) if (base + k < a.n) acc += in[base + k];
+    uint64_t tot;
+    (void)block_excl<OpSum>(acc, &tot, lds);
+    if (threadIdx.x == 0) a.bsum[blockIdx.y * (a.nb + 2) + blockIdx.x] = tot;
+}
+__global__ __launch_bounds__(T) void k_scan_bsum3(Scan3 a) {
+    __shared__ uint64_t lds[T / 64];
+    uint64_t* bsum = a.bsum + blockIdx.x * (a.nb + 2);
+    uint64_t carry = 0;
+    for (uint64_t base = 0; base < a.nb; base += T) {
+        const uint64_t i = base + threadIdx.x;
+        const uint64_t v = i < a.nb ? bsum[i] : 0;
+        uint64_t tot;
+        const uint64_t ex = block_excl<OpSum>(v, &tot, lds);
+        if (i < a.nb) bsum[i] = carry + ex;
+        carry += tot;
+    }
+    if (threadIdx.x == 0) bsum[a.nb] = carry;
+}
+__global__ __launch_bounds__(T) void k_down3(Scan3 a) {
+    __shared__ uint64_t lds[T / 64];
+    const uint64_t* in = a.in[blockIdx.y]; uint64_t* out = a.out[blockIdx.y];
+    const uint64_t* bsum = a.bsum + blockIdx.y * (a.nb + 2);
+    const uint64_t base = (uint64_t)blockIdx.x * TILE + (uint64_t)threadIdx.x * ITEMS;
+    uint64_t v[ITEMS];
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) { v[k] = base + k < a.n ? in[base + k] : 0; acc += v[k]; }
+    uint64_t tot;
+    uint64_t run = bsum[blockIdx.x] + block_excl<OpSum>(acc, &tot, lds);
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) if (base + k < a.n) { out[base + k] = run; run += v[k]; }
+    if (blockIdx.x == 0 && threadIdx.x == 0) out[a.n] = bsum[a.nb];
+}
+
+// a few values from device memory into pinned host memory with ONE small kernel: a hipMemcpyAsync into pageable memory (a
+// variable on the stack) is a host round trip each (~20 us), and a step of the path reads a dozen such scalars
+struct MailArgs { const uint8_t* src[8]; uint32_t off[8], n[8]; uint8_t* box; int items; };
+__global__ __launch_bounds__(256) void k_mail(MailArgs a) {
+    for (int k = 0; k < a.items; ++k)
+        for (uint32_t b = threadIdx.x; b < a.n[k]; b += 256) a.box[a.off[k] + b] = a.src[k][b];
+}
+
 }  // namespace
+
+int scan_exclusive_u64x3(bgp_ctx* c, const uint64_t* const in[3], uint64_t* const out[3], uint64_t n, uint64_t* totals_host) {
+    const uint64_t nb = (n + TILE - 1) / TILE;
+    BGP_TRY(c->d_scan_tmp.reserve(3 * (nb + 2) * sizeof(uint64_t)));
+    if (n == 0) {
+        for (int k = 0; k < 3; ++k) { BGP_HIP(hipMemsetAsync(out[k], 0, sizeof(uint64_t), c->stream)); if (totals_host) totals_host[k] = 0; }
+        return BGP_OK;
+    }
+    Scan3 a;
+    for (int k = 0; k < 3; ++k) { a.in[k] = in[k]; a.out[k] = out[k]; }
+    a.bsum = c->d_scan_tmp.as<uint64_t>(); a.n = n; a.nb = nb;
+    hipLaunchKernelGGL(k_reduce3, dim3((unsigned)nb, 3), dim3(T), 0, c->stream, a);
+    hipLaunchKernelGGL(k_scan_bsum3, dim3(3), dim3(T), 0, c->stream, a);
+    hipLaunchKernelGGL(k_down3, dim3((unsigned)nb, 3), dim3(T), 0, c->stream, a);
+    BGP_HIP(hipGetLastError());
+    if (totals_host) {
+        MailItem it[3];
+        for (int k = 0; k < 3; ++k) it[k] = MailItem{a.bsum + k * (nb + 2) + nb, totals_host + k, 8};
+        BGP_TRY(mail_fetch(c, it, 3));
+    }
+    return BGP_OK;
+}
+
+int mail_fetch(bgp_ctx* c, const MailItem* items, int n_items) {
+    if (n_items < 0 || n_items > 8) return BGP_EINVAL;
+    BGP_TRY(c->h_mail.reserve(8192));
+    MailArgs a;
+    a.box = c->h_mail.as<uint8_t>(); a.items = n_items;
+    uint32_t off = 0;
+    for (int k = 0; k < n_items; ++k) {
+        a.src[k] = (const uint8_t*)items[k].src; a.off[k] = off; a.n[k] = items[k].n;
+        off += (items[k].n + 15u) & ~15u;
+    }
+    if (off > 8192) return BGP_EINVAL;
+    if (n_items) hipLaunchKernelGGL(k_mail, dim3(1), dim3(256), 0, c->stream, a);
+    BGP_HIP(hipGetLastError());
+    BGP_HIP(hipStreamSynchronize(c->stream));
+    for (int k = 0; k < n_items; ++k) memcpy(items[k].dst, a.box + a.off[k], items[k].n);
+    return BGP_OK;
+}
 
 int scan_exclusive_u64(bgp_ctx* c, const uint64_t* in, uint64_t* out, uint64_t n, uint64_t* total_host) {
     return run_scan<OpSum, true>(c, in, out, n, total_host);
