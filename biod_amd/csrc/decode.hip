@@ -383,31 +383,59 @@ struct SdArgs {
 __device__ __forceinline__ u64 g_load(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void g_store(u64* p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-// unaligned little-endian dword at byte offset o of the LDS window (two aligned reads + v_alignbyte)
+// unaligned little-endian reads at byte offset o of the LDS window: gfx950's DS unit takes unaligned addresses, so each is ONE
+// ds_read (round 2 read the aligned dwords around it and funnel-shifted: two reads and a v_alignbyte per dword -- and VALU issue
+// is what bounds k12_lds, 82 % of its SIMD cycles by the SQ counters)
+#ifndef BGP_WL_NATIVE
+#define BGP_WL_NATIVE 0
+#endif
+#if BGP_WL_NATIVE
+__device__ __forceinline__ uint32_t wl32(const uint32_t* w, uint32_t o) { uint32_t v; __builtin_memcpy(&v, reinterpret_cast<const uint8_t*>(w) + o, 4); return v; }
+__device__ __forceinline__ uint2 wl64(const uint32_t* w, uint32_t o) { uint2 v; __builtin_memcpy(&v, reinterpret_cast<const uint8_t*>(w) + o, 8); return v; }
+__device__ __forceinline__ uint4 wl128(const uint32_t* w, uint32_t o) { uint4 v; __builtin_memcpy(&v, reinterpret_cast<const uint8_t*>(w) + o, 16); return v; }
+struct R3 { uint32_t x, y, z; };
+__device__ __forceinline__ R3 wl96(const uint32_t* w, uint32_t o) { R3 r; __builtin_memcpy(&r, reinterpret_cast<const uint8_t*>(w) + o, 12); return r; }
+#else
 __device__ __forceinline__ uint32_t wl32(const uint32_t* w, uint32_t o) { const uint32_t i = o >> 2; return __builtin_amdgcn_alignbyte(w[i + 1], w[i], o & 3u); }
+__device__ __forceinline__ uint2 wl64(const uint32_t* w, uint32_t o) { const uint32_t i = o >> 2, sh = o & 3u; const uint32_t a0 = w[i], a1 = w[i + 1], a2 = w[i + 2]; return make_uint2(__builtin_amdgcn_alignbyte(a1, a0, sh), __builtin_amdgcn_alignbyte(a2, a1, sh)); }
 __device__ __forceinline__ uint4 wl128(const uint32_t* w, uint32_t o) {
     const uint32_t i = o >> 2, sh = o & 3u;
     const uint32_t a0 = w[i], a1 = w[i + 1], a2 = w[i + 2], a3 = w[i + 3], a4 = w[i + 4];
     return make_uint4(__builtin_amdgcn_alignbyte(a1, a0, sh), __builtin_amdgcn_alignbyte(a2, a1, sh), __builtin_amdgcn_alignbyte(a3, a2, sh), __builtin_amdgcn_alignbyte(a4, a3, sh));
 }
-// expand16 (above) with its nine source bytes in LDS
-__device__ __forceinline__ uint4 expand16_w(const uint32_t* w, uint32_t p, uint32_t odd) {
-    const uint32_t i = p >> 2, sh = p & 3u;
-    const uint32_t a0 = w[i], a1 = w[i + 1], a2 = w[i + 2];
-    const uint32_t wx = __builtin_amdgcn_alignbyte(a1, a0, sh), wy = __builtin_amdgcn_alignbyte(a2, a1, sh), e = (a2 >> (8 * sh)) & 0xFFu;
+struct R3 { uint32_t x, y, z; };
+__device__ __forceinline__ R3 wl96(const uint32_t* w, uint32_t o) {      // (of z only the low byte)
+    const uint32_t i = o >> 2, sh = o & 3u; const uint32_t a0 = w[i], a1 = w[i + 1], a2 = w[i + 2];
+    R3 r; r.x = __builtin_amdgcn_alignbyte(a1, a0, sh); r.y = __builtin_amdgcn_alignbyte(a2, a1, sh); r.z = (a2 >> (8 * sh)) & 0xFFu; return r;
+}
+#endif
+// Sixteen consecutive bases of a 4-bit SEQ in the LDS window as a little-endian nibble stream (base k in bits 4k .. 4k+3 of y:x),
+// from base q of the SEQ section at window offset sec: the nibbles of every byte swapped (read.d:364-383: even index = high
+// nibble), an odd start funnel-shifted away.
+__device__ __forceinline__ uint2 nib16_w(const uint32_t* w, uint32_t sec, uint32_t q) {
+    const R3 r = wl96(w, sec + (q >> 1));
     auto swp = [](uint32_t x) { return ((x & 0x0F0F0F0Fu) << 4) | ((x >> 4) & 0x0F0F0F0Fu); };
-    const uint32_t s0 = swp(wx), s1 = swp(wy), s2 = swp(e);
-    const uint32_t t0 = __builtin_amdgcn_alignbit(s1, s0, odd * 4), t1 = __builtin_amdgcn_alignbit(s2, s1, odd * 4);
-    auto chars4 = [](uint32_t h) {
-        uint32_t z = (h | (h << 8)) & 0x00FF00FFu;
-        z = (z | (z << 4)) & 0x0F0F0F0Fu;
-        const uint32_t sel = z & 0x07070707u;
-        const uint32_t lo = __builtin_amdgcn_perm(0x56535247u, 0x4D43413Du, sel);
-        const uint32_t hi = __builtin_amdgcn_perm(0x4E42444Bu, 0x48595754u, sel);
-        const uint32_t m = ((z >> 3) & 0x01010101u) * 0xFFu;
-        return (lo & ~m) | (hi & m);
+    const uint32_t s0 = swp(r.x), s1 = swp(r.y), s2 = r.z >> 4, sh = (q & 1u) * 4u;      // (of the ninth byte only its high nibble, and only for an odd start)
+    return make_uint2(__builtin_amdgcn_alignbit(s1, s0, sh), __builtin_amdgcn_alignbit(s2, s1, sh));
+}
+// eight nibbles (little-endian: base k in bits 4k) -> eight chars "=ACMGRSVTWYHKDBN"[code] (base.d:85): even and odd bases apart,
+// four at a time through two v_perm tables and a third v_perm that picks the table by the code's bit 3, then interleaved
+__device__ __forceinline__ uint2 chars8(uint32_t t) {
+    auto lut = [](uint32_t x) {
+        const uint32_t sel = x & 0x07070707u;
+        const uint32_t lo = __builtin_amdgcn_perm(0x56535247u, 0x4D43413Du, sel);   // "=ACM" "GRSV"
+        const uint32_t hi = __builtin_amdgcn_perm(0x4E42444Bu, 0x48595754u, sel);   // "TWYH" "KDBN"
+        return __builtin_amdgcn_perm(hi, lo, ((x >> 1) & 0x04040404u) | 0x03020100u);
     };
-    return make_uint4(chars4(t0 & 0xFFFFu), chars4(t0 >> 16), chars4(t1 & 0xFFFFu), chars4(t1 >> 16));
+    const uint32_t ev = lut(t & 0x0F0F0F0Fu), od = lut((t >> 4) & 0x0F0F0F0Fu);
+    return make_uint2(__builtin_amdgcn_perm(od, ev, 0x05010400u), __builtin_amdgcn_perm(od, ev, 0x07030602u));
+}
+// first n bytes (nibbles) of a 64-bit word from a, the rest from b moved up behind them (1 <= n <= 15 nibbles, b's bases from its bit 0)
+__device__ __forceinline__ uint2 nib_join(uint2 a, uint2 b, uint32_t n) {
+    const unsigned long long A = ((unsigned long long)a.y << 32) | a.x, B = ((unsigned long long)b.y << 32) | b.x;
+    const unsigned long long keep = (1ull << (4u * n)) - 1ull;
+    const unsigned long long v = (A & keep) | (B << (4u * n));
+    return make_uint2((uint32_t)v, (uint32_t)(v >> 32));
 }
 
 // The fixed fields of `plausible`, branch free, for a header at window offset o (nine aligned dwords, eight v_alignbyte).
@@ -463,7 +491,7 @@ __device__ __forceinline__ int find_rec32(const uint32_t* off, int cnt, uint32_t
 // unpack_group for records that lie in the LDS window: soff / coff are relative to the group's first arena offsets B0 / C0,
 // info[3j..] = window offsets of record j's CIGAR, SEQ and QUAL sections
 template <bool SEQ, bool QUAL, bool CIG>
-__device__ __forceinline__ void unpack_lds(const SdArgs& a, const uint32_t* w, int cnt, uint64_t B0, uint64_t C0, const uint32_t* soff, const uint32_t* coff, const uint16_t* info) {
+__device__ __forceinline__ void unpack_lds(const SdArgs& a, const uint32_t* w, int cnt, uint64_t B0, uint64_t C0, const uint32_t* soff, const uint32_t* coff, const uint16_t* info, const uint8_t* cmap) {
     const uint8_t* wb = reinterpret_cast<const uint8_t*>(w);
     if (CIG) {
         const uint32_t ctot = coff[cnt];
@@ -483,7 +511,7 @@ __device__ __forceinline__ void unpack_lds(const SdArgs& a, const uint32_t* w, i
         const uint64_t B = ch << 4;
         const uint64_t lo = max(B, b0), hi = min(B + 16, b1);
         const uint32_t rlo = (uint32_t)(lo - b0);
-        int j = find_rec32(soff, cnt, rlo, (int)((float)rlo * inv));
+        int j = cmap ? (int)cmap[ch - ch0] : find_rec32(soff, cnt, rlo, (int)((float)rlo * inv));      // (the record of the chunk's first byte: a byte per chunk, written by the records' own lanes)
         const uint32_t q0 = rlo - soff[j];
         bool done = false;
         if (lo == B && hi == B + 16) {
@@ -493,16 +521,25 @@ __device__ __forceinline__ void unpack_lds(const SdArgs& a, const uint32_t* w, i
             const bool two = n1 < 16;
             const bool fits = !two || (j2 < cnt && soff[j2 + 1] - soff[j2] >= 16 - n1);
             if (fits) {
-                uint4 sv, qv;
-                if (SEQ) sv = expand16_w(w, info[3 * j + 1] + (q0 >> 1), q0 & 1u);
-                if (QUAL) qv = wl128(w, info[3 * j + 2] + q0);
-                if (two) {
-                    const int32_t nq = -(int32_t)n1;
-                    if (SEQ) sv = merge16(sv, expand16_w(w, (uint32_t)((int32_t)(uint32_t)info[3 * j2 + 1] + (nq >> 1)), (uint32_t)nq & 1u), n1);
-                    if (QUAL) qv = merge16(qv, wl128(w, info[3 * j2 + 2] - n1), n1);
+                // A chunk that straddles two records (one in nine at 150 bases a read: some lane of nearly every wave) joins the two
+                // records' NIBBLES and expands once -- expanding both records to chars and merging those was 140 of the loop's 250
+                // VALU instructions.  Straight-line: the second record's loads are a few LDS reads, a branch would cost as much.
+                const uint32_t jb = two ? (uint32_t)j2 : (uint32_t)j, nj = two ? n1 : 8u;
+                if (SEQ) {
+                    uint2 nb = nib16_w(w, info[3 * j + 1], q0);
+                    const uint2 rb = wl64(w, info[3 * jb + 1]);
+                    auto swp = [](uint32_t x) { return ((x & 0x0F0F0F0Fu) << 4) | ((x >> 4) & 0x0F0F0F0Fu); };
+                    const uint2 joined = nib_join(nb, make_uint2(swp(rb.x), swp(rb.y)), nj);
+                    if (two) nb = joined;
+                    const uint2 c0 = chars8(nb.x), c1 = chars8(nb.y);
+                    nt_store16(a.seq + B, make_uint4(c0.x, c0.y, c1.x, c1.y));
                 }
-                if (SEQ) nt_store16(a.seq + B, sv);
-                if (QUAL) nt_store16(a.qual + B, qv);
+                if (QUAL) {
+                    uint4 qv = wl128(w, info[3 * j + 2] + q0);
+                    const uint4 q2 = wl128(w, info[3 * jb + 2] - nj);
+                    if (two) qv = merge16(qv, q2, n1);
+                    nt_store16(a.qual + B, qv);
+                }
                 done = true;
             }
         }
@@ -772,6 +809,10 @@ __device__ __forceinline__ void sd_emit(const SdArgs& a, uint8_t* sd_lds, uint64
         }
         uint32_t es, ec, ts, tc;
         sd_excl2(lseq, ncig, &es, &ec, &ts, &tc, misc + M_WS);
+        // which record a 16-byte chunk of the SEQ / QUAL arenas starts in: a byte per chunk, behind the records' offsets (searching the
+        // offsets per chunk -- a guess and a binary search in LDS -- was a fifth of the arena loop's instructions)
+        const uint32_t sh16 = (uint32_t)carry_seq & 15u, map_at = (2u * cnt + 3u) & ~3u;
+        uint8_t* const cmap = (SEQ || QUAL) && map_at + ((sh16 + ts + 15u) >> 4) <= L_TAB - L_ROFF ? sd_lds + L_ROFF + map_at : nullptr;
         const uint64_t i = pn + r0 + t;
         const uint64_t tile0 = (pn + r0) / K3_TILE_RECORDS;
         if (valid) {
@@ -779,6 +820,10 @@ __device__ __forceinline__ void sd_emit(const SdArgs& a, uint8_t* sd_lds, uint64
             soff[t] = es; coff[t] = ec;
             info[3 * t] = (uint16_t)cig_o; info[3 * t + 1] = (uint16_t)(cig_o + 4 * ncig); info[3 * t + 2] = (uint16_t)(cig_o + 4 * ncig + (uint32_t)((rec.l_seq + 1) / 2));   // read.d:992-998
             if (t == rc - 1) { soff[rc] = ts; coff[rc] = tc; }
+            if (cmap && lseq) {
+                const uint32_t c1 = (es + lseq - 1u + sh16) >> 4;
+                for (uint32_t c = es ? (es + sh16 + 15u) >> 4 : 0u; c <= c1; ++c) cmap[c] = (uint8_t)t;
+            }
             if (a.tilemax) {            // K3's tile maxima: a round of 256 records touches one or two 2048-record tiles
                 const K3Key kk = k3_key_of(rec.ref_id, rec.pos, rec.end_pos);
                 const int sl = (i / K3_TILE_RECORDS == tile0) ? 0 : 2;
@@ -789,7 +834,7 @@ __device__ __forceinline__ void sd_emit(const SdArgs& a, uint8_t* sd_lds, uint64
         __syncthreads();
         if (a.tilemax && t < 4 && misc[M_TM + t]) atomicMax(&a.tilemax[2 * tile0 + t], misc[M_TM + t]);
         SDSTAMP(5);   // rows
-        unpack_lds<SEQ, QUAL, CIG>(a, w, rc, carry_seq, carry_cig, soff, coff, info);
+        unpack_lds<SEQ, QUAL, CIG>(a, w, rc, carry_seq, carry_cig, soff, coff, info, cmap);
         __syncthreads();
         SDSTAMP(6);   // arenas
         carry_seq += ts; carry_cig += tc;
