@@ -400,12 +400,15 @@ template <bool WPR> __global__ __launch_bounds__(256) void k4_ck_build(const uin
 // chain of chunks.
 __device__ __forceinline__ uint2 class_of_packed8(uint32_t cur);
 // the row bytes are k4_acc's classes: 0 any other base, 1 A, 2 C, 3 G, 4 T, 5 '-'
+#ifndef BGP_ROW_PIECE_COLS
+#define BGP_ROW_PIECE_COLS 30
+#endif
 __global__ __launch_bounds__(256) void k4_rows_build(const uint8_t* s, uint64_t stream_len, const bgp_record* rec, const uint4* cst, uint64_t n_chunks,
                                                      const uint64_t* row_off, uint8_t* rows) {
     constexpr uint32_t ROW_OTHER = 0u, ROW_DEL = 5u;
     constexpr int RB_CAP = 4096;
     __shared__ __attribute__((aligned(16))) uint8_t s_row[4][RB_CAP];
-    __shared__ uint8_t s_map[4][512];                     // piece of 14 columns -> lane of its op (at most RB_CAP / 14 + 64 pieces a chunk)
+    __shared__ uint8_t s_map[4][512];                     // piece of PC columns -> lane of its op (at most RB_CAP / PC + 64 pieces a chunk)
     const uint64_t ch = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (ch >= n_chunks) return;
@@ -445,10 +448,11 @@ __global__ __launch_bounds__(256) void k4_rows_build(const uint8_t* s, uint64_t 
                 const uint32_t wlen = cs_b >= covered ? 0u : min(rlen, covered - cs_b);     // (covered: a malformed read's zero-length ops hold columns its row has no room for)
                 if (via_lds) {
                     // Not a lane per op -- the wave would run as long as its longest op while most lanes sit out (cfg5: ops of ~15
-                    // columns, the longest of 32 around 60) -- but a lane per PIECE of 14 columns: an op announces its pieces in
+                    // columns, the longest of 32 around 60) -- but a lane per PIECE of PC columns: an op announces its pieces in
                     // an LDS map (piece -> lane of its op), every lane then takes one piece, fetches that op's numbers with two
                     // ds_bpermute and writes it.
-                    const uint32_t np = wlen ? (wlen + 13u) / 14u : 0u;
+                    constexpr uint32_t PC = BGP_ROW_PIECE_COLS;      // 30 columns a piece, a 16-byte load of packed bases: a chunk of 64 ops is ~55 pieces, one round of the loop below (14 columns and an 8-byte load: ~67 pieces, a second round for three of them -- k4_rows 7.07 -> 6.45 ms on cfg5)
+                    const uint32_t np = wlen ? (wlen + PC - 1u) / PC : 0u;
                     const uint32_t ipc = wave_incl_u32(np, lane), p_first = ipc - np, p_total = (uint32_t)__shfl((int)ipc, 63, 64);
                     for (uint32_t k = 0; k < np; ++k) s_map[wv][p_first + k] = (uint8_t)lane;
                     const uint32_t packed = (cs_b - cs) | (wlen << 12) | ((is_m ? 1u : 0u) << 22) | (p_first << 23);      // row offset < 4096 | columns <= 512 | M/=/X | first piece < 512
@@ -459,28 +463,43 @@ __global__ __launch_bounds__(256) void k4_rows_build(const uint8_t* s, uint64_t 
                         const int ol = mine ? (int)s_map[wv][pc] : 0;
                         const uint32_t pk = (uint32_t)__shfl((int)packed, ol, 64), oq = (uint32_t)__shfl((int)qs_b, ol, 64);
                         if (!mine) continue;
-                        const uint32_t t0 = 14u * (pc - (pk >> 23)), owl = (pk >> 12) & 0x3FFu, lim = min(14u, owl - t0);
+                        const uint32_t t0 = PC * (pc - (pk >> 23)), owl = (pk >> 12) & 0x3FFu, lim = min(PC, owl - t0);
                         uint8_t* const d = &s_row[wv][(pk & 0xFFFu) + t0];
-                        uint32_t wd[4];
-                        if (!((pk >> 22) & 1u)) { wd[0] = wd[1] = wd[2] = wd[3] = 0x01010101u * ROW_DEL; }
-                        else {
+                        constexpr int NW = PC > 14 ? 8 : 4;
+                        uint32_t wd[NW];
+                        if (!((pk >> 22) & 1u)) {
+#pragma unroll
+                            for (int e = 0; e < NW; ++e) wd[e] = 0x01010101u * ROW_DEL;
+                        } else {
                             const uint32_t q = oq + t0, odd = q & 1u;
                             const uint64_t src = seq_off + (q >> 1);
-                            if (src + 8 <= stream_len && q + lim <= l_seq_r) {
-                                uint2 v; __builtin_memcpy(&v, s + src, 8);
-                                const uint2 c0 = class_of_packed8(v.x), c1 = class_of_packed8(v.y);      // 16 class bytes, three v_perm for four of them
-                                wd[0] = odd ? __builtin_amdgcn_alignbyte(c0.y, c0.x, 1) : c0.x; wd[1] = odd ? __builtin_amdgcn_alignbyte(c1.x, c0.y, 1) : c0.y;
-                                wd[2] = odd ? __builtin_amdgcn_alignbyte(c1.y, c1.x, 1) : c1.x; wd[3] = odd ? (c1.y >> 8) : c1.y;
+                            if (src + 2 * NW <= stream_len && q + lim <= l_seq_r) {
+                                uint32_t v[NW / 2];
+                                __builtin_memcpy(v, s + src, 2 * NW);
+                                uint32_t c[NW + 1];
+#pragma unroll
+                                for (int e = 0; e < NW / 2; ++e) { const uint2 cc = class_of_packed8(v[e]); c[2 * e] = cc.x; c[2 * e + 1] = cc.y; }      // four class bytes a dword, three v_perm for them
+                                c[NW] = 0;
+#pragma unroll
+                                for (int e = 0; e < NW; ++e) wd[e] = odd ? __builtin_amdgcn_alignbyte(c[e + 1], c[e], 1) : c[e];
                             } else {
-                                wd[0] = wd[1] = wd[2] = wd[3] = 0;
-                                for (uint32_t b = 0; b < lim; ++b) wd[b >> 2] |= (uint32_t)base_byte(q + b) << (8 * (b & 3u));
+#pragma unroll
+                                for (int e = 0; e < NW; ++e) wd[e] = 0;
+                                for (uint32_t b = 0; b < lim; ++b) {
+                                    const uint32_t cb = (uint32_t)base_byte(q + b) << (8 * (b & 3u));
+#pragma unroll
+                                    for (int e = 0; e < NW; ++e) if ((b >> 2) == (uint32_t)e) wd[e] |= cb;
+                                }
                             }
                         }
                         // exactly `lim` bytes (the neighbours' columns are other lanes'), in as few LDS stores as that takes: gfx950's
                         // DS unit takes unaligned addresses
-                        uint64_t rest = ((uint64_t)wd[1] << 32) | wd[0];
                         uint32_t o = 0;
-                        if (lim & 8u) { __builtin_memcpy(d, &rest, 8); o = 8; rest = ((uint64_t)wd[3] << 32) | wd[2]; }
+                        if (NW == 8 && (lim & 16u)) { const uint4 x = make_uint4(wd[0], wd[1], wd[2], wd[3]); __builtin_memcpy(d, &x, 16); o = 16;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) wd[e] = wd[(e + 4) % NW]; }
+                        uint64_t rest = ((uint64_t)wd[1] << 32) | wd[0];
+                        if (lim & 8u) { __builtin_memcpy(d + o, &rest, 8); o += 8; rest = ((uint64_t)wd[3] << 32) | wd[2]; }
                         if (lim & 4u) { const uint32_t x = (uint32_t)rest; __builtin_memcpy(d + o, &x, 4); o += 4; rest >>= 32; }
                         if (lim & 2u) { const uint16_t x = (uint16_t)rest; __builtin_memcpy(d + o, &x, 2); o += 2; rest >>= 16; }
                         if (lim & 1u) d[o] = (uint8_t)rest;
