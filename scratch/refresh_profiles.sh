@@ -66,5 +66,6 @@ cd $R
 scratch/sq_pmc_k4.sh refresh_sq > /dev/null 2>&1; cp $R/gpurun_out/pmc_refresh_sq/summary.csv $OUT/${TAG}_pmc_sq_per_kernel_cfg3_100M.csv
 timeout 600 python scratch/e2e_batched.py 10000000 2>&1 | grep -v amdgpu.ids > $OUT/${TAG}_device_e2e_batched_10M.log
 BGP_VERBOSE=1 timeout 600 python scratch/e2e_file.py 10000000 2>&1 | grep -v "framing round\|amdgpu.ids" > $OUT/${TAG}_file_e2e_10M.log
+{ echo "# cfg3 at 1, 1/2, 1/4, 1/8 of its reads on ONE GPU with the N > 1 code path (BGP_BENCH_FORCE_COMM=1: process group, bgp_hist_reduce in the step): what a rank of the strong-scaling run sees; reads, Mreads/s, ms per step, sum of kernel times, stages"; scratch/strong_sizes.sh 2>&1 | grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl"; } > $OUT/${TAG}_strong_scaling_shard_sizes.log
 cut -c1-700 $OUT/${TAG}_bench_cfg3_100M.json; tail -6 $OUT/${TAG}_device_e2e_batched_10M.log
 ls -la $OUT
