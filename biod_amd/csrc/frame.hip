@@ -32,6 +32,7 @@ struct FrameArgs {
     const uint64_t* seg_hint;            // per segment: the smallest offset inside it where the caller says a record starts (NONE: no word), or null
     int tolerant_tail;                   // batched staging: the data may end inside a record -- the chain stops in front of it instead of ETRUNC
     int retry;                           // k0_guess, second pass: only segments the first pass found nothing in, names need not be printable (ref_bound is the widest then)
+    uint32_t* list; uint32_t list_cap;   // k0_verify lists the segments it sends round again (k0_rechase takes them from there)
     uint4* sub; uint32_t sub_n, sub_shift;   // k12_lds: a segment is sub_n windows of 1 << sub_shift bytes; sub[k * sub_n + w] = records, bases, CIGAR ops of segment k in front of window w (null: not wanted)
 };
 
@@ -122,6 +123,96 @@ __global__ __launch_bounds__(256) void k0_guess_wide(FrameArgs a) {
 
 constexpr int SIDE_GROUP = 16;          // offsets a lane of k0_chase collects before it stores them (one 64-byte line)
 
+// where the chase reads the stream from: global memory, or the segment's bytes staged in LDS (k0_rechase) with global memory behind them
+struct RdGlobal {
+    const uint8_t* s;
+    __device__ __forceinline__ uint32_t u32(uint64_t off) const { return ld_u32(s + off); }
+    __device__ __forceinline__ void f3(uint64_t off, uint32_t* o) const { __builtin_memcpy(o, s + off, 12); }
+};
+struct RdLds {
+    const uint8_t* s; const uint8_t* w; uint64_t w0, w1;      // window = stream bytes [w0, w1)
+    __device__ __forceinline__ uint32_t u32(uint64_t off) const { uint32_t v; if (off >= w0 && off + 4 <= w1) __builtin_memcpy(&v, w + (off - w0), 4); else v = ld_u32(s + off); return v; }
+    __device__ __forceinline__ void f3(uint64_t off, uint32_t* o) const { if (off >= w0 && off + 12 <= w1) __builtin_memcpy(o, w + (off - w0), 12); else __builtin_memcpy(o, s + off, 12); }
+};
+
+// The chase of ONE segment k from `off` (readrange.d:118-173): every record start inside the segment, its offset to the side array,
+// the segment's counts and where the chain leaves it.  Returns true when the chain goes on into a following segment the guesser
+// found nothing in (the caller chases that one right away from *off_io).
+template <class RD> __device__ __forceinline__ bool chase_one(const FrameArgs& a, uint64_t k, uint64_t* off_io, const RD& rd) {
+    uint64_t off = *off_io;
+    const uint64_t seg_end = min((k + 1) * (uint64_t)a.seg_bytes, a.len);
+    uint64_t cnt = 0, ls = 0, nc = 0;
+    uint32_t err = 0;
+    bool long_seen = false;
+    uint32_t wcur = 0;
+    const uint64_t seg0 = k * (uint64_t)a.seg_bytes;
+    // The records' offsets (relative to the segment) go to the side array SIDE_GROUP at a time, from registers: every
+    // active lane of the wave is at the same record count, so the buffer's indices are static, and a lane's stores are
+    // whole 64-byte lines.  One 4-byte store per record -- 10^8 partial-sector writes the L2 cannot merge, ~20 us apart
+    // per lane -- cost this kernel 1.6 of its 4.6 ms (scratch/chase_probe.hip).
+    uint32_t* dst = a.side + k * a.side_cap;
+    bool live = off < seg_end;
+    while (live) {
+        uint32_t buf[SIDE_GROUP];
+#pragma unroll
+        for (int e = 0; e < SIDE_GROUP; ++e) {
+            buf[e] = 0;
+            if (live) {
+                if (a.sub) {                                                     // the windows this record's start has passed: what lay in front of them
+                    const uint32_t w = (uint32_t)((off - seg0) >> a.sub_shift);
+                    while (wcur < w && wcur + 1 < a.sub_n) { ++wcur; a.sub[k * a.sub_n + wcur] = make_uint4((uint32_t)cnt, (uint32_t)ls, (uint32_t)nc, 0u); }
+                }
+                live = false;
+                if (a.len - off < 4) { if (!a.tolerant_tail) off = a.len; }     // readrange.d:139-149: short prefix ends the range (a batch keeps it for the next one)
+                else {
+                    const int32_t bs = (int32_t)rd.u32(off);
+                    if (bs < 0) err = ST_EINVAL;
+                    else if ((uint64_t)bs > a.len - off - 4) {                   // readrange.d:169; in a batch the rest of the record may still be to come --
+                        if (!a.tolerant_tail) err = ST_ETRUNC;                    // but only a record that can exist is waited for: a corrupt block_size in the
+                        else if (bs < 32 || (uint32_t)bs > (1u << 30)) err = ST_EINVAL;   // middle of a stream would otherwise be carried from batch to batch, growing,
+                        else if (a.len - off >= 24) {                             // and surface only at bgp_batch_end (the bound plausible() uses; the header
+                            uint32_t f3[3]; rd.f3(off + 12, f3);                      // fields that are there pass the chase's own checks)
+                            const int32_t lseq = (int32_t)f3[2];
+                            const uint32_t l_name = f3[0] & 0xFFu, n_cig = f3[1] & 0xFFFFu;
+                            if (lseq < 0 || l_name == 0 || 32ull + l_name + 4ull * n_cig + (uint64_t)((lseq + 1) / 2) + (uint64_t)lseq > (uint64_t)bs) err = ST_EINVAL;
+                        }
+                    }
+                    else if (bs < 32) err = ST_EINVAL;
+                    else {
+                        uint32_t f3[3]; rd.f3(off + 12, f3);                         // bin_mq_nl, flag_nc, l_seq in one load (bs >= 32: in bounds)
+                        const uint32_t bmn = f3[0], fnc = f3[1];
+                        const int32_t lseq = (int32_t)f3[2];
+                        const uint32_t l_name = bmn & 0xFFu, n_cig = fnc & 0xFFFFu;
+                        if (lseq < 0 || l_name == 0 || 32ull + l_name + 4ull * n_cig + (uint64_t)((lseq + 1) / 2) + (uint64_t)lseq > (uint64_t)bs) err = ST_EINVAL;
+                        else {
+                            buf[e] = (uint32_t)(off - seg0);
+                            ++cnt; ls += (uint64_t)lseq; nc += n_cig;
+                            long_seen |= n_cig > LONG_CIGAR;
+                            off += 4 + (uint64_t)bs;
+                            live = off < seg_end;
+                        }
+                    }
+                }
+            }
+        }
+        if (dst + SIDE_GROUP <= a.side + (k + 1) * a.side_cap) {                 // (always: a record is at least 36 bytes and side_cap is sized for that)
+#pragma unroll
+            for (int q = 0; q < SIDE_GROUP / 4; ++q) reinterpret_cast<uint4*>(dst)[q] = make_uint4(buf[4 * q], buf[4 * q + 1], buf[4 * q + 2], buf[4 * q + 3]);
+        }
+        dst += SIDE_GROUP;
+    }
+    if (a.sub) while (wcur + 1 < a.sub_n) { ++wcur; a.sub[k * a.sub_n + wcur] = make_uint4((uint32_t)cnt, (uint32_t)ls, (uint32_t)nc, 0u); }
+    a.end[k] = err ? STOP : off;
+    // per segment, not a sticky global bit: a chase from a wrong guess reads garbage and must not leave a trace
+    a.cnt[k] = cnt; a.lseq[k] = ls; a.ncig[k] = nc; a.seg_err[k] = err | (long_seen ? ST_LONGCIG : 0u);
+    *off_io = off;
+    // A following segment the guesser found nothing in (inside a record longer than a segment, or bytes that
+    // look like no header) is chased right away from where this chain stands -- otherwise every such segment
+    // would cost k0_verify one more round, host round trip included.  Its own lane wrote nothing (see k0_chase);
+    // should it read the entry set here it chases the same bytes to the same values.
+    return !(err || k + 1 >= a.n_seg || a.entry[k + 1] != NONE);
+}
+
 // one lane per segment
 __global__ __launch_bounds__(256) void k0_chase(FrameArgs a) {
     uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -133,79 +224,40 @@ __global__ __launch_bounds__(256) void k0_chase(FrameArgs a) {
     uint64_t off = a.entry[k];
     if (off == NONE) return;                                               // no guess: end/cnt/... keep their initial NONE/0 unless a chase from the left walks in (below)
     if (off == STOP) { a.end[k] = off; a.cnt[k] = 0; a.lseq[k] = 0; a.ncig[k] = 0; a.seg_err[k] = 0; return; }
-    for (;;) {
-        const uint64_t seg_end = min((k + 1) * (uint64_t)a.seg_bytes, a.len);
-        uint64_t cnt = 0, ls = 0, nc = 0;
-        uint32_t err = 0;
-        bool long_seen = false;
-        uint32_t wcur = 0;
-        const uint64_t seg0 = k * (uint64_t)a.seg_bytes;
-        // The records' offsets (relative to the segment) go to the side array SIDE_GROUP at a time, from registers: every
-        // active lane of the wave is at the same record count, so the buffer's indices are static, and a lane's stores are
-        // whole 64-byte lines.  One 4-byte store per record -- 10^8 partial-sector writes the L2 cannot merge, ~20 us apart
-        // per lane -- cost this kernel 1.6 of its 4.6 ms (scratch/chase_probe.hip).
-        uint32_t* dst = a.side + k * a.side_cap;
-        bool live = off < seg_end;
-        while (live) {
-            uint32_t buf[SIDE_GROUP];
-#pragma unroll
-            for (int e = 0; e < SIDE_GROUP; ++e) {
-                buf[e] = 0;
-                if (live) {
-                    if (a.sub) {                                                     // the windows this record's start has passed: what lay in front of them
-                        const uint32_t w = (uint32_t)((off - seg0) >> a.sub_shift);
-                        while (wcur < w && wcur + 1 < a.sub_n) { ++wcur; a.sub[k * a.sub_n + wcur] = make_uint4((uint32_t)cnt, (uint32_t)ls, (uint32_t)nc, 0u); }
-                    }
-                    live = false;
-                    if (a.len - off < 4) { if (!a.tolerant_tail) off = a.len; }     // readrange.d:139-149: short prefix ends the range (a batch keeps it for the next one)
-                    else {
-                        const int32_t bs = (int32_t)ld_u32(a.s + off);
-                        if (bs < 0) err = ST_EINVAL;
-                        else if ((uint64_t)bs > a.len - off - 4) {                   // readrange.d:169; in a batch the rest of the record may still be to come --
-                            if (!a.tolerant_tail) err = ST_ETRUNC;                    // but only a record that can exist is waited for: a corrupt block_size in the
-                            else if (bs < 32 || (uint32_t)bs > (1u << 30)) err = ST_EINVAL;   // middle of a stream would otherwise be carried from batch to batch, growing,
-                            else if (a.len - off >= 24) {                             // and surface only at bgp_batch_end (the bound plausible() uses; the header
-                                uint32_t f3[3]; __builtin_memcpy(f3, a.s + off + 12, 12);     // fields that are there pass the chase's own checks)
-                                const int32_t lseq = (int32_t)f3[2];
-                                const uint32_t l_name = f3[0] & 0xFFu, n_cig = f3[1] & 0xFFFFu;
-                                if (lseq < 0 || l_name == 0 || 32ull + l_name + 4ull * n_cig + (uint64_t)((lseq + 1) / 2) + (uint64_t)lseq > (uint64_t)bs) err = ST_EINVAL;
-                            }
-                        }
-                        else if (bs < 32) err = ST_EINVAL;
-                        else {
-                            uint32_t f3[3]; __builtin_memcpy(f3, a.s + off + 12, 12);    // bin_mq_nl, flag_nc, l_seq in one load (bs >= 32: in bounds)
-                            const uint32_t bmn = f3[0], fnc = f3[1];
-                            const int32_t lseq = (int32_t)f3[2];
-                            const uint32_t l_name = bmn & 0xFFu, n_cig = fnc & 0xFFFFu;
-                            if (lseq < 0 || l_name == 0 || 32ull + l_name + 4ull * n_cig + (uint64_t)((lseq + 1) / 2) + (uint64_t)lseq > (uint64_t)bs) err = ST_EINVAL;
-                            else {
-                                buf[e] = (uint32_t)(off - seg0);
-                                ++cnt; ls += (uint64_t)lseq; nc += n_cig;
-                                long_seen |= n_cig > LONG_CIGAR;
-                                off += 4 + (uint64_t)bs;
-                                live = off < seg_end;
-                            }
-                        }
-                    }
-                }
-            }
-            if (dst + SIDE_GROUP <= a.side + (k + 1) * a.side_cap) {                 // (always: a record is at least 36 bytes and side_cap is sized for that)
-#pragma unroll
-                for (int q = 0; q < SIDE_GROUP / 4; ++q) reinterpret_cast<uint4*>(dst)[q] = make_uint4(buf[4 * q], buf[4 * q + 1], buf[4 * q + 2], buf[4 * q + 3]);
-            }
-            dst += SIDE_GROUP;
+    const RdGlobal rd{a.s};
+    while (chase_one(a, k, &off, rd)) { ++k; a.entry[k] = off; a.dirty[k] = 0; }
+}
+
+// The repair rounds: k0_verify found a handful of segments whose guess was wrong (a byte pattern inside a record that passes for a
+// header: a few in 10^5 segments) and listed them.  One lane chasing such a segment again through global memory is ~230 dependent
+// misses, 0.18 ms -- 4 % of a step on 10 M reads -- whatever the number of segments; here a workgroup per listed segment copies
+// it into LDS (coalesced) and one thread chases there.
+__global__ __launch_bounds__(256) void k0_rechase(FrameArgs a, const uint32_t* list, uint32_t n_list) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t rw[];
+    __shared__ uint64_t s_off; __shared__ int s_go;
+    if (blockIdx.x >= n_list) return;
+    uint64_t k = list[blockIdx.x];
+    const int t = threadIdx.x;
+    if (t == 0) {
+        a.entry[k] = a.fix[k]; a.dirty[k] = 0;
+        s_off = a.entry[k]; s_go = 1;
+        if (s_off == NONE) s_go = 0;
+        else if (s_off == STOP) { a.end[k] = STOP; a.cnt[k] = 0; a.lseq[k] = 0; a.ncig[k] = 0; a.seg_err[k] = 0; s_go = 0; }
+    }
+    __syncthreads();
+    while (s_go) {
+        const uint64_t w0 = (s_off & ~15ull), w1 = min(a.len & ~15ull, ((k + 1) * (uint64_t)a.seg_bytes + 64) & ~15ull);      // from the entry to a header's length past the segment, whole 16-byte pieces
+        if (w1 > w0) for (uint64_t o = w0 + 16ull * t; o < w1; o += 16ull * 256) { uint4 v; __builtin_memcpy(&v, a.s + o, 16); *reinterpret_cast<uint4*>(rw + (o - w0)) = v; }
+        __syncthreads();
+        if (t == 0) {
+            uint64_t off = s_off;
+            const RdLds rd{a.s, rw, w0, w1 > w0 ? w1 : w0};
+            const bool on = chase_one(a, k, &off, rd);
+            if (on) { a.entry[k + 1] = off; a.dirty[k + 1] = 0; }
+            s_off = off; s_go = on ? 1 : 0;
         }
-        if (a.sub) while (wcur + 1 < a.sub_n) { ++wcur; a.sub[k * a.sub_n + wcur] = make_uint4((uint32_t)cnt, (uint32_t)ls, (uint32_t)nc, 0u); }
-        a.end[k] = err ? STOP : off;
-        // per segment, not a sticky global bit: a chase from a wrong guess reads garbage and must not leave a trace
-        a.cnt[k] = cnt; a.lseq[k] = ls; a.ncig[k] = nc; a.seg_err[k] = err | (long_seen ? ST_LONGCIG : 0u);
-        // A following segment the guesser found nothing in (inside a record longer than a segment, or bytes that
-        // look like no header) is chased right away from where this chain stands -- otherwise every such segment
-        // would cost k0_verify one more round, host round trip included.  Its own lane wrote nothing (see above);
-        // should it read the entry set here it chases the same bytes to the same values.
-        if (err || k + 1 >= a.n_seg || a.entry[k + 1] != NONE) break;
+        __syncthreads();
         ++k;
-        a.entry[k] = off; a.dirty[k] = 0;
     }
 }
 
@@ -222,7 +274,8 @@ __global__ __launch_bounds__(256) void k0_verify(FrameArgs a) {
     if (k >= 2 && a.entry[k - 1] != a.end[k - 2]) return;
     a.fix[k] = prev_end;
     a.dirty[k] = 2;
-    atomicAdd(&a.status[1], 1u);
+    const uint32_t slot = atomicAdd(&a.status[1], 1u);
+    if (slot < a.list_cap) a.list[slot] = (uint32_t)k;
 }
 
 __global__ __launch_bounds__(256) void k0_collect_errors(FrameArgs a) {
@@ -351,6 +404,9 @@ int k0_frame(bgp_ctx* c) {
     a.tolerant_tail = c->frame_tolerant_tail ? 1 : 0;
     a.sub = nullptr; a.sub_n = 0; a.sub_shift = 0; c->seg_windows = 0;
     a.seg_hint = nullptr; a.retry = 0;
+    constexpr uint32_t LIST_CAP = 1024;
+    BGP_TRY(c->d_seg_list.reserve(LIST_CAP * 4));
+    a.list = c->d_seg_list.as<uint32_t>(); a.list_cap = n_seg < (1ull << 32) ? LIST_CAP : 0u;
     a.entry = c->d_seg_entry.as<uint64_t>(); a.fix = a.entry + n_seg + 1; a.end = c->d_seg_end.as<uint64_t>();
     a.cnt = c->d_seg_cnt.as<uint64_t>(); a.lseq = c->d_seg_lseq.as<uint64_t>(); a.ncig = c->d_seg_ncig.as<uint64_t>();
     a.dirty = c->d_seg_dirty.as<uint32_t>(); a.seg_err = a.dirty + n_seg;
@@ -393,10 +449,12 @@ int k0_frame(bgp_ctx* c) {
         }
     }
     uint64_t rounds = 0;
+    uint32_t n_list = 0;                 // the segments of a repair round, when they are few enough to be listed and small enough for LDS
     for (;;) {
         {
             TimedRegion t(c, "k0_chase", 0);
-            hipLaunchKernelGGL(k0_chase, dim3(lane_blocks), dim3(256), 0, c->stream, a);
+            if (n_list) hipLaunchKernelGGL(k0_rechase, dim3(n_list), dim3(256), (size_t)seg + 96, c->stream, a, a.list, n_list);
+            else hipLaunchKernelGGL(k0_chase, dim3(lane_blocks), dim3(256), 0, c->stream, a);
         }
         BGP_HIP(hipMemsetAsync(a.status + 1, 0, 4, c->stream));
         hipLaunchKernelGGL(k0_verify, dim3(lane_blocks), dim3(256), 0, c->stream, a);
@@ -404,6 +462,7 @@ int k0_frame(bgp_ctx* c) {
         { const MailItem it{a.status + 1, &ndirty, 4}; BGP_TRY(mail_fetch(c, &it, 1)); }
         if (getenv("BGP_VERBOSE") && rounds < 8) fprintf(stderr, "[biodgpu] framing round %llu: %u of %llu segments re-entered (seg %u B)\n", (unsigned long long)rounds, ndirty, (unsigned long long)n_seg, seg);
         if (ndirty == 0) break;
+        n_list = ndirty <= a.list_cap && seg <= (128u << 10) ? ndirty : 0u;
         if (++rounds > n_seg + 2) { c->last_error = "record framing did not converge"; return BGP_EDEVICE; }
     }
     // errors, the three exclusive scans (records, bases, CIGAR ops in front of every segment) and where the chain stopped:
