@@ -51,7 +51,7 @@ def kernels_sha():
 TIMER_KERNELS = {"k12_lds": ("k12_lds",), "k012_stream": ("k_stream_decode",), "k2_unpack": ("k2_unpack",), "k12_fused": ("k12_fused",), "k1_rows": ("k12_fused",),
                  "k4_bounds": ("k4_bounds",), "k4_plan": ("k4_plan", "k4_wscan"), "k4_tile": ("k4_acc", "k4_tile", "k4_stats"),
                  "k4_checkpoints": ("k4_ck_",), "k4_rows": ("k4_rows_build",),
-                 "k0_guess": ("k0_guess",), "k0_chase": ("k0_chase", "k0_verify"), "k3_keys_scan": ("k3_",)}
+                 "k0_guess": ("k0_guess",), "k0_chase": ("k0_chase", "k0_verify"), "k0_rechase": ("k0_rechase",), "k3_keys_scan": ("k3_",)}
 
 
 FETCH_AS_COUNTED = ("k0_chase",)
@@ -59,7 +59,7 @@ FETCH_AS_COUNTED = ("k0_chase",)
 
 def pmc_traffic(timers, config, n_reads, launches=None):
     """HBM bytes per step of the kernels behind the timers of the stage: the mean per dispatch of each kernel times the
-    timer's launches per step (1 for all but k0_chase, whose second round re-enters a few segments), from the committed
+    timer's launches per step, from the committed
     rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected separately, FETCH doubled for
     gfx950 as MI355X_MICROARCH.md prescribes).  Counters cannot be read from inside this process, so the number is only
     reported when the workload is the one the profile was taken on (configuration and read count in the profile's header) AND

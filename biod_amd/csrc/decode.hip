@@ -71,10 +71,11 @@ __device__ __forceinline__ uint4 expand16(const uint8_t* p, uint32_t odd) {
     return make_uint4(chars4(t0 & 0xFFFFu), chars4(t0 >> 16), chars4(t1 & 0xFFFFu), chars4(t1 >> 16));
 }
 
-// first n bytes from a, the rest from b
+// first n bytes from a, the rest from b (0 <= n <= 16): two 64-bit masks instead of four 32-bit ones with their clamps
 __device__ __forceinline__ uint4 merge16(uint4 a, uint4 b, uint32_t n) {
-    auto m = [n](uint32_t d) { const int k = (int)n - 4 * (int)d; return k >= 4 ? 0xFFFFFFFFu : k <= 0 ? 0u : (1u << (8 * k)) - 1u; };
-    const uint32_t m0 = m(0), m1 = m(1), m2 = m(2), m3 = m(3);
+    const unsigned long long lo = n >= 8 ? ~0ull : (1ull << (8u * n)) - 1ull;
+    const unsigned long long hi = n <= 8 ? 0ull : n >= 16 ? ~0ull : (1ull << (8u * (n - 8u))) - 1ull;
+    const uint32_t m0 = (uint32_t)lo, m1 = (uint32_t)(lo >> 32), m2 = (uint32_t)hi, m3 = (uint32_t)(hi >> 32);
     return make_uint4((a.x & m0) | (b.x & ~m0), (a.y & m1) | (b.y & ~m1), (a.z & m2) | (b.z & ~m2), (a.w & m3) | (b.w & ~m3));
 }
 

@@ -452,7 +452,7 @@ int k0_frame(bgp_ctx* c) {
     uint32_t n_list = 0;                 // the segments of a repair round, when they are few enough to be listed and small enough for LDS
     for (;;) {
         {
-            TimedRegion t(c, "k0_chase", 0);
+            TimedRegion t(c, n_list ? "k0_rechase" : "k0_chase", 0);
             if (n_list) hipLaunchKernelGGL(k0_rechase, dim3(n_list), dim3(256), (size_t)seg + 96, c->stream, a, a.list, n_list);
             else hipLaunchKernelGGL(k0_chase, dim3(lane_blocks), dim3(256), 0, c->stream, a);
         }
