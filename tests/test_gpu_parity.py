@@ -2,6 +2,8 @@
 Run on the GPU box with `pytest -m gpu`."""
 import ctypes as C
 import os
+import struct
+import re
 
 import numpy as np
 import pytest
@@ -1430,6 +1432,36 @@ def test_framing_with_a_wrong_reference_bound(ctx):
     cfg = make_cfg(n_reads=30_000, n_ref=6, ref_len=30_000, read_len=150, profile=1, seed=11)
     st = host_stream(cfg)
     stage(ctx, st, n_ref=1)
+    check_decode(ctx, st)
+    check_pileup(ctx, st, entries=False)
+
+
+@pytest.mark.parametrize("decode_at_flush", [False, True])
+def test_false_record_headers_inside_a_tag_are_repaired(ctx, decode_at_flush, monkeypatch, capfd):
+    """Records whose aux data is a 70 kB B:C array made of complete, plausible BAM records: wherever a framing segment begins
+    inside such an array the boundary guesser finds a "record" with a plausible successor and the segment is chased from there.
+    k0_verify sees that the segment before ends elsewhere, lists the segment, and the repair round (k0_rechase: the listed
+    segments from LDS) chases it again from the true boundary (readrange.d:118-173: the chain of block_size prefixes is the
+    only truth).  Both framings: the flush's own segments, and the 64 KiB ones of the decode at flush (k12_lds, with records
+    longer than a window)."""
+    rng = np.random.default_rng(77)
+    decoy = bamio.pack_record("decoy", "ACGTACGTAC", [(10, "M")], ref_id=0, pos=5, qual=bytes([30] * 10))
+    payload = decoy * (70_000 // len(decoy))
+    big_tag = b"XB" + b"BC" + struct.pack("<I", len(payload)) + payload
+    recs, pos = [], 100
+    for i in range(2400):
+        n = int(rng.integers(80, 160))
+        seq = "".join("ACGT"[int(x)] for x in rng.integers(0, 4, n))
+        tags = big_tag if i % 400 == 200 else bamio.tag_z("MD", str(n))
+        recs.append(bamio.pack_record("r%05d" % i, seq, [(n, "M")], ref_id=0, pos=pos, qual=bytes(int(x) for x in rng.integers(2, 40, n)), tags=tags))
+        pos += int(rng.integers(1, 9))
+    st = b"".join(recs)
+    monkeypatch.setenv("BGP_VERBOSE", "1")
+    ctx.reset(); ctx.set_n_ref(1); ctx.push_inflated(st)
+    ctx.flush(decode=L.BGP_FETCH_ALL) if decode_at_flush else ctx.flush()
+    err = capfd.readouterr().err
+    rounds = [int(x) for x in re.findall(r"framing round \d+: (\d+) of", err)]
+    assert rounds and rounds[0] > 0 and rounds[-1] == 0, err            # something was repaired, and the last round found nothing left
     check_decode(ctx, st)
     check_pileup(ctx, st, entries=False)
 
