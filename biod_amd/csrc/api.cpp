@@ -102,12 +102,37 @@ void bgp_timing_collect(bgp_ctx* c) {
 
 static uint64_t md_ref_index(const bgp_ctx* c, uint32_t run_idx, uint64_t pos) { return (run_idx < c->md_run_base.size() ? c->md_run_base[run_idx] : 0) + (pos - c->runs[run_idx].start_pos); }
 
+void prefetch_cancel(bgp_ctx* c) {
+    if (c->pf.stream) (void)hipStreamSynchronize(c->pf.stream);
+    c->pf.valid = false;
+}
+
 // columns [a, b) of run `run_idx` copied to the host (ctx-owned buffers), with entries / reference bases / SNP verdicts on request
 int emit_window(bgp_ctx* c, uint32_t run_idx, uint64_t a, uint64_t b, int want_entries, int use_md, int snp, bgp_columns* o) {
     const bgp_run& r = c->runs[run_idx];
     const uint64_t np = b - a;
-    BGP_TRY(c->h_cols.reserve(np * sizeof(bgp_column)));
-    BGP_HIP(hipMemcpyAsync(c->h_cols.p, c->d_columns.as<bgp_column>() + r.column_base + (a - r.start_pos), np * sizeof(bgp_column), hipMemcpyDeviceToHost, c->stream));
+    // The columns come from the window copied ahead when the consumer walks the run window by window (every range of the facades does):
+    // while it looked at the previous window the copy of this one ran on a stream of its own.  h_cols is always the buffer handed out
+    // last -- a caller's view of it stays good until the next call, as the header promises -- and h_cols2 the one being filled.
+    static const bool pf_on = !(getenv("BGP_WINDOW_PREFETCH") && atoi(getenv("BGP_WINDOW_PREFETCH")) == 0);
+    const bool hit = c->pf.valid && c->pf.run == run_idx && c->pf.a == a && c->pf.b >= b;
+    if (c->pf.valid && !hit) prefetch_cancel(c);
+    if (hit) {
+        BGP_HIP(hipEventSynchronize(c->pf.done));
+        std::swap(c->h_cols, c->h_cols2);
+        c->pf.valid = false;
+    } else {
+        BGP_TRY(c->h_cols.reserve(np * sizeof(bgp_column)));
+        BGP_HIP(hipMemcpyAsync(c->h_cols.p, c->d_columns.as<bgp_column>() + r.column_base + (a - r.start_pos), np * sizeof(bgp_column), hipMemcpyDeviceToHost, c->stream));
+    }
+    if (pf_on && b < r.end_pos) {                       // the window behind this one, as long as this one
+        const uint64_t nb = std::min<uint64_t>(r.end_pos, b + np);
+        if (!c->pf.stream) { BGP_HIP(hipStreamCreateWithFlags(&c->pf.stream, hipStreamNonBlocking)); BGP_HIP(hipEventCreateWithFlags(&c->pf.done, hipEventDisableTiming)); }
+        BGP_TRY(c->h_cols2.reserve((nb - b) * sizeof(bgp_column)));
+        BGP_HIP(hipMemcpyAsync(c->h_cols2.p, c->d_columns.as<bgp_column>() + r.column_base + (b - r.start_pos), (nb - b) * sizeof(bgp_column), hipMemcpyDeviceToHost, c->pf.stream));
+        BGP_HIP(hipEventRecord(c->pf.done, c->pf.stream));
+        c->pf.valid = true; c->pf.run = run_idx; c->pf.a = b; c->pf.b = nb;
+    }
     memset(o, 0, sizeof *o);
     const bool maq = c->it.maq != 0;
     if (maq && !want_entries) { uint64_t ne = 0; BGP_TRY(k5_entries(c, run_idx, a, b, &ne)); }     // the MAQ model reads the per-read entries on the device; they are not copied out unless asked for
@@ -220,7 +245,7 @@ static void release_all(bgp_ctx* c) {
                    &c->d_md_row, &c->d_md_iv, &c->d_md_state, &c->d_refbase, &c->d_md_succ, &c->d_md_exit, &c->d_md_entry, &c->d_md_bmax, &c->d_md_long, &c->d_md_ck, &c->d_snp, &c->d_maq, &c->d_maq_tab, &c->d_rec2, &c->d_seq_off2, &c->d_cigar_off2,
                    &c->d_seg_hint, &c->d_seg_sub, &c->d_tilemax, &c->d_cig4, &c->d_slab, &c->d_wcount, &c->d_wdel, &c->d_wslow, &c->d_flt[0], &c->d_flt[1], &c->d_flt[2], &c->d_flt[3], &c->d_flt[4], &c->d_flt[5], &c->d_comp, &c->d_inf_blk};
     for (auto* b : d) b->release();
-    HostBuf* h[] = {&c->h_stage, &c->h_rec, &c->h_seq_off, &c->h_cigar_off, &c->h_seq, &c->h_qual, &c->h_cigar, &c->h_cols, &c->h_entry_off, &c->h_entries, &c->h_refbase, &c->h_snp, &c->h_maq, &c->h_ring, &c->h_stream_copy, &c->h_mail};
+    HostBuf* h[] = {&c->h_stage, &c->h_rec, &c->h_seq_off, &c->h_cigar_off, &c->h_seq, &c->h_qual, &c->h_cigar, &c->h_cols, &c->h_entry_off, &c->h_entries, &c->h_refbase, &c->h_snp, &c->h_maq, &c->h_ring, &c->h_stream_copy, &c->h_mail, &c->h_cols2};
     for (auto* b : h) b->release();
 }
 
@@ -228,6 +253,9 @@ void bgp_destroy(bgp_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    prefetch_cancel(c);
+    if (c->pf.done) (void)hipEventDestroy(c->pf.done);
+    if (c->pf.stream) (void)hipStreamDestroy(c->pf.stream);
     batch_release(c);
     bgp_timing_collect(c);
     release_all(c);
@@ -251,8 +279,9 @@ int bgp_reset(bgp_ctx* c) {
     BGP_API_TRY
     if (!c) return BGP_EINVAL;
     BGP_HIP(hipStreamSynchronize(c->stream));
+    prefetch_cancel(c);
     batch_release(c);
-    for (HostBuf* hb : {&c->h_rec, &c->h_seq_off, &c->h_cigar_off, &c->h_seq, &c->h_qual, &c->h_cigar, &c->h_cols, &c->h_entry_off, &c->h_entries, &c->h_refbase, &c->h_snp, &c->h_maq, &c->h_stream_copy}) hb->trim();
+    for (HostBuf* hb : {&c->h_cols2, &c->h_rec, &c->h_seq_off, &c->h_cigar_off, &c->h_seq, &c->h_qual, &c->h_cigar, &c->h_cols, &c->h_entry_off, &c->h_entries, &c->h_refbase, &c->h_snp, &c->h_maq, &c->h_stream_copy}) hb->trim();
     c->h_stage_len = 0; c->d_stream = nullptr; c->stream_len = 0; c->stream_on_device = false;
     c->flushed = false; c->piled = false; c->md_rows_ready = false; c->table_pending = false; c->n_records = 0; c->decoded_what = 0; c->it = bgp_ctx::Iter();
     c->hints.clear(); c->runs.clear(); c->chunks.clear(); c->chunks_ready = false; c->stage_map.clear(); c->region_pending = false; c->table_compacted = false; c->bai_buildable = false; c->cig4_ok = false; c->tilemax_ok = false;

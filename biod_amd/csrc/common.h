@@ -167,6 +167,10 @@ struct bgp_ctx {
     } it;
     std::vector<bgp_chunk_info> chunks; int chunks_use_md = 0, chunks_want_entries = 0; uint32_t chunks_window = 0; bool chunks_ready = false;   // pileupChunks: the planned chunks
     HostBuf h_cols, h_entry_off, h_entries, h_refbase, h_snp, h_maq;
+    // the window a consumer is likely to ask for next -- the columns behind the one just handed out -- is copied to the host while
+    // the consumer works on the current one (api.cpp: emit_window); h_cols2 is the second buffer the two windows alternate between
+    struct Prefetch { bool valid = false; uint32_t run = 0; uint64_t a = 0, b = 0; hipStream_t stream = nullptr; hipEvent_t done = nullptr; } pf;
+    HostBuf h_cols2;
     DevBuf d_snp;
     DevBuf d_maq, d_maq_tab; bool maq_tables_ready = false; float maq_tab_depcorr = 0, maq_tab_eta = 0;   // MAQ model (maq.hip): calls of a window; fk | lhet | beta
     DevBuf d_entry_off, d_entries, d_col_lo;
@@ -206,7 +210,9 @@ int k12_fused_decode(bgp_ctx* c, uint32_t what);            // decode.hip : K1 +
 bool k12_lds_applies(const bgp_ctx* c, uint32_t what); uint32_t k12_lds_segment_bytes(); uint32_t k12_lds_window_shift(); int k12_lds_decode(bgp_ctx* c, uint32_t what);   // decode.hip : K1 + K2 through LDS windows, framing from K0
 int k012_stream_decode(bgp_ctx* c, uint32_t what);          // decode.hip : K0 + K1 + K2 in ONE pass (framing by look-back); 1 = gave up, take the three-kernel path
 constexpr uint32_t BGP_LONG_CIGAR = 32;                      // more ops than this: basesCovered is summed by a whole wave (k1_long_cigar)
-int k34_pileup(bgp_ctx* c);                                 // pileup.hip : runs + dense columns
+int k34_pileup(bgp_ctx* c);
+void prefetch_cancel(bgp_ctx* c);      // api.cpp: before d_columns is written again, and when the ctx lets go of its results
+void prefetch_cancel(bgp_ctx* c);      // api.cpp: before d_columns is written again                                 // pileup.hip : runs + dense columns
 int k34_first_survivor(bgp_ctx* c, uint32_t run, uint64_t start_from, uint64_t* pos, uint64_t* record);
 int k5_entries(bgp_ctx* c, uint32_t run, uint64_t pos_begin, uint64_t pos_end, uint64_t* n_entries);  // pileup.hip : CSR for a window
 int scan_exclusive_u64(bgp_ctx* c, const uint64_t* in, uint64_t* out, uint64_t n, uint64_t* total_host);   // scan.hip (out has n+1 entries)

@@ -1830,6 +1830,7 @@ __global__ __launch_bounds__(256) void k5_fill(K5Args a) {
 
 int k34_pileup(bgp_ctx* c) {
     const uint64_t n = c->n_records;
+    prefetch_cancel(c);                                        // (a window of the previous result may still be on its way to the host)
     c->runs.clear();
     memset(&c->pinfo, 0, sizeof c->pinfo);
     BGP_TRY(c->d_pstats.reserve(256));
