@@ -54,9 +54,6 @@ TIMER_KERNELS = {"k12_lds": ("k12_lds",), "k012_stream": ("k_stream_decode",), "
                  "k0_guess": ("k0_guess",), "k0_chase": ("k0_chase", "k0_verify"), "k0_rechase": ("k0_rechase",), "k3_keys_scan": ("k3_",)}
 
 
-FETCH_AS_COUNTED = ("k0_chase",)
-
-
 def pmc_traffic(timers, config, n_reads, launches=None):
     """HBM bytes per step of the kernels behind the timers of the stage: the mean per dispatch of each kernel times the
     timer's launches per step, from the committed
@@ -76,9 +73,7 @@ def pmc_traffic(timers, config, n_reads, launches=None):
         for line in lines:
             f = line.strip().split(",")
             if len(f) >= 5 and names and f[0].startswith(names) and f[4].isdigit():
-                per_dispatch = int(f[4])
-                if f[0].startswith(FETCH_AS_COUNTED):       # (the guide's doubling is calibrated on wide coalesced reads: on the chase's
-                    per_dispatch = (int(f[1]) + int(f[2])) * 1024   # 4-byte hops it would report twice the lines the stream has)
+                per_dispatch = int(f[4])                    # (2 x FETCH + WRITE -- for the chase's sparse 4-byte hops too: profiles/r03_pmc_chase_probe.txt)
                 total = (total or 0) + per_dispatch * int((launches or {}).get(t, 1))
     return total
 

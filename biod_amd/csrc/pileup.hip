@@ -429,8 +429,8 @@ __global__ __launch_bounds__(256) void k4_rows_build(const uint8_t* s, uint64_t 
     const uint32_t ir = wave_incl_u32(rlen, lane), iq = wave_incl_u32(qlen, lane);
     const uint32_t cs_b = cs + ir - rlen, qs_b = qs + iq - qlen;
         {
-                // the read's row for the accumulate path: one class byte per COLUMN, k4_acc's classes (A 1, C 2, G 3,
-                // T 15, anything else 20, '-' 25).  A lane writes its own op's columns -- into LDS: the chunk's 64 ops cover a few
+                // the read's row for the accumulate path: one class byte per COLUMN, k4_acc's classes (any other base 0, A 1, C 2,
+                // G 3, T 4, '-' 5).  A lane writes its own op's columns -- into LDS: the chunk's 64 ops cover a few
                 // hundred consecutive columns, which then leave as 16-byte stores (byte stores straight to the arena, 64 lanes
                 // on a handful of lines each, cost four times the walk itself).  A chunk with an op of more than 512 columns
                 // (an intron, a long match) or more than RB_CAP columns altogether writes to the arena directly.
