@@ -165,22 +165,28 @@ template <class RD> __device__ __forceinline__ bool chase_one(const FrameArgs& a
                 live = false;
                 if (a.len - off < 4) { if (!a.tolerant_tail) off = a.len; }     // readrange.d:139-149: short prefix ends the range (a batch keeps it for the next one)
                 else {
+                    // block_size and the three header words the chase sums (bin_mq_nl, flag_nc, l_seq: bytes 12 .. 23) are requested TOGETHER.
+                    // Asked for only once block_size had come back and passed its tests, the second load found the line evicted again --
+                    // 442 k lanes keep 56 MB of lines in flight, the L2s hold 32 -- and fetched it a second time: 1.8 lines a record by
+                    // FETCH_SIZE where the two loads touch 1.18 (profiles/r03_pmc_chase_probe.txt).
+                    uint32_t f3[3] = {0u, 0u, 0u};
+                    const bool has_f3 = a.len - off >= 24;
                     const int32_t bs = (int32_t)rd.u32(off);
+                    if (has_f3) rd.f3(off + 12, f3);
+                    asm volatile("; header words settled" : "+v"(f3[0]), "+v"(f3[1]), "+v"(f3[2]));      // (keeps the load here: sunk into the branches that use it, it would be issued late again)
                     if (bs < 0) err = ST_EINVAL;
                     else if ((uint64_t)bs > a.len - off - 4) {                   // readrange.d:169; in a batch the rest of the record may still be to come --
                         if (!a.tolerant_tail) err = ST_ETRUNC;                    // but only a record that can exist is waited for: a corrupt block_size in the
                         else if (bs < 32 || (uint32_t)bs > (1u << 30)) err = ST_EINVAL;   // middle of a stream would otherwise be carried from batch to batch, growing,
-                        else if (a.len - off >= 24) {                             // and surface only at bgp_batch_end (the bound plausible() uses; the header
-                            uint32_t f3[3]; rd.f3(off + 12, f3);                      // fields that are there pass the chase's own checks)
-                            const int32_t lseq = (int32_t)f3[2];
+                        else if (has_f3) {                                        // and surface only at bgp_batch_end (the bound plausible() uses; the header
+                            const int32_t lseq = (int32_t)f3[2];                      // fields that are there pass the chase's own checks)
                             const uint32_t l_name = f3[0] & 0xFFu, n_cig = f3[1] & 0xFFFFu;
                             if (lseq < 0 || l_name == 0 || 32ull + l_name + 4ull * n_cig + (uint64_t)((lseq + 1) / 2) + (uint64_t)lseq > (uint64_t)bs) err = ST_EINVAL;
                         }
                     }
                     else if (bs < 32) err = ST_EINVAL;
                     else {
-                        uint32_t f3[3]; rd.f3(off + 12, f3);                         // bin_mq_nl, flag_nc, l_seq in one load (bs >= 32: in bounds)
-                        const uint32_t bmn = f3[0], fnc = f3[1];
+                        const uint32_t bmn = f3[0], fnc = f3[1];                     // (bs >= 32 and inside the data: the three words were there)
                         const int32_t lseq = (int32_t)f3[2];
                         const uint32_t l_name = bmn & 0xFFu, n_cig = fnc & 0xFFFFu;
                         if (lseq < 0 || l_name == 0 || 32ull + l_name + 4ull * n_cig + (uint64_t)((lseq + 1) / 2) + (uint64_t)lseq > (uint64_t)bs) err = ST_EINVAL;
