@@ -283,31 +283,49 @@ __device__ __forceinline__ K3Key k3_key_of(int32_t ref_id, int32_t pos, int32_t 
 // chain of records may be entered; every boundary is verified by the chain itself.
 __device__ __forceinline__ bool plausible(const uint8_t* s, uint64_t len, uint64_t o, int32_t ref_bound, uint32_t* bs_out, bool printable_name = true) {
     if (o + 36 > len) return false;
-    const uint32_t bs = ld_u32(s + o);
+    // Two rounds of loads instead of one per test: block_size and refID together turn nearly every candidate down (eight bytes a
+    // lane); a candidate that passes them gets the rest of its header and the first twelve bytes of its name in one go.  Word by
+    // word -- block_size, the fields, the NUL, the name -- the guesser walked eight to ten dependent round trips a segment.
+    uint32_t h01[2];
+    __builtin_memcpy(h01, s + o, 8);
+    const uint32_t bs = h01[0];
     *bs_out = bs;
     if (bs < 33u || bs > (1u << 30) || (uint64_t)bs > len - o - 4) return false;
-    const int32_t ref = (int32_t)ld_u32(s + o + 4), pos = (int32_t)ld_u32(s + o + 8);
-    const uint32_t bmn = ld_u32(s + o + 12), fnc = ld_u32(s + o + 16);
-    const int32_t lseq = (int32_t)ld_u32(s + o + 20), nref = (int32_t)ld_u32(s + o + 24), npos = (int32_t)ld_u32(s + o + 28);
-    if (ref < -1 || ref >= ref_bound || nref < -1 || nref >= ref_bound || pos < -1 || npos < -1 || lseq < 0) return false;
+    const int32_t ref = (int32_t)h01[1];
+    if (ref < -1 || ref >= ref_bound) return false;
+    uint32_t h[10];                                            // pos, bin_mq_nl, flag_nc, l_seq, next_refID, next_pos, tlen, name[0..11]
+    const bool wide = o + 48 <= len;
+    if (wide) __builtin_memcpy(h, s + o + 8, 40);
+    else { __builtin_memcpy(h, s + o + 8, 28); h[7] = h[8] = h[9] = 0u; }
+    const int32_t pos = (int32_t)h[0];
+    const uint32_t bmn = h[1], fnc = h[2];
+    const int32_t lseq = (int32_t)h[3], nref = (int32_t)h[4], npos = (int32_t)h[5];
+    if (nref < -1 || nref >= ref_bound || pos < -1 || npos < -1 || lseq < 0) return false;
     const uint32_t l_name = bmn & 0xFFu, n_cig = fnc & 0xFFFFu;
     if (l_name == 0) return false;
     const uint64_t need = 32ull + l_name + 4ull * n_cig + (uint64_t)((lseq + 1) / 2) + (uint64_t)lseq;
     if (need > bs) return false;
-    if (s[o + 36 + l_name - 1] != 0) return false;             // read name is NUL terminated
-    if (!printable_name) return true;                          // (the second, relaxed pass of the guesser: frame.hip)
     // ... and printable (SAM spec: [!-?A-~]{1,254}).  This is what tells a header from the same bytes read four or
     // eight bytes early: shifted, block_size lands in the reference field, position in bin_mq_nl, ... all in range,
     // but the "name" then starts in the zero bytes of next_pos / tlen.  (A file whose names are not printable is framed
-    // correctly all the same -- its guesses fail, the chain of records is followed serially.)  Eight bytes a load: a
+    // correctly all the same -- its guesses fail, the chain of records is followed serially.)  Eight bytes at a time: a
     // byte b is in [0x21, 0x7E] iff its top bit is clear, b + 0x5F carries into the top bit and b + 0x01 does not.
     const uint32_t nl = l_name - 1;
-    const uint8_t* nm = s + o + 36;
     auto printable8 = [](unsigned long long v, unsigned long long keep) {
         const unsigned long long H = 0x8080808080808080ull, t7 = v & ~H;
         const unsigned long long bad = (v & H) | (~(t7 + 0x5F5F5F5F5F5F5F5Full) & H) | ((t7 + 0x0101010101010101ull) & H);
         return (bad & keep) == 0;
     };
+    if (wide && l_name <= 12u) {                               // the name lies in what has been loaded (bytes 36 .. 47)
+        if (((h[7 + (nl >> 2)] >> (8u * (nl & 3u))) & 0xFFu) != 0u) return false;      // read name is NUL terminated
+        if (!printable_name) return true;                      // (the second, relaxed pass of the guesser: frame.hip)
+        const unsigned long long v0 = ((unsigned long long)h[8] << 32) | h[7];
+        if (nl <= 8u) return printable8(v0, nl == 8u ? ~0ull : (1ull << (8u * nl)) - 1ull);
+        return printable8(v0, ~0ull) && printable8((unsigned long long)h[9], (1ull << (8u * (nl - 8u))) - 1ull);
+    }
+    if (s[o + 36 + l_name - 1] != 0) return false;             // read name is NUL terminated
+    if (!printable_name) return true;
+    const uint8_t* nm = s + o + 36;
     uint32_t i = 0;
     for (; i + 8 <= nl; i += 8) { unsigned long long v; __builtin_memcpy(&v, nm + i, 8); if (!printable8(v, ~0ull)) return false; }
     if (i < nl) {
