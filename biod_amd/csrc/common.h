@@ -124,7 +124,7 @@ struct bgp_ctx {
     uint32_t seg_bytes = 0; uint64_t n_seg = 0;
     DevBuf d_seg_entry, d_seg_end, d_seg_cnt, d_seg_lseq, d_seg_ncig, d_seg_dirty;   // per segment
     DevBuf d_seg_rec_base, d_seg_seq_base, d_seg_cig_base;
-    DevBuf d_seg_side; uint32_t side_cap = 0;         // per segment: offsets of its records relative to the segment start (written by k0_chase)
+    DevBuf d_seg_side; uint32_t side_cap = 0; bool side16 = false;         // per segment: offsets of its records relative to the segment start (written by k0_chase)
     uint32_t seg_bytes_wanted = 0, seg_window_shift = 0, seg_windows = 0;   // K0: segment size asked for (0: its own choice), split into windows of 1 << shift bytes whose prefix counts the chase records (k12_lds); windows per segment of the framing at hand
     DevBuf d_seg_sub;
     bool frame_tolerant_tail = false; uint64_t frame_tail = 0;   // batched staging (batch.cpp): a stream may end inside a record; where the record chain stopped

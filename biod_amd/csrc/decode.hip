@@ -178,7 +178,7 @@ constexpr int G_SEG = 8;
 struct FusedArgs {
     DecArgs d;
     const uint64_t* entry; const uint64_t* rec_base; const uint64_t* seq_base; const uint64_t* cig_base; const uint32_t* side;
-    uint32_t side_cap, seg_bytes; uint64_t n_seg, sum_lseq, sum_ncig;
+    uint32_t side_cap, seg_bytes; int side16; uint64_t n_seg, sum_lseq, sum_ncig;
     bgp_record* rec_out; uint64_t* seq_off_out; uint64_t* cig_off_out; uint4* cig4_out;
     unsigned long long* tilemax;      // K3's keys, maximum per 2048-record tile (two u64 per tile), or null
 };
@@ -227,7 +227,7 @@ __global__ __launch_bounds__(256, BGP_K12_MINW) void k12_fused(FusedArgs a) {
 #pragma unroll
             for (int k = 1; k < G_SEG; ++k) if (k < g_n && s_rb[k] <= i) g = k;
             const uint64_t seg = k0 + g;
-            const uint64_t off = seg * a.seg_bytes + a.side[seg * a.side_cap + (i - s_rb[g])];
+            const uint64_t off = seg * a.seg_bytes + (a.side16 ? (uint32_t)reinterpret_cast<const uint16_t*>(a.side + seg * a.side_cap)[i - s_rb[g]] : a.side[seg * a.side_cap + (i - s_rb[g])]);
             const uint8_t* p = a.d.s + off;
             // few wide loads instead of many dword loads: the lanes' records are ~300 bytes apart, so every load
             // instruction costs the address coalescer 64 separate lines whatever its width
@@ -1038,7 +1038,7 @@ __global__ __launch_bounds__(SD_T, BGP_SD_MINW) void k_stream_decode(SdArgs a) {
 // the records' offsets from the side array k0_chase left, and emits exactly as the one-pass kernel does (sd_emit).
 struct LdsArgs {
     SdArgs d;                         // stream, outputs (capacities unused: the sizes are known)
-    const uint64_t* rec_base; const uint64_t* seq_base; const uint64_t* cig_base; const uint32_t* side; uint32_t side_cap;
+    const uint64_t* rec_base; const uint64_t* seq_base; const uint64_t* cig_base; const uint32_t* side; uint32_t side_cap; int side16;
     uint64_t n_seg, n_records, sum_lseq, sum_ncig;
     const uint4* sub; uint32_t sub_n;      // a K0 segment is sub_n windows: records / bases / ops of the segment in front of each (k0_chase)
 };
@@ -1070,7 +1070,8 @@ __global__ __launch_bounds__(SD_T, BGP_SD_MINW) void k12_lds(LdsArgs a) {
         uint4 v[NL];
 #pragma unroll
         for (int i = 0; i < NL; ++i) { const uint32_t o = 16u * (uint32_t)(t + SD_T * i); v[i] = make_uint4(0, 0, 0, 0); if (o + 16 <= wlen) __builtin_memcpy(&v[i], a.d.s + wbase + o, 16); }
-        for (uint32_t j = t; j < cnt; j += SD_T) roff[j] = (uint16_t)(a.side[sg * a.side_cap + p0.x + j] - h * SD_C);
+        if (a.side16) { const uint16_t* s16 = reinterpret_cast<const uint16_t*>(a.side + sg * a.side_cap); for (uint32_t j = t; j < cnt; j += SD_T) roff[j] = (uint16_t)(s16[p0.x + j] - h * SD_C); }
+        else for (uint32_t j = t; j < cnt; j += SD_T) roff[j] = (uint16_t)(a.side[sg * a.side_cap + p0.x + j] - h * SD_C);
 #pragma unroll
         for (int i = 0; i < NL; ++i) { const uint32_t o = 16u * (uint32_t)(t + SD_T * i); if (o < SD_WIN + 32) *reinterpret_cast<uint4*>(sd_lds + o) = v[i]; }
     }
@@ -1140,7 +1141,7 @@ int k12_fused_decode(bgp_ctx* c, uint32_t what) {
     a.d.s = c->d_stream; a.d.stream_len = c->stream_len; a.d.rec = nullptr; a.d.seq_off = nullptr; a.d.cigar_off = nullptr; a.d.n = n; a.d.rb = RB;
     a.d.seq = c->d_seq.as<uint8_t>(); a.d.qual = c->d_qual.as<uint8_t>(); a.d.cigar = c->d_cigar.as<uint32_t>();
     a.entry = c->d_seg_entry.as<uint64_t>(); a.rec_base = c->d_seg_rec_base.as<uint64_t>(); a.seq_base = c->d_seg_seq_base.as<uint64_t>(); a.cig_base = c->d_seg_cig_base.as<uint64_t>();
-    a.side = c->d_seg_side.as<uint32_t>(); a.side_cap = c->side_cap; a.seg_bytes = c->seg_bytes; a.n_seg = c->n_seg; a.sum_lseq = c->sum_lseq; a.sum_ncig = c->sum_ncig;
+    a.side = c->d_seg_side.as<uint32_t>(); a.side_cap = c->side_cap; a.side16 = c->side16 ? 1 : 0; a.seg_bytes = c->seg_bytes; a.n_seg = c->n_seg; a.sum_lseq = c->sum_lseq; a.sum_ncig = c->sum_ncig;
     a.rec_out = c->d_rec.as<bgp_record>(); a.seq_off_out = c->d_seq_off.as<uint64_t>(); a.cig_off_out = c->d_cigar_off.as<uint64_t>();
     a.cig4_out = c->d_cig4.as<uint4>();
     // K3's tile maxima on the way -- unless some record's end_position is finished later (CIGARs longer than the inline loop)
@@ -1341,7 +1342,7 @@ int k12_lds_decode(bgp_ctx* c, uint32_t what) {
         a.d.tilemax = (unsigned long long*)c->d_tilemax.p; c->tilemax_ok = true;
     }
     a.rec_base = c->d_seg_rec_base.as<uint64_t>(); a.seq_base = c->d_seg_seq_base.as<uint64_t>(); a.cig_base = c->d_seg_cig_base.as<uint64_t>();
-    a.side = c->d_seg_side.as<uint32_t>(); a.side_cap = c->side_cap; a.n_seg = c->n_seg; a.n_records = n; a.sum_lseq = c->sum_lseq; a.sum_ncig = c->sum_ncig;
+    a.side = c->d_seg_side.as<uint32_t>(); a.side_cap = c->side_cap; a.side16 = c->side16 ? 1 : 0; a.n_seg = c->n_seg; a.n_records = n; a.sum_lseq = c->sum_lseq; a.sum_ncig = c->sum_ncig;
     a.sub = c->d_seg_sub.as<uint4>(); a.sub_n = c->seg_windows;
     const uint64_t n_win = std::min<uint64_t>(c->n_seg * c->seg_windows, (c->stream_len + SD_C - 1) / SD_C);
     {

@@ -29,6 +29,7 @@ struct FrameArgs {
     uint64_t* entry; uint64_t* fix; uint64_t* end; uint64_t* cnt; uint64_t* lseq; uint64_t* ncig; uint32_t* dirty; uint32_t* seg_err;
     uint32_t* status; /* [0] status bits, [1] dirty counter */
     uint32_t* side; uint32_t side_cap;   // side[k * side_cap + j] = offset of segment k's j-th record relative to the segment start
+    int side16;                          // ... as 16-bit values (segments of at most 64 KiB), two to a word of the same array
     const uint64_t* seg_hint;            // per segment: the smallest offset inside it where the caller says a record starts (NONE: no word), or null
     int tolerant_tail;                   // batched staging: the data may end inside a record -- the chain stops in front of it instead of ETRUNC
     int retry;                           // k0_guess, second pass: only segments the first pass found nothing in, names need not be printable (ref_bound is the widest then)
@@ -138,7 +139,16 @@ struct RdLds {
 // The chase of ONE segment k from `off` (readrange.d:118-173): every record start inside the segment, its offset to the side array,
 // the segment's counts and where the chain leaves it.  Returns true when the chain goes on into a following segment the guesser
 // found nothing in (the caller chases that one right away from *off_io).
-template <class RD> __device__ __forceinline__ bool chase_one(const FrameArgs& a, uint64_t k, uint64_t* off_io, const RD& rd) {
+// SINK: how the records' offsets (relative to the segment) reach the side array.
+//   0  32-bit offsets, sixteen at a time from registers (any segment size): every active lane of the wave is at the same record
+//      count, so the buffer's indices are static, and a lane's stores are whole 64-byte groups.  One 4-byte store per record --
+//      10^8 partial-sector writes the L2 cannot merge, ~20 us apart per lane -- cost this kernel 1.6 of its 4.6 ms (scratch/chase_probe.hip).
+//   1  16-bit offsets (segments of at most 64 KiB: the LDS-window decode's), thirty-two at a time through a ring in LDS
+//      (ring[entry][thread]: the lanes of a wave write neighbouring halfwords): half the bytes and half the stores of sink 0 -- by
+//      the probe's arithmetic the stores were 0.7 of the chase's 3.3 ms, 0.3 of it per store and 0.4 per byte.
+//   2  16-bit offsets stored one by one (k0_rechase: one thread, a handful of segments)
+constexpr int RING_N = 32;
+template <class RD, int SINK> __device__ __forceinline__ bool chase_one(const FrameArgs& a, uint64_t k, uint64_t* off_io, const RD& rd, uint16_t* ring = nullptr) {
     uint64_t off = *off_io;
     const uint64_t seg_end = min((k + 1) * (uint64_t)a.seg_bytes, a.len);
     uint64_t cnt = 0, ls = 0, nc = 0;
@@ -146,66 +156,90 @@ template <class RD> __device__ __forceinline__ bool chase_one(const FrameArgs& a
     bool long_seen = false;
     uint32_t wcur = 0;
     const uint64_t seg0 = k * (uint64_t)a.seg_bytes;
-    // The records' offsets (relative to the segment) go to the side array SIDE_GROUP at a time, from registers: every
-    // active lane of the wave is at the same record count, so the buffer's indices are static, and a lane's stores are
-    // whole 64-byte lines.  One 4-byte store per record -- 10^8 partial-sector writes the L2 cannot merge, ~20 us apart
-    // per lane -- cost this kernel 1.6 of its 4.6 ms (scratch/chase_probe.hip).
-    uint32_t* dst = a.side + k * a.side_cap;
     bool live = off < seg_end;
-    while (live) {
-        uint32_t buf[SIDE_GROUP];
+    // one hop: true when a record starts at `off` and passes the reference's tests -- its offset in *v, the sums and `off` moved on;
+    // `live` says whether the chain goes on inside the segment
+    auto hop = [&](uint32_t* v) -> bool {
+        if (a.sub) {                                                     // the windows this record's start has passed: what lay in front of them
+            const uint32_t w = (uint32_t)((off - seg0) >> a.sub_shift);
+            while (wcur < w && wcur + 1 < a.sub_n) { ++wcur; a.sub[k * a.sub_n + wcur] = make_uint4((uint32_t)cnt, (uint32_t)ls, (uint32_t)nc, 0u); }
+        }
+        live = false;
+        if (a.len - off < 4) { if (!a.tolerant_tail) off = a.len; return false; }     // readrange.d:139-149: short prefix ends the range (a batch keeps it for the next one)
+        // block_size and the three header words the chase sums (bin_mq_nl, flag_nc, l_seq: bytes 12 .. 23) are requested TOGETHER.
+        // Asked for only once block_size had come back and passed its tests, the second load found the line evicted again --
+        // 442 k lanes keep 56 MB of lines in flight, the L2s hold 32 -- and fetched it a second time: 1.8 lines a record by
+        // FETCH_SIZE where the two loads touch 1.18 (profiles/r03_pmc_chase_probe.txt).
+        uint32_t f3[3] = {0u, 0u, 0u};
+        const bool has_f3 = a.len - off >= 24;
+        const int32_t bs = (int32_t)rd.u32(off);
+        if (has_f3) rd.f3(off + 12, f3);
+        asm volatile("; header words settled" : "+v"(f3[0]), "+v"(f3[1]), "+v"(f3[2]));      // (keeps the load here: sunk into the branches that use it, it would be issued late again)
+        if (bs < 0) { err = ST_EINVAL; return false; }
+        if ((uint64_t)bs > a.len - off - 4) {                        // readrange.d:169; in a batch the rest of the record may still be to come --
+            if (!a.tolerant_tail) err = ST_ETRUNC;                    // but only a record that can exist is waited for: a corrupt block_size in the
+            else if (bs < 32 || (uint32_t)bs > (1u << 30)) err = ST_EINVAL;   // middle of a stream would otherwise be carried from batch to batch, growing,
+            else if (has_f3) {                                        // and surface only at bgp_batch_end (the bound plausible() uses; the header
+                const int32_t lseq = (int32_t)f3[2];                      // fields that are there pass the chase's own checks)
+                const uint32_t l_name = f3[0] & 0xFFu, n_cig = f3[1] & 0xFFFFu;
+                if (lseq < 0 || l_name == 0 || 32ull + l_name + 4ull * n_cig + (uint64_t)((lseq + 1) / 2) + (uint64_t)lseq > (uint64_t)bs) err = ST_EINVAL;
+            }
+            return false;
+        }
+        if (bs < 32) { err = ST_EINVAL; return false; }
+        const uint32_t bmn = f3[0], fnc = f3[1];                     // (bs >= 32 and inside the data: the three words were there)
+        const int32_t lseq = (int32_t)f3[2];
+        const uint32_t l_name = bmn & 0xFFu, n_cig = fnc & 0xFFFFu;
+        if (lseq < 0 || l_name == 0 || 32ull + l_name + 4ull * n_cig + (uint64_t)((lseq + 1) / 2) + (uint64_t)lseq > (uint64_t)bs) { err = ST_EINVAL; return false; }
+        *v = (uint32_t)(off - seg0);
+        ++cnt; ls += (uint64_t)lseq; nc += n_cig;
+        long_seen |= n_cig > LONG_CIGAR;
+        off += 4 + (uint64_t)bs;
+        live = off < seg_end;
+        return true;
+    };
+    if (SINK == 0) {
+        uint32_t* dst = a.side + k * a.side_cap;
+        while (live) {
+            uint32_t buf[SIDE_GROUP];
 #pragma unroll
-        for (int e = 0; e < SIDE_GROUP; ++e) {
-            buf[e] = 0;
-            if (live) {
-                if (a.sub) {                                                     // the windows this record's start has passed: what lay in front of them
-                    const uint32_t w = (uint32_t)((off - seg0) >> a.sub_shift);
-                    while (wcur < w && wcur + 1 < a.sub_n) { ++wcur; a.sub[k * a.sub_n + wcur] = make_uint4((uint32_t)cnt, (uint32_t)ls, (uint32_t)nc, 0u); }
-                }
-                live = false;
-                if (a.len - off < 4) { if (!a.tolerant_tail) off = a.len; }     // readrange.d:139-149: short prefix ends the range (a batch keeps it for the next one)
-                else {
-                    // block_size and the three header words the chase sums (bin_mq_nl, flag_nc, l_seq: bytes 12 .. 23) are requested TOGETHER.
-                    // Asked for only once block_size had come back and passed its tests, the second load found the line evicted again --
-                    // 442 k lanes keep 56 MB of lines in flight, the L2s hold 32 -- and fetched it a second time: 1.8 lines a record by
-                    // FETCH_SIZE where the two loads touch 1.18 (profiles/r03_pmc_chase_probe.txt).
-                    uint32_t f3[3] = {0u, 0u, 0u};
-                    const bool has_f3 = a.len - off >= 24;
-                    const int32_t bs = (int32_t)rd.u32(off);
-                    if (has_f3) rd.f3(off + 12, f3);
-                    asm volatile("; header words settled" : "+v"(f3[0]), "+v"(f3[1]), "+v"(f3[2]));      // (keeps the load here: sunk into the branches that use it, it would be issued late again)
-                    if (bs < 0) err = ST_EINVAL;
-                    else if ((uint64_t)bs > a.len - off - 4) {                   // readrange.d:169; in a batch the rest of the record may still be to come --
-                        if (!a.tolerant_tail) err = ST_ETRUNC;                    // but only a record that can exist is waited for: a corrupt block_size in the
-                        else if (bs < 32 || (uint32_t)bs > (1u << 30)) err = ST_EINVAL;   // middle of a stream would otherwise be carried from batch to batch, growing,
-                        else if (has_f3) {                                        // and surface only at bgp_batch_end (the bound plausible() uses; the header
-                            const int32_t lseq = (int32_t)f3[2];                      // fields that are there pass the chase's own checks)
-                            const uint32_t l_name = f3[0] & 0xFFu, n_cig = f3[1] & 0xFFFFu;
-                            if (lseq < 0 || l_name == 0 || 32ull + l_name + 4ull * n_cig + (uint64_t)((lseq + 1) / 2) + (uint64_t)lseq > (uint64_t)bs) err = ST_EINVAL;
-                        }
-                    }
-                    else if (bs < 32) err = ST_EINVAL;
-                    else {
-                        const uint32_t bmn = f3[0], fnc = f3[1];                     // (bs >= 32 and inside the data: the three words were there)
-                        const int32_t lseq = (int32_t)f3[2];
-                        const uint32_t l_name = bmn & 0xFFu, n_cig = fnc & 0xFFFFu;
-                        if (lseq < 0 || l_name == 0 || 32ull + l_name + 4ull * n_cig + (uint64_t)((lseq + 1) / 2) + (uint64_t)lseq > (uint64_t)bs) err = ST_EINVAL;
-                        else {
-                            buf[e] = (uint32_t)(off - seg0);
-                            ++cnt; ls += (uint64_t)lseq; nc += n_cig;
-                            long_seen |= n_cig > LONG_CIGAR;
-                            off += 4 + (uint64_t)bs;
-                            live = off < seg_end;
-                        }
-                    }
+            for (int e = 0; e < SIDE_GROUP; ++e) {
+                buf[e] = 0;
+                if (live) { uint32_t v = 0; if (hop(&v)) buf[e] = v; }
+            }
+            if (dst + SIDE_GROUP <= a.side + (k + 1) * a.side_cap) {                 // (always: a record is at least 36 bytes and side_cap is sized for that)
+#pragma unroll
+                for (int q = 0; q < SIDE_GROUP / 4; ++q) reinterpret_cast<uint4*>(dst)[q] = make_uint4(buf[4 * q], buf[4 * q + 1], buf[4 * q + 2], buf[4 * q + 3]);
+            }
+            dst += SIDE_GROUP;
+        }
+    } else if (SINK == 1) {
+        uint16_t* const dst16 = reinterpret_cast<uint16_t*>(a.side + k * a.side_cap);
+        const uint32_t cap16 = 2u * a.side_cap;
+        uint16_t* const mine = ring + threadIdx.x;
+        uint32_t g = 0, flushed = 0;
+        auto flush = [&]() {
+            if (flushed + RING_N <= cap16) {
+#pragma unroll
+                for (int q = 0; q < RING_N / 8; ++q) {
+                    uint32_t wv[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { const uint32_t lo = (uint32_t)(8 * q + 2 * e) < g ? mine[(8 * q + 2 * e) * 256] : 0u, hi = (uint32_t)(8 * q + 2 * e + 1) < g ? mine[(8 * q + 2 * e + 1) * 256] : 0u; wv[e] = lo | (hi << 16); }
+                    reinterpret_cast<uint4*>(dst16 + flushed)[q] = make_uint4(wv[0], wv[1], wv[2], wv[3]);
                 }
             }
+            flushed += RING_N; g = 0;
+        };
+        while (live) {
+            uint32_t v = 0;
+            if (hop(&v)) { mine[g * 256] = (uint16_t)v; if (++g == RING_N) flush(); }
         }
-        if (dst + SIDE_GROUP <= a.side + (k + 1) * a.side_cap) {                 // (always: a record is at least 36 bytes and side_cap is sized for that)
-#pragma unroll
-            for (int q = 0; q < SIDE_GROUP / 4; ++q) reinterpret_cast<uint4*>(dst)[q] = make_uint4(buf[4 * q], buf[4 * q + 1], buf[4 * q + 2], buf[4 * q + 3]);
-        }
-        dst += SIDE_GROUP;
+        if (g) flush();
+    } else {
+        uint16_t* const dst16 = reinterpret_cast<uint16_t*>(a.side + k * a.side_cap);
+        const uint32_t cap16 = 2u * a.side_cap;
+        uint32_t n = 0;
+        while (live) { uint32_t v = 0; if (hop(&v)) { if (n < cap16) dst16[n] = (uint16_t)v; ++n; } }
     }
     if (a.sub) while (wcur + 1 < a.sub_n) { ++wcur; a.sub[k * a.sub_n + wcur] = make_uint4((uint32_t)cnt, (uint32_t)ls, (uint32_t)nc, 0u); }
     a.end[k] = err ? STOP : off;
@@ -221,6 +255,7 @@ template <class RD> __device__ __forceinline__ bool chase_one(const FrameArgs& a
 
 // one lane per segment
 __global__ __launch_bounds__(256) void k0_chase(FrameArgs a) {
+    __shared__ uint16_t ring[RING_N][256];
     uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= a.n_seg) return;
     const uint32_t d = a.dirty[k];
@@ -231,7 +266,8 @@ __global__ __launch_bounds__(256) void k0_chase(FrameArgs a) {
     if (off == NONE) return;                                               // no guess: end/cnt/... keep their initial NONE/0 unless a chase from the left walks in (below)
     if (off == STOP) { a.end[k] = off; a.cnt[k] = 0; a.lseq[k] = 0; a.ncig[k] = 0; a.seg_err[k] = 0; return; }
     const RdGlobal rd{a.s};
-    while (chase_one(a, k, &off, rd)) { ++k; a.entry[k] = off; a.dirty[k] = 0; }
+    if (a.side16) { while (chase_one<RdGlobal, 1>(a, k, &off, rd, &ring[0][0])) { ++k; a.entry[k] = off; a.dirty[k] = 0; } }
+    else { while (chase_one<RdGlobal, 0>(a, k, &off, rd)) { ++k; a.entry[k] = off; a.dirty[k] = 0; } }
 }
 
 // The repair rounds: k0_verify found a handful of segments whose guess was wrong (a byte pattern inside a record that passes for a
@@ -258,7 +294,7 @@ __global__ __launch_bounds__(256) void k0_rechase(FrameArgs a, const uint32_t* l
         if (t == 0) {
             uint64_t off = s_off;
             const RdLds rd{a.s, rw, w0, w1 > w0 ? w1 : w0};
-            const bool on = chase_one(a, k, &off, rd);
+            const bool on = a.side16 ? chase_one<RdLds, 2>(a, k, &off, rd) : chase_one<RdLds, 0>(a, k, &off, rd);
             if (on) { a.entry[k + 1] = off; a.dirty[k + 1] = 0; }
             s_off = off; s_go = on ? 1 : 0;
         }
@@ -427,6 +463,7 @@ int k0_frame(bgp_ctx* c) {
     BGP_TRY(c->d_seg_side.reserve((n_seg + 1) * (size_t)a.side_cap * 4));
     a.side = c->d_seg_side.as<uint32_t>();
     c->side_cap = a.side_cap;
+    a.side16 = a.sub != nullptr && seg <= 65536u; c->side16 = a.side16 != 0;
 
     if (!c->hints.empty()) {
         std::vector<uint64_t> sh(n_seg, NONE);
