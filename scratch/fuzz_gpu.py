@@ -20,6 +20,8 @@ for k in range(k0, k0 + n):
         st = T._random_stream(rng, int(rng.integers(50, 3000)), quirks=bool(k % 2))
         T.stage(ctx, st)
         T.check_decode(ctx, st)
+        ctx.reset(); ctx.push_inflated(st); ctx.flush(decode=L.BGP_FETCH_ALL)      # the decode at flush: 64 KiB segments, 16-bit side offsets, k12_lds
+        T.check_decode(ctx, st)
         try:
             O.pileup(st)
             T.check_pileup(ctx, st, entries=(k % 3 == 0), window=int(rng.integers(100, 9000)))
