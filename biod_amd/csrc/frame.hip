@@ -276,10 +276,13 @@ __global__ __launch_bounds__(256) void k0_chase(FrameArgs a) {
 // it into LDS (coalesced) and one thread chases there.
 __global__ __launch_bounds__(256) void k0_rechase(FrameArgs a, const uint32_t* list, uint32_t n_list) {
     extern __shared__ __attribute__((aligned(16))) uint8_t rw[];
-    __shared__ uint64_t s_off; __shared__ int s_go;
+    __shared__ uint64_t s_off, s_end; __shared__ int s_go, s_plain; __shared__ uint32_t s_n;
+    __shared__ unsigned long long s_acc[3 * 8 + 2];           // per window boundary: records, bases, ops in front of it; [24] a long CIGAR seen, [25] a record that fails its tests
     if (blockIdx.x >= n_list) return;
     uint64_t k = list[blockIdx.x];
     const int t = threadIdx.x;
+    const uint32_t lst_cap = a.seg_bytes / 36u + 2u;
+    uint32_t* const lst = reinterpret_cast<uint32_t*>(rw + (((size_t)a.seg_bytes + 96 + 15) & ~(size_t)15));      // the segment's record offsets (behind the window)
     if (t == 0) {
         a.entry[k] = a.fix[k]; a.dirty[k] = 0;
         s_off = a.entry[k]; s_go = 1;
@@ -288,10 +291,57 @@ __global__ __launch_bounds__(256) void k0_rechase(FrameArgs a, const uint32_t* l
     }
     __syncthreads();
     while (s_go) {
+        const uint64_t seg0 = k * (uint64_t)a.seg_bytes, seg_end = min(seg0 + a.seg_bytes, a.len);
         const uint64_t w0 = (s_off & ~15ull), w1 = min(a.len & ~15ull, ((k + 1) * (uint64_t)a.seg_bytes + 64) & ~15ull);      // from the entry to a header's length past the segment, whole 16-byte pieces
         if (w1 > w0) for (uint64_t o = w0 + 16ull * t; o < w1; o += 16ull * 256) { uint4 v; __builtin_memcpy(&v, a.s + o, 16); *reinterpret_cast<uint4*>(rw + (o - w0)) = v; }
+        if (t < 26) s_acc[t] = 0;
         __syncthreads();
+        // One thread follows the length prefixes -- nothing but "read four bytes, add": the full hop of chase_one is ~100 dependent
+        // instructions, 0.11 ms for a segment's 230 records by one thread -- and stops at anything that is not a plain hop; then
+        // every record is looked at by a thread of its own.  Whatever is not plain (the end of the data, a record that fails a test)
+        // is left to chase_one, in the reference's order of tests.
         if (t == 0) {
+            uint32_t n = 0; uint64_t off = s_off; bool plain = a.sub_n <= 8;
+            while (plain && off < seg_end) {
+                if (off < w0 || off + 24 > w1 || n >= lst_cap) { plain = false; break; }
+                uint32_t bs; __builtin_memcpy(&bs, rw + (off - w0), 4);
+                if ((int32_t)bs < 32 || (uint64_t)bs > a.len - off - 4) { plain = false; break; }
+                lst[n++] = (uint32_t)(off - seg0);
+                off += 4 + (uint64_t)bs;
+            }
+            s_n = n; s_plain = plain ? 1 : 0; s_end = off;
+        }
+        __syncthreads();
+        if (s_plain) {
+            const uint32_t n = s_n, nb = a.sub ? a.sub_n : 1u;
+            for (uint32_t j = t; j < n; j += 256) {
+                const uint32_t o = lst[j];
+                const uint8_t* h = rw + (seg0 + o - w0);
+                uint32_t bs, f3[3]; __builtin_memcpy(&bs, h, 4); __builtin_memcpy(f3, h + 12, 12);
+                const int32_t lseq = (int32_t)f3[2];
+                const uint32_t l_name = f3[0] & 0xFFu, n_cig = f3[1] & 0xFFFFu;
+                if (lseq < 0 || l_name == 0 || 32ull + l_name + 4ull * n_cig + (uint64_t)((lseq + 1) / 2) + (uint64_t)lseq > (uint64_t)bs) { atomicAdd(&s_acc[25], 1ull); continue; }
+                if (n_cig > LONG_CIGAR) atomicAdd(&s_acc[24], 1ull);
+                const uint32_t wj = a.sub ? o >> a.sub_shift : 0u;                     // the record counts in front of every window behind its own, and in the totals
+                for (uint32_t w = wj + 1; w <= nb; ++w) { unsigned long long* q = s_acc + 3 * (w - 1); atomicAdd(q, 1ull); atomicAdd(q + 1, (unsigned long long)(uint32_t)lseq); atomicAdd(q + 2, (unsigned long long)n_cig); }
+            }
+            __syncthreads();
+            if (s_acc[25]) { if (t == 0) s_plain = 0; }
+            __syncthreads();
+        }
+        if (s_plain) {
+            const uint32_t n = s_n, nb = a.sub ? a.sub_n : 1u;
+            if (a.side16) { uint16_t* d16 = reinterpret_cast<uint16_t*>(a.side + k * a.side_cap); for (uint32_t j = t; j < n && j < 2u * a.side_cap; j += 256) d16[j] = (uint16_t)lst[j]; }
+            else { uint32_t* d32 = a.side + k * a.side_cap; for (uint32_t j = t; j < n && j < a.side_cap; j += 256) d32[j] = lst[j]; }
+            if (a.sub && t >= 1 && (uint32_t)t < nb) a.sub[k * a.sub_n + t] = make_uint4((uint32_t)s_acc[3 * (t - 1)], (uint32_t)s_acc[3 * (t - 1) + 1], (uint32_t)s_acc[3 * (t - 1) + 2], 0u);
+            if (t == 0) {
+                const unsigned long long* tot = s_acc + 3 * (nb - 1);
+                a.end[k] = s_end; a.cnt[k] = tot[0]; a.lseq[k] = tot[1]; a.ncig[k] = tot[2]; a.seg_err[k] = s_acc[24] ? ST_LONGCIG : 0u;
+                const bool on = !(k + 1 >= a.n_seg || a.entry[k + 1] != NONE);
+                if (on) { a.entry[k + 1] = s_end; a.dirty[k + 1] = 0; }
+                s_off = s_end; s_go = on ? 1 : 0;
+            }
+        } else if (t == 0) {
             uint64_t off = s_off;
             const RdLds rd{a.s, rw, w0, w1 > w0 ? w1 : w0};
             const bool on = a.side16 ? chase_one<RdLds, 2>(a, k, &off, rd) : chase_one<RdLds, 0>(a, k, &off, rd);
@@ -496,7 +546,7 @@ int k0_frame(bgp_ctx* c) {
     for (;;) {
         {
             TimedRegion t(c, n_list ? "k0_rechase" : "k0_chase", 0);
-            if (n_list) hipLaunchKernelGGL(k0_rechase, dim3(n_list), dim3(256), (size_t)seg + 96, c->stream, a, a.list, n_list);
+            if (n_list) hipLaunchKernelGGL(k0_rechase, dim3(n_list), dim3(256), (((size_t)seg + 96 + 15) & ~(size_t)15) + 4 * ((size_t)seg / 36 + 2) + 16, c->stream, a, a.list, n_list);
             else hipLaunchKernelGGL(k0_chase, dim3(lane_blocks), dim3(256), 0, c->stream, a);
         }
         BGP_HIP(hipMemsetAsync(a.status + 1, 0, 4, c->stream));
