@@ -43,7 +43,7 @@ int flush_core(bgp_ctx* c, uint32_t what) {
     if (frame_mode() == 1) { rc = k012_stream_decode(c, what); if (rc < 0) return rc; }
     if (rc == 1) {                                       // K0, then K1 and K2
         const bool lds = lds_mode() && (what & BGP_FETCH_ALL) == BGP_FETCH_ALL;
-        c->seg_bytes_wanted = lds ? k12_lds_segment_bytes() : 0; c->seg_window_shift = lds ? k12_lds_window_shift() : 0;
+        c->seg_bytes_wanted = lds ? k12_lds_segment_bytes(c->stream_len) : 0; c->seg_window_shift = lds ? k12_lds_window_shift() : 0;
         rc = k0_frame(c);
         c->seg_bytes_wanted = 0; c->seg_window_shift = 0;
         if (rc < 0) return rc;

@@ -1318,7 +1318,9 @@ int k012_stream_decode(bgp_ctx* c, uint32_t what) {
 #endif
 static_assert((SD_C & (SD_C - 1)) == 0, "window = 1 << shift");
 bool k12_lds_applies(const bgp_ctx* c, uint32_t what) { return c->table_pending && c->seg_windows && c->seg_bytes == SD_C * c->seg_windows && (what & BGP_FETCH_ALL) == BGP_FETCH_ALL && c->n_seg * c->seg_windows < 0x7FFFFFFFull; }
-uint32_t k12_lds_segment_bytes() { return SD_C * BGP_LDS_WIN_PER_SEG; }
+// (a stream of up to a GB or two has too few segments to fill the device with chases -- one lane each, ~230 dependent hops at 64 KiB:
+// 0.17 ms whatever the size below ~100 MB --: one window a segment then, twice the lanes and half the hops)
+uint32_t k12_lds_segment_bytes(uint64_t stream_len) { return SD_C * (stream_len < (2048ull << 20) ? 1u : (uint32_t)BGP_LDS_WIN_PER_SEG); }
 uint32_t k12_lds_window_shift() { uint32_t s = 0; while ((1u << s) < SD_C) ++s; return s; }
 int k12_lds_decode(bgp_ctx* c, uint32_t what) {
     const uint64_t n = c->n_records;
