@@ -100,19 +100,38 @@ __global__ __launch_bounds__(256) void k0_guess_wide(FrameArgs a) {
     }
     __syncthreads();
     uint64_t found = s_found;
-    for (uint64_t base = beg + 64 * wv; found == NONE && base - 64 * wv < lim; base += 256) {
+    // 1024 candidates a step, four to a thread: block_size and refID of all four are requested together (what turns most candidates
+    // down, as in plausible()); a lane tests in full what passes them -- every lane its own, side by side: inside a long read's CIGAR
+    // every aligned offset passes the first two tests -- and only the successor test of a full pass is the wave's.  With 256 a step
+    // the first record start of a 4 MiB segment of long reads -- tens of KB in -- was ~100 dependent steps (cfg5: 0.66 ms).
+    for (uint64_t base = beg; found == NONE && base < lim; base += 1024) {
         uint64_t mine = NONE;
-        const uint64_t o = base + lane;
-        uint32_t bs = 0;
-        const bool ok = o < lim && plausible(a.s, a.len, o, a.ref_bound, &bs, names);
-        unsigned long long m = __ballot(ok);
-        while (m) {
-            const int l = __ffsll((long long)m) - 1;
-            const uint32_t bsl = __shfl(bs, l, 64);
-            const uint64_t nxt = base + l + 4 + bsl;
-            uint32_t dummy;
-            if (a.len - nxt < 4 || plausible(a.s, a.len, nxt, a.ref_bound, &dummy, names)) { mine = base + l; break; }
-            m &= m - 1;
+        uint32_t pre[4][2], bs4[4]; bool ok4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint64_t o = base + 256u * u + 64u * wv + lane;
+            pre[u][0] = pre[u][1] = 0u;
+            if (o < lim && o + 36 <= a.len) __builtin_memcpy(pre[u], a.s + o, 8);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint64_t o = base + 256u * u + 64u * wv + lane;
+            const uint32_t bs0 = pre[u][0];
+            const bool quick = o < lim && o + 36 <= a.len && bs0 >= 33u && bs0 <= (1u << 30) && (uint64_t)bs0 <= a.len - o - 4 && (int32_t)pre[u][1] >= -1 && (int32_t)pre[u][1] < a.ref_bound;
+            bs4[u] = 0;
+            ok4[u] = quick && plausible(a.s, a.len, o, a.ref_bound, &bs4[u], names);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            unsigned long long m = mine == NONE ? __ballot(ok4[u]) : 0ull;
+            while (m) {
+                const int l = __ffsll((long long)m) - 1;
+                const uint32_t bsl = __shfl(bs4[u], l, 64);
+                const uint64_t ol = base + 256u * u + 64u * wv + l, nxt = ol + 4 + bsl;
+                uint32_t dummy;
+                if (a.len - nxt < 4 || plausible(a.s, a.len, nxt, a.ref_bound, &dummy, names)) { mine = ol; break; }
+                m &= m - 1;
+            }
         }
         if (lane == 0 && mine != NONE) atomicMin(&s_found, (unsigned long long)mine);
         __syncthreads();
