@@ -448,12 +448,16 @@ __global__ __launch_bounds__(256) void k1_emit(EmitArgs a) {
 // basesCovered() of records with long CIGARs (read.d:255-262): a lane summing thousands of ops serially
 // stalls its whole wave in k1_emit, so those records are finished here, one wave per record, 64 ops per
 // coalesced load and a wave reduction.
-__global__ __launch_bounds__(256) void k1_long_cigar(const uint8_t* s, bgp_record* rec, uint64_t n) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+// rpw: records a wave looks after (its first lanes hold them).  A wave walks its long records one after the other, so a stream of
+// few, long reads wants few records a wave (cfg5: 200 k records are 3125 waves of 64 -- a chain of 64 x 8 round trips each on a device
+// with 8192 wave slots -- or 25 000 waves of 8); a stream of 10^8 short reads with the odd long CIGAR wants 64.
+__global__ __launch_bounds__(256) void k1_long_cigar(const uint8_t* s, bgp_record* rec, uint64_t n, uint32_t rpw) {
     const int lane = threadIdx.x & 63;
+    const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const uint64_t i = wave * rpw + (uint32_t)lane;
     bgp_record r{};
     bool lng = false;
-    if (i < n) { r = rec[i]; lng = (r.flag_nc & 0xFFFFu) > LONG_CIGAR && !((r.flag_nc >> 16) & 0x4u); }
+    if ((uint32_t)lane < rpw && i < n) { r = rec[i]; lng = (r.flag_nc & 0xFFFFu) > LONG_CIGAR && !((r.flag_nc >> 16) & 0x4u); }
     unsigned long long m = __ballot(lng);
     while (m) {
         const int src = __ffsll((long long)m) - 1;
@@ -637,7 +641,7 @@ int k1_table(bgp_ctx* c) {
         TimedRegion t(c, "k1_emit", n * (36 + 32 + 16) + sc * 4);
         hipLaunchKernelGGL(k1_emit, dim3(lane_blocks), dim3(256), 0, c->stream, e);
         if (c->long_cigar)                // only streams that hold a long CIGAR pay for the extra pass
-            hipLaunchKernelGGL(k1_long_cigar, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->d_stream, e.rec, n);
+            hipLaunchKernelGGL(k1_long_cigar, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->d_stream, e.rec, n, 64u);
     }
     BGP_HIP(hipGetLastError());
     return BGP_OK;
@@ -647,7 +651,9 @@ int k1_table(bgp_ctx* c) {
 // basesCovered() of long-CIGAR records after the fused K1+K2 wrote the table (same pass k1_table runs)
 int k1_finish_long_cigars(bgp_ctx* c) {
     if (!c->long_cigar || !c->n_records) return BGP_OK;
-    hipLaunchKernelGGL(k1_long_cigar, dim3((unsigned)((c->n_records + 255) / 256)), dim3(256), 0, c->stream, c->d_stream, c->d_rec.as<bgp_record>(), c->n_records);
+    const uint32_t rpw = c->n_records < (4ull << 20) ? 8u : 64u;
+    const uint64_t waves = (c->n_records + rpw - 1) / rpw;
+    hipLaunchKernelGGL(k1_long_cigar, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, c->stream, c->d_stream, c->d_rec.as<bgp_record>(), c->n_records, rpw);
     BGP_HIP(hipGetLastError());
     return BGP_OK;
 }
