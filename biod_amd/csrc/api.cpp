@@ -50,8 +50,11 @@ int flush_core(bgp_ctx* c, uint32_t what) {
         c->flushed = true;
         if (lds && k12_lds_applies(c, what)) BGP_TRY(k12_lds_decode(c, what));      // rows and arenas from LDS windows: the stream is read once more, not twice
         else {
+            c->defer_long_cigar = (what & BGP_FETCH_CIGAR) != 0 && fuse_mode() != 1;      // the unpack below reads every CIGAR anyway
             if (fuse_mode() != 1) BGP_TRY(ensure_table(c));  // K1; only the fused experiment (BGP_FUSE_MODE=1) defers it to the decode
+            c->defer_long_cigar = false;
             if (what) { if (c->table_pending) BGP_TRY(k12_fused_decode(c, what)); else BGP_TRY(k2_decode(c, what)); }
+            if (c->long_cigar_deferred) { c->long_cigar_deferred = false; BGP_TRY(k1_finish_long_cigars(c)); }      // (not taken up: by its own kernel after all)
         }
     }
     c->flushed = true;

@@ -129,6 +129,7 @@ struct bgp_ctx {
     DevBuf d_seg_sub;
     bool frame_tolerant_tail = false; uint64_t frame_tail = 0;   // batched staging (batch.cpp): a stream may end inside a record; where the record chain stopped
     bool table_compacted = false;                     // a region filter compacted the record table: records the filter dropped still lie between the kept ones in the stream
+    bool defer_long_cigar = false, long_cigar_deferred = false;   // a CIGAR unpack follows the record table at once: it sums the long CIGARs it copies anyway (k2_unpack) instead of k1_long_cigar reading them first
     bool table_pending = false, long_cigar = false;   // the record table is written lazily: by k1_table, or by the fused K1+K2 if a decode comes first
     DevBuf d_seg_list; DevBuf d_scan_tmp; HostBuf h_mail;                // (h_mail: pinned, written by k_mail)
     DevBuf d_sd_desc; int sd_timer_idx = -1;         // single-pass decode (decode.hip: k_stream_decode): control words + one 64-byte descriptor per chunk

@@ -24,6 +24,7 @@ struct DecArgs {
     const uint8_t* s; uint64_t stream_len; const bgp_record* rec; const uint64_t* seq_off; const uint64_t* cigar_off; uint64_t n;
     uint8_t* seq; uint8_t* qual; uint32_t* cigar;
     uint32_t rb;          // records per workgroup of k2_unpack (<= RB): fewer when records are long, so that the grid still fills the device
+    bgp_record* rec_fix;  // k2_unpack: records with more than BGP_LONG_CIGAR ops get their end_position here, from the ops it copies (null: k1_long_cigar has done it)
 };
 
 __device__ __forceinline__ uint8_t nt16_char(uint32_t code) {      // base.d:85
@@ -32,7 +33,7 @@ __device__ __forceinline__ uint8_t nt16_char(uint32_t code) {      // base.d:85
     return (uint8_t)(((code & 8u) ? hi : lo) >> ((code & 7u) * 8));
 }
 
-struct RecInfo { uint64_t cig_ptr, seq_ptr, qual_ptr; };
+struct RecInfo { uint64_t cig_ptr, seq_ptr, qual_ptr; uint32_t sum_cov, pad; };      // sum_cov: this record's basesCovered is summed while its CIGAR is copied (read.d:255-262)
 
 // largest j in [0, cnt) with off[j] <= b (caller guarantees off[0] <= b < off[cnt]); `g` is a guess
 __device__ __forceinline__ int find_rec(const uint64_t* off /*LDS, cnt+1*/, int cnt, uint64_t b, int g) {
@@ -81,13 +82,25 @@ __device__ __forceinline__ uint4 merge16(uint4 a, uint4 b, uint32_t n) {
 
 // Unpacks the `cnt` consecutive records whose arena offsets and section pointers sit in LDS.
 template <bool SEQ, bool QUAL, bool CIG>
-__device__ __forceinline__ void unpack_group(const DecArgs& a, int cnt, const uint64_t* s_seq_off, const uint64_t* s_cig_off, const RecInfo* s_info) {
+__device__ __forceinline__ void unpack_group(const DecArgs& a, int cnt, const uint64_t* s_seq_off, const uint64_t* s_cig_off, const RecInfo* s_info, uint32_t* s_cov = nullptr) {
     if (CIG) {
         const uint64_t c0 = s_cig_off[0], c1 = s_cig_off[cnt];
         const float inv = c1 > c0 ? (float)cnt / (float)(c1 - c0) : 0.f;
         for (uint64_t i = c0 + threadIdx.x; i < c1; i += blockDim.x) {
             const int j = find_rec(s_cig_off, cnt, i, (int)((float)(i - c0) * inv));
-            a.cigar[i] = ld_u32(a.s + s_info[j].cig_ptr + 4 * (i - s_cig_off[j]));
+            const uint32_t op = ld_u32(a.s + s_info[j].cig_ptr + 4 * (i - s_cig_off[j]));
+            a.cigar[i] = op;
+            if (s_cov) {                                   // basesCovered of the long CIGARs on the way (a wave's ops are nearly always one record's: one LDS atomic a wave)
+                const uint32_t cov = s_info[j].sum_cov && cig_rc(op) ? op >> 4 : 0u;
+                const unsigned long long act = __ballot(true);
+                const int j0 = __shfl(j, __ffsll((long long)act) - 1, 64);
+                if (__ballot(j != j0) == 0) {
+                    uint32_t t = cov;
+#pragma unroll
+                    for (int d = 32; d >= 1; d >>= 1) t += (uint32_t)__shfl_xor((int)t, d, 64);
+                    if (t && (int)(threadIdx.x & 63) == __ffsll((long long)act) - 1) atomicAdd(&s_cov[j0], t);
+                } else if (cov) atomicAdd(&s_cov[j], cov);
+            }
         }
     }
     if (!SEQ && !QUAL) return;
@@ -145,8 +158,10 @@ __global__ __launch_bounds__(256) void k2_unpack(DecArgs a) {
     __shared__ uint64_t s_seq_off[RB + 1];
     __shared__ uint64_t s_cig_off[RB + 1];
     __shared__ RecInfo s_info[RB];
+    __shared__ uint32_t s_cov[RB];
     const uint64_t r0 = (uint64_t)blockIdx.x * a.rb;
     const int cnt = (int)min((uint64_t)a.rb, a.n - r0);
+    const bool fix = CIG && a.rec_fix != nullptr;
     for (int j = threadIdx.x; j <= cnt; j += blockDim.x) {
         s_seq_off[j] = a.seq_off[r0 + j];
         s_cig_off[j] = a.cigar_off[r0 + j];
@@ -156,11 +171,17 @@ __global__ __launch_bounds__(256) void k2_unpack(DecArgs a) {
             ri.cig_ptr = r.rec_off + 36 + (r.bin_mq_nl & 0xFFu);                    // read.d:988-990
             ri.seq_ptr = ri.cig_ptr + 4ull * (r.flag_nc & 0xFFFFu);                 // read.d:992-994
             ri.qual_ptr = ri.seq_ptr + (uint64_t)((r.l_seq + 1) / 2);               // read.d:996-998
+            ri.sum_cov = fix && (r.flag_nc & 0xFFFFu) > BGP_LONG_CIGAR && !((r.flag_nc >> 16) & 0x4u) ? 1u : 0u; ri.pad = 0;      // read.d:257-259
             s_info[j] = ri;
+            s_cov[j] = 0;
         }
     }
     __syncthreads();
-    unpack_group<SEQ, QUAL, CIG>(a, cnt, s_seq_off, s_cig_off, s_info);
+    unpack_group<SEQ, QUAL, CIG>(a, cnt, s_seq_off, s_cig_off, s_info, fix ? s_cov : nullptr);
+    if (fix) {
+        __syncthreads();
+        for (int j = threadIdx.x; j < cnt; j += blockDim.x) if (s_cov[j]) atomicAdd(&a.rec_fix[r0 + j].end_pos, (int32_t)s_cov[j]);      // read.d:1382: position + basesCovered (the row held the position)
+    }
 }
 
 // ---------------------------------------------------------------------------------------------- K1 + K2 in one pass
@@ -1105,6 +1126,8 @@ int k2_decode(bgp_ctx* c, uint32_t what) {
     // 256 records a workgroup -- unless that leaves the device short of workgroups (200 k reads of 30 kb: 780 of them for 2048
     // slots, 9.5 ms): then as few records each as it takes to have ~16 k workgroups
     a.rb = (uint32_t)std::min<uint64_t>(RB, std::max<uint64_t>(1, n / 16384));
+    a.rec_fix = nullptr;
+    if (c->long_cigar_deferred && (what & BGP_FETCH_CIGAR)) { a.rec_fix = c->d_rec.as<bgp_record>(); c->long_cigar_deferred = false; }
     const unsigned blocks = (unsigned)((n + a.rb - 1) / a.rb);
     const bool S = what & BGP_FETCH_SEQ, Q = what & BGP_FETCH_QUAL, C = what & BGP_FETCH_CIGAR;
     uint64_t alg = n * 48;    // record table + two offsets read

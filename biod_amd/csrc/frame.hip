@@ -651,6 +651,7 @@ int k1_table(bgp_ctx* c) {
 // basesCovered() of long-CIGAR records after the fused K1+K2 wrote the table (same pass k1_table runs)
 int k1_finish_long_cigars(bgp_ctx* c) {
     if (!c->long_cigar || !c->n_records) return BGP_OK;
+    if (c->defer_long_cigar) { c->long_cigar_deferred = true; return BGP_OK; }      // (k2_decode does it on its way through the CIGARs)
     const uint32_t rpw = c->n_records < (4ull << 20) ? 8u : 64u;
     const uint64_t waves = (c->n_records + rpw - 1) / rpw;
     hipLaunchKernelGGL(k1_long_cigar, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, c->stream, c->d_stream, c->d_rec.as<bgp_record>(), c->n_records, rpw);
