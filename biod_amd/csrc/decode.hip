@@ -1177,7 +1177,7 @@ int k12_fused_decode(bgp_ctx* c, uint32_t what) {
     }
     const unsigned blocks = (unsigned)((c->n_seg + G_SEG - 1) / G_SEG);
     const bool S = what & BGP_FETCH_SEQ, Q = what & BGP_FETCH_QUAL, C = what & BGP_FETCH_CIGAR;
-    uint64_t alg = n * (36 + 32 + 16) + c->sum_ncig * 4;    // what k1_emit accounts for ...
+    uint64_t alg = n * (36 + 32 + 16) + (c->defer_long_cigar && c->long_cigar ? std::min<uint64_t>(c->sum_ncig, 4 * n) : c->sum_ncig) * 4;    // what k1_emit accounts for (the long CIGARs only when they are summed here, not by the unpack that follows) ...
     if (S) alg += (c->sum_lseq + 1) / 2 + c->sum_lseq;      // ... plus what k2_unpack accounts for, minus the table read back
     if (Q) alg += 2 * c->sum_lseq;
     if (C) alg += 8 * c->sum_ncig;
