@@ -219,6 +219,8 @@ int k5_entries(bgp_ctx* c, uint32_t run, uint64_t pos_begin, uint64_t pos_end, u
 int scan_exclusive_u64(bgp_ctx* c, const uint64_t* in, uint64_t* out, uint64_t n, uint64_t* total_host);   // scan.hip (out has n+1 entries)
 int scan_inclusive_max_u64(bgp_ctx* c, const uint64_t* in, uint64_t* out, uint64_t n);
 int scan_exclusive_u64x3(bgp_ctx* c, const uint64_t* const in[3], uint64_t* const out[3], uint64_t n, uint64_t* totals_host /* [3] or null */);   // three scans, three launches
+struct FillItem { void* p; uint64_t bytes; uint32_t value; };     // value: the byte every byte becomes
+int fill_many(bgp_ctx* c, const FillItem* items, int n_items);   // scan.hip: up to 8 device buffers (16-byte aligned) filled by one launch
 struct MailItem { const void* src; void* dst; uint32_t n; };
 int mail_fetch(bgp_ctx* c, const MailItem* items, int n_items);   // scan.hip: up to 8 small values from device memory with one kernel and one wait (0 items: just the wait)
 int k7_snp_simple(bgp_ctx* c, uint64_t col_index, uint64_t ref_index, uint64_t np, int min_cov, int min_wit);    // md.hip: d_snp[0..np) from d_columns/d_refbase

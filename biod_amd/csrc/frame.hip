@@ -559,10 +559,14 @@ int k0_frame(bgp_ctx* c) {
     const unsigned lane_blocks = (unsigned)((n_seg + 255) / 256);
     {
         TimedRegion t(c, "k0_guess", n_seg * 64);
-        BGP_HIP(hipMemsetAsync(a.dirty, 0x01, n_seg * 4, c->stream));        // every segment dirty (any non-zero)
-        BGP_HIP(hipMemsetAsync(a.seg_err, 0, n_seg * 4, c->stream));         // what a segment without an entry keeps: end NONE, no records
-        BGP_HIP(hipMemsetAsync(a.end, 0xFF, n_seg * 8, c->stream));
-        BGP_HIP(hipMemsetAsync(a.cnt, 0, n_seg * 8, c->stream)); BGP_HIP(hipMemsetAsync(a.lseq, 0, n_seg * 8, c->stream)); BGP_HIP(hipMemsetAsync(a.ncig, 0, n_seg * 8, c->stream));
+        {   // every segment dirty (any non-zero); what a segment without an entry keeps: end NONE, no records
+            const FillItem f[6] = {{a.dirty, n_seg * 4, 0x01u}, {a.seg_err, n_seg * 4, 0u}, {a.end, n_seg * 8, 0xFFu}, {a.cnt, n_seg * 8, 0u}, {a.lseq, n_seg * 8, 0u}, {a.ncig, n_seg * 8, 0u}};
+            if (((uintptr_t)a.seg_err & 15) == 0) BGP_TRY(fill_many(c, f, 6));
+            else {      // (seg_err sits behind dirty[n_seg] in one buffer: a multiple of four segments keeps it aligned)
+                BGP_HIP(hipMemsetAsync(a.dirty, 0x01, n_seg * 4, c->stream)); BGP_HIP(hipMemsetAsync(a.seg_err, 0, n_seg * 4, c->stream));
+                BGP_TRY(fill_many(c, f + 2, 4));
+            }
+        }
         // Second pass, only over segments the first found nothing in (their waves of the first pass have exited: same stream), with
         // the widest reference bound and without the printable-name test: a caller's wrong bgp_set_n_ref, or a file whose read names
         // are not printable, then costs this pass instead of one lane chasing the whole stream serially (measured on cfg3's model with

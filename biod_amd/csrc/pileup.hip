@@ -1835,9 +1835,7 @@ int k34_pileup(bgp_ctx* c) {
     memset(&c->pinfo, 0, sizeof c->pinfo);
     BGP_TRY(c->d_pstats.reserve(256));
     BGP_TRY(c->d_depth_hist.reserve((size_t)BGP_DEPTH_BINS * 8));
-    BGP_HIP(hipMemsetAsync(c->d_pstats.p, 0, 256, c->stream));
-    BGP_HIP(hipMemsetAsync(c->d_depth_hist.p, 0, (size_t)BGP_DEPTH_BINS * 8, c->stream));
-    BGP_HIP(hipMemsetAsync(c->d_status.p, 0, 64, c->stream));
+    { const FillItem f[3] = {{c->d_pstats.p, 256, 0u}, {c->d_depth_hist.p, (uint64_t)BGP_DEPTH_BINS * 8, 0u}, {c->d_status.p, 64, 0u}}; BGP_TRY(fill_many(c, f, 3)); }
     if (n == 0) { BGP_HIP(hipStreamSynchronize(c->stream)); c->pinfo.device_depth_hist = c->d_depth_hist.as<uint64_t>(); return BGP_OK; }
     if (n >= (1ull << 32)) return BGP_EINVAL;                  // read_ordinal is 32 bit
     BGP_TRY(c->d_pmax_end.reserve(n * 8)); BGP_TRY(c->d_pmax_pos.reserve(n * 8));
@@ -1987,9 +1985,8 @@ int k34_pileup(bgp_ctx* c) {
         // the plan: descriptor slabs per window, from one pass over the reads
         BGP_TRY(c->d_slab.reserve(tile_base * (size_t)SLAB_CAP * 8));
         BGP_TRY(c->d_wcount.reserve((tile_base + 1) * 4)); BGP_TRY(c->d_wdel.reserve((tile_base + 2) * 4)); BGP_TRY(c->d_wslow.reserve((tile_base + 2) * 4));
-        BGP_HIP(hipMemsetAsync(c->d_wcount.p, 0, (tile_base + 1) * 4, c->stream));
-        BGP_HIP(hipMemsetAsync(c->d_wdel.p, 0, (tile_base + 2) * 4, c->stream));
-        BGP_HIP(hipMemsetAsync(c->d_wslow.p, 0, (tile_base + 2) * 4, c->stream));
+        BGP_TRY(c->d_col_lo.reserve((tile_base + 65536) * 32));          // (k4_acc's totals: zeroed here with the planner's arrays, one launch)
+        { const FillItem f[4] = {{c->d_wcount.p, (tile_base + 1) * 4, 0u}, {c->d_wdel.p, (tile_base + 2) * 4, 0u}, {c->d_wslow.p, (tile_base + 2) * 4, 0u}, {c->d_col_lo.p, (tile_base + 65536) * 32, 0u}}; BGP_TRY(fill_many(c, f, 4)); }
         {
             TimedRegion tp(c, "k4_plan", c->n_records * 48);
             PlanArgs pa;
@@ -2008,7 +2005,7 @@ int k34_pileup(bgp_ctx* c) {
         }
         c->ck_w = a.ck ? tw : 0;                     // K5 resumes long reads from these checkpoints
         TimedRegion t(c, "k4_tile", used);
-        BGP_HIP(hipMemsetAsync(a.tile_stats, 0, (tile_base + WG_SLOTS) * 32, c->stream));      // the accumulate path adds its totals wave by wave
+        if (long_stream) BGP_HIP(hipMemsetAsync(a.tile_stats, 0, (tile_base + WG_SLOTS) * 32, c->stream));      // the accumulate path adds its totals wave by wave (zeroed with the planner's arrays above)
         if (!long_stream) {
             GArgs g;
             g.s = a.s; g.slab = (const unsigned long long*)c->d_slab.p; g.wcount = c->d_wcount.as<uint32_t>(); g.wdel = c->d_wdel.as<int32_t>(); g.tiles = a.tiles; g.n_tiles = tile_base;

@@ -2,6 +2,7 @@
 // Three passes (block reduce -> scan of block totals -> block scan with carry-in); wave64 shuffles
 // inside a wave, LDS only for the 4 wave totals of a 256-thread block.
 #include "common.h"
+#include <algorithm>
 
 namespace {
 
@@ -158,7 +159,34 @@ __global__ __launch_bounds__(256) void k_mail(MailArgs a) {
         for (uint32_t b = threadIdx.x; b < a.n[k]; b += 256) a.box[a.off[k] + b] = a.src[k][b];
 }
 
+// several buffers filled by ONE launch (blockIdx.y = the buffer): a stage of the path zeroes half a dozen small arrays before its first
+// kernel, each a launch of its own through hipMemsetAsync -- a third of a step's ~45 launches, which is what a small stream's step is
+struct FillArgs { uint8_t* p[8]; unsigned long long n[8]; uint32_t v[8]; };
+__global__ __launch_bounds__(256) void k_fill_many(FillArgs a) {
+    uint8_t* p = a.p[blockIdx.y];
+    const unsigned long long n = a.n[blockIdx.y];
+    const uint32_t w = a.v[blockIdx.y] * 0x01010101u;
+    const unsigned long long n16 = n >> 4;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < n16; i += (unsigned long long)gridDim.x * 256) reinterpret_cast<uint4*>(p)[i] = make_uint4(w, w, w, w);
+    if (blockIdx.x == 0 && threadIdx.x < (n & 15)) p[(n16 << 4) + threadIdx.x] = (uint8_t)w;
+}
+
 }  // namespace
+
+int fill_many(bgp_ctx* c, const FillItem* items, int n_items) {
+    if (n_items <= 0) return BGP_OK;
+    if (n_items > 8) return BGP_EINVAL;
+    FillArgs a;
+    unsigned long long most = 0;
+    for (int k = 0; k < n_items; ++k) {
+        if (((uintptr_t)items[k].p & 15) != 0) return BGP_EINVAL;      // (device buffers are 256-byte aligned; a pointer into one must keep 16)
+        a.p[k] = (uint8_t*)items[k].p; a.n[k] = items[k].bytes; a.v[k] = items[k].value; most = std::max<unsigned long long>(most, items[k].bytes);
+    }
+    const unsigned gx = (unsigned)std::min<unsigned long long>(2048, std::max<unsigned long long>(1, (most / 16 + 255) / 256));
+    hipLaunchKernelGGL(k_fill_many, dim3(gx, (unsigned)n_items), dim3(256), 0, c->stream, a);
+    BGP_HIP(hipGetLastError());
+    return BGP_OK;
+}
 
 int scan_exclusive_u64x3(bgp_ctx* c, const uint64_t* const in[3], uint64_t* const out[3], uint64_t n, uint64_t* totals_host) {
     const uint64_t nb = (n + TILE - 1) / TILE;
