@@ -605,7 +605,15 @@ __device__ __forceinline__ uint32_t sd_chase_sub(const SdArgs& a, const uint32_t
         else {
             const int32_t bs = (int32_t)wl32(w, o);
             if (bs < 0) err = ST_EINVAL;
-            else if ((uint64_t)bs > a.len - off - 4) { if (!a.tolerant) err = ST_ETRUNC; }      // readrange.d:169
+            else if ((uint64_t)bs > a.len - off - 4) {                                          // readrange.d:169; in a batch the rest may still be to come -- but only of a record that can exist (as in k0_chase)
+                if (!a.tolerant) err = ST_ETRUNC;
+                else if (bs < 32 || (uint32_t)bs > (1u << 30)) err = ST_EINVAL;
+                else if (a.len - off >= 24) {
+                    const uint32_t bmn = wl32(w, o + 12), fnc = wl32(w, o + 16); const int32_t lseq = (int32_t)wl32(w, o + 20);
+                    const uint32_t l_name = bmn & 0xFFu, n_cig = fnc & 0xFFFFu;
+                    if (lseq < 0 || l_name == 0 || 32ull + l_name + 4ull * n_cig + (uint64_t)((lseq + 1) / 2) + (uint64_t)lseq > (uint64_t)bs) err = ST_EINVAL;
+                }
+            }
             else err = ST_EINVAL;                          // bs < 32
         }
     }
