@@ -1352,6 +1352,9 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 #ifndef BGP_A_MAPCAP
 #define BGP_A_MAPCAP 1408
 #endif
+#ifndef BGP_A_PERM
+#define BGP_A_PERM 0                          // > 0 (odd): a batch takes every n_bat-th descriptor, neighbours in the batch this many picks apart
+#endif
 constexpr int AT = 256;                       // threads of a k4_acc workgroup
 constexpr int ANW = AT / 64;                  // waves
 constexpr int ABPW = (W / 64) / ANW;          // 64-position blocks a wave flushes
@@ -1438,12 +1441,20 @@ template <bool ROWS> __global__ __launch_bounds__(AT, BGP_A_MINW) void k4_acc(GA
         if (pad) continue;                                   // on the general kernel's list
         const unsigned long long* slab = a.slab + tile * (uint64_t)SLAB_CAP;
         // ---- accumulate: batches of A_DB descriptors, drawn from misc[0] (a wave's NEXT batch is requested before it works on the current one)
+        const uint32_t n_bat = (n_desc + (uint32_t)L::DRAW - 1) / (uint32_t)L::DRAW;
         auto draw = [&](uint32_t* base_out) {
             uint32_t b = 0;
             if (lane == 0) b = atomicAdd(&misc[0], 1u);
             b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
             *base_out = b * (uint32_t)L::DRAW;
             unsigned long long dd = 0;
+#if BGP_A_PERM
+            // a batch is every n_bat-th descriptor of the slab (the planner appends in file order, near enough): its reads lie all over the
+            // window, and neighbours in the batch are BGP_A_PERM x 64 / n_desc windows apart -- the three reads whose lanes share an LDS
+            // instruction hit different stretches of banks instead of the same one three times over
+            if (!ROWS) { const uint32_t idx = (((uint32_t)BGP_A_PERM * (uint32_t)lane) & 63u) * n_bat + b; if (b < n_bat && idx < n_desc) dd = slab[idx]; }
+            else
+#endif
             if (*base_out < n_desc && lane < L::DRAW && *base_out + (uint32_t)lane < n_desc) dd = slab[*base_out + lane];
             return dd;
         };
@@ -1586,6 +1597,279 @@ template <bool ROWS> __global__ __launch_bounds__(AT, BGP_A_MINW) void k4_acc(GA
         }
         r_ncol += ncol; r_nsum += nsum; r_mx = max(r_mx, mx); r_scov += scov;
         __syncthreads();                                     // the counters are zero again and misc[8..] is read: the next window may add
+    }
+    {   // the range's totals: wave reductions with DPP, then one atomic per wave and total (the slots were zeroed by the host)
+        const uint32_t w_ncol = wave_sum_u32(r_ncol), w_nsum = wave_sum_u32(r_nsum), w_mx = wave_max_u32(r_mx);
+        const uint32_t s0 = wave_sum_u32((uint32_t)r_scov & 0xFFFFu), s1 = wave_sum_u32((uint32_t)(r_scov >> 16) & 0xFFFFu), s2 = wave_sum_u32((uint32_t)(r_scov >> 32) & 0xFFFFu), s3 = wave_sum_u32((uint32_t)(r_scov >> 48));
+        if (lane == 0) {
+            unsigned long long* ts = a.tile_stats + (a.n_tiles + blockIdx.x) * 4;
+            if (w_ncol) atomicAdd(&ts[0], (unsigned long long)w_ncol);
+            const unsigned long long sc = ((unsigned long long)s3 << 48) + ((unsigned long long)s2 << 32) + ((unsigned long long)s1 << 16) + s0;
+            if (sc) atomicAdd(&ts[1], sc);
+            if (w_mx) atomicMax(&ts[2], (unsigned long long)w_mx);
+            if (w_nsum) atomicAdd(&ts[3], (unsigned long long)w_nsum);
+        }
+    }
+    __syncthreads();
+    for (int b = t; b < HB; b += AT) { const uint32_t h = hist[b]; if (h) atomicAdd(&a.hist[b], (unsigned long long)h); }
+}
+
+// ---------------------------------------------------------------------------------------------- K4, accumulate path, round 4: lane = piece, byte planes
+//
+// k4_acc (above, still the executor of streams with long reads' ROW descriptors) spends ~80 VALU instructions per lane-chunk of
+// eight positions -- a byte map and a 16-byte LDS read to find the chunk's descriptor, the limits of the chunk, one table
+// lookup, one address and one LDS atomic PER BASE -- and round 3's counters said that is what binds it (VALU issuing 60-70 % of
+// the time, LDS 46 %).  k4_acc2 runs the same plan (k4_plan's SEG / DEL descriptors) with a quarter of the instructions:
+//
+//   * a LANE owns a PIECE of a SEG descriptor -- up to 11 chunks of eight window-aligned positions -- for the piece's whole life:
+//     its packed bases are in registers (three 16-byte loads from the chunk-aligned origin), the loop over the chunks is unrolled,
+//     every register index and every LDS offset is static, and nothing is looked up per chunk;
+//   * no base is handled alone.  The four even and the four odd positions of a chunk are two words of nibble codes, one byte a
+//     position; v_perm_b32 with the codes as SELECTORS turns a word into the four "is A" bytes (0 / 1), another into "is C" ...:
+//     eight words of byte-wide increments per chunk, added to LDS by eight ds_add_u32 whose addresses differ by constants
+//     (class x even/odd planes of 136 words).  Positions outside the piece get selector 0 ('=': in no plane) by the AND that
+//     isolates the nibbles; the three codes v_perm cannot index (13..15: it answers 0xFF) are forced to 12 (answers 0) first;
+//   * "any other base" is not counted: coverage comes from a difference array (+1 / -1 per SEG descriptor, as '-' always did),
+//     other = coverage - A - C - G - T.  The same array says how deep the window is: the byte-wide counters hold 255, a window
+//     deeper than that is handed to the general kernel (k4_tile) by the flush -- nothing was written for it -- which at the
+//     reads' ~150 bases is past the slab's 1024 descriptors anyway;
+//   * lanes next to each other hold pieces a few positions apart: the same or neighbouring words, i.e. the same LDS banks
+//     (scratch/r4/lds_plane_bench.hip: 93 clocks a chunk-step against 34 for distinct consecutive words).  The counters exist
+//     FOUR times, copy = lane & 3, a copy 8 banks further: measured 34 clocks.  The flush adds the copies up;
+//   * pieces come from a ring per wave (LDS): a wave draws 64 descriptors, does their per-descriptor atomics ('-', starts,
+//     coverage), appends their pieces -- a 150-base read is two of 10 chunks -- and works off full batches of 64.
+//
+// Same descriptors, same columns: every pileup test checks them against the oracle.
+#ifndef BGP_ACC2_MINW
+#define BGP_ACC2_MINW 4
+#endif
+constexpr int P_CH = 11;                      // chunks of a piece at most (12 dwords loaded: chunk j of an odd-nibble piece wants dword j + 1 too)
+constexpr int P_PLW = W / 8 + 8;              // words of a plane (class x even/odd positions): one per chunk, + 8 so that ...
+constexpr int P_CPW = 8 * P_PLW + 8;          // ... a plane and a copy both start 8 banks after the one before
+constexpr int P_QCAP = 256;                   // entries of a wave's ring: < 64 left over + 3 pieces x 64 descriptors
+struct A2Lay {
+    static constexpr int CNT = 0;                               // 4 copies x P_CPW x u32
+    static constexpr int COVD = CNT + 4 * P_CPW * 4;            // (W + 8) x u32: SEG coverage, difference array
+    static constexpr int DELD = COVD + (W + 8) * 4;             // (W + 8) x u32: '-', difference array
+    static constexpr int NST = DELD + (W + 8) * 4;              // W x u16
+    static constexpr int HIST = NST + W * 2;                    // HB x u32 (kept for the workgroup's whole range)
+    static constexpr int QUE = (HIST + HB * 4 + 15) & ~15;      // ANW x P_QCAP x u64; the flush's staging (W x 8 bytes) lies over it
+    static constexpr int MISC = QUE + ANW * P_QCAP * 8;
+    static constexpr int BYTES = MISC + 256;
+};
+static_assert(ANW * P_QCAP * 8 >= W * 8, "the flush stages a window's sums where the rings are");
+static_assert(BGP_ACC2_MINW * A2Lay::BYTES <= 160 * 1024, "k4_acc2 workgroups per CU");
+static_assert(W == 1024 && AT == 256, "k4_acc2 geometry: a thread per (chunk, even/odd) in the flush");
+
+// one word of nibble codes (a byte a position; 0 where the position is not the piece's) -> its increments of the A, C, G, T planes
+__device__ __forceinline__ void planes_of_codes(uint32_t sel, uint32_t& pa, uint32_t& pc, uint32_t& pg, uint32_t& pt) {
+    const uint32_t bad = __builtin_amdgcn_perm(0u, 0u, sel);                       // 0xFF where the code is 13..15 (v_perm: "selector >= 13 -> 0xFF")
+    sel = (sel & ~bad) | (bad & 0x0C0C0C0Cu);                                     // ... those become 12 ("-> 0x00"): in no plane
+    pa = __builtin_amdgcn_perm(0u, 0x00000100u, sel);                             // code 1
+    pc = __builtin_amdgcn_perm(0u, 0x00010000u, sel);                             // code 2
+    pg = __builtin_amdgcn_perm(0x00000001u, 0u, sel);                             // code 4
+    pt = __builtin_amdgcn_perm(0u, 0x00008000u, sel) & 0x01010101u;               // code 8 selects "the sign of table byte 1": 0xFF (code 1 itself: 0x80)
+}
+
+__global__ __launch_bounds__(AT, BGP_ACC2_MINW) void k4_acc2(GArgs a) {
+    using L = A2Lay;
+    extern __shared__ __attribute__((aligned(16))) uint8_t alds[];
+    uint32_t* const cnt = reinterpret_cast<uint32_t*>(alds + L::CNT);
+    uint32_t* const covd = reinterpret_cast<uint32_t*>(alds + L::COVD);
+    uint32_t* const deld = reinterpret_cast<uint32_t*>(alds + L::DELD);
+    uint32_t* const nst = reinterpret_cast<uint32_t*>(alds + L::NST);
+    uint32_t* const hist = reinterpret_cast<uint32_t*>(alds + L::HIST);
+    uint32_t* const misc = reinterpret_cast<uint32_t*>(alds + L::MISC);      // [0] next draw of the window, [8..11] '-' totals of the waves, [12..15] coverage totals, [16..19] deepest SEG coverage
+    uint2* const stg = reinterpret_cast<uint2*>(alds + L::QUE);
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    unsigned long long* const ring = reinterpret_cast<unsigned long long*>(alds + L::QUE) + wave * P_QCAP;
+    const uint64_t nbt = a.n_tiles, per = (nbt + gridDim.x - 1) / gridDim.x;
+    const uint64_t tile_end = min(nbt, ((uint64_t)blockIdx.x + 1) * per);
+    uint64_t tile = (uint64_t)blockIdx.x * per;
+    if (tile >= tile_end) return;
+    for (int i = t; i < L::QUE / 4; i += AT) cnt[i] = 0;                       // counters, difference arrays, starts (a window leaves them zeroed again), hist
+    if (t < 32) misc[t] = 0;
+    struct Pre { uint2 col; uint4 tt; uint32_t n; int32_t wd; };                // the next window's header, a window ahead, in vector registers (see k4_acc)
+    auto prefetch = [&](uint64_t w) {
+        Pre p;
+        const char* tp = reinterpret_cast<const char*>(a.tiles + w);
+        __builtin_memcpy(&p.col, tp + 16, 8);
+        __builtin_memcpy(&p.tt, tp + 24, 16);
+        p.n = a.wcount[w]; p.wd = a.wdel[w];
+        return p;
+    };
+    Pre pre = prefetch(tile);
+    uint32_t r_ncol = 0, r_nsum = 0, r_mx = 0; unsigned long long r_scov = 0;
+    uint32_t* const cbase0 = cnt + (lane & 3) * P_CPW;
+    __syncthreads();
+    for (; tile < tile_end; ++tile) {
+        asm volatile("; window header settled" : "+v"(pre.col.x), "+v"(pre.col.y), "+v"(pre.tt.x), "+v"(pre.tt.y), "+v"(pre.tt.z), "+v"(pre.tt.w), "+v"(pre.n), "+v"(pre.wd));
+        const uint64_t col_out = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)pre.col.y) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)pre.col.x);
+        const uint32_t T0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)pre.tt.x), Tend = (uint32_t)__builtin_amdgcn_readfirstlane((int)pre.tt.y);
+        const uint32_t pad = (uint32_t)__builtin_amdgcn_readfirstlane((int)pre.tt.w);
+        const uint32_t n_desc = (uint32_t)__builtin_amdgcn_readfirstlane((int)pre.n);
+        const int32_t wd = __builtin_amdgcn_readfirstlane(pre.wd);
+        if (tile + 1 < tile_end) pre = prefetch(tile + 1);
+        if (pad) continue;                                   // on the general kernel's list
+        const unsigned long long* slab = a.slab + tile * (uint64_t)SLAB_CAP;
+        // ---- accumulate
+        auto draw = [&](uint32_t* base_out) {
+            uint32_t b = 0;
+            if (lane == 0) b = atomicAdd(&misc[0], 1u);
+            b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
+            *base_out = b * 64u;
+            unsigned long long dd = 0;
+            if (*base_out + (uint32_t)lane < n_desc) dd = slab[*base_out + lane];
+            return dd;
+        };
+        // one batch: lane = piece.  Entry: [41:0] nibble address of the piece's chunk-aligned origin in the stream, [48:42] the origin's chunk
+        // of the window, [51:49] first position of the piece in its first chunk, [58:52] one past its last position, from the origin
+        auto work = [&](uint32_t qh, uint32_t nb) {
+            unsigned long long e = 0;
+            if ((uint32_t)lane < nb) e = ring[(qh + (uint32_t)lane) & (uint32_t)(P_QCAP - 1)];
+            const uint64_t no = e & ((1ull << 42) - 1);
+            const uint32_t eh = (uint32_t)(e >> 32);
+            const uint32_t m0 = (eh >> 10) & 127u, s = (eh >> 17) & 7u, tl = (eh >> 20) & 127u;      // tl = 0: no piece
+            const uint32_t par = (uint32_t)no & 1u;
+            const uint8_t* b0 = a.s + (no >> 1);
+            const uint32_t need = (par + tl + 1u) >> 1;                                  // bytes from b0 on (branch-free: a dword nobody needs is loaded from b0 again)
+            uint4 q0, q1, q2;
+            __builtin_memcpy(&q0, b0, 16);
+            __builtin_memcpy(&q1, b0 + (need > 16u ? 16 : 0), 16);
+            __builtin_memcpy(&q2, b0 + (need > 32u ? 32 : 0), 16);
+            const uint32_t R[12] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w};
+            const uint32_t jl = (tl - 1u) >> 3, rr = tl - 8u * jl;                        // the piece's last chunk and its positions there (1..8)
+            const uint32_t vt_e = 0x0F0F0F0Fu >> (8u * (4u - ((rr + 1u) >> 1)));
+            const uint32_t vt_o = (uint32_t)(0x0F0F0F0Full >> (8u * (4u - (rr >> 1))));
+            const uint32_t vf_e = (uint32_t)(0x0F0F0F0Full << (8u * ((s + 1u) >> 1))), vf_o = 0x0F0F0F0Fu << (8u * (s >> 1));
+            uint32_t* const cb = cbase0 + m0;
+#pragma unroll
+            for (int j = 0; j < P_CH; ++j) {
+                if (!__builtin_amdgcn_ballot_w64(tl > 8u * (uint32_t)j)) break;
+                if (tl > 8u * (uint32_t)j) {
+                    const uint32_t D = R[j], Dn = R[j + 1];
+                    // even positions 8j, 8j+2 .. / odd ones: high / low nibbles of the four bytes -- or, for a piece whose origin is a low
+                    // nibble, the low nibbles of these four bytes / the high ones of the next four (read.d:368-373)
+                    const uint32_t es = par ? D : D >> 4, os = par ? __builtin_amdgcn_alignbit(Dn, D, 12) : D;
+                    uint32_t vme = (uint32_t)j == jl ? vt_e : 0x0F0F0F0Fu, vmo = (uint32_t)j == jl ? vt_o : 0x0F0F0F0Fu;
+                    if (j == 0) { vme &= vf_e; vmo &= vf_o; }
+                    uint32_t pa, pc, pg, pt;
+                    planes_of_codes(es & vme, pa, pc, pg, pt);
+                    atomicAdd(cb + j + 0 * P_PLW, pa); atomicAdd(cb + j + 2 * P_PLW, pc); atomicAdd(cb + j + 4 * P_PLW, pg); atomicAdd(cb + j + 6 * P_PLW, pt);
+                    planes_of_codes(os & vmo, pa, pc, pg, pt);
+                    atomicAdd(cb + j + 1 * P_PLW, pa); atomicAdd(cb + j + 3 * P_PLW, pc); atomicAdd(cb + j + 5 * P_PLW, pg); atomicAdd(cb + j + 7 * P_PLW, pt);
+                }
+            }
+        };
+        uint32_t qh = 0, qn = 0;                              // the wave's ring: head, entries
+        uint32_t base_next = 0;
+        unsigned long long d_next = draw(&base_next);
+        for (;;) {
+            const uint32_t base = base_next;
+            if (base >= n_desc) break;
+            const unsigned long long d = d_next;
+            d_next = draw(&base_next);
+            const uint32_t kind = (uint32_t)d & 3u;
+            const uint32_t lo = ((uint32_t)d >> 3) & 0x7FFu, f14 = (uint32_t)(d >> 14);
+            const uint32_t len = f14 & 0xFFu, nib = (f14 >> 8) & 1u;
+            if (kind == 2) { atomicAdd(&deld[lo], 1u); atomicAdd(&deld[f14 & 0xFFFu], 0xFFFFFFFFu); }       // D / N inside the window: '-' from lo up to the op's end (pileup.d:119-121)
+            const bool seg = kind == 1;
+            if (seg) {
+                if (d & 4u) atomicAdd(&nst[lo >> 1], 1u << ((lo & 1u) * 16));                              // n_starting_here, pileup.d:386,422
+                atomicAdd(&covd[lo], 1u); atomicAdd(&covd[lo + len], 0xFFFFFFFFu);                       // M / = / X: in the column from lo on (pileup.d:117-118, :352)
+            }
+            const uint32_t sft = lo & 7u;
+            const uint32_t nch = seg ? (sft + len + 7u) >> 3 : 0u;
+            const uint32_t npc = (nch + (uint32_t)P_CH - 1u) / (uint32_t)P_CH;            // 0..3
+            const uint32_t cpp = npc ? (nch + npc - 1u) / npc : 0u;                       // chunks a piece: the pieces of a descriptor are equally long
+            const uint32_t inc = wave_scan_u32(npc), tot = rl(inc, 63);
+            const uint64_t na = 2ull * (d >> 23) + nib - sft;                             // nibble address of the descriptor's chunk-aligned origin
+            for (uint32_t k = 0; k < npc; ++k) {
+                const uint32_t c0 = k * cpp;
+                const uint32_t tl = min(sft + len - 8u * c0, 8u * cpp);
+                const unsigned long long e = (na + 8u * c0) | ((unsigned long long)(((lo >> 3) + c0) | ((k ? 0u : sft) << 7) | (tl << 10)) << 42);
+                ring[(qh + qn + inc - npc + k) & (uint32_t)(P_QCAP - 1)] = e;
+            }
+            qn += tot;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            while (qn >= 64u) { work(qh, 64u); qh += 64u; qn -= 64u; }
+        }
+        if (qn) work(qh, qn);
+        __syncthreads();                                     // every add of the window is in
+        // ---- flush, first half: the two difference arrays summed up (a wave scans its own positions with DPP, the waves before it enter
+        // as one number each); the four copies of the counters added up by a thread per (chunk, even / odd) and staged a position at a time
+        const uint32_t np = Tend - T0;
+        uint32_t dl[ABPW], cv[ABPW], sw[ABPW];
+        uint32_t run_d = 0, run_c = 0, mxs = 0;
+#pragma unroll
+        for (int bb = 0; bb < ABPW; ++bb) {
+            const uint32_t p = 64 * (wave * ABPW + bb) + lane;
+            const uint32_t e = deld[p], f = covd[p];
+            deld[p] = 0; covd[p] = 0;
+            const uint32_t sd = wave_scan_u32(e), sc = wave_scan_u32(f);
+            dl[bb] = run_d + sd; cv[bb] = run_c + sc;
+            run_d += rl(sd, 63); run_c += rl(sc, 63);
+            sw[bb] = nst[p >> 1];
+            if ((p & 1u) == 0) nst[p >> 1] = 0;             // (two lanes share a word: both have read it -- the wave runs in lockstep)
+        }
+        if (t == 0) { deld[W] = 0; covd[W] = 0; misc[0] = 0; }      // (an op / a segment that ends with the window leaves its -1 here) | the next window's draws
+        if (lane == 0) { misc[8 + wave] = run_d; misc[12 + wave] = run_c; }
+        {
+            const uint32_t m = (uint32_t)t >> 1, eo = (uint32_t)t & 1u;
+            uint32_t s16[8] = {0, 0, 0, 0, 0, 0, 0, 0};     // class x (positions 0 and 2 | 1 and 3 of the word): two 16-bit sums each
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+#pragma unroll
+                for (int cl = 0; cl < 4; ++cl) {
+                    uint32_t* wp = cnt + c * P_CPW + (2 * cl + (int)eo) * P_PLW + m;
+                    const uint32_t w = *wp; *wp = 0;
+                    s16[2 * cl] += w & 0x00FF00FFu; s16[2 * cl + 1] += (w >> 8) & 0x00FF00FFu;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {                     // position 8m + eo + 2i: byte i of the words
+                const int h = i & 1, sh = (i >> 1) * 16;
+                stg[8 * m + eo + 2 * i] = make_uint2(((s16[0 + h] >> sh) & 0xFFFFu) | (((s16[2 + h] >> sh) & 0xFFFFu) << 16), ((s16[4 + h] >> sh) & 0xFFFFu) | (((s16[6 + h] >> sh) & 0xFFFFu) << 16));
+            }
+        }
+        {   // the waves' carries are needed for the deepest SEG coverage, which decides whether anything is written: a barrier of its own
+            __syncthreads();
+            uint32_t carry_d = (uint32_t)wd, carry_c = 0;
+            for (int k = 0; k < wave; ++k) { carry_d += misc[8 + k]; carry_c += misc[12 + k]; }
+#pragma unroll
+            for (int bb = 0; bb < ABPW; ++bb) { dl[bb] += carry_d; cv[bb] += carry_c; mxs = max(mxs, cv[bb]); }
+            mxs = wave_max_u32(mxs);
+            if (lane == 0) misc[16 + wave] = mxs;
+            __syncthreads();
+            mxs = max(max(misc[16], misc[17]), max(misc[18], misc[19]));
+        }
+        if (mxs > 255u) {                                    // a byte-wide counter may have wrapped: the window is the general kernel's (rare: deeper than 255 and still within the slab)
+            if (t == 0) a.deep[atomicAdd(a.n_deep, 1u)] = (uint32_t)tile;
+            __syncthreads();                                 // (the staging is not read: the next window's rings may overwrite it)
+            continue;
+        }
+        bgp_column* out = a.cols + col_out;
+        uint32_t ncol = 0, scov = 0, nsum = 0, mx = 0;
+#pragma unroll
+        for (int bb = 0; bb < ABPW; ++bb) {
+            const uint32_t p = 64 * (wave * ABPW + bb) + lane;
+            const uint2 q = stg[p];
+            if (p < np) {
+                const uint32_t cA = q.x & 0xFFFFu, cC = q.x >> 16, cG = q.y & 0xFFFFu, cT = q.y >> 16;
+                const uint32_t D = dl[bb], S = (sw[bb] >> ((p & 1u) * 16)) & 0xFFFFu;
+                const uint32_t cov = cv[bb] + D, cO = cv[bb] - (cA + cC + cG + cT);
+                uint4* o4 = reinterpret_cast<uint4*>(out + p);
+                o4[0] = make_uint4(cov, S, cA, cC);
+                o4[1] = make_uint4(cG, cT, cO, D);
+                ncol += cov > 0; scov += cov; mx = max(mx, cov); nsum += S;
+                if (cov < (uint32_t)HB) atomicAdd(&hist[cov], 1u);
+                else atomicAdd(&a.hist[min(cov, (uint32_t)BGP_DEPTH_BINS - 1)], 1ull);
+            }
+        }
+        r_ncol += ncol; r_nsum += nsum; r_mx = max(r_mx, mx); r_scov += scov;
+        __syncthreads();                                     // the staging is read: the next window's rings may use its place
     }
     {   // the range's totals: wave reductions with DPP, then one atomic per wave and total (the slots were zeroed by the host)
         const uint32_t w_ncol = wave_sum_u32(r_ncol), w_nsum = wave_sum_u32(r_nsum), w_mx = wave_max_u32(r_mx);
@@ -2015,7 +2299,9 @@ int k34_pileup(bgp_ctx* c) {
             // windows, lets it balance the ranges' unequal work at the tail (cfg3: 9.1 ms with 4096, 8.55 with 16384, the same with 65536)
             static const unsigned g_env = getenv("BGP_G_BLOCKS") ? (unsigned)atoi(getenv("BGP_G_BLOCKS")) : 0u;
             const unsigned g_blocks = std::min(65536u, g_env ? g_env : 16384u);
+            static const bool acc2 = !(getenv("BGP_ACC2") && atoi(getenv("BGP_ACC2")) == 0);
             if (have_rows) hipLaunchKernelGGL(k4_acc<true>, dim3((unsigned)std::min<uint64_t>(tile_base, g_blocks)), dim3(AT), (size_t)ALay<true>::BYTES, c->stream, g);
+            else if (acc2) hipLaunchKernelGGL(k4_acc2, dim3((unsigned)std::min<uint64_t>(tile_base, g_blocks)), dim3(AT), (size_t)A2Lay::BYTES, c->stream, g);
             else hipLaunchKernelGGL(k4_acc<false>, dim3((unsigned)std::min<uint64_t>(tile_base, g_blocks)), dim3(AT), (size_t)ALay<false>::BYTES, c->stream, g);
         }
         // windows the accumulate path left on the list (odd CIGARs, too deep): the general kernel
