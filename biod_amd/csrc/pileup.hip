@@ -1643,23 +1643,39 @@ template <bool ROWS> __global__ __launch_bounds__(AT, BGP_A_MINW) void k4_acc(GA
 #ifndef BGP_ACC2_MINW
 #define BGP_ACC2_MINW 4
 #endif
+#ifndef BGP_ACC2_ABL
+#define BGP_ACC2_ABL 0                        // timing experiments (wrong columns): 1 bases from a cache-resident stretch, 2 no column stores
+#endif
+#ifndef BGP_ACC2_COPIES
+#define BGP_ACC2_COPIES 4
+#endif
+#ifndef BGP_ACC2_DEPTH
+#define BGP_ACC2_DEPTH 1                      // batches whose loads are in flight while a wave works on one
+#endif
+#ifndef BGP_ACC2_CPSH
+#define BGP_ACC2_CPSH 1                       // a lane's copy: (lane >> this) & (copies - 1)
+#endif
+constexpr int P_NCP = BGP_ACC2_COPIES;        // private copies of the counters (2 or 4)
 constexpr int P_CH = 11;                      // chunks of a piece at most (12 dwords loaded: chunk j of an odd-nibble piece wants dword j + 1 too)
 constexpr int P_PLW = W / 8 + 8;              // words of a plane (class x even/odd positions): one per chunk, + 8 so that ...
 constexpr int P_CPW = 8 * P_PLW + 8;          // ... a plane and a copy both start 8 banks after the one before
-constexpr int P_QCAP = 256;                   // entries of a wave's ring: < 64 left over + 3 pieces x 64 descriptors
+constexpr int P_RD = 512;                     // descriptors of a round (two a thread) ...
+constexpr int P_POOL = 3 * P_RD;              // ... and the pieces they can make (a SEG descriptor: <= 255 bases + 7 = 33 chunks = 3 pieces)
+constexpr int P_HB = 128;                     // depth-histogram bins kept in LDS
+constexpr int P_SW = 8 * (W / 8 + 8);         // words of a staging array of the flush: position 8m + k at k x 136 + m
 struct A2Lay {
-    static constexpr int CNT = 0;                               // 4 copies x P_CPW x u32
-    static constexpr int COVD = CNT + 4 * P_CPW * 4;            // (W + 8) x u32: SEG coverage, difference array
+    static constexpr int CNT = 0;                               // P_NCP copies x P_CPW x u32
+    static constexpr int COVD = CNT + P_NCP * P_CPW * 4;        // (W + 8) x u32: SEG coverage, difference array
     static constexpr int DELD = COVD + (W + 8) * 4;             // (W + 8) x u32: '-', difference array
     static constexpr int NST = DELD + (W + 8) * 4;              // W x u16
-    static constexpr int HIST = NST + W * 2;                    // HB x u32 (kept for the workgroup's whole range)
-    static constexpr int QUE = (HIST + HB * 4 + 15) & ~15;      // ANW x P_QCAP x u64; the flush's staging (W x 8 bytes) lies over it
-    static constexpr int MISC = QUE + ANW * P_QCAP * 8;
+    static constexpr int HIST = NST + W * 2;                    // P_HB x u32 (kept for the workgroup's whole range)
+    static constexpr int POOL = (HIST + P_HB * 4 + 15) & ~15;   // P_POOL x u64: the round's pieces; the flush's two staging arrays lie over it
+    static constexpr int MISC = POOL + P_POOL * 8;
     static constexpr int BYTES = MISC + 256;
 };
-static_assert(ANW * P_QCAP * 8 >= W * 8, "the flush stages a window's sums where the rings are");
+static_assert(P_POOL * 8 >= 2 * P_SW * 4, "the flush stages a window's sums where the pool is");
 static_assert(BGP_ACC2_MINW * A2Lay::BYTES <= 160 * 1024, "k4_acc2 workgroups per CU");
-static_assert(W == 1024 && AT == 256, "k4_acc2 geometry: a thread per (chunk, even/odd) in the flush");
+static_assert(W == 1024 && AT == 256 && P_RD == 2 * AT, "k4_acc2 geometry: a thread per (chunk, even/odd) in the flush, two descriptors a thread and round");
 
 // one word of nibble codes (a byte a position; 0 where the position is not the piece's) -> its increments of the A, C, G, T planes
 __device__ __forceinline__ void planes_of_codes(uint32_t sel, uint32_t& pa, uint32_t& pc, uint32_t& pg, uint32_t& pt) {
@@ -1671,6 +1687,58 @@ __device__ __forceinline__ void planes_of_codes(uint32_t sel, uint32_t& pa, uint
     pt = __builtin_amdgcn_perm(0u, 0x00008000u, sel) & 0x01010101u;               // code 8 selects "the sign of table byte 1": 0xFF (code 1 itself: 0x80)
 }
 
+// a batch of the accumulate: a piece per lane.  Entry: [41:0] nibble address of the piece's chunk-aligned origin in the stream, [48:42] the origin's
+// chunk of the window, [51:49] first position of the piece in its first chunk, [58:52] one past its last position, counted from the origin (0: no piece)
+struct A2Batch { uint4 q0, q1, q2; uint32_t eh, par; };
+__device__ __forceinline__ A2Batch acc2_load(const uint8_t* s, unsigned long long e) {
+    A2Batch b;
+    const uint64_t no = e & ((1ull << 42) - 1);
+    b.eh = (uint32_t)(e >> 32); b.par = (uint32_t)no & 1u;
+    const uint32_t tl = (b.eh >> 20) & 127u;
+#if BGP_ACC2_ABL & 1
+    const uint8_t* b0 = s + ((no >> 1) & 0x3FFFFFull);          // timing experiment: every load from the stream's first 4 MiB
+#elif BGP_ACC2_ABL & 16
+    const uint8_t* b0 = s + (((no >> 1) * 33ull) >> 6);          // timing experiment: the traffic of a dense arena of bases (a read every ~150 bytes instead of every ~290)
+#else
+    const uint8_t* b0 = s + (no >> 1);
+#endif
+    const uint32_t need = (b.par + tl + 1u) >> 1;                                  // bytes from b0 on (branch-free: a dword nobody needs is loaded from b0 again)
+    __builtin_memcpy(&b.q0, b0, 16);
+    __builtin_memcpy(&b.q1, b0 + (need > 16u ? 16 : 0), 16);
+    __builtin_memcpy(&b.q2, b0 + (need > 32u ? 32 : 0), 16);
+    return b;
+}
+__device__ __forceinline__ void acc2_work(const A2Batch& b, uint32_t* cbase0) {
+#if BGP_ACC2_ABL & 4
+    if (b.q0.x == 0x12345678u && b.q1.y == 0x9ABCDEF0u && b.q2.z == 77u) cbase0[0] = 1;      // timing experiment: the loads, not the work
+    return;
+#endif
+    const uint32_t m0 = (b.eh >> 10) & 127u, s = (b.eh >> 17) & 7u, tl = (b.eh >> 20) & 127u, par = b.par;
+    const uint32_t R[12] = {b.q0.x, b.q0.y, b.q0.z, b.q0.w, b.q1.x, b.q1.y, b.q1.z, b.q1.w, b.q2.x, b.q2.y, b.q2.z, b.q2.w};
+    const uint32_t jl = (tl - 1u) >> 3, rr = tl - 8u * jl;                        // the piece's last chunk and its positions there (1..8)
+    const uint32_t vt_e = 0x0F0F0F0Fu >> (8u * (4u - ((rr + 1u) >> 1)));
+    const uint32_t vt_o = (uint32_t)(0x0F0F0F0Full >> (8u * (4u - (rr >> 1))));
+    const uint32_t vf_e = (uint32_t)(0x0F0F0F0Full << (8u * ((s + 1u) >> 1))), vf_o = 0x0F0F0F0Fu << (8u * (s >> 1));
+    uint32_t* const cb = cbase0 + m0;
+#pragma unroll
+    for (int j = 0; j < P_CH; ++j) {
+        if (!__builtin_amdgcn_ballot_w64(tl > 8u * (uint32_t)j)) break;
+        if (tl > 8u * (uint32_t)j) {
+            const uint32_t D = R[j], Dn = R[j + 1];
+            // even positions 8j, 8j+2 .. / odd ones: high / low nibbles of the four bytes -- or, for a piece whose origin is a low
+            // nibble, the low nibbles of these four bytes / the high ones of the next four (read.d:368-373)
+            const uint32_t es = par ? D : D >> 4, os = par ? __builtin_amdgcn_alignbit(Dn, D, 12) : D;
+            uint32_t vme = (uint32_t)j == jl ? vt_e : 0x0F0F0F0Fu, vmo = (uint32_t)j == jl ? vt_o : 0x0F0F0F0Fu;
+            if (j == 0) { vme &= vf_e; vmo &= vf_o; }
+            uint32_t pa, pc, pg, pt;
+            planes_of_codes(es & vme, pa, pc, pg, pt);
+            atomicAdd(cb + j + 0 * P_PLW, pa); atomicAdd(cb + j + 2 * P_PLW, pc); atomicAdd(cb + j + 4 * P_PLW, pg); atomicAdd(cb + j + 6 * P_PLW, pt);
+            planes_of_codes(os & vmo, pa, pc, pg, pt);
+            atomicAdd(cb + j + 1 * P_PLW, pa); atomicAdd(cb + j + 3 * P_PLW, pc); atomicAdd(cb + j + 5 * P_PLW, pg); atomicAdd(cb + j + 7 * P_PLW, pt);
+        }
+    }
+}
+
 __global__ __launch_bounds__(AT, BGP_ACC2_MINW) void k4_acc2(GArgs a) {
     using L = A2Lay;
     extern __shared__ __attribute__((aligned(16))) uint8_t alds[];
@@ -1679,29 +1747,32 @@ __global__ __launch_bounds__(AT, BGP_ACC2_MINW) void k4_acc2(GArgs a) {
     uint32_t* const deld = reinterpret_cast<uint32_t*>(alds + L::DELD);
     uint32_t* const nst = reinterpret_cast<uint32_t*>(alds + L::NST);
     uint32_t* const hist = reinterpret_cast<uint32_t*>(alds + L::HIST);
-    uint32_t* const misc = reinterpret_cast<uint32_t*>(alds + L::MISC);      // [0] next draw of the window, [8..11] '-' totals of the waves, [12..15] coverage totals, [16..19] deepest SEG coverage
-    uint2* const stg = reinterpret_cast<uint2*>(alds + L::QUE);
+    uint32_t* const misc = reinterpret_cast<uint32_t*>(alds + L::MISC);      // [0] long pieces of the round (from the pool's front), [1] short ones (from its back), [2] next batch; [8..11] '-' totals of the waves, [12..15] coverage totals, [16..19] deepest SEG coverage
+    unsigned long long* const pool = reinterpret_cast<unsigned long long*>(alds + L::POOL);
+    uint32_t* const stg = reinterpret_cast<uint32_t*>(alds + L::POOL);        // [0, P_SW) A | C << 16, [P_SW, 2 P_SW) G | T << 16
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    unsigned long long* const ring = reinterpret_cast<unsigned long long*>(alds + L::QUE) + wave * P_QCAP;
     const uint64_t nbt = a.n_tiles, per = (nbt + gridDim.x - 1) / gridDim.x;
     const uint64_t tile_end = min(nbt, ((uint64_t)blockIdx.x + 1) * per);
     uint64_t tile = (uint64_t)blockIdx.x * per;
     if (tile >= tile_end) return;
-    for (int i = t; i < L::QUE / 4; i += AT) cnt[i] = 0;                       // counters, difference arrays, starts (a window leaves them zeroed again), hist
+    for (int i = t; i < L::POOL / 4; i += AT) cnt[i] = 0;                      // counters, difference arrays, starts (a window leaves them zeroed again), hist
     if (t < 32) misc[t] = 0;
-    struct Pre { uint2 col; uint4 tt; uint32_t n; int32_t wd; };                // the next window's header, a window ahead, in vector registers (see k4_acc)
+    struct Pre { uint2 col; uint4 tt; uint32_t n; int32_t wd; unsigned long long d0, d1; };   // the next window's header and first round of descriptors, a window ahead, in vector registers (see k4_acc)
     auto prefetch = [&](uint64_t w) {
         Pre p;
         const char* tp = reinterpret_cast<const char*>(a.tiles + w);
         __builtin_memcpy(&p.col, tp + 16, 8);
         __builtin_memcpy(&p.tt, tp + 24, 16);
         p.n = a.wcount[w]; p.wd = a.wdel[w];
+        const unsigned long long* sl = a.slab + w * (uint64_t)SLAB_CAP;        // (the slab is there whatever the count says; slots behind the count hold anything)
+        p.d0 = sl[t]; p.d1 = sl[AT + t];
         return p;
     };
     Pre pre = prefetch(tile);
     uint32_t r_ncol = 0, r_nsum = 0, r_mx = 0; unsigned long long r_scov = 0;
-    uint32_t* const cbase0 = cnt + (lane & 3) * P_CPW;
+    uint32_t* const cbase0 = cnt + ((lane >> BGP_ACC2_CPSH) & (P_NCP - 1)) * P_CPW;
+    uint32_t rounds = 0;
     __syncthreads();
     for (; tile < tile_end; ++tile) {
         asm volatile("; window header settled" : "+v"(pre.col.x), "+v"(pre.col.y), "+v"(pre.tt.x), "+v"(pre.tt.y), "+v"(pre.tt.z), "+v"(pre.tt.w), "+v"(pre.n), "+v"(pre.wd));
@@ -1710,94 +1781,95 @@ __global__ __launch_bounds__(AT, BGP_ACC2_MINW) void k4_acc2(GArgs a) {
         const uint32_t pad = (uint32_t)__builtin_amdgcn_readfirstlane((int)pre.tt.w);
         const uint32_t n_desc = (uint32_t)__builtin_amdgcn_readfirstlane((int)pre.n);
         const int32_t wd = __builtin_amdgcn_readfirstlane(pre.wd);
+        unsigned long long dd[2] = {pre.d0, pre.d1};
         if (tile + 1 < tile_end) pre = prefetch(tile + 1);
         if (pad) continue;                                   // on the general kernel's list
         const unsigned long long* slab = a.slab + tile * (uint64_t)SLAB_CAP;
-        // ---- accumulate
-        auto draw = [&](uint32_t* base_out) {
-            uint32_t b = 0;
-            if (lane == 0) b = atomicAdd(&misc[0], 1u);
-            b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
-            *base_out = b * 64u;
-            unsigned long long dd = 0;
-            if (*base_out + (uint32_t)lane < n_desc) dd = slab[*base_out + lane];
-            return dd;
-        };
-        // one batch: lane = piece.  Entry: [41:0] nibble address of the piece's chunk-aligned origin in the stream, [48:42] the origin's chunk
-        // of the window, [51:49] first position of the piece in its first chunk, [58:52] one past its last position, from the origin
-        auto work = [&](uint32_t qh, uint32_t nb) {
-            unsigned long long e = 0;
-            if ((uint32_t)lane < nb) e = ring[(qh + (uint32_t)lane) & (uint32_t)(P_QCAP - 1)];
-            const uint64_t no = e & ((1ull << 42) - 1);
-            const uint32_t eh = (uint32_t)(e >> 32);
-            const uint32_t m0 = (eh >> 10) & 127u, s = (eh >> 17) & 7u, tl = (eh >> 20) & 127u;      // tl = 0: no piece
-            const uint32_t par = (uint32_t)no & 1u;
-            const uint8_t* b0 = a.s + (no >> 1);
-            const uint32_t need = (par + tl + 1u) >> 1;                                  // bytes from b0 on (branch-free: a dword nobody needs is loaded from b0 again)
-            uint4 q0, q1, q2;
-            __builtin_memcpy(&q0, b0, 16);
-            __builtin_memcpy(&q1, b0 + (need > 16u ? 16 : 0), 16);
-            __builtin_memcpy(&q2, b0 + (need > 32u ? 32 : 0), 16);
-            const uint32_t R[12] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w};
-            const uint32_t jl = (tl - 1u) >> 3, rr = tl - 8u * jl;                        // the piece's last chunk and its positions there (1..8)
-            const uint32_t vt_e = 0x0F0F0F0Fu >> (8u * (4u - ((rr + 1u) >> 1)));
-            const uint32_t vt_o = (uint32_t)(0x0F0F0F0Full >> (8u * (4u - (rr >> 1))));
-            const uint32_t vf_e = (uint32_t)(0x0F0F0F0Full << (8u * ((s + 1u) >> 1))), vf_o = 0x0F0F0F0Fu << (8u * (s >> 1));
-            uint32_t* const cb = cbase0 + m0;
+        for (uint32_t rb = 0; rb < ((BGP_ACC2_ABL & 8) ? 0u : n_desc); rb += (uint32_t)P_RD) {      // (8: timing experiment, the flush alone)
+            // ---- a round, first half: P_RD descriptors, two a thread.  Per-descriptor atomics ('-', starts, coverage); a SEG descriptor is cut
+            // into pieces of equal length, long pieces (9 chunks or more) fill the pool from its front, short ones from its back: a batch of 64
+            // from either end runs about as long in every lane
+            if (rb) { dd[0] = slab[rb + t]; dd[1] = slab[rb + AT + t]; }
+            uint32_t* const mc = misc + 4 * (rounds & 1u);       // the round's three counters; the other set is zeroed while this one is in use
+            ++rounds;
 #pragma unroll
-            for (int j = 0; j < P_CH; ++j) {
-                if (!__builtin_amdgcn_ballot_w64(tl > 8u * (uint32_t)j)) break;
-                if (tl > 8u * (uint32_t)j) {
-                    const uint32_t D = R[j], Dn = R[j + 1];
-                    // even positions 8j, 8j+2 .. / odd ones: high / low nibbles of the four bytes -- or, for a piece whose origin is a low
-                    // nibble, the low nibbles of these four bytes / the high ones of the next four (read.d:368-373)
-                    const uint32_t es = par ? D : D >> 4, os = par ? __builtin_amdgcn_alignbit(Dn, D, 12) : D;
-                    uint32_t vme = (uint32_t)j == jl ? vt_e : 0x0F0F0F0Fu, vmo = (uint32_t)j == jl ? vt_o : 0x0F0F0F0Fu;
-                    if (j == 0) { vme &= vf_e; vmo &= vf_o; }
-                    uint32_t pa, pc, pg, pt;
-                    planes_of_codes(es & vme, pa, pc, pg, pt);
-                    atomicAdd(cb + j + 0 * P_PLW, pa); atomicAdd(cb + j + 2 * P_PLW, pc); atomicAdd(cb + j + 4 * P_PLW, pg); atomicAdd(cb + j + 6 * P_PLW, pt);
-                    planes_of_codes(os & vmo, pa, pc, pg, pt);
-                    atomicAdd(cb + j + 1 * P_PLW, pa); atomicAdd(cb + j + 3 * P_PLW, pc); atomicAdd(cb + j + 5 * P_PLW, pg); atomicAdd(cb + j + 7 * P_PLW, pt);
+            for (int h = 0; h < 2; ++h) {
+                const unsigned long long d = rb + h * AT + t < n_desc ? dd[h] : 0ull;
+                const uint32_t kind = (uint32_t)d & 3u;
+                const uint32_t lo = ((uint32_t)d >> 3) & 0x7FFu, f14 = (uint32_t)(d >> 14);
+                const uint32_t len = f14 & 0xFFu, nib = (f14 >> 8) & 1u;
+                if (kind == 2) { atomicAdd(&deld[lo], 1u); atomicAdd(&deld[f14 & 0xFFFu], 0xFFFFFFFFu); }       // D / N inside the window: '-' from lo up to the op's end (pileup.d:119-121)
+                const bool seg = kind == 1;
+                if (seg) {
+                    if (d & 4u) atomicAdd(&nst[lo >> 1], 1u << ((lo & 1u) * 16));                              // n_starting_here, pileup.d:386,422
+                    atomicAdd(&covd[lo], 1u); atomicAdd(&covd[lo + len], 0xFFFFFFFFu);                       // M / = / X: in the column from lo on (pileup.d:117-118, :352)
+                }
+                const uint32_t sft = lo & 7u;
+                const uint32_t nch = seg ? (sft + len + 7u) >> 3 : 0u;
+                const uint32_t npc = (nch + (uint32_t)P_CH - 1u) / (uint32_t)P_CH;            // 0..3
+                const uint32_t cpp = npc ? (nch + npc - 1u) / npc : 0u;                       // chunks a piece: the pieces of a descriptor are equally long
+                const bool lng = cpp >= 9u;
+                const uint32_t pk = lng ? npc : npc << 16;
+                const uint32_t inc = wave_scan_u32(pk), tot = rl(inc, 63);
+                uint32_t bl = 0, bs = 0;
+                if (lane == 0) { if (tot & 0xFFFFu) bl = atomicAdd(&mc[0], tot & 0xFFFFu); if (tot >> 16) bs = atomicAdd(&mc[1], tot >> 16); }
+                bl = rl(bl, 0); bs = rl(bs, 0);
+                const uint32_t ex = inc - pk;
+                const uint32_t slot0 = lng ? bl + (ex & 0xFFFFu) : (uint32_t)P_POOL - 1u - (bs + (ex >> 16));
+                const uint64_t na = 2ull * (d >> 23) + nib - sft;                             // nibble address of the descriptor's chunk-aligned origin
+                for (uint32_t k = 0; k < npc; ++k) {
+                    const uint32_t c0 = k * cpp;
+                    const uint32_t tl = min(sft + len - 8u * c0, 8u * cpp);
+                    const unsigned long long e = (na + 8u * c0) | ((unsigned long long)(((lo >> 3) + c0) | ((k ? 0u : sft) << 7) | (tl << 10)) << 42);
+                    pool[lng ? slot0 + k : slot0 - k] = e;
                 }
             }
-        };
-        uint32_t qh = 0, qn = 0;                              // the wave's ring: head, entries
-        uint32_t base_next = 0;
-        unsigned long long d_next = draw(&base_next);
-        for (;;) {
-            const uint32_t base = base_next;
-            if (base >= n_desc) break;
-            const unsigned long long d = d_next;
-            d_next = draw(&base_next);
-            const uint32_t kind = (uint32_t)d & 3u;
-            const uint32_t lo = ((uint32_t)d >> 3) & 0x7FFu, f14 = (uint32_t)(d >> 14);
-            const uint32_t len = f14 & 0xFFu, nib = (f14 >> 8) & 1u;
-            if (kind == 2) { atomicAdd(&deld[lo], 1u); atomicAdd(&deld[f14 & 0xFFFu], 0xFFFFFFFFu); }       // D / N inside the window: '-' from lo up to the op's end (pileup.d:119-121)
-            const bool seg = kind == 1;
-            if (seg) {
-                if (d & 4u) atomicAdd(&nst[lo >> 1], 1u << ((lo & 1u) * 16));                              // n_starting_here, pileup.d:386,422
-                atomicAdd(&covd[lo], 1u); atomicAdd(&covd[lo + len], 0xFFFFFFFFu);                       // M / = / X: in the column from lo on (pileup.d:117-118, :352)
+            __syncthreads();
+            // ---- second half: batches of 64 pieces, a piece a lane; the loads of a wave's next batch are in flight while it works on the current one
+            {
+                if (t < 3) misc[4 * (rounds & 1u) + t] = 0;       // (the next round's: nobody has touched them since the barrier that ended the round before this one)
+                const uint32_t n_l = mc[0], n_s = mc[1];
+                const uint32_t nb_l = (n_l + 63u) >> 6, nb = nb_l + ((n_s + 63u) >> 6);
+                auto entry = [&](uint32_t b) {
+                    unsigned long long e = 0;
+                    if (b < nb_l) { const uint32_t i = b * 64u + (uint32_t)lane; if (i < n_l) e = pool[i]; }
+                    else if (b < nb) { const uint32_t i = (b - nb_l) * 64u + (uint32_t)lane; if (i < n_s) e = pool[(uint32_t)P_POOL - 1u - i]; }
+                    return e;
+                };
+                auto draw = [&]() { uint32_t b = 0; if (lane == 0) b = atomicAdd(&mc[2], 1u); return (uint32_t)__builtin_amdgcn_readfirstlane((int)b); };
+                uint32_t b = draw();
+                if (b < nb) {
+#if BGP_ACC2_DEPTH == 2
+                    A2Batch cur = acc2_load(a.s, entry(b));
+                    b = draw();
+                    if (b >= nb) acc2_work(cur, cbase0);
+                    else {
+                        A2Batch nxt = acc2_load(a.s, entry(b));
+                        for (;;) {
+                            b = draw();
+                            if (b >= nb) break;
+                            const A2Batch nx2 = acc2_load(a.s, entry(b));
+                            acc2_work(cur, cbase0);
+                            cur = nxt; nxt = nx2;
+                        }
+                        acc2_work(cur, cbase0);
+                        acc2_work(nxt, cbase0);
+                    }
+#else
+                    A2Batch cur = acc2_load(a.s, entry(b));
+                    for (;;) {
+                        b = draw();
+                        if (b >= nb) break;
+                        const A2Batch nxt = acc2_load(a.s, entry(b));
+                        acc2_work(cur, cbase0);
+                        cur = nxt;
+                    }
+                    acc2_work(cur, cbase0);
+#endif
+                }
             }
-            const uint32_t sft = lo & 7u;
-            const uint32_t nch = seg ? (sft + len + 7u) >> 3 : 0u;
-            const uint32_t npc = (nch + (uint32_t)P_CH - 1u) / (uint32_t)P_CH;            // 0..3
-            const uint32_t cpp = npc ? (nch + npc - 1u) / npc : 0u;                       // chunks a piece: the pieces of a descriptor are equally long
-            const uint32_t inc = wave_scan_u32(npc), tot = rl(inc, 63);
-            const uint64_t na = 2ull * (d >> 23) + nib - sft;                             // nibble address of the descriptor's chunk-aligned origin
-            for (uint32_t k = 0; k < npc; ++k) {
-                const uint32_t c0 = k * cpp;
-                const uint32_t tl = min(sft + len - 8u * c0, 8u * cpp);
-                const unsigned long long e = (na + 8u * c0) | ((unsigned long long)(((lo >> 3) + c0) | ((k ? 0u : sft) << 7) | (tl << 10)) << 42);
-                ring[(qh + qn + inc - npc + k) & (uint32_t)(P_QCAP - 1)] = e;
-            }
-            qn += tot;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            while (qn >= 64u) { work(qh, 64u); qh += 64u; qn -= 64u; }
+            __syncthreads();                                 // every add of the round is in; the pool is free
         }
-        if (qn) work(qh, qn);
-        __syncthreads();                                     // every add of the window is in
         // ---- flush, first half: the two difference arrays summed up (a wave scans its own positions with DPP, the waves before it enter
         // as one number each); the four copies of the counters added up by a thread per (chunk, even / odd) and staged a position at a time
         const uint32_t np = Tend - T0;
@@ -1814,13 +1886,13 @@ __global__ __launch_bounds__(AT, BGP_ACC2_MINW) void k4_acc2(GArgs a) {
             sw[bb] = nst[p >> 1];
             if ((p & 1u) == 0) nst[p >> 1] = 0;             // (two lanes share a word: both have read it -- the wave runs in lockstep)
         }
-        if (t == 0) { deld[W] = 0; covd[W] = 0; misc[0] = 0; }      // (an op / a segment that ends with the window leaves its -1 here) | the next window's draws
+        if (t == 0) { deld[W] = 0; covd[W] = 0; }           // (an op / a segment that ends with the window leaves its -1 here)
         if (lane == 0) { misc[8 + wave] = run_d; misc[12 + wave] = run_c; }
         {
             const uint32_t m = (uint32_t)t >> 1, eo = (uint32_t)t & 1u;
-            uint32_t s16[8] = {0, 0, 0, 0, 0, 0, 0, 0};     // class x (positions 0 and 2 | 1 and 3 of the word): two 16-bit sums each
+            uint32_t s16[8] = {0, 0, 0, 0, 0, 0, 0, 0};     // class x (bytes 0 and 2 | 1 and 3 of the word): two 16-bit sums each
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
+            for (int c = 0; c < P_NCP; ++c) {
 #pragma unroll
                 for (int cl = 0; cl < 4; ++cl) {
                     uint32_t* wp = cnt + c * P_CPW + (2 * cl + (int)eo) * P_PLW + m;
@@ -1831,7 +1903,9 @@ __global__ __launch_bounds__(AT, BGP_ACC2_MINW) void k4_acc2(GArgs a) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {                     // position 8m + eo + 2i: byte i of the words
                 const int h = i & 1, sh = (i >> 1) * 16;
-                stg[8 * m + eo + 2 * i] = make_uint2(((s16[0 + h] >> sh) & 0xFFFFu) | (((s16[2 + h] >> sh) & 0xFFFFu) << 16), ((s16[4 + h] >> sh) & 0xFFFFu) | (((s16[6 + h] >> sh) & 0xFFFFu) << 16));
+                const uint32_t at = (eo + 2u * (uint32_t)i) * (uint32_t)(P_SW / 8) + m;
+                stg[at] = ((s16[0 + h] >> sh) & 0xFFFFu) | (((s16[2 + h] >> sh) & 0xFFFFu) << 16);
+                stg[P_SW + at] = ((s16[4 + h] >> sh) & 0xFFFFu) | (((s16[6 + h] >> sh) & 0xFFFFu) << 16);
             }
         }
         {   // the waves' carries are needed for the deepest SEG coverage, which decides whether anything is written: a barrier of its own
@@ -1847,7 +1921,7 @@ __global__ __launch_bounds__(AT, BGP_ACC2_MINW) void k4_acc2(GArgs a) {
         }
         if (mxs > 255u) {                                    // a byte-wide counter may have wrapped: the window is the general kernel's (rare: deeper than 255 and still within the slab)
             if (t == 0) a.deep[atomicAdd(a.n_deep, 1u)] = (uint32_t)tile;
-            __syncthreads();                                 // (the staging is not read: the next window's rings may overwrite it)
+            __syncthreads();                                 // (the staging is not read: the next window's pool may overwrite it)
             continue;
         }
         bgp_column* out = a.cols + col_out;
@@ -1855,21 +1929,27 @@ __global__ __launch_bounds__(AT, BGP_ACC2_MINW) void k4_acc2(GArgs a) {
 #pragma unroll
         for (int bb = 0; bb < ABPW; ++bb) {
             const uint32_t p = 64 * (wave * ABPW + bb) + lane;
-            const uint2 q = stg[p];
+            const uint32_t at = (p & 7u) * (uint32_t)(P_SW / 8) + (p >> 3);
+            const uint32_t qx = stg[at], qy = stg[P_SW + at];
             if (p < np) {
-                const uint32_t cA = q.x & 0xFFFFu, cC = q.x >> 16, cG = q.y & 0xFFFFu, cT = q.y >> 16;
+                const uint32_t cA = qx & 0xFFFFu, cC = qx >> 16, cG = qy & 0xFFFFu, cT = qy >> 16;
                 const uint32_t D = dl[bb], S = (sw[bb] >> ((p & 1u) * 16)) & 0xFFFFu;
                 const uint32_t cov = cv[bb] + D, cO = cv[bb] - (cA + cC + cG + cT);
                 uint4* o4 = reinterpret_cast<uint4*>(out + p);
+#if BGP_ACC2_ABL & 2
+                if (cov == 0xFFFFFFF0u)                      // timing experiment: no column stores
+#endif
+                {
                 o4[0] = make_uint4(cov, S, cA, cC);
                 o4[1] = make_uint4(cG, cT, cO, D);
+                }
                 ncol += cov > 0; scov += cov; mx = max(mx, cov); nsum += S;
-                if (cov < (uint32_t)HB) atomicAdd(&hist[cov], 1u);
+                if (cov < (uint32_t)P_HB) atomicAdd(&hist[cov], 1u);
                 else atomicAdd(&a.hist[min(cov, (uint32_t)BGP_DEPTH_BINS - 1)], 1ull);
             }
         }
         r_ncol += ncol; r_nsum += nsum; r_mx = max(r_mx, mx); r_scov += scov;
-        __syncthreads();                                     // the staging is read: the next window's rings may use its place
+        __syncthreads();                                     // the staging is read: the next window's pool may use its place
     }
     {   // the range's totals: wave reductions with DPP, then one atomic per wave and total (the slots were zeroed by the host)
         const uint32_t w_ncol = wave_sum_u32(r_ncol), w_nsum = wave_sum_u32(r_nsum), w_mx = wave_max_u32(r_mx);
@@ -1884,7 +1964,7 @@ __global__ __launch_bounds__(AT, BGP_ACC2_MINW) void k4_acc2(GArgs a) {
         }
     }
     __syncthreads();
-    for (int b = t; b < HB; b += AT) { const uint32_t h = hist[b]; if (h) atomicAdd(&a.hist[b], (unsigned long long)h); }
+    for (int b = t; b < P_HB; b += AT) { const uint32_t h = hist[b]; if (h) atomicAdd(&a.hist[b], (unsigned long long)h); }
 }
 
 // ---------------------------------------------------------------------------------------------- K5
