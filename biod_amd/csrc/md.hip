@@ -358,7 +358,29 @@ __device__ uint32_t dna_length(const uint8_t* s, const bgp_record& r, bool* bad,
 struct alignas(16) MdRow { uint32_t pos, end, lf, mb; };      // one dwordx4 / ds_read_b128 per row
 constexpr uint32_t MD_BAD = 1u << 31, MD_ERR = 1u << 30, MD_COV = 1u << 29, MD_GST = 1u << 28, MD_LMASK = (1u << 28) - 1;
 
-__global__ __launch_bounds__(256) void k6_prep(const uint8_t* s, const bgp_record* rec, const uint4* cig4, const uint64_t* pmax_end, const uint64_t* pmax_pos, uint64_t n, MdRow* rows, uint32_t* bmax) {
+// what dna(read) is long when the MD tag says what the CIGAR says: the M / = / X bases and the deleted ones (md/reconstruct.d:38-214: a match
+// or a mismatch of the tag takes a query base under M / = / X, a deletion yields its own chars; N, S, I, H, P appear in neither).
+// k6_prep<false> puts this in a row WITHOUT reading the tag: only a provider's dna is ever looked at, by the reference
+// (pileup.d:560-562 "minimise the number of reads for which MD tag will be decoded") and here (the successor of P depends on P's length
+// and on the winner's flags alone), and k6_emit checks every provider's real tag against it -- a run with a provider whose tag disagrees,
+// stalls or is malformed is redone by the event loop over rows made by k6_prep<true>.
+__device__ __forceinline__ uint32_t dna_length_by_cigar(const uint8_t* s, const bgp_record& r, const uint4* c4) {
+    const uint32_t l_name = r.bin_mq_nl & 0xFFu, n_cig = r.flag_nc & 0xFFFFu;
+    uint64_t n = 0;
+    auto take = [&](uint32_t raw) { const uint32_t op = raw & 15u; if ((cig_qc(raw) && cig_rc(raw)) || op == 2u) n += raw >> 4; };
+    if (c4 && n_cig <= 4) {
+        const uint4 v = *c4;
+        const uint32_t ops[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k) if (k < n_cig) take(ops[k]);
+    } else {
+        const uint8_t* cg = s + r.rec_off + 36 + l_name;
+        for (uint32_t k = 0; k < n_cig; ++k) take(ld_u32(cg + 4ull * k));
+    }
+    return n > (uint64_t)MD_LMASK ? MD_LMASK : (uint32_t)n;
+}
+
+template <bool FULL> __global__ __launch_bounds__(256) void k6_prep(const uint8_t* s, const bgp_record* rec, const uint4* cig4, const uint64_t* pmax_end, const uint64_t* pmax_pos, uint64_t n, MdRow* rows, uint32_t* bmax) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     bgp_record r{};
     if (i < n) r = rec[i];
@@ -370,10 +392,12 @@ __global__ __launch_bounds__(256) void k6_prep(const uint8_t* s, const bgp_recor
     if (i >= n) return;
     MdRow o{(uint32_t)r.pos, (uint32_t)r.end_pos, 0u, 0u};
     if (r.end_pos != r.pos) {
-        bool bad, err;
+        bool bad = false, err = false;
         // (requested before the MD tag is walked: the common case -- this read is alone at its position -- needs nothing else)
         const uint64_t pm_prev = i ? pmax_pos[i - 1] : 0, pe_prev = i ? pmax_end[i - 1] : 0;
-        uint32_t L = dna_length(s, r, &bad, &err, cig4 ? cig4 + i : nullptr, cig4 && i + 1 < n ? (uint64_t)rec[i + 1].rec_off : 0);   // (cig4: the table is K1's own, record i ends where i + 1 begins -- its header line is not touched at all)
+        uint32_t L;
+        if (FULL) L = dna_length(s, r, &bad, &err, cig4 ? cig4 + i : nullptr, cig4 && i + 1 < n ? (uint64_t)rec[i + 1].rec_off : 0);   // (cig4: the table is K1's own, record i ends where i + 1 begins -- its header line is not touched at all)
+        else L = dna_length_by_cigar(s, r, cig4 ? cig4 + i : nullptr);
         if (L > MD_LMASK) L = MD_LMASK;
         // first record of this read's position group: the prefix maximum of the position key reaches the
         // read's own key exactly there (records are sorted; K3 has already rejected unsorted input).
@@ -593,6 +617,12 @@ __global__ __launch_bounds__(256) void k6_fill(const uint8_t* s, const bgp_recor
 // and every BGP_EMD comes from it.
 constexpr uint32_t SX_END = 0xFFFFFFFFu, SX_NONE = 0xFFFFFFFEu, SX_FLAG = 1u << 31;
 constexpr int SEG = 2048, SUCC_CAP = 4096;
+#ifndef BGP_SUCC_LANE_CAP
+#define BGP_SUCC_LANE_CAP 128                 // rows a lane of the general walk looks at before it hands its read to the wave
+#endif
+#ifndef BGP_SUCC_SCAN
+#define BGP_SUCC_SCAN 0                       // 1: every successor by the general row-by-row walk (rounds 2 and 3), for A/B runs
+#endif
 struct Succ { uint32_t nxt, fcol; };              // fcol: fetch column of nxt | SX_FLAG
 
 struct ParRun { uint64_t first, endrec; uint32_t run_end, ce_in, active, pad; };
@@ -694,7 +724,7 @@ __device__ Succ succ_coop(const MdRow* rows, const ParRun& R, uint64_t P, const 
 __global__ __launch_bounds__(256) void k6_succ(const MdRow* rows, const uint32_t* bmax, uint64_t n, const ParRun* pr, uint32_t n_runs, int skip_zero, Succ* succ) {
     // the window a lane scans is the ~50 rows behind its own: the block's 256 rows + 256 more sit in LDS (adjacent
     // lanes read adjacent rows, conflict free); a lane that needs more than LANE_CAP rows hands its read to the wave
-    constexpr int STAGE = 512, LANE_CAP = 128;
+    constexpr int STAGE = 512, LANE_CAP = BGP_SUCC_LANE_CAP;
     __shared__ MdRow s_rows[STAGE];
     const uint64_t base = (uint64_t)blockIdx.x * blockDim.x;
     for (int t = threadIdx.x; t < STAGE; t += 256) s_rows[t] = base + t < n ? rows[base + t] : MdRow{0, 0, 0, 0};
@@ -707,6 +737,47 @@ __global__ __launch_bounds__(256) void k6_succ(const MdRow* rows, const uint32_t
     bool node = P < n && (rp.lf & MD_COV);
     if (node) { R = pr[par_run_of(pr, n_runs, P)]; node = P >= R.first && P < R.endrec; }
     const uint32_t CE = rp.end, A = rp.pos + (rp.lf & MD_LMASK) - 1u;
+#if !BGP_SUCC_SCAN
+    // The regular step in closed form.  With A = the column the chunk empties at (pos + len(dna) - 1) in front of chunk_end (CE = the
+    // provider's end) and no position group behind uncovered ground among the reads that start up to A or right behind them, the sweep's
+    // bookkeeping collapses: some read starting at or before A ends beyond CE, so add() has a candidate before the chunk is empty, the
+    // fetch column is A (pileup.d:627-635), and the new provider is the FIRST read with the LARGEST end among those starting in
+    // (P, A] (pileup.d:563-596: every such read ending beyond CE passes the filter, the others cannot win).  That is one arg-max
+    // over ~30 staged rows -- four instructions a row where the general walk below spends ~90 on its cases -- and the same for all
+    // lanes of a wave (a read with a 5 kb N skip has a long CE, not a long dna).  Whatever does not fit (no candidate by A: N-skip
+    // providers and coverage edges; uncovered ground; rows beyond the staged ones) is handed to the wave, succ_coop, as the walk's
+    // long windows always were.
+    bool flag = false, deferred = false;
+    uint32_t out_n = node ? SX_END : SX_NONE, out_f = 0;
+    {
+        const uint32_t L = rp.lf & MD_LMASK;
+        bool ok = node && L >= 1u && A >= rp.pos && A < CE;
+        uint32_t best = SX_END, best_end = 0;
+        uint64_t j = P + 1;
+        const uint64_t lim = min(R.endrec, base + (uint64_t)STAGE);
+        bool special = false, ended = false;                                 // ended: a covering read beyond A closed the window
+        bool run = ok;
+        while (__ballot(run)) {
+            if (run) {
+                if (j >= lim) run = false;
+                else {
+                    const MdRow r = s_rows[j - base];
+                    const bool cov = (r.lf & MD_COV) != 0;
+                    special |= cov && r.mb < r.pos;                          // (the closing read's group included: a GAP would be taken there, pileup.d:382-393)
+                    if (r.pos > A) { run = false; ended = cov; special |= !cov; }
+                    else { const uint32_t e = cov ? r.end : 0u; if (e > best_end) { best_end = e; best = (uint32_t)j; } ++j; }
+                }
+            }
+        }
+        ok = ok && !special && best_end > CE && (ended || j >= R.endrec);      // (stopped by the staged rows' end: not decided here)
+        if (ok) {
+            if (ended || A < R.run_end) {                                    // FETCH at A; at the run's end only if it comes before the end of coverage
+                out_n = best; out_f = A;
+                flag = arrival_irregular(s_rows[best - base], A);
+            }
+        } else deferred = node;
+    }
+#else
     bool found = false, flag = false, deferred = false, done = !node;
     uint32_t F = 0, best = SX_END, best_end = 0, allmax = 0;
     MdRow bestrow{0, 0, 0, 0};
@@ -772,6 +843,7 @@ __global__ __launch_bounds__(256) void k6_succ(const MdRow* rows, const uint32_t
         out_n = best; out_f = F;
         flag |= best == SX_END || arrival_irregular(bestrow, F) || allmax > best_end;
     }
+#endif
     Succ res{out_n, out_f | (flag ? SX_FLAG : 0u)};
     // long windows: one read at a time, the whole wave on it
     for (uint64_t dm = __ballot(deferred); dm; dm &= dm - 1) {
@@ -862,7 +934,7 @@ struct EmitRun { uint64_t first, endrec, column_base; uint32_t start_pos, end_po
 // emits the pieces one lane each.  ctr[0] = long nodes, ctr[1] = pieces.
 struct LongNode { uint32_t rec, from, count, ck_base; uint64_t out_off; };
 __global__ __launch_bounds__(64) void k6_emit(const uint8_t* s, const bgp_record* rec, const MdRow* rows, const Succ* succ, const Succ* seg_entry, uint64_t slot_lo, uint64_t slot_n,
-                                              const EmitRun* er, uint32_t n_runs, ParOut* po, uint8_t* refbase, LongNode* longs, uint32_t longs_cap, unsigned int* ctr) {
+                                              const EmitRun* er, uint32_t n_runs, ParOut* po, uint8_t* refbase, LongNode* longs, uint32_t longs_cap, unsigned int* ctr, int verify) {
     __shared__ uint32_t nd[SEG + 1], fc[SEG + 1];
     __shared__ uint32_t s_cnt, s_run;
     if (blockIdx.x >= slot_n) return;
@@ -890,6 +962,11 @@ __global__ __launch_bounds__(64) void k6_emit(const uint8_t* s, const bgp_record
         const uint32_t F = fc[k];
         uint32_t endc = fc[k + 1];
         if (endc > R.end_pos) endc = R.end_pos;
+        if (verify) {                                         // this provider's real tag against what the rows assumed of it (k6_prep<false>)
+            bool vb, ve;
+            const uint32_t Lt = dna_length(s, rec[nd[k]], &vb, &ve);
+            if (vb || ve || Lt != dna_length_by_cigar(s, rec[nd[k]], nullptr)) po[s_run].flagged = 1u;
+        }
         if (F >= endc) continue;
         if (endc - F > DNA_LONG) {
             const uint32_t at = atomicAdd(&ctr[0], 1u), pieces = (endc - F + DNA_CK - 1) / DNA_CK;
@@ -982,18 +1059,20 @@ int k7_snp_simple(bgp_ctx* c, uint64_t col_index, uint64_t ref_index, uint64_t n
 }
 
 // rows for every record of the staged stream (needs K3's prefix maxima: call after k34_pileup)
-static int k6_rows(bgp_ctx* c) {
-    if (c->md_rows_ready) return BGP_OK;
+static int k6_rows(bgp_ctx* c, bool full) {
+    if (c->md_rows_ready && (c->md_rows_full || !full)) return BGP_OK;
     const uint64_t n = c->n_records;
     BGP_TRY(c->d_md_row.reserve((n + 1) * sizeof(MdRow)));
     BGP_TRY(c->d_md_bmax.reserve((n / 64 + 2) * 4));
     if (n) {
         TimedRegion t(c, "k6_prep", n * (32 + sizeof(MdRow)));
-        hipLaunchKernelGGL(k6_prep, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->d_stream, c->d_rec.as<bgp_record>(), c->cig4_ok ? c->d_cig4.as<uint4>() : nullptr,
+        if (full) hipLaunchKernelGGL(k6_prep<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->d_stream, c->d_rec.as<bgp_record>(), c->cig4_ok ? c->d_cig4.as<uint4>() : nullptr,
+                           c->d_pmax_end.as<uint64_t>(), c->d_pmax_pos.as<uint64_t>(), n, c->d_md_row.as<MdRow>(), c->d_md_bmax.as<uint32_t>());
+        else hipLaunchKernelGGL(k6_prep<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->d_stream, c->d_rec.as<bgp_record>(), c->cig4_ok ? c->d_cig4.as<uint4>() : nullptr,
                            c->d_pmax_end.as<uint64_t>(), c->d_pmax_pos.as<uint64_t>(), n, c->d_md_row.as<MdRow>(), c->d_md_bmax.as<uint32_t>());
         BGP_HIP(hipGetLastError());
     }
-    c->md_rows_ready = true;
+    c->md_rows_ready = true; c->md_rows_full = full;
     return BGP_OK;
 }
 
@@ -1029,7 +1108,10 @@ int k6_reference_bases(bgp_ctx* c, int skip_zero, uint32_t run_first, uint32_t r
     *md_err = 0; *md_err_from = -1;
     if (bt) { bt->out_have = 0; bt->out_ce = bt->in_ce; }
     if (c->n_records >= 0xFFFFFFF0ull) { c->last_error = "too many records for the MD path"; return BGP_EINVAL; }
-    BGP_TRY(k6_rows(c));
+    const char* mode = getenv("BGP_MD_CHAIN");                 // "seq": the event loop only; default: composed successors, event loop where premises fail
+    const bool use_par = !(mode && !strcmp(mode, "seq")) && !bt;      // (a batch's chain resumes and saves state: the event loop)
+    static const bool lazy_md = !(getenv("BGP_MD_LAZY") && atoi(getenv("BGP_MD_LAZY")) == 0);
+    BGP_TRY(k6_rows(c, !(use_par && lazy_md)));                 // the event loop reads real lengths; the composed chain assumes them and k6_emit checks its providers
     // The chain runs over whole REFERENCES: PileupRangeUsingMdTag keeps its chunk across a reference's uncovered stretches (it
     // walks them, or jumps and lets "the old chunk simply go on"), so the runs K3 cut at such stretches are put together again here
     // -- `mr` -- and d_refbase is dense over every reference's [first position, largest end) (a byte a position: 2 GB at worst);
@@ -1079,8 +1161,6 @@ int k6_reference_bases(bgp_ctx* c, int skip_zero, uint32_t run_first, uint32_t r
     BGP_TRY(c->d_md_iv.reserve((c->n_records + 2ull * nr + 2) * sizeof(MdIv)));
     uint8_t* st = c->d_md_state.as<uint8_t>();
     const uint64_t n = c->n_records;
-    const char* mode = getenv("BGP_MD_CHAIN");                 // "seq": the event loop only; default: composed successors, event loop where premises fail
-    const bool use_par = !(mode && !strcmp(mode, "seq")) && !bt;      // (a batch's chain resumes and saves state: the event loop)
     const uint64_t n_slots = (n + SEG - 1) / SEG + nr + 1;
     const uint32_t longs_cap = (uint32_t)std::min<uint64_t>(n_pos / DNA_LONG + nr + 64, 0x7FFFFFFFull);    // a long chunk covers > DNA_LONG columns of its run
     if (use_par) {
@@ -1120,7 +1200,7 @@ int k6_reference_bases(bgp_ctx* c, int skip_zero, uint32_t run_first, uint32_t r
                 TimedRegion t(c, "k6_emit", mr[k].end_pos - mr[k].start_pos);
                 hipLaunchKernelGGL(k6_emit, dim3((unsigned)(hi - lo)), dim3(64), 0, c->stream, c->d_stream, c->d_rec.as<bgp_record>(), c->d_md_row.as<MdRow>(), c->d_md_succ.as<Succ>(),
                                    c->d_md_entry.as<Succ>(), lo, hi - lo, (const EmitRun*)(st + off_er), nr, (ParOut*)(st + off_po), c->d_refbase.as<uint8_t>(),
-                                   (LongNode*)(c->d_md_long.as<uint8_t>() + 16), longs_cap, c->d_md_long.as<unsigned int>());
+                                   (LongNode*)(c->d_md_long.as<uint8_t>() + 16), longs_cap, c->d_md_long.as<unsigned int>(), 1);
             }
             BGP_HIP(hipGetLastError());
             std::vector<ParOut> po(nr);
@@ -1148,6 +1228,7 @@ int k6_reference_bases(bgp_ctx* c, int skip_zero, uint32_t run_first, uint32_t r
             for (uint32_t k : seq) { const MRun& r = mr[k]; if (r.end_pos > r.start_pos) BGP_HIP(hipMemsetAsync(c->d_refbase.as<uint8_t>() + r.column_base, 'N', r.end_pos - r.start_pos, c->stream)); }
         } else seq = ks;
         if (seq.empty()) return BGP_OK;
+        BGP_TRY(k6_rows(c, true));                             // the event loop is the authority: rows from the tags themselves
         for (uint32_t k = 0; k < nr; ++k) cr[k].active = 0;
         for (uint32_t k : seq) cr[k].active = 1;
         BGP_HIP(hipMemcpyAsync(st, cr.data(), sizeof(ChainRun) * nr, hipMemcpyHostToDevice, c->stream));
