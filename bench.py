@@ -88,6 +88,8 @@ def parse():
     ap.add_argument("--cpu-sample-reads", type=int, default=0, help="reads in the CPU-baseline sample (0 = auto, about 10-30 s of CPU work)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-checks", action="store_true", help="skip the full-size invariants after the timed region")
+    ap.add_argument("--parity", action="store_true", help="the oracle's interior-shard check even with --no-cpu-baseline (it is on by default otherwise)")
+    ap.add_argument("--no-md", action="store_true", help="skip the use_md_tag leg (reference_base from MD tags, what examples/make_pileup.d:16 asks for) after the timed region")
     ap.add_argument("--weak", action="store_true", help="weak scaling: every rank gets a full --reads-sized shard of its own contigs (default: strong, ONE BAM split by contig)")
     ap.add_argument("--strong", action="store_true", help="(default) kept for older command lines")
     return ap.parse_args()
@@ -156,6 +158,41 @@ def oracle_interior_check(ctx, cfg, cfg_name, info, torch, dev):
     two of them (tests/interior_parity.py)."""
     import interior_parity as IP
     return IP.run(ctx, cfg, info, 20_000 if cfg_name != "cfg5" else 200, torch, dev, want=16)
+
+
+def md_leg(ctx, cfg, cfg_name, info, n_reads, reps=3):
+    """`use_md_tag = true` on the resident result (examples/make_pileup.d:16 calls makePileup(bam.reads, true): PileupRangeUsingMdTag,
+    pileup.d:522-654): K6's kernels timed by their HIP events over `reps` runs of bgp_pileup_begin(use_md_tag = 1) -- K3 / K4 redone in
+    front of each, untimed here, so that nothing of K6 is cached --, the wall time up to the first window, and the oracle's sweep over
+    the stream's first records against the device's bytes (tests/interior_parity.py: md_prefix_check).
+    Algorithmic bytes: the 32-byte rows in, one byte per position out (the reference looks at a PROVIDER's MD tag, SEQ and CIGAR
+    only -- pileup.d:560-562 -- and so does K6: those bytes, a few per cent of the reads', are left out of the figure)."""
+    from biod_amd import _lib as L
+    import interior_parity as IP
+    ks, walls = [], []
+    for _ in range(reps):
+        ctx.pileup_run()
+        ctx.timing_enable(True); ctx.timing_reset()
+        t0 = time.perf_counter()
+        gen = ctx.pileup_windows(L.BGP_PILEUP_COLUMNS, use_md_tag=True, skip_zero_coverage=True, window_positions=1 << 20)
+        next(gen)
+        walls.append((time.perf_counter() - t0) * 1e3)
+        gen.close()
+        ks.append({k: v["total_ms"] for k, v in ctx.timing_get().items() if k.startswith("k6") and v["launches"]})
+        ctx.timing_enable(False)
+    names = sorted({k for d in ks for k in d})
+    med = {k: sorted(d.get(k, 0.0) for d in ks)[len(ks) // 2] for k in names}
+    k6_ms = sum(med.values())
+    alg = 32 * n_reads + int(info.n_positions)
+    out = {"what": "reference_base from MD tags for every position of the piled-up BAM (bgp_pileup_begin, use_md_tag = 1): K6 = " + " + ".join(names),
+           "k6_ms": round(k6_ms, 3), "kernels_ms": {k: round(v, 3) for k, v in med.items()}, "wall_ms_to_first_window": round(sorted(walls)[len(walls) // 2], 2),
+           "algorithmic_bytes": alg, "algorithmic_GBps": round(alg / (k6_ms * 1e-3) / 1e9, 1) if k6_ms else None,
+           "frac": round(alg / (k6_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if k6_ms else None, "reps": reps}
+    try:
+        out["prefix_vs_oracle"] = dict(IP.md_prefix_check(ctx, cfg, 20_000 if cfg_name != "cfg5" else 200), equal=True)
+    except AssertionError as e:
+        out["prefix_vs_oracle"] = {"equal": False, "why": str(e)[:300]}
+    return out
 
 
 from biod_amd.checks import DevArray as _DevArray, full_size_invariants      # device-side identities of the result (no oracle)
@@ -282,6 +319,10 @@ def main():
     checks = None
     if not a.no_checks:
         checks = full_size_invariants(torch, dev, ctx, info, n_reads)
+    # the oracle on this rank's own shard (records are functions of (contig, index): every rank regenerates its ranges on the host)
+    parity = None
+    if not a.no_cpu_baseline or a.parity:
+        parity = oracle_interior_check(ctx, cfg, a.config, info, torch, dev)
     hist_ok = None
     if with_comm:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -299,6 +340,12 @@ def main():
         if checks is not None:
             checks["ok_on_ranks"] = n_ok
             checks["ok"] = n_ok == world
+        if parity is not None:
+            pt = torch.tensor([int(parity["all_equal"]), parity["ranges"], parity["reads"], parity["positions"], parity["entries"]], dtype=torch.int64, device=dev)
+            dist.all_reduce(pt)
+            parity["all_equal_on_ranks"] = int(pt[0].item()); parity["all_equal"] = int(pt[0].item()) == world
+            parity["ranges"], parity["reads"], parity["positions"], parity["entries"] = (int(x) for x in pt[1:].tolist())
+            parity["checked"] = [f"(rank 0 of {world}) " + c_ for c_ in parity["checked"]]
     else:
         job_columns, job_cov, job_reads = info.n_columns, info.sum_coverage, n_reads
 
@@ -356,12 +403,15 @@ def main():
             out["checks_full_size"] = checks
         if hist_ok is not None:
             out["hist_reduce_equals_sum_of_ranks"] = hist_ok
-        if world == 1 and not a.no_cpu_baseline:
-            out["parity_interior"] = oracle_interior_check(ctx, cfg, a.config, info, torch, dev)
+        if parity is not None:
+            out["parity_interior"] = parity
+        if world == 1 and not a.no_md:
+            out["md_path"] = md_leg(ctx, cfg, a.config, info, n_reads)
+        if not a.no_cpu_baseline:                                       # (rank 0's host cores, whatever the number of ranks)
             out["cpu_baseline"] = cpu_baseline(a.config, a.cpu_sample_reads)
             out["speedup_vs_cpu_baseline"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
         print(json.dumps(out), file=result_out, flush=True)
-        if (checks is not None and not checks["ok"]) or hist_ok is False or ("parity_interior" in out and not out["parity_interior"]["all_equal"]):
+        if (checks is not None and not checks["ok"]) or hist_ok is False or ("parity_interior" in out and not out["parity_interior"]["all_equal"]) or ("md_path" in out and not out["md_path"]["prefix_vs_oracle"]["equal"]):
             sys.stderr.write("bench.py: a result check FAILED (see checks_full_size / hist_reduce_equals_sum_of_ranks / parity_interior)\n")
             ctx.close()
             sys.exit(3)

@@ -616,7 +616,10 @@ __global__ __launch_bounds__(256) void k6_fill(const uint8_t* s, const bgp_recor
 // chunk is fetched on its last base, ...) is redone by k6_chain -- the exact event loop stays the authority,
 // and every BGP_EMD comes from it.
 constexpr uint32_t SX_END = 0xFFFFFFFFu, SX_NONE = 0xFFFFFFFEu, SX_FLAG = 1u << 31;
-constexpr int SEG = 2048, SUCC_CAP = 4096;
+#ifndef BGP_MD_SEG
+#define BGP_MD_SEG 2048                       // (a test build with 32 makes a thousand reads many segments: the fuzz loop then runs k6_top's parts and meetings)
+#endif
+constexpr int SEG = BGP_MD_SEG, SUCC_CAP = 4096;
 #ifndef BGP_SUCC_LANE_CAP
 #define BGP_SUCC_LANE_CAP 128                 // rows a lane of the general walk looks at before it hands its read to the wave
 #endif
@@ -892,38 +895,132 @@ __global__ __launch_bounds__(256) void k6_exit(const Succ* succ, uint64_t n, Suc
 
 // One wave per run: the first provider (initNewReference on the run's first position group, filtered against the
 // chunk_end carried over from the previous reference), then segment to segment through the exit table.
+//
+// The walk is a chain of dependent loads, one per segment the chain enters (cfg3: 6 100 hops a reference, 2.9 ms with one lane at
+// it).  But the chain forgets where it came from: exit(P) depends on P alone, so two walks that ever stand on the same provider are
+// one walk from there on -- and they meet within a segment or two, because whatever the start, the next provider is "the read
+// reaching furthest" of nearly the same reads.  So the run's segments are dealt out to the 64 lanes in equal parts; lane 0 starts
+// on the real first provider, every other lane on the first covering read of its part (a guess), and all walk their parts side
+// by side, leaving their trails in seg_entry.  Then lane p walks ON into part p + 1 until it stands on a provider of that part's
+// trail: the true chain enters part p + 1 the way lane p does and is lane p + 1's trail from the meeting point on (by induction
+// from lane 0, whose trail is true).  The slots in front of the meeting point are rewritten by the lane that walked in.  A part
+// whose trail is never met (or a chain that ends on the way) sends the whole run through the one-lane walk: the guess only ever
+// costs time.  Flags are gathered over everything any lane walked -- a superset of the chain's.
+__device__ __forceinline__ Succ ld_entry(const Succ* p) {
+    const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return Succ{(uint32_t)v, (uint32_t)(v >> 32)};
+}
 __global__ __launch_bounds__(64) void k6_top(const MdRow* rows, const Succ* ex, const ParRun* pr, ParOut* po, Succ* seg_entry) {
     const ParRun R = pr[blockIdx.x];
-    if (!R.active || threadIdx.x != 0) return;
+    if (!R.active) return;
+    const int lane = threadIdx.x;
     bool flag = false;
-    // add() of the first group: the first read unconditionally, a later one if it ends beyond the stale chunk_end and beyond the best so far
-    const MdRow r0 = rows[R.first];
-    uint32_t node = (uint32_t)R.first, best_end = r0.end, later_max = 0; MdRow nr = r0;
-    int budget = SUCC_CAP;
-    for (uint64_t k = R.first + 1; k < R.endrec; ++k) {
-        if (--budget < 0) { flag = true; break; }
-        const MdRow q = rows[k];
-        if (!(q.lf & MD_COV)) continue;
-        if (q.pos != r0.pos) break;
-        if (q.end > R.ce_in && q.end > best_end) { node = (uint32_t)k; best_end = q.end; nr = q; later_max = 0; }
-        else later_max = max(later_max, q.end);
+    uint32_t node0 = 0, F0 = 0;
+    if (lane == 0) {
+        // add() of the first group: the first read unconditionally, a later one if it ends beyond the stale chunk_end and beyond the best so far
+        const MdRow r0 = rows[R.first];
+        uint32_t node = (uint32_t)R.first, best_end = r0.end, later_max = 0; MdRow nr = r0;
+        int budget = SUCC_CAP;
+        for (uint64_t k = R.first + 1; k < R.endrec; ++k) {
+            if (--budget < 0) { flag = true; break; }
+            const MdRow q = rows[k];
+            if (!(q.lf & MD_COV)) continue;
+            if (q.pos != r0.pos) break;
+            if (q.end > R.ce_in && q.end > best_end) { node = (uint32_t)k; best_end = q.end; nr = q; later_max = 0; }
+            else later_max = max(later_max, q.end);
+        }
+        // The one place where chunk_end can DROP is here: the stale value of the previous reference may exceed the winner's
+        // end.  A read of this group that add() turned down for not ending beyond the stale value, but that ends beyond the
+        // winner, would look like a candidate to succ() although the sweep never sees it again: not a regular start.
+        flag |= later_max > best_end;
+        flag |= arrival_irregular(nr, r0.pos);
+        node0 = node; F0 = r0.pos;
     }
-    // The one place where chunk_end can DROP is here: the stale value of the previous reference may exceed the winner's
-    // end.  A read of this group that add() turned down for not ending beyond the stale value, but that ends beyond the
-    // winner, would look like a candidate to succ() although the sweep never sees it again: not a regular start.
-    flag |= later_max > best_end;
-    uint32_t F = r0.pos;
-    flag |= arrival_irregular(nr, F);
-    uint32_t hops = 0;
-    for (;;) {
-        seg_entry[node / SEG + blockIdx.x] = Succ{node, F};       // slot = segment + run ordinal: two runs may share a segment
-        const Succ e = ex[node];
-        flag |= (e.fcol & SX_FLAG) != 0;
-        ++hops;
-        if (e.nxt >= SX_NONE || flag) { flag |= e.nxt == SX_NONE; break; }
-        node = e.nxt; F = e.fcol & ~SX_FLAG;
+    const uint64_t seg_f = R.first / SEG, seg_l = (R.endrec - 1) / SEG;
+    const uint64_t per = (seg_l - seg_f + 64) / 64;                           // segments a part
+    const uint64_t p_lo = seg_f + (uint64_t)lane * per, p_hi = min(p_lo + per, seg_l + 1);
+    const bool has = p_lo <= seg_l;
+    const uint32_t n_parts = (uint32_t)((seg_l - seg_f + per) / per);
+    auto slot = [&](uint64_t seg) { return seg + blockIdx.x; };                // slot = segment + run ordinal: two runs may share a segment
+    const bool flag0 = __builtin_amdgcn_readfirstlane((int)flag) != 0;         // the first provider's own premises
+    // ---- every lane its own part
+    uint32_t node = node0, F = F0, hops = 0;
+    bool live = lane == 0;                                                     // this lane stands on a provider
+    if (lane != 0 && has && !flag0) {
+        const uint64_t from = max(p_lo * SEG, R.first), to = min(min(p_hi * SEG, R.endrec), from + 256);
+        for (uint64_t k = from; k < to; ++k) { const MdRow q = rows[k]; if (q.lf & MD_COV) { node = (uint32_t)k; F = q.pos; live = true; break; } }
     }
-    po[blockIdx.x] = ParOut{0u, flag ? 1u : 0u, hops, 0u};
+    // a walk from (node, F) while the provider lies in a segment < hi.  write: leave the trail; meet: stop on a provider of the trail that is
+    // there.  Returns the last segment a flagged hop (or the chain's irregular end) left from, -1 if none.
+    auto walk = [&](uint64_t hi, bool write, bool meet, uint64_t* met_seg) -> int64_t {
+        int64_t lfs = -1;
+        while (live) {
+            const uint64_t seg = node / SEG;
+            if (seg >= hi) break;
+            if (meet) { const Succ t = ld_entry(seg_entry + slot(seg)); if (t.nxt == node) { *met_seg = seg; break; } }
+            if (write) seg_entry[slot(seg)] = Succ{node, F};
+            const Succ e = ex[node];
+            if ((e.fcol & SX_FLAG) || e.nxt == SX_NONE) lfs = (int64_t)seg;
+            ++hops;
+            if (e.nxt >= SX_NONE) { live = false; break; }                    // the chain ends here
+            node = e.nxt; F = e.fcol & ~SX_FLAG;
+        }
+        return lfs;
+    };
+    uint64_t met = ~0ull;
+    const int64_t lfs_own = walk(p_hi, true, false, &met);
+    __threadfence();
+    __builtin_amdgcn_wave_barrier();
+    // ---- on into the next part until the trails meet
+    const bool has_next = has && (uint32_t)lane + 1 < n_parts;
+    const uint32_t x_node = node, x_F = F;                                     // where this lane left its part
+    bool fine = true;                                                          // (lane 0 .. n_parts - 2: the next part's trail was met)
+    int64_t lfs_ext = -1;
+    if (has_next) {
+        if (!live) fine = false;                                               // no provider to walk on with (the chain ended in this part, or no guess)
+        else { lfs_ext = walk(min(p_hi + per, seg_l + 1), false, true, &met); fine = met != ~0ull; }
+    }
+    const bool all_fine = __ballot(has_next && !fine) == 0 && !flag0;
+    if (all_fine) {
+        // which flags lie on the chain: lane 0's all; of another lane's own walk those from the segment on where the lane before it met its trail;
+        // of a walk into the next part all (it stops where it meets)
+        const uint64_t met_prev = __shfl_up(met, 1, 64);
+        flag = has && ((lane == 0 ? lfs_own >= 0 : lfs_own >= (int64_t)met_prev) || lfs_ext >= 0);
+        if (has_next) {                                                        // the true entries of the next part in front of the meeting point: this lane's
+            for (uint64_t sg = p_hi; sg <= met; ++sg) seg_entry[slot(sg)] = Succ{SX_NONE, 0u};
+            node = x_node; F = x_F;
+            // (the same hops again, this time written; it stops in front of the meeting segment, whose entry is the provider met -- with THIS walk's fetch column)
+            for (;;) {
+                const uint64_t seg = node / SEG;
+                if (seg >= met) break;
+                seg_entry[slot(seg)] = Succ{node, F};
+                const Succ e = ex[node];
+                node = e.nxt; F = e.fcol & ~SX_FLAG;
+            }
+            seg_entry[slot(met)] = Succ{node, F};
+        }
+    } else {
+        // the one-lane walk (the round 2 kernel): every slot of the run first
+        for (uint64_t sg = seg_f + lane; sg <= seg_l; sg += 64) seg_entry[slot(sg)] = Succ{SX_NONE, 0u};
+        __threadfence();
+        __builtin_amdgcn_wave_barrier();
+        flag = false; hops = 0;
+        if (lane == 0) {
+            flag = flag0; node = node0; F = F0;
+            for (;;) {
+                seg_entry[slot(node / SEG)] = Succ{node, F};
+                const Succ e = ex[node];
+                flag |= (e.fcol & SX_FLAG) != 0;
+                ++hops;
+                if (e.nxt >= SX_NONE || flag) { flag |= e.nxt == SX_NONE; break; }
+                node = e.nxt; F = e.fcol & ~SX_FLAG;
+            }
+        }
+    }
+    const bool any_flag = __ballot(flag) != 0;
+    uint32_t h = hops;
+    for (int d = 32; d >= 1; d >>= 1) h += (uint32_t)__shfl_xor((int)h, d, 64);
+    if (lane == 0) po[blockIdx.x] = ParOut{0u, any_flag ? 1u : 0u, h, 0u};
 }
 
 // One wave per segment the chain enters: lane 0 re-walks the segment from its entry (nodes to LDS), then the

@@ -183,6 +183,34 @@ def check_range(ctx, cfg, first, count, entries=False, entry_positions=1500):
     return {"reads": count, "positions": n_pos, "entries": n_ent}
 
 
+def md_prefix_check(ctx, cfg, count=20_000):
+    """reference_base with use_md_tag (PileupRangeUsingMdTag, pileup.d:522-654) on the resident result: the columns in front of
+    record `count`'s position depend on records [0, count) alone -- add() sees a read when the sweep reaches its position
+    (pileup.d:563-596) -- so the oracle's sweep over that prefix must give the device's bytes there.  (Only the stream's first
+    reference: a later one begins under the chunk_end_position the one before left behind, pileup.d:583-595.)"""
+    n = ctx.num_records()
+    count = min(count, n - 1)
+    st = host_stream(cfg, 0, count + 1)
+    soa = O.decode_soa(st)
+    r0 = int(soa.ref_id[0])
+    same = np.nonzero(soa.ref_id != r0)[0]
+    if len(same):
+        count = int(same[0]) - 1
+    hi_p = int(soa.pos[count])
+    ora = O.pileup(host_stream(cfg, 0, count), use_md=True, skip_zero=True)
+    sel = (ora.ref == r0) & (ora.pos < hi_p)
+    poss, bases = [], []
+    for w in ctx.pileup_windows(L.BGP_MAKE_PILEUP, use_md_tag=True, ref_id=r0, start_from=0, end_at=hi_p, skip_zero_coverage=True, window_positions=1 << 20):
+        keep = w.columns["coverage"] > 0
+        poss.append((int(w.first_position) + np.arange(len(w.columns), dtype=np.int64))[keep]); bases.append(w.reference_base[keep])
+    poss = np.concatenate(poss) if poss else np.zeros(0, np.int64)
+    bases = np.concatenate(bases) if bases else np.zeros(0, np.uint8)
+    assert np.array_equal(poss, ora.pos[sel].astype(np.int64)), "use_md_tag: the columns visited"
+    bad = np.nonzero(bases != ora.refbase[sel])[0]
+    assert len(bad) == 0, f"reference_base differs at {len(bad)} columns, first {int(poss[bad[0]])}: device {chr(bases[bad[0]])}, oracle {chr(ora.refbase[sel][bad[0]])}"
+    return {"reads": count, "columns": int(len(poss))}
+
+
 def run(ctx, cfg, info, count, torch=None, dev=None, want=16, entries_on=(0, 5)):
     """All planned ranges; returns the summary bench.py prints as `parity_interior`."""
     plan = plan_ranges(ctx, cfg, info, count, torch, dev, want)
