@@ -27,6 +27,7 @@ struct Batch {
     int want_entries = 0; uint32_t window = 65536;
     HostBuf host[2]; uint64_t host_len[2] = {0, 0}; hipEvent_t host_free[2] = {nullptr, nullptr};
     int fill = 0;                                       // host buffer taking the pushes
+    int acq = -1; uint64_t acq_off = 0;                 // bgp_batch_acquire handed out host[acq] from acq_off on and waits for its commit (-1: nothing outstanding)
     DevBuf dev[2]; uint64_t new_off[2] = {0, 0}, new_len[2] = {0, 0}; hipEvent_t loaded_ev[2] = {nullptr, nullptr};
     enum { FREE, LOADED, CURRENT } state[2] = {FREE, FREE};
     int queue[2] = {0, 0}; int n_queue = 0;             // loaded device buffers, oldest first
@@ -206,6 +207,7 @@ int bgp_batch_push(bgp_ctx* c, const uint8_t* data, size_t len, size_t* taken) {
     if (!c || (!data && len) || !taken) return BGP_EINVAL;
     Batch* b = c->batch;
     if (!b || b->ended) return BGP_ESTATE;
+    if (b->acq >= 0) return BGP_ESTATE;                  // an acquired buffer is waiting for its commit: a push could ship it from under the caller
     BGP_HIP(hipSetDevice(c->device));
     *taken = 0;
     while (*taken < len) {
@@ -227,11 +229,15 @@ int bgp_batch_acquire(bgp_ctx* c, uint8_t** ptr, size_t* cap) {
     if (!c || !ptr || !cap) return BGP_EINVAL;
     Batch* b = c->batch;
     if (!b || b->ended) return BGP_ESTATE;
+    if (b->acq >= 0) return BGP_ESTATE;                  // one acquisition at a time: commit (0 bytes if need be) before the next
     BGP_HIP(hipSetDevice(c->device));
     *ptr = nullptr; *cap = 0;
-    if (b->host_len[b->fill] == b->batch_bytes) { const int rc = ship(c, b); if (rc != BGP_OK) return rc; }      // BGP_EAGAIN: hand out windows first
+    // a buffer with less room than one BGZF block inflates to (64 KiB, constants.d:26-61) is shipped as it is: a caller that writes
+    // whole blocks could otherwise be handed a tail it can never use, with no way to move on
+    if (b->batch_bytes - b->host_len[b->fill] < std::min<uint64_t>(b->batch_bytes, 65536) && b->host_len[b->fill]) { const int rc = ship(c, b); if (rc != BGP_OK) return rc; }      // BGP_EAGAIN: hand out windows first
     const int h = b->fill;
     *ptr = b->host[h].as<uint8_t>() + b->host_len[h]; *cap = (size_t)(b->batch_bytes - b->host_len[h]);
+    b->acq = h; b->acq_off = b->host_len[h];
     return BGP_OK;
     BGP_API_CATCH(c)
 }
@@ -240,9 +246,11 @@ int bgp_batch_commit(bgp_ctx* c, size_t n) {
     if (!c) return BGP_EINVAL;
     Batch* b = c->batch;
     if (!b || b->ended) return BGP_ESTATE;
-    const int h = b->fill;
-    if (n > b->batch_bytes - b->host_len[h]) return BGP_EINVAL;
+    if (b->acq < 0) return BGP_ESTATE;                   // nothing was acquired
+    const int h = b->acq;                                // the buffer that was handed out, whatever `fill` says by now
+    if (b->host_len[h] != b->acq_off || n > b->batch_bytes - b->host_len[h]) return BGP_EINVAL;
     b->host_len[h] += n;
+    b->acq = -1;
     return BGP_OK;
     BGP_API_CATCH(c)
 }
@@ -260,6 +268,7 @@ int bgp_batch_set_md(bgp_ctx* c, int use_md_tag, int skip_zero_coverage) {
 int bgp_batch_end(bgp_ctx* c) {
     BGP_API_TRY
     if (!c || !c->batch) return BGP_ESTATE;
+    if (c->batch->acq >= 0) return BGP_ESTATE;           // an acquired buffer was never committed
     c->batch->ended = true;
     return BGP_OK;
     BGP_API_CATCH(c)

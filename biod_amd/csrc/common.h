@@ -75,7 +75,9 @@ struct HostBuf {                      // pinned host memory
         p = np; cap = want;
         return BGP_OK;
     }
-    void retire(void* q) { try { retired.push_back(q); } catch (...) { (void)hipHostFree(q); } }
+    // (one generation is kept: a view is promised to live until the next call of the same kind, and that call is the one that retires
+    // its buffer -- older ones are nobody's; a window that grows a ninth at a time would otherwise keep ~9 x its final size pinned)
+    void retire(void* q) { for (void* o : retired) (void)hipHostFree(o); retired.clear(); try { retired.push_back(q); } catch (...) { (void)hipHostFree(q); } }
     void trim() { for (void* q : retired) (void)hipHostFree(q); retired.clear(); }       // bgp_reset: every iteration over the old results is over
     void release() { trim(); if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
     template <class T> T* as() const { return (T*)p; }
@@ -211,9 +213,8 @@ int k12_fused_decode(bgp_ctx* c, uint32_t what);            // decode.hip : K1 +
 bool k12_lds_applies(const bgp_ctx* c, uint32_t what); uint32_t k12_lds_segment_bytes(uint64_t stream_len); uint32_t k12_lds_window_shift(); int k12_lds_decode(bgp_ctx* c, uint32_t what);   // decode.hip : K1 + K2 through LDS windows, framing from K0
 int k012_stream_decode(bgp_ctx* c, uint32_t what);          // decode.hip : K0 + K1 + K2 in ONE pass (framing by look-back); 1 = gave up, take the three-kernel path
 constexpr uint32_t BGP_LONG_CIGAR = 32;                      // more ops than this: basesCovered is summed by a whole wave (k1_long_cigar)
-int k34_pileup(bgp_ctx* c);
+int k34_pileup(bgp_ctx* c);                                 // pileup.hip : runs + dense columns
 void prefetch_cancel(bgp_ctx* c);      // api.cpp: before d_columns is written again, and when the ctx lets go of its results
-void prefetch_cancel(bgp_ctx* c);      // api.cpp: before d_columns is written again                                 // pileup.hip : runs + dense columns
 int k34_first_survivor(bgp_ctx* c, uint32_t run, uint64_t start_from, uint64_t* pos, uint64_t* record);
 int k5_entries(bgp_ctx* c, uint32_t run, uint64_t pos_begin, uint64_t pos_end, uint64_t* n_entries);  // pileup.hip : CSR for a window
 int scan_exclusive_u64(bgp_ctx* c, const uint64_t* in, uint64_t* out, uint64_t n, uint64_t* total_host);   // scan.hip (out has n+1 entries)

@@ -86,20 +86,28 @@ __device__ __forceinline__ void unpack_group(const DecArgs& a, int cnt, const ui
     if (CIG) {
         const uint64_t c0 = s_cig_off[0], c1 = s_cig_off[cnt];
         const float inv = c1 > c0 ? (float)cnt / (float)(c1 - c0) : 0.f;
-        for (uint64_t i = c0 + threadIdx.x; i < c1; i += blockDim.x) {
-            const int j = find_rec(s_cig_off, cnt, i, (int)((float)(i - c0) * inv));
-            const uint32_t op = ld_u32(a.s + s_info[j].cig_ptr + 4 * (i - s_cig_off[j]));
-            a.cigar[i] = op;
+        for (uint64_t ib = c0; ib < c1; ib += blockDim.x) {      // (a bound every thread agrees on: the wave reduction below is over all 64 lanes, none of them masked off)
+            const uint64_t i = ib + threadIdx.x;
+            const bool in = i < c1;
+            int j = 0; uint32_t op = 0;
+            if (in) {
+                j = find_rec(s_cig_off, cnt, i, (int)((float)(i - c0) * inv));
+                op = ld_u32(a.s + s_info[j].cig_ptr + 4 * (i - s_cig_off[j]));
+                a.cigar[i] = op;
+            }
             if (s_cov) {                                   // basesCovered of the long CIGARs on the way (a wave's ops are nearly always one record's: one LDS atomic a wave)
-                const uint32_t cov = s_info[j].sum_cov && cig_rc(op) ? op >> 4 : 0u;
-                const unsigned long long act = __ballot(true);
-                const int j0 = __shfl(j, __ffsll((long long)act) - 1, 64);
-                if (__ballot(j != j0) == 0) {
-                    uint32_t t = cov;
+                const uint32_t cov = in && s_info[j].sum_cov && cig_rc(op) ? op >> 4 : 0u;
+                const unsigned long long act = __ballot(in);
+                if (act) {
+                    const int l0 = __ffsll((long long)act) - 1;
+                    const int j0 = __shfl(j, l0, 64);
+                    if (__ballot(in && j != j0) == 0) {
+                        uint32_t t = cov;                  // (0 in the lanes behind the last op)
 #pragma unroll
-                    for (int d = 32; d >= 1; d >>= 1) t += (uint32_t)__shfl_xor((int)t, d, 64);
-                    if (t && (int)(threadIdx.x & 63) == __ffsll((long long)act) - 1) atomicAdd(&s_cov[j0], t);
-                } else if (cov) atomicAdd(&s_cov[j], cov);
+                        for (int d = 32; d >= 1; d >>= 1) t += (uint32_t)__shfl_xor((int)t, d, 64);
+                        if (t && (int)(threadIdx.x & 63) == l0) atomicAdd(&s_cov[j0], t);
+                    } else if (cov) atomicAdd(&s_cov[j], cov);
+                }
             }
         }
     }
@@ -180,7 +188,7 @@ __global__ __launch_bounds__(256) void k2_unpack(DecArgs a) {
     unpack_group<SEQ, QUAL, CIG>(a, cnt, s_seq_off, s_cig_off, s_info, fix ? s_cov : nullptr);
     if (fix) {
         __syncthreads();
-        for (int j = threadIdx.x; j < cnt; j += blockDim.x) if (s_cov[j]) atomicAdd(&a.rec_fix[r0 + j].end_pos, (int32_t)s_cov[j]);      // read.d:1382: position + basesCovered (the row held the position)
+        for (int j = threadIdx.x; j < cnt; j += blockDim.x) if (s_cov[j]) a.rec_fix[r0 + j].end_pos = a.rec_fix[r0 + j].pos + (int32_t)s_cov[j];      // read.d:1382: position + basesCovered (written, not added: doing it twice changes nothing)
     }
 }
 

@@ -180,7 +180,7 @@ template <class RD, int SINK> __device__ __forceinline__ bool chase_one(const Fr
     // `live` says whether the chain goes on inside the segment
     auto hop = [&](uint32_t* v) -> bool {
         if (a.sub) {                                                     // the windows this record's start has passed: what lay in front of them
-            const uint32_t w = (uint32_t)((off - seg0) >> a.sub_shift);
+            const uint32_t w = off >= seg0 ? (uint32_t)((off - seg0) >> a.sub_shift) : 0u;      // (a batch's chain may stand in front of the segment: a record it still waits for)
             while (wcur < w && wcur + 1 < a.sub_n) { ++wcur; a.sub[k * a.sub_n + wcur] = make_uint4((uint32_t)cnt, (uint32_t)ls, (uint32_t)nc, 0u); }
         }
         live = false;
@@ -311,7 +311,9 @@ __global__ __launch_bounds__(256) void k0_rechase(FrameArgs a, const uint32_t* l
     __syncthreads();
     while (s_go) {
         const uint64_t seg0 = k * (uint64_t)a.seg_bytes, seg_end = min(seg0 + a.seg_bytes, a.len);
-        const uint64_t w0 = (s_off & ~15ull), w1 = min(a.len & ~15ull, ((k + 1) * (uint64_t)a.seg_bytes + 64) & ~15ull);      // from the entry to a header's length past the segment, whole 16-byte pieces
+        // from the entry to a header's length past the segment, whole 16-byte pieces -- and never more than the window holds: in a batch
+        // (tolerant tail) the entry may lie in front of the segment, with a record still incomplete at the batch's end
+        const uint64_t w0 = (s_off & ~15ull), w1 = min(min(a.len & ~15ull, ((k + 1) * (uint64_t)a.seg_bytes + 64) & ~15ull), w0 + (((uint64_t)a.seg_bytes + 96) & ~15ull));
         if (w1 > w0) for (uint64_t o = w0 + 16ull * t; o < w1; o += 16ull * 256) { uint4 v; __builtin_memcpy(&v, a.s + o, 16); *reinterpret_cast<uint4*>(rw + (o - w0)) = v; }
         if (t < 26) s_acc[t] = 0;
         __syncthreads();
@@ -322,7 +324,7 @@ __global__ __launch_bounds__(256) void k0_rechase(FrameArgs a, const uint32_t* l
         if (t == 0) {
             uint32_t n = 0; uint64_t off = s_off; bool plain = a.sub_n <= 8;
             while (plain && off < seg_end) {
-                if (off < w0 || off + 24 > w1 || n >= lst_cap) { plain = false; break; }
+                if (off < seg0 || off < w0 || off + 24 > w1 || n >= lst_cap) { plain = false; break; }
                 uint32_t bs; __builtin_memcpy(&bs, rw + (off - w0), 4);
                 if ((int32_t)bs < 32 || (uint64_t)bs > a.len - off - 4) { plain = false; break; }
                 lst[n++] = (uint32_t)(off - seg0);
@@ -583,8 +585,13 @@ int k0_frame(bgp_ctx* c) {
     for (;;) {
         {
             TimedRegion t(c, n_list ? "k0_rechase" : "k0_chase", 0);
-            if (n_list) hipLaunchKernelGGL(k0_rechase, dim3(n_list), dim3(256), (((size_t)seg + 96 + 15) & ~(size_t)15) + 4 * ((size_t)seg / 36 + 2) + 16, c->stream, a, a.list, n_list);
-            else hipLaunchKernelGGL(k0_chase, dim3(lane_blocks), dim3(256), 0, c->stream, a);
+            bool listed = false;
+            if (n_list) {      // (the window in LDS is the segment and a ninth more -- beyond the 64 KiB a kernel gets without asking, and only there on gfx950:
+                               // a launch that fails leaves dirty[] as it is, and the round falls to k0_chase, which takes every dirty segment)
+                hipLaunchKernelGGL(k0_rechase, dim3(n_list), dim3(256), (((size_t)seg + 96 + 15) & ~(size_t)15) + 4 * ((size_t)seg / 36 + 2) + 16, c->stream, a, a.list, n_list);
+                listed = hipGetLastError() == hipSuccess;
+            }
+            if (!listed) { hipLaunchKernelGGL(k0_chase, dim3(lane_blocks), dim3(256), 0, c->stream, a); BGP_HIP(hipGetLastError()); }
         }
         BGP_HIP(hipMemsetAsync(a.status + 1, 0, 4, c->stream));
         hipLaunchKernelGGL(k0_verify, dim3(lane_blocks), dim3(256), 0, c->stream, a);

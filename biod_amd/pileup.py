@@ -220,6 +220,18 @@ class Context:
         rc = L.check(L.lib().bgp_batch_push(self._h, buf, len(mv), C.byref(taken)), self._h)
         return int(taken.value), rc
 
+    def batch_acquire(self):
+        """(writable view of the pinned buffer's free tail, status): the zero-copy side of batch_push (bgp_batch_acquire).  BGP_EAGAIN
+        (view None): hand out windows first.  The view is the caller's until batch_commit(n)."""
+        ptr = C.c_void_p(); cap = C.c_size_t()
+        rc = L.check(L.lib().bgp_batch_acquire(self._h, C.byref(ptr), C.byref(cap)), self._h)
+        if rc != L.BGP_OK or not ptr.value:
+            return None, rc
+        return memoryview((C.c_char * cap.value).from_address(ptr.value)).cast("B"), rc
+
+    def batch_commit(self, n: int):
+        L.check(L.lib().bgp_batch_commit(self._h, n), self._h)
+
     def batch_end(self):
         L.check(L.lib().bgp_batch_end(self._h), self._h)
 
@@ -254,6 +266,24 @@ class Context:
                 off += taken
                 if rc == L.BGP_EAGAIN:
                     yield from self.batch_drain()
+        self.batch_end()
+        yield from self.batch_drain()
+
+    def batched_windows_zero_copy(self, pieces, batch_bytes: int = 0, want_entries: bool = False, window_positions: int = 0, use_md_tag=False, skip_zero_coverage=True):
+        """batched_windows with the pieces written straight into the pinned staging buffer (bgp_batch_acquire / _commit)."""
+        self.batch_begin(batch_bytes, want_entries, window_positions, None, use_md_tag, skip_zero_coverage)
+        for piece in pieces:
+            mv = memoryview(piece).cast("B")
+            off = 0
+            while off < len(mv):
+                view, rc = self.batch_acquire()
+                if rc == L.BGP_EAGAIN:
+                    yield from self.batch_drain()
+                    continue
+                m = min(len(view), len(mv) - off)
+                view[:m] = mv[off:off + m]
+                self.batch_commit(m)
+                off += m
         self.batch_end()
         yield from self.batch_drain()
 

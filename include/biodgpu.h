@@ -264,8 +264,10 @@ int bgp_batch_set_md(bgp_ctx* ctx, int use_md_tag, int skip_zero_coverage);
 int bgp_batch_push(bgp_ctx* ctx, const uint8_t* data, size_t len, size_t* taken);
 /* bgp_batch_push without the copy: bgp_batch_acquire hands out the free tail of the pinned buffer the next batch is copied to HBM
  * from (*cap bytes at *ptr; BGP_EAGAIN: hand out windows first), the caller -- an inflater, as decompressBgzfBlock writes into the
- * block's own buffer, block.d:127-216 -- fills it, bgp_batch_commit says how many bytes it wrote (<= *cap).  Pushes and
- * acquire / commit pairs may be mixed. */
+ * block's own buffer, block.d:127-216 -- fills it, bgp_batch_commit says how many bytes it wrote (<= *cap; 0 is fine).  Pushes and
+ * acquire / commit pairs may alternate, but between an acquire and its commit the buffer is the caller's: bgp_batch_push, a second
+ * bgp_batch_acquire and bgp_batch_end answer BGP_ESTATE until it is committed.  A tail shorter than one inflated BGZF block (64 KiB)
+ * is not handed out: the buffer is shipped as it is and the next one's beginning comes back. */
 int bgp_batch_acquire(bgp_ctx* ctx, uint8_t** ptr, size_t* cap);
 int bgp_batch_commit(bgp_ctx* ctx, size_t n);
 int bgp_batch_end(bgp_ctx* ctx);

@@ -1636,6 +1636,39 @@ def test_batched_staging_fixtures(ctx, data_dir, name, batch):
     assert npos == ctx.pileup_run().n_positions        # the zero-coverage positions inside the runs are handed out too, once
 
 
+@pytest.mark.parametrize("name,batch,piece", [("ex1_header.bam", 150_000, 7777), ("b7_295_chunk.bam", 70_000, 100_000)])
+def test_batched_staging_zero_copy(ctx, data_dir, name, batch, piece):
+    """bgp_batch_acquire / _commit: the caller writes into the pinned buffer the next copy to HBM starts from (the shape of
+    decompressBgzfBlock writing into the block's own buffer, block.d:127-216).  Same columns as the pushes' and the oracle's; and
+    between an acquire and its commit the buffer is the caller's -- a push, a second acquire, the end are refused."""
+    _, st = bamio.read_bam(os.path.join(data_dir, name))
+    assert len(st) > 2 * batch
+    ref, pos, cols, _, npos = _covered(ctx.batched_windows_zero_copy(_pieces(st, piece), batch))
+    _assert_columns_equal_oracle(ref, pos, cols, O.pileup(st))
+    ref2, pos2, cols2, _, npos2 = _covered(ctx.batched_windows(_pieces(st, piece), batch))
+    assert npos == npos2 and np.array_equal(pos, pos2) and np.array_equal(cols, cols2)
+    # the state rules
+    ctx.batch_begin(batch)
+    view, rc = ctx.batch_acquire()
+    assert rc == L.BGP_OK and len(view) == batch
+    for call in (lambda: ctx.batch_push(st[:100]), ctx.batch_acquire, ctx.batch_end):
+        with pytest.raises(L.BiodGpuError) as e:
+            call()
+        assert e.value.code == L.BGP_ESTATE
+    ctx.batch_commit(0)
+    with pytest.raises(L.BiodGpuError) as e:              # nothing is acquired any more
+        ctx.batch_commit(0)
+    assert e.value.code == L.BGP_ESTATE
+    view, rc = ctx.batch_acquire()
+    with pytest.raises(L.BiodGpuError) as e:              # more than was handed out
+        ctx.batch_commit(len(view) + 1)
+    assert e.value.code == L.BGP_EINVAL
+    ctx.batch_commit(0)
+    ctx.batch_end()
+    assert list(ctx.batch_drain()) == []
+    ctx.reset()
+
+
 def test_batched_staging_200k_reads_in_batches(ctx):
     """200 000 reads of cfg3's model (58 MB) in 16 MiB batches: columns == the stream staged at once, and == the oracle
     on a prefix; cut points of the pushes fall anywhere, also inside records."""
