@@ -152,8 +152,7 @@ struct bgp_ctx {
     // pileup (K3/K4)
     DevBuf d_pmax_end, d_pmax_pos;                    // prefix maxima (u64 keys)
     DevBuf d_runs, d_columns, d_depth_hist, d_pstats, d_tiles, d_ck_off, d_ck, d_deep;
-    DevBuf d_chunk_off, d_chunk_state;                // ... the long reads' CIGARs in chunks of 64 ops: where each read's chunks start, the walk's state at each chunk
-    DevBuf d_row_off, d_rows;                         // long reads on the gather path: one class byte per column of every long read (K4's row arena) and where each read's row starts
+    DevBuf d_wlong;                                   // K4: windows touched by a well-formed long read (k4_acc2 walks its ops there)
     DevBuf d_slab, d_wcount, d_wdel, d_wslow;        // K4 plan: per-window descriptor slabs, counts, whole-window '-' levels, slow-read marks
     std::vector<bgp_run> runs;
     uint32_t ck_w = 0;                                // window width the long-read checkpoints (d_ck_off / d_ck) were built for; 0: none

@@ -727,12 +727,17 @@ __device__ Succ succ_coop(const MdRow* rows, const ParRun& R, uint64_t P, const 
 __global__ __launch_bounds__(256) void k6_succ(const MdRow* rows, const uint32_t* bmax, uint64_t n, const ParRun* pr, uint32_t n_runs, int skip_zero, Succ* succ) {
     // the window a lane scans is the ~50 rows behind its own: the block's 256 rows + 256 more sit in LDS (adjacent
     // lanes read adjacent rows, conflict free); a lane that needs more than LANE_CAP rows hands its read to the wave
-    constexpr int STAGE = 512, LANE_CAP = BGP_SUCC_LANE_CAP;
+    constexpr int STAGE = 512;
+#if BGP_SUCC_SCAN
+    constexpr int LANE_CAP = BGP_SUCC_LANE_CAP;
+#endif
     __shared__ MdRow s_rows[STAGE];
     const uint64_t base = (uint64_t)blockIdx.x * blockDim.x;
     for (int t = threadIdx.x; t < STAGE; t += 256) s_rows[t] = base + t < n ? rows[base + t] : MdRow{0, 0, 0, 0};
     __syncthreads();
+#if BGP_SUCC_SCAN
     auto row_at = [&](uint64_t j) -> MdRow { const uint64_t d = j - base; return d < (uint64_t)STAGE ? s_rows[d] : rows[j]; };
+#endif
     const int lane = threadIdx.x & 63;
     const uint64_t P = base + threadIdx.x;
     const MdRow rp = s_rows[threadIdx.x];

@@ -60,7 +60,6 @@ struct RunDev { int32_t ref_id; uint32_t pad; uint64_t first_record, end_record,
 struct K3Args { const bgp_record* rec; uint64_t n; uint64_t* key_end; uint64_t* key_pos; uint32_t* status; /* [3] any long read */ uint32_t run_cap; uint32_t gap; /* a run also begins behind this many positions without coverage (0: never) */ };
 
 constexpr int FAST_LSEQ = 160;         // reads up to 20 dwords of packed SEQ and 4 CIGAR ops take K4's lane = read path
-constexpr uint32_t ROW_PIECE = 256;     // positions of a ROW descriptor (a long read's stretch of a window goes in pieces of this many)
 constexpr int FAST_SEG = 255;          // longest read the planner turns into SEG descriptors (a descriptor's length field: 8 bits; <= 8 staging chunks)
 // Reads that get per-window CIGAR checkpoints and, on the accumulate path, a row of class bytes: more than four ops, or longer
 // than a SEG descriptor holds.  (A read of 161..255 bases with up to four ops needs neither: the planner takes it as SEGs,
@@ -292,6 +291,8 @@ __device__ __forceinline__ uint32_t wave_incl_u32(uint32_t v, int) {
     return v;
 }
 
+__device__ __forceinline__ uint32_t rl(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
+
 // column / query length an op contributes, given whether the cursor has started (pileup.d:180-189,196-217)
 __device__ __forceinline__ void op_lens(uint32_t op, bool active, bool started, uint32_t* rlen, uint32_t* qlen) {
     const uint32_t len = op >> 4, qc = cig_qc(op), rc = cig_rc(op);
@@ -307,25 +308,23 @@ __device__ __forceinline__ uint32_t run_of_record(const RunDev* runs, uint32_t n
     return lo;
 }
 
-__global__ __launch_bounds__(256) void k4_ck_count(const bgp_record* rec, uint64_t n, const RunDev* runs, uint32_t n_runs, uint64_t* n_ck, uint64_t* n_cols, uint64_t* n_chunks, uint32_t W) {
+__global__ __launch_bounds__(256) void k4_ck_count(const bgp_record* rec, uint64_t n, const RunDev* runs, uint32_t n_runs, uint64_t* n_ck, uint32_t W) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const bgp_record r = rec[i];
-    uint64_t c = 0, cols = 0;
+    uint64_t c = 0;
     if (r.end_pos != r.pos && wants_ckpt(r.flag_nc & 0xFFFFu, (uint32_t)r.l_seq)) {
         const RunDev& run = runs[run_of_record(runs, n_runs, i)];
         c = ((uint64_t)(uint32_t)r.end_pos - 1 - run.start_pos) / W - ((uint64_t)(uint32_t)r.pos - run.start_pos) / W + 1;
-        cols = (uint32_t)r.end_pos - (uint32_t)r.pos;
     }
     n_ck[i] = c;
-    if (n_cols) { n_cols[i] = cols; n_chunks[i] = cols ? ((r.flag_nc & 0xFFFFu) + 63) / 64 : 0; }      // a long read's row in the arena: one class byte per column it covers; its CIGAR in chunks of 64 ops
 }
 
 // WPR: a wave per RECORD (a stream of long reads: with a lane per record a wave walks its 64 reads one after the other --
 // cfg5's 200 k reads are 3125 waves of 2000 serial steps on a device with 8192 wave slots); otherwise a lane per record
 // and the wave walks the few long reads among its 64.
 template <bool WPR> __global__ __launch_bounds__(256) void k4_ck_build(const uint8_t* s, uint64_t stream_len, const bgp_record* rec, uint64_t n, const RunDev* runs, uint32_t n_runs,
-                                                   const uint64_t* ck_off, Ckpt* ck, uint32_t W_, const uint64_t* chunk_off, uint4* cst) {
+                                                   const uint64_t* ck_off, Ckpt* ck, uint32_t W_) {
     const int64_t W = (int64_t)W_;
     const int lane = threadIdx.x & 63;
     const uint64_t wave0 = WPR ? (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6) : (uint64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63);   // the wave's (first) record
@@ -380,7 +379,6 @@ template <bool WPR> __global__ __launch_bounds__(256) void k4_ck_build(const uin
             const uint32_t ir = wave_incl_u32(rlen, lane), iq = wave_incl_u32(qlen, lane);
             const uint32_t cs_b = cs + ir - rlen, qs_b = qs + iq - qlen;
             if (__ballot(active && cig_rc(op) && (op >> 4) == 0) || __ballot(rlen && cig_qc(op) && qs_b + qlen > l_seq_r)) plain = false;
-            if (cst && lane == 0) cst[chunk_off[ri] + c0 / 64] = make_uint4((uint32_t)ri, c0 | (started ? 0x80000000u : 0u), cs, qs);      // where the chunk starts: k4_rows_build writes its columns
             if (rlen) {
                 if (cs_b == 0 && n_ck) { Ckpt e{c0 + (uint32_t)lane, 0u, qs_b, 0u}; out[0] = e; }      // window of the read's first column
                 int64_t j = (int64_t)cs_b - D <= 0 ? 1 : (int64_t)((uint64_t)((int64_t)cs_b - D + W - 1) >> wsh);   // first window starting at/after cs_b
@@ -392,141 +390,6 @@ template <bool WPR> __global__ __launch_bounds__(256) void k4_ck_build(const uin
         }
         if (lane == 0 && n_ck) out[0].pad = (plain && cs >= covered) ? 0u : 1u;      // the verdict rides on the read's first checkpoint (k4_plan reads it)
     }
-}
-
-// The rows of the accumulate path (ROW descriptors): one class byte per COLUMN of every long read (k4_acc's classes).
-// One wave per chunk of 64 CIGAR ops, from the state k4_ck_build left where the chunk starts -- the walk itself is serial
-// per read, this part is not: written inside the walk it took 13 ms of cfg5's 18, the SIMDs half idle behind one read's
-// chain of chunks.
-__device__ __forceinline__ uint2 class_of_packed8(uint32_t cur);
-// the row bytes are k4_acc's classes: 0 any other base, 1 A, 2 C, 3 G, 4 T, 5 '-'
-#ifndef BGP_ROW_PIECE_COLS
-#define BGP_ROW_PIECE_COLS 30
-#endif
-__global__ __launch_bounds__(256) void k4_rows_build(const uint8_t* s, uint64_t stream_len, const bgp_record* rec, const uint4* cst, uint64_t n_chunks,
-                                                     const uint64_t* row_off, uint8_t* rows) {
-    constexpr uint32_t ROW_OTHER = 0u, ROW_DEL = 5u;
-    constexpr int RB_CAP = 4096;
-    __shared__ __attribute__((aligned(16))) uint8_t s_row[4][RB_CAP];
-    __shared__ uint8_t s_map[4][512];                     // piece of PC columns -> lane of its op (at most RB_CAP / PC + 64 pieces a chunk)
-    const uint64_t ch = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (ch >= n_chunks) return;
-    const uint4 st = cst[ch];
-    if (st.x == 0xFFFFFFFFu) return;                       // (a chunk behind the read's last column: the walk never got there)
-    const uint64_t ri = st.x;
-    const uint32_t c0 = st.y & 0x7FFFFFFFu, cs = st.z, qs = st.w;
-    const bool started = (st.y >> 31) != 0;
-    const bgp_record r = rec[ri];
-    const uint32_t covered = (uint32_t)r.end_pos - (uint32_t)r.pos, n_cig = r.flag_nc & 0xFFFFu, l_name = r.bin_mq_nl & 0xFFu, l_seq_r = (uint32_t)r.l_seq;
-    const uint64_t rec_off = r.rec_off;
-    const bool active = c0 + lane < n_cig;
-    const uint32_t op = active ? ld_u32(s + rec_off + 36 + l_name + 4ull * (c0 + lane)) : 0u;
-    int fl = 64;
-    if (!started) { const unsigned long long stb = __ballot(active && cig_rc(op) && (op & 15u) != 3u); fl = stb ? __ffsll((long long)stb) - 1 : 64; }
-    uint32_t rlen, qlen;
-    op_lens(op, active, started || lane >= fl, &rlen, &qlen);
-    const uint32_t ir = wave_incl_u32(rlen, lane), iq = wave_incl_u32(qlen, lane);
-    const uint32_t cs_b = cs + ir - rlen, qs_b = qs + iq - qlen;
-        {
-                // the read's row for the accumulate path: one class byte per COLUMN, k4_acc's classes (any other base 0, A 1, C 2,
-                // G 3, T 4, '-' 5).  A lane writes its own op's columns -- into LDS: the chunk's 64 ops cover a few
-                // hundred consecutive columns, which then leave as 16-byte stores (byte stores straight to the arena, 64 lanes
-                // on a handful of lines each, cost four times the walk itself).  A chunk with an op of more than 512 columns
-                // (an intron, a long match) or more than RB_CAP columns altogether writes to the arena directly.
-                const uint64_t seq_off = rec_off + 36 + l_name + 4ull * n_cig;
-                const int wv = threadIdx.x >> 6;
-                const uint32_t total = (uint32_t)__shfl((int)ir, 63, 64);
-                uint8_t* const rbase = rows + row_off[ri];
-                const bool is_m = cig_qc(op) != 0;
-                const bool via_lds = total <= (uint32_t)RB_CAP && !__ballot(rlen > 512);
-                auto base_byte = [&](uint32_t q) -> uint8_t {
-                    if (q >= l_seq_r) return (uint8_t)ROW_OTHER;
-                    const uint32_t byte = s[seq_off + (q >> 1)], nib = (q & 1u) ? (byte & 0xFu) : (byte >> 4);
-                    return (uint8_t)(((nib & 8u) ? 0x0000000000000004ull : 0x0000000300020100ull) >> ((nib & 7u) * 8));
-                };
-                const uint32_t wlen = cs_b >= covered ? 0u : min(rlen, covered - cs_b);     // (covered: a malformed read's zero-length ops hold columns its row has no room for)
-                if (via_lds) {
-                    // Not a lane per op -- the wave would run as long as its longest op while most lanes sit out (cfg5: ops of ~15
-                    // columns, the longest of 32 around 60) -- but a lane per PIECE of PC columns: an op announces its pieces in
-                    // an LDS map (piece -> lane of its op), every lane then takes one piece, fetches that op's numbers with two
-                    // ds_bpermute and writes it.
-                    constexpr uint32_t PC = BGP_ROW_PIECE_COLS;      // 30 columns a piece, a 16-byte load of packed bases: a chunk of 64 ops is ~55 pieces, one round of the loop below (14 columns and an 8-byte load: ~67 pieces, a second round for three of them -- k4_rows 7.07 -> 6.45 ms on cfg5)
-                    const uint32_t np = wlen ? (wlen + PC - 1u) / PC : 0u;
-                    const uint32_t ipc = wave_incl_u32(np, lane), p_first = ipc - np, p_total = (uint32_t)__shfl((int)ipc, 63, 64);
-                    for (uint32_t k = 0; k < np; ++k) s_map[wv][p_first + k] = (uint8_t)lane;
-                    const uint32_t packed = (cs_b - cs) | (wlen << 12) | ((is_m ? 1u : 0u) << 22) | (p_first << 23);      // row offset < 4096 | columns <= 512 | M/=/X | first piece < 512
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                    for (uint32_t pb = 0; pb < p_total; pb += 64) {
-                        const uint32_t pc = pb + (uint32_t)lane;
-                        const bool mine = pc < p_total;
-                        const int ol = mine ? (int)s_map[wv][pc] : 0;
-                        const uint32_t pk = (uint32_t)__shfl((int)packed, ol, 64), oq = (uint32_t)__shfl((int)qs_b, ol, 64);
-                        if (!mine) continue;
-                        const uint32_t t0 = PC * (pc - (pk >> 23)), owl = (pk >> 12) & 0x3FFu, lim = min(PC, owl - t0);
-                        uint8_t* const d = &s_row[wv][(pk & 0xFFFu) + t0];
-                        constexpr int NW = PC > 14 ? 8 : 4;
-                        uint32_t wd[NW];
-                        if (!((pk >> 22) & 1u)) {
-#pragma unroll
-                            for (int e = 0; e < NW; ++e) wd[e] = 0x01010101u * ROW_DEL;
-                        } else {
-                            const uint32_t q = oq + t0, odd = q & 1u;
-                            const uint64_t src = seq_off + (q >> 1);
-                            if (src + 2 * NW <= stream_len && q + lim <= l_seq_r) {
-                                uint32_t v[NW / 2];
-                                __builtin_memcpy(v, s + src, 2 * NW);
-                                uint32_t c[NW + 1];
-#pragma unroll
-                                for (int e = 0; e < NW / 2; ++e) { const uint2 cc = class_of_packed8(v[e]); c[2 * e] = cc.x; c[2 * e + 1] = cc.y; }      // four class bytes a dword, three v_perm for them
-                                c[NW] = 0;
-#pragma unroll
-                                for (int e = 0; e < NW; ++e) wd[e] = odd ? __builtin_amdgcn_alignbyte(c[e + 1], c[e], 1) : c[e];
-                            } else {
-#pragma unroll
-                                for (int e = 0; e < NW; ++e) wd[e] = 0;
-                                for (uint32_t b = 0; b < lim; ++b) {
-                                    const uint32_t cb = (uint32_t)base_byte(q + b) << (8 * (b & 3u));
-#pragma unroll
-                                    for (int e = 0; e < NW; ++e) if ((b >> 2) == (uint32_t)e) wd[e] |= cb;
-                                }
-                            }
-                        }
-                        // exactly `lim` bytes (the neighbours' columns are other lanes'), in as few LDS stores as that takes: gfx950's
-                        // DS unit takes unaligned addresses
-                        uint32_t o = 0;
-                        if (NW == 8 && (lim & 16u)) { const uint4 x = make_uint4(wd[0], wd[1], wd[2], wd[3]); __builtin_memcpy(d, &x, 16); o = 16;
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) wd[e] = wd[(e + 4) % NW]; }
-                        uint64_t rest = ((uint64_t)wd[1] << 32) | wd[0];
-                        if (lim & 8u) { __builtin_memcpy(d + o, &rest, 8); o += 8; rest = ((uint64_t)wd[3] << 32) | wd[2]; }
-                        if (lim & 4u) { const uint32_t x = (uint32_t)rest; __builtin_memcpy(d + o, &x, 4); o += 4; rest >>= 32; }
-                        if (lim & 2u) { const uint16_t x = (uint16_t)rest; __builtin_memcpy(d + o, &x, 2); o += 2; rest >>= 16; }
-                        if (lim & 1u) d[o] = (uint8_t)rest;
-                    }
-                } else if (wlen && rlen <= 512) {                                        // (rare: straight to the arena)
-                    uint8_t* const dst = rbase + cs_b;
-                    for (uint32_t t = 0; t < wlen; ++t) dst[t] = is_m ? base_byte(qs_b + t) : (uint8_t)ROW_DEL;
-                }
-                if (via_lds) {
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                    const uint32_t out_n = cs >= covered ? 0u : min(total, covered - cs);
-                    for (uint32_t u = 16u * (uint32_t)lane; u < out_n; u += 1024) {
-                        if (u + 16 <= out_n) { const uint4 v = *reinterpret_cast<const uint4*>(&s_row[wv][u]); __builtin_memcpy(rbase + cs + u, &v, 16); }
-                        else for (uint32_t b = u; b < out_n; ++b) rbase[cs + b] = s_row[wv][b];
-                    }
-                    __builtin_amdgcn_wave_barrier();
-                } else {
-                    unsigned long long big = __ballot(rlen > 512);
-                    while (big) {
-                        const int o = __ffsll((long long)big) - 1;
-                        big &= big - 1;
-                        const uint32_t blen = (uint32_t)__shfl((int)wlen, o, 64), bcs = (uint32_t)__shfl((int)cs_b, o, 64), bqs = (uint32_t)__shfl((int)qs_b, o, 64);
-                        const bool bm = cig_qc((uint32_t)__shfl((int)op, o, 64)) != 0;
-                        for (uint32_t t = lane; t < blen; t += 64) rbase[bcs + t] = bm ? base_byte(bqs + t) : (uint8_t)ROW_DEL;
-                    }
-                }
-            }
 }
 
 // ---- K4: per-position column summary ----------------------------------------------------------
@@ -585,7 +448,6 @@ using L32 = Lay<false, K4_T, W>;
 using L16o = Lay<true, K4_T16, WO>;        // ... on its own tiling (streams of long reads)
 using L32o = Lay<false, K4_T, WO>;
 
-__device__ __forceinline__ uint32_t rl(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
 
 // packed SEQ dwords [w0, w0+64) of a read; lane i holds dword w0+i (bytes past the stream end read as 0)
 __device__ __forceinline__ uint32_t load_seq_words(const uint8_t* s, uint64_t stream_len, uint64_t seq_off, uint32_t n_bytes, uint32_t w0, int lane) {
@@ -1088,9 +950,8 @@ __global__ __launch_bounds__(256) void k4_stats(const unsigned long long* ts, ui
 //   SEG  [2] the read starts here (n_starting_here)  [13:3] first position in the window  [21:14] bases (1..255)
 //        [22] the first base is the LOW nibble of its byte  [63:23] stream offset of that byte
 //   DEL  [13:3] first position  [25:14] one past the last position (<= W)
-//   ROW  (kind 3) a long read's stretch of the window, one class byte per COLUMN (k4_ck_build walks every long read's
-//        CIGAR once and writes them: an M/=/X column its base's class, a D / N column '-'), copied to LDS as it is
-//        [2] the read starts here  [13:3] first position  [23:14] positions - 1  [63:24] offset of the first byte in the row arena
+//   A long read (more than four ops or 255 bases) whose CIGAR walk found it well formed gets no descriptors: it marks the windows it
+//   touches, and k4_acc2 walks its ops there, 64 a step from the window's checkpoint, an op a lane.
 #ifndef BGP_PLAN_ABL
 #define BGP_PLAN_ABL 0                        // timing experiments on k4_plan: 1 no '-' window atomics, 2 no far-slot atomics, 4 no descriptor stores
 #endif
@@ -1099,9 +960,9 @@ constexpr uint32_t SLAB_CAP = W;              // descriptors a window's slab hol
 struct PlanArgs {
     const bgp_record* rec; const uint4* cig4; const uint8_t* s; uint64_t stream_len, n;
     const RunDev* runs; uint32_t n_runs; uint64_t n_tiles;
-    unsigned long long* slab; uint32_t* wcount; int32_t* wdel; int32_t* wslow;
+    unsigned long long* slab; uint32_t slab_cap; uint32_t* wcount; int32_t* wdel; int32_t* wslow;
     const uint64_t* ck_off; const Ckpt* ck;       // long reads' checkpoints on this tiling (null: none, or long reads are left to the general kernel)
-    const uint64_t* row_off;                      // ... and where each one's row of class bytes starts in the arena
+    uint32_t* wlong;                              // ... and the windows a well-formed long read touches (k4_acc2 walks its CIGAR there, from the window's checkpoint)
 };
 
 __global__ __launch_bounds__(256) void k4_plan(PlanArgs a) {
@@ -1153,19 +1014,8 @@ __global__ __launch_bounds__(256) void k4_plan(PlanArgs a) {
     }
     if (covered && !simple) {
         if (a.ck && wants_ckpt(n_cig, l_seq) && a.ck[a.ck_off[ii]].pad == 0) {
-            // a long read that fits the mould (k4_ck_build walked its CIGAR): one ROW descriptor per window it touches
-            const uint32_t rel1 = x.z - (uint32_t)r_start_pos;
-            // (in pieces of at most ROW_PIECE positions: k4_acc's waves draw descriptors, and a window of long reads holds only a few dozen)
-            for (uint32_t w = wf0; w <= wl; ++w) {
-                const uint32_t w0 = (w - tb) * (uint32_t)W;
-                const uint32_t lo = max(rel0, w0) - w0, hi = min(rel1, w0 + (uint32_t)W) - w0;
-                const uint32_t j0 = lo / ROW_PIECE, j1 = (hi - 1) / ROW_PIECE;
-                const uint32_t slot0 = atomicAdd(&a.wcount[w], j1 - j0 + 1);
-                for (uint32_t j = j0; j <= j1; ++j) {
-                    const uint32_t plo = max(lo, j * ROW_PIECE), phi = min(hi, (j + 1) * ROW_PIECE), slot = slot0 + (j - j0);
-                    if (slot < SLAB_CAP) a.slab[(uint64_t)w * SLAB_CAP + slot] = 3ull | (w == wf0 && j == j0 ? 4ull : 0ull) | ((unsigned long long)plo << 3) | ((unsigned long long)(phi - plo - 1) << 14) | ((a.row_off[ii] + (w0 + plo - rel0)) << 24);
-                }
-            }
+            // a long read that fits the mould (k4_ck_build walked its CIGAR): no descriptors -- k4_acc2 walks its ops window by window
+            for (uint32_t w = wf0; w <= wl; ++w) atomicOr(&a.wlong[w], 1u);
         } else {                                          // left to the general kernel, with every window it overlaps
             atomicAdd(&a.wslow[wf0], 1); atomicAdd(&a.wslow[wl + 1], -1);
         }
@@ -1229,9 +1079,9 @@ __global__ __launch_bounds__(256) void k4_plan(PlanArgs a) {
         if (win[j] == 0xFFFFFFFFu) continue;
         const uint32_t slot = win[j] == A ? o0++ : win[j] == A + 1 ? o1++ : far_slot[j];
 #if !(BGP_PLAN_ABL & 4)
-        if (slot < SLAB_CAP) a.slab[(uint64_t)win[j] * SLAB_CAP + slot] = dsc[j];
+        if (slot < a.slab_cap) a.slab[(uint64_t)win[j] * a.slab_cap + slot] = dsc[j];
 #else
-        if (slot == 0xFFFFFFF0u) a.slab[(uint64_t)win[j] * SLAB_CAP] = dsc[j];
+        if (slot == 0xFFFFFFF0u) a.slab[(uint64_t)win[j] * a.slab_cap] = dsc[j];
 #endif
     }
 }
@@ -1271,23 +1121,23 @@ __global__ __launch_bounds__(1024) void k4_wscan_mid(int32_t* btot, uint32_t nb)
         cd += td; cs += ts;
     }
 }
-__global__ __launch_bounds__(1024) void k4_wscan(int32_t* wdel, const int32_t* wslow, const uint32_t* wcount, TileB* tiles, uint64_t n_tiles, const int32_t* btot, uint32_t* deep, uint32_t* n_deep) {
+__global__ __launch_bounds__(1024) void k4_wscan(int32_t* wdel, const int32_t* wslow, const uint32_t* wcount, TileB* tiles, uint64_t n_tiles, const int32_t* btot, uint32_t* deep, uint32_t* n_deep, uint32_t slab_cap) {
     __shared__ int32_t ws[2][16];
     const uint64_t i = (uint64_t)blockIdx.x * 1024 + threadIdx.x;
     int32_t id, is, pd, ps, td, ts;
     wscan_block(i < n_tiles ? wdel[i] : 0, i < n_tiles ? wslow[i] : 0, &id, &is, &pd, &ps, &td, &ts, ws);
     if (i < n_tiles) {
         wdel[i] = btot[2 * blockIdx.x] + pd + id;
-        const uint32_t pad = (tiles[i].pad & 1u) | ((btot[2 * blockIdx.x + 1] + ps + is > 0 || wcount[i] > SLAB_CAP) ? 2u : 0u);
+        const uint32_t pad = (tiles[i].pad & 1u) | ((btot[2 * blockIdx.x + 1] + ps + is > 0 || wcount[i] > slab_cap) ? 2u : 0u);
         tiles[i].pad = pad;
         if (pad) deep[atomicAdd(n_deep, 1u)] = (uint32_t)i;
     }
 }
 
 struct GArgs {
-    const uint8_t* s; const unsigned long long* slab; const uint32_t* wcount; const int32_t* wdel; const TileB* tiles; uint64_t n_tiles;
+    const uint8_t* s; const unsigned long long* slab; uint32_t slab_cap; const uint32_t* wcount; const int32_t* wdel; const TileB* tiles; uint64_t n_tiles;
     bgp_column* cols; unsigned long long* hist; unsigned long long* tile_stats; uint32_t* deep; uint32_t* n_deep;
-    const uint8_t* rows;          // long reads (ROW descriptors): their class bytes in reference coordinates, one byte per column, written by k4_ck_build
+    const uint32_t* wlong; const bgp_record* rec; const uint64_t* ck_off; const Ckpt* ck;      // long reads (null: none): windows they touch, the record table, their per-window checkpoints
 };
 
 // sum / max over the 64 lanes of a wave with DPP (row reductions, then row_bcast15 / row_bcast31); result in every lane
@@ -1308,318 +1158,14 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
     return rl(v, 63);
 }
 
-// ---------------------------------------------------------------------------------------------- K4, accumulate path (round 3)
+// ---------------------------------------------------------------------------------------------- K4, accumulate path: lane = piece, byte planes (round 4)
 //
-// Round 2's executor (k4_exec, the "gather path") made every POSITION read its bases out of class bytes staged in LDS: two passes over every base
-// (stage, gather), per-block segment lists in between, six barriers a window and 76 KB of LDS a workgroup -- two
-// workgroups a CU, whose dependent phases left the SIMDs waiting more than half of the time (round 2's counters).
-// k4_acc runs the same plan (k4_plan's descriptors) the other way round, with nothing staged:
-//
-//   lanes lie ALONG the reads ("consecutive positions -> consecutive LDS addresses"): a lane takes the eight
-//   reference positions 8m .. 8m+7 of one SEG descriptor -- one 8-byte load, eight classes with the v_perm tables -- and
-//   adds each base to its counter with one LDS atomic (ds_add_u32, no return).  Counters are 16 bits wide, positions 2i and
-//   2i+1 share a word, and the words of one class are laid out  plane (k >> 1) x 132 + m  for position 8m + k: in the k-th add
-//   of a chunk the lanes of a segment hit consecutive words, a lane's two positions of one word are never touched by the same
-//   instruction, and the flush reads 64 consecutive positions two lanes a bank.  Bases outside a segment's ends go to a dummy
-//   class.  Which descriptor a lane-chunk belongs to is a byte per chunk in LDS, written by the descriptor's lane; the loads
-//   of A_U steps of 64 chunks are in flight before the first is used (branch-free: a load inside a branch is waited for at
-//   the branch's end), and a wave's next batch of descriptors is requested before it works on the current one.
-//   (Sixteen positions a lane, and a layout with the classes of a chunk next to each other so that the class goes into the
-//   address with one SDWA add, were built and measured: 9.7 and 9.1 ms against 8.55 -- more LDS bank conflicts than they save
-//   in instructions.)
-//
-//   The bases come from the packed SEQ inside the record stream (two bases a byte: a chunk that starts on a low nibble is moved
-//   one nibble up with a funnel shift).  (Taking them from the SEQ arena the decode leaves -- dense chars, 19 instead of 25 GB
-//   fetched on cfg3 -- was built and measured: the same 8.9 ms; the kernel is bound by instruction issue and LDS atomics, not
-//   by HBM, and the chars cost seven more VALU instructions a chunk.  Not kept.)
-//
-//   A workgroup is 4 waves and 30 KB of LDS: five per CU, 20 waves whose phases are independent of each other; a window
-//   costs three barriers.  Waves draw batches of 64 descriptors from a counter in LDS.
-//
-// Same closed form, same descriptors, same columns: every pileup test checks them against the oracle.
-#ifndef BGP_A_U
-#define BGP_A_U 5
-#endif
-#ifndef BGP_A_PLPAD
-#define BGP_A_PLPAD 8
-#endif
-#ifndef BGP_A_MINW
-#define BGP_A_MINW 5
-#endif
-#ifndef BGP_A_DB
-#define BGP_A_DB 64
-#endif
-#ifndef BGP_A_MAPCAP
-#define BGP_A_MAPCAP 1408
-#endif
-#ifndef BGP_A_PERM
-#define BGP_A_PERM 0                          // > 0 (odd): a batch takes every n_bat-th descriptor, neighbours in the batch this many picks apart
-#endif
-constexpr int AT = 256;                       // threads of a k4_acc workgroup
-constexpr int ANW = AT / 64;                  // waves
-constexpr int ABPW = (W / 64) / ANW;          // 64-position blocks a wave flushes
-constexpr int A_PLW = W / 8 + BGP_A_PLPAD;    // words of a plane: one per chunk of eight positions; + 8: the four planes on different banks for the flush, and a class array a multiple of 32 words -- the class of a base does not move its bank, a segment's lanes hit consecutive banks
-constexpr int A_CSW = 4 * A_PLW;              // words of one class array
-constexpr int A_U = BGP_A_U;                  // steps of 64 lane-chunks whose loads are in flight together (six would spill under the 96 registers of five waves a SIMD)
-constexpr int A_DB = BGP_A_DB;                // descriptors of a batch (<= 64: a lane each)
-static_assert(W == 1024 && ABPW * ANW * 64 == W && A_DB == 64, "k4_acc geometry");
-// classes: 0 any other base, 1 A, 2 C, 3 G, 4 T, [5 '-' of long reads' rows,] NC: bases outside a segment (never read)
-template <bool ROWS> struct ALay {
-    static constexpr int NC = ROWS ? 6 : 5;
-    static constexpr int CNT = 0;                                 // (NC + 1) x A_CSW x u32
-    static constexpr int DELD = CNT + (NC + 1) * A_CSW * 4;       // (W + 4) x u32
-    static constexpr int NST = DELD + (W + 4) * 4;                // W x u16
-    static constexpr int HIST = NST + W * 2;                      // HB x u32
-    static constexpr int MARK = HIST + HB * 4;                    // ANW x MROW bytes: chunk -> descriptor of the batch
-    static constexpr int MAXCH = ((int)ROW_PIECE + 14) / 8 + 1;                // chunks of the longest descriptor (SEG: 255 bases, ROW: ROW_PIECE positions)
-    static constexpr int DRAW = ROWS ? 16 : 64;                               // descriptors a wave draws at a time (a window of long reads holds only ~150 pieces: smaller batches keep the four waves busy)
-    static constexpr int MROW = (BGP_A_MAPCAP > MAXCH * (A_DB / 4) ? BGP_A_MAPCAP : MAXCH * (A_DB / 4)) + 64;      // typical batch: 64 x ~20 chunks; a fuller one goes in halves or quarters of its lanes: a quarter always fits
-    static constexpr int DSC = (MARK + ANW * MROW + 15) & ~15;    // ANW x A_DB x uint4
-    static constexpr int MISC = DSC + ANW * A_DB * 16;            // 64 x u32
-    static constexpr int BYTES = MISC + 256;
-};
-static_assert(5 * ALay<false>::BYTES <= 160 * 1024, "five k4_acc workgroups per CU");
-
-// four nt16 codes, one per byte -> their classes (A 1, C 2, G 3, T 4, anything else 0)
-__device__ __forceinline__ uint32_t class_of_codes4(uint32_t x) {
-    const uint32_t idx = x & 0x07070707u;
-    const uint32_t lo = __builtin_amdgcn_perm(0x00000003u, 0x00020100u, idx);      // codes 0..7 : other A C other | G other other other
-    const uint32_t hi = __builtin_amdgcn_perm(0x00000000u, 0x00000004u, idx);      // codes 8..15: T other other other | other ...
-    const uint32_t sel = ((x >> 1) & 0x04040404u) | 0x03020100u;
-    return __builtin_amdgcn_perm(hi, lo, sel);
-}
-__device__ __forceinline__ uint2 class_of_packed8(uint32_t cur) {        // eight packed bases (high nibble first, read.d:368-373) -> eight classes in base order
-    const uint32_t ev = class_of_codes4((cur >> 4) & 0x0F0F0F0Fu), od = class_of_codes4(cur & 0x0F0F0F0Fu);
-    return make_uint2(__builtin_amdgcn_perm(od, ev, 0x05010400u), __builtin_amdgcn_perm(od, ev, 0x07030602u));
-}
-// bytes [lo, hi) of a 64-bit word keep `v`, the others become `padw`'s (0 <= lo, hi <= 8)
-__device__ __forceinline__ uint2 keep_bytes(uint2 v, uint32_t lo, uint32_t hi, uint32_t padw) {
-    const unsigned long long keep = hi > lo ? (~0ull << (8u * lo)) & (~0ull >> (64u - 8u * hi)) : 0ull;
-    return make_uint2((v.x & (uint32_t)keep) | (padw & ~(uint32_t)keep), (v.y & (uint32_t)(keep >> 32)) | (padw & ~(uint32_t)(keep >> 32)));
-}
-
-// ROWS: the stream holds long reads (ROW descriptors: a class byte per column from the row arena k4_rows_build wrote)
-template <bool ROWS> __global__ __launch_bounds__(AT, BGP_A_MINW) void k4_acc(GArgs a) {
-    using L = ALay<ROWS>;
-    constexpr int NC = L::NC;
-    extern __shared__ __attribute__((aligned(16))) uint8_t alds[];
-    uint32_t* const cnt = reinterpret_cast<uint32_t*>(alds + L::CNT);
-    uint32_t* const deld = reinterpret_cast<uint32_t*>(alds + L::DELD);
-    uint32_t* const nst = reinterpret_cast<uint32_t*>(alds + L::NST);
-    uint32_t* const hist = reinterpret_cast<uint32_t*>(alds + L::HIST);
-    uint32_t* const misc = reinterpret_cast<uint32_t*>(alds + L::MISC);      // [0] next batch of the window, [8 ..] wave totals of the '-' scan
-    const int t = threadIdx.x, lane = t & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    uint8_t* const mark = alds + L::MARK + wave * L::MROW;
-    uint4* const dsc = reinterpret_cast<uint4*>(alds + L::DSC) + wave * A_DB;
-    const uint64_t nbt = a.n_tiles, per = (nbt + gridDim.x - 1) / gridDim.x;
-    const uint64_t tile_end = min(nbt, ((uint64_t)blockIdx.x + 1) * per);
-    uint64_t tile = (uint64_t)blockIdx.x * per;
-    if (tile >= tile_end) return;
-    for (int i = t; i < (L::MARK - L::CNT) / 4; i += AT) cnt[i] = 0;           // counters, deld, nst (a window leaves them zeroed again), hist (kept for the whole range)
-    if (t == 0) misc[0] = 0;
-    struct Pre { uint2 col; uint4 tt; uint32_t n; int32_t wd; };                // the next window's header, requested a window ahead, in VECTOR registers made uniform only when used: left to the compiler the loads became scalars with an s_waitcnt right behind the "prefetch" -- which, gfx9 counting loads and stores with ONE in-order counter, also stood for the previous window's column stores
-    auto prefetch = [&](uint64_t w) {
-        Pre p;
-        const char* tp = reinterpret_cast<const char*>(a.tiles + w);
-        __builtin_memcpy(&p.col, tp + 16, 8);
-        __builtin_memcpy(&p.tt, tp + 24, 16);
-        p.n = a.wcount[w]; p.wd = a.wdel[w];
-        return p;
-    };
-    Pre pre = prefetch(tile);
-    uint32_t r_ncol = 0, r_nsum = 0, r_mx = 0; unsigned long long r_scov = 0;
-    __syncthreads();
-    for (; tile < tile_end; ++tile) {
-        asm volatile("; window header settled" : "+v"(pre.col.x), "+v"(pre.col.y), "+v"(pre.tt.x), "+v"(pre.tt.y), "+v"(pre.tt.z), "+v"(pre.tt.w), "+v"(pre.n), "+v"(pre.wd));
-        const uint64_t col_out = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)pre.col.y) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)pre.col.x);
-        const uint32_t T0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)pre.tt.x), Tend = (uint32_t)__builtin_amdgcn_readfirstlane((int)pre.tt.y);
-        const uint32_t pad = (uint32_t)__builtin_amdgcn_readfirstlane((int)pre.tt.w);
-        const uint32_t n_desc = (uint32_t)__builtin_amdgcn_readfirstlane((int)pre.n);
-        const int32_t wd = __builtin_amdgcn_readfirstlane(pre.wd);
-        if (tile + 1 < tile_end) pre = prefetch(tile + 1);
-        if (pad) continue;                                   // on the general kernel's list
-        const unsigned long long* slab = a.slab + tile * (uint64_t)SLAB_CAP;
-        // ---- accumulate: batches of A_DB descriptors, drawn from misc[0] (a wave's NEXT batch is requested before it works on the current one)
-        const uint32_t n_bat = (n_desc + (uint32_t)L::DRAW - 1) / (uint32_t)L::DRAW;
-        auto draw = [&](uint32_t* base_out) {
-            uint32_t b = 0;
-            if (lane == 0) b = atomicAdd(&misc[0], 1u);
-            b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
-            *base_out = b * (uint32_t)L::DRAW;
-            unsigned long long dd = 0;
-#if BGP_A_PERM
-            // a batch is every n_bat-th descriptor of the slab (the planner appends in file order, near enough): its reads lie all over the
-            // window, and neighbours in the batch are BGP_A_PERM x 64 / n_desc windows apart -- the three reads whose lanes share an LDS
-            // instruction hit different stretches of banks instead of the same one three times over
-            if (!ROWS) { const uint32_t idx = (((uint32_t)BGP_A_PERM * (uint32_t)lane) & 63u) * n_bat + b; if (b < n_bat && idx < n_desc) dd = slab[idx]; }
-            else
-#endif
-            if (*base_out < n_desc && lane < L::DRAW && *base_out + (uint32_t)lane < n_desc) dd = slab[*base_out + lane];
-            return dd;
-        };
-        uint32_t base_next = 0;
-        unsigned long long d_next = draw(&base_next);
-        for (;;) {
-            const uint32_t base = base_next;
-            if (base >= n_desc) break;
-            const unsigned long long d = d_next;
-            d_next = draw(&base_next);
-            uint32_t kind = (uint32_t)d & 3u;
-            const uint32_t lo = ((uint32_t)d >> 3) & 0x7FFu, f14 = (uint32_t)(d >> 14);
-            const bool is_row = ROWS && kind == 3;
-            if (!ROWS && kind == 3) kind = 0;
-            const uint32_t len = is_row ? (f14 & 0x3FFu) + 1u : f14 & 0xFFu, nib = is_row ? 0u : (f14 >> 8) & 1u;
-            const uint32_t nch = (kind == 1 || is_row) ? ((lo & 7u) + len + 7u) >> 3 : 0u;      // chunks of eight aligned positions the segment touches
-            if (kind == 2) { atomicAdd(&deld[lo], 1u); atomicAdd(&deld[f14 & 0xFFFu], 0xFFFFFFFFu); }       // D / N inside the window: '-' from lo up to the op's end (pileup.d:119-121)
-            if ((kind == 1 || is_row) && (d & 4u)) atomicAdd(&nst[lo >> 1], 1u << ((lo & 1u) * 16));        // n_starting_here, pileup.d:386,422
-            const uint32_t inc = wave_scan_u32(nch), tot_all = rl(inc, 63);
-            // what a chunk needs of its descriptor, once per descriptor: "nibble address minus position" (two bases a byte; a byte a
-            // position: twice the byte address) so that position 8m of the window is nibble adj + 8m of the source, and chunk c of the
-            // batch is chunk mb + c of the window
-            const uint64_t src = is_row ? d >> 24 : d >> 23;
-            const bool bytes_d = is_row;
-            const uint64_t origin = (uint64_t)(is_row ? a.rows : a.s) + src;
-            const uint64_t adj = (bytes_d ? origin : 2ull * origin + nib) - (uint64_t)lo;
-            // (a batch whose chunks do not fit the map goes in two halves or four quarters of its lanes: each fits by MROW's definition)
-            const uint32_t q1 = rl(inc, 15), q2 = rl(inc, 31), q3 = rl(inc, 47);
-            const uint32_t cap = (uint32_t)(L::MROW - 64);
-            const uint32_t parts = tot_all <= cap ? 1u : (q2 <= cap && tot_all - q2 <= cap) ? 2u : 4u;
-            for (uint32_t hv = 0; hv < parts; ++hv) {
-            const uint32_t l0 = hv * (64u / parts), l1 = l0 + 64u / parts;             // the part's lanes
-            const bool mine = (uint32_t)lane >= l0 && (uint32_t)lane < l1;
-            const uint32_t ex0 = l0 == 0 ? 0u : l0 == 16 ? q1 : l0 == 32 ? q2 : q3;
-            const uint32_t ex1 = l1 == 64 ? tot_all : l1 == 16 ? q1 : l1 == 32 ? q2 : q3;
-            const uint32_t ex = inc - nch - ex0, tot = ex1 - ex0;
-            if (mine) dsc[lane] = make_uint4((uint32_t)adj, (uint32_t)(adj >> 32), lo | (len << 11) | ((bytes_d ? 1u : 0u) << 22) | ((is_row ? 1u : 0u) << 23), (lo >> 3) - ex);
-            if (mine) for (uint32_t j = 0; j < nch; ++j) mark[ex + j] = (uint8_t)lane;      // chunk -> descriptor of the batch (a byte per chunk; ~20 a descriptor)
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            for (uint32_t c0 = 0; c0 < tot; c0 += 64u * A_U) {
-                uint32_t v0[A_U], v1[A_U], adr[A_U], klim[A_U];    // eight bytes of bases | byte offset of the chunk's word in a plane | first valid k, one past the last << 4, odd nibble << 8, a class byte per position << 9
-#pragma unroll
-                for (int u = 0; u < A_U; ++u) {
-                    // (branch-free: a lane behind the batch's last chunk works on chunk 0 again and keeps nothing)
-                    const uint32_t c = c0 + 64u * u + (uint32_t)lane;
-                    const bool in = c < tot;
-                    const uint32_t cc = in ? c : 0u;
-                    const uint4 f = dsc[mark[cc]];
-                    const uint32_t flo = f.z & 0x7FFu, flen = (f.z >> 11) & 0x7FFu;
-                    const uint32_t m = f.w + cc;                                         // chunk of the window: positions 8m .. 8m + 7
-                    const int32_t rel = (int32_t)(8u * m) - (int32_t)flo;                 // segment-relative index of position 8m (negative in the first chunk)
-                    const uint32_t k_lo = (uint32_t)max(-rel, 0), k_hi = min(8u, flen - (uint32_t)rel);
-                    const bool bytes = ROWS && (f.z >> 22 & 1u);                        // one byte a position (a row's classes): loaded from the first valid one on, moved up again below
-                    const bool row = ROWS && (f.z >> 23 & 1u);
-                    const uint64_t n = (((uint64_t)f.y << 32) | f.x) + 8u * m;           // nibble (byte) address of position 8m in the source
-                    const uint32_t odd = bytes ? 0u : (uint32_t)n & 1u;
-                    const uint8_t* p = reinterpret_cast<const uint8_t*>(bytes ? n + k_lo : n >> 1);
-                    uint2 q; __builtin_memcpy(&q, p, 8);
-                    v0[u] = q.x; v1[u] = q.y;
-                    adr[u] = m * 4u;
-                    klim[u] = in ? k_lo | (k_hi << 4) | (odd << 8) | ((bytes ? 1u : 0u) << 9) | ((row ? 1u : 0u) << 10) : 0u;
-                }
-#pragma unroll
-                for (int u = 0; u < A_U; ++u) {
-                    if (c0 + 64u * u >= tot) continue;
-                    const uint32_t kl = klim[u];
-                    const uint32_t k_lo = kl & 15u, k_hi = kl >> 4 & 15u;
-                    if (k_hi == 0) continue;                                             // (a lane behind the batch's last chunk)
-                    uint32_t w0 = v0[u], w1 = v1[u];
-                    if (ROWS && (kl >> 9 & 1u)) {                             // bytes were loaded from the first valid position on: back to their places
-                        const unsigned long long vv = (((unsigned long long)w1 << 32) | w0) << (8u * k_lo);
-                        w0 = (uint32_t)vv; w1 = (uint32_t)(vv >> 32);
-                    }
-                    uint2 cb;
-                    if (ROWS && (kl >> 10 & 1u)) cb = make_uint2(w0, w1);
-                    else {
-                        if (kl >> 8 & 1u) w0 = ((w0 & 0x0F0F0F0Fu) << 4) | (__builtin_amdgcn_alignbit(w1, w0, 12) & 0x0F0F0F0Fu);     // the chunk's first base is the low nibble of its byte: one nibble up
-                        cb = class_of_packed8(w0);
-                    }
-                    cb = keep_bytes(cb, k_lo, k_hi, (uint32_t)NC * 0x01010101u);         // bases outside the segment's ends count for the dummy class
-                    uint32_t* const row0 = cnt + (adr[u] >> 2);
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        const uint32_t cls = ((k < 4 ? cb.x : cb.y) >> (8 * (k & 3))) & 0xFFu;
-                        atomicAdd(row0 + cls * (uint32_t)A_CSW + (k >> 1) * A_PLW, 1u << (16 * (k & 1)));
-                    }
-                }
-            }
-            }
-        }
-        __syncthreads();                                     // every add of the window is in
-        // ---- flush: '-' difference array summed up (a wave scans its own positions with DPP, the waves before it enter as one number each), 32 contiguous bytes per position; what a lane reads it zeroes
-        const uint32_t np = Tend - T0;
-        uint32_t dl[ABPW], cA[ABPW], cC[ABPW], cG[ABPW], cT[ABPW], cO[ABPW], cD[ABPW], sw[ABPW];
-        {
-            uint32_t run = 0;
-#pragma unroll
-            for (int bb = 0; bb < ABPW; ++bb) {
-                const uint32_t p = 64 * (wave * ABPW + bb) + lane;
-                const uint32_t e = deld[p];
-                deld[p] = 0;
-                const uint32_t sc = wave_scan_u32(e);
-                dl[bb] = run + sc;
-                run += rl(sc, 63);
-                const uint32_t wi = ((p & 7u) >> 1) * A_PLW + (p >> 3), sh = (p & 1u) * 16;
-                cO[bb] = (cnt[wi] >> sh) & 0xFFFFu; cA[bb] = (cnt[A_CSW + wi] >> sh) & 0xFFFFu; cC[bb] = (cnt[2 * A_CSW + wi] >> sh) & 0xFFFFu;
-                cG[bb] = (cnt[3 * A_CSW + wi] >> sh) & 0xFFFFu; cT[bb] = (cnt[4 * A_CSW + wi] >> sh) & 0xFFFFu;
-                cD[bb] = ROWS ? (cnt[5 * A_CSW + wi] >> sh) & 0xFFFFu : 0u;
-                sw[bb] = nst[p >> 1];
-                if ((p & 1u) == 0) {                         // (two lanes share a word: both have read it -- the wave runs in lockstep)
-                    cnt[wi] = 0; cnt[A_CSW + wi] = 0; cnt[2 * A_CSW + wi] = 0; cnt[3 * A_CSW + wi] = 0; cnt[4 * A_CSW + wi] = 0;
-                    if (ROWS) cnt[5 * A_CSW + wi] = 0;
-                    nst[p >> 1] = 0;
-                }
-            }
-            if (t == 0) { deld[W] = 0; misc[0] = 0; }       // (an op that ends with the window leaves its -1 here) | the next window's batches
-            if (lane == 0) misc[8 + wave] = run;
-            __syncthreads();
-            uint32_t carry = (uint32_t)wd;
-            for (int k = 0; k < wave; ++k) carry += misc[8 + k];
-#pragma unroll
-            for (int bb = 0; bb < ABPW; ++bb) dl[bb] += carry;
-        }
-        bgp_column* out = a.cols + col_out;
-        uint32_t ncol = 0, scov = 0, nsum = 0, mx = 0;
-#pragma unroll
-        for (int bb = 0; bb < ABPW; ++bb) {
-            const uint32_t p = 64 * (wave * ABPW + bb) + lane;
-            if (p < np) {
-                const uint32_t D = dl[bb] + cD[bb], S = (sw[bb] >> ((p & 1u) * 16)) & 0xFFFFu;
-                const uint32_t cov = cA[bb] + cC[bb] + cG[bb] + cT[bb] + cO[bb] + D;
-                uint4* o4 = reinterpret_cast<uint4*>(out + p);
-                o4[0] = make_uint4(cov, S, cA[bb], cC[bb]);
-                o4[1] = make_uint4(cG[bb], cT[bb], cO[bb], D);
-                ncol += cov > 0; scov += cov; mx = max(mx, cov); nsum += S;
-                if (cov < (uint32_t)HB) atomicAdd(&hist[cov], 1u);
-                else atomicAdd(&a.hist[min(cov, (uint32_t)BGP_DEPTH_BINS - 1)], 1ull);
-            }
-        }
-        r_ncol += ncol; r_nsum += nsum; r_mx = max(r_mx, mx); r_scov += scov;
-        __syncthreads();                                     // the counters are zero again and misc[8..] is read: the next window may add
-    }
-    {   // the range's totals: wave reductions with DPP, then one atomic per wave and total (the slots were zeroed by the host)
-        const uint32_t w_ncol = wave_sum_u32(r_ncol), w_nsum = wave_sum_u32(r_nsum), w_mx = wave_max_u32(r_mx);
-        const uint32_t s0 = wave_sum_u32((uint32_t)r_scov & 0xFFFFu), s1 = wave_sum_u32((uint32_t)(r_scov >> 16) & 0xFFFFu), s2 = wave_sum_u32((uint32_t)(r_scov >> 32) & 0xFFFFu), s3 = wave_sum_u32((uint32_t)(r_scov >> 48));
-        if (lane == 0) {
-            unsigned long long* ts = a.tile_stats + (a.n_tiles + blockIdx.x) * 4;
-            if (w_ncol) atomicAdd(&ts[0], (unsigned long long)w_ncol);
-            const unsigned long long sc = ((unsigned long long)s3 << 48) + ((unsigned long long)s2 << 32) + ((unsigned long long)s1 << 16) + s0;
-            if (sc) atomicAdd(&ts[1], sc);
-            if (w_mx) atomicMax(&ts[2], (unsigned long long)w_mx);
-            if (w_nsum) atomicAdd(&ts[3], (unsigned long long)w_nsum);
-        }
-    }
-    __syncthreads();
-    for (int b = t; b < HB; b += AT) { const uint32_t h = hist[b]; if (h) atomicAdd(&a.hist[b], (unsigned long long)h); }
-}
-
-// ---------------------------------------------------------------------------------------------- K4, accumulate path, round 4: lane = piece, byte planes
-//
-// k4_acc (above, still the executor of streams with long reads' ROW descriptors) spends ~80 VALU instructions per lane-chunk of
-// eight positions -- a byte map and a 16-byte LDS read to find the chunk's descriptor, the limits of the chunk, one table
-// lookup, one address and one LDS atomic PER BASE -- and round 3's counters said that is what binds it (VALU issuing 60-70 % of
-// the time, LDS 46 %).  k4_acc2 runs the same plan (k4_plan's SEG / DEL descriptors) with a quarter of the instructions:
+// Four executors have run on k4_plan's descriptors or their predecessors (DESIGN.md / LABNOTES.md keep the measurements):
+// round 1 let every BASE find its counter with lanes = reads (k4_tile, still the general kernel: 15.5 ms on cfg3); round 2 made
+// every POSITION gather its bases out of class bytes staged in LDS (k4_exec: 10.3 ms); round 3 went back to atomics with lanes
+// along the reads, eight positions a lane (k4_acc: 8.6 ms) -- ~80 VALU instructions per lane-chunk of eight positions: a byte map and a
+// 16-byte LDS read to find the chunk's descriptor, the limits of the chunk, one table lookup, one address and one LDS atomic PER
+// BASE, and its counters said instruction issue is what binds it.  k4_acc2 runs the same plan with a quarter of the instructions:
 //
 //   * a LANE owns a PIECE of a SEG descriptor -- up to 11 chunks of eight window-aligned positions -- for the piece's whole life:
 //     its packed bases are in registers (three 16-byte loads from the chunk-aligned origin), the loop over the chunks is unrolled,
@@ -1635,11 +1181,21 @@ template <bool ROWS> __global__ __launch_bounds__(AT, BGP_A_MINW) void k4_acc(GA
 //     reads' ~150 bases is past the slab's 1024 descriptors anyway;
 //   * lanes next to each other hold pieces a few positions apart: the same or neighbouring words, i.e. the same LDS banks
 //     (scratch/r4/lds_plane_bench.hip: 93 clocks a chunk-step against 34 for distinct consecutive words).  The counters exist
-//     FOUR times, copy = lane & 3, a copy 8 banks further: measured 34 clocks.  The flush adds the copies up;
-//   * pieces come from a ring per wave (LDS): a wave draws 64 descriptors, does their per-descriptor atomics ('-', starts,
-//     coverage), appends their pieces -- a 150-base read is two of 10 chunks -- and works off full batches of 64.
+//     FOUR times, copy = (lane >> 1) & 3, a copy 8 banks further: measured 34 clocks (two copies: 9.3 ms instead of 8.0 on cfg3).
+//     The flush adds the copies up;
+//   * a window's descriptors become pieces in a pool in LDS, 512 descriptors a round: per-descriptor atomics ('-', starts, coverage),
+//     a 150-base read two pieces of 10 chunks; long pieces fill the pool from its front, short ones from its back, so that a batch of 64
+//     from either end runs about as long in every lane; the loads of a wave's next batch are in flight while it works on the current one;
+//   * long reads come as the same descriptors, an op each (k4_long_desc): pieces of one or two chunks from the pool's short end.
+//
+// What bounds it now (cfg3, `BGP_ACC2_ABL`): with the bases read from a cache-resident stretch and no column stores 6.65 ms, with the
+// loads and stores but no accumulate 7.8 ms, both 8.0 ms -- the 41 GB it moves (24.6 GB of 128-byte lines around 75-byte packed
+// sequences, 16 GB of columns) at 5.2 TB/s and the LDS (57 % busy) are about equally in the way.
 //
 // Same descriptors, same columns: every pileup test checks them against the oracle.
+constexpr int AT = 256;                       // threads of a k4_acc2 workgroup
+constexpr int ANW = AT / 64;                  // waves
+constexpr int ABPW = (W / 64) / ANW;          // 64-position blocks a wave flushes
 #ifndef BGP_ACC2_MINW
 #define BGP_ACC2_MINW 4
 #endif
@@ -1739,6 +1295,43 @@ __device__ __forceinline__ void acc2_work(const A2Batch& b, uint32_t* cbase0) {
     }
 }
 
+// A long read's ops are ~15 bases each: its pieces are cut at three chunks (24 positions: one 16-byte load), and three of them are
+// in flight per wave -- a piece's bases arrive while the two before it are accumulated.
+constexpr int P_CHS = 3;
+struct A2Small { uint4 q0; uint32_t eh, par; };
+__device__ __forceinline__ A2Small acc2_load_small(const uint8_t* s, unsigned long long e) {
+    A2Small b;
+    const uint64_t no = e & ((1ull << 42) - 1);
+    b.eh = (uint32_t)(e >> 32); b.par = (uint32_t)no & 1u;
+    __builtin_memcpy(&b.q0, s + (no >> 1), 16);
+    return b;
+}
+__device__ __forceinline__ void acc2_work_small(const A2Small& b, uint32_t* cbase0) {
+    const uint32_t m0 = (b.eh >> 10) & 127u, s = (b.eh >> 17) & 7u, tl = (b.eh >> 20) & 127u, par = b.par;
+    if (!__builtin_amdgcn_ballot_w64(tl != 0)) return;
+    const uint32_t R[4] = {b.q0.x, b.q0.y, b.q0.z, b.q0.w};
+    const uint32_t jl = (tl - 1u) >> 3, rr = tl - 8u * jl;
+    const uint32_t vt_e = 0x0F0F0F0Fu >> (8u * (4u - ((rr + 1u) >> 1)));
+    const uint32_t vt_o = (uint32_t)(0x0F0F0F0Full >> (8u * (4u - (rr >> 1))));
+    const uint32_t vf_e = (uint32_t)(0x0F0F0F0Full << (8u * ((s + 1u) >> 1))), vf_o = 0x0F0F0F0Fu << (8u * (s >> 1));
+    uint32_t* const cb = cbase0 + m0;
+#pragma unroll
+    for (int j = 0; j < P_CHS; ++j) {
+        if (!__builtin_amdgcn_ballot_w64(tl > 8u * (uint32_t)j)) break;
+        if (tl > 8u * (uint32_t)j) {
+            const uint32_t D = R[j], Dn = R[j + 1];
+            const uint32_t es = par ? D : D >> 4, os = par ? __builtin_amdgcn_alignbit(Dn, D, 12) : D;
+            uint32_t vme = (uint32_t)j == jl ? vt_e : 0x0F0F0F0Fu, vmo = (uint32_t)j == jl ? vt_o : 0x0F0F0F0Fu;
+            if (j == 0) { vme &= vf_e; vmo &= vf_o; }
+            uint32_t pa, pc, pg, pt;
+            planes_of_codes(es & vme, pa, pc, pg, pt);
+            atomicAdd(cb + j + 0 * P_PLW, pa); atomicAdd(cb + j + 2 * P_PLW, pc); atomicAdd(cb + j + 4 * P_PLW, pg); atomicAdd(cb + j + 6 * P_PLW, pt);
+            planes_of_codes(os & vmo, pa, pc, pg, pt);
+            atomicAdd(cb + j + 1 * P_PLW, pa); atomicAdd(cb + j + 3 * P_PLW, pc); atomicAdd(cb + j + 5 * P_PLW, pg); atomicAdd(cb + j + 7 * P_PLW, pt);
+        }
+    }
+}
+
 __global__ __launch_bounds__(AT, BGP_ACC2_MINW) void k4_acc2(GArgs a) {
     using L = A2Lay;
     extern __shared__ __attribute__((aligned(16))) uint8_t alds[];
@@ -1758,14 +1351,15 @@ __global__ __launch_bounds__(AT, BGP_ACC2_MINW) void k4_acc2(GArgs a) {
     if (tile >= tile_end) return;
     for (int i = t; i < L::POOL / 4; i += AT) cnt[i] = 0;                      // counters, difference arrays, starts (a window leaves them zeroed again), hist
     if (t < 32) misc[t] = 0;
-    struct Pre { uint2 col; uint4 tt; uint32_t n; int32_t wd; unsigned long long d0, d1; };   // the next window's header and first round of descriptors, a window ahead, in vector registers (see k4_acc)
+    struct Pre { uint4 ii; uint2 col; uint4 tt; uint32_t n; int32_t wd; unsigned long long d0, d1; };   // the next window's header and first round of descriptors, a window ahead, in vector registers: left to the compiler the loads became scalars with an s_waitcnt right behind the "prefetch" -- which, gfx9 counting loads and stores with ONE in-order counter, also stood for the previous window's column stores
     auto prefetch = [&](uint64_t w) {
         Pre p;
         const char* tp = reinterpret_cast<const char*>(a.tiles + w);
+        __builtin_memcpy(&p.ii, tp, 16);
         __builtin_memcpy(&p.col, tp + 16, 8);
         __builtin_memcpy(&p.tt, tp + 24, 16);
         p.n = a.wcount[w]; p.wd = a.wdel[w];
-        const unsigned long long* sl = a.slab + w * (uint64_t)SLAB_CAP;        // (the slab is there whatever the count says; slots behind the count hold anything)
+        const unsigned long long* sl = a.slab + w * (uint64_t)a.slab_cap;      // (the slab is there whatever the count says; slots behind the count hold anything)
         p.d0 = sl[t]; p.d1 = sl[AT + t];
         return p;
     };
@@ -1781,10 +1375,13 @@ __global__ __launch_bounds__(AT, BGP_ACC2_MINW) void k4_acc2(GArgs a) {
         const uint32_t pad = (uint32_t)__builtin_amdgcn_readfirstlane((int)pre.tt.w);
         const uint32_t n_desc = (uint32_t)__builtin_amdgcn_readfirstlane((int)pre.n);
         const int32_t wd = __builtin_amdgcn_readfirstlane(pre.wd);
+        const uint64_t i_lo = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)pre.ii.y) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)pre.ii.x);
+        const uint64_t i_hi = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)pre.ii.w) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)pre.ii.z);
+        const uint32_t run_start = (uint32_t)__builtin_amdgcn_readfirstlane((int)pre.tt.z);
         unsigned long long dd[2] = {pre.d0, pre.d1};
         if (tile + 1 < tile_end) pre = prefetch(tile + 1);
         if (pad) continue;                                   // on the general kernel's list
-        const unsigned long long* slab = a.slab + tile * (uint64_t)SLAB_CAP;
+        const unsigned long long* slab = a.slab + tile * (uint64_t)a.slab_cap;
         for (uint32_t rb = 0; rb < ((BGP_ACC2_ABL & 8) ? 0u : n_desc); rb += (uint32_t)P_RD) {      // (8: timing experiment, the flush alone)
             // ---- a round, first half: P_RD descriptors, two a thread.  Per-descriptor atomics ('-', starts, coverage); a SEG descriptor is cut
             // into pieces of equal length, long pieces (9 chunks or more) fill the pool from its front, short ones from its back: a batch of 64
@@ -1870,9 +1467,129 @@ __global__ __launch_bounds__(AT, BGP_ACC2_MINW) void k4_acc2(GArgs a) {
             }
             __syncthreads();                                 // every add of the round is in; the pool is free
         }
+        const uint32_t np = Tend - T0;
+        if (a.wlong && a.wlong[tile]) {
+            // ---- long reads.  Their checkpoint for this window (k4_ck_build) is the op that owns the window's first column with the
+            // columns and query bases in front of it; from there 64 ops a step, a LANE per op: two wave scans give the op's first column
+            // and query base (the closed form of pileup.d:175-222), and the op is accumulated as it stands -- an M / = / X op is a piece
+            // (or several) like any other, a D / N op two entries of the '-' difference array.  Nothing is written for a long read but its
+            // checkpoints: rounds 2 and 3 put every column of every long read into an arena of class bytes first (k4_rows_build 6.3 ms +
+            // k4_acc<ROWS> 3.6 ms on cfg5, 26 GB of traffic for it).
+            // A read is a chain of dependent loads (row -> checkpoint -> ops -> bases), so the window's candidates are looked at by all
+            // threads at once and the long reads that touch it listed in LDS (where the pool was); then a wave per listed read, the NEXT
+            // read's ops requested before the current one is scanned and the current one's bases while the one before is accumulated.
+            struct LRead { unsigned long long cg, nib; int32_t shift; uint32_t k, cs, qs, n_cig, pad; };
+            constexpr int LCAND = 128, LPB = 3 * 64;              // candidates a round; pieces a wave deals out per step (three an op at most)
+            static_assert(sizeof(LRead) == 40 && LCAND * sizeof(LRead) + ANW * LPB * 8 <= (size_t)P_POOL * 8, "the window's long reads and the waves' pieces are listed where the pool is");
+            LRead* const lst = reinterpret_cast<LRead*>(alds + L::POOL);
+            unsigned long long* const pcs = reinterpret_cast<unsigned long long*>(alds + L::POOL + LCAND * sizeof(LRead)) + wave * LPB;
+            constexpr uint32_t SH = (uint32_t)__builtin_ctz((unsigned)W);
+            for (uint64_t cb = i_lo; cb < i_hi; cb += LCAND) {
+                uint32_t* const mc = misc + 4 * (rounds & 1u);       // (a round like the descriptors': mc[0] counts the listed reads; the other set is zeroed meanwhile)
+                ++rounds;
+                const uint64_t i = cb + (uint64_t)t;
+                if (t < LCAND && i < i_hi) {
+                    const bgp_record r = a.rec[i];
+                    const uint64_t cko = a.ck_off[i];                 // (asked for with the row, not behind it)
+                    const uint32_t n_cig = r.flag_nc & 0xFFFFu, l_name = r.bin_mq_nl & 0xFFu;
+                    if (r.end_pos != r.pos && wants_ckpt(n_cig, (uint32_t)r.l_seq) && (uint32_t)r.pos < Tend && (uint32_t)r.end_pos > T0) {
+                        const uint32_t j = ((T0 - run_start) >> SH) - (((uint32_t)r.pos - run_start) >> SH);
+                        const Ckpt ck = a.ck[cko + j];
+                        const uint64_t cig = r.rec_off + 36 + l_name;
+                        lst[atomicAdd(&mc[0], 1u)] = LRead{(unsigned long long)(a.s + cig), 2ull * (cig + 4ull * n_cig), (int32_t)((int64_t)(uint32_t)r.pos - (int64_t)T0), ck.k, ck.cs, ck.qs, n_cig, 0u};
+                    }
+                }
+                __syncthreads();
+                if (t < 3) misc[4 * (rounds & 1u) + t] = 0;
+                const uint32_t n_l = mc[0];
+                A2Small pn0, pn1; pn0.eh = pn1.eh = 0; pn0.par = pn1.par = 0; pn0.q0 = pn1.q0 = make_uint4(0, 0, 0, 0);      // the two pieces whose bases are on their way
+                // (TWO ops a lane: a window of 1024 positions is ~68 ops of a read with an indel every ~15 bases -- one step of 128 instead of
+                // two of 64 --, and as M and I / D alternate nearly every lane then holds exactly one M op: the accumulate runs with full waves)
+                auto ops_of = [&](const LRead& E, uint32_t c0) {
+                    uint2 o = make_uint2(0u, 0u);
+                    const uint32_t k0 = c0 + 2u * (uint32_t)lane;
+                    const uint8_t* q = reinterpret_cast<const uint8_t*>(E.cg) + 4ull * k0;
+                    if (k0 + 1 < E.n_cig) __builtin_memcpy(&o, q, 8);
+                    else if (k0 < E.n_cig) o.x = ld_u32(q);
+                    return o;
+                };
+                constexpr int LQ = 8;                                 // reads whose first 128 ops a wave asks for before it scans the first
+                for (uint32_t e0 = (uint32_t)wave; e0 < n_l; e0 += ANW * LQ) {
+                uint2 opq[LQ];
+#pragma unroll
+                for (int q = 0; q < LQ; ++q) { const uint32_t e = e0 + ANW * q; opq[q] = make_uint2(0u, 0u); if (e < n_l) { const LRead Eq = lst[e]; opq[q] = ops_of(Eq, Eq.k); } }
+#pragma unroll
+                for (int q = 0; q < LQ; ++q) {
+                    const uint32_t e = e0 + ANW * q;
+                    if (e >= n_l) break;
+                    const LRead cur = lst[e]; uint2 op2 = opq[q];
+                    uint32_t cs = cur.cs, qs = cur.qs;
+                    for (uint32_t c0 = cur.k; c0 < cur.n_cig; c0 += 128) {
+                        if (c0 != cur.k) op2 = ops_of(cur, c0);
+                        const uint32_t k0 = c0 + 2u * (uint32_t)lane;
+                        uint32_t rl0, ql0, rl1, ql1;
+                        op_lens(op2.x, k0 < cur.n_cig, true, &rl0, &ql0);
+                        op_lens(op2.y, k0 + 1 < cur.n_cig, true, &rl1, &ql1);
+                        const uint32_t ir = wave_scan_u32(rl0 + rl1), iq = wave_scan_u32(ql0 + ql1);
+                        const uint32_t csb[2] = {cs + ir - rl0 - rl1, cs + ir - rl1}, qsb[2] = {qs + iq - ql0 - ql1, qs + iq - ql1};
+                        const uint32_t rln[2] = {rl0, rl1}, opv[2] = {op2.x, op2.y};
+                        int32_t sa0[2]; uint32_t sp[2], se[2];                              // per op: window position of its column 0; the stretch of the window still to be accumulated
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const int32_t a0 = cur.shift + (int32_t)csb[h], a1 = a0 + (int32_t)rln[h];      // the op's columns in window positions
+                            const uint32_t lo = (uint32_t)max(a0, 0), hi = (uint32_t)min(a1, (int32_t)np);
+                            const bool in_w = rln[h] && a1 > 0 && a0 < (int32_t)np;
+                            const bool isM = cig_qc(opv[h]) != 0;
+                            if (in_w) {
+                                if (isM) {
+                                    if (csb[h] == 0 && a0 >= 0) atomicAdd(&nst[lo >> 1], 1u << ((lo & 1u) * 16));       // n_starting_here, pileup.d:386,422
+                                    atomicAdd(&covd[lo], 1u); atomicAdd(&covd[hi], 0xFFFFFFFFu);
+                                } else { atomicAdd(&deld[lo], 1u); atomicAdd(&deld[hi], 0xFFFFFFFFu); }      // '-' while the op lasts (pileup.d:119-121)
+                            }
+                            sa0[h] = a0; sp[h] = lo; se[h] = in_w && isM ? hi : lo;
+                        }
+                        // the ops' pieces (three chunks at most: one 16-byte load), dealt out to the lanes: an op of 15 bases is one piece, the
+                        // odd long one several -- handled by the op's own lane the wave ran as long as its longest op while most lanes sat out
+                        while (__ballot(sp[0] < se[0] || sp[1] < se[1])) {
+                            uint32_t npc = 0;
+                            {
+                                uint32_t q0 = sp[0], q1 = sp[1];
+                                while (npc < 3u && (q0 < se[0] || q1 < se[1])) {
+                                    if (q0 < se[0]) q0 += min(se[0] - q0, 8u * (uint32_t)P_CHS - (q0 & 7u)); else q1 += min(se[1] - q1, 8u * (uint32_t)P_CHS - (q1 & 7u));
+                                    ++npc;
+                                }
+                            }
+                            const uint32_t ipc = wave_scan_u32(npc), tot = rl(ipc, 63);
+                            uint32_t at = ipc - npc;
+                            for (uint32_t k = 0; k < npc; ++k) {
+                                const int h = sp[0] < se[0] ? 0 : 1;
+                                const uint32_t p = sp[h];
+                                const uint32_t n = min(se[h] - p, 8u * (uint32_t)P_CHS - (p & 7u));
+                                const uint64_t nb = cur.nib + qsb[h] + (uint32_t)((int32_t)p - sa0[h]) - (p & 7u);
+                                pcs[at++] = nb | ((unsigned long long)((p >> 3) | ((p & 7u) << 7) | (((p & 7u) + n) << 10)) << 42);
+                                sp[h] = p + n;
+                            }
+                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                            __builtin_amdgcn_wave_barrier();
+                            for (uint32_t b0 = 0; b0 < tot; b0 += 64) {
+                                const unsigned long long en = b0 + (uint32_t)lane < tot ? pcs[b0 + (uint32_t)lane] : 0ull;
+                                const A2Small bt = acc2_load_small(a.s, en);
+                                acc2_work_small(pn0, cbase0);
+                                pn0 = pn1; pn1 = bt;
+                            }
+                            __builtin_amdgcn_wave_barrier();
+                        }
+                        cs += rl(ir, 63); qs += rl(iq, 63);
+                        if (cur.shift + (int32_t)cs >= (int32_t)np) break;                              // the next op begins behind the window
+                    }
+                }
+                }
+                acc2_work_small(pn0, cbase0); acc2_work_small(pn1, cbase0);
+                __syncthreads();                                 // the list is free, every add is in
+            }
+        }
         // ---- flush, first half: the two difference arrays summed up (a wave scans its own positions with DPP, the waves before it enter
         // as one number each); the four copies of the counters added up by a thread per (chunk, even / odd) and staged a position at a time
-        const uint32_t np = Tend - T0;
         uint32_t dl[ABPW], cv[ABPW], sw[ABPW];
         uint32_t run_d = 0, run_c = 0, mxs = 0;
 #pragma unroll
@@ -2307,47 +2024,34 @@ int k34_pileup(bgp_ctx* c) {
         BGP_TRY(c->d_col_lo.reserve((tile_base + WG_SLOTS) * 32));
         a.tile_stats = (unsigned long long*)c->d_col_lo.p;
         a.ck = nullptr; a.ck_off = nullptr;
-        bool have_rows = false;
+        bool have_rows = false;                        // long reads take the accumulate path (k4_acc2 walks their ops from the windows' checkpoints)
         if (st[3]) {                                   // the stream holds long reads: build their per-window CIGAR checkpoints (the planner reads their verdicts)
-            uint64_t total_cols = 0, total_chunks = 0; uint64_t* row_off = nullptr; bool rows = false;
+            bool rows = false;
             {
             TimedRegion tc(c, "k4_checkpoints", c->sum_ncig * 4);
             BGP_TRY(c->d_ck_off.reserve((n + 2) * 8));
             uint64_t* ck_off = c->d_ck_off.as<uint64_t>();
-            rows = long_rows && !long_stream;               // ... and, for the accumulate path, every long read's row of class bytes (one per column)
-            uint64_t* chunk_off = nullptr;
-            if (rows) { BGP_TRY(c->d_row_off.reserve((n + 2) * 8)); BGP_TRY(c->d_chunk_off.reserve((n + 2) * 8)); row_off = c->d_row_off.as<uint64_t>(); chunk_off = c->d_chunk_off.as<uint64_t>(); }
-            hipLaunchKernelGGL(k4_ck_count, dim3(nb), dim3(256), 0, c->stream, a.rec, n, a.runs, n_runs, ck_off, row_off, chunk_off, tw);
+            rows = long_rows && !long_stream;               // (the accumulate path takes the long reads: k4_acc2 walks their ops from these checkpoints)
+            hipLaunchKernelGGL(k4_ck_count, dim3(nb), dim3(256), 0, c->stream, a.rec, n, a.runs, n_runs, ck_off, tw);
             uint64_t total_ck = 0;
-            if (!rows) BGP_TRY(scan_exclusive_u64(c, ck_off, ck_off, n, &total_ck));
-            else {
-                const uint64_t* const in[3] = {ck_off, row_off, chunk_off};
-                uint64_t* const out[3] = {ck_off, row_off, chunk_off};
-                uint64_t tot[3];
-                BGP_TRY(scan_exclusive_u64x3(c, in, out, n, tot));
-                total_ck = tot[0]; total_cols = tot[1]; total_chunks = tot[2];
-                if (total_cols >= (1ull << 40) || total_chunks >= (1ull << 33)) return BGP_EINVAL;
-                BGP_TRY(c->d_rows.reserve(total_cols + 64));
-                BGP_TRY(c->d_chunk_state.reserve((total_chunks + 1) * 16));
-                BGP_HIP(hipMemsetAsync(c->d_chunk_state.p, 0xFF, (total_chunks + 1) * 16, c->stream));
-            }
+            BGP_TRY(scan_exclusive_u64(c, ck_off, ck_off, n, &total_ck));
             BGP_TRY(c->d_ck.reserve((total_ck + 1) * sizeof(Ckpt)));
             BGP_HIP(hipMemsetAsync(c->d_ck.p, 0xFF, (total_ck + 1) * sizeof(Ckpt), c->stream));
             if ((uint64_t)st[3] * 8 >= n)             // mostly long reads: a wave each
-                hipLaunchKernelGGL(k4_ck_build<true>, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, c->stream, a.s, a.stream_len, a.rec, n, a.runs, n_runs, ck_off, c->d_ck.as<Ckpt>(), tw, chunk_off, rows ? c->d_chunk_state.as<uint4>() : nullptr);
+                hipLaunchKernelGGL(k4_ck_build<true>, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, c->stream, a.s, a.stream_len, a.rec, n, a.runs, n_runs, ck_off, c->d_ck.as<Ckpt>(), tw);
             else
-                hipLaunchKernelGGL(k4_ck_build<false>, dim3(nb), dim3(256), 0, c->stream, a.s, a.stream_len, a.rec, n, a.runs, n_runs, ck_off, c->d_ck.as<Ckpt>(), tw, chunk_off, rows ? c->d_chunk_state.as<uint4>() : nullptr);
+                hipLaunchKernelGGL(k4_ck_build<false>, dim3(nb), dim3(256), 0, c->stream, a.s, a.stream_len, a.rec, n, a.runs, n_runs, ck_off, c->d_ck.as<Ckpt>(), tw);
             a.ck = c->d_ck.as<Ckpt>(); a.ck_off = ck_off;
             }
-            if (rows && total_chunks) { TimedRegion tr(c, "k4_rows", total_cols);
-            hipLaunchKernelGGL(k4_rows_build, dim3((unsigned)((total_chunks + 3) / 4)), dim3(256), 0, c->stream, a.s, a.stream_len, a.rec, c->d_chunk_state.as<uint4>(), total_chunks, row_off, c->d_rows.as<uint8_t>()); }
             have_rows = rows;
         }
         if (long_stream) {
             hipLaunchKernelGGL(k4_all_listed, dim3((unsigned)((tile_base + 255) / 256)), dim3(256), 0, c->stream, c->d_deep.as<uint32_t>() + 1, c->d_deep.as<uint32_t>(), (uint32_t)tile_base);
         } else {
         // the plan: descriptor slabs per window, from one pass over the reads
-        BGP_TRY(c->d_slab.reserve(tile_base * (size_t)SLAB_CAP * 8));
+        const uint32_t slab_cap = SLAB_CAP;
+        if (have_rows) { BGP_TRY(c->d_wlong.reserve((tile_base + 1) * 4)); BGP_HIP(hipMemsetAsync(c->d_wlong.p, 0, (tile_base + 1) * 4, c->stream)); }
+        BGP_TRY(c->d_slab.reserve(tile_base * (size_t)slab_cap * 8));
         BGP_TRY(c->d_wcount.reserve((tile_base + 1) * 4)); BGP_TRY(c->d_wdel.reserve((tile_base + 2) * 4)); BGP_TRY(c->d_wslow.reserve((tile_base + 2) * 4));
         BGP_TRY(c->d_col_lo.reserve((tile_base + 65536) * 32));          // (k4_acc's totals: zeroed here with the planner's arrays, one launch)
         { const FillItem f[4] = {{c->d_wcount.p, (tile_base + 1) * 4, 0u}, {c->d_wdel.p, (tile_base + 2) * 4, 0u}, {c->d_wslow.p, (tile_base + 2) * 4, 0u}, {c->d_col_lo.p, (tile_base + 65536) * 32, 0u}}; BGP_TRY(fill_many(c, f, 4)); }
@@ -2356,15 +2060,15 @@ int k34_pileup(bgp_ctx* c) {
             PlanArgs pa;
             pa.rec = a.rec; pa.cig4 = c->cig4_ok ? c->d_cig4.as<uint4>() : nullptr; pa.s = a.s; pa.stream_len = a.stream_len; pa.n = n;
             pa.runs = a.runs; pa.n_runs = n_runs; pa.n_tiles = tile_base;
-            pa.slab = (unsigned long long*)c->d_slab.p; pa.wcount = c->d_wcount.as<uint32_t>(); pa.wdel = c->d_wdel.as<int32_t>(); pa.wslow = c->d_wslow.as<int32_t>();
-            pa.ck = have_rows ? a.ck : nullptr; pa.ck_off = a.ck_off; pa.row_off = have_rows ? c->d_row_off.as<uint64_t>() : nullptr;
+            pa.slab = (unsigned long long*)c->d_slab.p; pa.slab_cap = slab_cap; pa.wcount = c->d_wcount.as<uint32_t>(); pa.wdel = c->d_wdel.as<int32_t>(); pa.wslow = c->d_wslow.as<int32_t>();
+            pa.ck = have_rows ? a.ck : nullptr; pa.ck_off = a.ck_off; pa.wlong = have_rows ? c->d_wlong.as<uint32_t>() : nullptr;
             hipLaunchKernelGGL(k4_plan, dim3(nb), dim3(256), 0, c->stream, pa);
             const unsigned wb = (unsigned)((tile_base + 1023) / 1024);
             BGP_TRY(c->d_scan_tmp.reserve((size_t)wb * 8 + 16));
             int32_t* btot = c->d_scan_tmp.as<int32_t>();
             hipLaunchKernelGGL(k4_wscan_tot, dim3(wb), dim3(1024), 0, c->stream, pa.wdel, pa.wslow, tile_base, btot);
             hipLaunchKernelGGL(k4_wscan_mid, dim3(1), dim3(1024), 0, c->stream, btot, wb);
-            hipLaunchKernelGGL(k4_wscan, dim3(wb), dim3(1024), 0, c->stream, pa.wdel, pa.wslow, pa.wcount, c->d_tiles.as<TileB>(), tile_base, btot, c->d_deep.as<uint32_t>() + 1, c->d_deep.as<uint32_t>());
+            hipLaunchKernelGGL(k4_wscan, dim3(wb), dim3(1024), 0, c->stream, pa.wdel, pa.wslow, pa.wcount, c->d_tiles.as<TileB>(), tile_base, btot, c->d_deep.as<uint32_t>() + 1, c->d_deep.as<uint32_t>(), slab_cap);
         }
         }
         c->ck_w = a.ck ? tw : 0;                     // K5 resumes long reads from these checkpoints
@@ -2372,17 +2076,14 @@ int k34_pileup(bgp_ctx* c) {
         if (long_stream) BGP_HIP(hipMemsetAsync(a.tile_stats, 0, (tile_base + WG_SLOTS) * 32, c->stream));      // the accumulate path adds its totals wave by wave (zeroed with the planner's arrays above)
         if (!long_stream) {
             GArgs g;
-            g.s = a.s; g.slab = (const unsigned long long*)c->d_slab.p; g.wcount = c->d_wcount.as<uint32_t>(); g.wdel = c->d_wdel.as<int32_t>(); g.tiles = a.tiles; g.n_tiles = tile_base;
+            g.s = a.s; g.slab = (const unsigned long long*)c->d_slab.p; g.slab_cap = SLAB_CAP; g.wcount = c->d_wcount.as<uint32_t>(); g.wdel = c->d_wdel.as<int32_t>(); g.tiles = a.tiles; g.n_tiles = tile_base;
+            g.wlong = have_rows ? c->d_wlong.as<uint32_t>() : nullptr; g.rec = a.rec; g.ck_off = a.ck_off; g.ck = a.ck;
             g.cols = a.cols; g.hist = a.hist; g.tile_stats = a.tile_stats; g.deep = c->d_deep.as<uint32_t>() + 1; g.n_deep = c->d_deep.as<uint32_t>();
-            g.rows = have_rows ? c->d_rows.as<uint8_t>() : nullptr;
             // 1280 workgroups are resident (five of 30 KB a CU); handing the device a dozen times as many, each with a shorter range of
             // windows, lets it balance the ranges' unequal work at the tail (cfg3: 9.1 ms with 4096, 8.55 with 16384, the same with 65536)
             static const unsigned g_env = getenv("BGP_G_BLOCKS") ? (unsigned)atoi(getenv("BGP_G_BLOCKS")) : 0u;
             const unsigned g_blocks = std::min(65536u, g_env ? g_env : 16384u);
-            static const bool acc2 = !(getenv("BGP_ACC2") && atoi(getenv("BGP_ACC2")) == 0);
-            if (have_rows) hipLaunchKernelGGL(k4_acc<true>, dim3((unsigned)std::min<uint64_t>(tile_base, g_blocks)), dim3(AT), (size_t)ALay<true>::BYTES, c->stream, g);
-            else if (acc2) hipLaunchKernelGGL(k4_acc2, dim3((unsigned)std::min<uint64_t>(tile_base, g_blocks)), dim3(AT), (size_t)A2Lay::BYTES, c->stream, g);
-            else hipLaunchKernelGGL(k4_acc<false>, dim3((unsigned)std::min<uint64_t>(tile_base, g_blocks)), dim3(AT), (size_t)ALay<false>::BYTES, c->stream, g);
+            hipLaunchKernelGGL(k4_acc2, dim3((unsigned)std::min<uint64_t>(tile_base, g_blocks)), dim3(AT), (size_t)A2Lay::BYTES, c->stream, g);
         }
         // windows the accumulate path left on the list (odd CIGARs, too deep): the general kernel
         const unsigned dgrid = (unsigned)std::min<uint64_t>(tile_base, 2048);
