@@ -1332,7 +1332,9 @@ __device__ __forceinline__ void acc2_work_small(const A2Small& b, uint32_t* cbas
     }
 }
 
-__global__ __launch_bounds__(AT, BGP_ACC2_MINW) void k4_acc2(GArgs a) {
+// LONG: the stream holds long reads (the phase that walks their CIGARs is compiled in: it costs registers -- 128 and a few spilled
+// against 102 -- that a stream of short reads need not pay for: cfg3 8.8 against 8.0 ms)
+template <bool LONG> __global__ __launch_bounds__(AT, BGP_ACC2_MINW) void k4_acc2(GArgs a) {
     using L = A2Lay;
     extern __shared__ __attribute__((aligned(16))) uint8_t alds[];
     uint32_t* const cnt = reinterpret_cast<uint32_t*>(alds + L::CNT);
@@ -1468,7 +1470,7 @@ __global__ __launch_bounds__(AT, BGP_ACC2_MINW) void k4_acc2(GArgs a) {
             __syncthreads();                                 // every add of the round is in; the pool is free
         }
         const uint32_t np = Tend - T0;
-        if (a.wlong && a.wlong[tile]) {
+        if (LONG && a.wlong[tile]) {
             // ---- long reads.  Their checkpoint for this window (k4_ck_build) is the op that owns the window's first column with the
             // columns and query bases in front of it; from there 64 ops a step, a LANE per op: two wave scans give the op's first column
             // and query base (the closed form of pileup.d:175-222), and the op is accumulated as it stands -- an M / = / X op is a piece
@@ -2083,7 +2085,8 @@ int k34_pileup(bgp_ctx* c) {
             // windows, lets it balance the ranges' unequal work at the tail (cfg3: 9.1 ms with 4096, 8.55 with 16384, the same with 65536)
             static const unsigned g_env = getenv("BGP_G_BLOCKS") ? (unsigned)atoi(getenv("BGP_G_BLOCKS")) : 0u;
             const unsigned g_blocks = std::min(65536u, g_env ? g_env : 16384u);
-            hipLaunchKernelGGL(k4_acc2, dim3((unsigned)std::min<uint64_t>(tile_base, g_blocks)), dim3(AT), (size_t)A2Lay::BYTES, c->stream, g);
+            if (have_rows) hipLaunchKernelGGL(k4_acc2<true>, dim3((unsigned)std::min<uint64_t>(tile_base, g_blocks)), dim3(AT), (size_t)A2Lay::BYTES, c->stream, g);
+            else hipLaunchKernelGGL(k4_acc2<false>, dim3((unsigned)std::min<uint64_t>(tile_base, g_blocks)), dim3(AT), (size_t)A2Lay::BYTES, c->stream, g);
         }
         // windows the accumulate path left on the list (odd CIGARs, too deep): the general kernel
         const unsigned dgrid = (unsigned)std::min<uint64_t>(tile_base, 2048);
