@@ -257,8 +257,12 @@ __device__ __forceinline__ uint32_t base_class(uint32_t code) {   // nt16 code -
 // One thread per window: the record range that can touch it (exact halo).  Done here, massively
 // parallel, because the two ~25-step dependent binary searches are pure latency.
 struct TileB { uint64_t i_lo, i_hi, col_out; uint32_t T0, Tend, run_start, pad; };   // everything a window needs in one 40-byte (scalar) load; pad = 1: deep window
-__global__ __launch_bounds__(256) void k4_bounds(const uint64_t* pmax_end, const uint64_t* pmax_pos, const RunDev* runs, uint32_t n_runs, uint64_t n_tiles, TileB* out, uint32_t w) {
-    const uint64_t tile = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+// mode 0: every window, geometry and record range (two binary searches through the halo keys); 1: geometry only -- the accumulate path of a
+// stream of short reads never asks which records can touch a window, its plan knows (cfg3: 0.16 -> 0.03 ms) --; 2: the record ranges of the
+// windows on `list` (what the accumulate path left for the general kernel, which does scan them)
+__global__ __launch_bounds__(256) void k4_bounds(const uint64_t* pmax_end, const uint64_t* pmax_pos, const RunDev* runs, uint32_t n_runs, uint64_t n_tiles, TileB* out, uint32_t w, int mode, const uint32_t* list, const uint32_t* n_list) {
+    uint64_t tile = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (mode == 2) { if (tile >= *n_list) return; tile = list[tile]; }
     if (tile >= n_tiles) return;
     uint32_t lo_r = 0, hi_r = n_runs;
     while (hi_r - lo_r > 1) { const uint32_t m = (lo_r + hi_r) >> 1; if (runs[m].tile_base <= tile) lo_r = m; else hi_r = m; }
@@ -267,11 +271,15 @@ __global__ __launch_bounds__(256) void k4_bounds(const uint64_t* pmax_end, const
     const uint32_t Tend = (uint32_t)min((uint64_t)T0 + w, run.end_pos);
     const uint64_t rk = ref_key(run.ref_id) << 32;
     TileB b;
-    b.i_lo = lower_bound_gt(pmax_end, run.first_record, run.end_record, rk | T0);             // first record whose running max end_position exceeds T0
-    b.i_hi = lower_bound_gt(pmax_pos, run.first_record, run.end_record, rk | (Tend - 1));     // first record starting at/after Tend
+    b.i_lo = b.i_hi = 0;
+    if (mode != 1) {
+        b.i_lo = lower_bound_gt(pmax_end, run.first_record, run.end_record, rk | T0);             // first record whose running max end_position exceeds T0
+        b.i_hi = lower_bound_gt(pmax_pos, run.first_record, run.end_record, rk | (Tend - 1));     // first record starting at/after Tend
+    }
     b.col_out = run.column_base + (T0 - run.start_pos); b.T0 = T0; b.Tend = Tend; b.run_start = (uint32_t)run.start_pos;
     b.pad = b.i_hi - b.i_lo >= DEEP_WINDOW ? 1u : 0u;     // bit 0: a count per position and class is bounded by the candidates, 16 bits are enough below this
-    out[tile] = b;                                        // (bit 1, "not for the accumulate path", is set by k4_wscan, which also builds the list of such windows)
+    if (mode == 2) b.pad |= out[tile].pad & 2u;           // (bit 1, "not for the accumulate path", is set by k4_wscan, which also builds the list of such windows)
+    out[tile] = b;
 }
 
 // ---- long reads: CIGAR checkpoints ------------------------------------------------------------
@@ -2014,13 +2022,16 @@ int k34_pileup(bgp_ctx* c) {
         uint64_t used = 0;   // algorithmic bytes: record table + CIGAR + packed SEQ per read, 32 B per position
         used = c->n_records * 32 + c->sum_ncig * 4 + (c->sum_lseq + 1) / 2 + col_base * 32;
         BGP_TRY(c->d_tiles.reserve(tile_base * sizeof(TileB)));
+        bool lite_bounds = false;
         BGP_TRY(c->d_deep.reserve((tile_base + 2) * 4));                 // [0] count, [1..] window indices
         BGP_HIP(hipMemsetAsync(c->d_deep.p, 0, 4, c->stream));
         a.n_deep = c->d_deep.as<uint32_t>(); a.deep = c->d_deep.as<uint32_t>() + 1;
         a.tiles = c->d_tiles.as<TileB>();
         {
             TimedRegion tb(c, "k4_bounds", tile_base * sizeof(TileB));
-            hipLaunchKernelGGL(k4_bounds, dim3((unsigned)((tile_base + 255) / 256)), dim3(256), 0, c->stream, a.pmax_end, a.pmax_pos, a.runs, n_runs, tile_base, c->d_tiles.as<TileB>(), tw);
+            // (a stream with long reads: k4_acc2 walks them from the window's record range; a stream left to the general kernel: every window is its)
+            lite_bounds = !long_stream && !st[3];
+            hipLaunchKernelGGL(k4_bounds, dim3((unsigned)((tile_base + 255) / 256)), dim3(256), 0, c->stream, a.pmax_end, a.pmax_pos, a.runs, n_runs, tile_base, c->d_tiles.as<TileB>(), tw, lite_bounds ? 1 : 0, (const uint32_t*)nullptr, (const uint32_t*)nullptr);
         }
         constexpr uint64_t WG_SLOTS = 65536;            // k4_acc's workgroups leave their ranges' totals behind the windows' slots
         BGP_TRY(c->d_col_lo.reserve((tile_base + WG_SLOTS) * 32));
@@ -2090,6 +2101,7 @@ int k34_pileup(bgp_ctx* c) {
         }
         // windows the accumulate path left on the list (odd CIGARs, too deep): the general kernel
         const unsigned dgrid = (unsigned)std::min<uint64_t>(tile_base, 2048);
+        if (lite_bounds) hipLaunchKernelGGL(k4_bounds, dim3((unsigned)((tile_base + 255) / 256)), dim3(256), 0, c->stream, a.pmax_end, a.pmax_pos, a.runs, n_runs, tile_base, c->d_tiles.as<TileB>(), tw, 2, (const uint32_t*)(c->d_deep.as<uint32_t>() + 1), (const uint32_t*)c->d_deep.as<uint32_t>());
         if (long_stream) {
             hipLaunchKernelGGL(k4_tile<L16o>, dim3(dgrid), dim3(L16o::T), lds16, c->stream, a, 1);
             hipLaunchKernelGGL(k4_tile<L32o>, dim3(std::min(dgrid, 512u)), dim3(L32o::T), lds32, c->stream, a, 1);
