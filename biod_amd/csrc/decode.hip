@@ -372,7 +372,6 @@ constexpr int SD_RB = 256;                         // records per emission round
 constexpr uint32_t SD_RMAX = SD_C / 36 + 2;        // a record is at least 36 bytes
 constexpr uint32_t SD_SUBCAP = SD_SC / 36 + 2;
 typedef unsigned long long u64;
-constexpr u64 G_VAL = (1ull << 56) - 1, G_NONE = G_VAL, G_STOP = G_VAL - 1, G_A = 1ull << 56, G_P = 2ull << 56, G_TAG = 0xFFull << 56;
 // LDS map (bytes)
 constexpr uint32_t L_ROFF = SD_WIN + 32;                              // u16[SD_RMAX]: where the chunk's records start (window offsets)
 constexpr uint32_t L_TAB = (L_ROFF + 2 * SD_RMAX + 15) & ~15u;        // emission tables: soff u32[257] | coff u32[257] | info u16[3 x 256] -- before that, the sub-chunks' own offset lists
@@ -387,18 +386,6 @@ enum { M_TICKET = 0, M_FOUND, M_CNT, M_EXIT, M_ERR, M_BAD, M_LS, M_NC, M_FLAGS, 
        M_SUBG = 36 /* SD_NS guesses */, M_SUBX = 44 /* exits */, M_SUBC = 52 /* records | status << 32 */, M_EFF = 60 /* records the chunk's chain takes from the sub-chunk */, M_SUBLS = 68 /* bases */, M_SUBNC = 76 /* CIGAR ops | a CIGAR longer than BGP_LONG_CIGAR << 63 */, M_N = 84 };
 static_assert(SD_NS <= 8 && SD_NS <= SD_NW, "misc slots; a wave per sub-chunk");
 
-#ifdef BGP_SD_PROF                             // phase clocks (thread 0 of every workgroup), summed per phase into g_sd_prof
-__device__ unsigned long long g_sd_prof[16];
-__device__ unsigned long long g_sd_dbg[64 * 4];
-#define SDSTAMP(k) do { if (threadIdx.x == 0 && (blockIdx.x & 63) == 0) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); atomicAdd(&g_sd_prof[k], now_ - stamp_); stamp_ = now_; } } while (0)      /* one workgroup in 64 keeps the clocks: same-address atomics from all of them distort what they measure */
-#else
-#define SDSTAMP(k) do { } while (0)
-#endif
-#ifdef BGP_SD_COUNT
-#define SDCOUNT(k, v) do { atomicAdd(&g_sd_prof[k], (unsigned long long)(v)); } while (0)
-#else
-#define SDCOUNT(k, v) do { } while (0)
-#endif
 struct SdArgs {
     const uint8_t* s; uint64_t len, n_chunks; int32_t ref_bound; int32_t tolerant;
     const uint64_t* hint;             // per chunk: smallest offset where the caller says a record starts (~0: no word), or null
@@ -410,8 +397,6 @@ struct SdArgs {
     uint64_t cap_n, cap_ls, cap_nc;
 };
 
-__device__ __forceinline__ u64 g_load(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void g_store(u64* p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // unaligned little-endian reads at byte offset o of the LDS window: gfx950's DS unit takes unaligned addresses, so each is ONE
 // ds_read (round 2 read the aligned dwords around it and funnel-shifted: two reads and a v_alignbyte per dword -- and VALU issue
@@ -466,45 +451,6 @@ __device__ __forceinline__ uint2 nib_join(uint2 a, uint2 b, uint32_t n) {
     const unsigned long long keep = (1ull << (4u * n)) - 1ull;
     const unsigned long long v = (A & keep) | (B << (4u * n));
     return make_uint2((uint32_t)v, (uint32_t)(v >> 32));
-}
-
-// The fixed fields of `plausible`, branch free, for a header at window offset o (nine aligned dwords, eight v_alignbyte).
-// lim = window offset of the end of the stream (clamped): o + 4 + block_size must not pass it.
-__device__ __forceinline__ bool hdr_fields_ok(const uint32_t* w, uint32_t o, uint32_t lim, int32_t ref_bound, uint32_t* bs_out, uint32_t* l_name_out) {
-    const uint32_t i = o >> 2, sh = o & 3u;
-    const uint32_t d0 = w[i], d1 = w[i + 1], d2 = w[i + 2], d3 = w[i + 3], d4 = w[i + 4], d5 = w[i + 5], d6 = w[i + 6], d7 = w[i + 7], d8 = w[i + 8];
-    const uint32_t bs = __builtin_amdgcn_alignbyte(d1, d0, sh), ref = __builtin_amdgcn_alignbyte(d2, d1, sh), pos = __builtin_amdgcn_alignbyte(d3, d2, sh), bmn = __builtin_amdgcn_alignbyte(d4, d3, sh);
-    const uint32_t fnc = __builtin_amdgcn_alignbyte(d5, d4, sh), lseq = __builtin_amdgcn_alignbyte(d6, d5, sh), nref = __builtin_amdgcn_alignbyte(d7, d6, sh), npos = __builtin_amdgcn_alignbyte(d8, d7, sh);
-    const uint32_t l_name = bmn & 0xFFu, n_cig = fnc & 0xFFFFu;
-    *bs_out = bs; *l_name_out = l_name;
-    const uint32_t rb = (uint32_t)ref_bound;
-    bool ok = (bs - 33u) <= ((1u << 30) - 33u);                                     // 33 <= block_size <= 2^30
-    ok &= o + 36 <= lim && bs <= lim - o - 4;                                        // the record lies inside the stream (o <= lim: the window does not reach past lim + spare)
-    ok &= (ref + 1u) <= rb && (nref + 1u) <= rb;                                     // -1 <= refID, next_refID < ref_bound
-    ok &= (int32_t)pos >= -1 && (int32_t)npos >= -1 && (int32_t)lseq >= 0 && l_name != 0;
-    ok &= lseq <= bs && 32u + l_name + 4u * n_cig + ((lseq + 1u) >> 1) + lseq <= bs; // the sections fit (lseq <= 2^30: no overflow)
-    return ok;
-}
-// NUL-terminated, printable read name (see plausible()), the whole wave looking at it: lane j takes bytes j, j + 64, ...
-__device__ __forceinline__ bool name_ok_wave(const uint32_t* w, uint32_t o, uint32_t l_name, int lane) {
-    const uint8_t* nm = reinterpret_cast<const uint8_t*>(w) + o + 36;
-    bool bad = false;
-    for (uint32_t j = lane; j < l_name; j += 64) { const uint32_t ch = nm[j]; bad |= j + 1 == l_name ? ch != 0 : (ch - 0x21u) > (0x7Eu - 0x21u); }
-    return __ballot(bad) == 0;
-}
-// `plausible` + a plausible successor for the candidate at stream offset o, evaluated by the whole wave (uniform)
-[[maybe_unused]] __device__ __forceinline__ bool candidate_ok_wave(const SdArgs& a, const uint32_t* w, uint64_t wbase, uint32_t lim, uint64_t o, int lane) {
-    uint64_t cur = o;
-    for (int d = 0; d < 2; ++d) {
-        if (d && a.len - cur < 4) return true;                                       // the chain ends with the stream
-        uint32_t bs, l_name;
-        if (cur - wbase + 296 <= SD_WIN) {
-            if (!hdr_fields_ok(w, (uint32_t)(cur - wbase), lim, a.ref_bound, &bs, &l_name)) return false;
-            if (!name_ok_wave(w, (uint32_t)(cur - wbase), l_name, lane)) return false;
-        } else if (!plausible(a.s, a.len, cur, a.ref_bound, &bs)) return false;      // past the window: from global memory
-        cur += 4 + (uint64_t)bs;
-    }
-    return true;
 }
 
 __device__ __forceinline__ int find_rec32(const uint32_t* off, int cnt, uint32_t b, int g) {
@@ -585,197 +531,6 @@ __device__ __forceinline__ void unpack_lds(const SdArgs& a, const uint32_t* w, i
     }
 }
 
-__device__ __forceinline__ u64 wave_sum_u64(u64 v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-    return v;
-}
-
-// One lane hops from record to record through the LDS window (readrange.d:118-173), from `entry` (inside the sub-chunk
-// that ends at `send`) until it leaves the sub-chunk; the records' window offsets land in tab.  The hop itself is kept
-// to a dozen instructions on 32-bit window offsets; whatever is not a plain hop is looked at again with the
-// reference's own tests, in its order.  Returns the number of records; *exit_ = where the chain stands, *err_ its status.
-__device__ __forceinline__ uint32_t sd_chase_sub(const SdArgs& a, const uint32_t* w, uint16_t* tab, uint64_t wbase, uint64_t send, uint64_t entry, u64* exit_, uint32_t* err_) {
-    const uint64_t len_rel = a.len - wbase;
-    const uint32_t lim = len_rel >= 0xFFFF0000ull ? 0xFFFF0000u : (uint32_t)len_rel;      // (far from the end of the stream no block_size can pass it)
-    const uint32_t se = (uint32_t)(send - wbase);
-    uint32_t o = (uint32_t)(entry - wbase), cnt = 0;
-    while (o < se) {
-        const uint32_t bs = wl32(w, o), nx = o + bs + 4;
-        if ((int32_t)bs < 32 || nx > lim) break;
-        tab[cnt++] = (uint16_t)o;
-        o = nx;
-    }
-    uint64_t off = wbase + o;
-    uint32_t err = 0;
-    if (o < se) {                                          // not a plain hop: the same tests as k0_chase, on the full offsets
-        if (a.len - off < 4) { if (!a.tolerant) off = a.len; }                 // readrange.d:139-149: a short prefix ends the range (a batch keeps it for the next one)
-        else {
-            const int32_t bs = (int32_t)wl32(w, o);
-            if (bs < 0) err = ST_EINVAL;
-            else if ((uint64_t)bs > a.len - off - 4) {                                          // readrange.d:169; in a batch the rest may still be to come -- but only of a record that can exist (as in k0_chase)
-                if (!a.tolerant) err = ST_ETRUNC;
-                else if (bs < 32 || (uint32_t)bs > (1u << 30)) err = ST_EINVAL;
-                else if (a.len - off >= 24) {
-                    const uint32_t bmn = wl32(w, o + 12), fnc = wl32(w, o + 16); const int32_t lseq = (int32_t)wl32(w, o + 20);
-                    const uint32_t l_name = bmn & 0xFFu, n_cig = fnc & 0xFFFFu;
-                    if (lseq < 0 || l_name == 0 || 32ull + l_name + 4ull * n_cig + (uint64_t)((lseq + 1) / 2) + (uint64_t)lseq > (uint64_t)bs) err = ST_EINVAL;
-                }
-            }
-            else err = ST_EINVAL;                          // bs < 32
-        }
-    }
-    *exit_ = off; *err_ = err;
-    return cnt;
-}
-
-// Sections of a sub-chunk's chased records checked (what k0_chase checks hop by hop: readrange.d:118-173 and the bounds
-// read.d's accessors rely on), l_seq and n_cigar_op summed up to the first bad record.  One wave, lane = record.
-[[maybe_unused]] __device__ __forceinline__ uint32_t sd_validate_sub(const uint32_t* w, const uint16_t* tab, uint32_t cq, int lane, u64* ls_out, u64* nc_out) {
-    uint32_t good = cq;
-    u64 ls = 0, nc = 0; uint32_t lng = 0;
-    for (int pass = 0; pass < 2; ++pass) {
-        uint32_t bad = cq;
-        ls = 0; nc = 0; lng = 0;
-        for (uint32_t r = lane; r < good; r += 64) {
-            const uint32_t o = tab[r];
-            const uint32_t bs = wl32(w, o), bmn = wl32(w, o + 12), fnc = wl32(w, o + 16);
-            const int32_t lseq = (int32_t)wl32(w, o + 20);
-            const uint32_t l_name = bmn & 0xFFu, n_cig = fnc & 0xFFFFu;
-            if (lseq < 0 || l_name == 0 || 32ull + l_name + 4ull * n_cig + (uint64_t)((lseq + 1) / 2) + (uint64_t)lseq > (uint64_t)bs) bad = min(bad, r);
-            ls += (uint32_t)lseq; nc += n_cig; lng |= n_cig > BGP_LONG_CIGAR;
-        }
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) bad = min(bad, (uint32_t)__shfl_xor((int)bad, d, 64));
-        if (bad >= good) break;                           // (always, in a well-formed stream)
-        good = bad;                                       // the chain stops in front of the first bad record: sums once more, up to it
-    }
-    ls = wave_sum_u64(ls); nc = wave_sum_u64(nc);
-    *ls_out = ls; *nc_out = nc | (__ballot(lng) ? 1ull << 63 : 0ull);
-    return good;
-}
-// the same by one thread (a sub-chunk chased again by sd_link: rare)
-__device__ __forceinline__ uint32_t sd_validate_sub_serial(const uint32_t* w, const uint16_t* tab, uint32_t cq, u64* ls_out, u64* nc_out) {
-    u64 ls = 0, nc = 0, lng = 0; uint32_t r = 0;
-    for (; r < cq; ++r) {
-        const uint32_t o = tab[r];
-        const uint32_t bs = wl32(w, o), bmn = wl32(w, o + 12), fnc = wl32(w, o + 16);
-        const int32_t lseq = (int32_t)wl32(w, o + 20);
-        const uint32_t l_name = bmn & 0xFFu, n_cig = fnc & 0xFFFFu;
-        if (lseq < 0 || l_name == 0 || 32ull + l_name + 4ull * n_cig + (uint64_t)((lseq + 1) / 2) + (uint64_t)lseq > (uint64_t)bs) break;
-        ls += (uint32_t)lseq; nc += n_cig; lng |= n_cig > BGP_LONG_CIGAR ? 1ull << 63 : 0ull;
-    }
-    *ls_out = ls; *nc_out = nc | lng;
-    return r;
-}
-
-// The chunk's chain of records put together from its sub-chunks (one thread).  The chain stands at `cur`; a sub-chunk it
-// enters exactly at the sub-chunk's own guess brings its list as it is, any other is chased again from where the chain
-// stands.  Leaves the sub-chunks' counts (M_SUBC), the chunk's count, exit, status and the end of its last record.
-[[maybe_unused]] __device__ __forceinline__ void sd_link(const SdArgs& a, const uint32_t* w, uint16_t* sub, u64* misc, uint64_t wbase, uint64_t cend, u64 cur) {
-    uint32_t total = 0, err = 0;
-    u64 ls = 0, nc = 0;
-    bool ended = cur == G_NONE || cur == G_STOP || cur < wbase;
-#pragma nounroll
-    for (int q = 0; q < SD_NS; ++q) {
-        const uint64_t sb = wbase + (uint64_t)q * SD_SC, se = min(sb + SD_SC, cend);
-        uint32_t cq = 0;
-        if (!ended && !err && sb < cend && cur < se) {
-            if (cur < sb) ended = true;                                        // (a batch's partial last record: the chain stopped in front of it)
-            else {
-                if (misc[M_SUBG + q] != cur) {                                 // not where this sub-chunk's own guess entered it: chased again from where the chain stands
-                    u64 x, l2, n2; uint32_t e;
-                    uint32_t c2 = sd_chase_sub(a, w, sub + q * SD_SUBCAP, wbase, se, cur, &x, &e);
-                    const uint32_t good = sd_validate_sub_serial(w, sub + q * SD_SUBCAP, c2, &l2, &n2);
-                    if (good < c2) { c2 = good; e = ST_EINVAL; }
-                    misc[M_SUBG + q] = cur; misc[M_SUBX + q] = x; misc[M_SUBC + q] = c2 | ((u64)e << 32); misc[M_SUBLS + q] = l2; misc[M_SUBNC + q] = n2;
-                }
-                cq = (uint32_t)misc[M_SUBC + q]; err = (uint32_t)(misc[M_SUBC + q] >> 32); cur = misc[M_SUBX + q];
-                ls += misc[M_SUBLS + q]; nc += misc[M_SUBNC + q] & ~(1ull << 63);
-                if (misc[M_SUBNC + q] >> 63) nc |= 1ull << 62;
-                if (!err && cur < se) ended = true;                            // short prefix / partial record: nothing follows
-            }
-        }
-        misc[M_EFF + q] = cq;                                                  // (a sub-chunk the chain passes over brings nothing)
-        total += cq;
-    }
-    misc[M_CNT] = total; misc[M_EXIT] = cur; misc[M_ERR] = err;
-    misc[M_LS] = ls; misc[M_NC] = nc & ~(1ull << 62); misc[M_FLAGS] = (nc >> 62) & 1ull;
-}
-
-// The look-back of chunk k (> 0), one wave: true entry, records / bases / ops in front of the chunk -> misc[M_ENT .. M_PNC].
-[[maybe_unused]] __device__ __forceinline__ void sd_lookback(const SdArgs& a, uint64_t k, int lane, u64* misc) {
-    uint32_t spins = 0;
-    for (;;) {                                            // (again from the nearest predecessor after a wait)
-        u64 acc_n = 0, acc_ls = 0, acc_nc = 0, e_cand = 0;
-        bool have_e = false, need_eq = false, again = false;
-        u64 need_val = 0;
-        for (uint64_t top = k - 1;; top -= 64) {          // lane i looks at chunk top - i
-            const bool act = (uint64_t)lane <= top;
-            const uint64_t m = top - (uint64_t)lane;
-            u64 x = 0, g = G_NONE, n = 0, ls = 0, nc = 0;
-            int st = 0, p = 64;
-            for (;;) {                                    // one granule of each kind per lane while waiting; the rest once every lane that counts shows one
-                st = 0;
-                const u64* d = a.desc + 8 * m;
-                u64 p0 = 0, a0 = 0;
-                if (act) { p0 = g_load(d); a0 = g_load(d + 4); }
-                const int hint = (p0 & G_TAG) == G_P ? 2 : (a0 & G_TAG) == G_A ? 1 : 0;
-                const u64 Ph = __ballot(hint == 2), Rh = __ballot(hint != 0 || !act);
-                const int ph = Ph ? __ffsll((long long)Ph) - 1 : 64;
-                const u64 needh = ph >= 63 ? ~0ull : ((2ull << ph) - 1);
-                bool ready = (Rh & needh) == needh;
-                if (ready) {
-                    if (act && hint == 2 && lane <= ph) {
-                        const u64 p1 = g_load(d + 1), p2 = g_load(d + 2), p3 = g_load(d + 3);
-                        if ((p1 & G_TAG) == G_P && (p2 & G_TAG) == G_P && (p3 & G_TAG) == G_P) { st = 2; x = p0 & G_VAL; n = p1 & G_VAL; ls = p2 & G_VAL; nc = p3 & G_VAL; g = G_NONE; }
-                    } else if (act && hint == 1 && lane <= ph) {
-                        const u64 a1 = g_load(d + 5), a2 = g_load(d + 6);
-                        if ((a1 & G_TAG) == G_A && (a2 & G_TAG) == G_A) {
-                            st = 1; x = a0 & G_VAL; ls = a2 & G_VAL;
-                            const uint32_t grel = (uint32_t)a1 & 0xFFFFu;
-                            g = grel == 0xFFFFu ? G_NONE : m * SD_C + grel; n = (a1 >> 16) & 0xFFFu; nc = (a1 >> 28) & 0xFFFFFu;
-                        }
-                    }
-                    const u64 Pm = __ballot(st == 2), Rm = __ballot(st != 0 || !act);
-                    p = Pm ? __ffsll((long long)Pm) - 1 : 64;
-                    const u64 needm = p >= 63 ? ~0ull : ((2ull << p) - 1);
-                    ready = p == ph && (Rm & needm) == needm;       // (a granule still on its way: once more)
-                }
-                if (lane == 0) SDCOUNT(8, 1);
-                if (ready) break;
-                if (g_load(a.ctl + 1) || ++spins > (1u << 21)) { if (lane == 0) { g_store(a.ctl + 1, 1ull); misc[M_ABORT] = 1; } return; }
-                __builtin_amdgcn_s_sleep(16);
-            }
-            const bool in = lane <= p && act;
-            const bool definite = in && (st == 2 || g != G_NONE);
-            const u64 D = __ballot(definite);
-            const u64 lower = D & ((1ull << lane) - 1);
-            bool nq = need_eq; u64 nv = need_val;
-            const int jl = lower ? 63 - __clzll((long long)lower) : 0;
-            const u64 gl = __shfl(g, jl, 64);
-            if (lower) { nq = true; nv = gl; }
-            bool ok = true;
-            if (definite) ok = nq ? x == nv : (x == G_STOP || x < (m + 1) * SD_C || x >= k * SD_C);
-            if (__ballot(definite && !ok)) { again = true; if (lane == 0) SDCOUNT(9, 1); break; }           // somebody's guess was wrong: its final descriptor is on the way
-            const bool counted = in && st == 1 && lane < p;
-            acc_n += wave_sum_u64(counted ? n : 0); acc_ls += wave_sum_u64(counted ? ls : 0); acc_nc += wave_sum_u64(counted ? nc : 0);
-            if (!have_e && D) { e_cand = __shfl(x, __ffsll((long long)D) - 1, 64); have_e = true; }
-            if (p < 64) {
-                const u64 pn = __shfl(n, p, 64), pls = __shfl(ls, p, 64), pnc = __shfl(nc, p, 64);
-                if (lane == 0) { misc[M_ENT] = e_cand; misc[M_PN] = pn + acc_n; misc[M_PLS] = pls + acc_ls; misc[M_PNC] = pnc + acc_nc; }
-                return;
-            }
-            if (D) { need_eq = true; need_val = __shfl(g, 63 - __clzll((long long)D), 64); }
-            if (lane == 0) SDCOUNT(10, 1);
-        }
-        if (!again) return;
-        if (g_load(a.ctl + 1) || ++spins > (1u << 21)) { if (lane == 0) { g_store(a.ctl + 1, 1ull); misc[M_ABORT] = 1; } return; }
-        __builtin_amdgcn_s_sleep(32);
-    }
-}
-
-
 // exclusive prefix sums of two per-thread values over the first SD_RB threads (waves 0 .. SD_RB/64-1; every thread of the
 // workgroup calls) + the totals
 __device__ __forceinline__ void sd_excl2(uint32_t v0, uint32_t v1, uint32_t* e0, uint32_t* e1, uint32_t* t0, uint32_t* t1, u64* ws) {
@@ -802,11 +557,7 @@ __device__ __forceinline__ void sd_excl2(uint32_t v0, uint32_t v1, uint32_t* e0,
 // chunk.  pn / pls / pnc: records, bases, CIGAR ops in front of the chunk.  A last record that runs past the window
 // (last_long) is unpacked from global memory by the whole workgroup.
 template <bool SEQ, bool QUAL, bool CIG>
-__device__ __forceinline__ void sd_emit(const SdArgs& a, uint8_t* sd_lds, uint64_t wbase, uint32_t cnt, bool last_long, u64 pn, u64 pls, u64 pnc
-#ifdef BGP_SD_PROF
-                                        , unsigned long long& stamp_
-#endif
-                                        ) {
+__device__ __forceinline__ void sd_emit(const SdArgs& a, uint8_t* sd_lds, uint64_t wbase, uint32_t cnt, bool last_long, u64 pn, u64 pls, u64 pnc) {
     uint32_t* const w = reinterpret_cast<uint32_t*>(sd_lds);
     uint16_t* const roff = reinterpret_cast<uint16_t*>(sd_lds + L_ROFF);
     uint32_t* const soff = reinterpret_cast<uint32_t*>(sd_lds + L_SOFF);
@@ -871,10 +622,8 @@ __device__ __forceinline__ void sd_emit(const SdArgs& a, uint8_t* sd_lds, uint64
         }
         __syncthreads();
         if (a.tilemax && t < 4 && misc[M_TM + t]) atomicMax(&a.tilemax[2 * tile0 + t], misc[M_TM + t]);
-        SDSTAMP(5);   // rows
         unpack_lds<SEQ, QUAL, CIG>(a, w, rc, carry_seq, carry_cig, soff, coff, info, cmap);
         __syncthreads();
-        SDSTAMP(6);   // arenas
         carry_seq += ts; carry_cig += tc;
     }
     if (last_long) {                    // the chunk's last record runs past the window: from global memory, by the whole workgroup
@@ -919,152 +668,8 @@ __device__ __forceinline__ void sd_emit(const SdArgs& a, uint8_t* sd_lds, uint64
     }
 }
 
-#ifdef BGP_EXPERIMENTS                         // the one-pass decode: exact, measured, slower -- not in the product build
-template <bool SEQ, bool QUAL, bool CIG>
-__global__ __launch_bounds__(SD_T, BGP_SD_MINW) void k_stream_decode(SdArgs a) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t sd_lds[];
-    uint32_t* const w = reinterpret_cast<uint32_t*>(sd_lds);
-    uint16_t* const roff = reinterpret_cast<uint16_t*>(sd_lds + L_ROFF);
-    uint16_t* const sub = reinterpret_cast<uint16_t*>(sd_lds + L_SUB);
-    u64* const misc = reinterpret_cast<u64*>(sd_lds + L_MISC);
-#ifdef BGP_SD_PROF
-    unsigned long long stamp_ = __builtin_amdgcn_s_memtime();
-#endif
-    const int t = threadIdx.x, lane = t & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    // One chunk per workgroup, chunk = blockIdx.x.  A chunk only ever waits for chunks before it, and the hardware starts
-    // the workgroups of a grid in rising order (per XCD: workgroup b goes to XCD b mod 8, each XCD in order), so the
-    // earliest unfinished chunk is always running.  HIP does not promise that order; what it would cost to be without
-    // it: a same-address ticket atomic per workgroup, from eight XCDs, took 18 of 52 ms, and a persistent grid with
-    // static chunk assignment walks in lock step (all loads at once, then all compute: 36 ms against 29) and spills.
-    // If the order ever failed, a chunk's look-back gives up after a bounded number of polls, the kernel aborts and the
-    // host takes the three-kernel path: a wrong assumption costs time, not correctness.
-  {
-    const uint64_t k = blockIdx.x;
-    if (t == 0) misc[M_ABORT] = 0;
-    const uint64_t wbase = k * SD_C, cend = min(wbase + SD_C, a.len);
-    const uint32_t wlen = (uint32_t)min((uint64_t)SD_WIN, a.len - wbase);
-    {   // the window: every load in flight before the first store
-        constexpr int NL = (SD_WIN + 32 + 16 * SD_T - 1) / (16 * SD_T);
-        uint4 v[NL];
-#pragma unroll
-        for (int i = 0; i < NL; ++i) { const uint32_t o = 16u * (uint32_t)(t + SD_T * i); v[i] = make_uint4(0, 0, 0, 0); if (o + 16 <= wlen) __builtin_memcpy(&v[i], a.s + wbase + o, 16); }
-#pragma unroll
-        for (int i = 0; i < NL; ++i) { const uint32_t o = 16u * (uint32_t)(t + SD_T * i); if (o < SD_WIN + 32) *reinterpret_cast<uint4*>(sd_lds + o) = v[i]; }
-    }
-    __syncthreads();
-    if (wlen & 15u) {                                      // the last few bytes of the stream, one by one
-        const uint32_t tail0 = wlen & ~15u;
-        if (tail0 + t < wlen) sd_lds[tail0 + t] = a.s[wbase + tail0 + t];
-        __syncthreads();
-    }
-    SDSTAMP(0);       // window loaded
-
-    // ---- frame: every wave guesses where the chain of records enters ITS sub-chunk -- the first offset where a
-    // plausible header is followed by two more, 64 candidates a step -- and one of its lanes chases from there
-    if (wave < SD_NS) {
-        const uint64_t sb = wbase + (uint64_t)wave * SD_SC, se = min(sb + SD_SC, cend);
-        u64 g = G_NONE;
-        if (k == 0 && wave == 0) g = 0;
-        else if (sb < cend) {
-            const uint64_t len_rel = a.len - wbase;
-            const uint32_t lim = len_rel >= 0xFFFF0000ull ? 0xFFFF0000u : (uint32_t)len_rel;
-            if (a.hint) {                                  // the caller's word (first_record_uoffset): first candidate, same test
-                const uint64_t h = a.hint[k];
-                if (h != ~0ull && h >= sb && h < se && candidate_ok_wave(a, w, wbase, lim, h, lane)) g = h;
-            }
-            for (uint64_t base = sb; base < se && g == G_NONE; base += 64) {
-                const uint32_t o = (uint32_t)(base - wbase) + lane;
-                // block_size and refID alone turn nearly every candidate down (three dwords, a dozen instructions for 64 of them) ...
-                const uint32_t i = o >> 2, sh = o & 3u;
-                const uint32_t d0 = w[i], d1 = w[i + 1], d2 = w[i + 2];
-                const uint32_t bs0 = __builtin_amdgcn_alignbyte(d1, d0, sh), ref0 = __builtin_amdgcn_alignbyte(d2, d1, sh);
-                u64 m = __ballot((bs0 - 33u) <= ((1u << 30) - 33u) && (ref0 + 1u) <= (uint32_t)a.ref_bound && base + lane < se);
-                while (m) {                                // ... the few that pass: all fields, name and successor, by the whole wave
-                    const int l = __ffsll((long long)m) - 1;
-                    m &= m - 1;
-                    if (candidate_ok_wave(a, w, wbase, lim, base + l, lane)) { g = base + l; break; }
-                }
-            }
-        }
-        SDSTAMP(7);   // guessed
-        u64 x = G_NONE, sls = 0, snc = 0; uint32_t e = 0, cq = 0;
-        if (g != G_NONE) {
-            if (lane == 0) cq = sd_chase_sub(a, w, sub + wave * SD_SUBCAP, wbase, se, g, &x, &e);
-            cq = (uint32_t)__shfl((int)cq, 0, 64);
-            SDSTAMP(8);   // chased
-            const uint32_t good = sd_validate_sub(w, sub + wave * SD_SUBCAP, cq, lane, &sls, &snc);       // lane = record
-            if (good < cq) { cq = good; e = ST_EINVAL; }
-        }
-        SDSTAMP(9);   // validated
-        if (lane == 0) { misc[M_SUBG + wave] = g; misc[M_SUBX + wave] = x; misc[M_SUBC + wave] = cq | ((u64)e << 32); misc[M_SUBLS + wave] = sls; misc[M_SUBNC + wave] = snc; }
-    }
-    __syncthreads();
-    SDSTAMP(1);       // sub-chunks guessed and chased
-
-    // the chunk's records from an entry: sub-chunk lists linked (their sums with them), offsets made one list
-    auto run_chain = [&](u64 entry) {                      // all threads
-        if (t == 0) sd_link(a, w, sub, misc, wbase, cend, entry);
-        __syncthreads();
-        uint32_t pre = 0;
-        for (int q = 0; q < SD_NS; ++q) {
-            const uint32_t cq = (uint32_t)misc[M_EFF + q];
-            for (uint32_t j = t; j < cq; j += SD_T) roff[pre + j] = sub[q * SD_SUBCAP + j];
-            pre += cq;
-        }
-        __syncthreads();
-    };
-    u64 g = G_NONE;                                        // the chunk's guess: its first sub-chunk guess
-#pragma unroll
-    for (int q = SD_NS - 1; q >= 0; --q) if (misc[M_SUBG + q] != G_NONE) g = misc[M_SUBG + q];
-    run_chain(g);
-    SDSTAMP(2);       // linked, validated
-    u64* const dsc = a.desc + 8 * k;
-    u64 pn = 0, pls = 0, pnc = 0;
-    if (k > 0) {
-        if (t == 0) {
-            const u64 x = g == G_NONE ? G_NONE : (misc[M_ERR] ? G_STOP : misc[M_EXIT]);
-            g_store(dsc + 6, G_A | misc[M_LS]);
-            g_store(dsc + 5, G_A | (g == G_NONE ? 0xFFFFull : g - wbase) | (misc[M_CNT] << 16) | (misc[M_NC] << 28));
-            g_store(dsc + 4, G_A | x);
-        }
-        if (t < 64) sd_lookback(a, k, lane, misc);
-        __syncthreads();
-        SDSTAMP(3);   // looked back
-        if (misc[M_ABORT]) return;                             // (gave up: see sd_lookback)
-        const u64 e = misc[M_ENT];
-        pn = misc[M_PN]; pls = misc[M_PLS]; pnc = misc[M_PNC];
-        const bool passes = e == G_STOP || e < wbase || e >= cend;          // no record of the true chain starts in this chunk
-        const bool consistent = g != G_NONE ? e == g : passes;
-#ifdef BGP_SD_COUNT
-        if (!consistent && t == 0) { const unsigned long long n_ = atomicAdd(&g_sd_prof[11], 1ull); if (n_ < 64) { g_sd_dbg[4 * n_] = k; g_sd_dbg[4 * n_ + 1] = g; g_sd_dbg[4 * n_ + 2] = e; g_sd_dbg[4 * n_ + 3] = misc[M_SUBG + 1]; } }
-#endif
-        if (!consistent || g == G_NONE) run_chain(e);                        // the guess was wrong or missing: once more from the true entry (sub-chunks entered at their guesses keep their lists)
-    }
-    SDSTAMP(4);       // (a wrong guess: linked again)
-    const uint32_t cnt = (uint32_t)misc[M_CNT], err = (uint32_t)misc[M_ERR];
-    const u64 ls_tot = misc[M_LS], nc_tot = misc[M_NC], x_true = err ? G_STOP : misc[M_EXIT];
-    const bool last_long = cnt && (uint64_t)roff[cnt - 1] + 4 + (uint64_t)wl32(w, roff[cnt - 1]) > wlen;
-    if (t == 0) {
-        g_store(dsc + 3, G_P | (pnc + nc_tot)); g_store(dsc + 2, G_P | (pls + ls_tot)); g_store(dsc + 1, G_P | (pn + cnt)); g_store(dsc, G_P | x_true);
-        uint32_t bits = err | ((misc[M_FLAGS] & 1ull) ? ST_LONGCIG : 0u);
-        if (bits) atomicOr(a.status, bits);
-        if (k + 1 == a.n_chunks) {
-            a.ctl[3] = pn + cnt; a.ctl[4] = pls + ls_tot; a.ctl[5] = pnc + nc_tot; a.ctl[6] = x_true;
-            if (pn + cnt <= a.cap_n) { a.seq_off[pn + cnt] = pls + ls_tot; a.cig_off[pn + cnt] = pnc + nc_tot; }
-        }
-    }
-    if (!cnt) return;
-    if (pn + cnt > a.cap_n || pls + ls_tot > a.cap_ls || pnc + nc_tot > a.cap_nc) { if (t == 0) a.ctl[2] = 1; return; }   // (sized from the first records: the host runs the pass again with what this one found)
-
-    // ---- emit: rows (lane = record), then the arenas (lane = 16-byte chunk)
-#ifdef BGP_SD_PROF
-    sd_emit<SEQ, QUAL, CIG>(a, sd_lds, wbase, cnt, last_long, pn, pls, pnc, stamp_);
-#else
-    sd_emit<SEQ, QUAL, CIG>(a, sd_lds, wbase, cnt, last_long, pn, pls, pnc);
-#endif
-  }
-}
+#ifdef BGP_EXPERIMENTS                         // the one-pass decode: exact, measured, slower (LABNOTES.md) -- not in the product build
+#include "decode_onepass.inc"
 #endif
 
 
@@ -1085,9 +690,6 @@ __global__ __launch_bounds__(SD_T, BGP_SD_MINW) void k12_lds(LdsArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t sd_lds[];
     uint16_t* const roff = reinterpret_cast<uint16_t*>(sd_lds + L_ROFF);
     const uint32_t* const w = reinterpret_cast<const uint32_t*>(sd_lds);
-#ifdef BGP_SD_PROF
-    unsigned long long stamp_ = __builtin_amdgcn_s_memtime();
-#endif
     const int t = threadIdx.x;
     const uint64_t k = blockIdx.x;
     if (k == 0 && t == 0) { a.d.seq_off[a.n_records] = a.sum_lseq; a.d.cig_off[a.n_records] = a.sum_ncig; }
@@ -1118,13 +720,8 @@ __global__ __launch_bounds__(SD_T, BGP_SD_MINW) void k12_lds(LdsArgs a) {
         if (tail0 + t < wlen) sd_lds[tail0 + t] = a.d.s[wbase + tail0 + t];
         __syncthreads();
     }
-    SDSTAMP(0);
     const bool last_long = (uint64_t)roff[cnt - 1] + 4 + (uint64_t)wl32(w, roff[cnt - 1]) > wlen;
-#ifdef BGP_SD_PROF
-    sd_emit<SEQ, QUAL, CIG>(a.d, sd_lds, wbase, cnt, last_long, pn, a.seq_base[sg] + p0.y, a.cig_base[sg] + p0.z, stamp_);
-#else
     sd_emit<SEQ, QUAL, CIG>(a.d, sd_lds, wbase, cnt, last_long, pn, a.seq_base[sg] + p0.y, a.cig_base[sg] + p0.z);
-#endif
 }
 
 }  // namespace
@@ -1220,135 +817,7 @@ int k12_fused_decode(bgp_ctx* c, uint32_t what) {
 #ifndef BGP_EXPERIMENTS
 int k012_stream_decode(bgp_ctx*, uint32_t) { return 1; }     // not built: the caller takes K0 + K1 + K2
 #else
-int k012_stream_decode(bgp_ctx* c, uint32_t what) {
-    const uint64_t len = c->stream_len;
-    c->n_records = 0; c->sum_lseq = 0; c->sum_ncig = 0;
-    BGP_TRY(c->d_status.reserve(64));
-    BGP_HIP(hipMemsetAsync(c->d_status.p, 0, 64, c->stream));
-    c->table_pending = false; c->long_cigar = false; c->cig4_ok = false; c->tilemax_ok = false;
-    if (len < 4) {                       // empty range (readrange.d:123-149)
-        BGP_TRY(c->d_rec.reserve(sizeof(bgp_record)));
-        BGP_TRY(c->d_seq_off.reserve(8)); BGP_TRY(c->d_cigar_off.reserve(8));
-        BGP_HIP(hipMemsetAsync(c->d_seq_off.p, 0, 8, c->stream));
-        BGP_HIP(hipMemsetAsync(c->d_cigar_off.p, 0, 8, c->stream));
-        BGP_HIP(hipStreamSynchronize(c->stream));
-        c->frame_tail = c->frame_tolerant_tail ? 0 : len;
-        return BGP_OK;
-    }
-    const bool S = what & BGP_FETCH_SEQ, Q = what & BGP_FETCH_QUAL, C = what & BGP_FETCH_CIGAR;
-    const bool all = S && Q && C;
-    const uint64_t n_chunks = (len + SD_C - 1) / SD_C;
-    // sizes of the products, from the records at the head of the stream (any value is correct: a pass that runs out of
-    // room reports it and is repeated with the sizes it found)
-    uint64_t est_n, est_ls, est_nc;
-    {
-        std::vector<uint8_t> head((size_t)std::min<uint64_t>(len, 1u << 16));
-        BGP_HIP(hipMemcpyAsync(head.data(), c->d_stream, head.size(), hipMemcpyDeviceToHost, c->stream));
-        BGP_HIP(hipStreamSynchronize(c->stream));
-        uint64_t off = 0, cnt = 0, ls = 0, nc = 0, bytes = 0;
-        uint32_t bs0 = 0, lseq0 = 0, nc0 = 0;
-        while (off + 36 <= head.size()) {
-            uint32_t bs, fnc; int32_t lseq;
-            memcpy(&bs, &head[off], 4); memcpy(&fnc, &head[off + 16], 4); memcpy(&lseq, &head[off + 20], 4);
-            if (bs < 32 || bs > (1u << 30) || lseq < 0) break;
-            if (!cnt) { bs0 = bs; lseq0 = (uint32_t)lseq; nc0 = fnc & 0xFFFFu; }
-            if (off + 4 + bs > head.size() && cnt) break;
-            ++cnt; ls += (uint32_t)lseq; nc += fnc & 0xFFFFu; bytes += 4ull + bs; off += 4ull + bs;
-        }
-        if (cnt >= 8) {
-            const double f = (double)len / (double)bytes * 1.03;
-            est_n = (uint64_t)(cnt * f) + 4096; est_ls = (uint64_t)(ls * f) + (1u << 20); est_nc = (uint64_t)(nc * f) + (1u << 16);
-        } else if (cnt) {
-            const double f = (double)len / (double)(4ull + bs0) * 1.25;
-            est_n = (uint64_t)f + 64; est_ls = (uint64_t)(f * lseq0) + 4096; est_nc = (uint64_t)(f * nc0) + 4096;
-        } else { est_n = len / 64 + 64; est_ls = len / 2 + 64; est_nc = len / 16 + 64; }
-        est_n = std::min(est_n, len / 36 + 1); est_ls = std::min(est_ls, len); est_nc = std::min(est_nc, len / 4 + 1);
-    }
-    BGP_TRY(c->d_sd_desc.reserve(n_chunks * 64 + 64));
-    if (!c->hints.empty()) {
-        std::vector<uint64_t> sh(n_chunks, ~0ull);
-        for (uint64_t h : c->hints) if (h < len) { uint64_t& e = sh[h / SD_C]; if (h < e) e = h; }
-        BGP_TRY(c->d_seg_hint.reserve(n_chunks * 8));
-        BGP_HIP(hipMemcpyAsync(c->d_seg_hint.p, sh.data(), n_chunks * 8, hipMemcpyHostToDevice, c->stream));
-        BGP_HIP(hipStreamSynchronize(c->stream));
-    }
-    if (n_chunks > 0x7FFFFFFFull) return 1;
-    const unsigned grid = (unsigned)n_chunks;
-    auto cap_of = [](const DevBuf& b, size_t unit, size_t slack) -> uint64_t { return b.cap > slack * unit ? b.cap / unit - slack : 0; };
-    for (int attempt = 0; attempt < 3; ++attempt) {
-        // what is already allocated counts (a ctx that decodes stream after stream of the same kind never allocates again)
-        uint64_t cap_n = std::max(est_n, std::min(std::min(cap_of(c->d_rec, sizeof(bgp_record), 1), cap_of(c->d_seq_off, 8, 1)), std::min(cap_of(c->d_cigar_off, 8, 1), cap_of(c->d_cig4, 16, 1))));
-        uint64_t cap_ls = est_ls, cap_nc = est_nc;
-        if (S || Q) cap_ls = std::max<uint64_t>(cap_ls, std::min<uint64_t>(S ? cap_of(c->d_seq, 1, 16) : ~0ull, Q ? cap_of(c->d_qual, 1, 16) : ~0ull));
-        if (C) cap_nc = std::max(cap_nc, cap_of(c->d_cigar, 4, 4));
-        BGP_TRY(c->d_rec.reserve((cap_n + 1) * sizeof(bgp_record)));
-        BGP_TRY(c->d_seq_off.reserve((cap_n + 1) * 8)); BGP_TRY(c->d_cigar_off.reserve((cap_n + 1) * 8)); BGP_TRY(c->d_cig4.reserve((cap_n + 1) * 16));
-        if (S) BGP_TRY(c->d_seq.reserve(cap_ls + 16));
-        if (Q) BGP_TRY(c->d_qual.reserve(cap_ls + 16));
-        if (C) BGP_TRY(c->d_cigar.reserve(cap_nc * 4 + 16));
-        const uint64_t nt = (cap_n + K3_TILE_RECORDS - 1) / K3_TILE_RECORDS;
-        BGP_TRY(c->d_tilemax.reserve((nt + 2) * 16));
-        SdArgs a;
-        a.s = c->d_stream; a.len = len; a.n_chunks = n_chunks; a.ref_bound = c->n_ref_hint > 0 ? c->n_ref_hint : (1 << 24); a.tolerant = c->frame_tolerant_tail ? 1 : 0;
-        a.hint = c->hints.empty() ? nullptr : c->d_seg_hint.as<uint64_t>();
-        a.desc = c->d_sd_desc.as<u64>() + 8; a.ctl = c->d_sd_desc.as<u64>();              // the first 64 bytes: ticket, flags, totals
-        a.status = c->d_status.as<uint32_t>();
-        a.rec = c->d_rec.as<bgp_record>(); a.seq_off = c->d_seq_off.as<uint64_t>(); a.cig_off = c->d_cigar_off.as<uint64_t>(); a.cig4 = c->d_cig4.as<uint4>();
-        a.tilemax = (unsigned long long*)c->d_tilemax.p;
-        a.seq = c->d_seq.as<uint8_t>(); a.qual = c->d_qual.as<uint8_t>(); a.cigar = c->d_cigar.as<uint32_t>();
-        a.cap_n = cap_n; a.cap_ls = (S || Q) ? cap_ls : ~0ull; a.cap_nc = C ? cap_nc : ~0ull;
-        u64 ctl[8]; uint32_t bits = 0;
-        {
-            TimedRegion tr(c, all ? "k012_stream" : "k01_stream", 0);
-            BGP_HIP(hipMemsetAsync(c->d_sd_desc.p, 0, n_chunks * 64 + 64, c->stream));
-            BGP_HIP(hipMemsetAsync(c->d_tilemax.p, 0, (nt + 2) * 16, c->stream));
-            if (attempt) BGP_HIP(hipMemsetAsync(c->d_status.p, 0, 64, c->stream));
-            if (all) hipLaunchKernelGGL((k_stream_decode<true, true, true>), dim3(grid), dim3(SD_T), L_TOTAL, c->stream, a);
-            else hipLaunchKernelGGL((k_stream_decode<false, false, false>), dim3(grid), dim3(SD_T), L_TOTAL, c->stream, a);
-            if (c->timing && tr.idx >= 0) c->sd_timer_idx = tr.idx;
-        }
-        BGP_HIP(hipGetLastError());
-#ifdef BGP_SD_PROF
-        {
-            unsigned long long pr[16];
-            BGP_HIP(hipStreamSynchronize(c->stream));
-            BGP_HIP(hipMemcpyFromSymbol(pr, HIP_SYMBOL(g_sd_prof), sizeof pr));
-            fprintf(stderr, "[sd_prof] per chunk: load %.0f guess %.0f chase %.0f lookback %.0f rechase %.0f rows %.0f arenas %.0f | wave 0: guess %.0f chase %.0f validate %.0f (s_memtime ticks, %llu chunks) | polls %.2f restarts %.4f extra windows %.3f wrong guesses %.5f guess steps %.2f\n", (double)pr[0] * 64 / n_chunks, (double)pr[1] * 64 / n_chunks, (double)pr[2] * 64 / n_chunks,
-                    (double)pr[3] * 64 / n_chunks, (double)pr[4] * 64 / n_chunks, (double)pr[5] * 64 / n_chunks, (double)pr[6] * 64 / n_chunks, (double)pr[7] * 64 / n_chunks, (double)pr[8] * 64 / n_chunks, (double)pr[9] * 64 / n_chunks, (unsigned long long)n_chunks,
-                    (double)pr[8] / n_chunks, (double)pr[9] / n_chunks, (double)pr[10] / n_chunks, (double)pr[11] / n_chunks, (double)pr[12] / n_chunks);
-            {
-                unsigned long long dbg[256];
-                BGP_HIP(hipMemcpyFromSymbol(dbg, HIP_SYMBOL(g_sd_dbg), sizeof dbg));
-                for (unsigned i = 0; i < 8 && i < pr[11]; ++i) fprintf(stderr, "[sd_dbg] chunk %llu (base %llu) guess %lld true entry %lld sub1 guess %lld\n", dbg[4 * i], dbg[4 * i] * SD_C, (long long)(dbg[4 * i + 1] - dbg[4 * i] * SD_C), (long long)(dbg[4 * i + 2] - dbg[4 * i] * SD_C), (long long)(dbg[4 * i + 3] - dbg[4 * i] * SD_C));
-            }
-            unsigned long long z[16] = {0};
-            BGP_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_sd_prof), z, sizeof z));
-        }
-#endif
-        BGP_HIP(hipMemcpyAsync(ctl, c->d_sd_desc.p, 64, hipMemcpyDeviceToHost, c->stream));
-        BGP_HIP(hipMemcpyAsync(&bits, a.status, 4, hipMemcpyDeviceToHost, c->stream));
-        BGP_HIP(hipStreamSynchronize(c->stream));
-        if (ctl[1]) { c->last_error = "single-pass decode: a chunk's look-back did not resolve"; return 1; }
-        const int st = bgp_status_from_bits(bits);
-        if (st < 0 && st != BGP_ESEQ) return st;
-        const uint64_t n = ctl[3], sl = ctl[4], sc = ctl[5];
-        if (ctl[2]) {                        // the estimate was short: again, with what the pass counted
-            if (attempt == 2) { c->last_error = "single-pass decode: products did not fit twice"; return BGP_EDEVICE; }
-            est_n = n; est_ls = sl; est_nc = sc;
-            continue;
-        }
-        c->n_records = n; c->sum_lseq = sl; c->sum_ncig = sc;
-        c->frame_tail = c->frame_tolerant_tail ? std::min<uint64_t>(ctl[6] & G_VAL, len) : len;
-        c->long_cigar = (bits & ST_LONGCIG) != 0;
-        c->cig4_ok = true; c->tilemax_ok = !c->long_cigar;
-        if (all) c->decoded_what |= BGP_FETCH_ALL;
-        if (c->timing && c->sd_timer_idx >= 0) c->timers[c->sd_timer_idx].algorithmic_bytes += len + n * 32 + (all ? 2 * sl + 4 * sc : 0);   // the record in, row + seq + qual + cigar out
-        BGP_TRY(k1_finish_long_cigars(c));
-        if (what && !all) BGP_TRY(k2_decode(c, what));
-        return BGP_OK;
-    }
-    return BGP_EDEVICE;
-}
+#include "decode_onepass_host.inc"
 #endif
 
 // K1 + K2 through LDS windows (k12_lds): when K0 framed the stream in SD_C-byte segments and every section is wanted
@@ -1392,16 +861,6 @@ int k12_lds_decode(bgp_ctx* c, uint32_t what) {
         BGP_TRY(k1_finish_long_cigars(c));
     }
     BGP_HIP(hipGetLastError());
-#ifdef BGP_SD_PROF
-    {
-        unsigned long long pr[16];
-        BGP_HIP(hipStreamSynchronize(c->stream));
-        BGP_HIP(hipMemcpyFromSymbol(pr, HIP_SYMBOL(g_sd_prof), sizeof pr));
-        fprintf(stderr, "[k12_lds prof] per segment: load %.0f rows %.0f arenas %.0f (s_memtime ticks, %llu segments)\n", (double)pr[0] * 64 / c->n_seg, (double)pr[5] * 64 / c->n_seg, (double)pr[6] * 64 / c->n_seg, (unsigned long long)c->n_seg);
-        unsigned long long z[16] = {0};
-        BGP_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_sd_prof), z, sizeof z));
-    }
-#endif
     (void)what;
     return BGP_OK;
 }
