@@ -1,11 +1,11 @@
 #!/bin/bash
 # Regenerates everything under profiles/ that bench.py and DESIGN.md quote (run on the GPU box through gpurun):
-#   usage: scratch/refresh_profiles.sh r03
+#   usage: scratch/refresh_profiles.sh r04
 #   bench lines for cfg3 (with cpu_baseline and parity_interior), cfg2, cfg5; rocprofv3 --kernel-trace --stats of the cfg3 and cfg5
 #   bench commands; the PMC passes (FETCH_SIZE, WRITE_SIZE -- separately, as MI355X_MICROARCH.md prescribes) folded into one CSV per
 #   configuration whose header carries the read count and the hash of the kernel sources (bench.py quotes the traffic only while both
 #   match); SQ counters per kernel of the cfg3 step; device-E2E through batched staging; file-E2E.
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/refresh
 rm -rf $OUT; mkdir -p $OUT
@@ -13,7 +13,7 @@ export TMPDIR=/tmp
 pmc() {   # config reads
   cd /tmp
   for C in FETCH_SIZE WRITE_SIZE; do
-    timeout 600 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/$1_$C -- python $R/bench.py --config $1 --steps 1 --warmup 0 --no-cpu-baseline --no-checks > $OUT/$1_$C.log 2>&1
+    timeout 600 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/$1_$C -- python $R/bench.py --config $1 --steps 1 --warmup 0 --no-cpu-baseline --no-checks --no-md > $OUT/$1_$C.log 2>&1
   done
   cd $R
   CFG=$1 READS=$2 TAG=$TAG python - <<'PY'
@@ -55,13 +55,15 @@ cd $R
 timeout 900 python bench.py --steps 20 --warmup 5 > $OUT/${TAG}_bench_cfg3_100M.json 2> $OUT/bench_cfg3.err
 timeout 600 python bench.py --steps 10 --warmup 3 --config cfg2 > $OUT/${TAG}_bench_cfg2_10M.json 2> $OUT/bench_cfg2.err
 timeout 600 python bench.py --steps 10 --warmup 3 --config cfg5 > $OUT/${TAG}_bench_cfg5_200k.json 2> $OUT/bench_cfg5.err
-BGP_BENCH_FORCE_COMM=1 timeout 600 python bench.py --steps 5 --warmup 2 --no-cpu-baseline 2> $OUT/bench_comm.err | grep "^{" | tail -1 > $OUT/${TAG}_bench_cfg3_100M_one_rank_communicator.json
+BGP_BENCH_FORCE_COMM=1 timeout 600 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --parity 2> $OUT/bench_comm.err | grep "^{" | tail -1 > $OUT/${TAG}_bench_cfg3_100M_one_rank_communicator.json
 cd /tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/${TAG}_bench_under_rocprofv3_cfg3_100M.json 2> $OUT/stats.err
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-md > $OUT/${TAG}_bench_under_rocprofv3_cfg3_100M.json 2> $OUT/stats.err
 find $OUT/stats -name "*kernel_stats.csv" -exec cp {} $OUT/${TAG}_rocprofv3_kernel_stats_cfg3_100M.csv \;
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats5 -- python $R/bench.py --steps 3 --warmup 1 --config cfg5 --no-cpu-baseline > /dev/null 2> $OUT/stats5.err
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats5 -- python $R/bench.py --steps 3 --warmup 1 --config cfg5 --no-cpu-baseline --no-md > /dev/null 2> $OUT/stats5.err
 find $OUT/stats5 -name "*kernel_stats.csv" -exec cp {} $OUT/${TAG}_rocprofv3_kernel_stats_cfg5_200k.csv \;
-rm -rf $OUT/stats $OUT/stats5
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/statsmd -- python $R/scratch/md_scale.py cfg3 100000000 > $OUT/${TAG}_md_path_cfg3_100M.log 2> $OUT/statsmd.err
+find $OUT/statsmd -name "*kernel_stats.csv" -exec cp {} $OUT/${TAG}_rocprofv3_md_path_cfg3_100M.csv \;
+rm -rf $OUT/stats $OUT/stats5 $OUT/statsmd
 cd $R
 scratch/sq_pmc_k4.sh refresh_sq > /dev/null 2>&1; cp $R/gpurun_out/pmc_refresh_sq/summary.csv $OUT/${TAG}_pmc_sq_per_kernel_cfg3_100M.csv
 timeout 600 python scratch/e2e_batched.py 10000000 2>&1 | grep -v amdgpu.ids > $OUT/${TAG}_device_e2e_batched_10M.log
