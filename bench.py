@@ -195,6 +195,35 @@ def md_leg(ctx, cfg, cfg_name, info, n_reads, reps=3):
     return out
 
 
+def entries_leg(ctx, cfg_name, n_reads, sum_lseq, sum_ncig, want_positions=4_000_000):
+    """K5, the rest of a PileupColumn (column.reads: PileupRead's cursor per read and column, pileup.d:86-230,267-274): windows WITH
+    entries over the first `want_positions` positions of the resident result, K5's kernels timed by their HIP events.  Algorithmic bytes:
+    16 per entry written, plus what the reads that make them are (row, CIGAR, packed SEQ, QUAL: the stream-wide average per read times the
+    reads a position's share of the stream amounts to).  The windows' copy to the host is in the wall time only."""
+    import ctypes as C
+    from biod_amd import _lib as L
+    ctx.timing_enable(True); ctx.timing_reset()
+    win = 1 << 20 if cfg_name != "cfg5" else 1 << 16
+    L.check(L.lib().bgp_pileup_begin(ctx.handle, L.BGP_PILEUP_COLUMNS, 0, 0, (1 << 64) - 1, 1, 1, win), ctx.handle)
+    t0 = time.perf_counter(); n_pos = 0; n_ent = 0
+    cw = L.Columns()
+    while n_pos < want_positions:
+        rc = L.check(L.lib().bgp_pileup_next_window(ctx.handle, C.byref(cw)), ctx.handle)
+        if rc == L.BGP_EOF:
+            break
+        n_pos += cw.n_positions
+        n_ent += C.cast(cw.entry_off, C.POINTER(C.c_uint64))[cw.n_positions]
+    wall = (time.perf_counter() - t0) * 1e3
+    tm = {k: v["total_ms"] for k, v in ctx.timing_get().items() if k.startswith("k5") and v["launches"]}
+    ctx.timing_enable(False)
+    k5_ms = sum(tm.values())
+    info_pos = ctx.pileup_info().n_positions if hasattr(ctx, "pileup_info") else None
+    per_read = 32 + (4 * sum_ncig + (sum_lseq + 1) // 2 + sum_lseq) / max(n_reads, 1)
+    return {"what": "per-read entries (column.reads) of the first windows of the piled-up BAM: K5 = " + " + ".join(sorted(tm)), "positions": n_pos, "entries": int(n_ent),
+            "k5_ms": round(k5_ms, 3), "kernels_ms": {k: round(v, 3) for k, v in tm.items()}, "G_entries_per_s_kernel": round(n_ent / (k5_ms * 1e-3) / 1e9, 2) if k5_ms else None,
+            "wall_ms_with_host_copies": round(wall, 1), "bytes_per_read": round(per_read, 1), "_n_pos_total": info_pos}
+
+
 from biod_amd.checks import DevArray as _DevArray, full_size_invariants      # device-side identities of the result (no oracle)
 
 
@@ -407,6 +436,13 @@ def main():
             out["parity_interior"] = parity
         if world == 1 and not a.no_md:
             out["md_path"] = md_leg(ctx, cfg, a.config, info, n_reads)
+            e = entries_leg(ctx, a.config, n_reads, sum_lseq, sum_ncig)
+            e.pop("_n_pos_total", None)
+            reads_share = n_reads * e["positions"] / max(int(info.n_positions), 1)          # the reads a stretch of that many positions holds, on average
+            e["algorithmic_bytes"] = int(16 * e["entries"] + reads_share * e.pop("bytes_per_read"))
+            e["algorithmic_GBps"] = round(e["algorithmic_bytes"] / (e["k5_ms"] * 1e-3) / 1e9, 1) if e["k5_ms"] else None
+            e["frac"] = round(e["algorithmic_GBps"] / HBM_PEAK_GBPS, 4) if e["k5_ms"] else None
+            out["entries_path"] = e
         if not a.no_cpu_baseline:                                       # (rank 0's host cores, whatever the number of ranks)
             out["cpu_baseline"] = cpu_baseline(a.config, a.cpu_sample_reads)
             out["speedup_vs_cpu_baseline"] = round(out["value"] / out["cpu_baseline"]["value"], 1)

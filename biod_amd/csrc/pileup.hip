@@ -1803,6 +1803,42 @@ __device__ __forceinline__ bgp_entry entry_of_ops(const uint8_t* s, const bgp_re
     return e;
 }
 
+// entry_of_ops in two halves, so that the two bytes an entry loads -- its base and its quality -- can be asked for for several columns
+// before the first is needed: where the cursor stands (no loads), then the entry from the bytes
+struct EntryAt { uint32_t op_index, op_offset, query_offset; bool hit, hit_qc; };
+__device__ __forceinline__ EntryAt entry_locate_ops(const bgp_record& r, const uint32_t (&ops)[4], uint32_t rr) {
+    const uint32_t n_cig = r.flag_nc & 0xFFFFu;
+    EntryAt e{0xFFFFu, 0u, 0u, false, false};
+    uint32_t cs = 0, qs = 0; bool started = false;
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k) {
+        if (k >= n_cig || e.hit) continue;
+        const uint32_t op = ops[k], len = op >> 4, qc = cig_qc(op), rc = cig_rc(op);
+        if (!started) {
+            if (rc) { if ((op & 15u) != 3u) started = true; else continue; }
+            else { if (qc) qs += len; continue; }
+        }
+        if (!rc) { if (qc) qs += len; continue; }
+        const uint32_t elen = len ? len : 1u;
+        if (rr < cs + elen) { e.op_index = k; e.op_offset = rr - cs; e.query_offset = qs + (qc ? rr - cs : 0u); e.hit = true; e.hit_qc = qc != 0; }
+        else { cs += elen; if (qc) qs += elen; }
+    }
+    return e;
+}
+__device__ __forceinline__ bgp_entry entry_finish(const EntryAt& at, uint32_t seq_byte, uint32_t qual_byte, bool in_seq, uint32_t ordinal) {
+    bgp_entry e; e.read_ordinal = ordinal; e.cigar_op_offset = at.op_offset; e.query_offset = at.query_offset; e.cigar_op_index = (uint16_t)at.op_index; e.base = 0xFF; e.qual = 0xFF;
+    if (!at.hit) { e.cigar_op_offset = 0; e.query_offset = 0; }
+    else if (at.hit_qc) {
+        if (in_seq) {
+            const uint32_t code = (at.query_offset & 1u) ? (seq_byte & 0xFu) : (seq_byte >> 4);
+            const uint64_t lo = 0x565352474D43413Dull, hi = 0x4E42444B48595754ull;   // "=ACMGRSVTWYHKDBN", base.d:85
+            e.base = (uint8_t)(((code & 8u) ? hi : lo) >> ((code & 7u) * 8));
+            e.qual = (uint8_t)qual_byte;
+        }
+    } else { e.base = '-'; e.qual = 255; }                                         // pileup.d:119-121,131-133
+    return e;
+}
+
 // One wave per 64 consecutive COLUMNS, lane = column: the candidate rows of the block are scanned once (64 rows a step,
 // coalesced), every row that touches the block is handed to all lanes in file order, and a lane whose column the read
 // covers appends the read's entry to its own column -- a counter a lane, no ranks, no ballots per entry.  (With a wave per
@@ -1825,71 +1861,174 @@ __global__ __launch_bounds__(256) void k5_fill_blk(K5Args a) {
     const uint64_t i_lo = lower_bound_gt(a.pmax_end, a.run.first_record, a.run.end_record, rk | (uint32_t)p0);          // first record whose running maximum of end_position exceeds p0
     const uint64_t i_hi = lower_bound_gt(a.pmax_pos, a.run.first_record, a.run.end_record, rk | (uint32_t)(p1 - 1));    // first record that starts behind the block
     uint64_t w = valid ? a.col_off[col0 + lane] : 0;
-    // A column's entries leave K5R at a time, from a ring in LDS (slot s of lane l at [s][l]: conflict free): one 16-byte
-    // store per entry and lane lands in 64 different lines whose other seven entries arrive microseconds later, long after
-    // the L2 has given the line up -- the partial-sector writes k0_chase had.
+    // Two ways to the same entries, by the read.  An ordinary read (up to four CIGAR ops, which came with its row: K1's side array) is
+    // listed in LDS; when 64 are listed -- or a read of the other kind comes up, or the rows run out -- a LANE takes a listed READ and the
+    // wave goes through the block's columns: the lanes whose reads cover the column work out their entries, and since lanes are in file
+    // order the entries of a column leave as one run of consecutive 16-byte stores (a counter a column, kept by the column's lane).
+    // Round 2 and 3 handed every read to all lanes (lane = column) and wrote each column's entries eight at a time from a ring in LDS:
+    // 64 different lines per store instruction, 2.24 ms for 2.1 * 10^8 entries of cfg3.  That way is kept for the reads that need a
+    // CIGAR walk (long reads: the cursor at the block's first column is found ONCE for the 64 lanes, 64 ops a step from the window's
+    // checkpoint); the ring is flushed where the two ways alternate, so a column's entries stay in file order.
     __shared__ uint4 s_ring[4][K5R][64];
+    __shared__ uint4 s_list[4][3][64];                 // the listed reads: row (two 16-byte halves) and first four CIGAR ops, a read a lane
     uint4 (*ring)[64] = s_ring[threadIdx.x >> 6];
-    uint32_t cnt = 0;
+    uint4 (*list)[64] = s_list[threadIdx.x >> 6];
+    uint32_t cnt = 0, n_list = 0;
+    auto flush_ring = [&]() {
+        for (uint32_t k = 0; k < (cnt & (K5R - 1)); ++k) { const uint4 x = ring[k][lane]; __builtin_memcpy(a.entries + w + k, &x, 16); }
+        w += cnt & (K5R - 1); cnt = 0;
+    };
+    auto flush_list = [&]() {
+        if (!n_list) return;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const bool have = (uint32_t)lane < n_list;
+        bgp_record q{}; uint32_t ops[4] = {0, 0, 0, 0}; uint32_t ord = 0;
+        if (have) {
+            const uint4 x = list[0][lane], y = list[1][lane], z = list[2][lane];
+            q.ref_id = (int32_t)x.x; q.pos = (int32_t)x.y; q.end_pos = (int32_t)x.z; q.bin_mq_nl = x.w;
+            q.flag_nc = y.x & 0xFFFFFFFFu; q.l_seq = (int32_t)y.y; q.rec_off = ((uint64_t)y.w << 32) | y.z;
+            ops[0] = z.x; ops[1] = z.y; ops[2] = z.z; ord = z.w;      // (a listed read has at most three ops: the slot's fourth word is its ordinal)
+        }
+        const uint32_t jn = (uint32_t)(p1 - p0);
+        const uint8_t* const sq = a.s + q.rec_off + 36 + (q.bin_mq_nl & 0xFFu) + 4ull * (q.flag_nc & 0xFFFFu);
+        const uint8_t* const ql = sq + (uint32_t)((q.l_seq + 1) / 2);
+        const uint32_t n_cig = q.flag_nc & 0xFFFFu;
+        // the read's columns of the block, and its cursor at the first of them (pileup.d:175-192 in closed form); from there the cursor
+        // is STEPPED column by column as incrementPosition does (pileup.d:195-222) -- a handful of instructions where locating it anew
+        // for every column was sixty
+        const uint32_t c_lo = have ? (uint32_t)(max(p0, (uint64_t)(uint32_t)q.pos) - p0) : 64u, c_hi = have ? (uint32_t)(min(p1, (uint64_t)(uint32_t)q.end_pos) - p0) : 0u;
+        const EntryAt at0 = entry_locate_ops(q, ops, have && c_lo < c_hi ? (uint32_t)(p0 + c_lo - (uint32_t)q.pos) : 0u);
+        uint32_t ck = at0.op_index, coff = at0.op_offset;
+        bool cqc = at0.hit_qc, chit = at0.hit;
+        uint32_t cqb = at0.query_offset - (at0.hit_qc ? at0.op_offset : 0u);      // query bases in front of the op
+        uint32_t clen = 1;
+        { const uint32_t opk = ck == 0 ? ops[0] : ck == 1 ? ops[1] : ck == 2 ? ops[2] : 0u; const uint32_t l = opk >> 4; clen = l ? l : 1u; }
+        for (uint32_t j = 0; j < jn; ++j) {
+            const bool cov = j >= c_lo && j < c_hi;
+            const unsigned long long m = __ballot(cov);
+            if (!m) continue;
+            const uint64_t wj = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(w >> 32), (int)j) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)w, (int)j);
+            if (cov) {
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                EntryAt at{ck, coff, cqb + (cqc ? coff : 0u), chit, cqc};
+                const bool ins = chit && cqc && at.query_offset < (uint32_t)q.l_seq;
+                uint32_t sb = 0, qb = 0;
+                if (ins) { sb = sq[at.query_offset >> 1]; qb = ql[at.query_offset]; }
+                const bgp_entry e = entry_finish(at, sb, qb, ins, ord);
+                uint4 v; __builtin_memcpy(&v, &e, 16);
+                __builtin_memcpy(a.entries + wj + rank, &v, 16);
+                // incrementPosition: one column on; at the op's end on to the next op that consumes reference, the query bases of
+                // what is stepped over (I, S) added
+                if (chit && ++coff >= clen) {
+                    cqb += cqc ? clen : 0u;
+                    chit = false;
+#pragma unroll
+                    for (uint32_t kk = 1; kk < 3; ++kk) {
+                        if (chit || kk <= ck || kk >= n_cig) continue;
+                        const uint32_t op = ops[kk], len = op >> 4;
+                        if (!cig_rc(op)) { if (cig_qc(op)) cqb += len; continue; }
+                        ck = kk; coff = 0; clen = len ? len : 1u; cqc = cig_qc(op) != 0; chit = true;
+                    }
+                    if (!chit) { ck = 0xFFFFu; coff = 0; }      // the cursor ran off the CIGAR (pileup.d:224-228): entry_of_ops' "no hit"
+                }
+            }
+            if ((uint32_t)lane == j) w += (uint64_t)__popcll(m);
+        }
+        n_list = 0;
+        __builtin_amdgcn_wave_barrier();
+    };
     for (uint64_t base = i_lo; base < i_hi; base += 64) {
         const uint64_t i = base + lane;
         bgp_record r{};
         bool hit = false;
         uint4 c4 = make_uint4(0, 0, 0, 0);
         if (i < i_hi) { r = a.rec[i]; hit = r.end_pos != r.pos && (uint64_t)(uint32_t)r.pos < p1 && (uint64_t)(uint32_t)r.end_pos > p0; if (hit && a.cig4) c4 = a.cig4[i]; }
-        for (unsigned long long m = __ballot(hit); m; m &= m - 1) {
-            const int src = __ffsll((long long)m) - 1;
-            bgp_record q;                                                           // the read, the same in every lane (scalar registers)
-            q.ref_id = __builtin_amdgcn_readlane(r.ref_id, src); q.pos = __builtin_amdgcn_readlane(r.pos, src); q.end_pos = __builtin_amdgcn_readlane(r.end_pos, src);
-            q.bin_mq_nl = (uint32_t)__builtin_amdgcn_readlane((int)r.bin_mq_nl, src); q.flag_nc = (uint32_t)__builtin_amdgcn_readlane((int)r.flag_nc, src);
-            q.l_seq = __builtin_amdgcn_readlane(r.l_seq, src);
-            q.rec_off = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(r.rec_off >> 32), src) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)r.rec_off, src);
-            const bool small = a.cig4 && (q.flag_nc & 0xFFFFu) <= 4u;           // its ops came with the row (K1's side array): no CIGAR load per entry
-            const uint32_t ops[4] = {(uint32_t)__builtin_amdgcn_readlane((int)c4.x, src), (uint32_t)__builtin_amdgcn_readlane((int)c4.y, src), (uint32_t)__builtin_amdgcn_readlane((int)c4.z, src), (uint32_t)__builtin_amdgcn_readlane((int)c4.w, src)};
-            // any other read: the cursor at the block's first column of the read, found ONCE for the 64 lanes (for a long read from
-            // the window's checkpoint: every lane walking there by itself was ~35 dependent CIGAR loads per entry on cfg5)
-            uint32_t bk = 0, bcs = 0, bqs = 0; bool bst = false;
-            if (!small) {
-                const uint32_t rr0 = (uint32_t)(max(p0, (uint64_t)(uint32_t)q.pos) - (uint32_t)q.pos);
-                entry_cursor(q, rr0, (uint32_t)(base + (uint64_t)src), a, &bk, &bcs, &bqs, &bst);
-                if (bst) {
-                    const uint32_t n_cig = q.flag_nc & 0xFFFFu;
-                    const uint8_t* cg = a.s + q.rec_off + 36 + (q.bin_mq_nl & 0xFFu);
-                    while (bk < n_cig) {                                      // 64 ops a step, lane = op: the first column-owning op that reaches past rr0
-                        const uint32_t kk = bk + (uint32_t)lane;
-                        const uint32_t op = kk < n_cig ? ld_u32(cg + 4ull * kk) : 0u;
-                        const bool on = kk < n_cig, qc = on && cig_qc(op), rc = on && cig_rc(op);
-                        const uint32_t len = op >> 4, elen = len ? len : 1u;
-                        const uint32_t cl = rc ? elen : 0u, ql = qc ? (rc ? elen : len) : 0u;
-                        const uint32_t ic = wave_incl_u32(cl, lane), iq = wave_incl_u32(ql, lane);
-                        const unsigned long long hm = __ballot(rc && rr0 < bcs + ic);
-                        if (hm) {
-                            const int L = __ffsll((long long)hm) - 1;
-                            bcs += (uint32_t)__builtin_amdgcn_readlane((int)(ic - cl), L); bqs += (uint32_t)__builtin_amdgcn_readlane((int)(iq - ql), L);
-                            bk += (uint32_t)L;
-                            break;
+        const bool small_r = hit && a.cig4 && (r.flag_nc & 0xFFFFu) <= 3u;      // (three ops: the list's third slot carries them and the read's ordinal)
+        unsigned long long mh = __ballot(hit);
+        const unsigned long long ms = __ballot(small_r);
+        while (mh) {
+            // the run of listable reads in front of the next read of the other kind (all of them, if there is none)
+            const unsigned long long big = mh & ~ms;
+            const int stop = big ? __ffsll((long long)big) - 1 : 64;
+            const unsigned long long runm = stop >= 64 ? mh : (mh & ((1ull << stop) - 1));
+            if (runm) {
+                if (cnt & (K5R - 1)) flush_ring(); else cnt = 0;
+                unsigned long long todo = runm;
+                while (todo) {
+                    const uint32_t room = 64u - n_list, have_n = (uint32_t)__popcll(todo);
+                    // the first `room` of them
+                    unsigned long long take = todo;
+                    if (have_n > room) { unsigned long long t2 = todo; for (uint32_t k = 0; k < room; ++k) t2 &= t2 - 1; take = todo & ~t2; }
+                    if ((take >> lane) & 1ull) {
+                        const uint32_t slot = n_list + (uint32_t)__popcll(take & ((1ull << lane) - 1));
+                        list[0][slot] = make_uint4((uint32_t)r.ref_id, (uint32_t)r.pos, (uint32_t)r.end_pos, r.bin_mq_nl);
+                        list[1][slot] = make_uint4(r.flag_nc, (uint32_t)r.l_seq, (uint32_t)r.rec_off, (uint32_t)(r.rec_off >> 32));
+                        list[2][slot] = make_uint4(c4.x, c4.y, c4.z, (uint32_t)i);
+                    }
+                    n_list += (uint32_t)__popcll(take);
+                    todo &= ~take;
+                    if (n_list == 64u) flush_list();
+                }
+                mh &= ~runm;
+            }
+            if (stop < 64) {
+                flush_list();
+                const int src = stop;
+                mh &= ~(1ull << src);
+                bgp_record q;                                                           // the read, the same in every lane (scalar registers)
+                q.ref_id = __builtin_amdgcn_readlane(r.ref_id, src); q.pos = __builtin_amdgcn_readlane(r.pos, src); q.end_pos = __builtin_amdgcn_readlane(r.end_pos, src);
+                q.bin_mq_nl = (uint32_t)__builtin_amdgcn_readlane((int)r.bin_mq_nl, src); q.flag_nc = (uint32_t)__builtin_amdgcn_readlane((int)r.flag_nc, src);
+                q.l_seq = __builtin_amdgcn_readlane(r.l_seq, src);
+                q.rec_off = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(r.rec_off >> 32), src) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)r.rec_off, src);
+                const bool small = a.cig4 && (q.flag_nc & 0xFFFFu) <= 4u;           // its ops came with the row (K1's side array): no CIGAR load per entry
+                const uint32_t ops[4] = {(uint32_t)__builtin_amdgcn_readlane((int)c4.x, src), (uint32_t)__builtin_amdgcn_readlane((int)c4.y, src), (uint32_t)__builtin_amdgcn_readlane((int)c4.z, src), (uint32_t)__builtin_amdgcn_readlane((int)c4.w, src)};
+                // any other read: the cursor at the block's first column of the read, found ONCE for the 64 lanes (for a long read from
+                // the window's checkpoint: every lane walking there by itself was ~35 dependent CIGAR loads per entry on cfg5)
+                uint32_t bk = 0, bcs = 0, bqs = 0; bool bst = false;
+                if (!small) {
+                    const uint32_t rr0 = (uint32_t)(max(p0, (uint64_t)(uint32_t)q.pos) - (uint32_t)q.pos);
+                    entry_cursor(q, rr0, (uint32_t)(base + (uint64_t)src), a, &bk, &bcs, &bqs, &bst);
+                    if (bst) {
+                        const uint32_t n_cig = q.flag_nc & 0xFFFFu;
+                        const uint8_t* cg = a.s + q.rec_off + 36 + (q.bin_mq_nl & 0xFFu);
+                        while (bk < n_cig) {                                      // 64 ops a step, lane = op: the first column-owning op that reaches past rr0
+                            const uint32_t kk = bk + (uint32_t)lane;
+                            const uint32_t op = kk < n_cig ? ld_u32(cg + 4ull * kk) : 0u;
+                            const bool on = kk < n_cig, qc = on && cig_qc(op), rc = on && cig_rc(op);
+                            const uint32_t len = op >> 4, elen = len ? len : 1u;
+                            const uint32_t cl = rc ? elen : 0u, ql = qc ? (rc ? elen : len) : 0u;
+                            const uint32_t ic = wave_incl_u32(cl, lane), iq = wave_incl_u32(ql, lane);
+                            const unsigned long long hm = __ballot(rc && rr0 < bcs + ic);
+                            if (hm) {
+                                const int L = __ffsll((long long)hm) - 1;
+                                bcs += (uint32_t)__builtin_amdgcn_readlane((int)(ic - cl), L); bqs += (uint32_t)__builtin_amdgcn_readlane((int)(iq - ql), L);
+                                bk += (uint32_t)L;
+                                break;
+                            }
+                            bcs += (uint32_t)__builtin_amdgcn_readlane((int)ic, 63); bqs += (uint32_t)__builtin_amdgcn_readlane((int)iq, 63);
+                            bk = min(bk + 64u, n_cig);
                         }
-                        bcs += (uint32_t)__builtin_amdgcn_readlane((int)ic, 63); bqs += (uint32_t)__builtin_amdgcn_readlane((int)iq, 63);
-                        bk = min(bk + 64u, n_cig);
                     }
                 }
-            }
-            if (valid && (uint64_t)(uint32_t)q.pos <= p && (uint64_t)(uint32_t)q.end_pos > p) {
-                bgp_entry e;
-                if (small) e = entry_of_ops(a.s, q, ops, (uint32_t)(p - (uint32_t)q.pos), (uint32_t)(base + (uint64_t)src));
-                else e = entry_walk(a.s, q, bk, bcs, bqs, bst, (uint32_t)(p - (uint32_t)q.pos), (uint32_t)(base + (uint64_t)src));
-                uint4 v; __builtin_memcpy(&v, &e, 16);
-                ring[cnt & (K5R - 1)][lane] = v;
-                ++cnt;
-                if ((cnt & (K5R - 1)) == 0) {
+                if (valid && (uint64_t)(uint32_t)q.pos <= p && (uint64_t)(uint32_t)q.end_pos > p) {
+                    bgp_entry e;
+                    if (small) e = entry_of_ops(a.s, q, ops, (uint32_t)(p - (uint32_t)q.pos), (uint32_t)(base + (uint64_t)src));
+                    else e = entry_walk(a.s, q, bk, bcs, bqs, bst, (uint32_t)(p - (uint32_t)q.pos), (uint32_t)(base + (uint64_t)src));
+                    uint4 v; __builtin_memcpy(&v, &e, 16);
+                    ring[cnt & (K5R - 1)][lane] = v;
+                    ++cnt;
+                    if ((cnt & (K5R - 1)) == 0) {
 #pragma unroll
-                    for (int k = 0; k < K5R; ++k) { const uint4 x = ring[k][lane]; __builtin_memcpy(a.entries + w + k, &x, 16); }
-                    w += K5R;
+                        for (int k = 0; k < K5R; ++k) { const uint4 x = ring[k][lane]; __builtin_memcpy(a.entries + w + k, &x, 16); }
+                        w += K5R;
+                    }
                 }
             }
         }
     }
-    for (uint32_t k = 0; k < (cnt & (K5R - 1)); ++k) { const uint4 x = ring[k][lane]; __builtin_memcpy(a.entries + w + k, &x, 16); }
+    flush_list();
+    flush_ring();
 }
 
 // one wave per column: stream-compact the overlapping reads in file order
@@ -2194,9 +2333,12 @@ int k5_entries(bgp_ctx* c, uint32_t run_idx, uint64_t pos_begin, uint64_t pos_en
     a.col_off = c->d_entry_off.as<uint64_t>(); a.entries = nullptr;
     a.ck_w = c->ck_w; a.ck = c->ck_w ? c->d_ck.as<Ckpt>() : nullptr; a.ck_off = c->ck_w ? c->d_ck_off.as<uint64_t>() : nullptr;
     a.cig4 = c->cig4_ok ? c->d_cig4.as<uint4>() : nullptr;
-    hipLaunchKernelGGL(k5_cov, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, c->stream, a);
     uint64_t total = 0;
-    BGP_TRY(scan_exclusive_u64(c, a.cov64, c->d_entry_off.as<uint64_t>(), np, &total));
+    {
+        TimedRegion t(c, "k5_cov", np * 40);           // a 32-byte column read and an 8-byte offset written per position, the scan on top
+        hipLaunchKernelGGL(k5_cov, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, c->stream, a);
+        BGP_TRY(scan_exclusive_u64(c, a.cov64, c->d_entry_off.as<uint64_t>(), np, &total));
+    }
     BGP_TRY(c->d_entries.reserve((total + 1) * sizeof(bgp_entry)));
     a.entries = c->d_entries.as<bgp_entry>();
     {
