@@ -1845,7 +1845,7 @@ __device__ __forceinline__ bgp_entry entry_finish(const EntryAt& at, uint32_t se
 // column every column scanned the whole candidate range for itself: ~1000 rows on cfg3, where a read with an N skip keeps
 // every later read a candidate -- 32 KB of rows for ~50 entries, 200 GB/s of entries.)
 #ifndef BGP_K5R
-#define BGP_K5R 8
+#define BGP_K5R 4
 #endif
 constexpr int K5R = BGP_K5R;            // entries of a column that leave together (a power of two)
 static_assert(sizeof(bgp_entry) == 16, "an entry is one 16-byte store");
