@@ -19,7 +19,7 @@ void bgp_note_hip_error(hipError_t e, const char* what, const char* file, int li
 
 // Decode implementations that were measured and lost are kept out of the product: they are compiled only with
 // `make EXPERIMENTS=1` (-DBGP_EXPERIMENTS), where environment switches select them and tests/test_gpu_single_pass.py runs them
-// (DESIGN.md section 4 has their measurements).  The product has ONE path per call: bgp_flush = K0 + k1_rows,
+// (LABNOTES.md has their measurements).  The product has ONE path per call: bgp_flush = K0 + k1_rows,
 // bgp_decode_* = k2_unpack, bgp_flush_decode(all sections) = K0 + k12_lds (k1_rows + k2_unpack when the records are too long
 // for its windows).
 #ifdef BGP_EXPERIMENTS

@@ -15,15 +15,16 @@
 //   * current_base = sequence[query_offset] for M/=/X, '-' otherwise (:115-122).
 // A column is the set of such reads, in file order (:351-359 stable compaction, :377-386 appends).
 //
-// MI355X design.  K4 is a histogram-shaped scatter (integer, HBM/LDS-bound, no MFMA): one workgroup
-// owns a window of W reference positions with its counters in LDS (A,C,G,T,other, a difference array
-// for '-', n_starting_here; coverage is their sum) and is handed the contiguous record range that can
-// touch the window (exact halo: first record whose running max end_position exceeds the window start
-// -- SURVEY.md 3.3 -- from two prefix-maximum arrays built by K3).  Three ways to walk a read, picked
-// per read: LANE = READ for ordinary short reads (64 reads per wave step the same query index; the
-// bulk of the work), LANE = OP for long reads (64 CIGAR ops per coalesced load, wave prefix scan,
-// resumed from per-window checkpoints), lanes along the read for the odd rest.  The window is
-// flushed once, 32 contiguous bytes per position, fully coalesced.  Details at each kernel.
+// MI355X design.  K4 is a histogram-shaped scatter (integer, HBM / LDS-bound, no MFMA).  The route nearly every window takes is
+// PLAN + ACCUMULATE (k4_plan / k4_acc2, further down): one pass over the reads turns every read into 8-byte descriptors in the
+// slabs of the 1024-position windows it touches, and a persistent workgroup per range of windows adds the described bases to
+// byte-wide counters in LDS -- a piece of a descriptor per lane, eight positions a step, the class of a base found for four bases
+// at once by v_perm_b32 -- and flushes 32 contiguous bytes a position.  Long reads are walked from per-window CIGAR checkpoints
+// (k4_ck_build) inside the same kernel.  What the plan does not take (odd CIGARs, windows too deep) goes to the GENERAL kernel
+// (k4_tile, round 1's K4): one workgroup owns a window with its counters in LDS and is handed the contiguous record range that
+// can touch it (exact halo: first record whose running max end_position exceeds the window start -- SURVEY.md 3.3 -- from two
+// prefix-maximum arrays built by K3), and walks a read one of three ways: LANE = READ for ordinary short reads, LANE = OP for long
+// reads (64 CIGAR ops per coalesced load, wave prefix scan, resumed from the checkpoints), lanes along the read for the odd rest.
 #include "common.h"
 
 #include <algorithm>
@@ -947,12 +948,13 @@ __global__ __launch_bounds__(256) void k4_stats(const unsigned long long* ts, ui
 //             DESCRIPTORS appended to the slabs of the windows it touches: one SEG per (M/=/X op, window) --
 //             where the bases are in the stream, where they land in the window -- and one DEL per (D/N op, edge
 //             window); windows an N/D op covers completely get +1 through a difference array over windows.  A long read
-//             whose CIGAR walk (k4_ck_build) found it well formed becomes ROW descriptors (its row of one class byte per
-//             column, written by k4_rows_build).  Any other read marks the windows it overlaps for the general kernel
+//             whose CIGAR walk (k4_ck_build) found it well formed marks the windows it touches (k4_acc2 walks its ops there,
+//             from the window's checkpoint).  Any other read marks the windows it overlaps for the general kernel
 //             (k4_tile above).
-//   k4_acc    (further down) walks the windows' slabs with lanes ALONG the reads and adds every base to a 16-bit counter
-//             in LDS.  Round 2's executor -- k4_exec: class bytes staged in LDS, then every POSITION gathering its bases
-//             out of them, 10.3 ms on cfg3 -- is gone; DESIGN.md section 4 keeps its measurements.
+//   k4_acc2   (further down) takes the windows' slabs a PIECE of a descriptor per lane and adds the bases to byte-wide
+//             counters in LDS, eight positions a step.  Its predecessors -- round 2's k4_exec (class bytes staged in LDS, every
+//             POSITION gathering its bases: 10.3 ms on cfg3) and round 3's k4_acc (lanes along the reads, an LDS atomic a base:
+//             8.6 ms) -- are gone; LABNOTES.md keeps their measurements.
 //
 // Descriptor (64 bits): [1:0] kind (0 none, 1 SEG, 2 DEL)
 //   SEG  [2] the read starts here (n_starting_here)  [13:3] first position in the window  [21:14] bases (1..255)

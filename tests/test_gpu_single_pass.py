@@ -1,6 +1,6 @@
 """bgp_flush_decode, and the ONE-PASS decode kernel behind BGP_FRAME_MODE=1 (k_stream_decode: framing by look-back over
 LDS windows, record table and arenas in the same pass).  The product path is K0 + k12_lds (K0 / k1_rows / k2_unpack for
-records too long for its windows); the one-pass kernel is an experiment that was measured and lost:
+records too long for its windows); the one-pass kernel is an experiment that was measured and lost (LABNOTES.md):
 it is compiled only by `make -C biod_amd/csrc EXPERIMENTS=1` into biod_amd/libbiodgpu_exp.so, and its half of these tests
 runs when that library is the one loaded (`BIODGPU_SO=biod_amd/libbiodgpu_exp.so pytest tests/test_gpu_single_pass.py -m gpu`).
 Both must give the oracle's bytes."""
