@@ -77,18 +77,19 @@ int bgp_status_from_bits(uint32_t bits) {
     return BGP_OK;
 }
 
-TimedRegion::TimedRegion(bgp_ctx* ctx, const char* name, uint64_t alg_bytes) : c(ctx) {
+TimedRegion::TimedRegion(bgp_ctx* ctx, const char* name, uint64_t alg_bytes, hipStream_t on) : c(ctx) {
+    st = on ? on : c->stream;
     if (!c->timing) return;
     for (size_t i = 0; i < c->timers.size(); ++i) if (c->timers[i].name == name) idx = (int)i;
     if (idx < 0) { c->timers.emplace_back(); c->timers.back().name = name; idx = (int)c->timers.size() - 1; }
     c->timers[idx].algorithmic_bytes += alg_bytes;
     c->timers[idx].launches += 1;
     if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { idx = -1; return; }
-    (void)hipEventRecord(a, c->stream);
+    (void)hipEventRecord(a, st);
 }
 TimedRegion::~TimedRegion() {
     if (!c->timing || idx < 0) return;
-    (void)hipEventRecord(b, c->stream);
+    (void)hipEventRecord(b, st);
     c->timers[idx].pending.emplace_back(a, b);
 }
 void bgp_timing_collect(bgp_ctx* c) {
@@ -126,13 +127,15 @@ int emit_window(bgp_ctx* c, uint32_t run_idx, uint64_t a, uint64_t b, int want_e
         c->pf.valid = false;
     } else {
         BGP_TRY(c->h_cols.reserve(np * sizeof(bgp_column)));
-        BGP_HIP(hipMemcpyAsync(c->h_cols.p, c->d_columns.as<bgp_column>() + r.column_base + (a - r.start_pos), np * sizeof(bgp_column), hipMemcpyDeviceToHost, c->stream));
+        { TimedRegion tw(c, "d2h_window_columns", np * sizeof(bgp_column));
+        BGP_HIP(hipMemcpyAsync(c->h_cols.p, c->d_columns.as<bgp_column>() + r.column_base + (a - r.start_pos), np * sizeof(bgp_column), hipMemcpyDeviceToHost, c->stream)); }
     }
     if (pf_on && b < r.end_pos) {                       // the window behind this one, as long as this one
         const uint64_t nb = std::min<uint64_t>(r.end_pos, b + np);
         if (!c->pf.stream) { BGP_HIP(hipStreamCreateWithFlags(&c->pf.stream, hipStreamNonBlocking)); BGP_HIP(hipEventCreateWithFlags(&c->pf.done, hipEventDisableTiming)); }
         BGP_TRY(c->h_cols2.reserve((nb - b) * sizeof(bgp_column)));
-        BGP_HIP(hipMemcpyAsync(c->h_cols2.p, c->d_columns.as<bgp_column>() + r.column_base + (b - r.start_pos), (nb - b) * sizeof(bgp_column), hipMemcpyDeviceToHost, c->pf.stream));
+        { TimedRegion tw(c, "d2h_window_columns", (nb - b) * sizeof(bgp_column), c->pf.stream);
+        BGP_HIP(hipMemcpyAsync(c->h_cols2.p, c->d_columns.as<bgp_column>() + r.column_base + (b - r.start_pos), (nb - b) * sizeof(bgp_column), hipMemcpyDeviceToHost, c->pf.stream)); }
         BGP_HIP(hipEventRecord(c->pf.done, c->pf.stream));
         c->pf.valid = true; c->pf.run = run_idx; c->pf.a = b; c->pf.b = nb;
     }
@@ -246,9 +249,9 @@ static void release_all(bgp_ctx* c) {
                    &c->d_seq, &c->d_qual, &c->d_cigar, &c->d_pmax_end, &c->d_pmax_pos, &c->d_runs, &c->d_columns, &c->d_depth_hist, &c->d_pstats,
                    &c->d_tiles, &c->d_ck_off, &c->d_ck, &c->d_deep, &c->d_wlong, &c->d_entry_off, &c->d_entries, &c->d_col_lo,
                    &c->d_md_row, &c->d_md_iv, &c->d_md_state, &c->d_refbase, &c->d_md_succ, &c->d_md_exit, &c->d_md_entry, &c->d_md_bmax, &c->d_md_long, &c->d_md_ck, &c->d_snp, &c->d_maq, &c->d_maq_tab, &c->d_rec2, &c->d_seq_off2, &c->d_cigar_off2,
-                   &c->d_seg_hint, &c->d_seg_sub, &c->d_tilemax, &c->d_cig4, &c->d_slab, &c->d_wcount, &c->d_wdel, &c->d_wslow, &c->d_flt[0], &c->d_flt[1], &c->d_flt[2], &c->d_flt[3], &c->d_flt[4], &c->d_flt[5], &c->d_comp, &c->d_inf_blk};
+                   &c->d_seg_hint, &c->d_seg_sub, &c->d_tilemax, &c->d_cig4, &c->d_slab, &c->d_wcount, &c->d_wdel, &c->d_wslow, &c->d_flt[0], &c->d_flt[1], &c->d_flt[2], &c->d_flt[3], &c->d_flt[4], &c->d_flt[5], &c->d_comp, &c->d_inf_blk, &c->d_batch[0], &c->d_batch[1]};
     for (auto* b : d) b->release();
-    HostBuf* h[] = {&c->h_stage, &c->h_rec, &c->h_seq_off, &c->h_cigar_off, &c->h_seq, &c->h_qual, &c->h_cigar, &c->h_cols, &c->h_entry_off, &c->h_entries, &c->h_refbase, &c->h_snp, &c->h_maq, &c->h_ring, &c->h_stream_copy, &c->h_mail, &c->h_cols2};
+    HostBuf* h[] = {&c->h_stage, &c->h_rec, &c->h_seq_off, &c->h_cigar_off, &c->h_seq, &c->h_qual, &c->h_cigar, &c->h_cols, &c->h_entry_off, &c->h_entries, &c->h_refbase, &c->h_snp, &c->h_maq, &c->h_ring, &c->h_stream_copy, &c->h_mail, &c->h_cols2, &c->h_batch[0], &c->h_batch[1]};
     for (auto* b : h) b->release();
 }
 

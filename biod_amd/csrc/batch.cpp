@@ -50,6 +50,9 @@ void batch_release(bgp_ctx* c) {
     for (int q = 0; q < 2; ++q) {
         if (b->host_free[q]) (void)hipEventDestroy(b->host_free[q]);
         if (b->loaded_ev[q]) (void)hipEventDestroy(b->loaded_ev[q]);
+        // (the two pinned buffers and the two device buffers go back to the ctx: the next bgp_batch_begin takes them again -- pinning
+        // 2 x 256 MiB anew cost ~70 ms, 40 % of a 10 M-read stream's whole pass)
+        std::swap(b->host[q], c->h_batch[q]); std::swap(b->dev[q], c->d_batch[q]);
         b->host[q].release(); b->dev[q].release();
     }
     delete b;
@@ -88,7 +91,8 @@ static int ship(bgp_ctx* c, Batch* b) {
     const int h = b->fill;
     BGP_TRY(b->dev[q].reserve(b->reserve + b->batch_bytes + 256));
     b->new_off[q] = b->reserve; b->new_len[q] = b->host_len[h];
-    if (b->host_len[h]) BGP_HIP(hipMemcpyAsync(b->dev[q].as<uint8_t>() + b->reserve, b->host[h].p, b->host_len[h], hipMemcpyHostToDevice, b->copy_stream));
+    if (b->host_len[h]) { TimedRegion th(c, "h2d_batch", b->host_len[h], b->copy_stream);
+        BGP_HIP(hipMemcpyAsync(b->dev[q].as<uint8_t>() + b->reserve, b->host[h].p, b->host_len[h], hipMemcpyHostToDevice, b->copy_stream)); }
     BGP_HIP(hipEventRecord(b->loaded_ev[q], b->copy_stream));
     BGP_HIP(hipEventRecord(b->host_free[h], b->copy_stream));
     b->state[q] = Batch::LOADED; b->queue[b->n_queue++] = q;
@@ -115,7 +119,8 @@ static int process_next(bgp_ctx* c, Batch* b) {
         b->reserve = std::max(b->reserve, room);
     }
     uint8_t* base = b->dev[q].as<uint8_t>() + b->new_off[q] - b->carry_len;
-    if (b->carry_len) BGP_HIP(hipMemcpyAsync(base, c->d_stream + b->carry_off, b->carry_len, hipMemcpyDeviceToDevice, c->stream));
+    if (b->carry_len) { TimedRegion tc(c, "d2d_carry", b->carry_len);
+        BGP_HIP(hipMemcpyAsync(base, c->d_stream + b->carry_off, b->carry_len, hipMemcpyDeviceToDevice, c->stream)); }
     if (b->cur >= 0) { BGP_HIP(hipStreamSynchronize(c->stream)); b->state[b->cur] = Batch::FREE; }     // the carry is out: the old batch's buffer can take the next load
     b->cur = q; b->state[q] = Batch::CURRENT; b->cur_final = final; b->any_batch = true;
     c->d_stream = base; c->stream_len = b->carry_len + b->new_len[q]; c->stream_on_device = true;
@@ -196,6 +201,7 @@ int bgp_batch_begin(bgp_ctx* c, uint64_t batch_bytes, int want_entries, uint32_t
     for (int q = 0; q < 2; ++q) {
         BGP_HIP(hipEventCreateWithFlags(&b->host_free[q], hipEventDisableTiming)); BGP_HIP(hipEventCreateWithFlags(&b->loaded_ev[q], hipEventDisableTiming));
         BGP_HIP(hipEventRecord(b->host_free[q], b->copy_stream));
+        std::swap(b->host[q], c->h_batch[q]); std::swap(b->dev[q], c->d_batch[q]);      // what the last batched pass left (empty the first time)
         BGP_TRY(b->host[q].reserve(b->batch_bytes));
     }
     return BGP_OK;

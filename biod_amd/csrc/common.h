@@ -152,6 +152,7 @@ struct bgp_ctx {
     // pileup (K3/K4)
     DevBuf d_pmax_end, d_pmax_pos;                    // prefix maxima (u64 keys)
     DevBuf d_runs, d_columns, d_depth_hist, d_pstats, d_tiles, d_ck_off, d_ck, d_deep;
+    HostBuf h_batch[2]; DevBuf d_batch[2];            // batched staging's pinned and device buffers between two passes (batch.cpp)
     DevBuf d_wlong;                                   // K4: windows touched by a well-formed long read (k4_acc2 walks its ops there)
     DevBuf d_slab, d_wcount, d_wdel, d_wslow;        // K4 plan: per-window descriptor slabs, counts, whole-window '-' levels, slow-read marks
     std::vector<bgp_run> runs;
@@ -197,8 +198,8 @@ struct bgp_ctx {
 
 // timing helpers: wrap a launch region with HIP events on the ctx stream
 struct TimedRegion {
-    bgp_ctx* c; int idx = -1; hipEvent_t a = nullptr, b = nullptr;
-    TimedRegion(bgp_ctx* ctx, const char* name, uint64_t alg_bytes);
+    bgp_ctx* c; int idx = -1; hipEvent_t a = nullptr, b = nullptr; hipStream_t st = nullptr;
+    TimedRegion(bgp_ctx* ctx, const char* name, uint64_t alg_bytes, hipStream_t on = nullptr);      // on: the stream the work is put on (default: the ctx's)
     ~TimedRegion();
 };
 void bgp_timing_collect(bgp_ctx* c);

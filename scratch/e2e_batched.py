@@ -122,3 +122,38 @@ ctx.reset(); ctx.push_inflated(st.tobytes()); ctx.flush()
 info = ctx.pileup_run()
 assert (info.n_positions, info.n_columns, info.sum_coverage) == tuple(last), "batched != one shot"
 print("batched == one shot (positions, columns, sum of coverage)")
+
+# The critical path of a batch, from HIP events on the streams the work runs on (bgp_timing_*): the copy to HBM, the carry in front
+# of it, the kernels, the windows' copies back -- and what the host spends filling the pinned buffer (wall clock around the fill).
+ctx.timing_enable(True); ctx.timing_reset()
+t_fill = [0.0]
+_fill = fill
+def fill(dst_ptr, src, m):
+    t = time.perf_counter(); _fill(dst_ptr, src, m); t_fill[0] += time.perf_counter() - t
+dt, stats = run("acquire", False)
+tm = ctx.timing_get()
+ctx.timing_enable(False)
+nb = max(1, tm.get("h2d_batch", {}).get("launches", 1))
+grp = {"h2d_batch": ("h2d_batch",), "d2d_carry": ("d2d_carry",), "K0 framing": ("k0_",), "K1 record table": ("k1_",), "K3 keys": ("k3_",), "K4 columns": ("k4_",), "d2h windows": ("d2h_",)}
+print(f"per batch ({nb} batches of {batch >> 20} MiB, acquire, consumer takes the windows only; wall {dt:.3f} s = {dt / nb * 1e3:.1f} ms a batch):")
+print(f"   host fills the pinned buffer ({P} threads): {t_fill[0] / nb * 1e3:.1f} ms a batch = {len(st) / t_fill[0] / 1e9:.1f} GB/s")
+for name, pre in grp.items():
+    ms = sum(v["total_ms"] for k, v in tm.items() if k.startswith(pre))
+    by = sum(v["algorithmic_bytes"] for k, v in tm.items() if k.startswith(pre))
+    extra = f" = {by / (ms * 1e-3) / 1e9:.1f} GB/s" if name in ("h2d_batch", "d2d_carry", "d2h windows") and ms > 0 else ""
+    print(f"   {name:18s} {ms / nb:7.2f} ms a batch{extra}")
+
+# ... and where the calling thread's wall time goes (the same run, untimed kernels): inside bgp_batch_acquire (ships a full buffer, waits for
+# the pinned buffer about to be refilled), the fill, bgp_batch_commit, bgp_batch_next_window
+_orig = {k: getattr(lib, k) for k in ("bgp_batch_acquire", "bgp_batch_commit", "bgp_batch_next_window", "bgp_batch_end")}
+wall = {k: 0.0 for k in _orig}
+class _Timed:
+    def __init__(self, name): self.name, self.f = name, _orig[name]
+    def __call__(self, *a):
+        t = time.perf_counter(); r = self.f(*a); wall[self.name] += time.perf_counter() - t; return r
+class _Lib:
+    def __getattr__(self, k): return _Timed(k) if k in _orig else getattr(L.lib(), k)
+lib = _Lib()
+t_fill[0] = 0.0
+dt, stats = run("acquire", False)
+print(f"calling thread, {dt:.3f} s: fill {t_fill[0]:.3f} s, " + ", ".join(f"{k[10:]} {v:.3f} s" for k, v in wall.items()))
