@@ -1703,6 +1703,7 @@ struct K5Args {
     RunDev run; uint64_t pos_begin, pos_end; const bgp_column* cols; uint64_t* cov64; const uint64_t* col_off; bgp_entry* entries;
     const uint64_t* ck_off; const Ckpt* ck; uint32_t ck_w;      // K4's long-read checkpoints (null / 0: none): per read and window, the cursor at the window's first column
     const uint4* cig4;                                          // K1's side array of first CIGAR ops, or null (a compacted table)
+    uint64_t stream_len;
 };
 
 __global__ __launch_bounds__(256) void k5_cov(K5Args a) {
@@ -1805,41 +1806,41 @@ __device__ __forceinline__ bgp_entry entry_of_ops(const uint8_t* s, const bgp_re
     return e;
 }
 
-// entry_of_ops in two halves, so that the two bytes an entry loads -- its base and its quality -- can be asked for for several columns
-// before the first is needed: where the cursor stands (no loads), then the entry from the bytes
-struct EntryAt { uint32_t op_index, op_offset, query_offset; bool hit, hit_qc; };
-__device__ __forceinline__ EntryAt entry_locate_ops(const bgp_record& r, const uint32_t (&ops)[4], uint32_t rr) {
-    const uint32_t n_cig = r.flag_nc & 0xFFFFu;
-    EntryAt e{0xFFFFu, 0u, 0u, false, false};
-    uint32_t cs = 0, qs = 0; bool started = false;
-#pragma unroll
-    for (uint32_t k = 0; k < 4; ++k) {
-        if (k >= n_cig || e.hit) continue;
-        const uint32_t op = ops[k], len = op >> 4, qc = cig_qc(op), rc = cig_rc(op);
-        if (!started) {
-            if (rc) { if ((op & 15u) != 3u) started = true; else continue; }
-            else { if (qc) qs += len; continue; }
-        }
-        if (!rc) { if (qc) qs += len; continue; }
-        const uint32_t elen = len ? len : 1u;
-        if (rr < cs + elen) { e.op_index = k; e.op_offset = rr - cs; e.query_offset = qs + (qc ? rr - cs : 0u); e.hit = true; e.hit_qc = qc != 0; }
-        else { cs += elen; if (qc) qs += elen; }
-    }
-    return e;
+// The cursor of a read of at most three ops in closed form, without a branch (pileup.d:175-222; entry_of_ops above is the same walk
+// written as one): every op that OWNS columns -- consumes reference, and is not an N in front of the first such op (the reference's
+// leading-N quirk) -- is a STOP: its first column cs, its length (a zero-length op owns one column), the query bases in front of it,
+// its index and whether it consumes query.  The cursor at column rr stands on the last stop with cs <= rr; it has run off the
+// CIGAR when rr lies behind that stop's columns (pileup.d:224-228).  (All of it by value: the optimizer turns a select between
+// values it finds in memory -- array elements, variables a lambda captured by reference -- into an indexed load from scratch.)
+struct Stop { uint32_t cs, len, qb, ix; };
+struct Stops { Stop a, b, c; };
+__device__ __forceinline__ Stops stops_of(uint32_t n_cig, uint32_t op0, uint32_t op1, uint32_t op2) {
+    Stops r; uint32_t cs = 0, qs = 0; bool started = false;
+#define BGP_STOP(K, OP, OUT) { \
+        const uint32_t len = (OP) >> 4; \
+        const bool on = (K) < n_cig, qc = on && cig_qc(OP), rc = on && cig_rc(OP); \
+        const bool stop = rc && (started || ((OP) & 15u) != 3u); \
+        started |= stop; \
+        const uint32_t elen = len ? len : 1u; \
+        OUT.cs = stop ? cs : 0xFFFFFFFFu; OUT.len = elen; OUT.qb = qs; OUT.ix = (K) | (qc ? 0x10000u : 0u); \
+        cs += stop ? elen : 0u; \
+        qs += qc ? (stop ? elen : (rc ? 0u : len)) : 0u; }
+    BGP_STOP(0u, op0, r.a) BGP_STOP(1u, op1, r.b) BGP_STOP(2u, op2, r.c)
+#undef BGP_STOP
+    return r;
 }
-__device__ __forceinline__ bgp_entry entry_finish(const EntryAt& at, uint32_t seq_byte, uint32_t qual_byte, bool in_seq, uint32_t ordinal) {
-    bgp_entry e; e.read_ordinal = ordinal; e.cigar_op_offset = at.op_offset; e.query_offset = at.query_offset; e.cigar_op_index = (uint16_t)at.op_index; e.base = 0xFF; e.qual = 0xFF;
-    if (!at.hit) { e.cigar_op_offset = 0; e.query_offset = 0; }
-    else if (at.hit_qc) {
-        if (in_seq) {
-            const uint32_t code = (at.query_offset & 1u) ? (seq_byte & 0xFu) : (seq_byte >> 4);
-            const uint64_t lo = 0x565352474D43413Dull, hi = 0x4E42444B48595754ull;   // "=ACMGRSVTWYHKDBN", base.d:85
-            e.base = (uint8_t)(((code & 8u) ? hi : lo) >> ((code & 7u) * 8));
-            e.qual = (uint8_t)qual_byte;
-        }
-    } else { e.base = '-'; e.qual = 255; }                                         // pileup.d:119-121,131-133
-    return e;
+struct CursorAt { uint32_t ix, off, qo; bool hit, hqc; };
+__device__ __forceinline__ CursorAt cursor_at(const Stops st, uint32_t rr) {
+    const bool c2 = rr >= st.c.cs, c1 = rr >= st.b.cs, c0 = rr >= st.a.cs;
+    const uint32_t cs = c2 ? st.c.cs : c1 ? st.b.cs : st.a.cs, len = c2 ? st.c.len : c1 ? st.b.len : st.a.len;
+    const uint32_t qb = c2 ? st.c.qb : c1 ? st.b.qb : st.a.qb, ix = c2 ? st.c.ix : c1 ? st.b.ix : st.a.ix;
+    CursorAt r; r.off = rr - cs; r.hit = (c0 || c1 || c2) && r.off < len; r.hqc = (ix >> 16) != 0; r.ix = ix & 0xFFFFu;
+    r.qo = qb + (r.hqc ? r.off : 0u);
+    return r;
 }
+// sixteen query bases of a read from query offset wb on (even): their nibbles and their qualities
+struct Staged { uint32_t s0, s1, q0, q1, q2, q3, wb; };
+__device__ __forceinline__ Staged staged_none() { Staged g; g.s0 = g.s1 = g.q0 = g.q1 = g.q2 = g.q3 = 0u; g.wb = 0x80000000u; return g; }
 
 // One wave per 64 consecutive COLUMNS, lane = column: the candidate rows of the block are scanned once (64 rows a step,
 // coalesced), every row that touches the block is handed to all lanes in file order, and a lane whose column the read
@@ -1848,6 +1849,9 @@ __device__ __forceinline__ bgp_entry entry_finish(const EntryAt& at, uint32_t se
 // every later read a candidate -- 32 KB of rows for ~50 entries, 200 GB/s of entries.)
 #ifndef BGP_K5R
 #define BGP_K5R 4
+#endif
+#ifndef BGP_K5_ABL
+#define BGP_K5_ABL 0                          // timing experiments: 1 searches only, 2 no entries of listed reads, 3 their entries computed but not stored
 #endif
 constexpr int K5R = BGP_K5R;            // entries of a column that leave together (a power of two)
 static_assert(sizeof(bgp_entry) == 16, "an entry is one 16-byte store");
@@ -1863,6 +1867,9 @@ __global__ __launch_bounds__(256) void k5_fill_blk(K5Args a) {
     const uint64_t i_lo = lower_bound_gt(a.pmax_end, a.run.first_record, a.run.end_record, rk | (uint32_t)p0);          // first record whose running maximum of end_position exceeds p0
     const uint64_t i_hi = lower_bound_gt(a.pmax_pos, a.run.first_record, a.run.end_record, rk | (uint32_t)(p1 - 1));    // first record that starts behind the block
     uint64_t w = valid ? a.col_off[col0 + lane] : 0;
+#if BGP_K5_ABL == 1
+    if (i_lo + w == 0xFFFFFFFFFFFFull) a.entries[0].qual = 1; return;
+#endif
     // Two ways to the same entries, by the read.  An ordinary read (up to four CIGAR ops, which came with its row: K1's side array) is
     // listed in LDS; when 64 are listed -- or a read of the other kind comes up, or the rows run out -- a LANE takes a listed READ and the
     // wave goes through the block's columns: the lanes whose reads cover the column work out their entries, and since lanes are in file
@@ -1882,61 +1889,92 @@ __global__ __launch_bounds__(256) void k5_fill_blk(K5Args a) {
     };
     auto flush_list = [&]() {
         if (!n_list) return;
+#if BGP_K5_ABL == 2
+        n_list = 0; return;
+#endif
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         const bool have = (uint32_t)lane < n_list;
-        bgp_record q{}; uint32_t ops[4] = {0, 0, 0, 0}; uint32_t ord = 0;
-        if (have) {
-            const uint4 x = list[0][lane], y = list[1][lane], z = list[2][lane];
-            q.ref_id = (int32_t)x.x; q.pos = (int32_t)x.y; q.end_pos = (int32_t)x.z; q.bin_mq_nl = x.w;
-            q.flag_nc = y.x & 0xFFFFFFFFu; q.l_seq = (int32_t)y.y; q.rec_off = ((uint64_t)y.w << 32) | y.z;
-            ops[0] = z.x; ops[1] = z.y; ops[2] = z.z; ord = z.w;      // (a listed read has at most three ops: the slot's fourth word is its ordinal)
-        }
+        uint4 x = make_uint4(0, 0, 0, 0), y = x, z = x;
+        if (have) { x = list[0][lane]; y = list[1][lane]; z = list[2][lane]; }
+        const uint32_t pos = x.y, end_pos = x.z, n_cig = y.x & 0xFFFFu, l_seq = y.y, ord = z.w;      // (a listed read has at most three ops: the slot's fourth word is its ordinal)
+        const uint64_t rec_off = ((uint64_t)y.w << 32) | y.z;
         const uint32_t jn = (uint32_t)(p1 - p0);
-        const uint8_t* const sq = a.s + q.rec_off + 36 + (q.bin_mq_nl & 0xFFu) + 4ull * (q.flag_nc & 0xFFFFu);
-        const uint8_t* const ql = sq + (uint32_t)((q.l_seq + 1) / 2);
-        const uint32_t n_cig = q.flag_nc & 0xFFFFu;
-        // the read's columns of the block, and its cursor at the first of them (pileup.d:175-192 in closed form); from there the cursor
-        // is STEPPED column by column as incrementPosition does (pileup.d:195-222) -- a handful of instructions where locating it anew
-        // for every column was sixty
-        const uint32_t c_lo = have ? (uint32_t)(max(p0, (uint64_t)(uint32_t)q.pos) - p0) : 64u, c_hi = have ? (uint32_t)(min(p1, (uint64_t)(uint32_t)q.end_pos) - p0) : 0u;
-        const EntryAt at0 = entry_locate_ops(q, ops, have && c_lo < c_hi ? (uint32_t)(p0 + c_lo - (uint32_t)q.pos) : 0u);
-        uint32_t ck = at0.op_index, coff = at0.op_offset;
-        bool cqc = at0.hit_qc, chit = at0.hit;
-        uint32_t cqb = at0.query_offset - (at0.hit_qc ? at0.op_offset : 0u);      // query bases in front of the op
-        uint32_t clen = 1;
-        { const uint32_t opk = ck == 0 ? ops[0] : ck == 1 ? ops[1] : ck == 2 ? ops[2] : 0u; const uint32_t l = opk >> 4; clen = l ? l : 1u; }
-        for (uint32_t j = 0; j < jn; ++j) {
-            const bool cov = j >= c_lo && j < c_hi;
-            const unsigned long long m = __ballot(cov);
-            if (!m) continue;
-            const uint64_t wj = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(w >> 32), (int)j) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)w, (int)j);
-            if (cov) {
-                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                EntryAt at{ck, coff, cqb + (cqc ? coff : 0u), chit, cqc};
-                const bool ins = chit && cqc && at.query_offset < (uint32_t)q.l_seq;
-                uint32_t sb = 0, qb = 0;
-                if (ins) { sb = sq[at.query_offset >> 1]; qb = ql[at.query_offset]; }
-                const bgp_entry e = entry_finish(at, sb, qb, ins, ord);
-                uint4 v; __builtin_memcpy(&v, &e, 16);
-                __builtin_memcpy(a.entries + wj + rank, &v, 16);
-                // incrementPosition: one column on; at the op's end on to the next op that consumes reference, the query bases of
-                // what is stepped over (I, S) added
-                if (chit && ++coff >= clen) {
-                    cqb += cqc ? clen : 0u;
-                    chit = false;
-#pragma unroll
-                    for (uint32_t kk = 1; kk < 3; ++kk) {
-                        if (chit || kk <= ck || kk >= n_cig) continue;
-                        const uint32_t op = ops[kk], len = op >> 4;
-                        if (!cig_rc(op)) { if (cig_qc(op)) cqb += len; continue; }
-                        ck = kk; coff = 0; clen = len ? len : 1u; cqc = cig_qc(op) != 0; chit = true;
-                    }
-                    if (!chit) { ck = 0xFFFFu; coff = 0; }      // the cursor ran off the CIGAR (pileup.d:224-228): entry_of_ops' "no hit"
-                }
-            }
-            if ((uint32_t)lane == j) w += (uint64_t)__popcll(m);
+        const uint64_t sq_off = rec_off + 36 + (x.w & 0xFFu) + 4ull * n_cig;
+        const uint8_t* const sq = a.s + sq_off;
+        const uint8_t* const ql = sq + ((l_seq + 1) >> 1);
+        const Stops st = stops_of(n_cig, z.x, z.y, z.z);
+        // the read's columns of the block
+        const uint32_t c_lo = have ? (uint32_t)(max(p0, (uint64_t)pos) - p0) : 64u, c_hi = have ? (uint32_t)(min(p1, (uint64_t)end_pos) - p0) : 0u;
+        const uint32_t rr0 = (uint32_t)p0 - pos;                               // column j of the block is column rr0 + j of the read
+        // The bases and qualities a read's entries need are STAGED, sixteen query bases at a time for eight columns: asked for one
+        // group of columns ahead (from the read's query offset at the group's first column; query offsets only grow from there), so
+        // no entry waits for a load of its own.  An entry whose query offset lies outside the staged sixteen (an insertion of more
+        // than eight bases inside the group) loads its two bytes.
+        const bool safe = have && sq_off + ((l_seq + 1) >> 1) + l_seq + 16 <= a.stream_len;
+#define BGP_STAGE(CFIRST, G) { \
+            G = staged_none(); \
+            const uint32_t c_ = max((uint32_t)(CFIRST), c_lo); \
+            const CursorAt an_ = cursor_at(st, rr0 + c_); \
+            const uint32_t qb_ = an_.qo & ~1u; \
+            if (safe && c_ < c_hi && c_ < (uint32_t)(CFIRST) + 8u && an_.hit && qb_ < l_seq) { \
+                uint2 S_; uint4 Q_; __builtin_memcpy(&S_, sq + (qb_ >> 1), 8); __builtin_memcpy(&Q_, ql + qb_, 16); \
+                G.s0 = S_.x; G.s1 = S_.y; G.q0 = Q_.x; G.q1 = Q_.y; G.q2 = Q_.z; G.q3 = Q_.w; G.wb = qb_; } }
+        // one column: the entries of the reads that cover it leave as one run of stores, in file order (lanes are in file order)
+#define BGP_K5_COLUMN(J, STAGED) { \
+            const uint32_t j_ = (J); \
+            const bool cov = j_ >= c_lo && j_ < c_hi && (STAGED || slow); \
+            const bool cov_all = j_ >= c_lo && j_ < c_hi; \
+            const unsigned long long m = __ballot(cov_all); \
+            if (m) { \
+                const uint64_t wj = (((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(w >> 32), (int)j_) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)w, (int)j_)) - (STAGED ? 0u : (uint32_t)__popcll(m)); \
+                if (cov) { \
+                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); \
+                    const CursorAt at = cursor_at(st, rr0 + j_); \
+                    const bool ins = at.hit && at.hqc && at.qo < l_seq; \
+                    uint32_t sb, qv; \
+                    if (STAGED) { /* byte t >> 1 of the nibble words holds the base (the even base the high nibble), byte t of the quality words its quality */ \
+                        const uint32_t t = at.qo - g_c.wb; \
+                        slow |= ins && t >= 16u; \
+                        sb = ((t & 8u) ? g_c.s1 : g_c.s0) >> (8u * ((t >> 1) & 3u)); \
+                        const uint32_t qlo = (t & 4u) ? g_c.q1 : g_c.q0, qhi = (t & 4u) ? g_c.q3 : g_c.q2; \
+                        qv = ((t & 8u) ? qhi : qlo) >> (8u * (t & 3u)); \
+                    } else { sb = ins ? sq[at.qo >> 1] : 0u; qv = ins ? ql[at.qo] : 0u; } \
+                    const uint32_t code = (sb >> ((at.qo & 1u) ? 0u : 4u)) & 15u; \
+                    const uint32_t c8 = code & 7u;      /* "=ACMGRSV" "TWYHKDBN" (base.d:85), a byte picked by v_perm */ \
+                    const uint32_t blo = __builtin_amdgcn_perm(0x56535247u, 0x4D43413Du, c8), bhi = __builtin_amdgcn_perm(0x4E42444Bu, 0x48595754u, c8); \
+                    const uint32_t bq = (((code & 8u) ? bhi : blo) & 0xFFu) | ((qv & 0xFFu) << 8); \
+                    /* no hit (the cursor ran off the CIGAR): index 0xFFFF, offsets 0, base and quality 0xFF; D / N: '-' and 255 */ \
+                    /* (pileup.d:119-121,131-133); a query offset behind SEQ: 0xFF, 0xFF */ \
+                    const uint32_t tail = !at.hit ? 0xFFFFu : !at.hqc ? (0xFF00u | (uint32_t)'-') : ins ? bq : 0xFFFFu; \
+                    uint4 v; \
+                    v.x = ord; v.y = at.hit ? at.off : 0u; v.z = at.hit ? at.qo : 0u; v.w = (at.hit ? at.ix : 0xFFFFu) | (tail << 16); \
+                    K5_STORE(a.entries + wj + rank, v) \
+                } \
+                if (STAGED && (uint32_t)lane == j_) w += (uint64_t)__popcll(m); \
+            } }
+#if BGP_K5_ABL == 3
+#define K5_STORE(P, V) if (V.x == 0xFFFFFFF3u && V.w == 77u) __builtin_memcpy(P, &V, 16);
+#else
+#define K5_STORE(P, V) __builtin_memcpy(P, &V, 16);
+#endif
+        // Groups of eight columns: the column steps hold no load and wait for none (a wait would also be one for the stores of the step
+        // before: vmcnt counts both); the next group's sixteen bases are asked for at a group's start.
+        bool slow = false;                                 // this read has an entry whose bases were not among the staged: its entries are written again below
+        Staged g_c, g_n;
+        BGP_STAGE(0u, g_c)
+        BGP_STAGE(8u, g_n)
+        for (uint32_t jg = 0; jg < jn; jg += 8u) {
+            if (jg) { g_c = g_n; BGP_STAGE(jg + 8u, g_n) }
+            const uint32_t je = min(jg + 8u, jn);
+            for (uint32_t j = jg; j < je; ++j) BGP_K5_COLUMN(j, true)
         }
+        if (__ballot(slow)) {
+            for (uint32_t j = 0; j < jn; ++j) BGP_K5_COLUMN(j, false)
+        }
+#undef K5_STORE
+#undef BGP_K5_COLUMN
+#undef BGP_STAGE
         n_list = 0;
         __builtin_amdgcn_wave_barrier();
     };
@@ -2335,6 +2373,7 @@ int k5_entries(bgp_ctx* c, uint32_t run_idx, uint64_t pos_begin, uint64_t pos_en
     a.col_off = c->d_entry_off.as<uint64_t>(); a.entries = nullptr;
     a.ck_w = c->ck_w; a.ck = c->ck_w ? c->d_ck.as<Ckpt>() : nullptr; a.ck_off = c->ck_w ? c->d_ck_off.as<uint64_t>() : nullptr;
     a.cig4 = c->cig4_ok ? c->d_cig4.as<uint4>() : nullptr;
+    a.stream_len = c->stream_len;
     uint64_t total = 0;
     {
         TimedRegion t(c, "k5_cov", np * 40);           // a 32-byte column read and an 8-byte offset written per position, the scan on top
