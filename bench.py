@@ -203,7 +203,7 @@ def entries_leg(ctx, cfg_name, n_reads, sum_lseq, sum_ncig, want_positions=4_000
     import ctypes as C
     from biod_amd import _lib as L
     ctx.timing_enable(True); ctx.timing_reset()
-    win = 1 << 20 if cfg_name != "cfg5" else 1 << 16
+    win = int(os.environ.get("BGP_BENCH_ENTRY_WINDOW", 1 << 22))      # positions a window (the consumer's choice: bgp_pileup_begin)
     L.check(L.lib().bgp_pileup_begin(ctx.handle, L.BGP_PILEUP_COLUMNS, 0, 0, (1 << 64) - 1, 1, 1, win), ctx.handle)
     t0 = time.perf_counter(); n_pos = 0; n_ent = 0
     cw = L.Columns()
@@ -219,7 +219,7 @@ def entries_leg(ctx, cfg_name, n_reads, sum_lseq, sum_ncig, want_positions=4_000
     k5_ms = sum(tm.values())
     info_pos = ctx.pileup_info().n_positions if hasattr(ctx, "pileup_info") else None
     per_read = 32 + (4 * sum_ncig + (sum_lseq + 1) // 2 + sum_lseq) / max(n_reads, 1)
-    return {"what": "per-read entries (column.reads) of the first windows of the piled-up BAM: K5 = " + " + ".join(sorted(tm)), "positions": n_pos, "entries": int(n_ent),
+    return {"what": "per-read entries (column.reads) of the first windows of the piled-up BAM: K5 = " + " + ".join(sorted(tm)), "positions": n_pos, "window_positions": win, "entries": int(n_ent),
             "k5_ms": round(k5_ms, 3), "kernels_ms": {k: round(v, 3) for k, v in tm.items()}, "G_entries_per_s_kernel": round(n_ent / (k5_ms * 1e-3) / 1e9, 2) if k5_ms else None,
             "wall_ms_with_host_copies": round(wall, 1), "bytes_per_read": round(per_read, 1), "_n_pos_total": info_pos}
 

@@ -1838,10 +1838,6 @@ __device__ __forceinline__ CursorAt cursor_at(const Stops st, uint32_t rr) {
     r.qo = qb + (r.hqc ? r.off : 0u);
     return r;
 }
-// sixteen query bases of a read from query offset wb on (even): their nibbles and their qualities
-struct Staged { uint32_t s0, s1, q0, q1, q2, q3, wb; };
-__device__ __forceinline__ Staged staged_none() { Staged g; g.s0 = g.s1 = g.q0 = g.q1 = g.q2 = g.q3 = 0u; g.wb = 0x80000000u; return g; }
-
 // One wave per 64 consecutive COLUMNS, lane = column: the candidate rows of the block are scanned once (64 rows a step,
 // coalesced), every row that touches the block is handed to all lanes in file order, and a lane whose column the read
 // covers appends the read's entry to its own column -- a counter a lane, no ranks, no ballots per entry.  (With a wave per
@@ -1850,12 +1846,15 @@ __device__ __forceinline__ Staged staged_none() { Staged g; g.s0 = g.s1 = g.q0 =
 #ifndef BGP_K5R
 #define BGP_K5R 4
 #endif
+#ifndef BGP_K5_MINW
+#define BGP_K5_MINW 4                         // waves a SIMD the register allocation leaves room for
+#endif
 #ifndef BGP_K5_ABL
 #define BGP_K5_ABL 0                          // timing experiments: 1 searches only, 2 no entries of listed reads, 3 their entries computed but not stored
 #endif
 constexpr int K5R = BGP_K5R;            // entries of a column that leave together (a power of two)
 static_assert(sizeof(bgp_entry) == 16, "an entry is one 16-byte store");
-__global__ __launch_bounds__(256) void k5_fill_blk(K5Args a) {
+__global__ __launch_bounds__(256, BGP_K5_MINW) void k5_fill_blk(K5Args a) {
     const uint64_t np = a.pos_end - a.pos_begin;
     const uint64_t col0 = ((uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;
     const int lane = threadIdx.x & 63;
@@ -1878,10 +1877,14 @@ __global__ __launch_bounds__(256) void k5_fill_blk(K5Args a) {
     // 64 different lines per store instruction, 2.24 ms for 2.1 * 10^8 entries of cfg3.  That way is kept for the reads that need a
     // CIGAR walk (long reads: the cursor at the block's first column is found ONCE for the 64 lanes, 64 ops a step from the window's
     // checkpoint); the ring is flushed where the two ways alternate, so a column's entries stay in file order.
-    __shared__ uint4 s_ring[4][K5R][64];
-    __shared__ uint4 s_list[4][3][64];                 // the listed reads: row (two 16-byte halves) and first four CIGAR ops, a read a lane
-    uint4 (*ring)[64] = s_ring[threadIdx.x >> 6];
-    uint4 (*list)[64] = s_list[threadIdx.x >> 6];
+    // a wave's LDS: the ring (K5R x 64 entries), behind it the listed reads -- row (two 16-byte halves) and first three CIGAR ops with the
+    // ordinal, a read a slot; while a list is flushed (the ring is empty then, and every lane holds its read in registers) the same
+    // words hold the reads' bases and qualities, word k of lane l at [k][l]
+    __shared__ uint4 s_wave[4][K5R + 3][64];
+    static_assert(K5R + 3 >= 7, "27 words a lane of staged bases and qualities");
+    uint4 (*ring)[64] = s_wave[threadIdx.x >> 6];
+    uint4 (*list)[64] = s_wave[threadIdx.x >> 6] + K5R;
+    uint32_t* const stg = reinterpret_cast<uint32_t*>(s_wave[threadIdx.x >> 6]) + lane;      // word k of this lane: stg[64 * k]
     uint32_t cnt = 0, n_list = 0;
     auto flush_ring = [&]() {
         for (uint32_t k = 0; k < (cnt & (K5R - 1)); ++k) { const uint4 x = ring[k][lane]; __builtin_memcpy(a.entries + w + k, &x, 16); }
@@ -1894,51 +1897,73 @@ __global__ __launch_bounds__(256) void k5_fill_blk(K5Args a) {
 #endif
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        const bool have = (uint32_t)lane < n_list;
+        // Lane = (read, stretch of columns): G lanes a read, each with 64 / G of the block's columns -- G = 1 with more than 32 reads
+        // listed, 8 with eight or fewer (the handful left over when 64 were listed and flushed: eight column steps instead of 64).
+        // The lanes that stand on the same column in a step are those of one stretch (lane mod G), in file order.
+        const uint32_t lg = n_list > 32u ? 0u : n_list > 16u ? 1u : n_list > 8u ? 2u : 3u, G = 1u << lg, CW = 64u >> lg;
+        const uint32_t ri = (uint32_t)lane >> lg, cg = (uint32_t)lane & (G - 1u);
+        const bool have = ri < n_list;
         uint4 x = make_uint4(0, 0, 0, 0), y = x, z = x;
-        if (have) { x = list[0][lane]; y = list[1][lane]; z = list[2][lane]; }
+        if (have) { x = list[0][ri]; y = list[1][ri]; z = list[2][ri]; }
         const uint32_t pos = x.y, end_pos = x.z, n_cig = y.x & 0xFFFFu, l_seq = y.y, ord = z.w;      // (a listed read has at most three ops: the slot's fourth word is its ordinal)
         const uint64_t rec_off = ((uint64_t)y.w << 32) | y.z;
-        const uint32_t jn = (uint32_t)(p1 - p0);
         const uint64_t sq_off = rec_off + 36 + (x.w & 0xFFu) + 4ull * n_cig;
         const uint8_t* const sq = a.s + sq_off;
         const uint8_t* const ql = sq + ((l_seq + 1) >> 1);
         const Stops st = stops_of(n_cig, z.x, z.y, z.z);
-        // the read's columns of the block
-        const uint32_t c_lo = have ? (uint32_t)(max(p0, (uint64_t)pos) - p0) : 64u, c_hi = have ? (uint32_t)(min(p1, (uint64_t)end_pos) - p0) : 0u;
+        // the read's columns of the block that fall into this lane's stretch [j0, j0 + CW)
+        const uint32_t j0 = cg * CW;
+        const uint32_t r_lo = have ? (uint32_t)(max(p0, (uint64_t)pos) - p0) : 64u, r_hi = have ? (uint32_t)(min(p1, (uint64_t)end_pos) - p0) : 0u;
+        const uint32_t c_lo = max(r_lo, j0), c_hi = min(r_hi, j0 + CW);
         const uint32_t rr0 = (uint32_t)p0 - pos;                               // column j of the block is column rr0 + j of the read
-        // The bases and qualities a read's entries need are STAGED, sixteen query bases at a time for eight columns: asked for one
-        // group of columns ahead (from the read's query offset at the group's first column; query offsets only grow from there), so
-        // no entry waits for a load of its own.  An entry whose query offset lies outside the staged sixteen (an insertion of more
-        // than eight bases inside the group) loads its two bytes.
-        const bool safe = have && sq_off + ((l_seq + 1) >> 1) + l_seq + 16 <= a.stream_len;
-#define BGP_STAGE(CFIRST, G) { \
-            G = staged_none(); \
-            const uint32_t c_ = max((uint32_t)(CFIRST), c_lo); \
-            const CursorAt an_ = cursor_at(st, rr0 + c_); \
-            const uint32_t qb_ = an_.qo & ~1u; \
-            if (safe && c_ < c_hi && c_ < (uint32_t)(CFIRST) + 8u && an_.hit && qb_ < l_seq) { \
-                uint2 S_; uint4 Q_; __builtin_memcpy(&S_, sq + (qb_ >> 1), 8); __builtin_memcpy(&Q_, ql + qb_, 16); \
-                G.s0 = S_.x; G.s1 = S_.y; G.q0 = Q_.x; G.q1 = Q_.y; G.q2 = Q_.z; G.q3 = Q_.w; G.wb = qb_; } }
-        // one column: the entries of the reads that cover it leave as one run of stores, in file order (lanes are in file order)
-#define BGP_K5_COLUMN(J, STAGED) { \
-            const uint32_t j_ = (J); \
-            const bool cov = j_ >= c_lo && j_ < c_hi && (STAGED || slow); \
+        const unsigned long long pat = lg == 0u ? ~0ull : lg == 1u ? 0x5555555555555555ull : lg == 2u ? 0x1111111111111111ull : 0x0101010101010101ull;
+        const unsigned long long gmask = pat << cg;                            // the lanes of this lane's stretch
+        const unsigned long long cmask = pat << ((uint32_t)lane >> (6u - lg)); // ... and, the lane taken as a COLUMN (w is kept a column a lane), of the stretch that column lies in
+        // The bases and qualities a lane's entries need are STAGED in LDS before the first entry leaves: 72 query bases from the
+        // read's query offset at the lane's first column on (query offsets only grow from there) -- 9 words of nibbles, 18 of
+        // qualities -- so that the column steps hold no load and wait for none (on this chip a wait for a load
+        // is also one for the stores issued since: vmcnt counts both; with the loads inside the loop, a group of columns ahead, the
+        // kernel spent 0.4 of its 1.4 ms on cfg3 draining its own stores).  An entry whose query offset lies outside the staged 72
+        // (more than eight inserted bases inside the block) loads its two bytes in a second pass over the lane's columns.
+        const CursorAt a0 = cursor_at(st, rr0 + min(c_lo, 63u));
+        const uint32_t qa = a0.qo & ~1u;                                        // staged: query bases [qa, qa + 72): a stretch's 64 and room for insertions
+        const bool want = have && c_lo < c_hi && a0.hit && qa < l_seq;
+        const bool safe = want && sq_off + ((l_seq + 1) >> 1) + qa + 72 <= a.stream_len;
+        bool slow = want && !safe;                         // this lane has an entry whose bases are not among the staged: its entries are written again below
+        {
+            uint4 n0 = make_uint4(0, 0, 0, 0), n1 = n0, q0 = n0, q1 = n0, q2 = n0, q3 = n0; uint32_t n2 = 0; uint2 q4 = make_uint2(0, 0);
+            if (BGP_K5_ABL != 4 && safe) {
+                const uint8_t* sp = sq + (qa >> 1); const uint8_t* qp = ql + qa;
+                __builtin_memcpy(&n0, sp, 16); __builtin_memcpy(&n1, sp + 16, 16); __builtin_memcpy(&n2, sp + 32, 4);
+                __builtin_memcpy(&q0, qp, 16); __builtin_memcpy(&q1, qp + 16, 16); __builtin_memcpy(&q2, qp + 32, 16); __builtin_memcpy(&q3, qp + 48, 16); __builtin_memcpy(&q4, qp + 64, 8);
+            }
+            __builtin_amdgcn_wave_barrier();               // (every lane has its read out of the list: the words are free)
+            stg[64 * 0] = n0.x; stg[64 * 1] = n0.y; stg[64 * 2] = n0.z; stg[64 * 3] = n0.w; stg[64 * 4] = n1.x; stg[64 * 5] = n1.y; stg[64 * 6] = n1.z; stg[64 * 7] = n1.w; stg[64 * 8] = n2;
+            stg[64 * 9] = q0.x; stg[64 * 10] = q0.y; stg[64 * 11] = q0.z; stg[64 * 12] = q0.w; stg[64 * 13] = q1.x; stg[64 * 14] = q1.y; stg[64 * 15] = q1.z; stg[64 * 16] = q1.w;
+            stg[64 * 17] = q2.x; stg[64 * 18] = q2.y; stg[64 * 19] = q2.z; stg[64 * 20] = q2.w; stg[64 * 21] = q3.x; stg[64 * 22] = q3.y; stg[64 * 23] = q3.z; stg[64 * 24] = q3.w;
+            stg[64 * 25] = q4.x; stg[64 * 26] = q4.y;
+        }
+        // one step: every stretch its column JJ; the entries of the reads that cover a column leave as one run of stores, in file order
+#define BGP_K5_COLUMN(JJ, STAGED) { \
+            const uint32_t j_ = j0 + (JJ); \
             const bool cov_all = j_ >= c_lo && j_ < c_hi; \
+            const bool cov = cov_all && (STAGED || slow); \
             const unsigned long long m = __ballot(cov_all); \
             if (m) { \
-                const uint64_t wj = (((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(w >> 32), (int)j_) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)w, (int)j_)) - (STAGED ? 0u : (uint32_t)__popcll(m)); \
+                const unsigned long long gm = m & gmask; \
+                const uint32_t gn = (uint32_t)__popcll(gm); \
+                const uint64_t wj = (((uint64_t)(uint32_t)__builtin_amdgcn_ds_bpermute((int)(j_ << 2), (int)(uint32_t)(w >> 32)) << 32) | (uint32_t)__builtin_amdgcn_ds_bpermute((int)(j_ << 2), (int)(uint32_t)w)) - (STAGED ? 0u : gn); \
                 if (cov) { \
-                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); \
+                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(gm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)gm, 0u)); \
                     const CursorAt at = cursor_at(st, rr0 + j_); \
                     const bool ins = at.hit && at.hqc && at.qo < l_seq; \
                     uint32_t sb, qv; \
-                    if (STAGED) { /* byte t >> 1 of the nibble words holds the base (the even base the high nibble), byte t of the quality words its quality */ \
-                        const uint32_t t = at.qo - g_c.wb; \
-                        slow |= ins && t >= 16u; \
-                        sb = ((t & 8u) ? g_c.s1 : g_c.s0) >> (8u * ((t >> 1) & 3u)); \
-                        const uint32_t qlo = (t & 4u) ? g_c.q1 : g_c.q0, qhi = (t & 4u) ? g_c.q3 : g_c.q2; \
-                        qv = ((t & 8u) ? qhi : qlo) >> (8u * (t & 3u)); \
+                    if (STAGED) { /* nibble word t >> 3: the base's byte is (t & 7) >> 1 (the even base the high nibble); quality word 9 + (t >> 2) */ \
+                        const uint32_t t = at.qo - qa; \
+                        slow |= BGP_K5_ABL != 4 && ins && t >= 72u; \
+                        const uint32_t tt = min(t, 71u); \
+                        sb = stg[64u * (tt >> 3)] >> (8u * ((tt >> 1) & 3u)); \
+                        qv = stg[64u * (9u + (tt >> 2))] >> (8u * (tt & 3u)); \
                     } else { sb = ins ? sq[at.qo >> 1] : 0u; qv = ins ? ql[at.qo] : 0u; } \
                     const uint32_t code = (sb >> ((at.qo & 1u) ? 0u : 4u)) & 15u; \
                     const uint32_t c8 = code & 7u;      /* "=ACMGRSV" "TWYHKDBN" (base.d:85), a byte picked by v_perm */ \
@@ -1951,30 +1976,22 @@ __global__ __launch_bounds__(256) void k5_fill_blk(K5Args a) {
                     v.x = ord; v.y = at.hit ? at.off : 0u; v.z = at.hit ? at.qo : 0u; v.w = (at.hit ? at.ix : 0xFFFFu) | (tail << 16); \
                     K5_STORE(a.entries + wj + rank, v) \
                 } \
-                if (STAGED && (uint32_t)lane == j_) w += (uint64_t)__popcll(m); \
+                /* the lane as a column: this step was its column's if it is column JJ of its stretch */ \
+                if (STAGED && ((uint32_t)lane & (CW - 1u)) == (JJ)) w += (uint64_t)__popcll(m & cmask); \
             } }
 #if BGP_K5_ABL == 3
 #define K5_STORE(P, V) if (V.x == 0xFFFFFFF3u && V.w == 77u) __builtin_memcpy(P, &V, 16);
 #else
 #define K5_STORE(P, V) __builtin_memcpy(P, &V, 16);
 #endif
-        // Groups of eight columns: the column steps hold no load and wait for none (a wait would also be one for the stores of the step
-        // before: vmcnt counts both); the next group's sixteen bases are asked for at a group's start.
-        bool slow = false;                                 // this read has an entry whose bases were not among the staged: its entries are written again below
-        Staged g_c, g_n;
-        BGP_STAGE(0u, g_c)
-        BGP_STAGE(8u, g_n)
-        for (uint32_t jg = 0; jg < jn; jg += 8u) {
-            if (jg) { g_c = g_n; BGP_STAGE(jg + 8u, g_n) }
-            const uint32_t je = min(jg + 8u, jn);
-            for (uint32_t j = jg; j < je; ++j) BGP_K5_COLUMN(j, true)
-        }
-        if (__ballot(slow)) {
-            for (uint32_t j = 0; j < jn; ++j) BGP_K5_COLUMN(j, false)
+#pragma unroll 1
+        for (uint32_t jj = 0; jj < CW; ++jj) BGP_K5_COLUMN(jj, true)
+        if (BGP_K5_ABL != 5 && __ballot(slow)) {
+#pragma unroll 1
+            for (uint32_t jj = 0; jj < CW; ++jj) BGP_K5_COLUMN(jj, false)
         }
 #undef K5_STORE
 #undef BGP_K5_COLUMN
-#undef BGP_STAGE
         n_list = 0;
         __builtin_amdgcn_wave_barrier();
     };
