@@ -25,8 +25,13 @@
 struct Batch {
     uint64_t batch_bytes = 0, reserve = 0;
     int want_entries = 0; uint32_t window = 65536;
-    HostBuf host[2]; uint64_t host_len[2] = {0, 0}; hipEvent_t host_free[2] = {nullptr, nullptr};
-    int fill = 0;                                       // host buffer taking the pushes
+    // Three pinned buffers: one takes the caller's bytes, full ones wait in a queue for a free device buffer, the rest are free or the
+    // source of a copy in flight (host_free tells).  With two, the full buffer a caller commits while batch i + 1 is on its way could
+    // only leave at the caller's next call -- after it had been handed batch i + 1's windows -- and the two directions of the link took turns.
+    static constexpr int NH = 3;
+    HostBuf host[NH]; uint64_t host_len[NH] = {0, 0, 0}; hipEvent_t host_free[NH] = {nullptr, nullptr, nullptr};
+    int fill = 0;                                       // host buffer taking the pushes (-1: none to be had before a full one has left)
+    int fullq[NH] = {0, 0, 0}; int n_full = 0;          // full buffers waiting for a device buffer, oldest first
     int acq = -1; uint64_t acq_off = 0;                 // bgp_batch_acquire handed out host[acq] from acq_off on and waits for its commit (-1: nothing outstanding)
     DevBuf dev[2]; uint64_t new_off[2] = {0, 0}, new_len[2] = {0, 0}; hipEvent_t loaded_ev[2] = {nullptr, nullptr};
     enum { FREE, LOADED, CURRENT } state[2] = {FREE, FREE};
@@ -47,21 +52,21 @@ void batch_release(bgp_ctx* c) {
     Batch* b = c->batch;
     if (!b) return;
     if (b->copy_stream) { (void)hipStreamSynchronize(b->copy_stream); (void)hipStreamDestroy(b->copy_stream); }
-    for (int q = 0; q < 2; ++q) {
+    // (the pinned buffers and the two device buffers go back to the ctx: the next bgp_batch_begin takes them again -- pinning
+    // 2 x 256 MiB anew cost ~70 ms, 40 % of a 10 M-read stream's whole pass)
+    for (int q = 0; q < Batch::NH; ++q) {
         if (b->host_free[q]) (void)hipEventDestroy(b->host_free[q]);
+        std::swap(b->host[q], c->h_batch[q]); b->host[q].release();
+    }
+    for (int q = 0; q < 2; ++q) {
         if (b->loaded_ev[q]) (void)hipEventDestroy(b->loaded_ev[q]);
-        // (the two pinned buffers and the two device buffers go back to the ctx: the next bgp_batch_begin takes them again -- pinning
-        // 2 x 256 MiB anew cost ~70 ms, 40 % of a 10 M-read stream's whole pass)
-        std::swap(b->host[q], c->h_batch[q]); std::swap(b->dev[q], c->d_batch[q]);
-        b->host[q].release(); b->dev[q].release();
+        std::swap(b->dev[q], c->d_batch[q]); b->dev[q].release();
     }
     delete b;
     c->batch = nullptr;
     c->frame_tolerant_tail = false; c->batch_maq = 0; c->batch_md = 0; c->batch_md_skip_zero = 1;
 }
 
-// the host buffer that takes the pushes goes to a free device buffer (asynchronous copy); BGP_EAGAIN when both device
-// buffers are taken
 // the caller's bytes into the pinned buffer: one thread copies ~10 GB/s on the GPU boxes' hosts, which made this memcpy the
 // whole of the device-E2E time (the H2D copy, the kernels and the D2H of the columns all hide behind it); large pushes are
 // split over a few threads
@@ -84,11 +89,13 @@ void bgp_staged_copy(uint8_t* dst, const uint8_t* src, uint64_t n) {
     for (auto& t : th) t.join();
 }
 
+// the oldest full pinned buffer goes to a free device buffer (asynchronous copy); BGP_EAGAIN when both device buffers are taken
 static int ship(bgp_ctx* c, Batch* b) {
+    if (!b->n_full) return BGP_OK;
     int q = -1;
     for (int k = 0; k < 2; ++k) if (b->state[k] == Batch::FREE) { q = k; break; }
     if (q < 0) return BGP_EAGAIN;
-    const int h = b->fill;
+    const int h = b->fullq[0];
     BGP_TRY(b->dev[q].reserve(b->reserve + b->batch_bytes + 256));
     b->new_off[q] = b->reserve; b->new_len[q] = b->host_len[h];
     if (b->host_len[h]) { TimedRegion th(c, "h2d_batch", b->host_len[h], b->copy_stream);
@@ -97,9 +104,47 @@ static int ship(bgp_ctx* c, Batch* b) {
     BGP_HIP(hipEventRecord(b->host_free[h], b->copy_stream));
     b->state[q] = Batch::LOADED; b->queue[b->n_queue++] = q;
     b->host_len[h] = 0;
-    b->fill ^= 1;
-    BGP_HIP(hipEventSynchronize(b->host_free[b->fill]));          // the buffer about to be filled was the source of the copy before last: long done
+    for (int k = 1; k < b->n_full; ++k) b->fullq[k - 1] = b->fullq[k];
+    --b->n_full;
     return BGP_OK;
+}
+// every full buffer a device buffer is free for
+static int ship_ready(bgp_ctx* c, Batch* b) {
+    while (b->n_full) { const int rc = ship(c, b); if (rc == BGP_EAGAIN) break; if (rc != BGP_OK) return rc; }
+    return BGP_OK;
+}
+// the buffer that takes the caller's bytes is full (or the stream is over): it joins the queue, and the next one that is not waiting
+// there takes its place (none: fill = -1 until a full one has left)
+static void next_fill(Batch* b) {
+    b->fill = -1;
+    for (int k = 0; k < Batch::NH && b->fill < 0; ++k) {
+        bool waiting = false;
+        for (int j = 0; j < b->n_full; ++j) waiting |= b->fullq[j] == k;
+        if (!waiting) b->fill = k;
+    }
+}
+static void close_fill(Batch* b) {
+    if (b->fill < 0) return;
+    b->fullq[b->n_full++] = b->fill;
+    next_fill(b);
+}
+static bool fill_is_full(const Batch* b) {
+    return b->fill >= 0 && b->host_len[b->fill] && b->batch_bytes - b->host_len[b->fill] < std::min<uint64_t>(b->batch_bytes, 65536);
+}
+// A buffer to write into: a full one is closed and leaves for the device the moment a device buffer is free -- at the commit / push
+// that filled it, or when the batch before last gives up its device buffer (process_next).  BGP_EAGAIN: every pinned buffer is full
+// and both device buffers are taken -- hand out windows first.  The buffer was the source of a copy a while ago: wait for that copy.
+static int fill_ready(bgp_ctx* c, Batch* b) {
+    if (fill_is_full(b)) close_fill(b);
+    BGP_TRY(ship_ready(c, b));
+    if (b->fill < 0) next_fill(b);
+    if (b->fill < 0) return BGP_EAGAIN;
+    if (b->host_len[b->fill] == 0) BGP_HIP(hipEventSynchronize(b->host_free[b->fill]));
+    return BGP_OK;
+}
+static int ship_if_full(bgp_ctx* c, Batch* b) {
+    if (b->acq < 0 && fill_is_full(b)) close_fill(b);      // (a buffer a caller is still writing into stays where it is)
+    return ship_ready(c, b);
 }
 
 // the oldest loaded batch becomes the current one: carry in front, framing (tolerant of a partial last record unless it
@@ -107,7 +152,7 @@ static int ship(bgp_ctx* c, Batch* b) {
 static int process_next(bgp_ctx* c, Batch* b) {
     const int q = b->queue[0];
     b->queue[0] = b->queue[1]; --b->n_queue;
-    const bool final = b->ended && b->n_queue == 0 && b->host_len[b->fill] == 0;
+    const bool final = b->ended && b->n_queue == 0 && b->n_full == 0 && (b->fill < 0 || b->host_len[b->fill] == 0);
     BGP_HIP(hipStreamWaitEvent(c->stream, b->loaded_ev[q], 0));
     if (b->carry_len > b->new_off[q]) {                              // a carry longer than the room in front of the new bytes: a bigger buffer, once
         DevBuf bigger;
@@ -121,7 +166,7 @@ static int process_next(bgp_ctx* c, Batch* b) {
     uint8_t* base = b->dev[q].as<uint8_t>() + b->new_off[q] - b->carry_len;
     if (b->carry_len) { TimedRegion tc(c, "d2d_carry", b->carry_len);
         BGP_HIP(hipMemcpyAsync(base, c->d_stream + b->carry_off, b->carry_len, hipMemcpyDeviceToDevice, c->stream)); }
-    if (b->cur >= 0) { BGP_HIP(hipStreamSynchronize(c->stream)); b->state[b->cur] = Batch::FREE; }     // the carry is out: the old batch's buffer can take the next load
+    if (b->cur >= 0) { BGP_HIP(hipStreamSynchronize(c->stream)); b->state[b->cur] = Batch::FREE; BGP_TRY(ship_if_full(c, b)); }     // the carry is out: the old batch's buffer can take the next load -- at once, if a full pinned buffer is waiting
     b->cur = q; b->state[q] = Batch::CURRENT; b->cur_final = final; b->any_batch = true;
     c->d_stream = base; c->stream_len = b->carry_len + b->new_len[q]; c->stream_on_device = true;
     c->frame_tolerant_tail = !final;
@@ -198,12 +243,13 @@ int bgp_batch_begin(bgp_ctx* c, uint64_t batch_bytes, int want_entries, uint32_t
     b->reserve = std::max<uint64_t>(b->batch_bytes / 8, 1ull << 16);         // room for the carry in front of a batch's new bytes (grown when a carry is longer)
     b->want_entries = want_entries; b->window = window_positions ? window_positions : 65536u;
     BGP_HIP(hipStreamCreateWithFlags(&b->copy_stream, hipStreamNonBlocking));
-    for (int q = 0; q < 2; ++q) {
-        BGP_HIP(hipEventCreateWithFlags(&b->host_free[q], hipEventDisableTiming)); BGP_HIP(hipEventCreateWithFlags(&b->loaded_ev[q], hipEventDisableTiming));
+    for (int q = 0; q < Batch::NH; ++q) {
+        BGP_HIP(hipEventCreateWithFlags(&b->host_free[q], hipEventDisableTiming));
         BGP_HIP(hipEventRecord(b->host_free[q], b->copy_stream));
-        std::swap(b->host[q], c->h_batch[q]); std::swap(b->dev[q], c->d_batch[q]);      // what the last batched pass left (empty the first time)
+        std::swap(b->host[q], c->h_batch[q]);                                            // what the last batched pass left (empty the first time)
         BGP_TRY(b->host[q].reserve(b->batch_bytes));
     }
+    for (int q = 0; q < 2; ++q) { BGP_HIP(hipEventCreateWithFlags(&b->loaded_ev[q], hipEventDisableTiming)); std::swap(b->dev[q], c->d_batch[q]); }
     return BGP_OK;
     BGP_API_CATCH(c)
 }
@@ -217,12 +263,14 @@ int bgp_batch_push(bgp_ctx* c, const uint8_t* data, size_t len, size_t* taken) {
     BGP_HIP(hipSetDevice(c->device));
     *taken = 0;
     while (*taken < len) {
+        if (b->fill >= 0 && b->host_len[b->fill] == b->batch_bytes) close_fill(b);
+        { const int rc = fill_ready(c, b); if (rc != BGP_OK) return rc; }      // BGP_EAGAIN: hand out windows first
         const int h = b->fill;
-        if (b->host_len[h] == b->batch_bytes) { const int rc = ship(c, b); if (rc != BGP_OK) return rc; continue; }
         const uint64_t n = std::min<uint64_t>(len - *taken, b->batch_bytes - b->host_len[h]);
         bgp_staged_copy(b->host[h].as<uint8_t>() + b->host_len[h], data + *taken, n);
         b->host_len[h] += n; *taken += n;
     }
+    if (b->fill >= 0 && b->host_len[b->fill] == b->batch_bytes) { close_fill(b); BGP_TRY(ship_ready(c, b)); }
     return BGP_OK;
     BGP_API_CATCH(c)
 }
@@ -240,7 +288,7 @@ int bgp_batch_acquire(bgp_ctx* c, uint8_t** ptr, size_t* cap) {
     *ptr = nullptr; *cap = 0;
     // a buffer with less room than one BGZF block inflates to (64 KiB, constants.d:26-61) is shipped as it is: a caller that writes
     // whole blocks could otherwise be handed a tail it can never use, with no way to move on
-    if (b->batch_bytes - b->host_len[b->fill] < std::min<uint64_t>(b->batch_bytes, 65536) && b->host_len[b->fill]) { const int rc = ship(c, b); if (rc != BGP_OK) return rc; }      // BGP_EAGAIN: hand out windows first
+    { const int rc = fill_ready(c, b); if (rc != BGP_OK) return rc; }      // BGP_EAGAIN: hand out windows first
     const int h = b->fill;
     *ptr = b->host[h].as<uint8_t>() + b->host_len[h]; *cap = (size_t)(b->batch_bytes - b->host_len[h]);
     b->acq = h; b->acq_off = b->host_len[h];
@@ -257,6 +305,8 @@ int bgp_batch_commit(bgp_ctx* c, size_t n) {
     if (b->host_len[h] != b->acq_off || n > b->batch_bytes - b->host_len[h]) return BGP_EINVAL;
     b->host_len[h] += n;
     b->acq = -1;
+    BGP_HIP(hipSetDevice(c->device));
+    BGP_TRY(ship_if_full(c, b));
     return BGP_OK;
     BGP_API_CATCH(c)
 }
@@ -316,13 +366,15 @@ int bgp_batch_next_window(bgp_ctx* c, bgp_columns* o) {
         // the next batch
         if (b->n_queue == 0) {
             if (!b->ended) return BGP_EAGAIN;                            // push more, or say the stream is over
-            if (b->host_len[b->fill] || !b->any_batch) {                 // what is left in the host buffer is the last batch (an empty stream is one, too)
-                const int rc = ship(c, b);
-                if (rc != BGP_OK) return rc == BGP_EAGAIN ? BGP_ESTATE : rc;
-            } else if (b->cur >= 0 && !b->cur_final) {                   // the stream ended exactly on a batch: what was carried is the last batch
-                const int rc = ship(c, b);
-                if (rc != BGP_OK) return rc == BGP_EAGAIN ? BGP_ESTATE : rc;
-            } else return BGP_EOF;
+            if (!b->n_full) {
+                if (b->fill < 0) next_fill(b);
+                if ((b->fill >= 0 && b->host_len[b->fill]) || !b->any_batch) close_fill(b);      // what is left in the host buffer is the last batch (an empty stream is one, too)
+                else if (b->cur >= 0 && !b->cur_final) close_fill(b);                            // the stream ended exactly on a batch: what was carried is the last batch
+                else return BGP_EOF;
+            }
+            const int rc = ship(c, b);
+            if (rc != BGP_OK) return rc == BGP_EAGAIN ? BGP_ESTATE : rc;
+            if (!b->n_queue) return BGP_ESTATE;
         }
         BGP_TRY(process_next(c, b));
     }

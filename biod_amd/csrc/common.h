@@ -152,7 +152,7 @@ struct bgp_ctx {
     // pileup (K3/K4)
     DevBuf d_pmax_end, d_pmax_pos;                    // prefix maxima (u64 keys)
     DevBuf d_runs, d_columns, d_depth_hist, d_pstats, d_tiles, d_ck_off, d_ck, d_deep;
-    HostBuf h_batch[2]; DevBuf d_batch[2];            // batched staging's pinned and device buffers between two passes (batch.cpp)
+    HostBuf h_batch[3]; DevBuf d_batch[2];            // batched staging's pinned and device buffers between two passes (batch.cpp)
     DevBuf d_wlong;                                   // K4: windows touched by a well-formed long read (k4_acc2 walks its ops there)
     DevBuf d_slab, d_wcount, d_wdel, d_wslow;        // K4 plan: per-window descriptor slabs, counts, whole-window '-' levels, slow-read marks
     std::vector<bgp_run> runs;

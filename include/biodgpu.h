@@ -240,12 +240,14 @@ int bgp_pileup_ref_id(bgp_ctx* ctx, int32_t* ref_id);          /* AbstractPileup
  * The shape of BgzfInputStream's bounded ring of blocks in flight (inputstream.d:386-447) under pileupColumns(reads)
  * (pileup.d:509-519; use_md_tag = false): push inflated record bytes in file order with any cut points, take dense
  * windows of FINAL columns out as they become final.  A batch (batch_bytes of input, 0 = 256 MiB) is copied to HBM
- * while the previous one is still in its kernels (two pinned host buffers, two device buffers, a copy stream of its
- * own); the reads that still overlap the position of a batch's last covering read -- found exactly, with the prefix
+ * while the previous one is still in its kernels (three pinned host buffers -- one taking the caller's bytes, full ones queued --,
+ * two device buffers, a copy stream of its own: a full buffer leaves for the device the moment a device buffer is free, at the
+ * push / commit that filled it or inside the bgp_batch_next_window that moved on to the next batch); the reads that still overlap the position of a batch's last covering read -- found exactly, with the prefix
  * maxima of K3 -- and a partial last record are carried over to the next batch on the device.  Columns and entries
  * (read_ordinal counts over the whole stream) are identical to staging everything at once.
- *   bgp_batch_push         BGP_OK (all bytes taken) or BGP_EAGAIN with *taken < len: both batches in flight are waiting
- *                          to be handed out -- call bgp_batch_next_window until it says BGP_EAGAIN, push the rest
+ *   bgp_batch_push         BGP_OK (all bytes taken) or BGP_EAGAIN with *taken < len: every pinned buffer is full and both
+ *                          device buffers are taken -- take a window (bgp_batch_next_window), push the rest.  Taking ONE window
+ *                          and offering bytes again, in turn, keeps both directions of the link busy
  *   bgp_batch_next_window  BGP_OK (a window), BGP_EAGAIN (push more or bgp_batch_end), BGP_EOF (after bgp_batch_end)
  * Between windows the ctx describes the CURRENT batch: bgp_decode_fetch etc. see its records; bgp_batch_ordinal_base
  * gives the stream-wide ordinal of its record 0.  bgp_reset leaves the mode.  bgp_set_n_ref before bgp_batch_begin holds

@@ -98,6 +98,54 @@ def run_overlapped(touch):
     return time.perf_counter() - t0, stats
 
 
+def take_one(stats, touch):
+    cw = L.Columns()
+    rc = L.check(lib.bgp_batch_next_window(h, C.byref(cw)), h)
+    if rc == L.BGP_OK:
+        stats[0] += cw.n_positions
+        if touch:
+            cov = np.ctypeslib.as_array(C.cast(cw.columns, C.POINTER(C.c_uint32)), shape=(cw.n_positions, 8))[:, 0]
+            stats[1] += int(np.count_nonzero(cov)); stats[2] += int(cov.sum(dtype=np.int64))
+    return rc
+
+
+def run_interleaved(touch):
+    """acquire / commit and the hand-out INTERLEAVED, a window at a time: as soon as a window of batch i + 1 has come (batch i's device
+    buffer is free from then on) the next buffer is acquired -- which ships the full one -- so that the copy to the device of batch i + 2
+    runs beside the kernels and the copies back of batch i + 1.  (Draining every window first, as run() does, leaves the two directions
+    of the link taking turns.)"""
+    t0 = time.perf_counter()
+    stats = [0, 0, 0]
+    L.check(lib.bgp_batch_begin(h, batch, 0, 1 << 22), h)
+    off, futs, m = 0, None, 0
+    while off < len(st) or futs is not None:
+        progressed = False
+        if futs is None and off < len(st):
+            ptr, cap = C.c_void_p(), C.c_size_t()
+            rc = L.check(lib.bgp_batch_acquire(h, C.byref(ptr), C.byref(cap)), h)
+            if rc == L.BGP_OK:
+                m = min(cap.value, len(st) - off)
+                dst = np.ctypeslib.as_array(C.cast(ptr.value, C.POINTER(C.c_uint8)), shape=(m,))
+                src = st[off:off + m]
+                step = -(-m // P)
+                futs = [pool.submit(np.copyto, dst[k * step:min(m, (k + 1) * step)], src[k * step:min(m, (k + 1) * step)]) for k in range(P)]
+                progressed = True
+        if futs is not None and all(f.done() for f in futs):
+            for f in futs:
+                f.result()
+            L.check(lib.bgp_batch_commit(h, m), h)
+            off += m; futs = None
+            continue
+        if take_one(stats, touch) == L.BGP_OK:
+            progressed = True
+        if not progressed and futs is not None:
+            for f in futs:
+                f.result()
+    L.check(lib.bgp_batch_end(h), h)
+    drain(stats, touch)
+    return time.perf_counter() - t0, stats
+
+
 print(f"{n} reads of cfg3's model, {len(st) / 1e9:.2f} GB inflated, batches of {batch >> 20} MiB ({len(st) / batch:.1f}), producer threads {P}")
 last = None
 for mode in ("push", "acquire"):
@@ -117,6 +165,14 @@ for touch in (True, False):
         best = dt if best is None or dt < best else best
     assert stats[0] == last[0] and (not touch or tuple(stats) == tuple(last)), "overlapped != serial"
     print(f"acquire, fill overlapped with the hand-out, consumer {'reads every column' if touch else 'takes the windows only'}: best of 3 {best:.3f} s = {n / best / 1e6:.1f} Mreads/s device-E2E, "
+          f"{len(st) / best / 1e9:.1f} GB/s of input", flush=True)
+for touch in (True, False):
+    best = None
+    for rep in range(3):
+        dt, stats = run_interleaved(touch)
+        best = dt if best is None or dt < best else best
+    assert stats[0] == last[0] and (not touch or tuple(stats) == tuple(last)), "interleaved != serial"
+    print(f"acquire, a window and a buffer in turn, consumer {'reads every column' if touch else 'takes the windows only'}: best of 3 {best:.3f} s = {n / best / 1e6:.1f} Mreads/s device-E2E, "
           f"{len(st) / best / 1e9:.1f} GB/s of input", flush=True)
 ctx.reset(); ctx.push_inflated(st.tobytes()); ctx.flush()
 info = ctx.pileup_run()
