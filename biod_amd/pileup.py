@@ -240,9 +240,13 @@ class Context:
         L.check(L.lib().bgp_batch_ordinal_base(self._h, C.byref(n)), self._h)
         return int(n.value)
 
-    def batch_drain(self):
-        """Windows of final columns until the library wants more input (or, after batch_end, until the stream is done)."""
-        while True:
+    def batch_drain(self, limit=None):
+        """Windows of final columns until the library wants more input (or, after batch_end, until the stream is done); at most
+        `limit` of them.  (Bytes and ONE window in turn keep a full pinned buffer queued whenever a device buffer frees, and both
+        directions of the link busy: INTEGRATION.md.)"""
+        while limit is None or limit > 0:
+            if limit is not None:
+                limit -= 1
             cw = L.Columns()
             rc = L.check(L.lib().bgp_batch_next_window(self._h, C.byref(cw)), self._h)
             if rc != L.BGP_OK:
@@ -264,8 +268,7 @@ class Context:
             while off < len(mv):
                 taken, rc = self.batch_push(mv[off:])
                 off += taken
-                if rc == L.BGP_EAGAIN:
-                    yield from self.batch_drain()
+                yield from self.batch_drain(1)
         self.batch_end()
         yield from self.batch_drain()
 
@@ -278,12 +281,13 @@ class Context:
             while off < len(mv):
                 view, rc = self.batch_acquire()
                 if rc == L.BGP_EAGAIN:
-                    yield from self.batch_drain()
+                    yield from self.batch_drain(1)
                     continue
                 m = min(len(view), len(mv) - off)
                 view[:m] = mv[off:off + m]
                 self.batch_commit(m)
                 off += m
+                yield from self.batch_drain(1)
         self.batch_end()
         yield from self.batch_drain()
 
