@@ -357,45 +357,75 @@ template <bool WPR> __global__ __launch_bounds__(256) void k4_ck_build(const uin
         Ckpt* out = ck + ck_off[ri];
         // window j (j >= 1) starts at column offset D + j*W of this read (D <= 0)
         const int64_t D = (int64_t)(run.start_pos + t_first * W) - (int64_t)pos;
+        const uint32_t mD = (uint32_t)(-D);
         uint32_t cs = 0, qs = 0; bool started = false;
         // what the accumulate path asks of a read (k4_plan: "the mould"): the first reference-consuming op is M/=/X (so the
         // read's first column is a base of it: no leading N, D), no zero-length reference-consuming op, no M base past SEQ
         bool plain = true;
         const uint32_t l_seq_r = (uint32_t)__shfl(r.l_seq, src, 64);
-        // The walk is a chain of chunks per read, and a chunk's scan is a fraction of a microsecond: with ONE chunk of ops on its way
-        // while the current one is scanned every step waited out an HBM round trip (cfg5: 2.6 ms for 6 M steps).  Four chunks ahead.
-        constexpr int CK_AHEAD = 4;
-        uint32_t opq[CK_AHEAD];
+        // The walk is a chain of chunks per read: 256 ops a chunk, FOUR consecutive ops a lane (one 16-byte load; a lane adds up its
+        // four before the wave's scan -- with an op a lane the two scans and the ballots of a chunk were paid for 64 ops: 1.83 ms
+        // for cfg5's 6 * 10^8 ops, bound by instruction issue), and two chunks on their way while one is scanned (a chunk's scan is a
+        // fraction of a microsecond: waiting out an HBM round trip per chunk was 2.6 ms).
+        constexpr int CK_AHEAD = 2;
+        const uint64_t cg_off = rec_off + 36 + l_name;
+        auto load4 = [&](uint32_t first) {                                // ops first .. first + 3 of the read (zeros behind its last op)
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (first < n_cig) {
+                if (cg_off + 4ull * first + 16 <= stream_len) __builtin_memcpy(&v, cg + 4ull * first, 16);      // (behind the CIGAR lies the read's SEQ: the bytes exist)
+                else { v.x = ld_u32(cg + 4ull * first); if (first + 1 < n_cig) v.y = ld_u32(cg + 4ull * first + 4); if (first + 2 < n_cig) v.z = ld_u32(cg + 4ull * first + 8); if (first + 3 < n_cig) v.w = ld_u32(cg + 4ull * first + 12); }
+            }
+            return v;
+        };
+        uint4 opq[CK_AHEAD];
 #pragma unroll
-        for (int q = 0; q < CK_AHEAD; ++q) opq[q] = 64u * q + (uint32_t)lane < n_cig ? ld_u32(cg + 4ull * (64u * q + lane)) : 0u;
-        for (uint32_t c0 = 0; c0 < n_cig && cs < covered; c0 += 64) {
-            const bool active = c0 + lane < n_cig;
-            const uint32_t op = opq[0];
+        for (int q = 0; q < CK_AHEAD; ++q) opq[q] = load4(256u * q + 4u * lane);
+        for (uint32_t c0 = 0; c0 < n_cig && cs < covered; c0 += 256) {
+            const uint4 o4 = opq[0];
 #pragma unroll
             for (int q = 0; q + 1 < CK_AHEAD; ++q) opq[q] = opq[q + 1];
-            opq[CK_AHEAD - 1] = c0 + 64u * CK_AHEAD + lane < n_cig ? ld_u32(cg + 4ull * (c0 + 64u * CK_AHEAD + lane)) : 0u;
+            opq[CK_AHEAD - 1] = load4(c0 + 256u * CK_AHEAD + 4u * lane);
+            const uint32_t k0 = c0 + 4u * (uint32_t)lane;                     // this lane's first op
+            const uint32_t op[4] = {o4.x, o4.y, o4.z, o4.w};
+            bool act[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) act[t] = k0 + t < n_cig;
             // the first reference-consuming non-N op starts the cursor (pileup.d:180-189)
-            int fl = 64;
+            uint32_t fl = 256;                                              // its place in the chunk (256: not in this chunk)
             if (!started) {
-                const unsigned long long st = __ballot(active && cig_rc(op) && (op & 15u) != 3u);
-                fl = st ? __ffsll((long long)st) - 1 : 64;
-                const unsigned long long anyrc = __ballot(active && cig_rc(op));
-                if (anyrc) { const int f0 = __ffsll((long long)anyrc) - 1; if (f0 != fl || !cig_qc((uint32_t)__shfl((int)op, f0, 64))) plain = false; }   // a leading N, or a first column that is a D
+                uint32_t f0 = 256;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const unsigned long long st = __ballot(act[t] && cig_rc(op[t]) && (op[t] & 15u) != 3u), anyrc = __ballot(act[t] && cig_rc(op[t]));
+                    if (st) fl = min(fl, 4u * (uint32_t)(__ffsll((long long)st) - 1) + t);
+                    if (anyrc) f0 = min(f0, 4u * (uint32_t)(__ffsll((long long)anyrc) - 1) + t);
+                }
+                if (f0 < 256u) {      // a leading N, or a first column that is a D
+                    const uint32_t sub = f0 & 3u, opsel = sub == 0 ? op[0] : sub == 1 ? op[1] : sub == 2 ? op[2] : op[3];
+                    if (f0 != fl || !cig_qc((uint32_t)__shfl((int)opsel, (int)(f0 >> 2), 64))) plain = false;
+                }
             }
-            const bool lane_started = started || lane >= fl;
-            uint32_t rlen, qlen;
-            op_lens(op, active, lane_started, &rlen, &qlen);
-            const uint32_t ir = wave_incl_u32(rlen, lane), iq = wave_incl_u32(qlen, lane);
-            const uint32_t cs_b = cs + ir - rlen, qs_b = qs + iq - qlen;
-            if (__ballot(active && cig_rc(op) && (op >> 4) == 0) || __ballot(rlen && cig_qc(op) && qs_b + qlen > l_seq_r)) plain = false;
-            if (rlen) {
-                if (cs_b == 0 && n_ck) { Ckpt e{c0 + (uint32_t)lane, 0u, qs_b, 0u}; out[0] = e; }      // window of the read's first column
-                int64_t j = (int64_t)cs_b - D <= 0 ? 1 : (int64_t)((uint64_t)((int64_t)cs_b - D + W - 1) >> wsh);   // first window starting at/after cs_b
-                if (j < 1) j = 1;
-                for (; j < (int64_t)n_ck && D + j * W < (int64_t)(cs_b + rlen); ++j) { Ckpt e{c0 + (uint32_t)lane, cs_b, qs_b, 0u}; out[j] = e; }
+            uint32_t rlen[4], qlen[4], rt = 0, qt = 0;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { op_lens(op[t], act[t], started || 4u * (uint32_t)lane + t >= fl, &rlen[t], &qlen[t]); rt += rlen[t]; qt += qlen[t]; }
+            const uint32_t ir = wave_incl_u32(rt, lane), iq = wave_incl_u32(qt, lane);
+            uint32_t cs_b = cs + ir - rt, qs_b = qs + iq - qt;
+            bool bad = false;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                bad |= (act[t] && cig_rc(op[t]) && (op[t] >> 4) == 0) || (rlen[t] && cig_qc(op[t]) && qs_b + qlen[t] > l_seq_r);
+                if (rlen[t]) {
+                    if (cs_b == 0 && n_ck) { Ckpt e{k0 + t, 0u, qs_b, 0u}; out[0] = e; }      // window of the read's first column
+                    // the windows that start inside the op's columns [cs_b, cs_b + rlen): window j starts at column D + j * W, so they are
+                    // j = ceil(u / W) .. ceil((u + rlen) / W) - 1 with u = cs_b - D (32 bits: D <= 0, a read's columns stay below 2^31)
+                    const uint32_t u = cs_b + mD, j_lo = max(1u, (u + W_ - 1u) >> wsh), j_hi = min(n_ck, (u + rlen[t] + W_ - 1u) >> wsh);
+                    for (uint32_t j = j_lo; j < j_hi; ++j) { Ckpt e{k0 + t, cs_b, qs_b, 0u}; out[j] = e; }
+                }
+                cs_b += rlen[t]; qs_b += qlen[t];
             }
+            if (__ballot(bad)) plain = false;
             cs += __shfl(ir, 63, 64); qs += __shfl(iq, 63, 64);
-            started = started || fl < 64;
+            started = started || fl < 256u;
         }
         if (lane == 0 && n_ck) out[0].pad = (plain && cs >= covered) ? 0u : 1u;      // the verdict rides on the read's first checkpoint (k4_plan reads it)
     }
