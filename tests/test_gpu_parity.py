@@ -640,6 +640,28 @@ def test_random_cigars_match_oracle(ctx, seed):
     check_pileup(ctx, st, entries=True, window=1021)
 
 
+@pytest.mark.parametrize("depth", [3, 20, 40, 90])
+def test_entries_staged_bases_edges(ctx, depth):
+    """K5's listed reads (<= 3 ops) with what its staging of bases has to get right: insertions of more than eight bases inside a
+    block of 64 columns (the entries beyond the staged 72 query bases are written again with loads of their own), soft clips and
+    skips in front, reads of more than 255 bases with one op, every number of listed reads (a lane a read with more than 32 of
+    them, eight lanes a read with eight or fewer), and a last record that ends the stream (nothing behind its qualities to read)."""
+    rng = np.random.default_rng(77 + depth)
+    shapes = [lambda: [(70, "M")], lambda: [(30, "M"), (20, "I"), (30, "M")], lambda: [(3, "M"), (40, "I"), (60, "M")], lambda: [(25, "S"), (50, "M")],
+              lambda: [(20, "M"), (700, "N"), (40, "M")], lambda: [(40, "M"), (9, "D"), (33, "M")], lambda: [(400, "M")], lambda: [(1, "M"), (1, "I"), (90, "=")],
+              lambda: [(10, "H"), (64, "M"), (5, "S")], lambda: [(60, "X"), (15, "I")]]
+    recs, pos = [], 100
+    for i in range(depth * 12):
+        ops = shapes[int(rng.integers(len(shapes)))]()
+        l_seq = sum(ln for ln, op in ops if op in "MIS=X")
+        seq = "".join("ACGTN"[int(x)] for x in rng.choice(5, size=l_seq, p=[0.24, 0.24, 0.24, 0.24, 0.04]))
+        recs.append(bamio.pack_record(f"r{i}", seq, ops, ref_id=0, pos=pos, qual=bytes(rng.integers(0, 60, l_seq).astype(np.uint8))))
+        pos += int(rng.integers(0, max(2, 160 // depth)))
+    st = b"".join(recs)                                   # the last record's qualities are the stream's last bytes
+    stage(ctx, st)
+    check_pileup(ctx, st, entries=True, window=997)
+
+
 # ------------------------------------------------------------------------------------------ MD tags / reference_base
 def _check_read_dna(ctx, st, limit=None):
     """The oracle materialises the chars BioD's lazy range yields (also when it then stalls on an exhausted
