@@ -32,7 +32,6 @@ struct FrameArgs {
     int side16;                          // ... as 16-bit values (segments of at most 64 KiB), two to a word of the same array
     const uint64_t* seg_hint;            // per segment: the smallest offset inside it where the caller says a record starts (NONE: no word), or null
     int tolerant_tail;                   // batched staging: the data may end inside a record -- the chain stops in front of it instead of ETRUNC
-    int retry;                           // k0_guess, second pass: only segments the first pass found nothing in, names need not be printable (ref_bound is the widest then)
     uint32_t* list; uint32_t list_cap;   // k0_verify lists the segments it sends round again (k0_rechase takes them from there)
     uint4* sub; uint32_t sub_n, sub_shift;   // k12_lds: a segment is sub_n windows of 1 << sub_shift bytes; sub[k * sub_n + w] = records, bases, CIGAR ops of segment k in front of window w (null: not wanted)
 };
@@ -43,12 +42,10 @@ __global__ __launch_bounds__(256) void k0_guess(FrameArgs a) {
     const int lane = threadIdx.x & 63;
     if (k >= a.n_seg) return;
     if (k == 0) { if (lane == 0) a.entry[0] = 0; return; }
-    if (a.retry && a.entry[k] != NONE) return;
-    const bool names = !a.retry;
     const uint64_t beg = k * a.seg_bytes;
     const uint64_t lim = min(beg + a.seg_bytes, a.len);
     uint64_t found = NONE;
-    if (a.seg_hint && !a.retry) {                       // the caller's hint (bgp_push_inflated: first_record_uoffset): tried first, by the same test as any candidate
+    if (a.seg_hint) {                                   // the caller's hint (bgp_push_inflated: first_record_uoffset): tried first, by the same test as any candidate
         const uint64_t h = a.seg_hint[k];
         uint32_t bs = 0, dummy;
         if (h != NONE && h >= beg && h < lim && plausible(a.s, a.len, h, a.ref_bound, &bs)) {
@@ -56,18 +53,26 @@ __global__ __launch_bounds__(256) void k0_guess(FrameArgs a) {
             if (a.len - nxt < 4 || plausible(a.s, a.len, nxt, a.ref_bound, &dummy)) found = h;
         }
     }
-    for (uint64_t base = beg; base < lim && found == NONE; base += 64) {      // (256 candidates a step, four to a lane as in k0_guess_wide: 0.65 against 0.52 ms -- the start is half a record in, and three quarters of the wider step's loads are for nothing)
-        const uint64_t o = base + lane;
-        uint32_t bs = 0;
-        const bool ok = o < lim && plausible(a.s, a.len, o, a.ref_bound, &bs, names);
-        unsigned long long m = __ballot(ok);
-        while (m) {
-            const int l = __ffsll((long long)m) - 1;
-            const uint32_t bsl = __shfl(bs, l, 64);
-            const uint64_t nxt = base + l + 4 + bsl;
-            uint32_t dummy;
-            if (a.len - nxt < 4 || plausible(a.s, a.len, nxt, a.ref_bound, &dummy, names)) { found = base + l; break; }
-            m &= m - 1;
+    // Second pass, only by a wave whose first found nothing, with the widest reference bound and without the printable-name test: a
+    // caller's wrong bgp_set_n_ref, or a file whose read names are not printable, then costs this pass instead of one lane chasing the
+    // whole stream serially (measured on cfg3's model with n_ref set to 1 where there are 8: INTEGRATION.md "Limits").  A segment that
+    // holds no record start is scanned twice.  (A launch of its own until round 4: 110 k workgroups that looked at one word and left.)
+    for (int pass = 0; pass < 2 && found == NONE; ++pass) {
+        const bool names = pass == 0;
+        const int32_t ref_bound = pass == 0 ? a.ref_bound : (1 << 24);
+        for (uint64_t base = beg; base < lim && found == NONE; base += 64) {      // (256 candidates a step, four to a lane as in k0_guess_wide: 0.65 against 0.52 ms -- the start is half a record in, and three quarters of the wider step's loads are for nothing)
+            const uint64_t o = base + lane;
+            uint32_t bs = 0;
+            const bool ok = o < lim && plausible(a.s, a.len, o, ref_bound, &bs, names);
+            unsigned long long m = __ballot(ok);
+            while (m) {
+                const int l = __ffsll((long long)m) - 1;
+                const uint32_t bsl = __shfl(bs, l, 64);
+                const uint64_t nxt = base + l + 4 + bsl;
+                uint32_t dummy;
+                if (a.len - nxt < 4 || plausible(a.s, a.len, nxt, ref_bound, &dummy, names)) { found = base + l; break; }
+                m &= m - 1;
+            }
         }
     }
     if (lane == 0) a.entry[k] = found;
@@ -82,13 +87,11 @@ __global__ __launch_bounds__(256) void k0_guess_wide(FrameArgs a) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     if (k >= a.n_seg) return;
     if (k == 0) { if (threadIdx.x == 0) a.entry[0] = 0; return; }
-    if (a.retry && a.entry[k] != NONE) return;          // (the same word for every thread of the workgroup; written only by thread 0 after the last barrier)
-    const bool names = !a.retry;
     const uint64_t beg = k * a.seg_bytes;
     const uint64_t lim = min(beg + a.seg_bytes, a.len);
     if (threadIdx.x == 0) {
         uint64_t f = NONE;
-        if (a.seg_hint && !a.retry) {
+        if (a.seg_hint) {
             const uint64_t h = a.seg_hint[k];
             uint32_t bs = 0, dummy;
             if (h != NONE && h >= beg && h < lim && plausible(a.s, a.len, h, a.ref_bound, &bs)) {
@@ -104,6 +107,9 @@ __global__ __launch_bounds__(256) void k0_guess_wide(FrameArgs a) {
     // down, as in plausible()); a lane tests in full what passes them -- every lane its own, side by side: inside a long read's CIGAR
     // every aligned offset passes the first two tests -- and only the successor test of a full pass is the wave's.  With 256 a step
     // the first record start of a 4 MiB segment of long reads -- tens of KB in -- was ~100 dependent steps (cfg5: 0.66 ms).
+    for (int pass = 0; pass < 2 && found == NONE; ++pass) {      // (the second pass: see k0_guess)
+    const bool names = pass == 0;
+    const int32_t ref_bound = pass == 0 ? a.ref_bound : (1 << 24);
     for (uint64_t base = beg; found == NONE && base < lim; base += 1024) {
         uint64_t mine = NONE;
         uint32_t pre[4][2], bs4[4]; bool ok4[4];
@@ -117,9 +123,9 @@ __global__ __launch_bounds__(256) void k0_guess_wide(FrameArgs a) {
         for (int u = 0; u < 4; ++u) {
             const uint64_t o = base + 256u * u + 64u * wv + lane;
             const uint32_t bs0 = pre[u][0];
-            const bool quick = o < lim && o + 36 <= a.len && bs0 >= 33u && bs0 <= (1u << 30) && (uint64_t)bs0 <= a.len - o - 4 && (int32_t)pre[u][1] >= -1 && (int32_t)pre[u][1] < a.ref_bound;
+            const bool quick = o < lim && o + 36 <= a.len && bs0 >= 33u && bs0 <= (1u << 30) && (uint64_t)bs0 <= a.len - o - 4 && (int32_t)pre[u][1] >= -1 && (int32_t)pre[u][1] < ref_bound;
             bs4[u] = 0;
-            ok4[u] = quick && plausible(a.s, a.len, o, a.ref_bound, &bs4[u], names);
+            ok4[u] = quick && plausible(a.s, a.len, o, ref_bound, &bs4[u], names);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -129,7 +135,7 @@ __global__ __launch_bounds__(256) void k0_guess_wide(FrameArgs a) {
                 const uint32_t bsl = __shfl(bs4[u], l, 64);
                 const uint64_t ol = base + 256u * u + 64u * wv + l, nxt = ol + 4 + bsl;
                 uint32_t dummy;
-                if (a.len - nxt < 4 || plausible(a.s, a.len, nxt, a.ref_bound, &dummy, names)) { mine = ol; break; }
+                if (a.len - nxt < 4 || plausible(a.s, a.len, nxt, ref_bound, &dummy, names)) { mine = ol; break; }
                 m &= m - 1;
             }
         }
@@ -137,6 +143,7 @@ __global__ __launch_bounds__(256) void k0_guess_wide(FrameArgs a) {
         __syncthreads();
         found = s_found;
         __syncthreads();
+    }
     }
     if (threadIdx.x == 0) a.entry[k] = found;
 }
@@ -530,7 +537,7 @@ int k0_frame(bgp_ctx* c) {
     a.ref_bound = c->n_ref_hint > 0 ? c->n_ref_hint : (1 << 24);
     a.tolerant_tail = c->frame_tolerant_tail ? 1 : 0;
     a.sub = nullptr; a.sub_n = 0; a.sub_shift = 0; c->seg_windows = 0;
-    a.seg_hint = nullptr; a.retry = 0;
+    a.seg_hint = nullptr;
     constexpr uint32_t LIST_CAP = 1024;
     BGP_TRY(c->d_seg_list.reserve(LIST_CAP * 4));
     a.list = c->d_seg_list.as<uint32_t>(); a.list_cap = n_seg < (1ull << 32) ? LIST_CAP : 0u;
@@ -569,16 +576,8 @@ int k0_frame(bgp_ctx* c) {
                 BGP_TRY(fill_many(c, f + 2, 4));
             }
         }
-        // Second pass, only over segments the first found nothing in (their waves of the first pass have exited: same stream), with
-        // the widest reference bound and without the printable-name test: a caller's wrong bgp_set_n_ref, or a file whose read names
-        // are not printable, then costs this pass instead of one lane chasing the whole stream serially (measured on cfg3's model with
-        // n_ref set to 1 where there are 8: INTEGRATION.md "Limits").  A segment that holds no record start is scanned twice.
-        for (int pass = 0; pass < 2; ++pass) {
-            FrameArgs g = a;
-            g.retry = pass; if (pass) g.ref_bound = 1 << 24;
-            if (n_seg <= 32768) hipLaunchKernelGGL(k0_guess_wide, dim3((unsigned)n_seg), dim3(256), 0, c->stream, g);      // few, large segments: a workgroup each
-            else hipLaunchKernelGGL(k0_guess, dim3((unsigned)((n_seg + 3) / 4)), dim3(256), 0, c->stream, g);
-        }
+        if (n_seg <= 32768) hipLaunchKernelGGL(k0_guess_wide, dim3((unsigned)n_seg), dim3(256), 0, c->stream, a);      // few, large segments: a workgroup each
+        else hipLaunchKernelGGL(k0_guess, dim3((unsigned)((n_seg + 3) / 4)), dim3(256), 0, c->stream, a);
     }
     uint64_t rounds = 0;
     uint32_t n_list = 0;                 // the segments of a repair round, when they are few enough to be listed and small enough for LDS
