@@ -1005,9 +1005,21 @@ struct PlanArgs {
     uint32_t* wlong;                              // ... and the windows a well-formed long read touches (k4_acc2 walks its CIGAR there, from the window's checkpoint)
 };
 
+#ifndef BGP_PLAN_NB
+#define BGP_PLAN_NB 4
+#endif
+constexpr int PLAN_NB = BGP_PLAN_NB;          // batches of 64 reads a wave plans, the next batch's rows requested before the current one is worked on
 __global__ __launch_bounds__(256) void k4_plan(PlanArgs a) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
+    // A wave's time was its chain of round trips -- rows, then the slots' atomics, then the stores -- with a wave slot held all the
+    // while (77 % of its cycles waiting): a wave takes PLAN_NB batches and asks for the next one's rows before it works on this one's.
+    const uint64_t first = ((uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * (uint64_t)(64 * PLAN_NB);
+    if (first >= a.n) return;
+    uint4 nx, ny, nc4 = make_uint4(0, 0, 0, 0);
+    { const uint64_t ii = min(first + (uint64_t)lane, a.n - 1); const uint4* rp = reinterpret_cast<const uint4*>(a.rec + ii); nx = rp[0]; ny = rp[1]; if (a.cig4) nc4 = a.cig4[ii]; }
+    uint64_t r_end = 0, r_start_pos = 0, r_tile_base = 0;
+    for (int it = 0; it < PLAN_NB; ++it) {
+    const uint64_t i = first + (uint64_t)(64 * it) + (uint64_t)lane;
     // Straight-line, selects instead of joins, descriptors in 32-bit halves: written with a branch per case and per op this
     // kernel spent 600 VALU instructions a wave, four in ten of them register moves where the branches met -- and VALU
     // issue is what bounds it (SQ counters: 78 % of its time).  Lanes behind the last record work on it a second time and
@@ -1017,24 +1029,25 @@ __global__ __launch_bounds__(256) void k4_plan(PlanArgs a) {
     // the reference run of a record: reads are sorted, so a wave nearly always lies inside one run -- the first lane's
     // run is looked up once (a binary search of dependent loads) and only lanes beyond its end search for themselves
     const uint64_t i0 = i - lane;
-    if (i0 >= a.n) return;
-    uint64_t r_end, r_start_pos, r_tile_base;
-    { const RunDev rd = a.runs[run_of_record(a.runs, a.n_runs, i0)]; r_end = rd.end_record; r_start_pos = rd.start_pos; r_tile_base = rd.tile_base; }
+    if (i0 >= a.n) break;
+    const uint4 x = nx, y = ny, c4 = nc4;                 // ref_id,pos,end_pos,bin_mq_nl | flag_nc,l_seq,rec_off | the first four CIGAR ops
+    if (it + 1 < PLAN_NB && i0 + 64 < a.n) { const uint64_t jn = min(i + 64, a.n - 1); const uint4* rp = reinterpret_cast<const uint4*>(a.rec + jn); nx = rp[0]; ny = rp[1]; if (a.cig4) nc4 = a.cig4[jn]; }
+    uint64_t w_start_pos, w_tile_base;                    // (the wave's run; lanes beyond its end look theirs up below)
+    if (it == 0 || i0 >= r_end) { const RunDev rd = a.runs[run_of_record(a.runs, a.n_runs, i0)]; r_end = rd.end_record; r_start_pos = rd.start_pos; r_tile_base = rd.tile_base; }
+    w_start_pos = r_start_pos; w_tile_base = r_tile_base;
     const bool in = i < a.n;
     const uint64_t ii = in ? i : a.n - 1;
-    const uint4* rp = reinterpret_cast<const uint4*>(a.rec + ii);
-    const uint4 x = rp[0], y = rp[1];                     // ref_id,pos,end_pos,bin_mq_nl | flag_nc,l_seq,rec_off
     const bool covered = in && x.z != x.y;                // basesCovered() > 0, pileup.d:481,510
-    if (covered && ii >= r_end) { const RunDev& rd = a.runs[run_of_record(a.runs, a.n_runs, ii)]; r_start_pos = rd.start_pos; r_tile_base = rd.tile_base; }
-    const uint32_t rel0 = x.y - (uint32_t)r_start_pos;
-    const uint32_t tb = (uint32_t)r_tile_base;
-    const uint32_t wf0 = tb + (rel0 >> SH), wl = tb + ((x.z - 1 - (uint32_t)r_start_pos) >> SH);
+    if (covered && ii >= r_end) { const RunDev& rd = a.runs[run_of_record(a.runs, a.n_runs, ii)]; w_start_pos = rd.start_pos; w_tile_base = rd.tile_base; }
+    const uint32_t rel0 = x.y - (uint32_t)w_start_pos;
+    const uint32_t tb = (uint32_t)w_tile_base;
+    const uint32_t wf0 = tb + (rel0 >> SH), wl = tb + ((x.z - 1 - (uint32_t)w_start_pos) >> SH);
     const uint32_t n_cig = y.x & 0xFFFFu, l_seq = y.y;
     const uint64_t cig_off = (((uint64_t)y.w << 32) | y.z) + 36 + (x.w & 0xFFu);
     const uint64_t seq_off = cig_off + 4ull * n_cig;
     bool simple = covered && n_cig >= 1 && n_cig <= 4 && l_seq >= 1 && l_seq <= (uint32_t)FAST_SEG && seq_off + (l_seq + 1) / 2 + 16 <= a.stream_len;   // (staging reads 16 bytes per lane)
     uint32_t ops[4];
-    if (a.cig4) { const uint4 c4 = a.cig4[ii]; ops[0] = c4.x; ops[1] = c4.y; ops[2] = c4.z; ops[3] = c4.w; }
+    if (a.cig4) { ops[0] = c4.x; ops[1] = c4.y; ops[2] = c4.z; ops[3] = c4.w; }
     else {
 #pragma unroll
         for (int k = 0; k < 4; ++k) { ops[k] = 0; if (simple && (uint32_t)k < n_cig) ops[k] = ld_u32(a.s + cig_off + 4 * k); }
@@ -1094,7 +1107,7 @@ __global__ __launch_bounds__(256) void k4_plan(PlanArgs a) {
     // window A or to A + 1: those two are claimed with one atomic each for the whole wave; the few others (second
     // halves of N-skip reads) claim theirs one by one.  All atomics are in flight together.
     const unsigned long long am = __ballot(any);
-    if (!am) return;
+    if (!am) continue;
     const uint32_t A = (uint32_t)__shfl((int)wf, __ffsll((long long)am) - 1, 64);
     uint32_t pk = 0;
 #pragma unroll
@@ -1123,6 +1136,7 @@ __global__ __launch_bounds__(256) void k4_plan(PlanArgs a) {
 #else
         if (slot == 0xFFFFFFF0u) a.slab[(uint64_t)win[j] * a.slab_cap] = dsc[j];
 #endif
+    }
     }
 }
 
@@ -2301,7 +2315,7 @@ int k34_pileup(bgp_ctx* c) {
             pa.runs = a.runs; pa.n_runs = n_runs; pa.n_tiles = tile_base;
             pa.slab = (unsigned long long*)c->d_slab.p; pa.slab_cap = slab_cap; pa.wcount = c->d_wcount.as<uint32_t>(); pa.wdel = c->d_wdel.as<int32_t>(); pa.wslow = c->d_wslow.as<int32_t>();
             pa.ck = have_rows ? a.ck : nullptr; pa.ck_off = a.ck_off; pa.wlong = have_rows ? c->d_wlong.as<uint32_t>() : nullptr;
-            hipLaunchKernelGGL(k4_plan, dim3(nb), dim3(256), 0, c->stream, pa);
+            hipLaunchKernelGGL(k4_plan, dim3((unsigned)((n + 256ull * PLAN_NB - 1) / (256ull * PLAN_NB))), dim3(256), 0, c->stream, pa);
             const unsigned wb = (unsigned)((tile_base + 1023) / 1024);
             BGP_TRY(c->d_scan_tmp.reserve((size_t)wb * 8 + 16));
             int32_t* btot = c->d_scan_tmp.as<int32_t>();
