@@ -384,14 +384,8 @@ template <bool FULL> __global__ __launch_bounds__(256) void k6_prep(const uint8_
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     bgp_record r{};
     if (i < n) r = rec[i];
-    {   // largest end_position of every 64 consecutive rows: lets k6_succ step over stretches in which nothing ends beyond a chunk
-        uint32_t m = (i < n && r.end_pos != r.pos) ? (uint32_t)r.end_pos : 0u;
-        for (int d = 32; d >= 1; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d, 64));
-        if ((threadIdx.x & 63) == 0 && i < n) bmax[i >> 6] = m;
-    }
-    if (i >= n) return;
     MdRow o{(uint32_t)r.pos, (uint32_t)r.end_pos, 0u, 0u};
-    if (r.end_pos != r.pos) {
+    if (i < n && r.end_pos != r.pos) {
         bool bad = false, err = false;
         // (requested before the MD tag is walked: the common case -- this read is alone at its position -- needs nothing else)
         const uint64_t pm_prev = i ? pmax_pos[i - 1] : 0, pe_prev = i ? pmax_end[i - 1] : 0;
@@ -415,7 +409,15 @@ template <bool FULL> __global__ __launch_bounds__(256) void k6_prep(const uint8_
         o.lf = L | MD_COV | (hi == i ? MD_GST : 0u) | (bad ? MD_BAD : 0u) | (err ? MD_ERR : 0u);
         o.mb = mb;
     }
-    rows[i] = o;
+    {   // largest end_position of every 64 consecutive rows, and in its top bit whether one of them starts a position group behind
+        // uncovered ground: lets k6_succ step over stretches in which nothing ends beyond a chunk and no GAP can be taken
+        uint32_t m = (o.lf & MD_COV) ? o.end : 0u;
+        for (int d = 32; d >= 1; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d, 64));
+        const bool gap = (o.lf & MD_COV) && (o.lf & MD_GST) && o.mb < o.pos;
+        if (__ballot(gap)) m |= 0x80000000u;
+        if ((threadIdx.x & 63) == 0 && i < n) bmax[i >> 6] = m;
+    }
+    if (i < n) rows[i] = o;
 }
 
 // ---------------------------------------------------------------------------------------------- k6_chain
@@ -647,7 +649,7 @@ __device__ __forceinline__ bool arrival_irregular(const MdRow& r, uint32_t F) {
 // The same successor, computed by a whole wave (64 rows per step, ballots + one arg-max): for the few providers whose
 // window is long -- a read with a 5 kb N skip has chunk_end 5 kb away and must look at a thousand rows before one
 // ends beyond it.  Left to its own lane such a read would hold its 63 neighbours for a thousand iterations.
-__device__ Succ succ_coop(const MdRow* rows, const ParRun& R, uint64_t P, const MdRow& rp, int skip_zero, int lane) {
+__device__ Succ succ_coop(const MdRow* rows, const uint32_t* bmax, const ParRun& R, uint64_t P, const MdRow& rp, int skip_zero, int lane) {
     const uint32_t CE = rp.end, A = rp.pos + (rp.lf & MD_LMASK) - 1u;
     bool found = false, flag = false;
     uint32_t F = 0, best = SX_END, best_end = 0, allmax = 0;
@@ -656,11 +658,32 @@ __device__ Succ succ_coop(const MdRow* rows, const ParRun& R, uint64_t P, const 
     auto bcast_row = [](const MdRow& r, int l) { return MdRow{(uint32_t)__shfl((int)r.pos, l, 64), (uint32_t)__shfl((int)r.end, l, 64), (uint32_t)__shfl((int)r.lf, l, 64), (uint32_t)__shfl((int)r.mb, l, 64)}; };
     uint64_t jb = P + 1;
     int budget = SUCC_CAP;
-    for (; jb < R.endrec; jb += 64) {
+    int width = 64;
+    for (; jb < R.endrec; jb += width) {
+        // Before the first candidate the steps end on multiples of 64 rows, and whole blocks of 64 in which nothing ends beyond the chunk
+        // and no position group stands behind uncovered ground (k6_prep's per-block maximum, its top bit) are stepped over 64 blocks at a
+        // time: nothing in them is a candidate or a GAP, and what they add to "the largest end in front of the window" is their maximum.
+        // (A read with a 5 kb N skip looked at a thousand rows, 16 steps, before one ended beyond its chunk: these reads, 4 % of cfg3's,
+        // were most of k6_succ's 5.1 ms.)
+        width = found ? 64 : 64 - (int)(jb & 63);
+        if (!found && (jb & 63) == 0) {
+            bool moved = false;
+            for (;;) {
+                const uint64_t blk = (jb >> 6) + (uint64_t)lane;
+                const bool whole = (blk << 6) + 64 <= R.endrec;
+                const uint32_t bm = whole ? bmax[blk] : 0xFFFFFFFFu;
+                const uint64_t stop = __ballot(bm > CE);
+                const int nskip = stop ? __ffsll((unsigned long long)stop) - 1 : 64;
+                if (nskip) { allmax = max(allmax, wmax32(lane < nskip ? bm : 0u)); jb += 64ull * (uint64_t)nskip; moved = true; }
+                if (nskip < 64) break;
+            }
+            if (moved) { width = 0; continue; }                              // (the loop's condition looks at the new jb)
+        }
         if ((budget -= 64) < 0) { flag = true; break; }
         const uint64_t idx = jb + lane;
-        const MdRow r = idx < R.endrec ? rows[idx] : MdRow{0, 0, 0, 0};
-        const bool cov = idx < R.endrec && (r.lf & MD_COV);
+        const bool inb = lane < width && idx < R.endrec;
+        const MdRow r = inb ? rows[idx] : MdRow{0, 0, 0, 0};
+        const bool cov = inb && (r.lf & MD_COV);
         const bool hz = r.mb < r.pos;
         const bool isg = cov && skip_zero && (r.lf & MD_GST) && hz;
         const bool cand = cov && (r.pos <= CE || hz) && r.end > CE;
@@ -761,22 +784,26 @@ __global__ __launch_bounds__(256) void k6_succ(const MdRow* rows, const uint32_t
         const uint32_t L = rp.lf & MD_LMASK;
         bool ok = node && L >= 1u && A >= rp.pos && A < CE;
         uint32_t best = SX_END, best_end = 0;
-        uint64_t j = P + 1;
-        const uint64_t lim = min(R.endrec, base + (uint64_t)STAGE);
+        // (a step without a branch: written with one per case the loop spent more scalar instructions on exec masks -- 35 a row -- than
+        // vector ones on the rows, 1373 SALU + 894 VALU a wave)
+        uint32_t jr = (uint32_t)(P + 1 - base);                              // the row looked at, as an index into the staged rows
+        const uint32_t limr = (uint32_t)(min(R.endrec, base + (uint64_t)STAGE) - base);
         bool special = false, ended = false;                                 // ended: a covering read beyond A closed the window
         bool run = ok;
         while (__ballot(run)) {
-            if (run) {
-                if (j >= lim) run = false;
-                else {
-                    const MdRow r = s_rows[j - base];
-                    const bool cov = (r.lf & MD_COV) != 0;
-                    special |= cov && r.mb < r.pos;                          // (the closing read's group included: a GAP would be taken there, pileup.d:382-393)
-                    if (r.pos > A) { run = false; ended = cov; special |= !cov; }
-                    else { const uint32_t e = cov ? r.end : 0u; if (e > best_end) { best_end = e; best = (uint32_t)j; } ++j; }
-                }
-            }
+            const MdRow r = s_rows[min(jr, (uint32_t)STAGE - 1u)];
+            const bool inr = run && jr < limr;
+            const bool cov = (r.lf & MD_COV) != 0, beyond = r.pos > A;
+            const bool take = inr && !beyond;
+            special |= inr && ((cov && r.mb < r.pos) || (beyond && !cov));    // (the closing read's group included: a GAP would be taken there, pileup.d:382-393)
+            ended |= inr && beyond && cov;
+            const uint32_t e = take && cov ? r.end : 0u;
+            best = e > best_end ? (uint32_t)base + jr : best;
+            best_end = max(best_end, e);
+            jr += take ? 1u : 0u;
+            run = take;
         }
+        const uint64_t j = base + jr;
         ok = ok && !special && best_end > CE && (ended || j >= R.endrec);      // (stopped by the staged rows' end: not decided here)
         if (ok) {
             if (ended || A < R.run_end) {                                    // FETCH at A; at the run's end only if it comes before the end of coverage
@@ -860,7 +887,7 @@ __global__ __launch_bounds__(256) void k6_succ(const MdRow* rows, const uint32_t
         const MdRow rs = s_rows[(threadIdx.x & ~63u) + src];
         ParRun Rs;
         Rs.first = __shfl(R.first, src, 64); Rs.endrec = __shfl(R.endrec, src, 64); Rs.run_end = (uint32_t)__shfl((int)R.run_end, src, 64); Rs.ce_in = 0; Rs.active = 0; Rs.pad = 0;
-        const Succ c = succ_coop(rows, Rs, Ps, rs, skip_zero, lane);
+        const Succ c = succ_coop(rows, bmax, Rs, Ps, rs, skip_zero, lane);
         if (lane == src) res = c;
     }
     if (P < n) succ[P] = res;
