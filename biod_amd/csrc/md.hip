@@ -230,6 +230,21 @@ __device__ void dna_restore(DnaState& st, const uint8_t* s, const bgp_record& r,
     QIter& q = st.q; q.cg = s + r.rec_off + 36 + l_name; q.sq = q.cg + 4ull * n_cig; q.n_cig = n_cig; q.op = ck.q_op; q.in_op = ck.q_in; q.q = ck.q_q; q.empty = ck.q_empty != 0;
     q_load(q);
 }
+// eight bases of the packed SEQ from query offset q on, as chars ("=ACMGRSVTWYHKDBN", base.d:85): one 8-byte load, the nibbles brought
+// to an even start, four codes a v_perm pair -- where a base a step was a byte load, a table shift and a byte store
+__device__ __forceinline__ uint64_t seq_chars8(const uint8_t* sq, uint32_t q) {
+    unsigned long long w; __builtin_memcpy(&w, sq + (q >> 1), 8);
+    if (q & 1u) w = ((w << 4) & 0xF0F0F0F0F0F0F0F0ull) | ((w >> 12) & 0x0F0F0F0F0F0F0F0Full);      // byte i: low nibble of byte i, high nibble of byte i + 1
+    const uint32_t w4 = (uint32_t)w, hi = (w4 >> 4) & 0x0F0F0F0Fu, lo = w4 & 0x0F0F0F0Fu;            // the even and the odd bases of four bytes
+    const uint32_t ca = __builtin_amdgcn_perm(hi, lo, 0x01050004u), cb = __builtin_amdgcn_perm(hi, lo, 0x03070206u);   // codes of bases 0..3 and 4..7, a byte each
+    auto chars4 = [](uint32_t c) {
+        const uint32_t sel = c & 0x07070707u, m8 = ((c >> 3) & 0x01010101u) * 0xFFu;
+        const uint32_t l = __builtin_amdgcn_perm(0x56535247u, 0x4D43413Du, sel), h = __builtin_amdgcn_perm(0x4E42444Bu, 0x48595754u, sel);
+        return (l & ~m8) | (h & m8);
+    };
+    return ((unsigned long long)chars4(cb) << 32) | chars4(ca);
+}
+
 // Runs until `stop` chars have been yielded or the range ends; chars with index >= from go to out[index - from]
 // (out may be null: then SEQ is never read).
 __device__ void dna_run(DnaState& st, const uint8_t* s, uint32_t from, uint32_t stop, uint8_t* out, bool* bad) {
@@ -246,6 +261,18 @@ __device__ void dna_run(DnaState& st, const uint8_t* s, uint32_t from, uint32_t 
             q_pop(st.q);
         } else if (st.cur.type == 0) {
             if (st.q.empty) { *bad = true; st.live = false; return; }
+            // a match run inside one M / = / X op: eight bases at a time (the pops of eight bases that stay inside the op are
+            // q += 8, in_op += 8; SEQ's bytes behind the eighth base are the read's own -- SEQ, then QUAL)
+            if (keep && st.cur.match >= 8u && (st.q.raw >> 4) - st.q.in_op >= 8u && stop - st.n >= 8u) {
+                const unsigned long long c8 = seq_chars8(st.q.sq, st.q.q);
+                __builtin_memcpy(out + (st.n - from), &c8, 8);
+                st.n += 8; st.cur.match -= 8; st.q.q += 8; st.q.in_op += 8;
+                q_settle(st.q);
+                if (st.cur.match != 0) continue;
+                if (md_empty(st.m)) { st.live = false; return; }
+                st.cur = st.m.front; mdf_pop_front(st.m);
+                continue;
+            }
             if (keep) out[st.n - from] = q_front(st.q);
             ++st.n;
             --st.cur.match;
@@ -310,6 +337,7 @@ __device__ uint32_t dna_walk(const uint8_t* s, const bgp_record& r, uint32_t fro
     DnaState st;
     dna_begin(st, s, r, err);
     if (*err) return 0;
+    if (out && from) dna_skip(st, from);       // an MD operation at a time up to the first char wanted (a range that stalls in front of it yields none: *bad is only told for from == 0)
     dna_run(st, s, from, out ? from + count : 0xFFFFFFFFu, out, bad);
     return st.n;
 }
