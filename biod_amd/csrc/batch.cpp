@@ -128,14 +128,19 @@ static void close_fill(Batch* b) {
     b->fullq[b->n_full++] = b->fill;
     next_fill(b);
 }
+// full: no room for another inflated BGZF block (64 KiB, constants.d:26-61) -- a caller that writes whole blocks through acquire / commit
+// could otherwise be handed a tail it can never use, with no way to move on.  (Batches smaller than that are full when they are full.)
 static bool fill_is_full(const Batch* b) {
-    return b->fill >= 0 && b->host_len[b->fill] && b->batch_bytes - b->host_len[b->fill] < std::min<uint64_t>(b->batch_bytes, 65536);
+    if (b->fill < 0 || !b->host_len[b->fill]) return false;
+    const uint64_t room = b->batch_bytes - b->host_len[b->fill];
+    return room == 0 || (b->batch_bytes > 65536 && room < 65536);
 }
 // A buffer to write into: a full one is closed and leaves for the device the moment a device buffer is free -- at the commit / push
 // that filled it, or when the batch before last gives up its device buffer (process_next).  BGP_EAGAIN: every pinned buffer is full
 // and both device buffers are taken -- hand out windows first.  The buffer was the source of a copy a while ago: wait for that copy.
-static int fill_ready(bgp_ctx* c, Batch* b) {
-    if (fill_is_full(b)) close_fill(b);
+static int fill_ready(bgp_ctx* c, Batch* b, bool whole_blocks = false) {
+    // (bgp_batch_acquire never hands out a tail shorter than an inflated BGZF block -- with batches of less than 64 KiB: no tail at all)
+    if (fill_is_full(b) || (whole_blocks && b->fill >= 0 && b->host_len[b->fill] && b->batch_bytes - b->host_len[b->fill] < std::min<uint64_t>(b->batch_bytes, 65536))) close_fill(b);
     BGP_TRY(ship_ready(c, b));
     if (b->fill < 0) next_fill(b);
     if (b->fill < 0) return BGP_EAGAIN;
@@ -288,7 +293,7 @@ int bgp_batch_acquire(bgp_ctx* c, uint8_t** ptr, size_t* cap) {
     *ptr = nullptr; *cap = 0;
     // a buffer with less room than one BGZF block inflates to (64 KiB, constants.d:26-61) is shipped as it is: a caller that writes
     // whole blocks could otherwise be handed a tail it can never use, with no way to move on
-    { const int rc = fill_ready(c, b); if (rc != BGP_OK) return rc; }      // BGP_EAGAIN: hand out windows first
+    { const int rc = fill_ready(c, b, true); if (rc != BGP_OK) return rc; }      // BGP_EAGAIN: hand out windows first
     const int h = b->fill;
     *ptr = b->host[h].as<uint8_t>() + b->host_len[h]; *cap = (size_t)(b->batch_bytes - b->host_len[h]);
     b->acq = h; b->acq_off = b->host_len[h];

@@ -544,6 +544,7 @@ __global__ __launch_bounds__(64) void k6_chain(const MdRow* rows, const ChainRun
         P = R.rs_P; ci = R.rs_ci; y = R.rs_y; i = R.rs_i;
         if (P != MD_NONE) { load(P); const uint32_t lf = __shfl(row.lf, 0, 64); L = lf & MD_LMASK; bad = (lf & MD_BAD) != 0; if (ci < L) emit(y + 1, ci, P); }
         started = true;
+        save();      // a batch of a few reads may hold no event in front of its cut: the chain then stands where it stood, and the next batch resumes from this very state (it is not "begun afresh")
     } else started = init_at(R.first, true);
     if (started) {
         for (;;) {

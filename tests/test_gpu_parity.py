@@ -1775,6 +1775,26 @@ def _batched_refbase(ctx, pieces, batch, skip):
     return cat(ref, np.int64), cat(pos, np.int64), cat(rb, np.uint8)
 
 
+@pytest.mark.parametrize("seed", range(8))
+def test_batched_reference_base_batches_of_a_few_reads(ctx, seed):
+    """use_md_tag across batches of ONE TO TEN reads (bgp_batch_acquire ships whatever a small buffer holds): a batch may hold no event of
+    the provider chain in front of its cut -- the chain then stands where it stood and the next batch resumes from the same state
+    (until round 4 it was begun afresh there: wrong bases wherever a provider outlived such a batch; found by scratch/fuzz_tiny_batches.py)."""
+    rng = np.random.default_rng(7130 + seed)
+    st = _md_stream(rng, int(rng.integers(60, 500)), **_MD_CFGS[seed % len(_MD_CFGS)])
+    for skip in (True, False):
+        try:
+            ora = O.pileup(st, use_md=True, skip_zero=skip)
+        except O.OracleError:
+            continue
+        pos, rb = [], []
+        for w in ctx.batched_windows_zero_copy(_pieces(st, int(rng.integers(200, 1500))), 4096, window_positions=3000, use_md_tag=True, skip_zero_coverage=skip):
+            nz = np.nonzero(w.columns["coverage"])[0]
+            pos.append(w.first_position + nz.astype(np.int64)); rb.append(w.reference_base[nz])
+        keep = ora.cov > 0
+        assert np.array_equal(np.concatenate(pos), ora.pos[keep].astype(np.int64)) and np.array_equal(np.concatenate(rb), ora.refbase[keep]), skip
+
+
 @pytest.mark.parametrize("skip", [True, False])
 @pytest.mark.parametrize("name,batch", [("illu_20_chunk.bam", 4096), ("b7_295_chunk.bam", 20_000), ("b7_295_chunk.bam", 70_000), ("ex1_header.bam", 30_000), ("tags.bam", 8192)])
 def test_batched_staging_reference_base_fixtures(ctx, data_dir, name, batch, skip):
