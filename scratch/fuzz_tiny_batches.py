@@ -34,4 +34,21 @@ for k in range(n):
                 print("MISMATCH seed", seed0 + k, "skip", skip, "piece", piece, "len", len(st), "positions equal", np.array_equal(pos, ora.pos[keep].astype(np.int64)), "first diffs", [(int(pos[i]), chr(rb[i]), chr(ora.refbase[keep][i])) for i in d[:5]], "n diff", len(d))
         except Exception as e:
             bad += 1; print("EXC seed", seed0 + k, "skip", skip, "piece", piece, type(e).__name__, e)
+    # columns and per-read entries (stream-wide ordinals) across the same kind of batches: random CIGARs, every field of every entry
+    st = T._random_stream(rng, int(rng.integers(30, 500)), quirks=False)
+    try:
+        ora = O.pileup(st, want_entries=True)
+    except O.OracleError:
+        continue
+    piece = int(rng.integers(150, 2500))
+    try:
+        ref, pos, cols, ents, _ = T._covered(ctx.batched_windows_zero_copy(T._pieces(st, piece), 4096, want_entries=True, window_positions=int(rng.integers(50, 2000))), want_entries=True)
+        T._assert_columns_equal_oracle(ref, pos, cols, ora)
+        assert len(ents) == ora.n_columns
+        for kk in range(ora.n_columns):
+            oe = ora.entries[int(ora.entry_off[kk]):int(ora.entry_off[kk + 1])]
+            for f in ("read_ordinal", "cigar_op_index", "cigar_op_offset", "query_offset", "base", "qual"):
+                assert np.array_equal(ents[kk][f].astype(np.int64), oe[f].astype(np.int64)), (kk, f)
+    except Exception as e:
+        bad += 1; print("ENTRIES seed", seed0 + k, "piece", piece, type(e).__name__, str(e)[:200])
 print(n, "rounds,", bad, "failures,", round(time.time() - t0, 1), "s")
