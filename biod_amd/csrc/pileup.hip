@@ -2087,31 +2087,71 @@ __global__ __launch_bounds__(256, BGP_K5_MINW) void k5_fill_blk(K5Args a) {
                 // any other read: the cursor at the block's first column of the read, found ONCE for the 64 lanes (for a long read from
                 // the window's checkpoint: every lane walking there by itself was ~35 dependent CIGAR loads per entry on cfg5)
                 uint32_t bk = 0, bcs = 0, bqs = 0; bool bst = false;
+                const bool mine = valid && (uint64_t)(uint32_t)q.pos <= p && (uint64_t)(uint32_t)q.end_pos > p;      // the read covers this lane's column
+                // A read walked from its window's checkpoint: WHICH op owns each of the block's columns is settled by the wave, 64 ops a step
+                // with a lane an op -- two scans give every op its first column and query base, an op that owns columns of the block leaves its
+                // lane number at the first of them (LDS, 64 words), a running maximum over the columns hands every column its op, three
+                // ds_bpermute its data.  (Every lane then walking from the block's first column by itself was a CIGAR load per op and
+                // lane: cfg5, an op every ~10 columns, 3.5 ms for 1.2 * 10^8 entries.)
+                bool res = false; uint32_t r_ix = 0xFFFFu, r_off = 0, r_qo = 0; bool r_hit = false, r_qc = false;
                 if (!small) {
                     const uint32_t rr0 = (uint32_t)(max(p0, (uint64_t)(uint32_t)q.pos) - (uint32_t)q.pos);
                     entry_cursor(q, rr0, (uint32_t)(base + (uint64_t)src), a, &bk, &bcs, &bqs, &bst);
                     if (bst) {
                         const uint32_t n_cig = q.flag_nc & 0xFFFFu;
                         const uint8_t* cg = a.s + q.rec_off + 36 + (q.bin_mq_nl & 0xFFu);
-                        while (bk < n_cig) {                                      // 64 ops a step, lane = op: the first column-owning op that reaches past rr0
+                        const uint32_t c0 = (uint32_t)(max(p0, (uint64_t)(uint32_t)q.pos) - p0);      // the read's first column of the block
+                        const uint32_t rrc = (uint32_t)(p - (uint32_t)q.pos);                          // this lane's column, counted from the read's first
+                        uint32_t* const mk = reinterpret_cast<uint32_t*>(list);                         // (the list is empty here: flush_list above)
+                        while (bk < n_cig && __ballot(mine && !res)) {
                             const uint32_t kk = bk + (uint32_t)lane;
                             const uint32_t op = kk < n_cig ? ld_u32(cg + 4ull * kk) : 0u;
                             const bool on = kk < n_cig, qc = on && cig_qc(op), rc = on && cig_rc(op);
                             const uint32_t len = op >> 4, elen = len ? len : 1u;
                             const uint32_t cl = rc ? elen : 0u, ql = qc ? (rc ? elen : len) : 0u;
                             const uint32_t ic = wave_incl_u32(cl, lane), iq = wave_incl_u32(ql, lane);
-                            const unsigned long long hm = __ballot(rc && rr0 < bcs + ic);
-                            if (hm) {
-                                const int L = __ffsll((long long)hm) - 1;
-                                bcs += (uint32_t)__builtin_amdgcn_readlane((int)(ic - cl), L); bqs += (uint32_t)__builtin_amdgcn_readlane((int)(iq - ql), L);
-                                bk += (uint32_t)L;
-                                break;
+                            const uint32_t s_k = bcs + ic - cl, q_k = bqs + iq - ql;                   // the op's first column; the query bases in front of it
+                            mk[lane] = 0u;
+                            __builtin_amdgcn_wave_barrier();
+                            if (cl && s_k + cl > rr0) { const uint32_t at = max(s_k, rr0) - rr0 + c0; if (at < 64u) mk[at] = (uint32_t)lane + 1u; }
+                            __builtin_amdgcn_wave_barrier();
+                            uint32_t own = mk[lane];
+#pragma unroll
+                            for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)own, d, 64); if (lane >= d) own = max(own, o); }
+                            const int ol = (int)own - 1;
+                            const uint32_t so = (uint32_t)__shfl((int)s_k, ol < 0 ? 0 : ol, 64), qo = (uint32_t)__shfl((int)q_k, ol < 0 ? 0 : ol, 64), ow = (uint32_t)__shfl((int)op, ol < 0 ? 0 : ol, 64);
+                            const uint32_t olen = (ow >> 4) ? (ow >> 4) : 1u;
+                            if (mine && !res && own && rrc >= so && rrc - so < olen) {
+                                res = true; r_hit = true; r_ix = bk + (uint32_t)ol; r_off = rrc - so; r_qc = cig_qc(ow) != 0; r_qo = qo + (r_qc ? r_off : 0u);
                             }
+                            __builtin_amdgcn_wave_barrier();
                             bcs += (uint32_t)__builtin_amdgcn_readlane((int)ic, 63); bqs += (uint32_t)__builtin_amdgcn_readlane((int)iq, 63);
                             bk = min(bk + 64u, n_cig);
                         }
                     }
                 }
+                if (!small && bst) {
+                    if (mine) {      // the entry as entry_walk writes it (a column no op owns: the cursor ran off the CIGAR, pileup.d:224-228)
+                        bgp_entry e; e.read_ordinal = (uint32_t)(base + (uint64_t)src); e.cigar_op_index = (uint16_t)(r_hit ? r_ix : 0xFFFFu);
+                        e.cigar_op_offset = r_hit ? r_off : 0u; e.query_offset = r_hit ? r_qo : 0u; e.base = 0xFF; e.qual = 0xFF;
+                        if (r_hit && !r_qc) { e.base = '-'; e.qual = 255; }
+                        else if (r_hit && r_qo < (uint32_t)q.l_seq) {
+                            const uint8_t* sq = a.s + q.rec_off + 36 + (q.bin_mq_nl & 0xFFu) + 4ull * (q.flag_nc & 0xFFFFu);
+                            const uint32_t byte = sq[r_qo >> 1], code = (r_qo & 1u) ? (byte & 0xFu) : (byte >> 4);
+                            const uint64_t lo = 0x565352474D43413Dull, hi = 0x4E42444B48595754ull;   // "=ACMGRSVTWYHKDBN", base.d:85
+                            e.base = (uint8_t)(((code & 8u) ? hi : lo) >> ((code & 7u) * 8));
+                            e.qual = sq[(uint32_t)((q.l_seq + 1) / 2) + r_qo];
+                        }
+                        uint4 v; __builtin_memcpy(&v, &e, 16);
+                        ring[cnt & (K5R - 1)][lane] = v;
+                        ++cnt;
+                        if ((cnt & (K5R - 1)) == 0) {
+#pragma unroll
+                            for (int k = 0; k < K5R; ++k) { const uint4 x = ring[k][lane]; __builtin_memcpy(a.entries + w + k, &x, 16); }
+                            w += K5R;
+                        }
+                    }
+                } else
                 if (valid && (uint64_t)(uint32_t)q.pos <= p && (uint64_t)(uint32_t)q.end_pos > p) {
                     bgp_entry e;
                     if (small) e = entry_of_ops(a.s, q, ops, (uint32_t)(p - (uint32_t)q.pos), (uint32_t)(base + (uint64_t)src));
