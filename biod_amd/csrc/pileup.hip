@@ -2045,6 +2045,15 @@ __global__ __launch_bounds__(256, BGP_K5_MINW) void k5_fill_blk(K5Args a) {
         bool hit = false;
         uint4 c4 = make_uint4(0, 0, 0, 0);
         if (i < i_hi) { r = a.rec[i]; hit = r.end_pos != r.pos && (uint64_t)(uint32_t)r.pos < p1 && (uint64_t)(uint32_t)r.end_pos > p0; if (hit && a.cig4) c4 = a.cig4[i]; }
+        // a long read's checkpoint for the window its first column of the block lies in, asked for here by the read's own lane: 64 rows'
+        // two dependent loads at once, not two round trips for every long read in its turn
+        Ckpt ckr{0xFFFFFFFFu, 0u, 0u, 0u};
+        const bool ckd = hit && a.ck && wants_ckpt(r.flag_nc & 0xFFFFu, (uint32_t)r.l_seq);
+        if (ckd) {
+            const uint64_t rr0 = max(p0, (uint64_t)(uint32_t)r.pos) - (uint32_t)r.pos;
+            const uint64_t wj = ((uint64_t)(uint32_t)r.pos + rr0 - a.run.start_pos) / a.ck_w - ((uint64_t)(uint32_t)r.pos - a.run.start_pos) / a.ck_w;
+            ckr = a.ck[a.ck_off[i] + wj];
+        }
         const bool small_r = hit && a.cig4 && (r.flag_nc & 0xFFFFu) <= 3u;      // (three ops: the list's third slot carries them and the read's ordinal)
         unsigned long long mh = __ballot(hit);
         const unsigned long long ms = __ballot(small_r);
@@ -2096,7 +2105,11 @@ __global__ __launch_bounds__(256, BGP_K5_MINW) void k5_fill_blk(K5Args a) {
                 bool res = false; uint32_t r_ix = 0xFFFFu, r_off = 0, r_qo = 0; bool r_hit = false, r_qc = false;
                 if (!small) {
                     const uint32_t rr0 = (uint32_t)(max(p0, (uint64_t)(uint32_t)q.pos) - (uint32_t)q.pos);
-                    entry_cursor(q, rr0, (uint32_t)(base + (uint64_t)src), a, &bk, &bcs, &bqs, &bst);
+                    if (__builtin_amdgcn_readlane((int)ckd, src)) {      // entry_cursor, from what the read's lane loaded with its row
+                        const uint32_t k_ = (uint32_t)__builtin_amdgcn_readlane((int)ckr.k, src);
+                        if (k_ != 0xFFFFFFFFu) { bk = k_; bcs = (uint32_t)__builtin_amdgcn_readlane((int)ckr.cs, src); bqs = (uint32_t)__builtin_amdgcn_readlane((int)ckr.qs, src); bst = true; }
+                        else bk = q.flag_nc & 0xFFFFu;                    // the cursor ran off the CIGAR before this window (pileup.d:224-228)
+                    }
                     if (bst) {
                         const uint32_t n_cig = q.flag_nc & 0xFFFFu;
                         const uint8_t* cg = a.s + q.rec_off + 36 + (q.bin_mq_nl & 0xFFu);
