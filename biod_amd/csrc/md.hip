@@ -1093,47 +1093,60 @@ struct EmitRun { uint64_t first, endrec, column_base; uint32_t start_pos, end_po
 struct LongNode { uint32_t rec, from, count, ck_base; uint64_t out_off; };
 __global__ __launch_bounds__(64) void k6_emit(const uint8_t* s, const bgp_record* rec, const MdRow* rows, const Succ* succ, const Succ* seg_entry, uint64_t slot_lo, uint64_t slot_n,
                                               const EmitRun* er, uint32_t n_runs, ParOut* po, uint8_t* refbase, LongNode* longs, uint32_t longs_cap, unsigned int* ctr, int verify) {
-    __shared__ uint32_t nd[SEG + 1], fc[SEG + 1];
-    __shared__ uint32_t s_cnt, s_run;
+    // (the segment's providers in stretches of EM_CH: with room for a whole segment's 2048 -- 16 KB a block of one wave -- ten blocks shared
+    // a CU and its 40 wave slots; a segment of cfg3 has ~32 providers)
+    constexpr uint32_t EM_CH = 192;
+    __shared__ uint32_t nd[EM_CH + 1], fc[EM_CH + 1];
+    __shared__ uint32_t s_cnt, s_run, s_more;
     if (blockIdx.x >= slot_n) return;
     const Succ ent = seg_entry[slot_lo + blockIdx.x];
     if (ent.nxt >= SX_NONE) return;
     const uint64_t seg = ent.nxt / SEG;
+    uint32_t node = ent.nxt, F0 = ent.fcol, hops = 0;                 // (thread 0's: where the chain stands between two stretches)
     if (threadIdx.x == 0) {
         uint32_t lo_r = 0, hi_r = n_runs;
         while (hi_r - lo_r > 1) { const uint32_t m = (lo_r + hi_r) >> 1; if (er[m].first <= ent.nxt) lo_r = m; else hi_r = m; }
-        const EmitRun R = er[lo_r];
-        uint32_t node = ent.nxt, F = ent.fcol, k = 0;
-        const uint64_t lo = seg * SEG, hi = lo + SEG;
-        for (;;) {
-            nd[k] = node; fc[k] = F; ++k;
-            const Succ e = succ[node];
-            if (e.nxt >= SX_NONE) { fc[k] = R.end_pos; po[lo_r].ce_out = rows[node].end; break; }     // the chain ends here: this run's chunk_end carried to the next reference
-            node = e.nxt; F = e.fcol & ~SX_FLAG;
-            if (node >= hi || k >= SEG) { fc[k] = F; break; }
-        }
-        s_cnt = k; s_run = lo_r;
+        s_run = lo_r;
     }
     __syncthreads();
     const EmitRun R = er[s_run];
-    for (uint32_t k = threadIdx.x; k < s_cnt; k += 64) {
-        const uint32_t F = fc[k];
-        uint32_t endc = fc[k + 1];
-        if (endc > R.end_pos) endc = R.end_pos;
-        if (verify) {                                         // this provider's real tag against what the rows assumed of it (k6_prep<false>)
-            bool vb, ve;
-            const uint32_t Lt = dna_length(s, rec[nd[k]], &vb, &ve);
-            if (vb || ve || Lt != dna_length_by_cigar(s, rec[nd[k]], nullptr)) po[s_run].flagged = 1u;
+    for (;;) {
+        if (threadIdx.x == 0) {
+            const uint64_t hi = seg * SEG + SEG;
+            uint32_t k = 0, more = 0;
+            for (;;) {
+                nd[k] = node; fc[k] = F0; ++k; ++hops;
+                const Succ e = succ[node];
+                if (e.nxt >= SX_NONE) { fc[k] = R.end_pos; po[s_run].ce_out = rows[node].end; break; }     // the chain ends here: this run's chunk_end carried to the next reference
+                node = e.nxt; F0 = e.fcol & ~SX_FLAG;
+                if (node >= hi || hops >= (uint32_t)SEG) { fc[k] = F0; break; }
+                if (k >= EM_CH) { fc[k] = F0; more = 1; break; }
+            }
+            s_cnt = k; s_more = more;
         }
-        if (F >= endc) continue;
-        if (endc - F > DNA_LONG) {
-            const uint32_t at = atomicAdd(&ctr[0], 1u), pieces = (endc - F + DNA_CK - 1) / DNA_CK;
-            const uint32_t base = atomicAdd(&ctr[1], pieces);
-            if (at < longs_cap) longs[at] = LongNode{nd[k], F - rows[nd[k]].pos, endc - F, base, R.column_base + (F - R.start_pos)};
-            continue;
+        __syncthreads();
+        const uint32_t cnt = s_cnt, more = s_more;
+        for (uint32_t k = threadIdx.x; k < cnt; k += 64) {
+            const uint32_t F = fc[k];
+            uint32_t endc = fc[k + 1];
+            if (endc > R.end_pos) endc = R.end_pos;
+            if (verify) {                                         // this provider's real tag against what the rows assumed of it (k6_prep<false>)
+                bool vb, ve;
+                const uint32_t Lt = dna_length(s, rec[nd[k]], &vb, &ve);
+                if (vb || ve || Lt != dna_length_by_cigar(s, rec[nd[k]], nullptr)) po[s_run].flagged = 1u;
+            }
+            if (F >= endc) continue;
+            if (endc - F > DNA_LONG) {
+                const uint32_t at = atomicAdd(&ctr[0], 1u), pieces = (endc - F + DNA_CK - 1) / DNA_CK;
+                const uint32_t base = atomicAdd(&ctr[1], pieces);
+                if (at < longs_cap) longs[at] = LongNode{nd[k], F - rows[nd[k]].pos, endc - F, base, R.column_base + (F - R.start_pos)};
+                continue;
+            }
+            bool bad, err;
+            dna_walk(s, rec[nd[k]], F - rows[nd[k]].pos, endc - F, refbase + R.column_base + (F - R.start_pos), &bad, &err);
         }
-        bool bad, err;
-        dna_walk(s, rec[nd[k]], F - rows[nd[k]].pos, endc - F, refbase + R.column_base + (F - R.start_pos), &bad, &err);
+        if (!more) break;
+        __syncthreads();                                          // (the stretch's entries are read: thread 0 may write the next)
     }
 }
 

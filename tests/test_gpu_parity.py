@@ -1775,6 +1775,31 @@ def _batched_refbase(ctx, pieces, batch, skip):
     return cat(ref, np.int64), cat(pos, np.int64), cat(rb, np.uint8)
 
 
+def test_reference_base_every_read_a_provider(ctx):
+    """Short reads at coverage ~1.3: nearly every read of a 2048-record segment is a provider, so k6_emit hands a segment's providers
+    out in several stretches (its list in LDS holds 192); mismatches and deletions in the tags so that the bases differ by provider."""
+    rng = np.random.default_rng(4242)
+    recs, pos = [], 50
+    for i in range(5000):
+        n = int(rng.integers(8, 14))
+        seq = "".join("ACGT"[int(x)] for x in rng.integers(0, 4, n))
+        kind = int(rng.integers(0, 4))
+        if kind == 0:
+            ops, md = [(n, "M")], str(n)
+        elif kind == 1:
+            k = int(rng.integers(0, n)); ops, md = [(n, "M")], f"{k}{'ACGT'[int(rng.integers(0, 4))]}{n - k - 1}"
+        elif kind == 2:
+            k = int(rng.integers(1, n)); ops, md = [(k, "M"), (2, "D"), (n - k, "M")], f"{k}^{'ACGT'[int(rng.integers(0, 4))]}{'ACGT'[int(rng.integers(0, 4))]}{n - k}"
+        else:
+            k = int(rng.integers(1, n - 1)); ops, md = [(k, "M"), (1, "I"), (n - k - 1, "M")], str(n - 1)
+        recs.append(bamio.pack_record(f"p{i}", seq, ops, ref_id=0, pos=pos, tags=bamio.tag_z("MD", md)))
+        pos += int(rng.integers(5, 11))
+    st = b"".join(recs)
+    stage(ctx, st)
+    for skip in (True, False):
+        _check_refbase(ctx, st, skip_zero=skip, window=4000)
+
+
 @pytest.mark.parametrize("seed", range(8))
 def test_batched_reference_base_batches_of_a_few_reads(ctx, seed):
     """use_md_tag across batches of ONE TO TEN reads (bgp_batch_acquire ships whatever a small buffer holds): a batch may hold no event of
