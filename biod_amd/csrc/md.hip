@@ -469,10 +469,18 @@ struct ChainOut { uint32_t ce_out, n_iv; int32_t err; uint32_t sv_have; int64_t 
 struct MdIv { uint32_t col, c0; uint64_t prov; };
 constexpr uint64_t MD_NONE = ~0ull, MD_INF = 1ull << 62;
 
-__device__ __forceinline__ uint64_t wave_max_u64(uint64_t v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) { const uint64_t o = __shfl_xor(v, d, 64); v = o > v ? o : v; }
-    return v;
+// the largest value of the wave, in every lane: DPP inside the rows of 16, the rows' maxima carried over (six instructions and a
+// readlane; the butterfly of __shfl_xor was six ds_bpermute round trips through the LDS for 32 bits, twelve for 64)
+#define MD_DPP(v, ctrl, rmask) (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), ctrl, rmask, 0xF, false)
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+    v = max(v, MD_DPP(v, 0xB1, 0xF)); v = max(v, MD_DPP(v, 0x4E, 0xF)); v = max(v, MD_DPP(v, 0x141, 0xF)); v = max(v, MD_DPP(v, 0x140, 0xF));
+    v = max(v, MD_DPP(v, 0x142, 0xA)); v = max(v, MD_DPP(v, 0x143, 0xC));
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ uint64_t wave_max_u64(uint64_t v) {      // (the high words' maximum, then the low words' among the lanes that hold it)
+    const uint32_t hi = (uint32_t)(v >> 32), mh = wave_max_u32(hi);
+    const uint32_t ml = wave_max_u32(hi == mh ? (uint32_t)v : 0u);
+    return ((uint64_t)mh << 32) | ml;
 }
 
 __global__ __launch_bounds__(64) void k6_chain(const MdRow* rows, const ChainRun* cr, ChainOut* co, MdIv* iv, int skip_zero) {
@@ -683,8 +691,8 @@ __device__ Succ succ_coop(const MdRow* rows, const uint32_t* bmax, const ParRun&
     bool found = false, flag = false;
     uint32_t F = 0, best = SX_END, best_end = 0, allmax = 0;
     MdRow bestrow{0, 0, 0, 0};
-    auto wmax32 = [](uint32_t v) { for (int d = 32; d >= 1; d >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, d, 64)); return v; };
-    auto bcast_row = [](const MdRow& r, int l) { return MdRow{(uint32_t)__shfl((int)r.pos, l, 64), (uint32_t)__shfl((int)r.end, l, 64), (uint32_t)__shfl((int)r.lf, l, 64), (uint32_t)__shfl((int)r.mb, l, 64)}; };
+    auto wmax32 = [](uint32_t v) { return wave_max_u32(v); };
+    auto bcast_row = [](const MdRow& r, int l) { return MdRow{(uint32_t)__builtin_amdgcn_readlane((int)r.pos, l), (uint32_t)__builtin_amdgcn_readlane((int)r.end, l), (uint32_t)__builtin_amdgcn_readlane((int)r.lf, l), (uint32_t)__builtin_amdgcn_readlane((int)r.mb, l)}; };      // (l is the same in every lane)
     uint64_t jb = P + 1;
     int budget = SUCC_CAP;
     int width = 64;
@@ -787,6 +795,60 @@ __global__ __launch_bounds__(256) void k6_succ(const MdRow* rows, const uint32_t
     const uint64_t base = (uint64_t)blockIdx.x * blockDim.x;
     for (int t = threadIdx.x; t < STAGE; t += 256) s_rows[t] = base + t < n ? rows[base + t] : MdRow{0, 0, 0, 0};
     __syncthreads();
+#if !BGP_SUCC_SCAN
+    // "First read with the largest end among rows (P, hi]" for 256 overlapping windows of the same 512 staged rows is a range-maximum
+    // query: a sparse table over the rows' ends (key = end relative to the first staged position, then 511 - row, so that the
+    // maximum of two keys is the larger end and, of equal ends, the earlier row), built once by the workgroup -- nine levels of two
+    // entries a thread -- and asked twice a lane; where the window ends is a binary search over the staged positions, whether a
+    // position group in it stands behind uncovered ground a difference of two prefix counts.  (A lane looking at its ~30-50 rows
+    // one by one, all lanes as long as the slowest: 810 of the kernel's 1270 VALU instructions a wave.)  Ends that do not fit the
+    // key's 22 bits (an N skip of megabases) send the workgroup through the row loop below instead.
+    constexpr int LV = 9;
+    __shared__ uint32_t s_key[LV][STAGE];
+    __shared__ uint32_t s_sp[STAGE + 1];                                      // rows in front of row j that stand behind uncovered ground
+    __shared__ uint32_t s_wsum[8], s_fallback;
+    const uint32_t pos_base = s_rows[0].pos;
+    if (threadIdx.x == 0) s_fallback = 0u;
+    __syncthreads();
+    {
+        uint32_t spc[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int j = 2 * (int)threadIdx.x + h;
+            const MdRow r = s_rows[j];
+            const bool cov = (r.lf & MD_COV) != 0;
+            const uint32_t rel = r.end - pos_base;
+            if (cov && (r.end < pos_base || rel >= (1u << 22))) s_fallback = 1u;
+            s_key[0][j] = cov ? ((rel + 1u) << 9) | (uint32_t)(STAGE - 1 - j) : 0u;      // (never 0 for a covering row)
+            spc[h] = cov && r.mb < r.pos ? 1u : 0u;
+        }
+        // exclusive prefix of the "behind uncovered ground" marks: a thread's two rows, the wave, the four waves
+        const uint32_t mine = spc[0] + spc[1];
+        uint32_t inc = mine;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)inc, d, 64); if ((int)(threadIdx.x & 63) >= d) inc += o; }
+        if ((threadIdx.x & 63) == 63) s_wsum[threadIdx.x >> 6] = inc;
+        __syncthreads();
+        uint32_t before = 0;
+        for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) before += s_wsum[w];
+        const uint32_t ex = before + inc - mine;
+        s_sp[2 * threadIdx.x] = ex; s_sp[2 * threadIdx.x + 1] = ex + spc[0];
+        if (threadIdx.x == 255) s_sp[STAGE] = ex + mine;
+#pragma unroll 1
+        for (int k = 1; k < LV; ++k) {
+            __syncthreads();
+            const int half = 1 << (k - 1);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int j = (int)threadIdx.x + 256 * h;
+                const uint32_t a0 = s_key[k - 1][j], a1 = j + half < STAGE ? s_key[k - 1][j + half] : 0u;
+                s_key[k][j] = max(a0, a1);
+            }
+        }
+        __syncthreads();
+    }
+    const bool table_ok = s_fallback == 0u;
+#endif
 #if BGP_SUCC_SCAN
     auto row_at = [&](uint64_t j) -> MdRow { const uint64_t d = j - base; return d < (uint64_t)STAGE ? s_rows[d] : rows[j]; };
 #endif
@@ -818,7 +880,21 @@ __global__ __launch_bounds__(256) void k6_succ(const MdRow* rows, const uint32_t
         uint32_t jr = (uint32_t)(P + 1 - base);                              // the row looked at, as an index into the staged rows
         const uint32_t limr = (uint32_t)(min(R.endrec, base + (uint64_t)STAGE) - base);
         bool special = false, ended = false;                                 // ended: a covering read beyond A closed the window
-        bool run = ok;
+        bool run = ok && !table_ok;
+        if (table_ok && ok) {
+            // rows [jr, je): the rows behind P that start at or before A (the staged rows of a run are sorted by position)
+            uint32_t lo = jr, hi = max(jr, limr);
+            while (lo < hi) { const uint32_t m = (lo + hi) >> 1; if (s_rows[m].pos <= A) lo = m + 1; else hi = m; }
+            const uint32_t je = lo;
+            if (je < limr) { const MdRow rc = s_rows[je]; const bool cc = (rc.lf & MD_COV) != 0; ended = cc; special = !cc || rc.mb < rc.pos; }      // the row that closes the window (its group's GAP included)
+            special |= s_sp[je] != s_sp[min(jr, je)];
+            if (je > jr) {
+                const uint32_t len = je - jr, k = 31u - (uint32_t)__builtin_clz(len);
+                const uint32_t m = max(s_key[k][jr], s_key[k][je - (1u << k)]);
+                if (m) { best_end = (m >> 9) - 1u + pos_base; best = (uint32_t)base + (uint32_t)(STAGE - 1) - (m & 511u); }
+            }
+            jr = max(jr, je);
+        }
         while (__ballot(run)) {
             const MdRow r = s_rows[min(jr, (uint32_t)STAGE - 1u)];
             const bool inr = run && jr < limr;
