@@ -686,7 +686,10 @@ __device__ __forceinline__ bool arrival_irregular(const MdRow& r, uint32_t F) {
 // The same successor, computed by a whole wave (64 rows per step, ballots + one arg-max): for the few providers whose
 // window is long -- a read with a 5 kb N skip has chunk_end 5 kb away and must look at a thousand rows before one
 // ends beyond it.  Left to its own lane such a read would hold its 63 neighbours for a thousand iterations.
-__device__ Succ succ_coop(const MdRow* rows, const uint32_t* bmax, const ParRun& R, uint64_t P, const MdRow& rp, int skip_zero, int lane) {
+// (rows the workgroup has staged in LDS -- the 512 from `sbase` on -- are taken from there: a deferred read's candidates mostly lie among them,
+// and with every step's rows fetched from memory the two or three deferred reads of a wave were two or three chains of round trips)
+__device__ Succ succ_coop(const MdRow* rows, const MdRow* srows, uint64_t sbase, uint32_t sn, const uint32_t* bmax, const ParRun& R, uint64_t P, const MdRow& rp, int skip_zero, int lane) {
+    auto row_at = [&](uint64_t idx) -> MdRow { const uint64_t d = idx - sbase; return d < (uint64_t)sn ? srows[d] : rows[idx]; };
     const uint32_t CE = rp.end, A = rp.pos + (rp.lf & MD_LMASK) - 1u;
     bool found = false, flag = false;
     uint32_t F = 0, best = SX_END, best_end = 0, allmax = 0;
@@ -719,7 +722,7 @@ __device__ Succ succ_coop(const MdRow* rows, const uint32_t* bmax, const ParRun&
         if ((budget -= 64) < 0) { flag = true; break; }
         const uint64_t idx = jb + lane;
         const bool inb = lane < width && idx < R.endrec;
-        const MdRow r = inb ? rows[idx] : MdRow{0, 0, 0, 0};
+        const MdRow r = inb ? row_at(idx) : MdRow{0, 0, 0, 0};
         const bool cov = inb && (r.lf & MD_COV);
         const bool hz = r.mb < r.pos;
         const bool isg = cov && skip_zero && (r.lf & MD_GST) && hz;
@@ -760,7 +763,7 @@ __device__ Succ succ_coop(const MdRow* rows, const uint32_t* bmax, const ParRun&
             for (uint64_t kb = jb + gap_at + 1; kb < R.endrec; kb += 64) {
                 if ((budget -= 64) < 0) { flag = true; break; }
                 const uint64_t ik = kb + lane;
-                const MdRow q = ik < R.endrec ? rows[ik] : MdRow{0, 0, 0, 0};
+                const MdRow q = ik < R.endrec ? row_at(ik) : MdRow{0, 0, 0, 0};
                 const bool qc = ik < R.endrec && (q.lf & MD_COV);
                 const uint64_t stop = __ballot(qc && q.pos != g0.pos);
                 const int fs = stop ? __ffsll((unsigned long long)stop) - 1 : 64;
@@ -992,7 +995,7 @@ __global__ __launch_bounds__(256) void k6_succ(const MdRow* rows, const uint32_t
         const MdRow rs = s_rows[(threadIdx.x & ~63u) + src];
         ParRun Rs;
         Rs.first = __shfl(R.first, src, 64); Rs.endrec = __shfl(R.endrec, src, 64); Rs.run_end = (uint32_t)__shfl((int)R.run_end, src, 64); Rs.ce_in = 0; Rs.active = 0; Rs.pad = 0;
-        const Succ c = succ_coop(rows, bmax, Rs, Ps, rs, skip_zero, lane);
+        const Succ c = succ_coop(rows, s_rows, base, (uint32_t)STAGE, bmax, Rs, Ps, rs, skip_zero, lane);
         if (lane == src) res = c;
     }
     if (P < n) succ[P] = res;
