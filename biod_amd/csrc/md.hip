@@ -655,6 +655,9 @@ __global__ __launch_bounds__(256) void k6_fill(const uint8_t* s, const bgp_recor
 // chunk is fetched on its last base, ...) is redone by k6_chain -- the exact event loop stays the authority,
 // and every BGP_EMD comes from it.
 constexpr uint32_t SX_END = 0xFFFFFFFFu, SX_NONE = 0xFFFFFFFEu, SX_FLAG = 1u << 31;
+#ifndef BGP_SUCC_LV
+#define BGP_SUCC_LV 6
+#endif
 #ifndef BGP_MD_SEG
 #define BGP_MD_SEG 2048                       // (a test build with 32 makes a thousand reads many segments: the fuzz loop then runs k6_top's parts and meetings)
 #endif
@@ -806,7 +809,7 @@ __global__ __launch_bounds__(256) void k6_succ(const MdRow* rows, const uint32_t
     // position group in it stands behind uncovered ground a difference of two prefix counts.  (A lane looking at its ~30-50 rows
     // one by one, all lanes as long as the slowest: 810 of the kernel's 1270 VALU instructions a wave.)  Ends that do not fit the
     // key's 22 bits (an N skip of megabases) send the workgroup through the row loop below instead.
-    constexpr int LV = 9;
+    constexpr int LV = BGP_SUCC_LV;                                           // windows of up to 2^LV - 1 rows are asked of the table, longer ones (rare) walk their rows
     __shared__ uint32_t s_key[LV][STAGE];
     __shared__ uint32_t s_sp[STAGE + 1];                                      // rows in front of row j that stand behind uncovered ground
     __shared__ uint32_t s_wsum[8], s_fallback;
@@ -837,15 +840,21 @@ __global__ __launch_bounds__(256) void k6_succ(const MdRow* rows, const uint32_t
         const uint32_t ex = before + inc - mine;
         s_sp[2 * threadIdx.x] = ex; s_sp[2 * threadIdx.x + 1] = ex + spc[0];
         if (threadIdx.x == 255) s_sp[STAGE] = ex + mine;
+        // two levels a barrier: level k and k + 1 both from level k - 1 (four reads)
 #pragma unroll 1
-        for (int k = 1; k < LV; ++k) {
+        for (int k = 1; k < LV; k += 2) {
             __syncthreads();
             const int half = 1 << (k - 1);
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int j = (int)threadIdx.x + 256 * h;
                 const uint32_t a0 = s_key[k - 1][j], a1 = j + half < STAGE ? s_key[k - 1][j + half] : 0u;
-                s_key[k][j] = max(a0, a1);
+                const uint32_t m01 = max(a0, a1);
+                s_key[k][j] = m01;
+                if (k + 1 < LV) {
+                    const uint32_t a2 = j + 2 * half < STAGE ? s_key[k - 1][j + 2 * half] : 0u, a3 = j + 3 * half < STAGE ? s_key[k - 1][j + 3 * half] : 0u;
+                    s_key[k + 1][j] = max(m01, max(a2, a3));
+                }
             }
         }
         __syncthreads();
@@ -889,6 +898,8 @@ __global__ __launch_bounds__(256) void k6_succ(const MdRow* rows, const uint32_t
             uint32_t lo = jr, hi = max(jr, limr);
             while (lo < hi) { const uint32_t m = (lo + hi) >> 1; if (s_rows[m].pos <= A) lo = m + 1; else hi = m; }
             const uint32_t je = lo;
+            if (je > jr && je - jr >= (1u << LV)) run = true;                 // (a window longer than the table's levels reach)
+            else {
             if (je < limr) { const MdRow rc = s_rows[je]; const bool cc = (rc.lf & MD_COV) != 0; ended = cc; special = !cc || rc.mb < rc.pos; }      // the row that closes the window (its group's GAP included)
             special |= s_sp[je] != s_sp[min(jr, je)];
             if (je > jr) {
@@ -897,6 +908,7 @@ __global__ __launch_bounds__(256) void k6_succ(const MdRow* rows, const uint32_t
                 if (m) { best_end = (m >> 9) - 1u + pos_base; best = (uint32_t)base + (uint32_t)(STAGE - 1) - (m & 511u); }
             }
             jr = max(jr, je);
+            }
         }
         while (__ballot(run)) {
             const MdRow r = s_rows[min(jr, (uint32_t)STAGE - 1u)];
