@@ -285,22 +285,16 @@ __device__ __forceinline__ K3Key k3_key_of(int32_t ref_id, int32_t pos, int32_t 
 // Is there a plausible record header at stream offset o?  (readrange.d:118-173 reads block_size, then the fixed fields
 // of read.d:907-931: the test is what those fields can hold in a well-formed record.)  Only ever a GUESS for where a
 // chain of records may be entered; every boundary is verified by the chain itself.
-__device__ __forceinline__ bool plausible(const uint8_t* s, uint64_t len, uint64_t o, int32_t ref_bound, uint32_t* bs_out, bool printable_name = true) {
-    if (o + 36 > len) return false;
-    // Two rounds of loads instead of one per test: block_size and refID together turn nearly every candidate down (eight bytes a
-    // lane); a candidate that passes them gets the rest of its header and the first twelve bytes of its name in one go.  Word by
-    // word -- block_size, the fields, the NUL, the name -- the guesser walked eight to ten dependent round trips a segment.
-    uint32_t h01[2];
-    __builtin_memcpy(h01, s + o, 8);
+// In two halves, so that a caller can ask for a candidate's second round of loads and for its successor's bytes together (k0_guess):
+// block_size and refID (the eight bytes at o, o + 36 <= len) turn nearly every candidate down ...
+__device__ __forceinline__ bool plausible_quick(const uint32_t (&h01)[2], uint64_t len, uint64_t o, int32_t ref_bound) {
     const uint32_t bs = h01[0];
-    *bs_out = bs;
     if (bs < 33u || bs > (1u << 30) || (uint64_t)bs > len - o - 4) return false;
     const int32_t ref = (int32_t)h01[1];
-    if (ref < -1 || ref >= ref_bound) return false;
-    uint32_t h[10];                                            // pos, bin_mq_nl, flag_nc, l_seq, next_refID, next_pos, tlen, name[0..11]
-    const bool wide = o + 48 <= len;
-    if (wide) __builtin_memcpy(h, s + o + 8, 40);
-    else { __builtin_memcpy(h, s + o + 8, 28); h[7] = h[8] = h[9] = 0u; }
+    return ref >= -1 && ref < ref_bound;
+}
+// ... and the rest of the header with the first twelve bytes of the name (h = the 40 bytes at o + 8 when `wide`, o + 48 <= len; else 28 and zeros)
+__device__ __forceinline__ bool plausible_rest(const uint8_t* s, uint64_t len, uint64_t o, uint32_t bs, const uint32_t (&h)[10], bool wide, int32_t ref_bound, bool printable_name) {
     const int32_t pos = (int32_t)h[0];
     const uint32_t bmn = h[1], fnc = h[2];
     const int32_t lseq = (int32_t)h[3], nref = (int32_t)h[4], npos = (int32_t)h[5];
@@ -338,6 +332,25 @@ __device__ __forceinline__ bool plausible(const uint8_t* s, uint64_t len, uint64
         for (; i < nl; ++i) { const uint8_t ch = nm[i]; if (ch < 0x21 || ch > 0x7E) return false; }
     }
     return true;
+}
+__device__ __forceinline__ void plausible_load_rest(const uint8_t* s, uint64_t len, uint64_t o, uint32_t (&h)[10], bool* wide) {
+    *wide = o + 48 <= len;
+    if (*wide) __builtin_memcpy(h, s + o + 8, 40);
+    else { __builtin_memcpy(h, s + o + 8, 28); h[7] = h[8] = h[9] = 0u; }
+}
+__device__ __forceinline__ bool plausible(const uint8_t* s, uint64_t len, uint64_t o, int32_t ref_bound, uint32_t* bs_out, bool printable_name = true) {
+    if (o + 36 > len) return false;
+    // Two rounds of loads instead of one per test: block_size and refID together turn nearly every candidate down (eight bytes a
+    // lane); a candidate that passes them gets the rest of its header and the first twelve bytes of its name in one go.  Word by
+    // word -- block_size, the fields, the NUL, the name -- the guesser walked eight to ten dependent round trips a segment.
+    uint32_t h01[2];
+    __builtin_memcpy(h01, s + o, 8);
+    *bs_out = h01[0];
+    if (!plausible_quick(h01, len, o, ref_bound)) return false;
+    uint32_t h[10];                                            // pos, bin_mq_nl, flag_nc, l_seq, next_refID, next_pos, tlen, name[0..11]
+    bool wide;
+    plausible_load_rest(s, len, o, h, &wide);
+    return plausible_rest(s, len, o, h01[0], h, wide, ref_bound, printable_name);
 }
 // CIGAR_TYPE bit pairs (cigar.d:113-116): bit0 query consuming, bit1 reference consuming
 __device__ __forceinline__ uint32_t cig_qc(uint32_t raw) { return (0x3C1A7u >> ((raw & 15u) * 2)) & 1u; }

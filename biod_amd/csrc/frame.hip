@@ -60,19 +60,37 @@ __global__ __launch_bounds__(256) void k0_guess(FrameArgs a) {
     for (int pass = 0; pass < 2 && found == NONE; ++pass) {
         const bool names = pass == 0;
         const int32_t ref_bound = pass == 0 ? a.ref_bound : (1 << 24);
-        for (uint64_t base = beg; base < lim && found == NONE; base += 64) {      // (256 candidates a step, four to a lane as in k0_guess_wide: 0.65 against 0.52 ms -- the start is half a record in, and three quarters of the wider step's loads are for nothing)
+        // A wave's time is its chain of round trips: the next step's eight bytes a lane are asked for before this step's are looked at,
+        // and a candidate that passes them asks for the rest of its header, for its successor's eight bytes and for the rest of the
+        // successor's header TOGETHER (the successor's offset is known from block_size) -- two round trips a segment's true header where
+        // there were four, and the steps in front of it no longer one each.  (256 candidates a step, four to a lane as in k0_guess_wide:
+        // 0.65 against 0.52 ms -- the start is half a record in, and three quarters of the wider step's loads are for nothing.)
+        auto ld01 = [&](uint64_t o, uint32_t (&h01)[2]) { h01[0] = h01[1] = 0u; if (o < lim && o + 36 <= a.len) __builtin_memcpy(h01, a.s + o, 8); };
+        uint32_t cur[2];
+        ld01(beg + lane, cur);
+        for (uint64_t base = beg; base < lim && found == NONE; base += 64) {
+            uint32_t nx01[2];
+            ld01(base + 64 + lane, nx01);
             const uint64_t o = base + lane;
-            uint32_t bs = 0;
-            const bool ok = o < lim && plausible(a.s, a.len, o, ref_bound, &bs, names);
-            unsigned long long m = __ballot(ok);
-            while (m) {
-                const int l = __ffsll((long long)m) - 1;
-                const uint32_t bsl = __shfl(bs, l, 64);
-                const uint64_t nxt = base + l + 4 + bsl;
-                uint32_t dummy;
-                if (a.len - nxt < 4 || plausible(a.s, a.len, nxt, ref_bound, &dummy, names)) { found = base + l; break; }
-                m &= m - 1;
+            const bool q = o < lim && o + 36 <= a.len && plausible_quick(cur, a.len, o, ref_bound);
+            if (__ballot(q)) {
+                bool ok = false;
+                if (q) {
+                    const uint32_t bs = cur[0];
+                    const uint64_t nxt = o + 4 + bs;
+                    uint32_t hc[10], hs01[2] = {0u, 0u}, hs[10];
+                    bool wc, ws = false;
+                    plausible_load_rest(a.s, a.len, o, hc, &wc);
+                    const bool s_in = nxt + 36 <= a.len;
+                    if (s_in) { __builtin_memcpy(hs01, a.s + nxt, 8); plausible_load_rest(a.s, a.len, nxt, hs, &ws); }
+                    else { for (int k = 0; k < 10; ++k) hs[k] = 0u; }
+                    ok = plausible_rest(a.s, a.len, o, bs, hc, wc, ref_bound, names)
+                         && (a.len - nxt < 4 || (s_in && plausible_quick(hs01, a.len, nxt, ref_bound) && plausible_rest(a.s, a.len, nxt, hs01[0], hs, ws, ref_bound, names)));
+                }
+                const unsigned long long mm = __ballot(ok);
+                if (mm) found = base + (uint64_t)(__ffsll((long long)mm) - 1);
             }
+            cur[0] = nx01[0]; cur[1] = nx01[1];
         }
     }
     if (lane == 0) a.entry[k] = found;
