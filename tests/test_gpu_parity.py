@@ -1597,6 +1597,24 @@ def test_pileup_chunks_fixtures(ctx, data_dir, name):
         _assert_columns_equal_oracle(ref, pos, cols, O.pileup(st))
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_pileup_chunks_of_a_read_or_two(ctx, seed):
+    """pileupChunks on random CIGARs with block sizes down to a read or two a chunk (scratch/fuzz_chunks.py's rounds): the plan is the
+    oracle's, the chunks' columns concatenated are pileupColumns."""
+    from biod_amd.pileup import pileupChunks
+    rng = np.random.default_rng(5100 + seed)
+    st = _random_stream(rng, int(rng.integers(50, 900)), quirks=False)
+    try:
+        ora = O.pileup(st)
+    except O.OracleError:
+        pytest.skip("the oracle rejects this stream (ECIGAR)")
+    for block in (int(rng.integers(150, 900)), int(rng.integers(900, 20_000))):
+        chunks = pileupChunks(RecordStream(st, ctx), False, block, want_entries=False)
+        assert [(c.first_record, c.last_record, c.ref_id, c.start_position, c.end_position) for c in chunks] == O.chunk_plan(st, block)
+        ref, pos, cols, _ = _chunk_columns(chunks)
+        _assert_columns_equal_oracle(ref, pos, cols, ora)
+
+
 def test_pileup_chunks_clipping_and_reference_bases(ctx):
     """start_from / end_at: the constructor drops leading chunks, later chunks are clipped (pileup.d:878-913); on one
     reference the concatenation is makePileup(reads, use_md, start_from, end_at).  With use_md_tag every column carries
