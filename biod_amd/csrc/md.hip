@@ -34,10 +34,18 @@ struct MdRes { const uint8_t* md; uint32_t b, e; MdOp front, back; int rem;
 
 // char i of the tag: from the register window where it covers i (a tag of up to 16 chars -- "75A74" -- is parsed without
 // another load: every operation used to cost a dependent load of its own), else from memory
-__device__ __forceinline__ uint8_t md_ch(const MdRes& r, uint32_t i) {
-    const int32_t d = (int32_t)i - r.wbase;
-    if (r.wok && d >= 0 && d < 16) return (uint8_t)((d < 8 ? r.wlo : r.whi) >> (8 * (d & 7)));
-    return r.md[i];
+// (the window slides: a char outside it brings the sixteen from that char on -- or, near the range's end, the sixteen in front of the end:
+// a tag's value starts at least 39 bytes into its record, so md + e - 16 is inside the stream whatever e is.  A byte a load made a
+// 30 kb read's tag -- ten thousand chars -- ten thousand dependent round trips: cfg5's provider check, 15 ms)
+__device__ __forceinline__ uint8_t md_ch(MdRes& r, uint32_t i) {
+    int32_t d = (int32_t)i - r.wbase;
+    if (!(r.wok && d >= 0 && d < 16)) {
+        const int32_t nb = min((int32_t)i, (int32_t)r.e - 16);
+        uint64_t w2[2]; __builtin_memcpy(w2, r.md + (int64_t)nb, 16);
+        r.wlo = w2[0]; r.whi = w2[1]; r.wbase = nb; r.wok = true;
+        d = (int32_t)i - nb;
+    }
+    return (uint8_t)((d < 8 ? r.wlo : r.whi) >> (8 * (d & 7)));
 }
 
 __device__ __forceinline__ bool is_digit_(uint8_t c) { return c >= '0' && c <= '9'; }
@@ -361,7 +369,15 @@ __device__ uint32_t dna_length(const uint8_t* s, const bgp_record& r, bool* bad,
 #pragma unroll
         for (uint32_t k = 0; k < 4; ++k) if (k < n_cig && cig_qc(ops[k]) && cig_rc(ops[k])) qleft += ops[k] >> 4;
     } else
-    for (uint32_t k = 0; k < n_cig; ++k) { const uint32_t raw = ld_u32(cg + 4ull * k); if (cig_qc(raw) && cig_rc(raw)) qleft += raw >> 4; }
+    {
+        auto takeq = [&](uint32_t raw) { if (cig_qc(raw) && cig_rc(raw)) qleft += raw >> 4; };
+        uint32_t k = 0;
+        for (; k + 8 <= n_cig; k += 8) {
+            uint4 v0, v1; __builtin_memcpy(&v0, cg + 4ull * k, 16); __builtin_memcpy(&v1, cg + 4ull * k + 16, 16);
+            takeq(v0.x); takeq(v0.y); takeq(v0.z); takeq(v0.w); takeq(v1.x); takeq(v1.y); takeq(v1.z); takeq(v1.w);
+        }
+        for (; k < n_cig; ++k) takeq(ld_u32(cg + 4ull * k));
+    }
     MdRes m;
     mdf_init(m, md, mdn);
     uint64_t n = 0;
@@ -403,7 +419,12 @@ __device__ __forceinline__ uint32_t dna_length_by_cigar(const uint8_t* s, const 
         for (uint32_t k = 0; k < 4; ++k) if (k < n_cig) take(ops[k]);
     } else {
         const uint8_t* cg = s + r.rec_off + 36 + l_name;
-        for (uint32_t k = 0; k < n_cig; ++k) take(ld_u32(cg + 4ull * k));
+        uint32_t k = 0;
+        for (; k + 8 <= n_cig; k += 8) {      // (eight ops, two loads in flight, a step: a long read's thousands of ops were as many round trips one after the other)
+            uint4 v0, v1; __builtin_memcpy(&v0, cg + 4ull * k, 16); __builtin_memcpy(&v1, cg + 4ull * k + 16, 16);
+            take(v0.x); take(v0.y); take(v0.z); take(v0.w); take(v1.x); take(v1.y); take(v1.z); take(v1.w);
+        }
+        for (; k < n_cig; ++k) take(ld_u32(cg + 4ull * k));
     }
     return n > (uint64_t)MD_LMASK ? MD_LMASK : (uint32_t)n;
 }
@@ -1227,7 +1248,7 @@ __global__ __launch_bounds__(64) void k6_emit(const uint8_t* s, const bgp_record
                 if (vb || ve || Lt != dna_length_by_cigar(s, rec[nd[k]], nullptr)) po[s_run].flagged = 1u;
             }
             if (F >= endc) continue;
-            if (endc - F > DNA_LONG) {
+            if (endc - F > DNA_LONG || F - rows[nd[k]].pos > DNA_LONG) {      // (a chunk far into a long read, too: getting there is the walk of thousands of operations -- a wave of its own, k6_ck_build)
                 const uint32_t at = atomicAdd(&ctr[0], 1u), pieces = (endc - F + DNA_CK - 1) / DNA_CK;
                 const uint32_t base = atomicAdd(&ctr[1], pieces);
                 if (at < longs_cap) longs[at] = LongNode{nd[k], F - rows[nd[k]].pos, endc - F, base, R.column_base + (F - R.start_pos)};
