@@ -1203,8 +1203,141 @@ struct EmitRun { uint64_t first, endrec, column_base; uint32_t start_pos, end_po
 // `longs`, gets one checkpoint per DNA_CK chars from k6_ck_build (a walk that never touches SEQ), and k6_emit_long
 // emits the pieces one lane each.  ctr[0] = long nodes, ctr[1] = pieces.
 struct LongNode { uint32_t rec, from, count, ck_base; uint64_t out_off; };
+struct VEntry { uint32_t node, run; };
+constexpr uint32_t VERIFY_LONG = 2048, VMD_CAP = 32768, FAR_CAP = 1u << 16;      // reads longer than this are checked by k6_verify_long; the longest tag it stages; far chunks a pass lists
+
+// length of the NUL-terminated string at t[0 .. lim) (lim if there is no NUL), by the wave: 512 bytes a step
+__device__ uint64_t wave_strnlen(const uint8_t* t, uint64_t lim, int lane) {
+    for (uint64_t b0 = 0; b0 < lim; b0 += 512) {
+        const uint64_t o = b0 + 8ull * (uint64_t)lane;
+        unsigned long long w = ~0ull;
+        if (o + 8 <= lim) __builtin_memcpy(&w, t + o, 8);
+        else if (o < lim) { for (uint64_t k = 0; k < lim - o; ++k) w = (w & ~(0xFFull << (8 * k))) | ((unsigned long long)t[o + k] << (8 * k)); }
+        const unsigned long long z = (w - 0x0101010101010101ull) & ~w & 0x8080808080808080ull;      // the lowest set bit marks the first zero byte
+        const unsigned long long m = __ballot(z != 0);
+        if (m) {
+            const int L = __ffsll((long long)m) - 1;
+            const uint32_t idx = (uint32_t)(__ffsll((long long)z) - 1) / 8u;
+            return b0 + 8ull * (uint64_t)L + (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)idx, L);
+        }
+    }
+    return lim;
+}
+
+// k6_emit's check of a provider -- dna_length(tag) against dna_length_by_cigar -- for a LONG read, by a whole wave.  The tag's tokens are
+// found without walking it: a char starts a number when it is a digit behind a non-digit, a deletion when it is '^' (its bases: the
+// upper-case run behind it, md/parse.d:85-109), and is a mismatch when it is anything else outside such a run; what the lazy range yields
+// is then a sum (md/reconstruct.d:98-182: every match takes its bases, every mismatch one, every deleted base itself) as long as the CIGAR
+// has the M / = / X bases the tag asks for.  The check only ever errs to the safe side: whatever it cannot vouch for -- a tag it cannot
+// stage, a number of more than nine digits, an empty deletion, more bases asked than there are, a last operation the reference's backward
+// parse (parse.d:111-131) would cut differently from the forward one -- FLAGS the run, and the event loop, which parses every tag the
+// reference's way, redoes it.
+__global__ __launch_bounds__(64) void k6_verify_long(const uint8_t* s, uint64_t stream_len, const bgp_record* rec, const VEntry* vl, const unsigned int* ctr, uint32_t vcap, ParOut* po) {
+    __shared__ uint8_t smd[VMD_CAP + 16];
+    const uint32_t cnt = min(ctr[2], vcap);
+    if (blockIdx.x >= cnt) return;
+    const int lane = threadIdx.x;
+    const VEntry v = vl[blockIdx.x];
+    const bgp_record r = rec[v.node];
+    const uint32_t l_name = r.bin_mq_nl & 0xFFu, n_cig = r.flag_nc & 0xFFFFu;
+    auto wsum = [](unsigned long long x) { for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d, 64); return x; };
+    // the CIGAR's M / = / X bases (what the tag may ask for) and deleted bases
+    unsigned long long q = 0, dl = 0;
+    {
+        const uint8_t* cg = s + r.rec_off + 36 + l_name;
+        for (uint32_t k = (uint32_t)lane; k < n_cig; k += 64) { const uint32_t raw = ld_u32(cg + 4ull * k); if (cig_qc(raw) && cig_rc(raw)) q += raw >> 4; else if ((raw & 15u) == 2u) dl += raw >> 4; }
+        q = wsum(q); dl = wsum(dl);
+    }
+    const unsigned long long by_cigar = q + dl > (unsigned long long)MD_LMASK ? (unsigned long long)MD_LMASK : q + dl;
+    // BamRead.opIndex("MD") (find_md above), every lane the same steps; a string's length by the wave
+    bool flag = false, found = false;
+    const uint8_t* md = nullptr; uint64_t mdn = 0;
+    {
+        const uint64_t end = r.rec_off + 4 + ld_u32(s + r.rec_off);
+        const uint64_t tags = r.rec_off + 36 + l_name + 4ull * n_cig + (uint64_t)((r.l_seq + 1) / 2) + (uint64_t)r.l_seq;
+        if (tags > end) flag = true;
+        else {
+            const uint8_t* t = s + tags;
+            const uint64_t tl = end - tags;
+            uint64_t off = 0;
+            while (tl >= 4 && off + 1 < tl) {
+                const bool match = t[off] == 'M' && t[off + 1] == 'D';
+                off += 2;
+                if (off >= tl) { flag = true; break; }
+                const uint8_t ty = t[off++];
+                if (match) {
+                    if (ty == 'Z' || ty == 'H') { md = t + off; mdn = wave_strnlen(t + off, tl - off, lane); found = true; }
+                    break;
+                }
+                if (ty == 'Z' || ty == 'H') { off += wave_strnlen(t + off, tl - off, lane); if (off >= tl) { flag = true; break; } ++off; }
+                else if (ty == 'B') {
+                    if (off + 5 > tl) { flag = true; break; }
+                    const uint8_t et = t[off];
+                    const int es = (et == 'c' || et == 'C') ? 1 : (et == 's' || et == 'S') ? 2 : (et == 'i' || et == 'I' || et == 'f') ? 4 : -1;
+                    if (es < 0) { flag = true; break; }
+                    off += 5 + (uint64_t)es * ld_u32(t + off + 1);
+                } else {
+                    const int es = (ty == 'A' || ty == 'c' || ty == 'C') ? 1 : (ty == 's' || ty == 'S') ? 2 : (ty == 'i' || ty == 'I' || ty == 'f') ? 4 : -1;
+                    if (es < 0) { flag = true; break; }
+                    off += (uint64_t)es;
+                }
+            }
+        }
+    }
+    unsigned long long lt = 0;
+    if (!flag && found) {
+        if (mdn > VMD_CAP) flag = true;
+        else {
+            const uint32_t n = (uint32_t)mdn;
+            const uint64_t md_off = (uint64_t)(md - s);
+            for (uint32_t o = 16u * (uint32_t)lane; o < n; o += 1024u) {
+                if (md_off + o + 16 <= stream_len) { uint4 w; __builtin_memcpy(&w, md + o, 16); *reinterpret_cast<uint4*>(smd + o) = w; }
+                else for (uint32_t k = 0; k < 16u && o + k < n; ++k) smd[o + k] = md[o + k];
+            }
+            __syncthreads();
+            unsigned long long num = 0, mm = 0, del = 0;
+            for (uint32_t i = (uint32_t)lane; i < n; i += 64) {
+                const uint8_t c = smd[i];
+                if (c == '^') {
+                    uint32_t len = 0;
+                    while (i + 1 + len < n && is_upper_(smd[i + 1 + len])) ++len;
+                    if (len == 0) flag = true;                                 // an empty deletion: the range stalls
+                    del += len;
+                } else if (is_digit_(c)) {
+                    if (i == 0 || !is_digit_(smd[i - 1])) {
+                        unsigned long long val = 0; uint32_t k = 0;
+                        while (i + k < n && is_digit_(smd[i + k])) { val = val * 10 + (unsigned long long)(smd[i + k] - '0'); if (++k > 9) { flag = true; break; } }
+                        num += val;
+                    }
+                } else {
+                    bool in_del = false;
+                    if (is_upper_(c)) {
+                        uint32_t j = i, steps = 0;
+                        while (j > 0 && is_upper_(smd[j - 1])) { --j; if (++steps > 4096u) { flag = true; break; } }
+                        in_del = j > 0 && smd[j - 1] == '^';
+                    }
+                    if (!in_del) ++mm;
+                }
+            }
+            if (lane == 0 && n) {      // the last operation as the backward parse cuts it (parse.d:111-131): a number, a single mismatch, or '^' with upper-case bases to the end
+                const uint8_t last = smd[n - 1];
+                if (!is_digit_(last) && !(n == 1 || is_digit_(smd[n - 2]))) {
+                    uint32_t j = n - 1; bool upper = true;
+                    while (smd[j] != '^') { upper = upper && is_upper_(smd[j]); if (j == 0) { upper = false; break; } --j; }
+                    if (!upper || j == n - 1) flag = true;
+                }
+            }
+            num = wsum(num); mm = wsum(mm); del = wsum(del);
+            if (num + mm > q) flag = true;                                     // the tag asks for more bases than the CIGAR has: the range stalls
+            lt = num + mm + del;
+        }
+    }
+    if (__ballot(flag) || lt != by_cigar) { if (lane == 0) po[v.run].flagged = 1u; }
+}
+
 __global__ __launch_bounds__(64) void k6_emit(const uint8_t* s, const bgp_record* rec, const MdRow* rows, const Succ* succ, const Succ* seg_entry, uint64_t slot_lo, uint64_t slot_n,
-                                              const EmitRun* er, uint32_t n_runs, ParOut* po, uint8_t* refbase, LongNode* longs, uint32_t longs_cap, unsigned int* ctr, int verify) {
+                                              const EmitRun* er, uint32_t n_runs, ParOut* po, uint8_t* refbase, LongNode* longs, uint32_t longs_cap, unsigned int* ctr, int verify,
+                                              VEntry* vlist, uint32_t vcap) {
     // (the segment's providers in stretches of EM_CH: with room for a whole segment's 2048 -- 16 KB a block of one wave -- ten blocks shared
     // a CU and its 40 wave slots; a segment of cfg3 has ~32 providers)
     constexpr uint32_t EM_CH = 192;
@@ -1243,15 +1376,25 @@ __global__ __launch_bounds__(64) void k6_emit(const uint8_t* s, const bgp_record
             uint32_t endc = fc[k + 1];
             if (endc > R.end_pos) endc = R.end_pos;
             if (verify) {                                         // this provider's real tag against what the rows assumed of it (k6_prep<false>)
-                bool vb, ve;
-                const uint32_t Lt = dna_length(s, rec[nd[k]], &vb, &ve);
-                if (vb || ve || Lt != dna_length_by_cigar(s, rec[nd[k]], nullptr)) po[s_run].flagged = 1u;
+                bool inl = true;
+                if (vlist && (uint32_t)rec[nd[k]].l_seq > VERIFY_LONG) {      // a long read's tag: a wave of its own (k6_verify_long), not a lane's ten thousand steps
+                    const uint32_t at = atomicAdd(&ctr[2], 1u);
+                    if (at < vcap) { vlist[at] = VEntry{nd[k], s_run}; inl = false; }
+                }
+                if (inl) {
+                    bool vb, ve;
+                    const uint32_t Lt = dna_length(s, rec[nd[k]], &vb, &ve);
+                    if (vb || ve || Lt != dna_length_by_cigar(s, rec[nd[k]], nullptr)) po[s_run].flagged = 1u;
+                }
             }
             if (F >= endc) continue;
-            if (endc - F > DNA_LONG || F - rows[nd[k]].pos > DNA_LONG) {      // (a chunk far into a long read, too: getting there is the walk of thousands of operations -- a wave of its own, k6_ck_build)
+            // a long chunk is emitted in pieces from checkpoints; so is a chunk far into a long read (getting there is the walk of thousands of
+            // operations: a wave of its own, k6_ck_build) while the list has room for it (long chunks are bounded by the columns, far ones by FAR_CAP)
+            const bool big = endc - F > DNA_LONG;
+            if (big || (F - rows[nd[k]].pos > DNA_LONG && atomicAdd(&ctr[3], 1u) < FAR_CAP)) {
                 const uint32_t at = atomicAdd(&ctr[0], 1u), pieces = (endc - F + DNA_CK - 1) / DNA_CK;
                 const uint32_t base = atomicAdd(&ctr[1], pieces);
-                if (at < longs_cap) longs[at] = LongNode{nd[k], F - rows[nd[k]].pos, endc - F, base, R.column_base + (F - R.start_pos)};
+                if (at < longs_cap + FAR_CAP) longs[at] = LongNode{nd[k], F - rows[nd[k]].pos, endc - F, base, R.column_base + (F - R.start_pos)};
                 continue;
             }
             bool bad, err;
@@ -1447,7 +1590,7 @@ int k6_reference_bases(bgp_ctx* c, int skip_zero, uint32_t run_first, uint32_t r
     const uint64_t n_slots = (n + SEG - 1) / SEG + nr + 1;
     const uint32_t longs_cap = (uint32_t)std::min<uint64_t>(n_pos / DNA_LONG + nr + 64, 0x7FFFFFFFull);    // a long chunk covers > DNA_LONG columns of its run
     if (use_par) {
-        BGP_TRY(c->d_md_long.reserve(16 + (size_t)longs_cap * sizeof(LongNode)));
+        BGP_TRY(c->d_md_long.reserve(16 + ((size_t)longs_cap + FAR_CAP) * sizeof(LongNode)));
         BGP_TRY(c->d_md_succ.reserve((n + 1) * sizeof(Succ))); BGP_TRY(c->d_md_exit.reserve((n + 1) * sizeof(Succ))); BGP_TRY(c->d_md_entry.reserve(n_slots * sizeof(Succ)));
         BGP_HIP(hipMemcpyAsync(st + off_pr, pr.data(), sizeof(ParRun) * nr, hipMemcpyHostToDevice, c->stream));
         BGP_HIP(hipMemcpyAsync(st + off_er, er.data(), sizeof(EmitRun) * nr, hipMemcpyHostToDevice, c->stream));
@@ -1474,6 +1617,10 @@ int k6_reference_bases(bgp_ctx* c, int skip_zero, uint32_t run_first, uint32_t r
                 BGP_HIP(hipMemsetAsync(c->d_md_entry.as<Succ>() + lo, 0xFF, (hi - lo) * sizeof(Succ), c->stream));
             }
             BGP_HIP(hipMemsetAsync(c->d_md_long.p, 0, 16, c->stream));
+            // (a stream of long records: the providers' tags are long too -- k6_emit lists them for k6_verify_long)
+            const uint32_t vcap = 1u << 14;
+            VEntry* vlist = nullptr;
+            if (c->n_records && c->stream_len / c->n_records >= 2048) { BGP_TRY(c->d_md_vlist.reserve((size_t)vcap * sizeof(VEntry))); vlist = c->d_md_vlist.as<VEntry>(); }
             {
                 TimedRegion t(c, "k6_top", 0);
                 hipLaunchKernelGGL(k6_top, dim3(nr), dim3(64), 0, c->stream, c->d_md_row.as<MdRow>(), c->d_md_exit.as<Succ>(), (const ParRun*)(st + off_pr), (ParOut*)(st + off_po), c->d_md_entry.as<Succ>());
@@ -1483,7 +1630,11 @@ int k6_reference_bases(bgp_ctx* c, int skip_zero, uint32_t run_first, uint32_t r
                 TimedRegion t(c, "k6_emit", mr[k].end_pos - mr[k].start_pos);
                 hipLaunchKernelGGL(k6_emit, dim3((unsigned)(hi - lo)), dim3(64), 0, c->stream, c->d_stream, c->d_rec.as<bgp_record>(), c->d_md_row.as<MdRow>(), c->d_md_succ.as<Succ>(),
                                    c->d_md_entry.as<Succ>(), lo, hi - lo, (const EmitRun*)(st + off_er), nr, (ParOut*)(st + off_po), c->d_refbase.as<uint8_t>(),
-                                   (LongNode*)(c->d_md_long.as<uint8_t>() + 16), longs_cap, c->d_md_long.as<unsigned int>(), 1);
+                                   (LongNode*)(c->d_md_long.as<uint8_t>() + 16), longs_cap, c->d_md_long.as<unsigned int>(), 1, vlist, vcap);
+            }
+            if (vlist) {      // the long reads among the providers: their tags checked a wave each (blocks beyond the list's count leave at once)
+                TimedRegion t(c, "k6_verify_long", 0);
+                hipLaunchKernelGGL(k6_verify_long, dim3(vcap), dim3(64), 0, c->stream, c->d_stream, c->stream_len, c->d_rec.as<bgp_record>(), vlist, c->d_md_long.as<unsigned int>(), vcap, (ParOut*)(st + off_po));
             }
             BGP_HIP(hipGetLastError());
             std::vector<ParOut> po(nr);
@@ -1492,7 +1643,7 @@ int k6_reference_bases(bgp_ctx* c, int skip_zero, uint32_t run_first, uint32_t r
             BGP_HIP(hipMemcpyAsync(ctr, c->d_md_long.p, sizeof ctr, hipMemcpyDeviceToHost, c->stream));
             BGP_HIP(hipStreamSynchronize(c->stream));
             if (ctr[0]) {                                          // long chunks: checkpoints, then one lane per DNA_CK chars
-                if (ctr[0] > longs_cap) { c->last_error = "MD: more long chunks than columns / DNA_LONG"; return BGP_EDEVICE; }
+                if (ctr[0] > longs_cap + FAR_CAP) { c->last_error = "MD: more long chunks than columns / DNA_LONG"; return BGP_EDEVICE; }
                 BGP_TRY(c->d_md_ck.reserve((size_t)ctr[1] * (sizeof(DnaCk) + 4) + 64));
                 DnaCk* ck = c->d_md_ck.as<DnaCk>(); uint32_t* piece_node = (uint32_t*)(ck + ctr[1]);
                 BGP_HIP(hipMemsetAsync(ck, 0, (size_t)ctr[1] * sizeof(DnaCk), c->stream));

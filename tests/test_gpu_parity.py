@@ -1793,6 +1793,64 @@ def _batched_refbase(ctx, pieces, batch, skip):
     return cat(ref, np.int64), cat(pos, np.int64), cat(rb, np.uint8)
 
 
+def _long_md_read(rng, i, pos, n_ops, damage=None):
+    """A long read (M / I / D / N ops, a mismatch every ~20 bases) with the MD tag its CIGAR implies, optionally damaged."""
+    ops, md, run, seq = [], "", 0, []
+    for k in range(n_ops):
+        ln = int(rng.integers(8, 40))
+        ops.append((ln, "M"))
+        for _ in range(ln):
+            if rng.random() < 0.05:
+                md += str(run) + "ACGT"[int(rng.integers(0, 4))]; run = 0
+            else:
+                run += 1
+        seq.append(ln)
+        u = rng.random()
+        if k + 1 < n_ops:
+            if u < 0.3:
+                il = int(rng.integers(1, 6)); ops.append((il, "I")); seq.append(il)
+            elif u < 0.6:
+                dlen = int(rng.integers(1, 8)); ops.append((dlen, "D"))
+                md += str(run) + "^" + "".join("ACGT"[int(x)] for x in rng.integers(0, 4, dlen)); run = 0
+            elif u < 0.65:
+                ops.append((int(rng.integers(10, 60)), "N"))
+    md += str(run)
+    if damage == "short":
+        md = md[:len(md) // 2]
+    elif damage == "long":
+        md += "A" + str(int(rng.integers(5, 50)))
+    elif damage == "empty_del":
+        k = md.find("^"); md = md[:k + 1] + md[k + 1:].lstrip("ACGT") if k >= 0 else md + "^5"
+    elif damage == "lower":
+        md = md.replace("^A", "^a", 1) if "^A" in md else md.lower()
+    elif damage == "tail":
+        md += "AC"
+    elif damage == "digits":
+        md = "00000000001" + md
+    elif damage == "none":
+        return bamio.pack_record(f"l{i}", "".join("ACGT"[int(x)] for x in rng.integers(0, 4, sum(seq))), ops, ref_id=0, pos=pos, tags=bamio.tag_z("XQ", "nomd"))
+    return bamio.pack_record(f"l{i}", "".join("ACGT"[int(x)] for x in rng.integers(0, 4, sum(seq))), ops, ref_id=0, pos=pos,
+                             tags=bamio.tag_z("XA", "q" * int(rng.integers(0, 40))) + bamio.tag_z("MD", md))
+
+
+@pytest.mark.parametrize("damage", [None, "short", "long", "empty_del", "lower", "tail", "digits", "none"])
+def test_reference_base_long_reads_checked_by_the_wave(ctx, damage):
+    """Providers of more than 2048 bases have their tags checked by k6_verify_long (tokens found in parallel, sums instead of a walk): with
+    consistent tags the composed chain stands, and every kind of damage -- a tag cut short, one that asks for more bases than the CIGAR has,
+    an empty deletion, lower-case deleted bases, trailing letters, a number of eleven digits, no MD at all -- must come out as the
+    reference's own parser has it (the oracle): the check flags what it cannot vouch for and the event loop redoes the run."""
+    rng = np.random.default_rng(991)
+    recs, pos = [], 100
+    for i in range(60):
+        recs.append(_long_md_read(rng, i, pos, int(rng.integers(110, 160)), damage if (damage and i % 7 == 3) else None))
+        pos += int(rng.integers(50, 400))
+    st = b"".join(recs)
+    assert len(st) // 60 >= 2048                      # (the library lists providers for the wave's check on streams of long records)
+    stage(ctx, st)
+    for skip in (True, False):
+        _check_refbase(ctx, st, skip_zero=skip, window=5000)
+
+
 def test_reference_base_every_read_a_provider(ctx):
     """Short reads at coverage ~1.3: nearly every read of a 2048-record segment is a provider, so k6_emit hands a segment's providers
     out in several stretches (its list in LDS holds 192); mismatches and deletions in the tags so that the bases differ by provider."""
