@@ -11,7 +11,7 @@ for damage in [None, "short", "long", "empty_del", "lower", "tail", "digits", "n
     rng = np.random.default_rng(991)
     recs, pos = [], 100
     for i in range(60):
-        recs.append(T._long_md_read(rng, i, pos, int(rng.integers(110, 160)), damage if (damage and i % 7 == 3) else None))
+        recs.append(T._long_indel_read(rng, i, pos, int(rng.integers(110, 160)), damage if (damage and i % 7 == 3) else None))
         pos += int(rng.integers(50, 400))
     st = b"".join(recs)
     T.stage(ctx, st)

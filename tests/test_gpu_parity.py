@@ -1793,7 +1793,7 @@ def _batched_refbase(ctx, pieces, batch, skip):
     return cat(ref, np.int64), cat(pos, np.int64), cat(rb, np.uint8)
 
 
-def _long_md_read(rng, i, pos, n_ops, damage=None):
+def _long_indel_read(rng, i, pos, n_ops, damage=None):
     """A long read (M / I / D / N ops, a mismatch every ~20 bases) with the MD tag its CIGAR implies, optionally damaged."""
     ops, md, run, seq = [], "", 0, []
     for k in range(n_ops):
@@ -1842,7 +1842,7 @@ def test_reference_base_long_reads_checked_by_the_wave(ctx, damage):
     rng = np.random.default_rng(991)
     recs, pos = [], 100
     for i in range(60):
-        recs.append(_long_md_read(rng, i, pos, int(rng.integers(110, 160)), damage if (damage and i % 7 == 3) else None))
+        recs.append(_long_indel_read(rng, i, pos, int(rng.integers(110, 160)), damage if (damage and i % 7 == 3) else None))
         pos += int(rng.integers(50, 400))
     st = b"".join(recs)
     assert len(st) // 60 >= 2048                      # (the library lists providers for the wave's check on streams of long records)
