@@ -30,7 +30,7 @@ namespace {
 
 struct MdOp { uint32_t type; /* 0 match, 1 mismatch, 2 deletion */ uint32_t match; uint32_t ch; uint32_t del_off, del_len; };
 struct MdRes { const uint8_t* md; uint32_t b, e; MdOp front, back; int rem;
-               uint64_t wlo, whi; int32_t wbase; bool wok; };     // the tag's last 16 chars in registers: chars [wbase, wbase + 16) (wok: loaded)
+               uint64_t wlo, whi; int32_t wbase; bool wok, slide; };     // the tag's last 16 chars in registers: chars [wbase, wbase + 16) (wok: loaded); slide: a long tag, the window follows the parse
 
 // char i of the tag: from the register window where it covers i (a tag of up to 16 chars -- "75A74" -- is parsed without
 // another load: every operation used to cost a dependent load of its own), else from memory
@@ -40,6 +40,7 @@ struct MdRes { const uint8_t* md; uint32_t b, e; MdOp front, back; int rem;
 __device__ __forceinline__ uint8_t md_ch(MdRes& r, uint32_t i) {
     int32_t d = (int32_t)i - r.wbase;
     if (!(r.wok && d >= 0 && d < 16)) {
+        if (!r.slide) return r.md[i];                  // (a short tag: the few chars in front of the window one by one)
         const int32_t nb = min((int32_t)i, (int32_t)r.e - 16);
         uint64_t w2[2]; __builtin_memcpy(w2, r.md + (int64_t)nb, 16);
         r.wlo = w2[0]; r.whi = w2[1]; r.wbase = nb; r.wok = true;
@@ -114,11 +115,11 @@ __device__ void md_pop_back(MdRes& r) {                         // md/parse.d:71
     else if (!md_cache_back(r)) r.rem = 0;
 }
 __device__ __forceinline__ bool md_zero(const MdOp& o) { return o.type == 0 && o.match == 0; }
-__device__ void mdf_init(MdRes& r, const uint8_t* md, uint32_t n) {   // md/parse.d:23-33 + filterBidirectional ctor
+__device__ void mdf_init(MdRes& r, const uint8_t* md, uint32_t n, bool slide = false) {   // md/parse.d:23-33 + filterBidirectional ctor (slide: a long read's tag, see md_ch -- a constant at every call, so that the short reads' kernels do not carry the window's code)
     r.md = md; r.b = 0; r.e = n; r.rem = 255;
     // the sixteen bytes in front of the tag's end in one load (a tag's value starts at least 39 bytes into its record, so
     // md + n - 16 is inside the stream whatever n is)
-    r.wbase = (int32_t)n - 16; r.wok = n > 0;
+    r.wbase = (int32_t)n - 16; r.wok = n > 0; r.slide = slide;
     if (r.wok) { uint64_t w2[2]; __builtin_memcpy(w2, md + (int64_t)r.wbase, 16); r.wlo = w2[0]; r.whi = w2[1]; } else { r.wlo = 0; r.whi = 0; }
     if (!md_cache_front(r)) r.rem = 0;
     else if (!md_cache_back(r)) { r.back = r.front; r.rem = 1; }
@@ -211,7 +212,7 @@ struct DnaState { MdRes m; MdOp cur; uint32_t del_i; QIter q; uint32_t n; bool l
 struct DnaCk { uint64_t md_off; uint32_t b, e; int32_t rem; MdOp front, back, cur; uint32_t del_i, q_op, q_in, q_q, q_empty, n, node, pad; };
 constexpr uint32_t DNA_CK = 512, DNA_LONG = 4096;     // checkpoint spacing; chunks longer than DNA_LONG are emitted in pieces
 
-__device__ void dna_begin(DnaState& st, const uint8_t* s, const bgp_record& r, bool* err) {
+__device__ void dna_begin(DnaState& st, const uint8_t* s, const bgp_record& r, bool* err, bool slide = false) {
     *err = false; st.live = false; st.n = 0; st.del_i = 0;
     const uint8_t* md = nullptr; uint32_t mdn = 0;
     const int f = find_md(s, r, &md, &mdn);
@@ -221,7 +222,7 @@ __device__ void dna_begin(DnaState& st, const uint8_t* s, const bgp_record& r, b
     QIter& q = st.q; q.cg = s + r.rec_off + 36 + l_name; q.sq = q.cg + 4ull * n_cig; q.n_cig = n_cig; q.op = 0; q.in_op = 0; q.q = 0; q.empty = false;
     q_load(q);
     q_settle(q);
-    mdf_init(st.m, md, mdn);
+    mdf_init(st.m, md, mdn, slide);
     if (md_empty(st.m)) return;
     st.cur = st.m.front; mdf_pop_front(st.m);
     st.live = true;
@@ -232,7 +233,7 @@ __device__ void dna_save(const DnaState& st, const uint8_t* s, uint32_t node, Dn
 }
 __device__ void dna_restore(DnaState& st, const uint8_t* s, const bgp_record& r, const DnaCk& ck) {
     st.m.md = s + ck.md_off; st.m.b = ck.b; st.m.e = ck.e; st.m.rem = ck.rem; st.m.front = ck.front; st.m.back = ck.back; st.cur = ck.cur;
-    st.m.wok = false; st.m.wlo = 0; st.m.whi = 0; st.m.wbase = 0;      // (a restored parser reads its chars from memory)
+    st.m.wok = false; st.m.wlo = 0; st.m.whi = 0; st.m.wbase = 0; st.m.slide = true;      // (a restored parser -- a long read's -- reads its chars through the sliding window)
     st.del_i = ck.del_i; st.n = ck.n; st.live = ck.pad != 0;
     const uint32_t l_name = r.bin_mq_nl & 0xFFu, n_cig = r.flag_nc & 0xFFFFu;
     QIter& q = st.q; q.cg = s + r.rec_off + 36 + l_name; q.sq = q.cg + 4ull * n_cig; q.n_cig = n_cig; q.op = ck.q_op; q.in_op = ck.q_in; q.q = ck.q_q; q.empty = ck.q_empty != 0;
@@ -1335,7 +1336,7 @@ __global__ __launch_bounds__(64) void k6_verify_long(const uint8_t* s, uint64_t 
     if (__ballot(flag) || lt != by_cigar) { if (lane == 0) po[v.run].flagged = 1u; }
 }
 
-__global__ __launch_bounds__(64) void k6_emit(const uint8_t* s, const bgp_record* rec, const MdRow* rows, const Succ* succ, const Succ* seg_entry, uint64_t slot_lo, uint64_t slot_n,
+template <bool LONGS> __global__ __launch_bounds__(64) void k6_emit(const uint8_t* s, const bgp_record* rec, const MdRow* rows, const Succ* succ, const Succ* seg_entry, uint64_t slot_lo, uint64_t slot_n,
                                               const EmitRun* er, uint32_t n_runs, ParOut* po, uint8_t* refbase, LongNode* longs, uint32_t longs_cap, unsigned int* ctr, int verify,
                                               VEntry* vlist, uint32_t vcap) {
     // (the segment's providers in stretches of EM_CH: with room for a whole segment's 2048 -- 16 KB a block of one wave -- ten blocks shared
@@ -1377,7 +1378,7 @@ __global__ __launch_bounds__(64) void k6_emit(const uint8_t* s, const bgp_record
             if (endc > R.end_pos) endc = R.end_pos;
             if (verify) {                                         // this provider's real tag against what the rows assumed of it (k6_prep<false>)
                 bool inl = true;
-                if (vlist && (uint32_t)rec[nd[k]].l_seq > VERIFY_LONG) {      // a long read's tag: a wave of its own (k6_verify_long), not a lane's ten thousand steps
+                if (LONGS && vlist && (uint32_t)rec[nd[k]].l_seq > VERIFY_LONG) {      // a long read's tag: a wave of its own (k6_verify_long), not a lane's ten thousand steps
                     const uint32_t at = atomicAdd(&ctr[2], 1u);
                     if (at < vcap) { vlist[at] = VEntry{nd[k], s_run}; inl = false; }
                 }
@@ -1391,7 +1392,7 @@ __global__ __launch_bounds__(64) void k6_emit(const uint8_t* s, const bgp_record
             // a long chunk is emitted in pieces from checkpoints; so is a chunk far into a long read (getting there is the walk of thousands of
             // operations: a wave of its own, k6_ck_build) while the list has room for it (long chunks are bounded by the columns, far ones by FAR_CAP)
             const bool big = endc - F > DNA_LONG;
-            if (big || (F - rows[nd[k]].pos > DNA_LONG && atomicAdd(&ctr[3], 1u) < FAR_CAP)) {
+            if (big || (LONGS && F - rows[nd[k]].pos > DNA_LONG && atomicAdd(&ctr[3], 1u) < FAR_CAP)) {
                 const uint32_t at = atomicAdd(&ctr[0], 1u), pieces = (endc - F + DNA_CK - 1) / DNA_CK;
                 const uint32_t base = atomicAdd(&ctr[1], pieces);
                 if (at < longs_cap + FAR_CAP) longs[at] = LongNode{nd[k], F - rows[nd[k]].pos, endc - F, base, R.column_base + (F - R.start_pos)};
@@ -1414,7 +1415,7 @@ __global__ __launch_bounds__(64) void k6_ck_build(const uint8_t* s, const bgp_re
     const uint32_t pieces = (L.count + DNA_CK - 1) / DNA_CK;
     for (uint32_t j = 0; j < pieces; ++j) piece_node[L.ck_base + j] = i;
     DnaState st; bool err, bad;
-    dna_begin(st, s, rec[L.rec], &err);
+    dna_begin(st, s, rec[L.rec], &err, true);
     if (err) return;                                              // the pool is zero-filled: every piece of this node stays dead
     (void)bad;
     for (uint32_t j = 0; j < pieces; ++j) {
@@ -1628,7 +1629,12 @@ int k6_reference_bases(bgp_ctx* c, int skip_zero, uint32_t run_first, uint32_t r
             for (uint32_t k : ks) {
                 const uint64_t lo = cr[k].first / SEG + k, hi = (cr[k].endrec ? (cr[k].endrec - 1) / SEG : 0) + k + 1;
                 TimedRegion t(c, "k6_emit", mr[k].end_pos - mr[k].start_pos);
-                hipLaunchKernelGGL(k6_emit, dim3((unsigned)(hi - lo)), dim3(64), 0, c->stream, c->d_stream, c->d_rec.as<bgp_record>(), c->d_md_row.as<MdRow>(), c->d_md_succ.as<Succ>(),
+                if (vlist)      // (a stream of long records: its instantiation lists long providers for k6_verify_long and sends far chunks the checkpointed way)
+                hipLaunchKernelGGL(k6_emit<true>, dim3((unsigned)(hi - lo)), dim3(64), 0, c->stream, c->d_stream, c->d_rec.as<bgp_record>(), c->d_md_row.as<MdRow>(), c->d_md_succ.as<Succ>(),
+                                   c->d_md_entry.as<Succ>(), lo, hi - lo, (const EmitRun*)(st + off_er), nr, (ParOut*)(st + off_po), c->d_refbase.as<uint8_t>(),
+                                   (LongNode*)(c->d_md_long.as<uint8_t>() + 16), longs_cap, c->d_md_long.as<unsigned int>(), 1, vlist, vcap);
+                else
+                hipLaunchKernelGGL(k6_emit<false>, dim3((unsigned)(hi - lo)), dim3(64), 0, c->stream, c->d_stream, c->d_rec.as<bgp_record>(), c->d_md_row.as<MdRow>(), c->d_md_succ.as<Succ>(),
                                    c->d_md_entry.as<Succ>(), lo, hi - lo, (const EmitRun*)(st + off_er), nr, (ParOut*)(st + off_po), c->d_refbase.as<uint8_t>(),
                                    (LongNode*)(c->d_md_long.as<uint8_t>() + 16), longs_cap, c->d_md_long.as<unsigned int>(), 1, vlist, vcap);
             }
