@@ -1898,7 +1898,9 @@ __device__ __forceinline__ CursorAt cursor_at(const Stops st, uint32_t rr) {
 #endif
 constexpr int K5R = BGP_K5R;            // entries of a column that leave together (a power of two)
 static_assert(sizeof(bgp_entry) == 16, "an entry is one 16-byte store");
-__global__ __launch_bounds__(256, BGP_K5_MINW) void k5_fill_blk(K5Args a) {
+// CK: the stream holds long reads (K4 left checkpoints): the route that settles a read's ops by the wave is compiled in.  (A stream without them
+// gets an instantiation without that route's registers.)
+template <bool CK> __global__ __launch_bounds__(256, BGP_K5_MINW) void k5_fill_blk(K5Args a) {
     const uint64_t np = a.pos_end - a.pos_begin;
     const uint64_t col0 = ((uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;
     const int lane = threadIdx.x & 63;
@@ -2048,7 +2050,7 @@ __global__ __launch_bounds__(256, BGP_K5_MINW) void k5_fill_blk(K5Args a) {
         // a long read's checkpoint for the window its first column of the block lies in, asked for here by the read's own lane: 64 rows'
         // two dependent loads at once, not two round trips for every long read in its turn
         Ckpt ckr{0xFFFFFFFFu, 0u, 0u, 0u};
-        const bool ckd = hit && a.ck && wants_ckpt(r.flag_nc & 0xFFFFu, (uint32_t)r.l_seq);
+        const bool ckd = CK && hit && a.ck && wants_ckpt(r.flag_nc & 0xFFFFu, (uint32_t)r.l_seq);
         if (ckd) {
             const uint64_t rr0 = max(p0, (uint64_t)(uint32_t)r.pos) - (uint32_t)r.pos;
             const uint64_t wj = ((uint64_t)(uint32_t)r.pos + rr0 - a.run.start_pos) / a.ck_w - ((uint64_t)(uint32_t)r.pos - a.run.start_pos) / a.ck_w;
@@ -2105,12 +2107,12 @@ __global__ __launch_bounds__(256, BGP_K5_MINW) void k5_fill_blk(K5Args a) {
                 bool res = false; uint32_t r_ix = 0xFFFFu, r_off = 0, r_qo = 0; bool r_hit = false, r_qc = false;
                 if (!small) {
                     const uint32_t rr0 = (uint32_t)(max(p0, (uint64_t)(uint32_t)q.pos) - (uint32_t)q.pos);
-                    if (__builtin_amdgcn_readlane((int)ckd, src)) {      // entry_cursor, from what the read's lane loaded with its row
+                    if (CK && __builtin_amdgcn_readlane((int)ckd, src)) {      // entry_cursor, from what the read's lane loaded with its row
                         const uint32_t k_ = (uint32_t)__builtin_amdgcn_readlane((int)ckr.k, src);
                         if (k_ != 0xFFFFFFFFu) { bk = k_; bcs = (uint32_t)__builtin_amdgcn_readlane((int)ckr.cs, src); bqs = (uint32_t)__builtin_amdgcn_readlane((int)ckr.qs, src); bst = true; }
                         else bk = q.flag_nc & 0xFFFFu;                    // the cursor ran off the CIGAR before this window (pileup.d:224-228)
                     }
-                    if (bst) {
+                    if (CK && bst) {
                         const uint32_t n_cig = q.flag_nc & 0xFFFFu;
                         const uint8_t* cg = a.s + q.rec_off + 36 + (q.bin_mq_nl & 0xFFu);
                         const uint32_t c0 = (uint32_t)(max(p0, (uint64_t)(uint32_t)q.pos) - p0);      // the read's first column of the block
@@ -2143,7 +2145,7 @@ __global__ __launch_bounds__(256, BGP_K5_MINW) void k5_fill_blk(K5Args a) {
                         }
                     }
                 }
-                if (!small && bst) {
+                if (CK && !small && bst) {
                     if (mine) {      // the entry as entry_walk writes it (a column no op owns: the cursor ran off the CIGAR, pileup.d:224-228)
                         bgp_entry e; e.read_ordinal = (uint32_t)(base + (uint64_t)src); e.cigar_op_index = (uint16_t)(r_hit ? r_ix : 0xFFFFu);
                         e.cigar_op_offset = r_hit ? r_off : 0u; e.query_offset = r_hit ? r_qo : 0u; e.base = 0xFF; e.qual = 0xFF;
@@ -2503,7 +2505,8 @@ int k5_entries(bgp_ctx* c, uint32_t run_idx, uint64_t pos_begin, uint64_t pos_en
         if (per_column) hipLaunchKernelGGL(k5_fill, dim3((unsigned)((np + 3) / 4)), dim3(256), 0, c->stream, a);
         else
 #endif
-        hipLaunchKernelGGL(k5_fill_blk, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, c->stream, a);
+        if (a.ck) hipLaunchKernelGGL(k5_fill_blk<true>, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, c->stream, a);
+        else hipLaunchKernelGGL(k5_fill_blk<false>, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, c->stream, a);
     }
     BGP_HIP(hipGetLastError());
     *n_entries = total;
