@@ -405,15 +405,31 @@ template <bool WPR> __global__ __launch_bounds__(256) void k4_ck_build(const uin
                     if (f0 != fl || !cig_qc((uint32_t)__shfl((int)opsel, (int)(f0 >> 2), 64))) plain = false;
                 }
             }
-            uint32_t rlen[4], qlen[4], rt = 0, qt = 0;
+            uint32_t rlen[4], qlen[4], rt = 0, qt = 0, qcm[4], badm = 0;
+            if (started) {      // (every chunk but a read's first: masks and arithmetic where op_lens' cases were exec-mask bookkeeping)
 #pragma unroll
-            for (int t = 0; t < 4; ++t) { op_lens(op[t], act[t], started || 4u * (uint32_t)lane + t >= fl, &rlen[t], &qlen[t]); rt += rlen[t]; qt += qlen[t]; }
+                for (int t = 0; t < 4; ++t) {
+                    const uint32_t o = op[t], len = o >> 4, tb = 0x3C1A7u >> ((o & 15u) * 2);
+                    const uint32_t am = act[t] ? ~0u : 0u, rcm = am & (0u - ((tb >> 1) & 1u)), qm = am & (0u - (tb & 1u));
+                    const uint32_t elen = max(len, 1u);
+                    rlen[t] = rcm & elen; qlen[t] = qm & ((rcm & elen) | (~rcm & len)); qcm[t] = qm;
+                    badm |= rcm & (len == 0u ? ~0u : 0u);
+                    rt += rlen[t]; qt += qlen[t];
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    op_lens(op[t], act[t], 4u * (uint32_t)lane + t >= fl, &rlen[t], &qlen[t]); rt += rlen[t]; qt += qlen[t];
+                    qcm[t] = act[t] && cig_qc(op[t]) ? ~0u : 0u;
+                    badm |= act[t] && cig_rc(op[t]) && (op[t] >> 4) == 0 ? ~0u : 0u;
+                }
+            }
             const uint32_t ir = wave_incl_u32(rt, lane), iq = wave_incl_u32(qt, lane);
             uint32_t cs_b = cs + ir - rt, qs_b = qs + iq - qt;
-            bool bad = false;
+            bool bad = badm != 0u;
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                bad |= (act[t] && cig_rc(op[t]) && (op[t] >> 4) == 0) || (rlen[t] && cig_qc(op[t]) && qs_b + qlen[t] > l_seq_r);
+                bad |= rlen[t] && qcm[t] && qs_b + qlen[t] > l_seq_r;
                 if (rlen[t]) {
                     if (cs_b == 0 && n_ck) { Ckpt e{k0 + t, 0u, qs_b, 0u}; out[0] = e; }      // window of the read's first column
                     // the windows that start inside the op's columns [cs_b, cs_b + rlen): window j starts at column D + j * W, so they are
