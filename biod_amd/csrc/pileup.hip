@@ -1019,6 +1019,7 @@ struct PlanArgs {
     unsigned long long* slab; uint32_t slab_cap; uint32_t* wcount; int32_t* wdel; int32_t* wslow;
     const uint64_t* ck_off; const Ckpt* ck;       // long reads' checkpoints on this tiling (null: none, or long reads are left to the general kernel)
     uint32_t* wlong;                              // ... and the windows a well-formed long read touches (k4_acc2 walks its CIGAR there, from the window's checkpoint)
+    int batches;                                  // batches of 64 reads a wave plans
 };
 
 #ifndef BGP_PLAN_NB
@@ -1029,12 +1030,13 @@ __global__ __launch_bounds__(256) void k4_plan(PlanArgs a) {
     const int lane = threadIdx.x & 63;
     // A wave's time was its chain of round trips -- rows, then the slots' atomics, then the stores -- with a wave slot held all the
     // while (77 % of its cycles waiting): a wave takes PLAN_NB batches and asks for the next one's rows before it works on this one's.
-    const uint64_t first = ((uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * (uint64_t)(64 * PLAN_NB);
+    const int nb_ = a.batches;                                             // (PLAN_NB; 1 for a stream of so few reads that the waves would not fill the device)
+    const uint64_t first = ((uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * (uint64_t)(64 * nb_);
     if (first >= a.n) return;
     uint4 nx, ny, nc4 = make_uint4(0, 0, 0, 0);
     { const uint64_t ii = min(first + (uint64_t)lane, a.n - 1); const uint4* rp = reinterpret_cast<const uint4*>(a.rec + ii); nx = rp[0]; ny = rp[1]; if (a.cig4) nc4 = a.cig4[ii]; }
     uint64_t r_end = 0, r_start_pos = 0, r_tile_base = 0;
-    for (int it = 0; it < PLAN_NB; ++it) {
+    for (int it = 0; it < nb_; ++it) {
     const uint64_t i = first + (uint64_t)(64 * it) + (uint64_t)lane;
     // Straight-line, selects instead of joins, descriptors in 32-bit halves: written with a branch per case and per op this
     // kernel spent 600 VALU instructions a wave, four in ten of them register moves where the branches met -- and VALU
@@ -1047,7 +1049,7 @@ __global__ __launch_bounds__(256) void k4_plan(PlanArgs a) {
     const uint64_t i0 = i - lane;
     if (i0 >= a.n) break;
     const uint4 x = nx, y = ny, c4 = nc4;                 // ref_id,pos,end_pos,bin_mq_nl | flag_nc,l_seq,rec_off | the first four CIGAR ops
-    if (it + 1 < PLAN_NB && i0 + 64 < a.n) { const uint64_t jn = min(i + 64, a.n - 1); const uint4* rp = reinterpret_cast<const uint4*>(a.rec + jn); nx = rp[0]; ny = rp[1]; if (a.cig4) nc4 = a.cig4[jn]; }
+    if (it + 1 < nb_ && i0 + 64 < a.n) { const uint64_t jn = min(i + 64, a.n - 1); const uint4* rp = reinterpret_cast<const uint4*>(a.rec + jn); nx = rp[0]; ny = rp[1]; if (a.cig4) nc4 = a.cig4[jn]; }
     uint64_t w_start_pos, w_tile_base;                    // (the wave's run; lanes beyond its end look theirs up below)
     if (it == 0 || i0 >= r_end) { const RunDev rd = a.runs[run_of_record(a.runs, a.n_runs, i0)]; r_end = rd.end_record; r_start_pos = rd.start_pos; r_tile_base = rd.tile_base; }
     w_start_pos = r_start_pos; w_tile_base = r_tile_base;
@@ -2386,7 +2388,8 @@ int k34_pileup(bgp_ctx* c) {
             pa.runs = a.runs; pa.n_runs = n_runs; pa.n_tiles = tile_base;
             pa.slab = (unsigned long long*)c->d_slab.p; pa.slab_cap = slab_cap; pa.wcount = c->d_wcount.as<uint32_t>(); pa.wdel = c->d_wdel.as<int32_t>(); pa.wslow = c->d_wslow.as<int32_t>();
             pa.ck = have_rows ? a.ck : nullptr; pa.ck_off = a.ck_off; pa.wlong = have_rows ? c->d_wlong.as<uint32_t>() : nullptr;
-            hipLaunchKernelGGL(k4_plan, dim3((unsigned)((n + 256ull * PLAN_NB - 1) / (256ull * PLAN_NB))), dim3(256), 0, c->stream, pa);
+            pa.batches = n >= (4ull << 20) ? PLAN_NB : 1;
+            hipLaunchKernelGGL(k4_plan, dim3((unsigned)((n + 256ull * pa.batches - 1) / (256ull * pa.batches))), dim3(256), 0, c->stream, pa);
             const unsigned wb = (unsigned)((tile_base + 1023) / 1024);
             BGP_TRY(c->d_scan_tmp.reserve((size_t)wb * 8 + 16));
             int32_t* btot = c->d_scan_tmp.as<int32_t>();
