@@ -1602,8 +1602,12 @@ template <bool LONG> __global__ __launch_bounds__(AT, BGP_ACC2_MINW) void k4_acc
                         if (c0 != cur.k) op2 = ops_of(cur, c0);
                         const uint32_t k0 = c0 + 2u * (uint32_t)lane;
                         uint32_t rl0, ql0, rl1, ql1;
-                        op_lens(op2.x, k0 < cur.n_cig, true, &rl0, &ql0);
-                        op_lens(op2.y, k0 + 1 < cur.n_cig, true, &rl1, &ql1);
+                        {   // op_lens with the cursor started, by masks and arithmetic (its cases were exec-mask bookkeeping)
+                            const uint32_t l0 = op2.x >> 4, t0 = 0x3C1A7u >> ((op2.x & 15u) * 2), a0 = k0 < cur.n_cig ? ~0u : 0u, r0 = a0 & (0u - ((t0 >> 1) & 1u)), e0 = max(l0, 1u);
+                            rl0 = r0 & e0; ql0 = a0 & (0u - (t0 & 1u)) & ((r0 & e0) | (~r0 & l0));
+                            const uint32_t l1 = op2.y >> 4, t1 = 0x3C1A7u >> ((op2.y & 15u) * 2), a1 = k0 + 1 < cur.n_cig ? ~0u : 0u, r1 = a1 & (0u - ((t1 >> 1) & 1u)), e1 = max(l1, 1u);
+                            rl1 = r1 & e1; ql1 = a1 & (0u - (t1 & 1u)) & ((r1 & e1) | (~r1 & l1));
+                        }
                         const uint32_t ir = wave_scan_u32(rl0 + rl1), iq = wave_scan_u32(ql0 + ql1);
                         const uint32_t csb[2] = {cs + ir - rl0 - rl1, cs + ir - rl1}, qsb[2] = {qs + iq - ql0 - ql1, qs + iq - ql1};
                         const uint32_t rln[2] = {rl0, rl1}, opv[2] = {op2.x, op2.y};
