@@ -1954,6 +1954,7 @@ template <bool CK> __global__ __launch_bounds__(256, BGP_K5_MINW) void k5_fill_b
     uint4 (*list)[64] = s_wave[threadIdx.x >> 6] + K5R;
     uint32_t* const stg = reinterpret_cast<uint32_t*>(s_wave[threadIdx.x >> 6]) + lane;      // word k of this lane: stg[64 * k]
     uint32_t cnt = 0, n_list = 0;
+    uint32_t pf_op = 0; int pf_src = -1; uint64_t pf_base = ~0ull;      // the ops of the NEXT checkpointed read of the step, asked for while this one is worked on
     auto flush_ring = [&]() {
         for (uint32_t k = 0; k < (cnt & (K5R - 1)); ++k) { const uint4 x = ring[k][lane]; __builtin_memcpy(a.entries + w + k, &x, 16); }
         w += cnt & (K5R - 1); cnt = 0;
@@ -2127,6 +2128,27 @@ template <bool CK> __global__ __launch_bounds__(256, BGP_K5_MINW) void k5_fill_b
                 // ds_bpermute its data.  (Every lane then walking from the block's first column by itself was a CIGAR load per op and
                 // lane: cfg5, an op every ~10 columns, 3.5 ms for 1.2 * 10^8 entries.)
                 bool res = false; uint32_t r_ix = 0xFFFFu, r_off = 0, r_qo = 0; bool r_hit = false, r_qc = false;
+                // (a read is two round trips -- its ops, then its bases -- and the reads of a block come one after the other: the first 64 ops of
+                // the next checkpointed read of this step are asked for before this read's are looked at)
+                const bool have_pf = CK && pf_src == src && pf_base == base;
+                const uint32_t my_pf = pf_op;
+                if (CK) {
+                    const unsigned long long rest = mh & ~ms;                      // (mh no longer holds src)
+                    pf_src = -1;
+                    if (rest) {
+                        const int ns = __ffsll((long long)rest) - 1;
+                        if (__builtin_amdgcn_readlane((int)ckd, ns)) {
+                            const uint32_t kn = (uint32_t)__builtin_amdgcn_readlane((int)ckr.k, ns);
+                            if (kn != 0xFFFFFFFFu) {
+                                const uint64_t ro = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(r.rec_off >> 32), ns) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)r.rec_off, ns);
+                                const uint32_t ncn = (uint32_t)__builtin_amdgcn_readlane((int)r.flag_nc, ns) & 0xFFFFu, lnn = (uint32_t)__builtin_amdgcn_readlane((int)r.bin_mq_nl, ns) & 0xFFu;
+                                const uint32_t kk = kn + (uint32_t)lane;
+                                pf_op = kk < ncn ? ld_u32(a.s + ro + 36 + lnn + 4ull * kk) : 0u;
+                                pf_src = ns; pf_base = base;
+                            }
+                        }
+                    }
+                }
                 if (!small) {
                     const uint32_t rr0 = (uint32_t)(max(p0, (uint64_t)(uint32_t)q.pos) - (uint32_t)q.pos);
                     if (CK && __builtin_amdgcn_readlane((int)ckd, src)) {      // entry_cursor, from what the read's lane loaded with its row
@@ -2140,9 +2162,11 @@ template <bool CK> __global__ __launch_bounds__(256, BGP_K5_MINW) void k5_fill_b
                         const uint32_t c0 = (uint32_t)(max(p0, (uint64_t)(uint32_t)q.pos) - p0);      // the read's first column of the block
                         const uint32_t rrc = (uint32_t)(p - (uint32_t)q.pos);                          // this lane's column, counted from the read's first
                         uint32_t* const mk = reinterpret_cast<uint32_t*>(list);                         // (the list is empty here: flush_list above)
+                        bool first_step = true;
                         while (bk < n_cig && __ballot(mine && !res)) {
                             const uint32_t kk = bk + (uint32_t)lane;
-                            const uint32_t op = kk < n_cig ? ld_u32(cg + 4ull * kk) : 0u;
+                            const uint32_t op = first_step && have_pf ? my_pf : (kk < n_cig ? ld_u32(cg + 4ull * kk) : 0u);
+                            first_step = false;
                             const bool on = kk < n_cig, qc = on && cig_qc(op), rc = on && cig_rc(op);
                             const uint32_t len = op >> 4, elen = len ? len : 1u;
                             const uint32_t cl = rc ? elen : 0u, ql = qc ? (rc ? elen : len) : 0u;
