@@ -946,13 +946,47 @@ __global__ __launch_bounds__(256) void k6_succ(const MdRow* rows, const uint32_t
             run = take;
         }
         const uint64_t j = base + jr;
+        const bool ok0 = ok;
         ok = ok && !special && best_end > CE && (ended || j >= R.endrec);      // (stopped by the staged rows' end: not decided here)
         if (ok) {
             if (ended || A < R.run_end) {                                    // FETCH at A; at the run's end only if it comes before the end of coverage
                 out_n = best; out_f = A;
                 flag = arrival_irregular(s_rows[best - base], A);
             }
-        } else deferred = node;
+        } else {
+            // No read that starts by A ends beyond the chunk (the provider has an N skip: its chunk_end lies kilobases behind its last char): the
+            // chunk runs empty, the sweep goes on to the FIRST read that ends beyond chunk_end -- add() takes nothing before it, pileup.d:583-588 --,
+            // fetches at F = max(A, its position) and keeps the first read with the largest end among those that start by F.  With the table that
+            // is a search by doubling for the first row whose end exceeds CE, a binary search for the window's end and one more range maximum;
+            // the wave's walk (succ_coop) did it with three or four steps of 64 rows for each such read, one read after the other -- half of this
+            // kernel's time for cfg3's 4 % of reads with a skip.  Whatever is not plainly this case is still handed to it.
+            bool done2 = false;
+            if (table_ok && ok0 && !special && ended && best_end <= CE && CE >= pos_base && CE - pos_base < (1u << 22)) {
+                const uint32_t ce_key = ((CE - pos_base + 1u) << 9) | 511u;      // a key is larger exactly when its row ends beyond CE
+                uint32_t x = jr;                                                  // (the row that closed the window by A)
+                while (x + (1u << (LV - 1)) <= limr && s_key[LV - 1][x] <= ce_key) x += 1u << (LV - 1);
+#pragma unroll
+                for (int k = LV - 2; k >= 0; --k) if (x + (1u << k) <= limr && s_key[k][x] <= ce_key) x += 1u << k;
+                if (x < limr && s_key[0][x] > ce_key) {
+                    const MdRow rj = s_rows[x];
+                    if (rj.pos <= CE) {
+                        const uint32_t F = max(A, rj.pos);
+                        uint32_t lo2 = x + 1u, hi2 = limr;
+                        while (lo2 < hi2) { const uint32_t m = (lo2 + hi2) >> 1; if (s_rows[m].pos <= F) lo2 = m + 1; else hi2 = m; }
+                        const uint32_t y = lo2;                                   // rows [x, y) start by F; row y closes the window
+                        if (y < limr && y - x < (1u << LV) && (s_rows[y].lf & MD_COV) && s_sp[y + 1] == s_sp[jr]) {
+                            const uint32_t len = y - x, k = 31u - (uint32_t)__builtin_clz(len);
+                            const uint32_t m = max(s_key[k][x], s_key[k][y - (1u << k)]);
+                            const uint32_t b2 = (uint32_t)base + (uint32_t)(STAGE - 1) - (m & 511u);
+                            out_n = b2; out_f = F;
+                            flag = arrival_irregular(s_rows[b2 - base], F);
+                            done2 = true;
+                        }
+                    }
+                }
+            }
+            if (!done2) deferred = node;
+        }
     }
 #else
     bool found = false, flag = false, deferred = false, done = !node;
