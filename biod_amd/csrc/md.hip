@@ -312,22 +312,22 @@ __device__ bool q_advance(QIter& q, uint32_t k, uint32_t* done) {      // k time
     }
     return true;
 }
-__device__ void dna_skip(DnaState& st, uint32_t target) {
+__device__ void dna_skip(DnaState& st, uint32_t target, bool* stall = nullptr) {      // *stall: the range stalls on an empty query or an empty deletion before `target` (dna_run's *bad)
     while (st.live && st.n < target) {
         if (st.cur.type == 1) {
             ++st.n;
-            if (st.q.empty) { st.live = false; return; }
+            if (st.q.empty) { st.live = false; if (stall) *stall = true; return; }
             q_pop(st.q);
         } else if (st.cur.type == 0) {
-            if (st.q.empty) { st.live = false; return; }
+            if (st.q.empty) { st.live = false; if (stall) *stall = true; return; }
             const uint32_t want = st.cur.match < target - st.n ? st.cur.match : target - st.n;
             uint32_t got;
             const bool all = q_advance(st.q, want, &got);
             st.n += got; st.cur.match -= got;
-            if (!all) { st.live = false; return; }
+            if (!all) { st.live = false; if (stall) *stall = true; return; }
             if (st.cur.match != 0) continue;
         } else {
-            if (st.cur.del_len == 0) { st.live = false; return; }
+            if (st.cur.del_len == 0) { st.live = false; if (stall) *stall = true; return; }
             const uint32_t left = st.cur.del_len - st.del_i, t = left < target - st.n ? left : target - st.n;
             st.n += t; st.del_i += t;
             if (st.del_i < st.cur.del_len) continue;
@@ -1410,30 +1410,36 @@ template <bool LONGS> __global__ __launch_bounds__(64) void k6_emit(const uint8_
             const uint32_t F = fc[k];
             uint32_t endc = fc[k + 1];
             if (endc > R.end_pos) endc = R.end_pos;
-            if (verify) {                                         // this provider's real tag against what the rows assumed of it (k6_prep<false>)
-                bool inl = true;
-                if (LONGS && vlist && (uint32_t)rec[nd[k]].l_seq > VERIFY_LONG) {      // a long read's tag: a wave of its own (k6_verify_long), not a lane's ten thousand steps
-                    const uint32_t at = atomicAdd(&ctr[2], 1u);
-                    if (at < vcap) { vlist[at] = VEntry{nd[k], s_run}; inl = false; }
-                }
-                if (inl) {
-                    bool vb, ve;
-                    const uint32_t Lt = dna_length(s, rec[nd[k]], &vb, &ve);
-                    if (vb || ve || Lt != dna_length_by_cigar(s, rec[nd[k]], nullptr)) po[s_run].flagged = 1u;
-                }
+            const MdRow rw = rows[nd[k]];
+            bool check = verify != 0;                             // this provider's real tag against what the rows assumed of it (k6_prep<false>: the length its CIGAR implies)
+            if (check && LONGS && vlist && (uint32_t)rec[nd[k]].l_seq > VERIFY_LONG) {      // a long read's tag: a wave of its own (k6_verify_long), not a lane's ten thousand steps
+                const uint32_t at = atomicAdd(&ctr[2], 1u);
+                if (at < vcap) { vlist[at] = VEntry{nd[k], s_run}; check = false; }
             }
-            if (F >= endc) continue;
             // a long chunk is emitted in pieces from checkpoints; so is a chunk far into a long read (getting there is the walk of thousands of
             // operations: a wave of its own, k6_ck_build) while the list has room for it (long chunks are bounded by the columns, far ones by FAR_CAP)
-            const bool big = endc - F > DNA_LONG;
-            if (big || (LONGS && F - rows[nd[k]].pos > DNA_LONG && atomicAdd(&ctr[3], 1u) < FAR_CAP)) {
+            bool walk = F < endc;
+            if (walk && (endc - F > DNA_LONG || (LONGS && F - rw.pos > DNA_LONG && atomicAdd(&ctr[3], 1u) < FAR_CAP))) {
                 const uint32_t at = atomicAdd(&ctr[0], 1u), pieces = (endc - F + DNA_CK - 1) / DNA_CK;
                 const uint32_t base = atomicAdd(&ctr[1], pieces);
-                if (at < longs_cap + FAR_CAP) longs[at] = LongNode{nd[k], F - rows[nd[k]].pos, endc - F, base, R.column_base + (F - R.start_pos)};
-                continue;
+                if (at < longs_cap + FAR_CAP) longs[at] = LongNode{nd[k], F - rw.pos, endc - F, base, R.column_base + (F - R.start_pos)};
+                walk = false;
             }
-            bool bad, err;
-            dna_walk(s, rec[nd[k]], F - rows[nd[k]].pos, endc - F, refbase + R.column_base + (F - R.start_pos), &bad, &err);
+            if (!walk && !check) continue;
+            // ONE walk of the tag for both: the chunk's chars, then on to the range's end an operation at a time for its length (the tag was
+            // found and parsed twice, once by dna_length and once by dna_walk)
+            DnaState st; bool err, bad = false, stall = false;
+            dna_begin(st, s, rec[nd[k]], &err);
+            if (err) { if (check) po[s_run].flagged = 1u; continue; }
+            if (walk) {
+                const uint32_t from = F - rw.pos;
+                if (from) dna_skip(st, from, &stall);
+                dna_run(st, s, from, from + (endc - F), refbase + R.column_base + (F - R.start_pos), &bad);
+            }
+            if (check) {
+                dna_skip(st, 0xFFFFFFFFu, &stall);
+                if (bad || stall || st.n != (rw.lf & MD_LMASK)) po[s_run].flagged = 1u;
+            }
         }
         if (!more) break;
         __syncthreads();                                          // (the stretch's entries are read: thread 0 may write the next)
