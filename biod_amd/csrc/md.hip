@@ -1073,32 +1073,35 @@ __global__ __launch_bounds__(256) void k6_succ(const MdRow* rows, const uint32_t
 // the flags on the way -- pointer doubling over the segment's 2048 entries in LDS (a hop advances by at least
 // one record, so 11 rounds always suffice; typical chains need 7).
 __global__ __launch_bounds__(256) void k6_exit(const Succ* succ, uint64_t n, Succ* ex) {
-    __shared__ Succ buf[2][SEG];
+    // Pointer jumping IN PLACE: an entry is written by its own thread only and read by others as one 64-bit word, and whatever a reader
+    // finds there -- the entry as it was or already jumped -- is a stretch of the chain from that record on with the flags met on it, so
+    // composing with it is right either way (and a round gets further than with a copy of the round before: 16 KB of LDS a block, not 32).
+    __shared__ unsigned long long buf[SEG];
     __shared__ int changed;
+    static_assert(sizeof(Succ) == 8, "an entry is one 64-bit word");
     const uint64_t lo = (uint64_t)blockIdx.x * SEG;
-    for (int t = threadIdx.x; t < SEG; t += 256) buf[0][t] = lo + t < n ? succ[lo + t] : Succ{SX_NONE, 0u};
+    auto pack = [](const Succ& e) { return ((unsigned long long)e.fcol << 32) | e.nxt; };
+    auto unpack = [](unsigned long long w) { return Succ{(uint32_t)w, (uint32_t)(w >> 32)}; };
+    for (int t = threadIdx.x; t < SEG; t += 256) buf[t] = pack(lo + t < n ? succ[lo + t] : Succ{SX_NONE, 0u});
     __syncthreads();
-    int cur = 0;
     for (int round = 0; round < 12; ++round) {
         if (threadIdx.x == 0) changed = 0;
         __syncthreads();
         bool any = false;
         for (int t = threadIdx.x; t < SEG; t += 256) {
-            Succ e = buf[cur][t];
+            Succ e = unpack(buf[t]);
             if (e.nxt < SX_NONE && e.nxt >= lo && e.nxt < lo + SEG) {
-                const Succ f = buf[cur][e.nxt - lo];
+                const Succ f = unpack(buf[e.nxt - lo]);
                 e = Succ{f.nxt, f.fcol | (e.fcol & SX_FLAG) | (f.nxt == SX_NONE ? SX_FLAG : 0u)};
+                buf[t] = pack(e);
                 any = true;
             }
-            buf[cur ^ 1][t] = e;
         }
         if (any) changed = 1;
         __syncthreads();
-        cur ^= 1;
         if (!changed) break;
-        __syncthreads();
     }
-    for (int t = threadIdx.x; t < SEG; t += 256) if (lo + t < n) ex[lo + t] = buf[cur][t];
+    for (int t = threadIdx.x; t < SEG; t += 256) if (lo + t < n) ex[lo + t] = unpack(buf[t]);
 }
 
 // One wave per run: the first provider (initNewReference on the run's first position group, filtered against the
