@@ -222,6 +222,7 @@ int bgzf_load_bam(bgp_ctx* c, const char* path, int n_threads) {
 // No inflated byte exists on the host; the virtual-offset map is filled as in bgzf_load_bam.
 #include <condition_variable>
 #include <mutex>
+#include <memory>
 
 int bgzf_load_bam_device(bgp_ctx* c, const char* path) {
     const bool verbose = getenv("BGP_VERBOSE") != nullptr;
@@ -247,7 +248,15 @@ int bgzf_load_bam_device(bgp_ctx* c, const char* path) {
     std::mutex mu; std::condition_variable cv;
     uint64_t turn = 0, scan_off = 0, scan_uoff = 0; int scan_rc = BGP_OK; std::string scan_err;
     std::atomic<uint64_t> next{0}; std::atomic<int> hip_rc{BGP_OK};
-    auto reader = [&](int t) {
+    // The blocks are inflated WHILE the file is still arriving: this thread follows the scan, and whenever a few thousand blocks lie whole in
+    // what has been uploaded it launches k_inflate for them on the ctx's stream, behind the uploads' events (read + upload and inflate took
+    // turns before: 66 + 69 ms for a 1.6 GB file).  The output buffer and the descriptor table are sized by estimate -- six times the file,
+    // a block per 2 KB -- and a file that outgrows either is inflated the old way, in one launch at the end.
+    std::vector<hipEvent_t> ev(n_chunks, nullptr);
+    std::unique_ptr<std::atomic<int>[]> ev_ready(new std::atomic<int>[n_chunks]);
+    for (uint64_t k = 0; k < n_chunks; ++k) { ev_ready[k].store(0); if (hipEventCreateWithFlags(&ev[k], hipEventDisableTiming) != hipSuccess) { c->last_error = "hipEventCreate failed"; return BGP_EDEVICE; } }
+    struct Events { std::vector<hipEvent_t>& e; ~Events() { for (hipEvent_t x : e) if (x) (void)hipEventDestroy(x); } } events_guard{ev};
+    auto reader_ev = [&](int t) {      // reader() with the upload's event made known
         if (hipSetDevice(c->device) != hipSuccess) { hip_rc.store(BGP_EDEVICE); }
         hipStream_t s = nullptr;
         if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) hip_rc.store(BGP_EDEVICE);
@@ -271,55 +280,145 @@ int bgzf_load_bam_device(bgp_ctx* c, const char* path) {
             }
             cv.notify_all();
             if (s && hip_rc.load() == BGP_OK &&
-                hipMemcpyAsync(c->d_comp.as<uint8_t>() + lo, buf, std::min(CH, fsz - lo), hipMemcpyHostToDevice, s) != hipSuccess) hip_rc.store(BGP_EDEVICE);
+                (hipMemcpyAsync(c->d_comp.as<uint8_t>() + lo, buf, std::min(CH, fsz - lo), hipMemcpyHostToDevice, s) != hipSuccess || hipEventRecord(ev[k], s) != hipSuccess)) hip_rc.store(BGP_EDEVICE);
+            ev_ready[k].store(1, std::memory_order_release);
         }
         if (s) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
     };
     std::vector<std::thread> th;
-    for (int t = 1; t < T; ++t) th.emplace_back(reader, t);
-    reader(0);
+    for (int t = 0; t < T; ++t) th.emplace_back(reader_ev, t);
+
+    const bool pipelined = !(getenv("BGP_INFLATE_PIPELINE") && atoi(getenv("BGP_INFLATE_PIPELINE")) == 0);
+    constexpr uint64_t SLACK = 65536;                     // the block that holds the first record starts up to 64 KB before it
+    const uint64_t est_bytes = std::max<uint64_t>(6 * fsz, 64ull << 20);
+    const size_t nb_cap = (size_t)(fsz / 2048 + 4096);
+    std::vector<bgp_inflate_block> desc;
+    std::vector<uint64_t> desc_src_blk;                    // (for error messages: nothing else)
+    desc.reserve(nb_cap);
+    int32_t* d_status = nullptr;
+    bool fallback = !pipelined, have_q = false;
+    uint64_t q = 0;
+    size_t bi = 0, n_desc_launched = 0;                    // blocks looked at; descriptors already launched
+    uint64_t up_chunks = 0;
+    std::vector<uint8_t> head, cbuf(65536 + 64);
+    size_t jh = 0;
+    int disp_rc = BGP_OK;
+    std::vector<Blk> snap;
+    // (the batches' launches go round four streams: one batch does not fill the device, and on one stream they ran one after the other)
+    constexpr int NS = 4;
+    hipStream_t istream[NS] = {nullptr, nullptr, nullptr, nullptr};
+    struct Streams { hipStream_t* s; ~Streams() { for (int i = 0; i < NS; ++i) if (s[i]) { (void)hipStreamSynchronize(s[i]); (void)hipStreamDestroy(s[i]); } } } streams_guard{istream};
+    for (int i = 0; i < NS; ++i) if (hipStreamCreateWithFlags(&istream[i], hipStreamNonBlocking) != hipSuccess) { c->last_error = "hipStreamCreate failed"; for (auto& x : th) x.join(); return BGP_EDEVICE; }
+    int n_batch = 0;
+    for (;;) {
+        uint64_t tn; int src; size_t nblk;
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            tn = turn; src = scan_rc; nblk = blocks.size();
+            if (nblk > snap.size()) snap.insert(snap.end(), blocks.begin() + (ptrdiff_t)snap.size(), blocks.end());
+        }
+        const bool all_scanned = tn >= n_chunks || src != BGP_OK || hip_rc.load() != BGP_OK;
+        if (src != BGP_OK || hip_rc.load() != BGP_OK) break;
+        if (!fallback && disp_rc == BGP_OK) {
+            // the BAM header: inflate its blocks on the host until it parses (reader.d:111-116,579-597)
+            while (!have_q && jh < snap.size()) {
+                const Blk& b = snap[jh];
+                head.resize((size_t)(b.uoff + b.isize));
+                if ((uint64_t)pread(fd, cbuf.data(), b.cdata_len, (off_t)(b.coff + b.cdata_off)) != b.cdata_len) { c->last_error = "short read"; disp_rc = BGP_ETRUNC; break; }
+                const int rc = inflate_cdata(cbuf.data(), b, head.data() + b.uoff);
+                if (rc < 0) { c->last_error = "zlib: corrupted BGZF block"; disp_rc = rc; break; }
+                ++jh;
+                const int got = bgp_parse_bam_header(head.data(), head.size(), c->refs, &q, c->last_error);
+                if (got < 0) { disp_rc = got; break; }
+                if (got > 0) {
+                    have_q = true;
+                    if (c->d_stream_own.reserve(SLACK + est_bytes + 256) != BGP_OK || c->d_inf_blk.reserve(nb_cap * (sizeof(bgp_inflate_block) + 4) + 64) != BGP_OK) fallback = true;
+                    else d_status = (int32_t*)(c->d_inf_blk.as<uint8_t>() + nb_cap * sizeof(bgp_inflate_block));
+                }
+            }
+            while (up_chunks < tn && ev_ready[up_chunks].load(std::memory_order_acquire)) ++up_chunks;
+            const uint64_t up_bytes = std::min(fsz, up_chunks * CH);
+            if (have_q && !fallback && disp_rc == BGP_OK) {
+                size_t j = bi; const size_t d0 = desc.size();
+                uint64_t bytes = 0;
+                while (j < snap.size() && snap[j].coff + snap[j].cdata_off + snap[j].cdata_len + 8 <= up_bytes) {
+                    const Blk& b = snap[j];
+                    if (b.isize && b.uoff + b.isize > q) {
+                        if (desc.size() >= nb_cap || b.uoff + b.isize - q > est_bytes) { fallback = true; break; }
+                        desc.push_back(bgp_inflate_block{b.coff + b.cdata_off, SLACK + b.uoff - q, b.cdata_len, b.isize, b.crc, 0});
+                        bytes += b.isize;
+                    }
+                    ++j;
+                }
+                const size_t nd = desc.size() - d0;
+                if (!fallback && nd && (nd >= 2048 || (all_scanned && j == snap.size()))) {
+                    const uint64_t k0 = snap[bi].coff / CH;
+                    bool ok = true;
+                    hipStream_t is = istream[n_batch++ % NS];
+                    for (uint64_t k = k0; k < up_chunks && ok; ++k) ok = hipStreamWaitEvent(is, ev[k], 0) == hipSuccess;
+                    ok = ok && hipMemcpyAsync(c->d_inf_blk.as<bgp_inflate_block>() + d0, desc.data() + d0, nd * sizeof(bgp_inflate_block), hipMemcpyHostToDevice, is) == hipSuccess;
+                    if (!ok) { c->last_error = "HIP error while launching the inflate"; disp_rc = BGP_EDEVICE; }
+                    else { const int rc = inflate_blocks_device(c, c->d_comp.as<uint8_t>(), c->d_stream_own.as<uint8_t>(), c->d_inf_blk.as<bgp_inflate_block>() + d0, (uint32_t)nd, d_status + d0, bytes, is); if (rc != BGP_OK) disp_rc = rc; }
+                    bi = j; n_desc_launched = desc.size();
+                } else if (!fallback && nd == 0) bi = j;    // (blocks of the header, empty blocks: nothing to launch for them)
+                else if (!fallback) desc.resize(d0);        // (not enough yet: looked at again next time round)
+            }
+        }
+        if (all_scanned && (fallback || disp_rc != BGP_OK || (have_q && bi == snap.size() && up_chunks >= n_chunks))) break;
+        if (all_scanned && !have_q) break;                 // (no header in the whole file: reported below)
+        std::this_thread::sleep_for(std::chrono::microseconds(150));
+    }
     for (auto& x : th) x.join();
-    if (hip_rc.load() < 0) { c->last_error = "HIP error while uploading the compressed file"; return hip_rc.load(); }
-    if (scan_rc < 0) { c->last_error = scan_err; return scan_rc; }
+    for (int i = 0; i < NS; ++i) (void)hipStreamSynchronize(istream[i]);
+    if (hip_rc.load() < 0) { (void)hipStreamSynchronize(c->stream); c->last_error = "HIP error while uploading the compressed file"; return hip_rc.load(); }
+    if (scan_rc < 0) { (void)hipStreamSynchronize(c->stream); c->last_error = scan_err; return scan_rc; }
+    if (disp_rc < 0) { (void)hipStreamSynchronize(c->stream); return disp_rc; }
     const auto t2 = now();
 
-    // the BAM header: inflate its blocks on the host until it parses (reader.d:111-116,579-597)
     const uint64_t total = blocks.empty() ? 0 : blocks.back().uoff + blocks.back().isize;
-    std::vector<uint8_t> head, cbuf(65536 + 64);
-    uint64_t q = 0; size_t jh = 0; int got = 0;
-    while (jh < blocks.size() && got == 0) {
-        const Blk& b = blocks[jh];
-        head.resize((size_t)(b.uoff + b.isize));
-        if ((uint64_t)pread(fd, cbuf.data(), b.cdata_len, (off_t)(b.coff + b.cdata_off)) != b.cdata_len) { c->last_error = "short read"; return BGP_ETRUNC; }
-        const int rc = inflate_cdata(cbuf.data(), b, head.data() + b.uoff);
-        if (rc < 0) { c->last_error = "zlib: corrupted BGZF block"; return rc; }
-        ++jh;
-        got = bgp_parse_bam_header(head.data(), head.size(), c->refs, &q, c->last_error);
-        if (got < 0) return got;
+    if (!have_q || fallback) {
+        // everything at the end, in one launch (the header did not parse on the way, or the file outgrew the estimates)
+        BGP_HIP(hipStreamSynchronize(c->stream));
+        head.clear(); q = 0; jh = 0; int got = 0;
+        c->refs.clear();
+        while (jh < blocks.size() && got == 0) {
+            const Blk& b = blocks[jh];
+            head.resize((size_t)(b.uoff + b.isize));
+            if ((uint64_t)pread(fd, cbuf.data(), b.cdata_len, (off_t)(b.coff + b.cdata_off)) != b.cdata_len) { c->last_error = "short read"; return BGP_ETRUNC; }
+            const int rc = inflate_cdata(cbuf.data(), b, head.data() + b.uoff);
+            if (rc < 0) { c->last_error = "zlib: corrupted BGZF block"; return rc; }
+            ++jh;
+            got = bgp_parse_bam_header(head.data(), head.size(), c->refs, &q, c->last_error);
+            if (got < 0) return got;
+        }
+        if (got == 0) { c->last_error = total < 4 ? "wrong BAM magic" : "truncated BAM header"; return total < 4 ? BGP_EINVAL : BGP_ETRUNC; }
     }
-    if (got == 0) { c->last_error = total < 4 ? "wrong BAM magic" : "truncated BAM header"; return total < 4 ? BGP_EINVAL : BGP_ETRUNC; }
     c->n_ref_hint = (int32_t)c->refs.size();
-
-    constexpr uint64_t SLACK = 65536;                     // the block that holds the first record starts up to 64 KB before it
     const uint64_t rec_bytes = total - q;
-    BGP_TRY(c->d_stream_own.reserve(SLACK + rec_bytes + 256));
-    std::vector<bgp_inflate_block> desc;
-    desc.reserve(blocks.size());
-    for (const Blk& b : blocks) {
-        if (!b.isize || b.uoff + b.isize <= q) continue;
-        desc.push_back(bgp_inflate_block{b.coff + b.cdata_off, SLACK + b.uoff - q, b.cdata_len, b.isize, b.crc, 0});
-    }
-    const uint32_t nb = (uint32_t)desc.size();
-    BGP_TRY(c->d_inf_blk.reserve((size_t)nb * (sizeof(bgp_inflate_block) + 4) + 64));
-    int32_t* d_status = (int32_t*)(c->d_inf_blk.as<uint8_t>() + (size_t)nb * sizeof(bgp_inflate_block));
-    std::vector<int32_t> st(nb, 0);
-    if (nb) {
-        BGP_HIP(hipMemcpyAsync(c->d_inf_blk.p, desc.data(), (size_t)nb * sizeof(bgp_inflate_block), hipMemcpyHostToDevice, c->stream));
-        BGP_TRY(inflate_blocks_device(c, c->d_comp.as<uint8_t>(), c->d_stream_own.as<uint8_t>(), c->d_inf_blk.as<bgp_inflate_block>(), nb, d_status, rec_bytes));
-        BGP_HIP(hipMemcpyAsync(st.data(), d_status, (size_t)nb * 4, hipMemcpyDeviceToHost, c->stream));
+    std::vector<int32_t> st;
+    if (fallback || !have_q) {
+        BGP_TRY(c->d_stream_own.reserve(SLACK + rec_bytes + 256));
+        desc.clear();
+        for (const Blk& b : blocks) {
+            if (!b.isize || b.uoff + b.isize <= q) continue;
+            desc.push_back(bgp_inflate_block{b.coff + b.cdata_off, SLACK + b.uoff - q, b.cdata_len, b.isize, b.crc, 0});
+        }
+        const uint32_t nb = (uint32_t)desc.size();
+        BGP_TRY(c->d_inf_blk.reserve((size_t)nb * (sizeof(bgp_inflate_block) + 4) + 64));
+        d_status = (int32_t*)(c->d_inf_blk.as<uint8_t>() + (size_t)nb * sizeof(bgp_inflate_block));
+        st.assign(nb, 0);
+        if (nb) {
+            BGP_HIP(hipMemcpyAsync(c->d_inf_blk.p, desc.data(), (size_t)nb * sizeof(bgp_inflate_block), hipMemcpyHostToDevice, c->stream));
+            BGP_TRY(inflate_blocks_device(c, c->d_comp.as<uint8_t>(), c->d_stream_own.as<uint8_t>(), c->d_inf_blk.as<bgp_inflate_block>(), nb, d_status, rec_bytes));
+            BGP_HIP(hipMemcpyAsync(st.data(), d_status, (size_t)nb * 4, hipMemcpyDeviceToHost, c->stream));
+        }
+    } else {
+        st.assign(desc.size(), 0);
+        if (!desc.empty()) BGP_HIP(hipMemcpyAsync(st.data(), d_status, desc.size() * 4, hipMemcpyDeviceToHost, c->stream));
+        (void)n_desc_launched;
     }
     BGP_HIP(hipStreamSynchronize(c->stream));
-    for (uint32_t i = 0; i < nb; ++i)
+    for (size_t i = 0; i < st.size(); ++i)
         if (st[i]) { c->last_error = "zlib: corrupted BGZF block (device inflate, block at " + std::to_string(desc[i].src) + ", reason " + std::to_string(st[i]) + ")"; return BGP_EINVAL; }
     if (verbose) fprintf(stderr, "[biodgpu] load_bam_device: %zu blocks, %.1f MB -> %.1f MB; buffers %.1f ms, read + scan + upload on %d threads %.1f ms, header + inflate %.1f ms\n",
                          blocks.size(), fsz / 1e6, total / 1e6, ms(t0, t1), T, ms(t1, t2), ms(t2, now()));

@@ -243,7 +243,7 @@ int bai_load_header(bgp_ctx* c, const char* path);
 int bai_stage_read_at(bgp_ctx* c, const char* path, uint64_t voffset);
 int bai_record_voffset(bgp_ctx* c, uint64_t staged_off, uint64_t* voffset);
 struct bgp_inflate_block { uint64_t src, dst; uint32_t clen, isize, crc, pad; };   // CDATA at comp + src -> isize bytes at out + dst
-int inflate_blocks_device(bgp_ctx* c, const uint8_t* d_comp, uint8_t* d_out, const bgp_inflate_block* d_blk, uint32_t n_blk, int32_t* d_status, uint64_t out_bytes);   // inflate.hip
+int inflate_blocks_device(bgp_ctx* c, const uint8_t* d_comp, uint8_t* d_out, const bgp_inflate_block* d_blk, uint32_t n_blk, int32_t* d_status, uint64_t out_bytes, hipStream_t on = nullptr);   // inflate.hip
 int bgzf_load_bam_device(bgp_ctx* c, const char* path);      // bgzf_host.cpp : file -> HBM compressed -> k_inflate
 int bgp_default_threads();                                   // bgzf_host.cpp : affinity mask and cgroup quota applied
 int bai_build(bgp_ctx* c, std::vector<uint8_t>& out);

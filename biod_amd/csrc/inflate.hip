@@ -393,10 +393,11 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(BGP_
 }  // namespace
 
 // Inflates n_blk blocks (descriptors on the device) from comp into out; status[i] = 0 or the reason block i failed.
-int inflate_blocks_device(bgp_ctx* c, const uint8_t* d_comp, uint8_t* d_out, const bgp_inflate_block* d_blk, uint32_t n_blk, int32_t* d_status, uint64_t out_bytes) {
+int inflate_blocks_device(bgp_ctx* c, const uint8_t* d_comp, uint8_t* d_out, const bgp_inflate_block* d_blk, uint32_t n_blk, int32_t* d_status, uint64_t out_bytes, hipStream_t on) {
     if (!n_blk) return BGP_OK;
-    TimedRegion t(c, "k_inflate", out_bytes);
-    hipLaunchKernelGGL(k_inflate, dim3((n_blk + WAVES - 1) / WAVES), dim3(64 * WAVES), 0, c->stream, d_comp, d_out, d_blk, n_blk, d_status);
+    hipStream_t st = on ? on : c->stream;
+    TimedRegion t(c, "k_inflate", out_bytes, st);
+    hipLaunchKernelGGL(k_inflate, dim3((n_blk + WAVES - 1) / WAVES), dim3(64 * WAVES), 0, st, d_comp, d_out, d_blk, n_blk, d_status);
     BGP_HIP(hipGetLastError());
 #ifdef BGP_INFLATE_STATS
     unsigned long long h[8];
