@@ -250,8 +250,8 @@ int bgzf_load_bam_device(bgp_ctx* c, const char* path) {
     std::atomic<uint64_t> next{0}; std::atomic<int> hip_rc{BGP_OK};
     // The blocks are inflated WHILE the file is still arriving: this thread follows the scan, and whenever a few thousand blocks lie whole in
     // what has been uploaded it launches k_inflate for them on the ctx's stream, behind the uploads' events (read + upload and inflate took
-    // turns before: 66 + 69 ms for a 1.6 GB file).  The output buffer and the descriptor table are sized by estimate -- six times the file,
-    // a block per 2 KB -- and a file that outgrows either is inflated the old way, in one launch at the end.
+    // turns before: 66 + 69 ms for a 1.6 GB file).  The output buffer and the descriptor table are sized by estimate -- the first chunk's
+    // ratio and a third more, a block per 2 KB -- and a file that outgrows either is inflated the old way, in one launch at the end.
     std::vector<hipEvent_t> ev(n_chunks, nullptr);
     std::unique_ptr<std::atomic<int>[]> ev_ready(new std::atomic<int>[n_chunks]);
     for (uint64_t k = 0; k < n_chunks; ++k) { ev_ready[k].store(0); if (hipEventCreateWithFlags(&ev[k], hipEventDisableTiming) != hipSuccess) { c->last_error = "hipEventCreate failed"; return BGP_EDEVICE; } }
@@ -290,7 +290,7 @@ int bgzf_load_bam_device(bgp_ctx* c, const char* path) {
 
     const bool pipelined = !(getenv("BGP_INFLATE_PIPELINE") && atoi(getenv("BGP_INFLATE_PIPELINE")) == 0);
     constexpr uint64_t SLACK = 65536;                     // the block that holds the first record starts up to 64 KB before it
-    const uint64_t est_bytes = std::max<uint64_t>(6 * fsz, 64ull << 20);
+    uint64_t est_bytes = 0;                                // the inflated size, estimated from the blocks scanned when the header has parsed (their ratio and a third more)
     const size_t nb_cap = (size_t)(fsz / 2048 + 4096);
     std::vector<bgp_inflate_block> desc;
     std::vector<uint64_t> desc_src_blk;                    // (for error messages: nothing else)
@@ -332,6 +332,11 @@ int bgzf_load_bam_device(bgp_ctx* c, const char* path) {
                 if (got < 0) { disp_rc = got; break; }
                 if (got > 0) {
                     have_q = true;
+                    {   // (a BAM compresses about evenly: what the first 32 MB inflate to says what the file will; a file that outgrows it is inflated at the end)
+                        const Blk& lb = snap.back();
+                        const double ratio = (double)(lb.uoff + lb.isize) / (double)std::max<uint64_t>(1, lb.coff + lb.cdata_off + lb.cdata_len + 8);
+                        est_bytes = (uint64_t)((double)fsz * ratio * 1.34) + (64ull << 20);
+                    }
                     if (c->d_stream_own.reserve(SLACK + est_bytes + 256) != BGP_OK || c->d_inf_blk.reserve(nb_cap * (sizeof(bgp_inflate_block) + 4) + 64) != BGP_OK) fallback = true;
                     else d_status = (int32_t*)(c->d_inf_blk.as<uint8_t>() + nb_cap * sizeof(bgp_inflate_block));
                 }
