@@ -262,6 +262,8 @@ void bgp_destroy(bgp_ctx* c) {
     prefetch_cancel(c);
     if (c->pf.done) (void)hipEventDestroy(c->pf.done);
     if (c->pf.stream) (void)hipStreamDestroy(c->pf.stream);
+    if (c->io_up) (void)hipStreamDestroy(c->io_up);
+    for (hipStream_t x : c->io_inf) if (x) (void)hipStreamDestroy(x);
     batch_release(c);
     bgp_timing_collect(c);
     release_all(c);

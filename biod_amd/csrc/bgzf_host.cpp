@@ -256,15 +256,20 @@ int bgzf_load_bam_device(bgp_ctx* c, const char* path) {
     std::unique_ptr<std::atomic<int>[]> ev_ready(new std::atomic<int>[n_chunks]);
     for (uint64_t k = 0; k < n_chunks; ++k) { ev_ready[k].store(0); if (hipEventCreateWithFlags(&ev[k], hipEventDisableTiming) != hipSuccess) { c->last_error = "hipEventCreate failed"; return BGP_EDEVICE; } }
     struct Events { std::vector<hipEvent_t>& e; ~Events() { for (hipEvent_t x : e) if (x) (void)hipEventDestroy(x); } } events_guard{ev};
+    // ONE stream for all uploads and one for the inflate (the ctx keeps them): a stream per reader and four for the batches were more
+    // streams than the device has hardware queues, and an upload that shared a queue with a running k_inflate waited for it to end --
+    // the uploads stalled for the 50 ms of the first batch; creating a dozen streams also took the load's first 25 ms.
+    if (!c->io_up && hipStreamCreateWithFlags(&c->io_up, hipStreamNonBlocking) != hipSuccess) { c->io_up = nullptr; c->last_error = "hipStreamCreate failed"; return BGP_EDEVICE; }
+    for (hipStream_t& x : c->io_inf) if (!x && hipStreamCreateWithFlags(&x, hipStreamNonBlocking) != hipSuccess) { x = nullptr; c->last_error = "hipStreamCreate failed"; return BGP_EDEVICE; }
+    std::mutex up_mu;                                                      // (a copy and its event are enqueued together)
     auto reader_ev = [&](int t) {      // reader() with the upload's event made known
         if (hipSetDevice(c->device) != hipSuccess) { hip_rc.store(BGP_EDEVICE); }
-        hipStream_t s = nullptr;
-        if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) hip_rc.store(BGP_EDEVICE);
         uint8_t* buf = c->h_ring.as<uint8_t>() + (size_t)t * (CH + OV);
+        int64_t last = -1;                                                 // the chunk whose upload reads this buffer
         for (;;) {
             const uint64_t k = next.fetch_add(1);
             if (k >= n_chunks) break;
-            if (s) (void)hipStreamSynchronize(s);                          // the previous piece has left this buffer
+            if (last >= 0 && hipEventSynchronize(ev[last]) != hipSuccess) hip_rc.store(BGP_EDEVICE);      // the previous piece has left this buffer
             const uint64_t lo = k * CH, hi = std::min(fsz, lo + CH + OV);
             uint64_t got = 0;
             while (got < hi - lo) { const ssize_t r = pread(fd, buf + got, hi - lo - got, (off_t)(lo + got)); if (r <= 0) break; got += (uint64_t)r; }
@@ -279,11 +284,14 @@ int bgzf_load_bam_device(bgp_ctx* c, const char* path) {
                 turn = k + 1;
             }
             cv.notify_all();
-            if (s && hip_rc.load() == BGP_OK &&
-                (hipMemcpyAsync(c->d_comp.as<uint8_t>() + lo, buf, std::min(CH, fsz - lo), hipMemcpyHostToDevice, s) != hipSuccess || hipEventRecord(ev[k], s) != hipSuccess)) hip_rc.store(BGP_EDEVICE);
+            if (hip_rc.load() == BGP_OK) {
+                std::lock_guard<std::mutex> ul(up_mu);
+                if (hipMemcpyAsync(c->d_comp.as<uint8_t>() + lo, buf, std::min(CH, fsz - lo), hipMemcpyHostToDevice, c->io_up) != hipSuccess || hipEventRecord(ev[k], c->io_up) != hipSuccess) hip_rc.store(BGP_EDEVICE);
+                else last = (int64_t)k;
+            }
             ev_ready[k].store(1, std::memory_order_release);
         }
-        if (s) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
+        if (last >= 0) (void)hipEventSynchronize(ev[last]);
     };
     std::vector<std::thread> th;
     for (int t = 0; t < T; ++t) th.emplace_back(reader_ev, t);
@@ -304,11 +312,10 @@ int bgzf_load_bam_device(bgp_ctx* c, const char* path) {
     size_t jh = 0;
     int disp_rc = BGP_OK;
     std::vector<Blk> snap;
-    // (the batches' launches go round four streams: one batch does not fill the device, and on one stream they ran one after the other)
-    constexpr int NS = 4;
-    hipStream_t istream[NS] = {nullptr, nullptr, nullptr, nullptr};
-    struct Streams { hipStream_t* s; ~Streams() { for (int i = 0; i < NS; ++i) if (s[i]) { (void)hipStreamSynchronize(s[i]); (void)hipStreamDestroy(s[i]); } } } streams_guard{istream};
-    for (int i = 0; i < NS; ++i) if (hipStreamCreateWithFlags(&istream[i], hipStreamNonBlocking) != hipSuccess) { c->last_error = "hipStreamCreate failed"; for (auto& x : th) x.join(); return BGP_EDEVICE; }
+    // (a batch goes to whichever of the two inflate streams has run dry and takes every block that is there: the upload outpaces the
+    // inflate, so the batches grow, and while one drains -- a block is 9-12 ms of one wave's work whatever runs beside it -- the other
+    // stream's fills the wave slots it leaves.  Batches down ONE stream left the device half empty for a block's time at every seam.)
+    constexpr size_t BATCH_MIN = 1024;
     int n_batch = 0;
     for (;;) {
         uint64_t tn; int src; size_t nblk;
@@ -332,6 +339,7 @@ int bgzf_load_bam_device(bgp_ctx* c, const char* path) {
                 if (got < 0) { disp_rc = got; break; }
                 if (got > 0) {
                     have_q = true;
+                    if (verbose) fprintf(stderr, "[biodgpu]   header parsed at %.2f ms\n", ms(t1, now()));
                     {   // (a BAM compresses about evenly: what the first 32 MB inflate to says what the file will; a file that outgrows it is inflated at the end)
                         const Blk& lb = snap.back();
                         const double ratio = (double)(lb.uoff + lb.isize) / (double)std::max<uint64_t>(1, lb.coff + lb.cdata_off + lb.cdata_len + 8);
@@ -356,10 +364,18 @@ int bgzf_load_bam_device(bgp_ctx* c, const char* path) {
                     ++j;
                 }
                 const size_t nd = desc.size() - d0;
-                if (!fallback && nd && (nd >= 2048 || (all_scanned && j == snap.size()))) {
+                hipStream_t is = nullptr;
+                if (!fallback && nd) {
+                    const bool last = all_scanned && j == snap.size();
+                    for (hipStream_t x : c->io_inf) if (!is && hipStreamQuery(x) == hipSuccess) is = x;
+                    if (!is && last) is = c->io_inf[n_batch & 1];
+                    if (is && !last && nd < BATCH_MIN) is = nullptr;
+                }
+                if (is) {
                     const uint64_t k0 = snap[bi].coff / CH;
                     bool ok = true;
-                    hipStream_t is = istream[n_batch++ % NS];
+                    ++n_batch;
+                    if (verbose) fprintf(stderr, "[biodgpu]   batch %d at %.2f ms: %zu blocks, %llu chunks uploaded, scanned %llu\n", n_batch - 1, ms(t1, now()), nd, (unsigned long long)up_chunks, (unsigned long long)tn);
                     for (uint64_t k = k0; k < up_chunks && ok; ++k) ok = hipStreamWaitEvent(is, ev[k], 0) == hipSuccess;
                     ok = ok && hipMemcpyAsync(c->d_inf_blk.as<bgp_inflate_block>() + d0, desc.data() + d0, nd * sizeof(bgp_inflate_block), hipMemcpyHostToDevice, is) == hipSuccess;
                     if (!ok) { c->last_error = "HIP error while launching the inflate"; disp_rc = BGP_EDEVICE; }
@@ -374,7 +390,7 @@ int bgzf_load_bam_device(bgp_ctx* c, const char* path) {
         std::this_thread::sleep_for(std::chrono::microseconds(150));
     }
     for (auto& x : th) x.join();
-    for (int i = 0; i < NS; ++i) (void)hipStreamSynchronize(istream[i]);
+    (void)hipStreamSynchronize(c->io_up); for (hipStream_t x : c->io_inf) (void)hipStreamSynchronize(x);
     if (hip_rc.load() < 0) { (void)hipStreamSynchronize(c->stream); c->last_error = "HIP error while uploading the compressed file"; return hip_rc.load(); }
     if (scan_rc < 0) { (void)hipStreamSynchronize(c->stream); c->last_error = scan_err; return scan_rc; }
     if (disp_rc < 0) { (void)hipStreamSynchronize(c->stream); return disp_rc; }

@@ -1323,6 +1323,34 @@ def test_device_inflate_synthetic_and_damage(tmp_path):
         assert dev_ok == host_ok, (trial, at)
 
 
+def test_device_inflate_file_of_several_chunks(tmp_path, monkeypatch):
+    """A file of several 32 MB read chunks: the blocks are inflated in batches while the file is still being uploaded
+    (bgzf_load_bam_device's dispatcher: one upload stream, a batch to whichever inflate stream has run dry) -- the
+    same bytes as the host inflate and as one launch at the end (BGP_INFLATE_PIPELINE=0)."""
+    from concurrent.futures import ThreadPoolExecutor
+    cfg = scaled("cfg2", 500_000)
+    st = host_stream(cfg)
+    path = str(tmp_path / "big.bam")
+    b = memoryview(st)
+    with open(path, "wb") as f, ThreadPoolExecutor(8) as ex:
+        f.write(bamio.bgzf_block(bamio.bam_header_bytes([(f"chr{i + 1}", 1 << 28) for i in range(max(1, cfg.n_ref))])))
+        for blk in ex.map(lambda at: bamio.bgzf_block(bytes(b[at:at + 60000])), range(0, len(b), 60000)):
+            f.write(blk)
+        f.write(bamio.BGZF_EOF)
+    assert os.path.getsize(path) > 2 * (32 << 20)
+    c, got = _device_stream(path)
+    assert got == st
+    info = c.pileup_run()
+    assert info.n_columns > 0 and c.num_records() == cfg.n_reads
+    c2, got2 = _device_stream(path)                       # (again in a fresh ctx, and in the first one: its streams are reused)
+    assert got2 == st
+    c.reset(); c.load_bam_device(path); c.flush()
+    assert c.staged_bytes().tobytes() == st
+    monkeypatch.setenv("BGP_INFLATE_PIPELINE", "0")
+    c3, got3 = _device_stream(path)
+    assert got3 == st
+
+
 def test_bam_reader_with_device_inflate(data_dir):
     """BamReader(filename, device_inflate=True): the reference's pileup checks (unittests.d:320-366) hold unchanged."""
     bam = BamReader(os.path.join(data_dir, "ex1_header.bam"), device_inflate=True)
