@@ -6,11 +6,12 @@ Three ways of getting the bytes into the pinned buffers, each with and without a
            array, standing in for P inflate workers that would otherwise write into buffers of their own)
 Raw ctypes calls: the Python facade's copies would be the slowest thing measured."""
 import ctypes as C
-import sys, time
+import os, sys, time
 from concurrent.futures import ThreadPoolExecutor
 import numpy as np
 sys.path.insert(0, "/root/repo")
-import torch  # noqa: F401  (first: its HIP runtime)
+if not os.environ.get("BGP_E2E_ONLY"):
+    import torch  # noqa: F401  (first: its HIP runtime)
 from biod_amd import _lib as L
 from biod_amd.pileup import Context
 from biod_amd.synth import host_stream_np, scaled
@@ -147,6 +148,13 @@ def run_interleaved(touch):
 
 
 print(f"{n} reads of cfg3's model, {len(st) / 1e9:.2f} GB inflated, batches of {batch >> 20} MiB ({len(st) / batch:.1f}), producer threads {P}")
+if os.environ.get("BGP_E2E_ONLY") == "interleaved":      # (for a trace: the in-turn loop alone)
+    for rep in range(3):
+        dt, stats = run_interleaved(False)
+        print(f"in turn, windows only: {dt:.3f} s = {len(st) / dt / 1e9:.1f} GB/s of input", flush=True)
+    pool.shutdown(wait=True)
+    ctx.close()
+    sys.exit(0)
 last = None
 for mode in ("push", "acquire"):
     for touch in (True, False):
