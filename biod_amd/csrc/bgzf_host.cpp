@@ -215,7 +215,7 @@ int bgzf_load_bam(bgp_ctx* c, const char* path, int n_threads) {
 
 // ---- device inflate: the file goes to HBM compressed, k_inflate (inflate.hip) does the rest -------------------------
 //
-// Phase A: reader threads pread 32 MB pieces into a pinned ring and push them to the device; the block headers are
+// Phase A: reader threads pread 16 MB pieces into a pinned ring and push them to the device; the block headers are
 // walked on the host as the pieces arrive, in file order (each header names the next), from the ring itself.
 // Phase B: the BAM header is inflated on the host (its blocks only) to find the first record; every block from there
 // on gets a descriptor (CDATA offset, output offset = uncompressed offset - first record, ISIZE, CRC) and one wave.
@@ -235,7 +235,7 @@ int bgzf_load_bam_device(bgp_ctx* c, const char* path) {
     struct stat sb;
     if (fstat(fd, &sb) != 0) { c->last_error = "fstat failed"; return BGP_EINVAL; }
     const uint64_t fsz = (uint64_t)sb.st_size;
-    constexpr uint64_t CH = 32ull << 20, OV = 192ull << 10;
+    constexpr uint64_t CH = 16ull << 20, OV = 192ull << 10;
     const uint64_t n_chunks = (fsz + CH - 1) / CH;
     // readers: 4 and 8 threads both take ~65 ms for 1.6 GB on the measured box, 16 take 95, 24 take 140 (scratch/read_threads.sh)
     const uint64_t t_max = getenv("BGP_READ_THREADS") ? (uint64_t)atoi(getenv("BGP_READ_THREADS")) : 8ull;
@@ -315,7 +315,7 @@ int bgzf_load_bam_device(bgp_ctx* c, const char* path) {
     // (a batch goes to whichever of the two inflate streams has run dry and takes every block that is there: the upload outpaces the
     // inflate, so the batches grow, and while one drains -- a block is 9-12 ms of one wave's work whatever runs beside it -- the other
     // stream's fills the wave slots it leaves.  Batches down ONE stream left the device half empty for a block's time at every seam.)
-    constexpr size_t BATCH_MIN = 1024;
+    constexpr size_t BATCH_MIN = 2048;
     int n_batch = 0;
     for (;;) {
         uint64_t tn; int src; size_t nblk;
@@ -340,7 +340,7 @@ int bgzf_load_bam_device(bgp_ctx* c, const char* path) {
                 if (got > 0) {
                     have_q = true;
                     if (verbose) fprintf(stderr, "[biodgpu]   header parsed at %.2f ms\n", ms(t1, now()));
-                    {   // (a BAM compresses about evenly: what the first 32 MB inflate to says what the file will; a file that outgrows it is inflated at the end)
+                    {   // (a BAM compresses about evenly: what the first chunk inflates to says what the file will; a file that outgrows it is inflated at the end)
                         const Blk& lb = snap.back();
                         const double ratio = (double)(lb.uoff + lb.isize) / (double)std::max<uint64_t>(1, lb.coff + lb.cdata_off + lb.cdata_len + 8);
                         est_bytes = (uint64_t)((double)fsz * ratio * 1.34) + (64ull << 20);

@@ -1324,7 +1324,7 @@ def test_device_inflate_synthetic_and_damage(tmp_path):
 
 
 def test_device_inflate_file_of_several_chunks(tmp_path, monkeypatch):
-    """A file of several 32 MB read chunks: the blocks are inflated in batches while the file is still being uploaded
+    """A file of several read chunks (16 MB each): the blocks are inflated in batches while the file is still being uploaded
     (bgzf_load_bam_device's dispatcher: one upload stream, a batch to whichever inflate stream has run dry) -- the
     same bytes as the host inflate and as one launch at the end (BGP_INFLATE_PIPELINE=0)."""
     from concurrent.futures import ThreadPoolExecutor
