@@ -4,7 +4,7 @@ import csv, glob, sys
 d = sys.argv[1]; W = float(sys.argv[2]) if len(sys.argv) > 2 else 100.0; mind = float(sys.argv[3]) if len(sys.argv) > 3 else 0.05
 ev = []
 for r in csv.DictReader(open(glob.glob(d + "/**/*kernel_trace.csv", recursive=True)[0])):
-    ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), "K " + r["Kernel_Name"].split("(")[0][:40] + " q" + r.get("Queue_Id", "?")))
+    ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), "K " + r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:44] + " q" + r.get("Queue_Id", "?")))
 mt = glob.glob(d + "/**/*memory_copy_trace.csv", recursive=True)
 if mt:
     for r in csv.DictReader(open(mt[0])):
