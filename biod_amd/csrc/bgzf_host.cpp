@@ -315,7 +315,7 @@ int bgzf_load_bam_device(bgp_ctx* c, const char* path) {
     // (a batch goes to whichever of the two inflate streams has run dry and takes every block that is there: the upload outpaces the
     // inflate, so the batches grow, and while one drains -- a block is 9-12 ms of one wave's work whatever runs beside it -- the other
     // stream's fills the wave slots it leaves.  Batches down ONE stream left the device half empty for a block's time at every seam.)
-    constexpr size_t BATCH_MIN = 2048;
+    const size_t BATCH_MIN = getenv("BGP_INFLATE_BATCH_MIN") ? (size_t)std::max(1, atoi(getenv("BGP_INFLATE_BATCH_MIN"))) : 2048;      // (tests: many small batches from a small file)
     int n_batch = 0;
     for (;;) {
         uint64_t tn; int src; size_t nblk;

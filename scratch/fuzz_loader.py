@@ -21,6 +21,7 @@ def load(ctx, fn, path):
         return False, e.code
 for k in range(n):
     rng = np.random.default_rng(seed0 + k)
+    os.environ["BGP_INFLATE_BATCH_MIN"] = str(int(rng.choice([16, 100, 500, 2048])))      # (read at every load: many small batches on both inflate streams, or few)
     cfg = scaled(("cfg2", "cfg3")[k & 1], int(rng.integers(250_000, 500_000)))
     st = host_stream_np(cfg); b = memoryview(st)
     cuts = [0]

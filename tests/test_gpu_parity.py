@@ -1346,9 +1346,41 @@ def test_device_inflate_file_of_several_chunks(tmp_path, monkeypatch):
     assert got2 == st
     c.reset(); c.load_bam_device(path); c.flush()
     assert c.staged_bytes().tobytes() == st
+    monkeypatch.setenv("BGP_INFLATE_BATCH_MIN", "50")          # dozens of batches, both inflate streams busy while the file still arrives
+    for _ in range(3):
+        c4, got4 = _device_stream(path)
+        assert got4 == st
+    monkeypatch.delenv("BGP_INFLATE_BATCH_MIN")
     monkeypatch.setenv("BGP_INFLATE_PIPELINE", "0")
     c3, got3 = _device_stream(path)
     assert got3 == st
+
+
+def test_device_inflate_file_that_outgrows_the_size_estimate(tmp_path):
+    """bgzf_load_bam_device sizes the inflated stream from the first read chunk's ratio (and a third more); a file whose later
+    blocks inflate far more than that -- here one record repeated a million times behind 17 MB of ordinary reads -- is inflated in
+    one launch at the end instead (batches already launched have stayed inside the estimate): the same bytes as the host loader."""
+    from concurrent.futures import ThreadPoolExecutor
+    cfg = scaled("cfg2", 115_000)
+    head = host_stream(cfg)
+    at, last = 0, 0
+    while at < len(head):                                  # the last record of the ordinary part
+        last = at; at += 4 + int.from_bytes(head[at:at + 4], "little")
+    st = head + head[last:] * 1_200_000
+    path = str(tmp_path / "grow.bam")
+    b = memoryview(st)
+    with open(path, "wb") as f, ThreadPoolExecutor(8) as ex:
+        f.write(bamio.bgzf_block(bamio.bam_header_bytes([(f"chr{i + 1}", 1 << 28) for i in range(max(1, cfg.n_ref))])))
+        for blk in ex.map(lambda o: bamio.bgzf_block(bytes(b[o:o + 64000])), range(0, len(b), 64000)):
+            f.write(blk)
+        f.write(bamio.BGZF_EOF)
+    size = os.path.getsize(path)
+    assert size > (17 << 20) and len(st) > 3 * size + (64 << 20)       # the first chunk is ordinary reads; the whole outgrows ratio * 1.34 + 64 MB
+    c, got = _device_stream(path)
+    assert got == st
+    assert c.num_records() == cfg.n_reads + 1_200_000
+    c.reset(); c.load_bam_device(path); c.flush()                       # (again in the same ctx: the buffers have the real size now)
+    assert c.staged_bytes().tobytes() == st
 
 
 def test_bam_reader_with_device_inflate(data_dir):
