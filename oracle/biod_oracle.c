@@ -1103,10 +1103,23 @@ int64_t orc_chunk_plan(const uint8_t* stream, uint64_t len, uint64_t chunk_bytes
     int rc = plan_build(&plan, stream, len, chunk_bytes, 1);
     if (rc) { plan_free(&plan); return rc; }
     int64_t n = 0;
+    int started = 0;
     for (size_t j = 0; j < plan.n_chunks; ++j) {
         if (plan.chunks[j].ref_id < 0) continue;
         int same_prev; size_t jp; uint64_t beg, end_pos;
         chunk_bounds(&plan, j, &same_prev, &jp, &beg, &end_pos);
+        if (!started) {
+            /* PileupChunkRange's constructor (pileup.d:878-900) walks on while _chunk_right_end > start_from does not hold
+             * (:894-896; the int widens to ulong, sign and all): leading chunks of reads that cover nothing at position 0 are
+             * never handed out -- and the first chunk kept has no _prev_chunk, whatever lay in front of it (:888). */
+            const chunk_t* c = &plan.chunks[j];
+            int32_t right_end = INT32_MIN;
+            for (uint64_t i = c->first; i <= c->last; ++i) { int32_t e = plan.pos[i] + plan.covered[i]; if (e > right_end) right_end = e; }
+            if (plan.pmax[c->last] > right_end) right_end = plan.pmax[c->last];
+            if (!((uint64_t)(int64_t)right_end > 0ull)) continue;
+            started = 1;
+            beg = (uint64_t)(int64_t)plan.pos[c->first];
+        }
         if ((uint64_t)n < cap) { out[n].first = plan.chunks[j].first; out[n].last = plan.chunks[j].last; out[n].ref_id = plan.chunks[j].ref_id; out[n].beg = beg; out[n].end = end_pos; }
         ++n;
     }

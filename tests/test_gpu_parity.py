@@ -1646,6 +1646,28 @@ def test_pileup_chunks_plan_and_concatenation(ctx, block):
     assert np.array_equal(a[1], c2[1]) and np.array_equal(a[2], c2[2]) and (k == 0 or not np.array_equal(a[1], b[1]))
 
 
+def test_pileup_chunks_leading_chunks_that_cover_nothing(ctx):
+    """pileup.d:894-896: the constructor never hands out leading chunks whose right end is not beyond start_from -- reads that cover
+    nothing at position 0 --, and the first chunk kept has no chunk in front of it; later such chunks are handed out (:915-939).
+    The lists are the reference's rule worked by hand (tests/test_oracle_kats.py holds the same for the oracle)."""
+    from biod_amd.pileup import pileupChunks
+    def plan_of(st, block):
+        return [(c.first_record, c.last_record, c.ref_id, c.start_position, c.end_position) for c in pileupChunks(RecordStream(st, ctx), False, block, want_entries=False)]
+    u = lambda ref: bamio.pack_record("u0", "ACGT", [(4, "S")], ref_id=ref, pos=0)
+    m = lambda name, ref, pos: bamio.pack_record(name, "ACGTACGT", [(8, "M")], ref_id=ref, pos=pos)
+    st = u(0) + m("r1", 1, 6) + m("r2", 1, 10)
+    assert plan_of(st, 16384000) == [(1, 2, 1, 6, 18)] == O.chunk_plan(st, 16384000)
+    st = u(1) + m("r1", 1, 6) + m("r2", 1, 10)
+    small = len(u(1)) - 1
+    assert plan_of(st, small) == [(1, 1, 1, 6, 6), (2, 2, 1, 6, 18)] == O.chunk_plan(st, small)
+    st = m("r1", 0, 6) + u(1) + m("r2", 2, 10)
+    assert plan_of(st, 16384000) == [(0, 0, 0, 6, 14), (1, 1, 1, 0, 0), (2, 2, 2, 10, 18)] == O.chunk_plan(st, 16384000)
+    for st_, block in ((u(0) + m("r1", 1, 6) + m("r2", 1, 10), 16384000), (u(1) + m("r1", 1, 6) + m("r2", 1, 10), small)):
+        chunks = pileupChunks(RecordStream(st_, ctx), False, block, want_entries=False)
+        ref, pos, cols, _ = _chunk_columns(chunks)
+        _assert_columns_equal_oracle(ref, pos, cols, O.pileup(st_))
+
+
 @pytest.mark.parametrize("name", ["ex1_header.bam", "b7_295_chunk.bam", "tags.bam"])
 def test_pileup_chunks_fixtures(ctx, data_dir, name):
     from biod_amd.pileup import pileupChunks

@@ -297,6 +297,32 @@ def test_chunked_equals_serial(data_dir, name, chunk_bytes):
         assert np.array_equal(a.entries[f], b.entries[f]), f
 
 
+def test_chunk_plan_drops_leading_chunks_that_cover_nothing():
+    """PileupChunkRange's constructor (pileup.d:878-900) keeps walking while `_chunk_right_end > start_from` does not hold (:894-896):
+    a leading chunk of reads that cover nothing at position 0 -- unmapped-flagged, or a CIGAR of soft clips only -- is never handed
+    out, and the first chunk kept begins at ITS first read (no _prev_chunk, :888).  Found by scratch/fuzz_chunks.py (seeds 2930100,
+    2931917): the device's plan followed the reference, this helper listed the empty chunk."""
+    from biod_amd import bamio
+    recs = [bamio.pack_record("u0", "ACGT", [(4, "S")], ref_id=0, pos=0),
+            bamio.pack_record("r1", "ACGTACGT", [(8, "M")], ref_id=1, pos=6),
+            bamio.pack_record("r2", "ACGTACGT", [(8, "M")], ref_id=1, pos=10)]
+    st = b"".join(recs)
+    assert O.chunk_plan(st, 16384000) == [(1, 2, 1, 6, 18)]
+    # the same reads on ONE reference: the dropped chunk is no _prev_chunk -- the first chunk kept begins at its own first read
+    recs = [bamio.pack_record("u0", "ACGT", [(4, "S")], ref_id=1, pos=0),
+            bamio.pack_record("r1", "ACGTACGT", [(8, "M")], ref_id=1, pos=6),
+            bamio.pack_record("r2", "ACGTACGT", [(8, "M")], ref_id=1, pos=10)]
+    st = b"".join(recs)
+    small = len(recs[0]) - 1                               # a chunk a read (a chunk closes once it holds more than block_size bytes)
+    assert O.chunk_plan(st, small) == [(1, 1, 1, 6, 6), (2, 2, 1, 6, 18)]       # (a chunk ends at its last read's position while its reference goes on, :905-908)
+    # a chunk that covers nothing LATER in the stream is handed out (popFront has no such test, :915-939)
+    recs = [bamio.pack_record("r1", "ACGTACGT", [(8, "M")], ref_id=0, pos=6),
+            bamio.pack_record("u0", "ACGT", [(4, "S")], ref_id=1, pos=0),
+            bamio.pack_record("r2", "ACGTACGT", [(8, "M")], ref_id=2, pos=10)]
+    st = b"".join(recs)
+    assert O.chunk_plan(st, 16384000) == [(0, 0, 0, 6, 14), (1, 1, 1, 0, 0), (2, 2, 2, 10, 18)]
+
+
 def test_bench_consumer_agrees(data_dir):
     _, st = _stream(data_dir, "ex1_header.bam")
     r1 = O.pileup_bench(st, 1)
