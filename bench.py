@@ -49,7 +49,7 @@ def kernels_sha():
 # kernels behind the timers of a step (a timer can bracket several launches; kernels of the set-up, e.g. the flush before the
 # timed region, are not the step's)
 TIMER_KERNELS = {"k12_lds": ("k12_lds",), "k012_stream": ("k_stream_decode",), "k2_unpack": ("k2_unpack",), "k12_fused": ("k12_fused",), "k1_rows": ("k12_fused",),
-                 "k4_bounds": ("k4_bounds",), "k4_plan": ("k4_plan", "k4_wscan"), "k4_tile": ("k4_acc", "k4_tile", "k4_stats"),
+                 "k4_bounds": ("k4_bounds",), "k4_plan": ("k4_plan(", "k4_wscan"), "k4_plan_rest": ("k4_plan_rest", "k4_wscan"), "k4_tile": ("k4_acc", "k4_tile", "k4_stats"),
                  "k4_checkpoints": ("k4_ck_",),
                  "k0_guess": ("k0_guess",), "k0_chase": ("k0_chase", "k0_verify"), "k0_rechase": ("k0_rechase",), "k3_keys_scan": ("k3_",)}
 

@@ -249,7 +249,7 @@ static void release_all(bgp_ctx* c) {
                    &c->d_seq, &c->d_qual, &c->d_cigar, &c->d_pmax_end, &c->d_pmax_pos, &c->d_runs, &c->d_columns, &c->d_depth_hist, &c->d_pstats,
                    &c->d_tiles, &c->d_ck_off, &c->d_ck, &c->d_deep, &c->d_wlong, &c->d_entry_off, &c->d_entries, &c->d_col_lo,
                    &c->d_md_row, &c->d_md_iv, &c->d_md_state, &c->d_refbase, &c->d_md_succ, &c->d_md_exit, &c->d_md_entry, &c->d_md_bmax, &c->d_md_long, &c->d_md_ck, &c->d_md_vlist, &c->d_snp, &c->d_maq, &c->d_maq_tab, &c->d_rec2, &c->d_seq_off2, &c->d_cigar_off2,
-                   &c->d_seg_hint, &c->d_seg_sub, &c->d_tilemax, &c->d_cig4, &c->d_slab, &c->d_wcount, &c->d_wdel, &c->d_wslow, &c->d_flt[0], &c->d_flt[1], &c->d_flt[2], &c->d_flt[3], &c->d_flt[4], &c->d_flt[5], &c->d_comp, &c->d_inf_blk, &c->d_batch[0], &c->d_batch[1]};
+                   &c->d_seg_hint, &c->d_seg_sub, &c->d_tilemax, &c->d_cig4, &c->d_prow, &c->d_rcls, &c->d_slab, &c->d_wcount, &c->d_wdel, &c->d_wslow, &c->d_flt[0], &c->d_flt[1], &c->d_flt[2], &c->d_flt[3], &c->d_flt[4], &c->d_flt[5], &c->d_comp, &c->d_inf_blk, &c->d_batch[0], &c->d_batch[1]};
     for (auto* b : d) b->release();
     HostBuf* h[] = {&c->h_stage, &c->h_rec, &c->h_seq_off, &c->h_cigar_off, &c->h_seq, &c->h_qual, &c->h_cigar, &c->h_cols, &c->h_entry_off, &c->h_entries, &c->h_refbase, &c->h_snp, &c->h_maq, &c->h_ring, &c->h_stream_copy, &c->h_mail, &c->h_cols2, &c->h_batch[0], &c->h_batch[1], &c->h_batch[2]};
     for (auto* b : h) b->release();
@@ -292,7 +292,7 @@ int bgp_reset(bgp_ctx* c) {
     for (HostBuf* hb : {&c->h_cols2, &c->h_rec, &c->h_seq_off, &c->h_cigar_off, &c->h_seq, &c->h_qual, &c->h_cigar, &c->h_cols, &c->h_entry_off, &c->h_entries, &c->h_refbase, &c->h_snp, &c->h_maq, &c->h_stream_copy}) hb->trim();
     c->h_stage_len = 0; c->d_stream = nullptr; c->stream_len = 0; c->stream_on_device = false;
     c->flushed = false; c->piled = false; c->md_rows_ready = false; c->table_pending = false; c->n_records = 0; c->decoded_what = 0; c->it = bgp_ctx::Iter();
-    c->hints.clear(); c->runs.clear(); c->chunks.clear(); c->chunks_ready = false; c->stage_map.clear(); c->region_pending = false; c->table_compacted = false; c->bai_buildable = false; c->cig4_ok = false; c->tilemax_ok = false;
+    c->hints.clear(); c->runs.clear(); c->chunks.clear(); c->chunks_ready = false; c->stage_map.clear(); c->region_pending = false; c->table_compacted = false; c->bai_buildable = false; c->cig4_ok = false; c->rows_ok = false; c->tilemax_ok = false;
     c->refs.clear(); c->n_ref_hint = 0; c->last_error.clear(); c->bai_bytes.clear();      // nothing of the previous file survives: the loaders and bgp_set_n_ref re-establish these
     return BGP_OK;
     BGP_API_CATCH(c)

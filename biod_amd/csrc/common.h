@@ -143,6 +143,7 @@ struct bgp_ctx {
     // record table (K1)
     DevBuf d_rec, d_seq_off, d_cigar_off;
     DevBuf d_tilemax; bool tilemax_ok = false;        // per 2048-record tile: maxima of K3's two keys, left by K1 (K3 then skips its own first pass)
+    DevBuf d_prow, d_rcls; bool rows_ok = false;      // K4's plan rows (16 B) and classes (1 B) of every record, written by k12_lds (bgp_plan_row below): the accumulate path takes ordinary reads from these, the planner only the rest
     DevBuf d_cig4; bool cig4_ok = false;              // first four raw CIGAR ops of every record (16 B, written by K1): K4's planner reads these, not the stream
     DevBuf d_rec2, d_seq_off2, d_cigar_off2, d_flt[6];   // region filter: compaction targets (swapped in) and scan scratch
     // decode arenas (K2)
@@ -356,4 +357,37 @@ __device__ __forceinline__ bool plausible(const uint8_t* s, uint64_t len, uint64
 // CIGAR_TYPE bit pairs (cigar.d:113-116): bit0 query consuming, bit1 reference consuming
 __device__ __forceinline__ uint32_t cig_qc(uint32_t raw) { return (0x3C1A7u >> ((raw & 15u) * 2)) & 1u; }
 __device__ __forceinline__ uint32_t cig_rc(uint32_t raw) { return (0x3C1A7u >> ((raw & 15u) * 2 + 1)) & 1u; }
+// ---- K4's plan row of a record (written by k12_lds beside the record table, read by k4_acc2; pileup.hip "rows").  An ORDINARY read --
+// one or two M / = / X runs with nothing but I / S / D / N / P / H between them, everything within BGP_ROW_REACH positions of its start --
+// is 16 bytes:   x  position (pileup.d:377-379: the column it enters)
+//                y  [7:0] bases of the first run  [15:8] of the second (0: none)  [24:16] where the second starts, counted from x
+//                   [25] the positions between the runs are D / N: '-' (pileup.d:119-121)  [28] the row is there (class 1)
+//              z,w  [41:0] nibble address of the first run's first base in the record stream (2 x byte offset + low nibble, read.d:364-383)
+//                   [49:42] query bases from there to the second run's first base
+// Classes (a byte a record): 0 the read covers nothing (pileup.d:481,510), 1 the row says it all, 2 anything else (the planner's, k4_plan).
+// The moulds are k4_plan's `simple` ones, so that a read contributes the same whichever way it takes.
+constexpr uint32_t BGP_ROW_REACH = 256;
+__device__ __forceinline__ uint32_t bgp_plan_row(uint32_t pos, uint32_t n_cig, uint32_t l_seq, bool covered, uint4 c4, uint64_t seq_abs, uint64_t stream_len, uint4* row) {
+    const uint32_t ops[4] = {c4.x, c4.y, c4.z, c4.w};
+    bool seen_ref = false, bad = false, tail_ref = false, gap_del = false;
+    uint32_t nseg = 0, p = 0, q = 0, len0 = 0, len1 = 0, r1 = 0, q0 = 0, q1 = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t op = ops[k], len = op >> 4;
+        const bool on = (uint32_t)k < n_cig, rc = on && cig_rc(op), qc = on && cig_qc(op);
+        const bool isM = rc && qc, isD = rc && !qc;
+        bad |= rc && (len == 0 || (!seen_ref && !qc));
+        if (isM) { if (nseg == 0) { len0 = len; q0 = q; } else { len1 = len; r1 = p; q1 = q; } ++nseg; tail_ref = false; }
+        if (isD) { tail_ref = true; gap_del = true; }
+        seen_ref |= rc;
+        p += rc ? len : 0u; q += qc ? len : 0u;
+    }
+    const bool ok = covered && n_cig >= 1 && n_cig <= 4 && l_seq >= 1 && l_seq <= 255 && seq_abs + (l_seq + 1) / 2 + 16 <= stream_len
+                    && !bad && q <= l_seq && nseg >= 1 && nseg <= 2 && !tail_ref && p <= BGP_ROW_REACH;
+    if (nseg == 1) r1 = len0;
+    const uint64_t na0 = 2ull * seq_abs + q0;
+    const uint64_t zw = na0 | ((uint64_t)((q1 - q0) & 0xFFu) << 42);
+    *row = ok ? make_uint4(pos, len0 | (len1 << 8) | (r1 << 16) | ((gap_del ? 1u : 0u) << 25) | (1u << 28), (uint32_t)zw, (uint32_t)(zw >> 32)) : make_uint4(0u, 0u, 0u, 0u);
+    return ok ? 1u : covered ? 2u : 0u;
+}
 #endif

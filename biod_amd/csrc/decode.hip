@@ -395,6 +395,7 @@ struct SdArgs {
     bgp_record* rec; uint64_t* seq_off; uint64_t* cig_off; uint4* cig4; unsigned long long* tilemax;
     uint8_t* seq; uint8_t* qual; uint32_t* cigar;
     uint64_t cap_n, cap_ls, cap_nc;
+    uint4* prow; uint8_t* rcls;       // K4's plan rows and classes (common.h: bgp_plan_row), or null
 };
 
 
@@ -574,8 +575,8 @@ __device__ __forceinline__ void sd_emit(const SdArgs& a, uint8_t* sd_lds, uint64
         const int rc = (int)min((uint32_t)SD_RB, nfast - r0);
         const bool valid = t < rc;
         bgp_record rec{};
-        uint32_t lseq = 0, ncig = 0, cig_o = 0;
-        uint4 c4v = make_uint4(0, 0, 0, 0);
+        uint32_t lseq = 0, ncig = 0, cig_o = 0, pcls = 0;
+        uint4 c4v = make_uint4(0, 0, 0, 0), prow = make_uint4(0, 0, 0, 0);
         if (t < 4) misc[M_TM + t] = 0;
         if (valid) {
             const uint32_t o = roff[r0 + t];
@@ -595,6 +596,10 @@ __device__ __forceinline__ void sd_emit(const SdArgs& a, uint8_t* sd_lds, uint64
             }
             rec.end_pos = (int32_t)((uint32_t)rec.pos + covered);                                   // read.d:1382
             lseq = (uint32_t)rec.l_seq; ncig = n_cig;
+            if (a.prow) {               // what K4 wants to know of the read, while its CIGAR is at hand (a long CIGAR's basesCovered is not summed yet: the planner looks again)
+                const bool cov = covered != 0 || (n_cig > BGP_LONG_CIGAR && !((rec.flag_nc >> 16) & 0x4u));
+                pcls = bgp_plan_row((uint32_t)rec.pos, n_cig, lseq, cov, c4v, wbase + cig_o + 4ull * n_cig, a.len, &prow);
+            }
         }
         uint32_t es, ec, ts, tc;
         sd_excl2(lseq, ncig, &es, &ec, &ts, &tc, misc + M_WS);
@@ -606,6 +611,7 @@ __device__ __forceinline__ void sd_emit(const SdArgs& a, uint8_t* sd_lds, uint64
         const uint64_t tile0 = (pn + r0) / K3_TILE_RECORDS;
         if (valid) {
             a.rec[i] = rec; a.seq_off[i] = carry_seq + es; a.cig_off[i] = carry_cig + ec; a.cig4[i] = c4v;
+            if (a.prow) { a.prow[i] = prow; a.rcls[i] = (uint8_t)pcls; }
             soff[t] = es; coff[t] = ec;
             info[3 * t] = (uint16_t)cig_o; info[3 * t + 1] = (uint16_t)(cig_o + 4 * ncig); info[3 * t + 2] = (uint16_t)(cig_o + 4 * ncig + (uint32_t)((rec.l_seq + 1) / 2));   // read.d:992-998
             if (t == rc - 1) { soff[rc] = ts; coff[rc] = tc; }
@@ -650,6 +656,7 @@ __device__ __forceinline__ void sd_emit(const SdArgs& a, uint8_t* sd_lds, uint64
             rec.end_pos = (int32_t)((uint32_t)rec.pos + covered);
             const uint64_t i = pn + cnt - 1;
             a.rec[i] = rec; a.seq_off[i] = carry_seq; a.cig_off[i] = carry_cig; a.cig4[i] = c4v;
+            if (a.prow) { a.prow[i] = make_uint4(0, 0, 0, 0); a.rcls[i] = (covered != 0 || (n_cig > BGP_LONG_CIGAR && !((rec.flag_nc >> 16) & 0x4u))) ? 2 : 0; }      // (a record that runs past its window: the planner's)
             if (a.tilemax) {
                 const K3Key kk = k3_key_of(rec.ref_id, rec.pos, rec.end_pos);
                 if (kk.e) atomicMax(&a.tilemax[2 * (i / K3_TILE_RECORDS)], (unsigned long long)kk.e);
@@ -669,7 +676,7 @@ __device__ __forceinline__ void sd_emit(const SdArgs& a, uint8_t* sd_lds, uint64
 }
 
 #ifdef BGP_EXPERIMENTS                         // the one-pass decode: exact, measured, slower (LABNOTES.md) -- not in the product build
-#include "decode_onepass.inc"
+#include "../../scratch/experiments/decode_onepass.inc"
 #endif
 
 
@@ -767,7 +774,7 @@ int k12_fused_decode(bgp_ctx* c, uint32_t what) {
     c->table_pending = false;
     BGP_TRY(c->d_rec.reserve((n + 1) * sizeof(bgp_record)));
     BGP_TRY(c->d_seq_off.reserve((n + 1) * 8)); BGP_TRY(c->d_cigar_off.reserve((n + 1) * 8));
-    BGP_TRY(c->d_cig4.reserve((n + 1) * 16)); c->cig4_ok = true;
+    BGP_TRY(c->d_cig4.reserve((n + 1) * 16)); c->cig4_ok = true; c->rows_ok = false;
     if (what & BGP_FETCH_SEQ) BGP_TRY(c->d_seq.reserve(c->sum_lseq + 16));
     if (what & BGP_FETCH_QUAL) BGP_TRY(c->d_qual.reserve(c->sum_lseq + 16));
     if (what & BGP_FETCH_CIGAR) BGP_TRY(c->d_cigar.reserve(c->sum_ncig * 4 + 16));
@@ -817,7 +824,7 @@ int k12_fused_decode(bgp_ctx* c, uint32_t what) {
 #ifndef BGP_EXPERIMENTS
 int k012_stream_decode(bgp_ctx*, uint32_t) { return 1; }     // not built: the caller takes K0 + K1 + K2
 #else
-#include "decode_onepass_host.inc"
+#include "../../scratch/experiments/decode_onepass_host.inc"
 #endif
 
 // K1 + K2 through LDS windows (k12_lds): when K0 framed the stream in SD_C-byte segments and every section is wanted
@@ -836,6 +843,9 @@ int k12_lds_decode(bgp_ctx* c, uint32_t what) {
     BGP_TRY(c->d_rec.reserve((n + 1) * sizeof(bgp_record)));
     BGP_TRY(c->d_seq_off.reserve((n + 1) * 8)); BGP_TRY(c->d_cigar_off.reserve((n + 1) * 8));
     BGP_TRY(c->d_cig4.reserve((n + 1) * 16)); c->cig4_ok = true;
+    static const bool want_rows = !(getenv("BGP_K4_ROWS") && atoi(getenv("BGP_K4_ROWS")) == 0);      // (0: K4 plans every read itself, as it does behind the other decode routes)
+    c->rows_ok = false;
+    if (want_rows) { BGP_TRY(c->d_prow.reserve((n + 1) * 16)); BGP_TRY(c->d_rcls.reserve(n + 16)); }
     BGP_TRY(c->d_seq.reserve(c->sum_lseq + 16)); BGP_TRY(c->d_qual.reserve(c->sum_lseq + 16)); BGP_TRY(c->d_cigar.reserve(c->sum_ncig * 4 + 16));
     c->decoded_what |= BGP_FETCH_ALL;
     if (c->stream_len < 4) return BGP_OK;
@@ -844,6 +854,7 @@ int k12_lds_decode(bgp_ctx* c, uint32_t what) {
     a.d.rec = c->d_rec.as<bgp_record>(); a.d.seq_off = c->d_seq_off.as<uint64_t>(); a.d.cig_off = c->d_cigar_off.as<uint64_t>(); a.d.cig4 = c->d_cig4.as<uint4>();
     a.d.seq = c->d_seq.as<uint8_t>(); a.d.qual = c->d_qual.as<uint8_t>(); a.d.cigar = c->d_cigar.as<uint32_t>();
     a.d.cap_n = ~0ull; a.d.cap_ls = ~0ull; a.d.cap_nc = ~0ull;
+    a.d.prow = want_rows ? c->d_prow.as<uint4>() : nullptr; a.d.rcls = want_rows ? c->d_rcls.as<uint8_t>() : nullptr; c->rows_ok = want_rows;
     a.d.tilemax = nullptr; c->tilemax_ok = false;
     if (!c->long_cigar) {             // K3's tile maxima on the way (see k12_fused_decode)
         const uint64_t nt = (n + K3_TILE_RECORDS - 1) / K3_TILE_RECORDS;

@@ -659,7 +659,7 @@ int k1_table(bgp_ctx* c) {
     const unsigned lane_blocks = (unsigned)((n_seg + 255) / 256);
     BGP_TRY(c->d_rec.reserve((n + 1) * sizeof(bgp_record)));
     BGP_TRY(c->d_seq_off.reserve((n + 1) * 8)); BGP_TRY(c->d_cigar_off.reserve((n + 1) * 8));
-    BGP_TRY(c->d_cig4.reserve((n + 1) * 16)); c->cig4_ok = true; c->tilemax_ok = false;
+    BGP_TRY(c->d_cig4.reserve((n + 1) * 16)); c->cig4_ok = true; c->rows_ok = false; c->tilemax_ok = false;
     EmitArgs e;
     e.s = c->d_stream; e.len = c->stream_len; e.seg_bytes = c->seg_bytes; e.n_seg = n_seg; e.entry = c->d_seg_entry.as<uint64_t>();
     e.rec_base = c->d_seg_rec_base.as<uint64_t>(); e.seq_base = c->d_seg_seq_base.as<uint64_t>(); e.cig_base = c->d_seg_cig_base.as<uint64_t>();

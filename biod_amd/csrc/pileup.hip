@@ -260,8 +260,18 @@ __device__ __forceinline__ uint32_t base_class(uint32_t code) {   // nt16 code -
 struct TileB { uint64_t i_lo, i_hi, col_out; uint32_t T0, Tend, run_start, pad; };   // everything a window needs in one 40-byte (scalar) load; pad = 1: deep window
 // mode 0: every window, geometry and record range (two binary searches through the halo keys); 1: geometry only -- the accumulate path of a
 // stream of short reads never asks which records can touch a window, its plan knows (cfg3: 0.16 -> 0.03 ms) --; 2: the record ranges of the
-// windows on `list` (what the accumulate path left for the general kernel, which does scan them)
-__global__ __launch_bounds__(256) void k4_bounds(const uint64_t* pmax_end, const uint64_t* pmax_pos, const RunDev* runs, uint32_t n_runs, uint64_t n_tiles, TileB* out, uint32_t w, int mode, const uint32_t* list, const uint32_t* n_list) {
+// windows on `list` (what the accumulate path left for the general kernel, which does scan them); 3: geometry and the range of plan ROWS the
+// accumulate path reads for the window (k12_lds wrote them, common.h: bgp_plan_row)
+// first i in [lo, hi) with a[i] > key, a = one of K3's prefix-maximum arrays over n records, through the exclusive maxima of its 2048-record tiles
+// (bs[j].p: what k3_bsum left; 16 steps in an array the L2 holds, then 11 inside one tile's 16 KB) instead of 27 steps through 800 MB
+__device__ __forceinline__ uint64_t lower_bound_gt_pos2(const uint64_t* a, const K3Key* bs, uint64_t nt, uint64_t n, uint64_t lo, uint64_t hi, uint64_t key) {
+    uint64_t tl = 0, th = nt;
+    while (tl < th) { const uint64_t m = (tl + th) >> 1; if (bs[m].p > key) th = m; else tl = m + 1; }      // first tile in front of which something exceeds the key
+    const uint64_t j = tl ? tl - 1 : 0;                                                                       // ... the tile before it holds the first record that does (or none does)
+    const uint64_t g = lower_bound_gt(a, j * K3_TILE_RECORDS, min(n, (j + 1) * (uint64_t)K3_TILE_RECORDS), key);
+    return min(max(g, lo), hi);
+}
+__global__ __launch_bounds__(256) void k4_bounds(const uint64_t* pmax_end, const uint64_t* pmax_pos, const RunDev* runs, uint32_t n_runs, uint64_t n_tiles, TileB* out, uint32_t w, int mode, const uint32_t* list, const uint32_t* n_list, const K3Key* bsum = nullptr, uint64_t n_rec = 0) {
     uint64_t tile = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (mode == 2) { if (tile >= *n_list) return; tile = list[tile]; }
     if (tile >= n_tiles) return;
@@ -273,12 +283,16 @@ __global__ __launch_bounds__(256) void k4_bounds(const uint64_t* pmax_end, const
     const uint64_t rk = ref_key(run.ref_id) << 32;
     TileB b;
     b.i_lo = b.i_hi = 0;
-    if (mode != 1) {
+    if (mode == 3) {         // the rows k4_acc2 takes the window's ordinary reads from: every record that starts less than BGP_ROW_REACH positions in front of the window or inside it (the stream is sorted)
+        const uint64_t nt = (n_rec + K3_TILE_RECORDS - 1) / K3_TILE_RECORDS;
+        b.i_lo = T0 >= BGP_ROW_REACH ? lower_bound_gt_pos2(pmax_pos, bsum, nt, n_rec, run.first_record, run.end_record, rk | (T0 - BGP_ROW_REACH)) : run.first_record;
+        b.i_hi = lower_bound_gt_pos2(pmax_pos, bsum, nt, n_rec, b.i_lo, run.end_record, rk | (Tend - 1));
+    } else if (mode != 1) {
         b.i_lo = lower_bound_gt(pmax_end, run.first_record, run.end_record, rk | T0);             // first record whose running max end_position exceeds T0
         b.i_hi = lower_bound_gt(pmax_pos, run.first_record, run.end_record, rk | (Tend - 1));     // first record starting at/after Tend
     }
     b.col_out = run.column_base + (T0 - run.start_pos); b.T0 = T0; b.Tend = Tend; b.run_start = (uint32_t)run.start_pos;
-    b.pad = b.i_hi - b.i_lo >= DEEP_WINDOW ? 1u : 0u;     // bit 0: a count per position and class is bounded by the candidates, 16 bits are enough below this
+    b.pad = mode != 3 && b.i_hi - b.i_lo >= DEEP_WINDOW ? 1u : 0u;     // bit 0: a count per position and class is bounded by the candidates, 16 bits are enough below this (mode 3's range is not the candidates': k4_wscan lists a window of too many rows, and mode 2 then judges it)
     if (mode == 2) b.pad |= out[tile].pad & 2u;           // (bit 1, "not for the accumulate path", is set by k4_wscan, which also builds the list of such windows)
     out[tile] = b;
 }
@@ -1008,6 +1022,24 @@ __global__ __launch_bounds__(256) void k4_stats(const unsigned long long* ts, ui
 //   DEL  [13:3] first position  [25:14] one past the last position (<= W)
 //   A long read (more than four ops or 255 bases) whose CIGAR walk found it well formed gets no descriptors: it marks the windows it
 //   touches, and k4_acc2 walks its ops there, 64 a step from the window's checkpoint, an op a lane.
+// sum / max over the 64 lanes of a wave with DPP (row reductions, then row_bcast15 / row_bcast31); result in every lane
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
+    v += BGP_DPP(v, 0xB1, 0xF); v += BGP_DPP(v, 0x4E, 0xF); v += BGP_DPP(v, 0x141, 0xF); v += BGP_DPP(v, 0x140, 0xF);
+    v += BGP_DPP(v, 0x142, 0xA); v += BGP_DPP(v, 0x143, 0xC);
+    return rl(v, 63);
+}
+// inclusive prefix sum over the 64 lanes: shifts inside the rows of 16, then the rows' totals carried over
+__device__ __forceinline__ uint32_t wave_scan_u32(uint32_t v) {
+    v += BGP_DPP(v, 0x111, 0xF); v += BGP_DPP(v, 0x112, 0xF); v += BGP_DPP(v, 0x114, 0xF); v += BGP_DPP(v, 0x118, 0xF);
+    v += BGP_DPP(v, 0x142, 0xA); v += BGP_DPP(v, 0x143, 0xC);
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+    v = max(v, BGP_DPP(v, 0xB1, 0xF)); v = max(v, BGP_DPP(v, 0x4E, 0xF)); v = max(v, BGP_DPP(v, 0x141, 0xF)); v = max(v, BGP_DPP(v, 0x140, 0xF));
+    v = max(v, BGP_DPP(v, 0x142, 0xA)); v = max(v, BGP_DPP(v, 0x143, 0xC));
+    return rl(v, 63);
+}
+
 #ifndef BGP_PLAN_ABL
 #define BGP_PLAN_ABL 0                        // timing experiments on k4_plan: 1 no '-' window atomics, 2 no far-slot atomics, 4 no descriptor stores
 #endif
@@ -1020,41 +1052,26 @@ struct PlanArgs {
     const uint64_t* ck_off; const Ckpt* ck;       // long reads' checkpoints on this tiling (null: none, or long reads are left to the general kernel)
     uint32_t* wlong;                              // ... and the windows a well-formed long read touches (k4_acc2 walks its CIGAR there, from the window's checkpoint)
     int batches;                                  // batches of 64 reads a wave plans
+    const uint8_t* rcls;                          // k4_plan_rest: the records' classes (k12_lds); null for k4_plan
 };
 
 #ifndef BGP_PLAN_NB
 #define BGP_PLAN_NB 4
 #endif
 constexpr int PLAN_NB = BGP_PLAN_NB;          // batches of 64 reads a wave plans, the next batch's rows requested before the current one is worked on
-__global__ __launch_bounds__(256) void k4_plan(PlanArgs a) {
-    const int lane = threadIdx.x & 63;
-    // A wave's time was its chain of round trips -- rows, then the slots' atomics, then the stores -- with a wave slot held all the
-    // while (77 % of its cycles waiting): a wave takes PLAN_NB batches and asks for the next one's rows before it works on this one's.
-    const int nb_ = a.batches;                                             // (PLAN_NB; 1 for a stream of so few reads that the waves would not fill the device)
-    const uint64_t first = ((uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * (uint64_t)(64 * nb_);
-    if (first >= a.n) return;
-    uint4 nx, ny, nc4 = make_uint4(0, 0, 0, 0);
-    { const uint64_t ii = min(first + (uint64_t)lane, a.n - 1); const uint4* rp = reinterpret_cast<const uint4*>(a.rec + ii); nx = rp[0]; ny = rp[1]; if (a.cig4) nc4 = a.cig4[ii]; }
-    uint64_t r_end = 0, r_start_pos = 0, r_tile_base = 0;
-    for (int it = 0; it < nb_; ++it) {
-    const uint64_t i = first + (uint64_t)(64 * it) + (uint64_t)lane;
+// One batch: lane `lane` plans record ii (x, y: its row; c4: its first four ops); lanes with !in work on a record a second time and keep
+// nothing.  i0 = the record of lane 0 (the smallest of the batch).  The wave's run is cached in r_* (fresh: look it up).
+template <bool SPARSE> __device__ __forceinline__ void plan_batch(const PlanArgs& a, int lane, bool in, uint64_t ii, uint64_t i0, uint4 x, uint4 y, uint4 c4, bool fresh, uint64_t& r_end, uint64_t& r_start_pos, uint64_t& r_tile_base, uint32_t* wlds = nullptr) {
     // Straight-line, selects instead of joins, descriptors in 32-bit halves: written with a branch per case and per op this
     // kernel spent 600 VALU instructions a wave, four in ten of them register moves where the branches met -- and VALU
-    // issue is what bounds it (SQ counters: 78 % of its time).  Lanes behind the last record work on it a second time and
-    // keep nothing.
+    // issue is what bounds it (SQ counters: 78 % of its time).
     constexpr uint32_t SH = (uint32_t)__builtin_ctz((unsigned)W);             // log2(W)
     unsigned long long dsc[8]; uint32_t win[8];
     // the reference run of a record: reads are sorted, so a wave nearly always lies inside one run -- the first lane's
     // run is looked up once (a binary search of dependent loads) and only lanes beyond its end search for themselves
-    const uint64_t i0 = i - lane;
-    if (i0 >= a.n) break;
-    const uint4 x = nx, y = ny, c4 = nc4;                 // ref_id,pos,end_pos,bin_mq_nl | flag_nc,l_seq,rec_off | the first four CIGAR ops
-    if (it + 1 < nb_ && i0 + 64 < a.n) { const uint64_t jn = min(i + 64, a.n - 1); const uint4* rp = reinterpret_cast<const uint4*>(a.rec + jn); nx = rp[0]; ny = rp[1]; if (a.cig4) nc4 = a.cig4[jn]; }
     uint64_t w_start_pos, w_tile_base;                    // (the wave's run; lanes beyond its end look theirs up below)
-    if (it == 0 || i0 >= r_end) { const RunDev rd = a.runs[run_of_record(a.runs, a.n_runs, i0)]; r_end = rd.end_record; r_start_pos = rd.start_pos; r_tile_base = rd.tile_base; }
+    if (fresh || i0 >= r_end) { const RunDev rd = a.runs[run_of_record(a.runs, a.n_runs, i0)]; r_end = rd.end_record; r_start_pos = rd.start_pos; r_tile_base = rd.tile_base; }
     w_start_pos = r_start_pos; w_tile_base = r_tile_base;
-    const bool in = i < a.n;
-    const uint64_t ii = in ? i : a.n - 1;
     const bool covered = in && x.z != x.y;                // basesCovered() > 0, pileup.d:481,510
     if (covered && ii >= r_end) { const RunDev& rd = a.runs[run_of_record(a.runs, a.n_runs, ii)]; w_start_pos = rd.start_pos; w_tile_base = rd.tile_base; }
     const uint32_t rel0 = x.y - (uint32_t)w_start_pos;
@@ -1121,11 +1138,44 @@ __global__ __launch_bounds__(256) void k4_plan(PlanArgs a) {
             q += qc ? len : 0u;
         }
     }
+    const unsigned long long am = __ballot(any);
+    if (!am) return;
+    if (SPARSE) {
+        // The batch is the few reads in a thousand that k4_plan_rest lists -- N skips mostly: their descriptors spread over a dozen windows
+        // (where the reads start, and up to a skip's length further on), a few lanes each.  Claimed one by one that was 1.8 x 10^7
+        // returning atomics on cfg3 (1.0 ms); the lanes count themselves into the 32 windows from the batch's first one on in LDS, and
+        // one global atomic a window claims the slots of all of them.
+        uint32_t mn = 0xFFFFFFFFu;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) mn = min(mn, win[j]);
+        const uint32_t A0 = ~wave_max_u32(~mn);
+        if (lane < 32) wlds[lane] = 0u;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+        uint32_t rank[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            rank[j] = 0;
+            if (win[j] == 0xFFFFFFFFu) continue;
+            const uint32_t off = win[j] - A0;
+            if (off < 32u) rank[j] = atomicAdd(&wlds[off], 1u);
+            else rank[j] = atomicAdd(&a.wcount[win[j]], 1u);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+        if (lane < 32) { const uint32_t cw = wlds[lane]; wlds[32 + lane] = cw ? atomicAdd(&a.wcount[A0 + (uint32_t)lane], cw) : 0u; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (win[j] == 0xFFFFFFFFu) continue;
+            const uint32_t off = win[j] - A0;
+            const uint32_t slot = off < 32u ? wlds[32 + off] + rank[j] : rank[j];
+            if (slot < a.slab_cap) a.slab[(uint64_t)win[j] * a.slab_cap + slot] = dsc[j];
+        }
+        __builtin_amdgcn_wave_barrier();
+        return;
+    }
     // slots in the windows' slabs.  Reads are sorted, so nearly every descriptor of a wave goes to the wave's first
     // window A or to A + 1: those two are claimed with one atomic each for the whole wave; the few others (second
     // halves of N-skip reads) claim theirs one by one.  All atomics are in flight together.
-    const unsigned long long am = __ballot(any);
-    if (!am) continue;
     const uint32_t A = (uint32_t)__shfl((int)wf, __ffsll((long long)am) - 1, 64);
     uint32_t pk = 0;
 #pragma unroll
@@ -1155,6 +1205,63 @@ __global__ __launch_bounds__(256) void k4_plan(PlanArgs a) {
         if (slot == 0xFFFFFFF0u) a.slab[(uint64_t)win[j] * a.slab_cap] = dsc[j];
 #endif
     }
+}
+
+__global__ __launch_bounds__(256) void k4_plan(PlanArgs a) {
+    const int lane = threadIdx.x & 63;
+    // A wave's time was its chain of round trips -- rows, then the slots' atomics, then the stores -- with a wave slot held all the
+    // while (77 % of its cycles waiting): a wave takes PLAN_NB batches and asks for the next one's rows before it works on this one's.
+    const int nb_ = a.batches;                                             // (PLAN_NB; 1 for a stream of so few reads that the waves would not fill the device)
+    const uint64_t first = ((uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * (uint64_t)(64 * nb_);
+    if (first >= a.n) return;
+    uint4 nx, ny, nc4 = make_uint4(0, 0, 0, 0);
+    { const uint64_t ii = min(first + (uint64_t)lane, a.n - 1); const uint4* rp = reinterpret_cast<const uint4*>(a.rec + ii); nx = rp[0]; ny = rp[1]; if (a.cig4) nc4 = a.cig4[ii]; }
+    uint64_t r_end = 0, r_start_pos = 0, r_tile_base = 0;
+    for (int it = 0; it < nb_; ++it) {
+        const uint64_t i = first + (uint64_t)(64 * it) + (uint64_t)lane;
+        const uint64_t i0 = i - lane;
+        if (i0 >= a.n) break;
+        const uint4 x = nx, y = ny, c4 = nc4;                 // ref_id,pos,end_pos,bin_mq_nl | flag_nc,l_seq,rec_off | the first four CIGAR ops
+        if (it + 1 < nb_ && i0 + 64 < a.n) { const uint64_t jn = min(i + 64, a.n - 1); const uint4* rp = reinterpret_cast<const uint4*>(a.rec + jn); nx = rp[0]; ny = rp[1]; if (a.cig4) nc4 = a.cig4[jn]; }
+        const bool in = i < a.n;
+        plan_batch<false>(a, lane, in, in ? i : a.n - 1, i0, x, y, c4, it == 0, r_end, r_start_pos, r_tile_base);
+    }
+}
+
+// The planner behind k12_lds's plan rows (a.rcls: a class byte a record, common.h): ordinary reads are taken from their rows by
+// k4_acc2 itself, and only what is left -- reads that reach further than a row says (N skips), odd CIGARs, long reads: a few in a
+// hundred -- is planned here.  A wave looks at 1024 class bytes (sixteen a lane, one load), lists the records of class 2 in LDS in
+// file order and plans them 64 at a time with plan_batch: the rows of 96 reads in a hundred are never loaded.
+constexpr int PLAN_SPAN = 1024;
+__global__ __launch_bounds__(256) void k4_plan_rest(PlanArgs a) {
+    __shared__ uint16_t lst[4][PLAN_SPAN];
+    __shared__ uint32_t wl[4][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint64_t base = ((uint64_t)blockIdx.x * 4 + (uint64_t)wv) * PLAN_SPAN;
+    if (base >= a.n) return;
+    const uint64_t o = base + 16ull * (uint64_t)lane;
+    uint32_t cw[4] = {0u, 0u, 0u, 0u};
+    if (o < a.n) __builtin_memcpy(cw, a.rcls + o, 16);        // (the array has sixteen bytes of room behind the last record)
+    uint32_t m = 0;                                              // bit j: record o + j is class 2
+#pragma unroll
+    for (int j = 0; j < 16; ++j) if (((cw[j >> 2] >> (8 * (j & 3))) & 0xFFu) == 2u && o + (uint64_t)j < a.n) m |= 1u << j;
+    const uint32_t cnt = (uint32_t)__builtin_popcount(m);
+    const uint32_t inc = wave_incl_u32(cnt, lane), total = rl(inc, 63);
+    if (!total) return;
+    {
+        uint32_t at = inc - cnt, mm = m;
+        while (mm) { const int j = __builtin_ctz(mm); mm &= mm - 1; lst[wv][at++] = (uint16_t)(16 * lane + j); }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    uint64_t r_end = 0, r_start_pos = 0, r_tile_base = 0;
+    for (uint32_t k = 0; k < total; k += 64) {
+        const bool in = k + (uint32_t)lane < total;
+        const uint64_t ii = base + lst[wv][in ? k + (uint32_t)lane : total - 1u], i0 = base + lst[wv][k];
+        const uint4* rp = reinterpret_cast<const uint4*>(a.rec + ii);
+        const uint4 x = rp[0], y = rp[1];
+        const uint4 c4 = a.cig4 ? a.cig4[ii] : make_uint4(0, 0, 0, 0);
+        plan_batch<true>(a, lane, in, ii, i0, x, y, c4, k == 0, r_end, r_start_pos, r_tile_base, wl[wv]);
     }
 }
 
@@ -1193,14 +1300,16 @@ __global__ __launch_bounds__(1024) void k4_wscan_mid(int32_t* btot, uint32_t nb)
         cd += td; cs += ts;
     }
 }
-__global__ __launch_bounds__(1024) void k4_wscan(int32_t* wdel, const int32_t* wslow, const uint32_t* wcount, TileB* tiles, uint64_t n_tiles, const int32_t* btot, uint32_t* deep, uint32_t* n_deep, uint32_t slab_cap) {
+constexpr uint32_t ROW_CAP = 8192;            // plan rows a window of the accumulate path reads at most (32 rounds); more: the general kernel's
+__global__ __launch_bounds__(1024) void k4_wscan(int32_t* wdel, const int32_t* wslow, const uint32_t* wcount, TileB* tiles, uint64_t n_tiles, const int32_t* btot, uint32_t* deep, uint32_t* n_deep, uint32_t slab_cap, uint32_t row_cap) {
     __shared__ int32_t ws[2][16];
     const uint64_t i = (uint64_t)blockIdx.x * 1024 + threadIdx.x;
     int32_t id, is, pd, ps, td, ts;
     wscan_block(i < n_tiles ? wdel[i] : 0, i < n_tiles ? wslow[i] : 0, &id, &is, &pd, &ps, &td, &ts, ws);
     if (i < n_tiles) {
         wdel[i] = btot[2 * blockIdx.x] + pd + id;
-        const uint32_t pad = (tiles[i].pad & 1u) | ((btot[2 * blockIdx.x + 1] + ps + is > 0 || wcount[i] > slab_cap) ? 2u : 0u);
+        const bool rows_over = row_cap && tiles[i].i_hi - tiles[i].i_lo > (uint64_t)row_cap;
+        const uint32_t pad = (tiles[i].pad & 1u) | ((btot[2 * blockIdx.x + 1] + ps + is > 0 || wcount[i] > slab_cap || rows_over) ? 2u : 0u);
         tiles[i].pad = pad;
         if (pad) deep[atomicAdd(n_deep, 1u)] = (uint32_t)i;
     }
@@ -1210,25 +1319,8 @@ struct GArgs {
     const uint8_t* s; const unsigned long long* slab; uint32_t slab_cap; const uint32_t* wcount; const int32_t* wdel; const TileB* tiles; uint64_t n_tiles;
     bgp_column* cols; unsigned long long* hist; unsigned long long* tile_stats; uint32_t* deep; uint32_t* n_deep;
     const uint32_t* wlong; const bgp_record* rec; const uint64_t* ck_off; const Ckpt* ck;      // long reads (null: none): windows they touch, the record table, their per-window checkpoints
+    const uint4* prow;                            // ROWS: the records' plan rows (k12_lds; common.h: bgp_plan_row); a window's are [tiles[w].i_lo, i_hi)
 };
-
-// sum / max over the 64 lanes of a wave with DPP (row reductions, then row_bcast15 / row_bcast31); result in every lane
-__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
-    v += BGP_DPP(v, 0xB1, 0xF); v += BGP_DPP(v, 0x4E, 0xF); v += BGP_DPP(v, 0x141, 0xF); v += BGP_DPP(v, 0x140, 0xF);
-    v += BGP_DPP(v, 0x142, 0xA); v += BGP_DPP(v, 0x143, 0xC);
-    return rl(v, 63);
-}
-// inclusive prefix sum over the 64 lanes: shifts inside the rows of 16, then the rows' totals carried over
-__device__ __forceinline__ uint32_t wave_scan_u32(uint32_t v) {
-    v += BGP_DPP(v, 0x111, 0xF); v += BGP_DPP(v, 0x112, 0xF); v += BGP_DPP(v, 0x114, 0xF); v += BGP_DPP(v, 0x118, 0xF);
-    v += BGP_DPP(v, 0x142, 0xA); v += BGP_DPP(v, 0x143, 0xC);
-    return v;
-}
-__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
-    v = max(v, BGP_DPP(v, 0xB1, 0xF)); v = max(v, BGP_DPP(v, 0x4E, 0xF)); v = max(v, BGP_DPP(v, 0x141, 0xF)); v = max(v, BGP_DPP(v, 0x140, 0xF));
-    v = max(v, BGP_DPP(v, 0x142, 0xA)); v = max(v, BGP_DPP(v, 0x143, 0xC));
-    return rl(v, 63);
-}
 
 // ---------------------------------------------------------------------------------------------- K4, accumulate path: lane = piece, byte planes (round 4)
 //
@@ -1406,7 +1498,10 @@ __device__ __forceinline__ void acc2_work_small(const A2Small& b, uint32_t* cbas
 
 // LONG: the stream holds long reads (the phase that walks their CIGARs is compiled in: it costs registers -- 128 and a few spilled
 // against 102 -- that a stream of short reads need not pay for: cfg3 8.8 against 8.0 ms)
-template <bool LONG> __global__ __launch_bounds__(AT, BGP_ACC2_MINW) void k4_acc2(GArgs a) {
+// ROWS: the window's ordinary reads come as k12_lds's plan rows, a row a thread and round -- its one or two M runs are cut at the window
+// here and become pieces like a SEG descriptor's -- and the slab holds only what k4_plan_rest planned (a few descriptors a window).
+template <bool LONG, bool ROWS> __global__ __launch_bounds__(AT, BGP_ACC2_MINW) void k4_acc2(GArgs a) {
+    static_assert(!(LONG && ROWS), "a stream with long reads is planned read by read");
     using L = A2Lay;
     extern __shared__ __attribute__((aligned(16))) uint8_t alds[];
     uint32_t* const cnt = reinterpret_cast<uint32_t*>(alds + L::CNT);
@@ -1425,19 +1520,31 @@ template <bool LONG> __global__ __launch_bounds__(AT, BGP_ACC2_MINW) void k4_acc
     if (tile >= tile_end) return;
     for (int i = t; i < L::POOL / 4; i += AT) cnt[i] = 0;                      // counters, difference arrays, starts (a window leaves them zeroed again), hist
     if (t < 32) misc[t] = 0;
-    struct Pre { uint4 ii; uint2 col; uint4 tt; uint32_t n; int32_t wd; unsigned long long d0, d1; };   // the next window's header and first round of descriptors, a window ahead, in vector registers: left to the compiler the loads became scalars with an s_waitcnt right behind the "prefetch" -- which, gfx9 counting loads and stores with ONE in-order counter, also stood for the previous window's column stores
-    auto prefetch = [&](uint64_t w) {
-        Pre p;
+    struct Pre { uint4 ii; uint2 col; uint4 tt; uint32_t n; int32_t wd; unsigned long long d0, d1; uint4 r0, r1; };   // the next window's header and first round of descriptors, a window ahead, in vector registers: left to the compiler the loads became scalars with an s_waitcnt right behind the "prefetch" -- which, gfx9 counting loads and stores with ONE in-order counter, also stood for the previous window's column stores
+    auto prefetch_hdr = [&](uint64_t w, Pre& p) {
         const char* tp = reinterpret_cast<const char*>(a.tiles + w);
         __builtin_memcpy(&p.ii, tp, 16);
         __builtin_memcpy(&p.col, tp + 16, 8);
         __builtin_memcpy(&p.tt, tp + 24, 16);
         p.n = a.wcount[w]; p.wd = a.wdel[w];
-        const unsigned long long* sl = a.slab + w * (uint64_t)a.slab_cap;      // (the slab is there whatever the count says; slots behind the count hold anything)
-        p.d0 = sl[t]; p.d1 = sl[AT + t];
-        return p;
     };
-    Pre pre = prefetch(tile);
+    auto prefetch_pay = [&](uint64_t w, Pre& p) {       // ROWS: the window's first round of rows lies where its header says -- the header is asked for TWO windows ahead, the rows one
+        const unsigned long long* sl = a.slab + w * (uint64_t)a.slab_cap;      // (the slab is there whatever the count says; slots behind the count hold anything)
+        p.d0 = sl[t];
+        if (!ROWS) p.d1 = sl[AT + t];
+        else {
+            p.d1 = 0ull;
+            const uint64_t lo = ((uint64_t)p.ii.y << 32) | p.ii.x, hi = ((uint64_t)p.ii.w << 32) | p.ii.z;
+            p.r0 = p.r1 = make_uint4(0u, 0u, 0u, 0u);
+            if (lo + (uint64_t)t < hi) p.r0 = a.prow[lo + (uint64_t)t];
+            if (lo + (uint64_t)(AT + t) < hi) p.r1 = a.prow[lo + (uint64_t)(AT + t)];
+        }
+    };
+    Pre pre;
+    uint4 ii2 = make_uint4(0u, 0u, 0u, 0u);          // ROWS: the record range of the window after next (the rows of the next window are asked for a window ahead, and where they lie has to be known by then)
+    prefetch_hdr(tile, pre);
+    if (ROWS && tile + 1 < tile_end) __builtin_memcpy(&ii2, reinterpret_cast<const char*>(a.tiles + tile + 1), 16);
+    prefetch_pay(tile, pre);
     uint32_t r_ncol = 0, r_nsum = 0, r_mx = 0; unsigned long long r_scov = 0;
     uint32_t* const cbase0 = cnt + ((lane >> BGP_ACC2_CPSH) & (P_NCP - 1)) * P_CPW;
     uint32_t rounds = 0;
@@ -1453,53 +1560,110 @@ template <bool LONG> __global__ __launch_bounds__(AT, BGP_ACC2_MINW) void k4_acc
         const uint64_t i_hi = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)pre.ii.w) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)pre.ii.z);
         const uint32_t run_start = (uint32_t)__builtin_amdgcn_readfirstlane((int)pre.tt.z);
         unsigned long long dd[2] = {pre.d0, pre.d1};
-        if (tile + 1 < tile_end) pre = prefetch(tile + 1);
+        uint4 rw = pre.r0; const uint4 pre_r1 = pre.r1;
+        if (!ROWS) { if (tile + 1 < tile_end) { prefetch_hdr(tile + 1, pre); prefetch_pay(tile + 1, pre); } }
+        else if (tile + 1 < tile_end) {                      // (the record range of tile + 1 has been on its way for a window: its rows can be asked for; and the range of tile + 2)
+            prefetch_hdr(tile + 1, pre);
+            pre.ii = ii2;
+            prefetch_pay(tile + 1, pre);
+            if (tile + 2 < tile_end) __builtin_memcpy(&ii2, reinterpret_cast<const char*>(a.tiles + tile + 2), 16);
+        }
         if (pad) continue;                                   // on the general kernel's list
         const unsigned long long* slab = a.slab + tile * (uint64_t)a.slab_cap;
-        for (uint32_t rb = 0; rb < ((BGP_ACC2_ABL & 8) ? 0u : n_desc); rb += (uint32_t)P_RD) {      // (8: timing experiment, the flush alone)
-            // ---- a round, first half: P_RD descriptors, two a thread.  Per-descriptor atomics ('-', starts, coverage); a SEG descriptor is cut
+        const uint32_t n_rows = ROWS ? (uint32_t)(i_hi - i_lo) : 0u;      // (k4_wscan lists a window of more than ROW_CAP rows for the general kernel)
+        const uint32_t n_items = ROWS ? max(n_rows, 2u * n_desc) : n_desc;      // (ROWS: a round is 512 rows and 256 descriptors of the slab)
+        bool ovf = false;
+        for (uint32_t rb = 0; rb < ((BGP_ACC2_ABL & 8) ? 0u : n_items); rb += (uint32_t)P_RD) {      // (8: timing experiment, the flush alone)
+            // ---- a round, first half: P_RD descriptors, two a thread -- ROWS: a plan row (its two M runs cut at the window: two descriptors) and a
+            // descriptor of the slab a thread.  Per-descriptor atomics ('-', starts, coverage); a SEG descriptor is cut
             // into pieces of equal length, long pieces (9 chunks or more) fill the pool from its front, short ones from its back: a batch of 64
             // from either end runs about as long in every lane
-            if (rb) { dd[0] = slab[rb + t]; dd[1] = slab[rb + AT + t]; }
+            uint4 rw2 = make_uint4(0u, 0u, 0u, 0u);
+            if (!ROWS) { if (rb) { dd[0] = slab[rb + t]; dd[1] = slab[rb + AT + t]; } }
+            else {
+                if (rb) { rw = make_uint4(0u, 0u, 0u, 0u); if (rb + t < n_rows) rw = a.prow[i_lo + rb + t]; rw2 = make_uint4(0u, 0u, 0u, 0u); if (rb + AT + t < n_rows) rw2 = a.prow[i_lo + rb + AT + t]; if (rb / 2 + t < n_desc) dd[0] = slab[rb / 2 + t]; }
+                else rw2 = pre_r1;
+            }
             uint32_t* const mc = misc + 4 * (rounds & 1u);       // the round's three counters; the other set is zeroed while this one is in use
             ++rounds;
+            // one or two SEG descriptors (d1: 0 or the second run of the same row) become pieces behind ONE scan of the wave
+            auto emit = [&](unsigned long long d0, unsigned long long d1, bool two) {
+                uint32_t lo_[2], len_[2], sft_[2], npc_[2], cpp_[2]; bool lng_[2]; uint64_t na_[2];
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const unsigned long long d = rb + h * AT + t < n_desc ? dd[h] : 0ull;
-                const uint32_t kind = (uint32_t)d & 3u;
-                const uint32_t lo = ((uint32_t)d >> 3) & 0x7FFu, f14 = (uint32_t)(d >> 14);
-                const uint32_t len = f14 & 0xFFu, nib = (f14 >> 8) & 1u;
-                if (kind == 2) { atomicAdd(&deld[lo], 1u); atomicAdd(&deld[f14 & 0xFFFu], 0xFFFFFFFFu); }       // D / N inside the window: '-' from lo up to the op's end (pileup.d:119-121)
-                const bool seg = kind == 1;
-                if (seg) {
-                    if (d & 4u) atomicAdd(&nst[lo >> 1], 1u << ((lo & 1u) * 16));                              // n_starting_here, pileup.d:386,422
-                    atomicAdd(&covd[lo], 1u); atomicAdd(&covd[lo + len], 0xFFFFFFFFu);                       // M / = / X: in the column from lo on (pileup.d:117-118, :352)
+                for (int q = 0; q < 2; ++q) {
+                    const unsigned long long d = q ? d1 : d0;
+                    const uint32_t kind = (q && !two) ? 0u : (uint32_t)d & 3u;
+                    const uint32_t lo = ((uint32_t)d >> 3) & 0x7FFu, f14 = (uint32_t)(d >> 14);
+                    const uint32_t len = f14 & 0xFFu, nib = (f14 >> 8) & 1u;
+                    if (kind == 2) { atomicAdd(&deld[lo], 1u); atomicAdd(&deld[f14 & 0xFFFu], 0xFFFFFFFFu); }       // D / N inside the window: '-' from lo up to the op's end (pileup.d:119-121)
+                    const bool seg = kind == 1;
+                    if (seg) {
+                        if (d & 4u) atomicAdd(&nst[lo >> 1], 1u << ((lo & 1u) * 16));                              // n_starting_here, pileup.d:386,422
+                        atomicAdd(&covd[lo], 1u); atomicAdd(&covd[lo + len], 0xFFFFFFFFu);                       // M / = / X: in the column from lo on (pileup.d:117-118, :352)
+                    }
+                    const uint32_t sft = lo & 7u;
+                    const uint32_t nch = seg ? (sft + len + 7u) >> 3 : 0u;
+                    const uint32_t npc = (nch + (uint32_t)P_CH - 1u) / (uint32_t)P_CH;            // 0..3
+                    const uint32_t cpp = npc ? (nch + npc - 1u) / npc : 0u;                       // chunks a piece: the pieces of a descriptor are equally long
+                    lo_[q] = lo; len_[q] = len; sft_[q] = sft; npc_[q] = npc; cpp_[q] = cpp; lng_[q] = cpp >= 9u;
+                    na_[q] = 2ull * (d >> 23) + nib - sft;                                          // nibble address of the descriptor's chunk-aligned origin
                 }
-                const uint32_t sft = lo & 7u;
-                const uint32_t nch = seg ? (sft + len + 7u) >> 3 : 0u;
-                const uint32_t npc = (nch + (uint32_t)P_CH - 1u) / (uint32_t)P_CH;            // 0..3
-                const uint32_t cpp = npc ? (nch + npc - 1u) / npc : 0u;                       // chunks a piece: the pieces of a descriptor are equally long
-                const bool lng = cpp >= 9u;
-                const uint32_t pk = lng ? npc : npc << 16;
+                const uint32_t pk0 = lng_[0] ? npc_[0] : npc_[0] << 16, pk1 = lng_[1] ? npc_[1] : npc_[1] << 16, pk = pk0 + pk1;
                 const uint32_t inc = wave_scan_u32(pk), tot = rl(inc, 63);
                 uint32_t bl = 0, bs = 0;
                 if (lane == 0) { if (tot & 0xFFFFu) bl = atomicAdd(&mc[0], tot & 0xFFFFu); if (tot >> 16) bs = atomicAdd(&mc[1], tot >> 16); }
                 bl = rl(bl, 0); bs = rl(bs, 0);
-                const uint32_t ex = inc - pk;
-                const uint32_t slot0 = lng ? bl + (ex & 0xFFFFu) : (uint32_t)P_POOL - 1u - (bs + (ex >> 16));
-                const uint64_t na = 2ull * (d >> 23) + nib - sft;                             // nibble address of the descriptor's chunk-aligned origin
-                for (uint32_t k = 0; k < npc; ++k) {
-                    const uint32_t c0 = k * cpp;
-                    const uint32_t tl = min(sft + len - 8u * c0, 8u * cpp);
-                    const unsigned long long e = (na + 8u * c0) | ((unsigned long long)(((lo >> 3) + c0) | ((k ? 0u : sft) << 7) | (tl << 10)) << 42);
-                    pool[lng ? slot0 + k : slot0 - k] = e;
+                uint32_t ex = inc - pk;
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    if (q && !two) break;
+                    const uint32_t slot0 = lng_[q] ? bl + (ex & 0xFFFFu) : (uint32_t)P_POOL - 1u - (bs + (ex >> 16));
+                    for (uint32_t k = 0; k < npc_[q]; ++k) {
+                        const uint32_t c0 = k * cpp_[q];
+                        const uint32_t tl = min(sft_[q] + len_[q] - 8u * c0, 8u * cpp_[q]);
+                        const unsigned long long e = (na_[q] + 8u * c0) | ((unsigned long long)(((lo_[q] >> 3) + c0) | ((k ? 0u : sft_[q]) << 7) | (tl << 10)) << 42);
+                        const uint32_t at = lng_[q] ? slot0 + k : slot0 - k;
+                        if (!ROWS || at < (uint32_t)P_POOL) pool[at] = e;      // (ROWS: a round can make more pieces than the pool holds -- reads of 250 bases in two runs next to a full slab; the window then goes to the general kernel, below)
+                    }
+                    ex += q ? 0u : pk0;
                 }
+            };
+            if (!ROWS) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) emit(rb + h * AT + t < n_desc ? dd[h] : 0ull, 0ull, false);
+            } else {
+                // a plan row a thread and half-round: its runs inside [T0, Tend) as SEG descriptors, its D / N stretch as two entries of the '-' difference array
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const uint4 r = h ? rw2 : rw;
+                    const bool on = (r.y >> 28) != 0u;
+                    const uint32_t len0 = r.y & 0xFFu, len1 = (r.y >> 8) & 0xFFu, r1 = (r.y >> 16) & 0x1FFu;
+                    const uint64_t zw = ((uint64_t)r.w << 32) | r.z, na0 = zw & ((1ull << 42) - 1ull);
+                    const uint32_t dq = (uint32_t)(zw >> 42) & 0xFFu;
+                    unsigned long long dr[2] = {0ull, 0ull};
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const uint32_t st = q ? r.x + r1 : r.x, len = q ? len1 : len0;
+                        const uint32_t c_lo = max(st, T0), c_hi = min(st + len, Tend);
+                        if (on && c_lo < c_hi) {
+                            const uint64_t nb = na0 + (q ? dq : 0u) + (c_lo - st);
+                            dr[q] = (unsigned long long)(1u | (q == 0 && c_lo == st ? 4u : 0u) | ((c_lo - T0) << 3) | ((c_hi - c_lo) << 14) | (((uint32_t)nb & 1u) << 22)) | ((nb >> 1) << 23);
+                        }
+                    }
+                    if (on && ((r.y >> 25) & 1u)) {
+                        const uint32_t c_lo = max(r.x + len0, T0), c_hi = min(r.x + r1, Tend);
+                        if (c_lo < c_hi) { atomicAdd(&deld[c_lo - T0], 1u); atomicAdd(&deld[c_hi - T0], 0xFFFFFFFFu); }      // pileup.d:119-121
+                    }
+                    if (h == 0 || rb + AT + 64u * (uint32_t)wave < n_rows) emit(dr[0], dr[1], true);      // (the second half-round: only the waves that hold rows)
+                }
+                if (rb / 2 + 64u * (uint32_t)wave < n_desc) emit(rb / 2 + t < n_desc ? dd[0] : 0ull, 0ull, false);      // what k4_plan_rest planned: a handful of descriptors, the first wave's
             }
             __syncthreads();
+            if (ROWS && mc[0] + mc[1] > (uint32_t)P_POOL) ovf = true;      // the pool's two ends have met: what it holds is not the round's pieces
             // ---- second half: batches of 64 pieces, a piece a lane; the loads of a wave's next batch are in flight while it works on the current one
             {
                 if (t < 3) misc[4 * (rounds & 1u) + t] = 0;       // (the next round's: nobody has touched them since the barrier that ended the round before this one)
-                const uint32_t n_l = mc[0], n_s = mc[1];
+                const uint32_t n_l = ovf ? 0u : mc[0], n_s = ovf ? 0u : mc[1];
                 const uint32_t nb_l = (n_l + 63u) >> 6, nb = nb_l + ((n_s + 63u) >> 6);
                 auto entry = [&](uint32_t b) {
                     unsigned long long e = 0;
@@ -1540,6 +1704,7 @@ template <bool LONG> __global__ __launch_bounds__(AT, BGP_ACC2_MINW) void k4_acc
                 }
             }
             __syncthreads();                                 // every add of the round is in; the pool is free
+            if (ovf) break;
         }
         const uint32_t np = Tend - T0;
         if (LONG && a.wlong[tile]) {
@@ -1714,7 +1879,7 @@ template <bool LONG> __global__ __launch_bounds__(AT, BGP_ACC2_MINW) void k4_acc
             __syncthreads();
             mxs = max(max(misc[16], misc[17]), max(misc[18], misc[19]));
         }
-        if (mxs > 255u) {                                    // a byte-wide counter may have wrapped: the window is the general kernel's (rare: deeper than 255 and still within the slab)
+        if (mxs > 255u || ovf) {                             // a byte-wide counter may have wrapped: the window is the general kernel's (rare: deeper than 255 and still within the slab)
             if (t == 0) a.deep[atomicAdd(a.n_deep, 1u)] = (uint32_t)tile;
             __syncthreads();                                 // (the staging is not read: the next window's pool may overwrite it)
             continue;
@@ -2363,7 +2528,7 @@ int k34_pileup(bgp_ctx* c) {
         uint64_t used = 0;   // algorithmic bytes: record table + CIGAR + packed SEQ per read, 32 B per position
         used = c->n_records * 32 + c->sum_ncig * 4 + (c->sum_lseq + 1) / 2 + col_base * 32;
         BGP_TRY(c->d_tiles.reserve(tile_base * sizeof(TileB)));
-        bool lite_bounds = false;
+        bool lite_bounds = false, use_rows = false;
         BGP_TRY(c->d_deep.reserve((tile_base + 2) * 4));                 // [0] count, [1..] window indices
         BGP_HIP(hipMemsetAsync(c->d_deep.p, 0, 4, c->stream));
         a.n_deep = c->d_deep.as<uint32_t>(); a.deep = c->d_deep.as<uint32_t>() + 1;
@@ -2372,7 +2537,10 @@ int k34_pileup(bgp_ctx* c) {
             TimedRegion tb(c, "k4_bounds", tile_base * sizeof(TileB));
             // (a stream with long reads: k4_acc2 walks them from the window's record range; a stream left to the general kernel: every window is its)
             lite_bounds = !long_stream && !st[3];
-            hipLaunchKernelGGL(k4_bounds, dim3((unsigned)((tile_base + 255) / 256)), dim3(256), 0, c->stream, a.pmax_end, a.pmax_pos, a.runs, n_runs, tile_base, c->d_tiles.as<TileB>(), tw, lite_bounds ? 1 : 0, (const uint32_t*)nullptr, (const uint32_t*)nullptr);
+            // k12_lds left plan rows: the accumulate path takes a window's ordinary reads from them (a sorted stream of short reads; anything else is planned read by read)
+            static const bool rows_env = !(getenv("BGP_K4_ROWS") && atoi(getenv("BGP_K4_ROWS")) == 0);
+            use_rows = rows_env && c->rows_ok && lite_bounds && rc == BGP_OK;
+            hipLaunchKernelGGL(k4_bounds, dim3((unsigned)((tile_base + 255) / 256)), dim3(256), 0, c->stream, a.pmax_end, a.pmax_pos, a.runs, n_runs, tile_base, c->d_tiles.as<TileB>(), tw, use_rows ? 3 : lite_bounds ? 1 : 0, (const uint32_t*)nullptr, (const uint32_t*)nullptr, c->d_scan_tmp.as<K3Key>(), n);      // (d_scan_tmp: K3's tile maxima, scanned -- nothing has touched it since)
         }
         constexpr uint64_t WG_SLOTS = 65536;            // k4_acc's workgroups leave their ranges' totals behind the windows' slots
         BGP_TRY(c->d_col_lo.reserve((tile_base + WG_SLOTS) * 32));
@@ -2410,20 +2578,22 @@ int k34_pileup(bgp_ctx* c) {
         BGP_TRY(c->d_col_lo.reserve((tile_base + 65536) * 32));          // (k4_acc's totals: zeroed here with the planner's arrays, one launch)
         { const FillItem f[4] = {{c->d_wcount.p, (tile_base + 1) * 4, 0u}, {c->d_wdel.p, (tile_base + 2) * 4, 0u}, {c->d_wslow.p, (tile_base + 2) * 4, 0u}, {c->d_col_lo.p, (tile_base + 65536) * 32, 0u}}; BGP_TRY(fill_many(c, f, 4)); }
         {
-            TimedRegion tp(c, "k4_plan", c->n_records * 48);
+            TimedRegion tp(c, use_rows ? "k4_plan_rest" : "k4_plan", use_rows ? c->n_records : c->n_records * 48);      // (what it reads of every record: the class byte | the row and the first ops)
             PlanArgs pa;
             pa.rec = a.rec; pa.cig4 = c->cig4_ok ? c->d_cig4.as<uint4>() : nullptr; pa.s = a.s; pa.stream_len = a.stream_len; pa.n = n;
             pa.runs = a.runs; pa.n_runs = n_runs; pa.n_tiles = tile_base;
             pa.slab = (unsigned long long*)c->d_slab.p; pa.slab_cap = slab_cap; pa.wcount = c->d_wcount.as<uint32_t>(); pa.wdel = c->d_wdel.as<int32_t>(); pa.wslow = c->d_wslow.as<int32_t>();
             pa.ck = have_rows ? a.ck : nullptr; pa.ck_off = a.ck_off; pa.wlong = have_rows ? c->d_wlong.as<uint32_t>() : nullptr;
             pa.batches = n >= (4ull << 20) ? PLAN_NB : 1;
-            hipLaunchKernelGGL(k4_plan, dim3((unsigned)((n + 256ull * pa.batches - 1) / (256ull * pa.batches))), dim3(256), 0, c->stream, pa);
+            pa.rcls = use_rows ? c->d_rcls.as<uint8_t>() : nullptr;
+            if (use_rows) hipLaunchKernelGGL(k4_plan_rest, dim3((unsigned)((n + 4ull * PLAN_SPAN - 1) / (4ull * PLAN_SPAN))), dim3(256), 0, c->stream, pa);
+            else hipLaunchKernelGGL(k4_plan, dim3((unsigned)((n + 256ull * pa.batches - 1) / (256ull * pa.batches))), dim3(256), 0, c->stream, pa);
             const unsigned wb = (unsigned)((tile_base + 1023) / 1024);
             BGP_TRY(c->d_scan_tmp.reserve((size_t)wb * 8 + 16));
             int32_t* btot = c->d_scan_tmp.as<int32_t>();
             hipLaunchKernelGGL(k4_wscan_tot, dim3(wb), dim3(1024), 0, c->stream, pa.wdel, pa.wslow, tile_base, btot);
             hipLaunchKernelGGL(k4_wscan_mid, dim3(1), dim3(1024), 0, c->stream, btot, wb);
-            hipLaunchKernelGGL(k4_wscan, dim3(wb), dim3(1024), 0, c->stream, pa.wdel, pa.wslow, pa.wcount, c->d_tiles.as<TileB>(), tile_base, btot, c->d_deep.as<uint32_t>() + 1, c->d_deep.as<uint32_t>(), slab_cap);
+            hipLaunchKernelGGL(k4_wscan, dim3(wb), dim3(1024), 0, c->stream, pa.wdel, pa.wslow, pa.wcount, c->d_tiles.as<TileB>(), tile_base, btot, c->d_deep.as<uint32_t>() + 1, c->d_deep.as<uint32_t>(), slab_cap, use_rows ? ROW_CAP : 0u);
         }
         }
         c->ck_w = a.ck ? tw : 0;                     // K5 resumes long reads from these checkpoints
@@ -2438,8 +2608,10 @@ int k34_pileup(bgp_ctx* c) {
             // windows, lets it balance the ranges' unequal work at the tail (cfg3: 9.1 ms with 4096, 8.55 with 16384, the same with 65536)
             static const unsigned g_env = getenv("BGP_G_BLOCKS") ? (unsigned)atoi(getenv("BGP_G_BLOCKS")) : 0u;
             const unsigned g_blocks = std::min(65536u, g_env ? g_env : 16384u);
-            if (have_rows) hipLaunchKernelGGL(k4_acc2<true>, dim3((unsigned)std::min<uint64_t>(tile_base, g_blocks)), dim3(AT), (size_t)A2Lay::BYTES, c->stream, g);
-            else hipLaunchKernelGGL(k4_acc2<false>, dim3((unsigned)std::min<uint64_t>(tile_base, g_blocks)), dim3(AT), (size_t)A2Lay::BYTES, c->stream, g);
+            g.prow = use_rows ? c->d_prow.as<uint4>() : nullptr;
+            if (have_rows) hipLaunchKernelGGL((k4_acc2<true, false>), dim3((unsigned)std::min<uint64_t>(tile_base, g_blocks)), dim3(AT), (size_t)A2Lay::BYTES, c->stream, g);
+            else if (use_rows) hipLaunchKernelGGL((k4_acc2<false, true>), dim3((unsigned)std::min<uint64_t>(tile_base, g_blocks)), dim3(AT), (size_t)A2Lay::BYTES, c->stream, g);
+            else hipLaunchKernelGGL((k4_acc2<false, false>), dim3((unsigned)std::min<uint64_t>(tile_base, g_blocks)), dim3(AT), (size_t)A2Lay::BYTES, c->stream, g);
         }
         // windows the accumulate path left on the list (odd CIGARs, too deep): the general kernel
         const unsigned dgrid = (unsigned)std::min<uint64_t>(tile_base, 2048);

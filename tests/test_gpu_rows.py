@@ -1,0 +1,177 @@
+"""K4 behind the bench's decode route: k12_lds leaves a 16-byte PLAN ROW and a class byte per record (common.h: bgp_plan_row),
+k4_acc2<ROWS> takes a window's ordinary reads from those rows and k4_plan_rest plans only what is left (pileup.hip).  Every case
+stages through bgp_flush_decode (K0 + k12_lds), asserts that the rows route ran, and compares decode, columns and per-read entries
+with the oracle bit for bit (pileup.d:115-134,175-222,345-397)."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from biod_amd import _lib as L
+from biod_amd import bamio
+from biod_amd.pileup import Context
+from biod_amd.synth import host_stream, make_cfg
+
+from test_gpu_parity import FIXTURES, _random_stream, check_decode, check_pileup
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = Context(0)
+    yield c
+    c.close()
+
+
+def stage_rows(ctx, st, n_ref=0, need_lds=True):
+    """The bench's route: framing, then record table + arenas + plan rows in one kernel over LDS windows."""
+    ctx.reset()
+    if n_ref:
+        ctx.set_n_ref(n_ref)
+    ctx.push_inflated(st)
+    ctx.timing_enable(True); ctx.timing_reset()
+    ctx.flush(decode=L.BGP_FETCH_ALL)
+    assert not need_lds or ctx.timing_get()["k12_lds"]["launches"] == 1
+    return ctx
+
+
+def ran_rows(ctx):
+    tm = ctx.timing_get()
+    return "k4_plan_rest" in tm and tm["k4_plan_rest"]["launches"] > 0
+
+
+def run(ctx, st, entries=True, window=4096, n_ref=0, expect_rows=True):
+    stage_rows(ctx, st, n_ref)
+    check_decode(ctx, st)
+    info, ora = check_pileup(ctx, st, entries=entries, window=window)
+    assert ran_rows(ctx) == expect_rows
+    ctx.timing_enable(False)
+    return info, ora
+
+
+@pytest.mark.parametrize("name", [f for f in FIXTURES if f != "bins.bam"])
+def test_rows_fixtures(ctx, data_dir, name):
+    hdr, st = bamio.read_bam(os.path.join(data_dir, name))
+    stage_rows(ctx, st, len(hdr.refs), need_lds=False)      # (a file with long CIGARs takes the other decode kernels: no rows then)
+    check_decode(ctx, st)
+    check_pileup(ctx, st, entries=True)
+    ctx.timing_enable(False)
+
+
+def rec(name, seq_len, cigar, pos, rng, ref_id=0, flag=0):
+    seq = "".join("ACGTNRY="[int(x)] for x in rng.choice(8, size=seq_len, p=[0.24, 0.24, 0.24, 0.24, 0.01, 0.01, 0.01, 0.01]))
+    return bamio.pack_record(name, seq, cigar, ref_id=ref_id, pos=pos, flag=flag, qual=bytes(int(x) for x in rng.integers(2, 41, seq_len)))
+
+
+def test_rows_every_mould(ctx):
+    """One read of every shape the row takes or refuses, around a window boundary (positions 1000 .. 1300 of a run that starts at 0:
+    the windows are cut at 1024): one and two M runs, soft clips and insertions in front, between and behind, D and N between the runs
+    within and beyond the row's reach (256 positions), = and X, P and H, a trailing D, three runs, an unmapped read, a read of clips only."""
+    rng = np.random.default_rng(5)
+    shapes = [
+        (150, [(150, "M")]), (150, [(10, "S"), (140, "M")]), (150, [(3, "I"), (147, "M")]), (150, [(70, "M"), (5, "I"), (75, "M")]),
+        (150, [(70, "M"), (20, "D"), (80, "M")]), (150, [(70, "M"), (105, "D"), (80, "M")]), (150, [(70, "M"), (106, "D"), (80, "M")]),
+        (150, [(70, "M"), (107, "N"), (80, "M")]), (150, [(70, "M"), (3000, "N"), (80, "M")]), (150, [(60, "="), (90, "X")]),
+        (150, [(60, "M"), (2, "P"), (90, "M")]), (150, [(5, "H"), (150, "M"), (5, "H")]), (150, [(140, "M"), (10, "S")]),
+        (150, [(100, "M"), (5, "D")]), (150, [(50, "M"), (50, "M"), (50, "M")]), (150, [(50, "M"), (1, "D"), (50, "M"), (50, "M")]),
+        (255, [(255, "M")]), (255, [(170, "M"), (1, "I"), (84, "M")]), (255, [(127, "M"), (1, "D"), (128, "M")]),
+        (100, [(100, "S")]), (1, [(1, "M")]), (8, [(4, "M"), (2, "I"), (1, "D"), (2, "M")]), (150, [(70, "M"), (2, "I"), (3, "D"), (78, "M")]),
+        (150, [(70, "M"), (3, "D"), (2, "I"), (78, "M")]), (150, [(1, "M"), (149, "I")]), (200, [(150, "M")]), (100, [(150, "M")]),
+    ]
+    recs = [(0, rec("first", 150, [(150, "M")], 0, rng))]      # (the run starts at 0: its windows are cut at 1024, 2048, ...)
+    pos = 100
+    for rnd in range(36):
+        for k, (n, cig) in enumerate(shapes):
+            recs.append((pos, rec("s%d_%d" % (rnd, k), n, cig, pos, rng)))
+            pos += int(rng.integers(0, 4))
+        recs.append((pos, rec("u%d" % rnd, 50, [(50, "M")], pos, rng, flag=4)))
+    st = b"".join(b for _, b in recs)
+    run(ctx, st, entries=True, window=999)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_rows_random_cigars(ctx, seed):
+    rng = np.random.default_rng(4000 + seed)
+    st = _random_stream(rng, 600, quirks=seed % 2 == 1)
+    stage_rows(ctx, st)
+    check_decode(ctx, st)
+    try:
+        O.pileup(st, want_entries=False)
+    except O.OracleError as e:
+        assert e.code == O.ORC_ECIGAR
+        with pytest.raises(L.BiodGpuError) as g:
+            ctx.pileup_run()
+        assert g.value.code == L.BGP_ECIGAR
+        ctx.timing_enable(False)
+        return
+    check_pileup(ctx, st, entries=True, window=1021)
+    ctx.timing_enable(False)
+
+
+@pytest.mark.parametrize("profile,read_len,n_reads,ref_len", [(0, 150, 20000, 120_000), (1, 150, 30000, 150_000), (1, 100, 10000, 50_000),
+                                                              (0, 250, 8000, 80_000), (1, (170, 255), 8000, 80_000), (1, (240, 300), 6000, 80_000)])
+def test_rows_synthetic(ctx, profile, read_len, n_reads, ref_len):
+    cfg = make_cfg(n_reads=n_reads, n_ref=2, ref_len=ref_len, read_len=read_len, profile=profile, seed=11)
+    st = host_stream(cfg)
+    long_reads = not isinstance(read_len, int) and read_len[1] > 255      # (reads a SEG descriptor cannot hold: the stream is planned read by read, long reads walked from checkpoints)
+    info, ora = run(ctx, st, entries=False, expect_rows=not long_reads)
+    assert info.n_columns > 0
+
+
+@pytest.mark.parametrize("n_reads,ref_len,profile,read_len", [(8000, 12_000, 1, 150), (5000, 6_000, 0, 150), (14_000, 12_000, 1, 150), (9000, 12_000, 1, (200, 255)), (30000, 9_000, 1, 40)])
+def test_rows_deep_windows(ctx, n_reads, ref_len, profile, read_len):
+    """100- to 250-fold coverage: several rounds of rows a window, windows beyond the byte-wide counters handed to the general kernel
+    next to windows that are not; short reads at depth: more rows a window than bases a position."""
+    cfg = make_cfg(n_reads=n_reads, n_ref=1, ref_len=ref_len, read_len=read_len, profile=profile, seed=77 + n_reads)
+    st = host_stream(cfg)
+    info, ora = run(ctx, st, entries=False)
+    assert info.max_coverage > 90
+
+
+def test_rows_two_runs_of_pieces(ctx):
+    """Reads of 255 bases in two M runs (five pieces a read) at 120-fold coverage next to N-skip reads the planner takes: the rounds
+    that make the most pieces."""
+    rng = np.random.default_rng(21)
+    recs, pos = [], 3
+    for i in range(2600):
+        r = rng.random()
+        if r < 0.6:
+            a = int(rng.integers(165, 175)); cig = [(a, "M"), (1, "I"), (254 - a, "M")]; n = 255
+        elif r < 0.8:
+            a = int(rng.integers(100, 130)); cig = [(a, "M"), (int(rng.integers(300, 2000)), "N"), (250 - a, "M")]; n = 250
+        else:
+            sc = int(rng.integers(0, 5)); cig = ([(sc, "S")] if sc else []) + [(250 - sc, "M")]; n = 250
+        recs.append(rec("p%d" % i, n, cig, pos, rng))
+        pos += int(rng.integers(0, 5))
+    st = b"".join(recs)
+    info, ora = run(ctx, st, entries=False)
+    assert info.max_coverage > 100
+
+
+def test_rows_unsorted_stream_is_refused(ctx):
+    """A stream that is not coordinate sorted is an error whichever way K4 would have gone (makePileup's precondition, pileup.d:25-27):
+    a window's rows would no longer be a contiguous range of records."""
+    rng = np.random.default_rng(8)
+    recs = [rec("a%d" % i, 100, [(100, "M")], p, rng) for i, p in enumerate([10, 400, 30, 2000, 1500, 1800, 50])]
+    st = b"".join(recs)
+    stage_rows(ctx, st)
+    with pytest.raises(L.BiodGpuError) as g:
+        ctx.pileup_run()
+    assert g.value.code == L.BGP_EUNSORTED
+    ctx.timing_enable(False)
+
+
+def test_rows_islands_and_references(ctx):
+    """Runs that begin in the middle of nowhere (a window's first position is the run's, not a multiple of 1024), several references,
+    reads at position 0, a run shorter than the row's reach."""
+    rng = np.random.default_rng(13)
+    recs = []
+    for ref_id, starts in enumerate([[0, 0, 1, 5, 100, 1000, 1023, 1024, 1025, 1279, 1280, 2047, 2048], [70000, 70001, 70100, 200000, 200255, 200256, 200257, 201279, 201280], [5]]):
+        for j, p in enumerate(starts):
+            for k in range(3):
+                cig = [[(150, "M")], [(70, "M"), (20, "D"), (80, "M")], [(20, "S"), (60, "M"), (4, "I"), (66, "M")]][k]
+                recs.append(rec("i%d_%d_%d" % (ref_id, j, k), 150, cig, p, rng, ref_id=ref_id))
+    st = b"".join(recs)
+    run(ctx, st, entries=True, window=500, n_ref=3)
