@@ -190,6 +190,10 @@ def md_leg(ctx, cfg, cfg_name, info, n_reads, reps=3):
            "frac": round(alg / (k6_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if k6_ms else None, "reps": reps}
     try:
         out["prefix_vs_oracle"] = dict(IP.md_prefix_check(ctx, cfg, 20_000 if cfg_name != "cfg5" else 200), equal=True)
+        # ... and at the start of every contig (provider chains restart at a reference change, pileup.d:573-579): records 12.5 M, 25 M, ... of cfg3
+        per = IP.md_contig_prefix_check(ctx, cfg, 20_000 if cfg_name != "cfg5" else 200)
+        out["prefix_vs_oracle"]["contigs"] = per
+        out["prefix_vs_oracle"]["ranges"] = len(per)
     except AssertionError as e:
         out["prefix_vs_oracle"] = {"equal": False, "why": str(e)[:300]}
     return out
@@ -230,11 +234,27 @@ def entries_leg(ctx, cfg_name, n_reads, sum_lseq, sum_ncig, want_positions=4_000
 from biod_amd.checks import DevArray as _DevArray, full_size_invariants      # device-side identities of the result (no oracle)
 
 
+def rccl_libraries_mapped():
+    """Paths of the librccl objects mapped into this process (/proc/self/maps)."""
+    seen = []
+    try:
+        for ln in open("/proc/self/maps"):
+            f = ln.split()
+            if len(f) >= 6 and "librccl" in os.path.basename(f[5]) and f[5] not in seen:
+                seen.append(f[5])
+    except OSError:
+        pass
+    return seen
+
+
 def rccl_communicator(torch, dist, rank, world, dev):
     """An RCCL communicator of this script's own (the product takes it as a void*): rank 0's unique id goes round
     through torch.distributed, every rank joins with ncclCommInitRank."""
-    try:                   # the same library bgp_hist_reduce resolves at run time (api.cpp: librccl.so.1, then librccl.so)
-        rccl = C.CDLL("librccl.so.1", mode=C.RTLD_GLOBAL)
+    # ONE RCCL in the process: torch.distributed has mapped its own copy by now (torch/lib/librccl.so) -- this script's communicator and the
+    # product's ncclAllReduce (api.cpp: bgp_hist_reduce takes whichever librccl is mapped already) come from that very object
+    mapped = rccl_libraries_mapped()
+    try:
+        rccl = C.CDLL(mapped[0] if mapped else "librccl.so.1", mode=C.RTLD_GLOBAL)
     except OSError:
         rccl = C.CDLL("librccl.so", mode=C.RTLD_GLOBAL)
 
@@ -289,12 +309,27 @@ def main():
     dev = torch.device("cuda", local)
     rccl = comm = None
     with_comm = world > 1 or bool(os.environ.get("BGP_BENCH_FORCE_COMM"))    # (FORCE_COMM: the N > 1 code path on a one-GPU box, one-rank communicator)
+    # REHEARSAL of N > 1 on a box with fewer GPUs than ranks (RCCL refuses two ranks on one device): the ranks share the device, every
+    # rank runs the real kernels on its own shard, and this SCRIPT sums a host copy of the depth histogram over gloo in place of the
+    # product's bgp_hist_reduce.  Never a measurement of config 4 -- the line says so.
+    reduce_gloo = with_comm and (os.environ.get("BGP_BENCH_REDUCE", "") == "gloo" or (world > 1 and torch.cuda.device_count() < world))
     if with_comm:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if "MASTER_PORT" not in os.environ:
             s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); os.environ["MASTER_PORT"] = str(s_.getsockname()[1]); s_.close()
-        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)      # nccl = RCCL over xGMI
-        rccl, comm = rccl_communicator(torch, dist, rank, world, dev)
+        if reduce_gloo:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)      # nccl = RCCL over xGMI
+            rccl, comm = rccl_communicator(torch, dist, rank, world, dev)
+
+    def allred(x, op=None):
+        """all-reduce of a device tensor over the process group (through the host when the group is gloo)"""
+        op = op or dist.ReduceOp.SUM
+        if reduce_gloo:
+            y = x.cpu(); dist.all_reduce(y, op=op); x.copy_(y)
+        else:
+            dist.all_reduce(x, op=op)
 
     total_reads = a.reads or CONFIGS[a.config]["n_reads"]
     from biod_amd.shard import strong_cfg, weak_cfg
@@ -326,7 +361,9 @@ def main():
         ctx.flush(decode=L.BGP_FETCH_ALL)                          # K0 framing, then record table + seq/qual/cigar arenas in one kernel over LDS windows (BGP_LDS_DECODE=0: k1_rows, k2_unpack)
         ctx.decode_device(L.BGP_FETCH_ALL)                         # (the arenas are there already: hands out the pointers)
         info = ctx.pileup_run()                                    # K3 + K4 dense columns
-        if with_comm:                                              # the path's only exchange: whole-BAM depth histogram, RCCL over xGMI, in place
+        if with_comm and reduce_gloo:                              # (rehearsal: the same exchange by this script, through the host)
+            allred(torch.as_tensor(_DevArray(info.device_depth_hist, (L.BGP_DEPTH_BINS,), "<i8"), device=dev))
+        elif with_comm:                                            # the path's only exchange: whole-BAM depth histogram, RCCL over xGMI, in place
             L.check(L.lib().bgp_hist_reduce(ctx.handle, comm, C.c_void_p(info.device_depth_hist), L.BGP_DEPTH_BINS), ctx.handle)
         return info
 
@@ -350,7 +387,7 @@ def main():
     # ---- outside the timed region: what the ranks produced, checked
     checks = None
     if not a.no_checks:
-        checks = full_size_invariants(torch, dev, ctx, info, n_reads)
+        checks = full_size_invariants(torch, dev, ctx, info, n_reads, own_histogram=not (with_comm and world > 1))      # (N > 1: the histogram on the device is the job's by now, checked against the job's totals below)
     # the oracle on this rank's own shard (records are functions of (contig, index): every rank regenerates its ranges on the host)
     parity = None
     if not a.no_cpu_baseline or a.parity:
@@ -358,23 +395,25 @@ def main():
     hist_ok = None
     if with_comm:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        allred(t, dist.ReduceOp.MAX)
         dt = float(t.item())
-        tot = torch.tensor([info.n_columns, info.sum_coverage, n_reads, int(bool(checks is None or checks["ok"]))], dtype=torch.int64, device=dev)
-        dist.all_reduce(tot)
-        job_columns, job_cov, job_reads, n_ok = (int(x) for x in tot.tolist())
+        tot = torch.tensor([info.n_columns, info.sum_coverage, n_reads, int(bool(checks is None or checks["ok"])), int(info.n_positions)], dtype=torch.int64, device=dev)
+        allred(tot)
+        job_columns, job_cov, job_reads, n_ok, job_positions = (int(x) for x in tot.tolist())
         # the reduced histogram the product left behind == the sum of the ranks' own histograms (recomputed, summed by torch)
         reduced = torch.as_tensor(_DevArray(info.device_depth_hist, (L.BGP_DEPTH_BINS,), "<i8"), device=dev).clone()
         ctx.reset(); ctx.attach_device_stream(sptr, slen); ctx.flush()
         mine = torch.as_tensor(_DevArray(ctx.pileup_run().device_depth_hist, (L.BGP_DEPTH_BINS,), "<i8"), device=dev).clone()
-        dist.all_reduce(mine)
+        allred(mine)
         hist_ok = bool(torch.equal(mine, reduced)) and int(reduced.sum().item()) > 0
+        if int(info.max_coverage) < L.BGP_DEPTH_BINS - 1:      # the job's histogram against the job's totals: a position per count, the counts' weighted sum = the summed coverage
+            hist_ok = hist_ok and int(reduced.sum().item()) == job_positions and int((reduced * torch.arange(L.BGP_DEPTH_BINS, device=dev)).sum().item()) == job_cov
         if checks is not None:
             checks["ok_on_ranks"] = n_ok
             checks["ok"] = n_ok == world
         if parity is not None:
             pt = torch.tensor([int(parity["all_equal"]), parity["ranges"], parity["reads"], parity["positions"], parity["entries"]], dtype=torch.int64, device=dev)
-            dist.all_reduce(pt)
+            allred(pt)
             parity["all_equal_on_ranks"] = int(pt[0].item()); parity["all_equal"] = int(pt[0].item()) == world
             parity["ranges"], parity["reads"], parity["positions"], parity["entries"] = (int(x) for x in pt[1:].tolist())
             parity["checked"] = [f"(rank 0 of {world}) " + c_ for c_ in parity["checked"]]
@@ -435,6 +474,9 @@ def main():
             out["checks_full_size"] = checks
         if hist_ok is not None:
             out["hist_reduce_equals_sum_of_ranks"] = hist_ok
+            out["reduce"] = ("REHEARSAL: %d ranks on %d GPU(s), the histogram summed by bench.py over gloo through the host -- not a measurement of config 4" % (world, torch.cuda.device_count())) if reduce_gloo \
+                else "bgp_hist_reduce: ncclAllReduce on a communicator of this script's making"
+            out["rccl_libraries_mapped"] = rccl_libraries_mapped()
         if parity is not None:
             out["parity_interior"] = parity
         if world == 1 and not a.no_md:
@@ -456,7 +498,8 @@ def main():
             sys.exit(3)
     ctx.close()
     if with_comm:
-        rccl.ncclCommDestroy(comm)
+        if comm is not None:
+            rccl.ncclCommDestroy(comm)
         dist.destroy_process_group()
 
 

@@ -4,6 +4,7 @@
 #include "common.h"
 
 #include <dlfcn.h>
+#include <link.h>
 
 #include <algorithm>
 #include <cstdio>
@@ -639,7 +640,17 @@ int bgp_hist_reduce(bgp_ctx* c, void* comm, uint64_t* device_hist, size_t n) {
     typedef int (*allreduce_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
     static allreduce_fn fn = nullptr;
     if (!fn) {
-        void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        // The communicator is the caller's: ncclAllReduce has to come from the RCCL that made it.  A librccl the process has mapped already
+        // (the caller's -- e.g. torch/lib/librccl.so, whatever its soname) is taken as it is; only a process without one gets the system's.
+        struct Found { char path[4096]; int n; } found; found.path[0] = 0; found.n = 0;
+        dl_iterate_phdr([](struct dl_phdr_info* info, size_t, void* p) {
+            Found* f = (Found*)p;
+            const char* nm = info->dlpi_name;
+            const char* base = nm ? strrchr(nm, '/') : nullptr; base = base ? base + 1 : nm;
+            if (base && strstr(base, "librccl") && strlen(nm) < sizeof f->path) { if (!f->n) strcpy(f->path, nm); ++f->n; }
+            return 0; }, &found);
+        void* h = found.n ? dlopen(found.path, RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD) : nullptr;
+        if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
         if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
         if (!h) { c->last_error = "librccl not found"; return BGP_EDEVICE; }
         fn = (allreduce_fn)dlsym(h, "ncclAllReduce");

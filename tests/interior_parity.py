@@ -211,6 +211,41 @@ def md_prefix_check(ctx, cfg, count=20_000):
     return {"reads": count, "columns": int(len(poss))}
 
 
+def md_contig_prefix_check(ctx, cfg, count=20_000):
+    """The same at the start of EVERY contig of the stream (cfg3: records 0, 12.5 M, 25 M, ... -- reference_base bytes past 4 / 8 / 16 GiB
+    of stream): bam[contig] piled up by itself (bgp_pileup_begin_ref: the contig's reads are the whole input, so its provider chain begins
+    afresh, as PileupRangeUsingMdTag's does on a new range, pileup.d:573-579) against the oracle's sweep over the contig's first `count`
+    records generated on the host.  Returns one entry per contig; raises AssertionError on the first difference."""
+    n = ctx.num_records()
+    per = reads_per_contig(cfg)
+    out = []
+    for c in range(int(cfg.n_ref)):
+        s = c * per
+        if s >= n:
+            break
+        cnt = min(count, n - s - 1, per - 1)
+        if cnt < 2:
+            continue
+        st = host_stream(cfg, s, cnt + 1)
+        soa = O.decode_soa(st)
+        rid = int(soa.ref_id[0])
+        assert (soa.ref_id == rid).all()
+        hi_p = int(soa.pos[cnt])
+        ora = O.pileup(host_stream(cfg, s, cnt), use_md=True, skip_zero=True)
+        sel = (ora.ref == rid) & (ora.pos < hi_p)
+        poss, bases = [], []
+        for w in ctx.pileup_windows(L.BGP_MAKE_PILEUP, use_md_tag=True, ref_id=rid, start_from=0, end_at=hi_p, skip_zero_coverage=True, window_positions=1 << 20):
+            keep = w.columns["coverage"] > 0
+            poss.append((int(w.first_position) + np.arange(len(w.columns), dtype=np.int64))[keep]); bases.append(w.reference_base[keep])
+        poss = np.concatenate(poss) if poss else np.zeros(0, np.int64)
+        bases = np.concatenate(bases) if bases else np.zeros(0, np.uint8)
+        assert np.array_equal(poss, ora.pos[sel].astype(np.int64)), f"use_md_tag, contig {rid}: the columns visited"
+        bad = np.nonzero(bases != ora.refbase[sel])[0]
+        assert len(bad) == 0, f"contig {rid}: reference_base differs at {len(bad)} columns, first {int(poss[bad[0]])}: device {chr(bases[bad[0]])}, oracle {chr(ora.refbase[sel][bad[0]])}"
+        out.append({"contig": rid, "first_record": int(s), "reads": int(cnt), "columns": int(len(poss))})
+    return out
+
+
 def run(ctx, cfg, info, count, torch=None, dev=None, want=16, entries_on=(0, 5)):
     """All planned ranges; returns the summary bench.py prints as `parity_interior`."""
     plan = plan_ranges(ctx, cfg, info, count, torch, dev, want)

@@ -35,3 +35,42 @@ def test_bench_prints_one_json_line(force_comm):
     if force_comm:
         assert d["hist_reduce_equals_sum_of_ranks"] is True
         assert d["parity_interior"]["all_equal_on_ranks"] == 1
+
+
+def _one_json_line(p):
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    return json.loads(lines[0])
+
+
+def test_one_rank_communicator_uses_one_rccl():
+    """bench.py's communicator (ncclCommInitRank) and the product's ncclAllReduce must be the same RCCL: the process holds exactly one
+    librccl -- the one torch.distributed mapped -- when the N > 1 code path runs (here with one rank on the one GPU)."""
+    env = dict(os.environ); env["BGP_BENCH_FORCE_COMM"] = "1"; env.pop("BGP_BENCH_REDUCE", None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--reads", "200000", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-md"],
+                       env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    d = _one_json_line(p)
+    assert d["hist_reduce_equals_sum_of_ranks"] is True and d["reduce"].startswith("bgp_hist_reduce")
+    assert len(d["rccl_libraries_mapped"]) == 1, d["rccl_libraries_mapped"]
+
+
+def test_two_ranks_rehearsed_on_one_gpu():
+    """`bench.py --gpus 2` on a box with one GPU: spawn_ranks -> strong_cfg(rank, 2) -> the real kernels on both ranks' shards of ONE BAM
+    (split by contig; pileup.d:497-506: a rank's columns are its own contigs') -> interior parity against the oracle on every
+    rank -> the depth histogram summed over the ranks (by the script, over gloo: RCCL refuses two ranks on one device) equals the sum of
+    the recomputed ones.  A rehearsal of the N > 1 path, not a scaling measurement: the line says so."""
+    env = dict(os.environ); env.pop("BGP_BENCH_FORCE_COMM", None); env.pop("BGP_BENCH_REDUCE", None)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--reads", "2000000", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--parity", "--no-md"],
+                       env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    d = _one_json_line(p)
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
+    assert d["config"]["reads_per_gpu"] == 1_000_000
+    assert d["hist_reduce_equals_sum_of_ranks"] is True
+    assert d["parity_interior"]["all_equal"] is True and d["parity_interior"]["all_equal_on_ranks"] == 2
+    assert d["checks_full_size"]["ok"] is True and d["checks_full_size"]["ok_on_ranks"] == 2
+    import torch
+    if torch.cuda.device_count() < 2:
+        assert d["reduce"].startswith("REHEARSAL")

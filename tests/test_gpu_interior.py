@@ -69,3 +69,6 @@ def test_full_size_interior_parity(ctx, name):
     res = IP.run(ctx, cfg, info, 20_000 if name != "cfg5" else 200, torch, torch.device("cuda", 0), want=16)
     assert res["all_equal"], res["failed"]
     assert res["ranges"] >= 16 and res["entries"] > 0, res
+    # use_md_tag against the oracle at the start of every contig (reference_base far into the stream, a provider chain per reference)
+    per = IP.md_contig_prefix_check(ctx, cfg, 20_000 if name != "cfg5" else 200)
+    assert len(per) == int(cfg.n_ref) and all(e["columns"] > 0 for e in per), per
