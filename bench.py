@@ -90,6 +90,8 @@ def parse():
     ap.add_argument("--no-checks", action="store_true", help="skip the full-size invariants after the timed region")
     ap.add_argument("--parity", action="store_true", help="the oracle's interior-shard check even with --no-cpu-baseline (it is on by default otherwise)")
     ap.add_argument("--no-md", action="store_true", help="skip the use_md_tag leg (reference_base from MD tags, what examples/make_pileup.d:16 asks for) after the timed region")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end legs after the timed region (device-E2E from host memory through batched staging; file-E2E from a BGZF file through the device inflate)")
+    ap.add_argument("--e2e-reads", type=int, default=0, help="reads of the end-to-end legs' input (0 = 10 M, or the workload's own size if that is smaller)")
     ap.add_argument("--weak", action="store_true", help="weak scaling: every rank gets a full --reads-sized shard of its own contigs (default: strong, ONE BAM split by contig)")
     ap.add_argument("--strong", action="store_true", help="(default) kept for older command lines")
     return ap.parse_args()
@@ -488,6 +490,17 @@ def main():
             e["algorithmic_GBps"] = round(e["algorithmic_bytes"] / (e["k5_ms"] * 1e-3) / 1e9, 1) if e["k5_ms"] else None
             e["frac"] = round(e["algorithmic_GBps"] / HBM_PEAK_GBPS, 4) if e["k5_ms"] else None
             out["entries_path"] = e
+        if world == 1 and not a.no_e2e and a.config != "cfg5":
+            # the same path fed from host memory and from a file -- PCIe- and inflate-inclusive, labelled, never `value`.
+            import bench_e2e
+            from biod_amd.synth import host_stream_np
+            n_e2e = min(a.e2e_reads or 10_000_000, total_reads)
+            ctx.reset()
+            cfg_e = scaled(a.config, n_e2e)
+            st_e = host_stream_np(cfg_e)
+            out["e2e"] = {"note": "input NOT resident in HBM: PCIe-inclusive (device_e2e) and inflate-inclusive (file_e2e) rates of the same hot path on %d reads of %s's model; the headline `value` is kernel-only" % (n_e2e, a.config),
+                          "device_e2e": bench_e2e.device_e2e(ctx, st_e, n_e2e), "file_e2e": bench_e2e.file_e2e(ctx, st_e, n_e2e, int(cfg_e.n_ref))}
+            del st_e
         if not a.no_cpu_baseline:                                       # (rank 0's host cores, whatever the number of ranks)
             out["cpu_baseline"] = cpu_baseline(a.config, a.cpu_sample_reads)
             out["speedup_vs_cpu_baseline"] = round(out["value"] / out["cpu_baseline"]["value"], 1)

@@ -1,0 +1,129 @@
+"""bench.py's end-to-end legs (SURVEY 8(d) ii and iii), measured in the bench's own process AFTER its timed region and reported
+beside the headline, never as `value`: the input crosses PCIe here (and, for the file, is inflated first).
+
+  device_e2e   inflated records in host memory -> pinned staging -> HBM -> K0..K4 per batch -> the windows of columns handed
+               out (bgp_batch_acquire / _commit / _next_window: what BioD's BgzfInputStream hands BamReadRange, inputstream.d:386-447,
+               taken a batch at a time).  The consumer takes every window and reads nothing: the link and the kernels, not Python.
+  file_e2e     a BGZF-compressed BAM file on disk -> HBM compressed -> k_inflate -> K0..K4 (bgp_load_bam_device + bgp_flush +
+               bgp_pileup_run): block.d:127-216 and everything behind it on the device.
+
+Raw ctypes calls: the Python facade's copies would be the slowest thing measured.
+"""
+import ctypes as C
+import os
+import time
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+
+from biod_amd import _lib as L
+from biod_amd import bamio
+
+
+def device_e2e(ctx, st, n_reads, batch_bytes=256 << 20, producers=16, reps=3):
+    lib, h = L.lib(), ctx.handle
+    pool = ThreadPoolExecutor(producers)
+
+    def take_one(stats):
+        cw = L.Columns()
+        rc = L.check(lib.bgp_batch_next_window(h, C.byref(cw)), h)
+        if rc == L.BGP_OK:
+            stats[0] += cw.n_positions
+        return rc
+
+    def run():
+        """a window and a buffer in turn: as soon as a window of batch i + 1 has come the next pinned buffer is acquired (which ships the
+        full one), so the copy in of batch i + 2 runs beside the kernels and the copies back of batch i + 1"""
+        t0 = time.perf_counter()
+        stats = [0]
+        L.check(lib.bgp_batch_begin(h, batch_bytes, 0, 1 << 22), h)
+        off, futs, m = 0, None, 0
+        while off < len(st) or futs is not None:
+            progressed = False
+            if futs is None and off < len(st):
+                ptr, cap = C.c_void_p(), C.c_size_t()
+                rc = L.check(lib.bgp_batch_acquire(h, C.byref(ptr), C.byref(cap)), h)
+                if rc == L.BGP_OK:
+                    m = min(cap.value, len(st) - off)
+                    dst = np.ctypeslib.as_array(C.cast(ptr.value, C.POINTER(C.c_uint8)), shape=(m,))
+                    src = st[off:off + m]
+                    step = -(-m // producers)
+                    futs = [pool.submit(np.copyto, dst[k * step:min(m, (k + 1) * step)], src[k * step:min(m, (k + 1) * step)]) for k in range(producers)]
+                    progressed = True
+            if futs is not None and all(f.done() for f in futs):
+                for f in futs:
+                    f.result()
+                L.check(lib.bgp_batch_commit(h, m), h)
+                off += m; futs = None
+                continue
+            if take_one(stats) == L.BGP_OK:
+                progressed = True
+            if not progressed and futs is not None:
+                for f in futs:
+                    f.result()
+        L.check(lib.bgp_batch_end(h), h)
+        while take_one(stats) == L.BGP_OK:
+            pass
+        return time.perf_counter() - t0, stats[0]
+
+    ctx.reset()
+    times, positions = [], 0
+    for _ in range(reps):
+        dt, positions = run()
+        times.append(dt)
+        ctx.reset()
+    # the critical path of a batch from HIP events on the streams the work runs on (bgp_timing_*)
+    ctx.timing_enable(True); ctx.timing_reset()
+    dt_t, _ = run()
+    tm = ctx.timing_get()
+    ctx.timing_enable(False)
+    ctx.reset()
+    pool.shutdown(wait=True)
+    nb = max(1, tm.get("h2d_batch", {}).get("launches", 1))
+    per = lambda pre: round(sum(v["total_ms"] for k, v in tm.items() if k.startswith(pre)) / nb, 3)      # noqa: E731
+    best = min(times)
+    return {"what": "inflated records in host memory -> bgp_batch_acquire/commit -> HBM -> K0..K4 per batch -> windows of columns handed out (a window and a buffer in turn; the consumer takes the windows, reads nothing)",
+            "reads": int(n_reads), "inflated_bytes": int(len(st)), "batch_bytes": int(batch_bytes), "producer_threads": producers,
+            "Mreads_per_s": round(n_reads / best / 1e6, 1), "input_GBps": round(len(st) / best / 1e9, 1), "best_s": round(best, 4), "runs_s": [round(t, 4) for t in times],
+            "columns_back_bytes": int(positions) * 32,
+            "per_batch_ms_hip_events": {"batches": nb, "h2d_batch": per("h2d_batch"), "d2d_carry": per("d2d_carry"), "K0 framing": per("k0_"), "K1 record table": per("k1_"), "K3 keys": per("k3_"),
+                                        "K4 columns": per("k4_"), "d2h windows": per("d2h"), "wall": round(dt_t / nb * 1e3, 3)}}
+
+
+def write_bam(path, st, n_ref, threads=32, block=64000):
+    """The stream as a BGZF file (writer.d:260: blocks of up to 64 KB, the EOF block at the end)."""
+    b = memoryview(st)
+    with open(path, "wb") as f, ThreadPoolExecutor(threads) as ex:
+        f.write(bamio.bgzf_block(bamio.bam_header_bytes([(f"chr{i + 1}", 1 << 28) for i in range(max(1, n_ref))])))
+        for blk in ex.map(lambda at: bamio.bgzf_block(bytes(b[at:at + block])), range(0, len(b), block)):
+            f.write(blk)
+        f.write(bamio.BGZF_EOF)
+    return os.path.getsize(path)
+
+
+def file_e2e(ctx, st, n_reads, n_ref, path="/tmp/bench_e2e.bam", reps=4):
+    t0 = time.perf_counter()
+    fsz = write_bam(path, st, n_ref)
+    t_write = time.perf_counter() - t0
+    rows = []
+    info = None
+    for rep in range(reps):
+        ctx.reset()
+        ctx.timing_enable(rep == reps - 1); ctx.timing_reset()
+        t0 = time.perf_counter(); ctx.load_bam_device(path); t1 = time.perf_counter()
+        ctx.flush(); t2 = time.perf_counter()
+        info = ctx.pileup_run(); t3 = time.perf_counter()
+        rows.append((t3 - t0, t1 - t0, t2 - t1, t3 - t2))
+    ctx.timing_enable(False)
+    ctx.reset()
+    try:
+        os.unlink(path)
+    except OSError:
+        pass
+    warm = sorted(rows[1:]) if len(rows) > 1 else rows      # (a ctx's first load also makes its streams and pins its ring)
+    best = warm[0]
+    return {"what": "BGZF BAM file -> HBM compressed -> k_inflate -> K0 framing, record table, K3, K4 (bgp_load_bam_device + bgp_flush + bgp_pileup_run)",
+            "reads": int(n_reads), "file_bytes": int(fsz), "inflated_bytes": int(len(st)), "columns": int(info.n_columns),
+            "Mreads_per_s": round(n_reads / best[0] / 1e6, 1), "file_GBps": round(fsz / best[0] / 1e9, 2), "inflated_GBps": round(len(st) / best[0] / 1e9, 1),
+            "best_s": {"total": round(best[0], 4), "load (read + upload + inflate)": round(best[1], 4), "flush (framing + table)": round(best[2], 4), "pileup": round(best[3], 4)},
+            "first_load_s": round(rows[0][0], 4), "runs_s": [round(r[0], 4) for r in rows], "file_written_s": round(t_write, 1)}

@@ -307,6 +307,7 @@ int bgp_push_inflated(bgp_ctx* c, const uint8_t* data, size_t len, uint64_t coff
     // boundaries are found and verified on the device (frame.hip); the hint only tells the guesser where to look first
     if (first_record_uoffset != BGP_UOFFSET_UNKNOWN && first_record_uoffset < len) c->hints.push_back(c->h_stage_len + first_record_uoffset);
     c->bai_buildable = false;
+    if (!c->h_stage_len) batch_unpark(c);
     BGP_TRY(c->h_stage.reserve_keep(c->h_stage_len + len, c->h_stage_len));
     bgp_staged_copy(c->h_stage.as<uint8_t>() + c->h_stage_len, data, len);
     c->h_stage_len += len;
@@ -504,6 +505,16 @@ static int pileup_begin_impl(bgp_ctx* c, int mode, int32_t one_ref, int use_md_t
                 }
             }
         }
+        if (want_entries && c->pinfo.n_positions) {
+            // The window's pinned host buffers are made HERE, by the stream's average depth and a third more (a deeper window still grows
+            // them): pinning gigabytes takes a quarter of a second (12 GB/s), and that used to be the first bgp_pileup_next_window's.
+            const uint64_t np = std::min<uint64_t>(it.window, c->pinfo.n_positions);
+            const double depth = (double)c->pinfo.sum_coverage / (double)c->pinfo.n_positions;
+            const uint64_t ne = (uint64_t)((double)np * depth * 1.34) + 4096;
+            BGP_TRY(c->h_cols.reserve(np * sizeof(bgp_column)));
+            BGP_TRY(c->h_entry_off.reserve((np + 1) * 8));
+            if (ne * sizeof(bgp_entry) <= (8ull << 30)) BGP_TRY(c->h_entries.reserve(ne * sizeof(bgp_entry)));
+        }
     }
     return BGP_OK;
 }
@@ -697,6 +708,7 @@ int bgp_synth_device(bgp_ctx* c, const bgp_synth_cfg_c* cfg, uint64_t* bytes) {
     if (!c || !cfg) return BGP_EINVAL;
     if (c->flushed || c->h_stage_len) return BGP_ESTATE;
     BGP_HIP(hipSetDevice(c->device));
+    batch_unpark(c);
     return synth_device(c, cfg, bytes);
     BGP_API_CATCH(c)
 }
@@ -705,6 +717,7 @@ int bgp_load_bam(bgp_ctx* c, const char* path, int n_threads) {
     BGP_API_TRY
     if (!c || !path) return BGP_EINVAL;
     if (c->flushed || c->stream_on_device) return BGP_ESTATE;
+    batch_unpark(c);
     return bgzf_load_bam(c, path, n_threads);
     BGP_API_CATCH(c)
 }
@@ -713,6 +726,7 @@ int bgp_load_bam_device(bgp_ctx* c, const char* path) {
     if (!c || !path) return BGP_EINVAL;
     if (c->flushed || c->stream_on_device || c->h_stage_len) return BGP_ESTATE;
     BGP_HIP(hipSetDevice(c->device));
+    batch_unpark(c);
     return bgzf_load_bam_device(c, path);
     BGP_API_CATCH(c)
 }
@@ -726,6 +740,7 @@ int bgp_load_bam_region(bgp_ctx* c, const char* path, bgp_bai* bai, int32_t ref_
     const bgp_chunk* ch = nullptr; uint32_t n = 0;
     const int rc = bgp_bai_chunks(bai, ref_id, beg, end, &ch, &n);
     if (rc < 0) { c->last_error = "Invalid reference sequence index"; return rc; }                   // randomaccessmanager.d:205-207
+    batch_unpark(c);
     BGP_TRY(bai_stage_chunks(c, path, ch, n, n_threads));
     c->bai_buildable = false;
     c->region_pending = true; c->region_ref = (uint32_t)ref_id; c->region_beg = beg; c->region_end = end;
@@ -748,6 +763,7 @@ int bgp_load_bam_read_at(bgp_ctx* c, const char* path, uint64_t voffset) {
     if (c->flushed || c->stream_on_device) return BGP_ESTATE;
     if (c->refs.empty()) BGP_TRY(bai_load_header(c, path));
     c->bai_buildable = false;
+    batch_unpark(c);
     return bai_stage_read_at(c, path, voffset);
     BGP_API_CATCH(c)
 }

@@ -48,6 +48,14 @@ struct Batch {
     struct { bool have = false; uint64_t P_ord = 0, i_ord = 0; uint32_t ci = 0, y = 0, ce = 0; int32_t ref = -1; } md;
 };
 
+// The pinned and device buffers a finished batched pass left in the ctx (for the next bgp_batch_begin) are given back as soon as the ctx
+// stages a stream any other way: a one-shot load then finds the pinned host memory and the HBM it had before batches were ever used.
+void batch_unpark(bgp_ctx* c) {
+    if (c->batch) return;
+    for (auto& h : c->h_batch) h.release();
+    for (auto& d : c->d_batch) d.release();
+}
+
 void batch_release(bgp_ctx* c) {
     Batch* b = c->batch;
     if (!b) return;

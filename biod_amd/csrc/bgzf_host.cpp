@@ -254,8 +254,8 @@ int bgzf_load_bam_device(bgp_ctx* c, const char* path) {
     // ratio and a third more, a block per 2 KB -- and a file that outgrows either is inflated the old way, in one launch at the end.
     std::vector<hipEvent_t> ev(n_chunks, nullptr);
     std::unique_ptr<std::atomic<int>[]> ev_ready(new std::atomic<int>[n_chunks]);
-    for (uint64_t k = 0; k < n_chunks; ++k) { ev_ready[k].store(0); if (hipEventCreateWithFlags(&ev[k], hipEventDisableTiming) != hipSuccess) { c->last_error = "hipEventCreate failed"; return BGP_EDEVICE; } }
-    struct Events { std::vector<hipEvent_t>& e; ~Events() { for (hipEvent_t x : e) if (x) (void)hipEventDestroy(x); } } events_guard{ev};
+    struct Events { std::vector<hipEvent_t>& e; ~Events() { for (hipEvent_t x : e) if (x) (void)hipEventDestroy(x); } } events_guard{ev};      // (in front of the loop that makes them: an early return inside it lets go of the ones made so far)
+    for (uint64_t k = 0; k < n_chunks; ++k) { ev_ready[k].store(0); if (hipEventCreateWithFlags(&ev[k], hipEventDisableTiming) != hipSuccess) { ev[k] = nullptr; c->last_error = "hipEventCreate failed"; return BGP_EDEVICE; } }
     // ONE stream for all uploads and one for the inflate (the ctx keeps them): a stream per reader and four for the batches were more
     // streams than the device has hardware queues, and an upload that shared a queue with a running k_inflate waited for it to end --
     // the uploads stalled for the 50 ms of the first batch; creating a dozen streams also took the load's first 25 ms.
@@ -345,7 +345,7 @@ int bgzf_load_bam_device(bgp_ctx* c, const char* path) {
                         const double ratio = (double)(lb.uoff + lb.isize) / (double)std::max<uint64_t>(1, lb.coff + lb.cdata_off + lb.cdata_len + 8);
                         est_bytes = (uint64_t)((double)fsz * ratio * 1.34) + (64ull << 20);
                     }
-                    if (c->d_stream_own.reserve(SLACK + est_bytes + 256) != BGP_OK || c->d_inf_blk.reserve(nb_cap * (sizeof(bgp_inflate_block) + 4) + 64) != BGP_OK) fallback = true;
+                    if (c->d_stream_own.reserve(SLACK + est_bytes + 256) != BGP_OK || c->d_inf_blk.reserve(nb_cap * (sizeof(bgp_inflate_block) + 4) + 64) != BGP_OK) { fallback = true; (void)hipGetLastError(); }      // (the estimate did not fit: the failed hipMalloc's error must not be what the next launch check reads)
                     else d_status = (int32_t*)(c->d_inf_blk.as<uint8_t>() + nb_cap * sizeof(bgp_inflate_block));
                 }
             }

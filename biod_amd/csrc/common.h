@@ -58,8 +58,12 @@ struct HostBuf {                      // pinned host memory
     int reserve(size_t bytes) {
         if (bytes <= cap) return BGP_OK;
         void* np = nullptr;
+        // geometric: a buffer that replaces one is at least twice its size, so the retired generations together stay below the live
+        // one's size -- and they can all be kept until bgp_reset (retire below), as include/biodgpu.h promises
         size_t want = bytes + (bytes >> 3) + 4096;
+        if (p && want < 2 * cap) want = 2 * cap;
         hipError_t e = hipHostMalloc(&np, want, hipHostMallocDefault);
+        if (e != hipSuccess && want > bytes + (bytes >> 3) + 4096) { (void)hipGetLastError(); want = bytes + (bytes >> 3) + 4096; e = hipHostMalloc(&np, want, hipHostMallocDefault); }      // (pinned memory is short: what is needed, no more)
         if (e != hipSuccess) { bgp_note_hip_error(e, "hipHostMalloc", __FILE__, __LINE__); return BGP_ENOMEM; }
         if (p) retire(p);
         p = np; cap = want;
@@ -75,9 +79,9 @@ struct HostBuf {                      // pinned host memory
         p = np; cap = want;
         return BGP_OK;
     }
-    // (one generation is kept: a view is promised to live until the next call of the same kind, and that call is the one that retires
-    // its buffer -- older ones are nobody's; a window that grows a ninth at a time would otherwise keep ~9 x its final size pinned)
-    void retire(void* q) { for (void* o : retired) (void)hipHostFree(o); retired.clear(); try { retired.push_back(q); } catch (...) { (void)hipHostFree(q); } }
+    // Every retired generation lives until trim() (bgp_reset) / release(): "a pointer kept too long reads stale bytes, never freed memory"
+    // (include/biodgpu.h).  Growth is geometric (reserve above), so they add up to less than the live buffer.
+    void retire(void* q) { try { retired.push_back(q); } catch (...) { /* (no room for the note: the buffer stays mapped until the process ends rather than under a caller's view) */ } }
     void trim() { for (void* q : retired) (void)hipHostFree(q); retired.clear(); }       // bgp_reset: every iteration over the old results is over
     void release() { trim(); if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
     template <class T> T* as() const { return (T*)p; }
@@ -254,6 +258,7 @@ int emit_window(bgp_ctx* c, uint32_t run, uint64_t a, uint64_t b, int want_entri
 int emit_gap_window(bgp_ctx* c, int32_t ref_id, uint64_t a, uint64_t b, int want_entries, int use_md, int snp, int maq, bgp_columns* o);   // api.cpp: an uncovered stretch between two runs of a reference
 int batch_cut(bgp_ctx* c, uint64_t* last_key, uint64_t* carry_record, uint64_t* carry_off);   // pileup.hip: last covering read of the staged stream and where its exact halo starts
 void batch_release(bgp_ctx* c);   // batch.cpp
+void batch_unpark(bgp_ctx* c);    // batch.cpp: a non-batched staging path begins -- the buffers a batched pass parked in the ctx go back to the system
 void bgp_staged_copy(uint8_t* dst, const uint8_t* src, uint64_t n);   // batch.cpp: memcpy into pinned staging, large copies over a few threads
 int flush_core(bgp_ctx* c, uint32_t what = 0);        // api.cpp: framing + record table (+ the arenas of `what`) of the stream c->d_stream points at   // chunks.hip : fills c->chunks         // bai_build.hip : createIndex over the staged file
 

@@ -599,16 +599,19 @@ int k0_frame(bgp_ctx* c) {
     }
     uint64_t rounds = 0;
     uint32_t n_list = 0;                 // the segments of a repair round, when they are few enough to be listed and small enough for LDS
+    // k0_rechase keeps a segment and a ninth more in LDS -- beyond the 64 KiB a kernel gets without asking: whether the device grants that is
+    // asked ONCE per framing (a refusal used to be swallowed round after round, with k0_chase's time booked under k0_rechase's name)
+    const size_t rechase_lds = (((size_t)seg + 96 + 15) & ~(size_t)15) + 4 * ((size_t)seg / 36 + 2) + 16;
+    bool rechase_ok = seg <= (128u << 10);
+    if (rechase_ok && rechase_lds > (48u << 10)) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k0_rechase), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rechase_lds) != hipSuccess) { (void)hipGetLastError(); rechase_ok = false; }
+    }
     for (;;) {
         {
-            TimedRegion t(c, n_list ? "k0_rechase" : "k0_chase", 0);
-            bool listed = false;
-            if (n_list) {      // (the window in LDS is the segment and a ninth more -- beyond the 64 KiB a kernel gets without asking, and only there on gfx950:
-                               // a launch that fails leaves dirty[] as it is, and the round falls to k0_chase, which takes every dirty segment)
-                hipLaunchKernelGGL(k0_rechase, dim3(n_list), dim3(256), (((size_t)seg + 96 + 15) & ~(size_t)15) + 4 * ((size_t)seg / 36 + 2) + 16, c->stream, a, a.list, n_list);
-                listed = hipGetLastError() == hipSuccess;
-            }
-            if (!listed) { hipLaunchKernelGGL(k0_chase, dim3(lane_blocks), dim3(256), 0, c->stream, a); BGP_HIP(hipGetLastError()); }
+            const bool listed = n_list != 0 && rechase_ok;
+            TimedRegion t(c, listed ? "k0_rechase" : "k0_chase", 0);
+            if (listed) { hipLaunchKernelGGL(k0_rechase, dim3(n_list), dim3(256), rechase_lds, c->stream, a, a.list, n_list); BGP_HIP(hipGetLastError()); }
+            else { hipLaunchKernelGGL(k0_chase, dim3(lane_blocks), dim3(256), 0, c->stream, a); BGP_HIP(hipGetLastError()); }
         }
         BGP_HIP(hipMemsetAsync(a.status + 1, 0, 4, c->stream));
         hipLaunchKernelGGL(k0_verify, dim3(lane_blocks), dim3(256), 0, c->stream, a);

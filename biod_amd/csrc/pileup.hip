@@ -1319,6 +1319,7 @@ struct GArgs {
     const uint8_t* s; const unsigned long long* slab; uint32_t slab_cap; const uint32_t* wcount; const int32_t* wdel; const TileB* tiles; uint64_t n_tiles;
     bgp_column* cols; unsigned long long* hist; unsigned long long* tile_stats; uint32_t* deep; uint32_t* n_deep;
     const uint32_t* wlong; const bgp_record* rec; const uint64_t* ck_off; const Ckpt* ck;      // long reads (null: none): windows they touch, the record table, their per-window checkpoints
+    uint64_t stream_len;
     const uint4* prow;                            // ROWS: the records' plan rows (k12_lds; common.h: bgp_plan_row); a window's are [tiles[w].i_lo, i_hi)
 };
 
@@ -1463,11 +1464,16 @@ __device__ __forceinline__ void acc2_work(const A2Batch& b, uint32_t* cbase0) {
 // in flight per wave -- a piece's bases arrive while the two before it are accumulated.
 constexpr int P_CHS = 3;
 struct A2Small { uint4 q0; uint32_t eh, par; };
-__device__ __forceinline__ A2Small acc2_load_small(const uint8_t* s, unsigned long long e) {
+__device__ __forceinline__ A2Small acc2_load_small(const uint8_t* s, uint64_t stream_len, unsigned long long e) {
     A2Small b;
-    const uint64_t no = e & ((1ull << 42) - 1);
+    const uint64_t no = e & ((1ull << 42) - 1), bo = no >> 1;
     b.eh = (uint32_t)(e >> 32); b.par = (uint32_t)no & 1u;
-    __builtin_memcpy(&b.q0, s + (no >> 1), 16);
+    if (bo + 16 <= stream_len) __builtin_memcpy(&b.q0, s + bo, 16);
+    else {                                          // the stream's last few bases (a long read without tags behind its QUAL... or an attached buffer of exactly `len` bytes): byte by byte, nothing behind the end
+        uint32_t w[4] = {0u, 0u, 0u, 0u};
+        for (uint32_t k = 0; k < 16u && bo + k < stream_len; ++k) w[k >> 2] |= (uint32_t)s[bo + k] << (8u * (k & 3u));
+        b.q0 = make_uint4(w[0], w[1], w[2], w[3]);
+    }
     return b;
 }
 __device__ __forceinline__ void acc2_work_small(const A2Small& b, uint32_t* cbase0) {
@@ -1816,7 +1822,7 @@ template <bool LONG, bool ROWS> __global__ __launch_bounds__(AT, BGP_ACC2_MINW) 
                             __builtin_amdgcn_wave_barrier();
                             for (uint32_t b0 = 0; b0 < tot; b0 += 64) {
                                 const unsigned long long en = b0 + (uint32_t)lane < tot ? pcs[b0 + (uint32_t)lane] : 0ull;
-                                const A2Small bt = acc2_load_small(a.s, en);
+                                const A2Small bt = acc2_load_small(a.s, a.stream_len, en);
                                 acc2_work_small(pn0, cbase0);
                                 pn0 = pn1; pn1 = bt;
                             }
@@ -2608,7 +2614,7 @@ int k34_pileup(bgp_ctx* c) {
             // windows, lets it balance the ranges' unequal work at the tail (cfg3: 9.1 ms with 4096, 8.55 with 16384, the same with 65536)
             static const unsigned g_env = getenv("BGP_G_BLOCKS") ? (unsigned)atoi(getenv("BGP_G_BLOCKS")) : 0u;
             const unsigned g_blocks = std::min(65536u, g_env ? g_env : 16384u);
-            g.prow = use_rows ? c->d_prow.as<uint4>() : nullptr;
+            g.prow = use_rows ? c->d_prow.as<uint4>() : nullptr; g.stream_len = a.stream_len;
             if (have_rows) hipLaunchKernelGGL((k4_acc2<true, false>), dim3((unsigned)std::min<uint64_t>(tile_base, g_blocks)), dim3(AT), (size_t)A2Lay::BYTES, c->stream, g);
             else if (use_rows) hipLaunchKernelGGL((k4_acc2<false, true>), dim3((unsigned)std::min<uint64_t>(tile_base, g_blocks)), dim3(AT), (size_t)A2Lay::BYTES, c->stream, g);
             else hipLaunchKernelGGL((k4_acc2<false, false>), dim3((unsigned)std::min<uint64_t>(tile_base, g_blocks)), dim3(AT), (size_t)A2Lay::BYTES, c->stream, g);

@@ -4,7 +4,7 @@ A=$1; B=$2; shift 2
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R; mkdir -p gpurun_out
 for rep in 1 2; do for V in A B; do
   if [ $V = A ]; then E="$A"; else E="$B"; fi
-  env $E python bench.py --no-cpu-baseline --no-checks --no-md --steps 10 --warmup 2 "$@" > gpurun_out/ab_$V$rep.json 2> gpurun_out/ab_$V$rep.err
+  env $E python bench.py --no-cpu-baseline --no-checks --no-md --no-e2e --steps 10 --warmup 2 "$@" > gpurun_out/ab_$V$rep.json 2> gpurun_out/ab_$V$rep.err
   python - gpurun_out/ab_$V$rep.json "$V$rep [$E]" <<'PY'
 import json, sys
 try:

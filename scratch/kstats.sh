@@ -5,7 +5,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 export TMPDIR=/tmp
 cd /tmp
 rm -rf /tmp/ks_$TAG
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks_$TAG -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-checks --no-md "$@" > $R/gpurun_out/${TAG}_bench.json 2> $R/gpurun_out/${TAG}_bench.err
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks_$TAG -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-checks --no-md --no-e2e "$@" > $R/gpurun_out/${TAG}_bench.json 2> $R/gpurun_out/${TAG}_bench.err
 F=$(find /tmp/ks_$TAG -name '*kernel_stats.csv' | head -1)
 python - "$F" > $R/gpurun_out/${TAG}_kstats.txt <<'PY'
 import csv, sys, re

@@ -13,7 +13,7 @@ export TMPDIR=/tmp
 pmc() {   # config reads
   cd /tmp
   for C in FETCH_SIZE WRITE_SIZE; do
-    timeout 600 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/$1_$C -- python $R/bench.py --config $1 --steps 1 --warmup 0 --no-cpu-baseline --no-checks --no-md > $OUT/$1_$C.log 2>&1
+    timeout 600 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/$1_$C -- python $R/bench.py --config $1 --steps 1 --warmup 0 --no-cpu-baseline --no-checks --no-md --no-e2e > $OUT/$1_$C.log 2>&1
   done
   cd $R
   CFG=$1 READS=$2 TAG=$TAG python - <<'PY'
