@@ -13,9 +13,11 @@
 
     Same function names, parameter lists and defaults as bio/std/hts/bam/pileup.d:683-687 (makePileup), :509
     (pileupColumns) and :1011-1012 (pileupChunks); the column type has PileupColumn's properties (pileup.d:236-290) and
-    `column.reads[k]` has PileupRead's (pileup.d:86-230) plus the BamRead accessors BioD's consumers use through
-    `alias _read this` (examples/read_bam_file.d:33-41, snpcallers/simple.d:24-28, snpcallers/maq.d:396-412): name,
-    sequence, base_qualities, cigar, position, ref_id, mapping_quality, is_reverse_strand.  Every column is computed by the
+    `column.reads[k]` has PileupRead's (pileup.d:86-230) and, as PileupRead does (`alias read this`, pileup.d:89), IS a
+    BioD read: an EagerBamRead over the host copy of the record's bytes (read.d:482,1380-1383), so everything a consumer
+    asks of it (examples/read_bam_file.d:33-41, snpcallers/simple.d:24-28, snpcallers/maq.d:396-412: name, sequence,
+    base_qualities, cigar, position, ref_id, mapping_quality, is_reverse_strand; tags: read["RG"], read.d:1070-1087) is
+    answered by the reference's own code.  Every column is computed by the
     HIP kernels behind the C ABI of include/biodgpu.h; this module moves pointers.  The only FFI precedent in BioD is
     zlib (bio/core/utils/zlib.d:6-245): plain pointers and sizes in, int status codes out, turned into exceptions here
     the way block.d:162-185 turns zlib's into ZlibException.
@@ -29,6 +31,7 @@
 module bio.std.hts.bam.gpu.pileup;
 
 import bio.std.hts.bam.cigar : CigarOperation;
+import bio.std.hts.bam.read : BamRead, EagerBamRead;
 import bio.core.base : Base;
 
 import std.algorithm : map;
@@ -353,22 +356,42 @@ struct GpuSequence {
     string toString() const { return (cast(const(char)[]) chars).idup; }
 }
 
-/// One read of a column: PileupRead's properties plus the BamRead accessors it forwards.
+/// One read of a column.  As BioD's PileupRead (pileup.d:86-89: `Read read; alias read this;`, Read = EagerBamRead) it IS the read:
+/// BioD's own BamRead, constructed over the host copy of the record's bytes (read.d:482: `this(ubyte[] chunk)`; the chunk is a slice,
+/// `_is_slice`, read.d:876-883 -- a setter duplicates it first, the window's memory is never written), so every BamRead accessor --
+/// name, sequence, base_qualities, cigar, flags, strand, cigarString, `read["RG"]` and the other tags (read.d:1070-1087), toSam,
+/// to!string -- comes from the reference's own code, not from a re-implementation here.  `end_position` is the device's (K1 computed
+/// position + basesCovered() for every record, read.d:1380-1383): the wrapper's field is filled in, its constructor's CIGAR walk is not run.
 struct GpuPileupRead {
     private const(bgp_entry)* e;
     private const(GpuRecordWindow)* w;
+
+    ///
+    EagerBamRead!BamRead read;
+    ///
+    alias read this;
+
+    this(const(bgp_entry)* e, const(GpuRecordWindow)* w) {
+        this.e = e; this.w = w;
+        const(bgp_record)* r = &w.r.rec[idx];
+        // the record's body: block_size bytes behind the four of the length prefix (readrange.d:139-163)
+        const(ubyte)* p = w.r.stream + cast(size_t)(r.rec_off - w.r.rec[0].rec_off);
+        uint block_size = *cast(const(uint)*) p;
+        read.read = BamRead(cast(ubyte[]) p[4 .. 4 + block_size]);
+        read.end_position = r.end_pos;
+    }
 
     private size_t idx() const { return cast(size_t)(e.read_ordinal - w.first); }
     private ref const(bgp_record) rec() const { return w.r.rec[idx]; }
 
     /// pileup.d:94
-    CigarOperation cigar_operation() const @property { return cigar[e.cigar_op_index]; }
+    CigarOperation cigar_operation() const @property { return decoded_cigar[e.cigar_op_index]; }
     /// pileup.d:99
     uint cigar_operation_offset() const @property { return e.cigar_op_offset; }
     /// pileup.d:104-106
-    const(CigarOperation)[] cigar_before() const @property { return cigar[0 .. e.cigar_op_index]; }
+    const(CigarOperation)[] cigar_before() const @property { return decoded_cigar[0 .. e.cigar_op_index]; }
     /// pileup.d:109-111
-    const(CigarOperation)[] cigar_after() const @property { return cigar[e.cigar_op_index + 1 .. $]; }
+    const(CigarOperation)[] cigar_after() const @property { return decoded_cigar[e.cigar_op_index + 1 .. $]; }
     /// pileup.d:115-122: the base, or '-' when the current operation is D or N
     char current_base() const @property { return cast(char) e.base; }
     /// pileup.d:127-134: the quality, or 255 when the current operation is D or N
@@ -379,52 +402,22 @@ struct GpuPileupRead {
     /// index of the read in the stream (file order)
     ulong read_ordinal() const @property { return e.read_ordinal; }
 
-    // ---- BamRead (read.d), through the host copy of the record
-    /// read.d:218-222
-    const(char)[] name() const @property {
-        const(ubyte)* p = w.r.stream + cast(size_t)(rec.rec_off - w.r.rec[0].rec_off) + 36;
-        return cast(const(char)[]) p[0 .. (rec.bin_mq_nl & 0xFF) - 1];
-    }
+    // ---- the device's decoded arenas of the same read (what K2 wrote: chars of base.d:85, Phred bytes, raw CIGAR ops), for a
+    // consumer that wants them without BamRead's lazy 4-bit range
     /// read.d:225-228: CigarOperation is exactly one uint (cigar.d:58-70)
-    const(CigarOperation)[] cigar() const @property {
+    const(CigarOperation)[] decoded_cigar() const @property {
         size_t b = cast(size_t)(w.r.cigar_off[idx] - w.r.cigar_off[0]), en = cast(size_t)(w.r.cigar_off[idx + 1] - w.r.cigar_off[0]);
         return cast(const(CigarOperation)[]) w.r.cigar[b .. en];
     }
     /// read.d:438-440
-    GpuSequence sequence() const @property {
+    GpuSequence decoded_sequence() const @property {
         size_t b = cast(size_t)(w.r.seq_off[idx] - w.r.seq_off[0]), en = cast(size_t)(w.r.seq_off[idx + 1] - w.r.seq_off[0]);
         return GpuSequence(w.r.seq[b .. en]);
     }
     /// read.d:468-470
-    const(ubyte)[] base_qualities() const @property {
+    const(ubyte)[] decoded_base_qualities() const @property {
         size_t b = cast(size_t)(w.r.seq_off[idx] - w.r.seq_off[0]), en = cast(size_t)(w.r.seq_off[idx + 1] - w.r.seq_off[0]);
         return w.r.qual[b .. en];
-    }
-    /// read.d:907
-    int ref_id() const @property { return rec.ref_id; }
-    /// read.d:911
-    int position() const @property { return rec.pos; }
-    /// EagerBamRead.end_position, read.d:1380-1383
-    int end_position() const @property { return rec.end_pos; }
-    /// read.d:255-262
-    int basesCovered() const { return rec.end_pos - rec.pos; }
-    /// read.d:923
-    int sequence_length() const @property { return rec.l_seq; }
-    /// read.d:958-972
-    ubyte mapping_quality() const @property { return cast(ubyte)((rec.bin_mq_nl >> 8) & 0xFF); }
-    ushort flag() const @property { return cast(ushort)(rec.flag_nc >> 16); }
-    /// read.d:137-194
-    bool is_paired() const @property { return (flag & 0x1) != 0; }
-    bool is_unmapped() const @property { return (flag & 0x4) != 0; }
-    bool is_reverse_strand() const @property { return (flag & 0x10) != 0; }
-    bool is_secondary_alignment() const @property { return (flag & 0x100) != 0; }
-    bool is_duplicate() const @property { return (flag & 0x400) != 0; }
-    char strand() const @property { return is_reverse_strand ? '-' : '+'; }
-    /// read.d: cigarString()
-    string cigarString() const {
-        string s;
-        foreach (op; cigar) s ~= to!string(op.length) ~ op.type;
-        return s.length ? s : "*";
     }
 }
 

@@ -11,6 +11,8 @@
 #include <cstdio>
 #include <limits>
 #include <stdexcept>
+#include <cstdio>
+#include <cstring>
 #include <string>
 #include <vector>
 
@@ -86,6 +88,43 @@ private:
     bgp_ctx* ctx_ = nullptr;
 };
 
+// A tag's value, tagvalue.d's Value as far as a reader needs it: found the way BamRead.opIndex finds it (read.d:1070-1087: a linear scan
+// of the aux area from _tags_offset, two key bytes, a type byte, the value skipped by its type -- read.d:1219-1230), rendered by to_sam()
+// the way Value.toSam does (tagvalue.d:461-505).  Views the host copy of the record.
+struct TagValue {
+    char type = 0;                 // 0: no such tag (Value(null), is_nothing); else the BAM type char: A c C s S i I f Z H B
+    char elem = 0;                 // B: the elements' type char
+    const uint8_t* p = nullptr;    // the value's bytes (Z / H: up to the NUL; B: the elements)
+    uint32_t count = 0;            // B: elements; Z / H: chars
+    bool is_nothing() const { return type == 0; }
+    static size_t size_of(char t) { switch (t) { case 'A': case 'c': case 'C': return 1; case 's': case 'S': return 2; case 'i': case 'I': case 'f': return 4; default: return 0; } }   // tagvalue.d:78-85,106-119
+    static std::string one(char t, const uint8_t* q) {
+        char buf[48];
+        switch (t) {
+            case 'c': std::snprintf(buf, sizeof buf, "%d", (int)*(const int8_t*)q); break;
+            case 'C': std::snprintf(buf, sizeof buf, "%u", (unsigned)*q); break;
+            case 's': { int16_t v; std::memcpy(&v, q, 2); std::snprintf(buf, sizeof buf, "%d", (int)v); break; }
+            case 'S': { uint16_t v; std::memcpy(&v, q, 2); std::snprintf(buf, sizeof buf, "%u", (unsigned)v); break; }
+            case 'i': { int32_t v; std::memcpy(&v, q, 4); std::snprintf(buf, sizeof buf, "%d", v); break; }
+            case 'I': { uint32_t v; std::memcpy(&v, q, 4); std::snprintf(buf, sizeof buf, "%u", v); break; }
+            case 'f': { float v; std::memcpy(&v, q, 4); if (v != v) return "nan"; std::snprintf(buf, sizeof buf, "%g", (double)v); break; }
+            default: buf[0] = 0;
+        }
+        return buf;
+    }
+    std::string to_sam() const {                                                                                            // tagvalue.d:468-505
+        switch (type) {
+            case 0: return "";
+            case 'A': return std::string("A:") + (char)*p;
+            case 'Z': return "Z:" + std::string((const char*)p, count);
+            case 'H': return "H:" + std::string((const char*)p, count);
+            case 'f': return "f:" + one('f', p);
+            case 'B': { std::string o = std::string("B:") + elem; const size_t w = size_of(elem); for (uint32_t k = 0; k < count; ++k) o += "," + one(elem, p + k * w); return o; }
+            default: return "i:" + one(type, p);                                                                          // every integer width is "i:" in SAM
+        }
+    }
+};
+
 // PileupRead, pileup.d:86-230 (a view into the window the range currently holds)
 struct PileupRead {
     const bgp_entry* e; const bgp_records* recs;
@@ -117,6 +156,36 @@ struct PileupRead {
     std::string name() const {                                                                                             // read.d:218-222: l_read_name - 1 chars behind the 32 fixed bytes
         if (!recs->stream) throw std::logic_error("read names need the host copy of the record stream (BGP_FETCH_STREAM)");
         return std::string((const char*)recs->stream + record().rec_off + 36, (size_t)(record().bin_mq_nl & 0xFF) - 1);
+    }
+    // read["RG"] (read.d:1070-1087): BioD's PileupRead is `alias read this` (pileup.d:89), so a consumer may ask column.reads[k] for a tag.
+    // The aux area lies behind QUAL (read.d:1000-1003) and ends with the record (block_size).
+    TagValue tag(const char* key) const {
+        if (!recs->stream) throw std::logic_error("tags need the host copy of the record stream (BGP_FETCH_STREAM)");
+        if (!key || std::strlen(key) != 2) throw std::invalid_argument("Key length must be 2");                           // read.d:1071
+        const bgp_record& r = record();
+        const uint8_t* rec0 = recs->stream + r.rec_off;
+        uint32_t block_size; std::memcpy(&block_size, rec0, 4);
+        const size_t l_name = r.bin_mq_nl & 0xFF, n_cig = r.flag_nc & 0xFFFF, l_seq = (size_t)r.l_seq;
+        const uint8_t* t = rec0 + 36 + l_name + 4 * n_cig + (l_seq + 1) / 2 + l_seq;                                     // read.d:984-1003
+        const uint8_t* end = rec0 + 4 + block_size;
+        TagValue none;
+        if (end - t < 4) return none;                                                                                      // read.d:1073-1074
+        while (t + 1 < end) {                                                                                              // read.d:1077
+            const bool hit = t[0] == (uint8_t)key[0] && t[1] == (uint8_t)key[1];
+            t += 2;
+            if (t >= end) break;
+            const char ty = (char)*t++;
+            TagValue v; v.type = ty; v.p = t;
+            if (ty == 'Z' || ty == 'H') { const uint8_t* z = t; while (z < end && *z) ++z; v.count = (uint32_t)(z - t); t = z + 1; }          // read.d:1221-1222
+            else if (ty == 'B') {                                                                                          // read.d:1223-1226
+                if (end - t < 5) break;
+                v.elem = (char)*t++; uint32_t n; std::memcpy(&n, t, 4); t += 4; v.p = t; v.count = n;
+                t += (size_t)n * TagValue::size_of(v.elem);
+            } else { const size_t w = TagValue::size_of(ty); if (!w) break; t += w; }                                      // read.d:1227-1229
+            if (t > end) break;
+            if (hit) return v;
+        }
+        return none;
     }
 };
 

@@ -11,7 +11,7 @@
 #define REQUIRE(x) do { if (!(x)) { std::fprintf(stderr, "FAILED %s:%d: %s\n", __FILE__, __LINE__, #x); return 1; } } while (0)
 
 int main(int argc, char** argv) {
-    if (argc < 3) { std::fprintf(stderr, "usage: %s ex1_header.bam illu_20_chunk.bam [bins.bam [copy_of_bins.bam [p1_records.bin]]]\n", argv[0]); return 2; }
+    if (argc < 3) { std::fprintf(stderr, "usage: %s ex1_header.bam illu_20_chunk.bam [bins.bam [copy_of_bins.bam [p1_records.bin [tags.bam]]]]\n", argv[0]); return 2; }
     using namespace biodgpu;
     {
         BamReader bam(argv[1], 2);
@@ -184,6 +184,31 @@ int main(int argc, char** argv) {
             }
         }
         REQUIRE(seen == 7);
+    }
+    if (argc > 6) {
+        // test/unittests.d:110-129 through column.reads: every read of tags.bam is named "tag_<key>:<the tag's value in SAM form>", and
+        // alignment[key].toSam() must say the same.  BioD's PileupRead forwards to its BamRead (pileup.d:89); here the read of a COLUMN
+        // is asked for its tag (read.d:1070-1087, tagvalue.d:461-505).
+        BamReader bam(argv[6], 2);
+        std::vector<char> seen(bam.num_reads(), 0);
+        size_t checked = 0;
+        for (auto column : pileupColumns(bam.reads()))
+            for (auto& read : column.reads()) {
+                if (seen[read.read_ordinal()]) continue;
+                seen[read.read_ordinal()] = 1;
+                const std::string name = read.name();
+                REQUIRE(name.compare(0, 4, "tag_") == 0);
+                const size_t colon = name.find(':', 4);
+                REQUIRE(colon == 6);                                                     // two-letter keys
+                const std::string key = name.substr(4, 2), want = name.substr(colon + 1);
+                const TagValue v = read.tag(key.c_str());
+                REQUIRE(!v.is_nothing());
+                if (v.to_sam() != want) { std::fprintf(stderr, "tag %s: name says %s, value says %s\n", key.c_str(), want.c_str(), v.to_sam().c_str()); return 1; }
+                REQUIRE(read.tag("??").is_nothing());                                    // "no such tag": Value(null)
+                ++checked;
+            }
+        REQUIRE(checked > 300);                                                          // (every read of the file that covers a position: 417 reads, a few of them clipped to nothing)
+        std::printf("tags through column.reads: %zu reads\n", checked);
     }
     std::puts("facade ok");
     return 0;

@@ -202,9 +202,19 @@ def _body(text, header):
 def test_facade_types_define_what_the_reference_consumers_use():
     text = open(DMOD).read()
     read = _body(text, "struct GpuPileupRead {")
-    for prop in ("current_base", "current_base_quality", "cigar_operation", "cigar_operation_offset", "query_offset", "cigar_before", "cigar_after",   # pileup.d:86-149
-                 "position", "ref_id", "mapping_quality", "is_reverse_strand", "name", "sequence", "base_qualities", "cigar", "cigarString"):
+    for prop in ("current_base", "current_base_quality", "cigar_operation", "cigar_operation_offset", "query_offset", "cigar_before", "cigar_after"):   # pileup.d:86-149
         assert re.search(r"\b%s\(\)" % prop, read), prop
+    # ... and IS BioD's own read, as PileupRead is (pileup.d:86-89): position, ref_id, mapping_quality, is_reverse_strand, name, sequence,
+    # base_qualities, cigar, cigarString, read["RG"] (read.d:1070-1087) -- SURVEY 8(b)'s list and everything else -- are BamRead's, over the
+    # host copy of the record (read.d:482), end_position the wrapper's field (read.d:1380-1383)
+    assert re.search(r"EagerBamRead!BamRead\s+read;", read) and re.search(r"alias\s+read\s+this;", read)
+    assert re.search(r"read\.read\s*=\s*BamRead\(cast\(ubyte\[\]\)\s*p\[4 \.\. 4 \+ block_size\]\);", read) and "read.end_position = r.end_pos;" in read
+    assert "import bio.std.hts.bam.read : BamRead, EagerBamRead;" in text
+    ref_read = open("/root/reference/bio/std/hts/bam/read.d").read() if os.path.exists("/root/reference/bio/std/hts/bam/read.d") else None
+    if ref_read is not None:        # (here, not on the GPU box: the names the facade relies on exist in the reference as it is used)
+        assert "this(ubyte[] chunk, bool fix_byte_order=true)" in ref_read and "struct EagerBamRead(R=BamRead)" in ref_read and "int end_position;" in ref_read
+        for prop in ("name", "sequence", "base_qualities", "cigar", "cigarString", "mapping_quality", "is_reverse_strand", "position", "ref_id", "opIndex(string key)"):
+                assert prop in ref_read, prop
     col = _body(text, "struct GpuPileupColumn {")
     for prop in ("coverage", "ref_id", "position", "reads", "reads_starting_here", "bases", "base_qualities", "read_qualities", "reference_base"):      # pileup.d:236-290
         assert re.search(r"\b%s\(\)" % prop, col), prop

@@ -506,9 +506,9 @@ def test_cpp_facade(tmp_path, data_dir):
     from test_oracle_kats import p1_stream
     p1 = str(tmp_path / "p1_records.bin")            # the ten literal reads of the reference's pileup unittest (pileup.d:699-749) as record bytes
     open(p1, "wb").write(p1_stream())
-    out = subprocess.run([exe, os.path.join(data_dir, "ex1_header.bam"), os.path.join(data_dir, "illu_20_chunk.bam"), os.path.join(data_dir, "bins.bam"), copy, p1],
-                         capture_output=True, text=True)
-    assert out.returncode == 0 and "facade ok" in out.stdout, out.stderr
+    out = subprocess.run([exe, os.path.join(data_dir, "ex1_header.bam"), os.path.join(data_dir, "illu_20_chunk.bam"), os.path.join(data_dir, "bins.bam"), copy, p1,
+                          os.path.join(data_dir, "tags.bam")], capture_output=True, text=True)
+    assert out.returncode == 0 and "facade ok" in out.stdout and "tags through column.reads" in out.stdout, out.stderr
 
 
 def test_records_larger_than_framing_segments(ctx):
