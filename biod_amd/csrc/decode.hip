@@ -352,6 +352,9 @@ __global__ __launch_bounds__(256, BGP_K12_MINW) void k12_fused(FusedArgs a) {
 // A record that runs past the window (only a chunk's last one can) is unpacked from global memory by the whole
 // workgroup.  Arena sizes are not known before the pass: the host sizes them from the first records and the pass
 // reports an overflow instead of writing past a buffer (then it is run again with the exact sizes it found).
+#ifndef BGP_K12_NT_ROWS
+#define BGP_K12_NT_ROWS 1            // the per-record arrays leave with non-temporal stores like the arenas (nothing reads them before K3: k12_lds 13.23 -> 13.11 ms)
+#endif
 #ifndef BGP_SD_NW
 #define BGP_SD_NW 8
 #define BGP_SD_NS 4
@@ -575,8 +578,8 @@ __device__ __forceinline__ void sd_emit(const SdArgs& a, uint8_t* sd_lds, uint64
         const int rc = (int)min((uint32_t)SD_RB, nfast - r0);
         const bool valid = t < rc;
         bgp_record rec{};
-        uint32_t lseq = 0, ncig = 0, cig_o = 0, pcls = 0;
-        uint4 c4v = make_uint4(0, 0, 0, 0), prow = make_uint4(0, 0, 0, 0);
+        uint32_t lseq = 0, ncig = 0, cig_o = 0;
+        uint4 c4v = make_uint4(0, 0, 0, 0);
         if (t < 4) misc[M_TM + t] = 0;
         if (valid) {
             const uint32_t o = roff[r0 + t];
@@ -596,10 +599,29 @@ __device__ __forceinline__ void sd_emit(const SdArgs& a, uint8_t* sd_lds, uint64
             }
             rec.end_pos = (int32_t)((uint32_t)rec.pos + covered);                                   // read.d:1382
             lseq = (uint32_t)rec.l_seq; ncig = n_cig;
-            if (a.prow) {               // what K4 wants to know of the read, while its CIGAR is at hand (a long CIGAR's basesCovered is not summed yet: the planner looks again)
-                const bool cov = covered != 0 || (n_cig > BGP_LONG_CIGAR && !((rec.flag_nc >> 16) & 0x4u));
-                pcls = bgp_plan_row((uint32_t)rec.pos, n_cig, lseq, cov, c4v, wbase + cig_o + 4ull * n_cig, a.len, &prow);
+        }
+        if (a.prow && t >= SD_RB && t - SD_RB < rc) {
+            // What K4 wants to know of the round's reads (common.h: bgp_plan_row), by the waves that have no table row to make: beside the
+            // row's own work it was 0.45 ms of the kernel's 13 -- two of a workgroup's eight waves hold records, the others waited for them.
+            // The read's few words once more from LDS; a CIGAR of more than four ops is the planner's whatever it covers (it looks again).
+            const uint32_t u = (uint32_t)t - SD_RB, o = roff[r0 + u];
+            const uint32_t pos = wl32(w, o + 8), bmn = wl32(w, o + 12), fnc = wl32(w, o + 16), lq = wl32(w, o + 20);
+            const uint32_t l_name = bmn & 0xFFu, n_cig = fnc & 0xFFFFu, co = o + 36 + l_name;
+            const bool unmapped = ((fnc >> 16) & 0x4u) != 0;
+            uint4 c4 = make_uint4(0, 0, 0, 0);
+            bool cov = !unmapped && n_cig > 4;
+            if (!unmapped && n_cig >= 1 && n_cig <= 4) {
+                const uint4 q = wl128(w, co);
+                c4.x = q.x; if (n_cig > 1) c4.y = q.y; if (n_cig > 2) c4.z = q.z; if (n_cig > 3) c4.w = q.w;
+                cov = ((cig_rc(c4.x) ? c4.x >> 4 : 0u) + (cig_rc(c4.y) ? c4.y >> 4 : 0u) + (cig_rc(c4.z) ? c4.z >> 4 : 0u) + (cig_rc(c4.w) ? c4.w >> 4 : 0u)) != 0;      // basesCovered() > 0 (ops behind the CIGAR's end are 0: an M of no bases)
             }
+            uint4 row;
+            const uint32_t cls = bgp_plan_row(pos, n_cig, lq, cov, c4, wbase + co + 4ull * n_cig, a.len, &row);
+#if BGP_K12_NT_ROWS
+            nt_store16(a.prow + pn + r0 + u, row); a.rcls[pn + r0 + u] = (uint8_t)cls;
+#else
+            a.prow[pn + r0 + u] = row; a.rcls[pn + r0 + u] = (uint8_t)cls;
+#endif
         }
         uint32_t es, ec, ts, tc;
         sd_excl2(lseq, ncig, &es, &ec, &ts, &tc, misc + M_WS);
@@ -610,8 +632,13 @@ __device__ __forceinline__ void sd_emit(const SdArgs& a, uint8_t* sd_lds, uint64
         const uint64_t i = pn + r0 + t;
         const uint64_t tile0 = (pn + r0) / K3_TILE_RECORDS;
         if (valid) {
+#if BGP_K12_NT_ROWS
+            { uint4 r0v, r1v; __builtin_memcpy(&r0v, &rec, 16); __builtin_memcpy(&r1v, reinterpret_cast<const char*>(&rec) + 16, 16);
+              nt_store16(reinterpret_cast<char*>(a.rec + i), r0v); nt_store16(reinterpret_cast<char*>(a.rec + i) + 16, r1v); nt_store16(a.cig4 + i, c4v);
+              __builtin_nontemporal_store(carry_seq + es, a.seq_off + i); __builtin_nontemporal_store(carry_cig + ec, a.cig_off + i); }
+#else
             a.rec[i] = rec; a.seq_off[i] = carry_seq + es; a.cig_off[i] = carry_cig + ec; a.cig4[i] = c4v;
-            if (a.prow) { a.prow[i] = prow; a.rcls[i] = (uint8_t)pcls; }
+#endif
             soff[t] = es; coff[t] = ec;
             info[3 * t] = (uint16_t)cig_o; info[3 * t + 1] = (uint16_t)(cig_o + 4 * ncig); info[3 * t + 2] = (uint16_t)(cig_o + 4 * ncig + (uint32_t)((rec.l_seq + 1) / 2));   // read.d:992-998
             if (t == rc - 1) { soff[rc] = ts; coff[rc] = tc; }
