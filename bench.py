@@ -61,7 +61,7 @@ def pmc_traffic(timers, config, n_reads, launches=None):
     gfx950 as MI355X_MICROARCH.md prescribes).  Counters cannot be read from inside this process, so the number is only
     reported when the workload is the one the profile was taken on (configuration and read count in the profile's header) AND
     that header carries the hash of the kernel sources as they are now (scratch/refresh_profiles.sh writes it); otherwise null."""
-    path = os.path.join(ROOT, "profiles", f"r04_pmc_hbm_traffic_{config}.csv")
+    path = os.path.join(ROOT, "profiles", f"r05_pmc_hbm_traffic_{config}.csv")
     if not os.path.exists(path):
         return None
     lines = open(path).read().splitlines()

@@ -1724,7 +1724,7 @@ template <bool LONG, bool ROWS> __global__ __launch_bounds__(AT, BGP_ACC2_MINW) 
             // threads at once and the long reads that touch it listed in LDS (where the pool was); then a wave per listed read, the NEXT
             // read's ops requested before the current one is scanned and the current one's bases while the one before is accumulated.
             struct LRead { unsigned long long cg, nib; int32_t shift; uint32_t k, cs, qs, n_cig, pad; };
-            constexpr int LCAND = 128, LPB = 3 * 64;              // candidates a round; pieces a wave deals out per step (three an op at most)
+            constexpr int LCAND = 96, LPB = 4 * 64;               // candidates a round; a wave's ring of pieces (a step deals out three an op at most, up to 63 wait from the step before)
             static_assert(sizeof(LRead) == 40 && LCAND * sizeof(LRead) + ANW * LPB * 8 <= (size_t)P_POOL * 8, "the window's long reads and the waves' pieces are listed where the pool is");
             LRead* const lst = reinterpret_cast<LRead*>(alds + L::POOL);
             unsigned long long* const pcs = reinterpret_cast<unsigned long long*>(alds + L::POOL + LCAND * sizeof(LRead)) + wave * LPB;
@@ -1748,6 +1748,9 @@ template <bool LONG, bool ROWS> __global__ __launch_bounds__(AT, BGP_ACC2_MINW) 
                 if (t < 3) misc[4 * (rounds & 1u) + t] = 0;
                 const uint32_t n_l = mc[0];
                 A2Small pn0, pn1; pn0.eh = pn1.eh = 0; pn0.par = pn1.par = 0; pn0.q0 = pn1.q0 = make_uint4(0, 0, 0, 0);      // the two pieces whose bases are on their way
+                // Pieces wait in a ring until 64 of them are there: a read's window is ~34 M ops, half a batch -- taken read by read the
+                // accumulate ran with half its lanes.  What is left when the round's reads are through leaves as one last batch.
+                uint32_t r_head = 0, r_pend = 0;
                 // (TWO ops a lane: a window of 1024 positions is ~68 ops of a read with an indel every ~15 bases -- one step of 128 instead of
                 // two of 64 --, and as M and I / D alternate nearly every lane then holds exactly one M op: the accumulate runs with full waves)
                 auto ops_of = [&](const LRead& E, uint32_t c0) {
@@ -1809,22 +1812,24 @@ template <bool LONG, bool ROWS> __global__ __launch_bounds__(AT, BGP_ACC2_MINW) 
                                 }
                             }
                             const uint32_t ipc = wave_scan_u32(npc), tot = rl(ipc, 63);
-                            uint32_t at = ipc - npc;
+                            uint32_t at = r_head + r_pend + ipc - npc;
                             for (uint32_t k = 0; k < npc; ++k) {
                                 const int h = sp[0] < se[0] ? 0 : 1;
                                 const uint32_t p = sp[h];
                                 const uint32_t n = min(se[h] - p, 8u * (uint32_t)P_CHS - (p & 7u));
                                 const uint64_t nb = cur.nib + qsb[h] + (uint32_t)((int32_t)p - sa0[h]) - (p & 7u);
-                                pcs[at++] = nb | ((unsigned long long)((p >> 3) | ((p & 7u) << 7) | (((p & 7u) + n) << 10)) << 42);
+                                pcs[at++ & (uint32_t)(LPB - 1)] = nb | ((unsigned long long)((p >> 3) | ((p & 7u) << 7) | (((p & 7u) + n) << 10)) << 42);
                                 sp[h] = p + n;
                             }
+                            r_pend += tot;
                             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                             __builtin_amdgcn_wave_barrier();
-                            for (uint32_t b0 = 0; b0 < tot; b0 += 64) {
-                                const unsigned long long en = b0 + (uint32_t)lane < tot ? pcs[b0 + (uint32_t)lane] : 0ull;
+                            while (r_pend >= 64u) {
+                                const unsigned long long en = pcs[(r_head + (uint32_t)lane) & (uint32_t)(LPB - 1)];
                                 const A2Small bt = acc2_load_small(a.s, a.stream_len, en);
                                 acc2_work_small(pn0, cbase0);
                                 pn0 = pn1; pn1 = bt;
+                                r_head += 64u; r_pend -= 64u;
                             }
                             __builtin_amdgcn_wave_barrier();
                         }
@@ -1832,6 +1837,12 @@ template <bool LONG, bool ROWS> __global__ __launch_bounds__(AT, BGP_ACC2_MINW) 
                         if (cur.shift + (int32_t)cs >= (int32_t)np) break;                              // the next op begins behind the window
                     }
                 }
+                }
+                if (r_pend) {                                    // the pieces still waiting: a last, partial batch
+                    const unsigned long long en = (uint32_t)lane < r_pend ? pcs[(r_head + (uint32_t)lane) & (uint32_t)(LPB - 1)] : 0ull;
+                    const A2Small bt = acc2_load_small(a.s, a.stream_len, en);
+                    acc2_work_small(pn0, cbase0);
+                    pn0 = pn1; pn1 = bt;
                 }
                 acc2_work_small(pn0, cbase0); acc2_work_small(pn1, cbase0);
                 __syncthreads();                                 // the list is free, every add is in

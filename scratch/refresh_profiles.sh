@@ -1,11 +1,11 @@
 #!/bin/bash
 # Regenerates everything under profiles/ that bench.py and DESIGN.md quote (run on the GPU box through gpurun):
-#   usage: scratch/refresh_profiles.sh r04
+#   usage: scratch/refresh_profiles.sh r05
 #   bench lines for cfg3 (with cpu_baseline and parity_interior), cfg2, cfg5; rocprofv3 --kernel-trace --stats of the cfg3 and cfg5
 #   bench commands; the PMC passes (FETCH_SIZE, WRITE_SIZE -- separately, as MI355X_MICROARCH.md prescribes) folded into one CSV per
 #   configuration whose header carries the read count and the hash of the kernel sources (bench.py quotes the traffic only while both
 #   match); SQ counters per kernel of the cfg3 step; device-E2E through batched staging; file-E2E.
-TAG=${1:-r04}
+TAG=${1:-r05}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/refresh
 rm -rf $OUT; mkdir -p $OUT
