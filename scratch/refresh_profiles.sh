@@ -55,11 +55,13 @@ cd $R
 timeout 900 python bench.py --steps 20 --warmup 5 > $OUT/${TAG}_bench_cfg3_100M.json 2> $OUT/bench_cfg3.err
 timeout 600 python bench.py --steps 10 --warmup 3 --config cfg2 > $OUT/${TAG}_bench_cfg2_10M.json 2> $OUT/bench_cfg2.err
 timeout 600 python bench.py --steps 10 --warmup 3 --config cfg5 > $OUT/${TAG}_bench_cfg5_200k.json 2> $OUT/bench_cfg5.err
-BGP_BENCH_FORCE_COMM=1 timeout 600 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --parity 2> $OUT/bench_comm.err | grep "^{" | tail -1 > $OUT/${TAG}_bench_cfg3_100M_one_rank_communicator.json
+BGP_BENCH_FORCE_COMM=1 timeout 600 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --parity --no-e2e 2> $OUT/bench_comm.err | grep "^{" | tail -1 > $OUT/${TAG}_bench_cfg3_100M_one_rank_communicator.json
+# N = 2 REHEARSED on the one GPU (two ranks, real kernels on both shards, histogram summed over gloo by the script): not a scaling measurement
+timeout 900 python bench.py --gpus 2 --steps 5 --warmup 2 --no-cpu-baseline --parity --no-md 2> $OUT/bench_two.err | grep "^{" | tail -1 > $OUT/${TAG}_bench_cfg3_100M_two_ranks_rehearsal_one_gpu.json
 cd /tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-md > $OUT/${TAG}_bench_under_rocprofv3_cfg3_100M.json 2> $OUT/stats.err
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-md --no-e2e > $OUT/${TAG}_bench_under_rocprofv3_cfg3_100M.json 2> $OUT/stats.err
 find $OUT/stats -name "*kernel_stats.csv" -exec cp {} $OUT/${TAG}_rocprofv3_kernel_stats_cfg3_100M.csv \;
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats5 -- python $R/bench.py --steps 3 --warmup 1 --config cfg5 --no-cpu-baseline --no-md > /dev/null 2> $OUT/stats5.err
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats5 -- python $R/bench.py --steps 3 --warmup 1 --config cfg5 --no-cpu-baseline --no-md --no-e2e > /dev/null 2> $OUT/stats5.err
 find $OUT/stats5 -name "*kernel_stats.csv" -exec cp {} $OUT/${TAG}_rocprofv3_kernel_stats_cfg5_200k.csv \;
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/statsmd -- python $R/scratch/md_scale.py cfg3 100000000 > $OUT/${TAG}_md_path_cfg3_100M.log 2> $OUT/statsmd.err
 find $OUT/statsmd -name "*kernel_stats.csv" -exec cp {} $OUT/${TAG}_rocprofv3_md_path_cfg3_100M.csv \;

@@ -6,7 +6,7 @@ OUT=$R/gpurun_out/pmc_$TAG; rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for set in "SQ_WAVES SQ_INSTS_SALU SQ_INSTS_VALU SQ_INSTS_LDS" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VMEM SQ_INSTS_VMEM_RD" "FETCH_SIZE" "WRITE_SIZE"; do
   tag=$(echo $set | tr ' ' '_' | cut -c1-40)
-  timeout 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/$tag -- python $R/bench.py ${BENCH_ARGS:-} --steps 1 --warmup 0 --no-cpu-baseline --no-checks --no-md > $OUT/$tag.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/$tag -- python $R/bench.py ${BENCH_ARGS:-} --steps 1 --warmup 0 --no-cpu-baseline --no-checks --no-md --no-e2e > $OUT/$tag.log 2>&1
 done
 python - <<PY
 import csv, glob, collections, re, os
