@@ -501,7 +501,7 @@ def main():
             out["e2e"] = {"note": "input NOT resident in HBM: PCIe-inclusive (device_e2e) and inflate-inclusive (file_e2e) rates of the same hot path on %d reads of %s's model; the headline `value` is kernel-only" % (n_e2e, a.config),
                           "device_e2e": bench_e2e.device_e2e(ctx, st_e, n_e2e), "file_e2e": bench_e2e.file_e2e(ctx, st_e, n_e2e, int(cfg_e.n_ref))}
             del st_e
-        if not a.no_cpu_baseline:                                       # (rank 0's host cores, whatever the number of ranks)
+        if not a.no_cpu_baseline and world == 1:                        # (at N = 1 only: with more ranks the host's cores are the ranks')
             out["cpu_baseline"] = cpu_baseline(a.config, a.cpu_sample_reads)
             out["speedup_vs_cpu_baseline"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
         print(json.dumps(out), file=result_out, flush=True)
