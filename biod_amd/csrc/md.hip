@@ -1656,9 +1656,13 @@ int k6_reference_bases(bgp_ctx* c, int skip_zero, uint32_t run_first, uint32_t r
             for (uint32_t k = 0; k < nr; ++k) pr[k].active = 0;
             for (uint32_t k : ks) { pr[k].active = 1; pr[k].ce_in = cr[k].ce_in; }
             BGP_HIP(hipMemcpyAsync(st + off_pr, pr.data(), sizeof(ParRun) * nr, hipMemcpyHostToDevice, c->stream));
-            for (uint32_t k : ks) {
-                const uint64_t lo = cr[k].first / SEG + k, hi = (cr[k].endrec ? (cr[k].endrec - 1) / SEG : 0) + k + 1;
+            for (size_t g0 = 0; g0 < ks.size();) {      // (the slots of runs next to each other in one piece: k6_emit takes them in one launch, and a slot between two runs' segments must say "nothing entered" too)
+                size_t g1 = g0 + 1;
+                while (g1 < ks.size() && ks[g1] == ks[g1 - 1] + 1) ++g1;
+                const uint32_t kf = ks[g0], kl = ks[g1 - 1];
+                const uint64_t lo = cr[kf].first / SEG + kf, hi = (cr[kl].endrec ? (cr[kl].endrec - 1) / SEG : 0) + kl + 1;
                 BGP_HIP(hipMemsetAsync(c->d_md_entry.as<Succ>() + lo, 0xFF, (hi - lo) * sizeof(Succ), c->stream));
+                g0 = g1;
             }
             BGP_HIP(hipMemsetAsync(c->d_md_long.p, 0, 16, c->stream));
             // (a stream of long records: the providers' tags are long too -- k6_emit lists them for k6_verify_long)
@@ -1669,9 +1673,17 @@ int k6_reference_bases(bgp_ctx* c, int skip_zero, uint32_t run_first, uint32_t r
                 TimedRegion t(c, "k6_top", 0);
                 hipLaunchKernelGGL(k6_top, dim3(nr), dim3(64), 0, c->stream, c->d_md_row.as<MdRow>(), c->d_md_exit.as<Succ>(), (const ParRun*)(st + off_pr), (ParOut*)(st + off_po), c->d_md_entry.as<Succ>());
             }
-            for (uint32_t k : ks) {
-                const uint64_t lo = cr[k].first / SEG + k, hi = (cr[k].endrec ? (cr[k].endrec - 1) / SEG : 0) + k + 1;
-                TimedRegion t(c, "k6_emit", mr[k].end_pos - mr[k].start_pos);
+            // (runs next to each other are emitted by ONE launch: their segments' slots are next to each other too, and a block finds its run from
+            // its entry -- eight launches of 6 100 one-wave blocks, a launch a contig of cfg3, were eight tails: 2.1 ms)
+            for (size_t g0 = 0; g0 < ks.size();) {
+                size_t g1 = g0 + 1;
+                while (g1 < ks.size() && ks[g1] == ks[g1 - 1] + 1) ++g1;
+                const uint32_t kf = ks[g0], kl = ks[g1 - 1];
+                const uint64_t lo = cr[kf].first / SEG + kf, hi = (cr[kl].endrec ? (cr[kl].endrec - 1) / SEG : 0) + kl + 1;
+                uint64_t span = 0;
+                for (size_t g = g0; g < g1; ++g) span += mr[ks[g]].end_pos - mr[ks[g]].start_pos;
+                g0 = g1;
+                TimedRegion t(c, "k6_emit", span);
                 if (vlist)      // (a stream of long records: its instantiation lists long providers for k6_verify_long and sends far chunks the checkpointed way)
                 hipLaunchKernelGGL(k6_emit<true>, dim3((unsigned)(hi - lo)), dim3(64), 0, c->stream, c->d_stream, c->d_rec.as<bgp_record>(), c->d_md_row.as<MdRow>(), c->d_md_succ.as<Succ>(),
                                    c->d_md_entry.as<Succ>(), lo, hi - lo, (const EmitRun*)(st + off_er), nr, (ParOut*)(st + off_po), c->d_refbase.as<uint8_t>(),
