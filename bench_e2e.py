@@ -101,7 +101,7 @@ def write_bam(path, st, n_ref, threads=32, block=64000):
     return os.path.getsize(path)
 
 
-def file_e2e(ctx, st, n_reads, n_ref, path="/tmp/bench_e2e.bam", reps=4):
+def file_e2e(ctx, st, n_reads, n_ref, path="/tmp/bench_e2e.bam", reps=8):
     t0 = time.perf_counter()
     fsz = write_bam(path, st, n_ref)
     t_write = time.perf_counter() - t0

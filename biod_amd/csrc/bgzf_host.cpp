@@ -318,6 +318,9 @@ int bgzf_load_bam_device(bgp_ctx* c, const char* path) {
     const size_t BATCH_MIN = getenv("BGP_INFLATE_BATCH_MIN") ? (size_t)std::max(1, atoi(getenv("BGP_INFLATE_BATCH_MIN"))) : 2048;      // (tests: many small batches from a small file)
     int n_batch = 0;
     for (;;) {
+        // (the reader threads are joinable from here on: an exception out of this loop -- its vectors grow -- would unwind past live
+        // std::thread objects and end the process; it becomes a status, the readers are told to stop, and the join below still happens)
+        try {
         uint64_t tn; int src; size_t nblk;
         {
             std::unique_lock<std::mutex> lk(mu);
@@ -388,6 +391,8 @@ int bgzf_load_bam_device(bgp_ctx* c, const char* path) {
         if (all_scanned && (fallback || disp_rc != BGP_OK || (have_q && bi == snap.size() && up_chunks >= n_chunks))) break;
         if (all_scanned && !have_q) break;                 // (no header in the whole file: reported below)
         std::this_thread::sleep_for(std::chrono::microseconds(150));
+        } catch (const std::bad_alloc&) { disp_rc = BGP_ENOMEM; try { c->last_error = "out of host memory while loading the file"; } catch (...) { } next.store(n_chunks); break; }
+          catch (...) { disp_rc = BGP_EINVAL; try { c->last_error = "unexpected C++ exception while loading the file"; } catch (...) { } next.store(n_chunks); break; }
     }
     for (auto& x : th) x.join();
     (void)hipStreamSynchronize(c->io_up); for (hipStream_t x : c->io_inf) (void)hipStreamSynchronize(x);
