@@ -237,6 +237,7 @@ struct K6Batch {                  // batched staging: the provider chain's state
     uint32_t in_have = 0, in_ci = 0, in_y = 0, in_ce = 0; uint64_t in_P = 0, in_i = 0;      // resume the first run from this state (record indices of THIS batch) | chunk_end_position carried in
     uint32_t stop_at = 0;                                                                     // save the last event boundary in front of this position of the LAST run (0: none)
     uint32_t out_have = 0, out_ci = 0, out_y = 0, out_ce = 0; uint64_t out_P = 0, out_i = 0;
+    uint32_t err_last_run = 0, err_dep = 0;      // an MD error: in the batch's last run? decided from the reads that start at or before err_dep (final only if the batch holds all of them: err_dep < the cut's position)
 };
 int k6_reference_bases(bgp_ctx* c, int skip_zero, uint32_t run_first, uint32_t run_end, uint64_t first_record, int* md_err, int64_t* md_err_from, K6Batch* bt = nullptr);   // md.hip: fills d_refbase
 int synth_device(bgp_ctx* c, const bgp_synth_cfg_c* cfg, uint64_t* bytes);   // synth.hip

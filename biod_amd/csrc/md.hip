@@ -487,7 +487,7 @@ template <bool FULL> __global__ __launch_bounds__(256) void k6_prep(const uint8_
 // state is (provider, cursor, chunk_end_position, column, next record to look at), nothing of add()'s bookkeeping is pending --
 // and the last such state in front of `stop_at` (the position from which the next batch hands out columns) is saved for it.
 struct ChainRun { uint64_t first, endrec, iv_base; uint32_t run_end, ce_in, active, resume; uint64_t rs_P, rs_i; uint32_t rs_ci, rs_y, stop_at, pad; };
-struct ChainOut { uint32_t ce_out, n_iv; int32_t err; uint32_t sv_have; int64_t err_from; uint64_t sv_P, sv_i; uint32_t sv_ci, sv_CE, sv_y, pad; };
+struct ChainOut { uint32_t ce_out, n_iv; int32_t err; uint32_t sv_have; int64_t err_from; uint64_t sv_P, sv_i; uint32_t sv_ci, sv_CE, sv_y, err_dep; };      // err_dep: the error was decided from the reads that start at or before this position (batched staging: only final if the batch holds all of those)
 struct MdIv { uint32_t col, c0; uint64_t prov; };
 constexpr uint64_t MD_NONE = ~0ull, MD_INF = 1ull << 62;
 
@@ -513,7 +513,7 @@ __global__ __launch_bounds__(64) void k6_chain(const MdRow* rows, const ChainRun
     uint64_t P = MD_NONE; uint32_t L = 0, ci = 0, CE = R.ce_in; bool bad = false;
     bool has_next = false; uint64_t NX = MD_NONE; uint32_t NXend = 0, NXpos = 0, NXlf = 0;
     uint64_t y = 0, i = R.first;
-    uint32_t n_iv = 0; int err = 0; int64_t err_from = -1;
+    uint32_t n_iv = 0; int err = 0; int64_t err_from = -1; uint32_t err_dep = 0, init_x = 0;
     const uint64_t iv_cap = R.endrec - R.first + 2;
     uint64_t b = MD_NONE; MdRow row{0, 0, 0, 0};
 
@@ -537,6 +537,7 @@ __global__ __launch_bounds__(64) void k6_chain(const MdRow* rows, const ChainRun
     auto init_at = [&](uint64_t j, bool new_ref) -> bool {
         if (j < b || j >= b + 64) load(j);
         const uint32_t x = __shfl(row.pos, (int)(j - b), 64);
+        init_x = x;
         uint64_t k = j, ge;
         for (;;) {
             if (k >= b + 64) load(k);
@@ -575,7 +576,7 @@ __global__ __launch_bounds__(64) void k6_chain(const MdRow* rows, const ChainRun
         if (P != MD_NONE) { load(P); const uint32_t lf = __shfl(row.lf, 0, 64); L = lf & MD_LMASK; bad = (lf & MD_BAD) != 0; if (ci < L) emit(y + 1, ci, P); }
         started = true;
         save();      // a batch of a few reads may hold no event in front of its cut: the chain then stands where it stood, and the next batch resumes from this very state (it is not "begun afresh")
-    } else started = init_at(R.first, true);
+    } else { started = init_at(R.first, true); if (!started) err_dep = init_x; }
     if (started) {
         for (;;) {
             const uint64_t empty_at = bad ? MD_INF : y + (L > ci + 1 ? L - ci : 1u);
@@ -617,23 +618,23 @@ __global__ __launch_bounds__(64) void k6_chain(const MdRow* rows, const ChainRun
             }
             if (outcome == 1) {                                       // pileup.d:627-652
                 P = NX; L = NXlf & MD_LMASK; bad = (NXlf & MD_BAD) != 0; CE = NXend; has_next = false;
-                if (NXlf & MD_ERR) { err = BGP_EINVAL; err_from = (int64_t)F - 1; break; }
+                if (NXlf & MD_ERR) { err = BGP_EINVAL; err_from = (int64_t)F - 1; err_dep = (uint32_t)F; break; }      // (the provider is the best of the reads that start at or before F)
                 const uint64_t skip = F - NXpos;                      // popFrontN(position - next_provider.position)
                 ci = skip < L ? (uint32_t)skip : L;
-                if (ci >= L) { err = BGP_EMD; err_from = (int64_t)F - 1; break; }
+                if (ci >= L) { err = BGP_EMD; err_from = (int64_t)F - 1; err_dep = (uint32_t)F; break; }
                 emit(F, ci, P); ci += 1; y = F; i = jn;
                 save();
                 continue;
             }
             const uint64_t E = outcome == 2 ? (egap > y + 1 ? egap : y + 1) : (R.run_end > y + 1 ? R.run_end : y + 1);
             const uint64_t adv = E - y;                               // every popFront consumed a char first (pileup.d:615-622)
-            if (bad && ci + adv > L) { err = BGP_EMD; err_from = (int64_t)(y + (L > ci ? L - ci : 0)); break; }
+            if (bad && ci + adv > L) { err = BGP_EMD; err_from = (int64_t)(y + (L > ci ? L - ci : 0)); err_dep = (uint32_t)err_from; break; }
             ci = ci + adv < L ? (uint32_t)(ci + adv) : L;
             if (outcome == 3) break;
-            if (!init_at(jn, false)) { err_from = (int64_t)E - 1; break; }
+            if (!init_at(jn, false)) { err_from = (int64_t)E - 1; err_dep = init_x; break; }      // (the new chunk's provider is the best of the position group at init_x)
         }
     }
-    if (lane == 0) co[blockIdx.x] = ChainOut{CE, n_iv, err, svhave, err_from, svP, svI, svci, svCE, svy, 0u};
+    if (lane == 0) co[blockIdx.x] = ChainOut{CE, n_iv, err, svhave, err_from, svP, svI, svci, svCE, svy, err_dep};
 }
 
 // ---------------------------------------------------------------------------------------------- k6_fill
@@ -1767,6 +1768,7 @@ int k6_reference_bases(bgp_ctx* c, int skip_zero, uint32_t run_first, uint32_t r
     }
     for (uint32_t k = 0; k < nr; ++k) if (co[k].err) {
         *md_err = co[k].err; *md_err_from = co[k].err_from;
+        if (bt) { bt->err_last_run = k + 1 == nr ? 1u : 0u; bt->err_dep = co[k].err_dep; }
         break;
     }
     if (bt) {

@@ -1978,6 +1978,44 @@ def test_batched_reference_base_batches_of_a_few_reads(ctx, seed):
         assert np.array_equal(np.concatenate(pos), ora.pos[keep].astype(np.int64)) and np.array_equal(np.concatenate(rb), ora.refbase[keep]), skip
 
 
+def _cut_stream(with_winner):
+    """r0 covers [0, 51): its chunk is used up at column 50, where the next provider is fetched from the reads that start at or before 50
+    and end beyond r0 (pileup.d:583-596, 627-652): D (position 30, an MD tag of five bases: twenty columns in it has nothing left --
+    BGP_EMD if it is ever the provider), H (position 50, ends before D) and -- with_winner -- G (position 50, the largest end_position: it wins).
+    r0's padding puts the end of a 4096-byte batch between H and G: the batch's cut is at position 50, and it holds H but not G."""
+    def rec(name, pos, n, md, pad=0):
+        seq = "".join("ACGT"[(7 * i + pos) % 4] for i in range(n))
+        return bamio.pack_record(name, seq, [(n, "M")], ref_id=0, pos=pos, tags=bamio.tag_z("MD", md) + (bamio.tag_z("XP", "p" * pad) if pad else b""))
+    recs = [rec("r0", 0, 51, "51", pad=3760), rec("D", 30, 30, "5"), rec("H", 50, 5, "5")]
+    if with_winner:
+        recs.append(rec("G", 50, 60, "60"))
+    recs += [rec("t%d" % i, 60 + 20 * i, 40, "40", pad=300) for i in range(12)]
+    st = b"".join(recs)
+    soa = O.decode_soa(st)
+    assert int(soa.rec_off[3]) < 4096 < int(soa.rec_off[3]) + 100      # the first batch ends inside the fourth record
+    return st
+
+
+def test_batched_reference_base_provider_fetched_at_the_cut(ctx):
+    """Found by fuzzing (round 5, fuzz_gpu seed 6210148; the bug predates the round): a batch's cut lies at the position of its last
+    read, and of the reads that START there the batch may hold only the first few.  A provider fetched AT that position is the best of
+    an incomplete group: the batch must not raise on it (here: D's damaged tag, when G in the next batch wins) -- and must still raise,
+    one batch later, when the error is real (the same stream without G: the oracle raises too)."""
+    st = _cut_stream(True)
+    ora = O.pileup(st, use_md=True, skip_zero=True)
+    ref, pos, rb = _batched_refbase(ctx, _pieces(st, 1000), 4096, True)
+    keep = ora.cov > 0
+    assert np.array_equal(pos, ora.pos[keep].astype(np.int64)) and np.array_equal(rb, ora.refbase[keep])
+    st = _cut_stream(False)
+    with pytest.raises(O.OracleError) as oe:
+        O.pileup(st, use_md=True, skip_zero=True)
+    assert oe.value.code == O.ORC_EMD
+    with pytest.raises(L.BiodGpuError) as ge:
+        _batched_refbase(ctx, _pieces(st, 1000), 4096, True)
+    assert ge.value.code == L.BGP_EMD
+    ctx.reset()
+
+
 @pytest.mark.parametrize("skip", [True, False])
 @pytest.mark.parametrize("name,batch", [("illu_20_chunk.bam", 4096), ("b7_295_chunk.bam", 20_000), ("b7_295_chunk.bam", 70_000), ("ex1_header.bam", 30_000), ("tags.bam", 8192)])
 def test_batched_staging_reference_base_fixtures(ctx, data_dir, name, batch, skip):
