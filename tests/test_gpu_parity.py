@@ -2155,6 +2155,39 @@ def test_python_windows_as_views(ctx, data_dir):
     assert k == len(copies) and k > 5
 
 
+def test_views_outlive_the_windows_that_replace_their_buffers(ctx):
+    """include/biodgpu.h: the memory behind a returned pointer stays mapped until bgp_reset / bgp_destroy -- a view kept too long reads
+    stale bytes, never freed memory.  Views of small windows are kept while ever larger windows (columns and entries) make the ctx replace
+    its pinned buffers several times over; every old view must still be readable and hold what it held."""
+    cfg = make_cfg(n_reads=60000, n_ref=1, ref_len=120_000, read_len=100, profile=1, seed=91)
+    st = host_stream(cfg)
+    stage(ctx, st)
+    ctx.pileup_run()
+    kept = []
+    for wp in (64, 700, 9000, 60_000, 120_000):            # (each window needs a buffer ~10 x the one before: five generations of pinned memory)
+        gen = ctx.pileup_windows(L.BGP_PILEUP_COLUMNS, want_entries=True, window_positions=wp, copy=False)
+        w = next(gen)
+        kept.append((w.columns, w.columns.copy(), w.entries, w.entries.copy()))
+        gen.close()
+        for view, was, ev, ewas in kept:                    # (the same bytes as when the view was taken, or stale ones of a later window of the same buffer: readable either way)
+            assert view.shape == was.shape and ev.shape == ewas.shape
+            _ = int(view["coverage"].sum()) + int(ev["read_ordinal"].sum())
+    assert np.array_equal(kept[-1][0], kept[-1][1]) and np.array_equal(kept[-1][2], kept[-1][3])
+
+
+def test_batched_staging_then_a_one_shot_load_on_the_same_ctx(ctx, data_dir):
+    """The pinned and device buffers a batched pass parks in the ctx are given back when the ctx stages a stream another way; one-shot and
+    batched passes alternate on one ctx with equal results."""
+    _, st = bamio.read_bam(os.path.join(data_dir, "ex1_header.bam"))
+    ora = O.pileup(st)
+    for _round in range(3):
+        cov = np.concatenate([w.columns["coverage"][w.columns["coverage"] > 0] for w in ctx.batched_windows(_pieces(st, 50_000), 150_000)])
+        assert np.array_equal(cov, ora.cov)
+        stage(ctx, st)                                      # bgp_reset + bgp_push_inflated: the parked batch buffers go
+        info = ctx.pileup_run()
+        assert (info.n_columns, info.sum_coverage) == (ora.n_columns, ora.sum_coverage)
+
+
 @pytest.mark.parametrize("name,rid,beg,end", [("ex1_header.bam", 0, 100, 900), ("ex1_header.bam", 1, 0, 1500), ("tags.bam", 0, 0, 100000)])
 def test_entries_after_a_region_filter(ctx, data_dir, name, rid, beg, end):
     """The record table is compacted by bgp_filter_region (K1's side array of first CIGAR ops is not): columns AND entries of
