@@ -133,7 +133,7 @@ int emit_window(bgp_ctx* c, uint32_t run_idx, uint64_t a, uint64_t b, int want_e
     }
     if (pf_on && b < r.end_pos) {                       // the window behind this one, as long as this one
         const uint64_t nb = std::min<uint64_t>(r.end_pos, b + np);
-        if (!c->pf.stream) { BGP_HIP(hipStreamCreateWithFlags(&c->pf.stream, hipStreamNonBlocking)); BGP_HIP(hipEventCreateWithFlags(&c->pf.done, hipEventDisableTiming)); }
+        if (!c->pf.done) BGP_HIP(hipEventCreateWithFlags(&c->pf.done, hipEventDisableTiming));
         BGP_TRY(c->h_cols2.reserve((nb - b) * sizeof(bgp_column)));
         { TimedRegion tw(c, "d2h_window_columns", (nb - b) * sizeof(bgp_column), c->pf.stream);
         BGP_HIP(hipMemcpyAsync(c->h_cols2.p, c->d_columns.as<bgp_column>() + r.column_base + (b - r.start_pos), (nb - b) * sizeof(bgp_column), hipMemcpyDeviceToHost, c->pf.stream)); }
@@ -236,9 +236,21 @@ int bgp_init(int device, bgp_ctx** out) {
     bgp_ctx* c = new (std::nothrow) bgp_ctx();
     if (!c) return BGP_ENOMEM;
     c->device = device;
-    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return BGP_EDEVICE; }
+    // The ctx's FOUR streams, made here and in this order: the device hands its (four) hardware queues to streams as they come, and a
+    // fifth stream shares a queue with an earlier one -- a copy then waits behind whatever kernel that one is running.  Made where they
+    // were first needed, a bgp_load_bam_device AFTER a batched pass found its uploads sharing a queue with k_inflate: 118 ms a load
+    // against 82 (scratch/e2e_gap3.py).  Kernels; every upload (the file's chunks, a batch's bytes); the inflate's two, the second of which
+    // also carries the next window's columns to the host while the caller looks at this one (never while a file is loading).
+    hipStream_t* four[4] = {&c->stream, &c->io_up, &c->io_inf[0], &c->io_inf[1]};
+    for (hipStream_t* s : four)
+        if (hipStreamCreateWithFlags(s, hipStreamNonBlocking) != hipSuccess) {
+            *s = nullptr;
+            for (hipStream_t* x : four) if (*x) (void)hipStreamDestroy(*x);
+            delete c; return BGP_EDEVICE;
+        }
     c->own_stream = true;
-    if (c->d_status.reserve(64) < 0) { (void)hipStreamDestroy(c->stream); delete c; return BGP_ENOMEM; }
+    c->pf.stream = c->io_inf[1];
+    if (c->d_status.reserve(64) < 0) { for (hipStream_t* x : four) (void)hipStreamDestroy(*x); delete c; return BGP_ENOMEM; }
     *out = c;
     return BGP_OK;
     BGP_API_CATCH((bgp_ctx*)nullptr)
@@ -262,7 +274,6 @@ void bgp_destroy(bgp_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     prefetch_cancel(c);
     if (c->pf.done) (void)hipEventDestroy(c->pf.done);
-    if (c->pf.stream) (void)hipStreamDestroy(c->pf.stream);
     if (c->io_up) (void)hipStreamDestroy(c->io_up);
     for (hipStream_t x : c->io_inf) if (x) (void)hipStreamDestroy(x);
     batch_release(c);

@@ -59,7 +59,7 @@ void batch_unpark(bgp_ctx* c) {
 void batch_release(bgp_ctx* c) {
     Batch* b = c->batch;
     if (!b) return;
-    if (b->copy_stream) { (void)hipStreamSynchronize(b->copy_stream); (void)hipStreamDestroy(b->copy_stream); }
+    if (b->copy_stream) (void)hipStreamSynchronize(b->copy_stream);      // (the ctx's upload stream: not this pass's to destroy)
     // (the pinned buffers and the two device buffers go back to the ctx: the next bgp_batch_begin takes them again -- pinning
     // 2 x 256 MiB anew cost ~70 ms, 40 % of a 10 M-read stream's whole pass)
     for (int q = 0; q < Batch::NH; ++q) {
@@ -259,7 +259,7 @@ int bgp_batch_begin(bgp_ctx* c, uint64_t batch_bytes, int want_entries, uint32_t
     b->batch_bytes = std::max<uint64_t>(batch_bytes ? batch_bytes : (256ull << 20), 1ull << 12);
     b->reserve = std::max<uint64_t>(b->batch_bytes / 8, 1ull << 16);         // room for the carry in front of a batch's new bytes (grown when a carry is longer)
     b->want_entries = want_entries; b->window = window_positions ? window_positions : 65536u;
-    BGP_HIP(hipStreamCreateWithFlags(&b->copy_stream, hipStreamNonBlocking));
+    b->copy_stream = c->io_up;                       // the ctx's upload stream (api.cpp, bgp_init: four streams, a hardware queue each)
     for (int q = 0; q < Batch::NH; ++q) {
         BGP_HIP(hipEventCreateWithFlags(&b->host_free[q], hipEventDisableTiming));
         BGP_HIP(hipEventRecord(b->host_free[q], b->copy_stream));

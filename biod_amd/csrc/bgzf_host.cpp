@@ -256,11 +256,10 @@ int bgzf_load_bam_device(bgp_ctx* c, const char* path) {
     std::unique_ptr<std::atomic<int>[]> ev_ready(new std::atomic<int>[n_chunks]);
     struct Events { std::vector<hipEvent_t>& e; ~Events() { for (hipEvent_t x : e) if (x) (void)hipEventDestroy(x); } } events_guard{ev};      // (in front of the loop that makes them: an early return inside it lets go of the ones made so far)
     for (uint64_t k = 0; k < n_chunks; ++k) { ev_ready[k].store(0); if (hipEventCreateWithFlags(&ev[k], hipEventDisableTiming) != hipSuccess) { ev[k] = nullptr; c->last_error = "hipEventCreate failed"; return BGP_EDEVICE; } }
-    // ONE stream for all uploads and one for the inflate (the ctx keeps them): a stream per reader and four for the batches were more
-    // streams than the device has hardware queues, and an upload that shared a queue with a running k_inflate waited for it to end --
-    // the uploads stalled for the 50 ms of the first batch; creating a dozen streams also took the load's first 25 ms.
-    if (!c->io_up && hipStreamCreateWithFlags(&c->io_up, hipStreamNonBlocking) != hipSuccess) { c->io_up = nullptr; c->last_error = "hipStreamCreate failed"; return BGP_EDEVICE; }
-    for (hipStream_t& x : c->io_inf) if (!x && hipStreamCreateWithFlags(&x, hipStreamNonBlocking) != hipSuccess) { x = nullptr; c->last_error = "hipStreamCreate failed"; return BGP_EDEVICE; }
+    // ONE stream for all uploads and two for the inflate, the ctx's own (bgp_init makes them, in front of any other stream: a stream per
+    // reader and four for the batches were more streams than the device has hardware queues, and an upload that shared a queue with a
+    // running k_inflate waited for it to end -- the uploads stalled for the 50 ms of the first batch; creating a dozen streams also took
+    // the load's first 25 ms).
     std::mutex up_mu;                                                      // (a copy and its event are enqueued together)
     auto reader_ev = [&](int t) {      // reader() with the upload's event made known
         if (hipSetDevice(c->device) != hipSuccess) { hip_rc.store(BGP_EDEVICE); }

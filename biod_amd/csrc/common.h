@@ -120,7 +120,7 @@ struct bgp_ctx {
     std::vector<uint64_t> hints;                      // staged offsets where, by the caller's word (first_record_uoffset), a record starts: candidates for the boundary guesser, verified like its own
     DevBuf d_seg_hint;
     DevBuf d_stream_own;                              // device copy of pushed bytes
-    hipStream_t io_up = nullptr, io_inf[2] = {nullptr, nullptr};    // bgp_load_bam_device: the uploads' stream and the inflate's two (made once: a stream costs milliseconds to create, and more streams than the device has hardware queues share them -- copies then wait behind a running kernel)
+    hipStream_t io_up = nullptr, io_inf[2] = {nullptr, nullptr};    // the uploads' stream (a file's chunks, a batch's bytes) and the inflate's two, the second also the window prefetch's: made by bgp_init right behind `stream` -- more streams than the device has hardware queues share them, and copies then wait behind a running kernel
     DevBuf d_comp, d_inf_blk; HostBuf h_ring, h_stream_copy;         // device inflate: compressed file, block descriptors + status, pinned read ring
     const uint8_t* d_stream = nullptr; uint64_t stream_len = 0;
     bool stream_on_device = false;                    // d_stream valid

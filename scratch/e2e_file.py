@@ -1,6 +1,8 @@
 """File-E2E phases on the GPU box: generator stream -> BGZF file -> bgp_load_bam (+BGP_VERBOSE split) -> flush -> pileup.
 Usage: BGP_VERBOSE=1 python scratch/e2e_file.py [n_reads]"""
 import os, sys, time
+if os.environ.get("E2E_IMPORT_TORCH"):      # torch first: its bundled HIP 7.0 runtime (torch/lib/libamdhip64.so, SONAME libamdhip64.so.7) is then the one libbiodgpu.so binds to
+    import torch; torch.cuda.init(); print("torch imported:", torch.version.hip, flush=True)
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
 from concurrent.futures import ThreadPoolExecutor
 from biod_amd import bamio
