@@ -1263,6 +1263,42 @@ __device__ uint64_t wave_strnlen(const uint8_t* t, uint64_t lim, int lane) {
     return lim;
 }
 
+// BamRead.opIndex("MD") (find_md above) by a whole wave, every lane the same steps; a string's length by the wave (a long read's tag is
+// ten thousand chars: a lane's strnlen8 is 1 250 dependent loads).  1: found (*val, *len); 0: no MD tag / not a string; -1: malformed aux data.
+__device__ int find_md_wave(const uint8_t* s, const bgp_record& r, int lane, const uint8_t** val, uint64_t* len) {
+    const uint32_t l_name = r.bin_mq_nl & 0xFFu, n_cig = r.flag_nc & 0xFFFFu;
+    const uint64_t end = r.rec_off + 4 + ld_u32(s + r.rec_off);
+    const uint64_t tags = r.rec_off + 36 + l_name + 4ull * n_cig + (uint64_t)((r.l_seq + 1) / 2) + (uint64_t)r.l_seq;
+    if (tags > end) return -1;
+    const uint8_t* t = s + tags;
+    const uint64_t tl = end - tags;
+    uint64_t off = 0;
+    while (tl >= 4 && off + 1 < tl) {
+        const bool match = t[off] == 'M' && t[off + 1] == 'D';
+        off += 2;
+        if (off >= tl) return -1;
+        const uint8_t ty = t[off++];
+        if (match) {
+            if (ty != 'Z' && ty != 'H') return 0;
+            *val = t + off; *len = wave_strnlen(t + off, tl - off, lane);
+            return 1;
+        }
+        if (ty == 'Z' || ty == 'H') { off += wave_strnlen(t + off, tl - off, lane); if (off >= tl) return -1; ++off; }
+        else if (ty == 'B') {
+            if (off + 5 > tl) return -1;
+            const uint8_t et = t[off];
+            const int es = (et == 'c' || et == 'C') ? 1 : (et == 's' || et == 'S') ? 2 : (et == 'i' || et == 'I' || et == 'f') ? 4 : -1;
+            if (es < 0) return -1;
+            off += 5 + (uint64_t)es * ld_u32(t + off + 1);
+        } else {
+            const int es = (ty == 'A' || ty == 'c' || ty == 'C') ? 1 : (ty == 's' || ty == 'S') ? 2 : (ty == 'i' || ty == 'I' || ty == 'f') ? 4 : -1;
+            if (es < 0) return -1;
+            off += (uint64_t)es;
+        }
+    }
+    return 0;
+}
+
 // k6_emit's check of a provider -- dna_length(tag) against dna_length_by_cigar -- for a LONG read, by a whole wave.  The tag's tokens are
 // found without walking it: a char starts a number when it is a digit behind a non-digit, a deletion when it is '^' (its bases: the
 // upper-case run behind it, md/parse.d:85-109), and is a mismatch when it is anything else outside such a run; what the lazy range yields
@@ -1288,41 +1324,10 @@ __global__ __launch_bounds__(64) void k6_verify_long(const uint8_t* s, uint64_t 
         q = wsum(q); dl = wsum(dl);
     }
     const unsigned long long by_cigar = q + dl > (unsigned long long)MD_LMASK ? (unsigned long long)MD_LMASK : q + dl;
-    // BamRead.opIndex("MD") (find_md above), every lane the same steps; a string's length by the wave
+    // BamRead.opIndex("MD") by the wave (find_md_wave above)
     bool flag = false, found = false;
     const uint8_t* md = nullptr; uint64_t mdn = 0;
-    {
-        const uint64_t end = r.rec_off + 4 + ld_u32(s + r.rec_off);
-        const uint64_t tags = r.rec_off + 36 + l_name + 4ull * n_cig + (uint64_t)((r.l_seq + 1) / 2) + (uint64_t)r.l_seq;
-        if (tags > end) flag = true;
-        else {
-            const uint8_t* t = s + tags;
-            const uint64_t tl = end - tags;
-            uint64_t off = 0;
-            while (tl >= 4 && off + 1 < tl) {
-                const bool match = t[off] == 'M' && t[off + 1] == 'D';
-                off += 2;
-                if (off >= tl) { flag = true; break; }
-                const uint8_t ty = t[off++];
-                if (match) {
-                    if (ty == 'Z' || ty == 'H') { md = t + off; mdn = wave_strnlen(t + off, tl - off, lane); found = true; }
-                    break;
-                }
-                if (ty == 'Z' || ty == 'H') { off += wave_strnlen(t + off, tl - off, lane); if (off >= tl) { flag = true; break; } ++off; }
-                else if (ty == 'B') {
-                    if (off + 5 > tl) { flag = true; break; }
-                    const uint8_t et = t[off];
-                    const int es = (et == 'c' || et == 'C') ? 1 : (et == 's' || et == 'S') ? 2 : (et == 'i' || et == 'I' || et == 'f') ? 4 : -1;
-                    if (es < 0) { flag = true; break; }
-                    off += 5 + (uint64_t)es * ld_u32(t + off + 1);
-                } else {
-                    const int es = (ty == 'A' || ty == 'c' || ty == 'C') ? 1 : (ty == 's' || ty == 'S') ? 2 : (ty == 'i' || ty == 'I' || ty == 'f') ? 4 : -1;
-                    if (es < 0) { flag = true; break; }
-                    off += (uint64_t)es;
-                }
-            }
-        }
-    }
+    { const int f = find_md_wave(s, r, lane, &md, &mdn); flag = f < 0; found = f > 0; }
     unsigned long long lt = 0;
     if (!flag && found) {
         if (mdn > VMD_CAP) flag = true;
@@ -1450,21 +1455,166 @@ template <bool LONGS> __global__ __launch_bounds__(64) void k6_emit(const uint8_
     }
 }
 
-__global__ __launch_bounds__(64) void k6_ck_build(const uint8_t* s, const bgp_record* rec, const LongNode* longs, uint32_t n_long, DnaCk* ck, uint32_t* piece_node) {
-    // a WAVE per long chunk with one lane at work: the walk is a chain of dependent loads, a few thousand chunks are all a
-    // stream of long reads has, and 64 of them in the lanes of one wave ran one after the other's divergent steps
-    const uint32_t i = blockIdx.x;
-    if (threadIdx.x || i >= n_long) return;
-    const LongNode L = longs[i];
-    const uint32_t pieces = (L.count + DNA_CK - 1) / DNA_CK;
-    for (uint32_t j = 0; j < pieces; ++j) piece_node[L.ck_base + j] = i;
-    DnaState st; bool err, bad;
+// The checkpoints of ONE long chunk by a lane's walk from the read's first char (the first version of k6_ck_build, and still what a tag
+// the wave cannot vouch for gets): ~300 instructions an MD operation, ~8 000 operations a 30 kb read -- 9 ms of cfg5's use_md_tag.
+__device__ void ck_build_serial(const uint8_t* s, const bgp_record* rec, const LongNode& L, uint32_t i, uint32_t pieces, DnaCk* ck) {
+    DnaState st; bool err;
     dna_begin(st, s, rec[L.rec], &err, true);
     if (err) return;                                              // the pool is zero-filled: every piece of this node stays dead
-    (void)bad;
     for (uint32_t j = 0; j < pieces; ++j) {
         dna_skip(st, L.from + j * DNA_CK);
         if (!st.live) return;                                     // the range ends (or stalls) before this piece
+        dna_save(st, s, i, ck[L.ck_base + j]);
+    }
+}
+
+__device__ __forceinline__ uint32_t wave_incl_u32(uint32_t v, int lane) { for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)v, d, 64); if (lane >= d) v += o; } return v; }
+__device__ __forceinline__ int32_t wave_incl_max_i32(int32_t v, int lane) { for (int d = 1; d < 64; d <<= 1) { const int32_t o = __shfl_up(v, d, 64); if (lane >= d) v = max(v, o); } return v; }
+
+// A WAVE per long chunk.  The state of dna(read)'s lazy range at char index t (md/reconstruct.d:98-182) is a function of two numbers: the
+// MD token that yields char t, and the M / = / X bases the tokens in front of it have taken from the query.  So instead of walking there:
+//   * the tag is staged in LDS and cut into UNITS by the wave, 64 chars a step -- a number (its value: that many chars yielded, that many
+//     bases asked of the query), a mismatch (1, 1), a deleted base (1, 0); md/parse.d:85-109's tokens are a number, a char outside a
+//     deletion, or '^' with the upper-case run behind it -- and prefix sums of (yield, asked) over the units give, for every checkpoint
+//     index from + j * 512, the token that holds it;
+//   * prefix sums of the CIGAR's M / = / X and query-consuming lengths turn "bases asked so far" into the query cursor (op, in_op, q) that
+//     q_settle would have reached (md/reconstruct.d:58-96);
+//   * a LANE per checkpoint then builds the parser at its token's first char -- e / back / rem from the ordinary mdf_init (parse.d:23-33: the
+//     backward pre-parse touches the last token only), front by md_cache_front at the token, `cur = front; mdf_pop_front` as the walk does
+//     between two operations -- and finishes inside the token with the walk's own dna_skip.
+// What the wave cannot vouch for goes to the serial walk: a tag longer than the staging buffer, a number of more than nine digits, an
+// empty deletion (the range stalls there), a last operation the backward parse cuts differently, a token behind the backward parse's cut.
+// Pieces behind a stall stay dead as the walk leaves them: a token in front of which the tag has asked for more bases than the CIGAR has.
+constexpr uint32_t CKP_MAX = 256, CK_NONE = 0xFFFFFFFFu;
+__device__ unsigned int g_ck_serial;             // long chunks that took the serial walk (read and reset by the host under BGP_VERBOSE: the tests look at it)
+__global__ __launch_bounds__(64) void k6_ck_build(const uint8_t* s, uint64_t stream_len, const bgp_record* rec, const LongNode* longs, uint32_t n_long, DnaCk* ck, uint32_t* piece_node, int serial_only) {
+    __shared__ __attribute__((aligned(16))) uint8_t smd[VMD_CAP + 32];
+    __shared__ uint32_t s_tok[CKP_MAX], s_y[CKP_MAX], s_d[CKP_MAX], s_op[CKP_MAX], s_in[CKP_MAX], s_q[CKP_MAX];
+    const uint32_t i = blockIdx.x;
+    const int lane = threadIdx.x;
+    if (i >= n_long) return;
+    const LongNode L = longs[i];
+    const uint32_t pieces = (L.count + DNA_CK - 1) / DNA_CK;
+    for (uint32_t j = (uint32_t)lane; j < pieces; j += 64) piece_node[L.ck_base + j] = i;
+    const bgp_record r = rec[L.rec];
+    const uint8_t* md = nullptr; uint64_t mdn = 0;
+    const int f = find_md_wave(s, r, lane, &md, &mdn);
+    if (f <= 0 || mdn == 0) return;                               // malformed aux data, no tag, an empty tag: the range yields nothing, every piece stays dead
+    bool flag = serial_only != 0 || mdn > VMD_CAP || pieces > CKP_MAX;
+    const uint32_t n = (uint32_t)mdn;
+    const uint32_t l_name = r.bin_mq_nl & 0xFFu, n_cig = r.flag_nc & 0xFFFFu;
+    const uint8_t* cg = s + r.rec_off + 36 + l_name;
+    uint64_t m_total = 0, q_total = 0;
+    if (!flag) {
+        const uint64_t md_off = (uint64_t)(md - s);
+        for (uint32_t o = 16u * (uint32_t)lane; o < n + 16u; o += 1024u) {
+            uint4 w = make_uint4(0u, 0u, 0u, 0u);
+            if (o < n) {
+                if (md_off + o + 16 <= stream_len) __builtin_memcpy(&w, md + o, 16);
+                else { uint8_t b[16]; for (uint32_t k = 0; k < 16u; ++k) b[k] = o + k < n ? md[o + k] : (uint8_t)0; __builtin_memcpy(&w, b, 16); }
+            }
+            *reinterpret_cast<uint4*>(smd + o) = w;
+        }
+        for (uint32_t j = (uint32_t)lane; j < CKP_MAX; j += 64) { s_tok[j] = CK_NONE; s_y[j] = 0u; s_d[j] = CK_NONE; s_op[j] = CK_NONE; s_in[j] = 0u; s_q[j] = 0u; }
+        __syncthreads();
+        // ---- the tag's units and the token that holds each checkpoint index
+        uint32_t Y = 0, D = 0; int32_t lnu = -1;                  // chars yielded, bases asked, the last char that is not an upper-case letter: in front of this step
+        for (uint32_t b0 = 0; b0 < n; b0 += 64) {
+            const uint32_t c_i = b0 + (uint32_t)lane;
+            const bool in = c_i < n;
+            const uint8_t c = in ? smd[c_i] : (uint8_t)0;         // (behind the tag: a NUL, not upper-case)
+            const bool up = is_upper_(c);
+            const int32_t nu = wave_incl_max_i32(max(lnu, in && !up ? (int32_t)c_i : -1), lane);      // the last non-upper char at or in front of this one
+            const bool in_del = up && nu >= 0 && smd[nu] == '^';
+            uint32_t y = 0, d = 0;
+            if (in) {
+                if (c == '^') { if (!is_upper_(smd[c_i + 1]) || c_i + 1 >= n) flag = true; }       // an empty deletion: the range stalls
+                else if (is_digit_(c)) {
+                    if (c_i == 0 || !is_digit_(smd[c_i - 1])) {
+                        uint32_t val = 0, k = 0;
+                        while (c_i + k < n && is_digit_(smd[c_i + k])) { if (++k > 9u) { flag = true; break; } val = val * 10u + (uint32_t)(smd[c_i + k - 1] - '0'); }
+                        if (val > (1u << 24)) flag = true;        // (no read has that many bases: the walk decides what such a tag means)
+                        else y = d = val;
+                    }
+                } else if (in_del) y = 1;
+                else y = d = 1;
+            }
+            const uint32_t iy = wave_incl_u32(y, lane), id = wave_incl_u32(d, lane);
+            const uint32_t yex = Y + iy - y, dex = D + id - d;
+            if (y && yex + y > L.from) {
+                const uint32_t lo = yex <= L.from ? 0u : (yex - L.from + DNA_CK - 1) / DNA_CK;
+                const uint32_t hi = min(pieces, (yex + y - L.from + DNA_CK - 1) / DNA_CK);      // from + j * 512 < yex + y
+                for (uint32_t j = lo; j < hi; ++j) {
+                    s_tok[j] = in_del ? (uint32_t)nu : c_i;
+                    s_y[j] = in_del ? yex - (c_i - (uint32_t)nu - 1u) : yex;
+                    s_d[j] = dex;
+                }
+            }
+            Y += (uint32_t)__shfl((int)iy, 63, 64); D += (uint32_t)__shfl((int)id, 63, 64);
+            lnu = __shfl(nu, 63, 64);
+            if (Y > (1u << 30) || D > (1u << 30)) flag = true;
+            if (__ballot(flag)) break;
+        }
+        if (lane == 0 && n) {      // the last operation as the backward parse cuts it (parse.d:111-131): a number, a single mismatch, or '^' with upper-case bases to the end
+            const uint8_t last = smd[n - 1];
+            if (!is_digit_(last) && !(n == 1 || is_digit_(smd[n - 2]))) {
+                uint32_t j = n - 1; bool upper = true;
+                while (smd[j] != '^') { upper = upper && is_upper_(smd[j]); if (j == 0) { upper = false; break; } --j; }
+                if (!upper || j == n - 1) flag = true;
+            }
+        }
+        flag = __ballot(flag) != 0;
+        __syncthreads();
+        // ---- the CIGAR: where the query cursor stands once `asked` M / = / X bases have been taken
+        if (!flag) {
+            for (uint32_t k0 = 0; k0 < n_cig; k0 += 64) {
+                const uint32_t k = k0 + (uint32_t)lane;
+                const uint32_t raw = k < n_cig ? ld_u32(cg + 4ull * k) : 0u;
+                const uint32_t len = raw >> 4;
+                const uint32_t ml = cig_qc(raw) && cig_rc(raw) ? len : 0u, ql = cig_qc(raw) ? len : 0u;
+                // (an op is below 2^28: 64 of them fit a 32-bit scan)
+                const uint32_t im = wave_incl_u32(ml, lane), iq = wave_incl_u32(ql, lane);
+                const uint64_t mex = m_total + im - ml, qex = q_total + iq - ql;
+                if (ml) {
+                    uint32_t lo = 0, hi = pieces;                 // the first checkpoint whose `asked` is not below mex (s_d is non-decreasing; the dead ones, at the end, hold the maximum)
+                    while (lo < hi) { const uint32_t m = (lo + hi) >> 1; if ((uint64_t)s_d[m] < mex) lo = m + 1; else hi = m; }
+                    for (uint32_t j = lo; j < pieces && (uint64_t)s_d[j] < mex + ml; ++j) { s_op[j] = k; s_in[j] = (uint32_t)((uint64_t)s_d[j] - mex); s_q[j] = (uint32_t)(qex + ((uint64_t)s_d[j] - mex)); }
+                }
+                m_total += (uint32_t)__shfl((int)im, 63, 64); q_total += (uint32_t)__shfl((int)iq, 63, 64);
+            }
+            __syncthreads();
+        }
+    }
+    // ---- a lane a checkpoint
+    MdRes m0;
+    if (!flag) {
+        mdf_init(m0, md, n, true);
+        if (md_empty(m0)) return;                                 // (only zero matches: nothing is yielded)
+        bool behind = false;
+        for (uint32_t j = (uint32_t)lane; j < pieces; j += 64) behind = behind || (s_tok[j] != CK_NONE && s_tok[j] > m0.e);
+        flag = __ballot(behind) != 0;                             // a token behind the backward parse's cut: not a tag this code reasons about
+    }
+    if (flag) { if (lane == 0) { atomicAdd(&g_ck_serial, 1u); ck_build_serial(s, rec, L, i, pieces, ck); } return; }
+    for (uint32_t j = (uint32_t)lane; j < pieces; j += 64) {
+        const uint32_t T = s_tok[j];
+        if (T == CK_NONE) continue;                               // the range ends before this piece
+        const uint64_t asked = s_d[j];
+        if (asked > m_total) continue;                            // the range has stalled in front of this token (a match or a mismatch met an empty query)
+        DnaState st;
+        st.m = m0; st.del_i = 0; st.n = s_y[j]; st.live = true;
+        QIter& q = st.q; q.cg = cg; q.sq = cg + 4ull * n_cig; q.n_cig = n_cig;
+        if (asked == m_total) { q.op = n_cig; q.in_op = 0; q.q = (uint32_t)q_total; q.empty = true; }
+        else { q.op = s_op[j]; q.in_op = s_in[j]; q.q = s_q[j]; q.empty = false; }
+        q_load(q);
+        if (T == m0.e) {                                          // the tag's LAST token: the one the backward pre-parse took (parse.d:57-69: the front hands it over, then the range is empty)
+            st.m.b = m0.e; st.m.front = m0.back; st.m.rem = 0; st.cur = m0.back;
+        } else {
+            st.m.b = T;
+            if (!md_cache_front(st.m)) continue;
+            st.cur = st.m.front; mdf_pop_front(st.m);
+        }
+        dna_skip(st, L.from + j * DNA_CK);
+        if (!st.live) continue;
         dna_save(st, s, i, ck[L.ck_base + j]);
     }
 }
@@ -1711,9 +1861,17 @@ int k6_reference_bases(bgp_ctx* c, int skip_zero, uint32_t run_first, uint32_t r
                 BGP_HIP(hipMemsetAsync(ck, 0, (size_t)ctr[1] * sizeof(DnaCk), c->stream));
                 const LongNode* longs = (const LongNode*)(c->d_md_long.as<uint8_t>() + 16);
                 TimedRegion t(c, "k6_emit_long", (uint64_t)ctr[1] * DNA_CK);
-                hipLaunchKernelGGL(k6_ck_build, dim3(ctr[0]), dim3(64), 0, c->stream, c->d_stream, c->d_rec.as<bgp_record>(), longs, ctr[0], ck, piece_node);
+                static const int ck_serial = getenv("BGP_MD_CK_SERIAL") && atoi(getenv("BGP_MD_CK_SERIAL")) != 0;      // (tests: the walk a lane did before the wave's prefix sums)
+                hipLaunchKernelGGL(k6_ck_build, dim3(ctr[0]), dim3(64), 0, c->stream, c->d_stream, c->stream_len, c->d_rec.as<bgp_record>(), longs, ctr[0], ck, piece_node, ck_serial);
                 hipLaunchKernelGGL(k6_emit_long, dim3((ctr[1] + 63) / 64), dim3(64), 0, c->stream, c->d_stream, c->d_rec.as<bgp_record>(), longs, ck, piece_node, ctr[1], c->d_refbase.as<uint8_t>());
                 BGP_HIP(hipGetLastError());
+                if (getenv("BGP_VERBOSE")) {
+                    unsigned int ser = 0, zero = 0;
+                    BGP_HIP(hipStreamSynchronize(c->stream));
+                    BGP_HIP(hipMemcpyFromSymbol(&ser, HIP_SYMBOL(g_ck_serial), sizeof ser));
+                    BGP_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_ck_serial), &zero, sizeof zero));
+                    fprintf(stderr, "[biodgpu] MD checkpoints: %u long chunk(s), %u piece(s), %u chunk(s) walked serially\n", ctr[0], ctr[1], ser);
+                }
             }
             for (uint32_t k : ks) {
                 if (po[k].flagged) seq.push_back(k);

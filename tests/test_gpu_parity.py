@@ -1452,6 +1452,94 @@ def test_reference_base_long_chunks_in_pieces(ctx, seed):
     _check_refbase(ctx, st, mode=L.BGP_MAKE_PILEUP, skip_zero=False, start_from=a, end_at=b)
 
 
+def _long_md_read_odd(rng, name, ref, pos, length, kind):
+    """A long read whose tag is cut into tokens the unusual way, or damaged: what k6_ck_build's prefix sums must either reproduce or hand to
+    the serial walk.  kind: plain | big_match (one M, one number: checkpoints inside a token) | long_dels (deletions of hundreds of bases:
+    checkpoints inside a deletion) | del_last (the tag ends with a deletion: the backward parse's token) | mm_last (... with a mismatch) |
+    zero_last (... with a 0 behind a mismatch) | lower (lower-case mismatches and one lower-case deleted base) | eq_n (= and N among the
+    mismatches) | empty_del | tail (two letters at the end) | digits (a number of eleven digits) | over | short | lead_zero ("0" first)."""
+    ops, md, run, seq = [], "", 0, []
+    if kind == "big_match":
+        seq = ["".join("ACGT"[int(x)] for x in rng.integers(0, 4, length))]
+        return bamio.pack_record(name, seq[0], [(length, "M")], ref_id=ref, pos=pos, tags=bamio.tag_z("MD", str(length)))
+    left = length
+    mm = "acgt" if kind == "lower" else ("ACGT=N" if kind == "eq_n" else "ACGT")
+    while left > 0:
+        m = int(min(left, rng.integers(10, 80)))
+        ops.append((m, "M")); left -= m
+        for _ in range(m):
+            if rng.random() < 0.04:
+                md += str(run) + mm[int(rng.integers(0, len(mm)))]; run = 0
+            else:
+                run += 1
+        seq.append("".join("ACGT"[int(x)] for x in rng.integers(0, 4, m)))
+        if left > 0:
+            if rng.random() < 0.5:
+                k = int(rng.integers(1, 4)); ops.append((k, "I")); seq.append("".join("ACGT"[int(x)] for x in rng.integers(0, 4, k)))
+            else:
+                k = int(rng.integers(200, 900)) if kind == "long_dels" and rng.random() < 0.04 else int(rng.integers(1, 5))      # (a few: the tag has to fit the wave's 32 KiB of staging)
+                ops.append((k, "D"))
+                md += str(run) + "^" + "".join("ACGT"[int(x)] for x in rng.integers(0, 4, k)); run = 0
+    if kind == "del_last":
+        ops.append((3, "D")); md += str(run) + "^ACG"
+    elif kind == "mm_last":
+        md += str(max(run - 1, 0)) + "T" if run else "5T"
+    elif kind == "zero_last":
+        md += str(max(run - 1, 0)) + "T0" if run else "T0"
+    else:
+        md += str(run)
+    if kind == "lower" and "^A" in md:
+        md = md.replace("^A", "^a", 1)
+    elif kind == "empty_del":
+        k = md.find("^", len(md) // 2); md = md[:k + 1] + md[k + 1:].lstrip("ACGT") if k >= 0 else md + "^5"
+    elif kind == "tail":
+        md += "AC"
+    elif kind == "digits":
+        k = len(md) // 2
+        while k < len(md) and not (md[k].isdigit() and not md[k - 1].isdigit()):
+            k += 1
+        md = md[:k] + "0000000000" + md[k:]           # (the number that starts here, with ten zeros in front: the same value in more than nine digits)
+    elif kind == "over":
+        md += "A999"
+    elif kind == "short":
+        md = md[:len(md) // 3]
+    elif kind == "lead_zero":
+        md = "0" + md
+    return bamio.pack_record(name, "".join(seq), ops, ref_id=ref, pos=pos, tags=bamio.tag_z("XA", "q" * int(rng.integers(0, 9))) + bamio.tag_z("MD", md))
+
+
+@pytest.mark.parametrize("kind", ["plain", "big_match", "long_dels", "del_last", "mm_last", "zero_last", "lower", "eq_n", "empty_del", "tail", "digits", "over", "short", "lead_zero"])
+def test_reference_base_long_chunks_token_shapes(ctx, kind, capfd, monkeypatch):
+    """k6_ck_build seeds a long chunk's checkpoints from prefix sums over the tag's tokens instead of walking there: every shape of token at
+    a checkpoint (inside a number, inside a deletion, the last token -- the backward parse's --, zero matches around it) and every kind of
+    tag the wave does not vouch for (those take the serial walk) against the oracle, which parses as md/parse.d does."""
+    rng = np.random.default_rng(7100 + sum(map(ord, kind)))
+    recs, pos = [], 0
+    for i in range(12):
+        length = int(rng.integers(5000, 16000)) if i % 4 != 3 else int(rng.integers(30, 200))
+        recs.append(_long_md_read_odd(rng, f"T{i}", 0, pos, length, kind if i % 3 != 1 else "plain"))
+        pos += int(rng.integers(200, 6000))
+    st = b"".join(recs)
+    stage(ctx, st)
+    monkeypatch.setenv("BGP_VERBOSE", "1")            # (the library then says how many chunks took the serial walk)
+    capfd.readouterr()
+    ctx.timing_enable(True); ctx.timing_reset()
+    try:
+        for skip in (True, False):
+            _check_refbase(ctx, st, skip_zero=skip, window=int(rng.integers(500, 9000)))
+        assert ctx.timing_get().get("k6_emit_long", {}).get("launches", 0) > 0
+    finally:
+        ctx.timing_enable(False)
+    import re
+    said = [(int(a), int(b)) for a, b in re.findall(r"MD checkpoints: (\d+) long chunk\(s\), \d+ piece\(s\), (\d+) chunk\(s\) walked serially", capfd.readouterr().err)]
+    assert said and all(n > 0 for n, _ in said)
+    vouched = kind in ("plain", "big_match", "long_dels", "del_last", "mm_last", "zero_last", "eq_n", "over", "short", "lead_zero")      # ("lower" holds one "^a": an empty deletion, md/parse.d:89-93)
+    if vouched:
+        assert all(ser == 0 for _, ser in said), said      # the prefix sums took every chunk
+    else:
+        assert any(ser > 0 for _, ser in said), said       # an empty deletion, trailing letters, a number of more than nine digits: the walk
+
+
 # ---- the plan / accumulate path of K4 (k4_plan / k4_acc): batches, map overflow, fallbacks; framing repairs; full-size properties ----
 
 @pytest.mark.parametrize("n_reads,ref_len,profile", [(8000, 12_000, 1), (5000, 6_000, 0), (14_000, 12_000, 1)])
