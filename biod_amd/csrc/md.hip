@@ -1861,15 +1861,16 @@ int k6_reference_bases(bgp_ctx* c, int skip_zero, uint32_t run_first, uint32_t r
                 BGP_HIP(hipMemsetAsync(ck, 0, (size_t)ctr[1] * sizeof(DnaCk), c->stream));
                 const LongNode* longs = (const LongNode*)(c->d_md_long.as<uint8_t>() + 16);
                 TimedRegion t(c, "k6_emit_long", (uint64_t)ctr[1] * DNA_CK);
+                const bool ck_verbose = getenv("BGP_VERBOSE") != nullptr;
+                if (ck_verbose) { unsigned int zero = 0; BGP_HIP(hipStreamSynchronize(c->stream)); BGP_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_ck_serial), &zero, sizeof zero)); }      // (the count is this launch's)
                 static const int ck_serial = getenv("BGP_MD_CK_SERIAL") && atoi(getenv("BGP_MD_CK_SERIAL")) != 0;      // (tests: the walk a lane did before the wave's prefix sums)
                 hipLaunchKernelGGL(k6_ck_build, dim3(ctr[0]), dim3(64), 0, c->stream, c->d_stream, c->stream_len, c->d_rec.as<bgp_record>(), longs, ctr[0], ck, piece_node, ck_serial);
                 hipLaunchKernelGGL(k6_emit_long, dim3((ctr[1] + 63) / 64), dim3(64), 0, c->stream, c->d_stream, c->d_rec.as<bgp_record>(), longs, ck, piece_node, ctr[1], c->d_refbase.as<uint8_t>());
                 BGP_HIP(hipGetLastError());
-                if (getenv("BGP_VERBOSE")) {
-                    unsigned int ser = 0, zero = 0;
+                if (ck_verbose) {
+                    unsigned int ser = 0;
                     BGP_HIP(hipStreamSynchronize(c->stream));
                     BGP_HIP(hipMemcpyFromSymbol(&ser, HIP_SYMBOL(g_ck_serial), sizeof ser));
-                    BGP_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_ck_serial), &zero, sizeof zero));
                     fprintf(stderr, "[biodgpu] MD checkpoints: %u long chunk(s), %u piece(s), %u chunk(s) walked serially\n", ctr[0], ctr[1], ser);
                 }
             }
