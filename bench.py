@@ -198,6 +198,11 @@ def md_leg(ctx, cfg, cfg_name, info, n_reads, reps=3):
         out["prefix_vs_oracle"]["ranges"] = len(per)
     except AssertionError as e:
         out["prefix_vs_oracle"] = {"equal": False, "why": str(e)[:300]}
+    if cfg_name in ("cfg2", "cfg5"):      # streams without N skips: every covered column of the WHOLE result against the generator's own reference (a property, not the oracle)
+        try:
+            out["whole_stream_vs_generator_reference"] = IP.md_generator_reference_check(ctx, cfg)
+        except AssertionError as e:
+            out["whole_stream_vs_generator_reference"] = {"equal": False, "why": str(e)[:300]}
     return out
 
 
@@ -505,7 +510,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(a.config, a.cpu_sample_reads)
             out["speedup_vs_cpu_baseline"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
         print(json.dumps(out), file=result_out, flush=True)
-        if (checks is not None and not checks["ok"]) or hist_ok is False or ("parity_interior" in out and not out["parity_interior"]["all_equal"]) or ("md_path" in out and not out["md_path"]["prefix_vs_oracle"]["equal"]):
+        if (checks is not None and not checks["ok"]) or hist_ok is False or ("parity_interior" in out and not out["parity_interior"]["all_equal"]) or ("md_path" in out and not (out["md_path"]["prefix_vs_oracle"]["equal"] and out["md_path"].get("whole_stream_vs_generator_reference", {"equal": True})["equal"])):
             sys.stderr.write("bench.py: a result check FAILED (see checks_full_size / hist_reduce_equals_sum_of_ranks / parity_interior)\n")
             ctx.close()
             sys.exit(3)

@@ -246,6 +246,48 @@ def md_contig_prefix_check(ctx, cfg, count=20_000):
     return out
 
 
+def synth_reference_chars(seed, contig, p0, n):
+    """The generator's reference (biod_amd/csrc/synth_record.h: ref2), positions [p0, p0 + n) of contig `contig`, as chars: a hash per block of 32
+    positions, two bits a base."""
+    M = np.uint64
+
+    def mix64(z):
+        z = z + M(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> M(30))) * M(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> M(27))) * M(0x94D049BB133111EB)
+        return z ^ (z >> M(31))
+    if n <= 0:
+        return np.zeros(0, np.uint8)
+    b0, b1 = p0 >> 5, (p0 + n - 1) >> 5
+    with np.errstate(over="ignore"):
+        h = mix64(M(seed) ^ M(0x5EEDBA5E) ^ (M(contig) << M(36)) ^ np.arange(b0, b1 + 1, dtype=np.uint64))
+    chars = _REF_LUT[h.astype("<u8").view(np.uint8)].reshape(-1)      # (a byte of the hash is four bases, lowest bits first)
+    return chars[(p0 & 31):(p0 & 31) + n]
+
+
+_REF_LUT = np.frombuffer(b"ACGT", np.uint8)[(np.arange(256)[:, None] >> (2 * np.arange(4))[None, :]) & 3]
+
+
+def md_generator_reference_check(ctx, cfg, window_positions=1 << 22):
+    """A property of the generator, good at any size and wherever in the stream: its MD tags are written against ONE hash-defined reference,
+    so whichever read provides a column, reference_base (PileupRangeUsingMdTag, pileup.d:522-654) must be that reference's base -- on streams
+    without N skips (dna(read) leaves skipped bases out, md/reconstruct.d:199: behind an N a chunk drifts off the reference, in BioD and
+    here alike; cfg3 has them, cfg2 and cfg5 do not).  Every covered column of the whole piled-up stream; uncovered ones inside a run hold
+    'N' (an empty chunk, pileup.d:620-622)."""
+    n_cols = n_bad = n_unc_bad = 0
+    first_bad = None
+    for w in ctx.pileup_windows(L.BGP_PILEUP_COLUMNS, use_md_tag=True, skip_zero_coverage=False, window_positions=window_positions, copy=False):
+        keep = w.columns["coverage"] > 0
+        exp = synth_reference_chars(int(cfg.seed), int(w.ref_id), int(w.first_position), len(w.columns))
+        bad = np.nonzero((w.reference_base != exp) & keep)[0]
+        n_cols += int(keep.sum()); n_bad += len(bad)
+        n_unc_bad += int((w.reference_base[~keep] != ord("N")).sum())
+        if len(bad) and first_bad is None:
+            first_bad = (int(w.ref_id), int(w.first_position) + int(bad[0]), chr(w.reference_base[bad[0]]), chr(exp[bad[0]]))
+    assert n_bad == 0 and n_unc_bad == 0, f"reference_base differs from the generator's reference at {n_bad} covered columns (first {first_bad}); {n_unc_bad} uncovered columns are not 'N'"
+    return {"covered_columns": n_cols, "equal": True}
+
+
 def run(ctx, cfg, info, count, torch=None, dev=None, want=16, entries_on=(0, 5)):
     """All planned ranges; returns the summary bench.py prints as `parity_interior`."""
     plan = plan_ranges(ctx, cfg, info, count, torch, dev, want)

@@ -72,3 +72,6 @@ def test_full_size_interior_parity(ctx, name):
     # use_md_tag against the oracle at the start of every contig (reference_base far into the stream, a provider chain per reference)
     per = IP.md_contig_prefix_check(ctx, cfg, 20_000 if name != "cfg5" else 200)
     assert len(per) == int(cfg.n_ref) and all(e["columns"] > 0 for e in per), per
+    if name != "cfg3":      # no N skips: every covered column of the whole stream must show the generator's own reference, whichever read provides it
+        whole = IP.md_generator_reference_check(ctx, cfg)
+        assert whole["equal"] and whole["covered_columns"] == info.n_columns, (whole, info.n_columns)
