@@ -216,7 +216,8 @@ int k1_table(bgp_ctx* c);                                   // frame.hip : K1 al
 int k1_finish_long_cigars(bgp_ctx* c);
 int k2_decode(bgp_ctx* c, uint32_t what);                   // decode.hip
 int k12_fused_decode(bgp_ctx* c, uint32_t what);            // decode.hip : K1 + K2 in one pass over the stream
-bool k12_lds_applies(const bgp_ctx* c, uint32_t what); uint32_t k12_lds_segment_bytes(uint64_t stream_len); uint32_t k12_lds_window_shift(); int k12_lds_decode(bgp_ctx* c, uint32_t what);   // decode.hip : K1 + K2 through LDS windows, framing from K0
+bool k12_lds_applies(const bgp_ctx* c, uint32_t what); uint32_t k12_lds_segment_bytes(uint64_t stream_len); uint32_t k12_lds_window_shift(); int k12_lds_decode(bgp_ctx* c, uint32_t what);
+int ensure_cig4(bgp_ctx* c);                           // the first-ops side array made from the CIGAR arena when k12_lds left it out (decode.hip)   // decode.hip : K1 + K2 through LDS windows, framing from K0
 int k012_stream_decode(bgp_ctx* c, uint32_t what);          // decode.hip : K0 + K1 + K2 in ONE pass (framing by look-back); 1 = gave up, take the three-kernel path
 constexpr uint32_t BGP_LONG_CIGAR = 32;                      // more ops than this: basesCovered is summed by a whole wave (k1_long_cigar)
 int k34_pileup(bgp_ctx* c);                                 // pileup.hip : runs + dense columns
@@ -370,9 +371,10 @@ __device__ __forceinline__ uint32_t cig_rc(uint32_t raw) { return (0x3C1A7u >> (
 //                   [25] the positions between the runs are D / N: '-' (pileup.d:119-121)  [28] the row is there (class 1)
 //              z,w  [41:0] nibble address of the first run's first base in the record stream (2 x byte offset + low nibble, read.d:364-383)
 //                   [49:42] query bases from there to the second run's first base
-// Classes (a byte a record): 0 the read covers nothing (pileup.d:481,510), 1 the row says it all, 2 anything else (the planner's, k4_plan).
+// Classes (a byte a record, its low two bits): 0 the read covers nothing (pileup.d:481,510), 1 the row says it all, 2 anything else (the planner's, k4_plan).
 // The moulds are k4_plan's `simple` ones, so that a read contributes the same whichever way it takes.
 constexpr uint32_t BGP_ROW_REACH = 256;
+constexpr uint32_t BGP_CLS_NO_SKIP = 0x10u;      // beside the class (low two bits): the whole CIGAR was seen (four ops at most) and holds no N -- dna(read) by the CIGAR is end_position - position
 __device__ __forceinline__ uint32_t bgp_plan_row(uint32_t pos, uint32_t n_cig, uint32_t l_seq, bool covered, uint4 c4, uint64_t seq_abs, uint64_t stream_len, uint4* row) {
     const uint32_t ops[4] = {c4.x, c4.y, c4.z, c4.w};
     bool seen_ref = false, bad = false, tail_ref = false, gap_del = false;

@@ -616,7 +616,9 @@ __device__ __forceinline__ void sd_emit(const SdArgs& a, uint8_t* sd_lds, uint64
                 cov = ((cig_rc(c4.x) ? c4.x >> 4 : 0u) + (cig_rc(c4.y) ? c4.y >> 4 : 0u) + (cig_rc(c4.z) ? c4.z >> 4 : 0u) + (cig_rc(c4.w) ? c4.w >> 4 : 0u)) != 0;      // basesCovered() > 0 (ops behind the CIGAR's end are 0: an M of no bases)
             }
             uint4 row;
-            const uint32_t cls = bgp_plan_row(pos, n_cig, lq, cov, c4, wbase + co + 4ull * n_cig, a.len, &row);
+            uint32_t cls = bgp_plan_row(pos, n_cig, lq, cov, c4, wbase + co + 4ull * n_cig, a.len, &row);
+            // (K6: a CIGAR seen whole and without an N implies dna(read) as long as the read covers, md/reconstruct.d:199 -- no ops need be read for that)
+            if (!unmapped && n_cig >= 1 && n_cig <= 4 && (c4.x & 15u) != 3u && (c4.y & 15u) != 3u && (c4.z & 15u) != 3u && (c4.w & 15u) != 3u) cls |= BGP_CLS_NO_SKIP;
 #if BGP_K12_NT_ROWS
             nt_store16(a.prow + pn + r0 + u, row); a.rcls[pn + r0 + u] = (uint8_t)cls;
 #else
@@ -634,10 +636,10 @@ __device__ __forceinline__ void sd_emit(const SdArgs& a, uint8_t* sd_lds, uint64
         if (valid) {
 #if BGP_K12_NT_ROWS
             { uint4 r0v, r1v; __builtin_memcpy(&r0v, &rec, 16); __builtin_memcpy(&r1v, reinterpret_cast<const char*>(&rec) + 16, 16);
-              nt_store16(reinterpret_cast<char*>(a.rec + i), r0v); nt_store16(reinterpret_cast<char*>(a.rec + i) + 16, r1v); nt_store16(a.cig4 + i, c4v);
+              nt_store16(reinterpret_cast<char*>(a.rec + i), r0v); nt_store16(reinterpret_cast<char*>(a.rec + i) + 16, r1v); if (a.cig4) nt_store16(a.cig4 + i, c4v);
               __builtin_nontemporal_store(carry_seq + es, a.seq_off + i); __builtin_nontemporal_store(carry_cig + ec, a.cig_off + i); }
 #else
-            a.rec[i] = rec; a.seq_off[i] = carry_seq + es; a.cig_off[i] = carry_cig + ec; a.cig4[i] = c4v;
+            a.rec[i] = rec; a.seq_off[i] = carry_seq + es; a.cig_off[i] = carry_cig + ec; if (a.cig4) a.cig4[i] = c4v;
 #endif
             soff[t] = es; coff[t] = ec;
             info[3 * t] = (uint16_t)cig_o; info[3 * t + 1] = (uint16_t)(cig_o + 4 * ncig); info[3 * t + 2] = (uint16_t)(cig_o + 4 * ncig + (uint32_t)((rec.l_seq + 1) / 2));   // read.d:992-998
@@ -682,7 +684,7 @@ __device__ __forceinline__ void sd_emit(const SdArgs& a, uint8_t* sd_lds, uint64
             }
             rec.end_pos = (int32_t)((uint32_t)rec.pos + covered);
             const uint64_t i = pn + cnt - 1;
-            a.rec[i] = rec; a.seq_off[i] = carry_seq; a.cig_off[i] = carry_cig; a.cig4[i] = c4v;
+            a.rec[i] = rec; a.seq_off[i] = carry_seq; a.cig_off[i] = carry_cig; if (a.cig4) a.cig4[i] = c4v;
             if (a.prow) { a.prow[i] = make_uint4(0, 0, 0, 0); a.rcls[i] = (covered != 0 || (n_cig > BGP_LONG_CIGAR && !((rec.flag_nc >> 16) & 0x4u))) ? 2 : 0; }      // (a record that runs past its window: the planner's)
             if (a.tilemax) {
                 const K3Key kk = k3_key_of(rec.ref_id, rec.pos, rec.end_pos);
@@ -863,22 +865,55 @@ bool k12_lds_applies(const bgp_ctx* c, uint32_t what) { return c->table_pending 
 // (a stream of up to a GB or two has too few segments to fill the device with chases -- one lane each, ~230 dependent hops at 64 KiB:
 // 0.17 ms whatever the size below ~100 MB --: one window a segment then, twice the lanes and half the hops)
 uint32_t k12_lds_segment_bytes(uint64_t stream_len) { return SD_C * (stream_len < (2048ull << 20) ? 1u : (uint32_t)BGP_LDS_WIN_PER_SEG); }
+// The side array of first CIGAR ops (16 bytes a record) when k12_lds left it out because it wrote plan rows: made from the CIGAR arena -- dense,
+// where the records' CIGARs lie 290 bytes apart in the stream -- the first time somebody wants it (K5's entries, K6's full rows).
+namespace {
+__global__ __launch_bounds__(256) void k_cig4_from_arena(const bgp_record* rec, const uint64_t* cig_off, const uint32_t* cigar, uint64_t n, uint4* out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t n_cig = rec[i].flag_nc & 0xFFFFu;
+    const uint32_t* q = cigar + cig_off[i];
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);                      // (ops behind the CIGAR's end are 0, as K1 leaves them)
+    if (n_cig > 0) v.x = q[0];
+    if (n_cig > 1) v.y = q[1];
+    if (n_cig > 2) v.z = q[2];
+    if (n_cig > 3) v.w = q[3];
+    out[i] = v;
+}
+}  // namespace
+int ensure_cig4(bgp_ctx* c) {
+    if (c->cig4_ok || !c->rows_ok || !c->n_records) return BGP_OK;      // there already; or no table of k12_lds's with its arenas: the consumers read the stream
+    const uint64_t n = c->n_records;
+    BGP_TRY(c->d_cig4.reserve((n + 1) * 16));
+    TimedRegion t(c, "k_cig4_from_arena", n * 44);
+    hipLaunchKernelGGL(k_cig4_from_arena, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->d_rec.as<bgp_record>(), c->d_cigar_off.as<uint64_t>(), c->d_cigar.as<uint32_t>(), n, c->d_cig4.as<uint4>());
+    BGP_HIP(hipGetLastError());
+    c->cig4_ok = true;
+    return BGP_OK;
+}
+
 uint32_t k12_lds_window_shift() { uint32_t s = 0; while ((1u << s) < SD_C) ++s; return s; }
 int k12_lds_decode(bgp_ctx* c, uint32_t what) {
     const uint64_t n = c->n_records;
     c->table_pending = false;
     BGP_TRY(c->d_rec.reserve((n + 1) * sizeof(bgp_record)));
     BGP_TRY(c->d_seq_off.reserve((n + 1) * 8)); BGP_TRY(c->d_cigar_off.reserve((n + 1) * 8));
-    BGP_TRY(c->d_cig4.reserve((n + 1) * 16)); c->cig4_ok = true;
     static const bool want_rows = !(getenv("BGP_K4_ROWS") && atoi(getenv("BGP_K4_ROWS")) == 0);      // (0: K4 plans every read itself, as it does behind the other decode routes)
     c->rows_ok = false;
+    // With rows the first-ops side array (16 bytes a record: what K4's planner, K5 and K6 read instead of the stream) is not written here: the
+    // planner only sees the few reads a row cannot hold, K6 takes the CIGAR-implied length from the class byte, and K5 has it made from the
+    // CIGAR arena when entries are first asked for (ensure_cig4) -- 1.6 GB of stores the step itself has no reader for.
+    static const bool cig4_with_rows = getenv("BGP_K12_CIG4") && atoi(getenv("BGP_K12_CIG4")) != 0;
+    const bool want_cig4 = !want_rows || cig4_with_rows;
+    c->cig4_ok = false;
+    if (want_cig4) { BGP_TRY(c->d_cig4.reserve((n + 1) * 16)); c->cig4_ok = true; }
     if (want_rows) { BGP_TRY(c->d_prow.reserve((n + 1) * 16)); BGP_TRY(c->d_rcls.reserve(n + 16)); }
     BGP_TRY(c->d_seq.reserve(c->sum_lseq + 16)); BGP_TRY(c->d_qual.reserve(c->sum_lseq + 16)); BGP_TRY(c->d_cigar.reserve(c->sum_ncig * 4 + 16));
     c->decoded_what |= BGP_FETCH_ALL;
     if (c->stream_len < 4) return BGP_OK;
     LdsArgs a;
     a.d.s = c->d_stream; a.d.len = c->stream_len; a.d.n_chunks = c->n_seg; a.d.ref_bound = 0; a.d.tolerant = 0; a.d.hint = nullptr; a.d.desc = nullptr; a.d.ctl = nullptr; a.d.status = nullptr;
-    a.d.rec = c->d_rec.as<bgp_record>(); a.d.seq_off = c->d_seq_off.as<uint64_t>(); a.d.cig_off = c->d_cigar_off.as<uint64_t>(); a.d.cig4 = c->d_cig4.as<uint4>();
+    a.d.rec = c->d_rec.as<bgp_record>(); a.d.seq_off = c->d_seq_off.as<uint64_t>(); a.d.cig_off = c->d_cigar_off.as<uint64_t>(); a.d.cig4 = want_cig4 ? c->d_cig4.as<uint4>() : nullptr;
     a.d.seq = c->d_seq.as<uint8_t>(); a.d.qual = c->d_qual.as<uint8_t>(); a.d.cigar = c->d_cigar.as<uint32_t>();
     a.d.cap_n = ~0ull; a.d.cap_ls = ~0ull; a.d.cap_nc = ~0ull;
     a.d.prow = want_rows ? c->d_prow.as<uint4>() : nullptr; a.d.rcls = want_rows ? c->d_rcls.as<uint8_t>() : nullptr; c->rows_ok = want_rows;

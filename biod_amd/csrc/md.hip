@@ -430,7 +430,7 @@ __device__ __forceinline__ uint32_t dna_length_by_cigar(const uint8_t* s, const 
     return n > (uint64_t)MD_LMASK ? MD_LMASK : (uint32_t)n;
 }
 
-template <bool FULL> __global__ __launch_bounds__(256) void k6_prep(const uint8_t* s, const bgp_record* rec, const uint4* cig4, const uint64_t* pmax_end, const uint64_t* pmax_pos, uint64_t n, MdRow* rows, uint32_t* bmax) {
+template <bool FULL> __global__ __launch_bounds__(256) void k6_prep(const uint8_t* s, const bgp_record* rec, const uint4* cig4, const uint8_t* rcls, const uint64_t* pmax_end, const uint64_t* pmax_pos, uint64_t n, MdRow* rows, uint32_t* bmax) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     bgp_record r{};
     if (i < n) r = rec[i];
@@ -441,6 +441,7 @@ template <bool FULL> __global__ __launch_bounds__(256) void k6_prep(const uint8_
         const uint64_t pm_prev = i ? pmax_pos[i - 1] : 0, pe_prev = i ? pmax_end[i - 1] : 0;
         uint32_t L;
         if (FULL) L = dna_length(s, r, &bad, &err, cig4 ? cig4 + i : nullptr, cig4 && i + 1 < n ? (uint64_t)rec[i + 1].rec_off : 0);   // (cig4: the table is K1's own, record i ends where i + 1 begins -- its header line is not touched at all)
+        else if (rcls && (rcls[i] & BGP_CLS_NO_SKIP)) L = (uint32_t)r.end_pos - (uint32_t)r.pos;      // (k12_lds saw the whole CIGAR and no N in it: M / = / X and D bases are all the read covers)
         else L = dna_length_by_cigar(s, r, cig4 ? cig4 + i : nullptr);
         if (L > MD_LMASK) L = MD_LMASK;
         // first record of this read's position group: the prefix maximum of the position key reaches the
@@ -1687,9 +1688,11 @@ static int k6_rows(bgp_ctx* c, bool full) {
     BGP_TRY(c->d_md_bmax.reserve((n / 64 + 2) * 4));
     if (n) {
         TimedRegion t(c, "k6_prep", n * (32 + sizeof(MdRow)));
-        if (full) hipLaunchKernelGGL(k6_prep<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->d_stream, c->d_rec.as<bgp_record>(), c->cig4_ok ? c->d_cig4.as<uint4>() : nullptr,
+        if (full) BGP_TRY(ensure_cig4(c));      // (rows from the tags themselves walk every read's ops)
+        const uint8_t* rcls = c->rows_ok ? c->d_rcls.as<uint8_t>() : nullptr;
+        if (full) hipLaunchKernelGGL(k6_prep<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->d_stream, c->d_rec.as<bgp_record>(), c->cig4_ok ? c->d_cig4.as<uint4>() : nullptr, rcls,
                            c->d_pmax_end.as<uint64_t>(), c->d_pmax_pos.as<uint64_t>(), n, c->d_md_row.as<MdRow>(), c->d_md_bmax.as<uint32_t>());
-        else hipLaunchKernelGGL(k6_prep<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->d_stream, c->d_rec.as<bgp_record>(), c->cig4_ok ? c->d_cig4.as<uint4>() : nullptr,
+        else hipLaunchKernelGGL(k6_prep<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->d_stream, c->d_rec.as<bgp_record>(), c->cig4_ok ? c->d_cig4.as<uint4>() : nullptr, rcls,
                            c->d_pmax_end.as<uint64_t>(), c->d_pmax_pos.as<uint64_t>(), n, c->d_md_row.as<MdRow>(), c->d_md_bmax.as<uint32_t>());
         BGP_HIP(hipGetLastError());
     }

@@ -1244,7 +1244,7 @@ __global__ __launch_bounds__(256) void k4_plan_rest(PlanArgs a) {
     if (o < a.n) __builtin_memcpy(cw, a.rcls + o, 16);        // (the array has sixteen bytes of room behind the last record)
     uint32_t m = 0;                                              // bit j: record o + j is class 2
 #pragma unroll
-    for (int j = 0; j < 16; ++j) if (((cw[j >> 2] >> (8 * (j & 3))) & 0xFFu) == 2u && o + (uint64_t)j < a.n) m |= 1u << j;
+    for (int j = 0; j < 16; ++j) if (((cw[j >> 2] >> (8 * (j & 3))) & 3u) == 2u && o + (uint64_t)j < a.n) m |= 1u << j;
     const uint32_t cnt = (uint32_t)__builtin_popcount(m);
     const uint32_t inc = wave_incl_u32(cnt, lane), total = rl(inc, 63);
     if (!total) return;
@@ -2594,6 +2594,7 @@ int k34_pileup(bgp_ctx* c) {
         BGP_TRY(c->d_wcount.reserve((tile_base + 1) * 4)); BGP_TRY(c->d_wdel.reserve((tile_base + 2) * 4)); BGP_TRY(c->d_wslow.reserve((tile_base + 2) * 4));
         BGP_TRY(c->d_col_lo.reserve((tile_base + 65536) * 32));          // (k4_acc's totals: zeroed here with the planner's arrays, one launch)
         { const FillItem f[4] = {{c->d_wcount.p, (tile_base + 1) * 4, 0u}, {c->d_wdel.p, (tile_base + 2) * 4, 0u}, {c->d_wslow.p, (tile_base + 2) * 4, 0u}, {c->d_col_lo.p, (tile_base + 65536) * 32, 0u}}; BGP_TRY(fill_many(c, f, 4)); }
+        if (!use_rows) BGP_TRY(ensure_cig4(c));      // (the planner over every read wants the first ops beside the rows it reads, not 290 bytes apart in the stream)
         {
             TimedRegion tp(c, use_rows ? "k4_plan_rest" : "k4_plan", use_rows ? c->n_records : c->n_records * 48);      // (what it reads of every record: the class byte | the row and the first ops)
             PlanArgs pa;
@@ -2724,6 +2725,7 @@ int k5_entries(bgp_ctx* c, uint32_t run_idx, uint64_t pos_begin, uint64_t pos_en
     a.pos_begin = pos_begin; a.pos_end = pos_end; a.cols = c->d_columns.as<bgp_column>(); a.cov64 = c->d_col_lo.as<uint64_t>();
     a.col_off = c->d_entry_off.as<uint64_t>(); a.entries = nullptr;
     a.ck_w = c->ck_w; a.ck = c->ck_w ? c->d_ck.as<Ckpt>() : nullptr; a.ck_off = c->ck_w ? c->d_ck_off.as<uint64_t>() : nullptr;
+    BGP_TRY(ensure_cig4(c));                             // (behind k12_lds's plan rows the side array is made now, from the CIGAR arena)
     a.cig4 = c->cig4_ok ? c->d_cig4.as<uint4>() : nullptr;
     a.stream_len = c->stream_len;
     uint64_t total = 0;
