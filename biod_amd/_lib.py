@@ -17,6 +17,7 @@ BGP_OK, BGP_EOF, BGP_EAGAIN = 0, 1, 2
 BGP_EINVAL, BGP_ETRUNC, BGP_ECIGAR, BGP_EDEVICE, BGP_ENOMEM, BGP_ESTATE, BGP_EMD, BGP_EUNSORTED, BGP_ESEQ = -1, -2, -3, -4, -5, -6, -7, -8, -9
 BGP_FETCH_SEQ, BGP_FETCH_QUAL, BGP_FETCH_CIGAR, BGP_FETCH_ALL = 1, 2, 4, 7
 BGP_FETCH_STREAM = 8
+BGP_DECODE_ONLY = 16        # bgp_flush_decode: no pileup will follow (the pass writes nothing for K4)
 BGP_PILEUP_COLUMNS, BGP_MAKE_PILEUP = 0, 1
 BGP_DEPTH_BINS = 65536
 BGP_SNP_NO, BGP_SNP_YES, BGP_SNP_TIE, BGP_SNP_NEEDS_ENTRIES = 0, 1, 2, 3

@@ -40,6 +40,7 @@ static int ensure_table(bgp_ctx* c) { return !c->table_pending ? BGP_OK : k12_fu
 int flush_core(bgp_ctx* c, uint32_t what) {
     c->piled = false; c->md_rows_ready = false; c->decoded_what = 0; c->table_compacted = false;
     if (c->region_pending) what = 0;                     // the arenas are made for the records the filter keeps
+    const bool decode_only = (what & BGP_DECODE_ONLY) != 0; what &= BGP_FETCH_ALL;
     int rc = 1;
     if (frame_mode() == 1) { rc = k012_stream_decode(c, what); if (rc < 0) return rc; }
     if (rc == 1) {                                       // K0, then K1 and K2
@@ -49,7 +50,7 @@ int flush_core(bgp_ctx* c, uint32_t what) {
         c->seg_bytes_wanted = 0; c->seg_window_shift = 0;
         if (rc < 0) return rc;
         c->flushed = true;
-        if (lds && k12_lds_applies(c, what)) BGP_TRY(k12_lds_decode(c, what));      // rows and arenas from LDS windows: the stream is read once more, not twice
+        if (lds && k12_lds_applies(c, what)) BGP_TRY(k12_lds_decode(c, what | (decode_only ? BGP_DECODE_ONLY : 0u)));      // rows and arenas from LDS windows: the stream is read once more, not twice
         else {
             c->defer_long_cigar = (what & BGP_FETCH_CIGAR) != 0 && fuse_mode() != 1;      // the unpack below reads every CIGAR anyway
             if (fuse_mode() != 1) BGP_TRY(ensure_table(c));  // K1; only the fused experiment (BGP_FUSE_MODE=1) defers it to the decode
@@ -304,7 +305,7 @@ int bgp_reset(bgp_ctx* c) {
     for (HostBuf* hb : {&c->h_cols2, &c->h_rec, &c->h_seq_off, &c->h_cigar_off, &c->h_seq, &c->h_qual, &c->h_cigar, &c->h_cols, &c->h_entry_off, &c->h_entries, &c->h_refbase, &c->h_snp, &c->h_maq, &c->h_stream_copy}) hb->trim();
     c->h_stage_len = 0; c->d_stream = nullptr; c->stream_len = 0; c->stream_on_device = false;
     c->flushed = false; c->piled = false; c->md_rows_ready = false; c->table_pending = false; c->n_records = 0; c->decoded_what = 0; c->it = bgp_ctx::Iter();
-    c->hints.clear(); c->runs.clear(); c->chunks.clear(); c->chunks_ready = false; c->stage_map.clear(); c->region_pending = false; c->table_compacted = false; c->bai_buildable = false; c->cig4_ok = false; c->rows_ok = false; c->tilemax_ok = false;
+    c->hints.clear(); c->runs.clear(); c->chunks.clear(); c->chunks_ready = false; c->stage_map.clear(); c->region_pending = false; c->table_compacted = false; c->bai_buildable = false; c->cig4_ok = false; c->rows_ok = false; c->lds_table = false; c->tilemax_ok = false;
     c->refs.clear(); c->n_ref_hint = 0; c->last_error.clear(); c->bai_bytes.clear();      // nothing of the previous file survives: the loaders and bgp_set_n_ref re-establish these
     return BGP_OK;
     BGP_API_CATCH(c)
@@ -350,7 +351,7 @@ static int flush_impl(bgp_ctx* c, uint32_t what) {
         if (c->h_stage_len) BGP_HIP(hipMemcpyAsync(c->d_stream_own.p, c->h_stage.p, c->h_stage_len, hipMemcpyHostToDevice, c->stream));
         c->d_stream = c->d_stream_own.as<uint8_t>(); c->stream_len = c->h_stage_len; c->stream_on_device = true;
     }
-    return flush_core(c, what & BGP_FETCH_ALL);
+    return flush_core(c, what & (BGP_FETCH_ALL | BGP_DECODE_ONLY));
 }
 
 int bgp_flush(bgp_ctx* c) {

@@ -183,7 +183,7 @@ static int process_next(bgp_ctx* c, Batch* b) {
     b->cur = q; b->state[q] = Batch::CURRENT; b->cur_final = final; b->any_batch = true;
     c->d_stream = base; c->stream_len = b->carry_len + b->new_len[q]; c->stream_on_device = true;
     c->frame_tolerant_tail = !final;
-    c->cig4_ok = false; c->rows_ok = false;
+    c->cig4_ok = false; c->rows_ok = false; c->lds_table = false;
     BGP_TRY(flush_core(c));
     BGP_TRY(k34_pileup(c));
     c->piled = true; c->md_rows_ready = false;

@@ -92,6 +92,7 @@ enum : uint32_t {
     ST_EINVAL = 1u << 0, ST_ETRUNC = 1u << 1, ST_ECIGAR = 1u << 2, ST_EUNSORTED = 1u << 3, ST_ESEQ = 1u << 4, ST_EMD = 1u << 5,
 };
 int bgp_status_from_bits(uint32_t bits);      // hard errors first; ESEQ is soft
+constexpr uint32_t ST_ODDREAD = 1u << 17;      // not an error: some record has more than four CIGAR ops or more than 255 bases -- K4 walks such reads from checkpoints and plans every read itself, so k12_lds writes the first-ops side array, not plan rows
 constexpr uint32_t ST_LONGCIG = 1u << 16;      // not an error: some record has more than BGP_LONG_CIGAR ops (its end_position is finished by k1_long_cigar)
 
 struct KernelTimer {
@@ -137,6 +138,7 @@ struct bgp_ctx {
     bool frame_tolerant_tail = false; uint64_t frame_tail = 0;   // batched staging (batch.cpp): a stream may end inside a record; where the record chain stopped
     bool table_compacted = false;                     // a region filter compacted the record table: records the filter dropped still lie between the kept ones in the stream
     bool defer_long_cigar = false, long_cigar_deferred = false;   // a CIGAR unpack follows the record table at once: it sums the long CIGARs it copies anyway (k2_unpack) instead of k1_long_cigar reading them first
+    bool odd_reads = false;                           // framing saw a record of more than four CIGAR ops or more than 255 bases (ST_ODDREAD)
     bool table_pending = false, long_cigar = false;   // the record table is written lazily: by k1_table, or by the fused K1+K2 if a decode comes first
     DevBuf d_seg_list; DevBuf d_scan_tmp; HostBuf h_mail;                // (h_mail: pinned, written by k_mail)
     DevBuf d_sd_desc; int sd_timer_idx = -1;         // single-pass decode (decode.hip: k_stream_decode): control words + one 64-byte descriptor per chunk
@@ -147,7 +149,7 @@ struct bgp_ctx {
     // record table (K1)
     DevBuf d_rec, d_seq_off, d_cigar_off;
     DevBuf d_tilemax; bool tilemax_ok = false;        // per 2048-record tile: maxima of K3's two keys, left by K1 (K3 then skips its own first pass)
-    DevBuf d_prow, d_rcls; bool rows_ok = false;      // K4's plan rows (16 B) and classes (1 B) of every record, written by k12_lds (bgp_plan_row below): the accumulate path takes ordinary reads from these, the planner only the rest
+    DevBuf d_prow, d_rcls; bool rows_ok = false, lds_table = false;   /* lds_table: the table and all three arenas are k12_lds's, uncompacted (ensure_cig4 can make the side array from them) */      // K4's plan rows (16 B) and classes (1 B) of every record, written by k12_lds (bgp_plan_row below): the accumulate path takes ordinary reads from these, the planner only the rest
     DevBuf d_cig4; bool cig4_ok = false;              // first four raw CIGAR ops of every record (16 B, written by K1): K4's planner reads these, not the stream
     DevBuf d_rec2, d_seq_off2, d_cigar_off2, d_flt[6];   // region filter: compaction targets (swapped in) and scan scratch
     // decode arenas (K2)

@@ -803,7 +803,7 @@ int k12_fused_decode(bgp_ctx* c, uint32_t what) {
     c->table_pending = false;
     BGP_TRY(c->d_rec.reserve((n + 1) * sizeof(bgp_record)));
     BGP_TRY(c->d_seq_off.reserve((n + 1) * 8)); BGP_TRY(c->d_cigar_off.reserve((n + 1) * 8));
-    BGP_TRY(c->d_cig4.reserve((n + 1) * 16)); c->cig4_ok = true; c->rows_ok = false;
+    BGP_TRY(c->d_cig4.reserve((n + 1) * 16)); c->cig4_ok = true; c->rows_ok = false; c->lds_table = false;
     if (what & BGP_FETCH_SEQ) BGP_TRY(c->d_seq.reserve(c->sum_lseq + 16));
     if (what & BGP_FETCH_QUAL) BGP_TRY(c->d_qual.reserve(c->sum_lseq + 16));
     if (what & BGP_FETCH_CIGAR) BGP_TRY(c->d_cigar.reserve(c->sum_ncig * 4 + 16));
@@ -882,7 +882,7 @@ __global__ __launch_bounds__(256) void k_cig4_from_arena(const bgp_record* rec, 
 }
 }  // namespace
 int ensure_cig4(bgp_ctx* c) {
-    if (c->cig4_ok || !c->rows_ok || !c->n_records) return BGP_OK;      // there already; or no table of k12_lds's with its arenas: the consumers read the stream
+    if (c->cig4_ok || !c->lds_table || !c->n_records) return BGP_OK;      // there already; or no table of k12_lds's with its arenas: the consumers read the stream
     const uint64_t n = c->n_records;
     BGP_TRY(c->d_cig4.reserve((n + 1) * 16));
     TimedRegion t(c, "k_cig4_from_arena", n * 44);
@@ -898,13 +898,15 @@ int k12_lds_decode(bgp_ctx* c, uint32_t what) {
     c->table_pending = false;
     BGP_TRY(c->d_rec.reserve((n + 1) * sizeof(bgp_record)));
     BGP_TRY(c->d_seq_off.reserve((n + 1) * 8)); BGP_TRY(c->d_cigar_off.reserve((n + 1) * 8));
-    static const bool want_rows = !(getenv("BGP_K4_ROWS") && atoi(getenv("BGP_K4_ROWS")) == 0);      // (0: K4 plans every read itself, as it does behind the other decode routes)
-    c->rows_ok = false;
+    static const bool rows_env = !(getenv("BGP_K4_ROWS") && atoi(getenv("BGP_K4_ROWS")) == 0);      // (0: K4 plans every read itself, as it does behind the other decode routes)
+    const bool decode_only = (what & BGP_DECODE_ONLY) != 0;      // the caller's word that no pileup follows: nothing is written for K4 (a pileup asked for anyway has the side array made from the arena)
+    const bool want_rows = rows_env && !decode_only && !c->odd_reads;      // (a stream with a read of more than four ops or 255 bases is planned read by read, its odd reads walked from checkpoints: rows would be written for nobody -- framing has seen every header)
+    c->rows_ok = false; c->lds_table = false;
     // With rows the first-ops side array (16 bytes a record: what K4's planner, K5 and K6 read instead of the stream) is not written here: the
     // planner only sees the few reads a row cannot hold, K6 takes the CIGAR-implied length from the class byte, and K5 has it made from the
     // CIGAR arena when entries are first asked for (ensure_cig4) -- 1.6 GB of stores the step itself has no reader for.
     static const bool cig4_with_rows = getenv("BGP_K12_CIG4") && atoi(getenv("BGP_K12_CIG4")) != 0;
-    const bool want_cig4 = !want_rows || cig4_with_rows;
+    const bool want_cig4 = (!want_rows && !decode_only) || cig4_with_rows;
     c->cig4_ok = false;
     if (want_cig4) { BGP_TRY(c->d_cig4.reserve((n + 1) * 16)); c->cig4_ok = true; }
     if (want_rows) { BGP_TRY(c->d_prow.reserve((n + 1) * 16)); BGP_TRY(c->d_rcls.reserve(n + 16)); }
@@ -916,7 +918,7 @@ int k12_lds_decode(bgp_ctx* c, uint32_t what) {
     a.d.rec = c->d_rec.as<bgp_record>(); a.d.seq_off = c->d_seq_off.as<uint64_t>(); a.d.cig_off = c->d_cigar_off.as<uint64_t>(); a.d.cig4 = want_cig4 ? c->d_cig4.as<uint4>() : nullptr;
     a.d.seq = c->d_seq.as<uint8_t>(); a.d.qual = c->d_qual.as<uint8_t>(); a.d.cigar = c->d_cigar.as<uint32_t>();
     a.d.cap_n = ~0ull; a.d.cap_ls = ~0ull; a.d.cap_nc = ~0ull;
-    a.d.prow = want_rows ? c->d_prow.as<uint4>() : nullptr; a.d.rcls = want_rows ? c->d_rcls.as<uint8_t>() : nullptr; c->rows_ok = want_rows;
+    a.d.prow = want_rows ? c->d_prow.as<uint4>() : nullptr; a.d.rcls = want_rows ? c->d_rcls.as<uint8_t>() : nullptr; c->rows_ok = want_rows; c->lds_table = true;
     a.d.tilemax = nullptr; c->tilemax_ok = false;
     if (!c->long_cigar) {             // K3's tile maxima on the way (see k12_fused_decode)
         const uint64_t nt = (n + K3_TILE_RECORDS - 1) / K3_TILE_RECORDS;

@@ -197,7 +197,7 @@ template <class RD, int SINK> __device__ __forceinline__ bool chase_one(const Fr
     const uint64_t seg_end = min((k + 1) * (uint64_t)a.seg_bytes, a.len);
     uint64_t cnt = 0, ls = 0, nc = 0;
     uint32_t err = 0;
-    bool long_seen = false;
+    bool long_seen = false, odd_seen = false;
     uint32_t wcur = 0;
     const uint64_t seg0 = k * (uint64_t)a.seg_bytes;
     bool live = off < seg_end;
@@ -237,7 +237,7 @@ template <class RD, int SINK> __device__ __forceinline__ bool chase_one(const Fr
         if (lseq < 0 || l_name == 0 || 32ull + l_name + 4ull * n_cig + (uint64_t)((lseq + 1) / 2) + (uint64_t)lseq > (uint64_t)bs) { err = ST_EINVAL; return false; }
         *v = (uint32_t)(off - seg0);
         ++cnt; ls += (uint64_t)lseq; nc += n_cig;
-        long_seen |= n_cig > LONG_CIGAR;
+        long_seen |= n_cig > LONG_CIGAR; odd_seen |= n_cig > 4u || lseq > 255;
         off += 4 + (uint64_t)bs;
         live = off < seg_end;
         return true;
@@ -288,7 +288,7 @@ template <class RD, int SINK> __device__ __forceinline__ bool chase_one(const Fr
     if (a.sub) while (wcur + 1 < a.sub_n) { ++wcur; a.sub[k * a.sub_n + wcur] = make_uint4((uint32_t)cnt, (uint32_t)ls, (uint32_t)nc, 0u); }
     a.end[k] = err ? STOP : off;
     // per segment, not a sticky global bit: a chase from a wrong guess reads garbage and must not leave a trace
-    a.cnt[k] = cnt; a.lseq[k] = ls; a.ncig[k] = nc; a.seg_err[k] = err | (long_seen ? ST_LONGCIG : 0u);
+    a.cnt[k] = cnt; a.lseq[k] = ls; a.ncig[k] = nc; a.seg_err[k] = err | (long_seen ? ST_LONGCIG : 0u) | (odd_seen ? ST_ODDREAD : 0u);
     *off_io = off;
     // A following segment the guesser found nothing in (inside a record longer than a segment, or bytes that
     // look like no header) is chased right away from where this chain stands -- otherwise every such segment
@@ -321,7 +321,7 @@ __global__ __launch_bounds__(256) void k0_chase(FrameArgs a) {
 __global__ __launch_bounds__(256) void k0_rechase(FrameArgs a, const uint32_t* list, uint32_t n_list) {
     extern __shared__ __attribute__((aligned(16))) uint8_t rw[];
     __shared__ uint64_t s_off, s_end; __shared__ int s_go, s_plain; __shared__ uint32_t s_n;
-    __shared__ unsigned long long s_acc[3 * 8 + 2];           // per window boundary: records, bases, ops in front of it; [24] a long CIGAR seen, [25] a record that fails its tests
+    __shared__ unsigned long long s_acc[3 * 8 + 3];           // per window boundary: records, bases, ops in front of it; [24] a long CIGAR seen, [25] a record that fails its tests
     if (blockIdx.x >= n_list) return;
     uint64_t k = list[blockIdx.x];
     const int t = threadIdx.x;
@@ -340,7 +340,7 @@ __global__ __launch_bounds__(256) void k0_rechase(FrameArgs a, const uint32_t* l
         // (tolerant tail) the entry may lie in front of the segment, with a record still incomplete at the batch's end
         const uint64_t w0 = (s_off & ~15ull), w1 = min(min(a.len & ~15ull, ((k + 1) * (uint64_t)a.seg_bytes + 64) & ~15ull), w0 + (((uint64_t)a.seg_bytes + 96) & ~15ull));
         if (w1 > w0) for (uint64_t o = w0 + 16ull * t; o < w1; o += 16ull * 256) { uint4 v; __builtin_memcpy(&v, a.s + o, 16); *reinterpret_cast<uint4*>(rw + (o - w0)) = v; }
-        if (t < 26) s_acc[t] = 0;
+        if (t < 27) s_acc[t] = 0;
         __syncthreads();
         // One thread follows the length prefixes -- nothing but "read four bytes, add": the full hop of chase_one is ~100 dependent
         // instructions, 0.11 ms for a segment's 230 records by one thread -- and stops at anything that is not a plain hop; then
@@ -368,6 +368,7 @@ __global__ __launch_bounds__(256) void k0_rechase(FrameArgs a, const uint32_t* l
                 const uint32_t l_name = f3[0] & 0xFFu, n_cig = f3[1] & 0xFFFFu;
                 if (lseq < 0 || l_name == 0 || 32ull + l_name + 4ull * n_cig + (uint64_t)((lseq + 1) / 2) + (uint64_t)lseq > (uint64_t)bs) { atomicAdd(&s_acc[25], 1ull); continue; }
                 if (n_cig > LONG_CIGAR) atomicAdd(&s_acc[24], 1ull);
+                if (n_cig > 4u || lseq > 255) atomicAdd(&s_acc[26], 1ull);
                 const uint32_t wj = a.sub ? o >> a.sub_shift : 0u;                     // the record counts in front of every window behind its own, and in the totals
                 for (uint32_t w = wj + 1; w <= nb; ++w) { unsigned long long* q = s_acc + 3 * (w - 1); atomicAdd(q, 1ull); atomicAdd(q + 1, (unsigned long long)(uint32_t)lseq); atomicAdd(q + 2, (unsigned long long)n_cig); }
             }
@@ -382,7 +383,7 @@ __global__ __launch_bounds__(256) void k0_rechase(FrameArgs a, const uint32_t* l
             if (a.sub && t >= 1 && (uint32_t)t < nb) a.sub[k * a.sub_n + t] = make_uint4((uint32_t)s_acc[3 * (t - 1)], (uint32_t)s_acc[3 * (t - 1) + 1], (uint32_t)s_acc[3 * (t - 1) + 2], 0u);
             if (t == 0) {
                 const unsigned long long* tot = s_acc + 3 * (nb - 1);
-                a.end[k] = s_end; a.cnt[k] = tot[0]; a.lseq[k] = tot[1]; a.ncig[k] = tot[2]; a.seg_err[k] = s_acc[24] ? ST_LONGCIG : 0u;
+                a.end[k] = s_end; a.cnt[k] = tot[0]; a.lseq[k] = tot[1]; a.ncig[k] = tot[2]; a.seg_err[k] = (s_acc[24] ? ST_LONGCIG : 0u) | (s_acc[26] ? ST_ODDREAD : 0u);
                 const bool on = !(k + 1 >= a.n_seg || a.entry[k + 1] != NONE);
                 if (on) { a.entry[k + 1] = s_end; a.dirty[k + 1] = 0; }
                 s_off = s_end; s_go = on ? 1 : 0;
@@ -647,7 +648,7 @@ int k0_frame(bgp_ctx* c) {
     if (c->timing)                       // what framing has to read: block_size and the 32 fixed bytes of every record (known only now)
         for (auto& t : c->timers) if (t.name == "k0_chase") t.algorithmic_bytes += n * 36;
 
-    c->long_cigar = (bits & ST_LONGCIG) != 0;
+    c->long_cigar = (bits & ST_LONGCIG) != 0; c->odd_reads = (bits & ST_ODDREAD) != 0;
     c->table_pending = true;             // the record table is written by whoever needs it first: k1_table, or the fused K1+K2 when a decode follows
     return BGP_OK;
 }
@@ -662,7 +663,7 @@ int k1_table(bgp_ctx* c) {
     const unsigned lane_blocks = (unsigned)((n_seg + 255) / 256);
     BGP_TRY(c->d_rec.reserve((n + 1) * sizeof(bgp_record)));
     BGP_TRY(c->d_seq_off.reserve((n + 1) * 8)); BGP_TRY(c->d_cigar_off.reserve((n + 1) * 8));
-    BGP_TRY(c->d_cig4.reserve((n + 1) * 16)); c->cig4_ok = true; c->rows_ok = false; c->tilemax_ok = false;
+    BGP_TRY(c->d_cig4.reserve((n + 1) * 16)); c->cig4_ok = true; c->rows_ok = false; c->lds_table = false; c->tilemax_ok = false;
     EmitArgs e;
     e.s = c->d_stream; e.len = c->stream_len; e.seg_bytes = c->seg_bytes; e.n_seg = n_seg; e.entry = c->d_seg_entry.as<uint64_t>();
     e.rec_base = c->d_seg_rec_base.as<uint64_t>(); e.seq_base = c->d_seg_seq_base.as<uint64_t>(); e.cig_base = c->d_seg_cig_base.as<uint64_t>();

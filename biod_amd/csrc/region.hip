@@ -85,7 +85,7 @@ int k_region_filter(bgp_ctx* c, uint32_t ref, uint32_t beg, uint32_t end) {
     std::swap(c->d_rec, c->d_rec2); std::swap(c->d_seq_off, c->d_seq_off2); std::swap(c->d_cigar_off, c->d_cigar_off2);
     c->n_records = n_new; c->sum_lseq = sl; c->sum_ncig = sc;
     c->table_compacted = true;
-    c->cig4_ok = false; c->rows_ok = false; c->tilemax_ok = false;                 // the side array of first CIGAR ops is not compacted: K4's planner takes the ops from the stream
+    c->cig4_ok = false; c->rows_ok = false; c->lds_table = false; c->tilemax_ok = false;                 // the side array of first CIGAR ops is not compacted: K4's planner takes the ops from the stream
     c->piled = false; c->md_rows_ready = false; c->decoded_what = 0; c->it = bgp_ctx::Iter();
     return BGP_OK;
 }

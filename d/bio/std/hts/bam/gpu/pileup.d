@@ -109,6 +109,7 @@ extern (C) nothrow @nogc {
     enum BGP_FETCH_CIGAR = 4u;
     enum BGP_FETCH_ALL = 7u;
     enum BGP_FETCH_STREAM = 8u;
+    enum BGP_DECODE_ONLY = 16u;
     int bgp_decode_fetch(bgp_ctx* ctx, uint what, bgp_records* out_);
     int bgp_decode_device(bgp_ctx* ctx, uint what, bgp_records* out_device);
     int bgp_decode_fetch_range(bgp_ctx* ctx, uint what, ulong first, ulong count, bgp_records* out_);

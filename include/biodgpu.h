@@ -130,6 +130,8 @@ typedef struct bgp_records {
 #define BGP_FETCH_CIGAR 4u
 #define BGP_FETCH_ALL 7u
 #define BGP_FETCH_STREAM 8u   /* bgp_decode_fetch: also a host copy of the record stream when the loader kept none */
+#define BGP_DECODE_ONLY 16u   /* bgp_flush_decode: no pileup is going to follow -- the pass writes the record table and the arenas and nothing for K4
+                              * (its plan rows: 17 bytes a record).  A pileup asked for all the same is correct, it plans every read itself. */
 /* Kernel K2 (4-bit seq -> chars, qual copy, CIGAR copy) + copy to host memory owned by the ctx. */
 int bgp_decode_fetch(bgp_ctx* ctx, uint32_t what, bgp_records* out);
 /* Same products left in HBM (device pointers); nothing is copied to the host. */

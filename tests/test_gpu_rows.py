@@ -175,3 +175,72 @@ def test_rows_islands_and_references(ctx):
                 recs.append(rec("i%d_%d_%d" % (ref_id, j, k), 150, cig, p, rng, ref_id=ref_id))
     st = b"".join(recs)
     run(ctx, st, entries=True, window=500, n_ref=3)
+
+
+def test_decode_only_writes_nothing_for_k4(ctx):
+    """bgp_flush_decode(BGP_FETCH_ALL | BGP_DECODE_ONLY): the caller says no pileup follows, so k12_lds writes the table and the arenas and neither
+    plan rows nor the first-ops side array.  The decode == oracle; a pileup asked for all the same is correct too -- the planner takes every read
+    (k4_plan, not k4_plan_rest), and the side array it and K5 read is made from the CIGAR arena first (k_cig4_from_arena)."""
+    cfg = make_cfg(n_reads=12000, n_ref=2, ref_len=60_000, read_len=150, profile=1, seed=31)
+    st = host_stream(cfg)
+    ctx.reset()
+    ctx.push_inflated(st)
+    ctx.timing_enable(True); ctx.timing_reset()
+    ctx.flush(decode=L.BGP_FETCH_ALL | L.BGP_DECODE_ONLY)
+    assert ctx.timing_get()["k12_lds"]["launches"] == 1
+    check_decode(ctx, st)
+    check_pileup(ctx, st, entries=True, window=3000)
+    tm = ctx.timing_get()
+    assert not ran_rows(ctx) and tm["k4_plan"]["launches"] > 0 and tm["k_cig4_from_arena"]["launches"] == 1
+    ctx.timing_enable(False)
+
+
+def test_rows_entries_and_reference_bases(ctx):
+    """Behind plan rows k12_lds leaves the first-ops side array out: K5's entries have it made from the CIGAR arena once (k_cig4_from_arena), K6 takes
+    the CIGAR-implied length of dna(read) from a bit beside the class -- end_position - position unless the CIGAR holds an N (md/reconstruct.d:199)
+    or was not seen whole.  Reads with N skips, with deletions, clipped ones: entries and reference_base == oracle."""
+    from test_gpu_parity import _check_refbase
+    rng = np.random.default_rng(61)
+    recs, pos = [], 10
+    for i in range(900):
+        k = int(rng.integers(0, 6))
+        if k == 0:
+            cig, n, md = [(150, "M")], 150, "150"
+        elif k == 1:
+            a = int(rng.integers(20, 120)); cig, n, md = [(a, "M"), (int(rng.integers(30, 400)), "N"), (150 - a, "M")], 150, "150"
+        elif k == 2:
+            a = int(rng.integers(20, 120)); d = int(rng.integers(1, 9)); cig, n = [(a, "M"), (d, "D"), (150 - a, "M")], 150
+            md = f"{a}^{'ACGT'[i % 4] * d}{150 - a}"
+        elif k == 3:
+            cig, n, md = [(5, "S"), (60, "M"), (3, "D"), (85, "M")], 150, "60^ACG85"
+        elif k == 4:
+            cig, n, md = [(10, "S"), (60, "M"), (70, "N"), (80, "M")], 150, "140"
+        else:
+            cig, n, md = [(3, "H"), (10, "S"), (140, "M")], 150, "70A69"
+        seq = "".join("ACGT"[int(x)] for x in rng.integers(0, 4, n))
+        recs.append(bamio.pack_record("e%d" % i, seq, cig, ref_id=0, pos=pos, qual=bytes(int(x) for x in rng.integers(2, 41, n)), tags=bamio.tag_z("MD", md)))
+        pos += int(rng.integers(0, 12))
+    st = b"".join(recs)
+    stage_rows(ctx, st)
+    check_decode(ctx, st)
+    check_pileup(ctx, st, entries=True, window=2000)
+    tm = ctx.timing_get()
+    assert ran_rows(ctx) and tm["k_cig4_from_arena"]["launches"] == 1
+    for skip in (True, False):
+        _check_refbase(ctx, st, skip_zero=skip, window=1500)
+    ctx.timing_enable(False)
+
+
+def test_a_read_of_five_ops_keeps_the_stream_off_the_rows_route(ctx):
+    """Framing sees every header: one read of more than four CIGAR ops (K4 walks such reads from checkpoints and plans every read itself) and k12_lds
+    writes the first-ops side array instead of plan rows, as it did before there were rows -- nothing is written for nobody, nothing made twice."""
+    rng = np.random.default_rng(71)
+    recs = [rec("n%d" % i, 150, [(150, "M")], 5 * i, rng) for i in range(400)]
+    recs.insert(200, rec("odd", 150, [(40, "M"), (2, "I"), (30, "M"), (3, "D"), (78, "M")], 5 * 200, rng))
+    st = b"".join(recs)
+    stage_rows(ctx, st)
+    check_decode(ctx, st)
+    check_pileup(ctx, st, entries=True, window=700)
+    tm = ctx.timing_get()
+    assert not ran_rows(ctx) and tm["k4_plan"]["launches"] > 0 and "k_cig4_from_arena" not in tm
+    ctx.timing_enable(False)
