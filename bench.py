@@ -495,6 +495,24 @@ def main():
             e["algorithmic_GBps"] = round(e["algorithmic_bytes"] / (e["k5_ms"] * 1e-3) / 1e9, 1) if e["k5_ms"] else None
             e["frac"] = round(e["algorithmic_GBps"] / HBM_PEAK_GBPS, 4) if e["k5_ms"] else None
             out["entries_path"] = e
+        if world == 1 and not a.no_md:
+            # The decode a caller with no pileup to follow asks for (bgp_flush_decode(BGP_FETCH_ALL | BGP_DECODE_ONLY): the table and the arenas, nothing
+            # for K4): K0 + the decode kernel by their HIP events, against SURVEY 8(d)'s decode bytes.  Beside the headline, not in it.
+            ctx.timing_enable(True); ctx.timing_reset()
+            for _ in range(3):
+                ctx.reset(); ctx.attach_device_stream(sptr, slen)
+                ctx.flush(decode=L.BGP_FETCH_ALL | L.BGP_DECODE_ONLY)
+            torch.cuda.synchronize(dev)
+            tm = ctx.timing_get(); ctx.timing_enable(False)
+            k0 = sum(v["total_ms"] for k, v in tm.items() if k.startswith("k0_")) / 3
+            dk = {k: v["total_ms"] / 3 for k, v in tm.items() if k.startswith(("k12_", "k1_", "k2_")) and v["launches"]}
+            dec_b = int(stream_bytes) + 32 * n_reads + 2 * sum_lseq + 4 * sum_ncig
+            kms = sum(dk.values())
+            out["decode_only"] = {"what": "bgp_flush_decode(BGP_FETCH_ALL | BGP_DECODE_ONLY): framing + record table + SEQ / QUAL / CIGAR arenas, no plan rows, no side array (3 passes, HIP events)",
+                                  "k0_ms": round(k0, 3), "decode_kernels_ms": {k: round(v, 3) for k, v in dk.items()},
+                                  "decode_kernel_frac": round(dec_b / (kms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if kms else None,
+                                  "decode_8d_frac": round(dec_b / ((k0 + kms) * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if kms else None}
+            ctx.reset(); ctx.attach_device_stream(sptr, slen)       # (the legs below stage their own input)
         if world == 1 and not a.no_e2e and a.config != "cfg5":
             # the same path fed from host memory and from a file -- PCIe- and inflate-inclusive, labelled, never `value`.
             import bench_e2e
