@@ -498,8 +498,9 @@ def main():
         if world == 1 and not a.no_md:
             # The decode a caller with no pileup to follow asks for (bgp_flush_decode(BGP_FETCH_ALL | BGP_DECODE_ONLY): the table and the arenas, nothing
             # for K4): K0 + the decode kernel by their HIP events, against SURVEY 8(d)'s decode bytes.  Beside the headline, not in it.
-            ctx.timing_enable(True); ctx.timing_reset()
-            for _ in range(3):
+            for rep in range(5):                                     # (two passes untimed: the legs in front of this one leave the device idle between their kernels)
+                if rep == 2:
+                    torch.cuda.synchronize(dev); ctx.timing_enable(True); ctx.timing_reset()
                 ctx.reset(); ctx.attach_device_stream(sptr, slen)
                 ctx.flush(decode=L.BGP_FETCH_ALL | L.BGP_DECODE_ONLY)
             torch.cuda.synchronize(dev)
