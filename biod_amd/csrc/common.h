@@ -92,7 +92,7 @@ enum : uint32_t {
     ST_EINVAL = 1u << 0, ST_ETRUNC = 1u << 1, ST_ECIGAR = 1u << 2, ST_EUNSORTED = 1u << 3, ST_ESEQ = 1u << 4, ST_EMD = 1u << 5,
 };
 int bgp_status_from_bits(uint32_t bits);      // hard errors first; ESEQ is soft
-constexpr uint32_t ST_ODDREAD = 1u << 17;      // not an error: some record has more than four CIGAR ops or more than 255 bases -- K4 walks such reads from checkpoints and plans every read itself, so k12_lds writes the first-ops side array, not plan rows
+constexpr uint32_t ST_ODDREAD = 1u << 17;      // not an error: some record has more than BGP_PLAN_MAX_OPS CIGAR ops or more than 255 bases -- K4 walks such reads from checkpoints and plans every read itself, so k12_lds writes the first-ops side array, not plan rows
 constexpr uint32_t ST_LONGCIG = 1u << 16;      // not an error: some record has more than BGP_LONG_CIGAR ops (its end_position is finished by k1_long_cigar)
 
 struct KernelTimer {
@@ -138,7 +138,7 @@ struct bgp_ctx {
     bool frame_tolerant_tail = false; uint64_t frame_tail = 0;   // batched staging (batch.cpp): a stream may end inside a record; where the record chain stopped
     bool table_compacted = false;                     // a region filter compacted the record table: records the filter dropped still lie between the kept ones in the stream
     bool defer_long_cigar = false, long_cigar_deferred = false;   // a CIGAR unpack follows the record table at once: it sums the long CIGARs it copies anyway (k2_unpack) instead of k1_long_cigar reading them first
-    bool odd_reads = false;                           // framing saw a record of more than four CIGAR ops or more than 255 bases (ST_ODDREAD)
+    bool odd_reads = false;                           // framing saw a record of more than BGP_PLAN_MAX_OPS CIGAR ops or more than 255 bases (ST_ODDREAD)
     bool table_pending = false, long_cigar = false;   // the record table is written lazily: by k1_table, or by the fused K1+K2 if a decode comes first
     DevBuf d_seg_list; DevBuf d_scan_tmp; HostBuf h_mail;                // (h_mail: pinned, written by k_mail)
     DevBuf d_sd_desc; int sd_timer_idx = -1;         // single-pass decode (decode.hip: k_stream_decode): control words + one 64-byte descriptor per chunk
@@ -376,6 +376,7 @@ __device__ __forceinline__ uint32_t cig_rc(uint32_t raw) { return (0x3C1A7u >> (
 // Classes (a byte a record, its low two bits): 0 the read covers nothing (pileup.d:481,510), 1 the row says it all, 2 anything else (the planner's, k4_plan).
 // The moulds are k4_plan's `simple` ones, so that a read contributes the same whichever way it takes.
 constexpr uint32_t BGP_ROW_REACH = 256;
+constexpr uint32_t BGP_PLAN_MAX_OPS = 16;       // the CIGAR ops of a read k4_plan_rest plans (behind plan rows; four at a time); a stream with a longer CIGAR takes no rows (ST_ODDREAD)
 constexpr uint32_t BGP_CLS_NO_SKIP = 0x10u;      // beside the class (low two bits): the whole CIGAR was seen (four ops at most) and holds no N -- dna(read) by the CIGAR is end_position - position
 __device__ __forceinline__ uint32_t bgp_plan_row(uint32_t pos, uint32_t n_cig, uint32_t l_seq, bool covered, uint4 c4, uint64_t seq_abs, uint64_t stream_len, uint4* row) {
     const uint32_t ops[4] = {c4.x, c4.y, c4.z, c4.w};

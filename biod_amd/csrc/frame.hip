@@ -237,7 +237,7 @@ template <class RD, int SINK> __device__ __forceinline__ bool chase_one(const Fr
         if (lseq < 0 || l_name == 0 || 32ull + l_name + 4ull * n_cig + (uint64_t)((lseq + 1) / 2) + (uint64_t)lseq > (uint64_t)bs) { err = ST_EINVAL; return false; }
         *v = (uint32_t)(off - seg0);
         ++cnt; ls += (uint64_t)lseq; nc += n_cig;
-        long_seen |= n_cig > LONG_CIGAR; odd_seen |= n_cig > 4u || lseq > 255;
+        long_seen |= n_cig > LONG_CIGAR; odd_seen |= n_cig > BGP_PLAN_MAX_OPS || lseq > 255;
         off += 4 + (uint64_t)bs;
         live = off < seg_end;
         return true;
@@ -368,7 +368,7 @@ __global__ __launch_bounds__(256) void k0_rechase(FrameArgs a, const uint32_t* l
                 const uint32_t l_name = f3[0] & 0xFFu, n_cig = f3[1] & 0xFFFFu;
                 if (lseq < 0 || l_name == 0 || 32ull + l_name + 4ull * n_cig + (uint64_t)((lseq + 1) / 2) + (uint64_t)lseq > (uint64_t)bs) { atomicAdd(&s_acc[25], 1ull); continue; }
                 if (n_cig > LONG_CIGAR) atomicAdd(&s_acc[24], 1ull);
-                if (n_cig > 4u || lseq > 255) atomicAdd(&s_acc[26], 1ull);
+                if (n_cig > BGP_PLAN_MAX_OPS || lseq > 255) atomicAdd(&s_acc[26], 1ull);
                 const uint32_t wj = a.sub ? o >> a.sub_shift : 0u;                     // the record counts in front of every window behind its own, and in the totals
                 for (uint32_t w = wj + 1; w <= nb; ++w) { unsigned long long* q = s_acc + 3 * (w - 1); atomicAdd(q, 1ull); atomicAdd(q + 1, (unsigned long long)(uint32_t)lseq); atomicAdd(q + 2, (unsigned long long)n_cig); }
             }

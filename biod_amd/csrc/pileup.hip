@@ -1080,7 +1080,11 @@ template <bool SPARSE> __device__ __forceinline__ void plan_batch(const PlanArgs
     const uint32_t n_cig = y.x & 0xFFFFu, l_seq = y.y;
     const uint64_t cig_off = (((uint64_t)y.w << 32) | y.z) + 36 + (x.w & 0xFFu);
     const uint64_t seq_off = cig_off + 4ull * n_cig;
-    bool simple = covered && n_cig >= 1 && n_cig <= 4 && l_seq >= 1 && l_seq <= (uint32_t)FAST_SEG && seq_off + (l_seq + 1) / 2 + 16 <= a.stream_len;   // (staging reads 16 bytes per lane)
+    // (k4_plan_rest, behind plan rows: reads of up to BGP_PLAN_MAX_OPS ops, four at a time, the ops behind the fourth from the stream -- such a stream
+    // has no other way for them: framing has vouched that nothing in it wants checkpoints)
+    constexpr uint32_t MAX_OPS = SPARSE ? BGP_PLAN_MAX_OPS : 4u;
+    constexpr int NG = SPARSE ? (int)(BGP_PLAN_MAX_OPS / 4u) : 1;
+    bool simple = covered && n_cig >= 1 && n_cig <= MAX_OPS && l_seq >= 1 && l_seq <= (uint32_t)FAST_SEG && seq_off + (l_seq + 1) / 2 + 16 <= a.stream_len;   // (staging reads 16 bytes per lane)
     uint32_t ops[4];
     if (a.cig4) { ops[0] = c4.x; ops[1] = c4.y; ops[2] = c4.z; ops[3] = c4.w; }
     else {
@@ -1098,6 +1102,21 @@ template <bool SPARSE> __device__ __forceinline__ void plan_batch(const PlanArgs
             seen_ref |= rc;
             qsum += qc ? len : 0u;
         }
+        for (int g = 1; g < NG; ++g) {                    // (SPARSE only) the ops behind the fourth
+            const bool more = simple && n_cig > 4u * (uint32_t)g;
+            if (!__builtin_amdgcn_ballot_w64(more)) break;
+            uint4 og = make_uint4(0u, 0u, 0u, 0u);
+            if (more) __builtin_memcpy(&og, a.s + cig_off + 16ull * (uint64_t)g, 16);      // (inside the record: the CIGAR lies in front of SEQ, and seq_off + 16 <= stream_len)
+            const uint32_t o4[4] = {og.x, og.y, og.z, og.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t op = o4[k], len = op >> 4;
+                const bool on = more && 4u * (uint32_t)g + (uint32_t)k < n_cig, rc = on && cig_rc(op), qc = on && cig_qc(op);
+                bad |= rc && (len == 0 || (!seen_ref && !qc));
+                seen_ref |= rc;
+                qsum += qc ? len : 0u;
+            }
+        }
         simple = simple && !bad && qsum <= l_seq;
     }
     if (covered && !simple) {
@@ -1109,14 +1128,22 @@ template <bool SPARSE> __device__ __forceinline__ void plan_batch(const PlanArgs
         }
     }
     const uint32_t wf = simple ? wf0 : 0xFFFFFFFFu;
-    const bool any = simple;
+    bool any = simple;
+    uint32_t p = 0, q = 0;                                // columns / query bases before the op (file header: cstart, qstart)
+    for (int g = 0; g < NG; ++g) {                        // (one round; SPARSE: a round per four ops)
+    if (g) {
+        any = simple && n_cig > 4u * (uint32_t)g;
+        if (!__builtin_amdgcn_ballot_w64(any)) break;
+        uint4 og = make_uint4(0u, 0u, 0u, 0u);
+        if (any) __builtin_memcpy(&og, a.s + cig_off + 16ull * (uint64_t)g, 16);
+        ops[0] = og.x; ops[1] = og.y; ops[2] = og.z; ops[3] = og.w;
+    }
     {
         const uint32_t n_ops = simple ? n_cig : 0u;
-        uint32_t p = 0, q = 0;                            // columns / query bases before the op (file header: cstart, qstart)
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const uint32_t op = ops[k], len = op >> 4;
-            const bool on = (uint32_t)k < n_ops, qc = on && cig_qc(op), rc = on && cig_rc(op);
+            const bool on = 4u * (uint32_t)g + (uint32_t)k < n_ops, qc = on && cig_qc(op), rc = on && cig_rc(op);
             const uint32_t a0 = rel0 + p, a1 = a0 + len;                             // run-relative columns [a0, a1) of the op
             const uint32_t w0 = a0 >> SH, w1 = (a1 - 1) >> SH;
             const uint32_t lo0 = a0 & (uint32_t)(W - 1), n0 = min(len, (uint32_t)W - lo0);
@@ -1139,7 +1166,7 @@ template <bool SPARSE> __device__ __forceinline__ void plan_batch(const PlanArgs
         }
     }
     const unsigned long long am = __ballot(any);
-    if (!am) return;
+    if (!am) { if (SPARSE) continue; return; }
     if (SPARSE) {
         // The batch is the few reads in a thousand that k4_plan_rest lists -- N skips mostly: their descriptors spread over a dozen windows
         // (where the reads start, and up to a skip's length further on), a few lanes each.  Claimed one by one that was 1.8 x 10^7
@@ -1171,7 +1198,7 @@ template <bool SPARSE> __device__ __forceinline__ void plan_batch(const PlanArgs
             if (slot < a.slab_cap) a.slab[(uint64_t)win[j] * a.slab_cap + slot] = dsc[j];
         }
         __builtin_amdgcn_wave_barrier();
-        return;
+        continue;
     }
     // slots in the windows' slabs.  Reads are sorted, so nearly every descriptor of a wave goes to the wave's first
     // window A or to A + 1: those two are claimed with one atomic each for the whole wave; the few others (second
@@ -1205,6 +1232,7 @@ template <bool SPARSE> __device__ __forceinline__ void plan_batch(const PlanArgs
         if (slot == 0xFFFFFFF0u) a.slab[(uint64_t)win[j] * a.slab_cap] = dsc[j];
 #endif
     }
+    }      // (rounds of four ops)
 }
 
 __global__ __launch_bounds__(256) void k4_plan(PlanArgs a) {
@@ -2506,6 +2534,7 @@ int k34_pileup(bgp_ctx* c) {
     constexpr bool long_rows = true;
 #endif
         // long reads through the accumulate path as rows in reference coordinates (0: the general kernel, as before)
+    if (c->rows_ok) st[3] = 0;      // (behind plan rows: framing has vouched that no read has more than BGP_PLAN_MAX_OPS ops or 255 bases -- k4_plan_rest plans them all, nothing wants checkpoints)
     const bool long_stream = !long_rows && (uint64_t)st[3] * 4 >= n && st[3] > 0;
     const uint32_t tw = long_stream ? (uint32_t)WO : (uint32_t)W;
     uint64_t col_base = 0, tile_base = 0;

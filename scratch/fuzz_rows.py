@@ -1,5 +1,5 @@
 """Differential fuzz of K4's rows route on the GPU box (k12_lds plan rows -> k4_acc2<ROWS> + k4_plan_rest): random sorted streams of reads with
-at most four CIGAR ops of every type and up to 255 bases (so that the stream holds no long read and the route is taken), every depth from a
+at most sixteen CIGAR ops (most: four) of every type and up to 255 bases (so that the stream holds no long read and the route is taken), every depth from a
 few to several hundred, runs that start anywhere, several references; decode, columns and (every third round) per-read entries vs the oracle.
 usage: python scratch/fuzz_rows.py [n_rounds] [seed0]"""
 import sys, time
@@ -24,7 +24,7 @@ def stream(rng, n_reads, quirks):
         if rng.random() < 0.002:
             pos += int(rng.integers(1000, 200_000))          # an island (a new run behind 65 536 uncovered positions, or not)
         pos += int(rng.integers(0, step_hi + 1))
-        n_ops = int(rng.integers(1, 5))
+        n_ops = int(rng.integers(1, 5)) if rng.random() < 0.8 else int(rng.integers(5, 17))      # (one read in five: up to 16 ops, the planner's, four at a time)
         budget = int(rng.integers(1, lmax + 1))
         ops = []
         for k in range(n_ops):

@@ -231,12 +231,34 @@ def test_rows_entries_and_reference_bases(ctx):
     ctx.timing_enable(False)
 
 
-def test_a_read_of_five_ops_keeps_the_stream_off_the_rows_route(ctx):
-    """Framing sees every header: one read of more than four CIGAR ops (K4 walks such reads from checkpoints and plans every read itself) and k12_lds
-    writes the first-ops side array instead of plan rows, as it did before there were rows -- nothing is written for nobody, nothing made twice."""
+def test_rows_reads_of_up_to_sixteen_ops(ctx):
+    """Behind plan rows the planner (k4_plan_rest) takes the reads a row cannot hold four ops at a time, up to sixteen: doubly-indelled reads, clips
+    on both sides, N skips between M runs, at depth -- columns and entries == oracle, the rows route taken."""
+    rng = np.random.default_rng(83)
+    shapes = [
+        [(5, "S"), (40, "M"), (2, "I"), (30, "M"), (3, "D"), (60, "M"), (13, "S")],
+        [(30, "M"), (1, "I"), (30, "M"), (1, "D"), (30, "M"), (1, "I"), (30, "M"), (1, "D"), (28, "M")],
+        [(3, "H"), (4, "S"), (20, "M"), (300, "N"), (20, "M"), (2, "P"), (20, "M"), (900, "N"), (20, "=", ), (10, "X"), (2, "D"), (30, "M"), (5, "I"), (15, "M"), (6, "S"), (2, "H")],
+        [(10, "M")] + [(1, "D"), (9, "M")] * 7 + [(1, "I")],
+        [(150, "M")], [(70, "M"), (5, "D"), (80, "M")],
+    ]
+    recs, pos = [], 40
+    for i in range(2400):
+        cig = shapes[int(rng.integers(0, len(shapes)))]
+        n = sum(ln for ln, op in cig if op in "MIS=X")
+        recs.append(rec("s%d" % i, n, cig, pos, rng))
+        pos += int(rng.integers(0, 7))
+    st = b"".join(recs)
+    info, ora = run(ctx, st, entries=True, window=1777)
+    assert info.max_coverage > 40
+
+
+def test_a_read_of_seventeen_ops_keeps_the_stream_off_the_rows_route(ctx):
+    """Framing sees every header: one read of more CIGAR ops than the planner takes (K4 walks such reads from checkpoints and plans every read itself)
+    and k12_lds writes the first-ops side array instead of plan rows, as it did before there were rows -- nothing is written for nobody, nothing made twice."""
     rng = np.random.default_rng(71)
     recs = [rec("n%d" % i, 150, [(150, "M")], 5 * i, rng) for i in range(400)]
-    recs.insert(200, rec("odd", 150, [(40, "M"), (2, "I"), (30, "M"), (3, "D"), (78, "M")], 5 * 200, rng))
+    recs.insert(200, rec("odd", 150, [(10, "M")] + [(1, "D"), (10, "M")] * 8 + [(60, "M")], 5 * 200, rng))
     st = b"".join(recs)
     stage_rows(ctx, st)
     check_decode(ctx, st)
