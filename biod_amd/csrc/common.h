@@ -138,6 +138,7 @@ struct bgp_ctx {
     bool frame_tolerant_tail = false; uint64_t frame_tail = 0;   // batched staging (batch.cpp): a stream may end inside a record; where the record chain stopped
     bool table_compacted = false;                     // a region filter compacted the record table: records the filter dropped still lie between the kept ones in the stream
     bool defer_long_cigar = false, long_cigar_deferred = false;   // a CIGAR unpack follows the record table at once: it sums the long CIGARs it copies anyway (k2_unpack) instead of k1_long_cigar reading them first
+    uint32_t bs0_hint = 0; const uint8_t* bs0_ptr = nullptr; uint64_t bs0_len = 0;   // the first record's block_size as the last framing read it, good while the same bytes are framed again (k0_frame sizes its segments by it: one host round trip less a pass)
     bool odd_reads = false;                           // framing saw a record of more than BGP_PLAN_MAX_OPS CIGAR ops or more than 255 bases (ST_ODDREAD)
     bool table_pending = false, long_cigar = false;   // the record table is written lazily: by k1_table, or by the fused K1+K2 if a decode comes first
     DevBuf d_seg_list; DevBuf d_scan_tmp; HostBuf h_mail;                // (h_mail: pinned, written by k_mail)

@@ -531,8 +531,11 @@ int k0_frame(bgp_ctx* c) {
         return BGP_OK;
     }
     // segment size: ~8 average records, from the first record's size (any value is correct)
+    // (a host round trip of its own -- 30 us on a quiet host, 200 on a busy one -- unless these very bytes were framed before: a consumer that
+    // frames a resident stream again finds the value the last pass read; every pass reads it afresh with its last fetch, below)
     uint32_t bs0 = 0;
-    { const MailItem it{c->d_stream, &bs0, 4}; BGP_TRY(mail_fetch(c, &it, 1)); }
+    if (c->bs0_hint && c->bs0_ptr == c->d_stream && c->bs0_len == len) bs0 = c->bs0_hint;
+    else { const MailItem it{c->d_stream, &bs0, 4}; BGP_TRY(mail_fetch(c, &it, 1)); }
     // ~64 records per segment: k0_guess costs one wave per segment, the chase is a per-lane serial chain per
     // segment that is bound by line fetches, not by its length (measured on cfg3, guess / chase / step: 8 records
     // 7.4 / 1.2 ms; 32: 1.87 / 1.58 / 43.8 ms; 64: 0.94 / 1.60 / 42.5 ms; 128: 0.48 / 1.66 / 43.0 ms)
@@ -598,6 +601,8 @@ int k0_frame(bgp_ctx* c) {
         if (n_seg <= 32768) hipLaunchKernelGGL(k0_guess_wide, dim3((unsigned)n_seg), dim3(256), 0, c->stream, a);      // few, large segments: a workgroup each
         else hipLaunchKernelGGL(k0_guess, dim3((unsigned)((n_seg + 3) / 4)), dim3(256), 0, c->stream, a);
     }
+    uint32_t bits = 0;
+    uint64_t n = 0, sl = 0, sc = 0, tail = len;      // (what the last round's fetch brings: status bits, the totals of the three scans, where the chain stopped)
     uint64_t rounds = 0;
     uint32_t n_list = 0;                 // the segments of a repair round, when they are few enough to be listed and small enough for LDS
     // k0_rechase keeps a segment and a ninth more in LDS -- beyond the 64 KiB a kernel gets without asking: whether the device grants that is
@@ -614,32 +619,31 @@ int k0_frame(bgp_ctx* c) {
             if (listed) { hipLaunchKernelGGL(k0_rechase, dim3(n_list), dim3(256), rechase_lds, c->stream, a, a.list, n_list); BGP_HIP(hipGetLastError()); }
             else { hipLaunchKernelGGL(k0_chase, dim3(lane_blocks), dim3(256), 0, c->stream, a); BGP_HIP(hipGetLastError()); }
         }
-        BGP_HIP(hipMemsetAsync(a.status + 1, 0, 4, c->stream));
+        BGP_HIP(hipMemsetAsync(a.status, 0, 8, c->stream));      // the status bits and the dirty counter are this round's
         hipLaunchKernelGGL(k0_verify, dim3(lane_blocks), dim3(256), 0, c->stream, a);
-        uint32_t ndirty = 0;
-        { const MailItem it{a.status + 1, &ndirty, 4}; BGP_TRY(mail_fetch(c, &it, 1)); }
+        // What follows the LAST round -- the segments' error bits, the three exclusive scans (records, bases, CIGAR ops in front of every
+        // segment), where the chain stopped -- is queued behind EVERY round and comes back with the round's dirty count in one round trip:
+        // a round that leaves nothing dirty (the second, as a rule) is the last, and its results are already here.  A round that does has
+        // run three small scans for nothing (~20 us of kernels against a host round trip of 30 us on a quiet host and 200 on a busy one).
+        hipLaunchKernelGGL(k0_collect_errors, dim3(lane_blocks), dim3(256), 0, c->stream, a);
+        {
+            const uint64_t* const in[3] = {a.cnt, a.lseq, a.ncig};
+            uint64_t* const out[3] = {c->d_seg_rec_base.as<uint64_t>(), c->d_seg_seq_base.as<uint64_t>(), c->d_seg_cig_base.as<uint64_t>()};
+            BGP_TRY(scan_exclusive_u64x3(c, in, out, n_seg, nullptr));
+        }
+        uint32_t ndirty = 0, first_bs = 0;
+        {   // (tail: where the chain of records stopped -- in a batch the bytes behind it belong to the next one; first_bs: the first record's block_size, for the next pass over these bytes)
+            const MailItem it[7] = {{a.status + 1, &ndirty, 4}, {a.status, &bits, 4}, {c->d_seg_rec_base.as<uint64_t>() + n_seg, &n, 8}, {c->d_seg_seq_base.as<uint64_t>() + n_seg, &sl, 8},
+                                    {c->d_seg_cig_base.as<uint64_t>() + n_seg, &sc, 8}, {a.end + (n_seg - 1), &tail, 8}, {c->d_stream, &first_bs, 4}};
+            BGP_TRY(mail_fetch(c, it, 7));
+        }
+        c->bs0_hint = first_bs; c->bs0_ptr = c->d_stream; c->bs0_len = len;
         if (getenv("BGP_VERBOSE") && rounds < 8) fprintf(stderr, "[biodgpu] framing round %llu: %u of %llu segments re-entered (seg %u B)\n", (unsigned long long)rounds, ndirty, (unsigned long long)n_seg, seg);
         if (ndirty == 0) break;
         n_list = ndirty <= a.list_cap && seg <= (128u << 10) ? ndirty : 0u;
         if (++rounds > n_seg + 2) { c->last_error = "record framing did not converge"; return BGP_EDEVICE; }
     }
-    // errors, the three exclusive scans (records, bases, CIGAR ops in front of every segment) and where the chain stopped:
-    // everything is queued, the host waits once
-    hipLaunchKernelGGL(k0_collect_errors, dim3(lane_blocks), dim3(256), 0, c->stream, a);
-    uint32_t bits = 0;
-    uint64_t n = 0, sl = 0, sc = 0;
-    {
-        const uint64_t* const in[3] = {a.cnt, a.lseq, a.ncig};
-        uint64_t* const out[3] = {c->d_seg_rec_base.as<uint64_t>(), c->d_seg_seq_base.as<uint64_t>(), c->d_seg_cig_base.as<uint64_t>()};
-        BGP_TRY(scan_exclusive_u64x3(c, in, out, n_seg, nullptr));
-    }
     c->frame_tail = len;
-    uint64_t tail = len;
-    {   // (where the chain of records stopped: in a batch the bytes behind it belong to the next one)
-        const MailItem it[5] = {{a.status, &bits, 4}, {c->d_seg_rec_base.as<uint64_t>() + n_seg, &n, 8}, {c->d_seg_seq_base.as<uint64_t>() + n_seg, &sl, 8},
-                                {c->d_seg_cig_base.as<uint64_t>() + n_seg, &sc, 8}, {a.end + (n_seg - 1), &tail, 8}};
-        BGP_TRY(mail_fetch(c, it, 5));
-    }
     if (c->frame_tolerant_tail) c->frame_tail = tail;
     const int st = bgp_status_from_bits(bits);
     if (st < 0 && st != BGP_ESEQ) return st;
