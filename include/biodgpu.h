@@ -109,7 +109,8 @@ int bgp_flush(bgp_ctx* ctx);
  * rows and unpack are one kernel that reads every stream byte once (the shape of BamReadRange feeding
  * read.sequence / base_qualities / cigar as it goes, readrange.d:118-173 + read.d:225-228,364-383,468-470).  A
  * following bgp_decode_device / _fetch for the same sections finds them done.  Same results and errors as bgp_flush
- * followed by bgp_decode_device(what). */
+ * followed by bgp_decode_device(what).  `what | BGP_DECODE_ONLY`: the caller's word that no pileup will follow -- the pass then
+ * writes nothing for the pileup kernels (a pileup asked for anyway is correct, it plans every read itself). */
 int bgp_flush_decode(bgp_ctx* ctx, uint32_t what);
 int bgp_num_records(bgp_ctx* ctx, uint64_t* n);
 
