@@ -27,3 +27,25 @@ def test_rccl_probe_lists_what_is_mapped():
     import bench
     libs = bench.rccl_libraries_mapped()
     assert isinstance(libs, list) and all("librccl" in os.path.basename(p) for p in libs)
+
+
+def test_generator_reference_property_holds_for_the_oracle():
+    """What bench.py's whole-stream check of `use_md_tag` rests on (interior_parity.md_generator_reference_check): the generator writes its MD tags against
+    one hash-defined reference, so on a stream without N skips the ORACLE's reference_base (PileupRangeUsingMdTag restated, pileup.d:522-654) is that
+    reference at every covered column -- and on a stream with N skips it is not (dna(read) leaves the skipped bases out, md/reconstruct.d:199)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import interior_parity as IP
+    import oracle_lib as O
+    from biod_amd.synth import host_stream, make_cfg
+    for profile, expect_equal in ((0, True), (1, False)):
+        cfg = make_cfg(n_reads=3000, n_ref=2, ref_len=30_000, read_len=150, profile=profile, seed=9)
+        ora = O.pileup(host_stream(cfg), use_md=True, skip_zero=True)
+        same = True
+        for r in (0, 1):
+            sel = ora.ref == r
+            pos = ora.pos[sel].astype(np.int64)
+            if not len(pos):
+                continue
+            ref = IP.synth_reference_chars(int(cfg.seed), r, int(pos.min()), int(pos.max() - pos.min()) + 1)
+            same = same and bool((ora.refbase[sel] == ref[pos - pos.min()]).all())
+        assert same == expect_equal, profile
