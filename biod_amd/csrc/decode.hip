@@ -402,9 +402,9 @@ struct SdArgs {
 };
 
 
-// unaligned little-endian reads at byte offset o of the LDS window: gfx950's DS unit takes unaligned addresses, so each is ONE
-// ds_read (round 2 read the aligned dwords around it and funnel-shifted: two reads and a v_alignbyte per dword -- and VALU issue
-// is what bounds k12_lds, 82 % of its SIMD cycles by the SQ counters)
+// unaligned little-endian reads at byte offset o of the LDS window: the aligned dwords around it, funnel-shifted (v_alignbyte).  gfx950's DS
+// unit does take unaligned addresses -- one ds_read each, fewer VALU instructions in a kernel whose SIMDs issue 80 % of their cycles -- but
+// measured slower (14.2-14.3 against 13.4 ms: the unaligned accesses cost the LDS more than they save the VALU); BGP_WL_NATIVE=1 builds that.
 #ifndef BGP_WL_NATIVE
 #define BGP_WL_NATIVE 0
 #endif
