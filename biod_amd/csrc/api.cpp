@@ -259,7 +259,7 @@ int bgp_init(int device, bgp_ctx** out) {
 
 static void release_all(bgp_ctx* c) {
     DevBuf* d[] = {&c->d_stream_own, &c->d_synth, &c->d_seg_entry, &c->d_seg_end, &c->d_seg_cnt, &c->d_seg_lseq, &c->d_seg_ncig, &c->d_seg_dirty,
-                   &c->d_seg_rec_base, &c->d_seg_seq_base, &c->d_seg_cig_base, &c->d_seg_side, &c->d_seg_list, &c->d_scan_tmp, &c->d_sd_desc, &c->d_status, &c->d_rec, &c->d_seq_off, &c->d_cigar_off,
+                   &c->d_seg_rec_base, &c->d_seg_seq_base, &c->d_seg_cig_base, &c->d_seg_side, &c->d_seg_list, &c->d_scan_tmp, &c->d_k3_bsum, &c->d_sd_desc, &c->d_status, &c->d_rec, &c->d_seq_off, &c->d_cigar_off,
                    &c->d_seq, &c->d_qual, &c->d_cigar, &c->d_pmax_end, &c->d_pmax_pos, &c->d_runs, &c->d_columns, &c->d_depth_hist, &c->d_pstats,
                    &c->d_tiles, &c->d_ck_off, &c->d_ck, &c->d_deep, &c->d_wlong, &c->d_entry_off, &c->d_entries, &c->d_col_lo,
                    &c->d_md_row, &c->d_md_iv, &c->d_md_state, &c->d_refbase, &c->d_md_succ, &c->d_md_exit, &c->d_md_entry, &c->d_md_bmax, &c->d_md_long, &c->d_md_ck, &c->d_md_vlist, &c->d_snp, &c->d_maq, &c->d_maq_tab, &c->d_rec2, &c->d_seq_off2, &c->d_cigar_off2,
@@ -275,9 +275,13 @@ void bgp_destroy(bgp_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     prefetch_cancel(c);
     if (c->pf.done) (void)hipEventDestroy(c->pf.done);
+    // an open batched pass copies on the ctx's upload stream (batch.cpp: Batch::copy_stream = c->io_up) and batch_release waits for it:
+    // the pass is closed and the I/O streams drained while they still exist, and only then destroyed
+    batch_release(c);
+    if (c->io_up) (void)hipStreamSynchronize(c->io_up);
+    for (hipStream_t x : c->io_inf) if (x) (void)hipStreamSynchronize(x);
     if (c->io_up) (void)hipStreamDestroy(c->io_up);
     for (hipStream_t x : c->io_inf) if (x) (void)hipStreamDestroy(x);
-    batch_release(c);
     bgp_timing_collect(c);
     release_all(c);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);

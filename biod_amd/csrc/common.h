@@ -64,6 +64,10 @@ struct HostBuf {                      // pinned host memory
         if (p && want < 2 * cap) want = 2 * cap;
         hipError_t e = hipHostMalloc(&np, want, hipHostMallocDefault);
         if (e != hipSuccess && want > bytes + (bytes >> 3) + 4096) { (void)hipGetLastError(); want = bytes + (bytes >> 3) + 4096; e = hipHostMalloc(&np, want, hipHostMallocDefault); }      // (pinned memory is short: what is needed, no more)
+        // still short: dead generations are given back before BGP_ENOMEM is -- first those older than the last one retired (a view a caller
+        // still holds is, by the header's contract, of the buffer this call replaces or of the one before), then that one too
+        if (e != hipSuccess && retired.size() > 1) { (void)hipGetLastError(); void* keep = retired.back(); retired.pop_back(); trim(); retired.push_back(keep); e = hipHostMalloc(&np, want, hipHostMallocDefault); }
+        if (e != hipSuccess && !retired.empty()) { (void)hipGetLastError(); trim(); e = hipHostMalloc(&np, want, hipHostMallocDefault); }
         if (e != hipSuccess) { bgp_note_hip_error(e, "hipHostMalloc", __FILE__, __LINE__); return BGP_ENOMEM; }
         if (p) retire(p);
         p = np; cap = want;
@@ -141,7 +145,7 @@ struct bgp_ctx {
     uint32_t bs0_hint = 0; const uint8_t* bs0_ptr = nullptr; uint64_t bs0_len = 0;   // the first record's block_size as the last framing read it, good while the same bytes are framed again (k0_frame sizes its segments by it: one host round trip less a pass)
     bool odd_reads = false;                           // framing saw a record of more than BGP_PLAN_MAX_OPS CIGAR ops or more than 255 bases (ST_ODDREAD)
     bool table_pending = false, long_cigar = false;   // the record table is written lazily: by k1_table, or by the fused K1+K2 if a decode comes first
-    DevBuf d_seg_list; DevBuf d_scan_tmp; HostBuf h_mail;                // (h_mail: pinned, written by k_mail)
+    DevBuf d_seg_list; DevBuf d_scan_tmp; DevBuf d_k3_bsum; uint64_t k3_bsum_n = 0; /* K3's scanned tile maxima (k4_bounds mode 3 searches them) and the record count they were made for */ HostBuf h_mail;                // (h_mail: pinned, written by k_mail)
     DevBuf d_sd_desc; int sd_timer_idx = -1;         // single-pass decode (decode.hip: k_stream_decode): control words + one 64-byte descriptor per chunk
     DevBuf d_status;                                  // uint32 status bits + counters
     bool flushed = false;

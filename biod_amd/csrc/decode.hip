@@ -384,6 +384,7 @@ constexpr uint32_t L_MISC = L_INFO + 1536;                            // u64[84]
 constexpr uint32_t L_TOTAL = L_MISC + 8 * 84;
 static_assert(SD_WIN + 32 <= 65535 && SD_NS * SD_SUBCAP * 2 <= 2080 + 1536, "the sub-chunk lists overlay the emission tables");
 static_assert(SD_C % 16 == 0 && SD_T <= 1024 && SD_RB <= SD_T, "geometry");
+static_assert(2 * SD_RB <= SD_T, "plan rows are made by the SD_RB threads behind the table's (sd_emit): fewer waves would leave rows unwritten");
 static_assert(BGP_SD_MINW * 4 / SD_NW * L_TOTAL <= 160 * 1024, "the workgroups the launch bounds promise must fit the LDS");
 enum { M_TICKET = 0, M_FOUND, M_CNT, M_EXIT, M_ERR, M_BAD, M_LS, M_NC, M_FLAGS, M_ENT, M_PN, M_PLS, M_PNC, M_ABORT, M_TM = 16 /* 4 tile maxima */, M_WS = 20 /* 2 x 8 u64 of scan scratch */,
        M_SUBG = 36 /* SD_NS guesses */, M_SUBX = 44 /* exits */, M_SUBC = 52 /* records | status << 32 */, M_EFF = 60 /* records the chunk's chain takes from the sub-chunk */, M_SUBLS = 68 /* bases */, M_SUBNC = 76 /* CIGAR ops | a CIGAR longer than BGP_LONG_CIGAR << 63 */, M_N = 84 };
@@ -560,7 +561,7 @@ __device__ __forceinline__ void sd_excl2(uint32_t v0, uint32_t v1, uint32_t* e0,
 // from the LDS window, block scan for the arena offsets, coalesced stores), then the arenas with one lane per 16-byte
 // chunk.  pn / pls / pnc: records, bases, CIGAR ops in front of the chunk.  A last record that runs past the window
 // (last_long) is unpacked from global memory by the whole workgroup.
-template <bool SEQ, bool QUAL, bool CIG>
+template <bool SEQ, bool QUAL, bool CIG, bool ROWS, bool CIG4>
 __device__ __forceinline__ void sd_emit(const SdArgs& a, uint8_t* sd_lds, uint64_t wbase, uint32_t cnt, bool last_long, u64 pn, u64 pls, u64 pnc) {
     uint32_t* const w = reinterpret_cast<uint32_t*>(sd_lds);
     uint16_t* const roff = reinterpret_cast<uint16_t*>(sd_lds + L_ROFF);
@@ -600,7 +601,7 @@ __device__ __forceinline__ void sd_emit(const SdArgs& a, uint8_t* sd_lds, uint64
             rec.end_pos = (int32_t)((uint32_t)rec.pos + covered);                                   // read.d:1382
             lseq = (uint32_t)rec.l_seq; ncig = n_cig;
         }
-        if (a.prow && t >= SD_RB && t - SD_RB < rc) {
+        if (ROWS && t >= SD_RB && t - SD_RB < rc) {
             // What K4 wants to know of the round's reads (common.h: bgp_plan_row), by the waves that have no table row to make: beside the
             // row's own work it was 0.45 ms of the kernel's 13 -- two of a workgroup's eight waves hold records, the others waited for them.
             // The read's few words once more from LDS; a CIGAR of more than four ops is the planner's whatever it covers (it looks again).
@@ -636,10 +637,10 @@ __device__ __forceinline__ void sd_emit(const SdArgs& a, uint8_t* sd_lds, uint64
         if (valid) {
 #if BGP_K12_NT_ROWS
             { uint4 r0v, r1v; __builtin_memcpy(&r0v, &rec, 16); __builtin_memcpy(&r1v, reinterpret_cast<const char*>(&rec) + 16, 16);
-              nt_store16(reinterpret_cast<char*>(a.rec + i), r0v); nt_store16(reinterpret_cast<char*>(a.rec + i) + 16, r1v); if (a.cig4) nt_store16(a.cig4 + i, c4v);
+              nt_store16(reinterpret_cast<char*>(a.rec + i), r0v); nt_store16(reinterpret_cast<char*>(a.rec + i) + 16, r1v); if (CIG4) nt_store16(a.cig4 + i, c4v);
               __builtin_nontemporal_store(carry_seq + es, a.seq_off + i); __builtin_nontemporal_store(carry_cig + ec, a.cig_off + i); }
 #else
-            a.rec[i] = rec; a.seq_off[i] = carry_seq + es; a.cig_off[i] = carry_cig + ec; if (a.cig4) a.cig4[i] = c4v;
+            a.rec[i] = rec; a.seq_off[i] = carry_seq + es; a.cig_off[i] = carry_cig + ec; if (CIG4) a.cig4[i] = c4v;
 #endif
             soff[t] = es; coff[t] = ec;
             info[3 * t] = (uint16_t)cig_o; info[3 * t + 1] = (uint16_t)(cig_o + 4 * ncig); info[3 * t + 2] = (uint16_t)(cig_o + 4 * ncig + (uint32_t)((rec.l_seq + 1) / 2));   // read.d:992-998
@@ -684,8 +685,8 @@ __device__ __forceinline__ void sd_emit(const SdArgs& a, uint8_t* sd_lds, uint64
             }
             rec.end_pos = (int32_t)((uint32_t)rec.pos + covered);
             const uint64_t i = pn + cnt - 1;
-            a.rec[i] = rec; a.seq_off[i] = carry_seq; a.cig_off[i] = carry_cig; if (a.cig4) a.cig4[i] = c4v;
-            if (a.prow) { a.prow[i] = make_uint4(0, 0, 0, 0); a.rcls[i] = (covered != 0 || (n_cig > BGP_LONG_CIGAR && !((rec.flag_nc >> 16) & 0x4u))) ? 2 : 0; }      // (a record that runs past its window: the planner's)
+            a.rec[i] = rec; a.seq_off[i] = carry_seq; a.cig_off[i] = carry_cig; if (CIG4) a.cig4[i] = c4v;
+            if (ROWS) { a.prow[i] = make_uint4(0, 0, 0, 0); a.rcls[i] = (covered != 0 || (n_cig > BGP_LONG_CIGAR && !((rec.flag_nc >> 16) & 0x4u))) ? 2 : 0; }      // (a record that runs past its window: the planner's)
             if (a.tilemax) {
                 const K3Key kk = k3_key_of(rec.ref_id, rec.pos, rec.end_pos);
                 if (kk.e) atomicMax(&a.tilemax[2 * (i / K3_TILE_RECORDS)], (unsigned long long)kk.e);
@@ -721,7 +722,7 @@ struct LdsArgs {
     const uint4* sub; uint32_t sub_n;      // a K0 segment is sub_n windows: records / bases / ops of the segment in front of each (k0_chase)
 };
 
-template <bool SEQ, bool QUAL, bool CIG>
+template <bool SEQ, bool QUAL, bool CIG, bool ROWS, bool CIG4>
 __global__ __launch_bounds__(SD_T, BGP_SD_MINW) void k12_lds(LdsArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t sd_lds[];
     uint16_t* const roff = reinterpret_cast<uint16_t*>(sd_lds + L_ROFF);
@@ -757,7 +758,7 @@ __global__ __launch_bounds__(SD_T, BGP_SD_MINW) void k12_lds(LdsArgs a) {
         __syncthreads();
     }
     const bool last_long = (uint64_t)roff[cnt - 1] + 4 + (uint64_t)wl32(w, roff[cnt - 1]) > wlen;
-    sd_emit<SEQ, QUAL, CIG>(a.d, sd_lds, wbase, cnt, last_long, pn, a.seq_base[sg] + p0.y, a.cig_base[sg] + p0.z);
+    sd_emit<SEQ, QUAL, CIG, ROWS, CIG4>(a.d, sd_lds, wbase, cnt, last_long, pn, a.seq_base[sg] + p0.y, a.cig_base[sg] + p0.z);
 }
 
 }  // namespace
@@ -932,7 +933,14 @@ int k12_lds_decode(bgp_ctx* c, uint32_t what) {
     const uint64_t n_win = std::min<uint64_t>(c->n_seg * c->seg_windows, (c->stream_len + SD_C - 1) / SD_C);
     {
         TimedRegion t(c, "k12_lds", c->stream_len + n * 32 + 2 * c->sum_lseq + 4 * c->sum_ncig);      // SURVEY 8(d) without the framing: the record in, row + seq + qual + cigar out
-        hipLaunchKernelGGL((k12_lds<true, true, true>), dim3((unsigned)n_win), dim3(SD_T), L_TOTAL, c->stream, a);
+        // what K4 is left (plan rows, the first-ops side array) is compiled in or out: the rows' block behind a run-time test cost every variant
+        // registers -- 64 VGPRs with a spill to scratch and 56 spilled SGPRs against 62 / 0 / 29 without it (round 5's lost 0.7 ms)
+#define LAUNCH(r_, c_) hipLaunchKernelGGL((k12_lds<true, true, true, r_, c_>), dim3((unsigned)n_win), dim3(SD_T), L_TOTAL, c->stream, a)
+        if (want_rows && want_cig4) LAUNCH(true, true);
+        else if (want_rows) LAUNCH(true, false);
+        else if (want_cig4) LAUNCH(false, true);
+        else LAUNCH(false, false);
+#undef LAUNCH
         BGP_TRY(k1_finish_long_cigars(c));
     }
     BGP_HIP(hipGetLastError());

@@ -2494,8 +2494,8 @@ int k34_pileup(bgp_ctx* c) {
             static const uint32_t run_gap = getenv("BGP_RUN_GAP") ? (uint32_t)atoll(getenv("BGP_RUN_GAP")) : 65536u;      // (tests: small islands)
             K3Args a{c->d_rec.as<bgp_record>(), n, c->d_pmax_end.as<uint64_t>(), c->d_pmax_pos.as<uint64_t>(), status, run_cap, run_gap};
             const uint64_t nt = (n + K3_TILE - 1) / K3_TILE;
-            BGP_TRY(c->d_scan_tmp.reserve((nt + 2) * sizeof(K3Key)));
-            K3Key* bsum = c->d_scan_tmp.as<K3Key>();
+            BGP_TRY(c->d_k3_bsum.reserve((nt + 2) * sizeof(K3Key))); c->k3_bsum_n = n;      // (a buffer of its own: k4_bounds searches it after other scans have used d_scan_tmp)
+            K3Key* bsum = c->d_k3_bsum.as<K3Key>();
             if (c->tilemax_ok)      // K1 left the tiles' maxima behind (it had every row in registers): no first pass over the table
                 BGP_HIP(hipMemcpyAsync(bsum, c->d_tilemax.p, nt * sizeof(K3Key), hipMemcpyDeviceToDevice, c->stream));
             else
@@ -2585,8 +2585,8 @@ int k34_pileup(bgp_ctx* c) {
             lite_bounds = !long_stream && !st[3];
             // k12_lds left plan rows: the accumulate path takes a window's ordinary reads from them (a sorted stream of short reads; anything else is planned read by read)
             static const bool rows_env = !(getenv("BGP_K4_ROWS") && atoi(getenv("BGP_K4_ROWS")) == 0);
-            use_rows = rows_env && c->rows_ok && lite_bounds && rc == BGP_OK;
-            hipLaunchKernelGGL(k4_bounds, dim3((unsigned)((tile_base + 255) / 256)), dim3(256), 0, c->stream, a.pmax_end, a.pmax_pos, a.runs, n_runs, tile_base, c->d_tiles.as<TileB>(), tw, use_rows ? 3 : lite_bounds ? 1 : 0, (const uint32_t*)nullptr, (const uint32_t*)nullptr, c->d_scan_tmp.as<K3Key>(), n);      // (d_scan_tmp: K3's tile maxima, scanned -- nothing has touched it since)
+            use_rows = rows_env && c->rows_ok && lite_bounds && rc == BGP_OK && c->k3_bsum_n == n;      // (the scanned tile maxima the row ranges are searched through must be this table's)
+            hipLaunchKernelGGL(k4_bounds, dim3((unsigned)((tile_base + 255) / 256)), dim3(256), 0, c->stream, a.pmax_end, a.pmax_pos, a.runs, n_runs, tile_base, c->d_tiles.as<TileB>(), tw, use_rows ? 3 : lite_bounds ? 1 : 0, (const uint32_t*)nullptr, (const uint32_t*)nullptr, c->d_k3_bsum.as<K3Key>(), n);      // (K3's tile maxima, scanned: k3_bsum's own buffer, made for these n records)
         }
         constexpr uint64_t WG_SLOTS = 65536;            // k4_acc's workgroups leave their ranges' totals behind the windows' slots
         BGP_TRY(c->d_col_lo.reserve((tile_base + WG_SLOTS) * 32));

@@ -14,7 +14,8 @@
  * functions taking a ctx are not re-entrant.  Ownership (mirrors bio/std/hts/bam/pileup.d:396,
  * 660-661 "storage is reused"): every pointer returned through an out-struct is owned by the ctx and
  * stays valid until the next call that produces the same kind of result, or bgp_destroy (the memory behind it stays
- * mapped until bgp_reset / bgp_destroy: a pointer kept too long reads stale bytes, never freed memory).
+ * mapped until bgp_reset / bgp_destroy: a pointer kept too long reads stale bytes, never freed memory -- unless pinned
+ * host memory runs out: replaced buffers are then given back, oldest first, before a call answers BGP_ENOMEM).
  *
  * There is NO CPU fallback: without a usable gfx950 device bgp_init fails with BGP_EDEVICE.
  */
