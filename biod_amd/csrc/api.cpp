@@ -10,6 +10,12 @@
 #include <cstdio>
 
 static thread_local std::string g_last_hip_error;
+DevMem& bgp_devmem() {
+    static DevMem m;
+    static const bool once = [] { if (const char* e = getenv("BGP_HBM_CAP")) m.cap.store(strtoull(e, nullptr, 0)); return true; }();
+    (void)once;
+    return m;
+}
 
 void bgp_note_hip_error(hipError_t e, const char* what, const char* file, int line) {
     char buf[512];
@@ -220,6 +226,15 @@ const char* bgp_strerror(int s) {
 }
 
 int bgp_abi_version(void) { return BGP_ABI_VERSION; }
+
+int bgp_device_memory(uint64_t* current, uint64_t* peak, int reset_peak) {
+    DevMem& m = bgp_devmem();
+    if (current) *current = m.cur.load();
+    if (peak) *peak = m.peak.load();
+    if (reset_peak) m.peak.store(m.cur.load());
+    return BGP_OK;
+}
+int bgp_set_device_memory_cap(uint64_t bytes) { bgp_devmem().cap.store(bytes); return BGP_OK; }
 
 int bgp_init(int device, bgp_ctx** out) {
     BGP_API_TRY

@@ -22,31 +22,7 @@
 
 #include <algorithm>
 
-struct Batch {
-    uint64_t batch_bytes = 0, reserve = 0;
-    int want_entries = 0; uint32_t window = 65536;
-    // Three pinned buffers: one takes the caller's bytes, full ones wait in a queue for a free device buffer, the rest are free or the
-    // source of a copy in flight (host_free tells).  With two, the full buffer a caller commits while batch i + 1 is on its way could
-    // only leave at the caller's next call -- after it had been handed batch i + 1's windows -- and the two directions of the link took turns.
-    static constexpr int NH = 3;
-    HostBuf host[NH]; uint64_t host_len[NH] = {0, 0, 0}; hipEvent_t host_free[NH] = {nullptr, nullptr, nullptr};
-    int fill = 0;                                       // host buffer taking the pushes (-1: none to be had before a full one has left)
-    int fullq[NH] = {0, 0, 0}; int n_full = 0;          // full buffers waiting for a device buffer, oldest first
-    int acq = -1; uint64_t acq_off = 0;                 // bgp_batch_acquire handed out host[acq] from acq_off on and waits for its commit (-1: nothing outstanding)
-    DevBuf dev[2]; uint64_t new_off[2] = {0, 0}, new_len[2] = {0, 0}; hipEvent_t loaded_ev[2] = {nullptr, nullptr};
-    enum { FREE, LOADED, CURRENT } state[2] = {FREE, FREE};
-    int queue[2] = {0, 0}; int n_queue = 0;             // loaded device buffers, oldest first
-    hipStream_t copy_stream = nullptr;
-    bool ended = false, any_batch = false;
-    int cur = -1; bool cur_final = false;
-    uint64_t carry_off = 0, carry_len = 0;              // suffix of the current batch's stream the next batch begins with
-    uint64_t ord_base = 0, next_ord_base = 0;           // stream-wide ordinal of the current batch's record 0
-    bool resume = false; int32_t resume_ref = 0; uint64_t resume_pos = 0;      // where handing out stopped before this batch
-    bool cut = false; int32_t cut_ref = 0; uint64_t cut_pos = 0;                // where it stops in this one
-    uint32_t run = 0; uint64_t next_pos = 0; bool run_open = false;
-    // use_md_tag across batches: the provider chain's state at the last event in front of the cut (stream-wide record ordinals)
-    struct { bool have = false; uint64_t P_ord = 0, i_ord = 0; uint32_t ci = 0, y = 0, ce = 0; int32_t ref = -1; } md;
-};
+#include "batch.h"
 
 // The pinned and device buffers a finished batched pass left in the ctx (for the next bgp_batch_begin) are given back as soon as the ctx
 // stages a stream any other way: a one-shot load then finds the pinned host memory and the HBM it had before batches were ever used.
@@ -59,6 +35,7 @@ void batch_unpark(bgp_ctx* c) {
 void batch_release(bgp_ctx* c) {
     Batch* b = c->batch;
     if (!b) return;
+    if (b->feed) { feed_release(c, b); for (hipStream_t x : c->io_inf) if (x) (void)hipStreamSynchronize(x); }      // (the readers stopped, no inflate left writing into a buffer that is about to go)
     if (b->copy_stream) (void)hipStreamSynchronize(b->copy_stream);      // (the ctx's upload stream: not this pass's to destroy)
     // (the pinned buffers and the two device buffers go back to the ctx: the next bgp_batch_begin takes them again -- pinning
     // 2 x 256 MiB anew cost ~70 ms, 40 % of a 10 M-read stream's whole pass)
@@ -167,6 +144,7 @@ static int process_next(bgp_ctx* c, Batch* b) {
     b->queue[0] = b->queue[1]; --b->n_queue;
     const bool final = b->ended && b->n_queue == 0 && b->n_full == 0 && (b->fill < 0 || b->host_len[b->fill] == 0);
     BGP_HIP(hipStreamWaitEvent(c->stream, b->loaded_ev[q], 0));
+    if (b->feed && b->new_len[q]) BGP_TRY(feed_check(c, b, q));      // a batch k_inflate made: every block's size and CRC held (block.d:197-207)
     if (b->carry_len > b->new_off[q]) {                              // a carry longer than the room in front of the new bytes: a bigger buffer, once
         DevBuf bigger;
         const uint64_t room = b->carry_len + (b->carry_len >> 2) + 256;
@@ -179,7 +157,7 @@ static int process_next(bgp_ctx* c, Batch* b) {
     uint8_t* base = b->dev[q].as<uint8_t>() + b->new_off[q] - b->carry_len;
     if (b->carry_len) { TimedRegion tc(c, "d2d_carry", b->carry_len);
         BGP_HIP(hipMemcpyAsync(base, c->d_stream + b->carry_off, b->carry_len, hipMemcpyDeviceToDevice, c->stream)); }
-    if (b->cur >= 0) { BGP_HIP(hipStreamSynchronize(c->stream)); b->state[b->cur] = Batch::FREE; BGP_TRY(ship_if_full(c, b)); }     // the carry is out: the old batch's buffer can take the next load -- at once, if a full pinned buffer is waiting
+    if (b->cur >= 0) { BGP_HIP(hipStreamSynchronize(c->stream)); b->state[b->cur] = Batch::FREE; BGP_TRY(ship_if_full(c, b)); if (b->feed) BGP_TRY(feed_pump(c, b, false)); }     // the carry is out: the old batch's buffer can take the next load -- at once, if a full pinned buffer is waiting
     b->cur = q; b->state[q] = Batch::CURRENT; b->cur_final = final; b->any_batch = true;
     c->d_stream = base; c->stream_len = b->carry_len + b->new_len[q]; c->stream_on_device = true;
     c->frame_tolerant_tail = !final;
@@ -250,6 +228,13 @@ extern "C" {
 int bgp_batch_begin(bgp_ctx* c, uint64_t batch_bytes, int want_entries, uint32_t window_positions) {
     BGP_API_TRY
     if (!c) return BGP_EINVAL;
+    return batch_begin_core(c, batch_bytes, want_entries, window_positions, true);
+    BGP_API_CATCH(c)
+}
+
+}  // extern "C"
+
+int batch_begin_core(bgp_ctx* c, uint64_t batch_bytes, int want_entries, uint32_t window_positions, bool host_buffers) {
     BGP_HIP(hipSetDevice(c->device));
     const int32_t n_ref_hint = c->n_ref_hint;                                // bgp_set_n_ref before bgp_batch_begin holds for every batch (bgp_reset forgets it)
     BGP_TRY(bgp_reset(c));
@@ -264,18 +249,19 @@ int bgp_batch_begin(bgp_ctx* c, uint64_t batch_bytes, int want_entries, uint32_t
         BGP_HIP(hipEventCreateWithFlags(&b->host_free[q], hipEventDisableTiming));
         BGP_HIP(hipEventRecord(b->host_free[q], b->copy_stream));
         std::swap(b->host[q], c->h_batch[q]);                                            // what the last batched pass left (empty the first time)
-        BGP_TRY(b->host[q].reserve(b->batch_bytes));
+        if (host_buffers) BGP_TRY(b->host[q].reserve(b->batch_bytes));
     }
     for (int q = 0; q < 2; ++q) { BGP_HIP(hipEventCreateWithFlags(&b->loaded_ev[q], hipEventDisableTiming)); std::swap(b->dev[q], c->d_batch[q]); }
     return BGP_OK;
-    BGP_API_CATCH(c)
 }
+
+extern "C" {
 
 int bgp_batch_push(bgp_ctx* c, const uint8_t* data, size_t len, size_t* taken) {
     BGP_API_TRY
     if (!c || (!data && len) || !taken) return BGP_EINVAL;
     Batch* b = c->batch;
-    if (!b || b->ended) return BGP_ESTATE;
+    if (!b || b->ended || b->feed) return BGP_ESTATE;      // (a pass bgp_stream_bam_begin feeds from a file takes no bytes from the caller)
     if (b->acq >= 0) return BGP_ESTATE;                  // an acquired buffer is waiting for its commit: a push could ship it from under the caller
     BGP_HIP(hipSetDevice(c->device));
     *taken = 0;
@@ -299,7 +285,7 @@ int bgp_batch_acquire(bgp_ctx* c, uint8_t** ptr, size_t* cap) {
     BGP_API_TRY
     if (!c || !ptr || !cap) return BGP_EINVAL;
     Batch* b = c->batch;
-    if (!b || b->ended) return BGP_ESTATE;
+    if (!b || b->ended || b->feed) return BGP_ESTATE;      // (a pass bgp_stream_bam_begin feeds from a file takes no bytes from the caller)
     if (b->acq >= 0) return BGP_ESTATE;                  // one acquisition at a time: commit (0 bytes if need be) before the next
     BGP_HIP(hipSetDevice(c->device));
     *ptr = nullptr; *cap = 0;
@@ -316,7 +302,7 @@ int bgp_batch_commit(bgp_ctx* c, size_t n) {
     BGP_API_TRY
     if (!c) return BGP_EINVAL;
     Batch* b = c->batch;
-    if (!b || b->ended) return BGP_ESTATE;
+    if (!b || b->ended || b->feed) return BGP_ESTATE;      // (a pass bgp_stream_bam_begin feeds from a file takes no bytes from the caller)
     if (b->acq < 0) return BGP_ESTATE;                   // nothing was acquired
     const int h = b->acq;                                // the buffer that was handed out, whatever `fill` says by now
     if (b->host_len[h] != b->acq_off || n > b->batch_bytes - b->host_len[h]) return BGP_EINVAL;
@@ -341,7 +327,7 @@ int bgp_batch_set_md(bgp_ctx* c, int use_md_tag, int skip_zero_coverage) {
 int bgp_batch_end(bgp_ctx* c) {
     BGP_API_TRY
     if (!c || !c->batch) return BGP_ESTATE;
-    if (c->batch->acq >= 0) return BGP_ESTATE;           // an acquired buffer was never committed
+    if (c->batch->acq >= 0 || c->batch->feed) return BGP_ESTATE;           // an acquired buffer was never committed | the file says when the stream is over
     c->batch->ended = true;
     return BGP_OK;
     BGP_API_CATCH(c)
@@ -353,6 +339,7 @@ int bgp_batch_next_window(bgp_ctx* c, bgp_columns* o) {
     Batch* b = c->batch;
     if (!b) return BGP_ESTATE;
     BGP_HIP(hipSetDevice(c->device));
+    if (b->feed) BGP_TRY(feed_pump(c, b, false));                        // (a file feeds the pass: whatever has been read by now and fits a free device buffer is on its way)
     for (;;) {
         if (b->cur >= 0) {                                               // hand out the current batch's final columns, run after run
             while (b->run < c->runs.size()) {
@@ -381,8 +368,9 @@ int bgp_batch_next_window(bgp_ctx* c, bgp_columns* o) {
             if (b->cur_final) return BGP_EOF;
         }
         // the next batch
+        if (b->n_queue == 0 && b->feed) BGP_TRY(feed_pump(c, b, true));       // (waits for the file: a batch is queued, or the stream is over)
         if (b->n_queue == 0) {
-            if (!b->ended) return BGP_EAGAIN;                            // push more, or say the stream is over
+            if (!b->ended) return b->feed ? BGP_ESTATE : BGP_EAGAIN;        // push more, or say the stream is over
             if (!b->n_full) {
                 if (b->fill < 0) next_fill(b);
                 if ((b->fill >= 0 && b->host_len[b->fill]) || !b->any_batch) close_fill(b);      // what is left in the host buffer is the last batch (an empty stream is one, too)

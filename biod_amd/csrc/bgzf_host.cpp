@@ -24,7 +24,7 @@
 
 namespace {
 
-struct Blk { uint64_t coff; uint32_t cdata_off, cdata_len, crc, isize; uint64_t uoff; };
+typedef BgzfBlk Blk;      // (common.h: shared with the file feeder, stream.cpp)
 
 // Block headers from file offset `off` on, while off < stop; f[x] is readable for x < n (n = file size, or the end
 // of the bytes read so far -- a block is at most 64 KB, so a reader that holds 128 KB past `stop` sees it whole).
@@ -84,6 +84,10 @@ int inflate_cdata(const uint8_t* cdata, const Blk& b, uint8_t* dst) {     // blo
 int inflate_block(const uint8_t* f, const Blk& b, uint8_t* dst) { return inflate_cdata(f + b.coff + b.cdata_off, b, dst); }   // f = the whole file
 
 }  // namespace
+
+// the same scan and the same zlib call for the feeder of bgp_stream_bam_begin (stream.cpp)
+int bgzf_scan_blocks(const uint8_t* f, uint64_t n, uint64_t stop, uint64_t& off, uint64_t& uoff, std::vector<BgzfBlk>& out, std::string& err) { return scan_blocks(f, n, stop, off, uoff, out, err); }
+int bgzf_inflate_cdata(const uint8_t* cdata, const BgzfBlk& b, uint8_t* dst) { return inflate_cdata(cdata, b, dst); }
 
 // Worker threads when the caller passes 0: the CPUs this process may run on (affinity mask), cut by the cgroup
 // CPU quota -- a container that shows 256 logical CPUs under a 16-CPU cpu.max inflates slower on 256 threads.
@@ -456,4 +460,33 @@ int bgzf_load_bam_device(bgp_ctx* c, const char* path) {
     for (const Blk& b : blocks) if (b.isize) c->stage_end_coff = b.coff + b.cdata_off + b.cdata_len + 8;
     c->d_stream = c->d_stream_own.as<uint8_t>() + SLACK; c->stream_len = rec_bytes; c->stream_on_device = true;
     return BGP_OK;
+}
+
+// BAM magic, header text and reference table (reader.d:111-116,579-597) of the file behind fd, its first blocks inflated on the
+// host until they parse: *q = offset of the first record in the inflated stream.
+int bgzf_read_bam_header(int fd, uint64_t fsz, std::vector<RefInfo>& refs, uint64_t* q, std::string& err) {
+    std::vector<uint8_t> raw, head;
+    std::vector<Blk> blocks;
+    uint64_t have = 0, off = 0, uoff = 0; size_t jh = 0;
+    for (uint64_t want = 1ull << 20;; want *= 4) {
+        const uint64_t upto = std::min(fsz, want);
+        raw.resize((size_t)upto);
+        while (have < upto) { const ssize_t r = pread(fd, raw.data() + have, (size_t)(upto - have), (off_t)have); if (r <= 0) { err = "short read"; return BGP_ETRUNC; } have += (uint64_t)r; }
+        // (blocks that lie whole in what has been read: a header cut by `upto` is a reason to read more, not an error, unless the file ends there)
+        const int rc = scan_blocks(raw.data(), upto, upto < fsz ? (upto > 65536 + 26 ? upto - 65536 - 26 : 0) : upto, off, uoff, blocks, err);
+        if (rc < 0) return rc;
+        while (jh < blocks.size()) {
+            const Blk& b = blocks[jh];
+            head.resize((size_t)(b.uoff + b.isize));
+            if (inflate_cdata(raw.data() + b.coff + b.cdata_off, b, head.data() + b.uoff) < 0) { err = "zlib: corrupted BGZF block"; return BGP_EINVAL; }
+            ++jh;
+            const int got = bgp_parse_bam_header(head.data(), head.size(), refs, q, err);
+            if (got < 0) return got;
+            if (got > 0) return BGP_OK;
+        }
+        if (upto == fsz) break;
+    }
+    const uint64_t total = blocks.empty() ? 0 : blocks.back().uoff + blocks.back().isize;
+    err = total < 4 ? "wrong BAM magic" : "truncated BAM header";
+    return total < 4 ? BGP_EINVAL : BGP_ETRUNC;
 }

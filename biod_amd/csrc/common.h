@@ -6,6 +6,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
 #include <new>
 #include <stdexcept>
 #include <string>
@@ -33,20 +34,29 @@ int bgp_api_caught(struct bgp_ctx* c, int status, const char* what);
                            catch (const std::exception& e_) { return bgp_api_caught(ctx, BGP_EINVAL, e_.what()); } \
                            catch (...) { return bgp_api_caught(ctx, BGP_EINVAL, "unknown C++ exception"); }
 
+// Device memory the library holds through DevBuf, process-wide: bgp_device_memory reports it, and BGP_HBM_CAP (bytes; api.cpp reads the
+// environment once) makes an allocation beyond it fail with BGP_ENOMEM -- how the bounded-memory file path (stream.cpp) is held to its word.
+struct DevMem { std::atomic<uint64_t> cur{0}, peak{0}, cap{0}; };
+DevMem& bgp_devmem();      // api.cpp
 // A growable device allocation (never shrinks; reused across bgp_reset).
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
     int reserve(size_t bytes) {
         if (bytes <= cap) return BGP_OK;
-        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        DevMem& m = bgp_devmem();
+        if (p) { (void)hipFree(p); p = nullptr; m.cur -= cap; cap = 0; }
         size_t want = bytes + (bytes >> 4) + 256;
+        const uint64_t lim = m.cap.load();
+        if (lim && m.cur.load() + want > lim) { want = bytes + 256; if (m.cur.load() + want > lim) { bgp_note_hip_error(hipErrorOutOfMemory, "BGP_HBM_CAP: the library's device memory would exceed the cap", __FILE__, __LINE__); return BGP_ENOMEM; } }
         hipError_t e = hipMalloc(&p, want);
         if (e != hipSuccess) { p = nullptr; bgp_note_hip_error(e, "hipMalloc", __FILE__, __LINE__); return e == hipErrorOutOfMemory ? BGP_ENOMEM : BGP_EDEVICE; }
         cap = want;
+        const uint64_t now = (m.cur += want);
+        for (uint64_t pk = m.peak.load(); now > pk && !m.peak.compare_exchange_weak(pk, now);) { }
         return BGP_OK;
     }
-    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    void release() { if (p) { (void)hipFree(p); bgp_devmem().cur -= cap; } p = nullptr; cap = 0; }
     template <class T> T* as() const { return (T*)p; }
 };
 
@@ -252,6 +262,10 @@ int synth_device(bgp_ctx* c, const bgp_synth_cfg_c* cfg, uint64_t* bytes);   // 
 int synth_host(const bgp_synth_cfg_c* cfg, uint64_t first, uint64_t count, uint8_t* out, uint64_t cap, uint64_t* bytes);
 int bgzf_load_bam(bgp_ctx* c, const char* path, int n_threads);               // bgzf_host.cpp
 int bgp_parse_bam_header(const uint8_t* p, uint64_t avail, std::vector<RefInfo>& refs, uint64_t* records_off, std::string& err);
+struct BgzfBlk { uint64_t coff; uint32_t cdata_off, cdata_len, crc, isize; uint64_t uoff; };      // a BGZF block: file offset, where its CDATA lies in it, footer CRC32 / ISIZE, offset of its first byte in the inflated stream
+int bgzf_scan_blocks(const uint8_t* f, uint64_t n, uint64_t stop, uint64_t& off, uint64_t& uoff, std::vector<BgzfBlk>& out, std::string& err);   // bgzf_host.cpp: block headers from file offset off while off < stop (inputstream.d:54-199)
+int bgzf_inflate_cdata(const uint8_t* cdata, const BgzfBlk& b, uint8_t* dst);      // zlib + size and CRC checks (block.d:127-216)
+int bgzf_read_bam_header(int fd, uint64_t fsz, std::vector<RefInfo>& refs, uint64_t* q, std::string& err);
 int k_region_filter(bgp_ctx* c, uint32_t ref, uint32_t beg, uint32_t end);    // region.hip
 int bai_stage_chunks(bgp_ctx* c, const char* path, const bgp_chunk* chunks, uint32_t n, int n_threads);   // bai_host.cpp
 int bai_load_header(bgp_ctx* c, const char* path);

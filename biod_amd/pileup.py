@@ -259,6 +259,16 @@ class Context:
                 w.maq = L.as_array(cw.maq, cw.n_positions, L.MAQ_CALL_DTYPE)
             yield w
 
+    def stream_bam_windows(self, path: str, batch_bytes: int = 0, want_entries: bool = False, window_positions: int = 0, maq=None, use_md_tag=False, skip_zero_coverage=True):
+        """The windows of pileupColumns(new BamReader(path).reads) with the FILE streamed through the device in bounded memory
+        (bgp_stream_bam_begin: reader threads -> compressed ring in HBM -> k_inflate -> a batch's kernels -> windows)."""
+        L.check(L.lib().bgp_stream_bam_begin(self._h, path.encode(), batch_bytes, int(want_entries), window_positions), self._h)
+        if use_md_tag:
+            L.check(L.lib().bgp_batch_set_md(self._h, 1, int(skip_zero_coverage)), self._h)
+        if maq is not None:
+            L.check(L.lib().bgp_pileup_maq(self._h, float(maq[0]), float(maq[1]), int(maq[2])), self._h)
+        yield from self.batch_drain()
+
     def batched_windows(self, pieces, batch_bytes: int = 0, want_entries: bool = False, window_positions: int = 0, maq=None, use_md_tag=False, skip_zero_coverage=True):
         """pileupColumns over a stream handed over piece by piece (any cut points): dense windows of final columns."""
         self.batch_begin(batch_bytes, want_entries, window_positions, maq, use_md_tag, skip_zero_coverage)

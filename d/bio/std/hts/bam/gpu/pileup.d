@@ -66,6 +66,8 @@ extern (C) nothrow @nogc {
 
     int bgp_init(int device, bgp_ctx** out_);
     void bgp_destroy(bgp_ctx* ctx);
+    int bgp_device_memory(ulong* current, ulong* peak, int reset_peak);
+    int bgp_set_device_memory_cap(ulong bytes);
     int bgp_set_stream(bgp_ctx* ctx, void* hip_stream);
     int bgp_set_n_ref(bgp_ctx* ctx, int n_ref);
     int bgp_reset(bgp_ctx* ctx);
@@ -181,6 +183,7 @@ extern (C) nothrow @nogc {
     int bgp_pileup_ref_id(bgp_ctx* ctx, int* ref_id);
 
     int bgp_batch_begin(bgp_ctx* ctx, ulong batch_bytes, int want_entries, uint window_positions);
+    int bgp_stream_bam_begin(bgp_ctx* ctx, const(char)* path, ulong batch_bytes, int want_entries, uint window_positions);
     int bgp_batch_set_md(bgp_ctx* ctx, int use_md_tag, int skip_zero_coverage);
     int bgp_batch_push(bgp_ctx* ctx, const(ubyte)* data, size_t len, size_t* taken);
     int bgp_batch_acquire(bgp_ctx* ctx, ubyte** ptr, size_t* cap);

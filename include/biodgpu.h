@@ -59,6 +59,11 @@ const char* bgp_last_error(bgp_ctx* ctx);
  * the role of `new BamReader(fn, taskPool)` resource setup, bio/std/hts/bam/reader.d:127-138. */
 int bgp_init(int device, bgp_ctx** out);
 void bgp_destroy(bgp_ctx* ctx);
+/* Device memory the library holds (all contexts of the process), now and at its peak; reset_peak != 0 makes the peak start over.
+ * bgp_set_device_memory_cap: an allocation that would take the total beyond `bytes` fails with BGP_ENOMEM (0: no cap; the environment
+ * variable BGP_HBM_CAP sets it at start) -- the bounded-memory file path (bgp_stream_bam_begin) is tested under one. */
+int bgp_device_memory(uint64_t* current, uint64_t* peak, int reset_peak);
+int bgp_set_device_memory_cap(uint64_t bytes);
 /* Use a caller-owned hipStream_t for every launch (NULL = the ctx's own stream). */
 int bgp_set_stream(bgp_ctx* ctx, void* hip_stream);
 /* Number of reference sequences from the BAM header (tightens the record-boundary guesser; 0 = unknown). */
@@ -260,6 +265,17 @@ int bgp_pileup_ref_id(bgp_ctx* ctx, int32_t* ref_id);          /* AbstractPileup
  * BAM record (beyond 2^30, or smaller than the sections its header announces) is BGP_EINVAL in the batch it appears in,
  * not "the rest is still to come". */
 int bgp_batch_begin(bgp_ctx* ctx, uint64_t batch_bytes, int want_entries, uint32_t window_positions);
+/* bgp_batch_begin FED BY A FILE, in bounded device memory: new BamReader(filename) under pileupColumns(reads) as BioD runs it -- a ring of
+ * BGZF blocks in flight (read, inflated by decompressBgzfBlock on a worker, consumed in file order: bio/core/bgzf/inputstream.d:386-447,
+ * 455-483, block.d:127-216) under a consumer that pulls, the file never held whole.  Reader threads bring the file to the device
+ * compressed, 8 MiB at a time, into a ring; k_inflate (a wave a BGZF block, size and CRC32 checked as block.d:197-207) inflates a batch of
+ * at most batch_bytes (0 = 256 MiB; at least 128 KiB) from the ring straight into one of the pass's two device buffers while the previous
+ * batch is in its kernels; no inflated byte exists on the host.  The BAM header is read here (bgp_n_ref / bgp_ref_info answer afterwards);
+ * then bgp_batch_next_window hands out the windows until BGP_EOF -- it never answers BGP_EAGAIN: nobody pushes (bgp_batch_push / _acquire /
+ * _commit / _end are BGP_ESTATE).  bgp_batch_set_md, bgp_pileup_maq, bgp_batch_ordinal_base, bgp_decode_fetch between windows: as for any
+ * batched pass.  Device memory is two batch buffers, the ring (batch_bytes and a few chunks) and ONE batch's tables and columns, whatever
+ * the file's size (bgp_device_memory).  Errors: those of bgp_load_bam_device, from the bgp_batch_next_window whose batch holds the block. */
+int bgp_stream_bam_begin(bgp_ctx* ctx, const char* path, uint64_t batch_bytes, int want_entries, uint32_t window_positions);
 /* use_md_tag for the batches (call right after bgp_batch_begin): every window carries reference_base as PileupRangeUsingMdTag
  * (pileup.d:522-654) yields it over the WHOLE stream -- the provider chain's state (provider, cursor, chunk_end_position, the next
  * read add() has not seen) is carried across the seam between two batches, so examples/make_pileup.d:16, makePileup(bam.reads,

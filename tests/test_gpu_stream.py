@@ -1,0 +1,200 @@
+"""A BAM FILE streamed through the device in bounded memory (bgp_stream_bam_begin, biod_amd/csrc/stream.cpp): reader threads ->
+ring of compressed chunks in HBM -> k_inflate into a batch's device buffer -> the batched pass of batch.cpp -> windows.  The shape
+of BgzfInputStream's ring of blocks in flight under a pulling consumer (bio/core/bgzf/inputstream.d:386-447,455-483; block.d:127-216).
+Columns, per-read entries and reference bases must be those of the one-shot load and of the oracle, whatever the batch size; the
+library's device memory must not grow with the file (asserted under a cap smaller than the file's inflated size)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from biod_amd import _lib as L
+from biod_amd import bamio
+from biod_amd.pileup import Context
+from biod_amd.synth import host_stream, host_stream_np, make_cfg, scaled
+
+from test_gpu_parity import FIXTURES, _assert_columns_equal_oracle, _covered, _write_bgzf, device_columns
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = Context(0)
+    yield c
+    c.close()
+
+
+def device_memory(reset_peak=False):
+    cur, peak = C.c_uint64(), C.c_uint64()
+    L.lib().bgp_device_memory(C.byref(cur), C.byref(peak), int(reset_peak))
+    return int(cur.value), int(peak.value)
+
+
+def write_bam_fast(path, refs, st, block=60000):
+    from concurrent.futures import ThreadPoolExecutor
+    b = memoryview(st)
+    with open(path, "wb") as f, ThreadPoolExecutor(8) as ex:
+        f.write(bamio.bgzf_block(bamio.bam_header_bytes(refs)))
+        for blk in ex.map(lambda at: bamio.bgzf_block(bytes(b[at:at + block])), range(0, len(b), block)):
+            f.write(blk)
+        f.write(bamio.BGZF_EOF)
+
+
+@pytest.mark.parametrize("name", FIXTURES)
+@pytest.mark.parametrize("batch", [128 << 10, 0])
+def test_stream_fixtures(ctx, data_dir, name, batch):
+    """Every fixture of the reference's test/data the other loaders are held to: columns == oracle, the header's references known
+    after the begin call; the smallest batches (two BGZF blocks) and the default."""
+    path = os.path.join(data_dir, name)
+    hdr, st = bamio.read_bam(path)
+    ref, pos, cols, _, npos = _covered(ctx.stream_bam_windows(path, batch))
+    assert ctx.references() == [(n, l) for n, l in hdr.refs]
+    ora = O.pileup(st)
+    if name != "bins.bam":
+        _assert_columns_equal_oracle(ref, pos, cols, ora)
+    else:                                               # empty SEQ: coverage only (test_bins_bam_coverage_parity)
+        assert np.array_equal(pos, ora.pos.astype(np.int64)) and np.array_equal(cols["coverage"], ora.cov) and np.array_equal(cols["n_starting_here"], ora.nstart)
+    ctx.reset()
+
+
+@pytest.mark.parametrize("name", ["corrupted_zlib_archive.bam", "duplicated_block_size.bam", "no_block_size.bam", "wrong_bc_subfield_length.bam", "wrong_extra_gzip_length.bam"])
+def test_stream_negative_fixtures(ctx, data_dir, name):
+    """test/unittests.d:132-142: every malformed container is refused on this path too (at the begin call when the damage is in the
+    header's blocks, else at the window whose batch holds the block)."""
+    with pytest.raises(L.BiodGpuError):
+        for _ in ctx.stream_bam_windows(os.path.join(data_dir, name), 128 << 10):
+            pass
+    ctx.reset()
+
+
+@pytest.mark.parametrize("batch", [128 << 10, 300_000, 1 << 20, 0])
+def test_stream_small_batches_entries_and_reference_bases(ctx, tmp_path, batch):
+    """Blocks of random sizes (records straddle them), batches of two to a few dozen blocks, N-skip reads reaching across batches:
+    columns, per-read entries (stream-wide ordinals) and use_md_tag's reference bases == the oracle's."""
+    cfg = make_cfg(n_reads=12_000, n_ref=3, ref_len=30_000, read_len=100, profile=1, seed=batch % 97 + 5)
+    st = host_stream(cfg)
+    path = str(tmp_path / "s.bam")
+    _write_bgzf(path, bamio.bam_header_bytes([(f"chr{i + 1}", 1 << 28) for i in range(cfg.n_ref)]) + st, np.random.default_rng(batch % 89))
+    ora = O.pileup(st, want_entries=True)
+    ref, pos, cols, ents, _ = _covered(ctx.stream_bam_windows(path, batch, want_entries=True, window_positions=3000), want_entries=True)
+    _assert_columns_equal_oracle(ref, pos, cols, ora)
+    assert len(ents) == ora.n_columns
+    for k in range(0, ora.n_columns, 11):
+        oe = ora.entries[int(ora.entry_off[k]):int(ora.entry_off[k + 1])]
+        assert np.array_equal(ents[k]["read_ordinal"], oe["read_ordinal"].astype(np.uint32)), k
+        assert np.array_equal(ents[k]["query_offset"], oe["query_offset"]) and np.array_equal(ents[k]["base"], oe["base"]) and np.array_equal(ents[k]["qual"], oe["qual"])
+    ora_md = O.pileup(st, use_md=True)
+    got = np.concatenate([w.reference_base[w.columns["coverage"] > 0] for w in ctx.stream_bam_windows(path, batch, use_md_tag=True, window_positions=5000)])
+    assert np.array_equal(got, ora_md.refbase)
+    ctx.reset()
+
+
+def test_stream_state_rules_and_reuse(ctx, data_dir, tmp_path):
+    """Nobody pushes into a pass a file feeds; a pass abandoned half way (reset) leaves a ctx that loads and streams again; an empty
+    BAM (header only) has no windows; a missing file and a file that is no BGZF are refused at the begin call."""
+    path = os.path.join(data_dir, "ex1_header.bam")
+    L.check(L.lib().bgp_stream_bam_begin(ctx._h, path.encode(), 128 << 10, 0, 0), ctx._h)
+    for call in (lambda: ctx.batch_push(b"abcd"), ctx.batch_acquire, ctx.batch_end):
+        with pytest.raises(L.BiodGpuError) as e:
+            call()
+        assert e.value.code == L.BGP_ESTATE
+    first = next(ctx.batch_drain(1))
+    assert len(first.columns) > 0
+    ctx.reset()                                            # readers stopped, rings given back
+    _, st = bamio.read_bam(path)
+    ctx.push_inflated(st); ctx.flush()
+    info = ctx.pileup_run()
+    ref, pos, cols, _, npos = _covered(ctx.stream_bam_windows(path, 200_000))
+    assert npos == info.n_positions and len(pos) == info.n_columns
+    empty = str(tmp_path / "empty.bam")
+    bamio.write_bam(empty, [("chr1", 1000)], [])
+    assert list(ctx.stream_bam_windows(empty)) == []
+    assert ctx.references() == [("chr1", 1000)]
+    for bad in (str(tmp_path / "nope.bam"), __file__):
+        with pytest.raises(L.BiodGpuError):
+            list(ctx.stream_bam_windows(bad))
+    ctx.reset()
+
+
+def test_stream_damage_is_refused_like_the_one_shot_load(ctx, tmp_path):
+    """One flipped bit anywhere in a block's CDATA, CRC or ISIZE: refused exactly when the host loader refuses it."""
+    cfg = scaled("cfg2", 60_000)
+    st = host_stream(cfg)
+    path = str(tmp_path / "s.bam")
+    rng = np.random.default_rng(11)
+    _write_bgzf(path, bamio.bam_header_bytes([(f"chr{i + 1}", 1 << 28) for i in range(max(1, cfg.n_ref))]) + st, rng)
+    raw = bytearray(open(path, "rb").read())
+    for trial in range(10):
+        bad = bytearray(raw)
+        at = int(rng.integers(200, len(raw) - 40))
+        bad[at] ^= 1 << int(rng.integers(0, 8))
+        p2 = str(tmp_path / f"bad{trial}.bam")
+        open(p2, "wb").write(bytes(bad))
+        host_ok = True
+        try:
+            h = Context(0); h.load_bam(p2, 2); h.close()
+        except L.BiodGpuError:
+            host_ok = False
+        dev_ok = True
+        try:
+            for _ in ctx.stream_bam_windows(p2, 1 << 20):
+                pass
+        except L.BiodGpuError:
+            dev_ok = False
+        ctx.reset()
+        assert dev_ok == host_ok, (trial, at)
+
+
+def test_stream_file_larger_than_the_memory_cap(tmp_path):
+    """2.4 M reads of cfg3's model (0.7 GB inflated, a file of 13 read chunks) streamed in 32 MiB batches under a cap of 400 MB on the
+    library's device memory -- less than the inflated stream alone: the one-shot device load is refused by that cap, the streamed
+    pass runs, its peak is far below the cap's worth of a whole-file load, and columns, coverage histogram and read count equal the
+    one-shot result (without the cap)."""
+    cfg = scaled("cfg3", 2_400_000)
+    st = host_stream_np(cfg)
+    path = str(tmp_path / "big.bam")
+    write_bam_fast(path, [(f"chr{i + 1}", 1 << 28) for i in range(max(1, cfg.n_ref))], st)
+    assert len(st) > 600 << 20 and os.path.getsize(path) > 5 * (8 << 20)
+    one = Context(0)
+    one.load_bam_device(path); one.flush()
+    info = one.pileup_run()
+    dense = device_columns(one, info)
+    nz = np.nonzero(dense["coverage"])[0]
+    n_reads = one.num_records()
+    one.close()
+    base = device_memory()[0]                              # (what other contexts of the process hold: the accounting is process-wide)
+    cap = base + (400 << 20)
+    L.lib().bgp_set_device_memory_cap(cap)
+    try:
+        c = Context(0)
+        with pytest.raises(L.BiodGpuError) as e:
+            c.load_bam_device(path)
+        assert e.value.code == L.BGP_ENOMEM
+        c.close()                                          # (bgp_reset keeps allocations for reuse -- the compressed file's 0.4 GB among them)
+        assert device_memory()[0] == base
+        c = Context(0)
+        device_memory(reset_peak=True)
+        pos, cols, npos, n_rec = [], [], 0, 0
+        L.check(L.lib().bgp_stream_bam_begin(c._h, path.encode(), 32 << 20, 0, 1 << 20), c._h)
+        last_base = -1
+        for w in c.batch_drain():
+            k = np.nonzero(w.columns["coverage"])[0]
+            pos.append(w.first_position + k.astype(np.int64)); cols.append(w.columns[k]); npos += len(w.columns)
+            ob = c.batch_ordinal_base()
+            if ob != last_base:
+                last_base = ob; n_rec = ob + c.num_records()
+        peak = device_memory()[1]
+        assert peak <= cap
+        print(f"streamed pass: peak device memory {(peak - base) / 2**20:.0f} MiB for a stream of {len(st) / 2**20:.0f} MiB")
+        c.close()
+        assert device_memory()[0] == base                  # (rings, batch buffers, tables: all given back)
+    finally:
+        L.lib().bgp_set_device_memory_cap(0)
+    pos = np.concatenate(pos); cols = np.concatenate(cols)
+    assert n_rec == n_reads == cfg.n_reads
+    assert npos == info.n_positions and len(pos) == info.n_columns == len(nz)
+    for f in L.COLUMN_DTYPE.names:
+        assert np.array_equal(cols[f], dense[f][nz]), f
