@@ -33,6 +33,21 @@ ENTRY_DTYPE = np.dtype([("read_ordinal", "<u4"), ("cigar_op_offset", "<u4"), ("q
                         ("cigar_op_index", "<u2"), ("base", "u1"), ("qual", "u1")])
 RUN_DTYPE = np.dtype([("ref_id", "<i4"), ("_pad", "<u4"), ("first_record", "<u8"), ("end_record", "<u8"),
                       ("start_pos", "<u8"), ("end_pos", "<u8"), ("column_base", "<u8")])
+COLUMN8_DTYPE = np.dtype([(f, "u1") for f in COLUMN_DTYPE.names])      # bgp_column8: the same fields, a byte each (bgp_set_compact_columns)
+
+
+def window_columns(cw, copy=True):
+    """A window's columns as COLUMN_DTYPE whichever way they crossed the link: bgp_columns.columns, or columns8 widened (the consumer
+    sees the same numbers, pileup.d:236-290)."""
+    if cw.columns or not cw.columns8:
+        return as_array(cw.columns, cw.n_positions, COLUMN_DTYPE, copy)
+    c8 = as_array(cw.columns8, cw.n_positions, COLUMN8_DTYPE, False)
+    out = np.empty(cw.n_positions, COLUMN_DTYPE)
+    for f in COLUMN_DTYPE.names:
+        out[f] = c8[f]
+    return out
+
+
 assert RECORD_DTYPE.itemsize == 32 and COLUMN_DTYPE.itemsize == 32 and ENTRY_DTYPE.itemsize == 16 and RUN_DTYPE.itemsize == 48
 
 
@@ -49,7 +64,7 @@ class PileupInfo(C.Structure):
 
 class Columns(C.Structure):
     _fields_ = [("ref_id", C.c_int32), ("n_positions", C.c_uint32), ("first_position", C.c_uint64), ("columns", C.c_void_p),
-                ("entry_off", C.c_void_p), ("entries", C.c_void_p), ("reference_base", C.c_void_p), ("snp", C.c_void_p), ("maq", C.c_void_p)]
+                ("entry_off", C.c_void_p), ("entries", C.c_void_p), ("reference_base", C.c_void_p), ("snp", C.c_void_p), ("maq", C.c_void_p), ("columns8", C.c_void_p)]
 
 
 class ChunkInfo(C.Structure):
@@ -100,6 +115,7 @@ SYMBOLS = {
     "bgp_batch_begin": (C.c_int, [_P, C.c_uint64, C.c_int, C.c_uint32]),
     "bgp_stream_bam_begin": (C.c_int, [_P, C.c_char_p, C.c_uint64, C.c_int, C.c_uint32]),
     "bgp_device_memory": (C.c_int, [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_int]),
+    "bgp_set_compact_columns": (C.c_int, [_P, C.c_int]),
     "bgp_set_device_memory_cap": (C.c_int, [C.c_uint64]),
     "bgp_batch_push": (C.c_int, [_P, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
     "bgp_batch_set_md": (C.c_int, [_P, C.c_int, C.c_int]),

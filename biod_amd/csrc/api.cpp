@@ -127,25 +127,48 @@ int emit_window(bgp_ctx* c, uint32_t run_idx, uint64_t a, uint64_t b, int want_e
     // while it looked at the previous window the copy of this one ran on a stream of its own.  h_cols is always the buffer handed out
     // last -- a caller's view of it stays good until the next call, as the header promises -- and h_cols2 the one being filled.
     static const bool pf_on = !(getenv("BGP_WINDOW_PREFETCH") && atoi(getenv("BGP_WINDOW_PREFETCH")) == 0);
-    const bool hit = c->pf.valid && c->pf.run == run_idx && c->pf.a == a && c->pf.b >= b;
+    // Compact transport (bgp_set_compact_columns): a window leaves the device as 8 bytes a position -- packed by k_pack_columns8 into a
+    // staging buffer, a flag word behind the last position telling whether some count was beyond 255 -- and only a window that holds
+    // such a count is copied again in the 32-byte layout.  The dense array on the device is what it was.
+    const bool compact = c->compact_cols;
+    auto queue_copy = [&](HostBuf& hb, DevBuf& stage, uint64_t first, uint64_t n, hipStream_t st) -> int {      // columns [first, first + n) of the dense array into hb
+        const bgp_column* src = c->d_columns.as<bgp_column>() + first;
+        if (!compact) {
+            BGP_TRY(hb.reserve(n * sizeof(bgp_column)));
+            TimedRegion tw(c, "d2h_window_columns", n * sizeof(bgp_column), st);
+            BGP_HIP(hipMemcpyAsync(hb.p, src, n * sizeof(bgp_column), hipMemcpyDeviceToHost, st));
+            return BGP_OK;
+        }
+        BGP_TRY(hb.reserve(n * 8 + 16)); BGP_TRY(stage.reserve(n * 8 + 16));
+        BGP_TRY(pack_columns8(c, src, n, stage.as<uint8_t>(), st));
+        TimedRegion tw(c, "d2h_window_columns8", n * 8 + 8, st);
+        BGP_HIP(hipMemcpyAsync(hb.p, stage.p, n * 8 + 8, hipMemcpyDeviceToHost, st));
+        return BGP_OK;
+    };
+    const bool hit = c->pf.valid && c->pf.run == run_idx && c->pf.a == a && c->pf.b >= b && c->pf.compact == compact;
     if (c->pf.valid && !hit) prefetch_cancel(c);
     if (hit) {
         BGP_HIP(hipEventSynchronize(c->pf.done));
         std::swap(c->h_cols, c->h_cols2);
         c->pf.valid = false;
-    } else {
-        BGP_TRY(c->h_cols.reserve(np * sizeof(bgp_column)));
-        { TimedRegion tw(c, "d2h_window_columns", np * sizeof(bgp_column));
-        BGP_HIP(hipMemcpyAsync(c->h_cols.p, c->d_columns.as<bgp_column>() + r.column_base + (a - r.start_pos), np * sizeof(bgp_column), hipMemcpyDeviceToHost, c->stream)); }
+    } else BGP_TRY(queue_copy(c->h_cols, c->d_cols8[0], r.column_base + (a - r.start_pos), np, c->stream));
+    bool wide_again = false;
+    if (compact) {                                      // the flag of the window at hand: a count beyond a byte somewhere in it?
+        if (!hit) BGP_HIP(hipStreamSynchronize(c->stream));
+        uint64_t flag; memcpy(&flag, c->h_cols.as<uint8_t>() + np * 8, 8);
+        wide_again = flag != 0;
     }
     if (pf_on && b < r.end_pos) {                       // the window behind this one, as long as this one
         const uint64_t nb = std::min<uint64_t>(r.end_pos, b + np);
         if (!c->pf.done) BGP_HIP(hipEventCreateWithFlags(&c->pf.done, hipEventDisableTiming));
-        BGP_TRY(c->h_cols2.reserve((nb - b) * sizeof(bgp_column)));
-        { TimedRegion tw(c, "d2h_window_columns", (nb - b) * sizeof(bgp_column), c->pf.stream);
-        BGP_HIP(hipMemcpyAsync(c->h_cols2.p, c->d_columns.as<bgp_column>() + r.column_base + (b - r.start_pos), (nb - b) * sizeof(bgp_column), hipMemcpyDeviceToHost, c->pf.stream)); }
+        BGP_TRY(queue_copy(c->h_cols2, c->d_cols8[1], r.column_base + (b - r.start_pos), nb - b, c->pf.stream));
         BGP_HIP(hipEventRecord(c->pf.done, c->pf.stream));
-        c->pf.valid = true; c->pf.run = run_idx; c->pf.a = b; c->pf.b = nb;
+        c->pf.valid = true; c->pf.run = run_idx; c->pf.a = b; c->pf.b = nb; c->pf.compact = compact;
+    }
+    if (wide_again) {                                   // (deeper than 255 somewhere: this window in the 32-byte layout after all)
+        BGP_TRY(c->h_cols_wide.reserve(np * sizeof(bgp_column)));
+        TimedRegion tw(c, "d2h_window_columns", np * sizeof(bgp_column));
+        BGP_HIP(hipMemcpyAsync(c->h_cols_wide.p, c->d_columns.as<bgp_column>() + r.column_base + (a - r.start_pos), np * sizeof(bgp_column), hipMemcpyDeviceToHost, c->stream));
     }
     memset(o, 0, sizeof *o);
     const bool maq = c->it.maq != 0;
@@ -176,7 +199,10 @@ int emit_window(bgp_ctx* c, uint32_t run_idx, uint64_t a, uint64_t b, int want_e
         o->maq = c->h_maq.as<bgp_maq_call>();
     }
     BGP_HIP(hipStreamSynchronize(c->stream));
-    o->ref_id = r.ref_id; o->n_positions = (uint32_t)np; o->first_position = a; o->columns = c->h_cols.as<bgp_column>();
+    o->ref_id = r.ref_id; o->n_positions = (uint32_t)np; o->first_position = a;
+    if (!compact) o->columns = c->h_cols.as<bgp_column>();
+    else if (wide_again) o->columns = c->h_cols_wide.as<bgp_column>();
+    else o->columns8 = c->h_cols.as<bgp_column8>();
     return BGP_OK;
 }
 
@@ -185,8 +211,9 @@ int emit_window(bgp_ctx* c, uint32_t run_idx, uint64_t a, uint64_t b, int want_e
 int emit_gap_window(bgp_ctx* c, int32_t ref_id, uint64_t a, uint64_t b, int want_entries, int use_md, int snp, int maq, bgp_columns* o) {
     const uint64_t np = b - a;
     BGP_HIP(hipStreamSynchronize(c->stream));
-    BGP_TRY(c->h_cols.reserve(np * sizeof(bgp_column)));
-    memset(c->h_cols.p, 0, np * sizeof(bgp_column));
+    const size_t col_bytes = c->compact_cols ? 8 : sizeof(bgp_column);
+    BGP_TRY(c->h_cols.reserve(np * col_bytes + 16));
+    memset(c->h_cols.p, 0, np * col_bytes);
     memset(o, 0, sizeof *o);
     if (want_entries) {
         BGP_TRY(c->h_entry_off.reserve((np + 1) * 8)); BGP_TRY(c->h_entries.reserve(sizeof(bgp_entry)));
@@ -201,7 +228,8 @@ int emit_gap_window(bgp_ctx* c, int32_t ref_id, uint64_t a, uint64_t b, int want
         for (uint64_t k = 0; k < np; ++k) c->h_maq.as<bgp_maq_call>()[k] = none;
         o->maq = c->h_maq.as<bgp_maq_call>();
     }
-    o->ref_id = ref_id; o->n_positions = (uint32_t)np; o->first_position = a; o->columns = c->h_cols.as<bgp_column>();
+    o->ref_id = ref_id; o->n_positions = (uint32_t)np; o->first_position = a;
+    if (c->compact_cols) o->columns8 = c->h_cols.as<bgp_column8>(); else o->columns = c->h_cols.as<bgp_column>();
     return BGP_OK;
 }
 
@@ -235,6 +263,7 @@ int bgp_device_memory(uint64_t* current, uint64_t* peak, int reset_peak) {
     return BGP_OK;
 }
 int bgp_set_device_memory_cap(uint64_t bytes) { bgp_devmem().cap.store(bytes); return BGP_OK; }
+int bgp_set_compact_columns(bgp_ctx* c, int on) { if (!c) return BGP_EINVAL; prefetch_cancel(c); c->compact_cols = on != 0; return BGP_OK; }
 
 int bgp_init(int device, bgp_ctx** out) {
     BGP_API_TRY
@@ -278,9 +307,9 @@ static void release_all(bgp_ctx* c) {
                    &c->d_seq, &c->d_qual, &c->d_cigar, &c->d_pmax_end, &c->d_pmax_pos, &c->d_runs, &c->d_columns, &c->d_depth_hist, &c->d_pstats,
                    &c->d_tiles, &c->d_ck_off, &c->d_ck, &c->d_deep, &c->d_wlong, &c->d_entry_off, &c->d_entries, &c->d_col_lo,
                    &c->d_md_row, &c->d_md_iv, &c->d_md_state, &c->d_refbase, &c->d_md_succ, &c->d_md_exit, &c->d_md_entry, &c->d_md_bmax, &c->d_md_long, &c->d_md_ck, &c->d_md_vlist, &c->d_snp, &c->d_maq, &c->d_maq_tab, &c->d_rec2, &c->d_seq_off2, &c->d_cigar_off2,
-                   &c->d_seg_hint, &c->d_seg_sub, &c->d_tilemax, &c->d_cig4, &c->d_prow, &c->d_rcls, &c->d_slab, &c->d_wcount, &c->d_wdel, &c->d_wslow, &c->d_flt[0], &c->d_flt[1], &c->d_flt[2], &c->d_flt[3], &c->d_flt[4], &c->d_flt[5], &c->d_comp, &c->d_inf_blk, &c->d_batch[0], &c->d_batch[1]};
+                   &c->d_seg_hint, &c->d_seg_sub, &c->d_tilemax, &c->d_cig4, &c->d_prow, &c->d_rcls, &c->d_slab, &c->d_wcount, &c->d_wdel, &c->d_wslow, &c->d_flt[0], &c->d_flt[1], &c->d_flt[2], &c->d_flt[3], &c->d_flt[4], &c->d_flt[5], &c->d_comp, &c->d_inf_blk, &c->d_cols8[0], &c->d_cols8[1], &c->d_batch[0], &c->d_batch[1]};
     for (auto* b : d) b->release();
-    HostBuf* h[] = {&c->h_stage, &c->h_rec, &c->h_seq_off, &c->h_cigar_off, &c->h_seq, &c->h_qual, &c->h_cigar, &c->h_cols, &c->h_entry_off, &c->h_entries, &c->h_refbase, &c->h_snp, &c->h_maq, &c->h_ring, &c->h_stream_copy, &c->h_mail, &c->h_cols2, &c->h_batch[0], &c->h_batch[1], &c->h_batch[2]};
+    HostBuf* h[] = {&c->h_stage, &c->h_rec, &c->h_seq_off, &c->h_cigar_off, &c->h_seq, &c->h_qual, &c->h_cigar, &c->h_cols, &c->h_cols_wide, &c->h_entry_off, &c->h_entries, &c->h_refbase, &c->h_snp, &c->h_maq, &c->h_ring, &c->h_stream_copy, &c->h_mail, &c->h_cols2, &c->h_batch[0], &c->h_batch[1], &c->h_batch[2]};
     for (auto* b : h) b->release();
 }
 

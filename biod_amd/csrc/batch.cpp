@@ -43,9 +43,10 @@ void batch_release(bgp_ctx* c) {
         if (b->host_free[q]) (void)hipEventDestroy(b->host_free[q]);
         std::swap(b->host[q], c->h_batch[q]); b->host[q].release();
     }
-    for (int q = 0; q < 2; ++q) {
+    for (int q = 0; q < Batch::NDV; ++q) {
         if (b->loaded_ev[q]) (void)hipEventDestroy(b->loaded_ev[q]);
-        std::swap(b->dev[q], c->d_batch[q]); b->dev[q].release();
+        if (q < 2) std::swap(b->dev[q], c->d_batch[q]);
+        b->dev[q].release();
     }
     delete b;
     c->batch = nullptr;
@@ -78,7 +79,7 @@ void bgp_staged_copy(uint8_t* dst, const uint8_t* src, uint64_t n) {
 static int ship(bgp_ctx* c, Batch* b) {
     if (!b->n_full) return BGP_OK;
     int q = -1;
-    for (int k = 0; k < 2; ++k) if (b->state[k] == Batch::FREE) { q = k; break; }
+    for (int k = 0; k < b->n_dev; ++k) if (b->state[k] == Batch::FREE) { q = k; break; }
     if (q < 0) return BGP_EAGAIN;
     const int h = b->fullq[0];
     BGP_TRY(b->dev[q].reserve(b->reserve + b->batch_bytes + 256));
@@ -141,7 +142,8 @@ static int ship_if_full(bgp_ctx* c, Batch* b) {
 // is the last batch), record table, pileup, the cut
 static int process_next(bgp_ctx* c, Batch* b) {
     const int q = b->queue[0];
-    b->queue[0] = b->queue[1]; --b->n_queue;
+    for (int k = 1; k < b->n_queue; ++k) b->queue[k - 1] = b->queue[k];
+    --b->n_queue;
     const bool final = b->ended && b->n_queue == 0 && b->n_full == 0 && (b->fill < 0 || b->host_len[b->fill] == 0);
     BGP_HIP(hipStreamWaitEvent(c->stream, b->loaded_ev[q], 0));
     if (b->feed && b->new_len[q]) BGP_TRY(feed_check(c, b, q));      // a batch k_inflate made: every block's size and CRC held (block.d:197-207)
@@ -157,7 +159,7 @@ static int process_next(bgp_ctx* c, Batch* b) {
     uint8_t* base = b->dev[q].as<uint8_t>() + b->new_off[q] - b->carry_len;
     if (b->carry_len) { TimedRegion tc(c, "d2d_carry", b->carry_len);
         BGP_HIP(hipMemcpyAsync(base, c->d_stream + b->carry_off, b->carry_len, hipMemcpyDeviceToDevice, c->stream)); }
-    if (b->cur >= 0) { BGP_HIP(hipStreamSynchronize(c->stream)); b->state[b->cur] = Batch::FREE; BGP_TRY(ship_if_full(c, b)); if (b->feed) BGP_TRY(feed_pump(c, b, false)); }     // the carry is out: the old batch's buffer can take the next load -- at once, if a full pinned buffer is waiting
+    if (b->cur >= 0) { BGP_HIP(hipStreamSynchronize(c->stream)); b->state[b->cur] = Batch::FREE; BGP_TRY(ship_if_full(c, b)); }     // the carry is out: the old batch's buffer can take the next load -- at once, if a full pinned buffer is waiting
     b->cur = q; b->state[q] = Batch::CURRENT; b->cur_final = final; b->any_batch = true;
     c->d_stream = base; c->stream_len = b->carry_len + b->new_len[q]; c->stream_on_device = true;
     c->frame_tolerant_tail = !final;
@@ -220,6 +222,9 @@ static int process_next(bgp_ctx* c, Batch* b) {
         }
     }
     b->run = 0; b->run_open = false;
+    // a file feeds the pass: the next inflate leaves NOW, when this batch's kernels are through -- it then runs beside the copies of this
+    // batch's windows and nothing else (launched beside the kernels it starved them of wave slots and LDS: batch.h)
+    if (b->feed) BGP_TRY(feed_pump(c, b, false));
     return BGP_OK;
 }
 
@@ -251,7 +256,9 @@ int batch_begin_core(bgp_ctx* c, uint64_t batch_bytes, int want_entries, uint32_
         std::swap(b->host[q], c->h_batch[q]);                                            // what the last batched pass left (empty the first time)
         if (host_buffers) BGP_TRY(b->host[q].reserve(b->batch_bytes));
     }
-    for (int q = 0; q < 2; ++q) { BGP_HIP(hipEventCreateWithFlags(&b->loaded_ev[q], hipEventDisableTiming)); std::swap(b->dev[q], c->d_batch[q]); }
+    b->n_dev = 2;
+    if (!host_buffers) if (const char* e = getenv("BGP_STREAM_BUFFERS")) b->n_dev = std::min<int>(Batch::NDV, std::max(2, atoi(e)));
+    for (int q = 0; q < b->n_dev; ++q) { BGP_HIP(hipEventCreateWithFlags(&b->loaded_ev[q], hipEventDisableTiming)); if (q < 2) std::swap(b->dev[q], c->d_batch[q]); }
     return BGP_OK;
 }
 
@@ -339,7 +346,7 @@ int bgp_batch_next_window(bgp_ctx* c, bgp_columns* o) {
     Batch* b = c->batch;
     if (!b) return BGP_ESTATE;
     BGP_HIP(hipSetDevice(c->device));
-    if (b->feed) BGP_TRY(feed_pump(c, b, false));                        // (a file feeds the pass: whatever has been read by now and fits a free device buffer is on its way)
+    if (b->feed && b->cur < 0) BGP_TRY(feed_pump(c, b, false));          // (a file feeds the pass: its first batches leave as soon as the file has been read that far; later ones when a batch's kernels are through, process_next)
     for (;;) {
         if (b->cur >= 0) {                                               // hand out the current batch's final columns, run after run
             while (b->run < c->runs.size()) {

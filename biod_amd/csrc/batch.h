@@ -13,9 +13,14 @@ struct Batch {
     int fill = 0;                                       // host buffer taking the pushes (-1: none to be had before a full one has left)
     int fullq[NH] = {0, 0, 0}; int n_full = 0;          // full buffers waiting for a device buffer, oldest first
     int acq = -1; uint64_t acq_off = 0;                 // bgp_batch_acquire handed out host[acq] from acq_off on and waits for its commit (-1: nothing outstanding)
-    DevBuf dev[2]; uint64_t new_off[2] = {0, 0}, new_len[2] = {0, 0}; hipEvent_t loaded_ev[2] = {nullptr, nullptr};
-    enum { FREE, LOADED, CURRENT } state[2] = {FREE, FREE};
-    int queue[2] = {0, 0}; int n_queue = 0;             // loaded device buffers, oldest first
+    // Device buffers: two (one in its kernels, one loading).  A file-fed pass (stream.cpp) can be given more (BGP_STREAM_BUFFERS, up to
+    // NDV) -- measured and not the default: k_inflate's waves live ten milliseconds and take every wave slot and all of a CU's LDS they can
+    // get, so a batch's kernels launched beside two or three inflating batches wait for slots (12 ms a 256 MiB batch instead of 1.5).
+    // What works is ONE large inflate at a time, launched when the batch's kernels are through, beside nothing but the windows' copies.
+    static constexpr int NDV = 4; int n_dev = 2;
+    DevBuf dev[NDV]; uint64_t new_off[NDV] = {0, 0, 0, 0}, new_len[NDV] = {0, 0, 0, 0}; hipEvent_t loaded_ev[NDV] = {nullptr, nullptr, nullptr, nullptr};
+    enum { FREE, LOADED, CURRENT } state[NDV] = {FREE, FREE, FREE, FREE};
+    int queue[NDV] = {0, 0, 0, 0}; int n_queue = 0;     // loaded device buffers, oldest first
     hipStream_t copy_stream = nullptr;
     bool ended = false, any_batch = false;
     int cur = -1; bool cur_final = false;

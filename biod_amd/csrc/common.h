@@ -195,8 +195,9 @@ struct bgp_ctx {
     HostBuf h_cols, h_entry_off, h_entries, h_refbase, h_snp, h_maq;
     // the window a consumer is likely to ask for next -- the columns behind the one just handed out -- is copied to the host while
     // the consumer works on the current one (api.cpp: emit_window); h_cols2 is the second buffer the two windows alternate between
-    struct Prefetch { bool valid = false; uint32_t run = 0; uint64_t a = 0, b = 0; hipStream_t stream = nullptr; hipEvent_t done = nullptr; } pf;
+    struct Prefetch { bool valid = false, compact = false; uint32_t run = 0; uint64_t a = 0, b = 0; hipStream_t stream = nullptr; hipEvent_t done = nullptr; } pf;
     HostBuf h_cols2;
+    bool compact_cols = false; DevBuf d_cols8[2]; HostBuf h_cols_wide;      // bgp_set_compact_columns: windows leave as 8 bytes a position (scan.hip: k_pack_columns8) through these staging buffers (the window at hand, the one copied ahead); a window with a count beyond 255 is copied again, wide
     DevBuf d_snp;
     DevBuf d_maq, d_maq_tab; bool maq_tables_ready = false; float maq_tab_depcorr = 0, maq_tab_eta = 0;   // MAQ model (maq.hip): calls of a window; fk | lhet | beta
     DevBuf d_entry_off, d_entries, d_col_lo;
@@ -244,6 +245,7 @@ int k5_entries(bgp_ctx* c, uint32_t run, uint64_t pos_begin, uint64_t pos_end, u
 int scan_exclusive_u64(bgp_ctx* c, const uint64_t* in, uint64_t* out, uint64_t n, uint64_t* total_host);   // scan.hip (out has n+1 entries)
 int scan_inclusive_max_u64(bgp_ctx* c, const uint64_t* in, uint64_t* out, uint64_t n);
 int scan_exclusive_u64x3(bgp_ctx* c, const uint64_t* const in[3], uint64_t* const out[3], uint64_t n, uint64_t* totals_host /* [3] or null */);   // three scans, three launches
+int pack_columns8(bgp_ctx* c, const bgp_column* in, uint64_t n, uint8_t* out, hipStream_t st);      // scan.hip: n columns as 8 x u8 each, then a u64 that is non-zero when some count was beyond 255
 struct FillItem { void* p; uint64_t bytes; uint32_t value; };     // value: the byte every byte becomes
 int fill_many(bgp_ctx* c, const FillItem* items, int n_items);   // scan.hip: up to 8 device buffers (16-byte aligned) filled by one launch
 struct MailItem { const void* src; void* dst; uint32_t n; };

@@ -16,6 +16,7 @@
 // the size of the file.  The columns (and entries, and reference bases with bgp_batch_set_md) are those of the one-shot load: tested.
 #include "batch.h"
 
+#include <cstdio>
 #include <fcntl.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -49,9 +50,11 @@ struct FileFeed {
     std::deque<BgzfBlk> todo;                              // blocks not yet in a batch, file order
     uint64_t seen_turn = 0, rel_next = 0;                  // chunks scanned as of the last look; chunks [0, rel_next) are released
     uint64_t u_next = 0;                                   // inflated offset the next batch begins at (q for the first)
-    bool all_dispatched = false; int n_batch = 0;
-    DevBuf d_desc[2]; HostBuf h_desc[2], h_status[2]; uint32_t n_desc[2] = {0, 0};
-    uint64_t first_coff[2] = {0, 0};
+    bool all_dispatched = false; int n_batch = 0, prev_q = -1;
+    bool verbose = getenv("BGP_VERBOSE") != nullptr; std::chrono::steady_clock::time_point t_begin = std::chrono::steady_clock::now();
+    double ms_now() const { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); }
+    DevBuf d_desc[Batch::NDV]; HostBuf h_desc[Batch::NDV], h_status[Batch::NDV]; uint32_t n_desc[Batch::NDV] = {0, 0, 0, 0};
+    uint64_t first_coff[Batch::NDV] = {0, 0, 0, 0};
 
     ~FileFeed() {
         { std::lock_guard<std::mutex> lk(mu); stop = true; }
@@ -62,7 +65,7 @@ struct FileFeed {
         for (hipEvent_t e : ev_up) if (e) (void)hipEventDestroy(e);
         for (hipEvent_t e : ev_free) if (e) (void)hipEventDestroy(e);
         h_ring.release(); d_ring.release();
-        for (int k = 0; k < 2; ++k) { d_desc[k].release(); h_desc[k].release(); h_status[k].release(); }
+        for (int k = 0; k < Batch::NDV; ++k) { d_desc[k].release(); h_desc[k].release(); h_status[k].release(); }
         if (fd >= 0) close(fd);
     }
 };
@@ -125,7 +128,9 @@ void feed_release(bgp_ctx*, Batch* b) {
 // the inflate's verdict on the batch in dev[q] (its event has passed: the status words are in pinned memory)
 int feed_check(bgp_ctx* c, Batch* b, int q) {
     FileFeed* f = b->feed;
+    const double w0 = f->verbose ? f->ms_now() : 0;
     BGP_HIP(hipEventSynchronize(b->loaded_ev[q]));
+    if (f->verbose) fprintf(stderr, "[biodgpu]   %8.2f ms: buffer %d inflated (waited %.2f ms for it)\n", f->ms_now(), q, f->ms_now() - w0);
     const int32_t* st = f->h_status[q].as<int32_t>();
     const bgp_inflate_block* d = f->h_desc[q].as<bgp_inflate_block>();
     for (uint32_t i = 0; i < f->n_desc[q]; ++i)
@@ -138,7 +143,7 @@ int feed_pump(bgp_ctx* c, Batch* b, bool need_one) {
     for (;;) {
         if (f->all_dispatched) { b->ended = true; return BGP_OK; }
         int q = -1;
-        for (int k = 0; k < 2; ++k) if (b->state[k] == Batch::FREE) { q = k; break; }
+        for (int k = 0; k < b->n_dev; ++k) if (b->state[k] == Batch::FREE) { q = k; break; }
         if (q < 0) return BGP_OK;                          // (both device buffers taken: the consumer hands out windows first)
         const bool must = need_one && b->n_queue == 0;
         // what has been scanned since the last look; enough for a batch?
@@ -181,7 +186,9 @@ int feed_pump(bgp_ctx* c, Batch* b, bool need_one) {
             return BGP_OK;
         }
         // enqueue: descriptors, k_inflate behind the uploads of the chunks it reads, the status back, the batch's event
-        hipStream_t is = c->io_inf[f->n_batch & 1];
+        // (with the default two device buffers one inflate runs at a time, on the first inflate stream: the second is the window prefetch's
+        // -- api.cpp: emit_window -- and a window's copy queued behind k_inflate there waited for the whole inflate, 9 GB/s of columns)
+        hipStream_t is = c->io_inf[b->n_dev > 2 ? (f->n_batch & 1) : 0];
         const uint32_t nd = (uint32_t)desc.size();
         BGP_TRY(b->dev[q].reserve(b->reserve + b->batch_bytes + 256));
         BGP_TRY(f->d_desc[q].reserve((size_t)nd * (sizeof(bgp_inflate_block) + 4) + 64));
@@ -194,8 +201,14 @@ int feed_pump(bgp_ctx* c, Batch* b, bool need_one) {
         BGP_TRY(inflate_blocks_device(c, f->d_ring.as<uint8_t>(), b->dev[q].as<uint8_t>() + b->reserve - SLACK, f->d_desc[q].as<bgp_inflate_block>(), nd, d_status, bytes, is));
         BGP_HIP(hipMemcpyAsync(f->h_status[q].p, d_status, (size_t)nd * 4, hipMemcpyDeviceToHost, is));
         BGP_HIP(hipEventRecord(b->loaded_ev[q], is));
+        // (a chunk's blocks can lie in several batches, the batches on the two inflate streams in turn: what follows on this stream -- the
+        // events that hand slots back to the readers -- also waits for the batch before this one, on the other stream)
+        if (f->prev_q >= 0) BGP_HIP(hipStreamWaitEvent(is, b->loaded_ev[f->prev_q], 0));
+        f->prev_q = q;
         b->new_off[q] = b->reserve; b->new_len[q] = bytes;
         b->state[q] = Batch::LOADED; b->queue[b->n_queue++] = q;
+        if (f->verbose) fprintf(stderr, "[biodgpu]   %8.2f ms: batch %d -> buffer %d on inflate stream %d: %u blocks, %.1f MB, chunks %llu..%llu (scanned %llu of %llu), %d queued\n", f->ms_now(), f->n_batch, q, is == c->io_inf[0] ? 0 : 1, nd, bytes / 1e6,
+                                (unsigned long long)c_first, (unsigned long long)c_last, (unsigned long long)f->seen_turn, (unsigned long long)f->n_chunks, b->n_queue);
         f->u_next = u0 + bytes; ++f->n_batch;
         for (size_t i = 0; i < n_take; ++i) f->todo.pop_front();
         {   // slots whose chunks have no block left to inflate go back to the readers
@@ -231,16 +244,16 @@ int bgp_stream_bam_begin(bgp_ctx* c, const char* path, uint64_t batch_bytes, int
     { const int rc = bgzf_read_bam_header(fd, f->fsz, refs, &q, err); if (rc < 0) { c->last_error = err; return rc; } }
     // (a batch holds whole BGZF blocks: at least two of them.  bgp_reset inside: the references are set behind it.  No pinned buffers
     // for pushed bytes: nobody pushes)
-    BGP_TRY(batch_begin_core(c, std::max<uint64_t>(batch_bytes ? batch_bytes : (256ull << 20), 128ull << 10), want_entries, window_positions, false));
+    BGP_TRY(batch_begin_core(c, std::max<uint64_t>(batch_bytes ? batch_bytes : (1ull << 30), 128ull << 10), want_entries, window_positions, false));
     Batch* b = c->batch;
     c->refs = refs; c->n_ref_hint = (int32_t)refs.size();
     f->q = q; f->device = c->device; f->io_up = c->io_up;
     f->n_chunks = (f->fsz + FileFeed::CH - 1) / FileFeed::CH;
     const uint64_t t_max = getenv("BGP_READ_THREADS") ? (uint64_t)atoi(getenv("BGP_READ_THREADS")) : 8ull;
     f->T = (int)std::max<uint64_t>(1, std::min<uint64_t>({t_max, (uint64_t)bgp_default_threads(), f->n_chunks}));
-    // the ring holds a batch's blocks whatever they compress to (a BGZF block is never much larger than what it inflates to: 26 bytes of
+    // the ring holds the blocks of the batches that can be inflating at a time (every device buffer but the current batch's) whatever they compress to (a BGZF block is never much larger than what it inflates to: 26 bytes of
     // header and footer, 5 of a stored deflate block), a chunk cut at either end of it, and one chunk a reader ahead
-    f->ND = std::min<uint64_t>(f->n_chunks, (b->batch_bytes + b->batch_bytes / 512 + FileFeed::CH - 1) / FileFeed::CH + 3 + (uint64_t)f->T);
+    f->ND = std::min<uint64_t>(f->n_chunks, ((uint64_t)(b->n_dev - 1) * (b->batch_bytes + b->batch_bytes / 512) + FileFeed::CH - 1) / FileFeed::CH + 3 + (uint64_t)f->T);
     f->ND = std::max<uint64_t>(f->ND, 1);
     int rc = f->d_ring.reserve((size_t)(f->ND * FileFeed::STRIDE + 256));
     if (rc == BGP_OK) rc = f->h_ring.reserve((size_t)f->T * FileFeed::STRIDE);

@@ -101,6 +101,10 @@ class Context:
         L.check(L.lib().bgp_decode_fetch(self._h, L.BGP_FETCH_STREAM, C.byref(r)), self._h)
         return L.as_array(r.stream, r.stream_len, "u1")
 
+    def set_compact_columns(self, on: bool = True):
+        """Windows cross the link as 8 bytes a position wherever every count fits a byte (bgp_set_compact_columns); this facade widens them."""
+        L.check(L.lib().bgp_set_compact_columns(self._h, int(on)), self._h)
+
     def references(self):
         n = C.c_int32()
         L.check(L.lib().bgp_n_ref(self._h, C.byref(n)), self._h)
@@ -251,7 +255,7 @@ class Context:
             rc = L.check(L.lib().bgp_batch_next_window(self._h, C.byref(cw)), self._h)
             if rc != L.BGP_OK:
                 return
-            cols = L.as_array(cw.columns, cw.n_positions, L.COLUMN_DTYPE)
+            cols = L.window_columns(cw)
             eoff = L.as_array(cw.entry_off, cw.n_positions + 1, "<u8") if cw.entry_off else None
             ents = L.as_array(cw.entries, int(eoff[-1]), L.ENTRY_DTYPE) if eoff is not None else None
             w = Window(cw.ref_id, cw.first_position, cols, eoff, ents, L.as_array(cw.reference_base, cw.n_positions, "u1") if cw.reference_base else None)
@@ -307,7 +311,7 @@ class Context:
             rc = L.check(L.lib().bgp_pileup_next_window(self._h, C.byref(cw)), self._h)
             if rc == L.BGP_EOF:
                 return
-            cols = L.as_array(cw.columns, cw.n_positions, L.COLUMN_DTYPE, copy)
+            cols = L.window_columns(cw, copy)
             eoff = L.as_array(cw.entry_off, cw.n_positions + 1, "<u8", copy) if cw.entry_off else None
             ents = L.as_array(cw.entries, int(eoff[-1]), L.ENTRY_DTYPE, copy) if eoff is not None else None
             refb = L.as_array(cw.reference_base, cw.n_positions, "u1", copy) if cw.reference_base else None

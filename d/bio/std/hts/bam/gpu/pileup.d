@@ -43,7 +43,7 @@ import std.string : fromStringz, toStringz;
 // include/biodgpu.h, declaration for declaration
 // ---------------------------------------------------------------------------------------------------------------------
 extern (C) nothrow @nogc {
-    enum BGP_ABI_VERSION = 3;
+    enum BGP_ABI_VERSION = 4;
 
     enum BGP_OK = 0;
     enum BGP_EINVAL = -1;
@@ -174,7 +174,19 @@ extern (C) nothrow @nogc {
         const(ubyte)* reference_base;
         const(ubyte)* snp;
         const(bgp_maq_call)* maq;
+        const(bgp_column8)* columns8;
     }
+    struct bgp_column8 {
+        ubyte coverage;
+        ubyte n_starting_here;
+        ubyte a;
+        ubyte c;
+        ubyte g;
+        ubyte t;
+        ubyte other;
+        ubyte del;
+    }
+    int bgp_set_compact_columns(bgp_ctx* ctx, int on);
     int bgp_pileup_begin(bgp_ctx* ctx, int mode, int use_md_tag, ulong start_from, ulong end_at,
                          int skip_zero_coverage, int want_entries, uint window_positions);
     int bgp_pileup_begin_ref(bgp_ctx* ctx, int ref_id, int use_md_tag, ulong start_from, ulong end_at,
@@ -487,6 +499,7 @@ struct GpuPileupColumn {
 final class GpuPileup {
     private GpuSource src;
     private bgp_columns win;
+    private bgp_column[] wide;                      // a window that came as columns8, widened
     private GpuRecordWindow recs;
     private uint k;
     private bool done, skipZero, useMd;
@@ -578,6 +591,17 @@ final class GpuPileup {
     private void fetch() {
         done = chk(bgp_pileup_next_window(src.ctx, &win), src.ctx) == BGP_EOF;
         k = 0;
+        if (!done && win.columns is null && win.columns8 !is null) {
+            // compact transport (bgp_set_compact_columns): a byte a count over the link, widened here; the consumer sees pileup.d:236-290's numbers
+            wide.length = win.n_positions;
+            foreach (i; 0 .. win.n_positions) {
+                auto s = win.columns8[i];
+                bgp_column w;
+                w.coverage = s.coverage; w.n_starting_here = s.n_starting_here; w.a = s.a; w.c = s.c; w.g = s.g; w.t = s.t; w.other = s.other; w.del = s.del;
+                wide[i] = w;
+            }
+            win.columns = wide.ptr;
+        }
         if (done || win.entry_off is null) return;
         size_t ne = cast(size_t) win.entry_off[win.n_positions];
         if (ne == 0) {

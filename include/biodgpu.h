@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define BGP_ABI_VERSION 3
+#define BGP_ABI_VERSION 4
 
 /* ---- status codes -------------------------------------------------------------------------- */
 enum {
@@ -231,7 +231,15 @@ typedef struct bgp_columns {
     const uint8_t* reference_base; /* host, n_positions (use_md_tag) or NULL                      */
     const uint8_t* snp;          /* host, n_positions of BGP_SNP_* after bgp_pileup_snp, else NULL */
     const struct bgp_maq_call* maq; /* host, n_positions after bgp_pileup_maq, else NULL             */
+    const struct bgp_column8* columns8; /* host, n_positions, INSTEAD of columns (then NULL) under bgp_set_compact_columns */
 } bgp_columns;
+/* Compact transport of the windows: the fields of bgp_column, one byte each.  With bgp_set_compact_columns(ctx, 1) every window whose
+ * counts all fit a byte (coverage <= 255 at every position) is handed out as columns8 -- 8 bytes a position over the link instead of
+ * 32 -- and bgp_columns.columns is NULL; a window with a deeper position comes in the 32-byte layout as always (columns8 NULL).  The
+ * consumer sees the same numbers (PileupColumn's accessors, pileup.d:236-290); the dense array on the device (bgp_pileup_info
+ * .device_columns) is untouched.  The setting holds for the ctx until it is changed (bgp_reset keeps it); default 0. */
+typedef struct bgp_column8 { uint8_t coverage, n_starting_here, a, c, g, t, other, del; } bgp_column8;
+int bgp_set_compact_columns(bgp_ctx* ctx, int on);
 int bgp_pileup_begin(bgp_ctx* ctx, int mode, int use_md_tag, uint64_t start_from, uint64_t end_at,
                      int skip_zero_coverage, int want_entries, uint32_t window_positions);
 /* makePileup(bam[ref_id].reads, use_md_tag, start_from, end_at, skip_zero_coverage): bgp_pileup_begin(BGP_MAKE_PILEUP)

@@ -294,7 +294,14 @@ private:
         done_ = false;
         fetch(); settle();
     }
-    void fetch() { const int rc = check(bgp_pileup_next_window(ctx_, &w_), ctx_); done_ = rc == BGP_EOF; k_ = 0; }
+    void fetch() {
+        const int rc = check(bgp_pileup_next_window(ctx_, &w_), ctx_); done_ = rc == BGP_EOF; k_ = 0;
+        if (!done_ && !w_.columns && w_.columns8) {     // compact transport (bgp_set_compact_columns): a byte a count over the link, widened here -- the consumer sees pileup.d:236-290's numbers
+            wide_.resize(w_.n_positions);
+            for (uint32_t k = 0; k < w_.n_positions; ++k) { const bgp_column8& s = w_.columns8[k]; wide_[k] = bgp_column{s.coverage, s.n_starting_here, s.a, s.c, s.g, s.t, s.other, s.del}; }
+            w_.columns = wide_.data();
+        }
+    }
     void settle() {            // skip zero-coverage positions the way PileupRange.popFront jumps over them, pileup.d:388-392
         while (!done_) {
             if (k_ >= w_.n_positions) { fetch(); continue; }
@@ -305,7 +312,7 @@ private:
     bgp_ctx* ctx_; bool skip_zero_, want_entries_; uint64_t start_, end_;
     int mode_; bool use_md_; uint32_t window_; bool snp_ = false; int snp_cov_ = 5, snp_wit_ = 2;
     bool maq_ = false; float maq_depcorr_ = 0.17f, maq_eta_ = 0.03f; unsigned maq_min_bq_ = 13;
-    bgp_columns w_{}; bgp_records recs_{}; uint32_t k_ = 0; bool done_ = false; int32_t ref_id_ = -1;
+    bgp_columns w_{}; std::vector<bgp_column> wide_; bgp_records recs_{}; uint32_t k_ = 0; bool done_ = false; int32_t ref_id_ = -1;
     int64_t chunk_ = -1; bgp_chunk_info ci_{};
 };
 

@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in include/biodgpu.h but not exported by libbiodgpu.so"
     assert declared == set(L.SYMBOLS), declared ^ set(L.SYMBOLS)
-    assert lib.bgp_abi_version() == 3          # 2: bgp_columns grew `maq`; 3: bgp_decode_fetch_range, bgp_pileup_begin_ref
+    assert lib.bgp_abi_version() == 4          # 2: bgp_columns grew `maq`; 3: bgp_decode_fetch_range, bgp_pileup_begin_ref; 4: bgp_columns grew `columns8` (compact transport), bgp_stream_bam_begin
 
 
 def test_header_cites_reference_for_every_entry_point():
@@ -41,7 +41,7 @@ def test_header_cites_reference_for_every_entry_point():
 
 
 def test_struct_layouts_match_header():
-    assert C.sizeof(L.Records) == 72 and C.sizeof(L.Columns) == 64 and C.sizeof(L.SynthCfg) == 40
+    assert C.sizeof(L.Records) == 72 and C.sizeof(L.Columns) == 72 and C.sizeof(L.SynthCfg) == 40
     assert L.RECORD_DTYPE.itemsize == 32 and L.COLUMN_DTYPE.itemsize == 32 and L.ENTRY_DTYPE.itemsize == 16 and L.MAQ_CALL_DTYPE.itemsize == 8
 
 

@@ -198,3 +198,93 @@ def test_stream_file_larger_than_the_memory_cap(tmp_path):
     assert npos == info.n_positions and len(pos) == info.n_columns == len(nz)
     for f in L.COLUMN_DTYPE.names:
         assert np.array_equal(cols[f], dense[f][nz]), f
+
+
+# ---- compact transport of the windows (bgp_set_compact_columns): a byte a count over the link, the same numbers for the consumer ----
+
+def _raw_windows(ctx, begin):
+    """(columns as COLUMN_DTYPE, came compact?) of every window of an iteration begun by `begin`"""
+    begin()
+    out = []
+    while True:
+        cw = L.Columns()
+        rc = L.check(L.lib().bgp_pileup_next_window(ctx._h, C.byref(cw)), ctx._h)
+        if rc == L.BGP_EOF:
+            return out
+        out.append((cw.ref_id, cw.first_position, L.window_columns(cw), bool(cw.columns8) and not cw.columns))
+
+
+@pytest.mark.parametrize("name", ["ex1_header.bam", "b7_295_chunk.bam", "mg1655_chunk.bam"])
+@pytest.mark.parametrize("window", [700, 0])
+def test_compact_columns_same_numbers(ctx, data_dir, name, window):
+    """Every window of pileupColumns and of makePileup with skip_zero_coverage = false (uncovered stretches are windows of zeros) in both
+    transports: the same positions and counts; the compact one really is columns8 wherever no position is deeper than 255 (windows are
+    copied ahead on a second stream: both buffers take part)."""
+    _, st = bamio.read_bam(os.path.join(data_dir, name))
+    ctx.reset(); ctx.push_inflated(st); ctx.flush()
+    for begin in (lambda: L.check(L.lib().bgp_pileup_begin(ctx._h, L.BGP_PILEUP_COLUMNS, 0, 0, 2**64 - 1, 1, 0, window), ctx._h),
+                  lambda: L.check(L.lib().bgp_pileup_begin(ctx._h, L.BGP_MAKE_PILEUP, 0, 0, 2**64 - 1, 0, 0, window), ctx._h)):
+        ctx.set_compact_columns(False)
+        wide = _raw_windows(ctx, begin)
+        ctx.set_compact_columns(True)
+        comp = _raw_windows(ctx, begin)
+        ctx.set_compact_columns(False)
+        assert len(wide) == len(comp) > 0 and not any(w[3] for w in wide)
+        for a, b in zip(wide, comp):
+            assert a[:2] == b[:2] and np.array_equal(a[2], b[2])
+            assert b[3] == (int(a[2]["coverage"].max(initial=0)) <= 255)
+
+
+def test_compact_columns_deep_window_comes_wide(ctx):
+    """A pile of 300 reads on one position among ordinary windows: the window that holds it crosses the link in the 32-byte layout, its
+    neighbours compact; entries and reference bases ride along unchanged; the batched and the file-fed pass take the setting too."""
+    recs = [bamio.pack_record(f"a{k}", "ACGTACGTAC", [(10, "M")], ref_id=0, pos=100 + k) for k in range(50)]
+    recs += [bamio.pack_record(f"d{k}", "ACGTACGTAC", [(10, "M")], ref_id=0, pos=5000, tags=bamio.tag_z("MD", "10")) for k in range(300)]
+    recs += [bamio.pack_record(f"b{k}", "ACGTACGTAC", [(10, "M")], ref_id=0, pos=9000 + k) for k in range(50)]
+    st = b"".join(recs)
+    ora = O.pileup(st, want_entries=True)
+    ctx.reset(); ctx.push_inflated(st); ctx.flush()
+    ctx.set_compact_columns(True)
+    try:
+        ws = _raw_windows(ctx, lambda: L.check(L.lib().bgp_pileup_begin(ctx._h, L.BGP_PILEUP_COLUMNS, 0, 0, 2**64 - 1, 1, 1, 1000), ctx._h))
+        kinds = [w[3] for w in ws]
+        assert False in kinds and True in kinds            # the deep window wide, others compact
+        pos = np.concatenate([w[1] + np.nonzero(w[2]["coverage"])[0] for w in ws]); cols = np.concatenate([w[2][w[2]["coverage"] > 0] for w in ws])
+        _assert_columns_equal_oracle(np.zeros(len(pos), np.int64), pos.astype(np.int64), cols, ora)
+        # through the facade (widened), with entries: the same as the oracle's
+        ref, pos2, cols2, ents, _ = _covered(ctx.pileup_windows(L.BGP_PILEUP_COLUMNS, want_entries=True, window_positions=1000), want_entries=True)
+        _assert_columns_equal_oracle(ref, pos2, cols2, ora)
+        assert sum(len(e) for e in ents) == int(ora.entry_off[-1])
+        # batched staging under the same setting
+        ref, pos3, cols3, _, _ = _covered(ctx.batched_windows([st[o:o + 3001] for o in range(0, len(st), 3001)], 8192, window_positions=1000))
+        _assert_columns_equal_oracle(ref, pos3, cols3, ora)
+    finally:
+        ctx.set_compact_columns(False)
+        ctx.reset()
+
+
+def test_compact_columns_streamed_file(ctx, tmp_path):
+    """The file-fed pass with compact transport: 150 k reads of cfg3's model, windows of 64 k positions (dozens of them, copied ahead),
+    columns == the wide transport's."""
+    cfg = scaled("cfg3", 150_000)
+    st = host_stream(cfg)
+    path = str(tmp_path / "c.bam")
+    write_bam_fast(path, [(f"chr{i + 1}", 1 << 28) for i in range(max(1, cfg.n_ref))], st)
+    wide = _covered(ctx.stream_bam_windows(path, 8 << 20, window_positions=65536))
+    ctx.set_compact_columns(True)
+    try:
+        n8 = 0
+        L.check(L.lib().bgp_stream_bam_begin(ctx._h, path.encode(), 8 << 20, 0, 65536), ctx._h)
+        pos, cols = [], []
+        while True:
+            cw = L.Columns()
+            if L.check(L.lib().bgp_batch_next_window(ctx._h, C.byref(cw)), ctx._h) != L.BGP_OK:
+                break
+            n8 += bool(cw.columns8)
+            w = L.window_columns(cw); k = np.nonzero(w["coverage"])[0]
+            pos.append(cw.first_position + k.astype(np.int64)); cols.append(w[k])
+        assert n8 > 10
+        assert np.array_equal(np.concatenate(pos), wide[1]) and np.array_equal(np.concatenate(cols), wide[2])
+    finally:
+        ctx.set_compact_columns(False)
+        ctx.reset()
