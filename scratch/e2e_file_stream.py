@@ -65,7 +65,8 @@ ctx = Context(0)
 h = ctx.handle
 
 
-def streamed(batch, window, check):
+def streamed(batch, window, check, compact=False):
+    lib.bgp_set_compact_columns(h, int(compact))
     devmem(reset=True)
     t0 = time.perf_counter()
     L.check(lib.bgp_stream_bam_begin(h, path.encode(), batch, 0, window), h)
@@ -80,7 +81,7 @@ def streamed(batch, window, check):
             t_first = time.perf_counter() - t0
         nwin += 1; npos += cw.n_positions
         if check:
-            cov = L.as_array(cw.columns, cw.n_positions, L.COLUMN_DTYPE)["coverage"]
+            cov = (L.as_array(cw.columns8, cw.n_positions, L.COLUMN8_DTYPE) if cw.columns8 else L.as_array(cw.columns, cw.n_positions, L.COLUMN_DTYPE))["coverage"]
             ncol += int(np.count_nonzero(cov)); scov += int(cov.sum(dtype=np.uint64)); mx = max(mx, int(cov.max()) if len(cov) else 0)
     base = C.c_uint64(); L.check(lib.bgp_batch_ordinal_base(h, C.byref(base)), h)
     nrec = base.value + ctx.num_records()
@@ -89,14 +90,16 @@ def streamed(batch, window, check):
     return dt, t_first, nwin, nrec, npos, ncol, scov, mx, devmem()[1]
 
 
+dt, tf, nwin, nrec, npos, ncol, scov, mx, peak = streamed(0, 1 << 22, True, True)
+assert (nrec, npos, ncol, scov, mx) == one, ((nrec, npos, ncol, scov, mx), one)
 dt, tf, nwin, nrec, npos, ncol, scov, mx, peak = streamed(0, 1 << 22, True)
-print(f"streamed, CHECKED pass (numpy sums every window): {dt:.2f} s; records {nrec}, positions {npos}, columns {ncol}, sum of coverage {scov}, max {mx}; peak device memory {peak / 2**30:.2f} GiB (cap {cap_gb} GiB)", flush=True)
+print(f"streamed, CHECKED pass (numpy sums every window; in both transports): {dt:.2f} s; records {nrec}, positions {npos}, columns {ncol}, sum of coverage {scov}, max {mx}; peak device memory {peak / 2**30:.2f} GiB (cap {cap_gb} GiB)", flush=True)
 assert (nrec, npos, ncol, scov, mx) == one, ((nrec, npos, ncol, scov, mx), one)
 print("streamed == one-shot: records, positions, covered columns, summed coverage, maximum")
-for batch in (256 << 20, 1 << 30, 3 << 29):
+for batch, compact in ((1 << 30, False), (256 << 20, True), (1 << 30, True), (3 << 29, True)):
     for rep in range(2):
-        dt, tf, nwin, nrec, npos, *_, peak = streamed(batch, 1 << 22, False)
+        dt, tf, nwin, nrec, npos, *_, peak = streamed(batch, 1 << 22, False, compact)
         assert (nrec, npos) == one[:2]
-        print(f"streamed, batch {batch >> 20} MiB rep {rep}: {dt:.3f} s -> {n / dt / 1e6:.1f} Mreads/s file-E2E ({fsz / dt / 1e9:.1f} GB/s of file, {inflated / dt / 1e9:.1f} GB/s inflated), first window after {tf * 1e3:.0f} ms, {nwin} windows, peak device memory {peak / 2**30:.2f} GiB of a {cap_gb} GiB cap", flush=True)
+        print(f"streamed, batch {batch >> 20} MiB, {'compact' if compact else '32-byte'} columns, rep {rep}: {dt:.3f} s -> {n / dt / 1e6:.1f} Mreads/s file-E2E ({fsz / dt / 1e9:.1f} GB/s of file, {inflated / dt / 1e9:.1f} GB/s inflated), first window after {tf * 1e3:.0f} ms, {nwin} windows, peak device memory {peak / 2**30:.2f} GiB of a {cap_gb} GiB cap", flush=True)
 ctx.close()
 os.unlink(path)
