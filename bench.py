@@ -49,7 +49,7 @@ def kernels_sha():
 # kernels behind the timers of a step (a timer can bracket several launches; kernels of the set-up, e.g. the flush before the
 # timed region, are not the step's)
 TIMER_KERNELS = {"k12_lds": ("k12_lds",), "k012_stream": ("k_stream_decode",), "k2_unpack": ("k2_unpack",), "k12_fused": ("k12_fused",), "k1_rows": ("k12_fused",),
-                 "k4_bounds": ("k4_bounds",), "k4_plan": ("k4_plan(", "k4_wscan"), "k4_plan_rest": ("k4_plan_rest", "k4_wscan"), "k4_tile": ("k4_acc", "k4_tile", "k4_stats"),
+                 "k4_bounds": ("k4_bounds",), "k4_plan": ("k4_plan(", "k4_wscan"), "k4_plan_rest": ("k4_plan_rest", "k4_wscan"), "k4_acc2": ("k4_acc",), "k4_tile": ("k4_tile",), "k4_stats": ("k4_stats",),
                  "k4_checkpoints": ("k4_ck_",),
                  "k0_guess": ("k0_guess",), "k0_chase": ("k0_chase", "k0_verify"), "k0_rechase": ("k0_rechase",), "k3_keys_scan": ("k3_",)}
 
@@ -61,7 +61,7 @@ def pmc_traffic(timers, config, n_reads, launches=None):
     gfx950 as MI355X_MICROARCH.md prescribes).  Counters cannot be read from inside this process, so the number is only
     reported when the workload is the one the profile was taken on (configuration and read count in the profile's header) AND
     that header carries the hash of the kernel sources as they are now (scratch/refresh_profiles.sh writes it); otherwise null."""
-    path = os.path.join(ROOT, "profiles", f"r05_pmc_hbm_traffic_{config}.csv")
+    path = os.path.join(ROOT, "profiles", f"r06_pmc_hbm_traffic_{config}.csv")
     if not os.path.exists(path):
         return None
     lines = open(path).read().splitlines()
@@ -443,8 +443,8 @@ def main():
                 stages[name] = {"ms_per_step": sum(kt[k]["total_ms"] for k in ks) / a.steps, "kernels": ks, "prefixes": pre}
         for name, st in stages.items():
             st["bytes"] = sum(kt[k]["algorithmic_bytes"] for k in st["kernels"]) // a.steps
-        if "k4_tile" in kt:      # K4's algorithmic bytes (row + CIGAR + packed SEQ per read, 32 B per position) are booked on k4_tile; the plan's own reads are not algorithmic
-            stages["K4 pileup columns"]["bytes"] = kt["k4_tile"]["algorithmic_bytes"] // a.steps
+        if "k4_acc2" in kt or "k4_tile" in kt:      # K4's algorithmic bytes (row + CIGAR + packed SEQ per read, 32 B per position) are booked on the accumulate launch (k4_acc2; on the general kernel, k4_tile, where that takes every window); the plan's own reads are not algorithmic
+            stages["K4 pileup columns"]["bytes"] = sum(kt[k]["algorithmic_bytes"] for k in ("k4_acc2", "k4_tile") if k in kt) // a.steps
         dec_bytes = stream_bytes + 32 * n_reads + 2 * sum_lseq + 4 * sum_ncig      # whole record in, row + seq + qual + cigar out
         dom = max(stages, key=lambda s: stages[s]["ms_per_step"])
         dom_bytes = stages[dom]["bytes"]
@@ -513,6 +513,24 @@ def main():
                                   "k0_ms": round(k0, 3), "decode_kernels_ms": {k: round(v, 3) for k, v in dk.items()},
                                   "decode_kernel_frac": round(dec_b / (kms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if kms else None,
                                   "decode_8d_frac": round(dec_b / ((k0 + kms) * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if kms else None}
+            # ... and the pileup a caller asks for who wants no decoded SEQ / QUAL / CIGAR (makePileup over bam.reads: bgp_flush + bgp_pileup_run):
+            # K0 + the record table alone + K3 + K4 planning every read from the stream -- no arenas are written.  Beside the headline, never `value`.
+            walls = []
+            for rep in range(5):
+                if rep == 2:
+                    torch.cuda.synchronize(dev); ctx.timing_enable(True); ctx.timing_reset()
+                t0p = time.perf_counter()
+                ctx.reset(); ctx.attach_device_stream(sptr, slen)
+                ctx.flush()
+                pinfo = ctx.pileup_run()
+                torch.cuda.synchronize(dev)
+                walls.append((time.perf_counter() - t0p) * 1e3)
+            tm = ctx.timing_get(); ctx.timing_enable(False)
+            pst = {name: round(sum(v["total_ms"] for k, v in tm.items() if k.startswith(pre) and v["launches"]) / 3, 3) for name, pre in STAGES.items()}
+            pst = {k: v for k, v in pst.items() if v}
+            out["pileup_only"] = {"what": "bgp_flush + bgp_pileup_run: framing, the record table alone (k1_rows), K3, K4 with every read planned from the stream -- no SEQ / QUAL / CIGAR arenas (3 passes; stages by HIP events, wall by the caller's clock)",
+                                  "stages_ms": pst, "kernels_ms": round(sum(pst.values()), 3), "wall_ms": round(sorted(walls[2:])[1], 3), "Mreads_per_s": round(n_reads / (sorted(walls[2:])[1] * 1e-3) / 1e6, 1),
+                                  "same_columns_as_the_step": bool(pinfo.n_columns == info.n_columns and pinfo.sum_coverage == info.sum_coverage)}
             ctx.reset(); ctx.attach_device_stream(sptr, slen)       # (the legs below stage their own input)
         if world == 1 and not a.no_e2e and a.config != "cfg5":
             # the same path fed from host memory and from a file -- PCIe- and inflate-inclusive, labelled, never `value`.
@@ -523,13 +541,14 @@ def main():
             cfg_e = scaled(a.config, n_e2e)
             st_e = host_stream_np(cfg_e)
             out["e2e"] = {"note": "input NOT resident in HBM: PCIe-inclusive (device_e2e) and inflate-inclusive (file_e2e) rates of the same hot path on %d reads of %s's model; the headline `value` is kernel-only" % (n_e2e, a.config),
-                          "device_e2e": bench_e2e.device_e2e(ctx, st_e, n_e2e), "file_e2e": bench_e2e.file_e2e(ctx, st_e, n_e2e, int(cfg_e.n_ref))}
+                          "device_e2e": bench_e2e.device_e2e(ctx, st_e, n_e2e), "device_e2e_compact_columns": bench_e2e.device_e2e(ctx, st_e, n_e2e, compact=True),
+                          "file_e2e": bench_e2e.file_e2e(ctx, st_e, n_e2e, int(cfg_e.n_ref)), "file_e2e_streamed": bench_e2e.file_e2e_streamed(ctx, st_e, n_e2e, int(cfg_e.n_ref))}
             del st_e
         if not a.no_cpu_baseline and world == 1:                        # (at N = 1 only: with more ranks the host's cores are the ranks')
             out["cpu_baseline"] = cpu_baseline(a.config, a.cpu_sample_reads)
             out["speedup_vs_cpu_baseline"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
         print(json.dumps(out), file=result_out, flush=True)
-        if (checks is not None and not checks["ok"]) or hist_ok is False or ("parity_interior" in out and not out["parity_interior"]["all_equal"]) or ("md_path" in out and not (out["md_path"]["prefix_vs_oracle"]["equal"] and out["md_path"].get("whole_stream_vs_generator_reference", {"equal": True})["equal"])):
+        if ("e2e" in out and not out["e2e"]["file_e2e_streamed"]["equals_one_shot"]["equal"]) or (checks is not None and not checks["ok"]) or hist_ok is False or ("parity_interior" in out and not out["parity_interior"]["all_equal"]) or ("md_path" in out and not (out["md_path"]["prefix_vs_oracle"]["equal"] and out["md_path"].get("whole_stream_vs_generator_reference", {"equal": True})["equal"])):
             sys.stderr.write("bench.py: a result check FAILED (see checks_full_size / hist_reduce_equals_sum_of_ranks / parity_interior)\n")
             ctx.close()
             sys.exit(3)

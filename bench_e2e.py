@@ -20,8 +20,10 @@ from biod_amd import _lib as L
 from biod_amd import bamio
 
 
-def device_e2e(ctx, st, n_reads, batch_bytes=256 << 20, producers=16, reps=3):
+def device_e2e(ctx, st, n_reads, batch_bytes=256 << 20, producers=16, reps=3, compact=False):
+    """compact: the windows cross the link as 8 bytes a position (bgp_set_compact_columns) -- the columns going back were the critical path."""
     lib, h = L.lib(), ctx.handle
+    L.check(lib.bgp_set_compact_columns(h, int(compact)), h)
     pool = ThreadPoolExecutor(producers)
 
     def take_one(stats):
@@ -79,13 +81,14 @@ def device_e2e(ctx, st, n_reads, batch_bytes=256 << 20, producers=16, reps=3):
     ctx.timing_enable(False)
     ctx.reset()
     pool.shutdown(wait=True)
+    L.check(lib.bgp_set_compact_columns(h, 0), h)
     nb = max(1, tm.get("h2d_batch", {}).get("launches", 1))
     per = lambda pre: round(sum(v["total_ms"] for k, v in tm.items() if k.startswith(pre)) / nb, 3)      # noqa: E731
     best = min(times)
     return {"what": "inflated records in host memory -> bgp_batch_acquire/commit -> HBM -> K0..K4 per batch -> windows of columns handed out (a window and a buffer in turn; the consumer takes the windows, reads nothing)",
             "reads": int(n_reads), "inflated_bytes": int(len(st)), "batch_bytes": int(batch_bytes), "producer_threads": producers,
             "Mreads_per_s": round(n_reads / best / 1e6, 1), "input_GBps": round(len(st) / best / 1e9, 1), "best_s": round(best, 4), "runs_s": [round(t, 4) for t in times],
-            "columns_back_bytes": int(positions) * 32,
+            "columns_back_bytes": int(positions) * (8 if compact else 32), "columns_layout": "8 x u8 a position (bgp_set_compact_columns; every window of this stream fits)" if compact else "bgp_column, 32 bytes a position",
             "per_batch_ms_hip_events": {"batches": nb, "h2d_batch": per("h2d_batch"), "d2d_carry": per("d2d_carry"), "K0 framing": per("k0_"), "K1 record table": per("k1_"), "K3 keys": per("k3_"),
                                         "K4 columns": per("k4_"), "d2h windows": per("d2h"), "wall": round(dt_t / nb * 1e3, 3)}}
 
@@ -127,3 +130,66 @@ def file_e2e(ctx, st, n_reads, n_ref, path="/tmp/bench_e2e.bam", reps=8):
             "Mreads_per_s": round(n_reads / best[0] / 1e6, 1), "file_GBps": round(fsz / best[0] / 1e9, 2), "inflated_GBps": round(len(st) / best[0] / 1e9, 1),
             "best_s": {"total": round(best[0], 4), "load (read + upload + inflate)": round(best[1], 4), "flush (framing + table)": round(best[2], 4), "pileup": round(best[3], 4)},
             "first_load_s": round(rows[0][0], 4), "runs_s": [round(r[0], 4) for r in rows], "file_written_s": round(t_write, 1)}
+
+
+def file_e2e_streamed(ctx, st, n_reads, n_ref, path="/tmp/bench_e2e_s.bam", batch_bytes=512 << 20, cap_bytes=8 << 30, reps=4):
+    """The same file through BOUNDED device memory: bgp_stream_bam_begin (reader threads -> compressed ring in HBM -> k_inflate -> a batch's
+    kernels) + bgp_batch_next_window until BGP_EOF, every window of columns handed to the host (compact transport), under a cap on the
+    library's device memory of `cap_bytes` beyond what the process holds when the leg begins (the bench's own resident result).  One
+    checked pass sums the windows' coverage on the host and holds it against the one-shot pass over the same file."""
+    import ctypes as C
+    import numpy as np
+    lib, h = L.lib(), ctx.handle
+    fsz = write_bam(path, st, n_ref)
+    ctx.reset()
+    ctx.load_bam_device(path); ctx.flush()
+    info = ctx.pileup_run()
+    one = (int(ctx.num_records()), int(info.n_positions), int(info.n_columns), int(info.sum_coverage))
+    ctx.reset()
+    cur, peak = C.c_uint64(), C.c_uint64()
+    lib.bgp_device_memory(C.byref(cur), C.byref(peak), 1)
+    base = cur.value
+    lib.bgp_set_device_memory_cap(base + cap_bytes)
+    rows, got, peak_b = [], None, 0
+    try:
+        L.check(lib.bgp_set_compact_columns(h, 1), h)
+        for rep in range(reps + 1):
+            check = rep == 0
+            lib.bgp_device_memory(C.byref(cur), C.byref(peak), 1)
+            t0 = time.perf_counter()
+            L.check(lib.bgp_stream_bam_begin(h, path.encode(), batch_bytes, 0, 1 << 22), h)
+            npos = ncol = scov = 0; t_first = None
+            cw = L.Columns()
+            while L.check(lib.bgp_batch_next_window(h, C.byref(cw)), h) == L.BGP_OK:
+                if t_first is None:
+                    t_first = time.perf_counter() - t0
+                npos += cw.n_positions
+                if check:
+                    cov = (L.as_array(cw.columns8, cw.n_positions, L.COLUMN8_DTYPE, False) if cw.columns8 else L.as_array(cw.columns, cw.n_positions, L.COLUMN_DTYPE, False))["coverage"]
+                    ncol += int(np.count_nonzero(cov)); scov += int(cov.sum(dtype=np.uint64))
+            ob = C.c_uint64(); L.check(lib.bgp_batch_ordinal_base(h, C.byref(ob)), h)
+            nrec = int(ob.value) + int(ctx.num_records())
+            dt = time.perf_counter() - t0
+            lib.bgp_device_memory(C.byref(cur), C.byref(peak), 0)
+            peak_b = max(peak_b, peak.value - base)
+            ctx.reset()
+            if check:
+                got = (nrec, npos, ncol, scov)
+            else:
+                rows.append((dt, t_first))
+    finally:
+        L.check(lib.bgp_set_compact_columns(h, 0), h)
+        lib.bgp_set_device_memory_cap(0)
+        try:
+            os.unlink(path)
+        except OSError:
+            pass
+    best = min(rows)
+    return {"what": "BGZF BAM file -> reader threads -> ring of compressed chunks in HBM -> k_inflate into a batch's buffer -> K0 framing, record table, K3, K4 per batch -> every window of columns "
+                    "handed to the host, 8 bytes a position (bgp_stream_bam_begin + bgp_batch_next_window): device memory bounded whatever the file's size",
+            "reads": int(n_reads), "file_bytes": int(fsz), "inflated_bytes": int(len(st)), "batch_bytes": int(batch_bytes),
+            "Mreads_per_s": round(n_reads / best[0] / 1e6, 1), "file_GBps": round(fsz / best[0] / 1e9, 2), "inflated_GBps": round(len(st) / best[0] / 1e9, 1),
+            "best_s": round(best[0], 4), "first_window_after_s": round(best[1], 4), "runs_s": [round(r[0], 4) for r in rows],
+            "device_memory_cap_bytes": int(cap_bytes), "peak_device_memory_bytes": int(peak_b), "within_cap": bool(peak_b <= cap_bytes),
+            "equals_one_shot": {"equal": got == one, "records": got[0], "positions": got[1], "covered_columns": got[2], "sum_coverage": got[3]},
+            "full_size": "the 100 M-read file (15.9 GB -> 29 GB of records): profiles/r06_file_e2e_100M_streamed.log"}

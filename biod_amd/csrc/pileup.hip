@@ -2644,9 +2644,11 @@ int k34_pileup(bgp_ctx* c) {
         }
         }
         c->ck_w = a.ck ? tw : 0;                     // K5 resumes long reads from these checkpoints
-        TimedRegion t(c, "k4_tile", used);
+        // (timers named after the kernels they bracket: K4's algorithmic bytes are booked on the accumulate launch -- on the general kernel's
+        // where that takes every window)
         if (long_stream) BGP_HIP(hipMemsetAsync(a.tile_stats, 0, (tile_base + WG_SLOTS) * 32, c->stream));      // the accumulate path adds its totals wave by wave (zeroed with the planner's arrays above)
         if (!long_stream) {
+            TimedRegion t(c, "k4_acc2", used);
             GArgs g;
             g.s = a.s; g.slab = (const unsigned long long*)c->d_slab.p; g.slab_cap = SLAB_CAP; g.wcount = c->d_wcount.as<uint32_t>(); g.wdel = c->d_wdel.as<int32_t>(); g.tiles = a.tiles; g.n_tiles = tile_base;
             g.wlong = have_rows ? c->d_wlong.as<uint32_t>() : nullptr; g.rec = a.rec; g.ck_off = a.ck_off; g.ck = a.ck;
@@ -2661,6 +2663,8 @@ int k34_pileup(bgp_ctx* c) {
             else hipLaunchKernelGGL((k4_acc2<false, false>), dim3((unsigned)std::min<uint64_t>(tile_base, g_blocks)), dim3(AT), (size_t)A2Lay::BYTES, c->stream, g);
         }
         // windows the accumulate path left on the list (odd CIGARs, too deep): the general kernel
+        {
+        TimedRegion t(c, "k4_tile", long_stream ? used : 0);
         const unsigned dgrid = (unsigned)std::min<uint64_t>(tile_base, 2048);
         if (lite_bounds) hipLaunchKernelGGL(k4_bounds, dim3((unsigned)((tile_base + 255) / 256)), dim3(256), 0, c->stream, a.pmax_end, a.pmax_pos, a.runs, n_runs, tile_base, c->d_tiles.as<TileB>(), tw, 2, (const uint32_t*)(c->d_deep.as<uint32_t>() + 1), (const uint32_t*)c->d_deep.as<uint32_t>());
         if (long_stream) {
@@ -2670,7 +2674,9 @@ int k34_pileup(bgp_ctx* c) {
             hipLaunchKernelGGL(k4_tile<L16>, dim3(dgrid), dim3(L16::T), lds16, c->stream, a, 1);
             hipLaunchKernelGGL(k4_tile<L32>, dim3(std::min(dgrid, 512u)), dim3(L32::T), lds32, c->stream, a, 1);
         }
-        hipLaunchKernelGGL(k4_stats, dim3(32), dim3(256), 0, c->stream, a.tile_stats, tile_base + WG_SLOTS, a.pstats);
+        }
+        { TimedRegion t(c, "k4_stats", 0);
+        hipLaunchKernelGGL(k4_stats, dim3(32), dim3(256), 0, c->stream, a.tile_stats, tile_base + WG_SLOTS, a.pstats); }
         BGP_HIP(hipGetLastError());
     }
     if (getenv("BGP_VERBOSE") && n_runs) {
