@@ -137,6 +137,7 @@ SYMBOLS = {
     "bgp_bin_can_overlap": (C.c_int, [C.c_uint32, C.c_int32, C.c_int32]),
     "bgp_bgzf_read_chunks": (C.c_int, [C.c_char_p, _P, C.c_uint32, C.c_int, _P, C.c_uint64, C.POINTER(C.c_uint64)]),
     "bgp_load_bam_region": (C.c_int, [_P, C.c_char_p, _P, C.c_int32, C.c_uint32, C.c_uint32, C.c_int]),
+    "bgp_load_bam_region_device": (C.c_int, [_P, C.c_char_p, _P, C.c_int32, C.c_uint32, C.c_uint32]),
     "bgp_filter_region": (C.c_int, [_P, C.c_int32, C.c_uint32, C.c_uint32]),
     "bgp_load_bam_read_at": (C.c_int, [_P, C.c_char_p, C.c_uint64]),
     "bgp_record_voffset": (C.c_int, [_P, C.c_uint64, C.POINTER(C.c_uint64)]),

@@ -807,6 +807,24 @@ int bgp_load_bam_region(bgp_ctx* c, const char* path, bgp_bai* bai, int32_t ref_
     return BGP_OK;
     BGP_API_CATCH(c)
 }
+int bgp_load_bam_region_device(bgp_ctx* c, const char* path, bgp_bai* bai, int32_t ref_id, uint32_t beg, uint32_t end) {
+    BGP_API_TRY
+    if (!c || !path || !bai) return BGP_EINVAL;
+    if (c->flushed || c->stream_on_device || c->h_stage_len) return BGP_ESTATE;
+    if (!(beg < end)) { c->last_error = "start must be less than end"; return BGP_EINVAL; }          // reference.d:76
+    if (ref_id < 0) { c->last_error = "invalid reference id"; return BGP_EINVAL; }                   // reference.d:78
+    BGP_HIP(hipSetDevice(c->device));
+    BGP_TRY(bai_load_header(c, path));
+    const bgp_chunk* ch = nullptr; uint32_t n = 0;
+    const int rc = bgp_bai_chunks(bai, ref_id, beg, end, &ch, &n);
+    if (rc < 0) { c->last_error = "Invalid reference sequence index"; return rc; }                   // randomaccessmanager.d:205-207
+    batch_unpark(c);
+    BGP_TRY(bai_stage_chunks_device(c, path, ch, n));
+    c->bai_buildable = false;
+    c->region_pending = true; c->region_ref = (uint32_t)ref_id; c->region_beg = beg; c->region_end = end;
+    return BGP_OK;
+    BGP_API_CATCH(c)
+}
 int bgp_filter_region(bgp_ctx* c, int32_t ref_id, uint32_t beg, uint32_t end) {
     BGP_API_TRY
     if (!c) return BGP_EINVAL;

@@ -18,6 +18,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <mutex>
 #include <cstdio>
 #include <memory>
 #include <thread>
@@ -342,6 +343,116 @@ int bai_stage_chunks(bgp_ctx* c, const char* path, const bgp_chunk* chunks, uint
     if (rc < 0) { c->last_error = "zlib: corrupted BGZF block"; return rc; }
     for (const Piece& p : pieces) c->stage_map.push_back(bgp_ctx::StageSeg{c->h_stage_len + p.dst, p.keep, p.coff, p.skip});
     c->h_stage_len += total;
+    return BGP_OK;
+}
+
+// The same chunk list with decompressBgzfBlock on the DEVICE (bgp_load_bam_region_device): the chunks' blocks go to HBM compressed --
+// reader threads pread the file ranges the chunks span, 8 MiB at a time, through pinned buffers --, k_inflate (inflate.hip: a wave a
+// block, size and CRC32 checked) writes every whole block where its bytes belong in the record stream and the few cut ones (a chunk's
+// first and last block: beg.uoffset bytes dropped, end.uoffset kept) into slots of their own, from which k_gather_pieces copies what the
+// chunk keeps.  With eight ranks a node reading their shards of one file the host's cores are the ranks': no zlib runs on them.
+namespace {
+__global__ void k_gather_pieces(const uint8_t* slots, const uint4* cut, uint32_t n_cut, uint8_t* out) {      // cut[j] = (slot, skip, keep, dst lo) / dst hi in the next
+    const uint4 a = cut[2 * blockIdx.x], b = cut[2 * blockIdx.x + 1];
+    const uint8_t* src = slots + (uint64_t)a.x * 65536 + a.y;
+    uint8_t* dst = out + (((uint64_t)b.x << 32) | a.w);
+    for (uint32_t k = threadIdx.x; k < a.z; k += blockDim.x) dst[k] = src[k];
+    (void)n_cut;
+}
+}  // namespace
+int bai_stage_chunks_device(bgp_ctx* c, const char* path, const bgp_chunk* chunks, uint32_t n) {
+    MappedFile mf;
+    BGP_TRY(mf.open(path, c->last_error));
+    std::vector<Piece> pieces; uint64_t total = 0;
+    BGP_TRY(plan_chunks(mf, chunks, n, pieces, &total, c->last_error));
+    if (pieces.empty()) { BGP_TRY(c->d_stream_own.reserve(65536 + 256)); c->d_stream = c->d_stream_own.as<uint8_t>(); c->stream_len = 0; c->stream_on_device = true; return BGP_OK; }      // (no chunk: no reads)
+    // file ranges of consecutive blocks, each placed one behind the other in the device's copy
+    struct Range { uint64_t lo, hi, at; };
+    std::vector<Range> ranges; std::vector<uint64_t> comp_at(pieces.size());
+    uint64_t comp_bytes = 0;
+    for (size_t j = 0; j < pieces.size(); ++j) {
+        const Piece& p = pieces[j];
+        const uint64_t end = p.coff + p.cdata_off + p.cdata_len + 8;
+        if (ranges.empty() || ranges.back().hi != p.coff) { ranges.push_back(Range{p.coff, end, comp_bytes}); }
+        else ranges.back().hi = end;
+        comp_at[j] = ranges.back().at + (p.coff - ranges.back().lo) + p.cdata_off;
+        comp_bytes = ranges.back().at + (ranges.back().hi - ranges.back().lo);
+    }
+    constexpr uint64_t PART = 8ull << 20, SLACK = 65536;
+    struct Part { uint64_t file_off, dev_off, len; };
+    std::vector<Part> parts;
+    for (const Range& r : ranges) for (uint64_t o = r.lo; o < r.hi; o += PART) parts.push_back(Part{o, r.at + (o - r.lo), std::min(PART, r.hi - o)});
+    const int T = (int)std::max<size_t>(1, std::min<size_t>({(size_t)8, (size_t)bgp_default_threads(), parts.size()}));
+    BGP_TRY(c->d_comp.reserve(comp_bytes + 1024));
+    BGP_TRY(c->h_ring.reserve((size_t)T * PART));
+    const int fd = ::open(path, O_RDONLY);
+    if (fd < 0) { c->last_error = std::string("cannot open ") + path; return BGP_EINVAL; }
+    struct CloseFd { int fd; ~CloseFd() { close(fd); } } close_fd{fd};
+    std::atomic<size_t> next{0}; std::atomic<int> status{BGP_OK};
+    std::mutex up_mu;
+    auto reader = [&](int t) {
+        if (hipSetDevice(c->device) != hipSuccess) { status.store(BGP_EDEVICE); return; }
+        uint8_t* buf = c->h_ring.as<uint8_t>() + (size_t)t * PART;
+        hipEvent_t ev = nullptr;
+        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { status.store(BGP_EDEVICE); return; }
+        bool pending = false;
+        for (;;) {
+            const size_t k = next.fetch_add(1);
+            if (k >= parts.size() || status.load() < 0) break;
+            if (pending && hipEventSynchronize(ev) != hipSuccess) { status.store(BGP_EDEVICE); break; }      // the previous part has left this buffer
+            const Part& p = parts[k];
+            uint64_t got = 0;
+            while (got < p.len) { const ssize_t r = pread(fd, buf + got, p.len - got, (off_t)(p.file_off + got)); if (r <= 0) break; got += (uint64_t)r; }
+            if (got < p.len) { status.store(BGP_ETRUNC); break; }
+            std::lock_guard<std::mutex> ul(up_mu);
+            if (hipMemcpyAsync(c->d_comp.as<uint8_t>() + p.dev_off, buf, p.len, hipMemcpyHostToDevice, c->io_up) != hipSuccess || hipEventRecord(ev, c->io_up) != hipSuccess) { status.store(BGP_EDEVICE); break; }
+            pending = true;
+        }
+        if (pending) (void)hipEventSynchronize(ev);
+        (void)hipEventDestroy(ev);
+    };
+    {
+        std::vector<std::thread> th;
+        try { for (int t = 1; t < T; ++t) th.emplace_back(reader, t); } catch (...) { }
+        reader(0);
+        for (auto& x : th) x.join();
+    }
+    BGP_HIP(hipStreamSynchronize(c->io_up));
+    if (status.load() < 0) { c->last_error = status.load() == BGP_ETRUNC ? "short read" : "HIP error while uploading the chunks' blocks"; return status.load(); }
+    // descriptors: a whole block inflates into place, a cut one into a 64 KiB slot behind the stream
+    std::vector<bgp_inflate_block> desc; std::vector<uint4> cut;
+    uint32_t n_slots = 0;
+    for (size_t j = 0; j < pieces.size(); ++j) if (!(pieces[j].skip == 0 && pieces[j].keep == pieces[j].isize)) ++n_slots;
+    const uint64_t slots_at = (SLACK + total + 255) & ~255ull;
+    BGP_TRY(c->d_stream_own.reserve(slots_at + (uint64_t)n_slots * 65536 + 256));
+    uint32_t slot = 0;
+    for (size_t j = 0; j < pieces.size(); ++j) {
+        const Piece& p = pieces[j];
+        if (!p.isize) continue;
+        if (p.skip == 0 && p.keep == p.isize) desc.push_back(bgp_inflate_block{comp_at[j], SLACK + p.dst, p.cdata_len, p.isize, p.crc, 0});
+        else {
+            desc.push_back(bgp_inflate_block{comp_at[j], slots_at + (uint64_t)slot * 65536, p.cdata_len, p.isize, p.crc, 0});
+            const uint64_t d = SLACK + p.dst;
+            cut.push_back(make_uint4(slot, p.skip, p.keep, (uint32_t)d)); cut.push_back(make_uint4((uint32_t)(d >> 32), 0u, 0u, 0u));
+            ++slot;
+        }
+    }
+    const uint32_t nb = (uint32_t)desc.size();
+    BGP_TRY(c->d_inf_blk.reserve((size_t)nb * (sizeof(bgp_inflate_block) + 4) + cut.size() * 16 + 64));
+    int32_t* d_status = (int32_t*)(c->d_inf_blk.as<uint8_t>() + (size_t)nb * sizeof(bgp_inflate_block));
+    uint4* d_cut = (uint4*)(c->d_inf_blk.as<uint8_t>() + (((size_t)nb * (sizeof(bgp_inflate_block) + 4) + 15) & ~(size_t)15));
+    std::vector<int32_t> st(nb, 0);
+    if (nb) {
+        BGP_HIP(hipMemcpyAsync(c->d_inf_blk.p, desc.data(), (size_t)nb * sizeof(bgp_inflate_block), hipMemcpyHostToDevice, c->stream));
+        if (!cut.empty()) BGP_HIP(hipMemcpyAsync(d_cut, cut.data(), cut.size() * 16, hipMemcpyHostToDevice, c->stream));
+        BGP_TRY(inflate_blocks_device(c, c->d_comp.as<uint8_t>(), c->d_stream_own.as<uint8_t>(), c->d_inf_blk.as<bgp_inflate_block>(), nb, d_status, total));
+        if (!cut.empty()) { hipLaunchKernelGGL(k_gather_pieces, dim3((unsigned)(cut.size() / 2)), dim3(256), 0, c->stream, c->d_stream_own.as<uint8_t>() + slots_at, d_cut, (uint32_t)(cut.size() / 2), c->d_stream_own.as<uint8_t>()); BGP_HIP(hipGetLastError()); }
+        BGP_HIP(hipMemcpyAsync(st.data(), d_status, (size_t)nb * 4, hipMemcpyDeviceToHost, c->stream));
+    }
+    BGP_HIP(hipStreamSynchronize(c->stream));
+    for (uint32_t i = 0; i < nb; ++i) if (st[i]) { c->last_error = "zlib: corrupted BGZF block (device inflate, reason " + std::to_string(st[i]) + ")"; return BGP_EINVAL; }
+    for (const Piece& p : pieces) c->stage_map.push_back(bgp_ctx::StageSeg{p.dst, p.keep, p.coff, p.skip});
+    c->d_stream = c->d_stream_own.as<uint8_t>() + SLACK; c->stream_len = total; c->stream_on_device = true;
     return BGP_OK;
 }
 

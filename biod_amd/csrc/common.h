@@ -270,6 +270,7 @@ int bgzf_inflate_cdata(const uint8_t* cdata, const BgzfBlk& b, uint8_t* dst);   
 int bgzf_read_bam_header(int fd, uint64_t fsz, std::vector<RefInfo>& refs, uint64_t* q, std::string& err);
 int k_region_filter(bgp_ctx* c, uint32_t ref, uint32_t beg, uint32_t end);    // region.hip
 int bai_stage_chunks(bgp_ctx* c, const char* path, const bgp_chunk* chunks, uint32_t n, int n_threads);   // bai_host.cpp
+int bai_stage_chunks_device(bgp_ctx* c, const char* path, const bgp_chunk* chunks, uint32_t n);      // bai_host.cpp: the same chunk list inflated by k_inflate
 int bai_load_header(bgp_ctx* c, const char* path);
 int bai_stage_read_at(bgp_ctx* c, const char* path, uint64_t voffset);
 int bai_record_voffset(bgp_ctx* c, uint64_t staged_off, uint64_t* voffset);

@@ -75,6 +75,10 @@ class Context:
         """bam[ref][beg .. end] (reference.d:73-81): stage the BAI chunks' records; flush() then keeps the overlapping reads."""
         L.check(L.lib().bgp_load_bam_region(self._h, path.encode(), bai.handle, ref_id, beg, end, n_threads), self._h)
 
+    def load_bam_region_device(self, path: str, bai: "BaiFile", ref_id: int, beg: int, end: int):
+        """load_bam_region with the blocks inflated on the device (bgp_load_bam_region_device)."""
+        L.check(L.lib().bgp_load_bam_region_device(self._h, path.encode(), bai.handle, ref_id, beg, end), self._h)
+
     def filter_region(self, ref_id: int, beg: int, end: int):
         """BamReadFilter (randomaccessmanager.d:366-462) on the flushed record table."""
         L.check(L.lib().bgp_filter_region(self._h, ref_id, beg, end), self._h)

@@ -154,12 +154,16 @@ def plan_file_shards(bai, ref_lengths, world: int):
     return shards
 
 
-def file_shard_windows(ctx, path: str, bai, regions, n_threads: int = 0, **window_args):
+def file_shard_windows(ctx, path: str, bai, regions, n_threads: int = 0, device_inflate: bool = False, **window_args):
     """The windows of one rank's regions: bam[ref][beg .. end] staged through the index, piled up, and the columns of
-    [beg, end) handed out (makePileup's start_from / end_at, pileup.d:683-694)."""
+    [beg, end) handed out (makePileup's start_from / end_at, pileup.d:683-694).  device_inflate: the chunks' BGZF blocks are
+    inflated by the GPU (bgp_load_bam_region_device) -- with a rank per GPU the host's cores are shared by all of them."""
     for ref_id, beg, end in regions:
         ctx.reset()
-        ctx.load_bam_region(path, bai, ref_id, beg, end, n_threads)
+        if device_inflate:
+            ctx.load_bam_region_device(path, bai, ref_id, beg, end)
+        else:
+            ctx.load_bam_region(path, bai, ref_id, beg, end, n_threads)
         ctx.flush()
         if ctx.num_records() == 0:
             continue

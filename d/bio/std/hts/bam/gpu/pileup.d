@@ -253,6 +253,7 @@ extern (C) nothrow @nogc {
     int bgp_bgzf_read_chunks(const(char)* bam_path, const(bgp_chunk)* chunks, uint n, int n_threads,
                              ubyte* out_, ulong cap, ulong* len);
     int bgp_load_bam_region(bgp_ctx* ctx, const(char)* bam_path, bgp_bai* bai, int ref_id, uint beg, uint end, int n_threads);
+    int bgp_load_bam_region_device(bgp_ctx* ctx, const(char)* bam_path, bgp_bai* bai, int ref_id, uint beg, uint end);
     int bgp_filter_region(bgp_ctx* ctx, int ref_id, uint beg, uint end);
     int bgp_load_bam_read_at(bgp_ctx* ctx, const(char)* bam_path, ulong voffset);
     int bgp_record_voffset(bgp_ctx* ctx, ulong record, ulong* voffset);

@@ -407,6 +407,11 @@ int bgp_bgzf_read_chunks(const char* bam_path, const bgp_chunk* chunks, uint32_t
  * header, stages the records of getChunks(region); the following bgp_flush frames them and keeps exactly
  * the reads BamReadFilter (randomaccessmanager.d:366-462) yields.  beg < end is enforced (reference.d:76). */
 int bgp_load_bam_region(bgp_ctx* ctx, const char* bam_path, bgp_bai* bai, int32_t ref_id, uint32_t beg, uint32_t end, int n_threads);
+/* The same with decompressBgzfBlock (block.d:127-216) on the DEVICE, as bgp_load_bam_device does it for a whole file: the chunks' blocks are
+ * read and uploaded compressed, a wave inflates a block (size and CRC32 checked), the blocks a chunk cuts (beg.uoffset, end.uoffset:
+ * inputstream.d:281-324) are trimmed on the device.  No zlib on the host's cores -- eight ranks a node reading their shards of one file
+ * share them.  Same staged bytes, same records, same errors as bgp_load_bam_region. */
+int bgp_load_bam_region_device(bgp_ctx* ctx, const char* bam_path, bgp_bai* bai, int32_t ref_id, uint32_t beg, uint32_t end);
 /* BamReadFilter applied to the flushed record table in place (any staged stream, e.g. a whole file). */
 int bgp_filter_region(bgp_ctx* ctx, int32_t ref_id, uint32_t beg, uint32_t end);
 /* getReadAt (randomaccessmanager.d:156-164): stages the single record that starts at `voffset`. */

@@ -2295,8 +2295,8 @@ def test_entries_after_a_region_filter(ctx, data_dir, name, rid, beg, end):
         assert [(c.first_record, c.last_record, c.ref_id, c.start_position, c.end_position) for c in got] == O.chunk_plan(exp_stream, block)
 
 
-@pytest.mark.parametrize("world", [2, 3, 5])
-def test_file_shards_by_the_index_equal_the_whole_file(ctx, tmp_path, world):
+@pytest.mark.parametrize("world,device_inflate", [(2, False), (3, True), (5, False), (8, True)])
+def test_file_shards_by_the_index_equal_the_whole_file(ctx, tmp_path, world, device_inflate):
     """shard.plan_file_shards + file_shard_windows: a generator BAM with its index (written by the device index writer),
     cut INSIDE its contigs at linear-index windows; the columns the ranks hand out, put together, are the columns of the
     whole file -- every position once, none missing."""
@@ -2325,7 +2325,7 @@ def test_file_shards_by_the_index_equal_the_whole_file(ctx, tmp_path, world):
     assert sum(len(r) for r in plan) >= world and any(b > 0 for rank in plan for _, b, _ in rank)       # cuts inside a contig
     got = {}
     for rank in plan:
-        for w in shard.file_shard_windows(ctx, path, bai, rank, 2, window_positions=1 << 16):
+        for w in shard.file_shard_windows(ctx, path, bai, rank, 2, device_inflate=device_inflate, window_positions=1 << 16):      # (device_inflate: the chunks' blocks through k_inflate, bgp_load_bam_region_device)
             nz = np.nonzero(w.columns["coverage"])[0]
             for j in nz:
                 key = (w.ref_id, int(w.first_position) + int(j))
