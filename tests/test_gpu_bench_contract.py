@@ -74,3 +74,37 @@ def test_two_ranks_rehearsed_on_one_gpu():
     import torch
     if torch.cuda.device_count() < 2:
         assert d["reduce"].startswith("REHEARSAL")
+
+
+def test_eight_ranks_rehearsed_on_one_gpu():
+    """`bench.py --gpus 8` at 8 M reads on whatever the box has: strong_cfg(rank, 8) -> eight shards of ONE BAM (a contig a rank), the real
+    kernels on every shard, interior parity against the oracle on every rank, the depth histogram summed over the ranks == the sum of the
+    recomputed ones.  So that the first run on an 8-GPU node cannot fail on plumbing (pileup.d:497-506, reference.d:96-104).
+    On a box with fewer than eight GPUs the line says REHEARSAL: nothing here measures config 4."""
+    env = dict(os.environ); env.pop("BGP_BENCH_FORCE_COMM", None); env.pop("BGP_BENCH_REDUCE", None)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--reads", "8000000", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--parity", "--no-md", "--no-e2e"],
+                       env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1200)
+    d = _one_json_line(p)
+    assert d["n_gpus"] == 8 and d["scaling"] == "strong" and d["value"] > 0
+    assert d["config"]["reads_per_gpu"] == 1_000_000
+    assert d["hist_reduce_equals_sum_of_ranks"] is True
+    assert d["parity_interior"]["all_equal"] is True and d["parity_interior"]["all_equal_on_ranks"] == 8
+    assert d["checks_full_size"]["ok"] is True and d["checks_full_size"]["ok_on_ranks"] == 8
+    import torch
+    if torch.cuda.device_count() < 8:
+        assert d["reduce"].startswith("REHEARSAL")
+
+
+def test_config4_file_form_rehearsed():
+    """Config 4's FILE form (scratch/cfg4_file.py): one indexed BAM, three ranks cut by its .bai (shard.plan_file_shards), every rank's regions
+    loaded with the blocks inflated on the device (bgp_load_bam_region_device), piled up, the depth histogram summed over the ranks: reads,
+    covered columns, summed coverage and the histogram of the WHOLE file, every read and position counted once."""
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "scratch", "cfg4_file.py"), "--gpus", "3", "--reads", "600000", "--reps", "1", "--path", "/tmp/test_cfg4_file.bam"],
+                       env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    d = _one_json_line(p)
+    assert d["n_gpus"] == 3 and d["equals_whole_file"] is True and d["reads_counted"] == 600_000 and d["Mreads_per_s"] > 0
