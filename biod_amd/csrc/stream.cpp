@@ -51,6 +51,7 @@ struct FileFeed {
     uint64_t seen_turn = 0, rel_next = 0;                  // chunks scanned as of the last look; chunks [0, rel_next) are released
     uint64_t u_next = 0;                                   // inflated offset the next batch begins at (q for the first)
     bool all_dispatched = false; int n_batch = 0, prev_q = -1;
+    uint64_t slots = 0;                                    // BGZF blocks the device inflates at a time: a wave each, 8 waves a SIMD (inflate.hip)
     bool verbose = getenv("BGP_VERBOSE") != nullptr; std::chrono::steady_clock::time_point t_begin = std::chrono::steady_clock::now();
     double ms_now() const { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); }
     DevBuf d_desc[Batch::NDV]; HostBuf h_desc[Batch::NDV], h_status[Batch::NDV]; uint32_t n_desc[Batch::NDV] = {0, 0, 0, 0};
@@ -170,9 +171,17 @@ int feed_pump(bgp_ctx* c, Batch* b, bool need_one) {
         uint64_t bytes = 0, c_first = ~0ull, c_last = 0; size_t n_take = 0;
         const uint64_t u0 = f->n_batch == 0 ? f->q : f->u_next;
         constexpr uint64_t SLACK = 65536;                  // (the block that holds the first record starts up to 64 KB before it: b->reserve >= SLACK)
+        // (a wave inflates a block and the device holds f->slots of them at a time: a batch of a few hundred blocks more than a multiple of
+        // that runs a whole extra round for them -- 16 777 blocks of 64 000 bytes, 1 GiB, took three block-times where 16 384 take two: 29
+        // against ~21 ms.  A batch of more than one round's worth is cut at a multiple of the round.)
+        size_t n_inf = 0;
+        for (const BgzfBlk& x : f->todo) { if (x.isize && x.uoff + x.isize > f->q) ++n_inf; }
+        uint64_t fit = 0, fit_bytes = 0;
+        for (const BgzfBlk& x : f->todo) { if (x.isize && x.uoff + x.isize > f->q) { if (fit_bytes + x.isize > batch_cap && fit) break; fit_bytes += x.isize; ++fit; } }
+        const uint64_t blk_cap = (f->slots && fit > f->slots && !(scanned_all && fit == n_inf)) ? fit / f->slots * f->slots : ~0ull;
         for (const BgzfBlk& x : f->todo) {
             if (x.isize && x.uoff + x.isize > f->q) {
-                if (bytes + x.isize > batch_cap && bytes) break;
+                if ((bytes + x.isize > batch_cap && bytes) || desc.size() >= blk_cap) break;
                 const uint64_t k = x.coff / FileFeed::CH;
                 desc.push_back(bgp_inflate_block{(k % f->ND) * FileFeed::STRIDE + (x.coff - k * FileFeed::CH) + x.cdata_off, SLACK + x.uoff - u0, x.cdata_len, x.isize, x.crc, 0});
                 bytes += x.uoff >= u0 ? x.isize : x.uoff + x.isize - u0;
@@ -251,6 +260,8 @@ int bgp_stream_bam_begin(bgp_ctx* c, const char* path, uint64_t batch_bytes, int
     Batch* b = c->batch;
     c->refs = refs; c->n_ref_hint = (int32_t)refs.size();
     f->q = q; f->device = c->device; f->io_up = c->io_up;
+    { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, c->device) == hipSuccess) f->slots = (uint64_t)prop.multiProcessorCount * 32; else (void)hipGetLastError(); }
+    if (const char* e = getenv("BGP_STREAM_ROUND")) f->slots = (uint64_t)atoll(e);      // (0: batches are cut by bytes alone)
     f->n_chunks = (f->fsz + FileFeed::CH - 1) / FileFeed::CH;
     const uint64_t t_max = getenv("BGP_READ_THREADS") ? (uint64_t)atoi(getenv("BGP_READ_THREADS")) : 8ull;
     f->T = (int)std::max<uint64_t>(1, std::min<uint64_t>({t_max, (uint64_t)bgp_default_threads(), f->n_chunks}));
