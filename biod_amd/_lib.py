@@ -116,6 +116,7 @@ SYMBOLS = {
     "bgp_stream_bam_begin": (C.c_int, [_P, C.c_char_p, C.c_uint64, C.c_int, C.c_uint32]),
     "bgp_device_memory": (C.c_int, [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_int]),
     "bgp_set_compact_columns": (C.c_int, [_P, C.c_int]),
+    "bgp_set_read_filter": (C.c_int, [_P, C.c_uint32, C.c_uint32, C.c_uint32]),
     "bgp_set_device_memory_cap": (C.c_int, [C.c_uint64]),
     "bgp_batch_push": (C.c_int, [_P, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
     "bgp_batch_set_md": (C.c_int, [_P, C.c_int, C.c_int]),

@@ -67,6 +67,8 @@ int flush_core(bgp_ctx* c, uint32_t what) {
     }
     c->flushed = true;
     if (c->region_pending) { BGP_TRY(ensure_table(c)); BGP_TRY(k_region_filter(c, c->region_ref, c->region_beg, c->region_end)); }   // bam[ref][beg..end]
+    c->flt_applied = false;
+    if (c->flt_on) { BGP_TRY(ensure_table(c)); BGP_TRY(read_filter_apply(c)); }      // reads.filter!(...) in front of the pileup: the reads it drops cover nothing
     return BGP_OK;
 }
 
@@ -263,6 +265,13 @@ int bgp_device_memory(uint64_t* current, uint64_t* peak, int reset_peak) {
     return BGP_OK;
 }
 int bgp_set_device_memory_cap(uint64_t bytes) { bgp_devmem().cap.store(bytes); return BGP_OK; }
+int bgp_set_read_filter(bgp_ctx* c, uint32_t flag_require, uint32_t flag_exclude, uint32_t min_mapping_quality) {
+    if (!c) return BGP_EINVAL;
+    if (flag_require > 0xFFFFu || flag_exclude > 0xFFFFu || min_mapping_quality > 255u) return BGP_EINVAL;
+    c->flt_require = flag_require; c->flt_exclude = flag_exclude; c->flt_min_mapq = min_mapping_quality;
+    c->flt_on = flag_require != 0 || flag_exclude != 0 || min_mapping_quality != 0;
+    return BGP_OK;
+}
 int bgp_set_compact_columns(bgp_ctx* c, int on) { if (!c) return BGP_EINVAL; prefetch_cancel(c); c->compact_cols = on != 0; return BGP_OK; }
 
 int bgp_init(int device, bgp_ctx** out) {
@@ -861,6 +870,7 @@ int bgp_bai_build(bgp_ctx* c, const uint8_t** bytes, uint64_t* n_bytes) {
     BGP_API_TRY
     if (!c || !bytes || !n_bytes) return BGP_EINVAL;
     if (!c->flushed) return BGP_ESTATE;
+    if (c->flt_applied) { c->last_error = "createIndex wants every read's end_position: flush without a read filter (bgp_set_read_filter)"; return BGP_ESTATE; }
     BGP_HIP(hipSetDevice(c->device));
     BGP_TRY(ensure_table(c));
     BGP_TRY(bai_build(c, c->bai_bytes));

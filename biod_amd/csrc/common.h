@@ -197,6 +197,7 @@ struct bgp_ctx {
     // the consumer works on the current one (api.cpp: emit_window); h_cols2 is the second buffer the two windows alternate between
     struct Prefetch { bool valid = false, compact = false; uint32_t run = 0; uint64_t a = 0, b = 0; hipStream_t stream = nullptr; hipEvent_t done = nullptr; } pf;
     HostBuf h_cols2;
+    bool flt_on = false, flt_applied = false; uint32_t flt_require = 0, flt_exclude = 0, flt_min_mapq = 0;      // bgp_set_read_filter: reads the predicate drops cover nothing from the next flush on (region.hip: k_read_filter)
     bool compact_cols = false; DevBuf d_cols8[2]; HostBuf h_cols_wide;      // bgp_set_compact_columns: windows leave as 8 bytes a position (scan.hip: k_pack_columns8) through these staging buffers (the window at hand, the one copied ahead); a window with a count beyond 255 is copied again, wide
     DevBuf d_snp;
     DevBuf d_maq, d_maq_tab; bool maq_tables_ready = false; float maq_tab_depcorr = 0, maq_tab_eta = 0;   // MAQ model (maq.hip): calls of a window; fk | lhet | beta
@@ -269,6 +270,7 @@ int bgzf_scan_blocks(const uint8_t* f, uint64_t n, uint64_t stop, uint64_t& off,
 int bgzf_inflate_cdata(const uint8_t* cdata, const BgzfBlk& b, uint8_t* dst);      // zlib + size and CRC checks (block.d:127-216)
 int bgzf_read_bam_header(int fd, uint64_t fsz, std::vector<RefInfo>& refs, uint64_t* q, std::string& err);
 int k_region_filter(bgp_ctx* c, uint32_t ref, uint32_t beg, uint32_t end);    // region.hip
+int read_filter_apply(bgp_ctx* c);                                           // region.hip: bgp_set_read_filter's predicate on the record table
 int bai_stage_chunks(bgp_ctx* c, const char* path, const bgp_chunk* chunks, uint32_t n, int n_threads);   // bai_host.cpp
 int bai_stage_chunks_device(bgp_ctx* c, const char* path, const bgp_chunk* chunks, uint32_t n);      // bai_host.cpp: the same chunk list inflated by k_inflate
 int bai_load_header(bgp_ctx* c, const char* path);

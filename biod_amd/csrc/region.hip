@@ -89,3 +89,31 @@ int k_region_filter(bgp_ctx* c, uint32_t ref, uint32_t beg, uint32_t end) {
     c->piled = false; c->md_rows_ready = false; c->decoded_what = 0; c->it = bgp_ctx::Iter();
     return BGP_OK;
 }
+
+// ---- makePileup over a FILTERED range of reads: reads.filter!(pred) in front of the pileup (pileup.d:683-687 takes any input range of reads; the
+// predicates callers write are the flag properties of read.d:137-194 -- is_duplicate, failed_quality_control, is_secondary_alignment ... -- and
+// mapping_quality).  A read the filter drops is not in the range: it takes part in no column, holds no entry, provides no reference base.  Here
+// the record table is marked instead of compacted: such a read "covers nothing" (end_position = position, the reads pileupInstance filters out
+// itself, pileup.d:481,510), its plan row and class are cleared -- every kernel behind the table then leaves it out, and read ordinals stay the stream's.
+namespace {
+__global__ __launch_bounds__(256) void k_read_filter(bgp_record* rec, uint64_t n, uint32_t require, uint32_t exclude, uint32_t min_mapq, uint4* prow, uint8_t* rcls) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t bmn = rec[i].bin_mq_nl, fnc = rec[i].flag_nc;
+    const uint32_t flag = fnc >> 16, mq = (bmn >> 8) & 0xFFu;
+    if ((flag & require) == require && !(flag & exclude) && mq >= min_mapq) return;
+    rec[i].end_pos = rec[i].pos;
+    if (prow) { prow[i] = make_uint4(0u, 0u, 0u, 0u); rcls[i] = 0; }
+}
+}  // namespace
+int read_filter_apply(bgp_ctx* c) {
+    const uint64_t n = c->n_records;
+    if (!c->flt_on || !n) return BGP_OK;
+    TimedRegion t(c, "k_read_filter", n * 12);
+    hipLaunchKernelGGL(k_read_filter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->d_rec.as<bgp_record>(), n, c->flt_require, c->flt_exclude, c->flt_min_mapq,
+                       c->rows_ok ? c->d_prow.as<uint4>() : nullptr, c->rows_ok ? c->d_rcls.as<uint8_t>() : nullptr);
+    BGP_HIP(hipGetLastError());
+    c->tilemax_ok = false;                               // (K3 takes its tiles' maxima from the table as it is now)
+    c->flt_applied = true;
+    return BGP_OK;
+}

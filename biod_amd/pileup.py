@@ -105,6 +105,10 @@ class Context:
         L.check(L.lib().bgp_decode_fetch(self._h, L.BGP_FETCH_STREAM, C.byref(r)), self._h)
         return L.as_array(r.stream, r.stream_len, "u1")
 
+    def set_read_filter(self, flag_require: int = 0, flag_exclude: int = 0, min_mapping_quality: int = 0):
+        """reads.filter!(...) in front of the pileup (bgp_set_read_filter): reads that fail take part in nothing from the next flush on."""
+        L.check(L.lib().bgp_set_read_filter(self._h, flag_require, flag_exclude, min_mapping_quality), self._h)
+
     def set_compact_columns(self, on: bool = True):
         """Windows cross the link as 8 bytes a position wherever every count fits a byte (bgp_set_compact_columns); this facade widens them."""
         L.check(L.lib().bgp_set_compact_columns(self._h, int(on)), self._h)

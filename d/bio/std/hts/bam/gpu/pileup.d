@@ -187,6 +187,7 @@ extern (C) nothrow @nogc {
         ubyte del;
     }
     int bgp_set_compact_columns(bgp_ctx* ctx, int on);
+    int bgp_set_read_filter(bgp_ctx* ctx, uint flag_require, uint flag_exclude, uint min_mapping_quality);
     int bgp_pileup_begin(bgp_ctx* ctx, int mode, int use_md_tag, ulong start_from, ulong end_at,
                          int skip_zero_coverage, int want_entries, uint window_positions);
     int bgp_pileup_begin_ref(bgp_ctx* ctx, int ref_id, int use_md_tag, ulong start_from, ulong end_at,

@@ -240,6 +240,17 @@ typedef struct bgp_columns {
  * .device_columns) is untouched.  The setting holds for the ctx until it is changed (bgp_reset keeps it); default 0. */
 typedef struct bgp_column8 { uint8_t coverage, n_starting_here, a, c, g, t, other, del; } bgp_column8;
 int bgp_set_compact_columns(bgp_ctx* ctx, int on);
+/* makePileup over a FILTERED range of reads.  makePileup / pileupColumns take any input range of reads (pileup.d:683-687, read.d:1402-1420), and
+ * callers hand them reads.filter!(r => ...) over the flag properties of read.d:137-194 (is_duplicate 0x400, failed_quality_control 0x200,
+ * is_secondary_alignment 0x100, is_unmapped 0x4, proper_pair 0x2 ...) and mapping_quality.  With a filter set, a read passes when
+ *     (flag & flag_require) == flag_require  &&  (flag & flag_exclude) == 0  &&  mapping_quality >= min_mapping_quality
+ * and a read that does not is not in the range the pileup sees: it takes part in no column, holds no entry, provides no reference base --
+ * exactly the reads pileupInstance drops itself for covering nothing (pileup.d:481,510).  The filter is applied where bgp_flush /
+ * bgp_flush_decode (and every batch of a batched or file-fed pass) makes the record table: set it BEFORE staging is flushed; it holds for the
+ * ctx until changed (0, 0, 0 = none; bgp_reset keeps it).  Read ordinals (bgp_entry.read_ordinal) stay those of the unfiltered stream, and so
+ * do pileupChunks' cut points; bgp_records.rec[i].end_pos of a dropped read equals its pos; bgp_bai_build answers BGP_ESTATE under a filter.
+ * Any other predicate is the caller's: BioD's CPU templates over the decoded reads. */
+int bgp_set_read_filter(bgp_ctx* ctx, uint32_t flag_require, uint32_t flag_exclude, uint32_t min_mapping_quality);
 int bgp_pileup_begin(bgp_ctx* ctx, int mode, int use_md_tag, uint64_t start_from, uint64_t end_at,
                      int skip_zero_coverage, int want_entries, uint32_t window_positions);
 /* makePileup(bam[ref_id].reads, use_md_tag, start_from, end_at, skip_zero_coverage): bgp_pileup_begin(BGP_MAKE_PILEUP)

@@ -352,3 +352,25 @@ def test_region_load_device_large_file_and_file_shards(ctx, tmp_path):
         a, b = ctx.pileup_run(), host.pileup_run()
         assert (a.n_columns, a.sum_coverage, a.max_coverage) == (b.n_columns, b.sum_coverage, b.max_coverage)
     host.close(); ctx.reset()
+
+
+def test_stream_ctx_destroyed_with_an_open_pass(data_dir, tmp_path):
+    """bgp_destroy with a file-fed pass open (an exception in the caller, a facade's destructor): the reader threads are stopped, the
+    inflate and upload streams drained and only then destroyed, everything given back -- and the process goes on to stream the file again."""
+    cfg = scaled("cfg3", 300_000)
+    st = host_stream(cfg)
+    path = str(tmp_path / "d.bam")
+    write_bam_fast(path, [(f"chr{i + 1}", 1 << 28) for i in range(max(1, cfg.n_ref))], st)
+    base = device_memory()[0]
+    for take in (0, 1, 3):
+        c = Context(0)
+        L.check(L.lib().bgp_stream_bam_begin(c._h, path.encode(), 4 << 20, 0, 65536), c._h)
+        for _ in c.batch_drain(take) if take else ():
+            pass
+        c.close()
+        assert device_memory()[0] == base
+    c = Context(0)
+    n = sum(len(w.columns) for w in c.stream_bam_windows(path, 4 << 20, window_positions=65536))
+    c.reset(); c.load_bam_device(path); c.flush()
+    assert n == c.pileup_run().n_positions
+    c.close()
