@@ -1505,6 +1505,10 @@ __device__ __forceinline__ A2Small acc2_load_small(const uint8_t* s, uint64_t st
     return b;
 }
 __device__ __forceinline__ void acc2_work_small(const A2Small& b, uint32_t* cbase0) {
+#if BGP_ACC2_ABL & 32
+    if (b.q0.x == 0x12345678u && b.q0.y == 0x9ABCDEF0u && b.q0.z == 77u) cbase0[0] = 1;      // timing experiment: a long read's loads and bookkeeping, not its accumulate
+    return;
+#endif
     const uint32_t m0 = (b.eh >> 10) & 127u, s = (b.eh >> 17) & 7u, tl = (b.eh >> 20) & 127u, par = b.par;
     if (!__builtin_amdgcn_ballot_w64(tl != 0)) return;
     const uint32_t R[4] = {b.q0.x, b.q0.y, b.q0.z, b.q0.w};
@@ -1830,7 +1834,7 @@ template <bool LONG, bool ROWS> __global__ __launch_bounds__(AT, BGP_ACC2_MINW) 
                         }
                         // the ops' pieces (three chunks at most: one 16-byte load), dealt out to the lanes: an op of 15 bases is one piece, the
                         // odd long one several -- handled by the op's own lane the wave ran as long as its longest op while most lanes sat out
-                        while (__ballot(sp[0] < se[0] || sp[1] < se[1])) {
+                        while (!(BGP_ACC2_ABL & 64) && __ballot(sp[0] < se[0] || sp[1] < se[1])) {      // (64: timing experiment, the ops' scan alone)
                             uint32_t npc = 0;
                             {
                                 uint32_t q0 = sp[0], q1 = sp[1];
