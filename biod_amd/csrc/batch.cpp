@@ -35,7 +35,7 @@ void batch_unpark(bgp_ctx* c) {
 void batch_release(bgp_ctx* c) {
     Batch* b = c->batch;
     if (!b) return;
-    if (b->feed) { feed_release(c, b); for (hipStream_t x : c->io_inf) if (x) (void)hipStreamSynchronize(x); }      // (the readers stopped, no inflate left writing into a buffer that is about to go)
+    if (b->feed) { for (hipStream_t x : c->io_inf) if (x) (void)hipStreamSynchronize(x); feed_release(c, b); }      // (no inflate left reading the ring or writing into a buffer that is about to go; then the readers are stopped and the rings given back)
     if (b->copy_stream) (void)hipStreamSynchronize(b->copy_stream);      // (the ctx's upload stream: not this pass's to destroy)
     // (the pinned buffers and the two device buffers go back to the ctx: the next bgp_batch_begin takes them again -- pinning
     // 2 x 256 MiB anew cost ~70 ms, 40 % of a 10 M-read stream's whole pass)
