@@ -1398,6 +1398,9 @@ constexpr int ABPW = (W / 64) / ANW;          // 64-position blocks a wave flush
 #ifndef BGP_ACC2_COPIES
 #define BGP_ACC2_COPIES 4
 #endif
+#ifndef BGP_ACC2_NT_COLS
+#define BGP_ACC2_NT_COLS 0                    // 1: the columns leave with non-temporal stores
+#endif
 #ifndef BGP_ACC2_DEPTH
 #define BGP_ACC2_DEPTH 1                      // batches whose loads are in flight while a wave works on one
 #endif
@@ -1949,12 +1952,19 @@ template <bool LONG, bool ROWS> __global__ __launch_bounds__(AT, BGP_ACC2_MINW) 
                 if (cov == 0xFFFFFFF0u)                      // timing experiment: no column stores
 #endif
                 {
+#if BGP_ACC2_NT_COLS
+                nt_store16(o4, make_uint4(cov, S, cA, cC));      // (written once, read by nobody inside the step)
+                nt_store16(o4 + 1, make_uint4(cG, cT, cO, D));
+#else
                 o4[0] = make_uint4(cov, S, cA, cC);
                 o4[1] = make_uint4(cG, cT, cO, D);
+#endif
                 }
                 ncol += cov > 0; scov += cov; mx = max(mx, cov); nsum += S;
+#if !(BGP_ACC2_ABL & 128)                            // (128: timing experiment, no depth histogram)
                 if (cov < (uint32_t)P_HB) atomicAdd(&hist[cov], 1u);
                 else atomicAdd(&a.hist[min(cov, (uint32_t)BGP_DEPTH_BINS - 1)], 1ull);
+#endif
             }
         }
         r_ncol += ncol; r_nsum += nsum; r_mx = max(r_mx, mx); r_scov += scov;

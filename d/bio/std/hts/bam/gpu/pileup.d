@@ -346,6 +346,22 @@ final class GpuSource {
         chk(bgp_num_records(ctx, &n), ctx);
         return n;
     }
+
+    /// The windows cross the link as 8 bytes a position wherever every count fits a byte; GpuPileup widens them (pileup.d:236-290's numbers either way).
+    GpuSource compactTransport(bool on = true) {
+        chk(bgp_set_compact_columns(ctx, on ? 1 : 0), ctx);
+        return this;
+    }
+
+    /// `reads.filter!(r => (r.flag & require) == require && !(r.flag & exclude) && r.mapping_quality >= minMapq)` in front of the pileup
+    /// (the flag properties of read.d:137-194): the file is staged again with the predicate applied where the record table is made.
+    GpuSource filtered(string filename, uint require, uint exclude, uint minMapq) {
+        chk(bgp_set_read_filter(ctx, require, exclude, minMapq), ctx);
+        chk(bgp_reset(ctx), ctx);
+        chk(bgp_load_bam(ctx, filename.toStringz, 0), ctx);
+        chk(bgp_flush(ctx), ctx);
+        return this;
+    }
 }
 
 /// Host copy of the records the reads of the current window belong to (bgp_decode_fetch_range): rows, SEQ / QUAL /

@@ -53,6 +53,17 @@ public:
         return v;
     }
     uint64_t num_reads() const { uint64_t n; check(bgp_num_records(ctx_, &n), ctx_); return n; }
+    // windows cross the link as 8 bytes a position wherever every count fits a byte (bgp_set_compact_columns); PileupRange widens them:
+    // the consumer sees the same numbers (pileup.d:236-290)
+    BamReader& compact_transport(bool on = true) { check(bgp_set_compact_columns(ctx_, on ? 1 : 0), ctx_); return *this; }
+    // reads.filter!(r => (r.flag & require) == require && !(r.flag & exclude) && r.mapping_quality >= min_mapq) in front of the pileup
+    // (read.d:137-194): re-flushes what is staged with the predicate applied (bgp_set_read_filter + bgp_flush); reads that fail take part in nothing
+    BamReader& filter(uint32_t flag_require, uint32_t flag_exclude, uint32_t min_mapping_quality, const std::string& filename, int n_threads = 0) {
+        check(bgp_set_read_filter(ctx_, flag_require, flag_exclude, min_mapping_quality), ctx_);
+        check(bgp_reset(ctx_), ctx_);
+        check(bgp_load_bam(ctx_, filename.c_str(), n_threads), ctx_); check(bgp_flush(ctx_), ctx_);
+        return *this;
+    }
     BamReader& reads() { return *this; }                                       // reader.d:228-231
     // bam["chr1"][beg .. end] (reader.d opIndex -> reference.d:73-81): re-stages this reader with the reads that
     // overlap the region, found through the .bai next to the file (RandomAccessManager.getReads, :330-336).

@@ -25,6 +25,21 @@ int main(int argc, char** argv) {
             ++n;
         }
         REQUIRE(n == 1470);
+        {   // the same sweep with the windows in compact transport (8 bytes a position over the link, widened by the range): same columns
+            bam.compact_transport(true);
+            size_t m = 0; uint64_t cov = 0, cov_wide = 0;
+            for (auto column : makePileup(bam.reads())) { ++m; cov += column.coverage(); REQUIRE(column.coverage() == column.reads().size()); }
+            bam.compact_transport(false);
+            for (auto column : makePileup(bam.reads())) cov_wide += column.coverage();
+            REQUIRE(m == 1470 && cov == cov_wide && cov > 0);
+        }
+        {   // reads.filter!(r => !r.is_reverse_strand) in front of the pileup (read.d:137-194): no column holds a reverse-strand read
+            bam.filter(0, 0x10, 0, argv[1], 2);
+            size_t seen = 0;
+            for (auto column : pileupColumns(bam.reads())) for (auto& read : column.reads()) { REQUIRE(!(read.flag() & 0x10)); ++seen; }
+            REQUIRE(seen > 0);
+            bam.filter(0, 0, 0, argv[1], 2);
+        }
         int expected[2] = {1470, 1567}, current = -1;
         for (auto column : pileupColumns(bam.reads())) {                 // unittests.d:334-366
             const int r = column.ref_id();
