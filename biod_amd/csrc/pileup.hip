@@ -2672,9 +2672,10 @@ int k34_pileup(bgp_ctx* c) {
             static const unsigned g_env = getenv("BGP_G_BLOCKS") ? (unsigned)atoi(getenv("BGP_G_BLOCKS")) : 0u;
             const unsigned g_blocks = std::min(65536u, g_env ? g_env : 16384u);
             g.prow = use_rows ? c->d_prow.as<uint4>() : nullptr; g.stream_len = a.stream_len;
-            if (have_rows) hipLaunchKernelGGL((k4_acc2<true, false>), dim3((unsigned)std::min<uint64_t>(tile_base, g_blocks)), dim3(AT), (size_t)A2Lay::BYTES, c->stream, g);
-            else if (use_rows) hipLaunchKernelGGL((k4_acc2<false, true>), dim3((unsigned)std::min<uint64_t>(tile_base, g_blocks)), dim3(AT), (size_t)A2Lay::BYTES, c->stream, g);
-            else hipLaunchKernelGGL((k4_acc2<false, false>), dim3((unsigned)std::min<uint64_t>(tile_base, g_blocks)), dim3(AT), (size_t)A2Lay::BYTES, c->stream, g);
+            static const size_t lds_pad = getenv("BGP_ACC2_LDS_PAD") ? (size_t)atoi(getenv("BGP_ACC2_LDS_PAD")) : 0;      // (occupancy experiments: LDS the kernel never touches, so that fewer workgroups fit a CU)
+            if (have_rows) hipLaunchKernelGGL((k4_acc2<true, false>), dim3((unsigned)std::min<uint64_t>(tile_base, g_blocks)), dim3(AT), (size_t)A2Lay::BYTES + lds_pad, c->stream, g);
+            else if (use_rows) hipLaunchKernelGGL((k4_acc2<false, true>), dim3((unsigned)std::min<uint64_t>(tile_base, g_blocks)), dim3(AT), (size_t)A2Lay::BYTES + lds_pad, c->stream, g);
+            else hipLaunchKernelGGL((k4_acc2<false, false>), dim3((unsigned)std::min<uint64_t>(tile_base, g_blocks)), dim3(AT), (size_t)A2Lay::BYTES + lds_pad, c->stream, g);
         }
         // windows the accumulate path left on the list (odd CIGARs, too deep): the general kernel
         {
