@@ -935,7 +935,12 @@ int k12_lds_decode(bgp_ctx* c, uint32_t what) {
         TimedRegion t(c, "k12_lds", c->stream_len + n * 32 + 2 * c->sum_lseq + 4 * c->sum_ncig);      // SURVEY 8(d) without the framing: the record in, row + seq + qual + cigar out
         // what K4 is left (plan rows, the first-ops side array) is compiled in or out: the rows' block behind a run-time test cost every variant
         // registers -- 64 VGPRs with a spill to scratch and 56 spilled SGPRs against 62 / 0 / 29 without it (round 5's lost 0.7 ms)
-#define LAUNCH(r_, c_) hipLaunchKernelGGL((k12_lds<true, true, true, r_, c_>), dim3((unsigned)n_win), dim3(SD_T), L_TOTAL, c->stream, a)
+#ifndef BGP_K12_S
+#define BGP_K12_S true       // (timing experiments, wrong arenas: false leaves a section's work and stores out)
+#define BGP_K12_Q true
+#define BGP_K12_C true
+#endif
+#define LAUNCH(r_, c_) hipLaunchKernelGGL((k12_lds<BGP_K12_S, BGP_K12_Q, BGP_K12_C, r_, c_>), dim3((unsigned)n_win), dim3(SD_T), L_TOTAL, c->stream, a)
         if (want_rows && want_cig4) LAUNCH(true, true);
         else if (want_rows) LAUNCH(true, false);
         else if (want_cig4) LAUNCH(false, true);
