@@ -149,6 +149,7 @@ int emit_window(bgp_ctx* c, uint32_t run_idx, uint64_t a, uint64_t b, int want_e
     };
     const bool hit = c->pf.valid && c->pf.run == run_idx && c->pf.a == a && c->pf.b >= b && c->pf.compact == compact;
     if (c->pf.valid && !hit) prefetch_cancel(c);
+    const uint64_t pf_len = c->pf.b - c->pf.a;
     if (hit) {
         BGP_HIP(hipEventSynchronize(c->pf.done));
         std::swap(c->h_cols, c->h_cols2);
@@ -157,7 +158,10 @@ int emit_window(bgp_ctx* c, uint32_t run_idx, uint64_t a, uint64_t b, int want_e
     bool wide_again = false;
     if (compact) {                                      // the flag of the window at hand: a count beyond a byte somewhere in it?
         if (!hit) BGP_HIP(hipStreamSynchronize(c->stream));
-        uint64_t flag; memcpy(&flag, c->h_cols.as<uint8_t>() + np * 8, 8);
+        // (it lies behind the positions that were PACKED: a window copied ahead may be longer than the one asked for now -- the last window in
+        // front of end_at, or of a batch's cut -- and its flag speaks for all of it)
+        const uint64_t packed = hit ? pf_len : np;
+        uint64_t flag; memcpy(&flag, c->h_cols.as<uint8_t>() + packed * 8, 8);
         wide_again = flag != 0;
     }
     if (pf_on && b < r.end_pos) {                       // the window behind this one, as long as this one

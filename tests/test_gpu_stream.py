@@ -263,6 +263,28 @@ def test_compact_columns_deep_window_comes_wide(ctx):
         ctx.reset()
 
 
+def test_compact_columns_window_shorter_than_the_one_copied_ahead(ctx):
+    """makePileup(..., end_at) ends inside the window that was copied ahead: the window handed out is shorter than what was packed, and
+    the flag that says "a count beyond 255" lies behind the PACKED positions.  A pile of 300 reads inside the short window, nothing at the
+    position where a flag would have been looked for: the window must come wide (or compact with the right counts), never wrapped."""
+    recs = [bamio.pack_record(f"a{k}", "ACGTACGTAC", [(10, "M")], ref_id=0, pos=10 * k) for k in range(400)]            # coverage 1 over [0, 4000)
+    recs += [bamio.pack_record(f"d{k}", "ACGTACGTAC", [(10, "M")], ref_id=0, pos=5000) for k in range(300)]
+    recs += [bamio.pack_record(f"b{k}", "ACGTACGTAC", [(10, "M")], ref_id=0, pos=6000 + 10 * k) for k in range(300)]
+    st = b"".join(recs)
+    ora = O.pileup(st, mode=O.MODE_MAKE_PILEUP, start_from=0, end_at=5500, skip_zero=True)
+    ctx.reset(); ctx.push_inflated(st); ctx.flush()
+    ctx.set_compact_columns(True)
+    try:
+        ws = _raw_windows(ctx, lambda: L.check(L.lib().bgp_pileup_begin(ctx._h, L.BGP_MAKE_PILEUP, 0, 0, 5500, 1, 0, 1000), ctx._h))
+        assert [len(w[2]) for w in ws][-1] == 500
+        pos = np.concatenate([w[1] + np.nonzero(w[2]["coverage"])[0] for w in ws]); cols = np.concatenate([w[2][w[2]["coverage"] > 0] for w in ws])
+        _assert_columns_equal_oracle(np.zeros(len(pos), np.int64), pos.astype(np.int64), cols, ora)
+        assert int(cols["coverage"].max()) == 300
+    finally:
+        ctx.set_compact_columns(False)
+        ctx.reset()
+
+
 def test_compact_columns_streamed_file(ctx, tmp_path):
     """The file-fed pass with compact transport: 150 k reads of cfg3's model, windows of 64 k positions (dozens of them, copied ahead),
     columns == the wide transport's."""
