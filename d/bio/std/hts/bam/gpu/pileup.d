@@ -705,6 +705,75 @@ GpuPileup pileupColumns(GpuSource reads, bool use_md_tag = false, bool skip_zero
     return new GpuPileup(reads, BGP_PILEUP_COLUMNS, use_md_tag, 0, ulong.max, skip_zero_coverage);
 }
 
+/// `pileupColumns(new BamReader(filename).reads, use_md_tag)` with the FILE streamed through the device in bounded memory
+/// (bgp_stream_bam_begin: reader threads -> ring of compressed chunks in HBM -> k_inflate -> a batch's kernels -> windows; BioD's own ring of
+/// blocks in flight under a pulling consumer, bio/core/bgzf/inputstream.d:386-447,455-483).  An input range of the columns' summaries
+/// (coverage, counts, reference_base); `column.reads` is empty -- for the reads of a file that fits the device use `BamReader`.
+final class GpuStreamedPileup {
+    private bgp_ctx* ctx;
+    private bgp_columns win;
+    private bgp_column[] wide;
+    private GpuRecordWindow recs;
+    private uint k;
+    private bool done;
+
+    this(string filename, bool use_md_tag = false, ulong batch_bytes = 0, uint window = 0, bool compact = true, int device = 0) {
+        chk(bgp_init(device, &ctx), null);
+        scope (failure) { bgp_destroy(ctx); ctx = null; }
+        chk(bgp_set_compact_columns(ctx, compact ? 1 : 0), ctx);
+        chk(bgp_stream_bam_begin(ctx, filename.toStringz, batch_bytes, 0, window), ctx);
+        if (use_md_tag) chk(bgp_batch_set_md(ctx, 1, 1), ctx);
+        fetch();
+        settle();
+    }
+
+    ~this() {
+        if (ctx !is null) bgp_destroy(ctx);
+        ctx = null;
+    }
+
+    bool empty() @property { return done; }
+
+    GpuPileupColumn front() @property {
+        return GpuPileupColumn(win.ref_id, win.first_position + k, win.columns + k, null, &recs,
+                               win.reference_base !is null ? cast(char) win.reference_base[k] : 'N', -1, null);
+    }
+
+    void popFront() {
+        ++k;
+        settle();
+    }
+
+    private void fetch() {
+        done = chk(bgp_batch_next_window(ctx, &win), ctx) != BGP_OK;
+        k = 0;
+        if (!done && win.columns is null && win.columns8 !is null) {
+            wide.length = win.n_positions;
+            foreach (i; 0 .. win.n_positions) {
+                auto s = win.columns8[i];
+                bgp_column w;
+                w.coverage = s.coverage; w.n_starting_here = s.n_starting_here; w.a = s.a; w.c = s.c; w.g = s.g; w.t = s.t; w.other = s.other; w.del = s.del;
+                wide[i] = w;
+            }
+            win.columns = wide.ptr;
+        }
+    }
+
+    private void settle() {
+        while (!done) {
+            if (k >= win.n_positions) {
+                fetch();
+                continue;
+            }
+            if (win.columns[k].coverage == 0) {
+                ++k;
+                continue;
+            }
+            return;
+        }
+    }
+}
+
 /// pileup.d:1011-1015: a random-access range of pileups, one per chunk of `block_size` bytes of reads
 /// (chunksConsumingLessThan, splitter.d:65-91; seams as PileupChunkRange sets them, pileup.d:905-913,932-939).  Elements
 /// of ONE source are consumed one at a time (a pool of sources gives `taskPool.map` real concurrency).

@@ -367,4 +367,48 @@ inline PileupChunks pileupChunks(BamReader& reads, bool use_md_tag = false, uint
     return PileupChunks(reads, use_md_tag, block_size, start_from, end_at, want_entries, window);
 }
 
+// pileupColumns(new BamReader(filename).reads, use_md_tag) with the FILE streamed through the device in bounded memory (bgp_stream_bam_begin:
+// reader threads -> ring of compressed chunks in HBM -> k_inflate -> a batch's kernels -> windows; BioD's ring of blocks in flight under a
+// pulling consumer, inputstream.d:386-447,455-483).  The columns' summaries (coverage, counts, reference_base): `reads()` of a column is
+// empty -- a consumer that wants the reads of a file that fits the device uses BamReader.  skip_zero_coverage as pileupColumns' default.
+class StreamedPileup {
+public:
+    explicit StreamedPileup(const std::string& filename, bool use_md_tag = false, uint64_t batch_bytes = 0, uint32_t window = 0, bool compact_transport = true, int device = 0) {
+        check(bgp_init(device, &ctx_));
+        try {
+            check(bgp_set_compact_columns(ctx_, compact_transport ? 1 : 0), ctx_);
+            check(bgp_stream_bam_begin(ctx_, filename.c_str(), batch_bytes, 0, window), ctx_);
+            if (use_md_tag) check(bgp_batch_set_md(ctx_, 1, 1), ctx_);
+            fetch(); settle();
+        } catch (...) { bgp_destroy(ctx_); throw; }
+    }
+    ~StreamedPileup() { bgp_destroy(ctx_); }
+    StreamedPileup(const StreamedPileup&) = delete;
+    StreamedPileup& operator=(const StreamedPileup&) = delete;
+    bool empty() const { return done_; }
+    PileupColumn front() const {
+        return PileupColumn{w_.ref_id, w_.first_position + k_, w_.columns + k_, nullptr, 0, nullptr, w_.reference_base ? (char)w_.reference_base[k_] : 'N', -1, nullptr};
+    }
+    void popFront() { ++k_; settle(); }
+    struct iterator {
+        StreamedPileup* r;
+        bool operator!=(const iterator&) const { return !r->empty(); }
+        void operator++() { r->popFront(); }
+        PileupColumn operator*() const { return r->front(); }
+    };
+    iterator begin() { return {this}; }
+    iterator end() { return {this}; }
+private:
+    void fetch() {
+        const int rc = check(bgp_batch_next_window(ctx_, &w_), ctx_); done_ = rc != BGP_OK; k_ = 0;
+        if (!done_ && !w_.columns && w_.columns8) {
+            wide_.resize(w_.n_positions);
+            for (uint32_t k = 0; k < w_.n_positions; ++k) { const bgp_column8& s = w_.columns8[k]; wide_[k] = bgp_column{s.coverage, s.n_starting_here, s.a, s.c, s.g, s.t, s.other, s.del}; }
+            w_.columns = wide_.data();
+        }
+    }
+    void settle() { while (!done_) { if (k_ >= w_.n_positions) { fetch(); continue; } if (w_.columns[k_].coverage == 0) { ++k_; continue; } return; } }
+    bgp_ctx* ctx_ = nullptr; bgp_columns w_{}; std::vector<bgp_column> wide_; uint32_t k_ = 0; bool done_ = false;
+};
+
 }  // namespace biodgpu

@@ -40,6 +40,12 @@ int main(int argc, char** argv) {
             REQUIRE(seen > 0);
             bam.filter(0, 0, 0, argv[1], 2);
         }
+        {   // the same file streamed through bounded device memory (bgp_stream_bam_begin), batches of two BGZF blocks: the same columns
+            size_t m = 0; uint64_t cov = 0, cov_ref = 0;
+            for (auto column : pileupColumns(bam.reads(), false, true, false)) cov_ref += column.coverage();
+            for (auto column : StreamedPileup(argv[1], false, 128 << 10, 500)) { ++m; cov += column.coverage(); REQUIRE(column.reads().empty()); }
+            REQUIRE(m == 1470 + 1567 && cov == cov_ref);
+        }
         int expected[2] = {1470, 1567}, current = -1;
         for (auto column : pileupColumns(bam.reads())) {                 // unittests.d:334-366
             const int r = column.ref_id();
