@@ -23,6 +23,12 @@ for k in range(n):
         st = host_stream(cfg)
     except L.BiodGpuError:
         continue
+    if rng.random() < 0.35:                                # a pile deeper than a byte holds, somewhere: that window crosses the link in the 32-byte layout
+        import oracle_lib as O
+        offs = [int(x) for x in O.frame(st)] + [len(st)]
+        k0 = int(rng.integers(0, len(offs) - 1))
+        rec = st[offs[k0]:offs[k0 + 1]]
+        st = st[:offs[k0 + 1]] + rec * int(rng.integers(260, 700)) + st[offs[k0 + 1]:]
     payload = bamio.bam_header_bytes([(f"chr{i + 1}", 1 << 28) for i in range(cfg.n_ref)], text="@HD\tVN:1.0\n" * int(rng.integers(0, 3000))) + st
     mode = int(rng.integers(0, 3))
     with open(path, "wb") as f:
@@ -54,6 +60,20 @@ for k in range(n):
     if entries:
         want_ne = sum(int(w.entry_off[-1]) for w in ctx.pileup_windows(L.BGP_PILEUP_COLUMNS, want_entries=True, window_positions=1 << 20))
     try:
+        if rng.random() < 0.5 and len(want):               # makePileup clipped at a random end_at, windows of a random size: compact == wide (the last window is shorter than the one copied ahead)
+            run0 = info.runs[0]
+            lo_p, hi_p = int(run0["start_pos"]), int(run0["end_pos"])
+            end_at = int(rng.integers(lo_p + 1, hi_p + 2)); start_from = int(rng.integers(lo_p, end_at))
+            wsz = int(rng.integers(50, 3000))
+            def clipped(comp):
+                L.check(lib.bgp_set_compact_columns(h, int(comp)), h)
+                L.check(lib.bgp_pileup_begin(h, L.BGP_MAKE_PILEUP, 0, start_from, end_at, int(rng.integers(0, 2)) if False else 1, 0, wsz), h)
+                out = []; cw = L.Columns()
+                while L.check(lib.bgp_pileup_next_window(h, C.byref(cw)), h) == L.BGP_OK:
+                    out.append((int(cw.first_position), L.window_columns(cw)))
+                return out
+            a_, b_ = clipped(False), clipped(True)
+            assert len(a_) == len(b_) and all(x[0] == y[0] and np.array_equal(x[1], y[1]) for x, y in zip(a_, b_)), "makePileup clipped: compact != wide"
         L.check(lib.bgp_set_compact_columns(h, int(compact)), h)
         if rng.random() < 0.15:                            # a pass abandoned after a window or two
             L.check(lib.bgp_stream_bam_begin(h, path.encode(), batch, 0, window), h)
