@@ -541,7 +541,7 @@ def main():
             cfg_e = scaled(a.config, n_e2e)
             st_e = host_stream_np(cfg_e)
             out["e2e"] = {"note": "input NOT resident in HBM: PCIe-inclusive (device_e2e) and inflate-inclusive (file_e2e) rates of the same hot path on %d reads of %s's model; the headline `value` is kernel-only" % (n_e2e, a.config),
-                          "device_e2e": bench_e2e.device_e2e(ctx, st_e, n_e2e), "device_e2e_compact_columns": bench_e2e.device_e2e(ctx, st_e, n_e2e, compact=True),
+                          "device_e2e": bench_e2e.device_e2e(ctx, st_e, n_e2e), "device_e2e_compact_columns": bench_e2e.device_e2e(ctx, st_e, n_e2e, compact=True), "device_e2e_pinned_source": bench_e2e.device_e2e_pinned(ctx, st_e, n_e2e),
                           "file_e2e": bench_e2e.file_e2e(ctx, st_e, n_e2e, int(cfg_e.n_ref)), "file_e2e_streamed": bench_e2e.file_e2e_streamed(ctx, st_e, n_e2e, int(cfg_e.n_ref))}
             del st_e
         if not a.no_cpu_baseline and world == 1:                        # (at N = 1 only: with more ranks the host's cores are the ranks')

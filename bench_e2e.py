@@ -93,6 +93,54 @@ def device_e2e(ctx, st, n_reads, batch_bytes=256 << 20, producers=16, reps=3, co
                                         "K4 columns": per("k4_"), "d2h windows": per("d2h"), "wall": round(dt_t / nb * 1e3, 3)}}
 
 
+def device_e2e_pinned(ctx, st, n_reads, batch_bytes=256 << 20, reps=3, compact=True):
+    """SURVEY 8(d) (ii) as it is worded -- "device E2E from pinned host inflated buffers incl. H2D / D2H": the inflated records lie in page-locked
+    memory already (where an inflater that owns its buffers keeps them) and go to the device from there (bgp_batch_push_pinned), no staging
+    copy inside the timed region; windows out in compact transport.  A buffer and a window in turn, as device_e2e."""
+    import torch
+    lib, h = L.lib(), ctx.handle
+    pinned = torch.from_numpy(st).pin_memory()                       # (set-up: the inflater's own buffers)
+    base = pinned.data_ptr()
+    L.check(lib.bgp_set_compact_columns(h, int(compact)), h)
+
+    def run():
+        t0 = time.perf_counter()
+        L.check(lib.bgp_batch_begin(h, batch_bytes, 0, 1 << 22), h)
+        npos = 0
+        cw = L.Columns()
+        taken = C.c_size_t()
+        L.check(lib.bgp_batch_push_pinned(h, C.c_void_p(base), len(st), C.byref(taken)), h)      # all of it: the library ships a piece whenever a device buffer falls free
+        assert taken.value == len(st)
+        L.check(lib.bgp_batch_end(h), h)
+        while L.check(lib.bgp_batch_next_window(h, C.byref(cw)), h) == L.BGP_OK:
+            npos += cw.n_positions
+        return time.perf_counter() - t0, npos
+
+    ctx.reset()
+    times, positions = [], 0
+    try:
+        for _ in range(reps):
+            dt, positions = run()
+            times.append(dt)
+            ctx.reset()
+        ctx.timing_enable(True); ctx.timing_reset()
+        dt_t, _ = run()
+        tm = ctx.timing_get()
+        ctx.timing_enable(False)
+        ctx.reset()
+    finally:
+        L.check(lib.bgp_set_compact_columns(h, 0), h)
+    nb = max(1, tm.get("h2d_batch", {}).get("launches", 1))
+    per = lambda pre: round(sum(v["total_ms"] for k, v in tm.items() if k.startswith(pre)) / nb, 3)      # noqa: E731
+    best = min(times)
+    return {"what": "inflated records in PAGE-LOCKED host memory -> bgp_batch_push_pinned (to the device from where they lie) -> K0..K4 per batch -> windows of columns handed out, 8 bytes a position "
+                    "(SURVEY 8(d) ii: 'from pinned host inflated buffers')",
+            "reads": int(n_reads), "inflated_bytes": int(len(st)), "batch_bytes": int(batch_bytes), "positions": int(positions),
+            "Mreads_per_s": round(n_reads / best / 1e6, 1), "input_GBps": round(len(st) / best / 1e9, 1), "best_s": round(best, 4), "runs_s": [round(t, 4) for t in times],
+            "per_batch_ms_hip_events": {"batches": nb, "h2d_batch": per("h2d_batch"), "K0 framing": per("k0_"), "K1 record table": per("k1_"), "K3 keys": per("k3_"), "K4 columns": per("k4_"),
+                                        "d2h windows": per("d2h"), "wall": round(dt_t / nb * 1e3, 3)}}
+
+
 def write_bam(path, st, n_ref, threads=32, block=64000):
     """The stream as a BGZF file (writer.d:260: blocks of up to 64 KB, the EOF block at the end)."""
     b = memoryview(st)

@@ -119,6 +119,7 @@ SYMBOLS = {
     "bgp_set_read_filter": (C.c_int, [_P, C.c_uint32, C.c_uint32, C.c_uint32]),
     "bgp_set_device_memory_cap": (C.c_int, [C.c_uint64]),
     "bgp_batch_push": (C.c_int, [_P, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "bgp_batch_push_pinned": (C.c_int, [_P, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
     "bgp_batch_set_md": (C.c_int, [_P, C.c_int, C.c_int]),
     "bgp_batch_acquire": (C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_size_t)]),
     "bgp_batch_commit": (C.c_int, [_P, C.c_size_t]),

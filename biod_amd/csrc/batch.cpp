@@ -95,9 +95,27 @@ static int ship(bgp_ctx* c, Batch* b) {
     return BGP_OK;
 }
 // every full buffer a device buffer is free for
+// the caller's page-locked bytes (bgp_batch_push_pinned), a batch_bytes piece into every free device buffer -- behind whatever full pinned
+// buffer of the pass's own is still waiting (pushed earlier: piled up earlier)
+static int ship_pinned(bgp_ctx* c, Batch* b) {
+    while (b->pin_len && !b->n_full) {
+        int q = -1;
+        for (int k = 0; k < b->n_dev; ++k) if (b->state[k] == Batch::FREE) { q = k; break; }
+        if (q < 0) break;
+        const uint64_t n = std::min<uint64_t>(b->pin_len, b->batch_bytes);
+        BGP_TRY(b->dev[q].reserve(b->reserve + b->batch_bytes + 256));
+        b->new_off[q] = b->reserve; b->new_len[q] = n;
+        { TimedRegion th(c, "h2d_batch", n, b->copy_stream);
+          BGP_HIP(hipMemcpyAsync(b->dev[q].as<uint8_t>() + b->reserve, b->pin_ptr, n, hipMemcpyHostToDevice, b->copy_stream)); }
+        BGP_HIP(hipEventRecord(b->loaded_ev[q], b->copy_stream));
+        b->state[q] = Batch::LOADED; b->queue[b->n_queue++] = q;
+        b->pin_ptr += n; b->pin_len -= n;
+    }
+    return BGP_OK;
+}
 static int ship_ready(bgp_ctx* c, Batch* b) {
     while (b->n_full) { const int rc = ship(c, b); if (rc == BGP_EAGAIN) break; if (rc != BGP_OK) return rc; }
-    return BGP_OK;
+    return ship_pinned(c, b);
 }
 // the buffer that takes the caller's bytes is full (or the stream is over): it joins the queue, and the next one that is not waiting
 // there takes its place (none: fill = -1 until a full one has left)
@@ -144,7 +162,7 @@ static int process_next(bgp_ctx* c, Batch* b) {
     const int q = b->queue[0];
     for (int k = 1; k < b->n_queue; ++k) b->queue[k - 1] = b->queue[k];
     --b->n_queue;
-    const bool final = b->ended && b->n_queue == 0 && b->n_full == 0 && (b->fill < 0 || b->host_len[b->fill] == 0);
+    const bool final = b->ended && b->n_queue == 0 && b->n_full == 0 && b->pin_len == 0 && (b->fill < 0 || b->host_len[b->fill] == 0);
     BGP_HIP(hipStreamWaitEvent(c->stream, b->loaded_ev[q], 0));
     if (b->feed && b->new_len[q]) BGP_TRY(feed_check(c, b, q));      // a batch k_inflate made: every block's size and CRC held (block.d:197-207)
     if (b->carry_len > b->new_off[q]) {                              // a carry longer than the room in front of the new bytes: a bigger buffer, once
@@ -272,6 +290,7 @@ int bgp_batch_push(bgp_ctx* c, const uint8_t* data, size_t len, size_t* taken) {
     if (b->acq >= 0) return BGP_ESTATE;                  // an acquired buffer is waiting for its commit: a push could ship it from under the caller
     BGP_HIP(hipSetDevice(c->device));
     *taken = 0;
+    if (b->pin_len) { BGP_TRY(ship_ready(c, b)); if (b->pin_len) return BGP_EAGAIN; }      // (page-locked bytes pushed earlier go first)
     while (*taken < len) {
         if (b->fill >= 0 && b->host_len[b->fill] == b->batch_bytes) close_fill(b);
         { const int rc = fill_ready(c, b); if (rc != BGP_OK) return rc; }      // BGP_EAGAIN: hand out windows first
@@ -281,6 +300,36 @@ int bgp_batch_push(bgp_ctx* c, const uint8_t* data, size_t len, size_t* taken) {
         b->host_len[h] += n; *taken += n;
     }
     if (b->fill >= 0 && b->host_len[b->fill] == b->batch_bytes) { close_fill(b); BGP_TRY(ship_ready(c, b)); }
+    return BGP_OK;
+    BGP_API_CATCH(c)
+}
+
+/* bgp_batch_push for bytes that already lie in page-locked host memory (hipHostMalloc / hipHostRegister): they go to the device from
+ * where they are, a batch_bytes piece a device buffer -- no copy into the pass's own pinned buffers.  SURVEY 8(d) (ii): "device E2E
+ * from pinned host inflated buffers".  BGP_EAGAIN with *taken < len: both device buffers are taken -- take a window, push the rest. */
+int bgp_batch_push_pinned(bgp_ctx* c, const uint8_t* data, size_t len, size_t* taken) {
+    BGP_API_TRY
+    if (!c || (!data && len) || !taken) return BGP_EINVAL;
+    Batch* b = c->batch;
+    if (!b || b->ended || b->feed) return BGP_ESTATE;
+    if (b->acq >= 0) return BGP_ESTATE;
+    BGP_HIP(hipSetDevice(c->device));
+    *taken = 0;
+    if (!len) return BGP_OK;
+    {   // page-locked, or refused: a pageable source would make every copy a synchronous, staged one behind the caller's back
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, data) != hipSuccess || at.type != hipMemoryTypeHost) { (void)hipGetLastError(); c->last_error = "bgp_batch_push_pinned: the bytes are not in page-locked host memory (hipHostMalloc / hipHostRegister)"; return BGP_EINVAL; }
+    }
+    // what was pushed before comes first: a partly filled buffer of the pass's own is closed and leaves in front of these bytes; bytes of an
+    // earlier bgp_batch_push_pinned still waiting are followed only by bytes that lie right behind them
+    if (b->pin_len) {
+        BGP_TRY(ship_ready(c, b));
+        if (b->pin_len && b->pin_ptr + b->pin_len != data) return BGP_EAGAIN;
+    }
+    if (b->fill >= 0 && b->host_len[b->fill]) close_fill(b);
+    if (!b->pin_len) b->pin_ptr = data;
+    b->pin_len += len; *taken = len;                     // (all of it is the pass's from here on: it leaves for the device as buffers fall free -- now, and inside bgp_batch_next_window)
+    BGP_TRY(ship_ready(c, b));
     return BGP_OK;
     BGP_API_CATCH(c)
 }
@@ -296,6 +345,7 @@ int bgp_batch_acquire(bgp_ctx* c, uint8_t** ptr, size_t* cap) {
     if (b->acq >= 0) return BGP_ESTATE;                  // one acquisition at a time: commit (0 bytes if need be) before the next
     BGP_HIP(hipSetDevice(c->device));
     *ptr = nullptr; *cap = 0;
+    if (b->pin_len) { BGP_TRY(ship_ready(c, b)); if (b->pin_len) return BGP_EAGAIN; }      // (page-locked bytes pushed earlier go first)
     // a buffer with less room than one BGZF block inflates to (64 KiB, constants.d:26-61) is shipped as it is: a caller that writes
     // whole blocks could otherwise be handed a tail it can never use, with no way to move on
     { const int rc = fill_ready(c, b, true); if (rc != BGP_OK) return rc; }      // BGP_EAGAIN: hand out windows first
@@ -376,6 +426,7 @@ int bgp_batch_next_window(bgp_ctx* c, bgp_columns* o) {
         }
         // the next batch
         if (b->n_queue == 0 && b->feed) BGP_TRY(feed_pump(c, b, true));       // (waits for the file: a batch is queued, or the stream is over)
+        if (b->n_queue == 0 && b->pin_len) BGP_TRY(ship_ready(c, b));           // (the caller's page-locked bytes still waiting: the buffer the last batch gave up is theirs)
         if (b->n_queue == 0) {
             if (!b->ended) return b->feed ? BGP_ESTATE : BGP_EAGAIN;        // push more, or say the stream is over
             if (!b->n_full) {

@@ -31,6 +31,7 @@ struct Batch {
     uint32_t run = 0; uint64_t next_pos = 0; bool run_open = false;
     // use_md_tag across batches: the provider chain's state at the last event in front of the cut (stream-wide record ordinals)
     struct { bool have = false; uint64_t P_ord = 0, i_ord = 0; uint32_t ci = 0, y = 0, ce = 0; int32_t ref = -1; } md;
+    const uint8_t* pin_ptr = nullptr; uint64_t pin_len = 0;      // bgp_batch_push_pinned: page-locked bytes of the caller's still to go to the device (a device buffer at a time, as buffers fall free)
     struct FileFeed* feed = nullptr;                    // bgp_stream_bam_begin (stream.cpp): the batches come from a BGZF file through k_inflate, nobody pushes
 };
 

@@ -199,6 +199,7 @@ extern (C) nothrow @nogc {
     int bgp_stream_bam_begin(bgp_ctx* ctx, const(char)* path, ulong batch_bytes, int want_entries, uint window_positions);
     int bgp_batch_set_md(bgp_ctx* ctx, int use_md_tag, int skip_zero_coverage);
     int bgp_batch_push(bgp_ctx* ctx, const(ubyte)* data, size_t len, size_t* taken);
+    int bgp_batch_push_pinned(bgp_ctx* ctx, const(ubyte)* data, size_t len, size_t* taken);
     int bgp_batch_acquire(bgp_ctx* ctx, ubyte** ptr, size_t* cap);
     int bgp_batch_commit(bgp_ctx* ctx, size_t n);
     int bgp_batch_end(bgp_ctx* ctx);

@@ -303,6 +303,14 @@ int bgp_stream_bam_begin(bgp_ctx* ctx, const char* path, uint64_t batch_bytes, i
  * BioD's popFront would throw at. */
 int bgp_batch_set_md(bgp_ctx* ctx, int use_md_tag, int skip_zero_coverage);
 int bgp_batch_push(bgp_ctx* ctx, const uint8_t* data, size_t len, size_t* taken);
+/* bgp_batch_push for bytes that already lie in PAGE-LOCKED host memory (hipHostMalloc, hipHostRegister -- where an inflater that owns its buffers
+ * keeps them): they are copied to the device from where they are, batch_bytes a device buffer, and never into the pass's own pinned buffers.
+ * ALL of `len` is taken (*taken = len): what no device buffer is free for yet waits where it lies and leaves as buffers fall free -- inside the
+ * bgp_batch_next_window that moves on to the next batch, so the link never waits for the caller.  The bytes must stay as they are until the
+ * windows of their batches have been handed out or the pass is over.  While bytes of an earlier call still wait, a further call is taken only
+ * if its bytes lie right behind them (else BGP_EAGAIN: take a window first), and bgp_batch_push / _acquire answer BGP_EAGAIN: what was pushed
+ * first is piled up first.  Bytes that are not page-locked are refused (BGP_EINVAL). */
+int bgp_batch_push_pinned(bgp_ctx* ctx, const uint8_t* data, size_t len, size_t* taken);
 /* bgp_batch_push without the copy: bgp_batch_acquire hands out the free tail of the pinned buffer the next batch is copied to HBM
  * from (*cap bytes at *ptr; BGP_EAGAIN: hand out windows first), the caller -- an inflater, as decompressBgzfBlock writes into the
  * block's own buffer, block.d:127-216 -- fills it, bgp_batch_commit says how many bytes it wrote (<= *cap; 0 is fine).  Pushes and

@@ -396,3 +396,53 @@ def test_stream_ctx_destroyed_with_an_open_pass(data_dir, tmp_path):
     c.reset(); c.load_bam_device(path); c.flush()
     assert n == c.pileup_run().n_positions
     c.close()
+
+
+# ---- bgp_batch_push_pinned: bytes that already lie in page-locked host memory go to the device from where they are ----
+
+def _pinned_copy(data: bytes):
+    hip = C.CDLL("libamdhip64.so")
+    p = C.c_void_p()
+    assert hip.hipHostMalloc(C.byref(p), C.c_size_t(max(len(data), 1)), C.c_uint(0)) == 0
+    C.memmove(p.value, data, len(data))
+    return hip, p
+
+
+@pytest.mark.parametrize("name,batch", [("ex1_header.bam", 150_000), ("b7_295_chunk.bam", 40_000)])
+def test_batch_push_pinned_equals_push(ctx, data_dir, name, batch):
+    """SURVEY 8(d) (ii), "from pinned host inflated buffers": pushes from page-locked memory (no staging copy) in pieces of any size, mixed
+    with ordinary pushes -- the oracle's columns; bytes that are not page-locked are refused."""
+    _, st = bamio.read_bam(os.path.join(data_dir, name))
+    ora = O.pileup(st)
+    hip, p = _pinned_copy(st)
+    try:
+        lib, h = L.lib(), ctx._h
+        for piece in (len(st), 3 * batch + 17, 9_999):
+            L.check(lib.bgp_batch_begin(h, batch, 0, 500), h)
+            wins, off, k = [], 0, 0
+            while off < len(st):
+                n = min(piece, len(st) - off)
+                taken = C.c_size_t()
+                if k % 3 == 2:                               # now and then the ordinary way: what was pushed first is piled up first
+                    buf = (C.c_char * n).from_buffer_copy(st[off:off + n])
+                    rc = L.check(lib.bgp_batch_push(h, buf, n, C.byref(taken)), h)
+                else:
+                    rc = L.check(lib.bgp_batch_push_pinned(h, C.c_void_p(p.value + off), n, C.byref(taken)), h)
+                off += taken.value; k += 1
+                if rc == L.BGP_EAGAIN:                       # (an ordinary push behind page-locked bytes that still wait: windows first)
+                    wins += list(ctx.batch_drain(1))
+                    assert wins
+            L.check(lib.bgp_batch_end(h), h)
+            wins += list(ctx.batch_drain())
+            ref, pos, cols, _, _ = _covered(wins)
+            _assert_columns_equal_oracle(ref, pos, cols, ora)
+            ctx.reset()
+        L.check(lib.bgp_batch_begin(h, batch, 0, 500), h)
+        pageable = (C.c_char * 1000).from_buffer_copy(st[:1000])
+        taken = C.c_size_t()
+        with pytest.raises(L.BiodGpuError) as e:
+            L.check(lib.bgp_batch_push_pinned(h, pageable, 1000, C.byref(taken)), h)
+        assert e.value.code == L.BGP_EINVAL
+        ctx.reset()
+    finally:
+        hip.hipHostFree(p)
