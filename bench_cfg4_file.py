@@ -4,10 +4,10 @@ regions with the blocks inflated on ITS GPU (bgp_load_bam_region_device: bam[ref
 piles them up (makePileup(reads, false, beg, end): pileup.d:683-694) and the whole-BAM depth histogram is summed over the ranks
 (bgp_hist_reduce, RCCL over xGMI -- or, REHEARSAL on a box with fewer GPUs than ranks, by this script over gloo).  No data-path
 collective.  Prints ONE JSON line on rank 0: whole-job Mreads/s by the slowest rank's clock (barrier + synchronize on both sides).
-Run:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P scratch/cfg4_file.py --reads R [--path F]
-      (python scratch/cfg4_file.py --gpus N ... spawns the launcher itself).  The file is written (and indexed on the device) by rank 0."""
+Run:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench_cfg4_file.py --reads R [--path F]
+      (python bench_cfg4_file.py --gpus N ... spawns the launcher itself).  The file is written (and indexed on the device) by rank 0."""
 import argparse, ctypes as C, json, os, socket, subprocess, sys, time
-ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 

@@ -9,6 +9,6 @@ for N in 1 2 4 8; do
   python -c "import json; d=json.load(open('gpurun_out/cfg4/bench_n$N.json')); print('N=$N', d['value'], 'Mreads/s', d['ms_per_step'], 'ms', d.get('reduce'), 'hist', d.get('hist_reduce_equals_sum_of_ranks'), 'parity', d['parity_interior']['all_equal'])"
 done
 for N in 1 2 4 8; do
-  timeout 1800 python scratch/cfg4_file.py --gpus $N --reads ${CFG4_FILE_READS:-100000000} 2> gpurun_out/cfg4/file_n$N.err | grep "^{" | tail -1 > gpurun_out/cfg4/file_n$N.json
+  timeout 1800 python bench_cfg4_file.py --gpus $N --reads ${CFG4_FILE_READS:-100000000} 2> gpurun_out/cfg4/file_n$N.err | grep "^{" | tail -1 > gpurun_out/cfg4/file_n$N.json
   python -c "import json; d=json.load(open('gpurun_out/cfg4/file_n$N.json')); print('file N=$N', d['Mreads_per_s'], 'Mreads/s', d['best_s'], 's', 'REHEARSAL' if d['REHEARSAL'] else '', 'equals whole file', d['equals_whole_file'])"
 done

@@ -98,13 +98,13 @@ def test_eight_ranks_rehearsed_on_one_gpu():
 
 
 def test_config4_file_form_rehearsed():
-    """Config 4's FILE form (scratch/cfg4_file.py): one indexed BAM, three ranks cut by its .bai (shard.plan_file_shards), every rank's regions
+    """Config 4's FILE form (bench_cfg4_file.py): one indexed BAM, three ranks cut by its .bai (shard.plan_file_shards), every rank's regions
     loaded with the blocks inflated on the device (bgp_load_bam_region_device), piled up, the depth histogram summed over the ranks: reads,
     covered columns, summed coverage and the histogram of the WHOLE file, every read and position counted once."""
     env = dict(os.environ)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
         env.pop(k, None)
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "scratch", "cfg4_file.py"), "--gpus", "3", "--reads", "600000", "--reps", "1", "--path", "/tmp/test_cfg4_file.bam"],
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench_cfg4_file.py"), "--gpus", "3", "--reads", "600000", "--reps", "1", "--path", "/tmp/test_cfg4_file.bam"],
                        env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
     d = _one_json_line(p)
     assert d["n_gpus"] == 3 and d["equals_whole_file"] is True and d["reads_counted"] == 600_000 and d["Mreads_per_s"] > 0
