@@ -1,4 +1,4 @@
-"""The batched-staging state machine under random call sequences: pushes and acquire / commit pairs of random sizes (0-byte commits, commits
+"""The batched-staging state machine under random call sequences: pushes, pushes from page-locked memory and acquire / commit pairs of random sizes (0-byte commits, commits
 that fill a buffer exactly, buffers left almost empty), windows taken none, one or all at a time, random batch sizes -- the columns handed out
 == the columns of the stream staged at once.  usage: python scratch/fuzz_batch_api.py [rounds] [seed0]"""
 import ctypes as C, sys, time
@@ -11,6 +11,10 @@ from biod_amd.synth import host_stream
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 3000
 ctx = Context(0); lib, h = L.lib(), ctx.handle
+hip = C.CDLL("libamdhip64.so")
+PIN_CAP = 8 << 20
+pin = C.c_void_p(); assert hip.hipHostMalloc(C.byref(pin), C.c_size_t(PIN_CAP), C.c_uint(0)) == 0      # (the stream's page-locked twin)
+npin = 0
 bad = 0; ran = 0; nbat = 0; t0 = time.time()
 for k in range(n):
     rng = np.random.default_rng(seed0 + k)
@@ -37,8 +41,18 @@ for k in range(n):
     try:
         L.check(lib.bgp_batch_begin(h, batch, 0, int(rng.integers(100, 5000))), h)
         off = 0; buf = np.frombuffer(st, np.uint8)
+        use_pin = len(st) <= PIN_CAP and rng.random() < 0.6
+        if use_pin: C.memmove(pin.value, buf.ctypes.data, len(st))
         while off < len(st):
-            if rng.random() < 0.5:
+            u = rng.random()
+            if use_pin and u < 0.4:                  # from where the bytes lie: all of them are taken, or none (EAGAIN: not right behind what waits -- cannot happen here -- or a caller's buffer is out)
+                m = int(min(len(st) - off, rng.choice([1, int(rng.integers(1, 3 * batch)), len(st) - off])))
+                taken = C.c_size_t()
+                rc = L.check(lib.bgp_batch_push_pinned(h, C.c_void_p(pin.value + off), m, C.byref(taken)), h)
+                assert taken.value in (0, m), (taken.value, m)
+                off += taken.value; npin += taken.value != 0
+                if rc == L.BGP_EAGAIN: take(int(rng.integers(1, 4)))
+            elif u < 0.7:
                 m = int(min(len(st) - off, rng.integers(1, 3 * batch)))
                 taken = C.c_size_t()
                 rc = L.check(lib.bgp_batch_push(h, C.c_void_p(buf.ctypes.data + off), m, C.byref(taken)), h)
@@ -66,4 +80,4 @@ for k in range(n):
     except Exception as e:
         bad += 1; print("BATCHAPI seed", seed0 + k, "batch", batch, "len", len(st), type(e).__name__, str(e)[:200])
         ctx.reset()
-print(n, "rounds,", ran, "ran,", nbat, "batches (at least),", bad, "failures,", round(time.time() - t0, 1), "s")
+print(n, "rounds,", ran, "ran,", nbat, "batches (at least),", npin, "page-locked pushes,", bad, "failures,", round(time.time() - t0, 1), "s")
