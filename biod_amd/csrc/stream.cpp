@@ -31,7 +31,8 @@
 #include <thread>
 
 struct FileFeed {
-    static constexpr uint64_t CH = 8ull << 20, OV = 192ull << 10, STRIDE = CH + OV;
+    static constexpr uint64_t OV = 192ull << 10;
+    uint64_t CH = 8ull << 20, STRIDE = CH + OV;             // a chunk of the file, and a slot of the rings: the chunk and the overlap (BGP_STREAM_CHUNK: small chunks, so that test files of a few MB go round the ring many times)
     int fd = -1; uint64_t fsz = 0, n_chunks = 0;
     uint64_t q = 0;                                        // the first record's offset in the inflated stream (behind the BAM header)
     int device = 0; hipStream_t io_up = nullptr;
@@ -75,7 +76,7 @@ namespace {
 
 void reader(FileFeed* f, int t) {
     if (hipSetDevice(f->device) != hipSuccess) f->hip_rc.store(BGP_EDEVICE);
-    uint8_t* buf = f->h_ring.as<uint8_t>() + (size_t)t * FileFeed::STRIDE;
+    uint8_t* buf = f->h_ring.as<uint8_t>() + (size_t)t * f->STRIDE;
     int64_t last = -1;                                     // the chunk whose upload reads this buffer
     for (;;) {
         const uint64_t k = f->next.fetch_add(1);
@@ -88,7 +89,7 @@ void reader(FileFeed* f, int t) {
             if (hipEventSynchronize(f->ev_free[k % f->ND]) != hipSuccess) f->hip_rc.store(BGP_EDEVICE);
         }
         if (last >= 0 && hipEventSynchronize(f->ev_up[(uint64_t)last % f->ND]) != hipSuccess) f->hip_rc.store(BGP_EDEVICE);      // the previous piece has left this buffer
-        const uint64_t lo = k * FileFeed::CH, hi = std::min(f->fsz, lo + FileFeed::STRIDE);
+        const uint64_t lo = k * f->CH, hi = std::min(f->fsz, lo + f->STRIDE);
         uint64_t got = 0;
         while (got < hi - lo) { const ssize_t r = pread(f->fd, buf + got, hi - lo - got, (off_t)(lo + got)); if (r <= 0) break; got += (uint64_t)r; }
         {
@@ -99,14 +100,14 @@ void reader(FileFeed* f, int t) {
                 if (got < hi - lo) { f->scan_rc = BGP_ETRUNC; f->scan_err = "short read"; }
                 else if (f->scan_off < lo) { f->scan_rc = BGP_EINVAL; f->scan_err = "BGZF block larger than 64 KB"; }
                 else {
-                    try { f->scan_rc = bgzf_scan_blocks(buf - lo, hi, std::min(f->fsz, lo + FileFeed::CH), f->scan_off, f->scan_uoff, f->fresh, f->scan_err); }
+                    try { f->scan_rc = bgzf_scan_blocks(buf - lo, hi, std::min(f->fsz, lo + f->CH), f->scan_off, f->scan_uoff, f->fresh, f->scan_err); }
                     catch (...) { f->scan_rc = BGP_ENOMEM; f->scan_err = "out of host memory while reading the file"; }
                 }
             }
         }
         if (f->hip_rc.load() == BGP_OK) {
             std::lock_guard<std::mutex> ul(f->up_mu);      // (a copy and its event are enqueued together)
-            if (hipMemcpyAsync(f->d_ring.as<uint8_t>() + (k % f->ND) * FileFeed::STRIDE, buf, hi - lo, hipMemcpyHostToDevice, f->io_up) != hipSuccess
+            if (hipMemcpyAsync(f->d_ring.as<uint8_t>() + (k % f->ND) * f->STRIDE, buf, hi - lo, hipMemcpyHostToDevice, f->io_up) != hipSuccess
                 || hipEventRecord(f->ev_up[k % f->ND], f->io_up) != hipSuccess) f->hip_rc.store(BGP_EDEVICE);
             else last = (int64_t)k;
         }
@@ -151,16 +152,20 @@ int feed_pump(bgp_ctx* c, Batch* b, bool need_one) {
         // window instead of 90 with batches of 1 GiB)
         const uint64_t batch_cap = f->n_batch == 0 ? std::min<uint64_t>(b->batch_bytes, 256ull << 20) : b->batch_bytes;
         // what has been scanned since the last look; enough for a batch?
-        bool scanned_all = false; int src = BGP_OK;
+        bool scanned_all = false, ring_full = false; int src = BGP_OK;
         for (;;) {
             {
                 std::unique_lock<std::mutex> lk(f->mu);
                 if (!f->fresh.empty()) { f->todo.insert(f->todo.end(), f->fresh.begin(), f->fresh.end()); f->fresh.clear(); }
                 f->seen_turn = f->turn; src = f->scan_rc;
                 scanned_all = f->seen_turn >= f->n_chunks || src != BGP_OK;
+                // (the ring is sized for blocks that are no larger than what they inflate to.  A file of tiny or empty blocks -- 28 bytes of
+                // container for nothing -- fills it before a batch's worth of bytes has been seen: the readers then wait for a slot, and a
+                // slot is only given back behind a batch.  What has been scanned is the batch.)
                 uint64_t bytes = 0;
                 for (const BgzfBlk& x : f->todo) { if (x.uoff + x.isize > f->q) bytes += x.isize; if (bytes + 65536 > batch_cap) break; }
-                if (scanned_all || bytes + 65536 > batch_cap || f->hip_rc.load() != BGP_OK) break;
+                ring_full = !scanned_all && bytes + 65536 <= batch_cap && f->seen_turn >= f->rel_next + f->ND;
+                if (scanned_all || ring_full || bytes + 65536 > batch_cap || f->hip_rc.load() != BGP_OK) break;
                 if (!must) return BGP_OK;                  // (not yet: looked at again at the next call)
                 f->cv.wait_for(lk, std::chrono::milliseconds(2));
             }
@@ -178,19 +183,39 @@ int feed_pump(bgp_ctx* c, Batch* b, bool need_one) {
         for (const BgzfBlk& x : f->todo) { if (x.isize && x.uoff + x.isize > f->q) ++n_inf; }
         uint64_t fit = 0, fit_bytes = 0;
         for (const BgzfBlk& x : f->todo) { if (x.isize && x.uoff + x.isize > f->q) { if (fit_bytes + x.isize > batch_cap && fit) break; fit_bytes += x.isize; ++fit; } }
-        const uint64_t blk_cap = (f->slots && fit > f->slots && !(scanned_all && fit == n_inf)) ? fit / f->slots * f->slots : ~0ull;
+        const uint64_t blk_cap = (f->slots && fit > f->slots && !(scanned_all && fit == n_inf) && !ring_full) ? fit / f->slots * f->slots : ~0ull;
         for (const BgzfBlk& x : f->todo) {
             if (x.isize && x.uoff + x.isize > f->q) {
                 if ((bytes + x.isize > batch_cap && bytes) || desc.size() >= blk_cap) break;
-                const uint64_t k = x.coff / FileFeed::CH;
-                desc.push_back(bgp_inflate_block{(k % f->ND) * FileFeed::STRIDE + (x.coff - k * FileFeed::CH) + x.cdata_off, SLACK + x.uoff - u0, x.cdata_len, x.isize, x.crc, 0});
+                const uint64_t k = x.coff / f->CH;
+                desc.push_back(bgp_inflate_block{(k % f->ND) * f->STRIDE + (x.coff - k * f->CH) + x.cdata_off, SLACK + x.uoff - u0, x.cdata_len, x.isize, x.crc, 0});
                 bytes += x.uoff >= u0 ? x.isize : x.uoff + x.isize - u0;
                 c_first = std::min(c_first, k); c_last = std::max(c_last, k);
             }
             ++n_take;
         }
         const bool last_batch = scanned_all && n_take == f->todo.size();
-        if (desc.empty() && !last_batch) { for (size_t i = 0; i < n_take; ++i) f->todo.pop_front(); continue; }      // (header blocks, empty blocks: nothing to inflate)
+        // (with the default two device buffers one inflate runs at a time, on the first inflate stream: the second is the window prefetch's
+        // -- api.cpp: emit_window -- and a window's copy queued behind k_inflate there waited for the whole inflate, 9 GB/s of columns)
+        hipStream_t is = c->io_inf[b->n_dev > 2 ? (f->n_batch & 1) : 0];
+        // slots whose chunks have no block left to inflate go back to the readers: an event on the inflate stream, behind every inflate that
+        // reads them
+        auto release_slots = [&]() -> int {
+            const uint64_t upto = f->todo.empty() ? f->seen_turn : std::min<uint64_t>(f->seen_turn, f->todo.front().coff / f->CH);
+            if (upto > f->rel_next) {
+                for (uint64_t k = f->rel_next; k < upto; ++k) BGP_HIP(hipEventRecord(f->ev_free[k % f->ND], is));
+                { std::lock_guard<std::mutex> lk(f->mu); for (uint64_t k = f->rel_next; k < upto; ++k) f->released[k] = 1; }
+                f->rel_next = upto;
+                f->cv.notify_all();
+            }
+            return BGP_OK;
+        };
+        if (desc.empty() && !last_batch) {      // (header blocks, empty blocks: nothing to inflate -- but their chunks' slots are wanted back)
+            for (size_t i = 0; i < n_take; ++i) f->todo.pop_front();
+            if (f->prev_q >= 0) BGP_HIP(hipStreamWaitEvent(is, b->loaded_ev[f->prev_q], 0));
+            BGP_TRY(release_slots());
+            continue;
+        }
         if (desc.empty() && last_batch) {
             for (size_t i = 0; i < n_take; ++i) f->todo.pop_front();
             if (src != BGP_OK) { c->last_error = f->scan_err; return src; }      // (everything in front of the bad block has been handed on)
@@ -198,9 +223,6 @@ int feed_pump(bgp_ctx* c, Batch* b, bool need_one) {
             return BGP_OK;
         }
         // enqueue: descriptors, k_inflate behind the uploads of the chunks it reads, the status back, the batch's event
-        // (with the default two device buffers one inflate runs at a time, on the first inflate stream: the second is the window prefetch's
-        // -- api.cpp: emit_window -- and a window's copy queued behind k_inflate there waited for the whole inflate, 9 GB/s of columns)
-        hipStream_t is = c->io_inf[b->n_dev > 2 ? (f->n_batch & 1) : 0];
         const uint32_t nd = (uint32_t)desc.size();
         BGP_TRY(b->dev[q].reserve(b->reserve + b->batch_bytes + 256));
         BGP_TRY(f->d_desc[q].reserve((size_t)nd * (sizeof(bgp_inflate_block) + 4) + 64));
@@ -219,19 +241,11 @@ int feed_pump(bgp_ctx* c, Batch* b, bool need_one) {
         f->prev_q = q;
         b->new_off[q] = b->reserve; b->new_len[q] = bytes;
         b->state[q] = Batch::LOADED; b->queue[b->n_queue++] = q;
-        if (f->verbose) fprintf(stderr, "[biodgpu]   %8.2f ms: batch %d -> buffer %d on inflate stream %d: %u blocks, %.1f MB, chunks %llu..%llu (scanned %llu of %llu), %d queued\n", f->ms_now(), f->n_batch, q, is == c->io_inf[0] ? 0 : 1, nd, bytes / 1e6,
-                                (unsigned long long)c_first, (unsigned long long)c_last, (unsigned long long)f->seen_turn, (unsigned long long)f->n_chunks, b->n_queue);
+        if (f->verbose) fprintf(stderr, "[biodgpu]   %8.2f ms: batch %d -> buffer %d on inflate stream %d: %u blocks, %.1f MB, chunks %llu..%llu (scanned %llu of %llu), %d queued%s\n", f->ms_now(), f->n_batch, q, is == c->io_inf[0] ? 0 : 1, nd, bytes / 1e6,
+                                (unsigned long long)c_first, (unsigned long long)c_last, (unsigned long long)f->seen_turn, (unsigned long long)f->n_chunks, b->n_queue, ring_full ? " -- cut because the ring was full" : "");
         f->u_next = u0 + bytes; ++f->n_batch;
         for (size_t i = 0; i < n_take; ++i) f->todo.pop_front();
-        {   // slots whose chunks have no block left to inflate go back to the readers
-            const uint64_t upto = f->todo.empty() ? f->seen_turn : std::min<uint64_t>(f->seen_turn, f->todo.front().coff / FileFeed::CH);
-            if (upto > f->rel_next) {
-                for (uint64_t k = f->rel_next; k < upto; ++k) BGP_HIP(hipEventRecord(f->ev_free[k % f->ND], is));
-                { std::lock_guard<std::mutex> lk(f->mu); for (uint64_t k = f->rel_next; k < upto; ++k) f->released[k] = 1; }
-                f->rel_next = upto;
-                f->cv.notify_all();
-            }
-        }
+        BGP_TRY(release_slots());
         if (last_batch) {
             if (src != BGP_OK) return BGP_OK;              // (the scan's error is reported when the consumer asks for what lies behind this batch: the next call finds nothing left to inflate)
             f->all_dispatched = true; b->ended = true;
@@ -245,10 +259,10 @@ int bgp_stream_bam_begin(bgp_ctx* c, const char* path, uint64_t batch_bytes, int
     BGP_API_TRY
     if (!c || !path) return BGP_EINVAL;
     BGP_HIP(hipSetDevice(c->device));
-    const int fd = open(path, O_RDONLY);
-    if (fd < 0) { c->last_error = std::string("cannot open ") + path; return BGP_EINVAL; }
     std::unique_ptr<FileFeed> f(new FileFeed());
-    f->fd = fd;
+    f->fd = open(path, O_RDONLY);
+    if (f->fd < 0) { c->last_error = std::string("cannot open ") + path; return BGP_EINVAL; }
+    const int fd = f->fd;
     struct stat sb;
     if (fstat(fd, &sb) != 0) { c->last_error = "fstat failed"; return BGP_EINVAL; }
     f->fsz = (uint64_t)sb.st_size;
@@ -262,15 +276,16 @@ int bgp_stream_bam_begin(bgp_ctx* c, const char* path, uint64_t batch_bytes, int
     f->q = q; f->device = c->device; f->io_up = c->io_up;
     { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, c->device) == hipSuccess) f->slots = (uint64_t)prop.multiProcessorCount * 32; else (void)hipGetLastError(); }
     if (const char* e = getenv("BGP_STREAM_ROUND")) f->slots = (uint64_t)atoll(e);      // (0: batches are cut by bytes alone)
-    f->n_chunks = (f->fsz + FileFeed::CH - 1) / FileFeed::CH;
+    if (const char* e = getenv("BGP_STREAM_CHUNK")) { f->CH = std::max<uint64_t>(65536, (uint64_t)atoll(e)); f->STRIDE = f->CH + FileFeed::OV; }
+    f->n_chunks = (f->fsz + f->CH - 1) / f->CH;
     const uint64_t t_max = getenv("BGP_READ_THREADS") ? (uint64_t)atoi(getenv("BGP_READ_THREADS")) : 8ull;
     f->T = (int)std::max<uint64_t>(1, std::min<uint64_t>({t_max, (uint64_t)bgp_default_threads(), f->n_chunks}));
     // the ring holds the blocks of the batches that can be inflating at a time (every device buffer but the current batch's) whatever they compress to (a BGZF block is never much larger than what it inflates to: 26 bytes of
     // header and footer, 5 of a stored deflate block), a chunk cut at either end of it, and one chunk a reader ahead
-    f->ND = std::min<uint64_t>(f->n_chunks, ((uint64_t)(b->n_dev - 1) * (b->batch_bytes + b->batch_bytes / 512) + FileFeed::CH - 1) / FileFeed::CH + 3 + (uint64_t)f->T);
+    f->ND = std::min<uint64_t>(f->n_chunks, ((uint64_t)(b->n_dev - 1) * (b->batch_bytes + b->batch_bytes / 512) + f->CH - 1) / f->CH + 3 + (uint64_t)f->T);
     f->ND = std::max<uint64_t>(f->ND, 1);
-    int rc = f->d_ring.reserve((size_t)(f->ND * FileFeed::STRIDE + 256));
-    if (rc == BGP_OK) rc = f->h_ring.reserve((size_t)f->T * FileFeed::STRIDE);
+    int rc = f->d_ring.reserve((size_t)(f->ND * f->STRIDE + 256));
+    if (rc == BGP_OK) rc = f->h_ring.reserve((size_t)f->T * f->STRIDE);
     if (rc != BGP_OK) { batch_release(c); return rc; }
     f->ev_up.assign(f->ND, nullptr); f->ev_free.assign(f->ND, nullptr);
     for (uint64_t k = 0; k < f->ND; ++k)

@@ -18,6 +18,7 @@ bad = ran = 0; t0 = time.time()
 path = "/tmp/fuzz_stream.bam"
 for k in range(n):
     rng = np.random.default_rng(seed0 + k)
+    with open("/tmp/fuzz_stream.seed", "w") as sf: sf.write(str(seed0 + k))      # (a round that never returns is found by its seed)
     cfg = T.make_cfg(n_reads=int(rng.integers(300, 30000)), n_ref=int(rng.integers(1, 4)), ref_len=int(rng.integers(20_000, 200_000)), read_len=int(rng.integers(50, 151)), profile=int(rng.integers(0, 2)), seed=int(rng.integers(1, 1 << 30)))
     try:
         st = host_stream(cfg)
@@ -38,12 +39,19 @@ for k in range(n):
             chunk = payload[at:at + m]; at += m
             if rng.random() < 0.03:
                 f.write(bamio.BGZF_EOF)                    # (an empty block in the middle of the file: skipped, inputstream.d:447-450)
+            if mode == 2 and rng.random() < 0.02:
+                f.write(bamio.BGZF_EOF * int(rng.integers(1000, 40000)))      # (a stretch of container that holds nothing: with small chunks it fills the ring of compressed chunks before a batch's worth of bytes has been scanned)
             level = int(rng.choice([0, 1, 6, 9]))
             co = zlib.compressobj(level, zlib.DEFLATED, -15)
             cdata = co.compress(chunk) + co.flush()
             f.write(bytes([31, 139, 8, 4, 0, 0, 0, 0, 0, 255, 6, 0, 66, 67, 2, 0]) + (len(cdata) + 25).to_bytes(2, "little") + cdata + (zlib.crc32(chunk) & 0xFFFFFFFF).to_bytes(4, "little") + len(chunk).to_bytes(4, "little"))
         if rng.random() < 0.8:
             f.write(bamio.BGZF_EOF)
+    # the ring of compressed chunks at test size: chunks of 64 KiB .. 1 MiB and one to eight readers, so that a file of a few MB goes round it many times
+    # (slots reused, batches cut because the ring is full); now and then the library's own 8 MiB
+    if rng.random() < 0.8: os.environ["BGP_STREAM_CHUNK"] = str(int(rng.choice([65536, 100_000, 262144, 1 << 20])))
+    else: os.environ.pop("BGP_STREAM_CHUNK", None)
+    os.environ["BGP_READ_THREADS"] = str(int(rng.choice([1, 2, 3, 8])))
     use_md = bool(rng.random() < 0.4); entries = bool(rng.random() < 0.3); compact = bool(rng.random() < 0.5)
     batch = int(rng.choice([128 << 10, int(rng.integers(128 << 10, 1 << 20)), int(rng.integers(1 << 20, 8 << 20)), 0]))
     window = int(rng.choice([0, int(rng.integers(100, 5000)), 65536]))

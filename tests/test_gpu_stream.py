@@ -446,3 +446,42 @@ def test_batch_push_pinned_equals_push(ctx, data_dir, name, batch):
         ctx.reset()
     finally:
         hip.hipHostFree(p)
+
+
+@pytest.mark.timeout(300, method="thread")           # (a regression here is a wait inside the library: only the thread method ends it)
+def test_stream_file_of_tiny_and_empty_blocks_longer_than_the_ring(ctx, tmp_path, monkeypatch):
+    """The ring of compressed chunks is sized for blocks no larger than what they inflate to.  A file that is mostly container -- runs of
+    empty BGZF blocks (28 bytes for nothing: what `cat a.bam b.bam` leaves in the middle, a million times over) and blocks of a few
+    records -- fills it long before a batch's worth of bytes has been scanned; the readers then wait for slots only a batch gives back.
+    The pass must cut its batch at what the ring holds (and give back the slots of chunks that held nothing to inflate): columns == the
+    oracle's, in time."""
+    cfg = make_cfg(n_reads=3000, n_ref=2, ref_len=40_000, read_len=100, profile=0, seed=77)
+    st = host_stream(cfg)
+    offs, o = [], 0
+    while o < len(st):
+        offs.append(o); o += 4 + int.from_bytes(st[o:o + 4], "little")
+    offs.append(len(st))
+    path = str(tmp_path / "tiny_blocks.bam")
+    empties = bamio.BGZF_EOF * 800_000                          # 22 MB of blocks that hold nothing
+    with open(path, "wb") as f:
+        f.write(bamio.bgzf_block(bamio.bam_header_bytes([("chr1", 40_000), ("chr2", 40_000)])))
+        n = len(offs) - 1
+        for part, (a, b) in enumerate(((0, n // 3), (n // 3, 2 * n // 3), (2 * n // 3, n))):
+            for i in range(a, b, 3):                            # three records a block, cut mid-record now and then
+                lo, hi = offs[i], offs[min(i + 3, b)]
+                cut = lo + (hi - lo) // 2 if i % 5 == 0 else hi
+                f.write(bamio.bgzf_block(st[lo:cut]))
+                if cut < hi: f.write(bamio.bgzf_block(st[cut:hi]))
+            if part < 2: f.write(empties)
+        f.write(bamio.BGZF_EOF)
+    assert os.path.getsize(path) > 5 * (8 << 20)                # longer than the ring of the smallest pass (five chunks with one reader)
+    monkeypatch.setenv("BGP_READ_THREADS", "1")
+    ora = O.pileup(st)
+    for batch in (128 << 10, 1 << 20):
+        ref, pos, cols, _, _ = _covered(ctx.stream_bam_windows(path, batch))
+        _assert_columns_equal_oracle(ref, pos, cols, ora)
+        ctx.reset()
+    monkeypatch.delenv("BGP_READ_THREADS")
+    ref, pos, cols, _, _ = _covered(ctx.stream_bam_windows(path, 256 << 10))
+    _assert_columns_equal_oracle(ref, pos, cols, ora)
+    ctx.reset()
