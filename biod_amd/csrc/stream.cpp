@@ -92,6 +92,9 @@ void reader(FileFeed* f, int t) {
         const uint64_t lo = k * f->CH, hi = std::min(f->fsz, lo + f->STRIDE);
         uint64_t got = 0;
         while (got < hi - lo) { const ssize_t r = pread(f->fd, buf + got, hi - lo - got, (off_t)(lo + got)); if (r <= 0) break; got += (uint64_t)r; }
+        // (the chunk's blocks are made known to the consumer below, together with the turn -- behind the upload's event: a batch cut between
+        // the scan and the upload would have its k_inflate wait for an event not yet recorded, i.e. not at all, and read the slot's old bytes)
+        std::vector<BgzfBlk> mine;
         {
             std::unique_lock<std::mutex> lk(f->mu);
             f->cv.wait(lk, [&] { return f->stop || f->turn == k; });
@@ -100,7 +103,7 @@ void reader(FileFeed* f, int t) {
                 if (got < hi - lo) { f->scan_rc = BGP_ETRUNC; f->scan_err = "short read"; }
                 else if (f->scan_off < lo) { f->scan_rc = BGP_EINVAL; f->scan_err = "BGZF block larger than 64 KB"; }
                 else {
-                    try { f->scan_rc = bgzf_scan_blocks(buf - lo, hi, std::min(f->fsz, lo + f->CH), f->scan_off, f->scan_uoff, f->fresh, f->scan_err); }
+                    try { f->scan_rc = bgzf_scan_blocks(buf - lo, hi, std::min(f->fsz, lo + f->CH), f->scan_off, f->scan_uoff, mine, f->scan_err); }
                     catch (...) { f->scan_rc = BGP_ENOMEM; f->scan_err = "out of host memory while reading the file"; }
                 }
             }
@@ -113,6 +116,8 @@ void reader(FileFeed* f, int t) {
         }
         {   // (the turn moves on only now: a chunk the consumer sees as scanned has its upload's event recorded)
             std::lock_guard<std::mutex> lk(f->mu);
+            try { f->fresh.insert(f->fresh.end(), mine.begin(), mine.end()); }
+            catch (...) { if (f->scan_rc == BGP_OK) { f->scan_rc = BGP_ENOMEM; f->scan_err = "out of host memory while reading the file"; } }
             f->uploaded[k] = 1; f->turn = k + 1;
         }
         f->cv.notify_all();
