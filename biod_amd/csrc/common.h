@@ -203,6 +203,7 @@ struct bgp_ctx {
     DevBuf d_maq, d_maq_tab; bool maq_tables_ready = false; float maq_tab_depcorr = 0, maq_tab_eta = 0;   // MAQ model (maq.hip): calls of a window; fk | lhet | beta
     DevBuf d_entry_off, d_entries, d_col_lo;
     DevBuf d_md_row, d_md_iv, d_md_state, d_refbase;   // MD path: per-record rows, provider intervals, per-run controller state, dense reference bases
+    DevBuf d_md_plong;                                                        // k6_prep: the records whose CIGAR a wave sums (count, then indices)
     DevBuf d_md_long, d_md_ck, d_md_vlist;                                    // long chunks of the provider chain: node list + counters, checkpoints
     DevBuf d_md_succ, d_md_exit, d_md_entry, d_md_bmax;           // parallel provider chain: successor function, per-segment exits, segment entries
     bool md_rows_ready = false, md_rows_full = false;   // K6's rows exist | ... with dna lengths from the MD tags themselves (else: what the CIGARs imply, providers checked later)

@@ -430,7 +430,10 @@ __device__ __forceinline__ uint32_t dna_length_by_cigar(const uint8_t* s, const 
     return n > (uint64_t)MD_LMASK ? MD_LMASK : (uint32_t)n;
 }
 
-template <bool FULL> __global__ __launch_bounds__(256) void k6_prep(const uint8_t* s, const bgp_record* rec, const uint4* cig4, const uint8_t* rcls, const uint64_t* pmax_end, const uint64_t* pmax_pos, uint64_t n, MdRow* rows, uint32_t* bmax) {
+// (a CIGAR of more than PREP_LONG_OPS ops is not summed by its record's lane -- a 30 kb read's 8 000 ops were a thousand dependent steps of 64 scattered loads a
+// wave, 1.7 ms of cfg5's use_md_tag leg for 200 000 records: the record goes on a list and k6_prep_long gives a WAVE to it)
+constexpr uint32_t PREP_LONG_OPS = 64;
+template <bool FULL> __global__ __launch_bounds__(256) void k6_prep(const uint8_t* s, const bgp_record* rec, const uint4* cig4, const uint8_t* rcls, const uint64_t* pmax_end, const uint64_t* pmax_pos, uint64_t n, MdRow* rows, uint32_t* bmax, uint32_t* long_list, uint32_t long_cap) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     bgp_record r{};
     if (i < n) r = rec[i];
@@ -442,7 +445,14 @@ template <bool FULL> __global__ __launch_bounds__(256) void k6_prep(const uint8_
         uint32_t L;
         if (FULL) L = dna_length(s, r, &bad, &err, cig4 ? cig4 + i : nullptr, cig4 && i + 1 < n ? (uint64_t)rec[i + 1].rec_off : 0);   // (cig4: the table is K1's own, record i ends where i + 1 begins -- its header line is not touched at all)
         else if (rcls && (rcls[i] & BGP_CLS_NO_SKIP)) L = (uint32_t)r.end_pos - (uint32_t)r.pos;      // (k12_lds saw the whole CIGAR and no N in it: M / = / X and D bases are all the read covers)
-        else L = dna_length_by_cigar(s, r, cig4 ? cig4 + i : nullptr);
+        else {
+            bool listed = false;
+            if (long_list && (r.flag_nc & 0xFFFFu) > PREP_LONG_OPS) {      // (its length: k6_prep_long -- while the list has room; a lane's own walk behind that)
+                const uint32_t slot = atomicAdd(long_list, 1u);
+                if (slot < long_cap) { long_list[1 + slot] = (uint32_t)i; listed = true; }
+            }
+            L = listed ? 0u : dna_length_by_cigar(s, r, cig4 ? cig4 + i : nullptr);
+        }
         if (L > MD_LMASK) L = MD_LMASK;
         // first record of this read's position group: the prefix maximum of the position key reaches the
         // read's own key exactly there (records are sorted; K3 has already rejected unsorted input).
@@ -469,6 +479,28 @@ template <bool FULL> __global__ __launch_bounds__(256) void k6_prep(const uint8_
         if ((threadIdx.x & 63) == 0 && i < n) bmax[i >> 6] = m;
     }
     if (i < n) rows[i] = o;
+}
+
+// dna_length_by_cigar of the listed records, a wave each: 64 ops a step, coalesced (the same sum: M / = / X and D lengths; the row's other bits stay)
+__global__ __launch_bounds__(64) void k6_prep_long(const uint8_t* s, const bgp_record* rec, const uint32_t* long_list, uint32_t long_cap, MdRow* rows) {
+    const uint32_t cnt = min(long_list[0], long_cap);
+    const int lane = threadIdx.x;
+    for (uint32_t e = blockIdx.x; e < cnt; e += gridDim.x) {
+        const uint32_t i = long_list[1 + e];
+        const bgp_record r = rec[i];
+        const uint32_t l_name = r.bin_mq_nl & 0xFFu, n_cig = r.flag_nc & 0xFFFFu;
+        const uint8_t* cg = s + r.rec_off + 36 + l_name;
+        unsigned long long sum = 0;
+        auto take = [&](uint32_t raw) { const uint32_t op = raw & 15u; if ((cig_qc(raw) && cig_rc(raw)) || op == 2u) sum += raw >> 4; };
+        uint32_t k = (uint32_t)lane;
+        for (; k + 192 < n_cig; k += 256) {      // (four loads in flight a lane: the sum does not wait for one round trip an iteration)
+            const uint32_t r0 = ld_u32(cg + 4ull * k), r1 = ld_u32(cg + 4ull * (k + 64)), r2 = ld_u32(cg + 4ull * (k + 128)), r3 = ld_u32(cg + 4ull * (k + 192));
+            take(r0); take(r1); take(r2); take(r3);
+        }
+        for (; k < n_cig; k += 64) take(ld_u32(cg + 4ull * k));
+        for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d, 64);
+        if (lane == 0) { const uint32_t L = sum > (unsigned long long)MD_LMASK ? MD_LMASK : (uint32_t)sum; rows[i].lf = (rows[i].lf & ~MD_LMASK) | L; }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------- k6_chain
@@ -1308,8 +1340,13 @@ __device__ int find_md_wave(const uint8_t* s, const bgp_record& r, int lane, con
 // stage, a number of more than nine digits, an empty deletion, more bases asked than there are, a last operation the reference's backward
 // parse (parse.d:111-131) would cut differently from the forward one -- FLAGS the run, and the event loop, which parses every tag the
 // reference's way, redoes it.
+#ifndef BGP_VERIFY_LDS
+#define BGP_VERIFY_LDS 0      // 1: the tag staged in LDS first (round 4's kernel: 32 KB a wave, five waves a CU -- the kernel waited for its own loads at that occupancy)
+#endif
 __global__ __launch_bounds__(64) void k6_verify_long(const uint8_t* s, uint64_t stream_len, const bgp_record* rec, const VEntry* vl, const unsigned int* ctr, uint32_t vcap, ParOut* po) {
-    __shared__ uint8_t smd[VMD_CAP + 16];
+#if BGP_VERIFY_LDS
+    __shared__ uint8_t smd_lds[VMD_CAP + 16];
+#endif
     const uint32_t cnt = min(ctr[2], vcap);
     if (blockIdx.x >= cnt) return;
     const int lane = threadIdx.x;
@@ -1321,7 +1358,13 @@ __global__ __launch_bounds__(64) void k6_verify_long(const uint8_t* s, uint64_t 
     unsigned long long q = 0, dl = 0;
     {
         const uint8_t* cg = s + r.rec_off + 36 + l_name;
-        for (uint32_t k = (uint32_t)lane; k < n_cig; k += 64) { const uint32_t raw = ld_u32(cg + 4ull * k); if (cig_qc(raw) && cig_rc(raw)) q += raw >> 4; else if ((raw & 15u) == 2u) dl += raw >> 4; }
+        auto take = [&](uint32_t raw) { if (cig_qc(raw) && cig_rc(raw)) q += raw >> 4; else if ((raw & 15u) == 2u) dl += raw >> 4; };
+        uint32_t k = (uint32_t)lane;
+        for (; k + 192 < n_cig; k += 256) {      // (four loads in flight a lane)
+            const uint32_t r0 = ld_u32(cg + 4ull * k), r1 = ld_u32(cg + 4ull * (k + 64)), r2 = ld_u32(cg + 4ull * (k + 128)), r3 = ld_u32(cg + 4ull * (k + 192));
+            take(r0); take(r1); take(r2); take(r3);
+        }
+        for (; k < n_cig; k += 64) take(ld_u32(cg + 4ull * k));
         q = wsum(q); dl = wsum(dl);
     }
     const unsigned long long by_cigar = q + dl > (unsigned long long)MD_LMASK ? (unsigned long long)MD_LMASK : q + dl;
@@ -1334,12 +1377,19 @@ __global__ __launch_bounds__(64) void k6_verify_long(const uint8_t* s, uint64_t 
         if (mdn > VMD_CAP) flag = true;
         else {
             const uint32_t n = (uint32_t)mdn;
+#if BGP_VERIFY_LDS
+            uint8_t* smd = smd_lds;
             const uint64_t md_off = (uint64_t)(md - s);
             for (uint32_t o = 16u * (uint32_t)lane; o < n; o += 1024u) {
                 if (md_off + o + 16 <= stream_len) { uint4 w; __builtin_memcpy(&w, md + o, 16); *reinterpret_cast<uint4*>(smd + o) = w; }
                 else for (uint32_t k = 0; k < 16u && o + k < n; ++k) smd[o + k] = md[o + k];
             }
             __syncthreads();
+#else
+            // (the tag where it lies: every char is looked at by its own lane and by a neighbour or two -- consecutive lanes, consecutive bytes, the
+            // lines stay in the CU's cache -- and without 32 KB of LDS a wave the CU holds its full set of waves instead of five)
+            const uint8_t* smd = md; (void)stream_len;
+#endif
             unsigned long long num = 0, mm = 0, del = 0;
             for (uint32_t i = (uint32_t)lane; i < n; i += 64) {
                 const uint8_t c = smd[i];
@@ -1489,7 +1539,9 @@ __device__ __forceinline__ int32_t wave_incl_max_i32(int32_t v, int lane) { for 
 constexpr uint32_t CKP_MAX = 256, CK_NONE = 0xFFFFFFFFu;
 __device__ unsigned int g_ck_serial;             // long chunks that took the serial walk (read and reset by the host under BGP_VERBOSE: the tests look at it)
 __global__ __launch_bounds__(64) void k6_ck_build(const uint8_t* s, uint64_t stream_len, const bgp_record* rec, const LongNode* longs, uint32_t n_long, DnaCk* ck, uint32_t* piece_node, int serial_only) {
-    __shared__ __attribute__((aligned(16))) uint8_t smd[VMD_CAP + 32];
+#if BGP_VERIFY_LDS
+    __shared__ __attribute__((aligned(16))) uint8_t smd_lds[VMD_CAP + 32];
+#endif
     __shared__ uint32_t s_tok[CKP_MAX], s_y[CKP_MAX], s_d[CKP_MAX], s_op[CKP_MAX], s_in[CKP_MAX], s_q[CKP_MAX];
     const uint32_t i = blockIdx.x;
     const int lane = threadIdx.x;
@@ -1507,6 +1559,8 @@ __global__ __launch_bounds__(64) void k6_ck_build(const uint8_t* s, uint64_t str
     const uint8_t* cg = s + r.rec_off + 36 + l_name;
     uint64_t m_total = 0, q_total = 0;
     if (!flag) {
+#if BGP_VERIFY_LDS
+        uint8_t* smd = smd_lds;
         const uint64_t md_off = (uint64_t)(md - s);
         for (uint32_t o = 16u * (uint32_t)lane; o < n + 16u; o += 1024u) {
             uint4 w = make_uint4(0u, 0u, 0u, 0u);
@@ -1516,6 +1570,9 @@ __global__ __launch_bounds__(64) void k6_ck_build(const uint8_t* s, uint64_t str
             }
             *reinterpret_cast<uint4*>(smd + o) = w;
         }
+#else
+        const uint8_t* smd = md; (void)stream_len;     // (the tag where it lies, as in k6_verify_long: 6 KB of LDS a wave instead of 38)
+#endif
         for (uint32_t j = (uint32_t)lane; j < CKP_MAX; j += 64) { s_tok[j] = CK_NONE; s_y[j] = 0u; s_d[j] = CK_NONE; s_op[j] = CK_NONE; s_in[j] = 0u; s_q[j] = 0u; }
         __syncthreads();
         // ---- the tag's units and the token that holds each checkpoint index
@@ -1529,7 +1586,7 @@ __global__ __launch_bounds__(64) void k6_ck_build(const uint8_t* s, uint64_t str
             const bool in_del = up && nu >= 0 && smd[nu] == '^';
             uint32_t y = 0, d = 0;
             if (in) {
-                if (c == '^') { if (!is_upper_(smd[c_i + 1]) || c_i + 1 >= n) flag = true; }       // an empty deletion: the range stalls
+                if (c == '^') { if (c_i + 1 >= n || !is_upper_(smd[c_i + 1])) flag = true; }       // an empty deletion: the range stalls
                 else if (is_digit_(c)) {
                     if (c_i == 0 || !is_digit_(smd[c_i - 1])) {
                         uint32_t val = 0, k = 0;
@@ -1686,14 +1743,21 @@ static int k6_rows(bgp_ctx* c, bool full) {
     const uint64_t n = c->n_records;
     BGP_TRY(c->d_md_row.reserve((n + 1) * sizeof(MdRow)));
     BGP_TRY(c->d_md_bmax.reserve((n / 64 + 2) * 4));
+    // (records with long CIGARs are listed for k6_prep_long -- only where framing has seen a read beyond the short-read shape at all, and
+    // while a 32-bit index names every record; a stream of short reads takes neither the list nor the second launch)
+    const bool list_long = !full && c->odd_reads && n < 0xFFFFFFFFull;
+    uint32_t* long_list = nullptr;
+    const uint32_t long_cap = (uint32_t)std::min<uint64_t>(n, 1ull << 22);
+    if (list_long) { BGP_TRY(c->d_md_plong.reserve(((size_t)long_cap + 2) * 4)); long_list = c->d_md_plong.as<uint32_t>(); BGP_HIP(hipMemsetAsync(long_list, 0, 4, c->stream)); }
     if (n) {
         TimedRegion t(c, "k6_prep", n * (32 + sizeof(MdRow)));
         if (full) BGP_TRY(ensure_cig4(c));      // (rows from the tags themselves walk every read's ops)
         const uint8_t* rcls = c->rows_ok ? c->d_rcls.as<uint8_t>() : nullptr;
         if (full) hipLaunchKernelGGL(k6_prep<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->d_stream, c->d_rec.as<bgp_record>(), c->cig4_ok ? c->d_cig4.as<uint4>() : nullptr, rcls,
-                           c->d_pmax_end.as<uint64_t>(), c->d_pmax_pos.as<uint64_t>(), n, c->d_md_row.as<MdRow>(), c->d_md_bmax.as<uint32_t>());
+                           c->d_pmax_end.as<uint64_t>(), c->d_pmax_pos.as<uint64_t>(), n, c->d_md_row.as<MdRow>(), c->d_md_bmax.as<uint32_t>(), (uint32_t*)nullptr, 0u);
         else hipLaunchKernelGGL(k6_prep<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->d_stream, c->d_rec.as<bgp_record>(), c->cig4_ok ? c->d_cig4.as<uint4>() : nullptr, rcls,
-                           c->d_pmax_end.as<uint64_t>(), c->d_pmax_pos.as<uint64_t>(), n, c->d_md_row.as<MdRow>(), c->d_md_bmax.as<uint32_t>());
+                           c->d_pmax_end.as<uint64_t>(), c->d_pmax_pos.as<uint64_t>(), n, c->d_md_row.as<MdRow>(), c->d_md_bmax.as<uint32_t>(), long_list, long_cap);
+        if (list_long) hipLaunchKernelGGL(k6_prep_long, dim3(8192), dim3(64), 0, c->stream, c->d_stream, c->d_rec.as<bgp_record>(), long_list, long_cap, c->d_md_row.as<MdRow>());
         BGP_HIP(hipGetLastError());
     }
     c->md_rows_ready = true; c->md_rows_full = full;
@@ -1863,12 +1927,13 @@ int k6_reference_bases(bgp_ctx* c, int skip_zero, uint32_t run_first, uint32_t r
                 DnaCk* ck = c->d_md_ck.as<DnaCk>(); uint32_t* piece_node = (uint32_t*)(ck + ctr[1]);
                 BGP_HIP(hipMemsetAsync(ck, 0, (size_t)ctr[1] * sizeof(DnaCk), c->stream));
                 const LongNode* longs = (const LongNode*)(c->d_md_long.as<uint8_t>() + 16);
-                TimedRegion t(c, "k6_emit_long", (uint64_t)ctr[1] * DNA_CK);
                 const bool ck_verbose = getenv("BGP_VERBOSE") != nullptr;
                 if (ck_verbose) { unsigned int zero = 0; BGP_HIP(hipStreamSynchronize(c->stream)); BGP_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_ck_serial), &zero, sizeof zero)); }      // (the count is this launch's)
                 static const int ck_serial = getenv("BGP_MD_CK_SERIAL") && atoi(getenv("BGP_MD_CK_SERIAL")) != 0;      // (tests: the walk a lane did before the wave's prefix sums)
-                hipLaunchKernelGGL(k6_ck_build, dim3(ctr[0]), dim3(64), 0, c->stream, c->d_stream, c->stream_len, c->d_rec.as<bgp_record>(), longs, ctr[0], ck, piece_node, ck_serial);
-                hipLaunchKernelGGL(k6_emit_long, dim3((ctr[1] + 63) / 64), dim3(64), 0, c->stream, c->d_stream, c->d_rec.as<bgp_record>(), longs, ck, piece_node, ctr[1], c->d_refbase.as<uint8_t>());
+                { TimedRegion t(c, "k6_ck_build", 0);
+                  hipLaunchKernelGGL(k6_ck_build, dim3(ctr[0]), dim3(64), 0, c->stream, c->d_stream, c->stream_len, c->d_rec.as<bgp_record>(), longs, ctr[0], ck, piece_node, ck_serial); }
+                { TimedRegion t(c, "k6_emit_long", (uint64_t)ctr[1] * DNA_CK);
+                  hipLaunchKernelGGL(k6_emit_long, dim3((ctr[1] + 63) / 64), dim3(64), 0, c->stream, c->d_stream, c->d_rec.as<bgp_record>(), longs, ck, piece_node, ctr[1], c->d_refbase.as<uint8_t>()); }
                 BGP_HIP(hipGetLastError());
                 if (ck_verbose) {
                     unsigned int ser = 0;
