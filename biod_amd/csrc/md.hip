@@ -1388,28 +1388,51 @@ __global__ __launch_bounds__(64) void k6_verify_long(const uint8_t* s, uint64_t 
 #else
             // (the tag where it lies: every char is looked at by its own lane and by a neighbour or two -- consecutive lanes, consecutive bytes, the
             // lines stay in the CU's cache -- and without 32 KB of LDS a wave the CU holds its full set of waves instead of five)
-            const uint8_t* smd = md; (void)stream_len;
+            const uint8_t* smd = md;
 #endif
             unsigned long long num = 0, mm = 0, del = 0;
-            for (uint32_t i = (uint32_t)lane; i < n; i += 64) {
-                const uint8_t c = smd[i];
+#if !BGP_VERIFY_LDS
+            // A lane's looks around its char -- the digits of a number, the bases of a deletion, the way back to a '^' -- are loads that wait for
+            // each other: from memory, ~30 round trips a step of the wave, 1.3 ms for a 10 000-char tag.  The 32 chars around the lane's own are
+            // fetched with two independent 16-byte loads into a row of LDS of the lane's own and looked at there; what reaches further (a run of
+            // sixteen letters, a number at the window's edge) is read where it lies, as before.
+            __shared__ __attribute__((aligned(16))) uint8_t wrow[64][32];
+            const uint64_t md_off = (uint64_t)(md - s);
+#endif
+#ifndef BGP_VERIFY_ABL
+#define BGP_VERIFY_ABL 0      // timing switches (wrong verdicts): 1 without the scan of the tag
+#endif
+            for (uint32_t i = (uint32_t)lane; i < (BGP_VERIFY_ABL == 1 ? 0u : n); i += 64) {
+#if !BGP_VERIFY_LDS
+                {   // chars [i - 16, i + 16): md lies at least 36 bytes into its record, so the bytes in front of the tag exist (and are never asked for)
+                    uint4 lo, hi = make_uint4(0u, 0u, 0u, 0u);
+                    __builtin_memcpy(&lo, md + i - 16, 16);
+                    if (md_off + i + 16 <= stream_len) __builtin_memcpy(&hi, md + i, 16);
+                    else { uint8_t b[16]; for (uint32_t k = 0; k < 16u; ++k) b[k] = md_off + i + k < stream_len ? md[i + k] : (uint8_t)0; __builtin_memcpy(&hi, b, 16); }
+                    *reinterpret_cast<uint4*>(&wrow[lane][0]) = lo; *reinterpret_cast<uint4*>(&wrow[lane][16]) = hi;
+                }
+                auto ch = [&](uint32_t x) -> uint8_t { const uint32_t rel = x + 16u - i; return rel < 32u ? wrow[lane][rel] : md[x]; };
+#else
+                auto ch = [&](uint32_t x) -> uint8_t { return smd[x]; };
+#endif
+                const uint8_t c = ch(i);
                 if (c == '^') {
                     uint32_t len = 0;
-                    while (i + 1 + len < n && is_upper_(smd[i + 1 + len])) ++len;
+                    while (i + 1 + len < n && is_upper_(ch(i + 1 + len))) ++len;
                     if (len == 0) flag = true;                                 // an empty deletion: the range stalls
                     del += len;
                 } else if (is_digit_(c)) {
-                    if (i == 0 || !is_digit_(smd[i - 1])) {
+                    if (i == 0 || !is_digit_(ch(i - 1))) {
                         unsigned long long val = 0; uint32_t k = 0;
-                        while (i + k < n && is_digit_(smd[i + k])) { val = val * 10 + (unsigned long long)(smd[i + k] - '0'); if (++k > 9) { flag = true; break; } }
+                        while (i + k < n && is_digit_(ch(i + k))) { val = val * 10 + (unsigned long long)(ch(i + k) - '0'); if (++k > 9) { flag = true; break; } }
                         num += val;
                     }
                 } else {
                     bool in_del = false;
                     if (is_upper_(c)) {
                         uint32_t j = i, steps = 0;
-                        while (j > 0 && is_upper_(smd[j - 1])) { --j; if (++steps > 4096u) { flag = true; break; } }
-                        in_del = j > 0 && smd[j - 1] == '^';
+                        while (j > 0 && is_upper_(ch(j - 1))) { --j; if (++steps > 4096u) { flag = true; break; } }
+                        in_del = j > 0 && ch(j - 1) == '^';
                     }
                     if (!in_del) ++mm;
                 }
