@@ -1278,6 +1278,10 @@ struct LongNode { uint32_t rec, from, count, ck_base; uint64_t out_off; };
 struct VEntry { uint32_t node, run; };
 constexpr uint32_t VERIFY_LONG = 2048, VMD_CAP = 32768, FAR_CAP = 1u << 16;      // reads longer than this are checked by k6_verify_long; the longest tag it stages; far chunks a pass lists
 
+// inclusive scans over the wave's lanes (a sum, a running maximum)
+__device__ __forceinline__ uint32_t wave_incl_u32(uint32_t v, int lane) { for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)v, d, 64); if (lane >= d) v += o; } return v; }
+__device__ __forceinline__ int32_t wave_incl_max_i32(int32_t v, int lane) { for (int d = 1; d < 64; d <<= 1) { const int32_t o = __shfl_up(v, d, 64); if (lane >= d) v = max(v, o); } return v; }
+
 // length of the NUL-terminated string at t[0 .. lim) (lim if there is no NUL), by the wave: 512 bytes a step
 __device__ uint64_t wave_strnlen(const uint8_t* t, uint64_t lim, int lane) {
     for (uint64_t b0 = 0; b0 < lim; b0 += 512) {
@@ -1388,55 +1392,64 @@ __global__ __launch_bounds__(64) void k6_verify_long(const uint8_t* s, uint64_t 
 #else
             // (the tag where it lies: every char is looked at by its own lane and by a neighbour or two -- consecutive lanes, consecutive bytes, the
             // lines stay in the CU's cache -- and without 32 KB of LDS a wave the CU holds its full set of waves instead of five)
-            const uint8_t* smd = md;
+            const uint8_t* smd = md; (void)stream_len;
 #endif
             unsigned long long num = 0, mm = 0, del = 0;
-#if !BGP_VERIFY_LDS
-            // A lane's looks around its char -- the digits of a number, the bases of a deletion, the way back to a '^' -- are loads that wait for
-            // each other: from memory, ~30 round trips a step of the wave, 1.3 ms for a 10 000-char tag.  The 32 chars around the lane's own are
-            // fetched with two independent 16-byte loads into a row of LDS of the lane's own and looked at there; what reaches further (a run of
-            // sixteen letters, a number at the window's edge) is read where it lies, as before.
-            __shared__ __attribute__((aligned(16))) uint8_t wrow[64][32];
-            const uint64_t md_off = (uint64_t)(md - s);
-#endif
 #ifndef BGP_VERIFY_ABL
 #define BGP_VERIFY_ABL 0      // timing switches (wrong verdicts): 1 without the scan of the tag
 #endif
-            for (uint32_t i = (uint32_t)lane; i < (BGP_VERIFY_ABL == 1 ? 0u : n); i += 64) {
 #if !BGP_VERIFY_LDS
-                {   // chars [i - 16, i + 16): md lies at least 36 bytes into its record, so the bytes in front of the tag exist (and are never asked for)
-                    uint4 lo, hi = make_uint4(0u, 0u, 0u, 0u);
-                    __builtin_memcpy(&lo, md + i - 16, 16);
-                    if (md_off + i + 16 <= stream_len) __builtin_memcpy(&hi, md + i, 16);
-                    else { uint8_t b[16]; for (uint32_t k = 0; k < 16u; ++k) b[k] = md_off + i + k < stream_len ? md[i + k] : (uint8_t)0; __builtin_memcpy(&hi, b, 16); }
-                    *reinterpret_cast<uint4*>(&wrow[lane][0]) = lo; *reinterpret_cast<uint4*>(&wrow[lane][16]) = hi;
+            // The tag's units as k6_ck_build finds them, 64 chars a step: whether an upper-case letter is a deleted base is asked of the last
+            // char that is NOT one at or in front of it (a running maximum over the wave), not of a walk back to the '^'; a deletion's length
+            // is the count of its letters.  (A lane looking left and right of its own char by loops of its own -- the digits of a number, the
+            // bases of a deletion, the way back -- was 1.05 of this kernel's 1.17 ms: the wave runs every lane's loop.)
+            {
+                int32_t lnu = -1;                                              // the last char that is not an upper-case letter, in front of this step
+                for (uint32_t b0 = 0; b0 < (BGP_VERIFY_ABL == 1 ? 0u : n); b0 += 64) {
+                    const uint32_t c_i = b0 + (uint32_t)lane;
+                    const bool in = c_i < n;
+                    const uint8_t c = in ? smd[c_i] : (uint8_t)0;
+                    const bool up = is_upper_(c);
+                    const int32_t nu = wave_incl_max_i32(max(lnu, in && !up ? (int32_t)c_i : -1), lane);
+                    if (in) {
+                        if (c == '^') { if (c_i + 1 >= n || !is_upper_(smd[c_i + 1])) flag = true; }      // an empty deletion: the range stalls
+                        else if (is_digit_(c)) {
+                            if (c_i == 0 || !is_digit_(smd[c_i - 1])) {
+                                unsigned long long val = 0; uint32_t k = 0;
+                                while (c_i + k < n && is_digit_(smd[c_i + k])) { val = val * 10 + (unsigned long long)(smd[c_i + k] - '0'); if (++k > 9) { flag = true; break; } }
+                                num += val;
+                            }
+                        } else if (up && nu >= 0 && smd[nu] == '^') ++del;
+                        else ++mm;
+                    }
+                    lnu = __shfl(nu, 63, 64);
                 }
-                auto ch = [&](uint32_t x) -> uint8_t { const uint32_t rel = x + 16u - i; return rel < 32u ? wrow[lane][rel] : md[x]; };
+            }
 #else
-                auto ch = [&](uint32_t x) -> uint8_t { return smd[x]; };
-#endif
-                const uint8_t c = ch(i);
+            for (uint32_t i = (uint32_t)lane; i < (BGP_VERIFY_ABL == 1 ? 0u : n); i += 64) {
+                const uint8_t c = smd[i];
                 if (c == '^') {
                     uint32_t len = 0;
-                    while (i + 1 + len < n && is_upper_(ch(i + 1 + len))) ++len;
+                    while (i + 1 + len < n && is_upper_(smd[i + 1 + len])) ++len;
                     if (len == 0) flag = true;                                 // an empty deletion: the range stalls
                     del += len;
                 } else if (is_digit_(c)) {
-                    if (i == 0 || !is_digit_(ch(i - 1))) {
+                    if (i == 0 || !is_digit_(smd[i - 1])) {
                         unsigned long long val = 0; uint32_t k = 0;
-                        while (i + k < n && is_digit_(ch(i + k))) { val = val * 10 + (unsigned long long)(ch(i + k) - '0'); if (++k > 9) { flag = true; break; } }
+                        while (i + k < n && is_digit_(smd[i + k])) { val = val * 10 + (unsigned long long)(smd[i + k] - '0'); if (++k > 9) { flag = true; break; } }
                         num += val;
                     }
                 } else {
                     bool in_del = false;
                     if (is_upper_(c)) {
                         uint32_t j = i, steps = 0;
-                        while (j > 0 && is_upper_(ch(j - 1))) { --j; if (++steps > 4096u) { flag = true; break; } }
-                        in_del = j > 0 && ch(j - 1) == '^';
+                        while (j > 0 && is_upper_(smd[j - 1])) { --j; if (++steps > 4096u) { flag = true; break; } }
+                        in_del = j > 0 && smd[j - 1] == '^';
                     }
                     if (!in_del) ++mm;
                 }
             }
+#endif
             if (lane == 0 && n) {      // the last operation as the backward parse cuts it (parse.d:111-131): a number, a single mismatch, or '^' with upper-case bases to the end
                 const uint8_t last = smd[n - 1];
                 if (!is_digit_(last) && !(n == 1 || is_digit_(smd[n - 2]))) {
@@ -1542,8 +1555,6 @@ __device__ void ck_build_serial(const uint8_t* s, const bgp_record* rec, const L
     }
 }
 
-__device__ __forceinline__ uint32_t wave_incl_u32(uint32_t v, int lane) { for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)v, d, 64); if (lane >= d) v += o; } return v; }
-__device__ __forceinline__ int32_t wave_incl_max_i32(int32_t v, int lane) { for (int d = 1; d < 64; d <<= 1) { const int32_t o = __shfl_up(v, d, 64); if (lane >= d) v = max(v, o); } return v; }
 
 // A WAVE per long chunk.  The state of dna(read)'s lazy range at char index t (md/reconstruct.d:98-182) is a function of two numbers: the
 // MD token that yields char t, and the M / = / X bases the tokens in front of it have taken from the query.  So instead of walking there:
