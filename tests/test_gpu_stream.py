@@ -485,3 +485,29 @@ def test_stream_file_of_tiny_and_empty_blocks_longer_than_the_ring(ctx, tmp_path
     ref, pos, cols, _, _ = _covered(ctx.stream_bam_windows(path, 256 << 10))
     _assert_columns_equal_oracle(ref, pos, cols, ora)
     ctx.reset()
+
+
+def test_a_closed_ctx_has_given_back_its_device_memory(data_dir, tmp_path):
+    """bgp_destroy releases every device buffer a ctx ever made (the count bgp_device_memory keeps must come back to where it stood): after
+    short reads, long reads with use_md_tag (k6_prep_long's list, the checkpoints, the long providers' lists), entries, compact windows, a
+    device-inflated file, a streamed file and a region load through the device."""
+    from biod_amd.pileup import BaiFile
+    before = device_memory()[0]
+    c = Context(0)
+    c.synth_device(scaled("cfg5", 300)); c.flush(); c.pileup_run()
+    for w in c.pileup_windows(L.BGP_PILEUP_COLUMNS, use_md_tag=True, want_entries=True, window_positions=1 << 16):
+        pass
+    c.reset()
+    path = os.path.join(data_dir, "ex1_header.bam")
+    c.load_bam_device(path); c.flush(); c.pileup_run()
+    L.check(L.lib().bgp_set_compact_columns(c._h, 1), c._h)
+    for w in c.pileup_windows(L.BGP_PILEUP_COLUMNS, window_positions=500):
+        pass
+    c.reset()
+    for w in c.stream_bam_windows(path, 128 << 10):
+        pass
+    c.reset()
+    c.load_bam_region_device(path, BaiFile(path), 0, 100, 900); c.flush(); c.pileup_run()
+    assert device_memory()[0] > before
+    c.close()
+    assert device_memory()[0] == before
