@@ -35,6 +35,14 @@ def test_library_exports_every_declared_symbol():
     assert lib.bgp_abi_version() == 4          # 2: bgp_columns grew `maq`; 3: bgp_decode_fetch_range, bgp_pileup_begin_ref; 4: bgp_columns grew `columns8` (compact transport), bgp_stream_bam_begin
 
 
+def test_integration_notes_name_every_entry_point():
+    """INTEGRATION.md is where a maintainer looks up what replaces what: every function the header declares has its line there."""
+    hdr = open(os.path.join(ROOT, "include", "biodgpu.h")).read()
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    missing = [n for n in sorted(set(re.findall(r"\b(bgp_[a-z0-9_]+)\s*\(", hdr))) if n not in doc]
+    assert not missing, missing
+
+
 def test_header_cites_reference_for_every_entry_point():
     hdr = open(os.path.join(ROOT, "include", "biodgpu.h")).read()
     assert len(re.findall(r"[a-z_/]+\.d:\d+", hdr)) >= 40
